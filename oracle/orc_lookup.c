@@ -1,0 +1,158 @@
+/* orc_lookup.c -- ORACLE (test infrastructure): query lookup tables restated
+ * from CORE/blast_nalookup.c, CORE/blast_lookup.c, CORE/lookup_util.c. */
+#include "orc_int.h"
+#include <stdlib.h>
+#include <string.h>
+
+/* CORE/blast_nalookup.c:51-189 (BlastChooseNaLookupTable); the word_size==11
+ * case is switchable between G-BLASTN's patch (:127-144) and the stock NCBI
+ * thresholds kept there as comments (:131-137). */
+static int choose_table(const OrcOptions *opt, int32_t entries, int32_t max_q_off,
+                        int32_t *lut_width)
+{
+    int type;
+    switch (opt->word_size) {
+    case 4: case 5: case 6:
+        type = ORC_LUT_SMALL_NA; *lut_width = opt->word_size; break;
+    case 7:
+        type = ORC_LUT_SMALL_NA; *lut_width = (entries < 250) ? 6 : 7; break;
+    case 8:
+        type = ORC_LUT_SMALL_NA; *lut_width = (entries < 8500) ? 7 : 8; break;
+    case 9:
+        if (entries < 1250) { *lut_width = 7; type = ORC_LUT_SMALL_NA; }
+        else if (entries < 21000) { *lut_width = 8; type = ORC_LUT_SMALL_NA; }
+        else { *lut_width = 9; type = ORC_LUT_MB; }
+        break;
+    case 10:
+        if (entries < 1250) { *lut_width = 7; type = ORC_LUT_SMALL_NA; }
+        else if (entries < 8500) { *lut_width = 8; type = ORC_LUT_SMALL_NA; }
+        else if (entries < 18000) { *lut_width = 9; type = ORC_LUT_MB; }
+        else { *lut_width = 10; type = ORC_LUT_MB; }
+        break;
+    case 11:
+        if (entries < 12000) { *lut_width = 8; type = ORC_LUT_SMALL_NA; }
+        else if (opt->lut11_gblastn_rule) { *lut_width = 11; type = ORC_LUT_MB; }
+        else if (entries < 180000) { *lut_width = 10; type = ORC_LUT_MB; }
+        else { *lut_width = 11; type = ORC_LUT_MB; }
+        break;
+    case 12:
+        if (entries < 8500) { *lut_width = 8; type = ORC_LUT_SMALL_NA; }
+        else if (entries < 18000) { *lut_width = 9; type = ORC_LUT_MB; }
+        else if (entries < 60000) { *lut_width = 10; type = ORC_LUT_MB; }
+        else if (entries < 900000) { *lut_width = 11; type = ORC_LUT_MB; }
+        else { *lut_width = 12; type = ORC_LUT_MB; }
+        break;
+    default:
+        if (entries < 8500) { *lut_width = 8; type = ORC_LUT_SMALL_NA; }
+        else if (entries < 300000) { *lut_width = 11; type = ORC_LUT_MB; }
+        else { *lut_width = 12; type = ORC_LUT_MB; }
+        break;
+    }
+    if (type == ORC_LUT_SMALL_NA && (entries >= 32767 || max_q_off >= 32768))
+        type = ORC_LUT_NA;
+    return type;
+}
+
+/* enumerate indexable lut-words of one segment [from,to] (inclusive):
+ * CORE/blast_lookup.c:87-137 and CORE/blast_nalookup.c:873-928 visit the
+ * same set -- every lut-word inside the segment that has no ambiguity code,
+ * provided the segment can hold a full word_size word. */
+typedef void (*word_cb)(void *arg, int32_t cell, int32_t q_off);
+
+static void for_each_word(const uint8_t *q, int32_t from, int32_t to, int32_t word,
+                          int32_t lut, word_cb cb, void *arg)
+{
+    int32_t p, run = 0; uint32_t code = 0;
+    const uint32_t mask = (lut == 16) ? 0xffffffffu : ((1u << (2 * lut)) - 1);
+    if (word > to - from + 1) return;
+    for (p = from; p <= to; p++) {
+        uint8_t b = q[p];
+        if (b & 0xfc) { run = 0; code = 0; continue; }
+        code = ((code << 2) | b) & mask;
+        if (++run >= lut) cb(arg, (int32_t)code, p - lut + 1);
+    }
+}
+
+typedef struct { OrcLookup *l; int32_t *count; int32_t *fill; int pass; } BuildCtx;
+
+static void mb_add(void *arg, int32_t cell, int32_t q_off)
+{
+    OrcLookup *l = ((BuildCtx *)arg)->l;
+    int32_t index = q_off + 1;          /* 1-based, :893-898 */
+    l->next_pos[index] = l->hashtable[cell];
+    l->hashtable[cell] = index;
+}
+static void na_add(void *arg, int32_t cell, int32_t q_off)
+{
+    BuildCtx *b = (BuildCtx *)arg;
+    if (b->pass == 0) b->count[cell]++;
+    else b->l->cell_offs[b->fill[cell]++] = q_off;
+}
+
+OrcLookup *orc_lookup_new(const OrcOptions *opt, const uint8_t *query,
+                          int32_t nctx, const OrcContext *ctx)
+{
+    OrcLookup *l = (OrcLookup *)calloc(1, sizeof(*l));
+    int32_t entries = 0, max_off = 0, c, lut_width = 0, qlen = 0;
+    BuildCtx b;
+    /* CORE/lookup_util.c:193-209 over one segment per valid context
+     * (CORE/blast_filter.c:1019-1119 with no masks) */
+    for (c = 0; c < nctx; c++) {
+        if (!ctx[c].is_valid) continue;
+        entries += ctx[c].query_length - 1;
+        max_off = ORC_MAX(max_off, ctx[c].query_offset + ctx[c].query_length - 1);
+        qlen = ctx[c].query_offset + ctx[c].query_length;
+    }
+    l->type = choose_table(opt, entries, max_off, &lut_width);
+    l->word_length = opt->word_size;
+    l->lut_word_length = lut_width;
+    l->scan_step = l->word_length - l->lut_word_length + 1;  /* :403, :572, :1018 */
+    l->ncells = 1 << (2 * lut_width);
+    b.l = l; b.count = NULL; b.fill = NULL; b.pass = 0;
+    if (l->type == ORC_LUT_MB) {
+        l->hashtable = (int32_t *)calloc((size_t)l->ncells, sizeof(int32_t));
+        l->next_pos = (int32_t *)calloc((size_t)qlen + 2, sizeof(int32_t));
+        for (c = 0; c < nctx; c++) {
+            if (!ctx[c].is_valid) continue;
+            for_each_word(query, ctx[c].query_offset,
+                          ctx[c].query_offset + ctx[c].query_length - 1,
+                          l->word_length, lut_width, mb_add, &b);
+        }
+    } else {
+        int32_t i, acc = 0, longest = 0, overflow_cells = 2;
+        b.count = (int32_t *)calloc((size_t)l->ncells, sizeof(int32_t));
+        for (b.pass = 0; b.pass < 2; b.pass++) {
+            if (b.pass == 1) {
+                l->cell_start = (int32_t *)malloc(((size_t)l->ncells + 1) * sizeof(int32_t));
+                b.fill = (int32_t *)malloc((size_t)l->ncells * sizeof(int32_t));
+                for (i = 0; i < l->ncells; i++) {
+                    l->cell_start[i] = acc; b.fill[i] = acc; acc += b.count[i];
+                    longest = ORC_MAX(longest, b.count[i]);
+                    if (b.count[i] > 1) overflow_cells += b.count[i] + 1;
+                }
+                l->cell_start[l->ncells] = acc;
+                l->cell_offs = (int32_t *)malloc(((size_t)acc + 1) * sizeof(int32_t));
+            }
+            for (c = 0; c < nctx; c++) {
+                if (!ctx[c].is_valid) continue;
+                for_each_word(query, ctx[c].query_offset,
+                              ctx[c].query_offset + ctx[c].query_length - 1,
+                              l->word_length, lut_width, na_add, &b);
+            }
+        }
+        l->longest_chain = longest;
+        /* CORE/blast_nalookup.c:234-238 + CORE/lookup_wrap.c:127-137: a small
+         * table whose overflow array would not fit 15 bits becomes a standard
+         * table */
+        if (l->type == ORC_LUT_SMALL_NA && overflow_cells >= 32768) l->type = ORC_LUT_NA;
+        free(b.count); free(b.fill);
+    }
+    return l;
+}
+
+void orc_lookup_free(OrcLookup *l)
+{
+    if (!l) return;
+    free(l->hashtable); free(l->next_pos); free(l->cell_start); free(l->cell_offs);
+    free(l);
+}

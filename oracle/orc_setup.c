@@ -1,0 +1,278 @@
+/* orc_setup.c -- ORACLE (test infrastructure): per-batch set-up restated from
+ * CORE/blast_setup.c, CORE/blast_parameters.c and the query layout shown in
+ * UT/ntscan_unit_test.cpp:119-185. */
+#include "orc_int.h"
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+
+void orc_default_options(OrcOptions *o, int megablast)
+{
+    /* API/blast_nucl_options.cpp:108-234 */
+    memset(o, 0, sizeof(*o));
+    if (megablast) {
+        o->word_size = 28; o->reward = 1; o->penalty = -2;
+        o->gap_open = 0; o->gap_extend = 0; o->greedy = 1;
+        o->xdrop_gap_bits = 25; o->min_diag_separation = 6;
+    } else {
+        o->word_size = 11; o->reward = 2; o->penalty = -3;
+        o->gap_open = 5; o->gap_extend = 2; o->greedy = 0;
+        o->xdrop_gap_bits = 30; o->min_diag_separation = 50;
+    }
+    o->xdrop_ungap_bits = 20; o->gap_trigger_bits = 27.0;
+    o->xdrop_gap_final_bits = 100; o->evalue = 10.0;
+    o->hitlist_size = 500; o->cutoff_score = 0;
+    o->lut11_gblastn_rule = 1;
+}
+
+/* complement in BLASTNA (via NCBI4NA bit reversal, CORE/blast_encoding.c:42-78) */
+static const uint8_t kComp[16] = { 3, 2, 1, 0, 5, 4, 7, 6, 8, 9, 13, 12, 11, 10, 14, 15 };
+
+/* CORE/blast_query_info.c:220-236 (BSearchContextInfo) */
+int orc_context_of(const OrcSearch *s, int32_t n)
+{
+    int32_t m, b = 0, e = s->nctx;
+    while (b < e - 1) {
+        m = (b + e) / 2;
+        if (s->ctx[m].query_offset > n) e = m; else b = m;
+    }
+    return b;
+}
+
+/* CORE/blast_setup.c:638-775 (BLAST_CalcEffLengths), nucleotide branch */
+void orc_setup_effective_lengths(OrcSearch *s, int64_t db_length, int32_t db_num_seqs)
+{
+    int i;
+    const OrcOptions *o = &s->opt;
+    if (db_length == 0) return;
+    for (i = 0; i < s->nctx; i++) {
+        OrcContext *c = &s->ctx[i];
+        int32_t length_adjustment = 0;
+        int64_t eff = 0;
+        if (c->is_valid && c->query_length > 0) {
+            double alpha = 0, beta = 0;
+            OrcKarlin ku; ku.Lambda = c->lambda_u; ku.K = c->K_u; ku.logK = c->logK_u; ku.H = c->H_u;
+            orc_nucl_alpha_beta(o->reward, o->penalty, o->gap_open, o->gap_extend,
+                                &ku, 1, &alpha, &beta);
+            orc_length_adjustment(s->kbp_gap.K, s->kbp_gap.logK, alpha / s->kbp_gap.Lambda,
+                                  beta, c->query_length, db_length, db_num_seqs,
+                                  &length_adjustment);
+            {
+                int64_t eff_db = db_length - ((int64_t)db_num_seqs * length_adjustment);
+                if (eff_db <= 0) eff_db = 1;
+                eff = eff_db * (c->query_length - length_adjustment);
+            }
+        }
+        c->eff_searchsp = eff;
+        c->length_adjustment = length_adjustment;
+    }
+}
+
+/* CORE/blast_parameters.c:822-979 (BlastHitSavingParametersUpdate, the branch a
+ * gapped blastn search takes) followed by :280-419
+ * (BlastInitialWordParametersUpdate, gapped_calculation branch) */
+static void update_cutoffs(OrcSearch *s)
+{
+    int i;
+    const OrcOptions *o = &s->opt;
+    for (i = 0; i < s->nctx; i++) {
+        OrcContext *c = &s->ctx[i];
+        int32_t new_cutoff = 1, gap_trigger = ORC_INT4_MAX;
+        double evalue = o->evalue;
+        if (!c->is_valid) {
+            c->gap_cutoff_score = ORC_INT4_MAX;
+            c->cutoff_score = ORC_INT4_MAX;
+            continue;
+        }
+        if (o->cutoff_score > 0) {
+            c->gap_cutoff_score = o->cutoff_score;
+            c->gap_cutoff_score_max = o->cutoff_score;
+        } else {
+            orc_cutoffs(&new_cutoff, &evalue, &s->kbp_gap, c->eff_searchsp);
+            c->gap_cutoff_score = new_cutoff;
+            c->gap_cutoff_score_max = new_cutoff;
+        }
+        /* ungapped (initial word) cutoffs */
+        if (c->lambda_u > 0 && c->K_u > 0 && c->H_u > 0)
+            gap_trigger = (int32_t)((o->gap_trigger_bits * ORC_LN2 + c->logK_u) / c->lambda_u);
+        new_cutoff = gap_trigger;
+        new_cutoff *= 1;    /* scale_factor */
+        new_cutoff = ORC_MIN(new_cutoff, c->gap_cutoff_score_max);
+        c->cutoff_score = new_cutoff;
+        c->reduced_cutoff = (int32_t)(0.9 * new_cutoff);
+    }
+}
+
+void orc_update_for_subject(OrcSearch *s, int32_t subject_length)
+{
+    /* CORE/blast_setup.c:905-932 (BLAST_OneSubjectUpdateParameters) */
+    orc_setup_effective_lengths(s, subject_length, 1);
+    update_cutoffs(s);
+}
+
+OrcSearch *orc_search_new(const OrcOptions *opt, int nq,
+                          const uint8_t *const *seqs, const int32_t *lens)
+{
+    OrcSearch *s = (OrcSearch *)calloc(1, sizeof(*s));
+    int i, c; int64_t total = 1; int32_t off;
+    double stdp[16];
+    OrcKarlin kfirst; int have_first = 0;
+    s->opt = *opt; s->nq = nq; s->nctx = 2 * nq;
+    s->ctx = (OrcContext *)calloc((size_t)s->nctx, sizeof(OrcContext));
+    for (i = 0; i < nq; i++) total += 2 * ((int64_t)lens[i] + 1);
+    s->qbuf = (uint8_t *)malloc((size_t)total + 8);
+    memset(s->qbuf, ORC_SENTINEL, (size_t)total + 8);
+    s->query = s->qbuf + 1;
+    off = 0;
+    for (i = 0; i < nq; i++) {
+        int32_t L = lens[i], j;
+        OrcContext *p = &s->ctx[2 * i], *m = &s->ctx[2 * i + 1];
+        p->query_offset = off; p->query_length = L; p->frame = 1; p->query_index = i;
+        memcpy(s->query + off, seqs[i], (size_t)L);
+        off += L + 1;
+        m->query_offset = off; m->query_length = L; m->frame = -1; m->query_index = i;
+        for (j = 0; j < L; j++) s->query[off + j] = kComp[seqs[i][L - 1 - j] & 15];
+        off += L + 1;
+    }
+    s->qlen = off - 1;      /* last context offset + length */
+
+    orc_nucl_matrix(opt->reward, opt->penalty, s->matrix);
+    /* CORE/blast_parameters.c:237-262 */
+    for (i = 0; i < 256; i++) {
+        int32_t sc = 0;
+        if (i & 3) sc += opt->penalty; else sc += opt->reward;
+        if ((i >> 2) & 3) sc += opt->penalty; else sc += opt->reward;
+        if ((i >> 4) & 3) sc += opt->penalty; else sc += opt->reward;
+        if (i >> 6) sc += opt->penalty; else sc += opt->reward;
+        s->score_table[i] = sc;
+    }
+
+    /* ungapped KA block per context, CORE/blast_stat.c:2711-2807 */
+    orc_std_nt_freq(stdp);
+    for (c = 0; c < s->nctx; c++) {
+        OrcContext *x = &s->ctx[c];
+        double p[16]; OrcKarlin k;
+        x->is_valid = 1;
+        if (x->query_length <= 0) { x->is_valid = 0; continue; }
+        orc_context_freq(s->query + x->query_offset, x->query_length, p);
+        if (orc_karlin_ungapped(opt->reward, opt->penalty, p, stdp, &k)) {
+            x->is_valid = 0; x->lambda_u = x->K_u = x->H_u = -1; continue;
+        }
+        x->lambda_u = k.Lambda; x->K_u = k.K; x->logK_u = k.logK; x->H_u = k.H;
+        if (!have_first) { kfirst = k; have_first = 1; }
+    }
+    /* gapped block: table lookup, or a copy of the context's ungapped block in
+     * the "infinite gap cost" regime (CORE/blast_setup.c:76-128).  The copy
+     * case is per context in the reference; the tables cover every default
+     * configuration, so one block is kept here and the copy case uses the
+     * first valid context. */
+    if (have_first) {
+        if (orc_karlin_nucl_gapped(opt->gap_open, opt->gap_extend, opt->reward, opt->penalty,
+                                   &kfirst, &s->kbp_gap, &s->round_down)) {
+            orc_search_free(s);
+            return NULL;
+        }
+    }
+    /* CORE/blast_parameters.c:422-470 (BlastExtensionParametersNew) */
+    s->gap_x_dropoff = (int32_t)(opt->xdrop_gap_bits * ORC_LN2 / s->kbp_gap.Lambda);
+    {
+        double f = opt->xdrop_gap_final_bits * ORC_LN2 / s->kbp_gap.Lambda;
+        s->gap_x_dropoff_final = (int32_t)ORC_MAX(f, (double)s->gap_x_dropoff);
+    }
+    /* x_dropoff per context, CORE/blast_parameters.c:203-225 */
+    for (c = 0; c < s->nctx; c++) {
+        OrcContext *x = &s->ctx[c];
+        if (!x->is_valid) continue;
+        x->x_dropoff = (int32_t)(1.0 * ceil(opt->xdrop_ungap_bits * ORC_LN2 / x->lambda_u));
+    }
+    if (opt->db_num_seqs > 0) {
+        orc_setup_effective_lengths(s, opt->db_length, opt->db_num_seqs);
+        update_cutoffs(s);
+    }
+    /* container choice, CORE/blast_parameters.c:174,227-232 */
+    s->container = (s->qlen > 8000) ? ORC_DIAG_HASH : ORC_DIAG_ARRAY;
+    if (s->container == ORC_DIAG_ARRAY) {
+        /* CORE/blast_extend.c:47-73 with window_size 0 */
+        int32_t n = 1;
+        while (n < s->qlen) n <<= 1;
+        s->diag_len = n; s->diag_mask = n - 1;
+        s->diag_last_hit = (int32_t *)calloc((size_t)n, sizeof(int32_t));
+    }
+    s->lut = orc_lookup_new(opt, s->query, s->nctx, s->ctx);
+    return s;
+}
+
+void orc_search_free(OrcSearch *s)
+{
+    if (!s) return;
+    orc_lookup_free(s->lut);
+    free(s->ctx); free(s->qbuf); free(s->seeds); free(s->ihits); free(s->hsps);
+    free(s->diag_last_hit); free(s->diag_hash);
+    free(s);
+}
+
+int32_t orc_num_contexts(const OrcSearch *s) { return s->nctx; }
+const OrcContext *orc_contexts(const OrcSearch *s) { return s->ctx; }
+int32_t orc_lut_type(const OrcSearch *s) { return s->lut ? s->lut->type : 0; }
+int32_t orc_lut_width(const OrcSearch *s) { return s->lut ? s->lut->lut_word_length : 0; }
+int32_t orc_scan_step(const OrcSearch *s) { return s->lut ? s->lut->scan_step : 0; }
+int32_t orc_diag_container(const OrcSearch *s) { return s->container; }
+int32_t orc_gap_x_dropoff(const OrcSearch *s) { return s->gap_x_dropoff; }
+int32_t orc_gap_x_dropoff_final(const OrcSearch *s) { return s->gap_x_dropoff_final; }
+double  orc_gap_lambda(const OrcSearch *s) { return s->kbp_gap.Lambda; }
+double  orc_gap_K(const OrcSearch *s) { return s->kbp_gap.K; }
+int32_t orc_query_concat_len(const OrcSearch *s) { return s->qlen; }
+const uint8_t *orc_query_concat(const OrcSearch *s) { return s->query; }
+
+int32_t orc_num_seeds(const OrcSearch *s) { return s->nseeds; }
+const OrcSeed *orc_seeds(const OrcSearch *s) { return s->seeds; }
+int32_t orc_num_init_hits(const OrcSearch *s) { return s->nihits; }
+const OrcInitHit *orc_init_hits(const OrcSearch *s) { return s->ihits; }
+int32_t orc_num_hsps(const OrcSearch *s) { return s->nhsps; }
+const OrcHSP *orc_hsps(const OrcSearch *s) { return s->hsps; }
+
+void orc_push_seed(OrcSearch *s, int32_t q, int32_t sb)
+{
+    if (s->nseeds == s->cseeds) {
+        s->cseeds = s->cseeds ? 2 * s->cseeds : 1024;
+        s->seeds = (OrcSeed *)realloc(s->seeds, (size_t)s->cseeds * sizeof(OrcSeed));
+    }
+    s->seeds[s->nseeds].q_off = q; s->seeds[s->nseeds].s_off = sb; s->nseeds++;
+}
+void orc_push_ihit(OrcSearch *s, const OrcInitHit *h)
+{
+    if (s->nihits == s->cihits) {
+        s->cihits = s->cihits ? 2 * s->cihits : 256;
+        s->ihits = (OrcInitHit *)realloc(s->ihits, (size_t)s->cihits * sizeof(OrcInitHit));
+    }
+    s->ihits[s->nihits++] = *h;
+}
+void orc_push_hsp(OrcSearch *s, const OrcHSP *h)
+{
+    if (s->nhsps == s->chsps) {
+        s->chsps = s->chsps ? 2 * s->chsps : 64;
+        s->hsps = (OrcHSP *)realloc(s->hsps, (size_t)s->chsps * sizeof(OrcHSP));
+    }
+    s->hsps[s->nhsps++] = *h;
+}
+
+void orc_update_for_subject(OrcSearch *s, int32_t subject_length);
+
+int orc_search_subject(OrcSearch *s, const uint8_t *packed, int32_t len, OrcStats *stats)
+{
+    OrcStats local; memset(&local, 0, sizeof(local));
+    s->nseeds = s->nihits = s->nhsps = 0;
+    if (s->opt.db_num_seqs == 0)    /* "db_length == 0" branch of the engine */
+        orc_update_for_subject(s, len);
+    orc_word_finder(s, packed, len, &local);
+    if (s->nihits > 0) orc_gapped_stage(s, packed, len, &local);
+    if (stats) {
+        stats->lookup_hits += local.lookup_hits;
+        stats->init_extends += local.init_extends;
+        stats->good_init_extends += local.good_init_extends;
+        stats->gapped_extensions += local.gapped_extensions;
+        stats->good_extensions += local.good_extensions;
+        stats->seqs_passed += local.seqs_passed;
+    }
+    return 0;
+}
