@@ -1,0 +1,253 @@
+"""Host-side mirror of the reference's preliminary-search interface, over the C ABI.
+
+Names follow the reference's operator surface for this path:
+  BlastSeqSrc       ~ the BlastSeqSrc / CSearchDatabase handle the engine iterates
+                      (API/seqsrc_seqdb.cpp): here one HBM-resident shard
+  BlastPrelimSearch ~ CBlastPrelimSearch(query_factory, options, dbinfo).Run()
+                      (API/prelim_stage.cpp:192-308), which calls
+                      Blast_gpu_RunPreliminarySearchWithInterrupt
+                      (GB/gpu_blastn_pre_search_engine.cpp:1466-1563)
+The HIP extension is mandatory: import fails loudly if libgblastn_amd.so is absent.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libgblastn_amd.so")
+
+
+class GbnOptions(C.Structure):
+    _fields_ = [("word_size", C.c_int32), ("reward", C.c_int32), ("penalty", C.c_int32),
+                ("gap_open", C.c_int32), ("gap_extend", C.c_int32), ("greedy", C.c_int32),
+                ("xdrop_ungap_bits", C.c_double), ("gap_trigger_bits", C.c_double),
+                ("xdrop_gap_bits", C.c_double), ("xdrop_gap_final_bits", C.c_double),
+                ("evalue", C.c_double), ("min_diag_separation", C.c_int32),
+                ("hitlist_size", C.c_int32), ("cutoff_score", C.c_int32),
+                ("lut11_gblastn_rule", C.c_int32), ("db_length", C.c_int64),
+                ("db_num_seqs", C.c_int32)]
+
+
+class GbnContext(C.Structure):
+    _fields_ = [("query_offset", C.c_int32), ("query_length", C.c_int32), ("frame", C.c_int32),
+                ("query_index", C.c_int32), ("is_valid", C.c_int32),
+                ("length_adjustment", C.c_int32), ("eff_searchsp", C.c_int64),
+                ("lambda_u", C.c_double), ("K_u", C.c_double), ("logK_u", C.c_double),
+                ("H_u", C.c_double), ("x_dropoff", C.c_int32), ("cutoff_score", C.c_int32),
+                ("reduced_cutoff", C.c_int32), ("gap_cutoff_score", C.c_int32),
+                ("gap_cutoff_score_max", C.c_int32)]
+
+
+class GbnDiagnostics(C.Structure):
+    _fields_ = [("lookup_hits", C.c_int64), ("init_extends", C.c_int64),
+                ("good_init_extends", C.c_int64), ("gapped_extensions", C.c_int64),
+                ("good_extensions", C.c_int64), ("seqs_passed", C.c_int64), ("seeds", C.c_int64),
+                ("scan_kernel_ms", C.c_double), ("total_ms", C.c_double),
+                ("scan_launches", C.c_int64), ("subject_bases_scanned", C.c_int64)]
+
+
+HSP_DT = np.dtype([("oid", "<i4"), ("context", "<i4"), ("q_offset", "<i4"), ("q_end", "<i4"),
+                   ("q_gapped_start", "<i4"), ("s_offset", "<i4"), ("s_end", "<i4"),
+                   ("s_gapped_start", "<i4"), ("score", "<i4"), ("pad_", "<i4"),
+                   ("evalue", "<f8")])
+SEED_DT = np.dtype([("oid", "<i4"), ("s_off", "<i4"), ("q_off", "<i4"), ("pad_", "<i4")])
+IHIT_DT = np.dtype([("oid", "<i4"), ("q_off", "<i4"), ("s_off", "<i4"), ("q_start", "<i4"),
+                    ("s_start", "<i4"), ("length", "<i4"), ("score", "<i4"), ("pad_", "<i4")])
+
+EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_default_options",
+           "gbn_db_new", "gbn_db_free", "gbn_db_total_bases", "gbn_db_num_seqs", "gbn_synth_fill",
+           "gbn_batch_new", "gbn_batch_new_ex", "gbn_batch_free", "gbn_batch_num_contexts", "gbn_batch_contexts",
+           "gbn_batch_lut_type", "gbn_batch_lut_width", "gbn_batch_scan_step",
+           "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff", "gbn_results_new",
+           "gbn_results_free", "gbn_results_clear", "gbn_results_num_hsps", "gbn_results_hsps",
+           "gbn_results_num_seeds", "gbn_results_seeds", "gbn_results_num_init_hits",
+           "gbn_results_init_hits", "gbn_prelim_search", "gbn_scan_only", "gbn_last_error",
+           "gbn_launch_scan_seed", "gbn_launch_ungapped", "gbn_launch_gapped"]
+
+_LIB = None
+
+
+def lib():
+    """Load the HIP extension; there is no fallback."""
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(_SO):
+            raise ImportError("gblastn_amd: %s is missing -- build it with "
+                              "`python -c 'import __graft_entry__ as g; g.build()'`" % _SO)
+        L = C.CDLL(_SO)
+        L.gbn_last_error.restype = C.c_char_p
+        L.gbn_default_options.argtypes = [C.POINTER(GbnOptions), C.c_int]
+        L.Blast_gpu_Init.argtypes = [C.c_int, C.c_int]
+        L.gbn_db_new.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int32,
+                                 C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
+        L.gbn_db_free.argtypes = [C.c_void_p]
+        L.gbn_db_total_bases.restype = C.c_int64; L.gbn_db_total_bases.argtypes = [C.c_void_p]
+        L.gbn_db_num_seqs.restype = C.c_int32; L.gbn_db_num_seqs.argtypes = [C.c_void_p]
+        L.gbn_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
+        L.gbn_batch_new.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GbnOptions), C.c_int32,
+                                    C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+        L.gbn_batch_free.argtypes = [C.c_void_p]
+        for nm in ["gbn_batch_num_contexts", "gbn_batch_lut_type", "gbn_batch_lut_width",
+                   "gbn_batch_scan_step", "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff"]:
+            getattr(L, nm).restype = C.c_int32; getattr(L, nm).argtypes = [C.c_void_p]
+        L.gbn_batch_contexts.restype = C.POINTER(GbnContext); L.gbn_batch_contexts.argtypes = [C.c_void_p]
+        L.gbn_results_new.argtypes = [C.POINTER(C.c_void_p)]
+        L.gbn_results_free.argtypes = [C.c_void_p]
+        L.gbn_results_clear.argtypes = [C.c_void_p]
+        for nm in ["gbn_results_num_hsps", "gbn_results_num_seeds", "gbn_results_num_init_hits"]:
+            getattr(L, nm).restype = C.c_int64; getattr(L, nm).argtypes = [C.c_void_p]
+        for nm in ["gbn_results_hsps", "gbn_results_seeds", "gbn_results_init_hits"]:
+            getattr(L, nm).restype = C.c_void_p; getattr(L, nm).argtypes = [C.c_void_p]
+        L.gbn_prelim_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
+                                        C.POINTER(GbnDiagnostics), C.c_int, C.c_void_p, C.c_void_p]
+        L.gbn_scan_only.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(GbnDiagnostics)]
+        _LIB = L
+    return _LIB
+
+
+class BlastError(RuntimeError):
+    pass
+
+
+def _check(rc):
+    if rc != 0:
+        raise BlastError("gblastn_amd status %d: %s" % (rc, lib().gbn_last_error().decode()))
+
+
+def default_options(task="megablast", db_length=0, db_num_seqs=0, **kw):
+    o = GbnOptions()
+    lib().gbn_default_options(C.byref(o), 1 if task == "megablast" else 0)
+    o.db_length = db_length; o.db_num_seqs = db_num_seqs
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def layout_slab(lengths, front=16, align=16, tail=64):
+    """Byte offsets of NCBI2na subjects in one slab (16-byte aligned, padded)."""
+    offs = np.zeros(len(lengths), dtype=np.int64)
+    pos = front
+    for i, n in enumerate(lengths):
+        offs[i] = pos
+        pos += (int(n) + 3) // 4
+        pos = (pos + align - 1) // align * align
+    return offs, pos + tail
+
+
+class BlastSeqSrc:
+    """One database shard resident in HBM."""
+
+    def __init__(self, handle, keep=None):
+        self._h = handle
+        self._keep = keep
+
+    @classmethod
+    def from_packed(cls, subjects, first_oid=0):
+        """subjects: list of (packed uint8 array, length in bases)."""
+        lens = np.array([n for _, n in subjects], dtype=np.int32)
+        offs, total = layout_slab(lens)
+        slab = np.zeros(total, dtype=np.uint8)
+        for (p, n), o in zip(subjects, offs):
+            nb = (n + 3) // 4
+            slab[o:o + nb] = np.asarray(p, dtype=np.uint8)[:nb]
+        return cls.from_slab(slab, offs, lens, first_oid, is_device=False)
+
+    @classmethod
+    def from_slab(cls, slab, byte_off, lens, first_oid=0, is_device=False, keep=None):
+        L = lib()
+        h = C.c_void_p()
+        byte_off = np.ascontiguousarray(byte_off, dtype=np.int64)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        if is_device:
+            ptr, nbytes = slab       # (device pointer, size)
+        else:
+            slab = np.ascontiguousarray(slab, dtype=np.uint8)
+            ptr, nbytes = slab.ctypes.data, slab.nbytes
+        _check(L.gbn_db_new(C.byref(h), ptr, nbytes, len(lens), byte_off.ctypes.data,
+                            lens.ctypes.data, first_oid, 1 if is_device else 0))
+        return cls(h, keep)
+
+    @property
+    def total_bases(self):
+        return lib().gbn_db_total_bases(self._h)
+
+    @property
+    def num_seqs(self):
+        return lib().gbn_db_num_seqs(self._h)
+
+    def close(self):
+        if self._h:
+            lib().gbn_db_free(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BlastPrelimSearch:
+    """CBlastPrelimSearch analogue: one query batch against one resident shard."""
+
+    def __init__(self, queries, options, seqsrc=None):
+        L = lib()
+        self._q = [np.ascontiguousarray(q, dtype=np.uint8) for q in queries]
+        ptrs = (C.c_void_p * len(self._q))(*[q.ctypes.data for q in self._q])
+        lens = (C.c_int32 * len(self._q))(*[len(q) for q in self._q])
+        self.options = options
+        self._b = C.c_void_p()
+        _check(L.gbn_batch_new(C.byref(self._b), C.byref(options), len(self._q), ptrs, lens))
+        self._r = C.c_void_p()
+        _check(L.gbn_results_new(C.byref(self._r)))
+        self.seqsrc = seqsrc
+        self.diagnostics = GbnDiagnostics()
+
+    def info(self):
+        L, b = lib(), self._b
+        return dict(lut_type=L.gbn_batch_lut_type(b), lut_width=L.gbn_batch_lut_width(b),
+                    scan_step=L.gbn_batch_scan_step(b), container=L.gbn_batch_diag_container(b),
+                    gap_x_dropoff=L.gbn_batch_gap_x_dropoff(b))
+
+    @property
+    def contexts(self):
+        n = lib().gbn_batch_num_contexts(self._b)
+        p = lib().gbn_batch_contexts(self._b)
+        return [p[i] for i in range(n)]
+
+    def _grab(self, nf, pf, dt):
+        n = nf(self._r)
+        if n == 0:
+            return np.zeros(0, dtype=dt)
+        return np.frombuffer(C.string_at(pf(self._r), n * dt.itemsize), dtype=dt).copy()
+
+    def run(self, seqsrc=None, keep_stages=False, clear=True):
+        """Returns dict(hsps[, seeds, init_hits]); HSPs grouped by ascending oid."""
+        L = lib()
+        src = seqsrc or self.seqsrc
+        if clear:
+            L.gbn_results_clear(self._r)
+        _check(L.gbn_prelim_search(self._b, src._h, self._r, C.byref(self.diagnostics),
+                                   1 if keep_stages else 0, None, None))
+        out = dict(hsps=self._grab(L.gbn_results_num_hsps, L.gbn_results_hsps, HSP_DT))
+        if keep_stages:
+            out["seeds"] = self._grab(L.gbn_results_num_seeds, L.gbn_results_seeds, SEED_DT)
+            out["init_hits"] = self._grab(L.gbn_results_num_init_hits, L.gbn_results_init_hits, IHIT_DT)
+        return out
+
+    def scan_only(self, seqsrc=None, repeats=1):
+        d = GbnDiagnostics()
+        _check(lib().gbn_scan_only(self._b, (seqsrc or self.seqsrc)._h, repeats, C.byref(d)))
+        return d
+
+    def close(self):
+        L = lib()
+        if self._b:
+            L.gbn_batch_free(self._b); self._b = None
+        if self._r:
+            L.gbn_results_free(self._r); self._r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,212 @@
+// batch.cpp -- per-query-batch host set-up: concatenated query with sentinels
+// and reverse strands, Karlin-Altschul blocks, integer cut-offs, and the query
+// word index in the cell order the reference's lookup tables yield.
+//
+// Mirrors what the reference hands INTO its GPU boundary (query, query_info,
+// sbp, lookup_wrap): CORE/blast_setup.c:502-775, CORE/blast_parameters.c:160-470,
+// :822-979, CORE/blast_nalookup.c:51-189,384-427,831-1041, CORE/blast_lookup.c:87-137.
+#include "gbn_host.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+static const double kLn2 = 0.69314718055994530941723212145818;
+
+void gbn_default_options(GbnOptions *o, int megablast) {
+    // API/blast_nucl_options.cpp:108-234
+    std::memset(o, 0, sizeof(*o));
+    o->word_size = megablast ? 28 : 11;
+    o->reward = megablast ? 1 : 2;  o->penalty = megablast ? -2 : -3;
+    o->gap_open = megablast ? 0 : 5; o->gap_extend = megablast ? 0 : 2;
+    o->greedy = megablast ? 1 : 0;
+    o->xdrop_ungap_bits = 20; o->gap_trigger_bits = 27.0;
+    o->xdrop_gap_bits = megablast ? 25 : 30; o->xdrop_gap_final_bits = 100;
+    o->evalue = 10.0; o->min_diag_separation = megablast ? 6 : 50;
+    o->hitlist_size = 500; o->cutoff_score = 0; o->lut11_gblastn_rule = 1;
+}
+
+int GbnBatch::context_of(int32_t n) const {
+    int32_t b = 0, e = (int32_t)ctx.size();
+    while (b < e - 1) {
+        int32_t m = (b + e) / 2;
+        if (ctx[m].query_offset > n) e = m; else b = m;
+    }
+    return b;
+}
+
+void GbnBatch::set_effective_lengths(int64_t db_len, int32_t db_nseq) {
+    if (db_len == 0) return;
+    for (auto &c : ctx) {
+        int32_t adj = 0; int64_t eff = 0;
+        if (c.is_valid && c.query_length > 0) {
+            gbn::Karlin ku; ku.lambda = c.lambda_u; ku.K = c.K_u; ku.logK = c.logK_u; ku.H = c.H_u;
+            double alpha = 0, beta = 0;
+            gbn::alpha_beta(opt.reward, opt.penalty, opt.gap_open, opt.gap_extend, ku, true, alpha, beta);
+            adj = gbn::length_adjustment(kbp_gap.K, kbp_gap.logK, alpha / kbp_gap.lambda, beta,
+                                         c.query_length, db_len, db_nseq);
+            int64_t eff_db = db_len - (int64_t)db_nseq * adj;
+            if (eff_db <= 0) eff_db = 1;
+            eff = eff_db * (c.query_length - adj);
+        }
+        c.eff_searchsp = eff; c.length_adjustment = adj;
+    }
+}
+
+void GbnBatch::update_cutoffs() {
+    for (auto &c : ctx) {
+        if (!c.is_valid) { c.gap_cutoff_score = INT32_MAX; c.cutoff_score = INT32_MAX; continue; }
+        if (opt.cutoff_score > 0) c.gap_cutoff_score = c.gap_cutoff_score_max = opt.cutoff_score;
+        else c.gap_cutoff_score = c.gap_cutoff_score_max =
+                 gbn::cutoff_from_evalue(opt.evalue, kbp_gap, c.eff_searchsp);
+        int32_t trigger = INT32_MAX;
+        if (c.lambda_u > 0 && c.K_u > 0 && c.H_u > 0)
+            trigger = (int32_t)((opt.gap_trigger_bits * kLn2 + c.logK_u) / c.lambda_u);
+        int32_t cut = std::min(trigger, c.gap_cutoff_score_max);
+        c.cutoff_score = cut;
+        c.reduced_cutoff = (int32_t)(0.9 * cut);
+    }
+}
+
+namespace gbn {
+
+static const uint8_t kComplement[16] = {3, 2, 1, 0, 5, 4, 7, 6, 8, 9, 13, 12, 11, 10, 14, 15};
+
+static int choose_lookup(const GbnOptions &o, int32_t entries, int32_t max_off, int &width) {
+    int type = GBN_LUT_SMALL_NA;
+    auto mb = [&](int w) { width = w; type = GBN_LUT_MB; };
+    auto sm = [&](int w) { width = w; type = GBN_LUT_SMALL_NA; };
+    switch (o.word_size) {
+    case 4: case 5: case 6: sm(o.word_size); break;
+    case 7: sm(entries < 250 ? 6 : 7); break;
+    case 8: sm(entries < 8500 ? 7 : 8); break;
+    case 9: if (entries < 1250) sm(7); else if (entries < 21000) sm(8); else mb(9); break;
+    case 10: if (entries < 1250) sm(7); else if (entries < 8500) sm(8);
+             else if (entries < 18000) mb(9); else mb(10); break;
+    case 11: if (entries < 12000) sm(8);
+             else if (o.lut11_gblastn_rule) mb(11);
+             else if (entries < 180000) mb(10); else mb(11);
+             break;
+    case 12: if (entries < 8500) sm(8); else if (entries < 18000) mb(9);
+             else if (entries < 60000) mb(10); else if (entries < 900000) mb(11); else mb(12);
+             break;
+    default: if (entries < 8500) sm(8); else if (entries < 300000) mb(11); else mb(12); break;
+    }
+    if (type == GBN_LUT_SMALL_NA && (entries >= 32767 || max_off >= 32768)) type = GBN_LUT_NA;
+    return type;
+}
+
+// Index every lut-word that lies inside a strand, has no ambiguity code and
+// whose strand can hold a full word_size word.
+template <class F>
+static void each_query_word(const uint8_t *q, const GbnContext &c, int word, int lut, F &&emit) {
+    if (!c.is_valid || word > c.query_length) return;
+    const uint32_t mask = (lut == 16) ? 0xffffffffu : ((1u << (2 * lut)) - 1);
+    uint32_t code = 0; int run = 0;
+    for (int32_t p = c.query_offset; p < c.query_offset + c.query_length; p++) {
+        uint8_t b = q[p];
+        if (b & 0xfc) { run = 0; code = 0; continue; }
+        code = ((code << 2) | b) & mask;
+        if (++run >= lut) emit(code, p - lut + 1);
+    }
+}
+
+static void build_lookup(GbnBatch &b) {
+    HostLookup &L = b.lut;
+    int32_t entries = 0, max_off = 0;
+    for (auto &c : b.ctx) if (c.is_valid) {
+        entries += c.query_length - 1;
+        max_off = std::max(max_off, c.query_offset + c.query_length - 1);
+    }
+    int width = 0;
+    L.type = choose_lookup(b.opt, entries, max_off, width);
+    L.word = b.opt.word_size; L.lut = width; L.step = L.word - L.lut + 1;
+    L.ncells = (int64_t)1 << (2 * width);
+    const uint8_t *q = b.query();
+    std::vector<uint32_t> count((size_t)L.ncells, 0);
+    for (auto &c : b.ctx) each_query_word(q, c, L.word, width, [&](uint32_t cell, int32_t) { count[cell]++; });
+    L.cell_start.assign((size_t)L.ncells + 1, 0);
+    uint32_t acc = 0; int64_t overflow_cells = 2;
+    for (int64_t i = 0; i < L.ncells; i++) {
+        L.cell_start[i] = acc; acc += count[i];
+        if (count[i] > 1) overflow_cells += count[i] + 1;
+    }
+    L.cell_start[L.ncells] = acc;
+    if (L.type == GBN_LUT_SMALL_NA && overflow_cells >= 32768) L.type = GBN_LUT_NA;
+    L.cell_qoff.assign(acc, 0);
+    std::vector<uint32_t> fill(L.cell_start.begin(), L.cell_start.end() - 1);
+    for (auto &c : b.ctx) each_query_word(q, c, L.word, width, [&](uint32_t cell, int32_t off) { L.cell_qoff[fill[cell]++] = off; });
+    if (L.type == GBN_LUT_MB) {
+        // megablast chains yield the LAST inserted offset first (CORE/blast_nalookup.c:925-926,
+        // CORE/blast_nascan.c:1413-1427): reverse every cell
+        for (int64_t i = 0; i < L.ncells; i++)
+            std::reverse(L.cell_qoff.begin() + L.cell_start[i], L.cell_qoff.begin() + L.cell_start[i + 1]);
+    }
+    L.pv.assign((size_t)((L.ncells + 31) / 32), 0);
+    for (int64_t i = 0; i < L.ncells; i++) if (count[i]) L.pv[i >> 5] |= 1u << (i & 31);
+}
+
+int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *const *seqs, const int32_t *lens) {
+    b.opt = opt; b.nq = nq;
+    b.ctx.assign((size_t)2 * nq, GbnContext{});
+    const int32_t pad = 64;         // sentinel padding so kernels may read windows past either end
+    int64_t total = 1;
+    for (int i = 0; i < nq; i++) total += 2 * ((int64_t)lens[i] + 1);
+    if (total > INT32_MAX - 4 * pad) { set_error("query batch too long"); return GBN_ERR_ARG; }
+    b.qbuf.assign((size_t)total + 2 * pad, 15);
+    b.qpad = pad + 1;
+    uint8_t *q = b.qbuf.data() + b.qpad;
+    int32_t off = 0;
+    for (int i = 0; i < nq; i++) {
+        int32_t L = lens[i];
+        GbnContext &p = b.ctx[2 * i], &m = b.ctx[2 * i + 1];
+        p.query_offset = off; p.query_length = L; p.frame = 1; p.query_index = i;
+        std::memcpy(q + off, seqs[i], (size_t)L);
+        off += L + 1;
+        m.query_offset = off; m.query_length = L; m.frame = -1; m.query_index = i;
+        for (int32_t j = 0; j < L; j++) q[off + j] = kComplement[seqs[i][L - 1 - j] & 15];
+        off += L + 1;
+    }
+    b.qlen = off - 1;
+    build_score_matrix(opt.reward, opt.penalty, b.matrix);
+    for (int i = 0; i < 256; i++) {
+        int32_t s = 0;
+        s += (i & 3) ? opt.penalty : opt.reward;
+        s += ((i >> 2) & 3) ? opt.penalty : opt.reward;
+        s += ((i >> 4) & 3) ? opt.penalty : opt.reward;
+        s += (i >> 6) ? opt.penalty : opt.reward;
+        b.score_table[i] = s;
+    }
+    double stdc[16]; uniform_acgt(stdc);
+    bool any = false; Karlin first;
+    for (auto &c : b.ctx) {
+        c.is_valid = 1;
+        if (c.query_length <= 0) { c.is_valid = 0; continue; }
+        double comp[16]; strand_composition(q + c.query_offset, c.query_length, comp);
+        Karlin k;
+        if (!ungapped_karlin(opt.reward, opt.penalty, comp, stdc, k)) {
+            c.is_valid = 0; c.lambda_u = c.K_u = c.H_u = -1; continue;
+        }
+        c.lambda_u = k.lambda; c.K_u = k.K; c.logK_u = k.logK; c.H_u = k.H;
+        if (!any) { first = k; any = true; }
+    }
+    if (!any) { set_error("no valid query context (Karlin-Altschul parameters)"); return GBN_ERR_SETUP; }
+    if (gapped_karlin(opt.gap_open, opt.gap_extend, opt.reward, opt.penalty, first, b.kbp_gap, b.round_down)) {
+        set_error("unsupported reward/penalty/gap cost combination"); return GBN_ERR_UNSUPPORTED;
+    }
+    if (opt.greedy && !(opt.gap_open == 0 && opt.gap_extend == 0)) {
+        set_error("affine greedy extension is not implemented yet"); return GBN_ERR_UNSUPPORTED;
+    }
+    b.gap_x_dropoff = (int32_t)(opt.xdrop_gap_bits * kLn2 / b.kbp_gap.lambda);
+    b.gap_x_dropoff_final = (int32_t)std::max(opt.xdrop_gap_final_bits * kLn2 / b.kbp_gap.lambda,
+                                               (double)b.gap_x_dropoff);
+    for (auto &c : b.ctx) if (c.is_valid)
+        c.x_dropoff = (int32_t)(1.0 * std::ceil(opt.xdrop_ungap_bits * kLn2 / c.lambda_u));
+    if (opt.db_num_seqs > 0) { b.set_effective_lengths(opt.db_length, opt.db_num_seqs); b.update_cutoffs(); }
+    b.container = b.qlen > 8000 ? 1 : 0;
+    b.diag_len = 1;
+    while (b.diag_len < b.qlen) b.diag_len <<= 1;
+    build_lookup(b);
+    return GBN_OK;
+}
+
+}  // namespace gbn

@@ -1,0 +1,601 @@
+// engine.cpp -- device residency and orchestration of the preliminary search
+// (the BLAST_PreliminarySearchEngine analogue,
+// GB/gpu_blastn_pre_search_engine.cpp:1125-1464), plus the C ABI.
+//
+// Pipeline per shard (all on one HIP stream):
+//   scan_seed_kernel -> 2 stable radix sorts (scan order, then diagonal slot)
+//   -> diag_ungapped_kernel -> greedy_kernel | dynprog_kernel (all initial hits)
+//   -> D2H of initial hits + gapped results -> host replay (hsp_host.cpp).
+#include <hip/hip_runtime.h>
+#include "gbn_host.hpp"
+#include "gbn_dev.h"
+#include "hsp_host.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+
+namespace gbn {
+hipError_t launch_scan_seed(const GbnScanParams &p, int grid, hipStream_t st);
+hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st);
+hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
+hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st);
+hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st);
+hipError_t launch_synth_fill(void *dev, int64_t nbytes, uint64_t seed, hipStream_t st);
+hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
+                          const uint32_t *vin, uint32_t *vout, int64_t n, int end_bit, hipStream_t st);
+
+static thread_local std::string g_err;
+void set_error(const std::string &m) { g_err = m; }
+
+#define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return GBN_ERR_HIP; } } while (0)
+
+struct DeviceBatch {
+    uint8_t *q8_base = nullptr;     // device copy of qbuf
+    const uint8_t *q8 = nullptr;    // q8_base + qpad
+    uint32_t *pv = nullptr, *cellw = nullptr, *cell_start = nullptr;
+    unsigned long long *ent = nullptr;
+    int32_t *ctx_off = nullptr, *ctx_len = nullptr, *ctx_xdrop = nullptr, *ctx_cutoff = nullptr,
+            *ctx_reduced = nullptr;
+    int32_t *matrix = nullptr, *score_table = nullptr;
+    int mode = 0, fl = 0, fr = 0;
+};
+
+struct Engine {
+    bool ready = false; int device = -1; hipStream_t stream = nullptr;
+    int num_cu = 256;
+    // growable scratch
+    GbnDevSeed *seeds = nullptr; size_t seed_cap = 0;
+    uint64_t *key_a = nullptr, *key_b = nullptr; uint32_t *idx_a = nullptr, *idx_b = nullptr;
+    int32_t *cell_diag = nullptr, *cell_level = nullptr; size_t key_cap = 0;
+    void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    GbnDevInitHit *ihits = nullptr; GbnDevGapped *gapped = nullptr; size_t ihit_cap = 0;
+    unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits
+    int32_t *gap_scratch = nullptr; size_t gap_scratch_ints = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    std::mutex mu;
+};
+static Engine E;
+
+static int ensure_init() {
+    if (E.ready) return GBN_OK;
+    return Blast_gpu_Init(1, -1);
+}
+
+template <class T> static int dev_alloc(T *&p, size_t n) {
+    p = nullptr;
+    if (n == 0) n = 1;
+    HIPCHK(hipMalloc((void **)&p, n * sizeof(T)));
+    return GBN_OK;
+}
+template <class T> static int dev_upload(T *&p, const T *h, size_t n) {
+    int rc = dev_alloc(p, n);
+    if (rc) return rc;
+    if (n) HIPCHK(hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice));
+    return GBN_OK;
+}
+template <class T> static void dev_free(T *&p) { if (p) (void)hipFree((void *)p); p = nullptr; }
+
+void free_device_batch(DeviceBatch *d) {
+    if (!d) return;
+    dev_free(d->q8_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cell_start); dev_free(d->ent);
+    dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff);
+    dev_free(d->ctx_reduced); dev_free(d->matrix); dev_free(d->score_table);
+    delete d;
+}
+
+// fingerprint word of one query offset (layout in gbn_dev.h / kernels.hip fp_pass)
+static inline uint32_t fingerprint(const uint8_t *q, int32_t off, int lut, bool force) {
+    uint32_t l = 0, r = 0;
+    for (int k = 1; k <= 8; k++) l |= (uint32_t)(q[off - k] & 3) << (2 * (k - 1));
+    for (int j = 0; j < 7; j++) r |= (uint32_t)(q[off + lut + j] & 3) << (2 * (6 - j));
+    return (l << 15) | (r << 1) | (force ? 1u : 0u);
+}
+
+static int upload_ctx_cutoffs(GbnBatch &b) {
+    DeviceBatch *d = b.dev;
+    std::vector<int32_t> xd, cu, rd;
+    for (auto &c : b.ctx) { xd.push_back(c.x_dropoff); cu.push_back(c.cutoff_score); rd.push_back(c.reduced_cutoff); }
+    size_t n = b.ctx.size();
+    HIPCHK(hipMemcpy(d->ctx_xdrop, xd.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d->ctx_cutoff, cu.data(), n * 4, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(d->ctx_reduced, rd.data(), n * 4, hipMemcpyHostToDevice));
+    return GBN_OK;
+}
+
+int upload_batch(GbnBatch &b) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    DeviceBatch *d = new DeviceBatch();
+    b.dev = d;
+    const HostLookup &L = b.lut;
+    const uint8_t *q = b.query();
+    // extension flavour, CORE/na_ungapped.c:1753-1795
+    if (L.lut == L.word) d->mode = GBN_EXT_DIRECT;
+    else if (L.type == GBN_LUT_SMALL_NA)
+        d->mode = (L.lut % 4 == 0 && L.step % 4 == 0 && L.word - L.lut <= 4) ? GBN_EXT_SMALL_ONEBYTE : GBN_EXT_SMALL;
+    else d->mode = GBN_EXT_NA;
+    {   // fingerprint lengths: a verified seed has >= ceil(e/2) matches on the left
+        // or > e - ceil(e/2) on the right, e = word - lut
+        int e = L.word - L.lut, h = (e + 1) / 2;
+        d->fl = std::min(8, h); d->fr = std::min(7, e - h + 1);
+        if (e == 0) { d->fl = 0; d->fr = 0; }
+    }
+    std::vector<uint32_t> cellw((size_t)L.ncells, 0);
+    std::vector<unsigned long long> ent(L.cell_qoff.size());
+    for (int64_t c = 0; c < L.ncells; c++) {
+        uint32_t s = L.cell_start[c], e = L.cell_start[c + 1];
+        for (uint32_t k = s; k < e; k++) {
+            int32_t off = L.cell_qoff[k];
+            bool force = (d->mode == GBN_EXT_SMALL_ONEBYTE) && (off + L.lut >= b.qlen);
+            uint32_t fp = fingerprint(q, off, L.lut, force);
+            ent[k] = ((unsigned long long)fp << 32) | (uint32_t)off;
+            if (k == s) cellw[c] = (fp & 0x7fffffffu) | ((e - s > 1) ? 0x80000000u : 0u);
+        }
+    }
+    if ((rc = dev_upload(d->q8_base, b.qbuf.data(), b.qbuf.size()))) return rc;
+    d->q8 = d->q8_base + b.qpad;
+    if ((rc = dev_upload(d->pv, L.pv.data(), L.pv.size()))) return rc;
+    if ((rc = dev_upload(d->cellw, cellw.data(), cellw.size()))) return rc;
+    if ((rc = dev_upload(d->cell_start, L.cell_start.data(), L.cell_start.size()))) return rc;
+    {
+        // one pad entry so that an empty list still has a valid pointer
+        ent.push_back(0);
+        if ((rc = dev_upload(d->ent, ent.data(), ent.size()))) return rc;
+    }
+    std::vector<int32_t> off, len;
+    for (auto &c : b.ctx) { off.push_back(c.query_offset); len.push_back(c.query_length); }
+    if ((rc = dev_upload(d->ctx_off, off.data(), off.size()))) return rc;
+    if ((rc = dev_upload(d->ctx_len, len.data(), len.size()))) return rc;
+    if ((rc = dev_alloc(d->ctx_xdrop, off.size()))) return rc;
+    if ((rc = dev_alloc(d->ctx_cutoff, off.size()))) return rc;
+    if ((rc = dev_alloc(d->ctx_reduced, off.size()))) return rc;
+    if ((rc = upload_ctx_cutoffs(b))) return rc;
+    if ((rc = dev_upload(d->matrix, &b.matrix[0][0], 256))) return rc;
+    if ((rc = dev_upload(d->score_table, b.score_table, 256))) return rc;
+    return GBN_OK;
+}
+
+// ---------------------------------------------------------------------------
+struct TileSet { GbnTile *d_tiles = nullptr; int64_t ntiles = 0; std::vector<int64_t> first_tile_of_subj; int64_t bases = 0; };
+
+static int build_tiles(const GbnDb &db, int lut, int step, int32_t s0, int32_t s1, TileSet &ts) {
+    std::vector<GbnTile> tiles;
+    ts.first_tile_of_subj.clear(); ts.bases = 0;
+    for (int32_t s = s0; s < s1; s++) {
+        ts.first_tile_of_subj.push_back((int64_t)tiles.size());
+        int32_t L = db.len[s];
+        ts.bases += L;
+        if (L < lut) continue;
+        int32_t npos = (L - lut) / step + 1;
+        for (int32_t p = 0; p < npos; p += GBN_TILE_POS) {
+            GbnTile t; t.subj = s; t.first_pos = p * step; t.npos = std::min(GBN_TILE_POS, npos - p); t.pad_ = 0;
+            tiles.push_back(t);
+        }
+    }
+    ts.first_tile_of_subj.push_back((int64_t)tiles.size());
+    ts.ntiles = (int64_t)tiles.size();
+    return dev_upload(ts.d_tiles, tiles.data(), tiles.size());
+}
+
+static int grow_seed_buffers(size_t want) {
+    if (want <= E.seed_cap) return GBN_OK;
+    dev_free(E.seeds);
+    int rc = dev_alloc(E.seeds, want);
+    if (rc) { E.seed_cap = 0; return rc; }
+    E.seed_cap = want;
+    return GBN_OK;
+}
+static int grow_key_buffers(size_t n) {
+    if (n <= E.key_cap) return GBN_OK;
+    dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
+    dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.sort_tmp);
+    size_t cap = std::max<size_t>(n, 1 << 16);
+    int rc;
+    if ((rc = dev_alloc(E.key_a, cap)) || (rc = dev_alloc(E.key_b, cap)) || (rc = dev_alloc(E.idx_a, cap)) ||
+        (rc = dev_alloc(E.idx_b, cap)) || (rc = dev_alloc(E.cell_diag, cap)) || (rc = dev_alloc(E.cell_level, cap)))
+        return rc;
+    size_t bytes = 0;
+    HIPCHK(sort_pairs_u64(nullptr, bytes, E.key_a, E.key_b, E.idx_a, E.idx_b, (int64_t)cap, 64, E.stream));
+    HIPCHK(hipMalloc(&E.sort_tmp, bytes));
+    E.sort_tmp_bytes = bytes; E.key_cap = cap;
+    return GBN_OK;
+}
+static int grow_ihit_buffers(size_t n) {
+    if (n <= E.ihit_cap) return GBN_OK;
+    dev_free(E.ihits); dev_free(E.gapped);
+    size_t cap = std::max<size_t>(n, 1 << 14);
+    int rc;
+    if ((rc = dev_alloc(E.ihits, cap)) || (rc = dev_alloc(E.gapped, cap))) return rc;
+    E.ihit_cap = cap;
+    return GBN_OK;
+}
+
+static void fill_scan_params(GbnScanParams &P, const GbnBatch &b, const GbnDb &db, const TileSet &ts) {
+    const DeviceBatch *d = b.dev;
+    std::memset(&P, 0, sizeof(P));
+    P.db = db.d_packed; P.byte_off = db.d_byte_off; P.len = db.d_len;
+    P.tiles = ts.d_tiles; P.ntiles = ts.ntiles;
+    P.pv = d->pv; P.cellw = d->cellw; P.cell_start = d->cell_start; P.ent = d->ent;
+    P.ncells = b.lut.ncells; P.lut = b.lut.lut; P.word = b.lut.word; P.step = b.lut.step;
+    P.mode = d->mode; P.fl = d->fl; P.fr = d->fr;
+    P.q8 = d->q8; P.qlen = b.qlen; P.ctx_off = d->ctx_off; P.ctx_len = d->ctx_len; P.nctx = (int32_t)b.ctx.size();
+    P.seeds = E.seeds; P.seed_count = E.counters; P.seed_cap = E.seed_cap; P.raw_hits = E.counters + 1;
+}
+
+static int scan_grid(int64_t ntiles) {
+    int64_t g = (int64_t)E.num_cu * 8;      // 8 resident 256-thread workgroups per CU
+    return (int)std::max<int64_t>(1, std::min(ntiles, g));
+}
+
+// one range of subjects [s0, s1) through the whole pipeline
+static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res,
+                        GbnDiagnostics *diag, int keep_stages)
+{
+    const DeviceBatch *d = b.dev;
+    TileSet ts;
+    int rc = build_tiles(db, b.lut.lut, b.lut.step, s0, s1, ts);
+    if (rc) return rc;
+    struct Free { TileSet &t; ~Free() { dev_free(t.d_tiles); } } fr{ts};
+    if (ts.ntiles == 0) return GBN_OK;
+    if ((rc = grow_seed_buffers(std::max<size_t>(E.seed_cap, (size_t)1 << 22)))) return rc;
+
+    unsigned long long cnt[3] = {0, 0, 0};
+    for (;;) {
+        HIPCHK(hipMemsetAsync(E.counters, 0, 3 * sizeof(unsigned long long), E.stream));
+        GbnScanParams P; fill_scan_params(P, b, db, ts);
+        HIPCHK(hipEventRecord(E.ev0, E.stream));
+        HIPCHK(launch_scan_seed(P, scan_grid(ts.ntiles), E.stream));
+        HIPCHK(hipEventRecord(E.ev1, E.stream));
+        HIPCHK(hipMemcpyAsync(cnt, E.counters, sizeof(cnt), hipMemcpyDeviceToHost, E.stream));
+        HIPCHK(hipStreamSynchronize(E.stream));
+        if (diag) {
+            float ms = 0; (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
+            diag->scan_kernel_ms += ms; diag->scan_launches++;
+        }
+        if (cnt[0] <= E.seed_cap) break;
+        // seed buffer too small: grow to what this range needs and rescan it
+        if ((rc = grow_seed_buffers((size_t)cnt[0] + (cnt[0] >> 3)))) return rc;
+    }
+    if (diag) { diag->lookup_hits += (int64_t)cnt[1]; diag->seeds += (int64_t)cnt[0]; diag->subject_bases_scanned += ts.bases; }
+    const int64_t n = (int64_t)cnt[0];
+    if (n == 0) return GBN_OK;
+    if (n > INT32_MAX) { set_error("too many seeds in one range"); return GBN_ERR_NOMEM; }
+
+    if ((rc = grow_key_buffers((size_t)n))) return rc;
+    GbnKeyParams K; std::memset(&K, 0, sizeof(K));
+    K.seeds = E.seeds; K.n = n; K.key_scan = E.key_a; K.idx = E.idx_a;
+    K.q_descending = (b.lut.type == GBN_LUT_MB); K.container_hash = b.container; K.diag_len = b.diag_len;
+    HIPCHK(launch_seed_keys(K, E.stream));
+    size_t tb = E.sort_tmp_bytes;
+    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, 64, E.stream));
+    // idx_b = seed indices in scan order (s_scan, chain order), subjects interleaved
+    K.idx = E.idx_b; K.key_group = E.key_a;
+    HIPCHK(launch_group_keys(K, E.stream));
+    tb = E.sort_tmp_bytes;
+    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_b, E.idx_a, n, 64, E.stream));
+    // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
+
+    if (keep_stages) {
+        std::vector<GbnDevSeed> hs((size_t)n); std::vector<uint32_t> order((size_t)n);
+        HIPCHK(hipMemcpyAsync(hs.data(), E.seeds, (size_t)n * sizeof(GbnDevSeed), hipMemcpyDeviceToHost, E.stream));
+        HIPCHK(hipMemcpyAsync(order.data(), E.idx_b, (size_t)n * 4, hipMemcpyDeviceToHost, E.stream));
+        HIPCHK(hipStreamSynchronize(E.stream));
+        std::vector<GbnSeed> tmp; tmp.reserve((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const GbnDevSeed &s = hs[order[i]];
+            GbnSeed o; o.oid = db.first_oid + s.subj; o.s_off = s.s_scan - s.ext_left; o.q_off = s.q_pos - s.ext_left; o.pad_ = 0;
+            tmp.push_back(o);
+        }
+        std::stable_sort(tmp.begin(), tmp.end(), [](const GbnSeed &a, const GbnSeed &c) { return a.oid < c.oid; });
+        res.seeds.insert(res.seeds.end(), tmp.begin(), tmp.end());
+    }
+
+    if ((rc = grow_ihit_buffers(std::max<size_t>(E.ihit_cap, 1 << 16)))) return rc;
+    unsigned long long nih = 0;
+    for (;;) {
+        HIPCHK(hipMemsetAsync(E.counters + 2, 0, sizeof(unsigned long long), E.stream));
+        GbnExtParams X; std::memset(&X, 0, sizeof(X));
+        X.db = db.d_packed; X.byte_off = db.d_byte_off; X.len = db.d_len;
+        X.seeds = E.seeds; X.idx = E.idx_a; X.key_group = E.key_b; X.n = n;
+        X.q8 = d->q8; X.qlen = b.qlen;
+        X.ctx_off = d->ctx_off; X.ctx_len = d->ctx_len; X.ctx_xdrop = d->ctx_xdrop;
+        X.ctx_cutoff = d->ctx_cutoff; X.ctx_reduced = d->ctx_reduced; X.nctx = (int32_t)b.ctx.size();
+        X.matrix = d->matrix; X.score_table = d->score_table;
+        X.word = b.lut.word; X.container_hash = b.container;
+        X.cell_diag = E.cell_diag; X.cell_level = E.cell_level;
+        X.ihits = E.ihits; X.ihit_count = E.counters + 2; X.ihit_cap = E.ihit_cap;
+        HIPCHK(launch_diag_ungapped(X, E.stream));
+        HIPCHK(hipMemcpyAsync(&nih, E.counters + 2, sizeof(nih), hipMemcpyDeviceToHost, E.stream));
+        HIPCHK(hipStreamSynchronize(E.stream));
+        if (nih <= E.ihit_cap) break;
+        if ((rc = grow_ihit_buffers((size_t)nih + (nih >> 3)))) return rc;
+    }
+    if (diag) { diag->init_extends += (int64_t)nih; diag->good_init_extends += (int64_t)nih; }
+    if (nih == 0) return GBN_OK;
+
+    // ---- gapped extension of every initial hit ----
+    int32_t max_len = 0, max_ctx = 0;
+    for (int32_t s = s0; s < s1; s++) max_len = std::max(max_len, db.len[s]);
+    for (auto &c : b.ctx) max_ctx = std::max(max_ctx, c.query_length);
+    GbnGapParams G; std::memset(&G, 0, sizeof(G));
+    G.db = db.d_packed; G.byte_off = db.d_byte_off; G.len = db.d_len;
+    G.ihits = E.ihits; G.q8 = d->q8; G.ctx_off = d->ctx_off; G.ctx_len = d->ctx_len; G.nctx = (int32_t)b.ctx.size();
+    G.matrix = d->matrix; G.reward = b.opt.reward; G.penalty = b.opt.penalty;
+    G.gap_open = b.opt.gap_open; G.gap_extend = b.opt.gap_extend; G.xdrop = b.gap_x_dropoff;
+    G.out = E.gapped;
+    size_t per_thread;
+    if (b.opt.greedy) {
+        int32_t max_dist = std::min(10000, max_len / 2 + 1);
+        int32_t X2 = (b.opt.reward % 2 == 1) ? 2 * b.gap_x_dropoff : b.gap_x_dropoff;
+        int32_t mc = (b.opt.reward % 2 == 1) ? 2 * b.opt.reward : b.opt.reward;
+        int32_t mm = (b.opt.reward % 2 == 1) ? -2 * b.opt.penalty : -b.opt.penalty;
+        int32_t xoff = (X2 + mc / 2) / (mc + mm) + 1;
+        G.row_len = 2 * max_dist + 8;
+        per_thread = 2 * (size_t)G.row_len + (size_t)max_dist + 4 + (size_t)xoff;
+    } else {
+        G.row_len = 0;
+        per_thread = 2 * ((size_t)max_ctx + 16);
+    }
+    per_thread = (per_thread + 3) & ~(size_t)3;
+    G.scratch_per_thread = (int32_t)per_thread;
+    const size_t budget_ints = (size_t)1 << 28;        // 1 GiB of scratch
+    size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)nih, budget_ints / per_thread));
+    if (chunk * per_thread > E.gap_scratch_ints) {
+        dev_free(E.gap_scratch);
+        if ((rc = dev_alloc(E.gap_scratch, chunk * per_thread))) { E.gap_scratch_ints = 0; return rc; }
+        E.gap_scratch_ints = chunk * per_thread;
+    }
+    G.scratch = E.gap_scratch;
+    for (size_t first = 0; first < (size_t)nih; first += chunk) {
+        G.first = (int64_t)first; G.n = (int64_t)std::min(chunk, (size_t)nih - first);
+        HIPCHK(launch_gapped(G, b.opt.greedy != 0, E.stream));
+    }
+    std::vector<GbnDevInitHit> hih((size_t)nih); std::vector<GbnDevGapped> hg((size_t)nih);
+    HIPCHK(hipMemcpyAsync(hih.data(), E.ihits, (size_t)nih * sizeof(GbnDevInitHit), hipMemcpyDeviceToHost, E.stream));
+    HIPCHK(hipMemcpyAsync(hg.data(), E.gapped, (size_t)nih * sizeof(GbnDevGapped), hipMemcpyDeviceToHost, E.stream));
+    HIPCHK(hipStreamSynchronize(E.stream));
+
+    // ---- host replay per subject, ascending oid ----
+    std::vector<uint32_t> order((size_t)nih);
+    for (size_t i = 0; i < (size_t)nih; i++) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
+        if (hih[a].subj != hih[c].subj) return hih[a].subj < hih[c].subj;
+        return hih[a].seq < hih[c].seq;
+    });
+    size_t i = 0;
+    while (i < order.size()) {
+        size_t j = i; int32_t subj = hih[order[i]].subj;
+        std::vector<std::pair<GbnDevInitHit, GbnDevGapped>> hits;
+        while (j < order.size() && hih[order[j]].subj == subj) {
+            if (hg[order[j]].score == INT32_MIN) { set_error("gapped DP scratch overflow"); return GBN_ERR_NOMEM; }
+            hits.emplace_back(hih[order[j]], hg[order[j]]); j++;
+        }
+        if (keep_stages) {
+            auto sorted = hits;
+            // reference order of the initial hit list
+            std::sort(sorted.begin(), sorted.end(), [](const auto &x, const auto &y) {
+                const GbnDevInitHit &a = x.first, &c = y.first;
+                if (a.score != c.score) return a.score > c.score;
+                if (a.s_start != c.s_start) return a.s_start < c.s_start;
+                if (a.length != c.length) return a.length > c.length;
+                if (a.q_start != c.q_start) return a.q_start < c.q_start;
+                return a.seq < c.seq;
+            });
+            for (auto &pr : sorted) {
+                GbnInitHit o; o.oid = db.first_oid + subj; o.q_off = pr.first.q_off; o.s_off = pr.first.s_off;
+                o.q_start = pr.first.q_start; o.s_start = pr.first.s_start; o.length = pr.first.length;
+                o.score = pr.first.score; o.pad_ = 0;
+                res.init_hits.push_back(o);
+            }
+        }
+        finish_subject(b, db.first_oid + subj, db.len[subj], hits, res.hsps, diag);
+        i = j;
+    }
+    return GBN_OK;
+}
+
+}  // namespace gbn
+
+using namespace gbn;
+
+// ===========================================================================
+// C ABI
+// ===========================================================================
+extern "C" {
+
+const char *gbn_last_error(void) { return g_err.c_str(); }
+
+int Blast_gpu_Init(int use_gpu, int gpu_id) {
+    std::lock_guard<std::mutex> lk(E.mu);
+    if (!use_gpu) { set_error("this engine has no CPU path: use_gpu must be true"); return GBN_ERR_NO_DEVICE; }
+    if (E.ready) return GBN_OK;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible"); return GBN_ERR_NO_DEVICE; }
+    int dev = gpu_id;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= n) { set_error("gpu_id out of range"); return GBN_ERR_ARG; }
+    HIPCHK(hipSetDevice(dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    E.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    HIPCHK(hipStreamCreateWithFlags(&E.stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&E.ev0)); HIPCHK(hipEventCreate(&E.ev1));
+    HIPCHK(hipMalloc((void **)&E.counters, 8 * sizeof(unsigned long long)));
+    E.device = dev; E.ready = true;
+    return GBN_OK;
+}
+
+void gpu_ReleaseDBMemory(void) { /* shards are owned by their GbnDb handles */ }
+
+void Blast_gpu_Release(void) {
+    std::lock_guard<std::mutex> lk(E.mu);
+    if (!E.ready) return;
+    dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
+    dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.sort_tmp); dev_free(E.ihits); dev_free(E.gapped);
+    dev_free(E.counters); dev_free(E.gap_scratch);
+    E.seed_cap = E.key_cap = E.ihit_cap = E.gap_scratch_ints = 0;
+    if (E.ev0) (void)hipEventDestroy(E.ev0);
+    if (E.ev1) (void)hipEventDestroy(E.ev1);
+    if (E.stream) (void)hipStreamDestroy(E.stream);
+    E.ev0 = E.ev1 = nullptr; E.stream = nullptr; E.ready = false;
+}
+
+int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_seqs,
+               const int64_t *byte_off, const int32_t *len, int32_t first_oid, int is_device) {
+    if (!out || !packed || num_seqs < 0 || (num_seqs > 0 && (!byte_off || !len))) { set_error("bad argument"); return GBN_ERR_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    GbnDb *db = new GbnDb();
+    db->num_seqs = num_seqs; db->first_oid = first_oid; db->nbytes = nbytes;
+    db->byte_off.assign(byte_off, byte_off + num_seqs); db->len.assign(len, len + num_seqs);
+    for (int32_t i = 0; i < num_seqs; i++) {
+        if (byte_off[i] < 16 || (byte_off[i] & 15) || byte_off[i] + (len[i] + 3) / 4 + 64 > nbytes) {
+            delete db; set_error("subject offsets must be 16-byte aligned, >= 16, and leave 64 pad bytes"); return GBN_ERR_ARG;
+        }
+        db->total_bases += len[i];
+    }
+    if (is_device) { db->d_packed = packed; db->owns = false; }
+    else {
+        uint8_t *p = nullptr;
+        if (hipMalloc((void **)&p, (size_t)nbytes) != hipSuccess) { delete db; set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
+        if (hipMemcpy(p, packed, (size_t)nbytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); delete db; set_error("H2D(db) failed"); return GBN_ERR_HIP; }
+        db->d_packed = p; db->owns = true;
+    }
+    if ((rc = dev_upload(db->d_byte_off, db->byte_off.data(), db->byte_off.size())) ||
+        (rc = dev_upload(db->d_len, db->len.data(), db->len.size()))) { gbn_db_free(db); return rc; }
+    *out = db;
+    return GBN_OK;
+}
+
+void gbn_db_free(GbnDb *db) {
+    if (!db) return;
+    if (db->owns && db->d_packed) (void)hipFree((void *)db->d_packed);
+    dev_free(db->d_byte_off); dev_free(db->d_len);
+    delete db;
+}
+int64_t gbn_db_total_bases(const GbnDb *db) { return db ? db->total_bases : 0; }
+int32_t gbn_db_num_seqs(const GbnDb *db) { return db ? db->num_seqs : 0; }
+
+int gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : E.stream;
+    HIPCHK(launch_synth_fill(dev_ptr, nbytes, seed, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return GBN_OK;
+}
+
+int gbn_batch_new_ex(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs,
+                     const int32_t *lens, int upload) {
+    if (!out || !opt || nq <= 0 || !seqs || !lens) { set_error("bad argument"); return GBN_ERR_ARG; }
+    GbnBatch *b = new GbnBatch();
+    int rc = build_batch(*b, *opt, nq, seqs, lens);
+    if (rc == GBN_OK && upload) rc = upload_batch(*b);
+    if (rc != GBN_OK) { gbn_batch_free(b); return rc; }
+    *out = b;
+    return GBN_OK;
+}
+int gbn_batch_new(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs, const int32_t *lens) {
+    return gbn_batch_new_ex(out, opt, nq, seqs, lens, 1);
+}
+int gbn_launch_scan_seed(const GbnScanParams *p, int grid, void *stream) {
+    if (!p) return GBN_ERR_ARG;
+    HIPCHK(launch_scan_seed(*p, grid, (hipStream_t)stream));
+    return GBN_OK;
+}
+int gbn_launch_ungapped(const GbnExtParams *p, void *stream) {
+    if (!p) return GBN_ERR_ARG;
+    HIPCHK(launch_diag_ungapped(*p, (hipStream_t)stream));
+    return GBN_OK;
+}
+int gbn_launch_gapped(const GbnGapParams *p, int greedy, void *stream) {
+    if (!p) return GBN_ERR_ARG;
+    HIPCHK(launch_gapped(*p, greedy != 0, (hipStream_t)stream));
+    return GBN_OK;
+}
+void gbn_batch_free(GbnBatch *b) { if (!b) return; free_device_batch(b->dev); delete b; }
+int32_t gbn_batch_num_contexts(const GbnBatch *b) { return (int32_t)b->ctx.size(); }
+const GbnContext *gbn_batch_contexts(const GbnBatch *b) { return b->ctx.data(); }
+int32_t gbn_batch_lut_type(const GbnBatch *b) { return b->lut.type; }
+int32_t gbn_batch_lut_width(const GbnBatch *b) { return b->lut.lut; }
+int32_t gbn_batch_scan_step(const GbnBatch *b) { return b->lut.step; }
+int32_t gbn_batch_diag_container(const GbnBatch *b) { return b->container; }
+int32_t gbn_batch_gap_x_dropoff(const GbnBatch *b) { return b->gap_x_dropoff; }
+
+int gbn_results_new(GbnResults **out) { if (!out) return GBN_ERR_ARG; *out = new GbnResults(); return GBN_OK; }
+void gbn_results_free(GbnResults *r) { delete r; }
+void gbn_results_clear(GbnResults *r) { if (r) { r->hsps.clear(); r->seeds.clear(); r->init_hits.clear(); } }
+int64_t gbn_results_num_hsps(const GbnResults *r) { return (int64_t)r->hsps.size(); }
+const GbnHSP *gbn_results_hsps(const GbnResults *r) { return r->hsps.data(); }
+int64_t gbn_results_num_seeds(const GbnResults *r) { return (int64_t)r->seeds.size(); }
+const GbnSeed *gbn_results_seeds(const GbnResults *r) { return r->seeds.data(); }
+int64_t gbn_results_num_init_hits(const GbnResults *r) { return (int64_t)r->init_hits.size(); }
+const GbnInitHit *gbn_results_init_hits(const GbnResults *r) { return r->init_hits.data(); }
+
+int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
+                      int keep_stages, GbnInterruptFn interrupt, void *progress) {
+    if (!batch || !db || !results) { set_error("bad argument"); return GBN_ERR_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(E.mu);
+    auto t0 = std::chrono::steady_clock::now();
+    if (batch->opt.db_num_seqs == 0) {
+        // "db_length == 0" branch of the engine: effective lengths and cut-offs are
+        // recomputed for every subject (CORE/blast_setup.c:905-932)
+        for (int32_t s = 0; s < db->num_seqs; s++) {
+            batch->set_effective_lengths(db->len[s], 1);
+            batch->update_cutoffs();
+            if ((rc = upload_ctx_cutoffs(*batch))) return rc;
+            if ((rc = search_range(*batch, *db, s, s + 1, *results, diag, keep_stages))) return rc;
+            if (interrupt && interrupt(progress)) { set_error("interrupted"); return GBN_ERR_INTERRUPTED; }
+        }
+    } else {
+        // ranges of subjects bounded by packed size so that scratch stays modest
+        const int64_t range_bytes = (int64_t)4 << 30;
+        int32_t s0 = 0;
+        while (s0 < db->num_seqs) {
+            int32_t s1 = s0; int64_t acc = 0;
+            while (s1 < db->num_seqs && (s1 == s0 || acc + (db->len[s1] + 3) / 4 <= range_bytes)) { acc += (db->len[s1] + 3) / 4; s1++; }
+            if ((rc = search_range(*batch, *db, s0, s1, *results, diag, keep_stages))) return rc;
+            if (interrupt && interrupt(progress)) { set_error("interrupted"); return GBN_ERR_INTERRUPTED; }
+            s0 = s1;
+        }
+    }
+    if (diag) diag->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    return GBN_OK;
+}
+
+int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag) {
+    if (!batch || !db || repeats <= 0) { set_error("bad argument"); return GBN_ERR_ARG; }
+    int rc = ensure_init();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(E.mu);
+    TileSet ts;
+    if ((rc = build_tiles(*db, batch->lut.lut, batch->lut.step, 0, db->num_seqs, ts))) return rc;
+    struct Free { TileSet &t; ~Free() { dev_free(t.d_tiles); } } fr{ts};
+    if ((rc = grow_seed_buffers(std::max<size_t>(E.seed_cap, (size_t)1 << 22)))) return rc;
+    auto t0 = std::chrono::steady_clock::now();
+    for (int r = 0; r < repeats; r++) {
+        HIPCHK(hipMemsetAsync(E.counters, 0, 3 * sizeof(unsigned long long), E.stream));
+        GbnScanParams P; fill_scan_params(P, *batch, *db, ts);
+        HIPCHK(hipEventRecord(E.ev0, E.stream));
+        HIPCHK(launch_scan_seed(P, scan_grid(ts.ntiles), E.stream));
+        HIPCHK(hipEventRecord(E.ev1, E.stream));
+        HIPCHK(hipStreamSynchronize(E.stream));
+        float ms = 0; (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
+        if (diag) { diag->scan_kernel_ms += ms; diag->scan_launches++; diag->subject_bases_scanned += ts.bases; }
+    }
+    unsigned long long cnt[2] = {0, 0};
+    HIPCHK(hipMemcpy(cnt, E.counters, sizeof(cnt), hipMemcpyDeviceToHost));
+    if (diag) {
+        diag->seeds = (int64_t)cnt[0]; diag->lookup_hits = (int64_t)cnt[1];
+        diag->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    return GBN_OK;
+}
+
+}  // extern "C"

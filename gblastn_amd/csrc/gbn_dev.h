@@ -1,0 +1,65 @@
+// gbn_dev.h -- structures shared by the HIP kernels and their host launchers.
+#pragma once
+#include <stdint.h>
+
+#define GBN_SCAN_THREADS 256
+#define GBN_TILE_POS     2048       // scan positions per tile (8 per lane)
+
+// mini-extension flavours (CORE/na_ungapped.c:1753-1795)
+#define GBN_EXT_DIRECT        0     // lut == word_size
+#define GBN_EXT_NA            1     // s_BlastNaExtend / s_BlastNaExtendAligned
+#define GBN_EXT_SMALL         2     // s_BlastSmallNaExtend
+#define GBN_EXT_SMALL_ONEBYTE 3     // s_BlastSmallNaExtendAlignedOneByte
+
+struct GbnTile { int32_t subj; int32_t first_pos; int32_t npos; int32_t pad_; };
+
+struct GbnDevSeed { int32_t subj, s_scan, q_pos, ext_left; };
+struct GbnDevInitHit { int32_t subj, q_off, s_off, q_start, s_start, length, score; uint32_t seq; };
+struct GbnDevGapped { int32_t q_start, q_stop, s_start, s_stop, score, seed_q, seed_s, context; };
+
+struct GbnScanParams {
+    // database slab
+    const uint8_t *db; const int64_t *byte_off; const int32_t *len;
+    const GbnTile *tiles; int64_t ntiles;
+    // lookup structures
+    const uint32_t *pv;             // 1 bit per cell
+    const uint32_t *cellw;          // bit31 = more than one entry, [30:15] left-8, [14:1] right-7, bit0 force
+    const uint32_t *cell_start;     // ncells + 1
+    const unsigned long long *ent;  // low 32 = query offset, high 32 = fingerprint word
+    int64_t ncells;
+    int lut, word, step, mode, fl, fr;
+    // query (one byte per base, index 0 = first base of strand 0)
+    const uint8_t *q8; int32_t qlen;
+    const int32_t *ctx_off, *ctx_len; int32_t nctx;
+    // outputs
+    GbnDevSeed *seeds; unsigned long long *seed_count; unsigned long long seed_cap;
+    unsigned long long *raw_hits;
+};
+
+struct GbnKeyParams {
+    const GbnDevSeed *seeds; int64_t n;
+    uint64_t *key_scan; uint64_t *key_group; uint32_t *idx;
+    int q_descending, container_hash, diag_len;
+};
+
+struct GbnExtParams {
+    const uint8_t *db; const int64_t *byte_off; const int32_t *len;
+    const GbnDevSeed *seeds; const uint32_t *idx; const uint64_t *key_group; int64_t n;
+    const uint8_t *q8; int32_t qlen;
+    const int32_t *ctx_off, *ctx_len, *ctx_xdrop, *ctx_cutoff, *ctx_reduced; int32_t nctx;
+    const int32_t *matrix;          // 16 x 16
+    const int32_t *score_table;     // 256
+    int word, container_hash;
+    int32_t *cell_diag, *cell_level;    // hash emulation scratch, n entries each
+    GbnDevInitHit *ihits; unsigned long long *ihit_count; unsigned long long ihit_cap;
+};
+
+struct GbnGapParams {
+    const uint8_t *db; const int64_t *byte_off; const int32_t *len;
+    const GbnDevInitHit *ihits; int64_t first, n;
+    const uint8_t *q8; const int32_t *ctx_off, *ctx_len; int32_t nctx;
+    const int32_t *matrix;
+    int32_t reward, penalty, gap_open, gap_extend, xdrop;
+    int32_t *scratch; int32_t scratch_per_thread, row_len;
+    GbnDevGapped *out;
+};

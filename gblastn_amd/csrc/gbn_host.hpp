@@ -1,0 +1,88 @@
+// gbn_host.hpp -- internal host-side declarations of the MI355X blastn engine.
+// Product code: never includes anything from oracle/.
+#pragma once
+#include "../../include/gblastn_amd.h"
+#include <cstdint>
+#include <string>
+#include <vector>
+
+namespace gbn {
+
+struct Karlin { double lambda = -1, K = -1, logK = 0, H = -1; bool valid() const { return lambda > 0 && K > 0 && H > 0; } };
+
+// ---- statistics (stat.cpp) : CORE/blast_stat.c restated for nucleotides ----
+void   build_score_matrix(int reward, int penalty, int32_t m[16][16]);        // blast_stat.c:1036
+bool   ungapped_karlin(int reward, int penalty, const double comp1[16],
+                       const double comp2[16], Karlin &out);                  // blast_stat.c:2673
+void   uniform_acgt(double comp[16]);                                         // blast_stat.c:1861
+void   strand_composition(const uint8_t *seq, int32_t len, double comp[16]);  // blast_stat.c:1958
+int    gapped_karlin(int gap_open, int gap_extend, int reward, int penalty,
+                     const Karlin &ungapped, Karlin &out, bool &round_down);  // blast_stat.c:3806
+int    alpha_beta(int reward, int penalty, int gap_open, int gap_extend,
+                  const Karlin &ungapped, bool gapped, double &alpha, double &beta); // :3919
+int32_t length_adjustment(double K, double logK, double alpha_d_lambda, double beta,
+                          int32_t qlen, int64_t db_len, int32_t db_nseq);     // :4994
+int32_t score_for_evalue(double E, const Karlin &k, int64_t searchsp);        // :3994
+double  evalue_for_score(int32_t S, const Karlin &k, int64_t searchsp);       // :4111
+int32_t cutoff_from_evalue(double E, const Karlin &k, int64_t searchsp);      // :4044
+
+// ---- query batch (batch.cpp) ----
+struct HostLookup {
+    int type = 0, word = 0, lut = 0, step = 0;
+    int64_t ncells = 0;
+    // per-cell chains in the order the reference reports them
+    // (MB: descending query offset; SmallNa/Na: ascending)
+    std::vector<uint32_t> cell_start;   // ncells + 1
+    std::vector<int32_t>  cell_qoff;    // 0-based query offsets
+    std::vector<uint32_t> pv;           // 1 bit per cell
+};
+
+struct DeviceBatch;     // device mirrors, defined in engine.cpp
+}  // namespace gbn
+
+struct GbnBatch {
+    GbnOptions opt{};
+    int32_t nq = 0;
+    std::vector<GbnContext> ctx;
+    std::vector<uint8_t> qbuf;          // [pad sentinels][15] ctx0 [15] ctx1 ... [15][pad]
+    int32_t qpad = 0;                   // index of query position 0 inside qbuf
+    int32_t qlen = 0;                   // concatenated length (no outer sentinels)
+    int32_t matrix[16][16];
+    int32_t score_table[256];
+    gbn::Karlin kbp_gap;
+    bool round_down = false;
+    int32_t gap_x_dropoff = 0, gap_x_dropoff_final = 0;
+    int32_t container = 0, diag_len = 0;
+    gbn::HostLookup lut;
+    gbn::DeviceBatch *dev = nullptr;
+    const uint8_t *query() const { return qbuf.data() + qpad; }
+    int context_of(int32_t q_off) const;                     // BSearchContextInfo
+    void set_effective_lengths(int64_t db_len, int32_t db_nseq);
+    void update_cutoffs();
+};
+
+struct GbnDb {
+    const uint8_t *d_packed = nullptr;  // device
+    bool owns = false;
+    int64_t nbytes = 0;
+    int32_t num_seqs = 0, first_oid = 0;
+    std::vector<int64_t> byte_off;
+    std::vector<int32_t> len;
+    int64_t total_bases = 0;
+    int64_t *d_byte_off = nullptr;
+    int32_t *d_len = nullptr;
+};
+
+struct GbnResults {
+    std::vector<GbnHSP> hsps;
+    std::vector<GbnSeed> seeds;
+    std::vector<GbnInitHit> init_hits;
+};
+
+namespace gbn {
+void set_error(const std::string &msg);
+int  build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq,
+                 const uint8_t *const *seqs, const int32_t *lens);
+int  upload_batch(GbnBatch &b);
+void free_device_batch(DeviceBatch *d);
+}

@@ -1,0 +1,664 @@
+// kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the blastn /
+// megablast preliminary search.  Integer work only: no MFMA.
+//
+//   scan_seed_kernel     subject scan + lookup + exact-match verification to
+//                        word_size (replaces TNaScanSubjectFunction +
+//                        TNaExtendFunction mini-extension; CORE/blast_nascan.c,
+//                        CORE/na_ungapped.c:1025-1555)
+//   diag_ungapped_kernel per-diagonal one-hit filter + X-drop ungapped extension
+//                        (CORE/na_ungapped.c:152-351, :611-922)
+//   greedy_kernel        megablast score-only greedy gapped extension
+//                        (CORE/greedy_align.c:385-753, CORE/blast_gapalign.c:2619-2751)
+//   dynprog_kernel       blastn score-only X-drop DP on the packed subject
+//                        (CORE/blast_gapalign.c:2762-3056)
+//
+// Data layout: subjects are NCBI2na (4 bases/byte, base 0 in
+// bits 7..6) back to back in one HBM slab, 16-byte aligned each; the query is
+// one byte per base (BLASTNA) with sentinel padding on both sides.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "gbn_dev.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
+
+// base `pos` of a packed sequence
+__device__ __forceinline__ int base_at(const uint8_t *__restrict__ p, int64_t pos) {
+    return (p[pos >> 2] >> (2 * (3 - (int)(pos & 3)))) & 3;
+}
+
+// 16 consecutive bases starting at base index `pos` (may be negative relative
+// to `p`; the slab is padded) as a big-endian 32-bit word: base pos in bits 31..30
+__device__ __forceinline__ uint32_t window16(const uint8_t *__restrict__ p, int64_t pos) {
+    int64_t w = pos >> 4;                       // dword index (floor)
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + w;
+    uint32_t hi = bswap32(d[0]), lo = bswap32(d[1]);
+    int sh = 2 * (int)(pos & 15);
+    return sh ? ((hi << sh) | (lo >> (32 - sh))) : hi;
+}
+
+// ---------------------------------------------------------------------------
+// exact verification of one lookup hit to word_size; returns ext_left or -1
+// ---------------------------------------------------------------------------
+__device__ int verify_hit(const GbnScanParams &P, const uint8_t *__restrict__ subj, int32_t slen,
+                          int32_t q_off, int32_t s_off)
+{
+    const uint8_t *q = P.q8;
+    const int word = P.word, lut = P.lut, ext_to = word - lut;
+    if (P.mode == GBN_EXT_DIRECT) return 0;
+    if (P.mode == GBN_EXT_NA) {
+        // s_BlastNaExtend: sentinel bytes never equal a 2-bit base
+        int ext_left = 0, ext_max = min(ext_to, s_off);
+        for (; ext_left < ext_max; ++ext_left)
+            if (base_at(subj, s_off - ext_left - 1) != q[q_off - ext_left - 1]) break;
+        if (ext_left < ext_to) {
+            int need = ext_to - ext_left, so = s_off + lut, r = 0;
+            if (so + need > slen) return -1;
+            for (; r < need; ++r)
+                if (base_at(subj, so + r) != q[q_off + lut + r]) break;
+            if (ext_left + r < ext_to) return -1;
+        }
+        return ext_left;
+    }
+    // small-query tables compare (code & 3) and clamp at the strand boundaries
+    int lo = 0, hi = P.nctx;
+    while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > q_off) hi = m; else lo = m; }
+    const int q_start = P.ctx_off[lo], q_range = q_start + P.ctx_len[lo];
+    if (P.mode == GBN_EXT_SMALL) {
+        int ext_max = min(min(ext_to, s_off), q_off - q_start);
+        int rsdl = 4 - (s_off & 3);
+        int so = s_off + rsdl, qo = q_off + rsdl, ext_left = 0, ext_right = 0;
+        ext_max += rsdl;
+        while (ext_left < ext_max && (q[qo - ext_left - 1] & 3) == base_at(subj, so - ext_left - 1)) ext_left++;
+        ext_max = min(min(word - ext_left, slen - so), q_range - qo);
+        while (ext_right < ext_max && (q[qo + ext_right] & 3) == base_at(subj, so + ext_right)) ext_right++;
+        if (ext_left + ext_right < word) return -1;
+        return ext_left - rsdl;
+    }
+    // GBN_EXT_SMALL_ONEBYTE (s_BlastSmallNaExtendAlignedOneByte)
+    {
+        int ext_left = 0;
+        if (s_off > 0 && q_off > 0) {
+            int k = 0;
+            while (k < 4 && (q[q_off - k - 1] & 3) == base_at(subj, s_off - k - 1)) k++;
+            ext_left = min(min(k, ext_to), q_off - q_start);
+        }
+        if (ext_left < ext_to && (q_off + lut) < P.qlen) {
+            int k = 0, so = s_off + lut, qo = q_off + lut;
+            while (k < 4) {
+                int qb = (qo + k < P.qlen) ? (q[qo + k] & 3) : 0;
+                if (qb != base_at(subj, so + k)) break;
+                k++;
+            }
+            int ext_right = min(min(k, slen - so), q_range - qo);
+            if (ext_left + ext_right < ext_to) return -1;
+        }
+        return ext_left;
+    }
+}
+
+// fingerprint test: a seed that verifies must match the `fl` query bases left
+// of the lookup word or the `fr` bases right of it
+__device__ __forceinline__ bool fp_pass(uint32_t fp, uint32_t s_left16, uint32_t s_right16, int fl, int fr)
+{
+    // fp bits [30:15] = 8 bases left of the word (base q-1 in the low pair),
+    //    bits [14:1]  = 7 bases right of the word (base q+lut in the high pair)
+    if (fp & 1u) return true;                   // forced (see upload: one-byte quirk entries)
+    uint32_t ql = (fp >> 15) & 0xffffu;
+    uint32_t qr = (fp >> 1) & 0x3fffu;
+    uint32_t lmask = (fl >= 8) ? 0xffffu : ((1u << (2 * fl)) - 1);
+    bool left = fl > 0 ? (((ql ^ s_left16) & lmask) == 0) : true;
+    uint32_t sr = s_right16 >> 18;              // top 7 bases
+    uint32_t rmask = (fr >= 7) ? 0x3fffu : (((1u << (2 * fr)) - 1) << (2 * (7 - fr)));
+    bool right = fr > 0 ? (((qr ^ sr) & rmask) == 0) : true;
+    return left || right;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------------------
+// Scan + seed kernel.
+// One workgroup per tile of consecutive scan positions of one subject; lane t
+// takes positions t, t+256, ... so a wave touches one contiguous ~272-byte
+// span per load.  Positions whose lookup word is present (presence bit array,
+// L2 resident) are compacted into LDS with wave ballots; phase 2 walks the
+// compacted list with every lane busy.
+// ---------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(GBN_SCAN_THREADS)
+scan_seed_kernel(GbnScanParams P)
+{
+    __shared__ uint32_t s_cell[GBN_TILE_POS];
+    __shared__ int32_t  s_pos[GBN_TILE_POS];
+    __shared__ uint32_t s_count;
+    __shared__ unsigned long long s_raw_hits;
+
+    const int tid = threadIdx.x;
+    for (int64_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        const GbnTile T = P.tiles[tile];
+        const uint8_t *__restrict__ subj = P.db + P.byte_off[T.subj];
+        const int32_t slen = P.len[T.subj];
+        if (tid == 0) { s_count = 0; s_raw_hits = 0; }
+        __syncthreads();
+
+        // ---- phase 1: extract lookup words, presence test, ballot-compact ----
+        const uint32_t mask = (uint32_t)(P.ncells - 1);
+        const int shift = 32 - 2 * P.lut;
+        for (int i = tid; i < GBN_TILE_POS; i += GBN_SCAN_THREADS) {
+            bool present = false; uint32_t cell = 0; int32_t s = 0;
+            if (i < T.npos) {
+                s = T.first_pos + i * P.step;
+                cell = (window16(subj, s) >> shift) & mask;
+                present = (P.pv[cell >> 5] >> (cell & 31)) & 1u;
+            }
+            unsigned long long b = __ballot(present);
+            if (b) {
+                int lane = tid & 63;
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&s_count, (uint32_t)__popcll(b));
+                base = __shfl(base, 0);
+                if (present) {
+                    uint32_t slot = base + (uint32_t)__popcll(b & ((1ull << lane) - 1));
+                    s_cell[slot] = cell; s_pos[slot] = s;
+                }
+            }
+        }
+        __syncthreads();
+
+        // ---- phase 2: fingerprint filter, chain walk, exact verification ----
+        const uint32_t n = s_count;
+        unsigned long long raw = 0;
+        for (uint32_t j = tid; j < n; j += GBN_SCAN_THREADS) {
+            const uint32_t cell = s_cell[j];
+            const int32_t s = s_pos[j];
+            const uint32_t w = P.cellw[cell];
+            const uint32_t sl = window16(subj, (int64_t)s - 8) >> 16;          // bases s-8..s-1
+            const uint32_t sr = window16(subj, (int64_t)s + P.lut);            // bases s+lut..
+            // left fingerprint in fp has base q-1 in the LOW pair; sl has s-1 in the low pair too
+            const bool more = w >> 31;
+            uint32_t start = 0, end = 0; bool have_range = false;
+            if (fp_pass(w, sl, sr, P.fl, P.fr)) {
+                start = P.cell_start[cell]; end = P.cell_start[cell + 1]; have_range = true;
+                int32_t q = (int32_t)(P.ent[start] & 0xffffffffu);
+                int el = verify_hit(P, subj, slen, q, s);
+                if (el >= 0) {
+                    unsigned long long o = atomicAdd(P.seed_count, 1ull);
+                    if (o < P.seed_cap) { GbnDevSeed sd; sd.subj = T.subj; sd.s_scan = s; sd.q_pos = q; sd.ext_left = el; P.seeds[o] = sd; }
+                }
+            }
+            if (more) {
+                if (!have_range) { start = P.cell_start[cell]; end = P.cell_start[cell + 1]; }
+                raw += end - start;
+                for (uint32_t e = start + 1; e < end; e++) {
+                    unsigned long long ent = P.ent[e];
+                    if (!fp_pass((uint32_t)(ent >> 32), sl, sr, P.fl, P.fr)) continue;
+                    int32_t q = (int32_t)(ent & 0xffffffffu);
+                    int el = verify_hit(P, subj, slen, q, s);
+                    if (el >= 0) {
+                        unsigned long long o = atomicAdd(P.seed_count, 1ull);
+                        if (o < P.seed_cap) { GbnDevSeed sd; sd.subj = T.subj; sd.s_scan = s; sd.q_pos = q; sd.ext_left = el; P.seeds[o] = sd; }
+                    }
+                }
+            } else {
+                raw += 1;
+            }
+        }
+        if (P.raw_hits) {
+            // lookup_hits diagnostic: one atomic per wave
+            for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
+            if ((tid & 63) == 0 && raw) atomicAdd(&s_raw_hits, raw);
+            __syncthreads();
+            if (tid == 0 && s_raw_hits) atomicAdd(P.raw_hits, s_raw_hits);
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------
+// seed keys for the two stable radix sorts done by the host with hipCUB
+// ---------------------------------------------------------------------------
+extern "C" __global__ void seed_keys_kernel(GbnKeyParams K)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K.n) return;
+    GbnDevSeed sd = K.seeds[i];
+    uint32_t qkey = K.q_descending ? (0xffffffffu - (uint32_t)sd.q_pos) : (uint32_t)sd.q_pos;
+    K.key_scan[i] = ((uint64_t)(uint32_t)sd.s_scan << 32) | qkey;
+    K.idx[i] = (uint32_t)i;
+}
+
+extern "C" __global__ void group_keys_kernel(GbnKeyParams K)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K.n) return;
+    GbnDevSeed sd = K.seeds[K.idx[i]];
+    int32_t q = sd.q_pos - sd.ext_left, s = sd.s_scan - sd.ext_left;
+    uint32_t grp = K.container_hash ? ((uint32_t)(s - q) & 511u)
+                                    : ((uint32_t)(s + K.diag_len - q) & (uint32_t)(K.diag_len - 1));
+    K.key_group[i] = ((uint64_t)(uint32_t)sd.subj << 32) | grp;
+}
+
+// ---------------------------------------------------------------------------
+// ungapped extension (device)
+// ---------------------------------------------------------------------------
+namespace {
+struct Ungapped { int32_t q_start, s_start, length, score; };
+
+__device__ void ungapped_exact(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
+                               int32_t q_off, int32_t s_off, int32_t X, Ungapped &u)
+{
+    const uint8_t *q = P.q8;
+    int32_t sum = 0, score = 0, q_beg = q_off, q_end = q_off;
+    const int32_t nleft = min(q_off, s_off);
+    const int32_t nright = min(P.qlen - q_off, slen - s_off);
+    for (int32_t i = 1; i <= nleft; i++) {
+        int32_t qi = q_off - i;
+        sum += P.matrix[q[qi] * 16 + base_at(subj, s_off - i)];
+        if (sum > 0) { q_beg = qi; score += sum; sum = 0; }
+        else if (sum < X) break;
+    }
+    u.q_start = q_beg; u.s_start = s_off - (q_off - q_beg);
+    sum = 0;
+    for (int32_t i = 0; i < nright; i++) {
+        int32_t qi = q_off + i;
+        sum += P.matrix[q[qi] * 16 + base_at(subj, s_off + i)];
+        if (sum > 0) { q_end = qi + 1; score += sum; sum = 0; }
+        else if (sum < X) break;
+    }
+    u.length = q_end - q_beg; u.score = score;
+}
+
+__device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
+                                int32_t q_off, int32_t s_match_end, int32_t s_off, int32_t X,
+                                int32_t reduced_cutoff, Ungapped &u)
+{
+    const uint8_t *qs = P.q8;
+    int32_t len = (4 - (s_off & 3)) & 3;
+    const int32_t q_ext = q_off + len, s_ext = s_off + len;
+    int32_t qi = q_ext, sb = s_ext >> 2;
+    len = min(q_ext, s_ext) >> 2;
+    int32_t score = 0, sum = 0, new_q = q_ext;
+    for (int32_t i = 0; i < len; sb--, qi -= 4, i++) {
+        uint8_t s_byte = subj[sb - 1];
+        uint8_t q_byte = (uint8_t)((qs[qi - 4] << 6) | (qs[qi - 3] << 4) | (qs[qi - 2] << 2) | qs[qi - 1]);
+        sum += P.score_table[q_byte ^ s_byte];
+        if (sum > 0) { new_q = qi - 4; score += sum; sum = 0; }
+        if (sum < X) break;
+    }
+    u.q_start = new_q;
+    u.s_start = s_ext - (q_ext - u.q_start);
+    qi = q_ext; sb = s_ext >> 2;
+    len = min(P.qlen - q_ext, slen - s_ext) >> 2;
+    sum = 0; new_q = q_ext;
+    for (int32_t i = 0; i < len; sb++, qi += 4, i++) {
+        uint8_t s_byte = subj[sb];
+        uint8_t q_byte = (uint8_t)((qs[qi] << 6) | (qs[qi + 1] << 4) | (qs[qi + 2] << 2) | qs[qi + 3]);
+        sum += P.score_table[q_byte ^ s_byte];
+        if (sum > 0) { new_q = qi + 3; score += sum; sum = 0; }
+        if (sum < X) break;
+    }
+    if (score >= reduced_cutoff) {
+        ungapped_exact(P, subj, slen, q_off, s_off, X, u);
+    } else {
+        u.score = score;
+        u.length = max(s_match_end - u.s_start, new_q - u.q_start + 1);
+    }
+}
+}  // namespace
+
+// One thread per (subject, diagonal-slot) run of seeds; the run is replayed in
+// scan order because the one-hit filter is a sequential state machine
+// (CORE/na_ungapped.c:652,748 / :818,917).  The hash container is emulated
+// exactly per subject: cells live in a scratch slice as long as the run.
+extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const uint64_t key = P.key_group[i];
+    if (i > 0 && P.key_group[i - 1] == key) return;     // not the head of a run
+    const int32_t subj_id = (int32_t)(key >> 32);
+    const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
+    const int32_t slen = P.len[subj_id];
+    const int word = P.word;
+    int32_t last_hit = 0;           // array container: one slot per run
+    int64_t ncell = 0;              // hash container: cells [i, i+ncell)
+    for (int64_t j = i; j < P.n && P.key_group[j] == key; j++) {
+        GbnDevSeed sd = P.seeds[P.idx[j]];
+        const int32_t q_off = sd.q_pos - sd.ext_left, s_off = sd.s_scan - sd.ext_left;
+        const int32_t diag = s_off - q_off;
+        int32_t s_end_pos = s_off + word;
+        if (P.container_hash) {
+            last_hit = 0;
+            for (int64_t c = ncell - 1; c >= 0; c--)
+                if (P.cell_diag[i + c] == diag) { last_hit = P.cell_level[i + c]; break; }
+        }
+        if (s_off < last_hit) continue;
+        // strand of the seed
+        int lo = 0, hi = P.nctx;
+        while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > q_off) hi = m; else lo = m; }
+        const int32_t X = -P.ctx_xdrop[lo];
+        Ungapped u;
+        if (!P.container_hash && word < 11) ungapped_exact(P, subj, slen, q_off, s_off, X, u);
+        else ungapped_approx(P, subj, slen, q_off, s_off + word, s_off, X, P.ctx_reduced[lo], u);
+        if (u.score >= P.ctx_cutoff[lo]) {
+            unsigned long long o = atomicAdd(P.ihit_count, 1ull);
+            if (o < P.ihit_cap) {
+                GbnDevInitHit h; h.subj = subj_id; h.q_off = q_off; h.s_off = s_off;
+                h.q_start = u.q_start; h.s_start = u.s_start; h.length = u.length; h.score = u.score;
+                h.seq = (uint32_t)j;
+                P.ihits[o] = h;
+            }
+            s_end_pos = u.length + u.s_start;
+        }
+        if (P.container_hash) {
+            // s_BlastDiagHashInsert with window = 0 + MIN(0, -word) + 1
+            const int32_t win = min(0, -word) + 1;
+            bool placed = false;
+            for (int64_t c = ncell - 1; c >= 0; c--) {
+                if (P.cell_diag[i + c] == diag) { P.cell_level[i + c] = s_end_pos; placed = true; break; }
+                if (s_off - P.cell_level[i + c] > win) { P.cell_diag[i + c] = diag; P.cell_level[i + c] = s_end_pos; placed = true; break; }
+            }
+            if (!placed) { P.cell_diag[i + ncell] = diag; P.cell_level[i + ncell] = s_end_pos; ncell++; }
+        } else {
+            last_hit = s_end_pos;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------
+// gapped extensions, one thread per initial hit (score-only)
+// ---------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ int32_t match_run_fwd(const uint8_t *q, const uint8_t *subj, int32_t len1, int32_t len2,
+                                                 int32_t i1, int32_t i2, int32_t s_base)
+{
+    int32_t t = i1;
+    while (i1 < len1 && i2 < len2 && q[i1] == base_at(subj, (int64_t)s_base + i2)) { ++i1; ++i2; }
+    return i1 - t;
+}
+__device__ __forceinline__ int32_t match_run_rev(const uint8_t *q, const uint8_t *subj, int32_t len1, int32_t len2,
+                                                 int32_t i1, int32_t i2)
+{
+    int32_t t = i1;
+    while (i1 < len1 && i2 < len2 && q[len1 - 1 - i1] == base_at(subj, len2 - 1 - i2)) { ++i1; ++i2; }
+    return i1 - t;
+}
+
+struct GSeed { int32_t start_q, start_s, match_length; };
+
+// non-affine greedy (BLAST_GreedyAlign), score only
+__device__ int32_t greedy_linear(const uint8_t *q, int32_t len1, const uint8_t *subj, int32_t s_base, int32_t len2,
+                                 bool reverse, int32_t xdrop, int32_t match_cost, int32_t mismatch_cost,
+                                 int32_t *l1, int32_t *l2, GSeed &seed, int32_t *row0, int32_t *row1,
+                                 int32_t *max_score_base)
+{
+    const int32_t kInvalid = -2;
+    int32_t max_dist = min(10000, len2 / 2 + 1);
+    int32_t diag_origin = max_dist + 2;
+    int32_t xdrop_offset = (xdrop + match_cost / 2) / (match_cost + mismatch_cost) + 1;
+    int32_t index = reverse ? match_run_rev(q, subj, len1, len2, 0, 0) : match_run_fwd(q, subj, len1, len2, 0, 0, s_base);
+    *l1 = index; *l2 = index;
+    int32_t seq1_index = index, seq2_index, best_dist = 0, best_diag = 0;
+    seed.start_q = 0; seed.start_s = 0; seed.match_length = index;
+    int32_t longest = index;
+    if (index == len1 || index == len2) return 0;
+    int32_t *max_score = max_score_base + xdrop_offset;
+    for (int32_t t = 0; t < xdrop_offset; t++) max_score_base[t] = 0;
+    row0[diag_origin] = seq1_index;
+    max_score[0] = seq1_index * match_cost;
+    int32_t diag_lower = diag_origin - 1, diag_upper = diag_origin + 1;
+    bool end1 = false, end2 = false;
+    for (int32_t d = 1; d <= max_dist; d++) {
+        int32_t curr_extent = 0, curr_seq2 = 0, curr_diag = 0;
+        const int32_t tl = diag_lower, tu = diag_upper;
+        int32_t *prev = ((d - 1) & 1) ? row1 : row0, *cur = (d & 1) ? row1 : row0;
+        prev[diag_lower - 1] = kInvalid; prev[diag_lower] = kInvalid;
+        prev[diag_upper] = kInvalid; prev[diag_upper + 1] = kInvalid;
+        int32_t xs = max_score[d - xdrop_offset] + (match_cost + mismatch_cost) * d - xdrop;
+        xs = (int32_t)ceil((double)xs / (double)(match_cost / 2));
+        for (int32_t k = tl; k <= tu; k++) {
+            seq2_index = max(prev[k + 1], prev[k]) + 1;
+            seq2_index = max(seq2_index, prev[k - 1]);
+            seq1_index = seq2_index + k - diag_origin;
+            if (seq2_index < 0 || seq1_index + seq2_index < xs) {
+                if (k == diag_lower) diag_lower++; else cur[k] = kInvalid;
+                continue;
+            }
+            diag_upper = k;
+            index = reverse ? match_run_rev(q, subj, len1, len2, seq1_index, seq2_index)
+                            : match_run_fwd(q, subj, len1, len2, seq1_index, seq2_index, s_base);
+            if (index > longest) { seed.start_q = seq1_index; seed.start_s = seq2_index; seed.match_length = longest = index; }
+            seq1_index += index; seq2_index += index;
+            cur[k] = seq2_index;
+            if (seq1_index + seq2_index > curr_extent) { curr_extent = seq1_index + seq2_index; curr_seq2 = seq2_index; curr_diag = k; }
+            if (seq2_index == len2) { diag_lower = k + 1; end2 = true; }
+            if (seq1_index == len1) { diag_upper = k - 1; end1 = true; }
+        }
+        int32_t curr_score = curr_extent * (match_cost / 2) - d * (match_cost + mismatch_cost);
+        if (curr_score > max_score[d - 1]) {
+            max_score[d] = curr_score; best_dist = d; best_diag = curr_diag;
+            *l2 = curr_seq2; *l1 = curr_seq2 + best_diag - diag_origin;
+        } else max_score[d] = max_score[d - 1];
+        if (diag_lower > diag_upper) break;
+        if (!end2) diag_lower--;
+        if (!end1) diag_upper++;
+    }
+    return best_dist;
+}
+}  // namespace
+
+extern "C" __global__ void greedy_kernel(GbnGapParams P)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const GbnDevInitHit h = P.ihits[P.first + i];
+    const uint8_t *__restrict__ subj = P.db + P.byte_off[h.subj];
+    const int32_t slen = P.len[h.subj];
+    int lo = 0, hi = P.nctx;
+    while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > h.q_off) hi = m; else lo = m; }
+    const int32_t qstart = P.ctx_off[lo], qlen = P.ctx_len[lo];
+    const uint8_t *q = P.q8 + qstart;
+    const int32_t q_start_u = h.q_start - qstart;
+    // start in the middle of the ungapped HSP (CORE/blast_gapalign.c:3466-3471)
+    const int32_t q_off = q_start_u + h.length / 2, s_off = h.s_start + h.length / 2;
+    int32_t *scratch = P.scratch + (size_t)i * P.scratch_per_thread;
+    int32_t *row0 = scratch, *row1 = scratch + P.row_len, *msb = scratch + 2 * (size_t)P.row_len;
+    int32_t reward = P.reward, pen = -P.penalty, X = P.xdrop;
+    int32_t mc = reward, mm = pen;
+    if (mc % 2 == 1) { mc *= 2; mm *= 2; X *= 2; }
+    int32_t qr, sr, ql, sl; GSeed fwd, rev;
+    int32_t dist = greedy_linear(q + q_off, qlen - q_off, subj, s_off, slen - s_off, false, X, mc, mm, &qr, &sr, fwd, row0, row1, msb);
+    dist += greedy_linear(q, q_off, subj, 0, s_off, true, X, mc, mm, &ql, &sl, rev, row0, row1, msb);
+    int32_t score = (qr + sr + ql + sl) * reward / 2 - dist * (reward - P.penalty);
+    int32_t q_box_l = q_off - ql, s_box_l = s_off - sl, q_box_r = q_off + qr, s_box_r = s_off + sr;
+    int32_t qsl = q_off - rev.start_q, ssl = s_off - rev.start_s;
+    int32_t qsr = q_off + fwd.start_q, ssr = s_off + fwd.start_s;
+    int32_t vl = 0, vr = 0;
+    if (qsr < q_box_r && ssr < s_box_r) { vr = min(min(q_box_r - qsr, s_box_r - ssr), fwd.match_length) / 2; }
+    else { qsr = q_off; ssr = s_off; }
+    if (qsl > q_box_l && ssl > s_box_l) { vl = min(min(qsl - q_box_l, ssl - s_box_l), rev.match_length) / 2; }
+    else { qsl = q_off; ssl = s_off; }
+    GbnDevGapped g;
+    if (vr > vl) { g.seed_q = qsr + vr; g.seed_s = ssr + vr; } else { g.seed_q = qsl - vl; g.seed_s = ssl - vl; }
+    g.q_start = q_box_l; g.s_start = s_box_l; g.q_stop = q_box_r; g.s_stop = s_box_r;
+    g.score = score; g.context = lo;
+    P.out[P.first + i] = g;
+}
+
+namespace {
+struct GapDP { int32_t best, best_gap; };
+#define GBN_MININT (INT32_MIN / 2)
+
+// s_BlastAlignPackedNucl: forward reads query[q0+b] / subject[s0+a-1];
+// reverse reads query[N-1-b] / subject[M-a]
+__device__ int32_t align_packed(const GbnGapParams &P, const uint8_t *q, const uint8_t *subj,
+                                int32_t q0, int32_t s0, int32_t N, int32_t M, int32_t *b_off, int32_t *a_off,
+                                bool reverse, GapDP *sa, int32_t cap, int *overflow)
+{
+    const int32_t gap_open = P.gap_open, gap_extend = P.gap_extend, goe = gap_open + gap_extend;
+    int32_t x_dropoff = P.xdrop;
+    *a_off = 0; *b_off = 0;
+    if (x_dropoff < goe) x_dropoff = goe;
+    if (N <= 0 || M <= 0) return 0;
+    int32_t score = -goe, i;
+    sa[0].best = 0; sa[0].best_gap = -goe;
+    for (i = 1; i <= N; i++) {
+        if (score < -x_dropoff) break;
+        if (i >= cap) { *overflow = 1; return 0; }
+        sa[i].best = score; sa[i].best_gap = score - goe; score -= gap_extend;
+    }
+    int32_t b_size = i, best_score = 0, first_b = 0, last_b;
+    for (int32_t a = 1; a <= M; a++) {
+        const int ab = reverse ? base_at(subj, M - a) : base_at(subj, (int64_t)s0 + a - 1);
+        const int32_t *row = P.matrix + ab * 16;
+        int32_t sc = GBN_MININT, sgr = GBN_MININT;
+        last_b = first_b;
+        for (int32_t b = first_b; b < b_size; b++) {
+            const uint8_t bl = reverse ? q[N - 1 - b] : q[q0 + b];
+            int32_t sgc = sa[b].best_gap;
+            int32_t next = sa[b].best + row[bl];
+            if (sc < sgc) sc = sgc;
+            if (sc < sgr) sc = sgr;
+            if (best_score - sc > x_dropoff) {
+                if (b == first_b) first_b++; else sa[b].best = GBN_MININT;
+            } else {
+                last_b = b;
+                if (sc > best_score) { best_score = sc; *a_off = a; *b_off = b; }
+                sgr -= gap_extend; sgc -= gap_extend;
+                sa[b].best_gap = max(sc - goe, sgc);
+                sgr = max(sc - goe, sgr);
+                sa[b].best = sc;
+            }
+            sc = next;
+        }
+        if (first_b == b_size) break;
+        if (last_b < b_size - 1) {
+            b_size = last_b + 1;
+        } else {
+            while (sgr >= (best_score - x_dropoff) && b_size <= N) {
+                if (b_size >= cap) { *overflow = 1; return 0; }
+                sa[b_size].best = sgr; sa[b_size].best_gap = sgr - goe; sgr -= gap_extend; b_size++;
+            }
+        }
+        if (b_size <= N) {
+            if (b_size >= cap) { *overflow = 1; return 0; }
+            sa[b_size].best = GBN_MININT; sa[b_size].best_gap = GBN_MININT; b_size++;
+        }
+    }
+    return best_score;
+}
+}  // namespace
+
+extern "C" __global__ void dynprog_kernel(GbnGapParams P)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const GbnDevInitHit h = P.ihits[P.first + i];
+    const uint8_t *__restrict__ subj = P.db + P.byte_off[h.subj];
+    const int32_t slen = P.len[h.subj];
+    int lo = 0, hi = P.nctx;
+    while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > h.q_off) hi = m; else lo = m; }
+    const int32_t qstart = P.ctx_off[lo], qlen = P.ctx_len[lo];
+    const uint8_t *q = P.q8 + qstart;
+    int32_t q_off = h.q_off - qstart, s_off = h.s_off;
+    const int32_t s_end = h.s_start + h.length;
+    if (s_end >= s_off + 8) { s_off += 3; q_off += 3; }       // CORE/blast_gapalign.c:3494-3497
+    GapDP *sa = reinterpret_cast<GapDP *>(P.scratch + (size_t)i * P.scratch_per_thread);
+    const int32_t cap = P.scratch_per_thread / 2;
+    int overflow = 0;
+    int32_t adj = 4 - (s_off & 3);
+    int32_t q_length = q_off + adj, s_length = s_off + adj;
+    if (q_length > qlen || s_length > slen) { q_length -= 4; s_length -= 4; }
+    int32_t pq, ps;
+    GbnDevGapped g; g.context = lo; g.seed_q = q_off; g.seed_s = s_off;
+    int32_t left = align_packed(P, q, subj, 0, 0, q_length, s_length, &pq, &ps, true, sa, cap, &overflow);
+    g.q_start = q_length - pq; g.s_start = s_length - ps;
+    int32_t right = 0;
+    if (q_length < qlen && s_length < slen) {
+        right = align_packed(P, q, subj, q_length, s_length, qlen - q_length, slen - s_length, &pq, &ps, false, sa, cap, &overflow);
+        g.q_stop = pq + q_length; g.s_stop = ps + s_length;
+    } else { g.q_stop = q_length; g.s_stop = s_length; }
+    g.score = overflow ? INT32_MIN : left + right;
+    P.out[P.first + i] = g;
+}
+
+// ---------------------------------------------------------------------------
+// deterministic synthetic database bytes: xorshift64* streams, one per 4 KiB
+// ---------------------------------------------------------------------------
+extern "C" __global__ void synth_fill_kernel(uint64_t *out, int64_t nwords, uint64_t seed)
+{
+    int64_t chunk = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t w0 = chunk * 512;
+    if (w0 >= nwords) return;
+    uint64_t x = seed ^ (0x9E3779B97F4A7C15ull * (uint64_t)(chunk + 1));
+    // splitmix64 scramble so neighbouring chunks decorrelate
+    x ^= x >> 30; x *= 0xBF58476D1CE4E5B9ull; x ^= x >> 27; x *= 0x94D049BB133111EBull; x ^= x >> 31;
+    if (x == 0) x = 0x9E3779B97F4A7C15ull;
+    int64_t w1 = min(nwords, w0 + 512);
+    for (int64_t w = w0; w < w1; w++) {
+        x ^= x >> 12; x ^= x << 25; x ^= x >> 27;
+        out[w] = x * 0x2545F4914F6CDD1Dull;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// host launchers (thin; the C ABI in abi.cpp re-exports them)
+// ---------------------------------------------------------------------------
+#include <hipcub/hipcub.hpp>
+
+namespace gbn {
+
+hipError_t launch_scan_seed(const GbnScanParams &p, int grid, hipStream_t st)
+{
+    if (p.ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scan_seed_kernel, dim3(grid), dim3(GBN_SCAN_THREADS), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st)
+{
+    if (k.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_keys_kernel, dim3((unsigned)((k.n + 255) / 256)), dim3(256), 0, st, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st)
+{
+    if (k.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(group_keys_kernel, dim3((unsigned)((k.n + 255) / 256)), dim3(256), 0, st, k);
+    return hipGetLastError();
+}
+
+hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
+{
+    if (p.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
+{
+    if (p.n <= 0) return hipSuccess;
+    if (greedy) hipLaunchKernelGGL(greedy_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(dynprog_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
+    return hipGetLastError();
+}
+
+hipError_t launch_synth_fill(void *dev, int64_t nbytes, uint64_t seed, hipStream_t st)
+{
+    int64_t nwords = nbytes / 8;
+    int64_t chunks = (nwords + 511) / 512;
+    if (chunks <= 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st,
+                       (uint64_t *)dev, nwords, seed);
+    return hipGetLastError();
+}
+
+// stable LSD radix sort of (u64 key, u32 value) pairs
+hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
+                          const uint32_t *vin, uint32_t *vout, int64_t n, int end_bit, hipStream_t st)
+{
+    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)n, 0, end_bit, st);
+}
+
+}  // namespace gbn

@@ -1,0 +1,193 @@
+/* gblastn_amd.h -- C ABI of the MI355X-native blastn/megablast preliminary-search
+ * engine.  This is the drop-in boundary for the one hot path this project
+ * replaces: G-BLASTN's GPU preliminary search.
+ *
+ * Reference interface each entry point replaces (paths relative to
+ * /root/reference/c++):
+ *
+ *   Blast_gpu_Init / Blast_gpu_Release
+ *       include/algo/blast/gpu_blast/gpu_blastn.h:50-51
+ *       (defined src/algo/blast/gpu_blast/gpu_blast_multi_gpu_utils.cpp:176-183)
+ *   gpu_ReleaseDBMemory
+ *       include/algo/blast/gpu_blast/gpu_blastn_na_ungapped_v3.h:21
+ *   gbn_db_*            replaces gpu_InitDBMemroy + the per-OID cudaMalloc cache
+ *       src/algo/blast/gpu_blast/gpu_blastn_MB_and_smallNa.cu:140-146,1462-1468
+ *       (one contiguous HBM slab per volume instead of one allocation per OID)
+ *   gbn_batch_*         replaces LookupTableWrapInit + BLAST_MainSetUp products
+ *       that the reference passes INTO the boundary (query, query_info, sbp,
+ *       lookup_wrap) plus GpuLookUpSetUp / gpu_InitQueryMemory
+ *       src/algo/blast/gpu_blast/gpu_blastn_na_ungapped_v3.cpp:595-696
+ *   gbn_prelim_search   replaces Blast_gpu_RunPreliminarySearchWithInterrupt
+ *       include/algo/blast/gpu_blast/gpu_blastn.h:31-48
+ *       src/algo/blast/gpu_blast/gpu_blastn_pre_search_engine.cpp:1466-1563
+ *       Same contract: caller owns query/options/database; callee creates and
+ *       frees all search parameters; results are appended to a caller-owned
+ *       result list (the BlastHSPStream analogue); 0 = success, non-zero
+ *       status codes, GBN_ERR_INTERRUPTED on user interrupt; no exceptions.
+ *   gbn_launch_*        the finer-grained hooks G-BLASTN swaps in:
+ *       scansub_callback / extend_callback (TNaScanSubjectFunction,
+ *       include/algo/blast/core/blast_nascan.h:43; TNaExtendFunction,
+ *       include/algo/blast/core/na_ungapped.h:51), BlastWordFinderType
+ *       (include/algo/blast/core/blast_engine.h:227) and BlastGetGappedScoreType.
+ *       They take device pointers and a hipStream_t (passed as void*).
+ *
+ * All structs are plain old data; no torch / C++ types cross this boundary.
+ */
+#ifndef GBLASTN_AMD_H
+#define GBLASTN_AMD_H
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GBN_OK                 0
+#define GBN_ERR_ARG            1
+#define GBN_ERR_NO_DEVICE      2
+#define GBN_ERR_HIP            3
+#define GBN_ERR_UNSUPPORTED    4
+#define GBN_ERR_NOMEM          5
+#define GBN_ERR_INTERRUPTED    6   /* BLASTERR_INTERRUPTED analogue */
+#define GBN_ERR_SETUP          7   /* no valid Karlin-Altschul block etc. */
+
+/* lookup table kinds (ELookupTableType subset) */
+#define GBN_LUT_SMALL_NA 1
+#define GBN_LUT_NA       2
+#define GBN_LUT_MB       3
+
+/* ---- options: the blastn-relevant subset of BlastScoringOptions,
+ * LookupTableOptions, BlastInitialWordOptions, BlastExtensionOptions,
+ * BlastHitSavingOptions, BlastEffectiveLengthsOptions (COREI/blast_options.h) */
+typedef struct GbnOptions {
+    int32_t word_size;
+    int32_t reward, penalty;
+    int32_t gap_open, gap_extend;
+    int32_t greedy;                 /* 1 = eGreedyScoreOnly, 0 = eDynProgScoreOnly */
+    double  xdrop_ungap_bits;
+    double  gap_trigger_bits;
+    double  xdrop_gap_bits;
+    double  xdrop_gap_final_bits;
+    double  evalue;
+    int32_t min_diag_separation;
+    int32_t hitlist_size;
+    int32_t cutoff_score;
+    int32_t lut11_gblastn_rule;     /* CORE/blast_nalookup.c:127-144 vs stock NCBI */
+    int64_t db_length;              /* GLOBAL database length (all shards) */
+    int32_t db_num_seqs;            /* GLOBAL number of subjects; 0 = per-subject stats */
+} GbnOptions;
+
+void gbn_default_options(GbnOptions *opt, int megablast);
+
+/* per query strand ("context", BlastContextInfo, COREI/blast_query_info.h:46-59) */
+typedef struct GbnContext {
+    int32_t query_offset, query_length, frame, query_index, is_valid;
+    int32_t length_adjustment;
+    int64_t eff_searchsp;
+    double  lambda_u, K_u, logK_u, H_u;
+    int32_t x_dropoff, cutoff_score, reduced_cutoff;
+    int32_t gap_cutoff_score, gap_cutoff_score_max;
+} GbnContext;
+
+/* preliminary HSP (BlastHSP subset that the preliminary stage fills,
+ * COREI/blast_hits.h:93-126) */
+typedef struct GbnHSP {
+    int32_t oid;                    /* GLOBAL subject ordinal id */
+    int32_t context;
+    int32_t q_offset, q_end, q_gapped_start;    /* context-relative */
+    int32_t s_offset, s_end, s_gapped_start;
+    int32_t score;
+    int32_t pad_;
+    double  evalue;
+} GbnHSP;
+
+typedef struct GbnSeed { int32_t oid, s_off, q_off, pad_; } GbnSeed;
+typedef struct GbnInitHit {
+    int32_t oid, q_off, s_off, q_start, s_start, length, score, pad_;
+} GbnInitHit;
+
+/* BlastDiagnostics subset (COREI/blast_diagnostics.h) */
+typedef struct GbnDiagnostics {
+    int64_t lookup_hits;            /* raw table hits before mini-extension */
+    int64_t init_extends, good_init_extends;
+    int64_t gapped_extensions, good_extensions, seqs_passed;
+    int64_t seeds;                  /* after mini-extension */
+    double  scan_kernel_ms;         /* HIP-event time of the scan kernel(s) */
+    double  total_ms;               /* wall time of the whole call */
+    int64_t scan_launches;
+    int64_t subject_bases_scanned;
+} GbnDiagnostics;
+
+typedef int (*GbnInterruptFn)(void *progress);   /* TInterruptFnPtr analogue */
+
+/* ---- process-level ---- */
+int  Blast_gpu_Init(int use_gpu, int gpu_id);
+void Blast_gpu_Release(void);
+void gpu_ReleaseDBMemory(void);
+
+/* ---- database shard resident in HBM ---- */
+typedef struct GbnDb GbnDb;
+/* `packed` holds the NCBI2na data of all subjects back to back: subject i
+ * occupies bytes [byte_off[i], byte_off[i] + ceil(len[i]/4)).  byte_off must be
+ * 16-byte aligned per subject and the buffer must extend 64 bytes past the
+ * last subject.  is_device != 0: `packed` is already a device pointer (e.g.
+ * a torch tensor) that stays owned by the caller. */
+int  gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_seqs,
+                const int64_t *byte_off, const int32_t *len, int32_t first_oid,
+                int is_device);
+void gbn_db_free(GbnDb *db);
+int64_t gbn_db_total_bases(const GbnDb *db);
+int32_t gbn_db_num_seqs(const GbnDb *db);
+/* deterministic synthetic DB bytes generated on the device (bench/tests) */
+int  gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream);
+
+/* ---- query batch: host set-up + upload of lookup structures ---- */
+typedef struct GbnBatch GbnBatch;
+/* seqs[i]: BLASTNA codes (0..15), plus strand, lens[i] bases */
+int  gbn_batch_new(GbnBatch **out, const GbnOptions *opt, int32_t nq,
+                   const uint8_t *const *seqs, const int32_t *lens);
+/* upload == 0 builds the host-side set-up only (no device needed) */
+int  gbn_batch_new_ex(GbnBatch **out, const GbnOptions *opt, int32_t nq,
+                      const uint8_t *const *seqs, const int32_t *lens, int upload);
+void gbn_batch_free(GbnBatch *b);
+int32_t gbn_batch_num_contexts(const GbnBatch *b);
+const GbnContext *gbn_batch_contexts(const GbnBatch *b);
+int32_t gbn_batch_lut_type(const GbnBatch *b);
+int32_t gbn_batch_lut_width(const GbnBatch *b);
+int32_t gbn_batch_scan_step(const GbnBatch *b);
+int32_t gbn_batch_diag_container(const GbnBatch *b);    /* 0 array, 1 hash */
+int32_t gbn_batch_gap_x_dropoff(const GbnBatch *b);
+
+/* ---- result list (the HSP stream analogue): caller-owned, callee-filled ---- */
+typedef struct GbnResults GbnResults;
+int  gbn_results_new(GbnResults **out);
+void gbn_results_free(GbnResults *r);
+void gbn_results_clear(GbnResults *r);
+int64_t gbn_results_num_hsps(const GbnResults *r);
+const GbnHSP *gbn_results_hsps(const GbnResults *r);     /* grouped by oid ascending */
+int64_t gbn_results_num_seeds(const GbnResults *r);
+const GbnSeed *gbn_results_seeds(const GbnResults *r);   /* only if keep_stages */
+int64_t gbn_results_num_init_hits(const GbnResults *r);
+const GbnInitHit *gbn_results_init_hits(const GbnResults *r);
+
+/* ---- the preliminary search over one resident shard ---- */
+int  gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results,
+                       GbnDiagnostics *diag, int keep_stages,
+                       GbnInterruptFn interrupt, void *progress);
+/* scan stage only (bench / roofline): runs the scan+seed kernel over the
+ * whole shard `repeats` times and reports the HIP-event time per launch */
+int  gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag);
+
+/* ---- thin kernel launchers: device pointers in the parameter blocks of
+ * gblastn_amd_kernels.h, hipStream_t passed as void* ---- */
+struct GbnScanParams; struct GbnExtParams; struct GbnGapParams;
+int  gbn_launch_scan_seed(const struct GbnScanParams *p, int grid, void *stream);
+int  gbn_launch_ungapped(const struct GbnExtParams *p, void *stream);
+int  gbn_launch_gapped(const struct GbnGapParams *p, int greedy, void *stream);
+
+const char *gbn_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
