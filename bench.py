@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""bench.py -- subject Gbp scanned per second of the megablast preliminary search.
+
+Workload (BASELINE.json configs[1], "C2"): 10,000 x 1 kb synthetic queries vs a
+50 Gbp synthetic 2-bit database (50,000 subjects x 1 Mb, 12.5 GB packed) on ONE
+MI355X, megablast word_size 28.  The reference batch plan applies: 5 Mb query
+batches (5,000 queries, 10 M lookup words -> megablast table lut 12, stride 17),
+so the config is 2 passes over the database.
+
+A "step" = one pass of the whole preliminary path (scan+seed, diagonal filter,
+ungapped X-drop, greedy gapped, HSP rules) of ONE query batch over the rank's
+resident shard.  Lookup structures of both batches and the database are
+resident in HBM before the timed region (the reference's boundary receives
+them ready-made too).  value = (bases of all shards x K passes) / max-over-ranks
+wall time.  With N > 1 every rank holds its own 50 Gbp shard (weak scaling, the
+C5 layout: volumes sharded by rank, global statistics) and rank 0 gathers the
+per-shard HSP records over RCCL after every pass, inside the timed region.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=4)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--subjects", type=int, default=50_000, help="subjects per GPU shard")
+    ap.add_argument("--subject-len", type=int, default=1_000_000)
+    ap.add_argument("--queries", type=int, default=10_000)
+    ap.add_argument("--batch-queries", type=int, default=5_000)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from gblastn_amd import api, synth, shard
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    rc = api.lib().Blast_gpu_Init(1, local_rank)
+    if rc:
+        raise SystemExit("Blast_gpu_Init failed: %s" % api.lib().gbn_last_error().decode())
+
+    # ---- database shard of this rank, generated in HBM ----
+    nsub, slen = args.subjects, args.subject_len
+    layouts = [synth.SynthDb(nsub, slen, seed=0x9E3779B97F4A7C15 ^ (r + 1), first_oid=r * nsub)
+               for r in range(world)]
+    mine = layouts[rank]
+    slab = torch.empty(mine.nbytes, dtype=torch.uint8, device=dev)
+    api._check(api.lib().gbn_synth_fill(slab.data_ptr(), mine.nbytes, mine.seed, None))
+    src = api.BlastSeqSrc.from_slab((slab.data_ptr(), mine.nbytes), mine.byte_off, mine.lens,
+                                    first_oid=mine.first_oid, is_device=True, keep=slab)
+    total_bases_global = world * nsub * slen
+
+    # ---- queries: replicated; planted homologs come from any shard ----
+    class AnyShard:
+        num, length, first_oid = world * nsub, slen, 0
+        _cache = {}
+
+        def subject_bases(self, g):
+            if g not in self._cache:
+                if len(self._cache) > 64:
+                    self._cache.clear()
+                self._cache[g] = layouts[g // nsub].subject_bases(g % nsub)
+            return self._cache[g]
+    queries, plants = synth.make_queries(args.queries, AnyShard())
+    opt = api.default_options("megablast", db_length=total_bases_global, db_num_seqs=world * nsub)
+    nbatch = (len(queries) + args.batch_queries - 1) // args.batch_queries
+    batches = [api.BlastPrelimSearch(queries[i * args.batch_queries:(i + 1) * args.batch_queries], opt, src)
+               for i in range(nbatch)]
+    info = batches[0].info()
+
+    def one_pass(step):
+        b = batches[step % nbatch]
+        out = b.run()
+        hs = shard.gather_records(out["hsps"], dst=0, device=dev)
+        return b, hs
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for w in range(args.warmup):
+        one_pass(w)
+    sync()
+    for b in batches:
+        b.diagnostics = api.GbnDiagnostics()
+    t0 = time.perf_counter()
+    nhsp = 0
+    for k in range(args.steps):
+        b, hs = one_pass(k)
+        if hs is not None:
+            nhsp += len(hs)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- roofline of the dominant kernel (scan+seed), from HIP events in the library ----
+    scan_ms = sum(b.diagnostics.scan_kernel_ms for b in batches)
+    launches = sum(b.diagnostics.scan_launches for b in batches)
+    scanned = sum(b.diagnostics.subject_bases_scanned for b in batches)
+    seeds = sum(b.diagnostics.seeds for b in batches)
+    lookup_hits = sum(b.diagnostics.lookup_hits for b in batches)
+    algo_bytes = 0.25 * scanned
+    achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "scan_traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline and args.cpu_seconds > 0:
+        cpu = cpu_baseline(args, queries[:args.batch_queries], opt, mine)
+
+    if rank == 0:
+        value = total_bases_global * args.steps / elapsed / 1e9
+        line = {
+            "metric": "subject Gbp scanned/sec (megablast preliminary search, DB bases x passes / wall)",
+            "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (2-bit packed bases, int32 scores)", "data": "synthetic",
+            "config": {
+                "workload": "C2: %d x 1 kb queries vs %.1f Gbp synthetic 2-bit DB per GPU, megablast W=28"
+                            % (len(queries), nsub * slen / 1e9),
+                "batch_plan": {"queries_per_batch": args.batch_queries, "passes_per_config": nbatch,
+                               "lut": info["lut_width"], "scan_step": info["scan_step"],
+                               "lut_type": info["lut_type"], "diag_container": info["container"]},
+                "subjects_per_gpu": nsub, "subject_len": slen,
+                "parallelism": "db-shard x%d (volumes by rank, RCCL gather of HSP records)" % world,
+                "hsps_per_pass": nhsp / max(args.steps, 1),
+                "seeds_per_pass": seeds / max(launches, 1),
+                "lookup_hits_per_pass": lookup_hits / max(launches, 1),
+            },
+            "roofline": {"bound": "hbm", "kernel": "scan_seed_kernel",
+                         "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
+                         "avg_launch_ms": scan_ms / max(launches, 1), "launches": launches},
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(args, batch_queries, gopt, layout):
+    """The oracle (a scalar C port of the reference algorithm) on this box's host cores,
+    one thread, same batch, a bounded sample of the same shard's subjects."""
+    from oracle import orc
+    from tests import util
+    s = orc.Search(util.oracle_options(gopt), batch_queries)
+    done, t = 0, 0.0
+    i = 0
+    while t < args.cpu_seconds and i < layout.num:
+        packed = layout.subject_packed(i)
+        t0 = time.perf_counter()
+        s.subject(packed, layout.length)
+        t += time.perf_counter() - t0
+        done += layout.length
+        i += 1
+    return {"value": done / t / 1e9 if t > 0 else 0.0, "unit": "Gbp/s", "cores": 1, "kind": "port",
+            "sample": "first %d subjects (%.0f Mbp) of the rank-0 shard, one 5 Mb query batch, %.1f s"
+                      % (i, done / 1e6, t)}
+
+
+if __name__ == "__main__":
+    main()

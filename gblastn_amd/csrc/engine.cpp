@@ -16,6 +16,8 @@
 #include <cstring>
 #include <map>
 #include <mutex>
+#include <tuple>
+#include <cstdlib>
 
 namespace gbn {
 hipError_t launch_scan_seed(const GbnScanParams &p, int grid, hipStream_t st);
@@ -162,7 +164,11 @@ int upload_batch(GbnBatch &b) {
 // ---------------------------------------------------------------------------
 struct TileSet { GbnTile *d_tiles = nullptr; int64_t ntiles = 0; std::vector<int64_t> first_tile_of_subj; int64_t bases = 0; };
 
-static int build_tiles(const GbnDb &db, int lut, int step, int32_t s0, int32_t s1, TileSet &ts) {
+struct TileKey { int lut, step; int32_t s0, s1; bool operator<(const TileKey &o) const {
+    return std::tie(lut, step, s0, s1) < std::tie(o.lut, o.step, o.s0, o.s1); } };
+typedef std::map<TileKey, TileSet> TileCache;
+
+static int build_tiles_uncached(const GbnDb &db, int lut, int step, int32_t s0, int32_t s1, TileSet &ts) {
     std::vector<GbnTile> tiles;
     ts.first_tile_of_subj.clear(); ts.bases = 0;
     for (int32_t s = s0; s < s1; s++) {
@@ -179,6 +185,28 @@ static int build_tiles(const GbnDb &db, int lut, int step, int32_t s0, int32_t s
     ts.first_tile_of_subj.push_back((int64_t)tiles.size());
     ts.ntiles = (int64_t)tiles.size();
     return dev_upload(ts.d_tiles, tiles.data(), tiles.size());
+}
+
+// tile tables depend only on (lut, step, subject range): cached on the shard
+static int get_tiles(GbnDb &db, int lut, int step, int32_t s0, int32_t s1, const TileSet **out) {
+    if (!db.tile_cache) db.tile_cache = new TileCache();
+    TileCache &tc = *static_cast<TileCache *>(db.tile_cache);
+    TileKey k{lut, step, s0, s1};
+    auto it = tc.find(k);
+    if (it == tc.end()) {
+        TileSet ts;
+        int rc = build_tiles_uncached(db, lut, step, s0, s1, ts);
+        if (rc) return rc;
+        it = tc.emplace(k, std::move(ts)).first;
+    }
+    *out = &it->second;
+    return GBN_OK;
+}
+static void free_tile_cache(GbnDb &db) {
+    if (!db.tile_cache) return;
+    TileCache *tc = static_cast<TileCache *>(db.tile_cache);
+    for (auto &kv : *tc) dev_free(kv.second.d_tiles);
+    delete tc; db.tile_cache = nullptr;
 }
 
 static int grow_seed_buffers(size_t want) {
@@ -236,10 +264,10 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
                         GbnDiagnostics *diag, int keep_stages)
 {
     const DeviceBatch *d = b.dev;
-    TileSet ts;
-    int rc = build_tiles(db, b.lut.lut, b.lut.step, s0, s1, ts);
+    const TileSet *tsp = nullptr;
+    int rc = get_tiles(db, b.lut.lut, b.lut.step, s0, s1, &tsp);
     if (rc) return rc;
-    struct Free { TileSet &t; ~Free() { dev_free(t.d_tiles); } } fr{ts};
+    const TileSet &ts = *tsp;
     if (ts.ntiles == 0) return GBN_OK;
     if ((rc = grow_seed_buffers(std::max<size_t>(E.seed_cap, (size_t)1 << 22)))) return rc;
 
@@ -473,6 +501,7 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
 
 void gbn_db_free(GbnDb *db) {
     if (!db) return;
+    free_tile_cache(*db);
     if (db->owns && db->d_packed) (void)hipFree((void *)db->d_packed);
     dev_free(db->d_byte_off); dev_free(db->d_len);
     delete db;
@@ -555,7 +584,9 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
         }
     } else {
         // ranges of subjects bounded by packed size so that scratch stays modest
-        const int64_t range_bytes = (int64_t)4 << 30;
+        int64_t range_gib = 16;
+        if (const char *e = getenv("GBN_RANGE_GIB")) range_gib = std::max(1, atoi(e));
+        const int64_t range_bytes = range_gib << 30;
         int32_t s0 = 0;
         while (s0 < db->num_seqs) {
             int32_t s1 = s0; int64_t acc = 0;
@@ -574,9 +605,9 @@ int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag)
     int rc = ensure_init();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(E.mu);
-    TileSet ts;
-    if ((rc = build_tiles(*db, batch->lut.lut, batch->lut.step, 0, db->num_seqs, ts))) return rc;
-    struct Free { TileSet &t; ~Free() { dev_free(t.d_tiles); } } fr{ts};
+    const TileSet *tsp = nullptr;
+    if ((rc = get_tiles(*db, batch->lut.lut, batch->lut.step, 0, db->num_seqs, &tsp))) return rc;
+    const TileSet &ts = *tsp;
     if ((rc = grow_seed_buffers(std::max<size_t>(E.seed_cap, (size_t)1 << 22)))) return rc;
     auto t0 = std::chrono::steady_clock::now();
     for (int r = 0; r < repeats; r++) {

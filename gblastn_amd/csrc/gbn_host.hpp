@@ -71,6 +71,7 @@ struct GbnDb {
     int64_t total_bases = 0;
     int64_t *d_byte_off = nullptr;
     int32_t *d_len = nullptr;
+    void *tile_cache = nullptr;         // engine-private (tile tables per lut/step)
 };
 
 struct GbnResults {
