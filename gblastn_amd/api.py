@@ -86,6 +86,8 @@ def lib():
         L.gbn_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
         L.gbn_batch_new.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GbnOptions), C.c_int32,
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+        L.gbn_batch_new_ex.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GbnOptions), C.c_int32,
+                                       C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int]
         L.gbn_batch_free.argtypes = [C.c_void_p]
         for nm in ["gbn_batch_num_contexts", "gbn_batch_lut_type", "gbn_batch_lut_width",
                    "gbn_batch_scan_step", "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff"]:
@@ -189,14 +191,16 @@ class BlastSeqSrc:
 class BlastPrelimSearch:
     """CBlastPrelimSearch analogue: one query batch against one resident shard."""
 
-    def __init__(self, queries, options, seqsrc=None):
+    def __init__(self, queries, options, seqsrc=None, upload=True):
+        """upload=False builds the host-side set-up only (no device needed)."""
         L = lib()
         self._q = [np.ascontiguousarray(q, dtype=np.uint8) for q in queries]
         ptrs = (C.c_void_p * len(self._q))(*[q.ctypes.data for q in self._q])
         lens = (C.c_int32 * len(self._q))(*[len(q) for q in self._q])
         self.options = options
         self._b = C.c_void_p()
-        _check(L.gbn_batch_new(C.byref(self._b), C.byref(options), len(self._q), ptrs, lens))
+        _check(L.gbn_batch_new_ex(C.byref(self._b), C.byref(options), len(self._q), ptrs, lens,
+                                  1 if upload else 0))
         self._r = C.c_void_p()
         _check(L.gbn_results_new(C.byref(self._r)))
         self.seqsrc = seqsrc

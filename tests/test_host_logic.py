@@ -1,0 +1,91 @@
+"""CPU: the product's host set-up (C++: Karlin-Altschul blocks, cut-offs, effective
+lengths, lookup-table choice) against the oracle, and C-ABI load/export checks.
+No compute calls -- there is no GPU here."""
+import ctypes as C
+import os
+import re
+import numpy as np
+import pytest
+from gblastn_amd import api
+from oracle import orc
+from tests import util
+
+CTX_INT = ["query_offset", "query_length", "frame", "query_index", "is_valid", "length_adjustment",
+           "eff_searchsp", "x_dropoff", "cutoff_score", "reduced_cutoff", "gap_cutoff_score",
+           "gap_cutoff_score_max"]
+CTX_F64 = ["lambda_u", "K_u", "logK_u", "H_u"]
+
+
+def bits(x):
+    return np.float64(x).view(np.uint64)
+
+
+@pytest.mark.parametrize("task,nq,qlen,dbl,dbn", [
+    ("megablast", 1, 1000, 10_000_000, 10),
+    ("megablast", 40, 1000, 50_000_000_000, 50_000),
+    ("megablast", 400, 1000, 400_000_000_000, 400_000),
+    ("blastn", 3, 700, 5_000_000_000, 5_000),
+    ("blastn", 30, 1000, 5_000_000_000, 5_000),
+])
+def test_setup_matches_oracle(task, nq, qlen, dbl, dbn):
+    rng = np.random.default_rng(nq * 7 + qlen)
+    qs = [rng.integers(0, 4, qlen, dtype=np.uint8) for _ in range(nq)]
+    qs[0][5] = 14                       # an N: not counted in the composition, never indexed
+    gopt = api.default_options(task, db_length=dbl, db_num_seqs=dbn)
+    b = api.BlastPrelimSearch(qs, gopt, upload=False)
+    s = orc.Search(util.oracle_options(gopt), qs)
+    gi, oi = b.info(), s.info()
+    for k in ["lut_type", "lut_width", "scan_step", "container", "gap_x_dropoff"]:
+        assert gi[k] == oi[k], k
+    gc, oc = b.contexts, s.contexts
+    assert len(gc) == len(oc) == 2 * nq
+    for g, o in zip(gc, oc):
+        for f in CTX_INT:
+            assert getattr(g, f) == getattr(o, f), f
+        for f in CTX_F64:
+            assert bits(getattr(g, f)) == bits(getattr(o, f)), f       # bit-identical doubles
+
+
+def test_unsupported_options_are_errors_not_fallbacks():
+    q = [np.zeros(100, dtype=np.uint8)]
+    with pytest.raises(api.BlastError):
+        api.BlastPrelimSearch(q, api.default_options("megablast", reward=2, penalty=-1), upload=False)
+    with pytest.raises(api.BlastError):     # affine greedy is not implemented: loud, not silent
+        api.BlastPrelimSearch([np.arange(100, dtype=np.uint8) % 4],
+                              api.default_options("megablast", gap_open=2, gap_extend=2), upload=False)
+
+
+def test_c_abi_exports_every_declared_symbol():
+    L = api.lib()
+    hdr = open(os.path.join(os.path.dirname(api._HERE), "include", "gblastn_amd.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    declared = set(re.findall(r"\b((?:gbn_|Blast_gpu_|gpu_Release)\w*)\s*\(", hdr))
+    assert len(declared) > 30
+    for name in sorted(declared):
+        assert hasattr(L, name), "declared in include/gblastn_amd.h but not exported: " + name
+    for name in api.EXPORTS:
+        assert name in declared, "exported but undeclared: " + name
+
+
+def test_no_gpu_is_reported_not_emulated():
+    # on a box without a HIP device the engine must fail loudly; there is no CPU path
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    L = api.lib()
+    assert L.Blast_gpu_Init(1, -1) != 0
+    assert b"HIP device" in L.gbn_last_error()
+    assert L.Blast_gpu_Init(0, -1) != 0          # use_gpu = false is refused as well
+    with pytest.raises(api.BlastError):
+        api.BlastPrelimSearch([np.zeros(64, dtype=np.uint8)], api.default_options("megablast"))
+
+
+def test_product_never_imports_oracle():
+    root = os.path.dirname(api._HERE)
+    for dirpath, _, files in os.walk(os.path.join(root, "gblastn_amd")):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hpp", ".h", ".hip")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for pat in [r"^\s*import\s+oracle", r"^\s*from\s+oracle\b", r"import\s+orc\b",
+                            r"#include\s*[\"<].*orc(_int)?\.h", r"liborc"]:
+                    assert not re.search(pat, txt, flags=re.M), (f, pat)

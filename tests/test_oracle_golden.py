@@ -1,0 +1,196 @@
+"""CPU: the oracle against every known-answer the reference's own unit tests hold for
+this path and that is reproducible offline."""
+import ctypes as C
+import math
+import os
+import numpy as np
+from oracle import orc
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_prelimsearch_BuildCStd_seg_blastn():
+    # UT/prelimsearch_unit_test.cpp:169-203 -- query = bases 54..560 of gi|41646578,
+    # megablast prelim vs data/nt.41646578: first segment q 0..506 <-> s 54..560, plus/plus
+    db = orc.read_blastdb_v4_nucl(os.path.join(G, "nt.41646578"))
+    assert len(db) == 1 and db[0][1] == 3300
+    packed, n = db[0]
+    q = orc.unpack_ncbi2na(packed, n)[54:561].copy()
+    s = orc.Search(orc.default_options(True, db_length=n, db_num_seqs=1), [q])
+    r = s.subject(packed, n)
+    h = r["hsps"]
+    assert len(h) >= 1
+    assert h[0]["context"] == 0                       # plus strand
+    assert (h[0]["q_offset"], h[0]["q_end"] - 1) == (0, 506)
+    assert (h[0]["s_offset"], h[0]["s_end"] - 1) == (54, 560)
+    assert h[0]["score"] == 507
+    info = s.info()
+    assert (info["lut_type"], info["lut_width"], info["scan_step"]) == (1, 8, 21)
+
+
+def _greedy_pair():
+    a = orc.encode_blastna(orc.read_fasta(os.path.join(G, "greedy1a.fsa"))[0])
+    b = orc.encode_blastna(orc.read_fasta(os.path.join(G, "greedy1b.fsa"))[0])
+    return a, b
+
+
+def test_bl2seq_MegablastGreedyTraceback2_score_619():
+    # UT/bl2seq_unit_test.cpp:1620-1672: megablast defaults, gap 0/0, no DUST -> one
+    # alignment, score 619 (bl2seq => per-subject statistics, db_num_seqs = 0)
+    a, b = _greedy_pair()
+    s = orc.Search(orc.default_options(True), [a])
+    r = s.subject(orc.pack_ncbi2na(b), len(b))
+    assert len(r["hsps"]) == 1
+    h = r["hsps"][0]
+    assert h["score"] == 619
+    assert (h["q_offset"], h["q_end"], h["s_offset"], h["s_end"]) == (159, 874, 30, 739)
+
+
+def test_bl2seq_MegablastGreedyTraceback2_score_6034():
+    # UT/bl2seq_unit_test.cpp:1674-1690: reward 10, penalty -25, X-drop 100/100 -> 6034
+    a, b = _greedy_pair()
+    opt = orc.default_options(True, reward=10, penalty=-25, xdrop_gap_bits=100.0,
+                              xdrop_gap_final_bits=100.0)
+    s = orc.Search(opt, [a])
+    r = s.subject(orc.pack_ncbi2na(b), len(b))
+    assert len(r["hsps"]) == 1 and r["hsps"][0]["score"] == 6034
+
+
+def _karlin():
+    return orc.OrcKarlin()
+
+
+def test_scoreblk_NuclGappedCalc():
+    # UT/scoreblk_unit_test.cpp:354-530
+    L = orc.lib()
+    ideal = _karlin()
+    assert L.orc_karlin_ideal(1, -2, C.byref(ideal)) == 0
+    k = _karlin(); rd = C.c_int(0)
+    assert L.orc_karlin_nucl_gapped(3, 1, 1, -2, C.byref(ideal), C.byref(k), C.byref(rd)) == 0
+    assert rd.value == 0
+    assert math.isclose(k.Lambda, 1.32, rel_tol=1e-5) and math.isclose(k.K, 0.57, rel_tol=1e-5)
+    assert math.isclose(k.logK, -0.562, rel_tol=1e-3)
+    al, be = C.c_double(), C.c_double()
+    L.orc_nucl_alpha_beta(1, -2, 3, 1, C.byref(ideal), 1, C.byref(al), C.byref(be))
+    assert math.isclose(al.value, 1.3, rel_tol=1e-5) and math.isclose(be.value, -1.0, rel_tol=1e-5)
+    # gap costs in the "infinite" regime copy the ungapped block
+    assert L.orc_karlin_nucl_gapped(4, 2, 1, -2, C.byref(ideal), C.byref(k), C.byref(rd)) == 0
+    assert (k.Lambda, k.K, k.logK) == (ideal.Lambda, ideal.K, ideal.logK)
+    L.orc_nucl_alpha_beta(1, -2, 4, 2, C.byref(ideal), 1, C.byref(al), C.byref(be))
+    assert math.isclose(al.value, ideal.Lambda / ideal.H, rel_tol=1e-12) and be.value == 0.0
+    # scaled-up scores
+    assert L.orc_karlin_nucl_gapped(30, 10, 10, -20, C.byref(ideal), C.byref(k), C.byref(rd)) == 0
+    assert math.isclose(k.Lambda, 0.132, rel_tol=1e-5) and math.isclose(k.K, 0.57, rel_tol=1e-5)
+    # 2/-7 rounds odd scores down
+    assert L.orc_karlin_nucl_gapped(4, 2, 2, -7, C.byref(ideal), C.byref(k), C.byref(rd)) == 0
+    assert rd.value == 1
+    assert math.isclose(k.Lambda, 0.675, rel_tol=1e-5) and math.isclose(k.K, 0.62, rel_tol=1e-5)
+    assert math.isclose(k.logK, -0.478036, rel_tol=1e-5)
+    # unsupported gap costs / substitution scores
+    assert L.orc_karlin_nucl_gapped(3, 2, 4, -5, C.byref(ideal), C.byref(k), C.byref(rd)) == 1
+    assert L.orc_karlin_nucl_gapped(1, 3, 1, -2, C.byref(ideal), C.byref(k), C.byref(rd)) == 1
+    assert L.orc_karlin_nucl_gapped(1, 3, 2, -1, C.byref(ideal), C.byref(k), C.byref(rd)) == -1
+    # ungapped alpha/beta for 2/-3
+    L.orc_nucl_alpha_beta(2, -3, 0, 0, C.byref(ideal), 0, C.byref(al), C.byref(be))
+    assert math.isclose(al.value, ideal.Lambda / ideal.H, rel_tol=1e-12) and be.value == -2.0
+
+
+def test_scoreblk_EqualRewardPenaltyLHtoK():
+    # UT/scoreblk_unit_test.cpp:337-352: reward 2 / penalty -2 -> ideal K = 1/3
+    k = _karlin()
+    assert orc.lib().orc_karlin_ideal(2, -2, C.byref(k)) == 0
+    assert abs(k.K - 1.0 / 3) < 1e-6
+
+
+def test_gapped_tables_defaults():
+    # megablast 1/-2 gap 0/0 and blastn 2/-3 gap 5/2
+    L = orc.lib()
+    ideal = _karlin(); L.orc_karlin_ideal(1, -2, C.byref(ideal))
+    k = _karlin(); rd = C.c_int(0)
+    L.orc_karlin_nucl_gapped(0, 0, 1, -2, C.byref(ideal), C.byref(k), C.byref(rd))
+    assert (k.Lambda, k.K, k.H, rd.value) == (1.28, 0.46, 0.85, 0)
+    L.orc_karlin_ideal(2, -3, C.byref(ideal))
+    L.orc_karlin_nucl_gapped(5, 2, 2, -3, C.byref(ideal), C.byref(k), C.byref(rd))
+    assert (k.Lambda, k.K, k.H, rd.value) == (0.625, 0.41, 0.78, 1)
+
+
+def _hsps(rows):
+    arr = (orc.OrcHSP * len(rows))()
+    for i, (qo, qe, so, se, sc) in enumerate(rows):
+        arr[i].context = 0; arr[i].q_offset = qo; arr[i].q_end = qe
+        arr[i].s_offset = so; arr[i].s_end = se; arr[i].score = sc
+    return arr
+
+
+def test_blasthits_testCheckHSPCommonEndpoints():
+    # UT/blasthits_unit_test.cpp:1114-1171: 9 HSPs -> 3 survivors (original indices 4, 0, 6)
+    scores = [1044, 995, 965, 219, 160, 125, 110, 107, 103]
+    qo = [2, 2, 2, 236, 88, 259, 278, 259, 278]
+    qe = [322, 336, 300, 322, 182, 322, 341, 341, 341]
+    so = [7, 7, 7, 194, 2, 194, 197, 194, 197]
+    se = [292, 293, 301, 292, 96, 292, 260, 260, 266]
+    arr = _hsps(list(zip(qo, qe, so, se, scores)))
+    n = orc.lib().orc_hsplist_purge_common_endpoints(arr, 9)
+    assert n == 3
+    for i, orig in enumerate([4, 0, 6]):
+        assert (arr[i].score, arr[i].q_offset, arr[i].s_offset, arr[i].q_end, arr[i].s_end) == \
+               (scores[orig], qo[orig], so[orig], qe[orig], se[orig])
+
+
+def test_blasthits_sort_by_score_rule():
+    # CORE/blast_hits.c:1182-1208: score desc, s.offset asc, s.end desc, q.offset asc, q.end desc
+    rows = [(10, 50, 30, 70, 40), (5, 45, 20, 60, 40), (5, 45, 20, 65, 40), (0, 90, 0, 90, 90),
+            (6, 45, 20, 65, 40)]
+    arr = _hsps(rows)
+    orc.lib().orc_hsplist_sort_by_score(arr, len(rows))
+    got = [(a.q_offset, a.q_end, a.s_offset, a.s_end, a.score) for a in arr]
+    assert got == [(0, 90, 0, 90, 90), (5, 45, 20, 65, 40), (6, 45, 20, 65, 40),
+                   (5, 45, 20, 60, 40), (10, 50, 30, 70, 40)]
+
+
+def test_blastn_word_size4_invariants():
+    # UT/bl2seq_unit_test.cpp:2246-2302 (NucleotideBlastWordSize4): structural invariants
+    a = orc.encode_blastna(orc.read_fasta(os.path.join(G, "blastn_size4a.fsa"))[0])
+    b = orc.encode_blastna(orc.read_fasta(os.path.join(G, "blastn_size4b.fsa"))[0])
+    opt = orc.default_options(False, word_size=4, reward=1, penalty=-1, evalue=10000.0)
+    s = orc.Search(opt, [a])
+    assert s.info()["lut_width"] == 4 and s.info()["scan_step"] == 1
+    r = s.subject(orc.pack_ncbi2na(b), len(b))
+    for h in r["hsps"]:
+        assert 0 <= h["q_offset"] < h["q_end"] <= len(a)
+        assert 0 <= h["s_offset"] < h["s_end"] <= len(b)
+        assert h["q_offset"] <= h["q_gapped_start"] <= h["q_end"]
+        assert h["s_offset"] <= h["s_gapped_start"] <= h["s_end"]
+
+
+def test_lookup_every_scan_hit_is_a_word_match():
+    # UT/ntscan_unit_test.cpp:717 property: every seed's word matches exactly on both sides
+    rng = np.random.default_rng(3)
+    q = rng.integers(0, 4, 900, dtype=np.uint8)
+    subj = rng.integers(0, 4, 30000, dtype=np.uint8)
+    subj[5000:5600] = q[100:700]
+    for mb, ws in [(True, 28), (False, 11)]:
+        s = orc.Search(orc.default_options(mb, db_length=len(subj), db_num_seqs=1), [q])
+        r = s.subject(orc.pack_ncbi2na(subj), len(subj))
+        qc = s.query_concat()
+        assert len(r["seeds"]) > 0
+        for sd in r["seeds"]:
+            assert np.array_equal(qc[sd["q_off"]:sd["q_off"] + ws], subj[sd["s_off"]:sd["s_off"] + ws])
+
+
+def test_lookup_table_choice_thresholds():
+    # CORE/blast_nalookup.c:51-189 incl. G-BLASTN's word_size==11 patch vs stock
+    rng = np.random.default_rng(1)
+
+    def choice(mb, nq, **kw):
+        qs = [rng.integers(0, 4, 1000, dtype=np.uint8) for _ in range(nq)]
+        s = orc.Search(orc.default_options(mb, db_length=10**7, db_num_seqs=10, **kw), qs)
+        i = s.info()
+        return i["lut_type"], i["lut_width"], i["scan_step"], i["container"]
+    assert choice(True, 1) == (1, 8, 21, 0)
+    assert choice(True, 4) == (1, 8, 21, 1)        # 7,992 entries < 8,500; 8,007 bases > 8,000
+    assert choice(True, 5) == (3, 11, 18, 1)
+    assert choice(True, 160) == (3, 12, 17, 1)
+    assert choice(False, 2) == (1, 8, 4, 0)
+    assert choice(False, 8) == (3, 11, 1, 1)
+    assert choice(False, 8, lut11_gblastn_rule=0) == (3, 10, 2, 1)
