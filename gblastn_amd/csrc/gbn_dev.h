@@ -36,6 +36,30 @@ struct GbnScanParams {
     unsigned long long *raw_hits;
 };
 
+// ---- key-range partitioned scan: phase 1 bins EVERY scan position by the top
+// bits of its lookup word (8-byte records, no table access at all); phase 2
+// loads one bin's cell table (<= 32768 cells x 4 B = 128 KiB) into LDS and
+// streams that bin's records through it.
+#define GBN_BIN_THREADS  1024
+#define GBN_BIN_TILE_POS 8192       // scan positions per tile (posid = tile << 13 | i)
+#define GBN_BIN_GROUPS   8          // probe workgroups with equal (blockIdx & 7) share a bin (and an XCD)
+#define GBN_BIN_MAXNB    512
+#define GBN_BIN_CELLS    32768      // cells per bin (LDS table entries)
+#define GBN_BIN_STAGE    (GBN_BIN_TILE_POS + 3 * GBN_BIN_MAXNB)
+#define GBN_BIN_QCAP     128        // per-wave queue of rare-path items in the probe kernel
+
+struct GbnBinParams {
+    GbnScanParams S;                // tiles here are GBN_BIN_TILE_POS-sized
+    int nb, cbits;                  // number of bins; cell = bin << cbits | low
+    int nwriters;                   // workgroups of the binning kernel = private output streams per bin
+    const uint32_t *cellt;          // per cell: [1:0] class 0/1/2/3(>=3 or forced), [15:2] fpA, [29:16] fpB
+    unsigned long long *rec;        // [nb][nwriters][subcap]: lo = posid, hi = low << 14 | sfp
+    uint32_t *gcount;               // [nb][nwriters] records written (multiple of 4, pads included)
+    uint32_t subcap;
+    uint32_t *overflow;             // set to 1 if any stream did not fit
+    int rfl, rfr;                   // reduced fingerprint lengths (<= 4 left, <= 3 right)
+};
+
 struct GbnKeyParams {
     const GbnDevSeed *seeds; int64_t n;
     uint64_t *key_scan; uint64_t *key_group; uint32_t *idx;

@@ -662,3 +662,259 @@ hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uin
 }
 
 }  // namespace gbn
+
+// ===========================================================================
+// Key-range partitioned scan (lookup tables too large for L2).
+//
+// Direct probing costs one L2 request per scan position for the presence bit
+// (2.9e9 per 50 Gbp pass: the L2 request rate, not HBM, is the wall) plus one
+// 64-byte HBM sector per present word.  Here phase 1 touches no table at all:
+// it streams the subject once and writes every scan position as an 8-byte
+// record {position id, low cell bits, 4+3 neighbouring subject bases} into
+// the bin given by the top bits of its lookup word, in full 32-byte sectors.
+// Phase 2 walks bin by bin with the bin's cell table resident in LDS (one
+// workgroup per CU, all workgroups with the same blockIdx & 7 -- observed to
+// share an XCD and its L2 -- on the same bin).  Only ~5 % of present words
+// (fingerprint survivors and cells with >= 3 entries) leave LDS.
+// ===========================================================================
+namespace {
+// 32 consecutive bases starting at base index `pos` as a big-endian 64-bit word
+__device__ __forceinline__ uint64_t window32(const uint8_t *__restrict__ p, int64_t pos) {
+    int64_t w = pos >> 4;
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + w;
+    uint64_t hi = ((uint64_t)bswap32(d[0]) << 32) | bswap32(d[1]);
+    uint32_t lo = bswap32(d[2]);
+    int sh = 2 * (int)(pos & 15);
+    return sh ? ((hi << sh) | ((uint64_t)lo >> (32 - sh))) : hi;
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, 8)
+scan_bin_kernel(GbnBinParams B)
+{
+    const GbnScanParams &P = B.S;
+    __shared__ uint32_t s_hi[GBN_BIN_STAGE];        // record high word, bin-sorted
+    __shared__ uint16_t s_idx[GBN_BIN_STAGE];       // position index in tile; 0xffff = pad
+    __shared__ uint16_t s_gbin[GBN_BIN_STAGE / 4 + 4]; // bin of every group of 4 slots
+    __shared__ uint32_t s_hist[GBN_BIN_MAXNB], s_off[GBN_BIN_MAXNB + 1], s_cur[GBN_BIN_MAXNB];
+    __shared__ uint32_t s_wcur[GBN_BIN_MAXNB];      // this workgroup's write cursor per bin (records)
+    const int tid = threadIdx.x;
+    const uint32_t mask = (uint32_t)(P.ncells - 1);
+    const int nb = B.nb, cbits = B.cbits;
+    const uint32_t lowmask = (1u << cbits) - 1;
+    const int cshift = 56 - 2 * P.lut, rshift = 50 - 2 * P.lut;
+    constexpr int PER = GBN_BIN_TILE_POS / GBN_BIN_THREADS;     // 8
+
+    for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_wcur[b] = 0;
+    for (int64_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
+        const GbnTile T = P.tiles[tile];
+        const uint8_t *__restrict__ subj = P.db + P.byte_off[T.subj];
+        uint64_t W[PER];
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {             // all loads first: 8 independent 12-byte reads in flight
+            int i = tid + k * GBN_BIN_THREADS;
+            W[k] = (i < T.npos) ? window32(subj, (int64_t)T.first_pos + (int64_t)i * P.step - 4) : 0;
+        }
+        for (int b = tid; b < nb; b += GBN_BIN_THREADS) { s_hist[b] = 0; s_cur[b] = 0; }
+        __syncthreads();
+        uint32_t bin[PER], hi[PER];
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            int i = tid + k * GBN_BIN_THREADS;
+            bin[k] = 0xffffffffu; hi[k] = 0;
+            if (i < T.npos) {
+                const uint32_t c = (uint32_t)(W[k] >> cshift) & mask;
+                const uint32_t left4 = (uint32_t)(W[k] >> 56);
+                const uint32_t right3 = (uint32_t)(W[k] >> rshift) & 0x3fu;
+                bin[k] = c >> cbits;
+                hi[k] = ((c & lowmask) << 14) | (left4 << 6) | right3;
+                atomicAdd(&s_hist[bin[k]], 1u);
+            }
+        }
+        __syncthreads();
+        // exclusive scan of the padded bin sizes (x4 records = 32-byte sectors) by wave 0
+        if (tid < 64) {
+            uint32_t carry = 0;
+            for (int base = 0; base < nb; base += 64) {
+                int b = base + tid;
+                uint32_t v = (b < nb) ? ((s_hist[b] + 3u) & ~3u) : 0u;
+                uint32_t x = v;
+                for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if (tid >= o) x += y; }
+                if (b < nb) s_off[b] = carry + x - v;
+                carry += __shfl(x, 63);
+            }
+            if (tid == 0) s_off[nb] = carry;
+        }
+        __syncthreads();
+        const uint32_t total = s_off[nb];
+        for (int b = tid; b < nb; b += GBN_BIN_THREADS) {
+            const uint32_t n = s_hist[b], o0 = s_off[b], o1 = s_off[b + 1];
+            for (uint32_t j = o0 + n; j < o1; j++) s_idx[j] = 0xffffu;
+            for (uint32_t g = o0 >> 2; g < (o1 >> 2); g++) s_gbin[g] = (uint16_t)b;
+            if (o1 > o0 && s_wcur[b] + (o1 - o0) > B.subcap) atomicExch(B.overflow, 1u);
+        }
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            if (bin[k] != 0xffffffffu) {
+                const uint32_t slot = s_off[bin[k]] + atomicAdd(&s_cur[bin[k]], 1u);
+                s_hi[slot] = hi[k];
+                s_idx[slot] = (uint16_t)(tid + k * GBN_BIN_THREADS);
+            }
+        }
+        __syncthreads();
+        for (uint32_t j = tid; j < total; j += GBN_BIN_THREADS) {
+            const uint32_t b = s_gbin[j >> 2];
+            const uint32_t li = s_idx[j];
+            const unsigned long long o = (li == 0xffffu) ? 0xffffffffull
+                : (((unsigned long long)s_hi[j] << 32) | (((uint32_t)tile << 13) | li));
+            const uint32_t w = s_wcur[b] + (j - s_off[b]);
+            if (w < B.subcap)
+                B.rec[((size_t)b * B.nwriters + blockIdx.x) * B.subcap + w] = o;
+        }
+        __syncthreads();
+        for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_wcur[b] += s_off[b + 1] - s_off[b];
+    }
+    __syncthreads();
+    for (int b = tid; b < nb; b += GBN_BIN_THREADS)
+        B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(s_wcur[b], B.subcap);
+}
+
+namespace {
+// reduced fingerprint test: rf = 14 bits {left4 (8 bits, base -1 low pair), right3 (6 bits, first base high pair)}
+__device__ __forceinline__ bool rfp_pass(uint32_t qf, uint32_t sf, uint32_t lmask, uint32_t rmask, bool lany, bool rany)
+{
+    const uint32_t x = qf ^ sf;
+    const bool left = lany || ((x >> 6) & lmask) == 0;
+    const bool right = rany || (x & rmask) == 0;
+    return left || right;
+}
+
+// rare path of the probe kernel: full fingerprints, chain walk, exact verification
+__device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell, bool count_raw,
+                           unsigned long long &raw)
+{
+    const uint32_t start = P.cell_start[cell], end = P.cell_start[cell + 1];
+    if (count_raw) raw += end - start;
+    const GbnTile T = P.tiles[posid >> 13];
+    const int32_t s = T.first_pos + (int32_t)(posid & 8191u) * P.step;
+    const uint8_t *__restrict__ subj = P.db + P.byte_off[T.subj];
+    const int32_t slen = P.len[T.subj];
+    const uint32_t sl = window16(subj, (int64_t)s - 8) >> 16;
+    const uint32_t sr = window16(subj, (int64_t)s + P.lut);
+    for (uint32_t e = start; e < end; e++) {
+        const unsigned long long ent = P.ent[e];
+        if (!fp_pass((uint32_t)(ent >> 32), sl, sr, P.fl, P.fr)) continue;
+        const int32_t q = (int32_t)(ent & 0xffffffffu);
+        const int el = verify_hit(P, subj, slen, q, s);
+        if (el >= 0) {
+            unsigned long long o = atomicAdd(P.seed_count, 1ull);
+            if (o < P.seed_cap) { GbnDevSeed sd; sd.subj = T.subj; sd.s_scan = s; sd.q_pos = q; sd.ext_left = el; P.seeds[o] = sd; }
+        }
+    }
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS)
+probe_bin_kernel(GbnBinParams B)
+{
+    const GbnScanParams &P = B.S;
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
+    uint32_t *s_tab = s_dyn;                                        // GBN_BIN_CELLS entries
+    volatile uint2 *s_q = reinterpret_cast<volatile uint2 *>(s_dyn + GBN_BIN_CELLS);   // [16 waves][QCAP]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int grp = blockIdx.x & (GBN_BIN_GROUPS - 1);
+    const int wi = blockIdx.x >> 3, nw = gridDim.x >> 3;            // workgroup index inside its group
+    const int cbits = B.cbits;
+    const uint32_t ncell_bin = 1u << cbits;
+    const bool lany = B.rfl <= 0, rany = B.rfr <= 0;
+    const uint32_t lmask = lany ? 0u : ((1u << (2 * B.rfl)) - 1);
+    const uint32_t rmask = rany ? 0u : (((1u << (2 * B.rfr)) - 1) << (2 * (3 - B.rfr)));
+    volatile uint2 *q = s_q + wave * GBN_BIN_QCAP;
+    int qn = 0;                                                     // wave-uniform
+    unsigned long long raw = 0;
+    const unsigned long long lt = (1ull << lane) - 1;
+
+    for (int b = grp; b < B.nb; b += GBN_BIN_GROUPS) {
+        __syncthreads();
+        {
+            const uint4 *src = reinterpret_cast<const uint4 *>(B.cellt + ((size_t)b << cbits));
+            uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
+            for (uint32_t i = tid; i < ncell_bin / 4; i += GBN_BIN_THREADS) dst[i] = src[i];
+        }
+        __syncthreads();
+        for (int w = wi; w < B.nwriters; w += nw) {
+            const uint32_t n = B.gcount[(size_t)b * B.nwriters + w];
+            const unsigned long long *__restrict__ rec = B.rec + ((size_t)b * B.nwriters + w) * B.subcap;
+            for (uint32_t j0 = 0; j0 < n; j0 += GBN_BIN_THREADS * 8u) {
+                // 4 independent 16-byte loads (8 records) per lane in flight
+                ulonglong2 rr[4];
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t j = j0 + (uint32_t)u * GBN_BIN_THREADS * 2u + (uint32_t)tid * 2u;
+                    rr[u] = (j < n) ? *reinterpret_cast<const ulonglong2 *>(rec + j)
+                                    : make_ulonglong2(0xffffffffull, 0xffffffffull);
+                }
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    #pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const unsigned long long r = h ? rr[u].y : rr[u].x;
+                        const uint32_t posid = (uint32_t)r;
+                        bool slow = false; uint32_t cellv = 0;
+                        if (posid != 0xffffffffu) {
+                            const uint32_t hi32 = (uint32_t)(r >> 32);
+                            const uint32_t low = hi32 >> 14, sf = hi32 & 0x3fffu;
+                            const uint32_t t = s_tab[low];
+                            const uint32_t cls = t & 3u;
+                            if (cls == 3) slow = true;
+                            else if (cls != 0) {
+                                raw += cls;
+                                slow = rfp_pass((t >> 2) & 0x3fffu, sf, lmask, rmask, lany, rany) ||
+                                       (cls == 2 && rfp_pass((t >> 16) & 0x3fffu, sf, lmask, rmask, lany, rany));
+                            }
+                            // bit 31 of the queued cell word: "raw hits not counted yet" (class 3)
+                            cellv = (((uint32_t)b << cbits) | low) | (cls == 3 ? 0x80000000u : 0u);
+                        }
+                        const unsigned long long m = __ballot(slow);
+                        if (m) {
+                            if (slow) { const int at = qn + __popcll(m & lt); q[at].x = posid; q[at].y = cellv; }
+                            qn += __popcll(m);
+                            if (qn >= 64) {                         // drain one dense batch
+                                qn -= 64;
+                                const uint32_t pid = q[qn + lane].x, cv = q[qn + lane].y;
+                                probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (lane < qn) {
+        const uint32_t pid = q[lane].x, cv = q[lane].y;
+        probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
+    }
+    if (P.raw_hits) {
+        for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
+        if (lane == 0 && raw) atomicAdd(P.raw_hits, raw);
+    }
+}
+
+namespace gbn {
+hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st)
+{
+    if (b.S.ntiles <= 0) return hipSuccess;
+    hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_BIN_THREADS), 0, st, b);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    const size_t lds = (size_t)GBN_BIN_CELLS * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8;
+    static bool attr_set = false;
+    if (!attr_set) {
+        e = hipFuncSetAttribute((const void *)probe_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(probe_bin_kernel, dim3(grid2), dim3(GBN_BIN_THREADS), lds, st, b);
+    return hipGetLastError();
+}
+}  // namespace gbn

@@ -30,6 +30,16 @@ def run_case(nsub, slen, nq, task="megablast", qlen=1000, expect=None, **kw):
     return nh, plants
 
 
+@pytest.fixture(params=["auto", "direct"], autouse=True)
+def scan_variant(request, monkeypatch):
+    """Every case runs with the engine's own choice of scan kernel (key-range partitioned
+    for lut >= 10) and with the direct-probe kernel forced."""
+    if request.param == "direct":
+        monkeypatch.setenv("GBN_SCAN_BINS", "1")
+    else:
+        monkeypatch.delenv("GBN_SCAN_BINS", raising=False)
+
+
 def test_megablast_small_query_smallna_lut8():
     # C1-shaped: one 1 kb query -> small table lut 8, stride 21, diag array
     nh, _ = run_case(6, 200_000, 1, planted_fraction=1.0,
