@@ -39,7 +39,8 @@ void set_error(const std::string &m) { g_err = m; }
 struct DeviceBatch {
     uint8_t *q8_base = nullptr;     // device copy of qbuf
     const uint8_t *q8 = nullptr;    // q8_base + qpad
-    uint32_t *pv = nullptr, *cellw = nullptr, *cell_start = nullptr, *cellt = nullptr;
+    uint32_t *pv = nullptr, *cellw = nullptr, *cell_start = nullptr, *cellt = nullptr, *side_start = nullptr;
+    uint16_t *sidet = nullptr;
     unsigned long long *ent = nullptr;
     int32_t *ctx_off = nullptr, *ctx_len = nullptr, *ctx_xdrop = nullptr, *ctx_cutoff = nullptr,
             *ctx_reduced = nullptr;
@@ -59,6 +60,7 @@ struct Engine {
     unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits
     int32_t *gap_scratch = nullptr; size_t gap_scratch_ints = 0;
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
+    GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
     uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;   // [nb][nwriters] + overflow flag
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     std::mutex mu;
@@ -86,7 +88,7 @@ template <class T> static void dev_free(T *&p) { if (p) (void)hipFree((void *)p)
 
 void free_device_batch(DeviceBatch *d) {
     if (!d) return;
-    dev_free(d->q8_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->cell_start); dev_free(d->ent);
+    dev_free(d->q8_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent);
     dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff);
     dev_free(d->ctx_reduced); dev_free(d->matrix); dev_free(d->score_table);
     delete d;
@@ -132,6 +134,7 @@ int upload_batch(GbnBatch &b) {
     std::vector<uint32_t> cellw((size_t)L.ncells, 0), cellt((size_t)L.ncells, 0);
     std::vector<unsigned long long> ent(L.cell_qoff.size());
     auto reduce = [](uint32_t fp) { return ((((fp >> 15) & 0xffu)) << 6) | (((fp >> 1) & 0x3fffu) >> 8); };
+    std::vector<uint16_t> sidet; std::vector<uint32_t> side_start; int64_t cur_bin = -1; bool forced_cell = false;
     for (int64_t c = 0; c < L.ncells; c++) {
         uint32_t s = L.cell_start[c], e = L.cell_start[c + 1];
         for (uint32_t k = s; k < e; k++) {
@@ -143,14 +146,33 @@ int upload_batch(GbnBatch &b) {
             // LDS cell table of the partitioned scan: class + two reduced fingerprints
             if (k == s) cellt[c] = std::min<uint32_t>(e - s, 3u) | (reduce(fp) << 2);
             else if (k == s + 1) cellt[c] |= reduce(fp) << 16;
-            if (force) cellt[c] |= 3u;
+            if (force) forced_cell = true;
         }
+        if (e - s >= 3 || forced_cell) {
+            // class 3: reduced fingerprints go to the bin's side list (capacity GBN_BIN_SIDE per bin,
+            // 16-bit offsets, 14-bit counts); anything that does not fit is "always rare path"
+            const int64_t bin = c / GBN_BIN_CELLS;
+            if (bin != cur_bin) { cur_bin = bin; while ((int64_t)side_start.size() <= bin) side_start.push_back((uint32_t)sidet.size()); }
+            const uint32_t off = (uint32_t)sidet.size() - side_start[bin], cnt = e - s;
+            if (!forced_cell && off + cnt <= GBN_BIN_SIDE && cnt < 16384) {
+                for (uint32_t k = s; k < e; k++) sidet.push_back((uint16_t)reduce((uint32_t)(ent[k] >> 32)));
+                cellt[c] = 3u | (off << 2) | (cnt << 18);
+            } else cellt[c] = 3u;
+            forced_cell = false;
+        }
+    }
+    {
+        const int64_t nbins = (L.ncells + GBN_BIN_CELLS - 1) / GBN_BIN_CELLS;
+        while ((int64_t)side_start.size() <= nbins) side_start.push_back((uint32_t)sidet.size());
+        sidet.push_back(0);
     }
     if ((rc = dev_upload(d->q8_base, b.qbuf.data(), b.qbuf.size()))) return rc;
     d->q8 = d->q8_base + b.qpad;
     if ((rc = dev_upload(d->pv, L.pv.data(), L.pv.size()))) return rc;
     if ((rc = dev_upload(d->cellw, cellw.data(), cellw.size()))) return rc;
     if ((rc = dev_upload(d->cellt, cellt.data(), cellt.size()))) return rc;
+    if ((rc = dev_upload(d->sidet, sidet.data(), sidet.size()))) return rc;
+    if ((rc = dev_upload(d->side_start, side_start.data(), side_start.size()))) return rc;
     if ((rc = dev_upload(d->cell_start, L.cell_start.data(), L.cell_start.size()))) return rc;
     {
         // one pad entry so that an empty list still has a valid pointer
@@ -297,8 +319,9 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
     if (nb > 1)
         for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) npos += (db.len[s] - b.lut.lut) / b.lut.step + 1;
     double slack = 1.25;
+    size_t rare_seg_hint = 0;
     for (;;) {
-        HIPCHK(hipMemsetAsync(E.counters, 0, 3 * sizeof(unsigned long long), E.stream));
+        HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream));
         GbnScanParams P; fill_scan_params(P, b, db, ts);
         uint32_t overflow = 0;
         if (nb == 1) {
@@ -327,10 +350,22 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
             HIPCHK(hipMemsetAsync(E.bin_count + nstream, 0, 16, E.stream));
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
             B.S = P; B.nb = nb; B.cbits = 15; B.nwriters = nwriters;
-            B.cellt = b.dev->cellt; B.rfl = std::min(4, b.dev->fl); B.rfr = std::min(3, b.dev->fr);
+            B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfr = std::min(3, b.dev->fr);
             B.rec = E.bin_rec; B.gcount = E.bin_count; B.subcap = (uint32_t)subcap;
             B.overflow = E.bin_count + nstream;
             int grid2 = std::max(8, E.num_cu & ~7);   // one 1024-thread workgroup per CU; group = blockIdx & 7
+            {   // rare-path queue: one segment per probe workgroup (~1.2 % of scan positions in total)
+                size_t seg = std::max<size_t>(rare_seg_hint, (size_t)(npos / 40 / grid2) + 4096);
+                size_t want = seg * (size_t)grid2;
+                if (want > E.rareq_cap) {
+                    dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
+                    if ((rc = dev_alloc(E.rareq, want))) return rc;
+                    E.rareq_cap = want;
+                }
+                seg = E.rareq_cap / (size_t)grid2;
+                if (!E.rare_counts && (rc = dev_alloc(E.rare_counts, (size_t)1024))) return rc;
+                B.rareq = E.rareq; B.rare_seg = (uint32_t)std::min<size_t>(seg, 0x7fffffff); B.rare_counts = E.rare_counts;
+            }
             HIPCHK(hipEventRecord(E.ev0, E.stream));
             HIPCHK(launch_scan_bin(B, grid2, E.stream));
             HIPCHK(hipEventRecord(E.ev1, E.stream));
@@ -341,6 +376,18 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
         if (diag) {
             float ms = 0; (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
             diag->scan_kernel_ms += ms; diag->scan_launches++;
+        }
+        if (nb > 1) {
+            const int grid2 = std::max(8, E.num_cu & ~7);
+            std::vector<uint32_t> rc_host((size_t)grid2);
+            HIPCHK(hipMemcpy(rc_host.data(), E.rare_counts, (size_t)grid2 * 4, hipMemcpyDeviceToHost));
+            unsigned long long sc = 0; uint32_t mx = 0;
+            for (uint32_t v : rc_host) { sc += v; mx = std::max(mx, v); }
+            if (getenv("GBN_DBG")) fprintf(stderr, "[gbn dbg] rare-path items %llu, seeds %llu, raw %llu\n", sc, cnt[0], cnt[1]);
+            if ((size_t)mx > E.rareq_cap / (size_t)grid2) {    // a segment overflowed: grow and rescan this range
+                rare_seg_hint = (size_t)mx + (mx >> 2);
+                continue;
+            }
         }
         if (overflow) { slack *= 2; if (slack > 64) { set_error("bin overflow"); return GBN_ERR_NOMEM; } continue; }
         if (cnt[0] <= E.seed_cap) break;
@@ -534,7 +581,7 @@ void Blast_gpu_Release(void) {
     if (!E.ready) return;
     dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
     dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.sort_tmp); dev_free(E.ihits); dev_free(E.gapped);
-    dev_free(E.counters); dev_free(E.gap_scratch); dev_free(E.bin_rec); dev_free(E.bin_count);
+    dev_free(E.counters); dev_free(E.gap_scratch); dev_free(E.bin_rec); dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
     E.bin_rec_cap = 0; E.bin_count_cap = 0;
     E.seed_cap = E.key_cap = E.ihit_cap = E.gap_scratch_ints = 0;
     if (E.ev0) (void)hipEventDestroy(E.ev0);

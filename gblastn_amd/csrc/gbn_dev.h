@@ -47,17 +47,25 @@ struct GbnScanParams {
 #define GBN_BIN_CELLS    32768      // cells per bin (LDS table entries)
 #define GBN_BIN_STAGE    (GBN_BIN_TILE_POS + 3 * GBN_BIN_MAXNB)
 #define GBN_BIN_QCAP     128        // per-wave queue of rare-path items in the probe kernel
+#define GBN_BIN_SIDE     4096       // LDS side-list capacity (u16 fingerprints) per bin
 
+struct GbnU2 { uint32_t x, y; };
 struct GbnBinParams {
     GbnScanParams S;                // tiles here are GBN_BIN_TILE_POS-sized
     int nb, cbits;                  // number of bins; cell = bin << cbits | low
     int nwriters;                   // workgroups of the binning kernel = private output streams per bin
-    const uint32_t *cellt;          // per cell: [1:0] class 0/1/2/3(>=3 or forced), [15:2] fpA, [29:16] fpB
+    const uint32_t *cellt;          // per cell: [1:0] class 0/1/2/3; class 1/2: [15:2] fpA, [29:16] fpB;
+                                    // class 3: [17:2] offset into the bin's side list, [31:18] count (0 = always rare path)
+    const uint16_t *sidet;          // reduced fingerprints of cells with >= 3 entries, per bin
+    const uint32_t *side_start;     // [nb + 1] offsets into sidet
     unsigned long long *rec;        // [nb][nwriters][subcap]: lo = posid, hi = low << 14 | sfp
     uint32_t *gcount;               // [nb][nwriters] records written (multiple of 4, pads included)
     uint32_t subcap;
     uint32_t *overflow;             // set to 1 if any stream did not fit
     int rfl, rfr;                   // reduced fingerprint lengths (<= 4 left, <= 3 right)
+    int dbg;                        // ablation switches for tools/scan_ablate.py (0 in production)
+    GbnU2 *rareq; uint32_t rare_seg;    // rare-path queue: one segment of rare_seg items per probe workgroup
+    uint32_t *rare_counts;              // [probe workgroups] items queued (may exceed rare_seg: overflow)
 };
 
 struct GbnKeyParams {

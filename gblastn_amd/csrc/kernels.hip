@@ -693,9 +693,9 @@ extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, 8)
 scan_bin_kernel(GbnBinParams B)
 {
     const GbnScanParams &P = B.S;
-    __shared__ uint32_t s_hi[GBN_BIN_STAGE];        // record high word, bin-sorted
-    __shared__ uint16_t s_idx[GBN_BIN_STAGE];       // position index in tile; 0xffff = pad
-    __shared__ uint16_t s_gbin[GBN_BIN_STAGE / 4 + 4]; // bin of every group of 4 slots
+    __shared__ __attribute__((aligned(16))) uint32_t s_hi[GBN_BIN_STAGE];   // record high word, bin-sorted
+    __shared__ __attribute__((aligned(16))) uint16_t s_idx[GBN_BIN_STAGE];  // position index in tile; 0xffff = pad
+    __shared__ uint32_t s_gmeta[GBN_BIN_STAGE / 4 + 4];    // per group of 4 slots: bin << 23 | (stream index - slot + BIAS)
     __shared__ uint32_t s_hist[GBN_BIN_MAXNB], s_off[GBN_BIN_MAXNB + 1], s_cur[GBN_BIN_MAXNB];
     __shared__ uint32_t s_wcur[GBN_BIN_MAXNB];      // this workgroup's write cursor per bin (records)
     const int tid = threadIdx.x;
@@ -732,6 +732,7 @@ scan_bin_kernel(GbnBinParams B)
             }
         }
         __syncthreads();
+        if (B.dbg & 4) continue;                    // ablation: loads + histogram only
         // exclusive scan of the padded bin sizes (x4 records = 32-byte sectors) by wave 0
         if (tid < 64) {
             uint32_t carry = 0;
@@ -750,7 +751,7 @@ scan_bin_kernel(GbnBinParams B)
         for (int b = tid; b < nb; b += GBN_BIN_THREADS) {
             const uint32_t n = s_hist[b], o0 = s_off[b], o1 = s_off[b + 1];
             for (uint32_t j = o0 + n; j < o1; j++) s_idx[j] = 0xffffu;
-            for (uint32_t g = o0 >> 2; g < (o1 >> 2); g++) s_gbin[g] = (uint16_t)b;
+            for (uint32_t g = o0 >> 2; g < (o1 >> 2); g++) s_gmeta[g] = ((uint32_t)b << 23) | (s_wcur[b] + 16384u - o0);
             if (o1 > o0 && s_wcur[b] + (o1 - o0) > B.subcap) atomicExch(B.overflow, 1u);
         }
         #pragma unroll
@@ -762,14 +763,24 @@ scan_bin_kernel(GbnBinParams B)
             }
         }
         __syncthreads();
-        for (uint32_t j = tid; j < total; j += GBN_BIN_THREADS) {
-            const uint32_t b = s_gbin[j >> 2];
-            const uint32_t li = s_idx[j];
-            const unsigned long long o = (li == 0xffffu) ? 0xffffffffull
-                : (((unsigned long long)s_hi[j] << 32) | (((uint32_t)tile << 13) | li));
-            const uint32_t w = s_wcur[b] + (j - s_off[b]);
-            if (w < B.subcap)
-                B.rec[((size_t)b * B.nwriters + blockIdx.x) * B.subcap + w] = o;
+        // write-out: one lane per group of 4 records = one 32-byte sector
+        for (uint32_t g = tid; g < (total >> 2); g += GBN_BIN_THREADS) {
+            const uint32_t meta = s_gmeta[g];
+            const uint32_t b = meta >> 23;
+            const uint32_t w = (meta & 0x7fffffu) - 16384u + 4u * g;      // index in this workgroup's stream of bin b
+            const uint2 i4 = *reinterpret_cast<const uint2 *>(&s_idx[4 * g]);
+            const uint4 h4 = *reinterpret_cast<const uint4 *>(&s_hi[4 * g]);
+            const uint32_t tbase = (uint32_t)tile << 13;
+            const uint32_t l0 = i4.x & 0xffffu, l1 = i4.x >> 16, l2 = i4.y & 0xffffu, l3 = i4.y >> 16;
+            ulonglong2 a, c;
+            a.x = (l0 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.x << 32) | (tbase | l0));
+            a.y = (l1 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.y << 32) | (tbase | l1));
+            c.x = (l2 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.z << 32) | (tbase | l2));
+            c.y = (l3 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.w << 32) | (tbase | l3));
+            if (w + 4u <= B.subcap && !(B.dbg & 2)) {
+                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(B.rec + ((size_t)b * B.nwriters + blockIdx.x) * B.subcap + w);
+                dst[0] = a; dst[1] = c;
+            }
         }
         __syncthreads();
         for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_wcur[b] += s_off[b + 1] - s_off[b];
@@ -821,18 +832,57 @@ probe_bin_kernel(GbnBinParams B)
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     uint32_t *s_tab = s_dyn;                                        // GBN_BIN_CELLS entries
     volatile uint2 *s_q = reinterpret_cast<volatile uint2 *>(s_dyn + GBN_BIN_CELLS);   // [16 waves][QCAP]
+    uint16_t *s_side = reinterpret_cast<uint16_t *>(s_dyn + GBN_BIN_CELLS + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2);
+    uint32_t *s_rcount = s_dyn + GBN_BIN_CELLS + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2 + GBN_BIN_SIDE / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = blockIdx.x & (GBN_BIN_GROUPS - 1);
     const int wi = blockIdx.x >> 3, nw = gridDim.x >> 3;            // workgroup index inside its group
     const int cbits = B.cbits;
     const uint32_t ncell_bin = 1u << cbits;
-    const bool lany = B.rfl <= 0, rany = B.rfr <= 0;
-    const uint32_t lmask = lany ? 0u : ((1u << (2 * B.rfl)) - 1);
-    const uint32_t rmask = rany ? 0u : (((1u << (2 * B.rfr)) - 1) << (2 * (3 - B.rfr)));
+    GbnU2 *myq = B.rareq + (size_t)blockIdx.x * B.rare_seg;          // this workgroup's segment: no global atomics
+    if (tid == 0) *s_rcount = 0;
+    // masks of the reduced fingerprint test; a zero mask makes that side "always matches"
+    const uint32_t lmask = (B.rfl <= 0) ? 0u : ((1u << (2 * B.rfl)) - 1);
+    const uint32_t rmask = (B.rfr <= 0) ? 0u : (((1u << (2 * B.rfr)) - 1) << (2 * (3 - B.rfr)));
     volatile uint2 *q = s_q + wave * GBN_BIN_QCAP;
     int qn = 0;                                                     // wave-uniform
     unsigned long long raw = 0;
     const unsigned long long lt = (1ull << lane) - 1;
+
+    // Flush `cnt` queued items (one per lane): cells with a side list get their reduced
+    // fingerprints checked here, densely; survivors go to the global rare-path queue.
+    auto flush = [&](int first, int cnt, int bin) {
+        bool keep = false; uint32_t pid = 0, cv = 0;
+        if (lane < cnt) {
+            pid = q[first + lane].x;
+            const uint32_t y = q[first + lane].y;
+            const uint32_t low = y & 0x7fffu, sf = (y >> 15) & 0x3fffu;
+            cv = ((uint32_t)bin << cbits) | low;
+            keep = true;
+            if (y >> 31) {                                          // cell with >= 3 entries
+                const uint32_t t = s_tab[low];
+                const uint32_t n3 = t >> 18, so = (t >> 2) & 0xffffu;
+                if (n3 == 0) cv |= 0x80000000u;                     // always-rare cell: raw hits counted later
+                else {
+                    raw += n3; keep = false;
+                    for (uint32_t e = 0; e < n3; e++) {
+                        const uint32_t x = (uint32_t)s_side[so + e] ^ sf;
+                        keep = keep || (((x >> 6) & lmask) == 0) || ((x & rmask) == 0);
+                    }
+                }
+            }
+        }
+        const unsigned long long m = __ballot(keep);
+        if (m) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(s_rcount, (uint32_t)__popcll(m));
+            base = __shfl(base, 0);
+            if (keep) {
+                const uint32_t at = base + (uint32_t)__popcll(m & lt);
+                if (at < B.rare_seg) { myq[at].x = pid; myq[at].y = cv; }
+            }
+        }
+    };
 
     for (int b = grp; b < B.nb; b += GBN_BIN_GROUPS) {
         __syncthreads();
@@ -840,63 +890,95 @@ probe_bin_kernel(GbnBinParams B)
             const uint4 *src = reinterpret_cast<const uint4 *>(B.cellt + ((size_t)b << cbits));
             uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
             for (uint32_t i = tid; i < ncell_bin / 4; i += GBN_BIN_THREADS) dst[i] = src[i];
+            const uint32_t s0 = B.side_start[b], s1 = B.side_start[b + 1];
+            for (uint32_t i = tid; i < s1 - s0 && i < GBN_BIN_SIDE; i += GBN_BIN_THREADS) s_side[i] = B.sidet[s0 + i];
         }
         __syncthreads();
-        for (int w = wi; w < B.nwriters; w += nw) {
+        // one writer stream per wave at a time
+        for (int w = wi + nw * wave; w < B.nwriters; w += nw * (GBN_BIN_THREADS / 64)) {
             const uint32_t n = B.gcount[(size_t)b * B.nwriters + w];
             const unsigned long long *__restrict__ rec = B.rec + ((size_t)b * B.nwriters + w) * B.subcap;
-            for (uint32_t j0 = 0; j0 < n; j0 += GBN_BIN_THREADS * 8u) {
-                // 4 independent 16-byte loads (8 records) per lane in flight
-                ulonglong2 rr[4];
+            // software pipeline: the next 4 loads (8 records per lane) are in flight while the
+            // current 8 records are looked up
+            ulonglong2 cur[4], nxt[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t j = (uint32_t)u * 128u + (uint32_t)lane * 2u;
+                cur[u] = (j < n) ? *reinterpret_cast<const ulonglong2 *>(rec + j)
+                                 : make_ulonglong2(0xffffffffull, 0xffffffffull);
+            }
+            for (uint32_t j0 = 0; j0 < n; j0 += 64u * 8u) {
                 #pragma unroll
                 for (int u = 0; u < 4; u++) {
-                    const uint32_t j = j0 + (uint32_t)u * GBN_BIN_THREADS * 2u + (uint32_t)tid * 2u;
-                    rr[u] = (j < n) ? *reinterpret_cast<const ulonglong2 *>(rec + j)
-                                    : make_ulonglong2(0xffffffffull, 0xffffffffull);
+                    const uint32_t j = j0 + 512u + (uint32_t)u * 128u + (uint32_t)lane * 2u;
+                    nxt[u] = (j < n) ? *reinterpret_cast<const ulonglong2 *>(rec + j)
+                                     : make_ulonglong2(0xffffffffull, 0xffffffffull);
                 }
+                uint32_t tv[8];
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {                       // all LDS lookups first
+                    // a pad record has hi = 0: it reads cell 0 of the bin; its posid marks it below
+                    tv[2 * u] = (B.dbg & 8) ? 0u : s_tab[(uint32_t)(cur[u].x >> 46)];
+                    tv[2 * u + 1] = (B.dbg & 8) ? 0u : s_tab[(uint32_t)(cur[u].y >> 46)];
+                }
+                uint32_t raw32 = 0;
                 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     #pragma unroll
                     for (int h = 0; h < 2; h++) {
-                        const unsigned long long r = h ? rr[u].y : rr[u].x;
-                        const uint32_t posid = (uint32_t)r;
-                        bool slow = false; uint32_t cellv = 0;
-                        if (posid != 0xffffffffu) {
-                            const uint32_t hi32 = (uint32_t)(r >> 32);
-                            const uint32_t low = hi32 >> 14, sf = hi32 & 0x3fffu;
-                            const uint32_t t = s_tab[low];
-                            const uint32_t cls = t & 3u;
-                            if (cls == 3) slow = true;
-                            else if (cls != 0) {
-                                raw += cls;
-                                slow = rfp_pass((t >> 2) & 0x3fffu, sf, lmask, rmask, lany, rany) ||
-                                       (cls == 2 && rfp_pass((t >> 16) & 0x3fffu, sf, lmask, rmask, lany, rany));
-                            }
-                            // bit 31 of the queued cell word: "raw hits not counted yet" (class 3)
-                            cellv = (((uint32_t)b << cbits) | low) | (cls == 3 ? 0x80000000u : 0u);
-                        }
+                        const unsigned long long r = h ? cur[u].y : cur[u].x;
+                        const uint32_t posid = (uint32_t)r, hi32 = (uint32_t)(r >> 32);
+                        const uint32_t t = (posid == 0xffffffffu) ? 0u : tv[2 * u + h];
+                        const uint32_t cls = t & 3u, sf = hi32 & 0x3fffu;
+                        const uint32_t x1 = (t >> 2) ^ sf, x2 = (t >> 16) ^ sf;
+                        const bool pA = (((x1 >> 6) & lmask) == 0) | ((x1 & rmask) == 0);
+                        const bool pB = ((((x2 >> 6) & lmask) == 0) | ((x2 & rmask & 0x3fffu) == 0));
+                        const bool slow = ((cls == 1) & pA) | ((cls == 2) & (pA | pB)) | (cls == 3);
+                        raw32 += (cls == 3) ? 0u : cls;
                         const unsigned long long m = __ballot(slow);
                         if (m) {
-                            if (slow) { const int at = qn + __popcll(m & lt); q[at].x = posid; q[at].y = cellv; }
-                            qn += __popcll(m);
-                            if (qn >= 64) {                         // drain one dense batch
-                                qn -= 64;
-                                const uint32_t pid = q[qn + lane].x, cv = q[qn + lane].y;
-                                probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
+                            if (slow) {
+                                const int at = qn + __popcll(m & lt);
+                                q[at].x = posid;
+                                q[at].y = (hi32 >> 14) | (sf << 15) | ((cls == 3) ? 0x80000000u : 0u);
                             }
+                            qn += __popcll(m);
+                            if (qn >= 64) { qn -= 64; flush(qn, 64, b); }
                         }
                     }
                 }
+                raw += raw32;
+                #pragma unroll
+                for (int u = 0; u < 4; u++) cur[u] = nxt[u];
             }
         }
-    }
-    if (lane < qn) {
-        const uint32_t pid = q[lane].x, cv = q[lane].y;
-        probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
+        if (qn > 0) { flush(0, qn, b); qn = 0; }                    // the side list changes with the bin
     }
     if (P.raw_hits) {
         for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
         if (lane == 0 && raw) atomicAdd(P.raw_hits, raw);
+    }
+    __syncthreads();
+    if (tid == 0) B.rare_counts[blockIdx.x] = *s_rcount;
+}
+
+// rare path of the partitioned scan: one queued item per thread
+extern "C" __global__ void __launch_bounds__(256)
+probe_rare_kernel(GbnBinParams B, int nseg)
+{
+    const GbnScanParams &P = B.S;
+    unsigned long long raw = 0;
+    // blockIdx.x % nseg = segment (probe workgroup), blockIdx.x / nseg = part
+    const int seg = blockIdx.x % nseg, part = blockIdx.x / nseg, nparts = gridDim.x / nseg;
+    const uint32_t n = min(B.rare_counts[seg], B.rare_seg);
+    const GbnU2 *qs = B.rareq + (size_t)seg * B.rare_seg;
+    for (uint32_t i = (uint32_t)part * 256u + threadIdx.x; i < n; i += (uint32_t)nparts * 256u) {
+        const uint32_t pid = qs[i].x, cv = qs[i].y;
+        probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
+    }
+    if (P.raw_hits) {
+        for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
+        if ((threadIdx.x & 63) == 0 && raw) atomicAdd(P.raw_hits, raw);
     }
 }
 
@@ -907,7 +989,7 @@ hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st)
     hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_BIN_THREADS), 0, st, b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    const size_t lds = (size_t)GBN_BIN_CELLS * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8;
+    const size_t lds = (size_t)GBN_BIN_CELLS * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8 + (size_t)GBN_BIN_SIDE * 2 + 16;
     static bool attr_set = false;
     if (!attr_set) {
         e = hipFuncSetAttribute((const void *)probe_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -915,6 +997,9 @@ hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st)
         attr_set = true;
     }
     hipLaunchKernelGGL(probe_bin_kernel, dim3(grid2), dim3(GBN_BIN_THREADS), lds, st, b);
+    e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * 8), dim3(256), 0, st, b, grid2);
     return hipGetLastError();
 }
 }  // namespace gbn
