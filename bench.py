@@ -128,12 +128,18 @@ def main():
     seeds = sum(b.diagnostics.seeds for b in batches)
     lookup_hits = sum(b.diagnostics.lookup_hits for b in batches)
     algo_bytes = 0.25 * scanned
-    achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
+    bin_ms = sum(b.diagnostics.bin_kernel_ms for b in batches)
+    probe_ms = sum(b.diagnostics.probe_kernel_ms for b in batches)
+    rare_ms = sum(b.diagnostics.rare_kernel_ms for b in batches)
+    # dominant kernel: the binning kernel when the partitioned scan is used, else the direct scan
+    dom_name, dom_ms = ("scan_bin_kernel", bin_ms) if bin_ms > 0 else ("scan_seed_kernel", scan_ms)
+    achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    stage_achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
     tf = os.path.join(ROOT, "profiles", "scan_traffic.json")
     if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tf)).get(dom_name, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
@@ -161,11 +167,17 @@ def main():
                 "seeds_per_pass": seeds / max(launches, 1),
                 "lookup_hits_per_pass": lookup_hits / max(launches, 1),
             },
-            "roofline": {"bound": "hbm", "kernel": "scan_seed_kernel",
+            "roofline": {"bound": "hbm", "kernel": dom_name,
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
-                         "avg_launch_ms": scan_ms / max(launches, 1), "launches": launches},
+                         "avg_launch_ms": dom_ms / max(launches, 1), "launches": launches,
+                         "scan_stage": {"kernels": "scan_bin_kernel + probe_bin_kernel + probe_rare_kernel"
+                                        if bin_ms > 0 else "scan_seed_kernel",
+                                        "avg_ms": scan_ms / max(launches, 1),
+                                        "avg_ms_by_kernel": [bin_ms / max(launches, 1), probe_ms / max(launches, 1),
+                                                             rare_ms / max(launches, 1)],
+                                        "achieved": stage_achieved, "frac": stage_achieved / 8000.0}},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))

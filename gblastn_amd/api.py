@@ -43,7 +43,9 @@ class GbnDiagnostics(C.Structure):
                 ("good_init_extends", C.c_int64), ("gapped_extensions", C.c_int64),
                 ("good_extensions", C.c_int64), ("seqs_passed", C.c_int64), ("seeds", C.c_int64),
                 ("scan_kernel_ms", C.c_double), ("total_ms", C.c_double),
-                ("scan_launches", C.c_int64), ("subject_bases_scanned", C.c_int64)]
+                ("scan_launches", C.c_int64), ("subject_bases_scanned", C.c_int64),
+                ("bin_kernel_ms", C.c_double), ("probe_kernel_ms", C.c_double),
+                ("rare_kernel_ms", C.c_double)]
 
 
 HSP_DT = np.dtype([("oid", "<i4"), ("context", "<i4"), ("q_offset", "<i4"), ("q_end", "<i4"),

@@ -21,7 +21,7 @@
 
 namespace gbn {
 hipError_t launch_scan_seed(const GbnScanParams &p, int grid, hipStream_t st);
-hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st);
+hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev);
 hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st);
@@ -62,7 +62,7 @@ struct Engine {
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
     GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
     uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;   // [nb][nwriters] + overflow flag
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr, evk[4] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex mu;
 };
 static Engine E;
@@ -324,6 +324,7 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
         HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream));
         GbnScanParams P; fill_scan_params(P, b, db, ts);
         uint32_t overflow = 0;
+        bool binned = false;
         if (nb == 1) {
             HIPCHK(hipEventRecord(E.ev0, E.stream));
             HIPCHK(launch_scan_seed(P, scan_grid(ts.ntiles), E.stream));
@@ -353,6 +354,7 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
             B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfr = std::min(3, b.dev->fr);
             B.rec = E.bin_rec; B.gcount = E.bin_count; B.subcap = (uint32_t)subcap;
             B.overflow = E.bin_count + nstream;
+            if (const char *e = getenv("GBN_DBG")) B.dbg = atoi(e);
             int grid2 = std::max(8, E.num_cu & ~7);   // one 1024-thread workgroup per CU; group = blockIdx & 7
             {   // rare-path queue: one segment per probe workgroup (~1.2 % of scan positions in total)
                 size_t seg = std::max<size_t>(rare_seg_hint, (size_t)(npos / 40 / grid2) + 4096);
@@ -367,7 +369,8 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
                 B.rareq = E.rareq; B.rare_seg = (uint32_t)std::min<size_t>(seg, 0x7fffffff); B.rare_counts = E.rare_counts;
             }
             HIPCHK(hipEventRecord(E.ev0, E.stream));
-            HIPCHK(launch_scan_bin(B, grid2, E.stream));
+            HIPCHK(launch_scan_bin(B, grid2, E.stream, E.evk));
+            binned = true;
             HIPCHK(hipEventRecord(E.ev1, E.stream));
             HIPCHK(hipMemcpyAsync(&overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
         }
@@ -376,6 +379,12 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
         if (diag) {
             float ms = 0; (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
             diag->scan_kernel_ms += ms; diag->scan_launches++;
+            if (binned) {
+                float a = 0, c = 0, r = 0;
+                (void)hipEventElapsedTime(&a, E.evk[0], E.evk[1]); (void)hipEventElapsedTime(&c, E.evk[1], E.evk[2]);
+                (void)hipEventElapsedTime(&r, E.evk[2], E.evk[3]);
+                diag->bin_kernel_ms += a; diag->probe_kernel_ms += c; diag->rare_kernel_ms += r;
+            }
         }
         if (nb > 1) {
             const int grid2 = std::max(8, E.num_cu & ~7);
@@ -569,6 +578,7 @@ int Blast_gpu_Init(int use_gpu, int gpu_id) {
     E.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&E.stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&E.ev0)); HIPCHK(hipEventCreate(&E.ev1));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&E.evk[i]));
     HIPCHK(hipMalloc((void **)&E.counters, 8 * sizeof(unsigned long long)));
     E.device = dev; E.ready = true;
     return GBN_OK;

@@ -777,7 +777,11 @@ scan_bin_kernel(GbnBinParams B)
             a.y = (l1 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.y << 32) | (tbase | l1));
             c.x = (l2 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.z << 32) | (tbase | l2));
             c.y = (l3 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.w << 32) | (tbase | l3));
-            if (w + 4u <= B.subcap && !(B.dbg & 2)) {
+            if (B.dbg & 16) {   // ablation: same bytes, written as one linear stream per workgroup
+                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(B.rec + (size_t)blockIdx.x * B.subcap * (size_t)nb
+                                  + ((size_t)(tile / gridDim.x) * GBN_BIN_STAGE + 4u * g) % ((size_t)B.subcap * nb - 8));
+                dst[0] = a; dst[1] = c;
+            } else if (w + 4u <= B.subcap && !(B.dbg & 2)) {
                 ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(B.rec + ((size_t)b * B.nwriters + blockIdx.x) * B.subcap + w);
                 dst[0] = a; dst[1] = c;
             }
@@ -983,12 +987,15 @@ probe_rare_kernel(GbnBinParams B, int nseg)
 }
 
 namespace gbn {
-hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st)
+hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev)
 {
+    // ev[0..3]: before bin, after bin, after probe, after rare (optional)
     if (b.S.ntiles <= 0) return hipSuccess;
+    if (ev) (void)hipEventRecord(ev[0], st);
     hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_BIN_THREADS), 0, st, b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (ev) (void)hipEventRecord(ev[1], st);
     const size_t lds = (size_t)GBN_BIN_CELLS * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8 + (size_t)GBN_BIN_SIDE * 2 + 16;
     static bool attr_set = false;
     if (!attr_set) {
@@ -999,7 +1006,10 @@ hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st)
     hipLaunchKernelGGL(probe_bin_kernel, dim3(grid2), dim3(GBN_BIN_THREADS), lds, st, b);
     e = hipGetLastError();
     if (e != hipSuccess) return e;
+    if (ev) (void)hipEventRecord(ev[2], st);
     if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * 8), dim3(256), 0, st, b, grid2);
-    return hipGetLastError();
+    e = hipGetLastError();
+    if (ev) (void)hipEventRecord(ev[3], st);
+    return e;
 }
 }  // namespace gbn

@@ -116,6 +116,8 @@ typedef struct GbnDiagnostics {
     double  total_ms;               /* wall time of the whole call */
     int64_t scan_launches;
     int64_t subject_bases_scanned;
+    /* partitioned scan, per kernel (HIP events on the engine's stream) */
+    double  bin_kernel_ms, probe_kernel_ms, rare_kernel_ms;
 } GbnDiagnostics;
 
 typedef int (*GbnInterruptFn)(void *progress);   /* TInterruptFnPtr analogue */
