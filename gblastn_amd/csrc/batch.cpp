@@ -193,9 +193,6 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
     if (gapped_karlin(opt.gap_open, opt.gap_extend, opt.reward, opt.penalty, first, b.kbp_gap, b.round_down)) {
         set_error("unsupported reward/penalty/gap cost combination"); return GBN_ERR_UNSUPPORTED;
     }
-    if (opt.greedy && !(opt.gap_open == 0 && opt.gap_extend == 0)) {
-        set_error("affine greedy extension is not implemented yet"); return GBN_ERR_UNSUPPORTED;
-    }
     b.gap_x_dropoff = (int32_t)(opt.xdrop_gap_bits * kLn2 / b.kbp_gap.lambda);
     b.gap_x_dropoff_final = (int32_t)std::max(opt.xdrop_gap_final_bits * kLn2 / b.kbp_gap.lambda,
                                                (double)b.gap_x_dropoff);

@@ -490,6 +490,17 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         int32_t xoff = (X2 + mc / 2) / (mc + mm) + 1;
         G.row_len = 2 * max_dist + 8;
         per_thread = 2 * (size_t)G.row_len + (size_t)max_dist + 4 + (size_t)xoff;
+        if (!(b.opt.gap_open == 0 && b.opt.gap_extend == 0)) {
+            // affine greedy: (max_penalty + 1) rows of 3 offsets, diagonal bounds and max_score per scaled distance
+            int32_t go = b.opt.gap_open, ge = b.opt.gap_extend;
+            if (b.opt.reward % 2 == 1) { go *= 2; ge *= 2; }
+            int32_t half = mc / 2, opc = mc + mm, gex = ge + half;
+            auto gcd2 = [](int a, int c) { c = std::abs(c); if (c > a) std::swap(a, c); while (c) { int t = a % c; a = c; c = t; } return a; };
+            int32_t g = go == 0 ? gcd2(opc, gex) : gcd2(opc, gcd2(go, gex));
+            if (g > 1) { opc /= g; go /= g; gex /= g; }
+            int32_t max_penalty = std::max(opc, go + gex), scaled = max_dist * gex, xo = (X2 + half) / g + 1;
+            per_thread = (size_t)(max_penalty + 1) * G.row_len * 3 + 2 * (size_t)(scaled + 1 + max_penalty) + (size_t)scaled + 4 + xo;
+        }
     } else {
         G.row_len = 0;
         per_thread = 2 * ((size_t)max_ctx + 16);

@@ -447,6 +447,104 @@ __device__ int32_t greedy_linear(const uint8_t *q, int32_t len1, const uint8_t *
 }
 }  // namespace
 
+namespace {
+struct GOff { int32_t insert_off, match_off, delete_off; };
+
+__device__ int gcd_dev(int a, int b) { b = abs(b); if (b > a) { int c = a; a = b; b = c; } while (b) { int c = a % b; a = b; b = c; } return a; }
+
+// affine greedy (BLAST_AffineGreedyAlign, CORE/greedy_align.c:755-1236), score only.
+// scratch: rows[(max_penalty+1) * row_len] GOff, bounds[2 * (scaled_max + 1 + max_penalty)], max_score
+__device__ int32_t greedy_affine(const uint8_t *q, int32_t len1, const uint8_t *subj, int32_t s_base, int32_t len2,
+                                 bool reverse, int32_t xdrop, int32_t match_score, int32_t mismatch_score,
+                                 int32_t in_gap_open, int32_t in_gap_extend, int32_t *l1, int32_t *l2, GSeed &seed,
+                                 int32_t *scratch, int32_t row_len_alloc)
+{
+    const int32_t kInvalid = -2, kInvalidDiag = 100000000;
+    const int32_t half = match_score / 2;
+    int32_t op_cost = match_score + mismatch_score, gap_open = in_gap_open, gap_extend = in_gap_extend + half;
+    int32_t g = (gap_open == 0) ? gcd_dev(op_cost, gap_extend) : gcd_dev(op_cost, gcd_dev(gap_open, gap_extend));
+    if (g > 1) { op_cost /= g; gap_open /= g; gap_extend /= g; }
+    const int32_t scf = g, goe = gap_open + gap_extend, max_penalty = max(op_cost, goe);
+    const int32_t max_dist = min(10000, len2 / 2 + 1), scaled_max = max_dist * gap_extend;
+    const int32_t diag_origin = max_dist + 2;
+    const int32_t xoff = (xdrop + half) / scf + 1;
+    int32_t index = reverse ? match_run_rev(q, subj, len1, len2, 0, 0) : match_run_fwd(q, subj, len1, len2, 0, 0, s_base);
+    *l1 = index; *l2 = index;
+    int32_t seq1_index = index, seq2_index, best_dist = 0, best_diag = 0, longest = index;
+    seed.start_q = 0; seed.start_s = 0; seed.match_length = index;
+    if (index == len1 || index == len2) return index * match_score;
+    const int32_t nrows = max_penalty + 1;
+    GOff *rows = reinterpret_cast<GOff *>(scratch);
+    int32_t *bounds = scratch + (size_t)nrows * row_len_alloc * 3;
+    int32_t *diag_lower = bounds, *diag_upper = bounds + scaled_max + 1 + max_penalty;
+    int32_t *msb = bounds + 2 * (size_t)(scaled_max + 1 + max_penalty);
+    int32_t *max_score = msb + xoff;
+    for (int32_t t = 0; t < xoff; t++) msb[t] = 0;
+    for (int32_t t = 0; t < max_penalty; t++) { diag_lower[t] = kInvalidDiag; diag_upper[t] = -kInvalidDiag; }
+    diag_lower += max_penalty; diag_upper += max_penalty;
+#define GROW(dd) (rows + (size_t)((dd) % nrows) * row_len_alloc)
+    GROW(0)[diag_origin].match_off = seq1_index; GROW(0)[diag_origin].insert_off = kInvalid; GROW(0)[diag_origin].delete_off = kInvalid;
+    max_score[0] = seq1_index * match_score;
+    diag_lower[0] = diag_origin; diag_upper[0] = diag_origin;
+    int32_t cdl = diag_origin - 1, cdu = diag_origin + 1, end1_diag = 0, end2_diag = 0, nonempty = 1, d = 1;
+    while (d <= scaled_max) {
+        int32_t curr_extent = 0, curr_seq2 = 0, curr_diag = 0;
+        const int32_t tl = cdl, tu = cdu;
+        GOff *cur = GROW(d);
+        int32_t xs = max_score[d - xoff] + scf * d - xdrop;
+        xs = (int32_t)ceil((double)xs / (double)half);
+        if (xs < 0) xs = 0;
+        for (int32_t k = tl; k <= tu; k++) {
+            seq2_index = kInvalid;
+            if (k + 1 <= diag_upper[d - goe] && k + 1 >= diag_lower[d - goe]) seq2_index = GROW(d - goe)[k + 1].match_off;
+            if (k + 1 <= diag_upper[d - gap_extend] && k + 1 >= diag_lower[d - gap_extend] &&
+                seq2_index < GROW(d - gap_extend)[k + 1].delete_off) seq2_index = GROW(d - gap_extend)[k + 1].delete_off;
+            cur[k].delete_off = (seq2_index == kInvalid) ? kInvalid : seq2_index + 1;
+            seq2_index = kInvalid;
+            if (k - 1 <= diag_upper[d - goe] && k - 1 >= diag_lower[d - goe]) seq2_index = GROW(d - goe)[k - 1].match_off;
+            if (k - 1 <= diag_upper[d - gap_extend] && k - 1 >= diag_lower[d - gap_extend] &&
+                seq2_index < GROW(d - gap_extend)[k - 1].insert_off) seq2_index = GROW(d - gap_extend)[k - 1].insert_off;
+            cur[k].insert_off = seq2_index;
+            seq2_index = max(cur[k].insert_off, cur[k].delete_off);
+            if (k <= diag_upper[d - op_cost] && k >= diag_lower[d - op_cost])
+                seq2_index = max(seq2_index, GROW(d - op_cost)[k].match_off + 1);
+            seq1_index = seq2_index + k - diag_origin;
+            if (seq2_index < 0 || seq1_index + seq2_index < xs) {
+                if (k == cdl) cdl++; else cur[k].match_off = kInvalid;
+                continue;
+            }
+            cdu = k;
+            index = reverse ? match_run_rev(q, subj, len1, len2, seq1_index, seq2_index)
+                            : match_run_fwd(q, subj, len1, len2, seq1_index, seq2_index, s_base);
+            if (index > longest) { seed.start_q = seq1_index; seed.start_s = seq2_index; seed.match_length = longest = index; }
+            seq1_index += index; seq2_index += index;
+            cur[k].match_off = seq2_index;
+            if (seq1_index + seq2_index > curr_extent) { curr_extent = seq1_index + seq2_index; curr_seq2 = seq2_index; curr_diag = k; }
+            if (seq1_index == len1) { cdu = k; end1_diag = k - 1; }
+            if (seq2_index == len2) { cdl = k; end2_diag = k + 1; }
+        }
+        const int32_t curr_score = curr_extent * half - d * scf;
+        if (curr_score > max_score[d - 1]) {
+            max_score[d] = curr_score; best_dist = d; best_diag = curr_diag;
+            *l2 = curr_seq2; *l1 = curr_seq2 + best_diag - diag_origin;
+        } else max_score[d] = max_score[d - 1];
+        if (cdl <= cdu) { nonempty++; diag_lower[d] = cdl; diag_upper[d] = cdu; }
+        else { diag_lower[d] = kInvalidDiag; diag_upper[d] = -kInvalidDiag; }
+        if (diag_lower[d - max_penalty] <= diag_upper[d - max_penalty]) nonempty--;
+        if (nonempty == 0) break;
+        d++;
+        cdl = min(diag_lower[d - goe], diag_lower[d - gap_extend]) - 1;
+        cdl = min(cdl, diag_lower[d - op_cost]);
+        if (end2_diag > 0) cdl = max(cdl, end2_diag);
+        cdu = max(diag_upper[d - goe], diag_upper[d - gap_extend]) + 1;
+        cdu = max(cdu, diag_upper[d - op_cost]);
+        if (end1_diag > 0) cdu = min(cdu, end1_diag);
+    }
+#undef GROW
+    return max_score[best_dist];
+}
+}  // namespace
+
 extern "C" __global__ void greedy_kernel(GbnGapParams P)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -467,9 +565,18 @@ extern "C" __global__ void greedy_kernel(GbnGapParams P)
     int32_t mc = reward, mm = pen;
     if (mc % 2 == 1) { mc *= 2; mm *= 2; X *= 2; }
     int32_t qr, sr, ql, sl; GSeed fwd, rev;
-    int32_t dist = greedy_linear(q + q_off, qlen - q_off, subj, s_off, slen - s_off, false, X, mc, mm, &qr, &sr, fwd, row0, row1, msb);
-    dist += greedy_linear(q, q_off, subj, 0, s_off, true, X, mc, mm, &ql, &sl, rev, row0, row1, msb);
-    int32_t score = (qr + sr + ql + sl) * reward / 2 - dist * (reward - P.penalty);
+    int32_t score;
+    if (P.gap_open == 0 && P.gap_extend == 0) {
+        int32_t dist = greedy_linear(q + q_off, qlen - q_off, subj, s_off, slen - s_off, false, X, mc, mm, &qr, &sr, fwd, row0, row1, msb);
+        dist += greedy_linear(q, q_off, subj, 0, s_off, true, X, mc, mm, &ql, &sl, rev, row0, row1, msb);
+        score = (qr + sr + ql + sl) * reward / 2 - dist * (reward - P.penalty);
+    } else {
+        int32_t go = P.gap_open, ge = P.gap_extend;
+        if (reward % 2 == 1) { go *= 2; ge *= 2; }
+        score = greedy_affine(q + q_off, qlen - q_off, subj, s_off, slen - s_off, false, X, mc, mm, go, ge, &qr, &sr, fwd, scratch, P.row_len);
+        score += greedy_affine(q, q_off, subj, 0, s_off, true, X, mc, mm, go, ge, &ql, &sl, rev, scratch, P.row_len);
+        if (reward % 2 == 1) score /= 2;
+    }
     int32_t q_box_l = q_off - ql, s_box_l = s_off - sl, q_box_r = q_off + qr, s_box_r = s_off + sr;
     int32_t qsl = q_off - rev.start_q, ssl = s_off - rev.start_s;
     int32_t qsr = q_off + fwd.start_q, ssr = s_off + fwd.start_s;

@@ -119,23 +119,151 @@ static int32_t greedy_linear(const uint8_t *seq1, int32_t len1, const uint8_t *s
     return best_dist;
 }
 
-/* CORE/greedy_align.c:755-815 (BLAST_AffineGreedyAlign entry): doubling of odd
- * match scores and dispatch.  Only the non-affine branch (gap 0/0, the
- * megablast default) is restated; affine greedy returns -1. */
+/* CORE/greedy_align.c:755-1236 (BLAST_AffineGreedyAlign), score-only path:
+ * three furthest-reaching offsets (match / insert / delete) per diagonal and
+ * distance, rows reused with period max_penalty + 1. */
+typedef struct { int32_t insert_off, match_off, delete_off; } GOff;
+
+static int32_t greedy_affine(const uint8_t *seq1, int32_t len1, const uint8_t *seq2, int32_t len2,
+                             int reverse, int32_t xdrop_threshold, int32_t match_score,
+                             int32_t mismatch_score, int32_t in_gap_open, int32_t in_gap_extend,
+                             int32_t *seq1_align_len, int32_t *seq2_align_len, int rem, GSeed *seed)
+{
+    int32_t seq1_index, seq2_index, index, d, k;
+    int32_t max_dist, scaled_max_dist, diag_origin, best_dist = 0, best_diag = 0;
+    int32_t longest_match_run, xdrop_offset, end1_diag, end2_diag;
+    int32_t op_cost, gap_open, gap_extend, gap_open_extend, max_penalty, score_common_factor;
+    int32_t match_score_half, curr_diag_lower, curr_diag_upper, num_nonempty_dist, result;
+    int32_t *bounds, *diag_lower, *diag_upper, *max_score_base, *max_score;
+    GOff *rows; int32_t row_len, nrows;
+    const int32_t kInvalidDiag = 100000000;
+#define ROW(dd) (rows + (size_t)((dd) % nrows) * row_len)
+
+    match_score_half = match_score / 2;
+    op_cost = match_score + mismatch_score;
+    gap_open = in_gap_open;
+    gap_extend = in_gap_extend + match_score_half;
+    score_common_factor = orc_gdb3(&op_cost, &gap_open, &gap_extend);
+    gap_open_extend = gap_open + gap_extend;
+    max_penalty = ORC_MAX(op_cost, gap_open_extend);
+    max_dist = ORC_MIN(GREEDY_MAX_COST, len2 / GREEDY_MAX_COST_FRACTION + 1);
+    scaled_max_dist = max_dist * gap_extend;
+    diag_origin = max_dist + 2;
+    xdrop_offset = (xdrop_threshold + match_score_half) / score_common_factor + 1;
+
+    index = first_mismatch(seq1, seq2, len1, len2, 0, 0, reverse, rem);
+    *seq1_align_len = index; *seq2_align_len = index;
+    seq1_index = index;
+    seed->start_q = 0; seed->start_s = 0;
+    seed->match_length = longest_match_run = index;
+    if (index == len1 || index == len2) return index * match_score;
+
+    nrows = max_penalty + 1; row_len = 2 * max_dist + 6;
+    rows = (GOff *)malloc((size_t)nrows * row_len * sizeof(GOff));
+    bounds = (int32_t *)malloc((size_t)2 * (scaled_max_dist + 1 + max_penalty) * sizeof(int32_t));
+    max_score_base = (int32_t *)malloc((size_t)(scaled_max_dist + 2 + xdrop_offset) * sizeof(int32_t));
+    max_score = max_score_base + xdrop_offset;
+    for (index = 0; index < xdrop_offset; index++) max_score_base[index] = 0;
+    diag_lower = bounds; diag_upper = bounds + scaled_max_dist + 1 + max_penalty;
+    for (index = 0; index < max_penalty; index++) { diag_lower[index] = kInvalidDiag; diag_upper[index] = -kInvalidDiag; }
+    diag_lower += max_penalty; diag_upper += max_penalty;
+
+    ROW(0)[diag_origin].match_off = seq1_index;
+    ROW(0)[diag_origin].insert_off = kInvalidOffset;
+    ROW(0)[diag_origin].delete_off = kInvalidOffset;
+    max_score[0] = seq1_index * match_score;
+    diag_lower[0] = diag_origin; diag_upper[0] = diag_origin;
+    curr_diag_lower = diag_origin - 1; curr_diag_upper = diag_origin + 1;
+    end1_diag = 0; end2_diag = 0; num_nonempty_dist = 1; d = 1;
+
+    while (d <= scaled_max_dist) {
+        int32_t xdrop_score, curr_score, curr_extent = 0, curr_seq2_index = 0, curr_diag = 0;
+        int32_t tmp_diag_lower = curr_diag_lower, tmp_diag_upper = curr_diag_upper;
+        GOff *cur = ROW(d);
+        xdrop_score = max_score[d - xdrop_offset] + score_common_factor * d - xdrop_threshold;
+        xdrop_score = (int32_t)ceil((double)xdrop_score / match_score_half);
+        if (xdrop_score < 0) xdrop_score = 0;
+        for (k = tmp_diag_lower; k <= tmp_diag_upper; k++) {
+            seq2_index = kInvalidOffset;
+            if (k + 1 <= diag_upper[d - gap_open_extend] && k + 1 >= diag_lower[d - gap_open_extend])
+                seq2_index = ROW(d - gap_open_extend)[k + 1].match_off;
+            if (k + 1 <= diag_upper[d - gap_extend] && k + 1 >= diag_lower[d - gap_extend] &&
+                seq2_index < ROW(d - gap_extend)[k + 1].delete_off)
+                seq2_index = ROW(d - gap_extend)[k + 1].delete_off;
+            if (seq2_index == kInvalidOffset) cur[k].delete_off = kInvalidOffset;
+            else cur[k].delete_off = seq2_index + 1;
+
+            seq2_index = kInvalidOffset;
+            if (k - 1 <= diag_upper[d - gap_open_extend] && k - 1 >= diag_lower[d - gap_open_extend])
+                seq2_index = ROW(d - gap_open_extend)[k - 1].match_off;
+            if (k - 1 <= diag_upper[d - gap_extend] && k - 1 >= diag_lower[d - gap_extend] &&
+                seq2_index < ROW(d - gap_extend)[k - 1].insert_off)
+                seq2_index = ROW(d - gap_extend)[k - 1].insert_off;
+            cur[k].insert_off = seq2_index;
+
+            seq2_index = ORC_MAX(cur[k].insert_off, cur[k].delete_off);
+            if (k <= diag_upper[d - op_cost] && k >= diag_lower[d - op_cost])
+                seq2_index = ORC_MAX(seq2_index, ROW(d - op_cost)[k].match_off + 1);
+            seq1_index = seq2_index + k - diag_origin;
+            if (seq2_index < 0 || seq1_index + seq2_index < xdrop_score) {
+                if (k == curr_diag_lower) curr_diag_lower++;
+                else cur[k].match_off = kInvalidOffset;
+                continue;
+            }
+            curr_diag_upper = k;
+            index = first_mismatch(seq1, seq2, len1, len2, seq1_index, seq2_index, reverse, rem);
+            if (index > longest_match_run) {
+                seed->start_q = seq1_index; seed->start_s = seq2_index;
+                seed->match_length = longest_match_run = index;
+            }
+            seq1_index += index; seq2_index += index;
+            cur[k].match_off = seq2_index;
+            if (seq1_index + seq2_index > curr_extent) {
+                curr_extent = seq1_index + seq2_index; curr_seq2_index = seq2_index; curr_diag = k;
+            }
+            if (seq1_index == len1) { curr_diag_upper = k; end1_diag = k - 1; }
+            if (seq2_index == len2) { curr_diag_lower = k; end2_diag = k + 1; }
+        }
+        curr_score = curr_extent * match_score_half - d * score_common_factor;
+        if (curr_score > max_score[d - 1]) {
+            max_score[d] = curr_score; best_dist = d; best_diag = curr_diag;
+            *seq2_align_len = curr_seq2_index;
+            *seq1_align_len = curr_seq2_index + best_diag - diag_origin;
+        } else max_score[d] = max_score[d - 1];
+        if (curr_diag_lower <= curr_diag_upper) {
+            num_nonempty_dist++; diag_lower[d] = curr_diag_lower; diag_upper[d] = curr_diag_upper;
+        } else { diag_lower[d] = kInvalidDiag; diag_upper[d] = -kInvalidDiag; }
+        if (diag_lower[d - max_penalty] <= diag_upper[d - max_penalty]) num_nonempty_dist--;
+        if (num_nonempty_dist == 0) break;
+        d++;
+        curr_diag_lower = ORC_MIN(diag_lower[d - gap_open_extend], diag_lower[d - gap_extend]) - 1;
+        curr_diag_lower = ORC_MIN(curr_diag_lower, diag_lower[d - op_cost]);
+        if (end2_diag > 0) curr_diag_lower = ORC_MAX(curr_diag_lower, end2_diag);
+        curr_diag_upper = ORC_MAX(diag_upper[d - gap_open_extend], diag_upper[d - gap_extend]) + 1;
+        curr_diag_upper = ORC_MAX(curr_diag_upper, diag_upper[d - op_cost]);
+        if (end1_diag > 0) curr_diag_upper = ORC_MIN(curr_diag_upper, end1_diag);
+    }
+    result = max_score[best_dist];
+    free(rows); free(bounds); free(max_score_base);
+#undef ROW
+    return result;
+}
+
+/* CORE/greedy_align.c:795-815: doubling of odd match scores and dispatch */
 static int32_t greedy_dispatch(const uint8_t *seq1, int32_t len1, const uint8_t *seq2, int32_t len2,
                                int reverse, int32_t xdrop, int32_t match_score, int32_t mismatch_score,
                                int32_t gap_open, int32_t gap_extend, int32_t *l1, int32_t *l2,
                                int rem, GSeed *seed, int *unsupported)
 {
+    (void)unsupported;
     if (match_score % 2 == 1) {
         match_score *= 2; mismatch_score *= 2; xdrop *= 2; gap_open *= 2; gap_extend *= 2;
     }
     if (gap_open == 0 && gap_extend == 0)
         return greedy_linear(seq1, len1, seq2, len2, reverse, xdrop, match_score,
                              mismatch_score, l1, l2, rem, seed);
-    *unsupported = 1;
-    *l1 = *l2 = 0; seed->start_q = seed->start_s = seed->match_length = 0;
-    return 0;
+    return greedy_affine(seq1, len1, seq2, len2, reverse, xdrop, match_score, mismatch_score,
+                         gap_open, gap_extend, l1, l2, rem, seed);
 }
 
 /* CORE/blast_gapalign.c:2619-2751 (BLAST_GreedyGappedAlignment), compressed

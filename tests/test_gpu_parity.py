@@ -59,6 +59,13 @@ def test_megablast_mb_lut12():
     assert nh >= 1
 
 
+@pytest.mark.parametrize("go,ge", [(2, 2), (1, 2), (0, 2), (3, 1), (1, 1)])
+def test_megablast_affine_greedy(go, ge):
+    # BLAST_AffineGreedyAlign: every affine gap cost of the 1/-2 table
+    nh, plants = run_case(6, 100_000, 12, gap_open=go, gap_extend=ge)
+    assert nh >= 1
+
+
 def test_blastn_small_lut8_stride4():
     nh, _ = run_case(4, 60_000, 2, task="blastn", planted_fraction=1.0,
                      expect=dict(lut_type=1, lut_width=8, scan_step=4, container=0))

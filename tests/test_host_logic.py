@@ -50,9 +50,9 @@ def test_unsupported_options_are_errors_not_fallbacks():
     q = [np.zeros(100, dtype=np.uint8)]
     with pytest.raises(api.BlastError):
         api.BlastPrelimSearch(q, api.default_options("megablast", reward=2, penalty=-1), upload=False)
-    with pytest.raises(api.BlastError):     # affine greedy is not implemented: loud, not silent
+    with pytest.raises(api.BlastError):     # gap costs outside the Karlin-Altschul tables
         api.BlastPrelimSearch([np.arange(100, dtype=np.uint8) % 4],
-                              api.default_options("megablast", gap_open=2, gap_extend=2), upload=False)
+                              api.default_options("megablast", gap_open=1, gap_extend=3), upload=False)
 
 
 def test_c_abi_exports_every_declared_symbol():

@@ -194,3 +194,29 @@ def test_lookup_table_choice_thresholds():
     assert choice(False, 2) == (1, 8, 4, 0)
     assert choice(False, 8) == (3, 11, 1, 1)
     assert choice(False, 8, lut11_gblastn_rule=0) == (3, 10, 2, 1)
+
+
+def test_affine_greedy_reduces_to_linear_when_costs_coincide():
+    # no offline golden exists for BLAST_AffineGreedyAlign (UT/bl2seq_unit_test.cpp:1575 needs
+    # GenBank).  Cross-check of the two restated code paths: with reward 2 / penalty -4 the
+    # non-affine greedy charges reward/2 - penalty = 5 per gap base, so the affine routine
+    # with gap_open 0 / gap_extend 5 must return the same box, score and seed.
+    L = orc.lib()
+    rng = np.random.default_rng(11)
+    for trial in range(20):
+        subj = rng.integers(0, 4, 3000, dtype=np.uint8)
+        q = subj[500:2300].copy()
+        for _ in range(25):
+            p = int(rng.integers(5, len(q) - 5)); q[p] = (q[p] + 1) & 3
+        for _ in range(6):
+            p = int(rng.integers(5, len(q) - 5))
+            q = np.delete(q, p) if rng.random() < 0.5 else np.insert(q, p, rng.integers(0, 4))
+        packed = orc.pack_ncbi2na(subj)
+        qa = np.ascontiguousarray(q, dtype=np.uint8)
+        a, b = orc.OrcHSP(), orc.OrcHSP()
+        assert L.orc_greedy_extend(qa.ctypes.data, len(qa), packed.ctypes.data, len(subj), 900, 1400, 30,
+                                   2, -4, 0, 0, C.byref(a)) == 0
+        assert L.orc_greedy_extend(qa.ctypes.data, len(qa), packed.ctypes.data, len(subj), 900, 1400, 30,
+                                   2, -4, 0, 5, C.byref(b)) == 0
+        for f in ["q_offset", "q_end", "s_offset", "s_end", "score", "q_gapped_start", "s_gapped_start"]:
+            assert getattr(a, f) == getattr(b, f), (trial, f, getattr(a, f), getattr(b, f))
