@@ -95,8 +95,9 @@ def main():
     def one_pass(step):
         b = batches[step % nbatch]
         out = b.run()
-        hs = shard.gather_records(out["hsps"], dst=0, device=dev)
-        return b, hs
+        # exchange + merge step: gather to rank 0, replay through the per-query top-N collector
+        got = shard.collect_on_root(out["hsps"], len(b._q), opt.hitlist_size, dst=0, device=dev)
+        return b, (got[0] if got is not None else None)
 
     def sync():
         if world > 1:

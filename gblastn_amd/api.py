@@ -64,7 +64,10 @@ EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_de
            "gbn_results_free", "gbn_results_clear", "gbn_results_num_hsps", "gbn_results_hsps",
            "gbn_results_num_seeds", "gbn_results_seeds", "gbn_results_num_init_hits",
            "gbn_results_init_hits", "gbn_prelim_search", "gbn_scan_only", "gbn_last_error",
-           "gbn_launch_scan_seed", "gbn_launch_ungapped", "gbn_launch_gapped"]
+           "gbn_launch_scan_seed", "gbn_launch_ungapped", "gbn_launch_gapped",
+           "gbn_prelim_hitlist_size", "gbn_collector_new", "gbn_collector_free", "gbn_collector_write",
+           "gbn_collector_close", "gbn_collector_num_lists", "gbn_collector_list_starts",
+           "gbn_collector_list_queries", "gbn_collector_num_hsps", "gbn_collector_hsps"]
 
 _LIB = None
 
@@ -105,6 +108,15 @@ def lib():
         L.gbn_prelim_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(GbnDiagnostics), C.c_int, C.c_void_p, C.c_void_p]
         L.gbn_scan_only.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(GbnDiagnostics)]
+        L.gbn_prelim_hitlist_size.restype = C.c_int32; L.gbn_prelim_hitlist_size.argtypes = [C.c_int32]
+        L.gbn_collector_new.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32]
+        L.gbn_collector_free.argtypes = [C.c_void_p]
+        L.gbn_collector_write.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        L.gbn_collector_close.argtypes = [C.c_void_p]
+        for nm in ["gbn_collector_num_lists", "gbn_collector_num_hsps"]:
+            getattr(L, nm).restype = C.c_int64; getattr(L, nm).argtypes = [C.c_void_p]
+        for nm in ["gbn_collector_list_starts", "gbn_collector_list_queries", "gbn_collector_hsps"]:
+            getattr(L, nm).restype = C.c_void_p; getattr(L, nm).argtypes = [C.c_void_p]
         _LIB = L
     return _LIB
 
@@ -255,5 +267,41 @@ class BlastPrelimSearch:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class BlastHSPCollector:
+    """The HSP stream's collector writer (BlastHSPStreamWrite / Blast_HitListUpdate analogue):
+    keeps, per query, the best min(2N, N+50) subjects.  Host only."""
+
+    def __init__(self, num_queries, hitlist_size=500):
+        self._c = C.c_void_p()
+        _check(lib().gbn_collector_new(C.byref(self._c), num_queries, hitlist_size))
+
+    def write(self, hsps):
+        """hsps: HSP_DT records grouped by oid (what BlastPrelimSearch.run() returns)."""
+        h = np.ascontiguousarray(hsps, dtype=HSP_DT)
+        _check(lib().gbn_collector_write(self._c, h.ctypes.data, len(h)))
+
+    def close(self):
+        """-> (hsps, list_starts, list_queries): surviving lists in (oid, query) ascending order."""
+        L = lib()
+        _check(L.gbn_collector_close(self._c))
+        nl, nh = L.gbn_collector_num_lists(self._c), L.gbn_collector_num_hsps(self._c)
+        starts = np.frombuffer(C.string_at(L.gbn_collector_list_starts(self._c), (nl + 1) * 8), dtype="<i8").copy()
+        queries = (np.frombuffer(C.string_at(L.gbn_collector_list_queries(self._c), nl * 4), dtype="<i4").copy()
+                   if nl else np.zeros(0, dtype="<i4"))
+        hsps = (np.frombuffer(C.string_at(L.gbn_collector_hsps(self._c), nh * HSP_DT.itemsize), dtype=HSP_DT).copy()
+                if nh else np.zeros(0, dtype=HSP_DT))
+        return hsps, starts, queries
+
+    def free(self):
+        if self._c:
+            lib().gbn_collector_free(self._c); self._c = None
+
+    def __del__(self):
+        try:
+            self.free()
         except Exception:
             pass

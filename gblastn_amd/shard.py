@@ -48,3 +48,21 @@ def gather_records(records, dst=0, device=None, group=None):
         return cat.view(records.dtype)
     dist.gather(buf, None, dst=dst, group=group)
     return None
+
+
+def collect_on_root(records, num_queries, hitlist_size, dst=0, device=None, group=None):
+    """One query batch's exchange + merge step: gather every shard's preliminary HSP records to
+    `dst` and replay them there, in ascending global OID order, through the per-query top-N
+    collector (CORE/blast_hspstream.c:316-365 is the reference's merge point).
+
+    Returns (hsps, list_starts, list_queries) on `dst`, None elsewhere."""
+    from . import api
+    merged = gather_records(records, dst=dst, device=device, group=group)
+    if merged is None:
+        return None
+    col = api.BlastHSPCollector(num_queries, hitlist_size)
+    try:
+        col.write(merged)
+        return col.close()
+    finally:
+        col.free()

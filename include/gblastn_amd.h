@@ -180,6 +180,26 @@ int  gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results,
  * whole shard `repeats` times and reports the HIP-event time per launch */
 int  gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag);
 
+/* ---- per-query top-N hit lists: the collector writer of the HSP stream
+ * (replaces BlastHSPStreamWrite CORE/blast_hspstream.c:316-365 ->
+ * s_BlastHSPCollectorRun CORE/hspfilter_collector.c:86-170 -> Blast_HitListUpdate
+ * CORE/blast_hits.c:2924-2981; read-out order of BlastHSPStreamClose/Read
+ * CORE/blast_hspstream.c:136-209,232-300).  Host only.  With several shards, rank 0
+ * writes the gathered records of all shards in ascending oid order. ---- */
+typedef struct GbnCollector GbnCollector;
+int32_t gbn_prelim_hitlist_size(int32_t hitlist_size);      /* min(2N, N+50), >= 10 */
+int  gbn_collector_new(GbnCollector **out, int32_t num_queries, int32_t hitlist_size);
+void gbn_collector_free(GbnCollector *c);
+/* records grouped by oid, each group sorted by score (what gbn_results_hsps yields) */
+int  gbn_collector_write(GbnCollector *c, const GbnHSP *hsps, int64_t n);
+int  gbn_collector_close(GbnCollector *c);
+/* after close: surviving (query, oid) lists in (oid, query) ascending order */
+int64_t gbn_collector_num_lists(const GbnCollector *c);
+const int64_t *gbn_collector_list_starts(const GbnCollector *c);   /* num_lists + 1 offsets into hsps */
+const int32_t *gbn_collector_list_queries(const GbnCollector *c);
+int64_t gbn_collector_num_hsps(const GbnCollector *c);
+const GbnHSP *gbn_collector_hsps(const GbnCollector *c);
+
 /* ---- thin kernel launchers: device pointers in the parameter blocks of
  * gblastn_amd_kernels.h, hipStream_t passed as void* ---- */
 struct GbnScanParams; struct GbnExtParams; struct GbnGapParams;

@@ -163,4 +163,15 @@ int orc_greedy_extend(const uint8_t *query, int32_t qlen,
 #ifdef __cplusplus
 }
 #endif
+/* ---- per-query top-N hit lists (the HSP stream's collector writer) ----
+ * CORE/blast_hspstream.c:316-365, CORE/hspfilter_collector.c:86-170,
+ * CORE/blast_hits.c:2924-2981 (orc_collect.c) */
+typedef struct OrcCollector OrcCollector;
+int orc_prelim_hitlist_size(int hitlist_size, int gapped);
+OrcCollector *orc_collector_new(int32_t num_queries, int32_t hitlist_size, int gapped);
+int orc_collector_write(OrcCollector *c, int32_t oid, const OrcHSP *h, int32_t n);
+int64_t orc_collector_close(OrcCollector *c);      /* number of surviving (query, oid) lists */
+int32_t orc_collector_list(const OrcCollector *c, int64_t i, int32_t *oid, int32_t *query, const OrcHSP **h);
+void orc_collector_free(OrcCollector *c);
+
 #endif

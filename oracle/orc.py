@@ -104,6 +104,14 @@ def lib():
         L.orc_hsplist_purge_common_endpoints.restype = C.c_int32
         L.orc_hsplist_purge_common_endpoints.argtypes = [C.POINTER(OrcHSP), C.c_int32]
         L.orc_hsplist_sort_by_score.argtypes = [C.POINTER(OrcHSP), C.c_int32]
+        L.orc_prelim_hitlist_size.argtypes = [C.c_int, C.c_int]
+        L.orc_collector_new.restype = C.c_void_p; L.orc_collector_new.argtypes = [C.c_int32, C.c_int32, C.c_int]
+        L.orc_collector_write.argtypes = [C.c_void_p, C.c_int32, C.POINTER(OrcHSP), C.c_int32]
+        L.orc_collector_close.restype = C.c_int64; L.orc_collector_close.argtypes = [C.c_void_p]
+        L.orc_collector_list.restype = C.c_int32
+        L.orc_collector_list.argtypes = [C.c_void_p, C.c_int64, C.POINTER(C.c_int32), C.POINTER(C.c_int32),
+                                         C.POINTER(C.POINTER(OrcHSP))]
+        L.orc_collector_free.argtypes = [C.c_void_p]
         L.orc_greedy_extend.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.POINTER(OrcHSP)]
@@ -265,3 +273,37 @@ IHIT_DT = np.dtype([("q_off", "<i4"), ("s_off", "<i4"), ("q_start", "<i4"), ("s_
 HSP_DT = np.dtype([("context", "<i4"), ("q_offset", "<i4"), ("q_end", "<i4"),
                    ("q_gapped_start", "<i4"), ("s_offset", "<i4"), ("s_end", "<i4"),
                    ("s_gapped_start", "<i4"), ("score", "<i4"), ("evalue", "<f8")])
+
+
+class Collector:
+    """orc_collect.c: the reference's collector writer, fed one subject's HSP list at a time."""
+    FIELDS = ["context", "q_offset", "q_end", "q_gapped_start", "s_offset", "s_end", "s_gapped_start", "score", "evalue"]
+
+    def __init__(self, num_queries, hitlist_size=500, gapped=True):
+        self._c = lib().orc_collector_new(num_queries, hitlist_size, 1 if gapped else 0)
+
+    def write(self, oid, hsps):
+        """hsps: sequence of dicts / records with FIELDS"""
+        arr = (OrcHSP * len(hsps))()
+        for i, h in enumerate(hsps):
+            for f in self.FIELDS:
+                setattr(arr[i], f, h[f].item() if hasattr(h[f], "item") else h[f])
+        return lib().orc_collector_write(self._c, oid, arr, len(hsps))
+
+    def close(self):
+        """-> list of (oid, query, [tuple(FIELDS)...]) in (oid, query) ascending order"""
+        L = lib()
+        n = L.orc_collector_close(self._c)
+        out = []
+        for i in range(n):
+            oid, q, p = C.c_int32(), C.c_int32(), C.POINTER(OrcHSP)()
+            k = L.orc_collector_list(self._c, i, C.byref(oid), C.byref(q), C.byref(p))
+            out.append((oid.value, q.value, [tuple(getattr(p[j], f) for f in self.FIELDS) for j in range(k)]))
+        return out
+
+    def __del__(self):
+        try:
+            if self._c:
+                lib().orc_collector_free(self._c); self._c = None
+        except Exception:
+            pass

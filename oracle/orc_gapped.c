@@ -354,6 +354,7 @@ int32_t orc_hsplist_purge_common_endpoints(OrcHSP *h, int32_t n)
     }
     return n;
 }
+int orc_score_compare_hsps(const OrcHSP *a, const OrcHSP *b) { return cmp_score(a, b); }
 void orc_hsplist_sort_by_score(OrcHSP *h, int32_t n)   /* :1226-1236 */
 {
     int32_t i; int sorted = 1;

@@ -84,4 +84,7 @@ int orc_greedy_gapped(const uint8_t *query, const uint8_t *subj, int32_t qlen, i
 int orc_dynprog_gapped(const int32_t matrix[16][16], const uint8_t *query, const uint8_t *subj,
                        int32_t qlen, int32_t slen, int32_t q_off, int32_t s_off, int32_t X,
                        int32_t gap_open, int32_t gap_extend, OrcGapResult *r);
+/* orc_gapped.c: ScoreCompareHSPs, CORE/blast_hits.c:1182-1208 */
+int orc_score_compare_hsps(const OrcHSP *a, const OrcHSP *b);
+
 #endif

@@ -29,6 +29,25 @@ if r == 0:
     print("GATHER_OK", len(out))
 else:
     assert out is None
+# exchange + merge: rank 0 replays both shards through the per-query top-N collector
+def shard_records(rank):
+    lo, hi = shard.shard_bounds(13, w, rank)
+    k = (hi - lo) * 3
+    a = np.zeros(k, dtype=api.HSP_DT)
+    a["oid"] = lo * 1000 + np.arange(k); a["context"] = np.arange(k) % 4
+    a["score"] = 60 + (np.arange(k) * 7 + rank) % 23; a["q_end"] = 50; a["s_end"] = 50
+    a["evalue"] = 10.0 ** (-(a["score"] - 50.0) / 3)
+    return a
+got = shard.collect_on_root(shard_records(r), num_queries=2, hitlist_size=5, dst=0)
+if r == 0:
+    col = api.BlastHSPCollector(2, 5)
+    col.write(np.concatenate([shard_records(x) for x in range(w)]))
+    want = col.close()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want))
+    assert len(got[2]) == 2 * api.lib().gbn_prelim_hitlist_size(5)
+    print("COLLECT_OK", len(got[0]))
+else:
+    assert got is None
 dist.destroy_process_group()
 '''
 
@@ -50,7 +69,7 @@ def run(extra_env=None):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     os.unlink(path)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "GATHER_OK" in p.stdout
+    assert "GATHER_OK" in p.stdout and "COLLECT_OK" in p.stdout
     return p.stdout
 
 
