@@ -34,13 +34,20 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=4)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--subjects", type=int, default=50_000, help="subjects per GPU shard")
+    ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
+                    help="C2 (the metric's config): megablast W=28 vs 50 Gbp; C3: blastn W=11 vs 5 Gbp, 100 kb batches")
+    ap.add_argument("--subjects", type=int, default=None, help="subjects per GPU shard")
     ap.add_argument("--subject-len", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=10_000)
-    ap.add_argument("--batch-queries", type=int, default=5_000)
+    ap.add_argument("--batch-queries", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.subjects is None:
+        a.subjects = 50_000 if a.workload == "C2" else 5_000
+    if a.batch_queries is None:
+        a.batch_queries = 5_000 if a.workload == "C2" else 100     # 5 Mb megablast / 100 kb blastn batches
+    return a
 
 
 def main():
@@ -86,8 +93,11 @@ def main():
                 self._cache[g] = layouts[g // nsub].subject_bases(g % nsub)
             return self._cache[g]
     queries, plants = synth.make_queries(args.queries, AnyShard())
-    opt = api.default_options("megablast", db_length=total_bases_global, db_num_seqs=world * nsub)
+    task = "megablast" if args.workload == "C2" else "blastn"
+    opt = api.default_options(task, db_length=total_bases_global, db_num_seqs=world * nsub)
     nbatch = (len(queries) + args.batch_queries - 1) // args.batch_queries
+    npass_config = nbatch
+    nbatch = min(nbatch, max(args.steps, args.warmup, 1))       # only the batches the run touches
     batches = [api.BlastPrelimSearch(queries[i * args.batch_queries:(i + 1) * args.batch_queries], opt, src)
                for i in range(nbatch)]
     info = batches[0].info()
@@ -151,15 +161,18 @@ def main():
     if rank == 0:
         value = total_bases_global * args.steps / elapsed / 1e9
         line = {
-            "metric": "subject Gbp scanned/sec (megablast preliminary search, DB bases x passes / wall)",
+            "metric": "subject Gbp scanned/sec (%s preliminary search, DB bases x passes / wall)" % task,
             "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (2-bit packed bases, int32 scores)", "data": "synthetic",
             "config": {
-                "workload": "C2: %d x 1 kb queries vs %.1f Gbp synthetic 2-bit DB per GPU, megablast W=28"
-                            % (len(queries), nsub * slen / 1e9),
-                "batch_plan": {"queries_per_batch": args.batch_queries, "passes_per_config": nbatch,
+                "workload": "%s: %d x 1 kb queries vs %.1f Gbp synthetic 2-bit DB per GPU, %s W=%d"
+                            % (args.workload, len(queries), nsub * slen / 1e9, task, opt.word_size),
+                "stage_ms_per_pass": {k: sum(getattr(b.diagnostics, k) for b in batches) / max(launches, 1)
+                                      for k in ["scan_stage_ms", "seed_stage_ms", "gapped_stage_ms", "host_stage_ms"]},
+                "init_hits_per_pass": sum(b.diagnostics.good_init_extends for b in batches) / max(launches, 1),
+                "batch_plan": {"queries_per_batch": args.batch_queries, "passes_per_config": npass_config,
                                "lut": info["lut_width"], "scan_step": info["scan_step"],
                                "lut_type": info["lut_type"], "diag_container": info["container"]},
                 "subjects_per_gpu": nsub, "subject_len": slen,

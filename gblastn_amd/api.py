@@ -45,7 +45,9 @@ class GbnDiagnostics(C.Structure):
                 ("scan_kernel_ms", C.c_double), ("total_ms", C.c_double),
                 ("scan_launches", C.c_int64), ("subject_bases_scanned", C.c_int64),
                 ("bin_kernel_ms", C.c_double), ("probe_kernel_ms", C.c_double),
-                ("rare_kernel_ms", C.c_double)]
+                ("rare_kernel_ms", C.c_double), ("scan_stage_ms", C.c_double),
+                ("seed_stage_ms", C.c_double), ("gapped_stage_ms", C.c_double),
+                ("host_stage_ms", C.c_double)]
 
 
 HSP_DT = np.dtype([("oid", "<i4"), ("context", "<i4"), ("q_offset", "<i4"), ("q_end", "<i4"),

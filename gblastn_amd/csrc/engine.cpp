@@ -209,7 +209,7 @@ static int build_tiles_uncached(const GbnDb &db, int lut, int step, int tpos, in
         if (L < lut) continue;
         int32_t npos = (L - lut) / step + 1;
         for (int32_t p = 0; p < npos; p += tpos) {
-            GbnTile t; t.subj = s; t.first_pos = p * step; t.npos = std::min(tpos, npos - p); t.pad_ = 0;
+            GbnTile t; t.subj = s; t.first_pos = p * step; t.npos = std::min(tpos, npos - p); t.off16 = (int32_t)(db.byte_off[s] >> 4);
             tiles.push_back(t);
         }
     }
@@ -331,7 +331,8 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
             HIPCHK(hipEventRecord(E.ev1, E.stream));
         } else {
             // private output stream per (bin, binning workgroup): no reservation atomics
-            const int nwriters = (int)std::max<int64_t>(8, std::min<int64_t>((int64_t)E.num_cu * 2, ts.ntiles));
+            const int wg_per_cu = getenv("GBN_BIN_WG_PER_CU") ? atoi(getenv("GBN_BIN_WG_PER_CU")) : GBN_BIN_WG_PER_CU;
+            const int nwriters = (int)std::max<int64_t>(8, std::min<int64_t>((int64_t)E.num_cu * wg_per_cu, ts.ntiles));
             const size_t nstream = (size_t)nb * nwriters;
             double expect = (double)npos / (double)nstream + 3.0 * ((double)ts.ntiles / nwriters + 1);   // + pads
             size_t subcap = (size_t)(expect * slack) + 256;
@@ -412,8 +413,14 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     const DeviceBatch *d = b.dev;
     unsigned long long cnt[3] = {0, 0, 0};
     int64_t bases = 0;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t_stage = now();
     int rc = run_scan(b, db, s0, s1, diag, cnt, &bases);
     if (rc) return rc;
+    if (diag) diag->scan_stage_ms += ms_since(t_stage);
+    t_stage = now();
     if (diag) { diag->lookup_hits += (int64_t)cnt[1]; diag->seeds += (int64_t)cnt[0]; diag->subject_bases_scanned += bases; }
     const int64_t n = (int64_t)cnt[0];
     if (n == 0) return GBN_OK;
@@ -468,7 +475,8 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         if (nih <= E.ihit_cap) break;
         if ((rc = grow_ihit_buffers((size_t)nih + (nih >> 3)))) return rc;
     }
-    if (diag) { diag->init_extends += (int64_t)nih; diag->good_init_extends += (int64_t)nih; }
+    if (diag) { diag->init_extends += (int64_t)nih; diag->good_init_extends += (int64_t)nih; diag->seed_stage_ms += ms_since(t_stage); }
+    t_stage = now();
     if (nih == 0) return GBN_OK;
 
     // ---- gapped extension of every initial hit ----
@@ -523,6 +531,8 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     HIPCHK(hipMemcpyAsync(hih.data(), E.ihits, (size_t)nih * sizeof(GbnDevInitHit), hipMemcpyDeviceToHost, E.stream));
     HIPCHK(hipMemcpyAsync(hg.data(), E.gapped, (size_t)nih * sizeof(GbnDevGapped), hipMemcpyDeviceToHost, E.stream));
     HIPCHK(hipStreamSynchronize(E.stream));
+    if (diag) diag->gapped_stage_ms += ms_since(t_stage);
+    t_stage = now();
 
     // ---- host replay per subject, ascending oid ----
     std::vector<uint32_t> order((size_t)nih);
@@ -560,6 +570,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         finish_subject(b, db.first_oid + subj, db.len[subj], hits, res.hsps, diag);
         i = j;
     }
+    if (diag) diag->host_stage_ms += ms_since(t_stage);
     return GBN_OK;
 }
 
@@ -733,7 +744,7 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
             while (s1 < db->num_seqs) {
                 int64_t nb = (db->len[s1] + 3) / 4;
                 int64_t nt = (db->len[s1] / step) / GBN_BIN_TILE_POS + 1;       // 32-bit position ids
-                if (s1 > s0 && (acc + nb > range_bytes || tiles + nt > (1 << 19))) break;
+                if (s1 > s0 && (acc + nb > range_bytes || tiles + nt > (1 << (32 - GBN_BIN_TILE_BITS)) - 1)) break;
                 acc += nb; tiles += nt; s1++;
             }
             if ((rc = search_range(*batch, *db, s0, s1, *results, diag, keep_stages))) return rc;

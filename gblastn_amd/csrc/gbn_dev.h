@@ -11,7 +11,7 @@
 #define GBN_EXT_SMALL         2     // s_BlastSmallNaExtend
 #define GBN_EXT_SMALL_ONEBYTE 3     // s_BlastSmallNaExtendAlignedOneByte
 
-struct GbnTile { int32_t subj; int32_t first_pos; int32_t npos; int32_t pad_; };
+struct GbnTile { int32_t subj; int32_t first_pos; int32_t npos; int32_t off16; };    // off16 = byte_off[subj] / 16
 
 struct GbnDevSeed { int32_t subj, s_scan, q_pos, ext_left; };
 struct GbnDevInitHit { int32_t subj, q_off, s_off, q_start, s_start, length, score; uint32_t seq; };
@@ -41,7 +41,9 @@ struct GbnScanParams {
 // loads one bin's cell table (<= 32768 cells x 4 B = 128 KiB) into LDS and
 // streams that bin's records through it.
 #define GBN_BIN_THREADS  1024
-#define GBN_BIN_TILE_POS 8192       // scan positions per tile (posid = tile << 13 | i)
+#define GBN_BIN_WG_PER_CU 1        // resident binning workgroups per CU (128 VGPRs per lane)
+#define GBN_BIN_TILE_BITS 14
+#define GBN_BIN_TILE_POS (1 << GBN_BIN_TILE_BITS)   // scan positions per tile (posid = tile << GBN_BIN_TILE_BITS | i)
 #define GBN_BIN_GROUPS   8          // probe workgroups with equal (blockIdx & 7) share a bin (and an XCD)
 #define GBN_BIN_MAXNB    512
 #define GBN_BIN_CELLS    32768      // cells per bin (LDS table entries)

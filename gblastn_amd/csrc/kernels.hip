@@ -18,6 +18,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gbn_dev.h"
+#ifndef GBN_BIN_OCC
+#define GBN_BIN_GBIAS 32768u  // > GBN_BIN_STAGE: keeps (stream cursor - staging offset) non-negative
+#define GBN_BIN_OCC (4 * GBN_BIN_WG_PER_CU)  // waves per SIMD the binning kernel is compiled for
+#endif
 
 namespace {
 
@@ -794,52 +798,95 @@ __device__ __forceinline__ uint64_t window32(const uint8_t *__restrict__ p, int6
     int sh = 2 * (int)(pos & 15);
     return sh ? ((hi << sh) | ((uint64_t)lo >> (32 - sh))) : hi;
 }
+// same window, addressed as uniform base + unsigned 32-bit offset (SGPR base + VGPR offset loads);
+// `base16` is the subject's first byte minus 16 and `upos` the base index plus 64
+__device__ __forceinline__ uint64_t window32u(const uint8_t *__restrict__ base16, uint32_t upos) {
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(base16) + (upos >> 4);
+    uint64_t hi = ((uint64_t)bswap32(d[0]) << 32) | bswap32(d[1]);
+    uint32_t lo = bswap32(d[2]);
+    uint32_t sh = 2 * (upos & 15);
+    return sh ? ((hi << sh) | ((uint64_t)lo >> (32 - sh))) : hi;
+}
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, 8)
+// Phase 1 of the key-range partitioned scan: every scan position becomes one 8-byte record
+// {posid = tile << GBN_BIN_TILE_BITS | index, hi = cell-in-bin << 14 | reduced fingerprint} in the private output
+// stream of (bin, this workgroup).  Per tile: LDS counting sort by bin, then the bin runs (padded
+// to 4 records = 32 bytes) are appended to the streams.  No global atomics, no table access.
+//
+// Software pipeline (global-memory latency never sits on the critical path of a tile):
+//   keys of tile t are in registers at the loop top;
+//   the bytes of tile t+1 and the descriptor of tile t+2 are requested right after the
+//   histogram atomics of tile t and first touched after its LDS sort;
+//   the stores of tile t are issued last and only waited for one tile later.
+extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, GBN_BIN_OCC)
 scan_bin_kernel(GbnBinParams B)
 {
     const GbnScanParams &P = B.S;
     __shared__ __attribute__((aligned(16))) uint32_t s_hi[GBN_BIN_STAGE];   // record high word, bin-sorted
     __shared__ __attribute__((aligned(16))) uint16_t s_idx[GBN_BIN_STAGE];  // position index in tile; 0xffff = pad
     __shared__ uint32_t s_gmeta[GBN_BIN_STAGE / 4 + 4];    // per group of 4 slots: bin << 23 | (stream index - slot + BIAS)
-    __shared__ uint32_t s_hist[GBN_BIN_MAXNB], s_off[GBN_BIN_MAXNB + 1], s_cur[GBN_BIN_MAXNB];
+    __shared__ uint32_t s_hist[GBN_BIN_MAXNB], s_off[GBN_BIN_MAXNB + 1];
     __shared__ uint32_t s_wcur[GBN_BIN_MAXNB];      // this workgroup's write cursor per bin (records)
     const int tid = threadIdx.x;
     const uint32_t mask = (uint32_t)(P.ncells - 1);
     const int nb = B.nb, cbits = B.cbits;
     const uint32_t lowmask = (1u << cbits) - 1;
     const int cshift = 56 - 2 * P.lut, rshift = 50 - 2 * P.lut;
-    constexpr int PER = GBN_BIN_TILE_POS / GBN_BIN_THREADS;     // 8
+    constexpr int PER = GBN_BIN_TILE_POS / GBN_BIN_THREADS;
+    const uint32_t ustep = (uint32_t)P.step;
+    const int64_t stride = gridDim.x, last = P.ntiles - 1;
 
-    for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_wcur[b] = 0;
-    for (int64_t tile = blockIdx.x; tile < P.ntiles; tile += gridDim.x) {
-        const GbnTile T = P.tiles[tile];
-        const uint8_t *__restrict__ subj = P.db + P.byte_off[T.subj];
-        uint64_t W[PER];
-        #pragma unroll
-        for (int k = 0; k < PER; k++) {             // all loads first: 8 independent 12-byte reads in flight
-            int i = tid + k * GBN_BIN_THREADS;
-            W[k] = (i < T.npos) ? window32(subj, (int64_t)T.first_pos + (int64_t)i * P.step - 4) : 0;
-        }
-        for (int b = tid; b < nb; b += GBN_BIN_THREADS) { s_hist[b] = 0; s_cur[b] = 0; }
-        __syncthreads();
-        uint32_t bin[PER], hi[PER];
+    // one unaligned 8-byte load per position: bases [pos - 4, pos + 15) are 38 bits that start at
+    // most 6 bits into the byte holding base pos - 4.  Lanes past the tile's end re-read its last
+    // position (and are dropped when ranks are taken).
+    auto upos_of = [&](const GbnTile &t, int k) -> uint32_t {
+        const uint32_t i = min((uint32_t)(tid + k * GBN_BIN_THREADS), (uint32_t)t.npos - 1u);
+        return (uint32_t)t.first_pos + i * ustep + 60u;         // base index + 64 (>= 60; subjects start >= 16 bytes into the slab)
+    };
+    auto fetch = [&](const GbnTile &t, int k) -> uint64_t {
+        uint64_t raw;
+        __builtin_memcpy(&raw, P.db + ((size_t)(uint32_t)t.off16 << 4) - 16 + (upos_of(t, k) >> 2), 8);
+        return raw;
+    };
+    auto keys = [&](const GbnTile &t, int k, uint64_t raw, uint32_t &bin, uint32_t &hi) {
+        const uint64_t w = __builtin_bswap64(raw) << (2 * (upos_of(t, k) & 3));   // bits 63..56 left-4, lut word, right-3
+        const uint32_t c = (uint32_t)(w >> cshift) & mask;
+        bin = c >> cbits;
+        hi = ((c & lowmask) << 14) | ((uint32_t)(w >> 56) << 6) | ((uint32_t)(w >> rshift) & 0x3fu);
+    };
+    auto uniform = [](GbnTile t) -> GbnTile {       // descriptors are workgroup-uniform: keep them in SGPRs
+        t.subj = __builtin_amdgcn_readfirstlane(t.subj); t.first_pos = __builtin_amdgcn_readfirstlane(t.first_pos);
+        t.npos = __builtin_amdgcn_readfirstlane(t.npos); t.off16 = __builtin_amdgcn_readfirstlane(t.off16);
+        return t;
+    };
+
+    for (int b = tid; b < nb; b += GBN_BIN_THREADS) { s_wcur[b] = 0; s_hist[b] = 0; }
+    int64_t tile = blockIdx.x;
+    if (tile > last) {                               // more workgroups than tiles: empty streams
+        for (int b = tid; b < nb; b += GBN_BIN_THREADS) B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0;
+        return;
+    }
+    GbnTile T = uniform(P.tiles[tile]);
+    GbnTile T1 = uniform(P.tiles[min(tile + stride, last)]);
+    uint32_t bin[PER], hi[PER];
+    #pragma unroll
+    for (int k = 0; k < PER; k++) keys(T, k, fetch(T, k), bin[k], hi[k]);
+    __syncthreads();
+
+    for (; tile <= last; tile += stride) {
+        uint32_t rank[PER];
         #pragma unroll
         for (int k = 0; k < PER; k++) {
-            int i = tid + k * GBN_BIN_THREADS;
-            bin[k] = 0xffffffffu; hi[k] = 0;
-            if (i < T.npos) {
-                const uint32_t c = (uint32_t)(W[k] >> cshift) & mask;
-                const uint32_t left4 = (uint32_t)(W[k] >> 56);
-                const uint32_t right3 = (uint32_t)(W[k] >> rshift) & 0x3fu;
-                bin[k] = c >> cbits;
-                hi[k] = ((c & lowmask) << 14) | (left4 << 6) | right3;
-                atomicAdd(&s_hist[bin[k]], 1u);
-            }
+            rank[k] = 0;
+            if (tid + k * GBN_BIN_THREADS < T.npos)
+                rank[k] = atomicAdd(&s_hist[bin[k]], 1u);       // arrival order inside the bin: any order will do
         }
-        __syncthreads();
-        if (B.dbg & 4) continue;                    // ablation: loads + histogram only
+        uint64_t R[PER];
+        #pragma unroll
+        for (int k = 0; k < PER; k++) R[k] = fetch(T1, k);     // tile t+1 (== the last tile again at the end)
+        GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
+        __syncthreads();                                        // (A) histogram complete
         // exclusive scan of the padded bin sizes (x4 records = 32-byte sectors) by wave 0
         if (tid < 64) {
             uint32_t carry = 0;
@@ -853,47 +900,47 @@ scan_bin_kernel(GbnBinParams B)
             }
             if (tid == 0) s_off[nb] = carry;
         }
-        __syncthreads();
+        __syncthreads();                                        // (B) offsets known
         const uint32_t total = s_off[nb];
         for (int b = tid; b < nb; b += GBN_BIN_THREADS) {
             const uint32_t n = s_hist[b], o0 = s_off[b], o1 = s_off[b + 1];
             for (uint32_t j = o0 + n; j < o1; j++) s_idx[j] = 0xffffu;
-            for (uint32_t g = o0 >> 2; g < (o1 >> 2); g++) s_gmeta[g] = ((uint32_t)b << 23) | (s_wcur[b] + 16384u - o0);
+            for (uint32_t g = o0 >> 2; g < (o1 >> 2); g++) s_gmeta[g] = ((uint32_t)b << 23) | (s_wcur[b] + GBN_BIN_GBIAS - o0);
             if (o1 > o0 && s_wcur[b] + (o1 - o0) > B.subcap) atomicExch(B.overflow, 1u);
         }
         #pragma unroll
         for (int k = 0; k < PER; k++) {
-            if (bin[k] != 0xffffffffu) {
-                const uint32_t slot = s_off[bin[k]] + atomicAdd(&s_cur[bin[k]], 1u);
+            if (tid + k * GBN_BIN_THREADS < T.npos) {
+                const uint32_t slot = s_off[bin[k]] + rank[k];
                 s_hi[slot] = hi[k];
                 s_idx[slot] = (uint16_t)(tid + k * GBN_BIN_THREADS);
             }
         }
-        __syncthreads();
-        // write-out: one lane per group of 4 records = one 32-byte sector
-        for (uint32_t g = tid; g < (total >> 2); g += GBN_BIN_THREADS) {
-            const uint32_t meta = s_gmeta[g];
+        __syncthreads();                                        // (C) tile is bin-sorted in LDS
+        for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_hist[b] = 0;     // for the next tile; ordered by (D)
+        // first touch of the prefetched data: everything older than these loads (the previous
+        // tile's stores) has long completed, nothing younger is outstanding yet
+        const uint32_t tbase = (uint32_t)tile << GBN_BIN_TILE_BITS;
+        T = T1; T1 = uniform(T2);
+        #pragma unroll
+        for (int k = 0; k < PER; k++) keys(T, k, R[k], bin[k], hi[k]);
+        // write-out: one lane per PAIR of records (one 16-byte store); consecutive lanes cover
+        // consecutive pairs of the bin-sorted staging area, so the lanes of a wave that fall into
+        // the same run write one contiguous stretch (whole 128-byte lines for a typical run)
+        for (uint32_t h = tid; h < (total >> 1); h += GBN_BIN_THREADS) {
+            const uint32_t meta = s_gmeta[h >> 1];
             const uint32_t b = meta >> 23;
-            const uint32_t w = (meta & 0x7fffffu) - 16384u + 4u * g;      // index in this workgroup's stream of bin b
-            const uint2 i4 = *reinterpret_cast<const uint2 *>(&s_idx[4 * g]);
-            const uint4 h4 = *reinterpret_cast<const uint4 *>(&s_hi[4 * g]);
-            const uint32_t tbase = (uint32_t)tile << 13;
-            const uint32_t l0 = i4.x & 0xffffu, l1 = i4.x >> 16, l2 = i4.y & 0xffffu, l3 = i4.y >> 16;
-            ulonglong2 a, c;
-            a.x = (l0 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.x << 32) | (tbase | l0));
-            a.y = (l1 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.y << 32) | (tbase | l1));
-            c.x = (l2 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.z << 32) | (tbase | l2));
-            c.y = (l3 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h4.w << 32) | (tbase | l3));
-            if (B.dbg & 16) {   // ablation: same bytes, written as one linear stream per workgroup
-                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(B.rec + (size_t)blockIdx.x * B.subcap * (size_t)nb
-                                  + ((size_t)(tile / gridDim.x) * GBN_BIN_STAGE + 4u * g) % ((size_t)B.subcap * nb - 8));
-                dst[0] = a; dst[1] = c;
-            } else if (w + 4u <= B.subcap && !(B.dbg & 2)) {
-                ulonglong2 *dst = reinterpret_cast<ulonglong2 *>(B.rec + ((size_t)b * B.nwriters + blockIdx.x) * B.subcap + w);
-                dst[0] = a; dst[1] = c;
-            }
+            const uint32_t w = (meta & 0x7fffffu) - GBN_BIN_GBIAS + 2u * h;      // index in this workgroup's stream of bin b
+            const uint32_t i2 = *reinterpret_cast<const uint32_t *>(&s_idx[2 * h]);
+            const uint2 h2 = *reinterpret_cast<const uint2 *>(&s_hi[2 * h]);
+            const uint32_t l0 = i2 & 0xffffu, l1 = i2 >> 16;
+            ulonglong2 a;
+            a.x = (l0 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h2.x << 32) | (tbase | l0));
+            a.y = (l1 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h2.y << 32) | (tbase | l1));
+            if (w + 2u <= B.subcap && !(B.dbg & 2))
+                *reinterpret_cast<ulonglong2 *>(B.rec + ((size_t)b * B.nwriters + blockIdx.x) * B.subcap + w) = a;
         }
-        __syncthreads();
+        __syncthreads();                                        // (D) staging buffers free again
         for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_wcur[b] += s_off[b + 1] - s_off[b];
     }
     __syncthreads();
@@ -917,8 +964,8 @@ __device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell
 {
     const uint32_t start = P.cell_start[cell], end = P.cell_start[cell + 1];
     if (count_raw) raw += end - start;
-    const GbnTile T = P.tiles[posid >> 13];
-    const int32_t s = T.first_pos + (int32_t)(posid & 8191u) * P.step;
+    const GbnTile T = P.tiles[posid >> GBN_BIN_TILE_BITS];
+    const int32_t s = T.first_pos + (int32_t)(posid & (uint32_t)(GBN_BIN_TILE_POS - 1)) * P.step;
     const uint8_t *__restrict__ subj = P.db + P.byte_off[T.subj];
     const int32_t slen = P.len[T.subj];
     const uint32_t sl = window16(subj, (int64_t)s - 8) >> 16;
@@ -1005,10 +1052,16 @@ probe_bin_kernel(GbnBinParams B)
             for (uint32_t i = tid; i < s1 - s0 && i < GBN_BIN_SIDE; i += GBN_BIN_THREADS) s_side[i] = B.sidet[s0 + i];
         }
         __syncthreads();
-        // one writer stream per wave at a time
-        for (int w = wi + nw * wave; w < B.nwriters; w += nw * (GBN_BIN_THREADS / 64)) {
-            const uint32_t n = B.gcount[(size_t)b * B.nwriters + w];
-            const unsigned long long *__restrict__ rec = B.rec + ((size_t)b * B.nwriters + w) * B.subcap;
+        // one piece of a writer stream per wave at a time; streams are cut into `split` pieces
+        // (multiples of 512 records) when there are fewer streams than waves working on the bin
+        const int nwaves = nw * (GBN_BIN_THREADS / 64);
+        const int split = (nwaves + B.nwriters - 1) / B.nwriters;
+        for (int v = wi + nw * wave; v < B.nwriters * split; v += nwaves) {
+            const int w = v / split, part = v - w * split;
+            const uint32_t ntot = B.gcount[(size_t)b * B.nwriters + w];
+            const uint32_t piece = ((ntot + (uint32_t)split * 512u - 1u) / ((uint32_t)split * 512u)) * 512u;
+            const uint32_t lo = min((uint32_t)part * piece, ntot), n = min(piece, ntot - lo);
+            const unsigned long long *__restrict__ rec = B.rec + ((size_t)b * B.nwriters + w) * B.subcap + lo;
             // software pipeline: the next 4 loads (8 records per lane) are in flight while the
             // current 8 records are looked up
             ulonglong2 cur[4], nxt[4];

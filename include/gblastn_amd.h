@@ -118,6 +118,11 @@ typedef struct GbnDiagnostics {
     int64_t subject_bases_scanned;
     /* partitioned scan, per kernel (HIP events on the engine's stream) */
     double  bin_kernel_ms, probe_kernel_ms, rare_kernel_ms;
+    /* host wall time per stage (each ends at a stream synchronisation) */
+    double  scan_stage_ms;          /* scan incl. launches, retries and counter read-back */
+    double  seed_stage_ms;          /* key build, two radix sorts, diagonal filter + ungapped kernel */
+    double  gapped_stage_ms;        /* gapped kernels + D2H of initial hits and extensions */
+    double  host_stage_ms;          /* replay of the acceptance rules, HSP list rules */
 } GbnDiagnostics;
 
 typedef int (*GbnInterruptFn)(void *progress);   /* TInterruptFnPtr analogue */

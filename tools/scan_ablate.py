@@ -17,5 +17,7 @@ qs, _ = synth.make_queries(nq, None)
 ps = api.BlastPrelimSearch(qs, api.default_options("megablast", db_length=nsub * 10**6, db_num_seqs=nsub), src)
 ps.scan_only(repeats=1)
 d = ps.scan_only(repeats=3)
-print("GBN_DBG=%s bins=%s: scan %.2f ms/launch, seeds %d, lookup_hits %d" % (
-    os.environ.get("GBN_DBG"), os.environ.get("GBN_SCAN_BINS"), d.scan_kernel_ms / d.scan_launches, d.seeds, d.lookup_hits))
+n = d.scan_launches
+print("GBN_DBG=%s bins=%s: scan %.2f ms/launch (bin %.2f probe %.2f rare %.2f), seeds %d, lookup_hits %d" % (
+    os.environ.get("GBN_DBG"), os.environ.get("GBN_SCAN_BINS"), d.scan_kernel_ms / n, d.bin_kernel_ms / n,
+    d.probe_kernel_ms / n, d.rare_kernel_ms / n, d.seeds, d.lookup_hits))
