@@ -14,7 +14,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libgblastn_amd.so")
+_SO = os.environ.get("GBN_AMD_LIB") or os.path.join(_HERE, "libgblastn_amd.so")   # GBN_AMD_LIB: A/B builds (tools/build_variant.sh)
 
 
 class GbnOptions(C.Structure):

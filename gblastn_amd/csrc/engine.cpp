@@ -133,7 +133,8 @@ int upload_batch(GbnBatch &b) {
     }
     std::vector<uint32_t> cellw((size_t)L.ncells, 0), cellt((size_t)L.ncells, 0);
     std::vector<unsigned long long> ent(L.cell_qoff.size());
-    auto reduce = [](uint32_t fp) { return ((((fp >> 15) & 0xffu)) << 6) | (((fp >> 1) & 0x3fffu) >> 8); };
+    // 15-bit reduced fingerprint: 3.5 bases to the right (7 bits, high) and 4 bases to the left (8 bits, low)
+    auto reduce = [](uint32_t fp) { return ((((fp >> 1) & 0x3fffu) >> 7) << 8) | ((fp >> 15) & 0xffu); };
     std::vector<uint16_t> sidet; std::vector<uint32_t> side_start; int64_t cur_bin = -1; bool forced_cell = false;
     for (int64_t c = 0; c < L.ncells; c++) {
         uint32_t s = L.cell_start[c], e = L.cell_start[c + 1];
@@ -143,21 +144,21 @@ int upload_batch(GbnBatch &b) {
             uint32_t fp = fingerprint(q, off, L.lut, force);
             ent[k] = ((unsigned long long)fp << 32) | (uint32_t)off;
             if (k == s) cellw[c] = (fp & 0x7fffffffu) | ((e - s > 1) ? 0x80000000u : 0u);
-            // LDS cell table of the partitioned scan: class + two reduced fingerprints
-            if (k == s) cellt[c] = std::min<uint32_t>(e - s, 3u) | (reduce(fp) << 2);
-            else if (k == s + 1) cellt[c] |= reduce(fp) << 16;
+            // LDS cell table of the partitioned scan (layout: GbnBinParams::cellt)
+            if (k == s) cellt[c] = 0x8000u | reduce(fp) | (reduce(fp) << 16);
+            else if (k == s + 1) cellt[c] = (cellt[c] & 0xffffu) | 0x80000000u | (reduce(fp) << 16);
             if (force) forced_cell = true;
         }
         if (e - s >= 3 || forced_cell) {
-            // class 3: reduced fingerprints go to the bin's side list (capacity GBN_BIN_SIDE per bin,
-            // 16-bit offsets, 14-bit counts); anything that does not fit is "always rare path"
+            // three or more entries: reduced fingerprints go to the bin's side list (capacity
+            // GBN_BIN_SIDE per bin); anything that does not fit is "always rare path"
             const int64_t bin = c / GBN_BIN_CELLS;
             if (bin != cur_bin) { cur_bin = bin; while ((int64_t)side_start.size() <= bin) side_start.push_back((uint32_t)sidet.size()); }
             const uint32_t off = (uint32_t)sidet.size() - side_start[bin], cnt = e - s;
             if (!forced_cell && off + cnt <= GBN_BIN_SIDE && cnt < 16384) {
                 for (uint32_t k = s; k < e; k++) sidet.push_back((uint16_t)reduce((uint32_t)(ent[k] >> 32)));
-                cellt[c] = 3u | (off << 2) | (cnt << 18);
-            } else cellt[c] = 3u;
+                cellt[c] = 0x80000000u | off | (cnt << 16);
+            } else cellt[c] = 0x80000000u;
             forced_cell = false;
         }
     }
@@ -336,7 +337,7 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
             const size_t nstream = (size_t)nb * nwriters;
             double expect = (double)npos / (double)nstream + 3.0 * ((double)ts.ntiles / nwriters + 1);   // + pads
             size_t subcap = (size_t)(expect * slack) + 256;
-            subcap = (subcap + 3) & ~(size_t)3;
+            subcap = (subcap + 511) & ~(size_t)511;       // whole record blocks, whole probe pieces
             if (subcap > 0x7ffffff0u) { set_error("bin capacity overflow: split the range"); return GBN_ERR_NOMEM; }
             size_t need = subcap * nstream;
             if (need > E.bin_rec_cap) {
@@ -352,8 +353,8 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
             HIPCHK(hipMemsetAsync(E.bin_count + nstream, 0, 16, E.stream));
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
             B.S = P; B.nb = nb; B.cbits = 15; B.nwriters = nwriters;
-            B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfr = std::min(3, b.dev->fr);
-            B.rec = E.bin_rec; B.gcount = E.bin_count; B.subcap = (uint32_t)subcap;
+            B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfrbits = std::min(7, 2 * b.dev->fr);
+            B.rec = reinterpret_cast<uint32_t *>(E.bin_rec); B.gcount = E.bin_count; B.subcap = (uint32_t)subcap;
             B.overflow = E.bin_count + nstream;
             if (const char *e = getenv("GBN_DBG")) B.dbg = atoi(e);
             int grid2 = std::max(8, E.num_cu & ~7);   // one 1024-thread workgroup per CU; group = blockIdx & 7

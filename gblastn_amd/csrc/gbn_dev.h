@@ -52,19 +52,34 @@ struct GbnScanParams {
 #define GBN_BIN_SIDE     4096       // LDS side-list capacity (u16 fingerprints) per bin
 
 struct GbnU2 { uint32_t x, y; };
+// word offset of record j (j = stream * subcap + index) inside GbnBinParams::rec
+#ifndef GBN_REC_BLOCK_BITS
+#define GBN_REC_BLOCK_BITS 5
+#endif
+#define GBN_REC_HI(j)  ((((size_t)(j)) >> GBN_REC_BLOCK_BITS << (GBN_REC_BLOCK_BITS + 1)) + (((size_t)(j)) & ((1u << GBN_REC_BLOCK_BITS) - 1)))
+#define GBN_REC_POS(j) (GBN_REC_HI(j) + (1u << GBN_REC_BLOCK_BITS))
 struct GbnBinParams {
     GbnScanParams S;                // tiles here are GBN_BIN_TILE_POS-sized
     int nb, cbits;                  // number of bins; cell = bin << cbits | low
     int nwriters;                   // workgroups of the binning kernel = private output streams per bin
-    const uint32_t *cellt;          // per cell: [1:0] class 0/1/2/3; class 1/2: [15:2] fpA, [29:16] fpB;
-                                    // class 3: [17:2] offset into the bin's side list, [31:18] count (0 = always rare path)
+    // cell table, one word per cell.  Reduced fingerprint fp15 = right-7-bits << 8 | left-4-bases.
+    //   bit 15 = c0, bit 31 = c1:  00 empty;  10 (c0) one entry: [14:0] = [30:16] = its fp15;
+    //   11 two entries: [14:0] fpA, [30:16] fpB;  01 (c1 only) three or more: [14:0] offset into the
+    //   bin's side list, [30:16] count (0 = always rare path)
+    const uint32_t *cellt;
     const uint16_t *sidet;          // reduced fingerprints of cells with >= 3 entries, per bin
     const uint32_t *side_start;     // [nb + 1] offsets into sidet
-    unsigned long long *rec;        // [nb][nwriters][subcap]: lo = posid, hi = low << 14 | sfp
+    // records: streams [nb][nwriters] of subcap records (a multiple of 32), stored in blocks of 32
+    // records = 128 bytes of `hi` words followed by 128 bytes of `posid` words (GBN_REC_HI/POS below).
+    // The probe kernel streams the hi lines only and fetches posid for the ~1 % of records that reach
+    // the rare path; a run of the binning kernel still lands in one contiguous stretch of memory.
+    //   hi:    bit 31 = pad, [29:15] cell inside the bin, [14:0] fp15 of the subject position
+    //   posid: tile << GBN_BIN_TILE_BITS | index
+    uint32_t *rec;
     uint32_t *gcount;               // [nb][nwriters] records written (multiple of 4, pads included)
     uint32_t subcap;
     uint32_t *overflow;             // set to 1 if any stream did not fit
-    int rfl, rfr;                   // reduced fingerprint lengths (<= 4 left, <= 3 right)
+    int rfl, rfrbits;               // reduced fingerprint: bases on the left (<= 4), BITS on the right (<= 7 = 3.5 bases)
     int dbg;                        // ablation switches for tools/scan_ablate.py (0 in production)
     GbnU2 *rareq; uint32_t rare_seg;    // rare-path queue: one segment of rare_seg items per probe workgroup
     uint32_t *rare_counts;              // [probe workgroups] items queued (may exceed rare_seg: overflow)

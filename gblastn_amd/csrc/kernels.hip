@@ -19,6 +19,9 @@
 #include <stdint.h>
 #include "gbn_dev.h"
 #ifndef GBN_BIN_OCC
+#ifndef GBN_PROBE_U
+#define GBN_PROBE_U 2        // 16-byte loads per lane and round of the probe kernel (4 records each)
+#endif
 #define GBN_BIN_GBIAS 32768u  // > GBN_BIN_STAGE: keeps (stream cursor - staging offset) non-negative
 #define GBN_BIN_OCC (4 * GBN_BIN_WG_PER_CU)  // waves per SIMD the binning kernel is compiled for
 #endif
@@ -810,8 +813,8 @@ __device__ __forceinline__ uint64_t window32u(const uint8_t *__restrict__ base16
 }  // namespace
 
 // Phase 1 of the key-range partitioned scan: every scan position becomes one 8-byte record
-// {posid = tile << GBN_BIN_TILE_BITS | index, hi = cell-in-bin << 14 | reduced fingerprint} in the private output
-// stream of (bin, this workgroup).  Per tile: LDS counting sort by bin, then the bin runs (padded
+// {posid = tile << GBN_BIN_TILE_BITS | index, hi = cell-in-bin << 15 | reduced fingerprint}, kept as two
+// parallel arrays, in the private output stream of (bin, this workgroup).  Per tile: LDS counting sort by bin, then the bin runs (padded
 // to 4 records = 32 bytes) are appended to the streams.  No global atomics, no table access.
 //
 // Software pipeline (global-memory latency never sits on the critical path of a tile):
@@ -832,13 +835,13 @@ scan_bin_kernel(GbnBinParams B)
     const uint32_t mask = (uint32_t)(P.ncells - 1);
     const int nb = B.nb, cbits = B.cbits;
     const uint32_t lowmask = (1u << cbits) - 1;
-    const int cshift = 56 - 2 * P.lut, rshift = 50 - 2 * P.lut;
+    const int cshift = 56 - 2 * P.lut, rshift = 49 - 2 * P.lut;     // right side: 3.5 bases = 7 bits
     constexpr int PER = GBN_BIN_TILE_POS / GBN_BIN_THREADS;
     const uint32_t ustep = (uint32_t)P.step;
     const int64_t stride = gridDim.x, last = P.ntiles - 1;
 
-    // one unaligned 8-byte load per position: bases [pos - 4, pos + 15) are 38 bits that start at
-    // most 6 bits into the byte holding base pos - 4.  Lanes past the tile's end re-read its last
+    // one unaligned 8-byte load per position: bases [pos - 4, pos + lut + 4) are <= 40 bits that
+    // start at most 6 bits into the byte holding base pos - 4.  Lanes past the tile's end re-read its last
     // position (and are dropped when ranks are taken).
     auto upos_of = [&](const GbnTile &t, int k) -> uint32_t {
         const uint32_t i = min((uint32_t)(tid + k * GBN_BIN_THREADS), (uint32_t)t.npos - 1u);
@@ -853,7 +856,7 @@ scan_bin_kernel(GbnBinParams B)
         const uint64_t w = __builtin_bswap64(raw) << (2 * (upos_of(t, k) & 3));   // bits 63..56 left-4, lut word, right-3
         const uint32_t c = (uint32_t)(w >> cshift) & mask;
         bin = c >> cbits;
-        hi = ((c & lowmask) << 14) | ((uint32_t)(w >> 56) << 6) | ((uint32_t)(w >> rshift) & 0x3fu);
+        hi = ((c & lowmask) << 15) | (((uint32_t)(w >> rshift) & 0x7fu) << 8) | (uint32_t)(w >> 56);
     };
     auto uniform = [](GbnTile t) -> GbnTile {       // descriptors are workgroup-uniform: keep them in SGPRs
         t.subj = __builtin_amdgcn_readfirstlane(t.subj); t.first_pos = __builtin_amdgcn_readfirstlane(t.first_pos);
@@ -924,21 +927,26 @@ scan_bin_kernel(GbnBinParams B)
         T = T1; T1 = uniform(T2);
         #pragma unroll
         for (int k = 0; k < PER; k++) keys(T, k, R[k], bin[k], hi[k]);
-        // write-out: one lane per PAIR of records (one 16-byte store); consecutive lanes cover
-        // consecutive pairs of the bin-sorted staging area, so the lanes of a wave that fall into
-        // the same run write one contiguous stretch (whole 128-byte lines for a typical run)
-        for (uint32_t h = tid; h < (total >> 1); h += GBN_BIN_THREADS) {
-            const uint32_t meta = s_gmeta[h >> 1];
+        // write-out: one lane per group of 4 records, one 16-byte store to each of the two record
+        // arrays; the lanes of a wave that fall into the same run write one contiguous stretch
+        for (uint32_t g = tid; g < (total >> 2); g += GBN_BIN_THREADS) {
+            const uint32_t meta = s_gmeta[g];
             const uint32_t b = meta >> 23;
-            const uint32_t w = (meta & 0x7fffffu) - GBN_BIN_GBIAS + 2u * h;      // index in this workgroup's stream of bin b
-            const uint32_t i2 = *reinterpret_cast<const uint32_t *>(&s_idx[2 * h]);
-            const uint2 h2 = *reinterpret_cast<const uint2 *>(&s_hi[2 * h]);
-            const uint32_t l0 = i2 & 0xffffu, l1 = i2 >> 16;
-            ulonglong2 a;
-            a.x = (l0 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h2.x << 32) | (tbase | l0));
-            a.y = (l1 == 0xffffu) ? 0xffffffffull : (((unsigned long long)h2.y << 32) | (tbase | l1));
-            if (w + 2u <= B.subcap && !(B.dbg & 2))
-                *reinterpret_cast<ulonglong2 *>(B.rec + ((size_t)b * B.nwriters + blockIdx.x) * B.subcap + w) = a;
+            const uint32_t w = (meta & 0x7fffffu) - GBN_BIN_GBIAS + 4u * g;     // index in this workgroup's stream of bin b
+            const uint2 i4 = *reinterpret_cast<const uint2 *>(&s_idx[4 * g]);
+            uint4 h4 = *reinterpret_cast<const uint4 *>(&s_hi[4 * g]);
+            const uint32_t l0 = i4.x & 0xffffu, l1 = i4.x >> 16, l2 = i4.y & 0xffffu, l3 = i4.y >> 16;
+            uint4 p4;
+            p4.x = tbase | l0; p4.y = tbase | l1; p4.z = tbase | l2; p4.w = tbase | l3;
+            if (l0 == 0xffffu) h4.x = 0x80000000u;                  // pads: flagged in the high word
+            if (l1 == 0xffffu) h4.y = 0x80000000u;
+            if (l2 == 0xffffu) h4.z = 0x80000000u;
+            if (l3 == 0xffffu) h4.w = 0x80000000u;
+            if (w + 4u <= B.subcap && !(B.dbg & 2)) {
+                const size_t at = ((size_t)b * B.nwriters + blockIdx.x) * B.subcap + w;
+                *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = h4;
+                *reinterpret_cast<uint4 *>(B.rec + GBN_REC_POS(at)) = p4;
+            }
         }
         __syncthreads();                                        // (D) staging buffers free again
         for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_wcur[b] += s_off[b + 1] - s_off[b];
@@ -949,15 +957,6 @@ scan_bin_kernel(GbnBinParams B)
 }
 
 namespace {
-// reduced fingerprint test: rf = 14 bits {left4 (8 bits, base -1 low pair), right3 (6 bits, first base high pair)}
-__device__ __forceinline__ bool rfp_pass(uint32_t qf, uint32_t sf, uint32_t lmask, uint32_t rmask, bool lany, bool rany)
-{
-    const uint32_t x = qf ^ sf;
-    const bool left = lany || ((x >> 6) & lmask) == 0;
-    const bool right = rany || (x & rmask) == 0;
-    return left || right;
-}
-
 // rare path of the probe kernel: full fingerprints, chain walk, exact verification
 __device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell, bool count_raw,
                            unsigned long long &raw)
@@ -1000,8 +999,9 @@ probe_bin_kernel(GbnBinParams B)
     GbnU2 *myq = B.rareq + (size_t)blockIdx.x * B.rare_seg;          // this workgroup's segment: no global atomics
     if (tid == 0) *s_rcount = 0;
     // masks of the reduced fingerprint test; a zero mask makes that side "always matches"
-    const uint32_t lmask = (B.rfl <= 0) ? 0u : ((1u << (2 * B.rfl)) - 1);
-    const uint32_t rmask = (B.rfr <= 0) ? 0u : (((1u << (2 * B.rfr)) - 1) << (2 * (3 - B.rfr)));
+    const uint32_t lmask = (B.rfl <= 0) ? 0u : ((1u << (2 * B.rfl)) - 1);                               // byte 0 of an fp15
+    const uint32_t rmask = (B.rfrbits <= 0) ? 0u : (((1u << B.rfrbits) - 1) << (7 - B.rfrbits));      // byte 1
+    const uint32_t m4 = (lmask | (rmask << 8)) * 0x10001u;          // both fingerprints of a cell word at once
     volatile uint2 *q = s_q + wave * GBN_BIN_QCAP;
     int qn = 0;                                                     // wave-uniform
     unsigned long long raw = 0;
@@ -1010,22 +1010,22 @@ probe_bin_kernel(GbnBinParams B)
     // Flush `cnt` queued items (one per lane): cells with a side list get their reduced
     // fingerprints checked here, densely; survivors go to the global rare-path queue.
     auto flush = [&](int first, int cnt, int bin) {
-        bool keep = false; uint32_t pid = 0, cv = 0;
+        bool keep = false; uint32_t at_rec = 0, cv = 0;
         if (lane < cnt) {
-            pid = q[first + lane].x;
+            at_rec = q[first + lane].x;                             // record index inside the bin's region
             const uint32_t y = q[first + lane].y;
-            const uint32_t low = y & 0x7fffu, sf = (y >> 15) & 0x3fffu;
+            const uint32_t low = y & 0x7fffu, sf = (y >> 15) & 0x7fffu;
             cv = ((uint32_t)bin << cbits) | low;
             keep = true;
             if (y >> 31) {                                          // cell with >= 3 entries
                 const uint32_t t = s_tab[low];
-                const uint32_t n3 = t >> 18, so = (t >> 2) & 0xffffu;
+                const uint32_t n3 = (t >> 16) & 0x7fffu, so = t & 0x7fffu;
                 if (n3 == 0) cv |= 0x80000000u;                     // always-rare cell: raw hits counted later
                 else {
                     raw += n3; keep = false;
                     for (uint32_t e = 0; e < n3; e++) {
                         const uint32_t x = (uint32_t)s_side[so + e] ^ sf;
-                        keep = keep || (((x >> 6) & lmask) == 0) || ((x & rmask) == 0);
+                        keep = keep || ((x & lmask) == 0) || (((x >> 8) & rmask) == 0);
                     }
                 }
             }
@@ -1037,6 +1037,7 @@ probe_bin_kernel(GbnBinParams B)
             base = __shfl(base, 0);
             if (keep) {
                 const uint32_t at = base + (uint32_t)__popcll(m & lt);
+                const uint32_t pid = B.rec[GBN_REC_POS((size_t)bin * B.nwriters * B.subcap + at_rec)];
                 if (at < B.rare_seg) { myq[at].x = pid; myq[at].y = cv; }
             }
         }
@@ -1059,61 +1060,67 @@ probe_bin_kernel(GbnBinParams B)
         for (int v = wi + nw * wave; v < B.nwriters * split; v += nwaves) {
             const int w = v / split, part = v - w * split;
             const uint32_t ntot = B.gcount[(size_t)b * B.nwriters + w];
-            const uint32_t piece = ((ntot + (uint32_t)split * 512u - 1u) / ((uint32_t)split * 512u)) * 512u;
+            constexpr uint32_t U = GBN_PROBE_U, BLK = 256u * U, NR = 4 * U;    // records per wave and per lane and round
+            const uint32_t piece = ((ntot + (uint32_t)split * BLK - 1u) / ((uint32_t)split * BLK)) * BLK;
             const uint32_t lo = min((uint32_t)part * piece, ntot), n = min(piece, ntot - lo);
-            const unsigned long long *__restrict__ rec = B.rec + ((size_t)b * B.nwriters + w) * B.subcap + lo;
-            // software pipeline: the next 4 loads (8 records per lane) are in flight while the
-            // current 8 records are looked up
-            ulonglong2 cur[4], nxt[4];
+            const uint32_t *__restrict__ rec = B.rec + GBN_REC_HI(((size_t)b * B.nwriters + w) * B.subcap + lo);   // lo: multiple of 512
+            const uint32_t rbase = (uint32_t)w * B.subcap + lo;     // of this piece inside the bin's region
+            // software pipeline: the loads of the next round are in flight while this round's
+            // records are looked up
+            const uint4 padv = make_uint4(0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u);
+            uint4 cur[U], nxt[U];
             #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                const uint32_t j = (uint32_t)u * 128u + (uint32_t)lane * 2u;
-                cur[u] = (j < n) ? *reinterpret_cast<const ulonglong2 *>(rec + j)
-                                 : make_ulonglong2(0xffffffffull, 0xffffffffull);
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t j = u * 256u + (uint32_t)lane * 4u;
+                cur[u] = (j < n) ? *reinterpret_cast<const uint4 *>(rec + GBN_REC_HI(j)) : padv;
             }
-            for (uint32_t j0 = 0; j0 < n; j0 += 64u * 8u) {
+            for (uint32_t j0 = 0; j0 < n; j0 += BLK) {
                 #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    const uint32_t j = j0 + 512u + (uint32_t)u * 128u + (uint32_t)lane * 2u;
-                    nxt[u] = (j < n) ? *reinterpret_cast<const ulonglong2 *>(rec + j)
-                                     : make_ulonglong2(0xffffffffull, 0xffffffffull);
+                for (uint32_t u = 0; u < U; u++) {
+                    const uint32_t j = j0 + BLK + u * 256u + (uint32_t)lane * 4u;
+                    nxt[u] = (j < n) ? *reinterpret_cast<const uint4 *>(rec + GBN_REC_HI(j)) : padv;
                 }
-                uint32_t tv[8];
+                uint32_t hv[NR], tv[NR];
                 #pragma unroll
-                for (int u = 0; u < 4; u++) {                       // all LDS lookups first
-                    // a pad record has hi = 0: it reads cell 0 of the bin; its posid marks it below
-                    tv[2 * u] = (B.dbg & 8) ? 0u : s_tab[(uint32_t)(cur[u].x >> 46)];
-                    tv[2 * u + 1] = (B.dbg & 8) ? 0u : s_tab[(uint32_t)(cur[u].y >> 46)];
+                for (uint32_t u = 0; u < U; u++) { hv[4 * u] = cur[u].x; hv[4 * u + 1] = cur[u].y; hv[4 * u + 2] = cur[u].z; hv[4 * u + 3] = cur[u].w; }
+                #pragma unroll
+                for (uint32_t r = 0; r < NR; r++) tv[r] = s_tab[(hv[r] >> 15) & 0x7fffu];   // all LDS lookups first (a pad reads cell 0)
+                // Both fingerprints of the cell word against the subject's in one go: a masked byte of
+                // (t ^ sf:sf) is zero iff that side matches; (x - 0x01010101) & ~x & 0x80808080 is nonzero
+                // iff some byte is zero.  One-entry cells hold their fingerprint twice.
+                uint32_t raw32 = 0, slowm = 0;
+                #pragma unroll
+                for (uint32_t r = 0; r < NR; r++) {
+                    const uint32_t t = ((int32_t)hv[r] < 0) ? 0u : tv[r];
+                    const uint32_t x = (t ^ ((hv[r] & 0x7fffu) * 0x10001u)) & m4;
+                    const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;
+                    const bool c0 = (t & 0x8000u) != 0, c1 = (int32_t)t < 0;
+                    const bool slow = c0 ? (z != 0) : c1;
+                    raw32 += c0 ? (c1 ? 2u : 1u) : 0u;
+                    slowm |= slow ? (1u << r) : 0u;
                 }
-                uint32_t raw32 = 0;
-                #pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const unsigned long long r = h ? cur[u].y : cur[u].x;
-                        const uint32_t posid = (uint32_t)r, hi32 = (uint32_t)(r >> 32);
-                        const uint32_t t = (posid == 0xffffffffu) ? 0u : tv[2 * u + h];
-                        const uint32_t cls = t & 3u, sf = hi32 & 0x3fffu;
-                        const uint32_t x1 = (t >> 2) ^ sf, x2 = (t >> 16) ^ sf;
-                        const bool pA = (((x1 >> 6) & lmask) == 0) | ((x1 & rmask) == 0);
-                        const bool pB = ((((x2 >> 6) & lmask) == 0) | ((x2 & rmask & 0x3fffu) == 0));
-                        const bool slow = ((cls == 1) & pA) | ((cls == 2) & (pA | pB)) | (cls == 3);
-                        raw32 += (cls == 3) ? 0u : cls;
-                        const unsigned long long m = __ballot(slow);
-                        if (m) {
-                            if (slow) {
-                                const int at = qn + __popcll(m & lt);
-                                q[at].x = posid;
-                                q[at].y = (hi32 >> 14) | (sf << 15) | ((cls == 3) ? 0x80000000u : 0u);
-                            }
-                            qn += __popcll(m);
-                            if (qn >= 64) { qn -= 64; flush(qn, 64, b); }
-                        }
+                // queue the (few) records that need the rare path: one per lane and round
+                while (true) {
+                    const unsigned long long m = __ballot(slowm != 0);
+                    if (!m) break;
+                    if (slowm) {
+                        const uint32_t r = (uint32_t)__ffs(slowm) - 1u;
+                        slowm &= slowm - 1;
+                        uint32_t hi32 = 0;
+                        #pragma unroll
+                        for (uint32_t k = 0; k < NR; k++) hi32 = (r == k) ? hv[k] : hi32;
+                        const uint32_t t = s_tab[(hi32 >> 15) & 0x7fffu];
+                        const bool many = ((t & 0x8000u) == 0);                         // only c1: three or more entries
+                        const int at = qn + __popcll(m & lt);
+                        q[at].x = rbase + j0 + (r >> 2) * 256u + (uint32_t)lane * 4u + (r & 3u);
+                        q[at].y = ((hi32 >> 15) & 0x7fffu) | ((hi32 & 0x7fffu) << 15) | (many ? 0x80000000u : 0u);
                     }
+                    qn += __popcll(m);
+                    if (qn >= 64) { qn -= 64; flush(qn, 64, b); }
                 }
                 raw += raw32;
                 #pragma unroll
-                for (int u = 0; u < 4; u++) cur[u] = nxt[u];
+                for (uint32_t u = 0; u < U; u++) cur[u] = nxt[u];
             }
         }
         if (qn > 0) { flush(0, qn, b); qn = 0; }                    // the side list changes with the bin

@@ -1,0 +1,14 @@
+#!/bin/bash
+# Build a variant of libgblastn_amd.so with extra -D flags for same-box A/B timing:
+#   tools/build_variant.sh NAME "-DGBN_REC_BLOCK_BITS=4"   ->  variants/libgblastn_amd_NAME.so
+# (select it with GBN_AMD_LIB=variants/libgblastn_amd_NAME.so)
+set -e
+cd "$(dirname "$0")/../gblastn_amd/csrc"
+NAME=$1; FLAGS=$2
+OUT=../../variants; mkdir -p $OUT /tmp/var_$NAME
+for f in kernels.hip engine.cpp batch.cpp stat.cpp hsp_host.cpp collector.cpp; do
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off $FLAGS -c $f -o /tmp/var_$NAME/${f%.*}.o &
+done
+wait
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -o $OUT/libgblastn_amd_$NAME.so /tmp/var_$NAME/*.o
+echo built $OUT/libgblastn_amd_$NAME.so
