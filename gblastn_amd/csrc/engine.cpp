@@ -39,6 +39,8 @@ void set_error(const std::string &m) { g_err = m; }
 struct DeviceBatch {
     uint8_t *q8_base = nullptr;     // device copy of qbuf
     const uint8_t *q8 = nullptr;    // q8_base + qpad
+    uint8_t *q2_base = nullptr, *qinv_base = nullptr;   // 2-bit packed query + "matches nothing" bitmap
+    const uint8_t *q2 = nullptr, *qinv = nullptr;       // ... at base 0 (256 bases of padding either side)
     uint32_t *pv = nullptr, *cellw = nullptr, *cell_start = nullptr, *cellt = nullptr, *side_start = nullptr;
     uint16_t *sidet = nullptr;
     unsigned long long *ent = nullptr;
@@ -88,7 +90,7 @@ template <class T> static void dev_free(T *&p) { if (p) (void)hipFree((void *)p)
 
 void free_device_batch(DeviceBatch *d) {
     if (!d) return;
-    dev_free(d->q8_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent);
+    dev_free(d->q8_base); dev_free(d->q2_base); dev_free(d->qinv_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent);
     dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff);
     dev_free(d->ctx_reduced); dev_free(d->matrix); dev_free(d->score_table);
     delete d;
@@ -169,6 +171,19 @@ int upload_batch(GbnBatch &b) {
     }
     if ((rc = dev_upload(d->q8_base, b.qbuf.data(), b.qbuf.size()))) return rc;
     d->q8 = d->q8_base + b.qpad;
+    {   // packed copy for the greedy kernel's 32-bases-per-step match runs
+        const int64_t pad = 256, n = (int64_t)b.qlen + 2 * pad;
+        std::vector<uint8_t> q2((size_t)(n + 3) / 4 + 16, 0), qi((size_t)(n + 7) / 8 + 16, 0xff);
+        for (int64_t i = 0; i < n; i++) {
+            const int64_t src = (int64_t)b.qpad + i - pad;
+            const uint8_t code = (src >= 0 && src < (int64_t)b.qbuf.size()) ? b.qbuf[(size_t)src] : 15;
+            q2[(size_t)(i >> 2)] |= (uint8_t)((code & 3) << (6 - 2 * (i & 3)));
+            if (code <= 3) qi[(size_t)(i >> 3)] &= (uint8_t)~(0x80u >> (i & 7));
+        }
+        if ((rc = dev_upload(d->q2_base, q2.data(), q2.size()))) return rc;
+        if ((rc = dev_upload(d->qinv_base, qi.data(), qi.size()))) return rc;
+        d->q2 = d->q2_base + pad / 4; d->qinv = d->qinv_base + pad / 8;
+    }
     if ((rc = dev_upload(d->pv, L.pv.data(), L.pv.size()))) return rc;
     if ((rc = dev_upload(d->cellw, cellw.data(), cellw.size()))) return rc;
     if ((rc = dev_upload(d->cellt, cellt.data(), cellt.size()))) return rc;
@@ -486,7 +501,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     for (auto &c : b.ctx) max_ctx = std::max(max_ctx, c.query_length);
     GbnGapParams G; std::memset(&G, 0, sizeof(G));
     G.db = db.d_packed; G.byte_off = db.d_byte_off; G.len = db.d_len;
-    G.ihits = E.ihits; G.q8 = d->q8; G.ctx_off = d->ctx_off; G.ctx_len = d->ctx_len; G.nctx = (int32_t)b.ctx.size();
+    G.ihits = E.ihits; G.q8 = d->q8; G.q2 = d->q2; G.qinv = d->qinv; G.ctx_off = d->ctx_off; G.ctx_len = d->ctx_len; G.nctx = (int32_t)b.ctx.size();
     G.matrix = d->matrix; G.reward = b.opt.reward; G.penalty = b.opt.penalty;
     G.gap_open = b.opt.gap_open; G.gap_extend = b.opt.gap_extend; G.xdrop = b.gap_x_dropoff;
     G.out = E.gapped;

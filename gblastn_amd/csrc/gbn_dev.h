@@ -107,6 +107,9 @@ struct GbnGapParams {
     const uint8_t *db; const int64_t *byte_off; const int32_t *len;
     const GbnDevInitHit *ihits; int64_t first, n;
     const uint8_t *q8; const int32_t *ctx_off, *ctx_len; int32_t nctx;
+    // greedy only: the query 2 bits per base (same packing as the subjects) and a bitmap (MSB first)
+    // of the codes that match nothing; both indexed from base 0 and readable 256 bases either side
+    const uint8_t *q2, *qinv;
     const int32_t *matrix;
     int32_t reward, penalty, gap_open, gap_extend, xdrop;
     int32_t *scratch; int32_t scratch_per_thread, row_len;

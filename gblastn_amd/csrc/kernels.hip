@@ -22,6 +22,13 @@
 #ifndef GBN_PROBE_U
 #define GBN_PROBE_U 2        // 16-byte loads per lane and round of the probe kernel (4 records each)
 #endif
+// stream of (bin, writer): writer-major keeps the 512 streams a binning workgroup appends to
+// inside one ~100 MB stretch (few TLB entries) instead of spreading them over the whole buffer
+#if GBN_STREAM_BIN_MAJOR
+#define GBN_STREAM(B, bin, writer) ((size_t)(bin) * (B).nwriters + (writer))
+#else
+#define GBN_STREAM(B, bin, writer) ((size_t)(writer) * (B).nb + (bin))
+#endif
 #define GBN_BIN_GBIAS 32768u  // > GBN_BIN_STAGE: keeps (stream cursor - staging offset) non-negative
 #define GBN_BIN_OCC (4 * GBN_BIN_WG_PER_CU)  // waves per SIMD the binning kernel is compiled for
 #endif
@@ -376,25 +383,60 @@ extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
 // gapped extensions, one thread per initial hit (score-only)
 // ---------------------------------------------------------------------------
 namespace {
-__device__ __forceinline__ int32_t match_run_fwd(const uint8_t *q, const uint8_t *subj, int32_t len1, int32_t len2,
+// 32 consecutive bases of a 2-bit packed sequence starting at base index `pos` (may be negative:
+// both the subject slab and the packed query carry padding in front), big-endian in 64 bits
+__device__ __forceinline__ uint64_t bases32(const uint8_t *__restrict__ p, int64_t pos) {
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + (pos >> 4);
+    const uint64_t hi = ((uint64_t)bswap32(d[0]) << 32) | bswap32(d[1]);
+    const uint32_t lo = bswap32(d[2]);
+    const int sh = 2 * (int)(pos & 15);
+    return sh ? ((hi << sh) | ((uint64_t)lo >> (32 - sh))) : hi;
+}
+// 32 consecutive bits of a bitmap (most significant bit first) starting at bit index `pos`
+__device__ __forceinline__ uint32_t bits32(const uint8_t *__restrict__ p, int64_t pos) {
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + (pos >> 5);
+    const uint32_t hi = bswap32(d[0]), lo = bswap32(d[1]);
+    const int sh = (int)(pos & 31);
+    return sh ? ((hi << sh) | (lo >> (32 - sh))) : hi;
+}
+
+// query as the gapped kernels see it: 2 bits per base plus a bitmap of the codes that can
+// never match a subject base (ambiguity codes, sentinels); a0 = index of "q[0]"
+struct GQ { const uint8_t *q2; const uint8_t *qinv; int64_t a0; };
+__device__ __forceinline__ GQ operator+(GQ q, int32_t d) { q.a0 += d; return q; }
+
+// s_FindFirstMismatch (CORE/greedy_align.c:318-381), 32 bases per step
+__device__ __forceinline__ int32_t match_run_fwd(const GQ &q, const uint8_t *subj, int32_t len1, int32_t len2,
                                                  int32_t i1, int32_t i2, int32_t s_base)
 {
-    int32_t t = i1;
-    while (i1 < len1 && i2 < len2 && q[i1] == base_at(subj, (int64_t)s_base + i2)) { ++i1; ++i2; }
-    return i1 - t;
+    const int32_t maxn = min(len1 - i1, len2 - i2);
+    const int64_t qa = q.a0 + i1, sa = (int64_t)s_base + i2;
+    for (int32_t n = 0; n < maxn; n += 32) {
+        const uint64_t x = bases32(q.q2, qa + n) ^ bases32(subj, sa + n);
+        const uint32_t inv = bits32(q.qinv, qa + n);
+        const int32_t m = min(x ? (__clzll((long long)x) >> 1) : 32, inv ? __clz((int)inv) : 32);
+        if (m < 32) return min(n + m, maxn);
+    }
+    return max(maxn, 0);
 }
-__device__ __forceinline__ int32_t match_run_rev(const uint8_t *q, const uint8_t *subj, int32_t len1, int32_t len2,
+__device__ __forceinline__ int32_t match_run_rev(const GQ &q, const uint8_t *subj, int32_t len1, int32_t len2,
                                                  int32_t i1, int32_t i2)
 {
-    int32_t t = i1;
-    while (i1 < len1 && i2 < len2 && q[len1 - 1 - i1] == base_at(subj, len2 - 1 - i2)) { ++i1; ++i2; }
-    return i1 - t;
+    const int32_t maxn = min(len1 - i1, len2 - i2);
+    const int64_t qa = q.a0 + len1 - 1 - i1, sa = (int64_t)len2 - 1 - i2;     // last pair compared first
+    for (int32_t n = 0; n < maxn; n += 32) {
+        const uint64_t x = bases32(q.q2, qa - n - 31) ^ bases32(subj, sa - n - 31);
+        const uint32_t inv = bits32(q.qinv, qa - n - 31);
+        const int32_t m = min(x ? ((__ffsll((long long)x) - 1) >> 1) : 32, inv ? (__ffs((int)inv) - 1) : 32);
+        if (m < 32) return min(n + m, maxn);
+    }
+    return max(maxn, 0);
 }
 
 struct GSeed { int32_t start_q, start_s, match_length; };
 
 // non-affine greedy (BLAST_GreedyAlign), score only
-__device__ int32_t greedy_linear(const uint8_t *q, int32_t len1, const uint8_t *subj, int32_t s_base, int32_t len2,
+__device__ int32_t greedy_linear(const GQ &q, int32_t len1, const uint8_t *subj, int32_t s_base, int32_t len2,
                                  bool reverse, int32_t xdrop, int32_t match_cost, int32_t mismatch_cost,
                                  int32_t *l1, int32_t *l2, GSeed &seed, int32_t *row0, int32_t *row1,
                                  int32_t *max_score_base)
@@ -461,7 +503,7 @@ __device__ int gcd_dev(int a, int b) { b = abs(b); if (b > a) { int c = a; a = b
 
 // affine greedy (BLAST_AffineGreedyAlign, CORE/greedy_align.c:755-1236), score only.
 // scratch: rows[(max_penalty+1) * row_len] GOff, bounds[2 * (scaled_max + 1 + max_penalty)], max_score
-__device__ int32_t greedy_affine(const uint8_t *q, int32_t len1, const uint8_t *subj, int32_t s_base, int32_t len2,
+__device__ int32_t greedy_affine(const GQ &q, int32_t len1, const uint8_t *subj, int32_t s_base, int32_t len2,
                                  bool reverse, int32_t xdrop, int32_t match_score, int32_t mismatch_score,
                                  int32_t in_gap_open, int32_t in_gap_extend, int32_t *l1, int32_t *l2, GSeed &seed,
                                  int32_t *scratch, int32_t row_len_alloc)
@@ -562,7 +604,7 @@ extern "C" __global__ void greedy_kernel(GbnGapParams P)
     int lo = 0, hi = P.nctx;
     while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > h.q_off) hi = m; else lo = m; }
     const int32_t qstart = P.ctx_off[lo], qlen = P.ctx_len[lo];
-    const uint8_t *q = P.q8 + qstart;
+    const GQ q = {P.q2, P.qinv, (int64_t)qstart};
     const int32_t q_start_u = h.q_start - qstart;
     // start in the middle of the ungapped HSP (CORE/blast_gapalign.c:3466-3471)
     const int32_t q_off = q_start_u + h.length / 2, s_off = h.s_start + h.length / 2;
@@ -943,7 +985,7 @@ scan_bin_kernel(GbnBinParams B)
             if (l2 == 0xffffu) h4.z = 0x80000000u;
             if (l3 == 0xffffu) h4.w = 0x80000000u;
             if (w + 4u <= B.subcap && !(B.dbg & 2)) {
-                const size_t at = ((size_t)b * B.nwriters + blockIdx.x) * B.subcap + w;
+                const size_t at = GBN_STREAM(B, b, blockIdx.x) * B.subcap + w;
                 *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = h4;
                 *reinterpret_cast<uint4 *>(B.rec + GBN_REC_POS(at)) = p4;
             }
@@ -1037,7 +1079,8 @@ probe_bin_kernel(GbnBinParams B)
             base = __shfl(base, 0);
             if (keep) {
                 const uint32_t at = base + (uint32_t)__popcll(m & lt);
-                const uint32_t pid = B.rec[GBN_REC_POS((size_t)bin * B.nwriters * B.subcap + at_rec)];
+                const uint32_t wr = at_rec / B.subcap;              // writer of the record's stream
+                const uint32_t pid = B.rec[GBN_REC_POS(GBN_STREAM(B, bin, wr) * B.subcap + (at_rec - wr * B.subcap))];
                 if (at < B.rare_seg) { myq[at].x = pid; myq[at].y = cv; }
             }
         }
@@ -1063,7 +1106,7 @@ probe_bin_kernel(GbnBinParams B)
             constexpr uint32_t U = GBN_PROBE_U, BLK = 256u * U, NR = 4 * U;    // records per wave and per lane and round
             const uint32_t piece = ((ntot + (uint32_t)split * BLK - 1u) / ((uint32_t)split * BLK)) * BLK;
             const uint32_t lo = min((uint32_t)part * piece, ntot), n = min(piece, ntot - lo);
-            const uint32_t *__restrict__ rec = B.rec + GBN_REC_HI(((size_t)b * B.nwriters + w) * B.subcap + lo);   // lo: multiple of 512
+            const uint32_t *__restrict__ rec = B.rec + GBN_REC_HI(GBN_STREAM(B, b, w) * B.subcap + lo);   // lo: multiple of 512
             const uint32_t rbase = (uint32_t)w * B.subcap + lo;     // of this piece inside the bin's region
             // software pipeline: the loads of the next round are in flight while this round's
             // records are looked up
