@@ -100,3 +100,66 @@ def test_reference_known_answers_on_gpu():
                                xdrop_gap_bits=100.0, xdrop_gap_final_bits=100.0), src)
     h = ps.run()["hsps"]
     assert len(h) == 1 and h[0]["score"] == 6034
+
+
+def _mutate(rng, seq, subs, indels):
+    s = seq.copy()
+    for _ in range(subs):
+        p = int(rng.integers(0, len(s))); s[p] = (s[p] + 1 + rng.integers(0, 3)) & 3
+    for _ in range(indels):
+        p = int(rng.integers(5, len(s) - 5))
+        s = np.delete(s, p) if rng.random() < 0.5 else np.insert(s, p, rng.integers(0, 4))
+    return s.astype(np.uint8)
+
+
+def ragged_case(task, rng_seed, with_n=True):
+    """Edge cases the reference's tests exercise: subjects shorter than the lookup word, lengths that
+    are not multiples of 4, hits touching either end of a subject, queries shorter than the word
+    size, ambiguity codes (N = 14 in BLASTNA) inside queries, hits on the minus strand."""
+    rng = np.random.default_rng(rng_seed)
+    lens = [2, 3, 7, 11, 12, 27, 28, 29, 31, 64, 257, 1001, 4099, 30_003, 50_001, 1]
+    subs = [rng.integers(0, 4, n, dtype=np.uint8) for n in lens]
+    queries = []
+    # homologs at the very start / very end of a subject, and spanning a whole short subject
+    queries.append(_mutate(rng, subs[13][:700], 12, 2))                         # starts at subject base 0
+    queries.append(_mutate(rng, subs[14][-650:], 10, 1))                        # ends at the last base
+    queries.append(np.concatenate([rng.integers(0, 4, 200, dtype=np.uint8), subs[11], rng.integers(0, 4, 200, dtype=np.uint8)]))
+    queries.append((3 - _mutate(rng, subs[13][9000:9800], 15, 2))[::-1].copy())  # minus strand
+    queries.append(rng.integers(0, 4, 20, dtype=np.uint8))                      # shorter than word size 28
+    queries.append(subs[9][:40].copy())                                         # tiny query, tiny subject
+    q = _mutate(rng, subs[13][20000:21000], 8, 1)
+    if with_n:
+        q[100:104] = 14; q[500] = 14; q[777] = 4                                # N runs, single N, another ambiguity code
+    queries.append(q)
+    q = _mutate(rng, subs[12][1000:1900], 30, 3)
+    if with_n:
+        q[::97] = 14
+    queries.append(q)
+    from oracle import orc
+    subjects = [(orc.pack_ncbi2na(s), len(s)) for s in subs]
+    opt = api.default_options(task, db_length=int(sum(lens)), db_num_seqs=len(lens))
+    return queries, subjects, opt
+
+
+@pytest.mark.parametrize("task", ["megablast", "blastn"])
+def test_ragged_subjects_short_queries_and_ambiguity_codes(task):
+    queries, subjects, opt = ragged_case(task, 2024)
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    gpu = ps.run(keep_stages=True)
+    ora, s = util.oracle_run(opt, queries, subjects)
+    util.compare_stages(gpu, ora)
+    assert len(gpu["hsps"]) >= 5
+    d = ps.diagnostics
+    assert (d.lookup_hits, d.good_init_extends, d.gapped_extensions, d.good_extensions) == \
+           (s.stats.lookup_hits, s.stats.good_init_extends, s.stats.gapped_extensions, s.stats.good_extensions)
+
+
+def test_first_oid_offsets_and_two_shards_equal_one():
+    # a database cut into two shards (global statistics) gives the records of the whole database
+    db, queries, plants, subjects, opt = util.small_case(8, 80_000, 12)
+    whole = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed(subjects)).run()["hsps"]
+    a = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed(subjects[:3], first_oid=0)).run()["hsps"]
+    b = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed(subjects[3:], first_oid=3)).run()["hsps"]
+    both = np.concatenate([a, b])
+    assert np.array_equal(both, whole)
