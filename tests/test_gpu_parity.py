@@ -163,3 +163,38 @@ def test_first_oid_offsets_and_two_shards_equal_one():
     b = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed(subjects[3:], first_oid=3)).run()["hsps"]
     both = np.concatenate([a, b])
     assert np.array_equal(both, whole)
+
+
+def test_full_size_c2_pass_against_the_oracle_subject_by_subject():
+    """BASELINE.json configs[1] at full size: 50,000 x 1 Mb subjects, one 5 Mb query batch (lut 12,
+    stride 17, diagonal hash).  Subjects are independent given the global statistics, so the pass is
+    checked bit for bit against the oracle on every subject that produced an HSP plus a sample of the
+    others, and for determinism (two passes give identical records)."""
+    import torch
+    nsub, slen, nq = 50_000, 1_000_000, 5_000
+    db = synth.SynthDb(nsub, slen, seed=0x9E3779B97F4A7C15 ^ 1)
+    slab = torch.empty(db.nbytes, dtype=torch.uint8, device="cuda")
+    api._check(api.lib().gbn_synth_fill(slab.data_ptr(), db.nbytes, db.seed, None))
+    src = api.BlastSeqSrc.from_slab((slab.data_ptr(), db.nbytes), db.byte_off, db.lens, is_device=True, keep=slab)
+    queries, plants = synth.make_queries(nq, db)
+    opt = api.default_options("megablast", db_length=nsub * slen, db_num_seqs=nsub)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    assert ps.info()["lut_width"] == 12 and ps.info()["scan_step"] == 17 and ps.info()["container"] == 1
+    first = ps.run()["hsps"]
+    again = ps.run()["hsps"]
+    assert np.array_equal(first, again)
+    assert np.all(np.diff(first["oid"]) >= 0)
+    assert ps.diagnostics.subject_bases_scanned == 2 * nsub * slen
+    hit_oids = np.unique(first["oid"])
+    assert len(hit_oids) >= 0.9 * len(plants)          # planted homologs are found
+    rng = np.random.default_rng(3)
+    sample = np.union1d(hit_oids, rng.choice(nsub, 25, replace=False))
+    from oracle import orc
+    s = orc.Search(util.oracle_options(opt), queries)
+    for oid in sample.tolist():
+        o = s.subject(db.subject_packed(oid), slen)
+        g = first[first["oid"] == oid]
+        assert len(g) == len(o["hsps"]), (oid, len(g), len(o["hsps"]))
+        for f in ["context", "q_offset", "q_end", "q_gapped_start", "s_offset", "s_end", "s_gapped_start", "score"]:
+            assert np.array_equal(g[f], o["hsps"][f]), (oid, f)
+        assert np.array_equal(g["evalue"].view(np.uint64), o["hsps"]["evalue"].view(np.uint64)), oid
