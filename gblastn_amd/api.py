@@ -141,7 +141,7 @@ def default_options(task="megablast", db_length=0, db_num_seqs=0, **kw):
     return o
 
 
-def layout_slab(lengths, front=16, align=16, tail=64):
+def layout_slab(lengths, front=16, align=16, tail=128):
     """Byte offsets of NCBI2na subjects in one slab (16-byte aligned, padded)."""
     offs = np.zeros(len(lengths), dtype=np.int64)
     pos = front

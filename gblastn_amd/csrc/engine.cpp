@@ -410,6 +410,12 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
             unsigned long long sc = 0; uint32_t mx = 0;
             for (uint32_t v : rc_host) { sc += v; mx = std::max(mx, v); }
             if (getenv("GBN_DBG")) fprintf(stderr, "[gbn dbg] rare-path items %llu, seeds %llu, raw %llu\n", sc, cnt[0], cnt[1]);
+            if (getenv("GBN_DBG") && (atoi(getenv("GBN_DBG")) & 32)) {
+                uint32_t ph[8]; HIPCHK(hipMemcpy(ph, E.rare_counts + 512, sizeof(ph), hipMemcpyDeviceToHost));
+                fprintf(stderr, "[gbn dbg] scan_bin workgroup 0 (GBN_BIN_TIMING build), cycles/16: bookkeeping+atomics issued %u, ranks returned %u, "
+                        "loads issued %u, barrier A %u | scan %u | pads+scatter %u | next keys %u | write-out %u\n",
+                        ph[5], ph[6], ph[7], ph[0], ph[1], ph[2], ph[3], ph[4]);
+            }
             if ((size_t)mx > E.rareq_cap / (size_t)grid2) {    // a segment overflowed: grow and rescan this range
                 rare_seg_hint = (size_t)mx + (mx >> 2);
                 continue;
@@ -647,8 +653,8 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
     db->num_seqs = num_seqs; db->first_oid = first_oid; db->nbytes = nbytes;
     db->byte_off.assign(byte_off, byte_off + num_seqs); db->len.assign(len, len + num_seqs);
     for (int32_t i = 0; i < num_seqs; i++) {
-        if (byte_off[i] < 16 || (byte_off[i] & 15) || byte_off[i] + (len[i] + 3) / 4 + 64 > nbytes) {
-            delete db; set_error("subject offsets must be 16-byte aligned, >= 16, and leave 64 pad bytes"); return GBN_ERR_ARG;
+        if (byte_off[i] < 16 || (byte_off[i] & 15) || byte_off[i] + (len[i] + 3) / 4 + 128 > nbytes) {
+            delete db; set_error("subject offsets must be 16-byte aligned, >= 16, and leave 128 pad bytes"); return GBN_ERR_ARG;
         }
         db->total_bases += len[i];
     }

@@ -864,8 +864,14 @@ __device__ __forceinline__ uint64_t window32u(const uint8_t *__restrict__ base16
 //   the bytes of tile t+1 and the descriptor of tile t+2 are requested right after the
 //   histogram atomics of tile t and first touched after its LDS sort;
 //   the stores of tile t are issued last and only waited for one tile later.
-extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, GBN_BIN_OCC)
-scan_bin_kernel(GbnBinParams B)
+// STEP > 0: the scan stride is a compile-time constant and every lane owns 16 CONSECUTIVE positions
+// (index = lane * 16 + j).  16 positions span exactly STEP dwords of the 2-bit subject and tiles start
+// on a dword, so a lane fetches its STEP + 2 dwords with a few wide loads and cuts all 16 windows out
+// of registers with constant shifts (5 vector-memory instructions per lane instead of 16: the
+// texture-address unit was the busiest pipe of the strided version).  STEP == 0: any stride, one
+// unaligned 8-byte load per position, index = lane + 1024 * j.
+template <int STEP>
+__device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
 {
     const GbnScanParams &P = B.S;
     __shared__ __attribute__((aligned(16))) uint32_t s_hi[GBN_BIN_STAGE];   // record high word, bin-sorted
@@ -882,20 +888,50 @@ scan_bin_kernel(GbnBinParams B)
     const uint32_t ustep = (uint32_t)P.step;
     const int64_t stride = gridDim.x, last = P.ntiles - 1;
 
-    // one unaligned 8-byte load per position: bases [pos - 4, pos + lut + 4) are <= 40 bits that
-    // start at most 6 bits into the byte holding base pos - 4.  Lanes past the tile's end re-read its last
-    // position (and are dropped when ranks are taken).
+    // raw subject data of one tile, per lane
+    constexpr int NDW = STEP > 0 ? ((2 * STEP * 15 - 8 + 38) >> 5) + 2 : 2 * PER;   // dwords -1 .. last
+    struct Raw { uint32_t d[NDW]; };
+    // index of a lane's k-th position inside the tile
+    auto idx_of = [&](int k) -> uint32_t { return STEP > 0 ? (uint32_t)(tid * PER + k) : (uint32_t)(tid + k * GBN_BIN_THREADS); };
+    // STEP == 0: one unaligned 8-byte load per position: bases [pos - 4, pos + lut + 4) are <= 40 bits
+    // that start at most 6 bits into the byte holding base pos - 4.  Lanes past the tile's end re-read
+    // its last position (and are dropped when ranks are taken).
     auto upos_of = [&](const GbnTile &t, int k) -> uint32_t {
-        const uint32_t i = min((uint32_t)(tid + k * GBN_BIN_THREADS), (uint32_t)t.npos - 1u);
+        const uint32_t i = min(idx_of(k), (uint32_t)t.npos - 1u);
         return (uint32_t)t.first_pos + i * ustep + 60u;         // base index + 64 (>= 60; subjects start >= 16 bytes into the slab)
     };
-    auto fetch = [&](const GbnTile &t, int k) -> uint64_t {
-        uint64_t raw;
-        __builtin_memcpy(&raw, P.db + ((size_t)(uint32_t)t.off16 << 4) - 16 + (upos_of(t, k) >> 2), 8);
-        return raw;
+    auto fetch = [&](const GbnTile &t, Raw &r) {
+        if constexpr (STEP > 0) {
+            // dwords [D0 - 1, D0 - 1 + NDW) of the subject, D0 = first_pos / 16 + lane * STEP; lanes past
+            // the tile's end re-read its last lane (the slab carries 128 pad bytes behind the last subject)
+            const uint32_t lane_c = min((uint32_t)tid, ((uint32_t)t.npos - 1u) / PER);
+            const uint8_t *p = P.db + ((size_t)(uint32_t)t.off16 << 4) + 4 * ((size_t)((uint32_t)t.first_pos >> 4) + (size_t)lane_c * STEP) - 4;
+            #pragma unroll
+            for (int i = 0; i + 4 <= NDW; i += 4) __builtin_memcpy(&r.d[i], p + 4 * i, 16);
+            if constexpr (NDW % 4 == 3) { __builtin_memcpy(&r.d[NDW - 3], p + 4 * (NDW - 3), 12); }
+            else if constexpr (NDW % 4 == 2) { __builtin_memcpy(&r.d[NDW - 2], p + 4 * (NDW - 2), 8); }
+            else if constexpr (NDW % 4 == 1) { __builtin_memcpy(&r.d[NDW - 1], p + 4 * (NDW - 1), 4); }
+        } else {
+            #pragma unroll
+            for (int k = 0; k < PER; k++)
+                __builtin_memcpy(&r.d[2 * k], P.db + ((size_t)(uint32_t)t.off16 << 4) - 16 + (upos_of(t, k) >> 2), 8);
+        }
     };
-    auto keys = [&](const GbnTile &t, int k, uint64_t raw, uint32_t &bin, uint32_t &hi) {
-        const uint64_t w = __builtin_bswap64(raw) << (2 * (upos_of(t, k) & 3));   // bits 63..56 left-4, lut word, right-3
+    // 64-bit window of position k: bits 63..56 = the 4 bases left of the lookup word, then the word, then
+    // the bases right of it
+    auto keys = [&](const GbnTile &t, int k, const Raw &r, uint32_t &bin, uint32_t &hi) {
+        uint64_t w;
+        if constexpr (STEP > 0) {
+            const int bit = 2 * STEP * k - 8 + 32;              // window start, in bits from dword -1 (compile-time)
+            const int a = bit >> 5, o = bit & 31;
+            const uint32_t x0 = bswap32(r.d[a]), x1 = bswap32(r.d[a + 1]), x2 = bswap32(r.d[a + 2 < NDW ? a + 2 : NDW - 1]);
+            const uint32_t hi32 = o ? ((x0 << o) | (x1 >> (32 - o))) : x0;
+            const uint32_t lo32 = o ? ((x1 << o) | (x2 >> (32 - o))) : x1;
+            w = ((uint64_t)hi32 << 32) | lo32;
+        } else {
+            uint64_t raw; __builtin_memcpy(&raw, &r.d[2 * k], 8);
+            w = __builtin_bswap64(raw) << (2 * (upos_of(t, k) & 3));
+        }
         const uint32_t c = (uint32_t)(w >> cshift) & mask;
         bin = c >> cbits;
         hi = ((c & lowmask) << 15) | (((uint32_t)(w >> rshift) & 0x7fu) << 8) | (uint32_t)(w >> 56);
@@ -915,37 +951,63 @@ scan_bin_kernel(GbnBinParams B)
     GbnTile T = uniform(P.tiles[tile]);
     GbnTile T1 = uniform(P.tiles[min(tile + stride, last)]);
     uint32_t bin[PER], hi[PER];
-    #pragma unroll
-    for (int k = 0; k < PER; k++) keys(T, k, fetch(T, k), bin[k], hi[k]);
+    {
+        Raw r0; fetch(T, r0);
+        #pragma unroll
+        for (int k = 0; k < PER; k++) keys(T, k, r0, bin[k], hi[k]);
+    }
     __syncthreads();
 
+#if GBN_BIN_TIMING   // phase timer of workgroup 0 (tools/build_variant.sh t "-DGBN_BIN_TIMING=1", GBN_DBG=32)
+    const bool timed = blockIdx.x == 0 && tid == 0;
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define GBN_LAP(ph) do { if (timed) { const unsigned long long t_ = __builtin_readcyclecounter(); tph[ph] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define GBN_LAP(ph) do { } while (0)
+#endif
     for (; tile <= last; tile += stride) {
         uint32_t rank[PER];
         #pragma unroll
         for (int k = 0; k < PER; k++) {
             rank[k] = 0;
-            if (tid + k * GBN_BIN_THREADS < T.npos)
+            if (idx_of(k) < (uint32_t)T.npos)
                 rank[k] = atomicAdd(&s_hist[bin[k]], 1u);       // arrival order inside the bin: any order will do
         }
-        uint64_t R[PER];
-        #pragma unroll
-        for (int k = 0; k < PER; k++) R[k] = fetch(T1, k);     // tile t+1 (== the last tile again at the end)
+        GBN_LAP(5);
+#if GBN_BIN_TIMING
+        __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): ranks returned
+        GBN_LAP(6);
+#endif
+        Raw R; fetch(T1, R);                                    // tile t+1 (== the last tile again at the end)
         GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
+        GBN_LAP(7);
         __syncthreads();                                        // (A) histogram complete
-        // exclusive scan of the padded bin sizes (x4 records = 32-byte sectors) by wave 0
+        GBN_LAP(0);
+        // exclusive scan of the padded bin sizes (x4 records = 32-byte sectors): wave 0, each lane sums
+        // nb/64 consecutive bins, one wave scan over the 64 partial sums
         if (tid < 64) {
-            uint32_t carry = 0;
-            for (int base = 0; base < nb; base += 64) {
-                int b = base + tid;
-                uint32_t v = (b < nb) ? ((s_hist[b] + 3u) & ~3u) : 0u;
-                uint32_t x = v;
-                for (int o = 1; o < 64; o <<= 1) { uint32_t y = __shfl_up(x, o); if (tid >= o) x += y; }
-                if (b < nb) s_off[b] = carry + x - v;
-                carry += __shfl(x, 63);
+            constexpr int MAXQ = GBN_BIN_MAXNB / 64;
+            const int per = (nb + 63) >> 6;                     // bins per lane (nb = 8 .. 512)
+            uint32_t v[MAXQ], sum = 0;
+            #pragma unroll
+            for (int i = 0; i < MAXQ; i++) {
+                const int b = tid * per + i;
+                v[i] = (i < per && b < nb) ? ((s_hist[b] + 3u) & ~3u) : 0u;
+                sum += v[i];
             }
-            if (tid == 0) s_off[nb] = carry;
+            uint32_t x = sum;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (tid >= o) x += y; }
+            uint32_t run = x - sum;
+            #pragma unroll
+            for (int i = 0; i < MAXQ; i++) {
+                const int b = tid * per + i;
+                if (i < per && b < nb) s_off[b] = run;
+                run += v[i];
+            }
+            if (tid == 63) s_off[nb] = x;
         }
         __syncthreads();                                        // (B) offsets known
+        GBN_LAP(1);
         const uint32_t total = s_off[nb];
         for (int b = tid; b < nb; b += GBN_BIN_THREADS) {
             const uint32_t n = s_hist[b], o0 = s_off[b], o1 = s_off[b + 1];
@@ -955,20 +1017,22 @@ scan_bin_kernel(GbnBinParams B)
         }
         #pragma unroll
         for (int k = 0; k < PER; k++) {
-            if (tid + k * GBN_BIN_THREADS < T.npos) {
+            if (idx_of(k) < (uint32_t)T.npos) {
                 const uint32_t slot = s_off[bin[k]] + rank[k];
                 s_hi[slot] = hi[k];
-                s_idx[slot] = (uint16_t)(tid + k * GBN_BIN_THREADS);
+                s_idx[slot] = (uint16_t)idx_of(k);
             }
         }
         __syncthreads();                                        // (C) tile is bin-sorted in LDS
+        GBN_LAP(2);
         for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_hist[b] = 0;     // for the next tile; ordered by (D)
         // first touch of the prefetched data: everything older than these loads (the previous
         // tile's stores) has long completed, nothing younger is outstanding yet
         const uint32_t tbase = (uint32_t)tile << GBN_BIN_TILE_BITS;
         T = T1; T1 = uniform(T2);
         #pragma unroll
-        for (int k = 0; k < PER; k++) keys(T, k, R[k], bin[k], hi[k]);
+        for (int k = 0; k < PER; k++) keys(T, k, R, bin[k], hi[k]);
+        GBN_LAP(3);
         // write-out: one lane per group of 4 records, one 16-byte store to each of the two record
         // arrays; the lanes of a wave that fall into the same run write one contiguous stretch
         for (uint32_t g = tid; g < (total >> 2); g += GBN_BIN_THREADS) {
@@ -991,12 +1055,20 @@ scan_bin_kernel(GbnBinParams B)
             }
         }
         __syncthreads();                                        // (D) staging buffers free again
+        GBN_LAP(4);
         for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_wcur[b] += s_off[b + 1] - s_off[b];
     }
+#if GBN_BIN_TIMING
+    if (timed) for (int i = 0; i < 8; i++) B.rare_counts[512 + i] = (uint32_t)(tph[i] >> 4);
+#endif
     __syncthreads();
     for (int b = tid; b < nb; b += GBN_BIN_THREADS)
         B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(s_wcur[b], B.subcap);
 }
+
+extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, GBN_BIN_OCC) scan_bin_kernel(GbnBinParams B) { scan_bin_body<0>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, GBN_BIN_OCC) scan_bin_kernel_s17(GbnBinParams B) { scan_bin_body<17>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { scan_bin_body<18>(B); }
 
 namespace {
 // rare path of the probe kernel: full fingerprints, chain walk, exact verification
@@ -1202,7 +1274,11 @@ hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hip
     // ev[0..3]: before bin, after bin, after probe, after rare (optional)
     if (b.S.ntiles <= 0) return hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], st);
-    hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_BIN_THREADS), 0, st, b);
+    // stride-specialised variants for the two megablast strides (word 28 with lut 12 / lut 11)
+    const bool generic = (b.dbg & 64) != 0;
+    if (b.S.step == 17 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_BIN_THREADS), 0, st, b);
+    else if (b.S.step == 18 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s18, dim3(b.nwriters), dim3(GBN_BIN_THREADS), 0, st, b);
+    else hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_BIN_THREADS), 0, st, b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[1], st);

@@ -58,7 +58,7 @@ class SynthDb:
         self.num, self.length, self.seed, self.first_oid = num, length, seed, first_oid
         self.stride = (((length + 3) // 4) + 15) // 16 * 16
         self.front = 16
-        self.nbytes = self.front + num * self.stride + 64
+        self.nbytes = self.front + num * self.stride + 128
         self.nbytes = (self.nbytes + 7) // 8 * 8
         self.byte_off = self.front + np.arange(num, dtype=np.int64) * self.stride
         self.lens = np.full(num, length, dtype=np.int32)

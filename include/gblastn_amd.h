@@ -136,7 +136,7 @@ void gpu_ReleaseDBMemory(void);
 typedef struct GbnDb GbnDb;
 /* `packed` holds the NCBI2na data of all subjects back to back: subject i
  * occupies bytes [byte_off[i], byte_off[i] + ceil(len[i]/4)).  byte_off must be
- * 16-byte aligned per subject and the buffer must extend 64 bytes past the
+ * 16-byte aligned per subject and the buffer must extend 128 bytes past the
  * last subject.  is_device != 0: `packed` is already a device pointer (e.g.
  * a torch tensor) that stays owned by the caller. */
 int  gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_seqs,
