@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--batch-queries", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="run every pass to completion before the next starts")
     a = ap.parse_args()
     if a.subjects is None:
         a.subjects = 50_000 if a.workload == "C2" else 5_000
@@ -102,29 +103,42 @@ def main():
                for i in range(nbatch)]
     info = batches[0].info()
 
-    def one_pass(step):
-        b = batches[step % nbatch]
-        out = b.run()
+    def merge(b, out):
         # exchange + merge step: gather to rank 0, replay through the per-query top-N collector
         got = shard.collect_on_root(out["hsps"], len(b._q), opt.hitlist_size, dst=0, device=dev)
-        return b, (got[0] if got is not None else None)
+        return 0 if got is None else len(got[0])
+
+    def run_passes(first, count):
+        """`count` passes, software-pipelined when there are two batches to alternate: the gapped
+        stage + host acceptance + gather/merge of pass k overlap the scan of pass k + 1.  Every pass
+        is complete (merged on rank 0) when this returns."""
+        n = 0
+        if nbatch < 2 or args.no_overlap:
+            for k in range(first, first + count):
+                b = batches[k % nbatch]
+                n += merge(b, b.run())
+            return n
+        prev = None
+        for k in range(first, first + count):
+            b = batches[k % nbatch]
+            b.begin()                       # waits for prev's gapped stage before queueing its own
+            if prev is not None:
+                n += merge(prev, prev.end())
+            prev = b
+        n += merge(prev, prev.end())
+        return n
 
     def sync():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for w in range(args.warmup):
-        one_pass(w)
+    run_passes(0, args.warmup)
     sync()
     for b in batches:
         b.diagnostics = api.GbnDiagnostics()
     t0 = time.perf_counter()
-    nhsp = 0
-    for k in range(args.steps):
-        b, hs = one_pass(k)
-        if hs is not None:
-            nhsp += len(hs)
+    nhsp = run_passes(args.warmup, args.steps)
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -177,6 +191,8 @@ def main():
                                "lut_type": info["lut_type"], "diag_container": info["container"]},
                 "subjects_per_gpu": nsub, "subject_len": slen,
                 "parallelism": "db-shard x%d (volumes by rank, RCCL gather of HSP records)" % world,
+                "pipeline": "off" if (nbatch < 2 or args.no_overlap) else
+                            "gapped stage + merge of pass k overlap the scan of pass k+1 (second HIP stream + host thread)",
                 "hsps_per_pass": nhsp / max(args.steps, 1),
                 "seeds_per_pass": seeds / max(launches, 1),
                 "lookup_hits_per_pass": lookup_hits / max(launches, 1),

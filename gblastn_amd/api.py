@@ -67,7 +67,7 @@ EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_de
            "gbn_results_num_seeds", "gbn_results_seeds", "gbn_results_num_init_hits",
            "gbn_results_init_hits", "gbn_prelim_search", "gbn_scan_only", "gbn_last_error",
            "gbn_launch_scan_seed", "gbn_launch_ungapped", "gbn_launch_gapped",
-           "gbn_prelim_hitlist_size", "gbn_collector_new", "gbn_collector_free", "gbn_collector_write",
+           "gbn_prelim_search_begin", "gbn_prelim_search_end", "gbn_prelim_hitlist_size", "gbn_collector_new", "gbn_collector_free", "gbn_collector_write",
            "gbn_collector_close", "gbn_collector_num_lists", "gbn_collector_list_starts",
            "gbn_collector_list_queries", "gbn_collector_num_hsps", "gbn_collector_hsps"]
 
@@ -110,6 +110,9 @@ def lib():
         L.gbn_prelim_search.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p,
                                         C.POINTER(GbnDiagnostics), C.c_int, C.c_void_p, C.c_void_p]
         L.gbn_scan_only.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(GbnDiagnostics)]
+        L.gbn_prelim_search_begin.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(GbnDiagnostics),
+                                              C.c_void_p, C.c_void_p]
+        L.gbn_prelim_search_end.argtypes = [C.c_void_p]
         L.gbn_prelim_hitlist_size.restype = C.c_int32; L.gbn_prelim_hitlist_size.argtypes = [C.c_int32]
         L.gbn_collector_new.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.c_int32]
         L.gbn_collector_free.argtypes = [C.c_void_p]
@@ -253,6 +256,19 @@ class BlastPrelimSearch:
             out["seeds"] = self._grab(L.gbn_results_num_seeds, L.gbn_results_seeds, SEED_DT)
             out["init_hits"] = self._grab(L.gbn_results_num_init_hits, L.gbn_results_init_hits, IHIT_DT)
         return out
+
+    def begin(self, seqsrc=None):
+        """Pipelined run: returns when only the gapped stage of this batch is still in flight."""
+        L = lib()
+        L.gbn_results_clear(self._r)
+        _check(L.gbn_prelim_search_begin(self._b, (seqsrc or self.seqsrc)._h, self._r,
+                                         C.byref(self.diagnostics), None, None))
+
+    def end(self):
+        """Wait for this batch's gapped stage if it is still in flight; returns the batch's HSPs."""
+        L = lib()
+        _check(L.gbn_prelim_search_end(self._r))
+        return dict(hsps=self._grab(L.gbn_results_num_hsps, L.gbn_results_hsps, HSP_DT))
 
     def scan_only(self, seqsrc=None, repeats=1):
         d = GbnDiagnostics()

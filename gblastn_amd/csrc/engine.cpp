@@ -15,6 +15,7 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <future>
 #include <mutex>
 #include <tuple>
 #include <cstdlib>
@@ -58,9 +59,13 @@ struct Engine {
     uint64_t *key_a = nullptr, *key_b = nullptr; uint32_t *idx_a = nullptr, *idx_b = nullptr;
     int32_t *cell_diag = nullptr, *cell_level = nullptr; size_t key_cap = 0;
     void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
-    GbnDevInitHit *ihits = nullptr; GbnDevGapped *gapped = nullptr; size_t ihit_cap = 0;
+    // initial hits / gapped extensions / gapped scratch exist twice: the gapped stage of one range
+    // (stream2 + a host thread) overlaps the scan of the next range or query batch
+    GbnDevInitHit *ihits_s[2] = {nullptr, nullptr}; GbnDevGapped *gapped_s[2] = {nullptr, nullptr}; size_t ihit_cap_s[2] = {0, 0};
+    int32_t *gap_scratch_s[2] = {nullptr, nullptr}; size_t gap_scratch_ints_s[2] = {0, 0};
+    int slot = 0; hipStream_t stream2 = nullptr;
+    std::future<int> pending; bool has_pending = false; std::string pending_err; const GbnResults *pending_res = nullptr;
     unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits
-    int32_t *gap_scratch = nullptr; size_t gap_scratch_ints = 0;
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
     GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
     uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;   // [nb][nwriters] + overflow flag
@@ -279,14 +284,23 @@ static int grow_key_buffers(size_t n) {
     E.sort_tmp_bytes = bytes; E.key_cap = cap;
     return GBN_OK;
 }
-static int grow_ihit_buffers(size_t n) {
-    if (n <= E.ihit_cap) return GBN_OK;
-    dev_free(E.ihits); dev_free(E.gapped);
+static int grow_ihit_buffers(int slot, size_t n) {
+    if (n <= E.ihit_cap_s[slot]) return GBN_OK;
+    dev_free(E.ihits_s[slot]); dev_free(E.gapped_s[slot]);
     size_t cap = std::max<size_t>(n, 1 << 14);
     int rc;
-    if ((rc = dev_alloc(E.ihits, cap)) || (rc = dev_alloc(E.gapped, cap))) return rc;
-    E.ihit_cap = cap;
+    if ((rc = dev_alloc(E.ihits_s[slot], cap)) || (rc = dev_alloc(E.gapped_s[slot], cap))) return rc;
+    E.ihit_cap_s[slot] = cap;
     return GBN_OK;
+}
+
+// wait for the gapped stage that is still in flight (if any); returns its status
+static int wait_pending() {
+    if (!E.has_pending) return GBN_OK;
+    int rc = E.pending.get();
+    E.has_pending = false;
+    if (rc && !E.pending_err.empty()) set_error(E.pending_err);
+    return rc;
 }
 
 static void fill_scan_params(GbnScanParams &P, const GbnBatch &b, const GbnDb &db, const TileSet &ts) {
@@ -429,9 +443,16 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
 }
 
 // one range of subjects [s0, s1) through the whole pipeline
+static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag,
+                        int keep_stages, int slot, unsigned long long nih, hipStream_t st);
+
+// one range of subjects [s0, s1): scan, seed order, diagonal filter + ungapped extension on the engine's
+// stream; then the gapped stage -- inline, or (overlap != 0) on stream2 + a host thread while the caller
+// goes on to the next range / batch.  At most one gapped stage is in flight.
 static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res,
-                        GbnDiagnostics *diag, int keep_stages)
+                        GbnDiagnostics *diag, int keep_stages, int overlap = 0)
 {
+    const int slot = E.slot;
     const DeviceBatch *d = b.dev;
     unsigned long long cnt[3] = {0, 0, 0};
     int64_t bases = 0;
@@ -477,7 +498,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         res.seeds.insert(res.seeds.end(), tmp.begin(), tmp.end());
     }
 
-    if ((rc = grow_ihit_buffers(std::max<size_t>(E.ihit_cap, 1 << 16)))) return rc;
+    if ((rc = grow_ihit_buffers(slot, std::max<size_t>(E.ihit_cap_s[slot], 1 << 16)))) return rc;
     unsigned long long nih = 0;
     for (;;) {
         HIPCHK(hipMemsetAsync(E.counters + 2, 0, sizeof(unsigned long long), E.stream));
@@ -490,27 +511,51 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         X.matrix = d->matrix; X.score_table = d->score_table;
         X.word = b.lut.word; X.container_hash = b.container;
         X.cell_diag = E.cell_diag; X.cell_level = E.cell_level;
-        X.ihits = E.ihits; X.ihit_count = E.counters + 2; X.ihit_cap = E.ihit_cap;
+        X.ihits = E.ihits_s[slot]; X.ihit_count = E.counters + 2; X.ihit_cap = E.ihit_cap_s[slot];
         HIPCHK(launch_diag_ungapped(X, E.stream));
         HIPCHK(hipMemcpyAsync(&nih, E.counters + 2, sizeof(nih), hipMemcpyDeviceToHost, E.stream));
         HIPCHK(hipStreamSynchronize(E.stream));
-        if (nih <= E.ihit_cap) break;
-        if ((rc = grow_ihit_buffers((size_t)nih + (nih >> 3)))) return rc;
+        if (nih <= E.ihit_cap_s[slot]) break;
+        if ((rc = grow_ihit_buffers(slot, (size_t)nih + (nih >> 3)))) return rc;
     }
     if (diag) { diag->init_extends += (int64_t)nih; diag->good_init_extends += (int64_t)nih; diag->seed_stage_ms += ms_since(t_stage); }
-    t_stage = now();
     if (nih == 0) return GBN_OK;
+    if ((rc = wait_pending())) return rc;                   // one gapped stage in flight at most
+    if (!overlap || keep_stages) return gapped_stage(b, db, s0, s1, res, diag, keep_stages, slot, nih, E.stream);
+    E.slot ^= 1;
+    E.pending_err.clear();
+    const int dev = E.device;
+    GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
+    E.pending = std::async(std::launch::async, [=]() -> int {
+        if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the gapped-stage thread"; return GBN_ERR_HIP; }
+        const int r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih, E.stream2);
+        if (r) E.pending_err = gbn_last_error();      // the error text is per thread
+        return r;
+    });
+    E.has_pending = true; E.pending_res = rp;
+    return GBN_OK;
+}
 
-    // ---- gapped extension of every initial hit ----
+// gapped extension of every initial hit of a range (slot buffers), D2H, host replay of the acceptance
+// rules per subject.  Touches only the slot's buffers, the results and the gapped fields of `diag`.
+static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag,
+                        int keep_stages, int slot, unsigned long long nih, hipStream_t st)
+{
+    const DeviceBatch *d = b.dev;
+    int rc;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t_stage = now();
     int32_t max_len = 0, max_ctx = 0;
     for (int32_t s = s0; s < s1; s++) max_len = std::max(max_len, db.len[s]);
     for (auto &c : b.ctx) max_ctx = std::max(max_ctx, c.query_length);
     GbnGapParams G; std::memset(&G, 0, sizeof(G));
     G.db = db.d_packed; G.byte_off = db.d_byte_off; G.len = db.d_len;
-    G.ihits = E.ihits; G.q8 = d->q8; G.q2 = d->q2; G.qinv = d->qinv; G.ctx_off = d->ctx_off; G.ctx_len = d->ctx_len; G.nctx = (int32_t)b.ctx.size();
+    G.ihits = E.ihits_s[slot]; G.q8 = d->q8; G.q2 = d->q2; G.qinv = d->qinv; G.ctx_off = d->ctx_off; G.ctx_len = d->ctx_len; G.nctx = (int32_t)b.ctx.size();
     G.matrix = d->matrix; G.reward = b.opt.reward; G.penalty = b.opt.penalty;
     G.gap_open = b.opt.gap_open; G.gap_extend = b.opt.gap_extend; G.xdrop = b.gap_x_dropoff;
-    G.out = E.gapped;
+    G.out = E.gapped_s[slot];
     size_t per_thread;
     if (b.opt.greedy) {
         int32_t max_dist = std::min(10000, max_len / 2 + 1);
@@ -539,20 +584,20 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     G.scratch_per_thread = (int32_t)per_thread;
     const size_t budget_ints = (size_t)1 << 28;        // 1 GiB of scratch
     size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)nih, budget_ints / per_thread));
-    if (chunk * per_thread > E.gap_scratch_ints) {
-        dev_free(E.gap_scratch);
-        if ((rc = dev_alloc(E.gap_scratch, chunk * per_thread))) { E.gap_scratch_ints = 0; return rc; }
-        E.gap_scratch_ints = chunk * per_thread;
+    if (chunk * per_thread > E.gap_scratch_ints_s[slot]) {
+        dev_free(E.gap_scratch_s[slot]);
+        if ((rc = dev_alloc(E.gap_scratch_s[slot], chunk * per_thread))) { E.gap_scratch_ints_s[slot] = 0; return rc; }
+        E.gap_scratch_ints_s[slot] = chunk * per_thread;
     }
-    G.scratch = E.gap_scratch;
+    G.scratch = E.gap_scratch_s[slot];
     for (size_t first = 0; first < (size_t)nih; first += chunk) {
         G.first = (int64_t)first; G.n = (int64_t)std::min(chunk, (size_t)nih - first);
-        HIPCHK(launch_gapped(G, b.opt.greedy != 0, E.stream));
+        HIPCHK(launch_gapped(G, b.opt.greedy != 0, st));
     }
     std::vector<GbnDevInitHit> hih((size_t)nih); std::vector<GbnDevGapped> hg((size_t)nih);
-    HIPCHK(hipMemcpyAsync(hih.data(), E.ihits, (size_t)nih * sizeof(GbnDevInitHit), hipMemcpyDeviceToHost, E.stream));
-    HIPCHK(hipMemcpyAsync(hg.data(), E.gapped, (size_t)nih * sizeof(GbnDevGapped), hipMemcpyDeviceToHost, E.stream));
-    HIPCHK(hipStreamSynchronize(E.stream));
+    HIPCHK(hipMemcpyAsync(hih.data(), E.ihits_s[slot], (size_t)nih * sizeof(GbnDevInitHit), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hg.data(), E.gapped_s[slot], (size_t)nih * sizeof(GbnDevGapped), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
     if (diag) diag->gapped_stage_ms += ms_since(t_stage);
     t_stage = now();
 
@@ -621,6 +666,7 @@ int Blast_gpu_Init(int use_gpu, int gpu_id) {
     HIPCHK(hipGetDeviceProperties(&prop, dev));
     E.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&E.stream, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&E.stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&E.ev0)); HIPCHK(hipEventCreate(&E.ev1));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&E.evk[i]));
     HIPCHK(hipMalloc((void **)&E.counters, 8 * sizeof(unsigned long long)));
@@ -633,15 +679,17 @@ void gpu_ReleaseDBMemory(void) { /* shards are owned by their GbnDb handles */ }
 void Blast_gpu_Release(void) {
     std::lock_guard<std::mutex> lk(E.mu);
     if (!E.ready) return;
+    (void)wait_pending();
     dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
-    dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.sort_tmp); dev_free(E.ihits); dev_free(E.gapped);
-    dev_free(E.counters); dev_free(E.gap_scratch); dev_free(E.bin_rec); dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
+    dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.sort_tmp); for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
+    dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
     E.bin_rec_cap = 0; E.bin_count_cap = 0;
-    E.seed_cap = E.key_cap = E.ihit_cap = E.gap_scratch_ints = 0;
+    E.seed_cap = E.key_cap = 0;
     if (E.ev0) (void)hipEventDestroy(E.ev0);
     if (E.ev1) (void)hipEventDestroy(E.ev1);
     if (E.stream) (void)hipStreamDestroy(E.stream);
-    E.ev0 = E.ev1 = nullptr; E.stream = nullptr; E.ready = false;
+    if (E.stream2) (void)hipStreamDestroy(E.stream2);
+    E.ev0 = E.ev1 = nullptr; E.stream = E.stream2 = nullptr; E.ready = false;
 }
 
 int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_seqs,
@@ -737,8 +785,8 @@ const GbnSeed *gbn_results_seeds(const GbnResults *r) { return r->seeds.data(); 
 int64_t gbn_results_num_init_hits(const GbnResults *r) { return (int64_t)r->init_hits.size(); }
 const GbnInitHit *gbn_results_init_hits(const GbnResults *r) { return r->init_hits.data(); }
 
-int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
-                      int keep_stages, GbnInterruptFn interrupt, void *progress) {
+static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
+                      int keep_stages, GbnInterruptFn interrupt, void *progress, int overlap) {
     if (!batch || !db || !results) { set_error("bad argument"); return GBN_ERR_ARG; }
     int rc = ensure_init();
     if (rc) return rc;
@@ -747,6 +795,7 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     if (batch->opt.db_num_seqs == 0) {
         // "db_length == 0" branch of the engine: effective lengths and cut-offs are
         // recomputed for every subject (CORE/blast_setup.c:905-932)
+        if ((rc = wait_pending())) return rc;           // this mode rewrites the batch's cut-offs per subject
         for (int32_t s = 0; s < db->num_seqs; s++) {
             batch->set_effective_lengths(db->len[s], 1);
             batch->update_cutoffs();
@@ -769,13 +818,34 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
                 if (s1 > s0 && (acc + nb > range_bytes || tiles + nt > (1 << (32 - GBN_BIN_TILE_BITS)) - 1)) break;
                 acc += nb; tiles += nt; s1++;
             }
-            if ((rc = search_range(*batch, *db, s0, s1, *results, diag, keep_stages))) return rc;
+            if ((rc = search_range(*batch, *db, s0, s1, *results, diag, keep_stages, overlap))) return rc;
             if (interrupt && interrupt(progress)) { set_error("interrupted"); return GBN_ERR_INTERRUPTED; }
             s0 = s1;
         }
     }
     if (diag) diag->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     return GBN_OK;
+}
+
+int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
+                      int keep_stages, GbnInterruptFn interrupt, void *progress) {
+    int rc = run_search(batch, db, results, diag, keep_stages, interrupt, progress, 0);
+    std::lock_guard<std::mutex> lk(E.mu);
+    int rc2 = wait_pending();                           // of an earlier gbn_prelim_search_begin
+    return rc ? rc : rc2;
+}
+
+int gbn_prelim_search_begin(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
+                            GbnInterruptFn interrupt, void *progress) {
+    return run_search(batch, db, results, diag, 0, interrupt, progress, 1);
+}
+
+int gbn_prelim_search_end(GbnResults *results) {
+    std::lock_guard<std::mutex> lk(E.mu);
+    // a stage that belongs to other results stays in flight: these results were completed when that
+    // stage was queued (one in flight at most)
+    if (results && E.has_pending && E.pending_res != results) return GBN_OK;
+    return wait_pending();
 }
 
 int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag) {

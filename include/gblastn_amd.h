@@ -181,6 +181,16 @@ const GbnInitHit *gbn_results_init_hits(const GbnResults *r);
 int  gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results,
                        GbnDiagnostics *diag, int keep_stages,
                        GbnInterruptFn interrupt, void *progress);
+/* Pipelined form (the reference's "-mode 1" PrelimSearchThread / TraceBackThread split,
+ * GB/work_thread.cpp:60-107, moved one stage down): _begin returns once the scan, the seed ordering
+ * and the ungapped stage of the LAST subject range are done; the gapped extensions of that range and
+ * their host-side acceptance run on a second HIP stream and a host thread while the caller starts
+ * the next query batch.  `results` and `diag` must stay alive and untouched until _end(results) has
+ * returned (it returns at once if a later _begin has already waited for them).  At most one gapped
+ * stage is in flight. */
+int  gbn_prelim_search_begin(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
+                             GbnInterruptFn interrupt, void *progress);
+int  gbn_prelim_search_end(GbnResults *results);   /* NULL: whatever is in flight */
 /* scan stage only (bench / roofline): runs the scan+seed kernel over the
  * whole shard `repeats` times and reports the HIP-event time per launch */
 int  gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag);

@@ -198,3 +198,24 @@ def test_full_size_c2_pass_against_the_oracle_subject_by_subject():
         for f in ["context", "q_offset", "q_end", "q_gapped_start", "s_offset", "s_end", "s_gapped_start", "score"]:
             assert np.array_equal(g[f], o["hsps"][f]), (oid, f)
         assert np.array_equal(g["evalue"].view(np.uint64), o["hsps"]["evalue"].view(np.uint64)), oid
+
+
+def test_pipelined_begin_end_equals_run():
+    # two query batches alternating, gapped stage of pass k overlapping the scan of pass k+1
+    db, queries, plants, subjects, opt = util.small_case(8, 150_000, 40)
+    src = api.BlastSeqSrc.from_packed(subjects)
+    a = api.BlastPrelimSearch(queries[:20], opt, src)
+    b = api.BlastPrelimSearch(queries[20:], opt, src)
+    want = [a.run()["hsps"], b.run()["hsps"]]
+    assert len(want[0]) + len(want[1]) >= 4
+    got, prev = [], None
+    for k in range(6):
+        cur = (a, b)[k % 2]
+        cur.begin()
+        if prev is not None:
+            got.append(prev.end()["hsps"])
+        prev = cur
+    got.append(prev.end()["hsps"])
+    for k, g in enumerate(got):
+        assert np.array_equal(g, want[k % 2]), k
+    assert np.array_equal(a.run()["hsps"], want[0])     # the synchronous call still works afterwards
