@@ -40,9 +40,14 @@ struct GbnScanParams {
 // bits of its lookup word (8-byte records, no table access at all); phase 2
 // loads one bin's cell table (<= 32768 cells x 4 B = 128 KiB) into LDS and
 // streams that bin's records through it.
-#define GBN_BIN_THREADS  1024
-#define GBN_BIN_WG_PER_CU 1        // resident binning workgroups per CU (128 VGPRs per lane)
-#define GBN_BIN_TILE_BITS 14
+#define GBN_BIN_THREADS  1024       // probe kernel workgroup
+#ifndef GBN_SORT_THREADS
+#define GBN_SORT_THREADS 1024       // binning kernel workgroup: one per CU with 16384-position tiles.  Measured
+#endif                              // alternative: 512 (two per CU, 8192-position tiles): 15-50 % slower (128-byte runs)
+#define GBN_BIN_WG_PER_CU (1024 / GBN_SORT_THREADS)
+#ifndef GBN_BIN_TILE_BITS
+#define GBN_BIN_TILE_BITS (GBN_SORT_THREADS == 512 ? 13 : 14)     // 16 scan positions per thread
+#endif
 #define GBN_BIN_TILE_POS (1 << GBN_BIN_TILE_BITS)   // scan positions per tile (posid = tile << GBN_BIN_TILE_BITS | i)
 #define GBN_BIN_GROUPS   8          // probe workgroups with equal (blockIdx & 7) share a bin (and an XCD)
 #define GBN_BIN_MAXNB    512

@@ -30,7 +30,10 @@
 #define GBN_STREAM(B, bin, writer) ((size_t)(writer) * (B).nb + (bin))
 #endif
 #define GBN_BIN_GBIAS 32768u  // > GBN_BIN_STAGE: keeps (stream cursor - staging offset) non-negative
-#define GBN_BIN_OCC (4 * GBN_BIN_WG_PER_CU)  // waves per SIMD the binning kernel is compiled for
+#define GBN_BIN_OCC 4       // waves per SIMD the binning kernel is compiled for (128 VGPRs)
+#ifndef GBN_BIN_MERGED_WRITEOUT
+#define GBN_BIN_MERGED_WRITEOUT 1    // stores of tile t-1 share a barrier interval with the histogram of tile t (3 barriers per tile)
+#endif
 #endif
 
 namespace {
@@ -884,7 +887,7 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
     const int nb = B.nb, cbits = B.cbits;
     const uint32_t lowmask = (1u << cbits) - 1;
     const int cshift = 56 - 2 * P.lut, rshift = 49 - 2 * P.lut;     // right side: 3.5 bases = 7 bits
-    constexpr int PER = GBN_BIN_TILE_POS / GBN_BIN_THREADS;
+    constexpr int PER = GBN_BIN_TILE_POS / GBN_SORT_THREADS;
     const uint32_t ustep = (uint32_t)P.step;
     const int64_t stride = gridDim.x, last = P.ntiles - 1;
 
@@ -892,7 +895,7 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
     constexpr int NDW = STEP > 0 ? ((2 * STEP * 15 - 8 + 38) >> 5) + 2 : 2 * PER;   // dwords -1 .. last
     struct Raw { uint32_t d[NDW]; };
     // index of a lane's k-th position inside the tile
-    auto idx_of = [&](int k) -> uint32_t { return STEP > 0 ? (uint32_t)(tid * PER + k) : (uint32_t)(tid + k * GBN_BIN_THREADS); };
+    auto idx_of = [&](int k) -> uint32_t { return STEP > 0 ? (uint32_t)(tid * PER + k) : (uint32_t)(tid + k * GBN_SORT_THREADS); };
     // STEP == 0: one unaligned 8-byte load per position: bases [pos - 4, pos + lut + 4) are <= 40 bits
     // that start at most 6 bits into the byte holding base pos - 4.  Lanes past the tile's end re-read
     // its last position (and are dropped when ranks are taken).
@@ -942,10 +945,10 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
         return t;
     };
 
-    for (int b = tid; b < nb; b += GBN_BIN_THREADS) { s_wcur[b] = 0; s_hist[b] = 0; }
+    for (int b = tid; b < nb; b += GBN_SORT_THREADS) { s_wcur[b] = 0; s_hist[b] = 0; }
     int64_t tile = blockIdx.x;
     if (tile > last) {                               // more workgroups than tiles: empty streams
-        for (int b = tid; b < nb; b += GBN_BIN_THREADS) B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0;
+        for (int b = tid; b < nb; b += GBN_SORT_THREADS) B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0;
         return;
     }
     GbnTile T = uniform(P.tiles[tile]);
@@ -965,6 +968,36 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
 #else
 #define GBN_LAP(ph) do { } while (0)
 #endif
+    // write-out of a bin-sorted tile: one lane per group of 4 records, one 16-byte store to each of the
+    // two record lines; the lanes of a wave that fall into the same run write one contiguous stretch
+    auto write_out = [&](uint32_t total, uint32_t tbase) {
+        for (uint32_t g = tid; g < (total >> 2); g += GBN_SORT_THREADS) {
+            const uint32_t meta = s_gmeta[g];
+            const uint32_t b = meta >> 23;
+            const uint32_t w = (meta & 0x7fffffu) - GBN_BIN_GBIAS + 4u * g;     // index in this workgroup's stream of bin b
+            const uint2 i4 = *reinterpret_cast<const uint2 *>(&s_idx[4 * g]);
+            uint4 h4 = *reinterpret_cast<const uint4 *>(&s_hi[4 * g]);
+            const uint32_t l0 = i4.x & 0xffffu, l1 = i4.x >> 16, l2 = i4.y & 0xffffu, l3 = i4.y >> 16;
+            uint4 p4;
+            p4.x = tbase | l0; p4.y = tbase | l1; p4.z = tbase | l2; p4.w = tbase | l3;
+            if (l0 == 0xffffu) h4.x = 0x80000000u;                  // pads: flagged in the high word
+            if (l1 == 0xffffu) h4.y = 0x80000000u;
+            if (l2 == 0xffffu) h4.z = 0x80000000u;
+            if (l3 == 0xffffu) h4.w = 0x80000000u;
+            if (w + 4u <= B.subcap && !(B.dbg & 2)) {
+                const size_t at = GBN_STREAM(B, b, blockIdx.x) * B.subcap + w;
+                *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = h4;
+                *reinterpret_cast<uint4 *>(B.rec + GBN_REC_POS(at)) = p4;
+            }
+        }
+    };
+    // Per tile t, three barrier intervals:
+    //   [0] histogram atomics of t, requests for the bytes of t+1 and the descriptor of t+2, and the
+    //       STORES of tile t-1 (its sorted records still sit in the staging arrays).  Stores and
+    //       compute of different waves overlap here, and the stores keep draining during [1] and [2];
+    //   [1] offset scan;   [2] pads, stream bookkeeping, scatter of t into the staging arrays;
+    //   then keys of t+1 out of the prefetched bytes (first touch: everything in flight is older).
+    uint32_t prev_total = 0, prev_tbase = 0;
     for (; tile <= last; tile += stride) {
         uint32_t rank[PER];
         #pragma unroll
@@ -974,14 +1007,14 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
                 rank[k] = atomicAdd(&s_hist[bin[k]], 1u);       // arrival order inside the bin: any order will do
         }
         GBN_LAP(5);
-#if GBN_BIN_TIMING
-        __builtin_amdgcn_s_waitcnt(0xc07f);                     // lgkmcnt(0): ranks returned
-        GBN_LAP(6);
-#endif
         Raw R; fetch(T1, R);                                    // tile t+1 (== the last tile again at the end)
         GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
         GBN_LAP(7);
-        __syncthreads();                                        // (A) histogram complete
+#if GBN_BIN_MERGED_WRITEOUT
+        write_out(prev_total, prev_tbase);
+        GBN_LAP(4);
+#endif
+        __syncthreads();                                        // (A) histogram complete, staging arrays free
         GBN_LAP(0);
         // exclusive scan of the padded bin sizes (x4 records = 32-byte sectors): wave 0, each lane sums
         // nb/64 consecutive bins, one wave scan over the 64 partial sums
@@ -1009,11 +1042,13 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
         __syncthreads();                                        // (B) offsets known
         GBN_LAP(1);
         const uint32_t total = s_off[nb];
-        for (int b = tid; b < nb; b += GBN_BIN_THREADS) {
-            const uint32_t n = s_hist[b], o0 = s_off[b], o1 = s_off[b + 1];
+        for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
+            const uint32_t n = s_hist[b], o0 = s_off[b], o1 = s_off[b + 1], wc = s_wcur[b];
             for (uint32_t j = o0 + n; j < o1; j++) s_idx[j] = 0xffffu;
-            for (uint32_t g = o0 >> 2; g < (o1 >> 2); g++) s_gmeta[g] = ((uint32_t)b << 23) | (s_wcur[b] + GBN_BIN_GBIAS - o0);
-            if (o1 > o0 && s_wcur[b] + (o1 - o0) > B.subcap) atomicExch(B.overflow, 1u);
+            for (uint32_t g = o0 >> 2; g < (o1 >> 2); g++) s_gmeta[g] = ((uint32_t)b << 23) | (wc + GBN_BIN_GBIAS - o0);
+            if (o1 > o0 && wc + (o1 - o0) > B.subcap) atomicExch(B.overflow, 1u);
+            s_wcur[b] = wc + (o1 - o0);
+            s_hist[b] = 0;                                      // for the next tile; ordered by (C) and (A)
         }
         #pragma unroll
         for (int k = 0; k < PER; k++) {
@@ -1025,50 +1060,30 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
         }
         __syncthreads();                                        // (C) tile is bin-sorted in LDS
         GBN_LAP(2);
-        for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_hist[b] = 0;     // for the next tile; ordered by (D)
-        // first touch of the prefetched data: everything older than these loads (the previous
-        // tile's stores) has long completed, nothing younger is outstanding yet
-        const uint32_t tbase = (uint32_t)tile << GBN_BIN_TILE_BITS;
+        prev_total = total; prev_tbase = (uint32_t)tile << GBN_BIN_TILE_BITS;
         T = T1; T1 = uniform(T2);
         #pragma unroll
         for (int k = 0; k < PER; k++) keys(T, k, R, bin[k], hi[k]);
         GBN_LAP(3);
-        // write-out: one lane per group of 4 records, one 16-byte store to each of the two record
-        // arrays; the lanes of a wave that fall into the same run write one contiguous stretch
-        for (uint32_t g = tid; g < (total >> 2); g += GBN_BIN_THREADS) {
-            const uint32_t meta = s_gmeta[g];
-            const uint32_t b = meta >> 23;
-            const uint32_t w = (meta & 0x7fffffu) - GBN_BIN_GBIAS + 4u * g;     // index in this workgroup's stream of bin b
-            const uint2 i4 = *reinterpret_cast<const uint2 *>(&s_idx[4 * g]);
-            uint4 h4 = *reinterpret_cast<const uint4 *>(&s_hi[4 * g]);
-            const uint32_t l0 = i4.x & 0xffffu, l1 = i4.x >> 16, l2 = i4.y & 0xffffu, l3 = i4.y >> 16;
-            uint4 p4;
-            p4.x = tbase | l0; p4.y = tbase | l1; p4.z = tbase | l2; p4.w = tbase | l3;
-            if (l0 == 0xffffu) h4.x = 0x80000000u;                  // pads: flagged in the high word
-            if (l1 == 0xffffu) h4.y = 0x80000000u;
-            if (l2 == 0xffffu) h4.z = 0x80000000u;
-            if (l3 == 0xffffu) h4.w = 0x80000000u;
-            if (w + 4u <= B.subcap && !(B.dbg & 2)) {
-                const size_t at = GBN_STREAM(B, b, blockIdx.x) * B.subcap + w;
-                *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = h4;
-                *reinterpret_cast<uint4 *>(B.rec + GBN_REC_POS(at)) = p4;
-            }
-        }
-        __syncthreads();                                        // (D) staging buffers free again
+#if !GBN_BIN_MERGED_WRITEOUT
+        write_out(prev_total, prev_tbase);
+        prev_total = 0;
         GBN_LAP(4);
-        for (int b = tid; b < nb; b += GBN_BIN_THREADS) s_wcur[b] += s_off[b + 1] - s_off[b];
+        __syncthreads();                                        // (D) staging arrays free again
+#endif
     }
+    write_out(prev_total, prev_tbase);                          // the last tile (merged variant)
 #if GBN_BIN_TIMING
     if (timed) for (int i = 0; i < 8; i++) B.rare_counts[512 + i] = (uint32_t)(tph[i] >> 4);
 #endif
     __syncthreads();
-    for (int b = tid; b < nb; b += GBN_BIN_THREADS)
+    for (int b = tid; b < nb; b += GBN_SORT_THREADS)
         B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(s_wcur[b], B.subcap);
 }
 
-extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, GBN_BIN_OCC) scan_bin_kernel(GbnBinParams B) { scan_bin_body<0>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, GBN_BIN_OCC) scan_bin_kernel_s17(GbnBinParams B) { scan_bin_body<17>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { scan_bin_body<18>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel(GbnBinParams B) { scan_bin_body<0>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s17(GbnBinParams B) { scan_bin_body<17>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { scan_bin_body<18>(B); }
 
 namespace {
 // rare path of the probe kernel: full fingerprints, chain walk, exact verification
@@ -1276,9 +1291,9 @@ hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hip
     if (ev) (void)hipEventRecord(ev[0], st);
     // stride-specialised variants for the two megablast strides (word 28 with lut 12 / lut 11)
     const bool generic = (b.dbg & 64) != 0;
-    if (b.S.step == 17 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_BIN_THREADS), 0, st, b);
-    else if (b.S.step == 18 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s18, dim3(b.nwriters), dim3(GBN_BIN_THREADS), 0, st, b);
-    else hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_BIN_THREADS), 0, st, b);
+    if (b.S.step == 17 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+    else if (b.S.step == 18 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s18, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+    else hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
     if (ev) (void)hipEventRecord(ev[1], st);
