@@ -69,7 +69,12 @@ EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_de
            "gbn_launch_scan_seed", "gbn_launch_ungapped", "gbn_launch_gapped",
            "gbn_prelim_search_begin", "gbn_prelim_search_end", "gbn_prelim_hitlist_size", "gbn_collector_new", "gbn_collector_free", "gbn_collector_write",
            "gbn_collector_close", "gbn_collector_num_lists", "gbn_collector_list_starts",
-           "gbn_collector_list_queries", "gbn_collector_num_hsps", "gbn_collector_hsps"]
+           "gbn_collector_list_queries", "gbn_collector_num_hsps", "gbn_collector_hsps",
+           "gbn_blastdb_open", "gbn_blastdb_close", "gbn_blastdb_num_volumes", "gbn_blastdb_num_seqs",
+           "gbn_blastdb_total_length", "gbn_blastdb_max_length", "gbn_blastdb_stat_num_seqs",
+           "gbn_blastdb_stat_length", "gbn_blastdb_title", "gbn_blastdb_volume_range", "gbn_blastdb_seq_length",
+           "gbn_blastdb_get_ncbi2na", "gbn_blastdb_num_ambiguities", "gbn_blastdb_get_ambiguities",
+           "gbn_blastdb_get_blastna", "gbn_blastdb_load_shard"]
 
 _LIB = None
 
@@ -122,6 +127,20 @@ def lib():
             getattr(L, nm).restype = C.c_int64; getattr(L, nm).argtypes = [C.c_void_p]
         for nm in ["gbn_collector_list_starts", "gbn_collector_list_queries", "gbn_collector_hsps"]:
             getattr(L, nm).restype = C.c_void_p; getattr(L, nm).argtypes = [C.c_void_p]
+        L.gbn_blastdb_open.argtypes = [C.POINTER(C.c_void_p), C.c_char_p]
+        L.gbn_blastdb_close.argtypes = [C.c_void_p]
+        for nm in ["gbn_blastdb_num_volumes", "gbn_blastdb_num_seqs", "gbn_blastdb_max_length", "gbn_blastdb_stat_num_seqs"]:
+            getattr(L, nm).restype = C.c_int32; getattr(L, nm).argtypes = [C.c_void_p]
+        for nm in ["gbn_blastdb_total_length", "gbn_blastdb_stat_length"]:
+            getattr(L, nm).restype = C.c_int64; getattr(L, nm).argtypes = [C.c_void_p]
+        L.gbn_blastdb_title.restype = C.c_char_p; L.gbn_blastdb_title.argtypes = [C.c_void_p]
+        L.gbn_blastdb_volume_range.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.gbn_blastdb_seq_length.restype = C.c_int32; L.gbn_blastdb_seq_length.argtypes = [C.c_void_p, C.c_int32]
+        L.gbn_blastdb_get_ncbi2na.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
+        L.gbn_blastdb_num_ambiguities.restype = C.c_int32; L.gbn_blastdb_num_ambiguities.argtypes = [C.c_void_p, C.c_int32]
+        L.gbn_blastdb_get_ambiguities.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        L.gbn_blastdb_get_blastna.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_int]
+        L.gbn_blastdb_load_shard.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         _LIB = L
     return _LIB
 
@@ -321,5 +340,71 @@ class BlastHSPCollector:
     def __del__(self):
         try:
             self.free()
+        except Exception:
+            pass
+
+
+class BlastDb:
+    """BLAST database files (v4, nucleotide): alias / index / sequence files (CSeqDB analogue)."""
+
+    def __init__(self, name):
+        self._d = C.c_void_p()
+        _check(lib().gbn_blastdb_open(C.byref(self._d), os.fsencode(name)))
+
+    num_volumes = property(lambda self: lib().gbn_blastdb_num_volumes(self._d))
+    num_seqs = property(lambda self: lib().gbn_blastdb_num_seqs(self._d))
+    total_length = property(lambda self: lib().gbn_blastdb_total_length(self._d))
+    max_length = property(lambda self: lib().gbn_blastdb_max_length(self._d))
+    stat_num_seqs = property(lambda self: lib().gbn_blastdb_stat_num_seqs(self._d))
+    stat_length = property(lambda self: lib().gbn_blastdb_stat_length(self._d))
+    title = property(lambda self: lib().gbn_blastdb_title(self._d).decode())
+
+    def volume_range(self, vol):
+        a, n = C.c_int32(), C.c_int32()
+        _check(lib().gbn_blastdb_volume_range(self._d, vol, C.byref(a), C.byref(n)))
+        return a.value, n.value
+
+    def seq_length(self, oid):
+        return lib().gbn_blastdb_seq_length(self._d, oid)
+
+    def ncbi2na(self, oid):
+        n = self.seq_length(oid)
+        if n < 0:
+            raise BlastError("oid out of range")
+        buf = np.zeros((n + 3) // 4, dtype=np.uint8)
+        _check(lib().gbn_blastdb_get_ncbi2na(self._d, oid, buf.ctypes.data, len(buf)))
+        return buf, n
+
+    def blastna(self, oid, sentinels=False):
+        n = self.seq_length(oid)
+        if n < 0:
+            raise BlastError("oid out of range")
+        buf = np.zeros(n + (2 if sentinels else 0), dtype=np.uint8)
+        _check(lib().gbn_blastdb_get_blastna(self._d, oid, buf.ctypes.data, len(buf), 1 if sentinels else 0))
+        return buf
+
+    def ambiguities(self, oid):
+        k = lib().gbn_blastdb_num_ambiguities(self._d, oid)
+        if k < 0:
+            raise BlastError("oid out of range")
+        st, ln, v = np.zeros(k, dtype=np.int32), np.zeros(k, dtype=np.int32), np.zeros(k, dtype=np.uint8)
+        if k:
+            _check(lib().gbn_blastdb_get_ambiguities(self._d, oid, st.ctypes.data, ln.ctypes.data, v.ctypes.data, k))
+        return st, ln, v
+
+    def load_shard(self, first_oid=0, num_oids=None):
+        """Subjects [first_oid, first_oid + num_oids) resident in HBM (needs a GPU) -> BlastSeqSrc."""
+        h = C.c_void_p()
+        n = self.num_seqs - first_oid if num_oids is None else num_oids
+        _check(lib().gbn_blastdb_load_shard(self._d, first_oid, n, C.byref(h)))
+        return BlastSeqSrc(h)
+
+    def close(self):
+        if self._d:
+            lib().gbn_blastdb_close(self._d); self._d = None
+
+    def __del__(self):
+        try:
+            self.close()
         except Exception:
             pass

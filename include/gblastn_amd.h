@@ -148,6 +148,35 @@ int32_t gbn_db_num_seqs(const GbnDb *db);
 /* deterministic synthetic DB bytes generated on the device (bench/tests) */
 int  gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream);
 
+/* ---- BLAST database files (format version 4, nucleotide): alias (.nal), index (.nin), sequence
+ * (.nsq) incl. ambiguity runs.  Replaces what the reference reaches through its SeqDB BlastSeqSrc
+ * (API/seqsrc_seqdb.cpp:283-382: s_SeqDbGetSequence, GetNumSeqs, GetTotLen, GetMaxLength, GetSeqLen);
+ * formats: objtools/blast/seqdb_reader/index_files.txt:62-120, sequence_files.txt:60-170,
+ * alias_files.txt.  `name` is the path without extension; NAME.nal takes precedence over NAME.nin.
+ * Alias filters (GILIST, OIDLIST, ...) are refused with GBN_ERR_UNSUPPORTED.  Host only. ---- */
+typedef struct GbnBlastDb GbnBlastDb;
+int  gbn_blastdb_open(GbnBlastDb **out, const char *name);
+void gbn_blastdb_close(GbnBlastDb *db);
+int32_t gbn_blastdb_num_volumes(const GbnBlastDb *db);
+int32_t gbn_blastdb_num_seqs(const GbnBlastDb *db);
+int64_t gbn_blastdb_total_length(const GbnBlastDb *db);
+int32_t gbn_blastdb_max_length(const GbnBlastDb *db);
+/* database size for the statistics: NSEQ / LENGTH of the alias file when given, else the sums */
+int32_t gbn_blastdb_stat_num_seqs(const GbnBlastDb *db);
+int64_t gbn_blastdb_stat_length(const GbnBlastDb *db);
+const char *gbn_blastdb_title(const GbnBlastDb *db);
+int  gbn_blastdb_volume_range(const GbnBlastDb *db, int32_t vol, int32_t *first_oid, int32_t *num_oids);
+int32_t gbn_blastdb_seq_length(const GbnBlastDb *db, int32_t oid);      /* < 0: bad oid */
+int  gbn_blastdb_get_ncbi2na(const GbnBlastDb *db, int32_t oid, uint8_t *dst, int64_t dst_bytes);
+int32_t gbn_blastdb_num_ambiguities(const GbnBlastDb *db, int32_t oid);
+int  gbn_blastdb_get_ambiguities(const GbnBlastDb *db, int32_t oid, int32_t *start, int32_t *length,
+                                 uint8_t *ncbi4na_value, int32_t cap);
+/* one BLASTNA code per base, ambiguities applied; sentinels != 0: code 15 in front and behind */
+int  gbn_blastdb_get_blastna(const GbnBlastDb *db, int32_t oid, uint8_t *dst, int64_t dst_bytes, int sentinels);
+/* subjects [first_oid, first_oid + num_oids) -> resident HBM shard with global OIDs */
+struct GbnDb;
+int  gbn_blastdb_load_shard(const GbnBlastDb *db, int32_t first_oid, int32_t num_oids, struct GbnDb **out);
+
 /* ---- query batch: host set-up + upload of lookup structures ---- */
 typedef struct GbnBatch GbnBatch;
 /* seqs[i]: BLASTNA codes (0..15), plus strand, lens[i] bases */
