@@ -15,7 +15,9 @@
 #include <cstdio>
 #include <cstring>
 #include <map>
+#include <atomic>
 #include <future>
+#include <thread>
 #include <mutex>
 #include <tuple>
 #include <cstdlib>
@@ -353,7 +355,7 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
     for (;;) {
         HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream));
         GbnScanParams P; fill_scan_params(P, b, db, ts);
-        uint32_t overflow = 0;
+        uint32_t overflow = 0; int dbg_nwriters = 0; uint32_t dbg_subcap = 0;
         bool binned = false;
         if (nb == 1) {
             HIPCHK(hipEventRecord(E.ev0, E.stream));
@@ -381,7 +383,7 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
             }
             HIPCHK(hipMemsetAsync(E.bin_count + nstream, 0, 16, E.stream));
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
-            B.S = P; B.nb = nb; B.cbits = 15; B.nwriters = nwriters;
+            B.S = P; B.nb = nb; B.cbits = 15; B.nwriters = nwriters; dbg_nwriters = nwriters; dbg_subcap = (uint32_t)subcap;
             B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfrbits = std::min(7, 2 * b.dev->fr);
             B.rec = reinterpret_cast<uint32_t *>(E.bin_rec); B.gcount = E.bin_count; B.subcap = (uint32_t)subcap;
             B.overflow = E.bin_count + nstream;
@@ -425,6 +427,14 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
             for (uint32_t v : rc_host) { sc += v; mx = std::max(mx, v); }
             if (getenv("GBN_DBG")) fprintf(stderr, "[gbn dbg] rare-path items %llu, seeds %llu, raw %llu\n", sc, cnt[0], cnt[1]);
             if (getenv("GBN_DBG") && (atoi(getenv("GBN_DBG")) & 32)) {
+                {   // stream fill statistics
+                    const size_t ns = (size_t)nb * (size_t)dbg_nwriters;
+                    std::vector<uint32_t> gc(ns);
+                    HIPCHK(hipMemcpy(gc.data(), E.bin_count, ns * 4, hipMemcpyDeviceToHost));
+                    uint32_t mn = ~0u, mx2 = 0; unsigned long long sum = 0;
+                    for (uint32_t v : gc) { mn = std::min(mn, v); mx2 = std::max(mx2, v); sum += v; }
+                    fprintf(stderr, "[gbn dbg] %zu streams: records min %u max %u total %llu (capacity %u each)\n", ns, mn, mx2, sum, dbg_subcap);
+                }
                 uint32_t ph[8]; HIPCHK(hipMemcpy(ph, E.rare_counts + 512, sizeof(ph), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[gbn dbg] scan_bin workgroup 0 (GBN_BIN_TIMING build), cycles/16: bookkeeping+atomics issued %u, ranks returned %u, "
                         "loads issued %u, barrier A %u | scan %u | pads+scatter %u | next keys %u | write-out %u\n",
@@ -608,14 +618,22 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         if (hih[a].subj != hih[c].subj) return hih[a].subj < hih[c].subj;
         return hih[a].seq < hih[c].seq;
     });
-    size_t i = 0;
-    while (i < order.size()) {
-        size_t j = i; int32_t subj = hih[order[i]].subj;
-        std::vector<std::pair<GbnDevInitHit, GbnDevGapped>> hits;
-        while (j < order.size() && hih[order[j]].subj == subj) {
-            if (hg[order[j]].score == INT32_MIN) { set_error("gapped DP scratch overflow"); return GBN_ERR_NOMEM; }
-            hits.emplace_back(hih[order[j]], hg[order[j]]); j++;
-        }
+    // subjects are independent: split the ordered hits into per-subject spans, replay the spans on a
+    // few host threads when there is enough work, append the HSP lists in ascending oid order
+    std::vector<std::pair<size_t, size_t>> spans;
+    for (size_t i = 0; i < order.size();) {
+        size_t j = i; const int32_t subj = hih[order[i]].subj;
+        while (j < order.size() && hih[order[j]].subj == subj) j++;
+        spans.emplace_back(i, j); i = j;
+    }
+    for (size_t k = 0; k < (size_t)nih; k++)
+        if (hg[k].score == INT32_MIN) { set_error("gapped DP scratch overflow"); return GBN_ERR_NOMEM; }
+    std::vector<std::vector<GbnHSP>> outs(spans.size());
+    std::vector<std::vector<GbnInitHit>> ihs(keep_stages ? spans.size() : 0);
+    auto replay = [&](size_t k, GbnDiagnostics *dg) {
+        const size_t i0 = spans[k].first, i1 = spans[k].second; const int32_t subj = hih[order[i0]].subj;
+        std::vector<std::pair<GbnDevInitHit, GbnDevGapped>> hits; hits.reserve(i1 - i0);
+        for (size_t j = i0; j < i1; j++) hits.emplace_back(hih[order[j]], hg[order[j]]);
         if (keep_stages) {
             auto sorted = hits;
             // reference order of the initial hit list
@@ -631,11 +649,30 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
                 GbnInitHit o; o.oid = db.first_oid + subj; o.q_off = pr.first.q_off; o.s_off = pr.first.s_off;
                 o.q_start = pr.first.q_start; o.s_start = pr.first.s_start; o.length = pr.first.length;
                 o.score = pr.first.score; o.pad_ = 0;
-                res.init_hits.push_back(o);
+                ihs[k].push_back(o);
             }
         }
-        finish_subject(b, db.first_oid + subj, db.len[subj], hits, res.hsps, diag);
-        i = j;
+        finish_subject(b, db.first_oid + subj, db.len[subj], hits, outs[k], dg);
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nthreads = (nih < 20000 || spans.size() < 2) ? 1u : std::min({hw, 16u, (unsigned)spans.size()});
+    std::vector<GbnDiagnostics> dloc(nthreads);
+    for (auto &dl : dloc) std::memset(&dl, 0, sizeof(dl));
+    if (nthreads == 1) {
+        for (size_t k = 0; k < spans.size(); k++) replay(k, &dloc[0]);
+    } else {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < nthreads; t++)
+            pool.emplace_back([&, t] { for (size_t k; (k = next.fetch_add(1)) < spans.size();) replay(k, &dloc[t]); });
+        for (auto &th : pool) th.join();
+    }
+    for (size_t k = 0; k < spans.size(); k++) {
+        res.hsps.insert(res.hsps.end(), outs[k].begin(), outs[k].end());
+        if (keep_stages) res.init_hits.insert(res.init_hits.end(), ihs[k].begin(), ihs[k].end());
+    }
+    if (diag) for (auto &dl : dloc) {
+        diag->gapped_extensions += dl.gapped_extensions; diag->good_extensions += dl.good_extensions; diag->seqs_passed += dl.seqs_passed;
     }
     if (diag) diag->host_stage_ms += ms_since(t_stage);
     return GBN_OK;

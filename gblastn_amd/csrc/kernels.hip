@@ -1007,7 +1007,8 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
                 rank[k] = atomicAdd(&s_hist[bin[k]], 1u);       // arrival order inside the bin: any order will do
         }
         GBN_LAP(5);
-        Raw R; fetch(T1, R);                                    // tile t+1 (== the last tile again at the end)
+        Raw R;
+        if constexpr (STEP > 0) fetch(T1, R);                   // tile t+1 (== the last tile again at the end)
         GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
         GBN_LAP(7);
 #if GBN_BIN_MERGED_WRITEOUT
@@ -1062,6 +1063,7 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
         GBN_LAP(2);
         prev_total = total; prev_tbase = (uint32_t)tile << GBN_BIN_TILE_BITS;
         T = T1; T1 = uniform(T2);
+        if constexpr (STEP == 0) fetch(T, R);                   // any-stride variant: no prefetch (32 more live registers would spill)
         #pragma unroll
         for (int k = 0; k < PER; k++) keys(T, k, R, bin[k], hi[k]);
         GBN_LAP(3);
@@ -1084,6 +1086,8 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
 extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel(GbnBinParams B) { scan_bin_body<0>(B); }
 extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s17(GbnBinParams B) { scan_bin_body<17>(B); }
 extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { scan_bin_body<18>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s1(GbnBinParams B) { scan_bin_body<1>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s2(GbnBinParams B) { scan_bin_body<2>(B); }
 
 namespace {
 // rare path of the probe kernel: full fingerprints, chain walk, exact verification
@@ -1103,9 +1107,17 @@ __device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell
         if (!fp_pass((uint32_t)(ent >> 32), sl, sr, P.fl, P.fr)) continue;
         const int32_t q = (int32_t)(ent & 0xffffffffu);
         const int el = verify_hit(P, subj, slen, q, s);
-        if (el >= 0) {
-            unsigned long long o = atomicAdd(P.seed_count, 1ull);
-            if (o < P.seed_cap) { GbnDevSeed sd; sd.subj = T.subj; sd.s_scan = s; sd.q_pos = q; sd.ext_left = el; P.seeds[o] = sd; }
+        // one reservation per wave and round: the lanes still in this loop that verified a hit
+        const unsigned long long okm = __ballot(el >= 0);
+        if (okm) {
+            const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)okm) - 1;
+            unsigned long long base = 0;
+            if (lane == leader) base = atomicAdd(P.seed_count, (unsigned long long)__popcll(okm));
+            base = __shfl(base, leader);
+            if (el >= 0) {
+                const unsigned long long o = base + (unsigned long long)__popcll(okm & ((1ull << lane) - 1));
+                if (o < P.seed_cap) { GbnDevSeed sd; sd.subj = T.subj; sd.s_scan = s; sd.q_pos = q; sd.ext_left = el; P.seeds[o] = sd; }
+            }
         }
     }
 }
@@ -1289,9 +1301,11 @@ hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hip
     // ev[0..3]: before bin, after bin, after probe, after rare (optional)
     if (b.S.ntiles <= 0) return hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], st);
-    // stride-specialised variants for the two megablast strides (word 28 with lut 12 / lut 11)
+    // stride-specialised variants: megablast (word 28 with lut 12 / lut 11) and blastn (word 11 with lut 11 / 10)
     const bool generic = (b.dbg & 64) != 0;
-    if (b.S.step == 17 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+    if (b.S.step == 1 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s1, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+    else if (b.S.step == 2 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s2, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+    else if (b.S.step == 17 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
     else if (b.S.step == 18 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s18, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
     else hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
     hipError_t e = hipGetLastError();

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
 """Time the scan stage only (gbn_scan_only) for a synthetic shard; GBN_DBG / GBN_SCAN_BINS
-environment switches select ablations.  usage: scan_ablate.py [subjects] [queries]"""
+environment switches select ablations, TASK=blastn the blastn options.  usage: scan_ablate.py [subjects] [queries]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -14,7 +14,9 @@ slab = torch.empty(lay.nbytes, dtype=torch.uint8, device="cuda")
 api._check(api.lib().gbn_synth_fill(slab.data_ptr(), lay.nbytes, lay.seed, None))
 src = api.BlastSeqSrc.from_slab((slab.data_ptr(), lay.nbytes), lay.byte_off, lay.lens, is_device=True, keep=slab)
 qs, _ = synth.make_queries(nq, None)
-ps = api.BlastPrelimSearch(qs, api.default_options("megablast", db_length=nsub * 10**6, db_num_seqs=nsub), src)
+task = os.environ.get("TASK", "megablast")
+ps = api.BlastPrelimSearch(qs, api.default_options(task, db_length=nsub * 10**6, db_num_seqs=nsub), src)
+print(ps.info())
 ps.scan_only(repeats=1)
 d = ps.scan_only(repeats=3)
 n = d.scan_launches
