@@ -1296,35 +1296,45 @@ probe_rare_kernel(GbnBinParams B, int nseg)
 }
 
 namespace gbn {
-hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev)
+// parts: 1 = binning kernel, 2 = probe + rare kernels, 3 = all
+hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts)
 {
     // ev[0..3]: before bin, after bin, after probe, after rare (optional)
     if (b.S.ntiles <= 0) return hipSuccess;
+    hipError_t e = hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], st);
-    // stride-specialised variants: megablast (word 28 with lut 12 / lut 11) and blastn (word 11 with lut 11 / 10)
-    const bool generic = (b.dbg & 64) != 0;
-    if (b.S.step == 1 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s1, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-    else if (b.S.step == 2 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s2, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-    else if (b.S.step == 17 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-    else if (b.S.step == 18 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s18, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-    else hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (ev) (void)hipEventRecord(ev[1], st);
-    const size_t lds = (size_t)GBN_BIN_CELLS * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8 + (size_t)GBN_BIN_SIDE * 2 + 16;
-    static bool attr_set = false;
-    if (!attr_set) {
-        e = hipFuncSetAttribute((const void *)probe_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (parts & 1) {
+        // stride-specialised variants: megablast (word 28 with lut 12 / lut 11) and blastn (word 11 with lut 11 / 10)
+        const bool generic = (b.dbg & 64) != 0;
+        if (b.S.step == 1 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s1, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else if (b.S.step == 2 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s2, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else if (b.S.step == 17 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else if (b.S.step == 18 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s18, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        e = hipGetLastError();
         if (e != hipSuccess) return e;
-        attr_set = true;
     }
-    hipLaunchKernelGGL(probe_bin_kernel, dim3(grid2), dim3(GBN_BIN_THREADS), lds, st, b);
-    e = hipGetLastError();
-    if (e != hipSuccess) return e;
-    if (ev) (void)hipEventRecord(ev[2], st);
-    if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * 8), dim3(256), 0, st, b, grid2);
-    e = hipGetLastError();
+    if (ev) (void)hipEventRecord(ev[1], st);
+    if (parts & 2) {
+        const size_t lds = (size_t)GBN_BIN_CELLS * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8 + (size_t)GBN_BIN_SIDE * 2 + 16;
+        static bool attr_set = false;
+        if (!attr_set) {
+            e = hipFuncSetAttribute((const void *)probe_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (e != hipSuccess) return e;
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(probe_bin_kernel, dim3(grid2), dim3(GBN_BIN_THREADS), lds, st, b);
+        e = hipGetLastError();
+        if (e != hipSuccess) return e;
+        if (ev) (void)hipEventRecord(ev[2], st);
+        if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * 8), dim3(256), 0, st, b, grid2);
+        e = hipGetLastError();
+    } else if (ev) (void)hipEventRecord(ev[2], st);
     if (ev) (void)hipEventRecord(ev[3], st);
     return e;
+}
+hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev)
+{
+    return launch_scan_bin_parts(b, grid2, st, ev, 3);
 }
 }  // namespace gbn
