@@ -219,3 +219,40 @@ def test_pipelined_begin_end_equals_run():
     for k, g in enumerate(got):
         assert np.array_equal(g, want[k % 2]), k
     assert np.array_equal(a.run()["hsps"], want[0])     # the synchronous call still works afterwards
+
+
+# option surface of the path: word sizes (every lookup choice of BlastChooseNaLookupTable that a
+# batch of this size reaches), scoring systems of the Karlin-Altschul tables, X-drops, e-value and
+# diagonal-separation settings, raw-score cut-off, stock-NCBI word_size 11 rule
+OPTION_SWEEP = [
+    ("megablast", dict(word_size=16)),
+    ("megablast", dict(word_size=20)),
+    ("megablast", dict(word_size=24)),
+    ("megablast", dict(word_size=32)),
+    ("megablast", dict(word_size=64)),
+    ("megablast", dict(word_size=12)),
+    ("megablast", dict(reward=1, penalty=-3)),
+    ("megablast", dict(reward=1, penalty=-1, gap_open=3, gap_extend=2)),
+    ("megablast", dict(reward=2, penalty=-3, gap_open=5, gap_extend=2)),
+    ("megablast", dict(xdrop_gap_bits=40.0, xdrop_ungap_bits=10.0)),
+    ("megablast", dict(evalue=1e-20, min_diag_separation=0)),
+    ("megablast", dict(cutoff_score=200)),
+    ("blastn", dict(word_size=7)),
+    ("blastn", dict(word_size=9)),
+    ("blastn", dict(word_size=10)),
+    ("blastn", dict(word_size=11, lut11_gblastn_rule=0)),
+    ("blastn", dict(word_size=15)),
+    ("blastn", dict(reward=1, penalty=-2, gap_open=2, gap_extend=2)),
+    ("blastn", dict(reward=4, penalty=-5, gap_open=12, gap_extend=8)),
+    ("blastn", dict(reward=1, penalty=-4, gap_open=5, gap_extend=2)),
+    ("blastn", dict(evalue=1e-3, min_diag_separation=10, xdrop_gap_bits=20.0)),
+    ("blastn", dict(greedy=1, gap_open=0, gap_extend=0)),       # greedy preliminary stage with blastn scoring
+]
+
+
+@pytest.mark.parametrize("task,kw", OPTION_SWEEP, ids=lambda v: v if isinstance(v, str) else "-".join("%s=%s" % i for i in v.items()))
+def test_option_sweep(task, kw):
+    nq = 24 if task == "megablast" else 6
+    nh, plants = run_case(5, 60_000, nq, task=task, planted_fraction=0.6, **kw)
+    if kw.get("cutoff_score", 0) == 0 and kw.get("evalue", 10) >= 1e-10:
+        assert nh >= 1
