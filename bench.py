@@ -113,6 +113,8 @@ def main():
         stage + host acceptance + gather/merge of pass k overlap the scan of pass k + 1.  Every pass
         is complete (merged on rank 0) when this returns."""
         n = 0
+        if count <= 0:
+            return 0
         if nbatch < 2 or args.no_overlap:
             for k in range(first, first + count):
                 b = batches[k % nbatch]
@@ -158,6 +160,8 @@ def main():
     rare_ms = sum(b.diagnostics.rare_kernel_ms for b in batches)
     # dominant kernel: the binning kernel when the partitioned scan is used, else the direct scan
     dom_name, dom_ms = ("scan_bin_kernel", bin_ms) if bin_ms > 0 else ("scan_seed_kernel", scan_ms)
+    # the binning kernel has stride-specialised variants; this is the name rocprof shows
+    dom_label = dom_name + ("_s%d" % info["scan_step"] if bin_ms > 0 and info["scan_step"] in (1, 2, 17, 18) else "")
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     stage_achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
@@ -197,12 +201,12 @@ def main():
                 "seeds_per_pass": seeds / max(launches, 1),
                 "lookup_hits_per_pass": lookup_hits / max(launches, 1),
             },
-            "roofline": {"bound": "hbm", "kernel": dom_name,
+            "roofline": {"bound": "hbm", "kernel": dom_label,
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
                          "avg_launch_ms": dom_ms / max(launches, 1), "launches": launches,
-                         "scan_stage": {"kernels": "scan_bin_kernel + probe_bin_kernel + probe_rare_kernel"
+                         "scan_stage": {"kernels": dom_label + " + probe_bin_kernel + probe_rare_kernel"
                                         if bin_ms > 0 else "scan_seed_kernel",
                                         "avg_ms": scan_ms / max(launches, 1),
                                         "avg_ms_by_kernel": [bin_ms / max(launches, 1), probe_ms / max(launches, 1),
