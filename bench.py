@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="run every pass to completion before the next starts")
+    ap.add_argument("--reuse-binning", action="store_true",
+                    help="NOT the headline metric: keep the query-independent scan records of the shard in HBM and "
+                         "skip the binning kernel for later batches with the same table shape (a database index)")
     a = ap.parse_args()
     if a.subjects is None:
         a.subjects = 50_000 if a.workload == "C2" else 5_000
@@ -53,6 +56,7 @@ def parse():
 
 def main():
     args = parse()
+    os.environ["GBN_REUSE_BINNING"] = "1" if args.reuse_binning else "0"
     import torch
     import torch.distributed as dist
     from gblastn_amd import api, synth, shard
@@ -195,6 +199,7 @@ def main():
                                "lut_type": info["lut_type"], "diag_container": info["container"]},
                 "subjects_per_gpu": nsub, "subject_len": slen,
                 "parallelism": "db-shard x%d (volumes by rank, RCCL gather of HSP records)" % world,
+                "binning_reused_across_batches": bool(args.reuse_binning),
                 "pipeline": "off" if (nbatch < 2 or args.no_overlap) else
                             "gapped stage + merge of pass k overlap the scan of pass k+1 (second HIP stream + host thread)",
                 "hsps_per_pass": nhsp / max(args.steps, 1),

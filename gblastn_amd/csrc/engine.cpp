@@ -25,6 +25,7 @@
 namespace gbn {
 hipError_t launch_scan_seed(const GbnScanParams &p, int grid, hipStream_t st);
 hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev);
+hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts);
 hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st);
@@ -286,6 +287,10 @@ static int grow_key_buffers(size_t n) {
     E.sort_tmp_bytes = bytes; E.key_cap = cap;
     return GBN_OK;
 }
+// which scan records E.bin_rec holds (GBN_REUSE_BINNING)
+struct BinKey { const void *db; int32_t s0, s1; int lut, step, nb, nwriters; size_t subcap; bool valid; };
+static BinKey g_binkey = {nullptr, 0, 0, 0, 0, 0, 0, 0, false};
+
 static int grow_ihit_buffers(int slot, size_t n) {
     if (n <= E.ihit_cap_s[slot]) return GBN_OK;
     dev_free(E.ihits_s[slot]); dev_free(E.gapped_s[slot]);
@@ -401,8 +406,18 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
                 if (!E.rare_counts && (rc = dev_alloc(E.rare_counts, (size_t)1024))) return rc;
                 B.rareq = E.rareq; B.rare_seg = (uint32_t)std::min<size_t>(seg, 0x7fffffff); B.rare_counts = E.rare_counts;
             }
+            // The scan records depend on the shard and on (lut width, stride) only, not on the queries.
+            // GBN_REUSE_BINNING=1 (off by default; bench.py never sets it for the headline number) keeps
+            // them for the next query batch with the same table shape: a database-side index held in HBM.
+            BinKey &have = g_binkey;
+            const BinKey want_key = {(const void *)&db, s0, s1, b.lut.lut, b.lut.step, nb, nwriters, subcap, true};
+            static const bool reuse = getenv("GBN_REUSE_BINNING") && atoi(getenv("GBN_REUSE_BINNING")) != 0;
+            const bool hit = reuse && have.valid && have.db == want_key.db && have.s0 == s0 && have.s1 == s1 && have.lut == want_key.lut &&
+                             have.step == want_key.step && have.nb == nb && have.nwriters == nwriters && have.subcap == subcap;
+            have.valid = false;
             HIPCHK(hipEventRecord(E.ev0, E.stream));
-            HIPCHK(launch_scan_bin(B, grid2, E.stream, E.evk));
+            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, hit ? 2 : 3));
+            have = want_key;                                    // invalidated below if this launch overflowed
             binned = true;
             HIPCHK(hipEventRecord(E.ev1, E.stream));
             HIPCHK(hipMemcpyAsync(&overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
@@ -445,7 +460,7 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
                 continue;
             }
         }
-        if (overflow) { slack *= 2; if (slack > 64) { set_error("bin overflow"); return GBN_ERR_NOMEM; } continue; }
+        if (overflow) { /* the kept records are incomplete */ slack *= 2; if (slack > 64) { set_error("bin overflow"); return GBN_ERR_NOMEM; } continue; }
         if (cnt[0] <= E.seed_cap) break;
         if ((rc = grow_seed_buffers((size_t)cnt[0] + (cnt[0] >> 3)))) return rc;
     }
@@ -717,6 +732,7 @@ void Blast_gpu_Release(void) {
     std::lock_guard<std::mutex> lk(E.mu);
     if (!E.ready) return;
     (void)wait_pending();
+    g_binkey.valid = false;
     dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
     dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.sort_tmp); for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
     dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
@@ -758,6 +774,7 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
 
 void gbn_db_free(GbnDb *db) {
     if (!db) return;
+    if (g_binkey.db == (const void *)db) g_binkey.valid = false;
     free_tile_cache(*db);
     if (db->owns && db->d_packed) (void)hipFree((void *)db->d_packed);
     dev_free(db->d_byte_off); dev_free(db->d_len);

@@ -256,3 +256,34 @@ def test_option_sweep(task, kw):
     nh, plants = run_case(5, 60_000, nq, task=task, planted_fraction=0.6, **kw)
     if kw.get("cutoff_score", 0) == 0 and kw.get("evalue", 10) >= 1e-10:
         assert nh >= 1
+
+
+def test_reused_binning_gives_identical_results(monkeypatch):
+    # opt-in database-side index: the scan records of a shard serve several query batches
+    import subprocess, sys, os, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from gblastn_amd import api
+from tests import util
+db, queries, plants, subjects, opt = util.small_case(12, 1_000_000, 320)
+src = api.BlastSeqSrc.from_packed(subjects)
+a = api.BlastPrelimSearch(queries[:160], opt, src); b = api.BlastPrelimSearch(queries[160:], opt, src)
+assert a.info()["lut_width"] == 12
+out = []
+for k in range(4):
+    cur = (a, b)[k %% 2]
+    before = cur.diagnostics.bin_kernel_ms
+    h = cur.run()["hsps"]
+    out.append([h.tobytes().hex(), cur.diagnostics.bin_kernel_ms - before])
+print(json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ); env["GBN_REUSE_BINNING"] = flag; env.pop("GBN_SCAN_BINS", None)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[flag] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert [r[0] for r in res["0"]] == [r[0] for r in res["1"]]
+    # with reuse only the first pass runs the binning kernel
+    assert sum(r[1] for r in res["1"][1:]) < 0.6 * sum(r[1] for r in res["0"][1:])
