@@ -536,6 +536,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         X.matrix = d->matrix; X.score_table = d->score_table;
         X.word = b.lut.word; X.container_hash = b.container;
         X.cell_diag = E.cell_diag; X.cell_level = E.cell_level;
+        X.run_heads = E.idx_b; X.run_count = reinterpret_cast<uint32_t *>(E.counters + 3);
         X.ihits = E.ihits_s[slot]; X.ihit_count = E.counters + 2; X.ihit_cap = E.ihit_cap_s[slot];
         HIPCHK(launch_diag_ungapped(X, E.stream));
         HIPCHK(hipMemcpyAsync(&nih, E.counters + 2, sizeof(nih), hipMemcpyDeviceToHost, E.stream));
@@ -627,12 +628,15 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     t_stage = now();
 
     // ---- host replay per subject, ascending oid ----
+    // group the hits by subject (counting sort; the order inside a subject does not matter,
+    // finish_subject sorts with the seed sequence number as the last key)
     std::vector<uint32_t> order((size_t)nih);
-    for (size_t i = 0; i < (size_t)nih; i++) order[i] = (uint32_t)i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t c) {
-        if (hih[a].subj != hih[c].subj) return hih[a].subj < hih[c].subj;
-        return hih[a].seq < hih[c].seq;
-    });
+    {
+        std::vector<uint32_t> start((size_t)(s1 - s0) + 1, 0);
+        for (size_t i = 0; i < (size_t)nih; i++) start[(size_t)(hih[i].subj - s0) + 1]++;
+        for (size_t k = 1; k < start.size(); k++) start[k] += start[k - 1];
+        for (size_t i = 0; i < (size_t)nih; i++) order[start[(size_t)(hih[i].subj - s0)]++] = (uint32_t)i;
+    }
     // subjects are independent: split the ordered hits into per-subject spans, replay the spans on a
     // few host threads when there is enough work, append the HSP lists in ascending oid order
     std::vector<std::pair<size_t, size_t>> spans;

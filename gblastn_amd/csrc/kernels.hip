@@ -340,12 +340,27 @@ __device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict
 // scan order because the one-hit filter is a sequential state machine
 // (CORE/na_ungapped.c:652,748 / :818,917).  The hash container is emulated
 // exactly per subject: cells live in a scratch slice as long as the run.
+// compaction of the run heads, so that every lane of the replay kernel below has a run to work on
+// (with the 512-bucket hash container a run is ~n / (512 x subjects) seeds long)
+extern "C" __global__ void run_heads_kernel(GbnExtParams P)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool head = i < P.n && (i == 0 || P.key_group[i - 1] != P.key_group[i]);
+    const unsigned long long m = __ballot(head);
+    if (!m) return;
+    const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(P.run_count, (uint32_t)__popcll(m));
+    base = __shfl(base, leader);
+    if (head) P.run_heads[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)i;
+}
+
 extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)*P.run_count) return;
+    const int64_t i = P.run_heads[t];
     const uint64_t key = P.key_group[i];
-    if (i > 0 && P.key_group[i - 1] == key) return;     // not the head of a run
     const int32_t subj_id = (int32_t)(key >> 32);
     const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
     const int32_t slen = P.len[subj_id];
@@ -804,6 +819,10 @@ hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st)
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
 {
     if (p.n <= 0) return hipSuccess;
+    hipError_t e = hipMemsetAsync(p.run_count, 0, sizeof(uint32_t), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(run_heads_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+    // grid for the worst case (every seed its own run); threads past the run count leave at once
     hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
     return hipGetLastError();
 }
