@@ -865,7 +865,8 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
         // ranges of subjects bounded by packed size so that scratch stays modest
         int64_t range_gib = 16;
         if (const char *e = getenv("GBN_RANGE_GIB")) range_gib = std::max(1, atoi(e));
-        const int64_t range_bytes = range_gib << 30;
+        int64_t range_bytes = range_gib << 30;
+        if (const char *e = getenv("GBN_RANGE_MIB")) range_bytes = (int64_t)std::max(1, atoi(e)) << 20;    // tests
         int32_t s0 = 0;
         while (s0 < db->num_seqs) {
             int32_t s1 = s0; int64_t acc = 0, tiles = 0;

@@ -287,3 +287,41 @@ print(json.dumps(out))
     assert [r[0] for r in res["0"]] == [r[0] for r in res["1"]]
     # with reuse only the first pass runs the binning kernel
     assert sum(r[1] for r in res["1"][1:]) < 0.6 * sum(r[1] for r in res["0"][1:])
+
+
+def test_subject_ranges_do_not_change_results():
+    # the engine cuts a shard into subject ranges (GBN_RANGE_GIB, position-id width); results must not depend on it
+    import subprocess, sys, os, json
+    code = r'''
+import sys, json
+sys.path.insert(0, %r)
+from gblastn_amd import api
+from tests import util
+db, queries, plants, subjects, opt = util.small_case(40, 60_000_0, 200)
+src = api.BlastSeqSrc.from_packed(subjects)
+ps = api.BlastPrelimSearch(queries, opt, src)
+h = ps.run()["hsps"]
+print(json.dumps([h.tobytes().hex(), int(ps.diagnostics.scan_launches), int(ps.diagnostics.lookup_hits)]))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = {}
+    for tag, env_add in (("one", {}), ("many", {"GBN_RANGE_MIB": "1"})):
+        env = dict(os.environ); env.update(env_add)
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        out[tag] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert out["one"][1] == 1 and out["many"][1] > 3
+    assert out["one"][0] == out["many"][0] and out["one"][2] == out["many"][2]
+
+
+def test_interrupt_callback_stops_between_ranges():
+    import ctypes as C
+    db, queries, plants, subjects, opt = util.small_case(8, 100_000, 8)
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    calls = []
+    CB = C.CFUNCTYPE(C.c_int, C.c_void_p)
+    cb = CB(lambda p: (calls.append(1), 1)[1])
+    L = api.lib()
+    rc = L.gbn_prelim_search(ps._b, src._h, ps._r, C.byref(ps.diagnostics), 0, C.cast(cb, C.c_void_p), None)
+    assert rc != 0 and b"interrupt" in L.gbn_last_error() and len(calls) == 1
+    assert len(ps.run()["hsps"]) >= 1                   # the engine is usable afterwards
