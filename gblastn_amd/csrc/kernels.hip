@@ -1161,7 +1161,7 @@ probe_bin_kernel(GbnBinParams B)
     const GbnScanParams &P = B.S;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     uint32_t *s_tab = s_dyn;                                        // GBN_BIN_CELLS entries
-    volatile uint2 *s_q = reinterpret_cast<volatile uint2 *>(s_dyn + GBN_BIN_CELLS);   // [16 waves][QCAP]
+    uint2 *s_q = reinterpret_cast<uint2 *>(s_dyn + GBN_BIN_CELLS);   // [16 waves][QCAP]; a wave's queue is touched by that wave only
     uint16_t *s_side = reinterpret_cast<uint16_t *>(s_dyn + GBN_BIN_CELLS + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2);
     uint32_t *s_rcount = s_dyn + GBN_BIN_CELLS + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2 + GBN_BIN_SIDE / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -1175,7 +1175,7 @@ probe_bin_kernel(GbnBinParams B)
     const uint32_t lmask = (B.rfl <= 0) ? 0u : ((1u << (2 * B.rfl)) - 1);                               // byte 0 of an fp15
     const uint32_t rmask = (B.rfrbits <= 0) ? 0u : (((1u << B.rfrbits) - 1) << (7 - B.rfrbits));      // byte 1
     const uint32_t m4 = (lmask | (rmask << 8)) * 0x10001u;          // both fingerprints of a cell word at once
-    volatile uint2 *q = s_q + wave * GBN_BIN_QCAP;
+    uint2 *q = s_q + wave * GBN_BIN_QCAP;
     int qn = 0;                                                     // wave-uniform
     unsigned long long raw = 0;
     const unsigned long long lt = (1ull << lane) - 1;
@@ -1183,6 +1183,7 @@ probe_bin_kernel(GbnBinParams B)
     // Flush `cnt` queued items (one per lane): cells with a side list get their reduced
     // fingerprints checked here, densely; survivors go to the global rare-path queue.
     auto flush = [&](int first, int cnt, int bin) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // queue slots written by other lanes of this wave
         bool keep = false; uint32_t at_rec = 0, cv = 0;
         if (lane < cnt) {
             at_rec = q[first + lane].x;                             // record index inside the bin's region
@@ -1237,8 +1238,8 @@ probe_bin_kernel(GbnBinParams B)
             constexpr uint32_t U = GBN_PROBE_U, BLK = 256u * U, NR = 4 * U;    // records per wave and per lane and round
             const uint32_t piece = ((ntot + (uint32_t)split * BLK - 1u) / ((uint32_t)split * BLK)) * BLK;
             const uint32_t lo = min((uint32_t)part * piece, ntot), n = min(piece, ntot - lo);
-            // lo and every round start are multiples of 512: one chunk per round
-            auto chunk_of = [&](uint32_t j0) -> const uint32_t * { return B.rec + GBN_REC_HI(GBN_RECIDX(B, b, w, lo + j0)); };
+            // lo and every round start are multiples of 512 (one chunk per round in the chunked layout)
+            const uint32_t *__restrict__ recb = B.rec;
             const uint32_t rbase = (uint32_t)w * B.subcap + lo;     // of this piece inside the bin's region
             // software pipeline: the loads of the next round are in flight while this round's
             // records are looked up
@@ -1247,13 +1248,17 @@ probe_bin_kernel(GbnBinParams B)
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t j = u * 256u + (uint32_t)lane * 4u;
-                cur[u] = (j < n) ? *reinterpret_cast<const uint4 *>(chunk_of(j & ~511u) + GBN_REC_HI(j & 511u)) : padv;
+                const uint32_t jj = (j < n) ? j : 0u;              // always a valid address: keeps the load a global load
+                const uint4 v = *reinterpret_cast<const uint4 *>(recb + GBN_REC_HI(GBN_RECIDX(B, b, w, lo + (jj & ~511u))) + GBN_REC_HI(jj & 511u));
+                cur[u] = (j < n) ? v : padv;
             }
             for (uint32_t j0 = 0; j0 < n; j0 += BLK) {
                 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) {
                     const uint32_t j = j0 + BLK + u * 256u + (uint32_t)lane * 4u;
-                    nxt[u] = (j < n) ? *reinterpret_cast<const uint4 *>(chunk_of(j & ~511u) + GBN_REC_HI(j & 511u)) : padv;
+                    const uint32_t jj = (j < n) ? j : 0u;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(recb + GBN_REC_HI(GBN_RECIDX(B, b, w, lo + (jj & ~511u))) + GBN_REC_HI(jj & 511u));
+                    nxt[u] = (j < n) ? v : padv;
                 }
                 uint32_t hv[NR], tv[NR];
                 #pragma unroll
