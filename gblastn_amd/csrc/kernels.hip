@@ -1132,13 +1132,13 @@ __device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell
     const int32_t s = T.first_pos + (int32_t)(posid & (uint32_t)(GBN_BIN_TILE_POS - 1)) * P.step;
     const uint8_t *__restrict__ subj = P.db + ((size_t)(uint32_t)T.off16 << 4);     // = byte_off[T.subj], one load less
     // one 32-base window from s - 8 holds the 8 bases left of the word and (lut <= 16) at least 8 right of it
-    const uint64_t w32 = bases32(subj, (int64_t)s - 8);
+    const uint64_t w32 = (P.fl > 0 || P.fr > 0) ? bases32(subj, (int64_t)s - 8) : 0ull;     // lut == word: nothing to compare
     const uint32_t sl = (uint32_t)(w32 >> 48);
     const uint32_t sr = (uint32_t)((w32 << (2 * (8 + P.lut))) >> 32);
     for (uint32_t e = start; e < end; e++) {
         const unsigned long long ent = P.ent[e];
         if (!fp_pass((uint32_t)(ent >> 32), sl, sr, P.fl, P.fr)) continue;
-        const int32_t slen = P.len[T.subj];
+        const int32_t slen = (P.mode == GBN_EXT_DIRECT) ? 0 : P.len[T.subj];
         const int32_t q = (int32_t)(ent & 0xffffffffu);
         const int el = verify_hit(P, subj, slen, q, s);
         // one reservation per wave and round: the lanes still in this loop that verified a hit
