@@ -60,7 +60,7 @@ IHIT_DT = np.dtype([("oid", "<i4"), ("q_off", "<i4"), ("s_off", "<i4"), ("q_star
 
 EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_default_options",
            "gbn_db_new", "gbn_db_free", "gbn_db_total_bases", "gbn_db_num_seqs", "gbn_synth_fill",
-           "gbn_batch_new", "gbn_batch_new_ex", "gbn_batch_free", "gbn_batch_num_contexts", "gbn_batch_contexts",
+           "gbn_batch_new", "gbn_batch_new_ex", "gbn_batch_new_masked", "gbn_batch_free", "gbn_batch_num_contexts", "gbn_batch_contexts",
            "gbn_batch_lut_type", "gbn_batch_lut_width", "gbn_batch_scan_step",
            "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff", "gbn_results_new",
            "gbn_results_free", "gbn_results_clear", "gbn_results_num_hsps", "gbn_results_hsps",
@@ -100,6 +100,9 @@ def lib():
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
         L.gbn_batch_new_ex.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GbnOptions), C.c_int32,
                                        C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int]
+        L.gbn_batch_new_masked.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GbnOptions), C.c_int32,
+                                           C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32,
+                                           C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]
         L.gbn_batch_free.argtypes = [C.c_void_p]
         for nm in ["gbn_batch_num_contexts", "gbn_batch_lut_type", "gbn_batch_lut_width",
                    "gbn_batch_scan_step", "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff"]:
@@ -229,16 +232,22 @@ class BlastSeqSrc:
 class BlastPrelimSearch:
     """CBlastPrelimSearch analogue: one query batch against one resident shard."""
 
-    def __init__(self, queries, options, seqsrc=None, upload=True):
-        """upload=False builds the host-side set-up only (no device needed)."""
+    def __init__(self, queries, options, seqsrc=None, upload=True, masks=None):
+        """upload=False builds the host-side set-up only (no device needed).
+        masks: soft query masks [(query index, from, to)], inclusive plus-strand intervals."""
         L = lib()
         self._q = [np.ascontiguousarray(q, dtype=np.uint8) for q in queries]
         ptrs = (C.c_void_p * len(self._q))(*[q.ctypes.data for q in self._q])
         lens = (C.c_int32 * len(self._q))(*[len(q) for q in self._q])
         self.options = options
         self._b = C.c_void_p()
-        _check(L.gbn_batch_new_ex(C.byref(self._b), C.byref(options), len(self._q), ptrs, lens,
-                                  1 if upload else 0))
+        masks = sorted(masks or [])
+        n = len(masks)
+        mq = (C.c_int32 * max(n, 1))(*[m[0] for m in masks])
+        mf = (C.c_int32 * max(n, 1))(*[m[1] for m in masks])
+        mt = (C.c_int32 * max(n, 1))(*[m[2] for m in masks])
+        _check(L.gbn_batch_new_masked(C.byref(self._b), C.byref(options), len(self._q), ptrs, lens,
+                                      n, mq, mf, mt, 1 if upload else 0))
         self._r = C.c_void_p()
         _check(L.gbn_results_new(C.byref(self._r)))
         self.seqsrc = seqsrc

@@ -95,14 +95,15 @@ static int choose_lookup(const GbnOptions &o, int32_t entries, int32_t max_off, 
     return type;
 }
 
-// Index every lut-word that lies inside a strand, has no ambiguity code and
-// whose strand can hold a full word_size word.
+// Index every lut-word that lies inside an indexed stretch [left, right] of the concatenated query,
+// has no ambiguity code, and whose stretch can hold a full word_size word
+// (CORE/blast_lookup.c:87-137, CORE/blast_nalookup.c:873-928).
 template <class F>
-static void each_query_word(const uint8_t *q, const GbnContext &c, int word, int lut, F &&emit) {
-    if (!c.is_valid || word > c.query_length) return;
+static void each_query_word(const uint8_t *q, int32_t left, int32_t right, int word, int lut, F &&emit) {
+    if (word > right - left + 1) return;
     const uint32_t mask = (lut == 16) ? 0xffffffffu : ((1u << (2 * lut)) - 1);
     uint32_t code = 0; int run = 0;
-    for (int32_t p = c.query_offset; p < c.query_offset + c.query_length; p++) {
+    for (int32_t p = left; p <= right; p++) {
         uint8_t b = q[p];
         if (b & 0xfc) { run = 0; code = 0; continue; }
         code = ((code << 2) | b) & mask;
@@ -110,20 +111,57 @@ static void each_query_word(const uint8_t *q, const GbnContext &c, int word, int
     }
 }
 
+// The indexed stretches: every valid strand minus the soft masks (mask coordinates are plus-strand,
+// mirrored onto the minus strand), in the form BLAST_ComplementMaskLocations produces them
+// (CORE/blast_filter.c:1019-1119) -- including its empty stretches between abutting masks, which
+// count in the table-size estimate below.
+static void indexed_stretches(GbnBatch &b, const std::vector<QueryMask> &masks) {
+    auto &out = b.lut.segments;
+    out.clear();
+    for (const GbnContext &c : b.ctx) {
+        if (!c.is_valid) continue;
+        const int32_t first = c.query_offset, last = c.query_offset + c.query_length - 1;
+        std::vector<std::pair<int32_t, int32_t>> m;         // masked intervals in concatenated coordinates, ascending
+        for (const QueryMask &k : masks) if (k.query == c.query_index) {
+            if (c.frame < 0) m.emplace_back(last - k.to, last - k.from);
+            else m.emplace_back(first + k.from, first + k.to);
+        }
+        if (c.frame < 0) std::reverse(m.begin(), m.end());
+        if (m.empty()) { out.emplace_back(first, last); continue; }
+        int32_t left = first; bool open = true; size_t i = 0;
+        if (m[0].first <= first) { left = m[0].second + 1; i = 1; }     // the strand starts masked
+        for (; i < m.size(); i++) {
+            out.emplace_back(left, m[i].first - 1);
+            if (m[i].second >= last) { open = false; break; }
+            left = m[i].second + 1;
+        }
+        if (open) out.emplace_back(left, last);
+    }
+    // seeds are re-checked against the table when some unindexed gap is longer than 3 positions
+    // (s_SeqLocListInvert, CORE/blast_nalookup.c:333-366) and the table words are shorter than word_size
+    bool gap = false;
+    if (!out.empty()) {
+        if (std::max(0, out[0].first - 1) - 0 > 2) gap = true;
+        for (size_t i = 0; i < out.size() && !gap; i++) {
+            const int32_t start = out[i].second + 1;
+            const int32_t stop = (i + 1 < out.size()) ? out[i + 1].first - 1 : b.qlen - 1;
+            if (stop - start > 2) gap = true;
+        }
+    }
+    b.lut.masked = gap;
+}
+
 static void build_lookup(GbnBatch &b) {
     HostLookup &L = b.lut;
-    int32_t entries = 0, max_off = 0;
-    for (auto &c : b.ctx) if (c.is_valid) {
-        entries += c.query_length - 1;
-        max_off = std::max(max_off, c.query_offset + c.query_length - 1);
-    }
+    int32_t entries = 0, max_off = 0;                   // EstimateNumTableEntries, CORE/lookup_util.c:193-209
+    for (auto &sg : L.segments) { entries += sg.second - sg.first; max_off = std::max(max_off, sg.second); }
     int width = 0;
     L.type = choose_lookup(b.opt, entries, max_off, width);
     L.word = b.opt.word_size; L.lut = width; L.step = L.word - L.lut + 1;
     L.ncells = (int64_t)1 << (2 * width);
     const uint8_t *q = b.query();
     std::vector<uint32_t> count((size_t)L.ncells, 0);
-    for (auto &c : b.ctx) each_query_word(q, c, L.word, width, [&](uint32_t cell, int32_t) { count[cell]++; });
+    for (auto &sg : L.segments) each_query_word(q, sg.first, sg.second, L.word, width, [&](uint32_t cell, int32_t) { count[cell]++; });
     L.cell_start.assign((size_t)L.ncells + 1, 0);
     uint32_t acc = 0; int64_t overflow_cells = 2;
     for (int64_t i = 0; i < L.ncells; i++) {
@@ -134,7 +172,7 @@ static void build_lookup(GbnBatch &b) {
     if (L.type == GBN_LUT_SMALL_NA && overflow_cells >= 32768) L.type = GBN_LUT_NA;
     L.cell_qoff.assign(acc, 0);
     std::vector<uint32_t> fill(L.cell_start.begin(), L.cell_start.end() - 1);
-    for (auto &c : b.ctx) each_query_word(q, c, L.word, width, [&](uint32_t cell, int32_t off) { L.cell_qoff[fill[cell]++] = off; });
+    for (auto &sg : L.segments) each_query_word(q, sg.first, sg.second, L.word, width, [&](uint32_t cell, int32_t off) { L.cell_qoff[fill[cell]++] = off; });
     if (L.type == GBN_LUT_MB) {
         // megablast chains yield the LAST inserted offset first (CORE/blast_nalookup.c:925-926,
         // CORE/blast_nascan.c:1413-1427): reverse every cell
@@ -145,7 +183,8 @@ static void build_lookup(GbnBatch &b) {
     for (int64_t i = 0; i < L.ncells; i++) if (count[i]) L.pv[i >> 5] |= 1u << (i & 31);
 }
 
-int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *const *seqs, const int32_t *lens) {
+int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *const *seqs, const int32_t *lens,
+                const std::vector<QueryMask> &masks) {
     b.opt = opt; b.nq = nq;
     b.ctx.assign((size_t)2 * nq, GbnContext{});
     const int32_t pad = 64;         // sentinel padding so kernels may read windows past either end
@@ -202,7 +241,17 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
     b.container = b.qlen > 8000 ? 1 : 0;
     b.diag_len = 1;
     while (b.diag_len < b.qlen) b.diag_len <<= 1;
+    // masks: per query ascending, disjoint, inside the query
+    for (size_t i = 0; i < masks.size(); i++) {
+        const QueryMask &k = masks[i];
+        if (k.query < 0 || k.query >= nq || k.from < 0 || k.to < k.from || k.to >= lens[k.query] ||
+            (i > 0 && masks[i - 1].query == k.query && masks[i - 1].to >= k.from) || (i > 0 && masks[i - 1].query > k.query)) {
+            set_error("query masks must be sorted by (query, from), disjoint and inside their query"); return GBN_ERR_ARG;
+        }
+    }
+    indexed_stretches(b, masks);
     build_lookup(b);
+    b.lut.masked = b.lut.masked && b.lut.word > b.lut.lut;
     return GBN_OK;
 }
 

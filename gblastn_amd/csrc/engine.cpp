@@ -536,6 +536,8 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         X.matrix = d->matrix; X.score_table = d->score_table;
         X.word = b.lut.word; X.container_hash = b.container;
         X.cell_diag = E.cell_diag; X.cell_level = E.cell_level;
+        X.cell_start = d->cell_start; X.ent = d->ent; X.cell_mask = (uint32_t)(b.lut.ncells - 1); X.lut = b.lut.lut;
+        X.masked = b.lut.masked ? 1 : 0;
         X.run_heads = E.idx_b; X.run_count = reinterpret_cast<uint32_t *>(E.counters + 3);
         X.ihits = E.ihits_s[slot]; X.ihit_count = E.counters + 2; X.ihit_cap = E.ihit_cap_s[slot];
         HIPCHK(launch_diag_ungapped(X, E.stream));
@@ -796,16 +798,27 @@ int gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream) {
     return GBN_OK;
 }
 
-int gbn_batch_new_ex(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs,
-                     const int32_t *lens, int upload) {
-    if (!out || !opt || nq <= 0 || !seqs || !lens) { set_error("bad argument"); return GBN_ERR_ARG; }
+int gbn_batch_new_masked(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs,
+                         const int32_t *lens, int32_t nmask, const int32_t *mask_query, const int32_t *mask_from,
+                         const int32_t *mask_to, int upload) {
+    if (!out || !opt || nq <= 0 || !seqs || !lens || nmask < 0 || (nmask > 0 && (!mask_query || !mask_from || !mask_to))) {
+        set_error("bad argument"); return GBN_ERR_ARG;
+    }
+    std::vector<QueryMask> masks((size_t)nmask);
+    for (int32_t i = 0; i < nmask; i++) masks[(size_t)i] = QueryMask{mask_query[i], mask_from[i], mask_to[i]};
     GbnBatch *b = new GbnBatch();
-    int rc = build_batch(*b, *opt, nq, seqs, lens);
+    int rc = build_batch(*b, *opt, nq, seqs, lens, masks);
     if (rc == GBN_OK && upload) rc = upload_batch(*b);
     if (rc != GBN_OK) { gbn_batch_free(b); return rc; }
     *out = b;
     return GBN_OK;
 }
+
+int gbn_batch_new_ex(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs,
+                     const int32_t *lens, int upload) {
+    return gbn_batch_new_masked(out, opt, nq, seqs, lens, 0, nullptr, nullptr, nullptr, upload);
+}
+
 int gbn_batch_new(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs, const int32_t *lens) {
     return gbn_batch_new_ex(out, opt, nq, seqs, lens, 1);
 }

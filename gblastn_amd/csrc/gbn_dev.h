@@ -105,6 +105,8 @@ struct GbnExtParams {
     const int32_t *score_table;     // 256
     int word, container_hash;
     int32_t *cell_diag, *cell_level;    // hash emulation scratch, n entries each
+    // re-check of seeds against the soft query masks (s_TypeOfWord): table membership tests
+    const uint32_t *cell_start; const unsigned long long *ent; uint32_t cell_mask; int lut, masked;
     uint32_t *run_heads, *run_count;    // scratch: index of the first seed of every (subject, slot) run (n entries), their number
     GbnDevInitHit *ihits; unsigned long long *ihit_count; unsigned long long ihit_cap;
 };

@@ -4,6 +4,7 @@
 #include "../../include/gblastn_amd.h"
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace gbn {
@@ -35,6 +36,9 @@ struct HostLookup {
     std::vector<uint32_t> cell_start;   // ncells + 1
     std::vector<int32_t>  cell_qoff;    // 0-based query offsets
     std::vector<uint32_t> pv;           // 1 bit per cell
+    // stretches of the concatenated query that are indexed: the contexts minus the soft masks
+    std::vector<std::pair<int32_t, int32_t>> segments;   // [left, right], as BLAST_ComplementMaskLocations yields them
+    bool masked = false;                // the reference's lut->masked_locations != NULL: seeds are re-checked
 };
 
 struct DeviceBatch;     // device mirrors, defined in engine.cpp
@@ -82,8 +86,10 @@ struct GbnResults {
 
 namespace gbn {
 void set_error(const std::string &msg);
+struct QueryMask { int32_t query, from, to; };      // soft mask, plus-strand coordinates, inclusive
 int  build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq,
-                 const uint8_t *const *seqs, const int32_t *lens);
+                 const uint8_t *const *seqs, const int32_t *lens,
+                 const std::vector<QueryMask> &masks = std::vector<QueryMask>());
 int  upload_batch(GbnBatch &b);
 void free_device_batch(DeviceBatch *d);
 }

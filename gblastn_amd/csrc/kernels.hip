@@ -336,6 +336,46 @@ __device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict
 }
 }  // namespace
 
+namespace {
+// s_IsSeedMasked (CORE/na_ungapped.c:459-471): is query offset q_pos absent from the cell of the lookup
+// word the subject carries at s_pos (a masked or ambiguous query position is not indexed)
+__device__ bool seed_masked(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t s_pos, int32_t q_pos)
+{
+    const uint32_t cell = (window16(subj, s_pos) >> (32 - 2 * P.lut)) & P.cell_mask;
+    for (uint32_t e = P.cell_start[cell]; e < P.cell_start[cell + 1]; e++)
+        if ((int32_t)(uint32_t)P.ent[e] == q_pos) return false;
+    return true;
+}
+
+// s_TypeOfWord (CORE/na_ungapped.c:488-587), one-hit mode: re-check of the mini-extended word against the
+// query masks; may move the left end of the word right and extend its right end.  false: drop the seed.
+__device__ bool type_of_word(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
+                             int32_t &q_off, int32_t &s_off, int32_t &extended)
+{
+    const int32_t word = P.word, lut = P.lut;
+    extended = 0;
+    if (word == lut) return true;
+    int32_t q_end = q_off + word, s_end = s_off + word;
+    int lo = 0, hi = P.nctx;
+    while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > q_end) hi = m; else lo = m; }
+    const int32_t q_range = P.ctx_off[lo] + P.ctx_len[lo];
+    if (P.masked) {
+        if (seed_masked(P, subj, s_end - lut, q_end - lut)) return false;
+        while (seed_masked(P, subj, s_off, q_off)) { ++s_off; ++q_off; }
+    }
+    const int32_t ext_to = word - (q_end - q_off);
+    const int32_t ext_max = min(q_range - q_end, slen - s_end);
+    if (ext_to || P.masked) {
+        if (ext_to > ext_max) return false;
+        q_end += ext_to; s_end += ext_to;
+        for (int32_t s_pos = s_end - lut, q_pos = q_end - lut; s_pos > s_off; s_pos -= lut, q_pos -= lut)
+            if (seed_masked(P, subj, s_pos, q_pos)) return false;
+        extended = ext_to;
+    }
+    return true;
+}
+}  // namespace
+
 // One thread per (subject, diagonal-slot) run of seeds; the run is replayed in
 // scan order because the one-hit filter is a sequential state machine
 // (CORE/na_ungapped.c:652,748 / :818,917).  The hash container is emulated
@@ -369,8 +409,9 @@ extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
     int64_t ncell = 0;              // hash container: cells [i, i+ncell)
     for (int64_t j = i; j < P.n && P.key_group[j] == key; j++) {
         GbnDevSeed sd = P.seeds[P.idx[j]];
-        const int32_t q_off = sd.q_pos - sd.ext_left, s_off = sd.s_scan - sd.ext_left;
+        int32_t q_off = sd.q_pos - sd.ext_left, s_off = sd.s_scan - sd.ext_left;
         const int32_t diag = s_off - q_off;
+        const int32_t s_off_pos = s_off;                // the container is keyed by the word as the scan delivered it
         int32_t s_end_pos = s_off + word;
         if (P.container_hash) {
             last_hit = 0;
@@ -378,13 +419,19 @@ extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
                 if (P.cell_diag[i + c] == diag) { last_hit = P.cell_level[i + c]; break; }
         }
         if (s_off < last_hit) continue;
+        int32_t s_match_end = s_off + word;
+        if (P.masked) {                                 // without masks s_TypeOfWord changes nothing
+            int32_t extended;
+            if (!type_of_word(P, subj, slen, q_off, s_off, extended)) continue;
+            s_match_end += extended; s_end_pos += extended;
+        }
         // strand of the seed
         int lo = 0, hi = P.nctx;
         while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > q_off) hi = m; else lo = m; }
         const int32_t X = -P.ctx_xdrop[lo];
         Ungapped u;
         if (!P.container_hash && word < 11) ungapped_exact(P, subj, slen, q_off, s_off, X, u);
-        else ungapped_approx(P, subj, slen, q_off, s_off + word, s_off, X, P.ctx_reduced[lo], u);
+        else ungapped_approx(P, subj, slen, q_off, s_match_end, s_off, X, P.ctx_reduced[lo], u);
         if (u.score >= P.ctx_cutoff[lo]) {
             unsigned long long o = atomicAdd(P.ihit_count, 1ull);
             if (o < P.ihit_cap) {
@@ -401,7 +448,7 @@ extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
             bool placed = false;
             for (int64_t c = ncell - 1; c >= 0; c--) {
                 if (P.cell_diag[i + c] == diag) { P.cell_level[i + c] = s_end_pos; placed = true; break; }
-                if (s_off - P.cell_level[i + c] > win) { P.cell_diag[i + c] = diag; P.cell_level[i + c] = s_end_pos; placed = true; break; }
+                if (s_off_pos - P.cell_level[i + c] > win) { P.cell_diag[i + c] = diag; P.cell_level[i + c] = s_end_pos; placed = true; break; }
             }
             if (!placed) { P.cell_diag[i + ncell] = diag; P.cell_level[i + ncell] = s_end_pos; ncell++; }
         } else {

@@ -185,6 +185,16 @@ int  gbn_batch_new(GbnBatch **out, const GbnOptions *opt, int32_t nq,
 /* upload == 0 builds the host-side set-up only (no device needed) */
 int  gbn_batch_new_ex(GbnBatch **out, const GbnOptions *opt, int32_t nq,
                       const uint8_t *const *seqs, const int32_t *lens, int upload);
+/* Soft query masks ("mask at hash": DUST / lower-case masks as blastn applies them by default,
+ * BlastMaskLoc -> lookup_segments, CORE/blast_setup.c BLAST_MainSetUp / CORE/blast_filter.c:1019-1119):
+ * nmask intervals [from, to] (inclusive, plus-strand coordinates of query mask_query[k]) sorted by
+ * (query, from) and disjoint.  Masked stretches are not indexed in the lookup table, and every seed
+ * is re-checked against the table (s_TypeOfWord, CORE/na_ungapped.c:488-587); the extensions see the
+ * unmasked query.  Hard masking = write the code for N (14) into the query instead. */
+int  gbn_batch_new_masked(GbnBatch **out, const GbnOptions *opt, int32_t nq,
+                          const uint8_t *const *seqs, const int32_t *lens,
+                          int32_t nmask, const int32_t *mask_query, const int32_t *mask_from,
+                          const int32_t *mask_to, int upload);
 void gbn_batch_free(GbnBatch *b);
 int32_t gbn_batch_num_contexts(const GbnBatch *b);
 const GbnContext *gbn_batch_contexts(const GbnBatch *b);

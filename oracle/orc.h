@@ -101,6 +101,13 @@ void orc_default_options(OrcOptions *o, int megablast);
  * seqs[i] is BLASTNA (one code 0..15 per base), plus strand. */
 OrcSearch *orc_search_new(const OrcOptions *opt, int nq,
                           const uint8_t *const *seqs, const int32_t *lens);
+/* Same with soft query masks ("mask at hash", the blastn default for DUST / lower-case masks):
+ * intervals [from, to] (inclusive) in plus-strand coordinates of query mq[k], sorted and
+ * non-overlapping per query.  Masked stretches are left out of the lookup table only
+ * (CORE/blast_filter.c:1019-1119 lookup segments; CORE/na_ungapped.c:459-587 word re-check). */
+OrcSearch *orc_search_new_masked(const OrcOptions *opt, int nq,
+                                 const uint8_t *const *seqs, const int32_t *lens,
+                                 int32_t nmask, const int32_t *mq, const int32_t *mfrom, const int32_t *mto);
 void orc_search_free(OrcSearch *s);
 
 /* introspection of the set-up (pins the integers that gate every kernel) */

@@ -71,6 +71,9 @@ def lib():
     global _LIB
     if _LIB is None:
         L = C.CDLL(build())
+        L.orc_search_new_masked.restype = C.c_void_p
+        L.orc_search_new_masked.argtypes = [C.POINTER(OrcOptions), C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int32),
+                                            C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
         L.orc_search_new.restype = C.c_void_p
         L.orc_search_new.argtypes = [C.POINTER(OrcOptions), C.c_int, C.POINTER(C.c_void_p),
                                      C.POINTER(C.c_int32)]
@@ -209,14 +212,20 @@ def default_options(megablast=True, db_length=0, db_num_seqs=0, **kw):
 
 
 class Search:
-    def __init__(self, opt, queries):
-        """queries: list of uint8 BLASTNA arrays (plus strand)."""
+    def __init__(self, opt, queries, masks=None):
+        """queries: list of uint8 BLASTNA arrays (plus strand); masks: [(query index, from, to)],
+        inclusive plus-strand intervals, sorted and non-overlapping per query (soft masking)."""
         self._L = lib()
         self._q = [np.ascontiguousarray(q, dtype=np.uint8) for q in queries]
         ptrs = (C.c_void_p * len(queries))(*[q.ctypes.data for q in self._q])
         lens = (C.c_int32 * len(queries))(*[len(q) for q in self._q])
         self.opt = opt
-        self._h = self._L.orc_search_new(C.byref(opt), len(queries), ptrs, lens)
+        masks = sorted(masks or [])
+        n = len(masks)
+        mq = (C.c_int32 * max(n, 1))(*[m[0] for m in masks])
+        mf = (C.c_int32 * max(n, 1))(*[m[1] for m in masks])
+        mt = (C.c_int32 * max(n, 1))(*[m[2] for m in masks])
+        self._h = self._L.orc_search_new_masked(C.byref(opt), len(queries), ptrs, lens, n, mq, mf, mt)
         if not self._h:
             raise RuntimeError("orc_search_new failed")
         self.stats = OrcStats()

@@ -34,8 +34,11 @@ typedef struct OrcLookup {
     int32_t longest_chain;
 } OrcLookup;
 
+typedef struct OrcSeg { int32_t left, right; } OrcSeg;     /* SSeqRange of a lookup segment */
 OrcLookup *orc_lookup_new(const OrcOptions *opt, const uint8_t *query /*past sentinel*/,
-                          int32_t nctx, const OrcContext *ctx);
+                          int32_t nseg, const OrcSeg *seg);
+/* lookup_callback of the three table kinds (CORE/na_ungapped.c:51-138): is q_pos in cell `index`? */
+int orc_lookup_has(const OrcLookup *l, int32_t index, int32_t q_pos);
 void orc_lookup_free(OrcLookup *l);
 
 struct OrcSearch {
@@ -52,6 +55,8 @@ struct OrcSearch {
     int32_t gap_x_dropoff, gap_x_dropoff_final;
     int32_t container;      /* ORC_DIAG_* */
     OrcLookup *lut;
+    OrcSeg *segs; int32_t nsegs;    /* lookup segments = complement of the query masks */
+    int masked;                     /* lut->masked_locations != NULL */
     /* per-subject outputs */
     OrcSeed *seeds; int32_t nseeds, cseeds;
     OrcInitHit *ihits; int32_t nihits, cihits;

@@ -90,18 +90,16 @@ static void na_add(void *arg, int32_t cell, int32_t q_off)
 }
 
 OrcLookup *orc_lookup_new(const OrcOptions *opt, const uint8_t *query,
-                          int32_t nctx, const OrcContext *ctx)
+                          int32_t nseg, const OrcSeg *seg)
 {
     OrcLookup *l = (OrcLookup *)calloc(1, sizeof(*l));
     int32_t entries = 0, max_off = 0, c, lut_width = 0, qlen = 0;
     BuildCtx b;
-    /* CORE/lookup_util.c:193-209 over one segment per valid context
-     * (CORE/blast_filter.c:1019-1119 with no masks) */
-    for (c = 0; c < nctx; c++) {
-        if (!ctx[c].is_valid) continue;
-        entries += ctx[c].query_length - 1;
-        max_off = ORC_MAX(max_off, ctx[c].query_offset + ctx[c].query_length - 1);
-        qlen = ctx[c].query_offset + ctx[c].query_length;
+    /* CORE/lookup_util.c:193-209 (EstimateNumTableEntries) over the lookup segments */
+    for (c = 0; c < nseg; c++) {
+        entries += seg[c].right - seg[c].left;
+        max_off = ORC_MAX(max_off, seg[c].right);
+        qlen = ORC_MAX(qlen, seg[c].right + 1);
     }
     l->type = choose_table(opt, entries, max_off, &lut_width);
     l->word_length = opt->word_size;
@@ -112,12 +110,8 @@ OrcLookup *orc_lookup_new(const OrcOptions *opt, const uint8_t *query,
     if (l->type == ORC_LUT_MB) {
         l->hashtable = (int32_t *)calloc((size_t)l->ncells, sizeof(int32_t));
         l->next_pos = (int32_t *)calloc((size_t)qlen + 2, sizeof(int32_t));
-        for (c = 0; c < nctx; c++) {
-            if (!ctx[c].is_valid) continue;
-            for_each_word(query, ctx[c].query_offset,
-                          ctx[c].query_offset + ctx[c].query_length - 1,
-                          l->word_length, lut_width, mb_add, &b);
-        }
+        for (c = 0; c < nseg; c++)
+            for_each_word(query, seg[c].left, seg[c].right, l->word_length, lut_width, mb_add, &b);
     } else {
         int32_t i, acc = 0, longest = 0, overflow_cells = 2;
         b.count = (int32_t *)calloc((size_t)l->ncells, sizeof(int32_t));
@@ -133,12 +127,8 @@ OrcLookup *orc_lookup_new(const OrcOptions *opt, const uint8_t *query,
                 l->cell_start[l->ncells] = acc;
                 l->cell_offs = (int32_t *)malloc(((size_t)acc + 1) * sizeof(int32_t));
             }
-            for (c = 0; c < nctx; c++) {
-                if (!ctx[c].is_valid) continue;
-                for_each_word(query, ctx[c].query_offset,
-                              ctx[c].query_offset + ctx[c].query_length - 1,
-                              l->word_length, lut_width, na_add, &b);
-            }
+            for (c = 0; c < nseg; c++)
+                for_each_word(query, seg[c].left, seg[c].right, l->word_length, lut_width, na_add, &b);
         }
         l->longest_chain = longest;
         /* CORE/blast_nalookup.c:234-238 + CORE/lookup_wrap.c:127-137: a small
@@ -148,6 +138,22 @@ OrcLookup *orc_lookup_new(const OrcOptions *opt, const uint8_t *query,
         free(b.count); free(b.fill);
     }
     return l;
+}
+
+int orc_lookup_has(const OrcLookup *l, int32_t index, int32_t q_pos)
+{
+    index &= l->ncells - 1;
+    if (l->type == ORC_LUT_MB) {            /* s_MBLookup :51-74 */
+        int32_t q_off = l->hashtable[index];
+        ++q_pos;
+        while (q_off) { if (q_off == q_pos) return 1; q_off = l->next_pos[q_off]; }
+        return 0;
+    } else {                                /* s_SmallNaLookup :82-104 / s_NaLookup :113-138 */
+        int32_t i;
+        for (i = l->cell_start[index]; i < l->cell_start[index + 1]; i++)
+            if (l->cell_offs[i] == q_pos) return 1;
+        return 0;
+    }
 }
 
 void orc_lookup_free(OrcLookup *l)

@@ -113,6 +113,63 @@ void orc_update_for_subject(OrcSearch *s, int32_t subject_length)
 OrcSearch *orc_search_new(const OrcOptions *opt, int nq,
                           const uint8_t *const *seqs, const int32_t *lens)
 {
+    return orc_search_new_masked(opt, nq, seqs, lens, 0, NULL, NULL, NULL);
+}
+
+/* CORE/blast_filter.c:1019-1119 (BLAST_ComplementMaskLocations): the unmasked stretches of every
+ * valid context in concatenated coordinates; masks are plus-strand coordinates, mirrored for the
+ * minus strand (:1061-1075).  Degenerate segments (left > right) are kept, as there. */
+static void lookup_segments(OrcSearch *s, int32_t nmask, const int32_t *mq, const int32_t *mfrom, const int32_t *mto)
+{
+    int c, cap = s->nctx + 2 * nmask + 2;
+    s->segs = (OrcSeg *)malloc((size_t)cap * sizeof(OrcSeg)); s->nsegs = 0;
+    for (c = 0; c < s->nctx; c++) {
+        const OrcContext *x = &s->ctx[c];
+        int32_t start_offset, end_offset, left = 0, right, k, k0 = -1, k1 = -1, first = 1, open = 1, step, kk;
+        if (!x->is_valid) continue;
+        start_offset = x->query_offset; end_offset = x->query_length + start_offset - 1;
+        for (k = 0; k < nmask; k++) if (mq[k] == x->query_index) { if (k0 < 0) k0 = k; k1 = k; }
+        if (k0 < 0) { s->segs[s->nsegs].left = start_offset; s->segs[s->nsegs++].right = end_offset; continue; }
+        /* minus strand: the list is reversed first (:1061-1063) */
+        step = (x->frame < 0) ? -1 : 1;
+        for (kk = (step > 0 ? k0 : k1); kk >= k0 && kk <= k1; kk += step) {
+            int32_t filter_start, filter_end;
+            if (x->frame < 0) { filter_start = end_offset - mto[kk]; filter_end = end_offset - mfrom[kk]; }
+            else { filter_start = start_offset + mfrom[kk]; filter_end = start_offset + mto[kk]; }
+            if (first) {
+                open = 1; first = 0;
+                if (filter_start > start_offset) left = start_offset;
+                else { left = filter_end + 1; continue; }
+            }
+            right = filter_start - 1;
+            s->segs[s->nsegs].left = left; s->segs[s->nsegs++].right = right;
+            if (filter_end >= end_offset) { open = 0; break; }
+            left = filter_end + 1;
+        }
+        if (open) { s->segs[s->nsegs].left = left; s->segs[s->nsegs++].right = end_offset; }
+    }
+}
+
+/* CORE/blast_nalookup.c:333-366 (s_SeqLocListInvert) != NULL, i.e. does any gap between the
+ * lookup segments span more than 3 positions */
+static int has_masked_locations(const OrcSearch *s)
+{
+    int32_t i, start = 0, stop;
+    if (s->nsegs == 0) return 0;
+    stop = ORC_MAX(0, s->segs[0].left - 1);
+    if (stop - start > 2) return 1;
+    for (i = 0; i < s->nsegs; i++) {
+        start = s->segs[i].right + 1;
+        stop = (i + 1 < s->nsegs) ? s->segs[i + 1].left - 1 : s->qlen - 1;
+        if (stop - start > 2) return 1;
+    }
+    return 0;
+}
+
+OrcSearch *orc_search_new_masked(const OrcOptions *opt, int nq,
+                                 const uint8_t *const *seqs, const int32_t *lens,
+                                 int32_t nmask, const int32_t *mq, const int32_t *mfrom, const int32_t *mto)
+{
     OrcSearch *s = (OrcSearch *)calloc(1, sizeof(*s));
     int i, c; int64_t total = 1; int32_t off;
     double stdp[16];
@@ -198,14 +255,17 @@ OrcSearch *orc_search_new(const OrcOptions *opt, int nq,
         s->diag_len = n; s->diag_mask = n - 1;
         s->diag_last_hit = (int32_t *)calloc((size_t)n, sizeof(int32_t));
     }
-    s->lut = orc_lookup_new(opt, s->query, s->nctx, s->ctx);
+    lookup_segments(s, nmask, mq, mfrom, mto);
+    s->lut = orc_lookup_new(opt, s->query, s->nsegs, s->segs);
+    /* lut->masked_locations (CORE/blast_nalookup.c:413-417, :582-586, :977-981), mask at hash on */
+    s->masked = s->lut->word_length > s->lut->lut_word_length && has_masked_locations(s);
     return s;
 }
 
 void orc_search_free(OrcSearch *s)
 {
     if (!s) return;
-    orc_lookup_free(s->lut);
+    orc_lookup_free(s->lut); free(s->segs);
     free(s->ctx); free(s->qbuf); free(s->seeds); free(s->ihits); free(s->hsps);
     free(s->diag_last_hit); free(s->diag_hash);
     free(s);

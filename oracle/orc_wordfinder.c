@@ -155,10 +155,46 @@ static void ungapped_approx(const OrcSearch *S, const uint8_t *subj, int32_t sle
     }
 }
 
+/* CORE/na_ungapped.c:459-471 (s_IsSeedMasked): the lookup word the SUBJECT carries at s_off, looked
+ * up in the table together with q_pos -- a masked (or ambiguous) query position is not in its cell */
+static int seed_masked(const OrcSearch *S, const uint8_t *subj, int32_t s_off, int32_t lut, int32_t q_pos)
+{
+    uint32_t index = 0; int32_t i;
+    for (i = 0; i < lut; i++) index = (index << 2) | (uint32_t)ORC_BASE(subj, s_off + i);
+    return !orc_lookup_has(S->lut, (int32_t)index, q_pos);
+}
+
+/* CORE/na_ungapped.c:488-587 (s_TypeOfWord) with check_double FALSE (one-hit mode): re-check of the
+ * mini-extended word against the query masks; may move the left end right and extend the right end */
+static int type_of_word(const OrcSearch *S, const uint8_t *subj, int32_t *q_off, int32_t *s_off,
+                        int32_t s_range, int32_t word_length, int32_t lut, int32_t *extended)
+{
+    int32_t context, q_range, ext_to, ext_max, s_pos, q_pos;
+    int32_t q_end = *q_off + word_length, s_end = *s_off + word_length;
+    *extended = 0;
+    if (word_length == lut) return 1;
+    context = orc_context_of(S, q_end);
+    q_range = S->ctx[context].query_offset + S->ctx[context].query_length;
+    if (S->masked) {
+        if (seed_masked(S, subj, s_end - lut, lut, q_end - lut)) return 0;
+        for (;; ++(*s_off), ++(*q_off))
+            if (!seed_masked(S, subj, *s_off, lut, *q_off)) break;
+    }
+    ext_to = word_length - (q_end - (*q_off));
+    ext_max = ORC_MIN(q_range - q_end, s_range - s_end);
+    if (ext_to || S->masked) {
+        if (ext_to > ext_max) return 0;
+        q_end += ext_to; s_end += ext_to;
+        for (s_pos = s_end - lut, q_pos = q_end - lut; s_pos > *s_off; s_pos -= lut, q_pos -= lut)
+            if (seed_masked(S, subj, s_pos, lut, q_pos)) return 0;
+        *extended = ext_to;
+    }
+    return 1;
+}
+
 /* one seed through the diagonal container and, if it survives, the ungapped
  * extension: CORE/na_ungapped.c:611-755 (array) / :778-922 (hash) in one-hit
- * mode (window_size 0).  With no mask-at-hash locations s_TypeOfWord
- * (:488-587) returns 1 with extended = 0. */
+ * mode (window_size 0). */
 static int diag_extend(OrcSearch *S, const uint8_t *subj, int32_t slen,
                        int32_t q_off, int32_t s_off, int32_t word_length)
 {
@@ -181,6 +217,11 @@ static int diag_extend(OrcSearch *S, const uint8_t *subj, int32_t slen,
     }
     if (s_off_pos < last_hit) return 0;
 
+    {   /* check the masks for the word (:696-704 / :868-876) */
+        int32_t extended = 0;
+        if (!type_of_word(S, subj, &q_off, &s_off, slen, word_length, S->lut->lut_word_length, &extended)) return 0;
+        s_end += extended; s_end_pos += extended;
+    }
     context = orc_context_of(S, q_off);
     c = &S->ctx[context];
     /* word_length < 11 in blastn goes straight to the exact extension on the

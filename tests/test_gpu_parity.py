@@ -325,3 +325,50 @@ def test_interrupt_callback_stops_between_ranges():
     rc = L.gbn_prelim_search(ps._b, src._h, ps._r, C.byref(ps.diagnostics), 0, C.cast(cb, C.c_void_p), None)
     assert rc != 0 and b"interrupt" in L.gbn_last_error() and len(calls) == 1
     assert len(ps.run()["hsps"]) >= 1                   # the engine is usable afterwards
+
+
+def random_masks(rng, queries, per_query=3, edge_cases=True):
+    """Soft masks like DUST produces them: a few intervals per query, some touching the ends,
+    some abutting, some shorter than a lookup word."""
+    masks = []
+    for qi, q in enumerate(queries):
+        n = len(q)
+        cuts = sorted(set(int(x) for x in rng.integers(0, n, 2 * per_query)))
+        iv = [(cuts[i], cuts[i + 1] - 1) for i in range(0, len(cuts) - 1, 2) if cuts[i + 1] - 1 >= cuts[i]]
+        if edge_cases and qi % 3 == 0 and iv:
+            iv[0] = (0, iv[0][1])                          # the query starts masked
+        if edge_cases and qi % 4 == 1 and iv:
+            iv[-1] = (iv[-1][0], n - 1)                    # ... or ends masked
+        if edge_cases and qi % 5 == 2 and len(iv) >= 2 and iv[0][1] + 1 < iv[1][0]:
+            iv[1] = (iv[0][1] + 1, iv[1][1])               # two abutting masks
+        masks += [(qi, a, b) for a, b in iv]
+    return masks
+
+
+@pytest.mark.parametrize("task,nq,kw", [
+    ("megablast", 1, {}),                                   # small table, lut 8, stride 21
+    ("megablast", 16, {}),                                  # megablast table lut 11
+    ("megablast", 160, {}),                                 # lut 12: partitioned scan
+    ("megablast", 16, dict(word_size=16)),
+    ("blastn", 4, {}),                                      # lut 8, word 11
+    ("blastn", 8, {}),                                      # lut 11 = word size: no re-check needed
+    ("blastn", 8, dict(word_size=15)),
+])
+def test_soft_query_masks(task, nq, kw):
+    rng = np.random.default_rng(nq * 31 + len(task))
+    db, queries, plants, subjects, opt = util.small_case(6, 100_000, nq, task=task, planted_fraction=1.0, **kw)
+    masks = random_masks(rng, queries)
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(queries, opt, src, masks=masks)
+    gpu = ps.run(keep_stages=True)
+    ora, s = util.oracle_run(opt, queries, subjects, masks=masks)
+    oi, gi = s.info(), ps.info()
+    assert (oi["lut_type"], oi["lut_width"], oi["scan_step"]) == (gi["lut_type"], gi["lut_width"], gi["scan_step"])
+    util.compare_stages(gpu, ora)
+    d = ps.diagnostics
+    assert (d.lookup_hits, d.good_init_extends, d.gapped_extensions, d.good_extensions) == \
+           (s.stats.lookup_hits, s.stats.good_init_extends, s.stats.gapped_extensions, s.stats.good_extensions)
+    # masking must matter in this case: fewer seeds than without masks, and still some HSPs
+    plain = api.BlastPrelimSearch(queries, opt, src).run(keep_stages=True)
+    assert len(gpu["seeds"]) < len(plain["seeds"])
+    assert len(gpu["hsps"]) >= 1

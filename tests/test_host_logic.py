@@ -89,3 +89,20 @@ def test_product_never_imports_oracle():
                 for pat in [r"^\s*import\s+oracle", r"^\s*from\s+oracle\b", r"import\s+orc\b",
                             r"#include\s*[\"<].*orc(_int)?\.h", r"liborc"]:
                     assert not re.search(pat, txt, flags=re.M), (f, pat)
+
+
+def test_masked_setup_matches_oracle_and_rejects_bad_masks():
+    rng = np.random.default_rng(3)
+    qs = [rng.integers(0, 4, 1000, dtype=np.uint8) for _ in range(12)]
+    # heavy masking moves the table-size estimate below a lookup-choice threshold
+    masks = [(i, 100, 899) for i in range(12)]
+    gopt = api.default_options("megablast", db_length=10**9, db_num_seqs=1000)
+    plain = api.BlastPrelimSearch(qs, gopt, upload=False).info()
+    b = api.BlastPrelimSearch(qs, gopt, upload=False, masks=masks).info()
+    o = orc.Search(util.oracle_options(gopt), qs, masks=masks).info()
+    for k in ["lut_type", "lut_width", "scan_step", "container"]:
+        assert b[k] == o[k], k
+    assert (plain["lut_type"], plain["lut_width"]) != (b["lut_type"], b["lut_width"])
+    for bad in ([(0, 10, 5)], [(0, 10, 2000)], [(12, 1, 2)], [(0, 10, 50), (0, 40, 60)], [(-1, 0, 1)]):
+        with pytest.raises(api.BlastError):
+            api.BlastPrelimSearch(qs, gopt, upload=False, masks=bad)

@@ -17,9 +17,9 @@ def oracle_options(gopt):
     return o
 
 
-def oracle_run(gopt, queries, subjects):
+def oracle_run(gopt, queries, subjects, masks=None):
     """subjects: list of (packed, length).  Returns per-oid dicts and the Search."""
-    s = orc.Search(oracle_options(gopt), queries)
+    s = orc.Search(oracle_options(gopt), queries, masks=masks)
     out = []
     for packed, n in subjects:
         out.append(s.subject(packed, n))
