@@ -60,7 +60,7 @@ IHIT_DT = np.dtype([("oid", "<i4"), ("q_off", "<i4"), ("s_off", "<i4"), ("q_star
 
 EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_default_options",
            "gbn_db_new", "gbn_db_free", "gbn_db_total_bases", "gbn_db_num_seqs", "gbn_synth_fill",
-           "gbn_batch_new", "gbn_batch_new_ex", "gbn_batch_new_masked", "gbn_batch_free", "gbn_batch_num_contexts", "gbn_batch_contexts",
+           "gbn_batch_new", "gbn_batch_new_ex", "gbn_batch_new_masked", "gbn_dust_mask", "gbn_batch_free", "gbn_batch_num_contexts", "gbn_batch_contexts",
            "gbn_batch_lut_type", "gbn_batch_lut_width", "gbn_batch_scan_step",
            "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff", "gbn_results_new",
            "gbn_results_free", "gbn_results_clear", "gbn_results_num_hsps", "gbn_results_hsps",
@@ -103,6 +103,8 @@ def lib():
         L.gbn_batch_new_masked.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GbnOptions), C.c_int32,
                                            C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32,
                                            C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int]
+        L.gbn_dust_mask.restype = C.c_int32
+        L.gbn_dust_mask.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
         L.gbn_batch_free.argtypes = [C.c_void_p]
         for nm in ["gbn_batch_num_contexts", "gbn_batch_lut_type", "gbn_batch_lut_width",
                    "gbn_batch_scan_step", "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff"]:
@@ -175,6 +177,19 @@ def layout_slab(lengths, front=16, align=16, tail=128):
         pos += (int(n) + 3) // 4
         pos = (pos + align - 1) // align * align
     return offs, pos + tail
+
+
+def dust_masks(queries, level=20, window=64, linker=1):
+    """blastn's default query filter: symmetric DUST intervals of every query, as the mask list
+    BlastPrelimSearch(masks=...) takes."""
+    out = []
+    for qi, q in enumerate(queries):
+        a = np.ascontiguousarray(q, dtype=np.uint8)
+        cap = len(a) // 2 + 4
+        f = np.zeros(cap, dtype=np.int32); t = np.zeros(cap, dtype=np.int32)
+        n = lib().gbn_dust_mask(a.ctypes.data, len(a), level, window, linker, f.ctypes.data, t.ctypes.data, cap)
+        out += [(qi, int(f[i]), int(t[i])) for i in range(n)]
+    return out
 
 
 class BlastSeqSrc:

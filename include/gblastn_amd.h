@@ -195,6 +195,13 @@ int  gbn_batch_new_masked(GbnBatch **out, const GbnOptions *opt, int32_t nq,
                           const uint8_t *const *seqs, const int32_t *lens,
                           int32_t nmask, const int32_t *mask_query, const int32_t *mask_from,
                           const int32_t *mask_to, int upload);
+/* Symmetric DUST low-complexity intervals of a BLASTNA sequence (CSymDustMasker,
+ * src/algo/dustmask/symdust.cpp:40-287, as blastn's default query filter uses it through
+ * Blast_FindDustFilterLoc, API/dust_filter.cpp:60-170: level 20, window 64, linker 1); intervals are
+ * inclusive, ascending and fused when overlapping or abutting.  Returns their number; at most cap are
+ * written.  Host only. */
+int32_t gbn_dust_mask(const uint8_t *seq, int32_t len, int32_t level, int32_t window, int32_t linker,
+                      int32_t *from, int32_t *to, int32_t cap);
 void gbn_batch_free(GbnBatch *b);
 int32_t gbn_batch_num_contexts(const GbnBatch *b);
 const GbnContext *gbn_batch_contexts(const GbnBatch *b);

@@ -181,4 +181,9 @@ int64_t orc_collector_close(OrcCollector *c);      /* number of surviving (query
 int32_t orc_collector_list(const OrcCollector *c, int64_t i, int32_t *oid, int32_t *query, const OrcHSP **h);
 void orc_collector_free(OrcCollector *c);
 
+/* ---- symmetric DUST (orc_dust.c): low-complexity intervals [from, to] of a BLASTNA sequence,
+ * merged as blastn merges them; returns their number (at most cap are written) ---- */
+int32_t orc_dust(const uint8_t *seq, int32_t len, int level, int window, int linker,
+                 int32_t *from, int32_t *to, int32_t cap);
+
 #endif

@@ -107,6 +107,8 @@ def lib():
         L.orc_hsplist_purge_common_endpoints.restype = C.c_int32
         L.orc_hsplist_purge_common_endpoints.argtypes = [C.POINTER(OrcHSP), C.c_int32]
         L.orc_hsplist_sort_by_score.argtypes = [C.POINTER(OrcHSP), C.c_int32]
+        L.orc_dust.restype = C.c_int32
+        L.orc_dust.argtypes = [C.c_void_p, C.c_int32, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int32]
         L.orc_prelim_hitlist_size.argtypes = [C.c_int, C.c_int]
         L.orc_collector_new.restype = C.c_void_p; L.orc_collector_new.argtypes = [C.c_int32, C.c_int32, C.c_int]
         L.orc_collector_write.argtypes = [C.c_void_p, C.c_int32, C.POINTER(OrcHSP), C.c_int32]
@@ -316,3 +318,12 @@ class Collector:
                 lib().orc_collector_free(self._c); self._c = None
         except Exception:
             pass
+
+
+def dust(seq, level=20, window=64, linker=1):
+    """Symmetric DUST intervals [(from, to)] of a BLASTNA sequence (orc_dust.c)."""
+    a = np.ascontiguousarray(seq, dtype=np.uint8)
+    cap = len(a) // 2 + 4
+    f = np.zeros(cap, dtype=np.int32); t = np.zeros(cap, dtype=np.int32)
+    n = lib().orc_dust(a.ctypes.data, len(a), level, window, linker, f.ctypes.data, t.ctypes.data, cap)
+    return [(int(f[i]), int(t[i])) for i in range(n)]

@@ -372,3 +372,40 @@ def test_soft_query_masks(task, nq, kw):
     plain = api.BlastPrelimSearch(queries, opt, src).run(keep_stages=True)
     assert len(gpu["seeds"]) < len(plain["seeds"])
     assert len(gpu["hsps"]) >= 1
+
+
+@pytest.mark.parametrize("task", ["megablast", "blastn"])
+def test_default_dust_filtering_end_to_end(task):
+    """blastn's default: DUST the queries, mask at hash.  Queries and subjects share low-complexity
+    stretches (poly-A, CA repeats) that would seed everywhere without the filter."""
+    from oracle import orc
+    rng = np.random.default_rng(11)
+    rep = [np.zeros(60, dtype=np.uint8), np.tile(np.array([1, 0], dtype=np.uint8), 40),
+           np.tile(np.array([2, 3, 3], dtype=np.uint8), 25)]
+    subs = []
+    for i in range(5):
+        s = rng.integers(0, 4, 60_000, dtype=np.uint8)
+        for k in range(12):
+            p = int(rng.integers(0, len(s) - 200)); r = rep[k % 3]; s[p:p + len(r)] = r
+        subs.append(s)
+    queries = []
+    for i in range(6):
+        src = subs[i % 5]; a = int(rng.integers(1000, 50_000))
+        q = src[a:a + 900].copy()
+        for k in range(2):
+            p = int(rng.integers(50, 800)); r = rep[(i + k) % 3]; q[p:p + len(r)] = r[:len(q) - p]
+        q[rng.integers(0, 900, 15)] = rng.integers(0, 4, 15)
+        queries.append(q)
+    subjects = [(orc.pack_ncbi2na(s), len(s)) for s in subs]
+    opt = api.default_options(task, db_length=sum(len(s) for s in subs), db_num_seqs=len(subs))
+    masks = api.dust_masks(queries)
+    assert len(masks) >= 6
+    srcdb = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(queries, opt, srcdb, masks=masks)
+    gpu = ps.run(keep_stages=True)
+    omasks = [(qi, a, b) for qi, q in enumerate(queries) for a, b in orc.dust(q)]
+    assert omasks == masks
+    ora, s = util.oracle_run(opt, queries, subjects, masks=omasks)
+    util.compare_stages(gpu, ora)
+    unfiltered = api.BlastPrelimSearch(queries, opt, srcdb).run(keep_stages=True)
+    assert len(gpu["seeds"]) < len(unfiltered["seeds"]) and len(gpu["hsps"]) >= 6
