@@ -70,6 +70,7 @@ struct Engine {
     std::future<int> pending; bool has_pending = false; std::string pending_err; const GbnResults *pending_res = nullptr;
     unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
+    uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;             // per-run stream cursors (6-byte records)
     GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
     uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;   // [nb][nwriters] + overflow flag
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -376,10 +377,17 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
             subcap = (subcap + 511) & ~(size_t)511;       // whole record blocks, whole probe pieces
             if (subcap > 0x7ffffff0u) { set_error("bin capacity overflow: split the range"); return GBN_ERR_NOMEM; }
             size_t need = subcap * nstream;
-            if (need > E.bin_rec_cap) {
-                dev_free(E.bin_rec); E.bin_rec_cap = 0;
-                if ((rc = dev_alloc(E.bin_rec, need))) return rc;
-                E.bin_rec_cap = need;
+            const size_t need_u64 = (GBN_REC_WORDS(need) + 1) / 2;
+            if (need_u64 > E.bin_rec_cap) {
+                dev_free(E.bin_rec); E.bin_rec_cap = 0; g_binkey.valid = false;
+                if ((rc = dev_alloc(E.bin_rec, need_u64))) return rc;
+                E.bin_rec_cap = need_u64;
+            }
+            const size_t nseq = (size_t)((ts.ntiles + nwriters - 1) / nwriters);
+            if (nstream * nseq > E.bin_tcur_cap) {
+                dev_free(E.bin_tcur); E.bin_tcur_cap = 0; g_binkey.valid = false;
+                if ((rc = dev_alloc(E.bin_tcur, nstream * nseq))) return rc;
+                E.bin_tcur_cap = nstream * nseq;
             }
             if (nstream + 4 > E.bin_count_cap) {
                 dev_free(E.bin_count); E.bin_count_cap = 0;
@@ -390,7 +398,7 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
             B.S = P; B.nb = nb; B.cbits = 15; B.nwriters = nwriters; dbg_nwriters = nwriters; dbg_subcap = (uint32_t)subcap;
             B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfrbits = std::min(7, 2 * b.dev->fr);
-            B.rec = reinterpret_cast<uint32_t *>(E.bin_rec); B.gcount = E.bin_count; B.subcap = (uint32_t)subcap;
+            B.rec = reinterpret_cast<uint32_t *>(E.bin_rec); B.tcur = E.bin_tcur; B.nseq = (uint32_t)nseq; B.gcount = E.bin_count; B.subcap = (uint32_t)subcap;
             B.overflow = E.bin_count + nstream;
             if (const char *e = getenv("GBN_DBG")) B.dbg = atoi(e);
             int grid2 = std::max(8, E.num_cu & ~7);   // one 1024-thread workgroup per CU; group = blockIdx & 7
@@ -741,7 +749,7 @@ void Blast_gpu_Release(void) {
     g_binkey.valid = false;
     dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
     dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.sort_tmp); for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
-    dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
+    dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_tcur); E.bin_tcur_cap = 0; dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
     E.bin_rec_cap = 0; E.bin_count_cap = 0;
     E.seed_cap = E.key_cap = 0;
     if (E.ev0) (void)hipEventDestroy(E.ev0);

@@ -57,12 +57,23 @@ struct GbnScanParams {
 #define GBN_BIN_SIDE     4096       // LDS side-list capacity (u16 fingerprints) per bin
 
 struct GbnU2 { uint32_t x, y; };
-// word offset of record j (j = stream * subcap + index) inside GbnBinParams::rec
-#ifndef GBN_REC_BLOCK_BITS
-#define GBN_REC_BLOCK_BITS 5
+// Scan records.  GBN_REC_BYTES 6 (default): blocks of 64 records = 256 bytes of `hi` words followed by
+// 128 bytes of 16-bit position indices inside the tile; the tile itself is not stored -- the few records
+// that reach the rare path find it in the cursor table (GbnBinParams::tcur).  GBN_REC_BYTES 8 (the
+// earlier layout, kept for A/B builds): blocks of 32 records = 128 bytes of hi + 128 bytes of 32-bit
+// position ids.  GBN_REC_HI(j) = 32-bit word offset of record j's hi word (j = linear record index).
+#ifndef GBN_REC_BYTES
+#define GBN_REC_BYTES 6
 #endif
-#define GBN_REC_HI(j)  ((((size_t)(j)) >> GBN_REC_BLOCK_BITS << (GBN_REC_BLOCK_BITS + 1)) + (((size_t)(j)) & ((1u << GBN_REC_BLOCK_BITS) - 1)))
-#define GBN_REC_POS(j) (GBN_REC_HI(j) + (1u << GBN_REC_BLOCK_BITS))
+#if GBN_REC_BYTES == 6
+#define GBN_REC_HI(j)    ((((size_t)(j)) >> 6) * 96 + (((size_t)(j)) & 63))
+#define GBN_REC_IDX16(j) (((((size_t)(j)) >> 6) * 96 + 64) * 2 + (((size_t)(j)) & 63))    /* 16-bit offset */
+#define GBN_REC_WORDS(n) ((size_t)(n) / 64 * 96)                                          /* n: multiple of 64 */
+#else
+#define GBN_REC_HI(j)    ((((size_t)(j)) >> 5) * 64 + (((size_t)(j)) & 31))
+#define GBN_REC_POS(j)   (GBN_REC_HI(j) + 32)
+#define GBN_REC_WORDS(n) ((size_t)(n) * 2)
+#endif
 struct GbnBinParams {
     GbnScanParams S;                // tiles here are GBN_BIN_TILE_POS-sized
     int nb, cbits;                  // number of bins; cell = bin << cbits | low
@@ -81,6 +92,9 @@ struct GbnBinParams {
     //   hi:    bit 31 = pad, [29:15] cell inside the bin, [14:0] fp15 of the subject position
     //   posid: tile << GBN_BIN_TILE_BITS | index
     uint32_t *rec;
+    // 6-byte records: stream cursor of (bin, writer) at the start of its seq-th tile,
+    // [nb][nwriters][nseq]; tile of a record = writer + seq * nwriters for the last seq whose cursor <= index
+    uint32_t *tcur; uint32_t nseq;
     uint32_t *gcount;               // [nb][nwriters] records written (multiple of 4, pads included)
     uint32_t subcap;
     uint32_t *overflow;             // set to 1 if any stream did not fit

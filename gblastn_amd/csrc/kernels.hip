@@ -1057,8 +1057,10 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
             const uint2 i4 = *reinterpret_cast<const uint2 *>(&s_idx[4 * g]);
             uint4 h4 = *reinterpret_cast<const uint4 *>(&s_hi[4 * g]);
             const uint32_t l0 = i4.x & 0xffffu, l1 = i4.x >> 16, l2 = i4.y & 0xffffu, l3 = i4.y >> 16;
+#if GBN_REC_BYTES != 6
             uint4 p4;
             p4.x = tbase | l0; p4.y = tbase | l1; p4.z = tbase | l2; p4.w = tbase | l3;
+#endif
             if (l0 == 0xffffu) h4.x = 0x80000000u;                  // pads: flagged in the high word
             if (l1 == 0xffffu) h4.y = 0x80000000u;
             if (l2 == 0xffffu) h4.z = 0x80000000u;
@@ -1066,7 +1068,11 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
             if (w + 4u <= B.subcap && !(B.dbg & 2)) {
                 const size_t at = GBN_RECIDX(B, b, blockIdx.x, w);
                 *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = h4;
+#if GBN_REC_BYTES == 6
+                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(B.rec) + GBN_REC_IDX16(at)) = i4;     // pads carry 0xffff
+#else
                 *reinterpret_cast<uint4 *>(B.rec + GBN_REC_POS(at)) = p4;
+#endif
             }
         }
     };
@@ -1076,8 +1082,8 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
     //       compute of different waves overlap here, and the stores keep draining during [1] and [2];
     //   [1] offset scan;   [2] pads, stream bookkeeping, scatter of t into the staging arrays;
     //   then keys of t+1 out of the prefetched bytes (first touch: everything in flight is older).
-    uint32_t prev_total = 0, prev_tbase = 0;
-    for (; tile <= last; tile += stride) {
+    uint32_t prev_total = 0, prev_tbase = 0, seq = 0;
+    for (; tile <= last; tile += stride, ++seq) {
         uint32_t rank[PER];
         #pragma unroll
         for (int k = 0; k < PER; k++) {
@@ -1127,6 +1133,9 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
             for (uint32_t j = o0 + n; j < o1; j++) s_idx[j] = 0xffffu;
             for (uint32_t g = o0 >> 2; g < (o1 >> 2); g++) s_gmeta[g] = ((uint32_t)b << 23) | (wc + GBN_BIN_GBIAS - o0);
             if (o1 > o0 && wc + (o1 - o0) > B.subcap) atomicExch(B.overflow, 1u);
+#if GBN_REC_BYTES == 6
+            B.tcur[((size_t)b * B.nwriters + blockIdx.x) * B.nseq + seq] = wc;
+#endif
             s_wcur[b] = wc + (o1 - o0);
             s_hist[b] = 0;                                      // for the next tile; ordered by (C) and (A)
         }
@@ -1260,8 +1269,12 @@ probe_bin_kernel(GbnBinParams B)
             base = __shfl(base, 0);
             if (keep) {
                 const uint32_t at = base + (uint32_t)__popcll(m & lt);
+#if GBN_REC_BYTES == 6
+                const uint32_t pid = at_rec;                        // resolved to a position id by the rare kernel
+#else
                 const uint32_t wr = at_rec / B.subcap;              // writer of the record's stream
                 const uint32_t pid = B.rec[GBN_REC_POS(GBN_RECIDX(B, bin, wr, at_rec - wr * B.subcap))];
+#endif
                 if (at < B.rare_seg) { myq[at].x = pid; myq[at].y = cv; }
             }
         }
@@ -1373,7 +1386,26 @@ probe_rare_kernel(GbnBinParams B, int nseg)
     const uint32_t n = min(B.rare_counts[seg], B.rare_seg);
     const GbnU2 *qs = B.rareq + (size_t)seg * B.rare_seg;
     for (uint32_t i = (uint32_t)part * 256u + threadIdx.x; i < n; i += (uint32_t)nparts * 256u) {
-        const uint32_t pid = qs[i].x, cv = qs[i].y;
+        uint32_t pid = qs[i].x; const uint32_t cv = qs[i].y;
+#if GBN_REC_BYTES == 6
+        {   // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
+            const uint32_t bin = (cv & 0x7fffffffu) >> B.cbits;
+            const uint32_t wr = pid / B.subcap, j = pid - wr * B.subcap;
+            const uint32_t *__restrict__ cur = B.tcur + ((size_t)bin * B.nwriters + wr) * B.nseq;
+            const uint32_t nt = (uint32_t)((P.ntiles - wr + B.nwriters - 1) / B.nwriters);     // tiles of this writer
+            uint32_t lo = 0, hi = nt;
+            {   // the cursors grow almost linearly: look around the interpolated run first
+                const uint32_t total = B.gcount[(size_t)bin * B.nwriters + wr];
+                const uint32_t g = (uint32_t)(((unsigned long long)j * nt) / (total ? total : 1u));
+                const uint32_t a = g > 12u ? g - 12u : 0u, z = min(nt, g + 12u);
+                const uint32_t ca = cur[a], cz = (z < nt) ? cur[z] : 0xffffffffu;
+                if (ca <= j && cz > j) { lo = a; hi = z; }
+            }
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] <= j) lo = mid; else hi = mid; }
+            const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, j))];
+            pid = ((wr + lo * (uint32_t)B.nwriters) << GBN_BIN_TILE_BITS) | idx;
+        }
+#endif
         probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
     }
     if (P.raw_hits) {
