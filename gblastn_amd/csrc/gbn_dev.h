@@ -45,8 +45,11 @@ struct GbnScanParams {
 #define GBN_SORT_THREADS 1024       // binning kernel workgroup: one per CU with 16384-position tiles.  Measured
 #endif                              // alternative: 512 (two per CU, 8192-position tiles): 15-50 % slower (128-byte runs)
 #define GBN_BIN_WG_PER_CU (1024 / GBN_SORT_THREADS)
+#ifndef GBN_BIN_CARRY
+#define GBN_BIN_CARRY 1         // line-exact binning kernel (carry in LDS, 8192-position tiles); 0: padded runs, 16384
+#endif
 #ifndef GBN_BIN_TILE_BITS
-#define GBN_BIN_TILE_BITS (GBN_SORT_THREADS == 512 ? 13 : 14)     // 16 scan positions per thread
+#define GBN_BIN_TILE_BITS ((GBN_SORT_THREADS == 512 || GBN_BIN_CARRY) ? 13 : 14)
 #endif
 #define GBN_BIN_TILE_POS (1 << GBN_BIN_TILE_BITS)   // scan positions per tile (posid = tile << GBN_BIN_TILE_BITS | i)
 #define GBN_BIN_GROUPS   8          // probe workgroups with equal (blockIdx & 7) share a bin (and an XCD)

@@ -1171,11 +1171,246 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
         B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(s_wcur[b], B.subcap);
 }
 
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel(GbnBinParams B) { scan_bin_body<0>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s17(GbnBinParams B) { scan_bin_body<17>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { scan_bin_body<18>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s1(GbnBinParams B) { scan_bin_body<1>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s2(GbnBinParams B) { scan_bin_body<2>(B); }
+#if GBN_BIN_CARRY
+// ---------------------------------------------------------------------------------------------------
+// Binning kernel, line-exact variant.  Measured on MI355X: the same bytes cost 3-4x more when a stream's
+// 128-byte lines are written in pieces by consecutive tiles (partial-line writes) than when every store
+// completes whole, aligned lines.  So each workgroup keeps, per bin, the < 32 records that do not fill a
+// line yet in LDS (the "carry") and only ever stores complete 32-record lines of `hi` words (128 bytes,
+// aligned) with their 64 bytes of indices; no pad records exist except in the last line of a stream.
+// 8192-position tiles (48 KB of bin-sorted staging) + 96 KB of carry.  Four barriers per tile:
+//   [0] histogram atomics of tile t, requests for the bytes of t+1 / descriptor of t+2
+//   [1] scans: staging offsets of the bins, number of complete lines per bin, line -> bin table
+//   [2] scatter of t into the staging arrays (and where each record that stays behind will sit)
+//   [3] stores of the complete lines (carry first, then staging), keys of t+1
+//   [4] the records that stay behind move into the carry (from registers), cursors advance
+template <int STEP>
+__device__ __forceinline__ void scan_bin_carry_body(const GbnBinParams &B)
+{
+    const GbnScanParams &P = B.S;
+    constexpr int TILE = GBN_BIN_TILE_POS, PER = TILE / GBN_SORT_THREADS, LINE = 32;
+    static_assert(PER == 8 && GBN_SORT_THREADS == 1024, "carry variant: 8192-position tiles, 1024 threads");
+    __shared__ __attribute__((aligned(16))) uint32_t s_hi[TILE];            // tile records, bin-sorted
+    __shared__ __attribute__((aligned(16))) uint16_t s_idx[TILE];
+    __shared__ __attribute__((aligned(16))) uint32_t c_hi[GBN_BIN_MAXNB * LINE];     // carry, LINE slots per bin
+    __shared__ __attribute__((aligned(16))) uint16_t c_idx[GBN_BIN_MAXNB * LINE];
+    __shared__ uint32_t s_hist[GBN_BIN_MAXNB], s_off[GBN_BIN_MAXNB + 1], s_loff[GBN_BIN_MAXNB + 1];
+    __shared__ uint32_t s_pk[GBN_BIN_MAXNB];        // per bin: staging offset | (complete-line records - carry count + 32) << 16
+    __shared__ uint32_t s_wpos[GBN_BIN_MAXNB];                              // records stored so far (multiple of LINE)
+    __shared__ uint16_t s_cc[GBN_BIN_MAXNB];                                // records in the carry (< LINE)
+    __shared__ uint16_t s_lbin[TILE / LINE + GBN_BIN_MAXNB];                // complete line of this tile -> bin
+    const int tid = threadIdx.x;
+    const uint32_t mask = (uint32_t)(P.ncells - 1);
+    const int nb = B.nb, cbits = B.cbits;
+    const uint32_t lowmask = (1u << cbits) - 1;
+    const int cshift = 56 - 2 * P.lut, rshift = 49 - 2 * P.lut;
+    const uint32_t ustep = (uint32_t)P.step;
+    const int64_t stride = gridDim.x, last = P.ntiles - 1;
+    const uint32_t wid = blockIdx.x;
+
+    // a lane owns PER consecutive positions = 16 * STEP bits of subject: a whole number of dwords for
+    // even strides, half a dword extra for odd lanes of odd strides (the raw dwords are then shifted by
+    // 16 bits first, after which every window is cut out with compile-time shifts as before)
+    constexpr int NDW = STEP > 0 ? ((2 * STEP * (PER - 1) - 8 + 38) >> 5) + 4 : 2 * PER;
+    struct Raw { uint32_t d[NDW]; };
+    auto idx_of = [&](int k) -> uint32_t { return STEP > 0 ? (uint32_t)(tid * PER + k) : (uint32_t)(tid + k * GBN_SORT_THREADS); };
+    auto upos_of = [&](const GbnTile &t, int k) -> uint32_t {
+        const uint32_t i = min(idx_of(k), (uint32_t)t.npos - 1u);
+        return (uint32_t)t.first_pos + i * ustep + 60u;
+    };
+    auto lane_half = [&](const GbnTile &t) -> uint32_t {    // lane's first base, in units of 8 bases (16 bits), from the tile start
+        return min((uint32_t)tid, ((uint32_t)t.npos - 1u) / PER) * (uint32_t)STEP;
+    };
+    auto fetch = [&](const GbnTile &t, Raw &r) {
+        if constexpr (STEP > 0) {
+            const uint8_t *p = P.db + ((size_t)(uint32_t)t.off16 << 4) + 4 * ((size_t)((uint32_t)t.first_pos >> 4) + (size_t)(lane_half(t) >> 1)) - 4;
+            #pragma unroll
+            for (int i = 0; i + 4 <= NDW; i += 4) __builtin_memcpy(&r.d[i], p + 4 * i, 16);
+            if constexpr (NDW % 4 == 3) { __builtin_memcpy(&r.d[NDW - 3], p + 4 * (NDW - 3), 12); }
+            else if constexpr (NDW % 4 == 2) { __builtin_memcpy(&r.d[NDW - 2], p + 4 * (NDW - 2), 8); }
+            else if constexpr (NDW % 4 == 1) { __builtin_memcpy(&r.d[NDW - 1], p + 4 * (NDW - 1), 4); }
+        } else {
+            #pragma unroll
+            for (int k = 0; k < PER; k++)
+                __builtin_memcpy(&r.d[2 * k], P.db + ((size_t)(uint32_t)t.off16 << 4) - 16 + (upos_of(t, k) >> 2), 8);
+        }
+    };
+    auto keys_all = [&](const GbnTile &t, const Raw &r, uint32_t (&bin)[PER], uint32_t (&hi)[PER]) {
+        uint32_t x[NDW];
+        if constexpr (STEP > 0) {
+            #pragma unroll
+            for (int i = 0; i < NDW; i++) x[i] = bswap32(r.d[i]);
+            if ((STEP & 1) && (lane_half(t) & 1u)) {
+                #pragma unroll
+                for (int i = 0; i + 1 < NDW; i++) x[i] = (x[i] << 16) | (x[i + 1] >> 16);
+            }
+        }
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            uint64_t w;
+            if constexpr (STEP > 0) {
+                const int bit = 2 * STEP * k - 8 + 32, a = bit >> 5, o = bit & 31;
+                const uint32_t x2 = x[a + 2 < NDW ? a + 2 : NDW - 1];
+                const uint32_t hi32 = o ? ((x[a] << o) | (x[a + 1] >> (32 - o))) : x[a];
+                const uint32_t lo32 = o ? ((x[a + 1] << o) | (x2 >> (32 - o))) : x[a + 1];
+                w = ((uint64_t)hi32 << 32) | lo32;
+            } else {
+                uint64_t raw; __builtin_memcpy(&raw, &r.d[2 * k], 8);
+                w = __builtin_bswap64(raw) << (2 * (upos_of(t, k) & 3));
+            }
+            const uint32_t c = (uint32_t)(w >> cshift) & mask;
+            bin[k] = c >> cbits;
+            hi[k] = ((c & lowmask) << 15) | (((uint32_t)(w >> rshift) & 0x7fu) << 8) | (uint32_t)(w >> 56);
+        }
+    };
+    auto uniform = [](GbnTile t) -> GbnTile {
+        t.subj = __builtin_amdgcn_readfirstlane(t.subj); t.first_pos = __builtin_amdgcn_readfirstlane(t.first_pos);
+        t.npos = __builtin_amdgcn_readfirstlane(t.npos); t.off16 = __builtin_amdgcn_readfirstlane(t.off16);
+        return t;
+    };
+    // one complete line of a bin: 8 lanes store 16 bytes of hi words each, the first 4 also 16 bytes of
+    // indices; record s of the bin's pending sequence = carry[s] for s < cc, else staging[off + s - cc]
+    auto store_line_part = [&](uint32_t b, uint32_t l, uint32_t p, uint32_t cc, uint32_t off, uint32_t wpos, uint32_t nvalid) {
+        auto rec_hi = [&](uint32_t s) -> uint32_t {
+            return s >= nvalid ? 0x80000000u : (s < cc ? c_hi[b * LINE + s] : s_hi[off + s - cc]); };
+        auto rec_ix = [&](uint32_t s) -> uint32_t {
+            return s >= nvalid ? 0xffffu : (uint32_t)(s < cc ? c_idx[b * LINE + s] : s_idx[off + s - cc]); };
+        const uint32_t s0 = l * LINE + p * 4;
+        const size_t at = GBN_RECIDX(B, b, wid, wpos + s0);
+        if (wpos + l * LINE + LINE > B.subcap || (B.dbg & 2)) return;
+        uint4 h4; h4.x = rec_hi(s0); h4.y = rec_hi(s0 + 1); h4.z = rec_hi(s0 + 2); h4.w = rec_hi(s0 + 3);
+        *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = h4;
+        if (p < 4) {
+            const uint32_t s1 = l * LINE + p * 8;
+            uint4 i4;
+            i4.x = rec_ix(s1) | (rec_ix(s1 + 1) << 16); i4.y = rec_ix(s1 + 2) | (rec_ix(s1 + 3) << 16);
+            i4.z = rec_ix(s1 + 4) | (rec_ix(s1 + 5) << 16); i4.w = rec_ix(s1 + 6) | (rec_ix(s1 + 7) << 16);
+            *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(B.rec) + GBN_REC_IDX16(GBN_RECIDX(B, b, wid, wpos + s1))) = i4;
+        }
+    };
+
+    for (int b = tid; b < nb; b += GBN_SORT_THREADS) { s_hist[b] = 0; s_wpos[b] = 0; s_cc[b] = 0; }
+    int64_t tile = blockIdx.x;
+    if (tile > last) {
+        for (int b = tid; b < nb; b += GBN_SORT_THREADS) B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0;
+        return;
+    }
+    GbnTile T = uniform(P.tiles[tile]);
+    GbnTile T1 = uniform(P.tiles[min(tile + stride, last)]);
+    uint32_t bin[PER], hi[PER];
+    {
+        Raw r0; fetch(T, r0);
+        keys_all(T, r0, bin, hi);
+    }
+    __syncthreads();
+
+    uint32_t seq = 0;
+    for (; tile <= last; tile += stride, ++seq) {
+        uint32_t rank[PER];
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            rank[k] = 0;
+            if (idx_of(k) < (uint32_t)T.npos) rank[k] = atomicAdd(&s_hist[bin[k]], 1u);
+        }
+        Raw R;
+        if constexpr (STEP > 0) fetch(T1, R);
+        GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
+        __syncthreads();                                        // (A) histogram complete
+        // exclusive scans over the bins by wave 0 (each lane nb/64 consecutive bins), both sums in one
+        // word: records of the tile (staging offsets, < 2^14) and complete lines (store work list, < 2^10)
+        if (tid < 64) {
+            constexpr int MAXQ = GBN_BIN_MAXNB / 64;
+            const int per = (nb + 63) >> 6;
+            uint32_t v[MAXQ], sum = 0;
+            #pragma unroll
+            for (int i = 0; i < MAXQ; i++) {
+                const int b = tid * per + i;
+                const bool ok = i < per && b < nb;
+                const uint32_t n = ok ? s_hist[b] : 0u, cc = ok ? (uint32_t)s_cc[b] : 0u;
+                v[i] = n | (((cc + n) / LINE) << 16);
+                sum += v[i];
+            }
+            uint32_t x = sum;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (tid >= o) x += y; }
+            uint32_t run = x - sum;
+            #pragma unroll
+            for (int i = 0; i < MAXQ; i++) {
+                const int b = tid * per + i;
+                if (i < per && b < nb) {
+                    const uint32_t nl = v[i] >> 16;
+                    s_off[b] = run & 0xffffu; s_loff[b] = run >> 16;
+                    s_pk[b] = (run & 0xffffu) | ((nl * LINE - (uint32_t)s_cc[b] + 32u) << 16);
+                }
+                run += v[i];
+            }
+            if (tid == 63) { s_off[nb] = x & 0xffffu; s_loff[nb] = x >> 16; }
+        }
+        __syncthreads();                                        // (B) offsets and line list known
+        const uint32_t nlines = s_loff[nb];
+        for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
+            const uint32_t cc = s_cc[b], wp = s_wpos[b], l0 = s_loff[b], nl = s_loff[b + 1] - l0;
+            B.tcur[((size_t)b * B.nwriters + wid) * B.nseq + seq] = wp + cc;    // stream index of this tile's first record
+            if (wp + nl * LINE > B.subcap) atomicExch(B.overflow, 1u);
+            for (uint32_t l = 0; l < nl; l++) s_lbin[l0 + l] = (uint16_t)b;     // read after (C)
+        }
+        int32_t stay[PER];                                      // carry slot of a record that stays behind, else -1
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            stay[k] = -1;
+            if (idx_of(k) < (uint32_t)T.npos) {
+                const uint32_t b = bin[k], pk = s_pk[b], slot = (pk & 0xffffu) + rank[k];
+                s_hi[slot] = hi[k];
+                s_idx[slot] = (uint16_t)idx_of(k);
+                const int32_t behind = (int32_t)rank[k] + 32 - (int32_t)(pk >> 16);     // rank + cc - complete-line records
+                if (behind >= 0) stay[k] = (int32_t)(b * LINE) + behind;
+            }
+        }
+        __syncthreads();                                        // (C) tile is bin-sorted in LDS
+        for (int b = tid; b < nb; b += GBN_SORT_THREADS) s_hist[b] = 0;     // for the next tile; ordered by (D)
+        uint32_t keep_hi[PER];                                  // of the records that stay behind: the keys are replaced below
+        #pragma unroll
+        for (int k = 0; k < PER; k++) keep_hi[k] = hi[k];
+        for (uint32_t i = tid; i < nlines * 8u; i += GBN_SORT_THREADS) {
+            const uint32_t L = i >> 3, p = i & 7u, b = s_lbin[L];
+            store_line_part(b, L - s_loff[b], p, s_cc[b], s_off[b], s_wpos[b], 0xffffffffu);
+        }
+        T = T1; T1 = uniform(T2);
+        if constexpr (STEP == 0) fetch(T, R);
+        keys_all(T, R, bin, hi);
+        __syncthreads();                                        // (D) lines stored, carry and staging free
+        #pragma unroll
+        for (int k = 0; k < PER; k++)
+            if (stay[k] >= 0) { c_hi[stay[k]] = keep_hi[k]; c_idx[stay[k]] = (uint16_t)idx_of(k); }
+        for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
+            const uint32_t nl = s_loff[b + 1] - s_loff[b], n = s_off[b + 1] - s_off[b];
+            s_wpos[b] += nl * LINE;
+            s_cc[b] = (uint16_t)(((uint32_t)s_cc[b] + n) & (LINE - 1));
+        }
+    }
+    __syncthreads();
+    // the last, incomplete line of every stream: padded with flagged records
+    for (uint32_t i = tid; i < (uint32_t)nb * 8u; i += GBN_SORT_THREADS) {
+        const uint32_t b = i >> 3, p = i & 7u, cc = s_cc[b];
+        if (cc) store_line_part(b, 0, p, cc, 0, s_wpos[b], cc);
+    }
+    for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
+        const uint32_t total = s_wpos[b] + (s_cc[b] ? LINE : 0u);
+        if (total > B.subcap) atomicExch(B.overflow, 1u);
+        B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(total, B.subcap);
+    }
+}
+#endif  // GBN_BIN_CARRY
+
+#if GBN_BIN_CARRY
+#define GBN_BIN_BODY scan_bin_carry_body
+#else
+#define GBN_BIN_BODY scan_bin_body
+#endif
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel(GbnBinParams B) { GBN_BIN_BODY<0>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s17(GbnBinParams B) { GBN_BIN_BODY<17>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { GBN_BIN_BODY<18>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s1(GbnBinParams B) { GBN_BIN_BODY<1>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s2(GbnBinParams B) { GBN_BIN_BODY<2>(B); }
 
 namespace {
 // rare path of the probe kernel: full fingerprints, chain walk, exact verification
