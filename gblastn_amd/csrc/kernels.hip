@@ -1195,6 +1195,7 @@ __device__ __forceinline__ void scan_bin_carry_body(const GbnBinParams &B)
     __shared__ __attribute__((aligned(16))) uint32_t c_hi[GBN_BIN_MAXNB * LINE];     // carry, LINE slots per bin
     __shared__ __attribute__((aligned(16))) uint16_t c_idx[GBN_BIN_MAXNB * LINE];
     __shared__ uint32_t s_hist[GBN_BIN_MAXNB], s_off[GBN_BIN_MAXNB + 1], s_loff[GBN_BIN_MAXNB + 1];
+    __shared__ uint32_t s_wtot[GBN_BIN_MAXNB / 64];
     __shared__ uint32_t s_pk[GBN_BIN_MAXNB];        // per bin: staging offset | (complete-line records - carry count + 32) << 16
     __shared__ uint32_t s_wpos[GBN_BIN_MAXNB];                              // records stored so far (multiple of LINE)
     __shared__ uint16_t s_cc[GBN_BIN_MAXNB];                                // records in the carry (< LINE)
@@ -1316,43 +1317,33 @@ __device__ __forceinline__ void scan_bin_carry_body(const GbnBinParams &B)
         if constexpr (STEP > 0) fetch(T1, R);
         GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
         __syncthreads();                                        // (A) histogram complete
-        // exclusive scans over the bins by wave 0 (each lane nb/64 consecutive bins), both sums in one
-        // word: records of the tile (staging offsets, < 2^14) and complete lines (store work list, < 2^10)
-        if (tid < 64) {
-            constexpr int MAXQ = GBN_BIN_MAXNB / 64;
-            const int per = (nb + 63) >> 6;
-            uint32_t v[MAXQ], sum = 0;
-            #pragma unroll
-            for (int i = 0; i < MAXQ; i++) {
-                const int b = tid * per + i;
-                const bool ok = i < per && b < nb;
-                const uint32_t n = ok ? s_hist[b] : 0u, cc = ok ? (uint32_t)s_cc[b] : 0u;
-                v[i] = n | (((cc + n) / LINE) << 16);
-                sum += v[i];
-            }
-            uint32_t x = sum;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (tid >= o) x += y; }
-            uint32_t run = x - sum;
-            #pragma unroll
-            for (int i = 0; i < MAXQ; i++) {
-                const int b = tid * per + i;
-                if (i < per && b < nb) {
-                    const uint32_t nl = v[i] >> 16;
-                    s_off[b] = run & 0xffffu; s_loff[b] = run >> 16;
-                    s_pk[b] = (run & 0xffffu) | ((nl * LINE - (uint32_t)s_cc[b] + 32u) << 16);
-                }
-                run += v[i];
-            }
-            if (tid == 63) { s_off[nb] = x & 0xffffu; s_loff[nb] = x >> 16; }
+        // exclusive scans over the bins, both sums in one word: records of the tile (staging offsets,
+        // < 2^14) and complete lines (store work list, < 2^10).  One bin per thread: scan inside each
+        // wave, wave totals through LDS.
+        uint32_t v = 0, incl = 0;
+        if (tid < nb) {
+            const uint32_t n = s_hist[tid], cc = s_cc[tid];
+            v = n | (((cc + n) / LINE) << 16);
+        }
+        if (tid < GBN_BIN_MAXNB) {
+            incl = v;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((tid & 63) >= o) incl += y; }
+            if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+        }
+        __syncthreads();                                        // (B0) wave totals
+        if (tid < nb) {
+            uint32_t run = incl - v;
+            for (int w = 0; w < (tid >> 6); w++) run += s_wtot[w];
+            const uint32_t nl = v >> 16, l0 = run >> 16, cc = s_cc[tid], wp = s_wpos[tid];
+            s_off[tid] = run & 0xffffu; s_loff[tid] = l0;
+            s_pk[tid] = (run & 0xffffu) | ((nl * LINE - cc + 32u) << 16);
+            if (tid == nb - 1) { s_off[nb] = (run + v) & 0xffffu; s_loff[nb] = (run + v) >> 16; }
+            B.tcur[((size_t)tid * B.nwriters + wid) * B.nseq + seq] = wp + cc;     // stream index of this tile's first record
+            if (wp + nl * LINE > B.subcap) atomicExch(B.overflow, 1u);
+            for (uint32_t l = 0; l < nl; l++) s_lbin[l0 + l] = (uint16_t)tid;        // read after (C)
         }
         __syncthreads();                                        // (B) offsets and line list known
         const uint32_t nlines = s_loff[nb];
-        for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
-            const uint32_t cc = s_cc[b], wp = s_wpos[b], l0 = s_loff[b], nl = s_loff[b + 1] - l0;
-            B.tcur[((size_t)b * B.nwriters + wid) * B.nseq + seq] = wp + cc;    // stream index of this tile's first record
-            if (wp + nl * LINE > B.subcap) atomicExch(B.overflow, 1u);
-            for (uint32_t l = 0; l < nl; l++) s_lbin[l0 + l] = (uint16_t)b;     // read after (C)
-        }
         int32_t stay[PER];                                      // carry slot of a record that stays behind, else -1
         #pragma unroll
         for (int k = 0; k < PER; k++) {
