@@ -340,10 +340,32 @@ static int choose_bins(const GbnBatch &b) {
 
 // one scan of the subjects [s0, s1): fills E.seeds / cnt[0] seeds, cnt[1] raw hits;
 // dispatches to the direct-probe kernel (small tables) or the partitioned pair
+static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
+                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed);
+
+// The partitioned scan sizes its streams for lookup words spread evenly over the bins (x1.25, x2.5).
+// Subjects dominated by one repeat (satellite arrays, poly-A) put most positions of a range into a
+// few bins; such a range goes through the direct-probe kernel instead, which has no streams.
+static const int kSkewedRange = -1000;       // internal: split this subject range and try again
+
 static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
                     unsigned long long cnt[2], int64_t *bases_out)
 {
-    const int nb = choose_bins(b);
+    bool skewed = false;
+    int rc = run_scan_impl(b, db, s0, s1, diag, cnt, bases_out, false, &skewed);
+    if (rc != GBN_OK || !skewed) return rc;
+    int64_t bases = 0;
+    for (int32_t s = s0; s < s1; s++) bases += db.len[s];
+    int64_t split_mb = 256;
+    if (const char *e = getenv("GBN_SKEW_SPLIT_MB")) split_mb = std::max(1, atoi(e));       // tests
+    if (s1 - s0 > 1 && bases > (split_mb << 20)) return kSkewedRange;         // the caller halves the range
+    return run_scan_impl(b, db, s0, s1, diag, cnt, bases_out, true, &skewed);
+}
+
+static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
+                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed)
+{
+    const int nb = direct ? 1 : choose_bins(b);
     const TileSet *tsp = nullptr;
     int rc = get_tiles(db, b.lut.lut, b.lut.step, nb > 1 ? GBN_BIN_TILE_POS : GBN_TILE_POS, s0, s1, &tsp);
     if (rc) return rc;
@@ -468,7 +490,11 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
                 continue;
             }
         }
-        if (overflow) { /* the kept records are incomplete */ slack *= 2; if (slack > 64) { set_error("bin overflow"); return GBN_ERR_NOMEM; } continue; }
+        if (overflow) {     // the records are incomplete: once more with twice the room, then give the range to the direct kernel
+            slack *= 2;
+            if (slack > 3.0) { *skewed = true; return GBN_OK; }
+            continue;
+        }
         if (cnt[0] <= E.seed_cap) break;
         if ((rc = grow_seed_buffers((size_t)cnt[0] + (cnt[0] >> 3)))) return rc;
     }
@@ -494,6 +520,18 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_stage = now();
     int rc = run_scan(b, db, s0, s1, diag, cnt, &bases);
+    if (rc == kSkewedRange) {
+        // lookup words of this range pile up in a few bins: halve it (by packed size) until the repeat-rich
+        // subjects sit in small ranges of their own, which the direct-probe kernel scans
+        int64_t half = 0, acc = 0;
+        for (int32_t s = s0; s < s1; s++) half += db.len[s];
+        half /= 2;
+        int32_t mid = s0;
+        while (mid < s1 - 1 && acc + db.len[mid] <= half) acc += db.len[mid++];
+        if (mid == s0) mid = s0 + 1;
+        if ((rc = search_range(b, db, s0, mid, res, diag, keep_stages, overlap))) return rc;
+        return search_range(b, db, mid, s1, res, diag, keep_stages, overlap);
+    }
     if (rc) return rc;
     if (diag) diag->scan_stage_ms += ms_since(t_stage);
     t_stage = now();
@@ -937,7 +975,9 @@ int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag)
     unsigned long long cnt[2] = {0, 0};
     for (int r = 0; r < repeats; r++) {
         int64_t bases = 0;
-        if ((rc = run_scan(*batch, *db, 0, db->num_seqs, diag, cnt, &bases))) return rc;
+        rc = run_scan(*batch, *db, 0, db->num_seqs, diag, cnt, &bases);
+        if (rc == kSkewedRange) { set_error("gbn_scan_only: lookup words pile up in a few bins of this shard (use gbn_prelim_search, which splits the range)"); return GBN_ERR_UNSUPPORTED; }
+        if (rc) return rc;
         if (diag) diag->subject_bases_scanned += bases;
     }
     if (diag) {

@@ -409,3 +409,54 @@ def test_default_dust_filtering_end_to_end(task):
     util.compare_stages(gpu, ora)
     unfiltered = api.BlastPrelimSearch(queries, opt, srcdb).run(keep_stages=True)
     assert len(gpu["seeds"]) < len(unfiltered["seeds"]) and len(gpu["hsps"]) >= 6
+
+
+@pytest.mark.parametrize("split_mb", ["256", "1"])
+def test_skewed_subjects_fill_few_bins(split_mb, monkeypatch):
+    """Real genomes have megabase satellite arrays: whole tiles of scan positions fall into one or two
+    bins of the partitioned scan (hundreds of complete lines of one bin per tile, empty runs for all
+    other bins over many consecutive tiles).  Subjects: long poly-A / short-period repeats with
+    unique islands that the queries hit; 200 queries -> lut 12, 512 bins.  The engine notices that the
+    streams of a few bins overflow, halves the subject range until the repeat-rich subjects are in
+    small ranges (threshold GBN_SKEW_SPLIT_MB) and scans those with the direct-probe kernel; two random
+    subjects in the shard stay on the partitioned path."""
+    from oracle import orc
+    monkeypatch.setenv("GBN_SKEW_SPLIT_MB", split_mb)
+    rng = np.random.default_rng(77)
+    subs, islands = [], []
+    for i in range(4):
+        parts, pos = [], 0
+        for k in range(10):
+            kind = (i + k) % 3
+            n = int(rng.integers(150_000, 400_000))
+            if kind == 0:
+                parts.append(np.zeros(n, dtype=np.uint8))                                   # poly-A: one lookup word only
+            elif kind == 1:
+                parts.append(np.tile(rng.integers(0, 4, int(rng.integers(2, 40)), dtype=np.uint8), n // 2 + 40)[:n])   # tandem repeat
+            else:
+                parts.append(rng.integers(0, 4, n // 8, dtype=np.uint8))                    # unique island
+                islands.append((i, pos, len(parts[-1])))
+            pos += len(parts[-1])
+        subs.append(np.concatenate(parts))
+    subs.insert(0, rng.integers(0, 4, 2_000_000, dtype=np.uint8))          # two ordinary subjects around them
+    subs.append(rng.integers(0, 4, 2_000_000, dtype=np.uint8))
+    islands = [(i + 1, p, n) for i, p, n in islands] + [(0, 0, 2_000_000), (5, 0, 2_000_000)]
+    queries = []
+    for qi in range(200):
+        if qi % 2 == 0:                                       # a mutated piece of a unique island
+            si, p0, ln = islands[qi % len(islands)]
+            a = p0 + int(rng.integers(0, ln - 1000))
+            q = subs[si][a:a + 1000].copy()
+            q[rng.integers(0, 1000, 20)] = rng.integers(0, 4, 20)
+        else:
+            q = rng.integers(0, 4, 1000, dtype=np.uint8)
+        queries.append(q)
+    subjects = [(orc.pack_ncbi2na(s), len(s)) for s in subs]
+    opt = api.default_options("megablast", db_length=sum(len(s) for s in subs), db_num_seqs=len(subs))
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    assert ps.info()["lut_width"] == 12
+    gpu = ps.run(keep_stages=True)
+    ora, s = util.oracle_run(opt, queries, subjects)
+    util.compare_stages(gpu, ora)
+    assert ps.diagnostics.lookup_hits == s.stats.lookup_hits and len(gpu["hsps"]) >= 50
