@@ -42,6 +42,7 @@ def parse():
     ap.add_argument("--batch-queries", type=int, default=None)
     ap.add_argument("--cpu-seconds", type=float, default=15.0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the CPU baseline (0: half of the host cores, at most 64)")
     ap.add_argument("--no-overlap", action="store_true", help="run every pass to completion before the next starts")
     ap.add_argument("--reuse-binning", action="store_true",
                     help="NOT the headline metric: keep the query-independent scan records of the shard in HBM and "
@@ -225,24 +226,48 @@ def main():
         dist.destroy_process_group()
 
 
-def cpu_baseline(args, batch_queries, gopt, layout):
-    """The oracle (a scalar C port of the reference algorithm) on this box's host cores,
-    one thread, same batch, a bounded sample of the same shard's subjects."""
+def _cpu_worker(job):
+    """One host core: the oracle over subjects w, w + cores, ... of the rank-0 shard for ~seconds."""
+    w, cores, seconds, queries, optd, nsub, slen, seed, first_oid = job
     from oracle import orc
     from tests import util
-    s = orc.Search(util.oracle_options(gopt), batch_queries)
-    done, t = 0, 0.0
-    i = 0
-    while t < args.cpu_seconds and i < layout.num:
+    from gblastn_amd import api, synth
+    gopt = api.default_options("megablast")
+    for k, v in optd.items():
+        setattr(gopt, k, v)
+    layout = synth.SynthDb(nsub, slen, seed=seed, first_oid=first_oid)
+    s = orc.Search(util.oracle_options(gopt), queries)
+    done, t, i = 0, 0.0, w
+    while t < seconds and i < layout.num:
         packed = layout.subject_packed(i)
         t0 = time.perf_counter()
         s.subject(packed, layout.length)
         t += time.perf_counter() - t0
         done += layout.length
-        i += 1
-    return {"value": done / t / 1e9 if t > 0 else 0.0, "unit": "Gbp/s", "cores": 1, "kind": "port",
-            "sample": "first %d subjects (%.0f Mbp) of the rank-0 shard, one 5 Mb query batch, %.1f s"
-                      % (i, done / 1e6, t)}
+        i += cores
+    return done, t
+
+
+def cpu_baseline(args, batch_queries, gopt, layout):
+    """The oracle (a scalar C port of the reference algorithm) on this box's host cores: the same
+    query batch, a bounded sample of the same shard's subjects, one process per core (the reference
+    shares OID chunks among threads the same way, x_LaunchMultiThreadedSearch)."""
+    import multiprocessing as mp
+    from gblastn_amd import api
+    cores = args.cpu_cores if args.cpu_cores > 0 else max(1, min(64, (os.cpu_count() or 1) // 2))
+    optd = {f: getattr(gopt, f) for f, _ in api.GbnOptions._fields_}
+    jobs = [(w, cores, args.cpu_seconds, batch_queries, optd, layout.num, layout.length, layout.seed, layout.first_oid)
+            for w in range(cores)]
+    ctx = mp.get_context("spawn")                       # no HIP state in the children
+    with ctx.Pool(cores) as pool:
+        res = pool.map(_cpu_worker, jobs)
+    done = sum(r[0] for r in res)
+    t = max(r[1] for r in res)
+    single = max(r[0] / r[1] for r in res if r[1] > 0) / 1e9
+    return {"value": done / t / 1e9 if t > 0 else 0.0, "unit": "Gbp/s", "cores": cores, "kind": "port",
+            "single_core_value": single,
+            "sample": "%d subjects (%.0f Mbp) of the rank-0 shard spread over %d processes, one 5 Mb query batch, %.1f s each"
+                      % (done // layout.length, done / 1e6, cores, t)}
 
 
 if __name__ == "__main__":
