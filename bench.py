@@ -178,7 +178,7 @@ def main():
             traffic = None
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_seconds > 0:
         cpu = cpu_baseline(args, queries[:args.batch_queries], opt, mine)
 
     if rank == 0:
