@@ -113,6 +113,11 @@ struct GbnKeyParams {
     int q_descending, container_hash, diag_len;
 };
 
+// seeds per launch below which the diagonal kernel runs thread-per-seed instead of on compacted run heads
+#ifndef GBN_DIAG_COMPACT_MIN
+#define GBN_DIAG_COMPACT_MIN (1 << 20)
+#endif
+
 struct GbnExtParams {
     const uint8_t *db; const int64_t *byte_off; const int32_t *len;
     const GbnDevSeed *seeds; const uint32_t *idx; const uint64_t *key_group; int64_t n;
