@@ -1202,7 +1202,7 @@ template <int STEP>
 __device__ __forceinline__ void scan_bin_carry_body(const GbnBinParams &B)
 {
     const GbnScanParams &P = B.S;
-    constexpr int TILE = GBN_BIN_TILE_POS, PER = TILE / GBN_SORT_THREADS, LINE = 32;
+    constexpr int TILE = GBN_BIN_TILE_POS, PER = TILE / GBN_SORT_THREADS, LINE = GBN_CARRY_LINE, LP = LINE / 4;    // LP lanes store one line
     static_assert(PER == 8 && GBN_SORT_THREADS == 1024, "carry variant: 8192-position tiles, 1024 threads");
     __shared__ __attribute__((aligned(16))) uint32_t s_hi[TILE];            // tile records, bin-sorted
     __shared__ __attribute__((aligned(16))) uint16_t s_idx[TILE];
@@ -1295,7 +1295,7 @@ __device__ __forceinline__ void scan_bin_carry_body(const GbnBinParams &B)
         if (wpos + l * LINE + LINE > B.subcap || (B.dbg & 2)) return;
         uint4 h4; h4.x = rec_hi(s0); h4.y = rec_hi(s0 + 1); h4.z = rec_hi(s0 + 2); h4.w = rec_hi(s0 + 3);
         *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = h4;
-        if (p < 4) {
+        if (p < LP / 2) {
             const uint32_t s1 = l * LINE + p * 8;
             uint4 i4;
             i4.x = rec_ix(s1) | (rec_ix(s1 + 1) << 16); i4.y = rec_ix(s1 + 2) | (rec_ix(s1 + 3) << 16);
@@ -1375,14 +1375,24 @@ __device__ __forceinline__ void scan_bin_carry_body(const GbnBinParams &B)
         uint32_t keep_hi[PER];                                  // of the records that stay behind: the keys are replaced below
         #pragma unroll
         for (int k = 0; k < PER; k++) keep_hi[k] = hi[k];
-        for (uint32_t i = tid; i < nlines * 8u; i += GBN_SORT_THREADS) {
-            const uint32_t L = i >> 3, p = i & 7u, b = s_lbin[L];
-            store_line_part(b, L - s_loff[b], p, s_cc[b], s_off[b], s_wpos[b], 0xffffffffu);
-        }
+        // keys of t+1 BEFORE the stores: whatever waits for the loads of t+1 (vmcnt counts loads and
+        // stores alike) must not sit behind this tile's stores, or every wave idles for the full
+        // write latency once per tile
+#if !GBN_KEYS_AFTER_STORES
         T = T1; T1 = uniform(T2);
         if constexpr (STEP == 0) fetch(T, R);
         keys_all(T, R, bin, hi);
-        __syncthreads();                                        // (D) lines stored, carry and staging free
+#endif
+        for (uint32_t i = tid; i < nlines * (uint32_t)LP; i += GBN_SORT_THREADS) {
+            const uint32_t L = i / LP, p = i % LP, b = s_lbin[L];
+            store_line_part(b, L - s_loff[b], p, s_cc[b], s_off[b], s_wpos[b], 0xffffffffu);
+        }
+#if GBN_KEYS_AFTER_STORES
+        T = T1; T1 = uniform(T2);
+        if constexpr (STEP == 0) fetch(T, R);
+        keys_all(T, R, bin, hi);
+#endif
+        __syncthreads();                                        // (D) lines issued, carry and staging free
         #pragma unroll
         for (int k = 0; k < PER; k++)
             if (stay[k] >= 0) { c_hi[stay[k]] = keep_hi[k]; c_idx[stay[k]] = (uint16_t)idx_of(k); }
@@ -1394,8 +1404,8 @@ __device__ __forceinline__ void scan_bin_carry_body(const GbnBinParams &B)
     }
     __syncthreads();
     // the last, incomplete line of every stream: padded with flagged records
-    for (uint32_t i = tid; i < (uint32_t)nb * 8u; i += GBN_SORT_THREADS) {
-        const uint32_t b = i >> 3, p = i & 7u, cc = s_cc[b];
+    for (uint32_t i = tid; i < (uint32_t)nb * LP; i += GBN_SORT_THREADS) {
+        const uint32_t b = i / LP, p = i % LP, cc = s_cc[b];
         if (cc) store_line_part(b, 0, p, cc, 0, s_wpos[b], cc);
     }
     for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
@@ -1406,7 +1416,225 @@ __device__ __forceinline__ void scan_bin_carry_body(const GbnBinParams &B)
 }
 #endif  // GBN_BIN_CARRY
 
-#if GBN_BIN_CARRY
+#if GBN_BIN_CARRY == 2
+// ---------------------------------------------------------------------------------------------------
+// Binning kernel, line-exact variant 2 (default).  Same output as the carry variant above, with the store
+// phase reduced from ~500 to ~40 instructions per lane: records sit in LDS as 8-byte {hi, index} pairs,
+// and every bin owns one "open line" of 16 records that the scatter fills first, so that each complete
+// 16-record line (64 bytes of hi words + 32 of indices: measured as cheap as 128 + 64) is 16 consecutive
+// LDS records -- the bin's open line, or a run of the staging area -- read with 4 ds_read_b64 per lane
+// and written with one 16-byte and one 8-byte store.  64 KB staging + 64 KB open lines.
+template <int STEP>
+__device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
+{
+    const GbnScanParams &P = B.S;
+    constexpr int TILE = GBN_BIN_TILE_POS, PER = TILE / GBN_SORT_THREADS, LINE = 16, LP = LINE / 4;    // LP lanes store one line
+    static_assert(PER == 8 && GBN_SORT_THREADS == 1024, "line variant: 8192-position tiles, 1024 threads");
+    // records in LDS are 8 bytes: .x = hi word, .y = index in the tile.  [0, TILE): staging, bin-sorted;
+    // [TILE, TILE + bins * LINE): one line under construction per bin
+    __shared__ __attribute__((aligned(16))) uint2 s_all[TILE + GBN_BIN_MAXNB * LINE];
+    __shared__ uint32_t s_hist[GBN_BIN_MAXNB], s_off[GBN_BIN_MAXNB + 1], s_loff[GBN_BIN_MAXNB + 1];
+    __shared__ uint32_t s_wtot[GBN_BIN_MAXNB / 64];
+    __shared__ uint32_t s_pk[GBN_BIN_MAXNB];        // per bin: staging offset | records in the open line << 14 | complete lines << 19
+    __shared__ uint32_t s_wpos[GBN_BIN_MAXNB];                              // records stored so far (multiple of LINE)
+    __shared__ uint16_t s_cc[GBN_BIN_MAXNB];                                // records in the open line (< LINE)
+    __shared__ uint16_t s_lbin[TILE / LINE + GBN_BIN_MAXNB];                // complete line of this tile -> bin
+    const int tid = threadIdx.x;
+    const uint32_t mask = (uint32_t)(P.ncells - 1);
+    const int nb = B.nb, cbits = B.cbits;
+    const uint32_t lowmask = (1u << cbits) - 1;
+    const int cshift = 56 - 2 * P.lut, rshift = 49 - 2 * P.lut;
+    const uint32_t ustep = (uint32_t)P.step;
+    const int64_t stride = gridDim.x, last = P.ntiles - 1;
+    const uint32_t wid = blockIdx.x;
+
+    // a lane owns PER consecutive positions = 16 * STEP bits of subject: a whole number of dwords for
+    // even strides, half a dword extra for odd lanes of odd strides (the raw dwords are then shifted by
+    // 16 bits first, after which every window is cut out with compile-time shifts as before)
+    constexpr int NDW = STEP > 0 ? ((2 * STEP * (PER - 1) - 8 + 38) >> 5) + 4 : 2 * PER;
+    struct Raw { uint32_t d[NDW]; };
+    auto idx_of = [&](int k) -> uint32_t { return STEP > 0 ? (uint32_t)(tid * PER + k) : (uint32_t)(tid + k * GBN_SORT_THREADS); };
+    auto upos_of = [&](const GbnTile &t, int k) -> uint32_t {
+        const uint32_t i = min(idx_of(k), (uint32_t)t.npos - 1u);
+        return (uint32_t)t.first_pos + i * ustep + 60u;
+    };
+    auto lane_half = [&](const GbnTile &t) -> uint32_t {    // lane's first base, in units of 8 bases (16 bits), from the tile start
+        return min((uint32_t)tid, ((uint32_t)t.npos - 1u) / PER) * (uint32_t)STEP;
+    };
+    auto fetch = [&](const GbnTile &t, Raw &r) {
+        if constexpr (STEP > 0) {
+            const uint8_t *p = P.db + ((size_t)(uint32_t)t.off16 << 4) + 4 * ((size_t)((uint32_t)t.first_pos >> 4) + (size_t)(lane_half(t) >> 1)) - 4;
+            #pragma unroll
+            for (int i = 0; i + 4 <= NDW; i += 4) __builtin_memcpy(&r.d[i], p + 4 * i, 16);
+            if constexpr (NDW % 4 == 3) { __builtin_memcpy(&r.d[NDW - 3], p + 4 * (NDW - 3), 12); }
+            else if constexpr (NDW % 4 == 2) { __builtin_memcpy(&r.d[NDW - 2], p + 4 * (NDW - 2), 8); }
+            else if constexpr (NDW % 4 == 1) { __builtin_memcpy(&r.d[NDW - 1], p + 4 * (NDW - 1), 4); }
+        } else {
+            #pragma unroll
+            for (int k = 0; k < PER; k++)
+                __builtin_memcpy(&r.d[2 * k], P.db + ((size_t)(uint32_t)t.off16 << 4) - 16 + (upos_of(t, k) >> 2), 8);
+        }
+    };
+    auto keys_all = [&](const GbnTile &t, const Raw &r, uint32_t (&bin)[PER], uint32_t (&hi)[PER]) {
+        uint32_t x[NDW];
+        if constexpr (STEP > 0) {
+            #pragma unroll
+            for (int i = 0; i < NDW; i++) x[i] = bswap32(r.d[i]);
+            if ((STEP & 1) && (lane_half(t) & 1u)) {
+                #pragma unroll
+                for (int i = 0; i + 1 < NDW; i++) x[i] = (x[i] << 16) | (x[i + 1] >> 16);
+            }
+        }
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            uint64_t w;
+            if constexpr (STEP > 0) {
+                const int bit = 2 * STEP * k - 8 + 32, a = bit >> 5, o = bit & 31;
+                const uint32_t x2 = x[a + 2 < NDW ? a + 2 : NDW - 1];
+                const uint32_t hi32 = o ? ((x[a] << o) | (x[a + 1] >> (32 - o))) : x[a];
+                const uint32_t lo32 = o ? ((x[a + 1] << o) | (x2 >> (32 - o))) : x[a + 1];
+                w = ((uint64_t)hi32 << 32) | lo32;
+            } else {
+                uint64_t raw; __builtin_memcpy(&raw, &r.d[2 * k], 8);
+                w = __builtin_bswap64(raw) << (2 * (upos_of(t, k) & 3));
+            }
+            const uint32_t c = (uint32_t)(w >> cshift) & mask;
+            bin[k] = c >> cbits;
+            hi[k] = ((c & lowmask) << 15) | (((uint32_t)(w >> rshift) & 0x7fu) << 8) | (uint32_t)(w >> 56);
+        }
+    };
+    auto uniform = [](GbnTile t) -> GbnTile {
+        t.subj = __builtin_amdgcn_readfirstlane(t.subj); t.first_pos = __builtin_amdgcn_readfirstlane(t.first_pos);
+        t.npos = __builtin_amdgcn_readfirstlane(t.npos); t.off16 = __builtin_amdgcn_readfirstlane(t.off16);
+        return t;
+    };
+    // LP lanes store one line: 16 bytes of hi words and 8 bytes of indices each, from 4 consecutive LDS records
+    auto store_quarter = [&](uint32_t b, uint32_t at_rec, uint32_t src) {
+        const uint2 r0 = s_all[src], r1 = s_all[src + 1], r2 = s_all[src + 2], r3 = s_all[src + 3];
+        const size_t at = GBN_RECIDX(B, b, wid, at_rec);
+        *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = make_uint4(r0.x, r1.x, r2.x, r3.x);
+        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(B.rec) + GBN_REC_IDX16(at)) =
+            make_uint2(r0.y | (r1.y << 16), r2.y | (r3.y << 16));
+    };
+
+    for (int b = tid; b < nb; b += GBN_SORT_THREADS) { s_hist[b] = 0; s_wpos[b] = 0; s_cc[b] = 0; }
+    int64_t tile = blockIdx.x;
+    if (tile > last) {
+        for (int b = tid; b < nb; b += GBN_SORT_THREADS) B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0;
+        return;
+    }
+    GbnTile T = uniform(P.tiles[tile]);
+    GbnTile T1 = uniform(P.tiles[min(tile + stride, last)]);
+    uint32_t bin[PER], hi[PER];
+    {
+        Raw r0; fetch(T, r0);
+        keys_all(T, r0, bin, hi);
+    }
+    __syncthreads();
+
+    uint32_t seq = 0;
+    for (; tile <= last; tile += stride, ++seq) {
+        uint32_t rank[PER];
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            rank[k] = 0;
+            if (idx_of(k) < (uint32_t)T.npos) rank[k] = atomicAdd(&s_hist[bin[k]], 1u);
+        }
+        Raw R;
+        if constexpr (STEP > 0) fetch(T1, R);
+        GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
+        __syncthreads();                                        // (A) histogram complete
+        // exclusive scans over the bins, both sums in one word: records that go to the staging area
+        // (all but the ones that fill the bin's open line; < 2^14) and complete lines (< 2^10)
+        uint32_t v = 0, incl = 0, my_nl = 0, my_cc = 0;
+        if (tid < nb) {
+            const uint32_t tot = (uint32_t)s_cc[tid] + s_hist[tid];
+            my_nl = tot / LINE; my_cc = tot & (LINE - 1);
+            v = (tot > LINE ? tot - LINE : 0u) | (my_nl << 16);
+        }
+        if (tid < GBN_BIN_MAXNB) {
+            incl = v;
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((tid & 63) >= o) incl += y; }
+            if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
+        }
+        __syncthreads();                                        // (B0) wave totals
+        if (tid < nb) {
+            uint32_t run = incl - v;
+            for (int w = 0; w < (tid >> 6); w++) run += s_wtot[w];
+            const uint32_t l0 = run >> 16, cc = s_cc[tid], wp = s_wpos[tid];
+            s_off[tid] = run & 0xffffu; s_loff[tid] = l0;
+            s_pk[tid] = (run & 0xffffu) | (cc << 14) | (my_nl << 19);
+            if (tid == nb - 1) s_loff[nb] = (run + v) >> 16;
+            B.tcur[((size_t)tid * B.nwriters + wid) * B.nseq + seq] = wp + cc;     // stream index of this tile's first record
+            if (wp + my_nl * LINE > B.subcap) atomicExch(B.overflow, 1u);
+            for (uint32_t l = 0; l < my_nl; l++) s_lbin[l0 + l] = (uint16_t)tid;     // read after (C)
+        }
+        __syncthreads();                                        // (B) offsets and line list known
+        const uint32_t nlines = s_loff[nb];
+        int32_t stay[PER];                                      // slot (in s_all) of a record past the bin's last complete line, else -1
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            stay[k] = -1;
+            if (idx_of(k) < (uint32_t)T.npos) {
+                const uint32_t b = bin[k], pk = s_pk[b];
+                const uint32_t pos = ((pk >> 14) & 31u) + rank[k], full = (pk >> 19) * LINE;
+                // the bin's open line first, then the staging area; what lies past the last complete line
+                // waits in registers until the open line has been stored
+                const uint32_t slot = pos < (uint32_t)LINE ? TILE + b * LINE + pos : (pk & 0x3fffu) + pos - LINE;
+                if (full && pos >= full) stay[k] = (int32_t)(TILE + b * LINE + pos - full);
+                else s_all[slot] = make_uint2(hi[k], idx_of(k));
+            }
+        }
+        __syncthreads();                                        // (C) open lines and staging filled
+        for (int b = tid; b < nb; b += GBN_SORT_THREADS) s_hist[b] = 0;     // for the next tile; ordered by (D)
+        uint32_t keep_hi[PER];                                  // of the records that stay behind: the keys are replaced below
+        #pragma unroll
+        for (int k = 0; k < PER; k++) keep_hi[k] = hi[k];
+#if !GBN_KEYS_AFTER_STORES
+        T = T1; T1 = uniform(T2);
+        if constexpr (STEP == 0) fetch(T, R);
+        keys_all(T, R, bin, hi);
+#endif
+        if (!(B.dbg & 2))
+        for (uint32_t i = tid; i < nlines * (uint32_t)LP; i += GBN_SORT_THREADS) {
+            const uint32_t L = i / LP, p = i % LP, b = s_lbin[L], l = L - s_loff[b], wpos = s_wpos[b] + l * LINE;
+            if (wpos + LINE > B.subcap) continue;
+            store_quarter(b, wpos + p * 4, (l == 0 ? TILE + b * LINE : s_off[b] + (l - 1) * LINE) + p * 4);
+        }
+#if GBN_KEYS_AFTER_STORES
+        T = T1; T1 = uniform(T2);
+        if constexpr (STEP == 0) fetch(T, R);
+        keys_all(T, R, bin, hi);
+#endif
+        __syncthreads();                                        // (D) lines issued, open lines and staging free
+        #pragma unroll
+        for (int k = 0; k < PER; k++)
+            if (stay[k] >= 0) s_all[stay[k]] = make_uint2(keep_hi[k], idx_of(k));
+        if (tid < nb) { s_wpos[tid] += my_nl * LINE; s_cc[tid] = (uint16_t)my_cc; }
+    }
+    __syncthreads();
+    // the last, incomplete line of every stream: padded with flagged records
+    for (uint32_t i = tid; i < (uint32_t)nb * LINE; i += GBN_SORT_THREADS) {
+        const uint32_t b = i / LINE, s = i % LINE;
+        if (s >= s_cc[b]) s_all[TILE + b * LINE + s] = make_uint2(0x80000000u, 0xffffu);
+    }
+    __syncthreads();
+    for (uint32_t i = tid; i < (uint32_t)nb * LP; i += GBN_SORT_THREADS) {
+        const uint32_t b = i / LP, p = i % LP;
+        if (s_cc[b] && s_wpos[b] + LINE <= B.subcap && !(B.dbg & 2)) store_quarter(b, s_wpos[b] + p * 4, TILE + b * LINE + p * 4);
+    }
+    for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
+        const uint32_t total = s_wpos[b] + (s_cc[b] ? LINE : 0u);
+        if (total > B.subcap) atomicExch(B.overflow, 1u);
+        B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(total, B.subcap);
+    }
+}
+#endif  // GBN_BIN_CARRY == 2
+
+
+#if GBN_BIN_CARRY == 2
+#define GBN_BIN_BODY scan_bin_line_body
+#elif GBN_BIN_CARRY
 #define GBN_BIN_BODY scan_bin_carry_body
 #else
 #define GBN_BIN_BODY scan_bin_body
