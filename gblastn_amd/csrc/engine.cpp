@@ -406,7 +406,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 if ((rc = dev_alloc(E.bin_rec, need_u64))) return rc;
                 E.bin_rec_cap = need_u64;
             }
-            const size_t nseq = (size_t)((ts.ntiles + nwriters - 1) / nwriters);
+            const size_t nseq = ((size_t)((ts.ntiles + nwriters - 1) / nwriters) + ((size_t)1 << GBN_TCUR_SHIFT) - 1) >> GBN_TCUR_SHIFT;    // cursor entries per stream
             if (nstream * nseq > E.bin_tcur_cap) {
                 dev_free(E.bin_tcur); E.bin_tcur_cap = 0; g_binkey.valid = false;
                 if ((rc = dev_alloc(E.bin_tcur, nstream * nseq))) return rc;
@@ -482,9 +482,9 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                     fprintf(stderr, "[gbn dbg] %zu streams: records min %u max %u total %llu (capacity %u each)\n", ns, mn, mx2, sum, dbg_subcap);
                 }
                 uint32_t ph[8]; HIPCHK(hipMemcpy(ph, E.rare_counts + 512, sizeof(ph), hipMemcpyDeviceToHost));
-                fprintf(stderr, "[gbn dbg] scan_bin workgroup 0 (GBN_BIN_TIMING build), cycles/16: bookkeeping+atomics issued %u, ranks returned %u, "
-                        "loads issued %u, barrier A %u | scan %u | pads+scatter %u | next keys %u | write-out %u\n",
-                        ph[5], ph[6], ph[7], ph[0], ph[1], ph[2], ph[3], ph[4]);
+                fprintf(stderr, "[gbn dbg] scan_bin workgroup 0 (GBN_BIN_TIMING build), cycles/16 of wave 0 per phase: "
+                        "%u %u %u %u %u %u %u %u (line variant: histogram | wait A | wave scan | wait B0 + offsets | wait B + scatter | wait C + keys + stores | wait D | stay-behind moves)\n",
+                        ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
             }
             if ((size_t)mx > E.rareq_cap / (size_t)grid2) {    // a segment overflowed: grow and rescan this range
                 rare_seg_hint = (size_t)mx + (mx >> 2);

@@ -46,8 +46,11 @@ struct GbnScanParams {
 #endif                              // alternative: 512 (two per CU, 8192-position tiles): 15-50 % slower (128-byte runs)
 #define GBN_BIN_WG_PER_CU (1024 / GBN_SORT_THREADS)
 #ifndef GBN_BIN_CARRY
-#define GBN_BIN_CARRY 2         // 2: line-exact binning kernel, 8-byte LDS records + open lines (default); 1: carry variant; 0: padded runs, 16384-position tiles
+#define GBN_BIN_CARRY 2         // 2: line-exact binning kernel (open lines in LDS, 8192-position tiles); 0: padded runs, 16384-position tiles
 #endif
+// cursor table resolution: one entry per 2^GBN_TCUR_SHIFT tiles of a (bin, writer) stream; the low bits of the
+// tile's sequence number then travel in the spare top bits of every record's 16-bit index
+#define GBN_TCUR_SHIFT (GBN_BIN_CARRY ? 3 : 0)
 #ifndef GBN_BIN_TILE_BITS
 #define GBN_BIN_TILE_BITS ((GBN_SORT_THREADS == 512 || GBN_BIN_CARRY) ? 13 : 14)
 #endif
@@ -114,10 +117,6 @@ struct GbnKeyParams {
 };
 
 // seeds per launch below which the diagonal kernel runs thread-per-seed instead of on compacted run heads
-// records per stored line of the carry binning kernel (32 = one 128-byte line of hi words)
-#ifndef GBN_CARRY_LINE
-#define GBN_CARRY_LINE 32
-#endif
 #ifndef GBN_DIAG_COMPACT_MIN
 #define GBN_DIAG_COMPACT_MIN (1 << 20)
 #endif

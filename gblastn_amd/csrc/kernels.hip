@@ -1185,245 +1185,28 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
         B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(s_wcur[b], B.subcap);
 }
 
-#if GBN_BIN_CARRY
-// ---------------------------------------------------------------------------------------------------
-// Binning kernel, line-exact variant.  Measured on MI355X: the same bytes cost 3-4x more when a stream's
-// 128-byte lines are written in pieces by consecutive tiles (partial-line writes) than when every store
-// completes whole, aligned lines.  So each workgroup keeps, per bin, the < 32 records that do not fill a
-// line yet in LDS (the "carry") and only ever stores complete 32-record lines of `hi` words (128 bytes,
-// aligned) with their 64 bytes of indices; no pad records exist except in the last line of a stream.
-// 8192-position tiles (48 KB of bin-sorted staging) + 96 KB of carry.  Four barriers per tile:
-//   [0] histogram atomics of tile t, requests for the bytes of t+1 / descriptor of t+2
-//   [1] scans: staging offsets of the bins, number of complete lines per bin, line -> bin table
-//   [2] scatter of t into the staging arrays (and where each record that stays behind will sit)
-//   [3] stores of the complete lines (carry first, then staging), keys of t+1
-//   [4] the records that stay behind move into the carry (from registers), cursors advance
-template <int STEP>
-__device__ __forceinline__ void scan_bin_carry_body(const GbnBinParams &B)
-{
-    const GbnScanParams &P = B.S;
-    constexpr int TILE = GBN_BIN_TILE_POS, PER = TILE / GBN_SORT_THREADS, LINE = GBN_CARRY_LINE, LP = LINE / 4;    // LP lanes store one line
-    static_assert(PER == 8 && GBN_SORT_THREADS == 1024, "carry variant: 8192-position tiles, 1024 threads");
-    __shared__ __attribute__((aligned(16))) uint32_t s_hi[TILE];            // tile records, bin-sorted
-    __shared__ __attribute__((aligned(16))) uint16_t s_idx[TILE];
-    __shared__ __attribute__((aligned(16))) uint32_t c_hi[GBN_BIN_MAXNB * LINE];     // carry, LINE slots per bin
-    __shared__ __attribute__((aligned(16))) uint16_t c_idx[GBN_BIN_MAXNB * LINE];
-    __shared__ uint32_t s_hist[GBN_BIN_MAXNB], s_off[GBN_BIN_MAXNB + 1], s_loff[GBN_BIN_MAXNB + 1];
-    __shared__ uint32_t s_wtot[GBN_BIN_MAXNB / 64];
-    __shared__ uint32_t s_pk[GBN_BIN_MAXNB];        // per bin: staging offset | (complete-line records - carry count + 32) << 16
-    __shared__ uint32_t s_wpos[GBN_BIN_MAXNB];                              // records stored so far (multiple of LINE)
-    __shared__ uint16_t s_cc[GBN_BIN_MAXNB];                                // records in the carry (< LINE)
-    __shared__ uint16_t s_lbin[TILE / LINE + GBN_BIN_MAXNB];                // complete line of this tile -> bin
-    const int tid = threadIdx.x;
-    const uint32_t mask = (uint32_t)(P.ncells - 1);
-    const int nb = B.nb, cbits = B.cbits;
-    const uint32_t lowmask = (1u << cbits) - 1;
-    const int cshift = 56 - 2 * P.lut, rshift = 49 - 2 * P.lut;
-    const uint32_t ustep = (uint32_t)P.step;
-    const int64_t stride = gridDim.x, last = P.ntiles - 1;
-    const uint32_t wid = blockIdx.x;
-
-    // a lane owns PER consecutive positions = 16 * STEP bits of subject: a whole number of dwords for
-    // even strides, half a dword extra for odd lanes of odd strides (the raw dwords are then shifted by
-    // 16 bits first, after which every window is cut out with compile-time shifts as before)
-    constexpr int NDW = STEP > 0 ? ((2 * STEP * (PER - 1) - 8 + 38) >> 5) + 4 : 2 * PER;
-    struct Raw { uint32_t d[NDW]; };
-    auto idx_of = [&](int k) -> uint32_t { return STEP > 0 ? (uint32_t)(tid * PER + k) : (uint32_t)(tid + k * GBN_SORT_THREADS); };
-    auto upos_of = [&](const GbnTile &t, int k) -> uint32_t {
-        const uint32_t i = min(idx_of(k), (uint32_t)t.npos - 1u);
-        return (uint32_t)t.first_pos + i * ustep + 60u;
-    };
-    auto lane_half = [&](const GbnTile &t) -> uint32_t {    // lane's first base, in units of 8 bases (16 bits), from the tile start
-        return min((uint32_t)tid, ((uint32_t)t.npos - 1u) / PER) * (uint32_t)STEP;
-    };
-    auto fetch = [&](const GbnTile &t, Raw &r) {
-        if constexpr (STEP > 0) {
-            const uint8_t *p = P.db + ((size_t)(uint32_t)t.off16 << 4) + 4 * ((size_t)((uint32_t)t.first_pos >> 4) + (size_t)(lane_half(t) >> 1)) - 4;
-            #pragma unroll
-            for (int i = 0; i + 4 <= NDW; i += 4) __builtin_memcpy(&r.d[i], p + 4 * i, 16);
-            if constexpr (NDW % 4 == 3) { __builtin_memcpy(&r.d[NDW - 3], p + 4 * (NDW - 3), 12); }
-            else if constexpr (NDW % 4 == 2) { __builtin_memcpy(&r.d[NDW - 2], p + 4 * (NDW - 2), 8); }
-            else if constexpr (NDW % 4 == 1) { __builtin_memcpy(&r.d[NDW - 1], p + 4 * (NDW - 1), 4); }
-        } else {
-            #pragma unroll
-            for (int k = 0; k < PER; k++)
-                __builtin_memcpy(&r.d[2 * k], P.db + ((size_t)(uint32_t)t.off16 << 4) - 16 + (upos_of(t, k) >> 2), 8);
-        }
-    };
-    auto keys_all = [&](const GbnTile &t, const Raw &r, uint32_t (&bin)[PER], uint32_t (&hi)[PER]) {
-        uint32_t x[NDW];
-        if constexpr (STEP > 0) {
-            #pragma unroll
-            for (int i = 0; i < NDW; i++) x[i] = bswap32(r.d[i]);
-            if ((STEP & 1) && (lane_half(t) & 1u)) {
-                #pragma unroll
-                for (int i = 0; i + 1 < NDW; i++) x[i] = (x[i] << 16) | (x[i + 1] >> 16);
-            }
-        }
-        #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            uint64_t w;
-            if constexpr (STEP > 0) {
-                const int bit = 2 * STEP * k - 8 + 32, a = bit >> 5, o = bit & 31;
-                const uint32_t x2 = x[a + 2 < NDW ? a + 2 : NDW - 1];
-                const uint32_t hi32 = o ? ((x[a] << o) | (x[a + 1] >> (32 - o))) : x[a];
-                const uint32_t lo32 = o ? ((x[a + 1] << o) | (x2 >> (32 - o))) : x[a + 1];
-                w = ((uint64_t)hi32 << 32) | lo32;
-            } else {
-                uint64_t raw; __builtin_memcpy(&raw, &r.d[2 * k], 8);
-                w = __builtin_bswap64(raw) << (2 * (upos_of(t, k) & 3));
-            }
-            const uint32_t c = (uint32_t)(w >> cshift) & mask;
-            bin[k] = c >> cbits;
-            hi[k] = ((c & lowmask) << 15) | (((uint32_t)(w >> rshift) & 0x7fu) << 8) | (uint32_t)(w >> 56);
-        }
-    };
-    auto uniform = [](GbnTile t) -> GbnTile {
-        t.subj = __builtin_amdgcn_readfirstlane(t.subj); t.first_pos = __builtin_amdgcn_readfirstlane(t.first_pos);
-        t.npos = __builtin_amdgcn_readfirstlane(t.npos); t.off16 = __builtin_amdgcn_readfirstlane(t.off16);
-        return t;
-    };
-    // one complete line of a bin: 8 lanes store 16 bytes of hi words each, the first 4 also 16 bytes of
-    // indices; record s of the bin's pending sequence = carry[s] for s < cc, else staging[off + s - cc]
-    auto store_line_part = [&](uint32_t b, uint32_t l, uint32_t p, uint32_t cc, uint32_t off, uint32_t wpos, uint32_t nvalid) {
-        auto rec_hi = [&](uint32_t s) -> uint32_t {
-            return s >= nvalid ? 0x80000000u : (s < cc ? c_hi[b * LINE + s] : s_hi[off + s - cc]); };
-        auto rec_ix = [&](uint32_t s) -> uint32_t {
-            return s >= nvalid ? 0xffffu : (uint32_t)(s < cc ? c_idx[b * LINE + s] : s_idx[off + s - cc]); };
-        const uint32_t s0 = l * LINE + p * 4;
-        const size_t at = GBN_RECIDX(B, b, wid, wpos + s0);
-        if (wpos + l * LINE + LINE > B.subcap || (B.dbg & 2)) return;
-        uint4 h4; h4.x = rec_hi(s0); h4.y = rec_hi(s0 + 1); h4.z = rec_hi(s0 + 2); h4.w = rec_hi(s0 + 3);
-        *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = h4;
-        if (p < LP / 2) {
-            const uint32_t s1 = l * LINE + p * 8;
-            uint4 i4;
-            i4.x = rec_ix(s1) | (rec_ix(s1 + 1) << 16); i4.y = rec_ix(s1 + 2) | (rec_ix(s1 + 3) << 16);
-            i4.z = rec_ix(s1 + 4) | (rec_ix(s1 + 5) << 16); i4.w = rec_ix(s1 + 6) | (rec_ix(s1 + 7) << 16);
-            *reinterpret_cast<uint4 *>(reinterpret_cast<uint16_t *>(B.rec) + GBN_REC_IDX16(GBN_RECIDX(B, b, wid, wpos + s1))) = i4;
-        }
-    };
-
-    for (int b = tid; b < nb; b += GBN_SORT_THREADS) { s_hist[b] = 0; s_wpos[b] = 0; s_cc[b] = 0; }
-    int64_t tile = blockIdx.x;
-    if (tile > last) {
-        for (int b = tid; b < nb; b += GBN_SORT_THREADS) B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0;
-        return;
-    }
-    GbnTile T = uniform(P.tiles[tile]);
-    GbnTile T1 = uniform(P.tiles[min(tile + stride, last)]);
-    uint32_t bin[PER], hi[PER];
-    {
-        Raw r0; fetch(T, r0);
-        keys_all(T, r0, bin, hi);
-    }
-    __syncthreads();
-
-    uint32_t seq = 0;
-    for (; tile <= last; tile += stride, ++seq) {
-        uint32_t rank[PER];
-        #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            rank[k] = 0;
-            if (idx_of(k) < (uint32_t)T.npos) rank[k] = atomicAdd(&s_hist[bin[k]], 1u);
-        }
-        Raw R;
-        if constexpr (STEP > 0) fetch(T1, R);
-        GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
-        __syncthreads();                                        // (A) histogram complete
-        // exclusive scans over the bins, both sums in one word: records of the tile (staging offsets,
-        // < 2^14) and complete lines (store work list, < 2^10).  One bin per thread: scan inside each
-        // wave, wave totals through LDS.
-        uint32_t v = 0, incl = 0;
-        if (tid < nb) {
-            const uint32_t n = s_hist[tid], cc = s_cc[tid];
-            v = n | (((cc + n) / LINE) << 16);
-        }
-        if (tid < GBN_BIN_MAXNB) {
-            incl = v;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((tid & 63) >= o) incl += y; }
-            if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
-        }
-        __syncthreads();                                        // (B0) wave totals
-        if (tid < nb) {
-            uint32_t run = incl - v;
-            for (int w = 0; w < (tid >> 6); w++) run += s_wtot[w];
-            const uint32_t nl = v >> 16, l0 = run >> 16, cc = s_cc[tid], wp = s_wpos[tid];
-            s_off[tid] = run & 0xffffu; s_loff[tid] = l0;
-            s_pk[tid] = (run & 0xffffu) | ((nl * LINE - cc + 32u) << 16);
-            if (tid == nb - 1) { s_off[nb] = (run + v) & 0xffffu; s_loff[nb] = (run + v) >> 16; }
-            B.tcur[((size_t)tid * B.nwriters + wid) * B.nseq + seq] = wp + cc;     // stream index of this tile's first record
-            if (wp + nl * LINE > B.subcap) atomicExch(B.overflow, 1u);
-            for (uint32_t l = 0; l < nl; l++) s_lbin[l0 + l] = (uint16_t)tid;        // read after (C)
-        }
-        __syncthreads();                                        // (B) offsets and line list known
-        const uint32_t nlines = s_loff[nb];
-        int32_t stay[PER];                                      // carry slot of a record that stays behind, else -1
-        #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            stay[k] = -1;
-            if (idx_of(k) < (uint32_t)T.npos) {
-                const uint32_t b = bin[k], pk = s_pk[b], slot = (pk & 0xffffu) + rank[k];
-                s_hi[slot] = hi[k];
-                s_idx[slot] = (uint16_t)idx_of(k);
-                const int32_t behind = (int32_t)rank[k] + 32 - (int32_t)(pk >> 16);     // rank + cc - complete-line records
-                if (behind >= 0) stay[k] = (int32_t)(b * LINE) + behind;
-            }
-        }
-        __syncthreads();                                        // (C) tile is bin-sorted in LDS
-        for (int b = tid; b < nb; b += GBN_SORT_THREADS) s_hist[b] = 0;     // for the next tile; ordered by (D)
-        uint32_t keep_hi[PER];                                  // of the records that stay behind: the keys are replaced below
-        #pragma unroll
-        for (int k = 0; k < PER; k++) keep_hi[k] = hi[k];
-        // keys of t+1 BEFORE the stores: whatever waits for the loads of t+1 (vmcnt counts loads and
-        // stores alike) must not sit behind this tile's stores, or every wave idles for the full
-        // write latency once per tile
-#if !GBN_KEYS_AFTER_STORES
-        T = T1; T1 = uniform(T2);
-        if constexpr (STEP == 0) fetch(T, R);
-        keys_all(T, R, bin, hi);
-#endif
-        for (uint32_t i = tid; i < nlines * (uint32_t)LP; i += GBN_SORT_THREADS) {
-            const uint32_t L = i / LP, p = i % LP, b = s_lbin[L];
-            store_line_part(b, L - s_loff[b], p, s_cc[b], s_off[b], s_wpos[b], 0xffffffffu);
-        }
-#if GBN_KEYS_AFTER_STORES
-        T = T1; T1 = uniform(T2);
-        if constexpr (STEP == 0) fetch(T, R);
-        keys_all(T, R, bin, hi);
-#endif
-        __syncthreads();                                        // (D) lines issued, carry and staging free
-        #pragma unroll
-        for (int k = 0; k < PER; k++)
-            if (stay[k] >= 0) { c_hi[stay[k]] = keep_hi[k]; c_idx[stay[k]] = (uint16_t)idx_of(k); }
-        for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
-            const uint32_t nl = s_loff[b + 1] - s_loff[b], n = s_off[b + 1] - s_off[b];
-            s_wpos[b] += nl * LINE;
-            s_cc[b] = (uint16_t)(((uint32_t)s_cc[b] + n) & (LINE - 1));
-        }
-    }
-    __syncthreads();
-    // the last, incomplete line of every stream: padded with flagged records
-    for (uint32_t i = tid; i < (uint32_t)nb * LP; i += GBN_SORT_THREADS) {
-        const uint32_t b = i / LP, p = i % LP, cc = s_cc[b];
-        if (cc) store_line_part(b, 0, p, cc, 0, s_wpos[b], cc);
-    }
-    for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
-        const uint32_t total = s_wpos[b] + (s_cc[b] ? LINE : 0u);
-        if (total > B.subcap) atomicExch(B.overflow, 1u);
-        B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(total, B.subcap);
-    }
-}
-#endif  // GBN_BIN_CARRY
 
 #if GBN_BIN_CARRY == 2
 // ---------------------------------------------------------------------------------------------------
-// Binning kernel, line-exact variant 2 (default).  Same output as the carry variant above, with the store
-// phase reduced from ~500 to ~40 instructions per lane: records sit in LDS as 8-byte {hi, index} pairs,
-// and every bin owns one "open line" of 16 records that the scatter fills first, so that each complete
-// 16-record line (64 bytes of hi words + 32 of indices: measured as cheap as 128 + 64) is 16 consecutive
-// LDS records -- the bin's open line, or a run of the staging area -- read with 4 ds_read_b64 per lane
-// and written with one 16-byte and one 8-byte store.  64 KB staging + 64 KB open lines.
+// Binning kernel, line-exact variant (default).  Measured on MI355X: the same bytes cost 3-4x more when a
+// stream's lines are written in pieces by consecutive tiles (partial-line writes) than when every store
+// completes whole, aligned 64-byte pieces.  So each workgroup keeps, per bin, one "open line" of 16 records
+// in LDS and only ever stores complete lines: 64 bytes of `hi` words, aligned, with their 32 bytes of
+// indices (measured as cheap as 128 + 64); no pad records exist except in the last line of a stream.
+// Records sit in LDS as 8-byte {hi, index} pairs; the scatter fills a bin's open line first and puts the rest
+// into the bin-sorted staging area, so every complete line is 16 consecutive LDS records -- the open line
+// or a run of the staging area -- read with 4 ds_read_b64 per lane and written with one 16-byte and one
+// 8-byte store (~40 instructions per lane; the first line-exact version gathered record by record from two
+// sources and spent ~500).  64 KB staging (8192-position tiles) + 64 KB open lines.  Five barriers per tile:
+//   [0] histogram atomics of tile t, requests for the bytes of t+1 / descriptor of t+2
+//   [1] scans: staging offsets of the bins, number of complete lines per bin, line -> bin table
+//   [2] scatter of t into open lines / staging (records past a bin's last complete line wait in registers)
+//   [3] keys of t+1, then stores of the complete lines
+//   [4] the waiting records move into the open lines, cursors advance
+// The tile of a record is not stored: every 8th tile leaves a cursor (stream index of its first record) per
+// bin, and the low 3 bits of the tile's sequence number ride in the spare top bits of the 16-bit index.
+// A three-interval software pipeline of the same steps (histogram of t+1 next to the scatter of t) was
+// measured 0-10 % slower and is not kept.
 template <int STEP>
 __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
 {
@@ -1532,6 +1315,13 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     }
     __syncthreads();
 
+#if GBN_BIN_TIMING   // phase timer of workgroup 0 (tools/build_variant.sh t "-DGBN_BIN_TIMING=1", GBN_DBG=32)
+    const bool timed = blockIdx.x == 0 && tid == 0;
+    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
+#define GBN_LAP2(ph) do { if (timed) { const unsigned long long t_ = __builtin_readcyclecounter(); tph[ph] += t_ - tprev; tprev = t_; } } while (0)
+#else
+#define GBN_LAP2(ph) do { } while (0)
+#endif
     uint32_t seq = 0;
     for (; tile <= last; tile += stride, ++seq) {
         uint32_t rank[PER];
@@ -1543,7 +1333,9 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         Raw R;
         if constexpr (STEP > 0) fetch(T1, R);
         GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
+        GBN_LAP2(0);
         __syncthreads();                                        // (A) histogram complete
+        GBN_LAP2(1);
         // exclusive scans over the bins, both sums in one word: records that go to the staging area
         // (all but the ones that fill the bin's open line; < 2^14) and complete lines (< 2^10)
         uint32_t v = 0, incl = 0, my_nl = 0, my_cc = 0;
@@ -1558,18 +1350,21 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
             if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
         }
         __syncthreads();                                        // (B0) wave totals
+        GBN_LAP2(2);
         if (tid < nb) {
             uint32_t run = incl - v;
-            for (int w = 0; w < (tid >> 6); w++) run += s_wtot[w];
+            #pragma unroll
+            for (int w = 0; w < GBN_BIN_MAXNB / 64 - 1; w++) run += (tid >> 6) > w ? s_wtot[w] : 0u;
             const uint32_t l0 = run >> 16, cc = s_cc[tid], wp = s_wpos[tid];
             s_off[tid] = run & 0xffffu; s_loff[tid] = l0;
             s_pk[tid] = (run & 0xffffu) | (cc << 14) | (my_nl << 19);
             if (tid == nb - 1) s_loff[nb] = (run + v) >> 16;
-            B.tcur[((size_t)tid * B.nwriters + wid) * B.nseq + seq] = wp + cc;     // stream index of this tile's first record
+            if ((seq & 7u) == 0) B.tcur[((size_t)tid * B.nwriters + wid) * B.nseq + (seq >> 3)] = wp + cc;     // stream index of this tile's first record
             if (wp + my_nl * LINE > B.subcap) atomicExch(B.overflow, 1u);
             for (uint32_t l = 0; l < my_nl; l++) s_lbin[l0 + l] = (uint16_t)tid;     // read after (C)
         }
         __syncthreads();                                        // (B) offsets and line list known
+        GBN_LAP2(3);
         const uint32_t nlines = s_loff[nb];
         int32_t stay[PER];                                      // slot (in s_all) of a record past the bin's last complete line, else -1
         #pragma unroll
@@ -1582,36 +1377,38 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
                 // waits in registers until the open line has been stored
                 const uint32_t slot = pos < (uint32_t)LINE ? TILE + b * LINE + pos : (pk & 0x3fffu) + pos - LINE;
                 if (full && pos >= full) stay[k] = (int32_t)(TILE + b * LINE + pos - full);
-                else s_all[slot] = make_uint2(hi[k], idx_of(k));
+                else s_all[slot] = make_uint2(hi[k], idx_of(k) | ((seq & 7u) << 13));
             }
         }
         __syncthreads();                                        // (C) open lines and staging filled
+        GBN_LAP2(4);
         for (int b = tid; b < nb; b += GBN_SORT_THREADS) s_hist[b] = 0;     // for the next tile; ordered by (D)
         uint32_t keep_hi[PER];                                  // of the records that stay behind: the keys are replaced below
         #pragma unroll
         for (int k = 0; k < PER; k++) keep_hi[k] = hi[k];
-#if !GBN_KEYS_AFTER_STORES
+        // keys of t+1 before the stores: the wait for the loads of t+1 counts every outstanding memory
+        // operation and would otherwise sit behind this tile's stores
         T = T1; T1 = uniform(T2);
         if constexpr (STEP == 0) fetch(T, R);
         keys_all(T, R, bin, hi);
-#endif
         if (!(B.dbg & 2))
         for (uint32_t i = tid; i < nlines * (uint32_t)LP; i += GBN_SORT_THREADS) {
             const uint32_t L = i / LP, p = i % LP, b = s_lbin[L], l = L - s_loff[b], wpos = s_wpos[b] + l * LINE;
             if (wpos + LINE > B.subcap) continue;
             store_quarter(b, wpos + p * 4, (l == 0 ? TILE + b * LINE : s_off[b] + (l - 1) * LINE) + p * 4);
         }
-#if GBN_KEYS_AFTER_STORES
-        T = T1; T1 = uniform(T2);
-        if constexpr (STEP == 0) fetch(T, R);
-        keys_all(T, R, bin, hi);
-#endif
+        GBN_LAP2(5);
         __syncthreads();                                        // (D) lines issued, open lines and staging free
+        GBN_LAP2(6);
         #pragma unroll
         for (int k = 0; k < PER; k++)
-            if (stay[k] >= 0) s_all[stay[k]] = make_uint2(keep_hi[k], idx_of(k));
+            if (stay[k] >= 0) s_all[stay[k]] = make_uint2(keep_hi[k], idx_of(k) | ((seq & 7u) << 13));
         if (tid < nb) { s_wpos[tid] += my_nl * LINE; s_cc[tid] = (uint16_t)my_cc; }
+        GBN_LAP2(7);
     }
+#if GBN_BIN_TIMING
+    if (timed) for (int i = 0; i < 8; i++) B.rare_counts[512 + i] = (uint32_t)(tph[i] >> 4);
+#endif
     __syncthreads();
     // the last, incomplete line of every stream: padded with flagged records
     for (uint32_t i = tid; i < (uint32_t)nb * LINE; i += GBN_SORT_THREADS) {
@@ -1632,10 +1429,10 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
 #endif  // GBN_BIN_CARRY == 2
 
 
+
+
 #if GBN_BIN_CARRY == 2
 #define GBN_BIN_BODY scan_bin_line_body
-#elif GBN_BIN_CARRY
-#define GBN_BIN_BODY scan_bin_carry_body
 #else
 #define GBN_BIN_BODY scan_bin_body
 #endif
@@ -1860,18 +1657,21 @@ probe_rare_kernel(GbnBinParams B, int nseg)
             const uint32_t bin = (cv & 0x7fffffffu) >> B.cbits;
             const uint32_t wr = pid / B.subcap, j = pid - wr * B.subcap;
             const uint32_t *__restrict__ cur = B.tcur + ((size_t)bin * B.nwriters + wr) * B.nseq;
-            const uint32_t nt = (uint32_t)((P.ntiles - wr + B.nwriters - 1) / B.nwriters);     // tiles of this writer
+            const uint32_t ntiles_w = (uint32_t)((P.ntiles - wr + B.nwriters - 1) / B.nwriters);     // tiles of this writer
+            const uint32_t nt = (ntiles_w + (1u << GBN_TCUR_SHIFT) - 1u) >> GBN_TCUR_SHIFT;          // cursor entries
             uint32_t lo = 0, hi = nt;
             {   // the cursors grow almost linearly: look around the interpolated run first
                 const uint32_t total = B.gcount[(size_t)bin * B.nwriters + wr];
                 const uint32_t g = (uint32_t)(((unsigned long long)j * nt) / (total ? total : 1u));
-                const uint32_t a = g > 12u ? g - 12u : 0u, z = min(nt, g + 12u);
+                constexpr uint32_t W = GBN_TCUR_SHIFT ? 3u : 12u;
+                const uint32_t a = g > W ? g - W : 0u, z = min(nt, g + W);
                 const uint32_t ca = cur[a], cz = (z < nt) ? cur[z] : 0xffffffffu;
                 if (ca <= j && cz > j) { lo = a; hi = z; }
             }
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] <= j) lo = mid; else hi = mid; }
             const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, j))];
-            pid = ((wr + lo * (uint32_t)B.nwriters) << GBN_BIN_TILE_BITS) | idx;
+            const uint32_t seqn = GBN_TCUR_SHIFT ? ((lo << GBN_TCUR_SHIFT) | (idx >> GBN_BIN_TILE_BITS)) : lo;
+            pid = ((wr + seqn * (uint32_t)B.nwriters) << GBN_BIN_TILE_BITS) | (idx & (uint32_t)(GBN_BIN_TILE_POS - 1));
         }
 #endif
         probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
