@@ -113,6 +113,9 @@ def main():
         got = shard.collect_on_root(out["hsps"], len(b._q), opt.hitlist_size, dst=0, device=dev)
         return 0 if got is None else len(got[0])
 
+    from concurrent.futures import ThreadPoolExecutor
+    merger = ThreadPoolExecutor(max_workers=1, initializer=lambda: torch.cuda.set_device(dev))
+
     def run_passes(first, count):
         """`count` passes, software-pipelined when there are two batches to alternate: the gapped
         stage + host acceptance + gather/merge of pass k overlap the scan of pass k + 1.  Every pass
@@ -125,15 +128,17 @@ def main():
                 b = batches[k % nbatch]
                 n += merge(b, b.run())
             return n
-        prev = None
+        # begin(k) returns when scan k is done and its extension stages are in flight; the gather + top-N
+        # merge of pass k-1 (host work, or an RCCL gather at N > 1) runs on a worker thread underneath scan k+1
+        prev, futs = None, []
         for k in range(first, first + count):
             b = batches[k % nbatch]
-            b.begin()                       # waits for prev's gapped stage before queueing its own
+            b.begin()                       # waits for prev's extension stages before queueing its own
             if prev is not None:
-                n += merge(prev, prev.end())
+                futs.append(merger.submit(merge, prev, prev.end()))
             prev = b
-        n += merge(prev, prev.end())
-        return n
+        futs.append(merger.submit(merge, prev, prev.end()))
+        return n + sum(f.result() for f in futs)
 
     def sync():
         if world > 1:

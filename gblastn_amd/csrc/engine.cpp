@@ -68,7 +68,9 @@ struct Engine {
     int32_t *gap_scratch_s[2] = {nullptr, nullptr}; size_t gap_scratch_ints_s[2] = {0, 0};
     int slot = 0; hipStream_t stream2 = nullptr;
     std::future<int> pending; bool has_pending = false; std::string pending_err; const GbnResults *pending_res = nullptr;
-    unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits
+    unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits, [3] runs; [4], [5]: init hits, runs of an asynchronous seed stage
+    GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
+    hipEvent_t ev_seed = nullptr; bool pending_uses_keys = false;
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
     uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;             // per-run stream cursors (6-byte records)
     GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
@@ -306,7 +308,7 @@ static int grow_ihit_buffers(int slot, size_t n) {
 static int wait_pending() {
     if (!E.has_pending) return GBN_OK;
     int rc = E.pending.get();
-    E.has_pending = false;
+    E.has_pending = false; E.pending_uses_keys = false;
     if (rc && !E.pending_err.empty()) set_error(E.pending_err);
     return rc;
 }
@@ -506,6 +508,76 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
 static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag,
                         int keep_stages, int slot, unsigned long long nih, hipStream_t st);
 
+// seeds of a range -> scan order (two stable sorts) -> diagonal filter + ungapped extension on stream `st`;
+// the initial hits are left in the slot's buffers.  ctr: [0] initial hits, [1] runs (device counters).
+static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *diag, int keep_stages, int slot,
+                      const GbnDevSeed *seeds, int64_t n, unsigned long long *ctr, hipStream_t st, unsigned long long *nih_out)
+{
+    const DeviceBatch *d = b.dev;
+    int rc;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t_stage = now();
+    if ((rc = grow_key_buffers((size_t)n))) return rc;
+    GbnKeyParams K; std::memset(&K, 0, sizeof(K));
+    K.seeds = seeds; K.n = n; K.key_scan = E.key_a; K.idx = E.idx_a;
+    K.q_descending = (b.lut.type == GBN_LUT_MB); K.container_hash = b.container; K.diag_len = b.diag_len;
+    HIPCHK(launch_seed_keys(K, st));
+    size_t tb = E.sort_tmp_bytes;
+    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, 64, st));
+    // idx_b = seed indices in scan order (s_scan, chain order), subjects interleaved
+    K.idx = E.idx_b; K.key_group = E.key_a;
+    HIPCHK(launch_group_keys(K, st));
+    tb = E.sort_tmp_bytes;
+    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_b, E.idx_a, n, 64, st));
+    // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
+
+    if (keep_stages) {
+        std::vector<GbnDevSeed> hs((size_t)n); std::vector<uint32_t> order((size_t)n);
+        HIPCHK(hipMemcpyAsync(hs.data(), seeds, (size_t)n * sizeof(GbnDevSeed), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(order.data(), E.idx_b, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<GbnSeed> tmp; tmp.reserve((size_t)n);
+        for (int64_t i = 0; i < n; i++) {
+            const GbnDevSeed &s = hs[order[i]];
+            GbnSeed o; o.oid = db.first_oid + s.subj; o.s_off = s.s_scan - s.ext_left; o.q_off = s.q_pos - s.ext_left; o.pad_ = 0;
+            tmp.push_back(o);
+        }
+        std::stable_sort(tmp.begin(), tmp.end(), [](const GbnSeed &a, const GbnSeed &c) { return a.oid < c.oid; });
+        res.seeds.insert(res.seeds.end(), tmp.begin(), tmp.end());
+    }
+
+    if ((rc = grow_ihit_buffers(slot, std::max<size_t>(E.ihit_cap_s[slot], 1 << 16)))) return rc;
+    unsigned long long nih = 0;
+    *nih_out = 0;
+    for (;;) {
+        HIPCHK(hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned long long), st));      // initial hits, runs
+        GbnExtParams X; std::memset(&X, 0, sizeof(X));
+        X.db = db.d_packed; X.byte_off = db.d_byte_off; X.len = db.d_len;
+        X.seeds = seeds; X.idx = E.idx_a; X.key_group = E.key_b; X.n = n;
+        X.q8 = d->q8; X.qlen = b.qlen;
+        X.ctx_off = d->ctx_off; X.ctx_len = d->ctx_len; X.ctx_xdrop = d->ctx_xdrop;
+        X.ctx_cutoff = d->ctx_cutoff; X.ctx_reduced = d->ctx_reduced; X.nctx = (int32_t)b.ctx.size();
+        X.matrix = d->matrix; X.score_table = d->score_table;
+        X.word = b.lut.word; X.container_hash = b.container;
+        X.cell_diag = E.cell_diag; X.cell_level = E.cell_level;
+        X.cell_start = d->cell_start; X.ent = d->ent; X.cell_mask = (uint32_t)(b.lut.ncells - 1); X.lut = b.lut.lut;
+        X.masked = b.lut.masked ? 1 : 0;
+        X.run_heads = E.idx_b; X.run_count = reinterpret_cast<uint32_t *>(ctr + 1);
+        X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
+        HIPCHK(launch_diag_ungapped(X, st));
+        HIPCHK(hipMemcpyAsync(&nih, ctr, sizeof(nih), hipMemcpyDeviceToHost, st));
+        HIPCHK(hipStreamSynchronize(st));
+        if (nih <= E.ihit_cap_s[slot]) break;
+        if ((rc = grow_ihit_buffers(slot, (size_t)nih + (nih >> 3)))) return rc;
+    }
+    if (diag) { diag->init_extends += (int64_t)nih; diag->good_init_extends += (int64_t)nih; diag->seed_stage_ms += ms_since(t_stage); }
+    *nih_out = nih;
+    return GBN_OK;
+
+}
+
 // one range of subjects [s0, s1): scan, seed order, diagonal filter + ungapped extension on the engine's
 // stream; then the gapped stage -- inline, or (overlap != 0) on stream2 + a host thread while the caller
 // goes on to the next range / batch.  At most one gapped stage is in flight.
@@ -513,7 +585,6 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
                         GbnDiagnostics *diag, int keep_stages, int overlap = 0)
 {
     const int slot = E.slot;
-    const DeviceBatch *d = b.dev;
     unsigned long long cnt[3] = {0, 0, 0};
     int64_t bases = 0;
     auto now = [] { return std::chrono::steady_clock::now(); };
@@ -541,59 +612,40 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     if (n == 0) return GBN_OK;
     if (n > INT32_MAX) { set_error("too many seeds in one range"); return GBN_ERR_NOMEM; }
 
-    if ((rc = grow_key_buffers((size_t)n))) return rc;
-    GbnKeyParams K; std::memset(&K, 0, sizeof(K));
-    K.seeds = E.seeds; K.n = n; K.key_scan = E.key_a; K.idx = E.idx_a;
-    K.q_descending = (b.lut.type == GBN_LUT_MB); K.container_hash = b.container; K.diag_len = b.diag_len;
-    HIPCHK(launch_seed_keys(K, E.stream));
-    size_t tb = E.sort_tmp_bytes;
-    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, 64, E.stream));
-    // idx_b = seed indices in scan order (s_scan, chain order), subjects interleaved
-    K.idx = E.idx_b; K.key_group = E.key_a;
-    HIPCHK(launch_group_keys(K, E.stream));
-    tb = E.sort_tmp_bytes;
-    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_b, E.idx_a, n, 64, E.stream));
-    // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
-
-    if (keep_stages) {
-        std::vector<GbnDevSeed> hs((size_t)n); std::vector<uint32_t> order((size_t)n);
-        HIPCHK(hipMemcpyAsync(hs.data(), E.seeds, (size_t)n * sizeof(GbnDevSeed), hipMemcpyDeviceToHost, E.stream));
-        HIPCHK(hipMemcpyAsync(order.data(), E.idx_b, (size_t)n * 4, hipMemcpyDeviceToHost, E.stream));
-        HIPCHK(hipStreamSynchronize(E.stream));
-        std::vector<GbnSeed> tmp; tmp.reserve((size_t)n);
-        for (int64_t i = 0; i < n; i++) {
-            const GbnDevSeed &s = hs[order[i]];
-            GbnSeed o; o.oid = db.first_oid + s.subj; o.s_off = s.s_scan - s.ext_left; o.q_off = s.q_pos - s.ext_left; o.pad_ = 0;
-            tmp.push_back(o);
+    // Few seeds (megablast shapes): the whole rest of the range -- seed order, diagonal filter, ungapped and
+    // gapped extension, host replay -- runs on stream2 + a host thread on a copy of the seeds, and the
+    // caller's next scan follows this one without a gap.  Many seeds (blastn shapes): the seed stage stays
+    // on the engine's stream (it is as long as the scan) and only the gapped stage is asynchronous.
+    const bool async_seed = overlap && !keep_stages && n < ((int64_t)1 << 20);
+    if (async_seed) {
+        if ((rc = wait_pending())) return rc;               // one asynchronous stage in flight at most
+        if ((size_t)n > E.seeds_async_cap) {
+            dev_free(E.seeds_async); E.seeds_async_cap = 0;
+            if ((rc = dev_alloc(E.seeds_async, std::max<size_t>((size_t)n + (size_t)n / 4, 1 << 16)))) return rc;
+            E.seeds_async_cap = std::max<size_t>((size_t)n + (size_t)n / 4, 1 << 16);
         }
-        std::stable_sort(tmp.begin(), tmp.end(), [](const GbnSeed &a, const GbnSeed &c) { return a.oid < c.oid; });
-        res.seeds.insert(res.seeds.end(), tmp.begin(), tmp.end());
+        HIPCHK(hipMemcpyAsync(E.seeds_async, E.seeds, (size_t)n * sizeof(GbnDevSeed), hipMemcpyDeviceToDevice, E.stream));
+        HIPCHK(hipEventRecord(E.ev_seed, E.stream));
+        E.slot ^= 1;
+        E.pending_err.clear();
+        const int dev = E.device;
+        GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
+        E.pending = std::async(std::launch::async, [=]() -> int {
+            int r = GBN_OK;
+            unsigned long long nih2 = 0;
+            if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the extension thread"; return GBN_ERR_HIP; }
+            if (hipStreamWaitEvent(E.stream2, E.ev_seed, 0) != hipSuccess) { E.pending_err = "hipStreamWaitEvent failed"; return GBN_ERR_HIP; }
+            r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n, E.counters + 4, E.stream2, &nih2);
+            if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2);
+            if (r) E.pending_err = gbn_last_error();      // the error text is per thread
+            return r;
+        });
+        E.has_pending = true; E.pending_res = rp; E.pending_uses_keys = true;
+        return GBN_OK;
     }
-
-    if ((rc = grow_ihit_buffers(slot, std::max<size_t>(E.ihit_cap_s[slot], 1 << 16)))) return rc;
+    if (E.pending_uses_keys && (rc = wait_pending())) return rc;     // the sort buffers exist once
     unsigned long long nih = 0;
-    for (;;) {
-        HIPCHK(hipMemsetAsync(E.counters + 2, 0, sizeof(unsigned long long), E.stream));
-        GbnExtParams X; std::memset(&X, 0, sizeof(X));
-        X.db = db.d_packed; X.byte_off = db.d_byte_off; X.len = db.d_len;
-        X.seeds = E.seeds; X.idx = E.idx_a; X.key_group = E.key_b; X.n = n;
-        X.q8 = d->q8; X.qlen = b.qlen;
-        X.ctx_off = d->ctx_off; X.ctx_len = d->ctx_len; X.ctx_xdrop = d->ctx_xdrop;
-        X.ctx_cutoff = d->ctx_cutoff; X.ctx_reduced = d->ctx_reduced; X.nctx = (int32_t)b.ctx.size();
-        X.matrix = d->matrix; X.score_table = d->score_table;
-        X.word = b.lut.word; X.container_hash = b.container;
-        X.cell_diag = E.cell_diag; X.cell_level = E.cell_level;
-        X.cell_start = d->cell_start; X.ent = d->ent; X.cell_mask = (uint32_t)(b.lut.ncells - 1); X.lut = b.lut.lut;
-        X.masked = b.lut.masked ? 1 : 0;
-        X.run_heads = E.idx_b; X.run_count = reinterpret_cast<uint32_t *>(E.counters + 3);
-        X.ihits = E.ihits_s[slot]; X.ihit_count = E.counters + 2; X.ihit_cap = E.ihit_cap_s[slot];
-        HIPCHK(launch_diag_ungapped(X, E.stream));
-        HIPCHK(hipMemcpyAsync(&nih, E.counters + 2, sizeof(nih), hipMemcpyDeviceToHost, E.stream));
-        HIPCHK(hipStreamSynchronize(E.stream));
-        if (nih <= E.ihit_cap_s[slot]) break;
-        if ((rc = grow_ihit_buffers(slot, (size_t)nih + (nih >> 3)))) return rc;
-    }
-    if (diag) { diag->init_extends += (int64_t)nih; diag->good_init_extends += (int64_t)nih; diag->seed_stage_ms += ms_since(t_stage); }
+    if ((rc = seed_stage(b, db, res, diag, keep_stages, slot, E.seeds, n, E.counters + 2, E.stream, &nih))) return rc;
     if (nih == 0) return GBN_OK;
     if ((rc = wait_pending())) return rc;                   // one gapped stage in flight at most
     if (!overlap || keep_stages) return gapped_stage(b, db, s0, s1, res, diag, keep_stages, slot, nih, E.stream);
@@ -774,6 +826,7 @@ int Blast_gpu_Init(int use_gpu, int gpu_id) {
     HIPCHK(hipStreamCreateWithFlags(&E.stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&E.ev0)); HIPCHK(hipEventCreate(&E.ev1));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&E.evk[i]));
+    HIPCHK(hipEventCreateWithFlags(&E.ev_seed, hipEventDisableTiming));
     HIPCHK(hipMalloc((void **)&E.counters, 8 * sizeof(unsigned long long)));
     E.device = dev; E.ready = true;
     return GBN_OK;
@@ -786,6 +839,7 @@ void Blast_gpu_Release(void) {
     if (!E.ready) return;
     (void)wait_pending();
     g_binkey.valid = false;
+    dev_free(E.seeds_async); E.seeds_async_cap = 0; if (E.ev_seed) { (void)hipEventDestroy(E.ev_seed); E.ev_seed = nullptr; }
     dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
     dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.sort_tmp); for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
     dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_tcur); E.bin_tcur_cap = 0; dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
