@@ -58,6 +58,8 @@ struct GbnScanParams {
 #define GBN_BIN_GROUPS   8          // probe workgroups with equal (blockIdx & 7) share a bin (and an XCD)
 #define GBN_BIN_MAXNB    512
 #define GBN_BIN_CELLS    32768      // cells per bin (LDS table entries)
+#define GBN_BIN_TABW     (GBN_BIN_CELLS + 4)   // words of the probe kernel's LDS table: the cells + one always-empty cell (+ alignment)
+#define GBN_REC_PAD      0x40000000u  // hi word of a pad record: "cell" GBN_BIN_CELLS, the always-empty one -- needs no special case
 #define GBN_BIN_STAGE    (GBN_BIN_TILE_POS + 3 * GBN_BIN_MAXNB)
 #define GBN_BIN_QCAP     128        // per-wave queue of rare-path items in the probe kernel
 #define GBN_BIN_SIDE     4096       // LDS side-list capacity (u16 fingerprints) per bin
@@ -95,7 +97,7 @@ struct GbnBinParams {
     // records = 128 bytes of `hi` words followed by 128 bytes of `posid` words (GBN_REC_HI/POS below).
     // The probe kernel streams the hi lines only and fetches posid for the ~1 % of records that reach
     // the rare path; a run of the binning kernel still lands in one contiguous stretch of memory.
-    //   hi:    bit 31 = pad, [29:15] cell inside the bin, [14:0] fp15 of the subject position
+    //   hi:    bit 30 = pad (GBN_REC_PAD), [29:15] cell inside the bin, [14:0] fp15 of the subject position
     //   posid: tile << GBN_BIN_TILE_BITS | index
     uint32_t *rec;
     // 6-byte records: stream cursor of (bin, writer) at the start of its seq-th tile,

@@ -1075,10 +1075,10 @@ __device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
             uint4 p4;
             p4.x = tbase | l0; p4.y = tbase | l1; p4.z = tbase | l2; p4.w = tbase | l3;
 #endif
-            if (l0 == 0xffffu) h4.x = 0x80000000u;                  // pads: flagged in the high word
-            if (l1 == 0xffffu) h4.y = 0x80000000u;
-            if (l2 == 0xffffu) h4.z = 0x80000000u;
-            if (l3 == 0xffffu) h4.w = 0x80000000u;
+            if (l0 == 0xffffu) h4.x = GBN_REC_PAD;                  // pads: flagged in the high word
+            if (l1 == 0xffffu) h4.y = GBN_REC_PAD;
+            if (l2 == 0xffffu) h4.z = GBN_REC_PAD;
+            if (l3 == 0xffffu) h4.w = GBN_REC_PAD;
             if (w + 4u <= B.subcap && !(B.dbg & 2)) {
                 const size_t at = GBN_RECIDX(B, b, blockIdx.x, w);
                 *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = h4;
@@ -1413,7 +1413,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     // the last, incomplete line of every stream: padded with flagged records
     for (uint32_t i = tid; i < (uint32_t)nb * LINE; i += GBN_SORT_THREADS) {
         const uint32_t b = i / LINE, s = i % LINE;
-        if (s >= s_cc[b]) s_all[TILE + b * LINE + s] = make_uint2(0x80000000u, 0xffffu);
+        if (s >= s_cc[b]) s_all[TILE + b * LINE + s] = make_uint2(GBN_REC_PAD, 0xffffu);
     }
     __syncthreads();
     for (uint32_t i = tid; i < (uint32_t)nb * LP; i += GBN_SORT_THREADS) {
@@ -1484,16 +1484,16 @@ probe_bin_kernel(GbnBinParams B)
     const GbnScanParams &P = B.S;
     extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
     uint32_t *s_tab = s_dyn;                                        // GBN_BIN_CELLS entries
-    uint2 *s_q = reinterpret_cast<uint2 *>(s_dyn + GBN_BIN_CELLS);   // [16 waves][QCAP]; a wave's queue is touched by that wave only
-    uint16_t *s_side = reinterpret_cast<uint16_t *>(s_dyn + GBN_BIN_CELLS + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2);
-    uint32_t *s_rcount = s_dyn + GBN_BIN_CELLS + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2 + GBN_BIN_SIDE / 2;
+    uint2 *s_q = reinterpret_cast<uint2 *>(s_dyn + GBN_BIN_TABW);    // [16 waves][QCAP]; a wave's queue is touched by that wave only
+    uint16_t *s_side = reinterpret_cast<uint16_t *>(s_dyn + GBN_BIN_TABW + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2);
+    uint32_t *s_rcount = s_dyn + GBN_BIN_TABW + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2 + GBN_BIN_SIDE / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = blockIdx.x & (GBN_BIN_GROUPS - 1);
     const int wi = blockIdx.x >> 3, nw = gridDim.x >> 3;            // workgroup index inside its group
     const int cbits = B.cbits;
     const uint32_t ncell_bin = 1u << cbits;
     GbnU2 *myq = B.rareq + (size_t)blockIdx.x * B.rare_seg;          // this workgroup's segment: no global atomics
-    if (tid == 0) *s_rcount = 0;
+    if (tid == 0) { *s_rcount = 0; s_tab[GBN_BIN_CELLS] = 0; }      // the empty cell pad records point at
     // masks of the reduced fingerprint test; a zero mask makes that side "always matches"
     const uint32_t lmask = (B.rfl <= 0) ? 0u : ((1u << (2 * B.rfl)) - 1);                               // byte 0 of an fp15
     const uint32_t rmask = (B.rfrbits <= 0) ? 0u : (((1u << B.rfrbits) - 1) << (7 - B.rfrbits));      // byte 1
@@ -1570,7 +1570,7 @@ probe_bin_kernel(GbnBinParams B)
             const uint32_t rbase = (uint32_t)w * B.subcap + lo;     // of this piece inside the bin's region
             // software pipeline: the loads of the next round are in flight while this round's
             // records are looked up
-            const uint4 padv = make_uint4(0x80000000u, 0x80000000u, 0x80000000u, 0x80000000u);
+            const uint4 padv = make_uint4(GBN_REC_PAD, GBN_REC_PAD, GBN_REC_PAD, GBN_REC_PAD);
             uint4 cur[U], nxt[U];
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
@@ -1591,21 +1591,25 @@ probe_bin_kernel(GbnBinParams B)
                 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) { hv[4 * u] = cur[u].x; hv[4 * u + 1] = cur[u].y; hv[4 * u + 2] = cur[u].z; hv[4 * u + 3] = cur[u].w; }
                 #pragma unroll
-                for (uint32_t r = 0; r < NR; r++) tv[r] = s_tab[(hv[r] >> 15) & 0x7fffu];   // all LDS lookups first (a pad reads cell 0)
+                for (uint32_t r = 0; r < NR; r++) tv[r] = s_tab[(hv[r] >> 15) & 0xffffu];   // all LDS lookups first (a pad reads the empty extra cell)
                 // Both fingerprints of the cell word against the subject's in one go: a masked byte of
                 // (t ^ sf:sf) is zero iff that side matches; (x - 0x01010101) & ~x & 0x80808080 is nonzero
                 // iff some byte is zero.  One-entry cells hold their fingerprint twice.
-                uint32_t raw32 = 0, slowm = 0;
+                // lookup hits = entries of the cells hit: cells with one (c0) or two (c0 and c1) entries are
+                // counted as #c0 + #c1 - #(c1 only); the c1-only cells (three or more entries) all take the
+                // queue below, where they are subtracted again and their true size is added in flush()
+                uint32_t flags = 0, slowm = 0;
                 #pragma unroll
                 for (uint32_t r = 0; r < NR; r++) {
-                    const uint32_t t = ((int32_t)hv[r] < 0) ? 0u : tv[r];
+                    const uint32_t t = tv[r];
                     const uint32_t x = (t ^ ((hv[r] & 0x7fffu) * 0x10001u)) & m4;
                     const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;
                     const bool c0 = (t & 0x8000u) != 0, c1 = (int32_t)t < 0;
                     const bool slow = c0 ? (z != 0) : c1;
-                    raw32 += c0 ? (c1 ? 2u : 1u) : 0u;
+                    flags += (t >> 15) & 0x10001u;              // c0 in the low half, c1 in the high half
                     slowm |= slow ? (1u << r) : 0u;
                 }
+                uint32_t raw32 = (flags & 0xffffu) + (flags >> 16);
                 // queue the (few) records that need the rare path: one per lane and round
                 while (true) {
                     const unsigned long long m = __ballot(slowm != 0);
@@ -1618,6 +1622,7 @@ probe_bin_kernel(GbnBinParams B)
                         for (uint32_t k = 0; k < NR; k++) hi32 = (r == k) ? hv[k] : hi32;
                         const uint32_t t = s_tab[(hi32 >> 15) & 0x7fffu];
                         const bool many = ((t & 0x8000u) == 0);                         // only c1: three or more entries
+                        raw32 -= many ? 1u : 0u;
                         const int at = qn + __popcll(m & lt);
                         q[at].x = rbase + j0 + (r >> 2) * 256u + (uint32_t)lane * 4u + (r & 3u);
                         q[at].y = ((hi32 >> 15) & 0x7fffu) | ((hi32 & 0x7fffu) << 15) | (many ? 0x80000000u : 0u);
@@ -1703,7 +1708,7 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
     }
     if (ev) (void)hipEventRecord(ev[1], st);
     if (parts & 2) {
-        const size_t lds = (size_t)GBN_BIN_CELLS * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8 + (size_t)GBN_BIN_SIDE * 2 + 16;
+        const size_t lds = (size_t)GBN_BIN_TABW * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8 + (size_t)GBN_BIN_SIDE * 2 + 16;
         static bool attr_set = false;
         if (!attr_set) {
             e = hipFuncSetAttribute((const void *)probe_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
