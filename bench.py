@@ -176,7 +176,8 @@ def main():
     stage_achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
     traffic = None
     tf = os.path.join(ROOT, "profiles", "scan_traffic.json")
-    if os.path.exists(tf):
+    # the committed PMC passes were taken on the default workload (C2, full shard); other shapes: null
+    if os.path.exists(tf) and args.workload == "C2" and abs(algo_bytes / max(launches, 1) - 12.5e9) < 1e6:
         try:
             traffic = json.load(open(tf)).get(dom_name, {}).get("hbm_bytes_per_launch")
         except Exception:
