@@ -48,6 +48,17 @@ if r == 0:
     print("COLLECT_OK", len(got[0]))
 else:
     assert got is None
+# bench.py issues the merges of consecutive passes from one worker thread while the main thread scans
+from concurrent.futures import ThreadPoolExecutor
+pool = ThreadPoolExecutor(max_workers=1)
+futs = [pool.submit(shard.collect_on_root, shard_records(r), 2, 5, 0) for _ in range(3)]
+outs = [f.result() for f in futs]
+dist.barrier()
+if r == 0:
+    assert all(all(np.array_equal(a, b) for a, b in zip(o, want)) for o in outs)
+    print("THREADED_OK", len(outs))
+else:
+    assert all(o is None for o in outs)
 dist.destroy_process_group()
 '''
 
@@ -69,7 +80,7 @@ def run(extra_env=None):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     os.unlink(path)
     assert p.returncode == 0, p.stdout + p.stderr
-    assert "GATHER_OK" in p.stdout and "COLLECT_OK" in p.stdout
+    assert "GATHER_OK" in p.stdout and "COLLECT_OK" in p.stdout and "THREADED_OK" in p.stdout
     return p.stdout
 
 
