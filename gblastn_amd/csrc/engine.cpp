@@ -37,6 +37,15 @@ hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uin
 static thread_local std::string g_err;
 void set_error(const std::string &m) { g_err = m; }
 
+// GBN_TRACE=1: wall-clock marks of the host-side pipeline on stderr (ms since the first mark)
+static void trace_mark(const char *what) {
+    static const bool on = getenv("GBN_TRACE") && atoi(getenv("GBN_TRACE")) != 0;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[gbn trace] %9.3f ms  %s\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+}
+
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return GBN_ERR_HIP; } } while (0)
 
@@ -523,14 +532,22 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     GbnKeyParams K; std::memset(&K, 0, sizeof(K));
     K.seeds = seeds; K.n = n; K.key_scan = E.key_a; K.idx = E.idx_a;
     K.q_descending = (b.lut.type == GBN_LUT_MB); K.container_hash = b.container; K.diag_len = b.diag_len;
+    // key widths: the radix sorts stop at the top bit a key can have
+    auto bits_for = [](uint64_t below) { int k = 1; while (k < 63 && ((uint64_t)1 << k) < below) k++; return k; };
+    int32_t max_len = 1;
+    for (int32_t s = 0; s < db.num_seqs; s++) max_len = std::max(max_len, db.len[s]);
+    K.q_bits = std::min(32, bits_for((uint64_t)b.qlen + 1));
+    K.group_bits = b.container ? 9 : bits_for((uint64_t)std::max(b.diag_len, 2));
+    const int scan_bits = std::min(64, K.q_bits + bits_for((uint64_t)max_len + 1));
+    const int group_key_bits = std::min(64, K.group_bits + bits_for((uint64_t)db.num_seqs + 1));
     HIPCHK(launch_seed_keys(K, st));
     size_t tb = E.sort_tmp_bytes;
-    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, 64, st));
+    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, scan_bits, st));
     // idx_b = seed indices in scan order (s_scan, chain order), subjects interleaved
     K.idx = E.idx_b; K.key_group = E.key_a;
     HIPCHK(launch_group_keys(K, st));
     tb = E.sort_tmp_bytes;
-    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_b, E.idx_a, n, 64, st));
+    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_b, E.idx_a, n, group_key_bits, st));
     // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
 
     if (keep_stages) {
@@ -564,7 +581,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         X.cell_diag = E.cell_diag; X.cell_level = E.cell_level;
         X.cell_start = d->cell_start; X.ent = d->ent; X.cell_mask = (uint32_t)(b.lut.ncells - 1); X.lut = b.lut.lut;
         X.masked = b.lut.masked ? 1 : 0;
-        X.run_heads = E.idx_b; X.run_count = reinterpret_cast<uint32_t *>(ctr + 1);
+        X.run_heads = E.idx_b; X.run_count = reinterpret_cast<uint32_t *>(ctr + 1); X.group_bits = K.group_bits;
         X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
         HIPCHK(launch_diag_ungapped(X, st));
         HIPCHK(hipMemcpyAsync(&nih, ctr, sizeof(nih), hipMemcpyDeviceToHost, st));
@@ -591,7 +608,9 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     auto ms_since = [&](std::chrono::steady_clock::time_point t) {
         return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_stage = now();
+    trace_mark("range: scan starts");
     int rc = run_scan(b, db, s0, s1, diag, cnt, &bases);
+    trace_mark("scan done");
     if (rc == kSkewedRange) {
         // lookup words of this range pile up in a few bins: halve it (by packed size) until the repeat-rich
         // subjects sit in small ranges of their own, which the direct-probe kernel scans
@@ -646,8 +665,10 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     if (E.pending_uses_keys && (rc = wait_pending())) return rc;     // the sort buffers exist once
     unsigned long long nih = 0;
     if ((rc = seed_stage(b, db, res, diag, keep_stages, slot, E.seeds, n, E.counters + 2, E.stream, &nih))) return rc;
+    trace_mark("seed stage done (inline)");
     if (nih == 0) return GBN_OK;
     if ((rc = wait_pending())) return rc;                   // one gapped stage in flight at most
+    trace_mark("previous asynchronous stage finished");
     if (!overlap || keep_stages) return gapped_stage(b, db, s0, s1, res, diag, keep_stages, slot, nih, E.stream);
     E.slot ^= 1;
     E.pending_err.clear();
@@ -711,10 +732,11 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     G.scratch_per_thread = (int32_t)per_thread;
     const size_t budget_ints = (size_t)1 << 28;        // 1 GiB of scratch
     size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)nih, budget_ints / per_thread));
-    if (chunk * per_thread > E.gap_scratch_ints_s[slot]) {
+    const size_t scratch_ints = ((chunk + 63) & ~(size_t)63) * per_thread;     // whole waves (the DP kernel interleaves a wave's rows)
+    if (scratch_ints > E.gap_scratch_ints_s[slot]) {
         dev_free(E.gap_scratch_s[slot]);
-        if ((rc = dev_alloc(E.gap_scratch_s[slot], chunk * per_thread))) { E.gap_scratch_ints_s[slot] = 0; return rc; }
-        E.gap_scratch_ints_s[slot] = chunk * per_thread;
+        if ((rc = dev_alloc(E.gap_scratch_s[slot], scratch_ints))) { E.gap_scratch_ints_s[slot] = 0; return rc; }
+        E.gap_scratch_ints_s[slot] = scratch_ints;
     }
     G.scratch = E.gap_scratch_s[slot];
     for (size_t first = 0; first < (size_t)nih; first += chunk) {
@@ -724,7 +746,9 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     std::vector<GbnDevInitHit> hih((size_t)nih); std::vector<GbnDevGapped> hg((size_t)nih);
     HIPCHK(hipMemcpyAsync(hih.data(), E.ihits_s[slot], (size_t)nih * sizeof(GbnDevInitHit), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hg.data(), E.gapped_s[slot], (size_t)nih * sizeof(GbnDevGapped), hipMemcpyDeviceToHost, st));
+    trace_mark("gapped: kernels + copies queued");
     HIPCHK(hipStreamSynchronize(st));
+    trace_mark("gapped: kernels + copies done");
     if (diag) diag->gapped_stage_ms += ms_since(t_stage);
     t_stage = now();
 
@@ -795,6 +819,7 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         diag->gapped_extensions += dl.gapped_extensions; diag->good_extensions += dl.good_extensions; diag->seqs_passed += dl.seqs_passed;
     }
     if (diag) diag->host_stage_ms += ms_since(t_stage);
+    trace_mark("gapped: host replay done");
     return GBN_OK;
 }
 
@@ -981,14 +1006,26 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
         if (const char *e = getenv("GBN_RANGE_GIB")) range_gib = std::max(1, atoi(e));
         int64_t range_bytes = range_gib << 30;
         if (const char *e = getenv("GBN_RANGE_MIB")) range_bytes = (int64_t)std::max(1, atoi(e)) << 20;    // tests
+        // Hard limits of a range: packed bytes (scratch) and 32-bit position ids.  Seed-rich shapes (small
+        // stride) are cut into ~1 G scan positions, so that the seed / extension stages of one range run
+        // underneath the scan of the next.  Whatever number of ranges that takes, they are made equal:
+        // a big range followed by a small remainder would leave nothing to overlap with.
+        const int step = batch->lut.step;
+        int64_t tile_limit = ((int64_t)1 << (32 - GBN_BIN_TILE_BITS)) - 1;
+        if (step <= 4) tile_limit = std::min<int64_t>(tile_limit, (int64_t)1 << 17);
+        if (const char *e = getenv("GBN_RANGE_TILES")) tile_limit = std::max(1, atoi(e));                  // tests
+        auto tiles_of = [&](int32_t s) { return (int64_t)(db->len[s] / step) / GBN_BIN_TILE_POS + 1; };
+        int64_t all_bytes = 0, all_tiles = 0;
+        for (int32_t s = 0; s < db->num_seqs; s++) { all_bytes += (db->len[s] + 3) / 4; all_tiles += tiles_of(s); }
+        const int64_t nranges = std::max<int64_t>(1, std::max((all_bytes + range_bytes - 1) / range_bytes, (all_tiles + tile_limit - 1) / tile_limit));
+        const int64_t want_bytes = (all_bytes + nranges - 1) / nranges, want_tiles = (all_tiles + nranges - 1) / nranges;
         int32_t s0 = 0;
         while (s0 < db->num_seqs) {
             int32_t s1 = s0; int64_t acc = 0, tiles = 0;
-            const int step = batch->lut.step;
             while (s1 < db->num_seqs) {
-                int64_t nb = (db->len[s1] + 3) / 4;
-                int64_t nt = (db->len[s1] / step) / GBN_BIN_TILE_POS + 1;       // 32-bit position ids
-                if (s1 > s0 && (acc + nb > range_bytes || tiles + nt > (1 << (32 - GBN_BIN_TILE_BITS)) - 1)) break;
+                const int64_t nb = (db->len[s1] + 3) / 4, nt = tiles_of(s1);
+                if (s1 > s0 && (acc + nb > range_bytes || tiles + nt > tile_limit)) break;       // hard limits
+                if (s1 > s0 && (acc >= want_bytes || tiles >= want_tiles)) break;                // equal shares
                 acc += nb; tiles += nt; s1++;
             }
             if ((rc = search_range(*batch, *db, s0, s1, *results, diag, keep_stages, overlap))) return rc;

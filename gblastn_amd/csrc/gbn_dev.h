@@ -116,6 +116,7 @@ struct GbnKeyParams {
     const GbnDevSeed *seeds; int64_t n;
     uint64_t *key_scan; uint64_t *key_group; uint32_t *idx;
     int q_descending, container_hash, diag_len;
+    int q_bits, group_bits;     // key widths: query offsets < 2^q_bits, slots < 2^group_bits (the sorts stop at the keys' top bit)
 };
 
 // seeds per launch below which the diagonal kernel runs thread-per-seed instead of on compacted run heads
@@ -135,6 +136,7 @@ struct GbnExtParams {
     // re-check of seeds against the soft query masks (s_TypeOfWord): table membership tests
     const uint32_t *cell_start; const unsigned long long *ent; uint32_t cell_mask; int lut, masked;
     uint32_t *run_heads, *run_count;    // scratch: index of the first seed of every (subject, slot) run (n entries), their number
+    int32_t group_bits;                 // key_group = subject << group_bits | slot (0 is read as 32)
     GbnDevInitHit *ihits; unsigned long long *ihit_count; unsigned long long ihit_cap;
 };
 

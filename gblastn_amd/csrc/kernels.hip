@@ -252,8 +252,9 @@ extern "C" __global__ void seed_keys_kernel(GbnKeyParams K)
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= K.n) return;
     GbnDevSeed sd = K.seeds[i];
-    uint32_t qkey = K.q_descending ? (0xffffffffu - (uint32_t)sd.q_pos) : (uint32_t)sd.q_pos;
-    K.key_scan[i] = ((uint64_t)(uint32_t)sd.s_scan << 32) | qkey;
+    const uint32_t qmax = (K.q_bits >= 32) ? 0xffffffffu : ((1u << K.q_bits) - 1u);
+    uint32_t qkey = K.q_descending ? (qmax - (uint32_t)sd.q_pos) : (uint32_t)sd.q_pos;
+    K.key_scan[i] = ((uint64_t)(uint32_t)sd.s_scan << K.q_bits) | qkey;
     K.idx[i] = (uint32_t)i;
 }
 
@@ -265,7 +266,7 @@ extern "C" __global__ void group_keys_kernel(GbnKeyParams K)
     int32_t q = sd.q_pos - sd.ext_left, s = sd.s_scan - sd.ext_left;
     uint32_t grp = K.container_hash ? ((uint32_t)(s - q) & 511u)
                                     : ((uint32_t)(s + K.diag_len - q) & (uint32_t)(K.diag_len - 1));
-    K.key_group[i] = ((uint64_t)(uint32_t)sd.subj << 32) | grp;
+    K.key_group[i] = ((uint64_t)(uint32_t)sd.subj << K.group_bits) | grp;
 }
 
 // ---------------------------------------------------------------------------
@@ -382,17 +383,23 @@ __device__ bool type_of_word(const GbnExtParams &P, const uint8_t *__restrict__ 
 // exactly per subject: cells live in a scratch slice as long as the run.
 // compaction of the run heads, so that every lane of the replay kernel below has a run to work on
 // (with the 512-bucket hash container a run is ~n / (512 x subjects) seeds long)
-extern "C" __global__ void run_heads_kernel(GbnExtParams P)
+extern "C" __global__ void __launch_bounds__(1024) run_heads_kernel(GbnExtParams P)
 {
+    // one reservation per 1024-thread block (a single counter takes ~90 atomics per microsecond)
+    __shared__ uint32_t s_cnt[16], s_base;
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const bool head = i < P.n && (i == 0 || P.key_group[i - 1] != P.key_group[i]);
     const unsigned long long m = __ballot(head);
-    if (!m) return;
-    const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(P.run_count, (uint32_t)__popcll(m));
-    base = __shfl(base, leader);
-    if (head) P.run_heads[base + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)i;
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < 16; w++) { const uint32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
+        s_base = tot ? atomicAdd(P.run_count, tot) : 0u;
+    }
+    __syncthreads();
+    if (head) P.run_heads[s_base + s_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)i;
 }
 
 extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
@@ -410,7 +417,7 @@ extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
         i = P.run_heads[t];
         key = P.key_group[i];
     }
-    const int32_t subj_id = (int32_t)(key >> 32);
+    const int32_t subj_id = (int32_t)(key >> (P.group_bits ? P.group_bits : 32));
     const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
     const int32_t slen = P.len[subj_id];
     const int word = P.word;
@@ -733,22 +740,24 @@ struct GapDP { int32_t best, best_gap; };
 #define GBN_MININT (INT32_MIN / 2)
 
 // s_BlastAlignPackedNucl: forward reads query[q0+b] / subject[s0+a-1];
-// reverse reads query[N-1-b] / subject[M-a]
+// reverse reads query[N-1-b] / subject[M-a].  `sa` is this lane's column of a wave-interleaved array
+// (stride 64 cells, see dynprog_kernel).
 __device__ int32_t align_packed(const GbnGapParams &P, const uint8_t *q, const uint8_t *subj,
                                 int32_t q0, int32_t s0, int32_t N, int32_t M, int32_t *b_off, int32_t *a_off,
                                 bool reverse, GapDP *sa, int32_t cap, int *overflow)
 {
     const int32_t gap_open = P.gap_open, gap_extend = P.gap_extend, goe = gap_open + gap_extend;
+    auto SA = [&](int32_t b) -> GapDP & { return sa[(size_t)b * 64]; };
     int32_t x_dropoff = P.xdrop;
     *a_off = 0; *b_off = 0;
     if (x_dropoff < goe) x_dropoff = goe;
     if (N <= 0 || M <= 0) return 0;
     int32_t score = -goe, i;
-    sa[0].best = 0; sa[0].best_gap = -goe;
+    SA(0).best = 0; SA(0).best_gap = -goe;
     for (i = 1; i <= N; i++) {
         if (score < -x_dropoff) break;
         if (i >= cap) { *overflow = 1; return 0; }
-        sa[i].best = score; sa[i].best_gap = score - goe; score -= gap_extend;
+        SA(i).best = score; SA(i).best_gap = score - goe; score -= gap_extend;
     }
     int32_t b_size = i, best_score = 0, first_b = 0, last_b;
     for (int32_t a = 1; a <= M; a++) {
@@ -758,19 +767,19 @@ __device__ int32_t align_packed(const GbnGapParams &P, const uint8_t *q, const u
         last_b = first_b;
         for (int32_t b = first_b; b < b_size; b++) {
             const uint8_t bl = reverse ? q[N - 1 - b] : q[q0 + b];
-            int32_t sgc = sa[b].best_gap;
-            int32_t next = sa[b].best + row[bl];
+            int32_t sgc = SA(b).best_gap;
+            int32_t next = SA(b).best + row[bl];
             if (sc < sgc) sc = sgc;
             if (sc < sgr) sc = sgr;
             if (best_score - sc > x_dropoff) {
-                if (b == first_b) first_b++; else sa[b].best = GBN_MININT;
+                if (b == first_b) first_b++; else SA(b).best = GBN_MININT;
             } else {
                 last_b = b;
                 if (sc > best_score) { best_score = sc; *a_off = a; *b_off = b; }
                 sgr -= gap_extend; sgc -= gap_extend;
-                sa[b].best_gap = max(sc - goe, sgc);
+                SA(b).best_gap = max(sc - goe, sgc);
                 sgr = max(sc - goe, sgr);
-                sa[b].best = sc;
+                SA(b).best = sc;
             }
             sc = next;
         }
@@ -780,12 +789,12 @@ __device__ int32_t align_packed(const GbnGapParams &P, const uint8_t *q, const u
         } else {
             while (sgr >= (best_score - x_dropoff) && b_size <= N) {
                 if (b_size >= cap) { *overflow = 1; return 0; }
-                sa[b_size].best = sgr; sa[b_size].best_gap = sgr - goe; sgr -= gap_extend; b_size++;
+                SA(b_size).best = sgr; SA(b_size).best_gap = sgr - goe; sgr -= gap_extend; b_size++;
             }
         }
         if (b_size <= N) {
             if (b_size >= cap) { *overflow = 1; return 0; }
-            sa[b_size].best = GBN_MININT; sa[b_size].best_gap = GBN_MININT; b_size++;
+            SA(b_size).best = GBN_MININT; SA(b_size).best_gap = GBN_MININT; b_size++;
         }
     }
     return best_score;
@@ -806,7 +815,9 @@ extern "C" __global__ void dynprog_kernel(GbnGapParams P)
     int32_t q_off = h.q_off - qstart, s_off = h.s_off;
     const int32_t s_end = h.s_start + h.length;
     if (s_end >= s_off + 8) { s_off += 3; q_off += 3; }       // CORE/blast_gapalign.c:3494-3497
-    GapDP *sa = reinterpret_cast<GapDP *>(P.scratch + (size_t)i * P.scratch_per_thread);
+    // DP rows of the 64 lanes of a wave interleaved cell by cell (cell b of lane l at [b * 64 + l]): lanes
+    // walk their bands roughly in step, so a wave's accesses to cell b fall into one 512-byte stretch
+    GapDP *sa = reinterpret_cast<GapDP *>(P.scratch + (size_t)blockIdx.x * 64 * P.scratch_per_thread) + (threadIdx.x & 63);
     const int32_t cap = P.scratch_per_thread / 2;
     int overflow = 0;
     int32_t adj = 4 - (s_off & 3);
@@ -882,7 +893,7 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
     if (p.n < GBN_DIAG_COMPACT_MIN) { GbnExtParams q = p; q.run_heads = nullptr;
         hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, q);
         return hipGetLastError(); }
-    hipLaunchKernelGGL(run_heads_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+    hipLaunchKernelGGL(run_heads_kernel, dim3((unsigned)((p.n + 1023) / 1024)), dim3(1024), 0, st, p);
     // grid for the worst case (every seed its own run); threads past the run count leave at once
     hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
     return hipGetLastError();
