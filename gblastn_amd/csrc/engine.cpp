@@ -730,7 +730,7 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     }
     per_thread = (per_thread + 3) & ~(size_t)3;
     G.scratch_per_thread = (int32_t)per_thread;
-    const size_t budget_ints = (size_t)1 << 28;        // 1 GiB of scratch
+    const size_t budget_ints = (size_t)1 << 30;        // 4 GiB of scratch per slot: the kernel time is the longest extension of a launch, so few launches
     size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)nih, budget_ints / per_thread));
     const size_t scratch_ints = ((chunk + 63) & ~(size_t)63) * per_thread;     // whole waves (the DP kernel interleaves a wave's rows)
     if (scratch_ints > E.gap_scratch_ints_s[slot]) {
