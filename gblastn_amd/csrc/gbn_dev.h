@@ -48,6 +48,9 @@ struct GbnScanParams {
 #ifndef GBN_BIN_CARRY
 #define GBN_BIN_CARRY 2         // 2: line-exact binning kernel (open lines in LDS, 8192-position tiles); 0: padded runs, 16384-position tiles
 #endif
+#ifndef GBN_OPEN_LINE
+#define GBN_OPEN_LINE 16        // records per stored piece of the line-exact binning kernel (64 bytes of hi words + 32 of indices)
+#endif
 // cursor table resolution: one entry per 2^GBN_TCUR_SHIFT tiles of a (bin, writer) stream; the low bits of the
 // tile's sequence number then travel in the spare top bits of every record's 16-bit index
 #define GBN_TCUR_SHIFT (GBN_BIN_CARRY ? 3 : 0)

@@ -1222,7 +1222,7 @@ template <int STEP>
 __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
 {
     const GbnScanParams &P = B.S;
-    constexpr int TILE = GBN_BIN_TILE_POS, PER = TILE / GBN_SORT_THREADS, LINE = 16, LP = LINE / 4;    // LP lanes store one line
+    constexpr int TILE = GBN_BIN_TILE_POS, PER = TILE / GBN_SORT_THREADS, LINE = GBN_OPEN_LINE, LP = LINE / 4;    // LP lanes store one line
     static_assert(PER == 8 && GBN_SORT_THREADS == 1024, "line variant: 8192-position tiles, 1024 threads");
     // records in LDS are 8 bytes: .x = hi word, .y = index in the tile.  [0, TILE): staging, bin-sorted;
     // [TILE, TILE + bins * LINE): one line under construction per bin

@@ -301,16 +301,22 @@ db, queries, plants, subjects, opt = util.small_case(40, 60_000_0, 200)
 src = api.BlastSeqSrc.from_packed(subjects)
 ps = api.BlastPrelimSearch(queries, opt, src)
 h = ps.run()["hsps"]
-print(json.dumps([h.tobytes().hex(), int(ps.diagnostics.scan_launches), int(ps.diagnostics.lookup_hits)]))
+launches, hits = int(ps.diagnostics.scan_launches), int(ps.diagnostics.lookup_hits)
+# the pipelined entry points: every range's seed + extension stages run on the second stream
+# underneath the scan of the next range, results appended range by range
+ps.begin(); h2 = ps.end()["hsps"]
+assert h2.tobytes() == h.tobytes()
+print(json.dumps([h.tobytes().hex(), launches, hits]))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for tag, env_add in (("one", {}), ("many", {"GBN_RANGE_MIB": "1"})):
+    for tag, env_add in (("one", {}), ("many", {"GBN_RANGE_MIB": "1"}), ("tiles", {"GBN_RANGE_TILES": "3"})):
         env = dict(os.environ); env.update(env_add)
         p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
         assert p.returncode == 0, p.stderr[-2000:]
         out[tag] = json.loads(p.stdout.strip().splitlines()[-1])
-    assert out["one"][1] == 1 and out["many"][1] > 3
+    assert out["one"][1] == 1 and out["many"][1] > 3 and out["tiles"][1] > 3
     assert out["one"][0] == out["many"][0] and out["one"][2] == out["many"][2]
+    assert out["one"][0] == out["tiles"][0] and out["one"][2] == out["tiles"][2]
 
 
 def test_interrupt_callback_stops_between_ranges():
