@@ -66,7 +66,7 @@ EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_de
            "gbn_results_free", "gbn_results_clear", "gbn_results_num_hsps", "gbn_results_hsps",
            "gbn_results_num_seeds", "gbn_results_seeds", "gbn_results_num_init_hits",
            "gbn_results_init_hits", "gbn_prelim_search", "gbn_scan_only", "gbn_last_error",
-           "gbn_launch_scan_seed", "gbn_launch_ungapped", "gbn_launch_gapped",
+           "gbn_launch_scan_seed", "gbn_launch_ungapped", "gbn_launch_gapped", "gbn_batch_karlin_gapped",
            "gbn_prelim_search_begin", "gbn_prelim_search_end", "gbn_prelim_hitlist_size", "gbn_collector_new", "gbn_collector_free", "gbn_collector_write",
            "gbn_collector_close", "gbn_collector_num_lists", "gbn_collector_list_starts",
            "gbn_collector_list_queries", "gbn_collector_num_hsps", "gbn_collector_hsps",

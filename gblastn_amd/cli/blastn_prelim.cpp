@@ -1,0 +1,233 @@
+// blastn_prelim -- the reference's `blastn` command line for the stage this library replaces.
+//
+// Same flag spelling as G-BLASTN's blastn (c++/src/algo/blast/blastinput/cmdline_flags.cpp:40-230,
+// blast_args.cpp:2473-2550 for -use_gpu / -gpu_id / -mode / -query_list; shell/g.m.sh is the usage
+// the reference documents): FASTA queries against a BLAST nucleotide database (v4 .nal/.nin/.nsq),
+// default DUST soft masking, reference batch sizes (5 Mb megablast, 100 kb blastn:
+// API/blast_options_cxx / split_query "GetQueryBatchSize"), database volumes loaded as one HBM shard.
+// It stops where the preliminary search stops: the table it prints holds the score-only gapped HSPs
+// that survive the per-query top-N collector (CBlastPrelimSearch::Run + BlastHSPStream), not the
+// traceback alignments -- identities, mismatches and gap counts do not exist at this stage.
+// Everything goes through the C ABI of include/gblastn_amd.h; no CPU fallback (-use_gpu false is refused).
+#include "gblastn_amd.h"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Query { std::string id; std::vector<uint8_t> seq; };
+
+// IUPACna -> BLASTNA (COREI/blast_encoding.c IUPACNA_TO_BLASTNA): ACGT RYMK WSBD HVN-
+int blastna_of(char c)
+{
+    switch (c >= 'a' && c <= 'z' ? c - 32 : c) {
+    case 'A': return 0; case 'C': return 1; case 'G': return 2; case 'T': case 'U': return 3;
+    case 'R': return 4; case 'Y': return 5; case 'M': return 6; case 'K': return 7;
+    case 'W': return 8; case 'S': return 9; case 'B': return 10; case 'D': return 11;
+    case 'H': return 12; case 'V': return 13; case 'N': return 14; case '-': return 15;
+    default: return -1;
+    }
+}
+
+bool read_fasta(const std::string &path, std::vector<Query> &out, std::string &err)
+{
+    std::ifstream f(path);
+    if (!f) { err = "cannot open query file " + path; return false; }
+    std::string line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty()) continue;
+        if (line[0] == '>') {
+            Query q; std::istringstream is(line.substr(1)); is >> q.id;
+            if (q.id.empty()) q.id = "Query_" + std::to_string(out.size() + 1);
+            out.push_back(std::move(q));
+            continue;
+        }
+        if (out.empty()) { Query q; q.id = "Query_1"; out.push_back(std::move(q)); }
+        for (char c : line) {
+            if (c == ' ' || c == '\t' || (c >= '0' && c <= '9')) continue;
+            const int v = blastna_of(c);
+            if (v < 0) { err = std::string("bad residue '") + c + "' in " + path; return false; }
+            out.back().seq.push_back((uint8_t)v);
+        }
+    }
+    return true;
+}
+
+[[noreturn]] void die(const std::string &m) { std::fprintf(stderr, "blastn_prelim: %s\n", m.c_str()); std::exit(1); }
+void check(int rc, const char *what) { if (rc) die(std::string(what) + ": " + gbn_last_error()); }
+
+const char *kUsage =
+    "usage: blastn_prelim -db NAME (-query FASTA | -query_list FILE) -use_gpu true [-gpu_id N] [-out FILE]\n"
+    "       [-task megablast|blastn] [-word_size N] [-evalue X] [-reward N] [-penalty N] [-gapopen N]\n"
+    "       [-gapextend N] [-dust yes|no|'level window linker'] [-max_target_seqs N] [-outfmt 6|7] [-mode 1|2]\n";
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    std::map<std::string, std::string> a;
+    for (int i = 1; i < argc; i++) {
+        std::string k = argv[i];
+        if (k == "-h" || k == "-help") { std::fputs(kUsage, stdout); return 0; }
+        if (k.size() < 2 || k[0] != '-' || i + 1 >= argc) die("bad argument '" + k + "'\n" + kUsage);
+        a[k.substr(1)] = argv[++i];
+    }
+    auto get = [&](const char *k, const std::string &d) { auto it = a.find(k); return it == a.end() ? d : it->second; };
+    if (!a.count("db") || (!a.count("query") && !a.count("query_list"))) die(std::string("-db and -query are required\n") + kUsage);
+    const std::string gpu = get("use_gpu", "true");
+    if (!(gpu == "true" || gpu == "T" || gpu == "1" || gpu == "yes")) die("this build has no CPU path: -use_gpu true is required");
+    const std::string task = get("task", "megablast");
+    if (task != "megablast" && task != "blastn") die("-task must be megablast or blastn (discontiguous megablast is not supported, as in G-BLASTN)");
+
+    // ---- queries ----
+    std::vector<std::string> files;
+    if (a.count("query")) files.push_back(a["query"]);
+    if (a.count("query_list")) {
+        std::ifstream l(a["query_list"]);
+        if (!l) die("cannot open query list " + a["query_list"]);
+        std::string p; while (std::getline(l, p)) if (!p.empty()) files.push_back(p);
+    }
+    std::vector<Query> queries; std::string err;
+    for (auto &f : files) if (!read_fasta(f, queries, err)) die(err);
+    if (queries.empty()) die("no query sequences");
+
+    // ---- database: every volume into one resident shard ----
+    check(Blast_gpu_Init(1, std::atoi(get("gpu_id", "-1").c_str())), "Blast_gpu_Init");
+    GbnBlastDb *bdb = nullptr;
+    check(gbn_blastdb_open(&bdb, a["db"].c_str()), "gbn_blastdb_open");
+    GbnDb *shard = nullptr;
+    check(gbn_blastdb_load_shard(bdb, 0, gbn_blastdb_num_seqs(bdb), &shard), "gbn_blastdb_load_shard");
+
+    // ---- options (API/blast_nucl_options.cpp defaults of the task, then the flags) ----
+    GbnOptions opt; gbn_default_options(&opt, task == "megablast");
+    if (a.count("word_size")) opt.word_size = std::atoi(a["word_size"].c_str());
+    if (a.count("evalue")) opt.evalue = std::atof(a["evalue"].c_str());
+    if (a.count("reward")) opt.reward = std::atoi(a["reward"].c_str());
+    if (a.count("penalty")) opt.penalty = std::atoi(a["penalty"].c_str());
+    if (a.count("gapopen")) opt.gap_open = std::atoi(a["gapopen"].c_str());
+    if (a.count("gapextend")) opt.gap_extend = std::atoi(a["gapextend"].c_str());
+    if (a.count("max_target_seqs")) opt.hitlist_size = std::atoi(a["max_target_seqs"].c_str());
+    if (a.count("xdrop_ungap")) opt.xdrop_ungap_bits = std::atof(a["xdrop_ungap"].c_str());
+    if (a.count("xdrop_gap")) opt.xdrop_gap_bits = std::atof(a["xdrop_gap"].c_str());
+    if (opt.penalty > 0) opt.penalty = -opt.penalty;
+    // statistics over the alias file's totals when it states them (DBLIST files with STATS_*), else the database's
+    const int64_t stat_len = gbn_blastdb_stat_length(bdb); const int32_t stat_n = gbn_blastdb_stat_num_seqs(bdb);
+    opt.db_length = stat_len > 0 ? stat_len : gbn_blastdb_total_length(bdb);
+    opt.db_num_seqs = stat_n > 0 ? stat_n : gbn_blastdb_num_seqs(bdb);
+
+    int dust_level = 20, dust_window = 64, dust_linker = 1; bool dust = true;       // blastn's default filter
+    {
+        const std::string d = get("dust", "yes");
+        if (d == "no" || d == "false") dust = false;
+        else if (d != "yes" && d != "true") {
+            std::istringstream is(d);
+            if (!(is >> dust_level >> dust_window >> dust_linker)) die("-dust takes yes, no or 'level window linker'");
+        }
+    }
+    const int outfmt = std::atoi(get("outfmt", "6").c_str());
+    if (outfmt != 6 && outfmt != 7) die("-outfmt 6 or 7 (tabular, preliminary HSPs)");
+    const bool pipelined = get("mode", "1") != "1";
+
+    FILE *out = stdout;
+    if (a.count("out")) { out = std::fopen(a["out"].c_str(), "w"); if (!out) die("cannot write " + a["out"]); }
+
+    // ---- query batches of the reference's size ----
+    const int64_t batch_bases = task == "megablast" ? 5000000 : 100000;
+    struct Batch { size_t first, count; GbnBatch *b = nullptr; GbnResults *r = nullptr; };
+    std::vector<Batch> batches;
+    for (size_t i = 0; i < queries.size();) {
+        Batch bt; bt.first = i; int64_t acc = 0;
+        while (i < queries.size() && (i == bt.first || acc + (int64_t)queries[i].seq.size() <= batch_bases)) acc += (int64_t)queries[i++].seq.size();
+        bt.count = i - bt.first;
+        batches.push_back(bt);
+    }
+    auto build = [&](Batch &bt) {
+        std::vector<const uint8_t *> seqs; std::vector<int32_t> lens, mq, mf, mt;
+        for (size_t k = 0; k < bt.count; k++) {
+            const Query &q = queries[bt.first + k];
+            seqs.push_back(q.seq.data()); lens.push_back((int32_t)q.seq.size());
+            if (dust && !q.seq.empty()) {
+                std::vector<int32_t> f(q.seq.size() / 2 + 2), t(f.size());
+                const int32_t n = gbn_dust_mask(q.seq.data(), (int32_t)q.seq.size(), dust_level, dust_window, dust_linker, f.data(), t.data(), (int32_t)f.size());
+                for (int32_t j = 0; j < n && j < (int32_t)f.size(); j++) { mq.push_back((int32_t)k); mf.push_back(f[(size_t)j]); mt.push_back(t[(size_t)j]); }
+            }
+        }
+        check(gbn_batch_new_masked(&bt.b, &opt, (int32_t)bt.count, seqs.data(), lens.data(), (int32_t)mq.size(), mq.data(), mf.data(), mt.data(), 1), "gbn_batch_new_masked");
+        check(gbn_results_new(&bt.r), "gbn_results_new");
+    };
+    // rows of one batch: the collector keeps the best lists per query; printed per query, best first
+    auto emit = [&](Batch &bt) {
+        GbnCollector *col = nullptr;
+        check(gbn_collector_new(&col, (int32_t)bt.count, opt.hitlist_size), "gbn_collector_new");
+        check(gbn_collector_write(col, gbn_results_hsps(bt.r), gbn_results_num_hsps(bt.r)), "gbn_collector_write");
+        check(gbn_collector_close(col), "gbn_collector_close");
+        const int64_t nl = gbn_collector_num_lists(col); const int64_t *st = gbn_collector_list_starts(col);
+        const int32_t *lq = gbn_collector_list_queries(col); const GbnHSP *h = gbn_collector_hsps(col);
+        const GbnContext *ctx = gbn_batch_contexts(bt.b);
+        double lambda = 0, K = 0; gbn_batch_karlin_gapped(bt.b, &lambda, &K);
+        std::vector<std::vector<int64_t>> per((size_t)bt.count);
+        for (int64_t l = 0; l < nl; l++) per[(size_t)lq[l]].push_back(l);
+        for (size_t k = 0; k < bt.count; k++) {
+            const Query &q = queries[bt.first + k];
+            auto &ls = per[k];
+            std::stable_sort(ls.begin(), ls.end(), [&](int64_t x, int64_t y) {
+                const GbnHSP &u = h[st[x]], &v = h[st[y]];
+                if (u.evalue != v.evalue) return u.evalue < v.evalue;
+                if (u.score != v.score) return u.score > v.score;
+                return u.oid < v.oid; });
+            if (outfmt == 7) {
+                std::fprintf(out, "# BLASTN preliminary search (gblastn_amd)\n# Query: %s\n# Database: %s\n", q.id.c_str(), a["db"].c_str());
+                std::fprintf(out, "# Fields: query id, subject oid, q. start, q. end, s. start, s. end, evalue, bit score, score, strand\n# %zu subjects\n", ls.size());
+            }
+            for (int64_t l : ls)
+                for (int64_t i = st[l]; i < st[l + 1]; i++) {
+                    const GbnHSP &x = h[i];
+                    const bool minus = (x.context & 1) != 0;
+                    const int32_t qlen = ctx[x.context].query_length;
+                    // plus/minus presentation of the formatter: query always forward, subject reversed for minus hits
+                    const int32_t qs = minus ? qlen - x.q_end + 1 : x.q_offset + 1, qe = minus ? qlen - x.q_offset : x.q_end;
+                    const int32_t ss = minus ? x.s_end : x.s_offset + 1, se = minus ? x.s_offset + 1 : x.s_end;
+                    const double bits = (lambda * x.score - std::log(K)) / std::log(2.0);
+                    std::fprintf(out, "%s\t%d\t%d\t%d\t%d\t%d\t%.3g\t%.1f\t%d\t%s\n", q.id.c_str(), x.oid, qs, qe, ss, se,
+                                 x.evalue, bits, x.score, minus ? "minus" : "plus");
+                }
+        }
+        gbn_collector_free(col);
+    };
+
+    GbnDiagnostics diag; std::memset(&diag, 0, sizeof(diag));
+    if (!pipelined) {
+        for (auto &bt : batches) {
+            build(bt);
+            check(gbn_prelim_search(bt.b, shard, bt.r, &diag, 0, nullptr, nullptr), "gbn_prelim_search");
+            emit(bt);
+            gbn_batch_free(bt.b); gbn_results_free(bt.r);
+        }
+    } else {
+        // -mode 2: the extension stages of batch k run underneath the scan of batch k+1
+        Batch *prev = nullptr;
+        for (auto &bt : batches) {
+            build(bt);
+            check(gbn_prelim_search_begin(bt.b, shard, bt.r, &diag, nullptr, nullptr), "gbn_prelim_search_begin");
+            if (prev) { check(gbn_prelim_search_end(prev->r), "gbn_prelim_search_end"); emit(*prev); gbn_batch_free(prev->b); gbn_results_free(prev->r); }
+            prev = &bt;
+        }
+        if (prev) { check(gbn_prelim_search_end(prev->r), "gbn_prelim_search_end"); emit(*prev); gbn_batch_free(prev->b); gbn_results_free(prev->r); }
+    }
+    std::fprintf(stderr, "blastn_prelim: %zu queries in %zu batches, %lld subject bases scanned, %lld seeds, %lld gapped extensions, %.1f ms\n",
+                 queries.size(), batches.size(), (long long)diag.subject_bases_scanned, (long long)diag.seeds,
+                 (long long)diag.gapped_extensions, diag.total_ms);
+    if (out != stdout) std::fclose(out);
+    gbn_db_free(shard); gbn_blastdb_close(bdb); Blast_gpu_Release();
+    return 0;
+}

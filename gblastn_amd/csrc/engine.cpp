@@ -966,6 +966,11 @@ int gbn_launch_gapped(const GbnGapParams *p, int greedy, void *stream) {
 void gbn_batch_free(GbnBatch *b) { if (!b) return; free_device_batch(b->dev); delete b; }
 int32_t gbn_batch_num_contexts(const GbnBatch *b) { return (int32_t)b->ctx.size(); }
 const GbnContext *gbn_batch_contexts(const GbnBatch *b) { return b->ctx.data(); }
+int gbn_batch_karlin_gapped(const GbnBatch *b, double *lambda, double *K) {
+    if (!b || !lambda || !K) { set_error("bad argument"); return GBN_ERR_ARG; }
+    *lambda = b->kbp_gap.lambda; *K = b->kbp_gap.K;
+    return GBN_OK;
+}
 int32_t gbn_batch_lut_type(const GbnBatch *b) { return b->lut.type; }
 int32_t gbn_batch_lut_width(const GbnBatch *b) { return b->lut.lut; }
 int32_t gbn_batch_scan_step(const GbnBatch *b) { return b->lut.step; }

@@ -205,6 +205,9 @@ int32_t gbn_dust_mask(const uint8_t *seq, int32_t len, int32_t level, int32_t wi
 void gbn_batch_free(GbnBatch *b);
 int32_t gbn_batch_num_contexts(const GbnBatch *b);
 const GbnContext *gbn_batch_contexts(const GbnBatch *b);
+/* gapped Karlin-Altschul parameters of the batch's scoring system (Blast_KarlinBlkNuclGappedCalc,
+ * CORE/blast_stat.c:3718-3810): bit score = (lambda * score - ln K) / ln 2 */
+int  gbn_batch_karlin_gapped(const GbnBatch *b, double *lambda, double *K);
 int32_t gbn_batch_lut_type(const GbnBatch *b);
 int32_t gbn_batch_lut_width(const GbnBatch *b);
 int32_t gbn_batch_scan_step(const GbnBatch *b);
