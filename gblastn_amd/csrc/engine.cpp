@@ -465,7 +465,9 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             HIPCHK(hipMemcpyAsync(&overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
         }
         HIPCHK(hipMemcpyAsync(cnt, E.counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, E.stream));
+        trace_mark("scan: kernels queued");
         HIPCHK(hipStreamSynchronize(E.stream));
+        trace_mark("scan: kernels done");
         if (diag) {
             float ms = 0; (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
             diag->scan_kernel_ms += ms; diag->scan_launches++;
@@ -994,6 +996,7 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(E.mu);
     auto t0 = std::chrono::steady_clock::now();
+    trace_mark("search: entered");
     if (batch->opt.db_num_seqs == 0) {
         // "db_length == 0" branch of the engine: effective lengths and cut-offs are
         // recomputed for every subject (CORE/blast_setup.c:905-932)
@@ -1039,6 +1042,7 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
         }
     }
     if (diag) diag->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    trace_mark("search: returns");
     return GBN_OK;
 }
 
