@@ -1455,8 +1455,11 @@ extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan
 
 namespace {
 // rare path of the probe kernel: full fingerprints, chain walk, exact verification
+// Seeds go to P.seeds through one wave-aggregated reservation per loop round, or -- when the caller passes
+// an LDS staging buffer (`s_buf`, `s_n`, capacity `cap`) -- are collected there first and flushed by the
+// whole workgroup (dense-seed shapes: a single counter takes only ~90 reservations per microsecond).
 __device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell, bool count_raw,
-                           unsigned long long &raw)
+                           unsigned long long &raw, GbnDevSeed *s_buf = nullptr, uint32_t *s_n = nullptr, uint32_t cap = 0)
 {
     const uint32_t start = P.cell_start[cell], end = P.cell_start[cell + 1];
     if (count_raw) raw += end - start;
@@ -1477,12 +1480,22 @@ __device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell
         const unsigned long long okm = __ballot(el >= 0);
         if (okm) {
             const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)okm) - 1;
-            unsigned long long base = 0;
-            if (lane == leader) base = atomicAdd(P.seed_count, (unsigned long long)__popcll(okm));
-            base = __shfl(base, leader);
-            if (el >= 0) {
-                const unsigned long long o = base + (unsigned long long)__popcll(okm & ((1ull << lane) - 1));
-                if (o < P.seed_cap) { GbnDevSeed sd; sd.subj = T.subj; sd.s_scan = s; sd.q_pos = q; sd.ext_left = el; P.seeds[o] = sd; }
+            const uint32_t mine = (uint32_t)__popcll(okm & ((1ull << lane) - 1)), cnt = (uint32_t)__popcll(okm);
+            GbnDevSeed sd; sd.subj = T.subj; sd.s_scan = s; sd.q_pos = q; sd.ext_left = el;
+            // staging: the wave's seeds take slots [lbase, lbase + cnt); whatever falls past the capacity
+            // goes straight to the global array, so the staged part never has holes
+            uint32_t lbase = cap;
+            if (s_buf) {
+                if (lane == leader) lbase = atomicAdd(s_n, cnt);
+                lbase = min(__shfl(lbase, leader), cap);
+            }
+            const uint32_t staged_n = min(cnt, cap - lbase);
+            if (el >= 0 && mine < staged_n) s_buf[lbase + mine] = sd;
+            if (staged_n < cnt) {
+                unsigned long long base = 0;
+                if (lane == leader) base = atomicAdd(P.seed_count, (unsigned long long)(cnt - staged_n));
+                base = __shfl(base, leader);
+                if (el >= 0 && mine >= staged_n) { const unsigned long long o = base + (mine - staged_n); if (o < P.seed_cap) P.seeds[o] = sd; }
             }
         }
     }
@@ -1666,7 +1679,32 @@ probe_rare_kernel(GbnBinParams B, int nseg)
     const int seg = blockIdx.x % nseg, part = blockIdx.x / nseg, nparts = gridDim.x / nseg;
     const uint32_t n = min(B.rare_counts[seg], B.rare_seg);
     const GbnU2 *qs = B.rareq + (size_t)seg * B.rare_seg;
-    for (uint32_t i = (uint32_t)part * 256u + threadIdx.x; i < n; i += (uint32_t)nparts * 256u) {
+    // dense-seed shapes (lut == word: every lookup hit is a seed) stage their seeds in LDS
+    constexpr uint32_t CAP = 1536;
+    __shared__ GbnDevSeed s_buf[CAP];
+    __shared__ uint32_t s_n, s_flush_at;
+    const bool staged = (P.fl == 0 && P.fr == 0);
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    auto flush = [&]() {                                        // whole workgroup, after a barrier
+        const uint32_t have = min(s_n, CAP);
+        if (threadIdx.x == 0 && have) {
+            const unsigned long long at = atomicAdd(P.seed_count, (unsigned long long)have);
+            s_flush_at = (uint32_t)min(at, (unsigned long long)0xffffffffu);
+        }
+        __syncthreads();
+        if (have) {
+            const unsigned long long at = s_flush_at;
+            for (uint32_t k = threadIdx.x; k < have; k += blockDim.x) if (at + k < P.seed_cap) P.seeds[at + k] = s_buf[k];
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    };
+    for (uint32_t i0 = (uint32_t)part * 256u; i0 < n; i0 += (uint32_t)nparts * 256u) {     // uniform over the workgroup
+        if (staged) { __syncthreads(); if (s_n > CAP - 512u) flush(); }      // s_n is stable between the barriers
+        const uint32_t i = i0 + threadIdx.x;
+        if (i >= n) continue;
         uint32_t pid = qs[i].x; const uint32_t cv = qs[i].y;
 #if GBN_REC_BYTES == 6
         {   // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
@@ -1690,8 +1728,10 @@ probe_rare_kernel(GbnBinParams B, int nseg)
             pid = ((wr + seqn * (uint32_t)B.nwriters) << GBN_BIN_TILE_BITS) | (idx & (uint32_t)(GBN_BIN_TILE_POS - 1));
         }
 #endif
-        probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
+        if (staged) probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw, s_buf, &s_n, CAP);
+        else probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
     }
+    if (staged) { __syncthreads(); flush(); }
     if (P.raw_hits) {
         for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
         if ((threadIdx.x & 63) == 0 && raw) atomicAdd(P.raw_hits, raw);
