@@ -69,7 +69,8 @@ void check(int rc, const char *what) { if (rc) die(std::string(what) + ": " + gb
 const char *kUsage =
     "usage: blastn_prelim -db NAME (-query FASTA | -query_list FILE) -use_gpu true [-gpu_id N] [-out FILE]\n"
     "       [-task megablast|blastn] [-word_size N] [-evalue X] [-reward N] [-penalty N] [-gapopen N]\n"
-    "       [-gapextend N] [-dust yes|no|'level window linker'] [-max_target_seqs N] [-outfmt 6|7] [-mode 1|2]\n";
+    "       [-gapextend N] [-dust yes|no|'level window linker'] [-max_target_seqs N] [-outfmt 6|7] [-mode 1|2]\n"
+    "       [-num_threads N (ignored)] [-strand both]; environment BATCH_SIZE overrides the query batch size\n";
 
 }  // namespace
 
@@ -137,12 +138,18 @@ int main(int argc, char **argv)
     const int outfmt = std::atoi(get("outfmt", "6").c_str());
     if (outfmt != 6 && outfmt != 7) die("-outfmt 6 or 7 (tabular, preliminary HSPs)");
     const bool pipelined = get("mode", "1") != "1";
+    if (get("strand", "both") != "both") die("-strand: only both strands are searched (the batch always holds the two contexts of a query)");
+    // accepted for command-line compatibility, without effect here: the host side has no per-thread OID chunks
+    // (-num_threads), and window masker databases (-window_masker_db, shell/g.m.sh) are not read
+    for (const char *k : {"window_masker_db", "window_masker_taxid"}) if (a.count(k)) std::fprintf(stderr, "blastn_prelim: -%s is ignored (only DUST masking is built in)\n", k);
 
     FILE *out = stdout;
     if (a.count("out")) { out = std::fopen(a["out"].c_str(), "w"); if (!out) die("cannot write " + a["out"]); }
 
     // ---- query batches of the reference's size ----
-    const int64_t batch_bases = task == "megablast" ? 5000000 : 100000;
+    // GetQueryBatchSize (blastinput/blast_input_aux.cpp:66-124), including its BATCH_SIZE override
+    int64_t batch_bases = task == "megablast" ? 5000000 : 100000;
+    if (const char *e = std::getenv("BATCH_SIZE")) batch_bases = std::max(1, std::atoi(e));
     struct Batch { size_t first, count; GbnBatch *b = nullptr; GbnResults *r = nullptr; };
     std::vector<Batch> batches;
     for (size_t i = 0; i < queries.size();) {
