@@ -6,6 +6,7 @@
 // sbp, lookup_wrap): CORE/blast_setup.c:502-775, CORE/blast_parameters.c:160-470,
 // :822-979, CORE/blast_nalookup.c:51-189,384-427,831-1041, CORE/blast_lookup.c:87-137.
 #include "gbn_host.hpp"
+#include <thread>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
@@ -151,7 +152,9 @@ static void indexed_stretches(GbnBatch &b, const std::vector<QueryMask> &masks) 
     b.lut.masked = gap;
 }
 
-static void build_lookup(GbnBatch &b) {
+// table kind and width from the size estimate (the small-NA -> standard fallback needs the cell counts
+// and is applied by whoever fills the table: fill_lookup_host below, or the device builder)
+static void choose_table(GbnBatch &b) {
     HostLookup &L = b.lut;
     int32_t entries = 0, max_off = 0;                   // EstimateNumTableEntries, CORE/lookup_util.c:193-209
     for (auto &sg : L.segments) { entries += sg.second - sg.first; max_off = std::max(max_off, sg.second); }
@@ -159,6 +162,12 @@ static void build_lookup(GbnBatch &b) {
     L.type = choose_lookup(b.opt, entries, max_off, width);
     L.word = b.opt.word_size; L.lut = width; L.step = L.word - L.lut + 1;
     L.ncells = (int64_t)1 << (2 * width);
+    L.cell_start.clear(); L.cell_qoff.clear(); L.pv.clear();
+}
+
+void fill_lookup_host(GbnBatch &b) {
+    HostLookup &L = b.lut;
+    const int width = L.lut;
     const uint8_t *q = b.query();
     std::vector<uint32_t> count((size_t)L.ncells, 0);
     for (auto &sg : L.segments) each_query_word(q, sg.first, sg.second, L.word, width, [&](uint32_t cell, int32_t) { count[cell]++; });
@@ -184,8 +193,9 @@ static void build_lookup(GbnBatch &b) {
 }
 
 int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *const *seqs, const int32_t *lens,
-                const std::vector<QueryMask> &masks) {
+                const std::vector<QueryMask> &masks, bool host_tables) {
     b.opt = opt; b.nq = nq;
+    trace_mark("batch: set-up starts");
     b.ctx.assign((size_t)2 * nq, GbnContext{});
     const int32_t pad = 64;         // sentinel padding so kernels may read windows past either end
     int64_t total = 1;
@@ -206,6 +216,7 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
         off += L + 1;
     }
     b.qlen = off - 1;
+    trace_mark("batch: query concatenated");
     build_score_matrix(opt.reward, opt.penalty, b.matrix);
     for (int i = 0; i < 256; i++) {
         int32_t s = 0;
@@ -216,18 +227,34 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
         b.score_table[i] = s;
     }
     double stdc[16]; uniform_acgt(stdc);
-    bool any = false; Karlin first;
-    for (auto &c : b.ctx) {
-        c.is_valid = 1;
-        if (c.query_length <= 0) { c.is_valid = 0; continue; }
-        double comp[16]; strand_composition(q + c.query_offset, c.query_length, comp);
-        Karlin k;
-        if (!ungapped_karlin(opt.reward, opt.penalty, comp, stdc, k)) {
-            c.is_valid = 0; c.lambda_u = c.K_u = c.H_u = -1; continue;
+    // ungapped Karlin-Altschul parameters per context: independent, so a large batch spreads them over a few threads
+    auto ka_range = [&](size_t c0, size_t c1) {
+        for (size_t i = c0; i < c1; i++) {
+            GbnContext &c = b.ctx[i];
+            c.is_valid = 1;
+            if (c.query_length <= 0) { c.is_valid = 0; continue; }
+            double comp[16]; strand_composition(q + c.query_offset, c.query_length, comp);
+            Karlin k;
+            if (!ungapped_karlin(opt.reward, opt.penalty, comp, stdc, k)) {
+                c.is_valid = 0; c.lambda_u = c.K_u = c.H_u = -1; continue;
+            }
+            c.lambda_u = k.lambda; c.K_u = k.K; c.logK_u = k.logK; c.H_u = k.H;
         }
-        c.lambda_u = k.lambda; c.K_u = k.K; c.logK_u = k.logK; c.H_u = k.H;
-        if (!any) { first = k; any = true; }
+    };
+    {
+        const size_t nctx = b.ctx.size();
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t nthr = nctx < 512 ? 1 : std::min<size_t>({(size_t)hw, (size_t)16, nctx / 128});
+        if (nthr <= 1) ka_range(0, nctx);
+        else {
+            std::vector<std::thread> pool;
+            for (size_t t = 0; t < nthr; t++) pool.emplace_back(ka_range, nctx * t / nthr, nctx * (t + 1) / nthr);
+            for (auto &th : pool) th.join();
+        }
     }
+    bool any = false; Karlin first;
+    for (auto &c : b.ctx) if (c.is_valid) { first.lambda = c.lambda_u; first.K = c.K_u; first.logK = c.logK_u; first.H = c.H_u; any = true; break; }
+    trace_mark("batch: Karlin-Altschul per context done");
     if (!any) { set_error("no valid query context (Karlin-Altschul parameters)"); return GBN_ERR_SETUP; }
     if (gapped_karlin(opt.gap_open, opt.gap_extend, opt.reward, opt.penalty, first, b.kbp_gap, b.round_down)) {
         set_error("unsupported reward/penalty/gap cost combination"); return GBN_ERR_UNSUPPORTED;
@@ -249,8 +276,11 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
             set_error("query masks must be sorted by (query, from), disjoint and inside their query"); return GBN_ERR_ARG;
         }
     }
+    trace_mark("batch: cut-offs done");
     indexed_stretches(b, masks);
-    build_lookup(b);
+    choose_table(b);
+    if (host_tables) fill_lookup_host(b);
+    trace_mark(host_tables ? "batch: lookup table built" : "batch: table kind chosen (tables are built on the device)");
     b.lut.masked = b.lut.masked && b.lut.word > b.lut.lut;
     return GBN_OK;
 }

@@ -8,6 +8,7 @@
 //   -> D2H of initial hits + gapped results -> host replay (hsp_host.cpp).
 #include <hip/hip_runtime.h>
 #include "gbn_host.hpp"
+#include "lutbuild.h"
 #include "gbn_dev.h"
 #include "hsp_host.hpp"
 #include <algorithm>
@@ -38,7 +39,7 @@ static thread_local std::string g_err;
 void set_error(const std::string &m) { g_err = m; }
 
 // GBN_TRACE=1: wall-clock marks of the host-side pipeline on stderr (ms since the first mark)
-static void trace_mark(const char *what) {
+void trace_mark(const char *what) {
     static const bool on = getenv("GBN_TRACE") && atoi(getenv("GBN_TRACE")) != 0;
     if (!on) return;
     static const auto t0 = std::chrono::steady_clock::now();
@@ -135,24 +136,12 @@ static int upload_ctx_cutoffs(GbnBatch &b) {
     return GBN_OK;
 }
 
-int upload_batch(GbnBatch &b) {
-    int rc = ensure_init();
-    if (rc) return rc;
-    DeviceBatch *d = new DeviceBatch();
-    b.dev = d;
+// lookup structures from host-built tables (GBN_HOST_LOOKUP=1; the device builder below is the default)
+static int upload_host_tables(GbnBatch &b) {
+    DeviceBatch *d = b.dev;
     const HostLookup &L = b.lut;
     const uint8_t *q = b.query();
-    // extension flavour, CORE/na_ungapped.c:1753-1795
-    if (L.lut == L.word) d->mode = GBN_EXT_DIRECT;
-    else if (L.type == GBN_LUT_SMALL_NA)
-        d->mode = (L.lut % 4 == 0 && L.step % 4 == 0 && L.word - L.lut <= 4) ? GBN_EXT_SMALL_ONEBYTE : GBN_EXT_SMALL;
-    else d->mode = GBN_EXT_NA;
-    {   // fingerprint lengths: a verified seed has >= ceil(e/2) matches on the left
-        // or > e - ceil(e/2) on the right, e = word - lut
-        int e = L.word - L.lut, h = (e + 1) / 2;
-        d->fl = std::min(8, h); d->fr = std::min(7, e - h + 1);
-        if (e == 0) { d->fl = 0; d->fr = 0; }
-    }
+    int rc;
     std::vector<uint32_t> cellw((size_t)L.ncells, 0), cellt((size_t)L.ncells, 0);
     std::vector<unsigned long long> ent(L.cell_qoff.size());
     // 15-bit reduced fingerprint: 3.5 bases to the right (7 bits, high) and 4 bases to the left (8 bits, low)
@@ -176,11 +165,14 @@ int upload_batch(GbnBatch &b) {
             // GBN_BIN_SIDE per bin); anything that does not fit is "always rare path"
             const int64_t bin = c / GBN_BIN_CELLS;
             if (bin != cur_bin) { cur_bin = bin; while ((int64_t)side_start.size() <= bin) side_start.push_back((uint32_t)sidet.size()); }
+            // (same layout as the device builder: a list that does not fit still takes up its slots)
             const uint32_t off = (uint32_t)sidet.size() - side_start[bin], cnt = e - s;
-            if (!forced_cell && off + cnt <= GBN_BIN_SIDE && cnt < 16384) {
-                for (uint32_t k = s; k < e; k++) sidet.push_back((uint16_t)reduce((uint32_t)(ent[k] >> 32)));
-                cellt[c] = 0x80000000u | off | (cnt << 16);
-            } else cellt[c] = 0x80000000u;
+            cellt[c] = 0x80000000u;
+            if (!forced_cell && cnt < 16384) {
+                const bool fits = off + cnt <= GBN_BIN_SIDE;
+                for (uint32_t k = s; k < e; k++) sidet.push_back(fits ? (uint16_t)reduce((uint32_t)(ent[k] >> 32)) : (uint16_t)0);
+                if (fits) cellt[c] = 0x80000000u | off | (cnt << 16);
+            }
             forced_cell = false;
         }
     }
@@ -189,6 +181,115 @@ int upload_batch(GbnBatch &b) {
         while ((int64_t)side_start.size() <= nbins) side_start.push_back((uint32_t)sidet.size());
         sidet.push_back(0);
     }
+    if ((rc = dev_upload(d->pv, L.pv.data(), L.pv.size()))) return rc;
+    if ((rc = dev_upload(d->cellw, cellw.data(), cellw.size()))) return rc;
+    if ((rc = dev_upload(d->cellt, cellt.data(), cellt.size()))) return rc;
+    if ((rc = dev_upload(d->sidet, sidet.data(), sidet.size()))) return rc;
+    if ((rc = dev_upload(d->side_start, side_start.data(), side_start.size()))) return rc;
+    if ((rc = dev_upload(d->cell_start, L.cell_start.data(), L.cell_start.size()))) return rc;
+    {
+        // one pad entry so that an empty list still has a valid pointer
+        ent.push_back(0);
+        if ((rc = dev_upload(d->ent, ent.data(), ent.size()))) return rc;
+    }
+    return GBN_OK;
+}
+
+// lookup structures built on the device from the uploaded query (lutbuild.hip)
+static int build_tables_on_device(GbnBatch &b) {
+    DeviceBatch *d = b.dev;
+    HostLookup &L = b.lut;
+    int rc;
+    hipStream_t st = E.stream;
+    std::vector<int32_t> sl, sr;
+    for (auto &sg : L.segments) if (sg.second >= sg.first) { sl.push_back(sg.first); sr.push_back(sg.second); }
+    int32_t *d_sl = nullptr, *d_sr = nullptr;
+    uint32_t *count = nullptr, *many = nullptr, *many_prefix = nullptr, *vals_a = nullptr, *vals_b = nullptr;
+    uint64_t *keys_a = nullptr, *keys_b = nullptr; unsigned long long *ctr = nullptr; void *tmp = nullptr;
+    auto cleanup = [&]() { dev_free(d_sl); dev_free(d_sr); dev_free(count); dev_free(many); dev_free(many_prefix);
+                           dev_free(vals_a); dev_free(vals_b); dev_free(keys_a); dev_free(keys_b); dev_free(ctr); if (tmp) (void)hipFree(tmp); tmp = nullptr; };
+#define LUTCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); cleanup(); return GBN_ERR_HIP; } } while (0)
+#define LUTRC(x) do { if ((rc = (x))) { cleanup(); return rc; } } while (0)
+    const size_t nc1 = (size_t)L.ncells + 1, qn = (size_t)std::max(b.qlen, 1);
+    LUTRC(dev_upload(d_sl, sl.data(), sl.size())); LUTRC(dev_upload(d_sr, sr.data(), sr.size()));
+    LUTRC(dev_alloc(count, nc1)); LUTRC(dev_alloc(many, nc1)); LUTRC(dev_alloc(many_prefix, nc1));
+    LUTRC(dev_alloc(keys_a, qn)); LUTRC(dev_alloc(keys_b, qn)); LUTRC(dev_alloc(vals_a, qn)); LUTRC(dev_alloc(vals_b, qn));
+    LUTRC(dev_alloc(ctr, 2));
+    LUTRC(dev_alloc(d->cell_start, nc1)); LUTRC(dev_alloc(d->cellw, (size_t)L.ncells)); LUTRC(dev_alloc(d->cellt, (size_t)L.ncells));
+    LUTRC(dev_alloc(d->pv, (size_t)((L.ncells + 31) / 32)));
+    LUTCHK(hipMemsetAsync(count, 0, nc1 * 4, st)); LUTCHK(hipMemsetAsync(ctr, 0, 16, st));
+    auto bits_for = [](uint64_t below) { int k = 1; while (k < 63 && ((uint64_t)1 << k) < below) k++; return k; };
+    LutBuild B; std::memset(&B, 0, sizeof(B));
+    B.q8 = d->q8; B.qlen = b.qlen; B.seg_left = d_sl; B.seg_right = d_sr; B.nseg = (int32_t)sl.size();
+    B.lut = L.lut; B.word = L.word; B.q_bits = std::min(31, bits_for((uint64_t)b.qlen + 1)); B.ncells = L.ncells;
+    B.count = count; B.n_words = ctr; B.keys_a = keys_a; B.keys_b = keys_b; B.vals_a = vals_a; B.vals_b = vals_b;
+    B.cell_start = d->cell_start; B.cellw = d->cellw; B.cellt = d->cellt; B.pv = d->pv; B.many = many; B.many_prefix = many_prefix;
+    B.nbins = (int32_t)((L.ncells + GBN_BIN_CELLS - 1) / GBN_BIN_CELLS);
+    B.descending = (L.type == GBN_LUT_MB) ? 1 : 0;     // (the fallback below never produces or removes a megablast table)
+    LUTCHK(lut_enumerate(B, st));
+    if (L.type == GBN_LUT_SMALL_NA) LUTCHK(lut_overflow_cells(B, ctr + 1, st));
+    unsigned long long h[2] = {0, 0};
+    LUTCHK(hipMemcpyAsync(h, ctr, 16, hipMemcpyDeviceToHost, st));
+    LUTCHK(hipStreamSynchronize(st));
+    const int64_t n = (int64_t)h[0];
+    // small-NA table whose overflow array would not fit 15 bits: the standard table (CORE/blast_nalookup.c:184-187)
+    if (L.type == GBN_LUT_SMALL_NA && 2 + h[1] >= 32768) L.type = GBN_LUT_NA;
+    // (extension flavour and chain order depend on the final table kind)
+    if (L.lut == L.word) d->mode = GBN_EXT_DIRECT;
+    else if (L.type == GBN_LUT_SMALL_NA)
+        d->mode = (L.lut % 4 == 0 && L.step % 4 == 0 && L.word - L.lut <= 4) ? GBN_EXT_SMALL_ONEBYTE : GBN_EXT_SMALL;
+    else d->mode = GBN_EXT_NA;
+    B.onebyte_mode = (d->mode == GBN_EXT_SMALL_ONEBYTE) ? 1 : 0;
+    LUTRC(dev_alloc(d->ent, (size_t)n + 1));
+    LUTCHK(hipMemsetAsync(d->ent + n, 0, 8, st));
+    size_t b1 = 0, b2 = 0;
+    const int key_bits = std::min(64, 2 * L.lut + B.q_bits);
+    LUTCHK(lut_sort(nullptr, b1, B, std::max<int64_t>(n, 1), key_bits, st));
+    LUTCHK(lut_scan(nullptr, b2, count, d->cell_start, (int64_t)nc1, st));
+    LUTCHK(hipMalloc(&tmp, std::max(b1, b2) + 256));
+    size_t tb = std::max(b1, b2) + 256;
+    if (n > 0) LUTCHK(lut_sort(tmp, tb, B, n, key_bits, st));
+    tb = std::max(b1, b2) + 256;
+    LUTCHK(lut_scan(tmp, tb, count, d->cell_start, (int64_t)nc1, st));
+    B.ent = d->ent;
+    LUTCHK(lut_entries(B, n, st));
+    LUTCHK(lut_cells(B, st));
+    tb = std::max(b1, b2) + 256;
+    LUTCHK(lut_scan(tmp, tb, many, many_prefix, (int64_t)nc1, st));
+    uint32_t side_total = 0;
+    LUTCHK(hipMemcpyAsync(&side_total, many_prefix + L.ncells, 4, hipMemcpyDeviceToHost, st));
+    LUTCHK(hipStreamSynchronize(st));
+    LUTRC(dev_alloc(d->sidet, (size_t)side_total + 1)); LUTRC(dev_alloc(d->side_start, (size_t)B.nbins + 1));
+    LUTCHK(hipMemsetAsync(d->sidet + side_total, 0, 2, st));
+    B.sidet = d->sidet; B.side_start = d->side_start;
+    LUTCHK(lut_side(B, st));
+    LUTCHK(lut_pv(B, st));
+    LUTCHK(hipStreamSynchronize(st));
+#undef LUTCHK
+#undef LUTRC
+    cleanup();
+    return GBN_OK;
+}
+
+int upload_batch(GbnBatch &b) {
+    int rc = ensure_init();
+    if (rc) return rc;
+    DeviceBatch *d = new DeviceBatch();
+    b.dev = d;
+    trace_mark("upload: starts");
+    HostLookup &L = b.lut;
+    // extension flavour, CORE/na_ungapped.c:1753-1795
+    if (L.lut == L.word) d->mode = GBN_EXT_DIRECT;
+    else if (L.type == GBN_LUT_SMALL_NA)
+        d->mode = (L.lut % 4 == 0 && L.step % 4 == 0 && L.word - L.lut <= 4) ? GBN_EXT_SMALL_ONEBYTE : GBN_EXT_SMALL;
+    else d->mode = GBN_EXT_NA;
+    {   // fingerprint lengths: a verified seed has >= ceil(e/2) matches on the left
+        // or > e - ceil(e/2) on the right, e = word - lut
+        int e = L.word - L.lut, h = (e + 1) / 2;
+        d->fl = std::min(8, h); d->fr = std::min(7, e - h + 1);
+        if (e == 0) { d->fl = 0; d->fr = 0; }
+    }
+    static const bool host_lookup = getenv("GBN_HOST_LOOKUP") && atoi(getenv("GBN_HOST_LOOKUP")) != 0;
     if ((rc = dev_upload(d->q8_base, b.qbuf.data(), b.qbuf.size()))) return rc;
     d->q8 = d->q8_base + b.qpad;
     {   // packed copy for the greedy kernel's 32-bases-per-step match runs
@@ -204,17 +305,15 @@ int upload_batch(GbnBatch &b) {
         if ((rc = dev_upload(d->qinv_base, qi.data(), qi.size()))) return rc;
         d->q2 = d->q2_base + pad / 4; d->qinv = d->qinv_base + pad / 8;
     }
-    if ((rc = dev_upload(d->pv, L.pv.data(), L.pv.size()))) return rc;
-    if ((rc = dev_upload(d->cellw, cellw.data(), cellw.size()))) return rc;
-    if ((rc = dev_upload(d->cellt, cellt.data(), cellt.size()))) return rc;
-    if ((rc = dev_upload(d->sidet, sidet.data(), sidet.size()))) return rc;
-    if ((rc = dev_upload(d->side_start, side_start.data(), side_start.size()))) return rc;
-    if ((rc = dev_upload(d->cell_start, L.cell_start.data(), L.cell_start.size()))) return rc;
-    {
-        // one pad entry so that an empty list still has a valid pointer
-        ent.push_back(0);
-        if ((rc = dev_upload(d->ent, ent.data(), ent.size()))) return rc;
+    if (host_lookup) {
+        if (L.cell_start.empty()) fill_lookup_host(b);
+        // (the host builder may have turned a small-NA table into a standard one)
+        if (L.lut != L.word) d->mode = (L.type == GBN_LUT_SMALL_NA) ? ((L.lut % 4 == 0 && L.step % 4 == 0 && L.word - L.lut <= 4) ? GBN_EXT_SMALL_ONEBYTE : GBN_EXT_SMALL) : GBN_EXT_NA;
+        if ((rc = upload_host_tables(b))) return rc;
+    } else {
+        if ((rc = build_tables_on_device(b))) return rc;
     }
+    trace_mark("upload: lookup structures on the device");
     std::vector<int32_t> off, len;
     for (auto &c : b.ctx) { off.push_back(c.query_offset); len.push_back(c.query_length); }
     if ((rc = dev_upload(d->ctx_off, off.data(), off.size()))) return rc;
@@ -225,6 +324,7 @@ int upload_batch(GbnBatch &b) {
     if ((rc = upload_ctx_cutoffs(b))) return rc;
     if ((rc = dev_upload(d->matrix, &b.matrix[0][0], 256))) return rc;
     if ((rc = dev_upload(d->score_table, b.score_table, 256))) return rc;
+    trace_mark("upload: done");
     return GBN_OK;
 }
 
@@ -935,7 +1035,8 @@ int gbn_batch_new_masked(GbnBatch **out, const GbnOptions *opt, int32_t nq, cons
     std::vector<QueryMask> masks((size_t)nmask);
     for (int32_t i = 0; i < nmask; i++) masks[(size_t)i] = QueryMask{mask_query[i], mask_from[i], mask_to[i]};
     GbnBatch *b = new GbnBatch();
-    int rc = build_batch(*b, *opt, nq, seqs, lens, masks);
+    // with a device the lookup tables are built there (upload_batch); a host-only set-up fills them here
+    int rc = build_batch(*b, *opt, nq, seqs, lens, masks, /* host_tables = */ upload == 0);
     if (rc == GBN_OK && upload) rc = upload_batch(*b);
     if (rc != GBN_OK) { gbn_batch_free(b); return rc; }
     *out = b;

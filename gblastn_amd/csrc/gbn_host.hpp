@@ -42,6 +42,7 @@ struct HostLookup {
 };
 
 struct DeviceBatch;     // device mirrors, defined in engine.cpp
+void trace_mark(const char *what);   // GBN_TRACE=1: wall-clock marks on stderr (engine.cpp)
 }  // namespace gbn
 
 struct GbnBatch {
@@ -89,7 +90,8 @@ void set_error(const std::string &msg);
 struct QueryMask { int32_t query, from, to; };      // soft mask, plus-strand coordinates, inclusive
 int  build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq,
                  const uint8_t *const *seqs, const int32_t *lens,
-                 const std::vector<QueryMask> &masks = std::vector<QueryMask>());
+                 const std::vector<QueryMask> &masks = std::vector<QueryMask>(), bool host_tables = true);
+void fill_lookup_host(GbnBatch &b);     // the host-side table builder (host-only set-up, GBN_HOST_LOOKUP=1)
 int  upload_batch(GbnBatch &b);
 void free_device_batch(DeviceBatch *d);
 }

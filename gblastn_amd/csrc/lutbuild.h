@@ -1,0 +1,31 @@
+// lutbuild.h -- device-side construction of a query batch's lookup structures (lutbuild.hip)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace gbn {
+
+struct LutBuild {                           // device pointers throughout
+    const uint8_t *q8; int32_t qlen;        // concatenated query, position 0 (sentinel padding either side)
+    const int32_t *seg_left, *seg_right; int32_t nseg;      // indexed stretches, ascending, non-empty
+    int32_t lut, word, q_bits, descending, onebyte_mode;
+    int64_t ncells;
+    uint32_t *count;                        // ncells + 1, zero on entry
+    unsigned long long *n_words;            // zero on entry
+    uint64_t *keys_a, *keys_b; uint32_t *vals_a, *vals_b;   // qlen entries each
+    uint32_t *cell_start;                   // ncells + 1
+    uint32_t *cellw, *cellt, *pv; unsigned long long *ent;
+    uint32_t *many, *many_prefix;           // ncells + 1
+    uint16_t *sidet; uint32_t *side_start; int32_t nbins;
+};
+
+hipError_t lut_enumerate(const LutBuild &b, hipStream_t st);
+hipError_t lut_overflow_cells(const LutBuild &b, unsigned long long *out, hipStream_t st);
+hipError_t lut_sort(void *tmp, size_t &bytes, const LutBuild &b, int64_t n, int key_bits, hipStream_t st);
+hipError_t lut_scan(void *tmp, size_t &bytes, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st);
+hipError_t lut_entries(const LutBuild &b, int64_t n, hipStream_t st);
+hipError_t lut_cells(const LutBuild &b, hipStream_t st);
+hipError_t lut_side(const LutBuild &b, hipStream_t st);
+hipError_t lut_pv(const LutBuild &b, hipStream_t st);
+
+}  // namespace gbn

@@ -1,0 +1,183 @@
+// lutbuild.hip -- the lookup structures of a query batch, built on the device.
+//
+// Same tables as the host builder (batch.cpp build_lookup + the cell tables of engine.cpp), i.e. the word
+// enumeration of CORE/blast_lookup.c:87-137 / CORE/blast_nalookup.c:873-928 over the indexed stretches
+// (strands minus soft masks, only stretches of at least word_size bases, no word with an ambiguity code),
+// every cell's query offsets in the order the reference reports them (megablast chains: descending;
+// small / standard tables: ascending).  A 5 Mb megablast batch puts 10 M words into 16.7 M cells: 0.57 s
+// of cache misses on one host core, plus 0.28 GB of uploads -- here a few kernels and two library calls
+// (radix sort, prefix sums) on data that never leaves HBM.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include "gbn_dev.h"
+#include "lutbuild.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t fingerprint_dev(const uint8_t *__restrict__ q, int32_t off, int lut, bool force)
+{
+    uint32_t l = 0, r = 0;
+    #pragma unroll
+    for (int k = 1; k <= 8; k++) l |= (uint32_t)(q[off - k] & 3) << (2 * (k - 1));
+    #pragma unroll
+    for (int j = 0; j < 7; j++) r |= (uint32_t)(q[off + lut + j] & 3) << (2 * (6 - j));
+    return (l << 15) | (r << 1) | (force ? 1u : 0u);
+}
+// 15-bit reduced fingerprint: 3.5 bases to the right (7 bits, high) and 4 bases to the left (8 bits, low)
+__device__ __forceinline__ uint32_t reduce_fp(uint32_t fp) { return ((((fp >> 1) & 0x3fffu) >> 7) << 8) | ((fp >> 15) & 0xffu); }
+
+// one thread per query position: is a lookup word indexed here?
+__global__ void __launch_bounds__(1024) lut_enumerate_kernel(gbn::LutBuild B)
+{
+    __shared__ uint32_t s_cnt[16], s_base;
+    const int32_t p = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    bool ok = false; uint32_t cell = 0;
+    if (p < B.qlen) {
+        int lo = 0, hi = B.nseg;                    // last stretch that starts at or before p
+        while (lo < hi) { const int m = (lo + hi) >> 1; if (B.seg_left[m] <= p) lo = m + 1; else hi = m; }
+        if (lo > 0) {
+            const int32_t left = B.seg_left[lo - 1], right = B.seg_right[lo - 1];
+            if (right - left + 1 >= B.word && p + B.lut - 1 <= right) {
+                ok = true;
+                for (int k = 0; k < B.lut; k++) {
+                    const uint8_t b = B.q8[p + k];
+                    if (b & 0xfc) { ok = false; break; }
+                    cell = (cell << 2) | b;
+                }
+            }
+        }
+    }
+    if (ok) atomicAdd(&B.count[cell], 1u);
+    // dense (key, offset) list: one reservation per block
+    const unsigned long long m = __ballot(ok);
+    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
+    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t tot = 0;
+        for (int w = 0; w < 16; w++) { const uint32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
+        s_base = tot ? (uint32_t)atomicAdd(B.n_words, (unsigned long long)tot) : 0u;
+    }
+    __syncthreads();
+    if (ok) {
+        const uint32_t at = s_base + s_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        const uint32_t qmax = (B.q_bits >= 32) ? 0xffffffffu : ((1u << B.q_bits) - 1u);
+        B.keys_a[at] = ((uint64_t)cell << B.q_bits) | (B.descending ? (qmax - (uint32_t)p) : (uint32_t)p);
+        B.vals_a[at] = (uint32_t)p;
+    }
+}
+
+// small-NA table: does the overflow array stay below 32,768 entries?  (CORE/blast_nalookup.c:184-187, :200-324)
+__global__ void lut_overflow_kernel(const uint32_t *count, int64_t ncells, unsigned long long *out)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long v = (c < ncells && count[c] > 1) ? (unsigned long long)count[c] + 1ull : 0ull;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off);
+    if ((threadIdx.x & 63) == 0 && v) atomicAdd(out, v);
+}
+
+// entries in chain order: fingerprint + offset
+__global__ void lut_entries_kernel(gbn::LutBuild B, int64_t n)
+{
+    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    const int32_t off = (int32_t)B.vals_b[k];
+    const bool force = B.onebyte_mode && (off + B.lut >= B.qlen);
+    B.ent[k] = ((unsigned long long)fingerprint_dev(B.q8, off, B.lut, force) << 32) | (uint32_t)off;
+}
+
+// per cell: direct-probe word, LDS table word for cells with one or two entries, size of its side list
+__global__ void lut_cells_kernel(gbn::LutBuild B)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c > B.ncells) return;
+    if (c == B.ncells) { B.many[c] = 0; return; }
+    const uint32_t s = B.cell_start[c], e = B.cell_start[c + 1];
+    uint32_t w = 0, t = 0, many = 0;
+    if (e > s) {
+        bool forced = false;
+        if (B.onebyte_mode) for (uint32_t k = s; k < e; k++) forced = forced || ((B.ent[k] >> 32) & 1ull);
+        const uint32_t fp0 = (uint32_t)(B.ent[s] >> 32);
+        w = (fp0 & 0x7fffffffu) | ((e - s > 1) ? 0x80000000u : 0u);
+        t = 0x8000u | reduce_fp(fp0) | (reduce_fp(fp0) << 16);
+        if (e - s >= 2) t = (t & 0xffffu) | 0x80000000u | (reduce_fp((uint32_t)(B.ent[s + 1] >> 32)) << 16);
+        if (forced) t = 0x80000000u;                            // always the rare path
+        else if (e - s >= 3) { t = 0x80000000u; many = (e - s < 16384u) ? e - s : 0u; }    // decided by lut_side_kernel
+    }
+    B.cellw[c] = w; B.cellt[c] = t; B.many[c] = many;
+}
+
+// cells with three or more entries: their reduced fingerprints go to the bin's side list while it has room
+__global__ void lut_side_kernel(gbn::LutBuild B)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < (int64_t)B.nbins + 1) {
+        const int64_t first = min(c * (int64_t)GBN_BIN_CELLS, B.ncells);
+        B.side_start[c] = B.many_prefix[first];
+    }
+    if (c >= B.ncells) return;
+    const uint32_t cnt = B.many[c];
+    if (!cnt) return;
+    const int64_t bin = c / GBN_BIN_CELLS;
+    const uint32_t base = B.many_prefix[bin * (int64_t)GBN_BIN_CELLS], off = B.many_prefix[c] - base;
+    if (off + cnt > (uint32_t)GBN_BIN_SIDE) return;             // stays "always rare"
+    const uint32_t s = B.cell_start[c];
+    for (uint32_t k = 0; k < cnt; k++) B.sidet[base + off + k] = (uint16_t)reduce_fp((uint32_t)(B.ent[s + k] >> 32));
+    B.cellt[c] = 0x80000000u | off | (cnt << 16);
+}
+
+__global__ void lut_pv_kernel(const uint32_t *count, int64_t ncells, uint32_t *pv)
+{
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool present = c < ncells && count[c] != 0;
+    const unsigned long long m = __ballot(present);
+    const int lane = (int)(threadIdx.x & 63);
+    if (c < ncells && (lane & 31) == 0) pv[c >> 5] = (uint32_t)(m >> (lane & 32));
+}
+
+}  // namespace
+
+namespace gbn {
+
+hipError_t lut_enumerate(const LutBuild &b, hipStream_t st)
+{
+    if (b.qlen <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lut_enumerate_kernel, dim3((unsigned)((b.qlen + 1023) / 1024)), dim3(1024), 0, st, b);
+    return hipGetLastError();
+}
+hipError_t lut_overflow_cells(const LutBuild &b, unsigned long long *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(lut_overflow_kernel, dim3((unsigned)((b.ncells + 255) / 256)), dim3(256), 0, st, b.count, b.ncells, out);
+    return hipGetLastError();
+}
+hipError_t lut_sort(void *tmp, size_t &bytes, const LutBuild &b, int64_t n, int key_bits, hipStream_t st)
+{
+    return hipcub::DeviceRadixSort::SortPairs(tmp, bytes, b.keys_a, b.keys_b, b.vals_a, b.vals_b, (int)n, 0, key_bits, st);
+}
+hipError_t lut_scan(void *tmp, size_t &bytes, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st)
+{
+    return hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, st);
+}
+hipError_t lut_entries(const LutBuild &b, int64_t n, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lut_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b, n);
+    return hipGetLastError();
+}
+hipError_t lut_cells(const LutBuild &b, hipStream_t st)
+{
+    hipLaunchKernelGGL(lut_cells_kernel, dim3((unsigned)((b.ncells + 1 + 255) / 256)), dim3(256), 0, st, b);
+    return hipGetLastError();
+}
+hipError_t lut_side(const LutBuild &b, hipStream_t st)
+{
+    hipLaunchKernelGGL(lut_side_kernel, dim3((unsigned)((b.ncells + 255) / 256)), dim3(256), 0, st, b);
+    return hipGetLastError();
+}
+hipError_t lut_pv(const LutBuild &b, hipStream_t st)
+{
+    hipLaunchKernelGGL(lut_pv_kernel, dim3((unsigned)((b.ncells + 255) / 256)), dim3(256), 0, st, b.count, b.ncells, b.pv);
+    return hipGetLastError();
+}
+
+}  // namespace gbn

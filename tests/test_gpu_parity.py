@@ -466,3 +466,44 @@ def test_skewed_subjects_fill_few_bins(split_mb, monkeypatch):
     ora, s = util.oracle_run(opt, queries, subjects)
     util.compare_stages(gpu, ora)
     assert ps.diagnostics.lookup_hits == s.stats.lookup_hits and len(gpu["hsps"]) >= 50
+
+
+def test_device_built_lookup_tables_equal_the_host_builder():
+    """The lookup structures are built on the device (lutbuild.hip); GBN_HOST_LOOKUP=1 selects the host
+    builder they replaced.  Same HSPs, seeds and lookup-hit counts for every table kind: megablast chains
+    (descending offsets), small-NA (one-byte and general extension), the standard table a crowded small-NA
+    table falls back to, direct mode (lut = word), and a masked batch."""
+    import subprocess, sys, os, json
+    code = r'''
+import sys, json, numpy as np
+sys.path.insert(0, %r)
+from gblastn_amd import api
+from tests import util
+out = []
+db, queries, plants, subjects, opt = util.small_case(10, 300_000, 60)
+src = api.BlastSeqSrc.from_packed(subjects)
+cases = [("megablast", {}, queries), ("megablast", {"word_size": 16}, queries[:3]), ("blastn", {}, queries[:8]),
+         ("blastn", {"word_size": 7}, queries[:2]), ("blastn", {}, queries), ("blastn", {"word_size": 12}, queries[:1])]
+for task, kw, qs in cases:
+    o = api.default_options(task, db_length=opt.db_length, db_num_seqs=opt.db_num_seqs, **kw)
+    ps = api.BlastPrelimSearch(qs, o, src)
+    h = ps.run()["hsps"]
+    out.append([ps.info(), h.tobytes().hex(), int(ps.diagnostics.lookup_hits), int(ps.diagnostics.seeds)])
+qs = queries[:6]
+ps = api.BlastPrelimSearch(qs, api.default_options("blastn", db_length=opt.db_length, db_num_seqs=opt.db_num_seqs), src,
+                           masks=[(0, 100, 400), (3, 0, 50), (3, 700, 900)])
+h = ps.run()["hsps"]
+out.append([ps.info(), h.tobytes().hex(), int(ps.diagnostics.lookup_hits), int(ps.diagnostics.seeds)])
+print(json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ); env["GBN_HOST_LOOKUP"] = flag
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0, p.stderr[-2000:]
+        res[flag] = json.loads(p.stdout.strip().splitlines()[-1])
+    kinds = set()
+    for dev, host in zip(res["0"], res["1"]):
+        assert dev == host, (dev[0], host[0])
+        kinds.add((dev[0]["lut_type"], dev[0]["lut_width"]))
+    assert len(kinds) >= 3 and sum(len(r[1]) for r in res["0"]) > 0
