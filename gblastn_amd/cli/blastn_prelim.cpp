@@ -16,6 +16,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
+#include <future>
 #include <iostream>
 #include <map>
 #include <sstream>
@@ -222,12 +223,17 @@ int main(int argc, char **argv)
         }
     } else {
         // -mode 2: the extension stages of batch k run underneath the scan of batch k+1
+        // ... and batch k+1 is set up (host work + lookup structures on the device) on another thread meanwhile
         Batch *prev = nullptr;
-        for (auto &bt : batches) {
-            build(bt);
+        std::future<void> next;
+        build(batches[0]);
+        for (size_t i = 0; i < batches.size(); i++) {
+            Batch &bt = batches[i];
+            if (i + 1 < batches.size()) next = std::async(std::launch::async, [&, i] { build(batches[i + 1]); });
             check(gbn_prelim_search_begin(bt.b, shard, bt.r, &diag, nullptr, nullptr), "gbn_prelim_search_begin");
             if (prev) { check(gbn_prelim_search_end(prev->r), "gbn_prelim_search_end"); emit(*prev); gbn_batch_free(prev->b); gbn_results_free(prev->r); }
             prev = &bt;
+            if (i + 1 < batches.size()) next.get();
         }
         if (prev) { check(gbn_prelim_search_end(prev->r), "gbn_prelim_search_end"); emit(*prev); gbn_batch_free(prev->b); gbn_results_free(prev->r); }
     }

@@ -77,6 +77,7 @@ struct Engine {
     GbnDevInitHit *ihits_s[2] = {nullptr, nullptr}; GbnDevGapped *gapped_s[2] = {nullptr, nullptr}; size_t ihit_cap_s[2] = {0, 0};
     int32_t *gap_scratch_s[2] = {nullptr, nullptr}; size_t gap_scratch_ints_s[2] = {0, 0};
     int slot = 0; hipStream_t stream2 = nullptr;
+    hipStream_t stream_build = nullptr;      // lookup structures of the next query batch are built next to a running search
     std::future<int> pending; bool has_pending = false; std::string pending_err; const GbnResults *pending_res = nullptr;
     unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits, [3] runs; [4], [5]: init hits, runs of an asynchronous seed stage
     GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
@@ -200,7 +201,7 @@ static int build_tables_on_device(GbnBatch &b) {
     DeviceBatch *d = b.dev;
     HostLookup &L = b.lut;
     int rc;
-    hipStream_t st = E.stream;
+    hipStream_t st = E.stream_build;
     std::vector<int32_t> sl, sr;
     for (auto &sg : L.segments) if (sg.second >= sg.first) { sl.push_back(sg.first); sr.push_back(sg.second); }
     int32_t *d_sl = nullptr, *d_sr = nullptr;
@@ -951,6 +952,7 @@ int Blast_gpu_Init(int use_gpu, int gpu_id) {
     E.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     HIPCHK(hipStreamCreateWithFlags(&E.stream, hipStreamNonBlocking));
     HIPCHK(hipStreamCreateWithFlags(&E.stream2, hipStreamNonBlocking));
+    HIPCHK(hipStreamCreateWithFlags(&E.stream_build, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&E.ev0)); HIPCHK(hipEventCreate(&E.ev1));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&E.evk[i]));
     HIPCHK(hipEventCreateWithFlags(&E.ev_seed, hipEventDisableTiming));
@@ -976,6 +978,8 @@ void Blast_gpu_Release(void) {
     if (E.ev1) (void)hipEventDestroy(E.ev1);
     if (E.stream) (void)hipStreamDestroy(E.stream);
     if (E.stream2) (void)hipStreamDestroy(E.stream2);
+    if (E.stream_build) (void)hipStreamDestroy(E.stream_build);
+    E.stream_build = nullptr;
     E.ev0 = E.ev1 = nullptr; E.stream = E.stream2 = nullptr; E.ready = false;
 }
 

@@ -37,15 +37,24 @@ def _queries(db):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("task,mode", [("megablast", "1"), ("blastn", "1"), ("megablast", "2")])
-def test_cli_rows_equal_the_library_calls(tmp_path, task, mode):
+@pytest.mark.parametrize("task,mode,batch", [("megablast", "1", None), ("blastn", "1", None), ("megablast", "2", None),
+                                             ("megablast", "2", "900"), ("blastn", "2", "900")])
+def test_cli_rows_equal_the_library_calls(tmp_path, task, mode, batch):
+    """batch: BATCH_SIZE override (the reference's experimentation knob) -- one query per batch, so that
+    -mode 2 really pipelines: batch k+1 is set up on a second thread and its lookup tables are built on the
+    device while batch k is searched"""
     db = api.BlastDb(DB)
     qs = _queries(db)
     fa = tmp_path / "q.fa"
     fa.write_text("".join(">%s some description\n%s\n" % (n, "".join(IUPAC[int(x)] for x in s)) for n, s in qs))
     out = tmp_path / "out.tsv"
+    env = dict(os.environ)
+    if batch:
+        env["BATCH_SIZE"] = batch
     p = subprocess.run([CLI, "-db", DB, "-query", str(fa), "-task", task, "-use_gpu", "true", "-mode", mode,
-                        "-evalue", "1e-3", "-max_target_seqs", "5", "-out", str(out)], capture_output=True, text=True, timeout=600)
+                        "-evalue", "1e-3", "-max_target_seqs", "5", "-out", str(out)], capture_output=True, text=True, timeout=600, env=env)
+    if batch:
+        assert " in 1 batches" not in p.stderr and "batches" in p.stderr, p.stderr
     assert p.returncode == 0, p.stderr[-2000:]
     rows = [l.split("\t") for l in out.read_text().splitlines()]
     assert rows, p.stderr
