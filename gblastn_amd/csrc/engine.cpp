@@ -79,6 +79,7 @@ struct Engine {
     int slot = 0; hipStream_t stream2 = nullptr;
     hipStream_t stream_build = nullptr;      // lookup structures of the next query batch are built next to a running search
     std::future<int> pending; bool has_pending = false; std::string pending_err; const GbnResults *pending_res = nullptr;
+    const GbnBatch *pending_batch = nullptr;   // the batch the stage in flight reads (its device memory must outlive the stage)
     unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits, [3] runs; [4], [5]: init hits, runs of an asynchronous seed stage
     GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
     hipEvent_t ev_seed = nullptr; bool pending_uses_keys = false;
@@ -96,10 +97,64 @@ static int ensure_init() {
     return Blast_gpu_Init(1, -1);
 }
 
+// Device memory of query batches and of the table builder comes from a small pool: freed blocks are kept
+// (up to kPoolCap bytes) and handed out again for requests of about their size.  hipFree waits for the
+// whole device, which would stall a running search every time a finished batch is released.
+namespace {
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> idle;         // size -> block
+    std::map<void *, size_t> size_of;           // every block handed out by the pool
+    size_t held = 0;
+};
+DevPool g_pool;
+const size_t kPoolCap = (size_t)24 << 30;
+size_t pool_round(size_t bytes) { const size_t g = bytes >= ((size_t)1 << 20) ? ((size_t)1 << 20) : 4096; return (bytes + g - 1) / g * g; }
+hipError_t pool_alloc(void **p, size_t bytes) {
+    bytes = pool_round(std::max<size_t>(bytes, 1));
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        auto it = g_pool.idle.lower_bound(bytes);
+        if (it != g_pool.idle.end() && it->first <= bytes + bytes / 4) {
+            *p = it->second; g_pool.held -= it->first; g_pool.size_of[*p] = it->first; g_pool.idle.erase(it);
+            return hipSuccess;
+        }
+    }
+    hipError_t e = hipMalloc(p, bytes);
+    if (e != hipSuccess) {                      // give the idle blocks back and try again
+        std::vector<void *> drop;
+        { std::lock_guard<std::mutex> lk(g_pool.mu); for (auto &kv : g_pool.idle) drop.push_back(kv.second); g_pool.idle.clear(); g_pool.held = 0; }
+        for (void *q : drop) (void)hipFree(q);
+        (void)hipGetLastError();
+        e = hipMalloc(p, bytes);
+    }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.size_of[*p] = bytes; }
+    return e;
+}
+void pool_free(void *p) {
+    if (!p) return;
+    size_t bytes = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_pool.mu);
+        auto it = g_pool.size_of.find(p);
+        if (it != g_pool.size_of.end()) {
+            bytes = it->second; g_pool.size_of.erase(it);
+            if (g_pool.held + bytes <= kPoolCap) { g_pool.idle.emplace(bytes, p); g_pool.held += bytes; return; }
+        }
+    }
+    (void)hipFree(p);
+}
+void pool_drain() {
+    std::vector<void *> drop;
+    { std::lock_guard<std::mutex> lk(g_pool.mu); for (auto &kv : g_pool.idle) drop.push_back(kv.second); g_pool.idle.clear(); g_pool.held = 0; }
+    for (void *q : drop) (void)hipFree(q);
+}
+}  // namespace
+
 template <class T> static int dev_alloc(T *&p, size_t n) {
     p = nullptr;
     if (n == 0) n = 1;
-    HIPCHK(hipMalloc((void **)&p, n * sizeof(T)));
+    HIPCHK(pool_alloc((void **)&p, n * sizeof(T)));
     return GBN_OK;
 }
 template <class T> static int dev_upload(T *&p, const T *h, size_t n) {
@@ -108,7 +163,7 @@ template <class T> static int dev_upload(T *&p, const T *h, size_t n) {
     if (n) HIPCHK(hipMemcpy(p, h, n * sizeof(T), hipMemcpyHostToDevice));
     return GBN_OK;
 }
-template <class T> static void dev_free(T *&p) { if (p) (void)hipFree((void *)p); p = nullptr; }
+template <class T> static void dev_free(T *&p) { if (p) pool_free((void *)p); p = nullptr; }
 
 void free_device_batch(DeviceBatch *d) {
     if (!d) return;
@@ -208,7 +263,7 @@ static int build_tables_on_device(GbnBatch &b) {
     uint32_t *count = nullptr, *many = nullptr, *many_prefix = nullptr, *vals_a = nullptr, *vals_b = nullptr;
     uint64_t *keys_a = nullptr, *keys_b = nullptr; unsigned long long *ctr = nullptr; void *tmp = nullptr;
     auto cleanup = [&]() { dev_free(d_sl); dev_free(d_sr); dev_free(count); dev_free(many); dev_free(many_prefix);
-                           dev_free(vals_a); dev_free(vals_b); dev_free(keys_a); dev_free(keys_b); dev_free(ctr); if (tmp) (void)hipFree(tmp); tmp = nullptr; };
+                           dev_free(vals_a); dev_free(vals_b); dev_free(keys_a); dev_free(keys_b); dev_free(ctr); if (tmp) pool_free(tmp); tmp = nullptr; };
 #define LUTCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); cleanup(); return GBN_ERR_HIP; } } while (0)
 #define LUTRC(x) do { if ((rc = (x))) { cleanup(); return rc; } } while (0)
     const size_t nc1 = (size_t)L.ncells + 1, qn = (size_t)std::max(b.qlen, 1);
@@ -247,7 +302,7 @@ static int build_tables_on_device(GbnBatch &b) {
     const int key_bits = std::min(64, 2 * L.lut + B.q_bits);
     LUTCHK(lut_sort(nullptr, b1, B, std::max<int64_t>(n, 1), key_bits, st));
     LUTCHK(lut_scan(nullptr, b2, count, d->cell_start, (int64_t)nc1, st));
-    LUTCHK(hipMalloc(&tmp, std::max(b1, b2) + 256));
+    LUTCHK(pool_alloc(&tmp, std::max(b1, b2) + 256));
     size_t tb = std::max(b1, b2) + 256;
     if (n > 0) LUTCHK(lut_sort(tmp, tb, B, n, key_bits, st));
     tb = std::max(b1, b2) + 256;
@@ -396,7 +451,7 @@ static int grow_key_buffers(size_t n) {
         return rc;
     size_t bytes = 0;
     HIPCHK(sort_pairs_u64(nullptr, bytes, E.key_a, E.key_b, E.idx_a, E.idx_b, (int64_t)cap, 64, E.stream));
-    HIPCHK(hipMalloc(&E.sort_tmp, bytes));
+    HIPCHK(pool_alloc(&E.sort_tmp, bytes));
     E.sort_tmp_bytes = bytes; E.key_cap = cap;
     return GBN_OK;
 }
@@ -418,7 +473,7 @@ static int grow_ihit_buffers(int slot, size_t n) {
 static int wait_pending() {
     if (!E.has_pending) return GBN_OK;
     int rc = E.pending.get();
-    E.has_pending = false; E.pending_uses_keys = false;
+    E.has_pending = false; E.pending_uses_keys = false; E.pending_batch = nullptr;
     if (rc && !E.pending_err.empty()) set_error(E.pending_err);
     return rc;
 }
@@ -762,7 +817,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
             if (r) E.pending_err = gbn_last_error();      // the error text is per thread
             return r;
         });
-        E.has_pending = true; E.pending_res = rp; E.pending_uses_keys = true;
+        E.has_pending = true; E.pending_res = rp; E.pending_uses_keys = true; E.pending_batch = bp;
         return GBN_OK;
     }
     if (E.pending_uses_keys && (rc = wait_pending())) return rc;     // the sort buffers exist once
@@ -783,7 +838,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         if (r) E.pending_err = gbn_last_error();      // the error text is per thread
         return r;
     });
-    E.has_pending = true; E.pending_res = rp;
+    E.has_pending = true; E.pending_res = rp; E.pending_batch = bp;
     return GBN_OK;
 }
 
@@ -956,7 +1011,7 @@ int Blast_gpu_Init(int use_gpu, int gpu_id) {
     HIPCHK(hipEventCreate(&E.ev0)); HIPCHK(hipEventCreate(&E.ev1));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&E.evk[i]));
     HIPCHK(hipEventCreateWithFlags(&E.ev_seed, hipEventDisableTiming));
-    HIPCHK(hipMalloc((void **)&E.counters, 8 * sizeof(unsigned long long)));
+    HIPCHK(pool_alloc((void **)&E.counters, 8 * sizeof(unsigned long long)));
     E.device = dev; E.ready = true;
     return GBN_OK;
 }
@@ -980,6 +1035,7 @@ void Blast_gpu_Release(void) {
     if (E.stream2) (void)hipStreamDestroy(E.stream2);
     if (E.stream_build) (void)hipStreamDestroy(E.stream_build);
     E.stream_build = nullptr;
+    pool_drain();
     E.ev0 = E.ev1 = nullptr; E.stream = E.stream2 = nullptr; E.ready = false;
 }
 
@@ -1070,7 +1126,14 @@ int gbn_launch_gapped(const GbnGapParams *p, int greedy, void *stream) {
     HIPCHK(launch_gapped(*p, greedy != 0, (hipStream_t)stream));
     return GBN_OK;
 }
-void gbn_batch_free(GbnBatch *b) { if (!b) return; free_device_batch(b->dev); delete b; }
+void gbn_batch_free(GbnBatch *b) {
+    if (!b) return;
+    {   // an extension stage still reading this batch finishes first (its memory goes back to the pool, not to hipFree)
+        std::lock_guard<std::mutex> lk(E.mu);
+        if (E.has_pending && E.pending_batch == b) (void)wait_pending();
+    }
+    free_device_batch(b->dev); delete b;
+}
 int32_t gbn_batch_num_contexts(const GbnBatch *b) { return (int32_t)b->ctx.size(); }
 const GbnContext *gbn_batch_contexts(const GbnBatch *b) { return b->ctx.data(); }
 int gbn_batch_karlin_gapped(const GbnBatch *b, double *lambda, double *K) {
