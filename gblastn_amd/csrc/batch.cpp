@@ -209,13 +209,29 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
         int32_t L = lens[i];
         GbnContext &p = b.ctx[2 * i], &m = b.ctx[2 * i + 1];
         p.query_offset = off; p.query_length = L; p.frame = 1; p.query_index = i;
-        std::memcpy(q + off, seqs[i], (size_t)L);
         off += L + 1;
         m.query_offset = off; m.query_length = L; m.frame = -1; m.query_index = i;
-        for (int32_t j = 0; j < L; j++) q[off + j] = kComplement[seqs[i][L - 1 - j] & 15];
         off += L + 1;
     }
     b.qlen = off - 1;
+    auto fill_range = [&](int i0, int i1) {             // both strands of queries [i0, i1)
+        for (int i = i0; i < i1; i++) {
+            const int32_t L = lens[i];
+            std::memcpy(q + b.ctx[2 * i].query_offset, seqs[i], (size_t)L);
+            uint8_t *r = q + b.ctx[2 * i + 1].query_offset;
+            for (int32_t j = 0; j < L; j++) r[j] = kComplement[seqs[i][L - 1 - j] & 15];
+        }
+    };
+    {
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const int nthr = (total < (1 << 20) || nq < 16) ? 1 : (int)std::min<unsigned>({hw, 8u, (unsigned)nq / 8u});
+        if (nthr <= 1) fill_range(0, nq);
+        else {
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nthr; t++) pool.emplace_back(fill_range, (int)((int64_t)nq * t / nthr), (int)((int64_t)nq * (t + 1) / nthr));
+            for (auto &th : pool) th.join();
+        }
+    }
     trace_mark("batch: query concatenated");
     build_score_matrix(opt.reward, opt.penalty, b.matrix);
     for (int i = 0; i < 256; i++) {
