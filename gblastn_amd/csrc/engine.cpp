@@ -558,7 +558,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             HIPCHK(hipEventRecord(E.ev1, E.stream));
         } else {
             // private output stream per (bin, binning workgroup): no reservation atomics
-            const int wg_per_cu = getenv("GBN_BIN_WG_PER_CU") ? atoi(getenv("GBN_BIN_WG_PER_CU")) : GBN_BIN_WG_PER_CU;
+            const int wg_per_cu = GBN_BIN_WG_PER_CU;
             int nwriters = (int)std::max<int64_t>(8, std::min<int64_t>((int64_t)E.num_cu * wg_per_cu, ts.ntiles));
             if (const char *e = getenv("GBN_BIN_WRITERS")) nwriters = std::max(8, std::min(nwriters, atoi(e)));     // experiments
             const size_t nstream = (size_t)nb * nwriters;

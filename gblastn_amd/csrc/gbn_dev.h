@@ -41,50 +41,32 @@ struct GbnScanParams {
 // loads one bin's cell table (<= 32768 cells x 4 B = 128 KiB) into LDS and
 // streams that bin's records through it.
 #define GBN_BIN_THREADS  1024       // probe kernel workgroup
-#ifndef GBN_SORT_THREADS
-#define GBN_SORT_THREADS 1024       // binning kernel workgroup: one per CU with 16384-position tiles.  Measured
-#endif                              // alternative: 512 (two per CU, 8192-position tiles): 15-50 % slower (128-byte runs)
-#define GBN_BIN_WG_PER_CU (1024 / GBN_SORT_THREADS)
-#ifndef GBN_BIN_CARRY
-#define GBN_BIN_CARRY 2         // 2: line-exact binning kernel (open lines in LDS, 8192-position tiles); 0: padded runs, 16384-position tiles
-#endif
+#define GBN_SORT_THREADS 1024       // binning kernel workgroup: one per CU (two of 512 threads were measured 15-50 % slower)
+#define GBN_BIN_WG_PER_CU 1
 #ifndef GBN_OPEN_LINE
-#define GBN_OPEN_LINE 16        // records per stored piece of the line-exact binning kernel (64 bytes of hi words + 32 of indices)
+#define GBN_OPEN_LINE 16        // records per stored piece of the binning kernel (64 bytes of hi words + 32 of indices)
 #endif
 // cursor table resolution: one entry per 2^GBN_TCUR_SHIFT tiles of a (bin, writer) stream; the low bits of the
 // tile's sequence number then travel in the spare top bits of every record's 16-bit index
-#define GBN_TCUR_SHIFT (GBN_BIN_CARRY ? 3 : 0)
-#ifndef GBN_BIN_TILE_BITS
-#define GBN_BIN_TILE_BITS ((GBN_SORT_THREADS == 512 || GBN_BIN_CARRY) ? 13 : 14)
-#endif
+#define GBN_TCUR_SHIFT 3
+#define GBN_BIN_TILE_BITS 13
 #define GBN_BIN_TILE_POS (1 << GBN_BIN_TILE_BITS)   // scan positions per tile (posid = tile << GBN_BIN_TILE_BITS | i)
 #define GBN_BIN_GROUPS   8          // probe workgroups with equal (blockIdx & 7) share a bin (and an XCD)
 #define GBN_BIN_MAXNB    512
 #define GBN_BIN_CELLS    32768      // cells per bin (LDS table entries)
 #define GBN_BIN_TABW     (GBN_BIN_CELLS + 4)   // words of the probe kernel's LDS table: the cells + one always-empty cell (+ alignment)
 #define GBN_REC_PAD      0x40000000u  // hi word of a pad record: "cell" GBN_BIN_CELLS, the always-empty one -- needs no special case
-#define GBN_BIN_STAGE    (GBN_BIN_TILE_POS + 3 * GBN_BIN_MAXNB)
 #define GBN_BIN_QCAP     128        // per-wave queue of rare-path items in the probe kernel
 #define GBN_BIN_SIDE     4096       // LDS side-list capacity (u16 fingerprints) per bin
 
 struct GbnU2 { uint32_t x, y; };
-// Scan records.  GBN_REC_BYTES 6 (default): blocks of 64 records = 256 bytes of `hi` words followed by
-// 128 bytes of 16-bit position indices inside the tile; the tile itself is not stored -- the few records
-// that reach the rare path find it in the cursor table (GbnBinParams::tcur).  GBN_REC_BYTES 8 (the
-// earlier layout, kept for A/B builds): blocks of 32 records = 128 bytes of hi + 128 bytes of 32-bit
-// position ids.  GBN_REC_HI(j) = 32-bit word offset of record j's hi word (j = linear record index).
-#ifndef GBN_REC_BYTES
-#define GBN_REC_BYTES 6
-#endif
-#if GBN_REC_BYTES == 6
+// Scan records: blocks of 64 records = 256 bytes of `hi` words followed by 128 bytes of 16-bit indices
+// (13 bits: position inside the tile, 3 bits: the tile's sequence number mod 8); the tile itself is not
+// stored -- the few records that reach the rare path find it in the cursor table (GbnBinParams::tcur).
+// GBN_REC_HI(j) = 32-bit word offset of record j's hi word (j = linear record index).
 #define GBN_REC_HI(j)    ((((size_t)(j)) >> 6) * 96 + (((size_t)(j)) & 63))
 #define GBN_REC_IDX16(j) (((((size_t)(j)) >> 6) * 96 + 64) * 2 + (((size_t)(j)) & 63))    /* 16-bit offset */
 #define GBN_REC_WORDS(n) ((size_t)(n) / 64 * 96)                                          /* n: multiple of 64 */
-#else
-#define GBN_REC_HI(j)    ((((size_t)(j)) >> 5) * 64 + (((size_t)(j)) & 31))
-#define GBN_REC_POS(j)   (GBN_REC_HI(j) + 32)
-#define GBN_REC_WORDS(n) ((size_t)(n) * 2)
-#endif
 struct GbnBinParams {
     GbnScanParams S;                // tiles here are GBN_BIN_TILE_POS-sized
     int nb, cbits;                  // number of bins; cell = bin << cbits | low

@@ -18,36 +18,15 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "gbn_dev.h"
-#ifndef GBN_BIN_OCC
 #ifndef GBN_PROBE_U
 #define GBN_PROBE_U 2        // 16-byte loads per lane and round of the probe kernel (4 records each)
 #endif
 // stream of (bin, writer): writer-major keeps the 512 streams a binning workgroup appends to
-// inside one ~100 MB stretch (few TLB entries) instead of spreading them over the whole buffer
-#if GBN_STREAM_BIN_MAJOR
-#define GBN_STREAM(B, bin, writer) ((size_t)(bin) * (B).nwriters + (writer))
-#else
+// inside one ~100 MB stretch instead of spreading them over the whole buffer
 #define GBN_STREAM(B, bin, writer) ((size_t)(writer) * (B).nb + (bin))
-#endif
-// Linear index of record j of stream (bin, writer).  Chunked (build knob, off): a writer's streams
-// interleaved in chunks of 512 records, [writer][chunk][bin][512], so that its 512 write fronts stay
-// inside one or two 2 MB chunk rows (page-table locality).  Measured on four boxes: binning -1 %,
-// probe +2 % -- the box-to-box spread of the binning kernel is not a TLB effect.
-#ifndef GBN_REC_CHUNKED
-#define GBN_REC_CHUNKED 0
-#endif
-#if GBN_REC_CHUNKED
-#define GBN_RECIDX(B, bin, writer, j) \
-    (((((size_t)(writer) * ((B).subcap >> 9) + ((size_t)(j) >> 9)) * (B).nb + (bin)) << 9) + ((size_t)(j) & 511))
-#else
+// linear index of record j of stream (bin, writer)
 #define GBN_RECIDX(B, bin, writer, j) (GBN_STREAM(B, bin, writer) * (B).subcap + (size_t)(j))
-#endif
-#define GBN_BIN_GBIAS 32768u  // > GBN_BIN_STAGE: keeps (stream cursor - staging offset) non-negative
 #define GBN_BIN_OCC 4       // waves per SIMD the binning kernel is compiled for (128 VGPRs)
-#ifndef GBN_BIN_MERGED_WRITEOUT
-#define GBN_BIN_MERGED_WRITEOUT 1    // stores of tile t-1 share a barrier interval with the histogram of tile t (3 barriers per tile)
-#endif
-#endif
 
 namespace {
 
@@ -932,272 +911,16 @@ hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uin
 // Direct probing costs one L2 request per scan position for the presence bit
 // (2.9e9 per 50 Gbp pass: the L2 request rate, not HBM, is the wall) plus one
 // 64-byte HBM sector per present word.  Here phase 1 touches no table at all:
-// it streams the subject once and writes every scan position as an 8-byte
-// record {position id, low cell bits, 4+3 neighbouring subject bases} into
-// the bin given by the top bits of its lookup word, in full 32-byte sectors.
-// Phase 2 walks bin by bin with the bin's cell table resident in LDS (one
-// workgroup per CU, all workgroups with the same blockIdx & 7 -- observed to
-// share an XCD and its L2 -- on the same bin).  Only ~5 % of present words
-// (fingerprint survivors and cells with >= 3 entries) leave LDS.
+// it streams the subject once and writes every scan position as a 6-byte
+// record {cell inside the bin + 15 neighbouring subject bits, 16-bit index} into
+// the stream of (bin given by the top bits of its lookup word, workgroup), in
+// complete aligned pieces.  Phase 2 walks bin by bin with the bin's cell table
+// resident in LDS (one workgroup per CU, all workgroups with the same
+// blockIdx & 7 -- observed to share an XCD and its L2 -- on the same bin).
+// Only ~0.7 % of the records (fingerprint survivors and cells with >= 3 entries)
+// leave LDS, through per-workgroup queues, for phase 3 (exact verification).
 // ===========================================================================
-namespace {
-// 32 consecutive bases starting at base index `pos` as a big-endian 64-bit word
-__device__ __forceinline__ uint64_t window32(const uint8_t *__restrict__ p, int64_t pos) {
-    int64_t w = pos >> 4;
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + w;
-    uint64_t hi = ((uint64_t)bswap32(d[0]) << 32) | bswap32(d[1]);
-    uint32_t lo = bswap32(d[2]);
-    int sh = 2 * (int)(pos & 15);
-    return sh ? ((hi << sh) | ((uint64_t)lo >> (32 - sh))) : hi;
-}
-// same window, addressed as uniform base + unsigned 32-bit offset (SGPR base + VGPR offset loads);
-// `base16` is the subject's first byte minus 16 and `upos` the base index plus 64
-__device__ __forceinline__ uint64_t window32u(const uint8_t *__restrict__ base16, uint32_t upos) {
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(base16) + (upos >> 4);
-    uint64_t hi = ((uint64_t)bswap32(d[0]) << 32) | bswap32(d[1]);
-    uint32_t lo = bswap32(d[2]);
-    uint32_t sh = 2 * (upos & 15);
-    return sh ? ((hi << sh) | ((uint64_t)lo >> (32 - sh))) : hi;
-}
-}  // namespace
 
-// Phase 1 of the key-range partitioned scan: every scan position becomes one 8-byte record
-// {posid = tile << GBN_BIN_TILE_BITS | index, hi = cell-in-bin << 15 | reduced fingerprint}, kept as two
-// parallel arrays, in the private output stream of (bin, this workgroup).  Per tile: LDS counting sort by bin, then the bin runs (padded
-// to 4 records = 32 bytes) are appended to the streams.  No global atomics, no table access.
-//
-// Software pipeline (global-memory latency never sits on the critical path of a tile):
-//   keys of tile t are in registers at the loop top;
-//   the bytes of tile t+1 and the descriptor of tile t+2 are requested right after the
-//   histogram atomics of tile t and first touched after its LDS sort;
-//   the stores of tile t are issued last and only waited for one tile later.
-// STEP > 0: the scan stride is a compile-time constant and every lane owns 16 CONSECUTIVE positions
-// (index = lane * 16 + j).  16 positions span exactly STEP dwords of the 2-bit subject and tiles start
-// on a dword, so a lane fetches its STEP + 2 dwords with a few wide loads and cuts all 16 windows out
-// of registers with constant shifts (5 vector-memory instructions per lane instead of 16: the
-// texture-address unit was the busiest pipe of the strided version).  STEP == 0: any stride, one
-// unaligned 8-byte load per position, index = lane + 1024 * j.
-template <int STEP>
-__device__ __forceinline__ void scan_bin_body(const GbnBinParams &B)
-{
-    const GbnScanParams &P = B.S;
-    __shared__ __attribute__((aligned(16))) uint32_t s_hi[GBN_BIN_STAGE];   // record high word, bin-sorted
-    __shared__ __attribute__((aligned(16))) uint16_t s_idx[GBN_BIN_STAGE];  // position index in tile; 0xffff = pad
-    __shared__ uint32_t s_gmeta[GBN_BIN_STAGE / 4 + 4];    // per group of 4 slots: bin << 23 | (stream index - slot + BIAS)
-    __shared__ uint32_t s_hist[GBN_BIN_MAXNB], s_off[GBN_BIN_MAXNB + 1];
-    __shared__ uint32_t s_wcur[GBN_BIN_MAXNB];      // this workgroup's write cursor per bin (records)
-    const int tid = threadIdx.x;
-    const uint32_t mask = (uint32_t)(P.ncells - 1);
-    const int nb = B.nb, cbits = B.cbits;
-    const uint32_t lowmask = (1u << cbits) - 1;
-    const int cshift = 56 - 2 * P.lut, rshift = 49 - 2 * P.lut;     // right side: 3.5 bases = 7 bits
-    constexpr int PER = GBN_BIN_TILE_POS / GBN_SORT_THREADS;
-    const uint32_t ustep = (uint32_t)P.step;
-    const int64_t stride = gridDim.x, last = P.ntiles - 1;
-
-    // raw subject data of one tile, per lane
-    constexpr int NDW = STEP > 0 ? ((2 * STEP * 15 - 8 + 38) >> 5) + 2 : 2 * PER;   // dwords -1 .. last
-    struct Raw { uint32_t d[NDW]; };
-    // index of a lane's k-th position inside the tile
-    auto idx_of = [&](int k) -> uint32_t { return STEP > 0 ? (uint32_t)(tid * PER + k) : (uint32_t)(tid + k * GBN_SORT_THREADS); };
-    // STEP == 0: one unaligned 8-byte load per position: bases [pos - 4, pos + lut + 4) are <= 40 bits
-    // that start at most 6 bits into the byte holding base pos - 4.  Lanes past the tile's end re-read
-    // its last position (and are dropped when ranks are taken).
-    auto upos_of = [&](const GbnTile &t, int k) -> uint32_t {
-        const uint32_t i = min(idx_of(k), (uint32_t)t.npos - 1u);
-        return (uint32_t)t.first_pos + i * ustep + 60u;         // base index + 64 (>= 60; subjects start >= 16 bytes into the slab)
-    };
-    auto fetch = [&](const GbnTile &t, Raw &r) {
-        if constexpr (STEP > 0) {
-            // dwords [D0 - 1, D0 - 1 + NDW) of the subject, D0 = first_pos / 16 + lane * STEP; lanes past
-            // the tile's end re-read its last lane (the slab carries 128 pad bytes behind the last subject)
-            const uint32_t lane_c = min((uint32_t)tid, ((uint32_t)t.npos - 1u) / PER);
-            const uint8_t *p = P.db + ((size_t)(uint32_t)t.off16 << 4) + 4 * ((size_t)((uint32_t)t.first_pos >> 4) + (size_t)lane_c * STEP) - 4;
-            #pragma unroll
-            for (int i = 0; i + 4 <= NDW; i += 4) __builtin_memcpy(&r.d[i], p + 4 * i, 16);
-            if constexpr (NDW % 4 == 3) { __builtin_memcpy(&r.d[NDW - 3], p + 4 * (NDW - 3), 12); }
-            else if constexpr (NDW % 4 == 2) { __builtin_memcpy(&r.d[NDW - 2], p + 4 * (NDW - 2), 8); }
-            else if constexpr (NDW % 4 == 1) { __builtin_memcpy(&r.d[NDW - 1], p + 4 * (NDW - 1), 4); }
-        } else {
-            #pragma unroll
-            for (int k = 0; k < PER; k++)
-                __builtin_memcpy(&r.d[2 * k], P.db + ((size_t)(uint32_t)t.off16 << 4) - 16 + (upos_of(t, k) >> 2), 8);
-        }
-    };
-    // 64-bit window of position k: bits 63..56 = the 4 bases left of the lookup word, then the word, then
-    // the bases right of it
-    auto keys = [&](const GbnTile &t, int k, const Raw &r, uint32_t &bin, uint32_t &hi) {
-        uint64_t w;
-        if constexpr (STEP > 0) {
-            const int bit = 2 * STEP * k - 8 + 32;              // window start, in bits from dword -1 (compile-time)
-            const int a = bit >> 5, o = bit & 31;
-            const uint32_t x0 = bswap32(r.d[a]), x1 = bswap32(r.d[a + 1]), x2 = bswap32(r.d[a + 2 < NDW ? a + 2 : NDW - 1]);
-            const uint32_t hi32 = o ? ((x0 << o) | (x1 >> (32 - o))) : x0;
-            const uint32_t lo32 = o ? ((x1 << o) | (x2 >> (32 - o))) : x1;
-            w = ((uint64_t)hi32 << 32) | lo32;
-        } else {
-            uint64_t raw; __builtin_memcpy(&raw, &r.d[2 * k], 8);
-            w = __builtin_bswap64(raw) << (2 * (upos_of(t, k) & 3));
-        }
-        const uint32_t c = (uint32_t)(w >> cshift) & mask;
-        bin = c >> cbits;
-        hi = ((c & lowmask) << 15) | (((uint32_t)(w >> rshift) & 0x7fu) << 8) | (uint32_t)(w >> 56);
-    };
-    auto uniform = [](GbnTile t) -> GbnTile {       // descriptors are workgroup-uniform: keep them in SGPRs
-        t.subj = __builtin_amdgcn_readfirstlane(t.subj); t.first_pos = __builtin_amdgcn_readfirstlane(t.first_pos);
-        t.npos = __builtin_amdgcn_readfirstlane(t.npos); t.off16 = __builtin_amdgcn_readfirstlane(t.off16);
-        return t;
-    };
-
-    for (int b = tid; b < nb; b += GBN_SORT_THREADS) { s_wcur[b] = 0; s_hist[b] = 0; }
-    int64_t tile = blockIdx.x;
-    if (tile > last) {                               // more workgroups than tiles: empty streams
-        for (int b = tid; b < nb; b += GBN_SORT_THREADS) B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0;
-        return;
-    }
-    GbnTile T = uniform(P.tiles[tile]);
-    GbnTile T1 = uniform(P.tiles[min(tile + stride, last)]);
-    uint32_t bin[PER], hi[PER];
-    {
-        Raw r0; fetch(T, r0);
-        #pragma unroll
-        for (int k = 0; k < PER; k++) keys(T, k, r0, bin[k], hi[k]);
-    }
-    __syncthreads();
-
-#if GBN_BIN_TIMING   // phase timer of workgroup 0 (tools/build_variant.sh t "-DGBN_BIN_TIMING=1", GBN_DBG=32)
-    const bool timed = blockIdx.x == 0 && tid == 0;
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-#define GBN_LAP(ph) do { if (timed) { const unsigned long long t_ = __builtin_readcyclecounter(); tph[ph] += t_ - tprev; tprev = t_; } } while (0)
-#else
-#define GBN_LAP(ph) do { } while (0)
-#endif
-    // write-out of a bin-sorted tile: one lane per group of 4 records, one 16-byte store to each of the
-    // two record lines; the lanes of a wave that fall into the same run write one contiguous stretch
-    auto write_out = [&](uint32_t total, uint32_t tbase) {
-        for (uint32_t g = tid; g < (total >> 2); g += GBN_SORT_THREADS) {
-            const uint32_t meta = s_gmeta[g];
-            const uint32_t b = meta >> 23;
-            const uint32_t w = (meta & 0x7fffffu) - GBN_BIN_GBIAS + 4u * g;     // index in this workgroup's stream of bin b
-            const uint2 i4 = *reinterpret_cast<const uint2 *>(&s_idx[4 * g]);
-            uint4 h4 = *reinterpret_cast<const uint4 *>(&s_hi[4 * g]);
-            const uint32_t l0 = i4.x & 0xffffu, l1 = i4.x >> 16, l2 = i4.y & 0xffffu, l3 = i4.y >> 16;
-#if GBN_REC_BYTES != 6
-            uint4 p4;
-            p4.x = tbase | l0; p4.y = tbase | l1; p4.z = tbase | l2; p4.w = tbase | l3;
-#endif
-            if (l0 == 0xffffu) h4.x = GBN_REC_PAD;                  // pads: flagged in the high word
-            if (l1 == 0xffffu) h4.y = GBN_REC_PAD;
-            if (l2 == 0xffffu) h4.z = GBN_REC_PAD;
-            if (l3 == 0xffffu) h4.w = GBN_REC_PAD;
-            if (w + 4u <= B.subcap && !(B.dbg & 2)) {
-                const size_t at = GBN_RECIDX(B, b, blockIdx.x, w);
-                *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = h4;
-#if GBN_REC_BYTES == 6
-                *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(B.rec) + GBN_REC_IDX16(at)) = i4;     // pads carry 0xffff
-#else
-                *reinterpret_cast<uint4 *>(B.rec + GBN_REC_POS(at)) = p4;
-#endif
-            }
-        }
-    };
-    // Per tile t, three barrier intervals:
-    //   [0] histogram atomics of t, requests for the bytes of t+1 and the descriptor of t+2, and the
-    //       STORES of tile t-1 (its sorted records still sit in the staging arrays).  Stores and
-    //       compute of different waves overlap here, and the stores keep draining during [1] and [2];
-    //   [1] offset scan;   [2] pads, stream bookkeeping, scatter of t into the staging arrays;
-    //   then keys of t+1 out of the prefetched bytes (first touch: everything in flight is older).
-    uint32_t prev_total = 0, prev_tbase = 0, seq = 0;
-    for (; tile <= last; tile += stride, ++seq) {
-        uint32_t rank[PER];
-        #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            rank[k] = 0;
-            if (idx_of(k) < (uint32_t)T.npos)
-                rank[k] = atomicAdd(&s_hist[bin[k]], 1u);       // arrival order inside the bin: any order will do
-        }
-        GBN_LAP(5);
-        Raw R;
-        if constexpr (STEP > 0) fetch(T1, R);                   // tile t+1 (== the last tile again at the end)
-        GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
-        GBN_LAP(7);
-#if GBN_BIN_MERGED_WRITEOUT
-        write_out(prev_total, prev_tbase);
-        GBN_LAP(4);
-#endif
-        __syncthreads();                                        // (A) histogram complete, staging arrays free
-        GBN_LAP(0);
-        // exclusive scan of the padded bin sizes (x4 records = 32-byte sectors): wave 0, each lane sums
-        // nb/64 consecutive bins, one wave scan over the 64 partial sums
-        if (tid < 64) {
-            constexpr int MAXQ = GBN_BIN_MAXNB / 64;
-            const int per = (nb + 63) >> 6;                     // bins per lane (nb = 8 .. 512)
-            uint32_t v[MAXQ], sum = 0;
-            #pragma unroll
-            for (int i = 0; i < MAXQ; i++) {
-                const int b = tid * per + i;
-                v[i] = (i < per && b < nb) ? ((s_hist[b] + 3u) & ~3u) : 0u;
-                sum += v[i];
-            }
-            uint32_t x = sum;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(x, o); if (tid >= o) x += y; }
-            uint32_t run = x - sum;
-            #pragma unroll
-            for (int i = 0; i < MAXQ; i++) {
-                const int b = tid * per + i;
-                if (i < per && b < nb) s_off[b] = run;
-                run += v[i];
-            }
-            if (tid == 63) s_off[nb] = x;
-        }
-        __syncthreads();                                        // (B) offsets known
-        GBN_LAP(1);
-        const uint32_t total = s_off[nb];
-        for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
-            const uint32_t n = s_hist[b], o0 = s_off[b], o1 = s_off[b + 1], wc = s_wcur[b];
-            for (uint32_t j = o0 + n; j < o1; j++) s_idx[j] = 0xffffu;
-            for (uint32_t g = o0 >> 2; g < (o1 >> 2); g++) s_gmeta[g] = ((uint32_t)b << 23) | (wc + GBN_BIN_GBIAS - o0);
-            if (o1 > o0 && wc + (o1 - o0) > B.subcap) atomicExch(B.overflow, 1u);
-#if GBN_REC_BYTES == 6
-            B.tcur[((size_t)b * B.nwriters + blockIdx.x) * B.nseq + seq] = wc;
-#endif
-            s_wcur[b] = wc + (o1 - o0);
-            s_hist[b] = 0;                                      // for the next tile; ordered by (C) and (A)
-        }
-        #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            if (idx_of(k) < (uint32_t)T.npos) {
-                const uint32_t slot = s_off[bin[k]] + rank[k];
-                s_hi[slot] = hi[k];
-                s_idx[slot] = (uint16_t)idx_of(k);
-            }
-        }
-        __syncthreads();                                        // (C) tile is bin-sorted in LDS
-        GBN_LAP(2);
-        prev_total = total; prev_tbase = (uint32_t)tile << GBN_BIN_TILE_BITS;
-        T = T1; T1 = uniform(T2);
-        if constexpr (STEP == 0) fetch(T, R);                   // any-stride variant: no prefetch (32 more live registers would spill)
-        #pragma unroll
-        for (int k = 0; k < PER; k++) keys(T, k, R, bin[k], hi[k]);
-        GBN_LAP(3);
-#if !GBN_BIN_MERGED_WRITEOUT
-        write_out(prev_total, prev_tbase);
-        prev_total = 0;
-        GBN_LAP(4);
-        __syncthreads();                                        // (D) staging arrays free again
-#endif
-    }
-    write_out(prev_total, prev_tbase);                          // the last tile (merged variant)
-#if GBN_BIN_TIMING
-    if (timed) for (int i = 0; i < 8; i++) B.rare_counts[512 + i] = (uint32_t)(tph[i] >> 4);
-#endif
-    __syncthreads();
-    for (int b = tid; b < nb; b += GBN_SORT_THREADS)
-        B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(s_wcur[b], B.subcap);
-}
-
-
-#if GBN_BIN_CARRY == 2
 // ---------------------------------------------------------------------------------------------------
 // Binning kernel, line-exact variant (default).  Measured on MI355X: the same bytes cost 3-4x more when a
 // stream's lines are written in pieces by consecutive tiles (partial-line writes) than when every store
@@ -1437,16 +1160,11 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(total, B.subcap);
     }
 }
-#endif  // GBN_BIN_CARRY == 2
 
 
 
 
-#if GBN_BIN_CARRY == 2
 #define GBN_BIN_BODY scan_bin_line_body
-#else
-#define GBN_BIN_BODY scan_bin_body
-#endif
 extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel(GbnBinParams B) { GBN_BIN_BODY<0>(B); }
 extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s17(GbnBinParams B) { GBN_BIN_BODY<17>(B); }
 extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { GBN_BIN_BODY<18>(B); }
@@ -1558,12 +1276,7 @@ probe_bin_kernel(GbnBinParams B)
             base = __shfl(base, 0);
             if (keep) {
                 const uint32_t at = base + (uint32_t)__popcll(m & lt);
-#if GBN_REC_BYTES == 6
                 const uint32_t pid = at_rec;                        // resolved to a position id by the rare kernel
-#else
-                const uint32_t wr = at_rec / B.subcap;              // writer of the record's stream
-                const uint32_t pid = B.rec[GBN_REC_POS(GBN_RECIDX(B, bin, wr, at_rec - wr * B.subcap))];
-#endif
                 if (at < B.rare_seg) { myq[at].x = pid; myq[at].y = cv; }
             }
         }
@@ -1706,7 +1419,6 @@ probe_rare_kernel(GbnBinParams B, int nseg)
         const uint32_t i = i0 + threadIdx.x;
         if (i >= n) continue;
         uint32_t pid = qs[i].x; const uint32_t cv = qs[i].y;
-#if GBN_REC_BYTES == 6
         {   // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
             const uint32_t bin = (cv & 0x7fffffffu) >> B.cbits;
             const uint32_t wr = pid / B.subcap, j = pid - wr * B.subcap;
@@ -1717,17 +1429,16 @@ probe_rare_kernel(GbnBinParams B, int nseg)
             {   // the cursors grow almost linearly: look around the interpolated run first
                 const uint32_t total = B.gcount[(size_t)bin * B.nwriters + wr];
                 const uint32_t g = (uint32_t)(((unsigned long long)j * nt) / (total ? total : 1u));
-                constexpr uint32_t W = GBN_TCUR_SHIFT ? 3u : 12u;
+                constexpr uint32_t W = 3u;
                 const uint32_t a = g > W ? g - W : 0u, z = min(nt, g + W);
                 const uint32_t ca = cur[a], cz = (z < nt) ? cur[z] : 0xffffffffu;
                 if (ca <= j && cz > j) { lo = a; hi = z; }
             }
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] <= j) lo = mid; else hi = mid; }
             const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, j))];
-            const uint32_t seqn = GBN_TCUR_SHIFT ? ((lo << GBN_TCUR_SHIFT) | (idx >> GBN_BIN_TILE_BITS)) : lo;
+            const uint32_t seqn = (lo << GBN_TCUR_SHIFT) | (idx >> GBN_BIN_TILE_BITS);
             pid = ((wr + seqn * (uint32_t)B.nwriters) << GBN_BIN_TILE_BITS) | (idx & (uint32_t)(GBN_BIN_TILE_POS - 1));
         }
-#endif
         if (staged) probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw, s_buf, &s_n, CAP);
         else probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
     }
