@@ -6,6 +6,7 @@ import sys
 
 
 def short(name):
+    name = name.replace(",", ";")               # kernel signatures contain commas; the output is CSV
     return name if len(name) < 70 else name[:40] + "..." + name[-24:]
 
 
