@@ -348,17 +348,13 @@ int upload_batch(GbnBatch &b) {
     static const bool host_lookup = getenv("GBN_HOST_LOOKUP") && atoi(getenv("GBN_HOST_LOOKUP")) != 0;
     if ((rc = dev_upload(d->q8_base, b.qbuf.data(), b.qbuf.size()))) return rc;
     d->q8 = d->q8_base + b.qpad;
-    {   // packed copy for the greedy kernel's 32-bases-per-step match runs
+    {   // packed copy for the greedy kernel's 32-bases-per-step match runs, made on the device from q8
         const int64_t pad = 256, n = (int64_t)b.qlen + 2 * pad;
-        std::vector<uint8_t> q2((size_t)(n + 3) / 4 + 16, 0), qi((size_t)(n + 7) / 8 + 16, 0xff);
-        for (int64_t i = 0; i < n; i++) {
-            const int64_t src = (int64_t)b.qpad + i - pad;
-            const uint8_t code = (src >= 0 && src < (int64_t)b.qbuf.size()) ? b.qbuf[(size_t)src] : 15;
-            q2[(size_t)(i >> 2)] |= (uint8_t)((code & 3) << (6 - 2 * (i & 3)));
-            if (code <= 3) qi[(size_t)(i >> 3)] &= (uint8_t)~(0x80u >> (i & 7));
-        }
-        if ((rc = dev_upload(d->q2_base, q2.data(), q2.size()))) return rc;
-        if ((rc = dev_upload(d->qinv_base, qi.data(), qi.size()))) return rc;
+        const size_t q2_bytes = (size_t)(n + 3) / 4 + 16, qi_bytes = (size_t)(n + 7) / 8 + 16;
+        if ((rc = dev_alloc(d->q2_base, q2_bytes)) || (rc = dev_alloc(d->qinv_base, qi_bytes))) return rc;
+        HIPCHK(hipMemsetAsync(d->q2_base, 0xff, q2_bytes, E.stream_build));        // tails: "matches nothing"
+        HIPCHK(hipMemsetAsync(d->qinv_base, 0xff, qi_bytes, E.stream_build));
+        HIPCHK(lut_pack_query(d->q8_base, (int64_t)b.qbuf.size(), (int64_t)b.qpad - pad, n, d->q2_base, d->qinv_base, E.stream_build));
         d->q2 = d->q2_base + pad / 4; d->qinv = d->qinv_base + pad / 8;
     }
     if (host_lookup) {

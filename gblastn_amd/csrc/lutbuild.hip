@@ -135,9 +135,34 @@ __global__ void lut_pv_kernel(const uint32_t *count, int64_t ncells, uint32_t *p
     if (c < ncells && (lane & 31) == 0) pv[c >> 5] = (uint32_t)(m >> (lane & 32));
 }
 
+// 2-bit copy of the query + bitmap of the codes that can never match a subject base, for the gapped kernels'
+// 32-bases-per-step match runs: base i of the packed copy = qbuf[first + i] (15 outside the buffer)
+__global__ void lut_pack_query_kernel(const uint8_t *qbuf, int64_t qbuf_len, int64_t first, int64_t n, uint8_t *q2, uint8_t *qinv)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 8 bases
+    if (t * 8 >= n) return;
+    uint32_t two = 0, inv = 0;
+    for (int k = 0; k < 8; k++) {
+        const int64_t i = t * 8 + k, src = first + i;
+        const uint8_t code = (i < n && src >= 0 && src < qbuf_len) ? qbuf[src] : 15;
+        two = (two << 2) | (uint32_t)(code & 3);
+        inv = (inv << 1) | (code <= 3 ? 0u : 1u);
+    }
+    q2[t * 2] = (uint8_t)(two >> 8); q2[t * 2 + 1] = (uint8_t)two;
+    qinv[t] = (uint8_t)inv;
+}
+
 }  // namespace
 
 namespace gbn {
+
+hipError_t lut_pack_query(const uint8_t *qbuf, int64_t qbuf_len, int64_t first, int64_t n, uint8_t *q2, uint8_t *qinv, hipStream_t st)
+{
+    const int64_t groups = (n + 7) / 8;
+    if (groups <= 0) return hipSuccess;
+    hipLaunchKernelGGL(lut_pack_query_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, qbuf, qbuf_len, first, n, q2, qinv);
+    return hipGetLastError();
+}
 
 hipError_t lut_enumerate(const LutBuild &b, hipStream_t st)
 {
