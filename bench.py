@@ -7,14 +7,16 @@ MI355X, megablast word_size 28.  The reference batch plan applies: 5 Mb query
 batches (5,000 queries, 10 M lookup words -> megablast table lut 12, stride 17),
 so the config is 2 passes over the database.
 
-A "step" = one pass of the whole preliminary path (scan+seed, diagonal filter,
-ungapped X-drop, greedy gapped, HSP rules) of ONE query batch over the rank's
-resident shard.  Lookup structures of both batches and the database are
-resident in HBM before the timed region (the reference's boundary receives
-them ready-made too).  value = (bases of all shards x K passes) / max-over-ranks
-wall time.  With N > 1 every rank holds its own 50 Gbp shard (weak scaling, the
-C5 layout: volumes sharded by rank, global statistics) and rank 0 gathers the
-per-shard HSP records over RCCL after every pass, inside the timed region.
+A "step" = one pass of ONE query batch over the rank's resident shard, from the caller's query arrays to
+merged results: set-up of the batch (concatenation, Karlin-Altschul parameters, cut-offs on the host; lookup
+structures built on the device), the whole preliminary path (scan + seed, diagonal filter, ungapped X-drop,
+greedy gapped, HSP rules) and the gather + top-N merge.  Nothing is reused between steps; set-up, extension
+stages and merge run on worker threads / a second stream underneath the neighbouring steps' scans.  Only the
+database shard is resident in HBM before the timed region.  value = (bases of all shards x K passes) /
+max-over-ranks wall time.  `config.engine_only` gives, beside it, the engine entry point alone on reused
+query batches (its lookup tables are inputs of that entry point).  With N > 1 every rank holds its own
+50 Gbp shard (weak scaling, the C5 layout: volumes sharded by rank, global statistics) and rank 0 gathers
+the per-shard HSP records over RCCL after every pass, inside the timed region.
 """
 import argparse
 import json
@@ -32,8 +34,8 @@ if ROOT not in sys.path:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
                     help="C2 (the metric's config): megablast W=28 vs 50 Gbp; C3: blastn W=11 vs 5 Gbp, 100 kb batches")
     ap.add_argument("--subjects", type=int, default=None, help="subjects per GPU shard")
@@ -44,7 +46,7 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the CPU baseline (0: half of the host cores, at most 64)")
     ap.add_argument("--no-overlap", action="store_true", help="run every pass to completion before the next starts")
-    ap.add_argument("--stream-steps", type=int, default=16, help="passes of the streamed variant (fresh batch set-up per pass, overlapped); 0: skip")
+    ap.add_argument("--engine-steps", type=int, default=8, help="passes of the side measurement on reused query batches (engine entry point alone); 0: skip")
     ap.add_argument("--reuse-binning", action="store_true",
                     help="NOT the headline metric: keep the query-independent scan records of the shard in HBM and "
                          "skip the binning kernel for later batches with the same table shape (a database index)")
@@ -105,45 +107,53 @@ def main():
     nbatch = (len(queries) + args.batch_queries - 1) // args.batch_queries
     npass_config = nbatch
     nbatch = min(nbatch, max(args.steps, args.warmup, 1))       # only the batches the run touches
-    t_setup = time.perf_counter()
-    batches = [api.BlastPrelimSearch(queries[i * args.batch_queries:(i + 1) * args.batch_queries], opt, src)
-               for i in range(nbatch)]
-    torch.cuda.synchronize()
-    # outside the timed region (the lookup table is an input of the preliminary search engine): host set-up
-    # (concatenation, Karlin-Altschul, cut-offs) + lookup structures built on the device, per query batch
-    batch_setup_ms = (time.perf_counter() - t_setup) * 1e3 / max(nbatch, 1)
-    info = batches[0].info()
+    # query batches as the caller would hand them over: one contiguous BLASTNA array per query
+    qsets = [api.QuerySet(queries[i * args.batch_queries:(i + 1) * args.batch_queries]) for i in range(nbatch)]
 
-    def merge(b, out):
+    def make(k):
+        """set-up of the query batch of pass k from scratch: concatenation, Karlin-Altschul parameters,
+        cut-offs on the host; lookup structures built on the device"""
+        return api.BlastPrelimSearch(qsets[k % nbatch], opt, src)
+
+    def merge(nq, out):
         # exchange + merge step: gather to rank 0, replay through the per-query top-N collector
-        got = shard.collect_on_root(out["hsps"], len(b._q), opt.hitlist_size, dst=0, device=dev)
+        got = shard.collect_on_root(out["hsps"], nq, opt.hitlist_size, dst=0, device=dev)
         return 0 if got is None else len(got[0])
 
     from concurrent.futures import ThreadPoolExecutor
-    merger = ThreadPoolExecutor(max_workers=1, initializer=lambda: torch.cuda.set_device(dev))
+    pin = lambda: torch.cuda.set_device(dev)
+    merger = ThreadPoolExecutor(max_workers=1, initializer=pin)
+    setup_pool = ThreadPoolExecutor(max_workers=2, initializer=pin)     # two set-ups in flight
 
-    def run_passes(first, count):
-        """`count` passes, software-pipelined when there are two batches to alternate: the gapped
-        stage + host acceptance + gather/merge of pass k overlap the scan of pass k + 1.  Every pass
-        is complete (merged on rank 0) when this returns."""
-        n = 0
+    def run_passes(count, diags):
+        """`count` passes.  Nothing is carried over between passes: every pass sets its query batch up
+        from scratch (worker threads, underneath the passes before it), scans the whole shard, extends,
+        and is merged on rank 0 (worker thread: host work, or an RCCL gather at N > 1).  The extension
+        stages and the merge of pass k overlap the scan of pass k + 1.  With --no-overlap every step runs
+        to completion before the next starts, set-up included."""
         if count <= 0:
             return 0
-        if nbatch < 2 or args.no_overlap:
-            for k in range(first, first + count):
-                b = batches[k % nbatch]
-                n += merge(b, b.run())
+        n = 0
+        if args.no_overlap:
+            for k in range(count):
+                b = make(k)
+                n += merge(len(b._q), b.run()); diags.append(b.diagnostics); b.close()
             return n
-        # begin(k) returns when scan k is done and its extension stages are in flight; the gather + top-N
-        # merge of pass k-1 (host work, or an RCCL gather at N > 1) runs on a worker thread underneath scan k+1
+        def finish(b, out):                 # worker thread: merge, then release the batch
+            got = merge(len(b._q), out)
+            b.close()
+            return got
         prev, futs = None, []
-        for k in range(first, first + count):
-            b = batches[k % nbatch]
+        ahead = [setup_pool.submit(make, k) for k in range(min(2, count))]
+        for k in range(count):
+            b = ahead.pop(0).result()
+            if k + 2 < count:
+                ahead.append(setup_pool.submit(make, k + 2))
             b.begin()                       # waits for prev's extension stages before queueing its own
             if prev is not None:
-                futs.append(merger.submit(merge, prev, prev.end()))
+                futs.append(merger.submit(finish, prev, prev.end())); diags.append(prev.diagnostics)
             prev = b
-        futs.append(merger.submit(merge, prev, prev.end()))
+        futs.append(merger.submit(finish, prev, prev.end())); diags.append(prev.diagnostics)
         return n + sum(f.result() for f in futs)
 
     def sync():
@@ -151,66 +161,61 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    run_passes(0, args.warmup)
-    sync()
-    for b in batches:
-        b.diagnostics = api.GbnDiagnostics()
-    t0 = time.perf_counter()
-    nhsp = run_passes(args.warmup, args.steps)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- the same job streamed: every pass sets its query batch up from scratch (host set-up + lookup
-    # structures built on the device), on a worker thread underneath the previous pass, as
-    # `blastn_prelim -mode 2` does.  Reported beside `value`, which times the engine entry point alone
-    # (the lookup table is one of its inputs).
-    streamed = None
-    if not args.no_overlap and args.stream_steps > 0:
-        qsets = [queries[i * args.batch_queries:(i + 1) * args.batch_queries] for i in range(nbatch)]
-        qsets = [[np.ascontiguousarray(q, dtype=np.uint8) for q in qs] for qs in qsets]
-        # two set-ups in flight: a 5 Mb megablast batch takes ~25 ms to set up, a 50 Gbp pass ~16 ms
-        setup_pool = ThreadPoolExecutor(max_workers=2, initializer=lambda: torch.cuda.set_device(dev))
-        make = lambda k: api.BlastPrelimSearch(qsets[k % nbatch], opt, src)
-
-        def stream(count):
-            prev, futs = None, []
-            ahead = [setup_pool.submit(make, k) for k in range(min(2, count))]
-            for k in range(count):
-                b = ahead.pop(0).result()
-                if k + 2 < count:
-                    ahead.append(setup_pool.submit(make, k + 2))
-                b.begin()
-                if prev is not None:
-                    out = prev.end(); futs.append(merger.submit(merge, prev, out)); prev.close()
-                prev = b
-            out = prev.end(); futs.append(merger.submit(merge, prev, out)); prev.close()
-            return sum(f.result() for f in futs)
-        stream(3); sync()
-        ts = time.perf_counter()
-        stream(args.stream_steps); sync()
-        el = time.perf_counter() - ts
+    def timed(fn):
+        sync()
+        t0 = time.perf_counter()
+        r = fn()
+        sync()
+        el = time.perf_counter() - t0
         if world > 1:
             t = torch.tensor([el], dtype=torch.float64, device=dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        streamed = {"ms_per_pass": el / args.stream_steps * 1e3,
-                    "value": world * nsub * slen * args.stream_steps / el / 1e9, "unit": "Gbp/s", "passes": args.stream_steps,
-                    "what": "every pass builds its query batch from scratch (host set-up + lookup tables on the device), two set-ups in flight on worker threads underneath the passes; the first set-up is inside the timed region"}
+        return r, el
+
+    t_setup = time.perf_counter()
+    probe_batch = make(0)
+    batch_setup_ms = (time.perf_counter() - t_setup) * 1e3      # one set-up alone (first call: includes allocations)
+    info = probe_batch.info()
+    probe_batch.close()
+    run_passes(args.warmup, [])
+    diags = []
+    nhsp, elapsed = timed(lambda: run_passes(args.steps, diags))
+
+    # ---- beside it: the engine entry point alone, on query batches set up once and reused (their lookup
+    # tables are inputs of the entry point).  Not the headline number.
+    engine_only = None
+    if not args.no_overlap and args.engine_steps > 0 and nbatch >= 2:
+        held = [make(k) for k in range(2)]
+
+        def reuse(count):
+            prev, futs = None, []
+            for k in range(count):
+                b = held[k % 2]
+                b.begin()
+                if prev is not None:
+                    futs.append(merger.submit(merge, len(prev._q), prev.end()))
+                prev = b
+            futs.append(merger.submit(merge, len(prev._q), prev.end()))
+            return sum(f.result() for f in futs)
+        reuse(2)
+        _, el = timed(lambda: reuse(args.engine_steps))
+        engine_only = {"ms_per_pass": el / args.engine_steps * 1e3, "value": world * nsub * slen * args.engine_steps / el / 1e9,
+                       "unit": "Gbp/s", "passes": args.engine_steps,
+                       "what": "gbn_prelim_search_begin/_end on two query batches set up once and reused alternately"}
+        for b in held:
+            b.close()
 
     # ---- roofline of the dominant kernel (scan+seed), from HIP events in the library ----
-    scan_ms = sum(b.diagnostics.scan_kernel_ms for b in batches)
-    launches = sum(b.diagnostics.scan_launches for b in batches)
-    scanned = sum(b.diagnostics.subject_bases_scanned for b in batches)
-    seeds = sum(b.diagnostics.seeds for b in batches)
-    lookup_hits = sum(b.diagnostics.lookup_hits for b in batches)
+    scan_ms = sum(d.scan_kernel_ms for d in diags)
+    launches = sum(d.scan_launches for d in diags)
+    scanned = sum(d.subject_bases_scanned for d in diags)
+    seeds = sum(d.seeds for d in diags)
+    lookup_hits = sum(d.lookup_hits for d in diags)
     algo_bytes = 0.25 * scanned
-    bin_ms = sum(b.diagnostics.bin_kernel_ms for b in batches)
-    probe_ms = sum(b.diagnostics.probe_kernel_ms for b in batches)
-    rare_ms = sum(b.diagnostics.rare_kernel_ms for b in batches)
+    bin_ms = sum(d.bin_kernel_ms for d in diags)
+    probe_ms = sum(d.probe_kernel_ms for d in diags)
+    rare_ms = sum(d.rare_kernel_ms for d in diags)
     # dominant kernel: the binning kernel when the partitioned scan is used, else the direct scan
     dom_name, dom_ms = ("scan_bin_kernel", bin_ms) if bin_ms > 0 else ("scan_seed_kernel", scan_ms)
     # the binning kernel has stride-specialised variants; this is the name rocprof shows
@@ -241,17 +246,18 @@ def main():
             "config": {
                 "workload": "%s: %d x 1 kb queries vs %.1f Gbp synthetic 2-bit DB per GPU, %s W=%d"
                             % (args.workload, len(queries), nsub * slen / 1e9, task, opt.word_size),
-                "stage_ms_per_pass": {k: sum(getattr(b.diagnostics, k) for b in batches) / max(launches, 1)
+                "stage_ms_per_pass": {k: sum(getattr(d, k) for d in diags) / max(launches, 1)
                                       for k in ["scan_stage_ms", "seed_stage_ms", "gapped_stage_ms", "host_stage_ms"]},
-                "batch_setup_ms": batch_setup_ms, "streamed": streamed, "init_hits_per_pass": sum(b.diagnostics.good_init_extends for b in batches) / max(launches, 1),
+                "batch_setup_ms": batch_setup_ms, "engine_only": engine_only, "init_hits_per_pass": sum(d.good_init_extends for d in diags) / max(launches, 1),
                 "batch_plan": {"queries_per_batch": args.batch_queries, "passes_per_config": npass_config,
                                "lut": info["lut_width"], "scan_step": info["scan_step"],
                                "lut_type": info["lut_type"], "diag_container": info["container"]},
                 "subjects_per_gpu": nsub, "subject_len": slen,
                 "parallelism": "db-shard x%d (volumes by rank, RCCL gather of HSP records)" % world,
                 "binning_reused_across_batches": bool(args.reuse_binning),
-                "pipeline": "off" if (nbatch < 2 or args.no_overlap) else
-                            "gapped stage + merge of pass k overlap the scan of pass k+1 (second HIP stream + host thread)",
+                "query_batches": "set up from scratch in every step (inside the timed region); nothing reused between steps",
+                "pipeline": "off" if args.no_overlap else
+                            "set-up of pass k+1/k+2 (worker threads) and seed/gapped stages + merge of pass k (second HIP stream + host threads) overlap the scan of pass k+1",
                 "hsps_per_pass": nhsp / max(args.steps, 1),
                 "seeds_per_pass": seeds / max(launches, 1),
                 "lookup_hits_per_pass": lookup_hits / max(launches, 1),

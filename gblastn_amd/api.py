@@ -244,16 +244,30 @@ class BlastSeqSrc:
             pass
 
 
+class QuerySet:
+    """The caller's queries of one batch (BLASTNA arrays) with the pointer / length arrays the C ABI takes,
+    prepared once: a streaming caller sets the same queries up against several shards or options."""
+
+    def __init__(self, queries):
+        self.q = [np.ascontiguousarray(q, dtype=np.uint8) for q in queries]
+        self.ptrs = (C.c_void_p * len(self.q))(*[q.ctypes.data for q in self.q])
+        self.lens = (C.c_int32 * len(self.q))(*[len(q) for q in self.q])
+
+    def __len__(self):
+        return len(self.q)
+
+
 class BlastPrelimSearch:
     """CBlastPrelimSearch analogue: one query batch against one resident shard."""
 
     def __init__(self, queries, options, seqsrc=None, upload=True, masks=None):
-        """upload=False builds the host-side set-up only (no device needed).
-        masks: soft query masks [(query index, from, to)], inclusive plus-strand intervals."""
+        """queries: list of BLASTNA arrays, or a QuerySet.  upload=False builds the host-side set-up only
+        (no device needed).  masks: soft query masks [(query index, from, to)], inclusive plus-strand intervals."""
         L = lib()
-        self._q = [np.ascontiguousarray(q, dtype=np.uint8) for q in queries]
-        ptrs = (C.c_void_p * len(self._q))(*[q.ctypes.data for q in self._q])
-        lens = (C.c_int32 * len(self._q))(*[len(q) for q in self._q])
+        qs = queries if isinstance(queries, QuerySet) else QuerySet(queries)
+        self._qs = qs
+        self._q = qs.q
+        ptrs, lens = qs.ptrs, qs.lens
         self.options = options
         self._b = C.c_void_p()
         masks = sorted(masks or [])
