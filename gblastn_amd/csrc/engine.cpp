@@ -884,19 +884,21 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     }
     per_thread = (per_thread + 3) & ~(size_t)3;
     G.scratch_per_thread = (int32_t)per_thread;
-    const size_t budget_ints = (size_t)1 << 30;        // 4 GiB of scratch per slot: the kernel time is the longest extension of a launch, so few launches
-    size_t chunk = std::max<size_t>(1, std::min<size_t>((size_t)nih, budget_ints / per_thread));
-    const size_t scratch_ints = ((chunk + 63) & ~(size_t)63) * per_thread;     // whole waves (the DP kernel interleaves a wave's rows)
+    // grid: at most 24 waves per CU (measured on the blastn shape: 12-20 make the gapped stage the longer one, 28+ starve the scan; the scan kernels of the next range need room, see greedy_kernel) and at
+    // most 4 GiB of scratch; the threads stride over the initial hits
+    const size_t budget_ints = (size_t)1 << 30;
+    static const int waves_per_cu = getenv("GBN_GAP_WAVES") ? std::max(1, atoi(getenv("GBN_GAP_WAVES"))) : 24;
+    const size_t by_budget = std::max<size_t>(1, budget_ints / per_thread / 64);
+    const size_t blocks = std::max<size_t>(1, std::min({((size_t)nih + 63) / 64, (size_t)E.num_cu * (size_t)waves_per_cu, by_budget}));
+    const size_t scratch_ints = blocks * 64 * per_thread;
     if (scratch_ints > E.gap_scratch_ints_s[slot]) {
         dev_free(E.gap_scratch_s[slot]);
         if ((rc = dev_alloc(E.gap_scratch_s[slot], scratch_ints))) { E.gap_scratch_ints_s[slot] = 0; return rc; }
         E.gap_scratch_ints_s[slot] = scratch_ints;
     }
     G.scratch = E.gap_scratch_s[slot];
-    for (size_t first = 0; first < (size_t)nih; first += chunk) {
-        G.first = (int64_t)first; G.n = (int64_t)std::min(chunk, (size_t)nih - first);
-        HIPCHK(launch_gapped(G, b.opt.greedy != 0, st));
-    }
+    G.first = 0; G.n = (int64_t)nih; G.max_blocks = (int32_t)blocks;
+    HIPCHK(launch_gapped(G, b.opt.greedy != 0, st));
     std::vector<GbnDevInitHit> hih((size_t)nih); std::vector<GbnDevGapped> hg((size_t)nih);
     HIPCHK(hipMemcpyAsync(hih.data(), E.ihits_s[slot], (size_t)nih * sizeof(GbnDevInitHit), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hg.data(), E.gapped_s[slot], (size_t)nih * sizeof(GbnDevGapped), hipMemcpyDeviceToHost, st));

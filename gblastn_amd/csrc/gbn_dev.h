@@ -134,6 +134,7 @@ struct GbnGapParams {
     const uint8_t *q2, *qinv;
     const int32_t *matrix;
     int32_t reward, penalty, gap_open, gap_extend, xdrop;
-    int32_t *scratch; int32_t scratch_per_thread, row_len;
+    int32_t *scratch; int32_t scratch_per_thread, row_len;      // scratch: one slot per thread of the grid
     GbnDevGapped *out;
+    int32_t max_blocks;             // grid cap in 64-thread blocks (0: one thread per initial hit); the threads stride over the hits
 };

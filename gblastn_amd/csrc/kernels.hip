@@ -17,6 +17,7 @@
 // one byte per base (BLASTNA) with sentinel padding on both sides.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <algorithm>
 #include "gbn_dev.h"
 #ifndef GBN_PROBE_U
 #define GBN_PROBE_U 2        // 16-byte loads per lane and round of the probe kernel (4 records each)
@@ -667,10 +668,10 @@ __device__ int32_t greedy_affine(const GQ &q, int32_t len1, const uint8_t *subj,
 }
 }  // namespace
 
-extern "C" __global__ void greedy_kernel(GbnGapParams P)
+namespace {
+// one initial hit; `slot` = the thread's scratch slot
+__device__ void greedy_hit(const GbnGapParams &P, int64_t i, int64_t slot)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
     const GbnDevInitHit h = P.ihits[P.first + i];
     const uint8_t *__restrict__ subj = P.db + P.byte_off[h.subj];
     const int32_t slen = P.len[h.subj];
@@ -681,7 +682,7 @@ extern "C" __global__ void greedy_kernel(GbnGapParams P)
     const int32_t q_start_u = h.q_start - qstart;
     // start in the middle of the ungapped HSP (CORE/blast_gapalign.c:3466-3471)
     const int32_t q_off = q_start_u + h.length / 2, s_off = h.s_start + h.length / 2;
-    int32_t *scratch = P.scratch + (size_t)i * P.scratch_per_thread;
+    int32_t *scratch = P.scratch + (size_t)slot * P.scratch_per_thread;
     int32_t *row0 = scratch, *row1 = scratch + P.row_len, *msb = scratch + 2 * (size_t)P.row_len;
     int32_t reward = P.reward, pen = -P.penalty, X = P.xdrop;
     int32_t mc = reward, mm = pen;
@@ -712,6 +713,18 @@ extern "C" __global__ void greedy_kernel(GbnGapParams P)
     g.q_start = q_box_l; g.s_start = s_box_l; g.q_stop = q_box_r; g.s_stop = s_box_r;
     g.score = score; g.context = lo;
     P.out[P.first + i] = g;
+}
+}  // namespace
+
+// The gapped kernels run on the second stream underneath the next range's scan, whose kernels need whole
+// CUs (one 1024-thread workgroup + most of the LDS each): a grid sized to the initial hits would fill
+// every wave slot for as long as its longest extension lasts and keep those workgroups waiting.  So the
+// grid is capped (the engine asks for 24 waves per CU) and the threads walk the hits with a grid stride; the
+// scratch then depends on the grid, not on the number of hits.
+extern "C" __global__ void greedy_kernel(GbnGapParams P)
+{
+    const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = slot; i < P.n; i += total) greedy_hit(P, i, slot);
 }
 
 namespace {
@@ -780,10 +793,9 @@ __device__ int32_t align_packed(const GbnGapParams &P, const uint8_t *q, const u
 }
 }  // namespace
 
-extern "C" __global__ void dynprog_kernel(GbnGapParams P)
+namespace {
+__device__ void dynprog_hit(const GbnGapParams &P, int64_t i)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
     const GbnDevInitHit h = P.ihits[P.first + i];
     const uint8_t *__restrict__ subj = P.db + P.byte_off[h.subj];
     const int32_t slen = P.len[h.subj];
@@ -813,6 +825,13 @@ extern "C" __global__ void dynprog_kernel(GbnGapParams P)
     } else { g.q_stop = q_length; g.s_stop = s_length; }
     g.score = overflow ? INT32_MIN : left + right;
     P.out[P.first + i] = g;
+}
+}  // namespace
+
+extern "C" __global__ void dynprog_kernel(GbnGapParams P)
+{
+    const int64_t total = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += total) dynprog_hit(P, i);
 }
 
 // ---------------------------------------------------------------------------
@@ -881,8 +900,10 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
 hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
 {
     if (p.n <= 0) return hipSuccess;
-    if (greedy) hipLaunchKernelGGL(greedy_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
-    else hipLaunchKernelGGL(dynprog_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
+    const int64_t need = (p.n + 63) / 64;
+    const unsigned blocks = (unsigned)std::max<int64_t>(1, p.max_blocks > 0 ? std::min<int64_t>(need, p.max_blocks) : need);
+    if (greedy) hipLaunchKernelGGL(greedy_kernel, dim3(blocks), dim3(64), 0, st, p);
+    else hipLaunchKernelGGL(dynprog_kernel, dim3(blocks), dim3(64), 0, st, p);
     return hipGetLastError();
 }
 
