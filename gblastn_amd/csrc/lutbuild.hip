@@ -8,6 +8,7 @@
 // of cache misses on one host core, plus 0.28 GB of uploads -- here a few kernels and two library calls
 // (radix sort, prefix sums) on data that never leaves HBM.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <hipcub/hipcub.hpp>
 #include "gbn_dev.h"
 #include "lutbuild.h"
@@ -30,7 +31,8 @@ __device__ __forceinline__ uint32_t reduce_fp(uint32_t fp) { return ((((fp >> 1)
 __global__ void __launch_bounds__(1024) lut_enumerate_kernel(gbn::LutBuild B)
 {
     __shared__ uint32_t s_cnt[16], s_base;
-    const int32_t p = (int32_t)(blockIdx.x * blockDim.x + threadIdx.x);
+    for (int64_t chunk = blockIdx.x; chunk * 1024 < B.qlen; chunk += gridDim.x) {    // uniform over the workgroup
+    const int32_t p = (int32_t)(chunk * 1024 + threadIdx.x);
     bool ok = false; uint32_t cell = 0;
     if (p < B.qlen) {
         int lo = 0, hi = B.nseg;                    // last stretch that starts at or before p
@@ -65,6 +67,8 @@ __global__ void __launch_bounds__(1024) lut_enumerate_kernel(gbn::LutBuild B)
         B.keys_a[at] = ((uint64_t)cell << B.q_bits) | (B.descending ? (qmax - (uint32_t)p) : (uint32_t)p);
         B.vals_a[at] = (uint32_t)p;
     }
+    __syncthreads();                                // s_cnt / s_base are reused by the next chunk
+    }
 }
 
 // small-NA table: does the overflow array stay below 32,768 entries?  (CORE/blast_nalookup.c:184-187, :200-324)
@@ -79,19 +83,18 @@ __global__ void lut_overflow_kernel(const uint32_t *count, int64_t ncells, unsig
 // entries in chain order: fingerprint + offset
 __global__ void lut_entries_kernel(gbn::LutBuild B, int64_t n)
 {
-    const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
-    const int32_t off = (int32_t)B.vals_b[k];
-    const bool force = B.onebyte_mode && (off + B.lut >= B.qlen);
-    B.ent[k] = ((unsigned long long)fingerprint_dev(B.q8, off, B.lut, force) << 32) | (uint32_t)off;
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+        const int32_t off = (int32_t)B.vals_b[k];
+        const bool force = B.onebyte_mode && (off + B.lut >= B.qlen);
+        B.ent[k] = ((unsigned long long)fingerprint_dev(B.q8, off, B.lut, force) << 32) | (uint32_t)off;
+    }
 }
 
 // per cell: direct-probe word, LDS table word for cells with one or two entries, size of its side list
 __global__ void lut_cells_kernel(gbn::LutBuild B)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c > B.ncells) return;
-    if (c == B.ncells) { B.many[c] = 0; return; }
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= B.ncells; c += (int64_t)gridDim.x * blockDim.x) {
+    if (c == B.ncells) { B.many[c] = 0; continue; }
     const uint32_t s = B.cell_start[c], e = B.cell_start[c + 1];
     uint32_t w = 0, t = 0, many = 0;
     if (e > s) {
@@ -105,34 +108,37 @@ __global__ void lut_cells_kernel(gbn::LutBuild B)
         else if (e - s >= 3) { t = 0x80000000u; many = (e - s < 16384u) ? e - s : 0u; }    // decided by lut_side_kernel
     }
     B.cellw[c] = w; B.cellt[c] = t; B.many[c] = many;
+    }
 }
 
 // cells with three or more entries: their reduced fingerprints go to the bin's side list while it has room
 __global__ void lut_side_kernel(gbn::LutBuild B)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < B.ncells; c += (int64_t)gridDim.x * blockDim.x) {
     if (c < (int64_t)B.nbins + 1) {
         const int64_t first = min(c * (int64_t)GBN_BIN_CELLS, B.ncells);
         B.side_start[c] = B.many_prefix[first];
     }
-    if (c >= B.ncells) return;
     const uint32_t cnt = B.many[c];
-    if (!cnt) return;
+    if (!cnt) continue;
     const int64_t bin = c / GBN_BIN_CELLS;
     const uint32_t base = B.many_prefix[bin * (int64_t)GBN_BIN_CELLS], off = B.many_prefix[c] - base;
-    if (off + cnt > (uint32_t)GBN_BIN_SIDE) return;             // stays "always rare"
+    if (off + cnt > (uint32_t)GBN_BIN_SIDE) continue;           // stays "always rare"
     const uint32_t s = B.cell_start[c];
     for (uint32_t k = 0; k < cnt; k++) B.sidet[base + off + k] = (uint16_t)reduce_fp((uint32_t)(B.ent[s + k] >> 32));
     B.cellt[c] = 0x80000000u | off | (cnt << 16);
+    }
 }
 
 __global__ void lut_pv_kernel(const uint32_t *count, int64_t ncells, uint32_t *pv)
 {
-    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool present = c < ncells && count[c] != 0;
-    const unsigned long long m = __ballot(present);
     const int lane = (int)(threadIdx.x & 63);
-    if (c < ncells && (lane & 31) == 0) pv[c >> 5] = (uint32_t)(m >> (lane & 32));
+    const int64_t span = (ncells + 63) & ~(int64_t)63;      // whole waves: the ballot needs every lane of a wave
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < span; c += (int64_t)gridDim.x * blockDim.x) {
+        const bool present = c < ncells && count[c] != 0;
+        const unsigned long long m = __ballot(present);
+        if (c < ncells && (lane & 31) == 0) pv[c >> 5] = (uint32_t)(m >> (lane & 32));
+    }
 }
 
 // 2-bit copy of the query + bitmap of the codes that can never match a subject base, for the gapped kernels'
@@ -156,6 +162,15 @@ __global__ void lut_pack_query_kernel(const uint8_t *qbuf, int64_t qbuf_len, int
 
 namespace gbn {
 
+// The builder runs next to a search whose kernels need whole CUs: its own kernels keep to a few waves per CU
+// (grid-stride loops) instead of filling every wave slot for a moment.
+static unsigned polite_grid(int64_t work_items, int block) {
+    static int cus = 0;
+    if (!cus) { hipDeviceProp_t pr; int dev = 0; (void)hipGetDevice(&dev); cus = (hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256; }
+    const int64_t need = (work_items + block - 1) / block, cap = (int64_t)cus * (block >= 1024 ? 1 : 2);
+    return (unsigned)std::max<int64_t>(1, std::min(need, cap));
+}
+
 hipError_t lut_pack_query(const uint8_t *qbuf, int64_t qbuf_len, int64_t first, int64_t n, uint8_t *q2, uint8_t *qinv, hipStream_t st)
 {
     const int64_t groups = (n + 7) / 8;
@@ -167,7 +182,7 @@ hipError_t lut_pack_query(const uint8_t *qbuf, int64_t qbuf_len, int64_t first, 
 hipError_t lut_enumerate(const LutBuild &b, hipStream_t st)
 {
     if (b.qlen <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_enumerate_kernel, dim3((unsigned)((b.qlen + 1023) / 1024)), dim3(1024), 0, st, b);
+    hipLaunchKernelGGL(lut_enumerate_kernel, dim3(polite_grid(b.qlen, 1024)), dim3(1024), 0, st, b);
     return hipGetLastError();
 }
 hipError_t lut_overflow_cells(const LutBuild &b, unsigned long long *out, hipStream_t st)
@@ -186,22 +201,22 @@ hipError_t lut_scan(void *tmp, size_t &bytes, const uint32_t *in, uint32_t *out,
 hipError_t lut_entries(const LutBuild &b, int64_t n, hipStream_t st)
 {
     if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_entries_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b, n);
+    hipLaunchKernelGGL(lut_entries_kernel, dim3(polite_grid(n, 256)), dim3(256), 0, st, b, n);
     return hipGetLastError();
 }
 hipError_t lut_cells(const LutBuild &b, hipStream_t st)
 {
-    hipLaunchKernelGGL(lut_cells_kernel, dim3((unsigned)((b.ncells + 1 + 255) / 256)), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(lut_cells_kernel, dim3(polite_grid(b.ncells + 1, 256)), dim3(256), 0, st, b);
     return hipGetLastError();
 }
 hipError_t lut_side(const LutBuild &b, hipStream_t st)
 {
-    hipLaunchKernelGGL(lut_side_kernel, dim3((unsigned)((b.ncells + 255) / 256)), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(lut_side_kernel, dim3(polite_grid(b.ncells, 256)), dim3(256), 0, st, b);
     return hipGetLastError();
 }
 hipError_t lut_pv(const LutBuild &b, hipStream_t st)
 {
-    hipLaunchKernelGGL(lut_pv_kernel, dim3((unsigned)((b.ncells + 255) / 256)), dim3(256), 0, st, b.count, b.ncells, b.pv);
+    hipLaunchKernelGGL(lut_pv_kernel, dim3(polite_grid(b.ncells, 256)), dim3(256), 0, st, b.count, b.ncells, b.pv);
     return hipGetLastError();
 }
 
