@@ -154,13 +154,23 @@ scan_seed_kernel(GbnScanParams P)
         // ---- phase 1: extract lookup words, presence test, ballot-compact ----
         const uint32_t mask = (uint32_t)(P.ncells - 1);
         const int shift = 32 - 2 * P.lut;
-        for (int i = tid; i < GBN_TILE_POS; i += GBN_SCAN_THREADS) {
-            bool present = false; uint32_t cell = 0; int32_t s = 0;
-            if (i < T.npos) {
-                s = T.first_pos + i * P.step;
-                cell = (window16(subj, s) >> shift) & mask;
-                present = (P.pv[cell >> 5] >> (cell & 31)) & 1u;
-            }
+        // all subject windows of the lane first, then all presence words, then the ballots: 8 independent
+        // loads in flight per lane instead of a chain of two dependent ones per position
+        constexpr int PER = GBN_TILE_POS / GBN_SCAN_THREADS;
+        uint32_t win[PER], pvw[PER];
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = min(tid + k * GBN_SCAN_THREADS, T.npos - 1);      // clamped: always a valid address
+            win[k] = window16(subj, T.first_pos + i * P.step);
+        }
+        #pragma unroll
+        for (int k = 0; k < PER; k++) pvw[k] = P.pv[((win[k] >> shift) & mask) >> 5];
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const int i = tid + k * GBN_SCAN_THREADS;
+            const uint32_t cell = (win[k] >> shift) & mask;
+            const int32_t s = T.first_pos + i * P.step;
+            const bool present = i < T.npos && ((pvw[k] >> (cell & 31)) & 1u);
             unsigned long long b = __ballot(present);
             if (b) {
                 int lane = tid & 63;
