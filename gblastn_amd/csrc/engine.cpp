@@ -219,7 +219,7 @@ static int upload_host_tables(GbnBatch &b) {
         if (e - s >= 3 || forced_cell) {
             // three or more entries: reduced fingerprints go to the bin's side list (capacity
             // GBN_BIN_SIDE per bin); anything that does not fit is "always rare path"
-            const int64_t bin = c / GBN_BIN_CELLS;
+            const int64_t bin = c >> GBN_BIN_CBITS(L.lut);
             if (bin != cur_bin) { cur_bin = bin; while ((int64_t)side_start.size() <= bin) side_start.push_back((uint32_t)sidet.size()); }
             // (same layout as the device builder: a list that does not fit still takes up its slots)
             const uint32_t off = (uint32_t)sidet.size() - side_start[bin], cnt = e - s;
@@ -233,7 +233,7 @@ static int upload_host_tables(GbnBatch &b) {
         }
     }
     {
-        const int64_t nbins = (L.ncells + GBN_BIN_CELLS - 1) / GBN_BIN_CELLS;
+        const int64_t nbins = std::max<int64_t>(1, L.ncells >> GBN_BIN_CBITS(L.lut));
         while ((int64_t)side_start.size() <= nbins) side_start.push_back((uint32_t)sidet.size());
         sidet.push_back(0);
     }
@@ -280,7 +280,8 @@ static int build_tables_on_device(GbnBatch &b) {
     B.lut = L.lut; B.word = L.word; B.q_bits = std::min(31, bits_for((uint64_t)b.qlen + 1)); B.ncells = L.ncells;
     B.count = count; B.n_words = ctr; B.keys_a = keys_a; B.keys_b = keys_b; B.vals_a = vals_a; B.vals_b = vals_b;
     B.cell_start = d->cell_start; B.cellw = d->cellw; B.cellt = d->cellt; B.pv = d->pv; B.many = many; B.many_prefix = many_prefix;
-    B.nbins = (int32_t)((L.ncells + GBN_BIN_CELLS - 1) / GBN_BIN_CELLS);
+    B.cbits = GBN_BIN_CBITS(L.lut);
+    B.nbins = (int32_t)std::max<int64_t>(1, L.ncells >> B.cbits);
     B.descending = (L.type == GBN_LUT_MB) ? 1 : 0;     // (the fallback below never produces or removes a megablast table)
     LUTCHK(lut_enumerate(B, st));
     if (L.type == GBN_LUT_SMALL_NA) LUTCHK(lut_overflow_cells(B, ctr + 1, st));
@@ -491,12 +492,11 @@ static int scan_grid(int64_t ntiles) {
     return (int)std::max<int64_t>(1, std::min(ntiles, g));
 }
 
-// number of key-range bins of the partitioned scan: GBN_BIN_CELLS cells per bin
-// (one LDS-resident slice of the cell table).  Tables below 8 slices stay on
-// the direct-probe kernel.  GBN_SCAN_BINS=1 forces the direct kernel.
+// number of key-range bins of the partitioned scan: 2^GBN_BIN_CBITS(lut) cells per bin (one LDS-resident
+// slice of the cell table), 512 bins for every table from lut 8 up.  GBN_SCAN_BINS=1 forces the direct kernel.
 static int choose_bins(const GbnBatch &b) {
-    int64_t nb = b.lut.ncells / GBN_BIN_CELLS;
-    if (nb < 8 || nb > GBN_BIN_MAXNB) nb = 1;
+    int64_t nb = b.lut.ncells >> GBN_BIN_CBITS(b.lut.lut);
+    if (nb < 2 || nb > GBN_BIN_MAXNB) nb = 1;
     if (const char *e = getenv("GBN_SCAN_BINS")) { if (atoi(e) == 1) nb = 1; }
     return (int)nb;
 }
@@ -582,7 +582,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             }
             HIPCHK(hipMemsetAsync(E.bin_count + nstream, 0, 16, E.stream));
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
-            B.S = P; B.nb = nb; B.cbits = 15; B.nwriters = nwriters; dbg_nwriters = nwriters; dbg_subcap = (uint32_t)subcap;
+            B.S = P; B.nb = nb; B.cbits = GBN_BIN_CBITS(b.lut.lut); B.nwriters = nwriters; dbg_nwriters = nwriters; dbg_subcap = (uint32_t)subcap;
             B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfrbits = std::min(7, 2 * b.dev->fr);
             B.rec = reinterpret_cast<uint32_t *>(E.bin_rec); B.tcur = E.bin_tcur; B.nseq = (uint32_t)nseq; B.gcount = E.bin_count; B.subcap = (uint32_t)subcap;
             B.overflow = E.bin_count + nstream;

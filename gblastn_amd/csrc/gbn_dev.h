@@ -53,7 +53,11 @@ struct GbnScanParams {
 #define GBN_BIN_TILE_POS (1 << GBN_BIN_TILE_BITS)   // scan positions per tile (posid = tile << GBN_BIN_TILE_BITS | i)
 #define GBN_BIN_GROUPS   8          // probe workgroups with equal (blockIdx & 7) share a bin (and an XCD)
 #define GBN_BIN_MAXNB    512
-#define GBN_BIN_CELLS    32768      // cells per bin (LDS table entries)
+#define GBN_BIN_CELLS    32768      // most cells a bin can have (LDS table entries)
+// cells per bin = 2^cbits: 128 bins for tables of 4^8 .. 4^11 cells, 512 for 4^12 -- a histogram over a handful
+// of bins is a queue of LDS atomics on the same addresses (2 bins: binning 10.5 instead of 8 ms per 50 Gbp),
+// 512 bins where 128 do cost more stream ends and cursors (lut 11: +10 %); never below 128 cells per bin
+#define GBN_BIN_CBITS(lut) ((2 * (lut) - 7) < 7 ? 7 : ((2 * (lut) - 7) > 15 ? 15 : (2 * (lut) - 7)))
 #define GBN_BIN_TABW     (GBN_BIN_CELLS + 4)   // words of the probe kernel's LDS table: the cells + one always-empty cell (+ alignment)
 #define GBN_REC_PAD      0x40000000u  // hi word of a pad record: "cell" GBN_BIN_CELLS, the always-empty one -- needs no special case
 #define GBN_BIN_QCAP     128        // per-wave queue of rare-path items in the probe kernel

@@ -1201,6 +1201,8 @@ extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan
 extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { GBN_BIN_BODY<18>(B); }
 extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s1(GbnBinParams B) { GBN_BIN_BODY<1>(B); }
 extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s2(GbnBinParams B) { GBN_BIN_BODY<2>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s4(GbnBinParams B) { GBN_BIN_BODY<4>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s21(GbnBinParams B) { GBN_BIN_BODY<21>(B); }
 
 namespace {
 // rare path of the probe kernel: full fingerprints, chain walk, exact verification
@@ -1262,7 +1264,9 @@ probe_bin_kernel(GbnBinParams B)
     uint32_t *s_rcount = s_dyn + GBN_BIN_TABW + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2 + GBN_BIN_SIDE / 2;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int grp = blockIdx.x & (GBN_BIN_GROUPS - 1);
-    const int wi = blockIdx.x >> 3, nw = gridDim.x >> 3;            // workgroup index inside its group
+    // tables of fewer slices than groups (2 or 4 bins): the groups that share a bin split its streams
+    const int bstep = B.nb < GBN_BIN_GROUPS ? B.nb : GBN_BIN_GROUPS, sub = grp / bstep, nsub = GBN_BIN_GROUPS / bstep;
+    const int wi = (int)(blockIdx.x >> 3) + sub * (int)(gridDim.x >> 3), nw = (int)(gridDim.x >> 3) * nsub;   // workgroup index among those on the bin
     const int cbits = B.cbits;
     const uint32_t ncell_bin = 1u << cbits;
     GbnU2 *myq = B.rareq + (size_t)blockIdx.x * B.rare_seg;          // this workgroup's segment: no global atomics
@@ -1313,7 +1317,7 @@ probe_bin_kernel(GbnBinParams B)
         }
     };
 
-    for (int b = grp; b < B.nb; b += GBN_BIN_GROUPS) {
+    for (int b = grp % bstep; b < B.nb; b += GBN_BIN_GROUPS) {
         __syncthreads();
         {
             const uint4 *src = reinterpret_cast<const uint4 *>(B.cellt + ((size_t)b << cbits));
@@ -1489,10 +1493,12 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
     hipError_t e = hipSuccess;
     if (ev) (void)hipEventRecord(ev[0], st);
     if (parts & 1) {
-        // stride-specialised variants: megablast (word 28 with lut 12 / lut 11) and blastn (word 11 with lut 11 / 10)
+        // stride-specialised variants: megablast (word 28 with lut 12 / 11 / 8) and blastn (word 11 with lut 11 / 10 / 8)
         const bool generic = (b.dbg & 64) != 0;
         if (b.S.step == 1 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s1, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
         else if (b.S.step == 2 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s2, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else if (b.S.step == 4 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s4, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else if (b.S.step == 21 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s21, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
         else if (b.S.step == 17 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
         else if (b.S.step == 18 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s18, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
         else hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);

@@ -16,7 +16,7 @@ struct LutBuild {                           // device pointers throughout
     uint32_t *cell_start;                   // ncells + 1
     uint32_t *cellw, *cellt, *pv; unsigned long long *ent;
     uint32_t *many, *many_prefix;           // ncells + 1
-    uint16_t *sidet; uint32_t *side_start; int32_t nbins;
+    uint16_t *sidet; uint32_t *side_start; int32_t nbins, cbits;     // bins of 2^cbits cells (GBN_BIN_CBITS)
 };
 
 hipError_t lut_enumerate(const LutBuild &b, hipStream_t st);

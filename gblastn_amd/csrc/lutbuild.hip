@@ -116,13 +116,13 @@ __global__ void lut_side_kernel(gbn::LutBuild B)
 {
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < B.ncells; c += (int64_t)gridDim.x * blockDim.x) {
     if (c < (int64_t)B.nbins + 1) {
-        const int64_t first = min(c * (int64_t)GBN_BIN_CELLS, B.ncells);
+        const int64_t first = min(c << B.cbits, B.ncells);
         B.side_start[c] = B.many_prefix[first];
     }
     const uint32_t cnt = B.many[c];
     if (!cnt) continue;
-    const int64_t bin = c / GBN_BIN_CELLS;
-    const uint32_t base = B.many_prefix[bin * (int64_t)GBN_BIN_CELLS], off = B.many_prefix[c] - base;
+    const int64_t bin = c >> B.cbits;
+    const uint32_t base = B.many_prefix[bin << B.cbits], off = B.many_prefix[c] - base;
     if (off + cnt > (uint32_t)GBN_BIN_SIDE) continue;           // stays "always rare"
     const uint32_t s = B.cell_start[c];
     for (uint32_t k = 0; k < cnt; k++) B.sidet[base + off + k] = (uint16_t)reduce_fp((uint32_t)(B.ent[s + k] >> 32));
