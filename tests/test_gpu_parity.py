@@ -507,3 +507,40 @@ print(json.dumps(out))
         assert dev == host, (dev[0], host[0])
         kinds.add((dev[0]["lut_type"], dev[0]["lut_width"]))
     assert len(kinds) >= 3 and sum(len(r[1]) for r in res["0"]) > 0
+
+
+import os as _os
+_FUZZ = [101, 202, 303, 404, 505, 606] + list(range(1000, 1000 + int(_os.environ.get("GBN_FUZZ_EXTRA", "0"))))
+
+
+@pytest.mark.parametrize("seed", _FUZZ)
+def test_randomised_shapes_against_the_oracle(seed):
+    """Random task / word size / scoring / batch size / subject count per seed, every stage compared with the
+    oracle: exercises the device-built tables of every kind, the stride variants of the binning kernel
+    (1, 2, 4, 17, 18, 21 and the generic one), 2..512 bins, masks, and both gapped kernels."""
+    rng = np.random.default_rng(seed)
+    for _ in range(5):
+        task = "megablast" if rng.random() < 0.5 else "blastn"
+        nq = int(rng.choice([1, 2, 7, 30, 120]))
+        nsub, slen = int(rng.integers(2, 9)), int(rng.choice([30_000, 120_000, 400_000]))
+        kw = {}
+        if task == "megablast":
+            kw["word_size"] = int(rng.choice([28, 28, 20, 32, 16, 48]))
+        else:
+            kw["word_size"] = int(rng.choice([11, 11, 9, 7, 13, 15]))
+            if rng.random() < 0.3:
+                kw.update(reward=1, penalty=-3, gap_open=5, gap_extend=2)
+        db, queries, plants, subjects, opt = util.small_case(nsub, slen, nq, seed=int(rng.integers(1, 1 << 30)),
+                                                             planted_fraction=0.6, task=task, **kw)
+        masks = None
+        if rng.random() < 0.4:
+            masks = sorted((int(q), int(a), int(a + rng.integers(5, 200))) for q, a in
+                           zip(rng.choice(nq, min(nq, 3), replace=False), rng.integers(0, 700, 3)))
+        src = api.BlastSeqSrc.from_packed(subjects)
+        ps = api.BlastPrelimSearch(queries, opt, src, masks=masks)
+        got = ps.run(keep_stages=True)
+        ora, osearch = util.oracle_run(opt, queries, subjects, masks=masks)
+        util.compare_stages(got, ora)
+        d, st = ps.diagnostics, osearch.stats
+        assert (d.lookup_hits, d.good_init_extends, d.gapped_extensions, d.good_extensions) == \
+               (st.lookup_hits, st.good_init_extends, st.gapped_extensions, st.good_extensions), (task, kw, ps.info())
