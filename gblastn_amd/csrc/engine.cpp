@@ -2,10 +2,11 @@
 // (the BLAST_PreliminarySearchEngine analogue,
 // GB/gpu_blastn_pre_search_engine.cpp:1125-1464), plus the C ABI.
 //
-// Pipeline per shard (all on one HIP stream):
-//   scan_seed_kernel -> 2 stable radix sorts (scan order, then diagonal slot)
-//   -> diag_ungapped_kernel -> greedy_kernel | dynprog_kernel (all initial hits)
-//   -> D2H of initial hits + gapped results -> host replay (hsp_host.cpp).
+// Per query batch: host set-up (batch.cpp) + lookup structures built on the device (lutbuild.hip, own
+// stream).  Per subject range of a shard, on the engine's stream: scan_bin -> probe_bin -> probe_rare
+// (or scan_seed_kernel); then -- on the second stream + a host thread when the caller pipelines batches --
+// two stable radix sorts (scan order, then diagonal slot) -> diag_ungapped_kernel -> greedy_kernel |
+// dynprog_kernel (all initial hits) -> D2H of initial hits + gapped results -> host replay (hsp_host.cpp).
 #include <hip/hip_runtime.h>
 #include "gbn_host.hpp"
 #include "lutbuild.h"

@@ -1,16 +1,22 @@
 // kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the blastn /
 // megablast preliminary search.  Integer work only: no MFMA.
 //
-//   scan_seed_kernel     subject scan + lookup + exact-match verification to
-//                        word_size (replaces TNaScanSubjectFunction +
-//                        TNaExtendFunction mini-extension; CORE/blast_nascan.c,
-//                        CORE/na_ungapped.c:1025-1555)
+//   scan_bin_kernel*     phase 1 of the key-range partitioned scan: every scan position of the
+//                        subjects becomes a 6-byte record in the stream of its lookup word's bin
+//   probe_bin_kernel     phase 2: a bin's slice of the cell table in LDS, its records streamed through
+//   probe_rare_kernel    phase 3: exact verification of the survivors to word_size
+//                        (together: TNaScanSubjectFunction + TNaExtendFunction mini-extension;
+//                        CORE/blast_nascan.c, CORE/na_ungapped.c:1025-1555)
+//   scan_seed_kernel     the same work by direct table probes, without streams (fallback for
+//                        repeat-dominated subject ranges)
+//   seed_keys / group_keys / run_heads kernels: the scan order and the (subject, diagonal slot) runs
 //   diag_ungapped_kernel per-diagonal one-hit filter + X-drop ungapped extension
 //                        (CORE/na_ungapped.c:152-351, :611-922)
-//   greedy_kernel        megablast score-only greedy gapped extension
+//   greedy_kernel        megablast score-only greedy gapped extension, linear and affine
 //                        (CORE/greedy_align.c:385-753, CORE/blast_gapalign.c:2619-2751)
 //   dynprog_kernel       blastn score-only X-drop DP on the packed subject
 //                        (CORE/blast_gapalign.c:2762-3056)
+// (lookup tables of a query batch: lutbuild.hip)
 //
 // Data layout: subjects are NCBI2na (4 bases/byte, base 0 in
 // bits 7..6) back to back in one HBM slab, 16-byte aligned each; the query is
