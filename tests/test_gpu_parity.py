@@ -510,7 +510,7 @@ print(json.dumps(out))
 
 
 import os as _os
-_FUZZ = [101, 202, 303, 404, 505, 606] + list(range(1000, 1000 + int(_os.environ.get("GBN_FUZZ_EXTRA", "0"))))
+_FUZZ = [101, 202, 303, 404, 505, 606] + list(range(int(_os.environ.get("GBN_FUZZ_BASE", "1000")), int(_os.environ.get("GBN_FUZZ_BASE", "1000")) + int(_os.environ.get("GBN_FUZZ_EXTRA", "0"))))
 
 
 @pytest.mark.parametrize("seed", _FUZZ)
