@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
                     help="C2 (the metric's config): megablast W=28 vs 50 Gbp; C3: blastn W=11 vs 5 Gbp, 100 kb batches")
