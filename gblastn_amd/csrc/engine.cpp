@@ -1004,9 +1004,14 @@ int Blast_gpu_Init(int use_gpu, int gpu_id) {
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, dev));
     E.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
-    HIPCHK(hipStreamCreateWithFlags(&E.stream, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&E.stream2, hipStreamNonBlocking));
-    HIPCHK(hipStreamCreateWithFlags(&E.stream_build, hipStreamNonBlocking));
+    {   // the scan stream outranks the extension and table-builder streams: its kernels need whole CUs
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least, hi = greatest priority
+        const bool prio = getenv("GBN_STREAM_PRIORITY") ? atoi(getenv("GBN_STREAM_PRIORITY")) != 0 : true;
+        HIPCHK(hipStreamCreateWithPriority(&E.stream, hipStreamNonBlocking, prio ? hi : 0));
+        HIPCHK(hipStreamCreateWithPriority(&E.stream2, hipStreamNonBlocking, prio ? lo : 0));
+        HIPCHK(hipStreamCreateWithPriority(&E.stream_build, hipStreamNonBlocking, prio ? lo : 0));
+    }
     HIPCHK(hipEventCreate(&E.ev0)); HIPCHK(hipEventCreate(&E.ev1));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&E.evk[i]));
     HIPCHK(hipEventCreateWithFlags(&E.ev_seed, hipEventDisableTiming));
