@@ -177,7 +177,10 @@ int  gbn_blastdb_get_blastna(const GbnBlastDb *db, int32_t oid, uint8_t *dst, in
 struct GbnDb;
 int  gbn_blastdb_load_shard(const GbnBlastDb *db, int32_t first_oid, int32_t num_oids, struct GbnDb **out);
 
-/* ---- query batch: host set-up + upload of lookup structures ---- */
+/* ---- query batch: host set-up (concatenation, Karlin-Altschul parameters, cut-offs, table kind) + lookup
+ * structures built on the device from the uploaded query (a 5 Mb megablast batch: ~5 ms in all).  Thread
+ * safe next to a running search: the builder has its own stream, its memory comes from a pool.  The
+ * reference builds these tables on the host in LookupTableWrapInit (CORE/lookup_wrap.c:52-174). ---- */
 typedef struct GbnBatch GbnBatch;
 /* seqs[i]: BLASTNA codes (0..15), plus strand, lens[i] bases */
 int  gbn_batch_new(GbnBatch **out, const GbnOptions *opt, int32_t nq,
