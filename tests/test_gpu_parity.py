@@ -514,7 +514,7 @@ _FUZZ = [101, 202, 303, 404, 505, 606] + list(range(int(_os.environ.get("GBN_FUZ
 
 
 @pytest.mark.parametrize("seed", _FUZZ)
-def test_randomised_shapes_against_the_oracle(seed):
+def test_randomised_shapes_against_the_oracle(seed, monkeypatch):
     """Random task / word size / scoring / batch size / subject count per seed, every stage compared with the
     oracle: exercises the device-built tables of every kind, the stride variants of the binning kernel
     (1, 2, 4, 17, 18, 21 and the generic one), 2..512 bins, masks, and both gapped kernels."""
@@ -544,3 +544,9 @@ def test_randomised_shapes_against_the_oracle(seed):
         d, st = ps.diagnostics, osearch.stats
         assert (d.lookup_hits, d.good_init_extends, d.gapped_extensions, d.good_extensions) == \
                (st.lookup_hits, st.good_init_extends, st.gapped_extensions, st.good_extensions), (task, kw, ps.info())
+        # the pipelined entry points over subject ranges of a few tiles: seed + extension stages of a range
+        # on the second stream underneath the scan of the next one
+        monkeypatch.setenv("GBN_RANGE_TILES", str(int(rng.integers(2, 9))))
+        ps.begin()
+        assert np.array_equal(ps.end()["hsps"], got["hsps"]), (task, kw, ps.info())
+        monkeypatch.delenv("GBN_RANGE_TILES")
