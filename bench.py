@@ -144,11 +144,12 @@ def main():
             b.close()
             return got
         prev, futs = None, []
-        ahead = [setup_pool.submit(make, k) for k in range(min(2, count))]
+        # the first set-up runs alone (nothing to hide behind yet); from then on two are in flight
+        ahead, queued = [setup_pool.submit(make, 0)], 1
         for k in range(count):
             b = ahead.pop(0).result()
-            if k + 2 < count:
-                ahead.append(setup_pool.submit(make, k + 2))
+            while queued < count and queued <= k + 2:
+                ahead.append(setup_pool.submit(make, queued)); queued += 1
             b.begin()                       # waits for prev's extension stages before queueing its own
             if prev is not None:
                 futs.append(merger.submit(finish, prev, prev.end())); diags.append(prev.diagnostics)
