@@ -234,12 +234,13 @@ int  gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results,
                        GbnDiagnostics *diag, int keep_stages,
                        GbnInterruptFn interrupt, void *progress);
 /* Pipelined form (the reference's "-mode 1" PrelimSearchThread / TraceBackThread split,
- * GB/work_thread.cpp:60-107, moved one stage down): _begin returns once the scan, the seed ordering
- * and the ungapped stage of the LAST subject range are done; the gapped extensions of that range and
- * their host-side acceptance run on a second HIP stream and a host thread while the caller starts
- * the next query batch.  `results` and `diag` must stay alive and untouched until _end(results) has
- * returned (it returns at once if a later _begin has already waited for them).  At most one gapped
- * stage is in flight. */
+ * GB/work_thread.cpp:60-107, moved one stage down): _begin returns once the scan of the LAST subject
+ * range is done.  For ranges with few seeds (megablast shapes) everything after the scan -- seed order,
+ * diagonal filter, ungapped and gapped extension, host-side acceptance -- runs on a second HIP stream and
+ * a host thread while the caller starts the next query batch; with many seeds (blastn shapes) the seed
+ * stage stays on the engine's stream and the gapped stage is asynchronous.  `batch`, `results` and `diag`
+ * must stay alive and untouched until _end(results) has returned (it returns at once if a later _begin
+ * has already waited for them; gbn_batch_free waits by itself).  At most one such stage is in flight. */
 int  gbn_prelim_search_begin(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
                              GbnInterruptFn interrupt, void *progress);
 int  gbn_prelim_search_end(GbnResults *results);   /* NULL: whatever is in flight */
