@@ -27,7 +27,7 @@
 namespace gbn {
 hipError_t launch_scan_seed(const GbnScanParams &p, int grid, hipStream_t st);
 hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev);
-hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts);
+hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts, hipEvent_t tables_ready);
 hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st);
@@ -63,6 +63,9 @@ struct DeviceBatch {
             *ctx_reduced = nullptr;
     int32_t *matrix = nullptr, *score_table = nullptr;
     int mode = 0, fl = 0, fr = 0;
+    // lookup structures still being built on the builder's stream: the event they are complete at, and the
+    // builder's scratch, which goes back to the pool once it has fired
+    hipEvent_t ready = nullptr; std::vector<void *> build_scratch;
 };
 
 struct Engine {
@@ -166,8 +169,18 @@ template <class T> static int dev_upload(T *&p, const T *h, size_t n) {
 }
 template <class T> static void dev_free(T *&p) { if (p) pool_free((void *)p); p = nullptr; }
 
+// the batch's lookup structures are complete (waits for the builder if they are not): scratch back to the pool
+static void finish_build(DeviceBatch *d) {
+    if (!d || !d->ready) return;
+    (void)hipEventSynchronize(d->ready);
+    for (void *p : d->build_scratch) pool_free(p);
+    d->build_scratch.clear();
+    (void)hipEventDestroy(d->ready); d->ready = nullptr;
+}
+
 void free_device_batch(DeviceBatch *d) {
     if (!d) return;
+    finish_build(d);
     dev_free(d->q8_base); dev_free(d->q2_base); dev_free(d->qinv_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent);
     dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff);
     dev_free(d->ctx_reduced); dev_free(d->matrix); dev_free(d->score_table);
@@ -284,6 +297,39 @@ static int build_tables_on_device(GbnBatch &b) {
     B.cbits = GBN_BIN_CBITS(L.lut);
     B.nbins = (int32_t)std::max<int64_t>(1, L.ncells >> B.cbits);
     B.descending = (L.type == GBN_LUT_MB) ? 1 : 0;     // (the fallback below never produces or removes a megablast table)
+    // Megablast / standard tables need nothing back on the host: the whole build is queued on the builder's
+    // stream, sized by upper bounds (at most one word per query position), and the batch carries an event;
+    // the engine lets the probe kernel wait for it -- the binning kernel of the search starts at once.
+    static const bool sync_build = getenv("GBN_SYNC_BUILD") && atoi(getenv("GBN_SYNC_BUILD")) != 0;
+    if (L.type != GBN_LUT_SMALL_NA && !sync_build) {
+        LUTCHK(hipMemsetAsync(keys_a, 0xff, qn * 8, st));           // positions without a word sort behind the words
+        LUTCHK(lut_enumerate(B, st));
+        B.onebyte_mode = 0;
+        LUTRC(dev_alloc(d->ent, qn + 1));
+        LUTRC(dev_alloc(d->sidet, qn + 1)); LUTRC(dev_alloc(d->side_start, (size_t)B.nbins + 1));
+        LUTCHK(hipMemsetAsync(d->sidet, 0, (qn + 1) * 2, st));
+        size_t b1 = 0, b2 = 0;
+        const int key_bits = std::min(64, 2 * L.lut + B.q_bits);
+        LUTCHK(lut_sort(nullptr, b1, B, (int64_t)qn, key_bits, st));
+        LUTCHK(lut_scan(nullptr, b2, count, d->cell_start, (int64_t)nc1, st));
+        LUTCHK(pool_alloc(&tmp, std::max(b1, b2) + 256));
+        size_t tb = std::max(b1, b2) + 256;
+        LUTCHK(lut_sort(tmp, tb, B, (int64_t)qn, key_bits, st));
+        tb = std::max(b1, b2) + 256;
+        LUTCHK(lut_scan(tmp, tb, count, d->cell_start, (int64_t)nc1, st));
+        B.ent = d->ent; B.sidet = d->sidet; B.side_start = d->side_start;
+        LUTCHK(lut_entries(B, -1, st));
+        LUTCHK(lut_cells(B, st));
+        tb = std::max(b1, b2) + 256;
+        LUTCHK(lut_scan(tmp, tb, many, many_prefix, (int64_t)nc1, st));
+        LUTCHK(lut_side(B, st));
+        LUTCHK(lut_pv(B, st));
+        LUTCHK(hipEventCreateWithFlags(&d->ready, hipEventDisableTiming));
+        LUTCHK(hipEventRecord(d->ready, st));
+        for (void *p : {(void *)d_sl, (void *)d_sr, (void *)count, (void *)many, (void *)many_prefix, (void *)vals_a, (void *)vals_b,
+                        (void *)keys_a, (void *)keys_b, (void *)ctr, tmp}) d->build_scratch.push_back(p);
+        return GBN_OK;
+    }
     LUTCHK(lut_enumerate(B, st));
     if (L.type == GBN_LUT_SMALL_NA) LUTCHK(lut_overflow_cells(B, ctr + 1, st));
     unsigned long long h[2] = {0, 0};
@@ -551,6 +597,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         bool binned = false;
         if (nb == 1) {
             HIPCHK(hipEventRecord(E.ev0, E.stream));
+            if (b.dev->ready) HIPCHK(hipStreamWaitEvent(E.stream, b.dev->ready, 0));
             HIPCHK(launch_scan_seed(P, scan_grid(ts.ntiles), E.stream));
             HIPCHK(hipEventRecord(E.ev1, E.stream));
         } else {
@@ -611,7 +658,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                              have.step == want_key.step && have.nb == nb && have.nwriters == nwriters && have.subcap == subcap;
             have.valid = false;
             HIPCHK(hipEventRecord(E.ev0, E.stream));
-            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, hit ? 2 : 3));
+            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, hit ? 2 : 3, b.dev->ready));
             have = want_key;                                    // invalidated below if this launch overflowed
             binned = true;
             HIPCHK(hipEventRecord(E.ev1, E.stream));
@@ -621,6 +668,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         trace_mark("scan: kernels queued");
         HIPCHK(hipStreamSynchronize(E.stream));
         trace_mark("scan: kernels done");
+        finish_build(b.dev);                                // (the scan has waited for the builder's event)
         if (diag) {
             float ms = 0; (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
             diag->scan_kernel_ms += ms; diag->scan_launches++;

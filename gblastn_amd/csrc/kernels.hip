@@ -1492,7 +1492,7 @@ probe_rare_kernel(GbnBinParams B, int nseg)
 
 namespace gbn {
 // parts: 1 = binning kernel, 2 = probe + rare kernels, 3 = all
-hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts)
+hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts, hipEvent_t tables_ready)
 {
     // ev[0..3]: before bin, after bin, after probe, after rare (optional)
     if (b.S.ntiles <= 0) return hipSuccess;
@@ -1512,6 +1512,8 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
         if (e != hipSuccess) return e;
     }
     if (ev) (void)hipEventRecord(ev[1], st);
+    // the binning kernel needs no table: a batch whose lookup structures are still being built is waited for here
+    if (tables_ready && (parts & 2)) { e = hipStreamWaitEvent(st, tables_ready, 0); if (e != hipSuccess) return e; }
     if (parts & 2) {
         const size_t lds = (size_t)GBN_BIN_TABW * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8 + (size_t)GBN_BIN_SIDE * 2 + 16;
         static bool attr_set = false;
@@ -1532,6 +1534,6 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
 }
 hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev)
 {
-    return launch_scan_bin_parts(b, grid2, st, ev, 3);
+    return launch_scan_bin_parts(b, grid2, st, ev, 3, nullptr);
 }
 }  // namespace gbn

@@ -83,7 +83,9 @@ __global__ void lut_overflow_kernel(const uint32_t *count, int64_t ncells, unsig
 // entries in chain order: fingerprint + offset
 __global__ void lut_entries_kernel(gbn::LutBuild B, int64_t n)
 {
-    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < n; k += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t nn = n >= 0 ? n : (int64_t)*B.n_words;           // n < 0: the word count is still on the device only
+    if (blockIdx.x == 0 && threadIdx.x == 0) B.ent[nn] = 0;         // pad entry: an empty list still has a valid pointer
+    for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nn; k += (int64_t)gridDim.x * blockDim.x) {
         const int32_t off = (int32_t)B.vals_b[k];
         const bool force = B.onebyte_mode && (off + B.lut >= B.qlen);
         B.ent[k] = ((unsigned long long)fingerprint_dev(B.q8, off, B.lut, force) << 32) | (uint32_t)off;
@@ -200,8 +202,8 @@ hipError_t lut_scan(void *tmp, size_t &bytes, const uint32_t *in, uint32_t *out,
 }
 hipError_t lut_entries(const LutBuild &b, int64_t n, hipStream_t st)
 {
-    if (n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_entries_kernel, dim3(polite_grid(n, 256)), dim3(256), 0, st, b, n);
+    // n < 0: count on the device (B.n_words), at most b.qlen
+    hipLaunchKernelGGL(lut_entries_kernel, dim3(polite_grid(n >= 0 ? std::max<int64_t>(n, 1) : b.qlen, 256)), dim3(256), 0, st, b, n);
     return hipGetLastError();
 }
 hipError_t lut_cells(const LutBuild &b, hipStream_t st)
