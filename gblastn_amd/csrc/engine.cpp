@@ -83,6 +83,8 @@ struct Engine {
     int slot = 0; hipStream_t stream2 = nullptr;
     hipStream_t stream_build = nullptr;      // lookup structures of the next query batch are built next to a running search
     std::future<int> pending; bool has_pending = false; std::string pending_err; const GbnResults *pending_res = nullptr;
+    // stages that failed, by the results they were filling: reported by gbn_prelim_search_end for THOSE results
+    std::map<const GbnResults *, std::pair<int, std::string>> failed;
     const GbnBatch *pending_batch = nullptr;   // the batch the stage in flight reads (its device memory must outlive the stage)
     unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits, [3] runs; [4], [5]: init hits, runs of an asynchronous seed stage
     GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
@@ -100,6 +102,10 @@ static int ensure_init() {
     if (E.ready) return GBN_OK;
     return Blast_gpu_Init(1, -1);
 }
+
+// The HIP current device is per host thread: every C-ABI entry point that touches HIP (callers use worker
+// threads for set-up and extension stages) selects the engine's device first.
+static inline void use_engine_device() { if (E.ready && E.device >= 0) (void)hipSetDevice(E.device); }
 
 // Device memory of query batches and of the table builder comes from a small pool: freed blocks are kept
 // (up to kPoolCap bytes) and handed out again for requests of about their size.  hipFree waits for the
@@ -278,8 +284,9 @@ static int build_tables_on_device(GbnBatch &b) {
     uint64_t *keys_a = nullptr, *keys_b = nullptr; unsigned long long *ctr = nullptr; void *tmp = nullptr;
     auto cleanup = [&]() { dev_free(d_sl); dev_free(d_sr); dev_free(count); dev_free(many); dev_free(many_prefix);
                            dev_free(vals_a); dev_free(vals_b); dev_free(keys_a); dev_free(keys_b); dev_free(ctr); if (tmp) pool_free(tmp); tmp = nullptr; };
-#define LUTCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); cleanup(); return GBN_ERR_HIP; } } while (0)
-#define LUTRC(x) do { if ((rc = (x))) { cleanup(); return rc; } } while (0)
+    // (on an error kernels may already be queued on the builder's stream: they finish before their scratch goes back to the pool)
+#define LUTCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); (void)hipStreamSynchronize(st); cleanup(); return GBN_ERR_HIP; } } while (0)
+#define LUTRC(x) do { if ((rc = (x))) { (void)hipStreamSynchronize(st); cleanup(); return rc; } } while (0)
     const size_t nc1 = (size_t)L.ncells + 1, qn = (size_t)std::max(b.qlen, 1);
     LUTRC(dev_upload(d_sl, sl.data(), sl.size())); LUTRC(dev_upload(d_sr, sr.data(), sr.size()));
     LUTRC(dev_alloc(count, nc1)); LUTRC(dev_alloc(many, nc1)); LUTRC(dev_alloc(many_prefix, nc1));
@@ -378,6 +385,7 @@ static int build_tables_on_device(GbnBatch &b) {
 int upload_batch(GbnBatch &b) {
     int rc = ensure_init();
     if (rc) return rc;
+    use_engine_device();
     DeviceBatch *d = new DeviceBatch();
     b.dev = d;
     trace_mark("upload: starts");
@@ -406,6 +414,7 @@ int upload_batch(GbnBatch &b) {
         d->q2 = d->q2_base + pad / 4; d->qinv = d->qinv_base + pad / 8;
     }
     if (host_lookup) {
+        HIPCHK(hipStreamSynchronize(E.stream_build));       // q2 / qinv packed: no event travels with a host-built batch
         if (L.cell_start.empty()) fill_lookup_host(b);
         // (the host builder may have turned a small-NA table into a standard one)
         if (L.lut != L.word) d->mode = (L.type == GBN_LUT_SMALL_NA) ? ((L.lut % 4 == 0 && L.step % 4 == 0 && L.word - L.lut <= 4) ? GBN_EXT_SMALL_ONEBYTE : GBN_EXT_SMALL) : GBN_EXT_NA;
@@ -513,12 +522,22 @@ static int grow_ihit_buffers(int slot, size_t n) {
     return GBN_OK;
 }
 
-// wait for the gapped stage that is still in flight (if any); returns its status
+// wait for the extension stage that is still in flight (if any).  Its failure belongs to the results it was
+// filling, not to whoever happens to wait for it: it is kept in E.failed and returned by
+// gbn_prelim_search_end(those results) (take_failure).
 static int wait_pending() {
     if (!E.has_pending) return GBN_OK;
     int rc = E.pending.get();
+    if (rc) E.failed[E.pending_res] = std::make_pair(rc, E.pending_err);
     E.has_pending = false; E.pending_uses_keys = false; E.pending_batch = nullptr;
-    if (rc && !E.pending_err.empty()) set_error(E.pending_err);
+    return GBN_OK;
+}
+static int take_failure(const GbnResults *res) {
+    auto it = E.failed.find(res);
+    if (it == E.failed.end()) return GBN_OK;
+    const int rc = it->second.first;
+    if (!it->second.second.empty()) set_error(it->second.second);
+    E.failed.erase(it);
     return rc;
 }
 
@@ -645,7 +664,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                     E.rareq_cap = want;
                 }
                 seg = E.rareq_cap / (size_t)grid2;
-                if (!E.rare_counts && (rc = dev_alloc(E.rare_counts, (size_t)1024))) return rc;
+                if (!E.rare_counts && (rc = dev_alloc(E.rare_counts, (size_t)2048))) return rc;
                 B.rareq = E.rareq; B.rare_seg = (uint32_t)std::min<size_t>(seg, 0x7fffffff); B.rare_counts = E.rare_counts;
             }
             // The scan records depend on the shard and on (lut width, stride) only, not on the queries.
@@ -695,9 +714,18 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                     for (uint32_t v : gc) { mn = std::min(mn, v); mx2 = std::max(mx2, v); sum += v; }
                     fprintf(stderr, "[gbn dbg] %zu streams: records min %u max %u total %llu (capacity %u each)\n", ns, mn, mx2, sum, dbg_subcap);
                 }
+                {   // wall clock of the binning workgroups (GBN_BIN_TIMING build)
+                    std::vector<uint32_t> w(1024);
+                    HIPCHK(hipMemcpy(w.data(), E.rare_counts + 1024, 4096, hipMemcpyDeviceToHost));
+                    uint32_t s_min = ~0u, d_min = ~0u, d_max = 0, s_max = 0; const int nw = std::min(dbg_nwriters, 512);
+                    for (int i = 0; i < nw; i++) s_min = std::min(s_min, w[i]);
+                    for (int i = 0; i < nw; i++) { s_max = std::max(s_max, w[i] - s_min); d_min = std::min(d_min, w[512 + i]); d_max = std::max(d_max, w[512 + i]); }
+                    if (getenv("GBN_DBG_WG")) { for (int i = 0; i < nw; i++) fprintf(stderr, "%u%c", w[512 + i] / 100, (i & 31) == 31 ? '\n' : ' '); }
+                    fprintf(stderr, "[gbn dbg] scan_bin workgroups: start spread %.1f us, duration min %.1f max %.1f us\n", s_max / 100.0, d_min / 100.0, d_max / 100.0);
+                }
                 uint32_t ph[8]; HIPCHK(hipMemcpy(ph, E.rare_counts + 512, sizeof(ph), hipMemcpyDeviceToHost));
                 fprintf(stderr, "[gbn dbg] scan_bin workgroup 0 (GBN_BIN_TIMING build), cycles/16 of wave 0 per phase: "
-                        "%u %u %u %u %u %u %u %u (line variant: histogram | wait A | wave scan | wait B0 + offsets | wait B + scatter | wait C + keys + stores | wait D | stay-behind moves)\n",
+                        "%u %u %u %u %u %u %u %u ([0] atomics + loads issued | wait A | [1] lines + scan | wait B0 | [2] descriptors | wait B | [3] scatter | wait C + [4] keys + stores)\n",
                         ph[0], ph[1], ph[2], ph[3], ph[4], ph[5], ph[6], ph[7]);
             }
             if ((size_t)mx > E.rareq_cap / (size_t)grid2) {    // a segment overflowed: grow and rescan this range
@@ -1081,8 +1109,10 @@ void Blast_gpu_Release(void) {
     dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_tcur); E.bin_tcur_cap = 0; dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
     E.bin_rec_cap = 0; E.bin_count_cap = 0;
     E.seed_cap = E.key_cap = 0;
+    use_engine_device();
     if (E.ev0) (void)hipEventDestroy(E.ev0);
     if (E.ev1) (void)hipEventDestroy(E.ev1);
+    for (int i = 0; i < 4; i++) { if (E.evk[i]) (void)hipEventDestroy(E.evk[i]); E.evk[i] = nullptr; }
     if (E.stream) (void)hipStreamDestroy(E.stream);
     if (E.stream2) (void)hipStreamDestroy(E.stream2);
     if (E.stream_build) (void)hipStreamDestroy(E.stream_build);
@@ -1096,6 +1126,7 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
     if (!out || !packed || num_seqs < 0 || (num_seqs > 0 && (!byte_off || !len))) { set_error("bad argument"); return GBN_ERR_ARG; }
     int rc = ensure_init();
     if (rc) return rc;
+    use_engine_device();
     GbnDb *db = new GbnDb();
     db->num_seqs = num_seqs; db->first_oid = first_oid; db->nbytes = nbytes;
     db->byte_off.assign(byte_off, byte_off + num_seqs); db->len.assign(len, len + num_seqs);
@@ -1120,6 +1151,11 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
 
 void gbn_db_free(GbnDb *db) {
     if (!db) return;
+    use_engine_device();
+    {   // a stage in flight may still read this shard
+        std::lock_guard<std::mutex> lk(E.mu);
+        if (E.has_pending) (void)wait_pending();
+    }
     if (g_binkey.db == (const void *)db) g_binkey.valid = false;
     free_tile_cache(*db);
     if (db->owns && db->d_packed) (void)hipFree((void *)db->d_packed);
@@ -1132,6 +1168,7 @@ int32_t gbn_db_num_seqs(const GbnDb *db) { return db ? db->num_seqs : 0; }
 int gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream) {
     int rc = ensure_init();
     if (rc) return rc;
+    use_engine_device();
     hipStream_t st = stream ? (hipStream_t)stream : E.stream;
     HIPCHK(launch_synth_fill(dev_ptr, nbytes, seed, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1180,6 +1217,7 @@ int gbn_launch_gapped(const GbnGapParams *p, int greedy, void *stream) {
 }
 void gbn_batch_free(GbnBatch *b) {
     if (!b) return;
+    use_engine_device();
     {   // an extension stage still reading this batch finishes first (its memory goes back to the pool, not to hipFree)
         std::lock_guard<std::mutex> lk(E.mu);
         if (E.has_pending && E.pending_batch == b) (void)wait_pending();
@@ -1200,7 +1238,15 @@ int32_t gbn_batch_diag_container(const GbnBatch *b) { return b->container; }
 int32_t gbn_batch_gap_x_dropoff(const GbnBatch *b) { return b->gap_x_dropoff; }
 
 int gbn_results_new(GbnResults **out) { if (!out) return GBN_ERR_ARG; *out = new GbnResults(); return GBN_OK; }
-void gbn_results_free(GbnResults *r) { delete r; }
+void gbn_results_free(GbnResults *r) {
+    if (!r) return;
+    {
+        std::lock_guard<std::mutex> lk(E.mu);
+        if (E.has_pending && E.pending_res == r) (void)wait_pending();
+        E.failed.erase(r);
+    }
+    delete r;
+}
 void gbn_results_clear(GbnResults *r) { if (r) { r->hsps.clear(); r->seeds.clear(); r->init_hits.clear(); } }
 int64_t gbn_results_num_hsps(const GbnResults *r) { return (int64_t)r->hsps.size(); }
 const GbnHSP *gbn_results_hsps(const GbnResults *r) { return r->hsps.data(); }
@@ -1214,6 +1260,7 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     if (!batch || !db || !results) { set_error("bad argument"); return GBN_ERR_ARG; }
     int rc = ensure_init();
     if (rc) return rc;
+    use_engine_device();
     std::lock_guard<std::mutex> lk(E.mu);
     auto t0 = std::chrono::steady_clock::now();
     trace_mark("search: entered");
@@ -1270,7 +1317,8 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
                       int keep_stages, GbnInterruptFn interrupt, void *progress) {
     int rc = run_search(batch, db, results, diag, keep_stages, interrupt, progress, 0);
     std::lock_guard<std::mutex> lk(E.mu);
-    int rc2 = wait_pending();                           // of an earlier gbn_prelim_search_begin
+    (void)wait_pending();                               // of an earlier gbn_prelim_search_begin (its status stays with its results)
+    const int rc2 = take_failure(results);
     return rc ? rc : rc2;
 }
 
@@ -1283,14 +1331,16 @@ int gbn_prelim_search_end(GbnResults *results) {
     std::lock_guard<std::mutex> lk(E.mu);
     // a stage that belongs to other results stays in flight: these results were completed when that
     // stage was queued (one in flight at most)
-    if (results && E.has_pending && E.pending_res != results) return GBN_OK;
-    return wait_pending();
+    if (results && E.has_pending && E.pending_res != results) return take_failure(results);
+    (void)wait_pending();
+    return results ? take_failure(results) : GBN_OK;
 }
 
 int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag) {
     if (!batch || !db || repeats <= 0) { set_error("bad argument"); return GBN_ERR_ARG; }
     int rc = ensure_init();
     if (rc) return rc;
+    use_engine_device();
     std::lock_guard<std::mutex> lk(E.mu);
     auto t0 = std::chrono::steady_clock::now();
     unsigned long long cnt[2] = {0, 0};

@@ -63,6 +63,9 @@ struct GbnScanParams {
 #define GBN_BIN_QCAP     128        // per-wave queue of rare-path items in the probe kernel
 #define GBN_BIN_SIDE     4096       // LDS side-list capacity (u16 fingerprints) per bin
 
+// tile processed by binning workgroup (= writer) w in its round k, n writers (see scan_bin_line_body)
+#define GBN_TILE_OF(w, k, n) ((uint32_t)(k) * (uint32_t)(n) + (((uint32_t)(w) + (uint32_t)(k)) % (uint32_t)(n)))
+
 struct GbnU2 { uint32_t x, y; };
 // Scan records: blocks of 64 records = 256 bytes of `hi` words followed by 128 bytes of 16-bit indices
 // (13 bits: position inside the tile, 3 bits: the tile's sequence number mod 8); the tile itself is not

@@ -33,7 +33,9 @@
 #define GBN_STREAM(B, bin, writer) ((size_t)(writer) * (B).nb + (bin))
 // linear index of record j of stream (bin, writer)
 #define GBN_RECIDX(B, bin, writer, j) (GBN_STREAM(B, bin, writer) * (B).subcap + (size_t)(j))
-#define GBN_BIN_OCC 4       // waves per SIMD the binning kernel is compiled for (128 VGPRs)
+#ifndef GBN_BIN_OCC
+#define GBN_BIN_OCC 4       // waves per SIMD the binning kernel is compiled for
+#endif
 
 namespace {
 
@@ -959,45 +961,75 @@ hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uin
 // ===========================================================================
 
 // ---------------------------------------------------------------------------------------------------
-// Binning kernel, line-exact variant (default).  Measured on MI355X: the same bytes cost 3-4x more when a
-// stream's lines are written in pieces by consecutive tiles (partial-line writes) than when every store
-// completes whole, aligned 64-byte pieces.  So each workgroup keeps, per bin, one "open line" of 16 records
-// in LDS and only ever stores complete lines: 64 bytes of `hi` words, aligned, with their 32 bytes of
-// indices (measured as cheap as 128 + 64); no pad records exist except in the last line of a stream.
-// Records sit in LDS as 8-byte {hi, index} pairs; the scatter fills a bin's open line first and puts the rest
-// into the bin-sorted staging area, so every complete line is 16 consecutive LDS records -- the open line
-// or a run of the staging area -- read with 4 ds_read_b64 per lane and written with one 16-byte and one
-// 8-byte store (~40 instructions per lane; the first line-exact version gathered record by record from two
-// sources and spent ~500).  64 KB staging (8192-position tiles) + 64 KB open lines.  Five barriers per tile:
-//   [0] histogram atomics of tile t, requests for the bytes of t+1 / descriptor of t+2
-//   [1] scans: staging offsets of the bins, number of complete lines per bin, line -> bin table
-//   [2] scatter of t into open lines / staging (records past a bin's last complete line wait in registers)
-//   [3] keys of t+1, then stores of the complete lines
-//   [4] the waiting records move into the open lines, cursors advance
+// Binning kernel, line-exact.  Measured on MI355X: the same bytes cost 3-4x more when a stream's lines are
+// written in pieces by consecutive tiles (partial-line writes) than when every store completes whole, aligned
+// 64-byte pieces.  So each workgroup keeps, per bin, one "open line" of 16 records in LDS and only ever
+// stores complete lines: 64 bytes of `hi` words, aligned, with their 32 bytes of indices; no pad records
+// exist except in the last line of a stream.  Records sit in LDS as 8-byte {hi, index} pairs; the scatter
+// fills a bin's open line first and puts the rest into the bin-sorted staging area, so every complete line
+// is 16 consecutive LDS records -- the open line or a run of the staging area.  64 KB staging (8192-position
+// tiles) + 64 KB open lines.
+//
+// Round 2: the kernel is bound by VALU issue and by LDS round-trip latency, not by LDS throughput (a
+// returning LDS atomic costs ~3 cycles per wave-instruction with 16 waves issuing, tools/lds_microbench.hip;
+// the round-1 build waited for every bin descriptor before the next record's branchy slot computation, ran
+// the bin scan through six dependent ds_bpermute round trips and followed three dependent LDS reads per
+// stored line).  Now: four barriers per tile instead of five, every group of LDS reads issued back to back,
+// the prefix sums over the bins with DPP row shifts, one 8-byte descriptor per complete line, per-bin
+// stream state in the owner thread's registers, lookup width a compile-time constant in the specialised
+// variants:
+//   [0] histogram atomics of tile t (rank inside the bin), requests for the bytes of t+1
+//   (A)
+//   [1] owner thread of a bin: records + open line -> complete lines, wave-level DPP scan
+//   (B0)
+//   [2] owner: staging offset, scatter descriptor, one descriptor per complete line, cursor
+//   (B)
+//   [3] the records of t-1 that waited in registers move into the (now stored) open lines; scatter of t into
+//       open lines / staging -- records past a bin's last complete line wait in registers in turn
+//   (C)
+//   [4] keys of t+1, then stores of the complete lines of t
 // The tile of a record is not stored: every 8th tile leaves a cursor (stream index of its first record) per
 // bin, and the low 3 bits of the tile's sequence number ride in the spare top bits of the 16-bit index.
-// A three-interval software pipeline of the same steps (histogram of t+1 next to the scatter of t) was
-// measured 0-10 % slower and is not kept.
-template <int STEP>
+namespace {
+// inclusive prefix sum over the 64 lanes of a fully active wave: DPP row shifts and row broadcasts
+__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
+{
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);     // row_shr:4, lanes 4.. of a row
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);     // row_shr:8, lanes 8.. of a row
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+}  // namespace
+
+template <int STEP, int LUT>
 __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
 {
     const GbnScanParams &P = B.S;
     constexpr int TILE = GBN_BIN_TILE_POS, PER = TILE / GBN_SORT_THREADS, LINE = GBN_OPEN_LINE, LP = LINE / 4;    // LP lanes store one line
-    static_assert(PER == 8 && GBN_SORT_THREADS == 1024, "line variant: 8192-position tiles, 1024 threads");
+    static_assert(PER == 8 && GBN_SORT_THREADS == 1024 && LINE == 16, "8192-position tiles, 1024 threads, 16-record lines");
+    static_assert(GBN_BIN_MAXNB <= GBN_SORT_THREADS, "one owner thread per bin");
     // records in LDS are 8 bytes: .x = hi word, .y = index in the tile.  [0, TILE): staging, bin-sorted;
     // [TILE, TILE + bins * LINE): one line under construction per bin
     __shared__ __attribute__((aligned(16))) uint2 s_all[TILE + GBN_BIN_MAXNB * LINE];
-    __shared__ uint32_t s_hist[GBN_BIN_MAXNB], s_off[GBN_BIN_MAXNB + 1], s_loff[GBN_BIN_MAXNB + 1];
+    __shared__ uint32_t s_hist[GBN_BIN_MAXNB];
     __shared__ uint32_t s_wtot[GBN_BIN_MAXNB / 64];
-    __shared__ uint32_t s_pk[GBN_BIN_MAXNB];        // per bin: staging offset | records in the open line << 14 | complete lines << 19
-    __shared__ uint32_t s_wpos[GBN_BIN_MAXNB];                              // records stored so far (multiple of LINE)
-    __shared__ uint16_t s_cc[GBN_BIN_MAXNB];                                // records in the open line (< LINE)
-    __shared__ uint16_t s_lbin[TILE / LINE + GBN_BIN_MAXNB];                // complete line of this tile -> bin
+    // scatter descriptor of a bin (r = rank of a record among the tile's records of the bin):
+    //   .x [15:0]  slot of r = 0 while the open line has room     [31:16] the same for the staging area (signed)
+    //   .y [15:0]  first r that lies past the bin's last complete line (0xffff: none)   [31:16] room in the open line
+    __shared__ uint2 s_pk[GBN_BIN_MAXNB];
+    __shared__ uint2 s_line[TILE / LINE + GBN_BIN_MAXNB];     // complete line of this tile: .x = stream line (16 records) it becomes, .y = its first LDS record
+    __shared__ uint2 s_fin[GBN_BIN_MAXNB];                    // at the end: records stored, records in the open line
+    __shared__ uint32_t s_nlines;
     const int tid = threadIdx.x;
-    const uint32_t mask = (uint32_t)(P.ncells - 1);
-    const int nb = B.nb, cbits = B.cbits;
+    const int lut = LUT > 0 ? LUT : P.lut;
+    const uint32_t mask = LUT > 0 ? (uint32_t)((1ull << (2 * LUT)) - 1) : (uint32_t)(P.ncells - 1);
+    const int cbits = LUT > 0 ? GBN_BIN_CBITS(LUT) : B.cbits;
+    const int nb = LUT > 0 ? (int)(((int64_t)1 << (2 * LUT)) >> GBN_BIN_CBITS(LUT)) : B.nb;
     const uint32_t lowmask = (1u << cbits) - 1;
-    const int cshift = 56 - 2 * P.lut, rshift = 49 - 2 * P.lut;
+    const int cshift = 56 - 2 * lut, rshift = 49 - 2 * lut;
     const uint32_t ustep = (uint32_t)P.step;
     const int64_t stride = gridDim.x, last = P.ntiles - 1;
     const uint32_t wid = blockIdx.x;
@@ -1062,153 +1094,208 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         t.npos = __builtin_amdgcn_readfirstlane(t.npos); t.off16 = __builtin_amdgcn_readfirstlane(t.off16);
         return t;
     };
-    // LP lanes store one line: 16 bytes of hi words and 8 bytes of indices each, from 4 consecutive LDS records
-    auto store_quarter = [&](uint32_t b, uint32_t at_rec, uint32_t src) {
-        const uint2 r0 = s_all[src], r1 = s_all[src + 1], r2 = s_all[src + 2], r3 = s_all[src + 3];
-        const size_t at = GBN_RECIDX(B, b, wid, at_rec);
-        *reinterpret_cast<uint4 *>(B.rec + GBN_REC_HI(at)) = make_uint4(r0.x, r1.x, r2.x, r3.x);
-        *reinterpret_cast<uint2 *>(reinterpret_cast<uint16_t *>(B.rec) + GBN_REC_IDX16(at)) =
-            make_uint2(r0.y | (r1.y << 16), r2.y | (r3.y << 16));
+    // a quarter of a line (4 records: 16 bytes of hi words, 8 bytes of indices) to stream line `dl`
+    uint32_t *const rec32 = B.rec; uint16_t *const rec16 = reinterpret_cast<uint16_t *>(B.rec);
+    auto store_quarter = [&](uint32_t dl, uint32_t p, const uint2 &r0, const uint2 &r1, const uint2 &r2, const uint2 &r3) {
+        // = GBN_REC_HI / GBN_REC_IDX16 of record dl * 16 + p * 4 (blocks of 64 records: 64 hi words, 64 indices)
+        const size_t blk = (size_t)(dl >> 2) * 96, in = (size_t)((dl & 3u) * 16u + p * 4u);
+        if (!(B.dbg & 4)) *reinterpret_cast<uint4 *>(rec32 + blk + in) = make_uint4(r0.x, r1.x, r2.x, r3.x);
+        if (!(B.dbg & 8)) *reinterpret_cast<uint2 *>(rec16 + (blk + 64) * 2 + in) = make_uint2(r0.y | (r1.y << 16), r2.y | (r3.y << 16));
     };
 
-    for (int b = tid; b < nb; b += GBN_SORT_THREADS) { s_hist[b] = 0; s_wpos[b] = 0; s_cc[b] = 0; }
+    if (tid < GBN_BIN_MAXNB) s_hist[tid] = 0;
+    // Tile of (writer w, round k) = k * writers + (w + k) mod writers: the rotation keeps tiles of one kind
+    // (the short last tile of every subject, when the tiles per subject divide the grid) from always
+    // landing on the same workgroups (GBN_TILE_OF in gbn_dev.h; the rare kernel inverts it).
+    uint32_t rot = wid;                                          // (wid + seq) mod stride
+    auto rot_next = [&](uint32_t r) -> uint32_t { return r + 1u == (uint32_t)stride ? 0u : r + 1u; };
     int64_t tile = blockIdx.x;
     if (tile > last) {
         for (int b = tid; b < nb; b += GBN_SORT_THREADS) B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0;
         return;
     }
+    // owner thread of bin `tid`: its stream's state lives in registers
+    uint32_t wpos = 0, cc = 0;                                  // records stored so far (multiple of LINE), records in the open line (< LINE)
+    const uint32_t sline0 = (uint32_t)((GBN_STREAM(B, (tid < nb ? tid : 0), wid) * (size_t)B.subcap) >> 4);    // first line of the stream (subcap is a multiple of 512)
+    const uint32_t open0 = (uint32_t)(TILE + tid * LINE);       // the bin's open line in s_all
+    uint32_t *const tcur = B.tcur + ((size_t)(tid < nb ? tid : 0) * B.nwriters + wid) * B.nseq;
+
     GbnTile T = uniform(P.tiles[tile]);
-    GbnTile T1 = uniform(P.tiles[min(tile + stride, last)]);
+    GbnTile T1 = uniform(P.tiles[min(stride + (int64_t)rot_next(rot), last)]);
     uint32_t bin[PER], hi[PER];
     {
         Raw r0; fetch(T, r0);
         keys_all(T, r0, bin, hi);
     }
+    int32_t stay[PER];                                          // slot (in s_all) of a record that waits for its open line to be stored, else -1
+    uint32_t keep_hi[PER];
+    #pragma unroll
+    for (int k = 0; k < PER; k++) { stay[k] = -1; keep_hi[k] = 0; }
     __syncthreads();
 
 #if GBN_BIN_TIMING   // phase timer of workgroup 0 (tools/build_variant.sh t "-DGBN_BIN_TIMING=1", GBN_DBG=32)
     const bool timed = blockIdx.x == 0 && tid == 0;
+    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
 #define GBN_LAP2(ph) do { if (timed) { const unsigned long long t_ = __builtin_readcyclecounter(); tph[ph] += t_ - tprev; tprev = t_; } } while (0)
 #else
 #define GBN_LAP2(ph) do { } while (0)
 #endif
+    uint32_t ntask = 0;                                         // quarter lines of the tile before (for late_stores)
+    auto late_stores = [&]() {
+        const uint32_t i = (uint32_t)tid + GBN_SORT_THREADS;
+        if (i < ntask && !(B.dbg & 2)) {
+            const uint2 d = s_line[i / LP];
+            if (d.y != 0xffffffffu) {
+                const uint32_t p = i % LP, src = d.y + p * 4;
+                const uint2 a0 = s_all[src], a1 = s_all[src + 1], a2 = s_all[src + 2], a3 = s_all[src + 3];
+                store_quarter(d.x, p, a0, a1, a2, a3);
+            }
+        }
+    };
     uint32_t seq = 0;
-    for (; tile <= last; tile += stride, ++seq) {
-        uint32_t rank[PER];
+    for (; tile <= last; ++seq, rot = rot_next(rot), tile = (int64_t)seq * stride + rot) {
+        // ---- [0] rank of every record inside its bin; the bytes of the next tile ----
+        uint32_t rank[PER]; bool valid[PER];
         #pragma unroll
-        for (int k = 0; k < PER; k++) {
+        for (int k = 0; k < PER; k++) valid[k] = idx_of(k) < (uint32_t)T.npos;
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {     // (positions past the end of a partial tile all carry the same key: they must not touch the histogram)
             rank[k] = 0;
-            if (idx_of(k) < (uint32_t)T.npos) rank[k] = atomicAdd(&s_hist[bin[k]], 1u);
+            if (valid[k]) rank[k] = atomicAdd(&s_hist[bin[k]], 1u);
         }
         Raw R;
         if constexpr (STEP > 0) fetch(T1, R);
-        GbnTile T2 = P.tiles[min(tile + 2 * stride, last)];
+        GbnTile T2 = P.tiles[min((int64_t)(seq + 2) * stride + (int64_t)rot_next(rot_next(rot)), last)];
+        late_stores();                                          // second quarter-line round of the previous tile
         GBN_LAP2(0);
         __syncthreads();                                        // (A) histogram complete
         GBN_LAP2(1);
-        // exclusive scans over the bins, both sums in one word: records that go to the staging area
-        // (all but the ones that fill the bin's open line; < 2^14) and complete lines (< 2^10)
-        uint32_t v = 0, incl = 0, my_nl = 0, my_cc = 0;
-        if (tid < nb) {
-            const uint32_t tot = (uint32_t)s_cc[tid] + s_hist[tid];
-            my_nl = tot / LINE; my_cc = tot & (LINE - 1);
-            v = (tot > LINE ? tot - LINE : 0u) | (my_nl << 16);
-        }
+        // ---- [1] + [2] owner threads: complete lines, staging offsets (both sums in one word: records
+        // that go to the staging area < 2^14, complete lines < 2^10), descriptors ----
+        uint32_t v = 0, incl = 0, my_nl = 0, my_cc = 0, tot = 0;
         if (tid < GBN_BIN_MAXNB) {
-            incl = v;
-            for (int o = 1; o < 64; o <<= 1) { const uint32_t y = __shfl_up(incl, o); if ((tid & 63) >= o) incl += y; }
+            if (tid < nb) {
+                tot = cc + s_hist[tid];
+                my_nl = tot / LINE; my_cc = tot & (LINE - 1);
+                v = (tot > LINE ? tot - LINE : 0u) | (my_nl << 16);
+            }
+            incl = wave_scan_incl(v);
             if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
         }
-        __syncthreads();                                        // (B0) wave totals
         GBN_LAP2(2);
+        __syncthreads();                                        // (B0) wave totals
+        GBN_LAP2(3);
         if (tid < nb) {
             uint32_t run = incl - v;
             #pragma unroll
             for (int w = 0; w < GBN_BIN_MAXNB / 64 - 1; w++) run += (tid >> 6) > w ? s_wtot[w] : 0u;
-            const uint32_t l0 = run >> 16, cc = s_cc[tid], wp = s_wpos[tid];
-            s_off[tid] = run & 0xffffu; s_loff[tid] = l0;
-            s_pk[tid] = (run & 0xffffu) | (cc << 14) | (my_nl << 19);
-            if (tid == nb - 1) s_loff[nb] = (run + v) >> 16;
-            if ((seq & 7u) == 0) B.tcur[((size_t)tid * B.nwriters + wid) * B.nseq + (seq >> 3)] = wp + cc;     // stream index of this tile's first record
-            if (wp + my_nl * LINE > B.subcap) atomicExch(B.overflow, 1u);
-            for (uint32_t l = 0; l < my_nl; l++) s_lbin[l0 + l] = (uint16_t)tid;     // read after (C)
+            const uint32_t off = run & 0xffffu, l0 = run >> 16;
+            const uint32_t first_past = my_nl ? my_nl * LINE - cc : 0xffffu;
+            s_pk[tid] = make_uint2((open0 + cc) | ((off + cc - LINE) << 16), first_past | ((LINE - cc) << 16));
+            if ((seq & 7u) == 0) tcur[seq >> 3] = wpos + cc;    // stream index of this tile's first record
+            if (wpos + my_nl * LINE > B.subcap) atomicExch(B.overflow, 1u);
+            for (uint32_t l = 0; l < my_nl; l++) {
+                const bool fits = wpos + (l + 1) * LINE <= B.subcap;
+                s_line[l0 + l] = make_uint2(sline0 + (wpos >> 4) + l, fits ? (l == 0 ? open0 : off + (l - 1) * LINE) : 0xffffffffu);
+            }
+            if (tid == nb - 1) s_nlines = l0 + my_nl;
+            wpos += my_nl * LINE; cc = my_cc;
+            s_hist[tid] = 0;                                    // for the next tile: its atomics come after (C)
         }
-        __syncthreads();                                        // (B) offsets and line list known
-        GBN_LAP2(3);
-        const uint32_t nlines = s_loff[nb];
-        int32_t stay[PER];                                      // slot (in s_all) of a record past the bin's last complete line, else -1
-        #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            stay[k] = -1;
-            if (idx_of(k) < (uint32_t)T.npos) {
-                const uint32_t b = bin[k], pk = s_pk[b];
-                const uint32_t pos = ((pk >> 14) & 31u) + rank[k], full = (pk >> 19) * LINE;
+        GBN_LAP2(4);
+        __syncthreads();                                        // (B) descriptors known
+        GBN_LAP2(5);
+        // ---- [3] scatter ----
+        {
+            uint2 pk[PER];
+            #pragma unroll
+            for (int k = 0; k < PER; k++) pk[k] = s_pk[bin[k]];
+            // the records of the previous tile that waited: their open lines were stored in that tile's [4]
+            #pragma unroll
+            for (int k = 0; k < PER; k++)
+                if (stay[k] >= 0) s_all[stay[k]] = make_uint2(keep_hi[k], idx_of(k) | (((seq - 1u) & 7u) << 13));
+            #pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const uint32_t r = rank[k];
+                const uint32_t open_at = pk[k].x & 0xffffu, room = pk[k].y >> 16, past = pk[k].y & 0xffffu;
+                const int32_t stage_at = (int32_t)pk[k].x >> 16;
                 // the bin's open line first, then the staging area; what lies past the last complete line
                 // waits in registers until the open line has been stored
-                const uint32_t slot = pos < (uint32_t)LINE ? TILE + b * LINE + pos : (pk & 0x3fffu) + pos - LINE;
-                if (full && pos >= full) stay[k] = (int32_t)(TILE + b * LINE + pos - full);
-                else s_all[slot] = make_uint2(hi[k], idx_of(k) | ((seq & 7u) << 13));
+                const uint32_t slot = (r < room ? open_at : (uint32_t)stage_at) + r;
+                const bool waits = valid[k] && r >= past;
+                stay[k] = waits ? (int32_t)((uint32_t)TILE + bin[k] * LINE + (r - past)) : -1;
+                keep_hi[k] = hi[k];
+                if (valid[k] && !waits) s_all[slot] = make_uint2(hi[k], idx_of(k) | ((seq & 7u) << 13));
             }
         }
+        GBN_LAP2(6);
         __syncthreads();                                        // (C) open lines and staging filled
-        GBN_LAP2(4);
-        for (int b = tid; b < nb; b += GBN_SORT_THREADS) s_hist[b] = 0;     // for the next tile; ordered by (D)
-        uint32_t keep_hi[PER];                                  // of the records that stay behind: the keys are replaced below
-        #pragma unroll
-        for (int k = 0; k < PER; k++) keep_hi[k] = hi[k];
-        // keys of t+1 before the stores: the wait for the loads of t+1 counts every outstanding memory
-        // operation and would otherwise sit behind this tile's stores
+        // ---- [4] keys of t+1 before the stores: the wait for the loads of t+1 counts every outstanding
+        // memory operation and would otherwise sit behind this tile's stores ----
         T = T1; T1 = uniform(T2);
         if constexpr (STEP == 0) fetch(T, R);
         keys_all(T, R, bin, hi);
+        // Stores of the complete lines, a quarter line per thread and step.  The first 1024 quarter lines leave
+        // here; the next 1024 wait until [0] of the next tile (behind its loads, next to its atomics: spreading
+        // the stores over the tile keeps the store queue from stalling every wave at once); the rare rest here.
+        ntask = s_nlines * (uint32_t)LP;
         if (!(B.dbg & 2))
-        for (uint32_t i = tid; i < nlines * (uint32_t)LP; i += GBN_SORT_THREADS) {
-            const uint32_t L = i / LP, p = i % LP, b = s_lbin[L], l = L - s_loff[b], wpos = s_wpos[b] + l * LINE;
-            if (wpos + LINE > B.subcap) continue;
-            store_quarter(b, wpos + p * 4, (l == 0 ? TILE + b * LINE : s_off[b] + (l - 1) * LINE) + p * 4);
+        for (uint32_t i = tid; i < ntask; i += (i == (uint32_t)tid ? 2u : 1u) * GBN_SORT_THREADS) {
+            const uint2 d = s_line[i / LP];
+            if (d.y == 0xffffffffu) continue;
+            const uint32_t p = i % LP, src = d.y + p * 4;
+            const uint2 a0 = s_all[src], a1 = s_all[src + 1], a2 = s_all[src + 2], a3 = s_all[src + 3];
+            store_quarter(d.x, p, a0, a1, a2, a3);
         }
-        GBN_LAP2(5);
-        __syncthreads();                                        // (D) lines issued, open lines and staging free
-        GBN_LAP2(6);
-        #pragma unroll
-        for (int k = 0; k < PER; k++)
-            if (stay[k] >= 0) s_all[stay[k]] = make_uint2(keep_hi[k], idx_of(k) | ((seq & 7u) << 13));
-        if (tid < nb) { s_wpos[tid] += my_nl * LINE; s_cc[tid] = (uint16_t)my_cc; }
-        GBN_LAP2(7);
+        // (no barrier here: the open lines just read are next written in [3] of the next tile, after (A)..(B))
     }
 #if GBN_BIN_TIMING
     if (timed) for (int i = 0; i < 8; i++) B.rare_counts[512 + i] = (uint32_t)(tph[i] >> 4);
+    if (tid == 0 && blockIdx.x < 512) {     // wall clock (100 MHz) of every workgroup: start, duration
+        B.rare_counts[1024 + blockIdx.x] = (uint32_t)wg_t0;
+        B.rare_counts[1536 + blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - wg_t0);
+    }
 #endif
+    late_stores();
+    __syncthreads();
+    // the records of the last tile that waited
+    #pragma unroll
+    for (int k = 0; k < PER; k++)
+        if (stay[k] >= 0) s_all[stay[k]] = make_uint2(keep_hi[k], idx_of(k) | (((seq - 1u) & 7u) << 13));
+    if (tid < nb) s_fin[tid] = make_uint2(wpos, cc);
     __syncthreads();
     // the last, incomplete line of every stream: padded with flagged records
     for (uint32_t i = tid; i < (uint32_t)nb * LINE; i += GBN_SORT_THREADS) {
         const uint32_t b = i / LINE, s = i % LINE;
-        if (s >= s_cc[b]) s_all[TILE + b * LINE + s] = make_uint2(GBN_REC_PAD, 0xffffu);
+        if (s >= s_fin[b].y) s_all[TILE + b * LINE + s] = make_uint2(GBN_REC_PAD, 0xffffu);
     }
     __syncthreads();
     for (uint32_t i = tid; i < (uint32_t)nb * LP; i += GBN_SORT_THREADS) {
         const uint32_t b = i / LP, p = i % LP;
-        if (s_cc[b] && s_wpos[b] + LINE <= B.subcap && !(B.dbg & 2)) store_quarter(b, s_wpos[b] + p * 4, TILE + b * LINE + p * 4);
+        const uint2 f = s_fin[b];
+        if (f.y && f.x + LINE <= B.subcap && !(B.dbg & 2)) {
+            const uint32_t src = TILE + b * LINE + p * 4;
+            store_quarter((uint32_t)((GBN_STREAM(B, b, wid) * (size_t)B.subcap + f.x) >> 4), p, s_all[src], s_all[src + 1], s_all[src + 2], s_all[src + 3]);
+        }
     }
     for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
-        const uint32_t total = s_wpos[b] + (s_cc[b] ? LINE : 0u);
+        const uint2 f = s_fin[b];
+        const uint32_t total = f.x + (f.y ? LINE : 0u);
         if (total > B.subcap) atomicExch(B.overflow, 1u);
         B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(total, B.subcap);
     }
 }
 
-
-
-
-#define GBN_BIN_BODY scan_bin_line_body
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel(GbnBinParams B) { GBN_BIN_BODY<0>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s17(GbnBinParams B) { GBN_BIN_BODY<17>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { GBN_BIN_BODY<18>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s1(GbnBinParams B) { GBN_BIN_BODY<1>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s2(GbnBinParams B) { GBN_BIN_BODY<2>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s4(GbnBinParams B) { GBN_BIN_BODY<4>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s21(GbnBinParams B) { GBN_BIN_BODY<21>(B); }
+// stride- and width-specialised variants: megablast (word 28: lut 12 / 11 / 8) and blastn (word 11: lut 11 / 10 / 8);
+// every other (stride, lut) pair takes the generic kernel
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel(GbnBinParams B) { scan_bin_line_body<0, 0>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s17(GbnBinParams B) { scan_bin_line_body<17, 12>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { scan_bin_line_body<18, 11>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s1(GbnBinParams B) { scan_bin_line_body<1, 11>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s2(GbnBinParams B) { scan_bin_line_body<2, 10>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s4(GbnBinParams B) { scan_bin_line_body<4, 8>(B); }
+extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s21(GbnBinParams B) { scan_bin_line_body<21, 8>(B); }
 
 namespace {
 // rare path of the probe kernel: full fingerprints, chain walk, exact verification
@@ -1464,7 +1551,9 @@ probe_rare_kernel(GbnBinParams B, int nseg)
             const uint32_t bin = (cv & 0x7fffffffu) >> B.cbits;
             const uint32_t wr = pid / B.subcap, j = pid - wr * B.subcap;
             const uint32_t *__restrict__ cur = B.tcur + ((size_t)bin * B.nwriters + wr) * B.nseq;
-            const uint32_t ntiles_w = (uint32_t)((P.ntiles - wr + B.nwriters - 1) / B.nwriters);     // tiles of this writer
+            // tiles of this writer: one per full round, and one of the last, incomplete round if its rotated index falls into it
+            const uint32_t full_rounds = (uint32_t)(P.ntiles / B.nwriters), rest = (uint32_t)(P.ntiles % B.nwriters);
+            const uint32_t ntiles_w = full_rounds + (((wr + full_rounds) % (uint32_t)B.nwriters) < rest ? 1u : 0u);
             const uint32_t nt = (ntiles_w + (1u << GBN_TCUR_SHIFT) - 1u) >> GBN_TCUR_SHIFT;          // cursor entries
             uint32_t lo = 0, hi = nt;
             {   // the cursors grow almost linearly: look around the interpolated run first
@@ -1478,7 +1567,7 @@ probe_rare_kernel(GbnBinParams B, int nseg)
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] <= j) lo = mid; else hi = mid; }
             const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, j))];
             const uint32_t seqn = (lo << GBN_TCUR_SHIFT) | (idx >> GBN_BIN_TILE_BITS);
-            pid = ((wr + seqn * (uint32_t)B.nwriters) << GBN_BIN_TILE_BITS) | (idx & (uint32_t)(GBN_BIN_TILE_POS - 1));
+            pid = (GBN_TILE_OF(wr, seqn, (uint32_t)B.nwriters) << GBN_BIN_TILE_BITS) | (idx & (uint32_t)(GBN_BIN_TILE_POS - 1));
         }
         if (staged) probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw, s_buf, &s_n, CAP);
         else probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
@@ -1501,12 +1590,13 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
     if (parts & 1) {
         // stride-specialised variants: megablast (word 28 with lut 12 / 11 / 8) and blastn (word 11 with lut 11 / 10 / 8)
         const bool generic = (b.dbg & 64) != 0;
-        if (b.S.step == 1 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s1, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else if (b.S.step == 2 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s2, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else if (b.S.step == 4 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s4, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else if (b.S.step == 21 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s21, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else if (b.S.step == 17 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else if (b.S.step == 18 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s18, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        const int step = b.S.step, lut = b.S.lut;
+        if (step == 1 && lut == 11 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s1, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else if (step == 2 && lut == 10 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s2, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else if (step == 4 && lut == 8 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s4, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else if (step == 21 && lut == 8 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s21, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else if (step == 17 && lut == 12 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
+        else if (step == 18 && lut == 11 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s18, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
         else hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
         e = hipGetLastError();
         if (e != hipSuccess) return e;

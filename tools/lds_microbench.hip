@@ -1,0 +1,100 @@
+// lds_microbench.hip -- what the binning kernel's LDS steps cost on this chip (cycles per wave-instruction
+// with 16 waves per CU issuing), to decide between ranking schemes.  Build + run on the GPU box:
+//   hipcc --offload-arch=gfx950 -O3 tools/lds_microbench.hip -o /tmp/ldsmb && /tmp/ldsmb
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <vector>
+
+#define CHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+template <int MODE, int NBINS>
+__global__ void __launch_bounds__(1024) k(uint32_t *out, unsigned long long *cyc, int iters)
+{
+    __shared__ uint32_t s_hist[2048];
+    __shared__ uint2 s_rec[8192 + 512 * 16];
+    const int tid = threadIdx.x;
+    for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0;
+    __syncthreads();
+    uint32_t x = tid * 2654435761u + blockIdx.x * 40503u + 12345u, acc = 0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
+    for (int it = 0; it < iters; it++) {
+        uint32_t b[8];
+        #pragma unroll
+        for (int j = 0; j < 8; j++) { x = x * 1664525u + 1013904223u; b[j] = (x >> 11) & (NBINS - 1); }
+        if (MODE == 0) {            // returning atomic add, random counters
+            uint32_t r[8];
+            #pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = atomicAdd(&s_hist[b[j]], 1u);
+            #pragma unroll
+            for (int j = 0; j < 8; j++) acc += r[j];
+        } else if (MODE == 1) {     // non-returning atomic add
+            #pragma unroll
+            for (int j = 0; j < 8; j++) __hip_atomic_fetch_add(&s_hist[b[j]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        } else if (MODE == 2) {     // random 8-byte scatter
+            #pragma unroll
+            for (int j = 0; j < 8; j++) s_rec[(b[j] * 16 + ((x >> (3 + j)) & 15)) & 8191] = make_uint2(x, b[j]);
+        } else if (MODE == 3) {     // random 4-byte read
+            #pragma unroll
+            for (int j = 0; j < 8; j++) acc += s_hist[b[j]];
+        } else if (MODE == 4) {     // random 8-byte read
+            #pragma unroll
+            for (int j = 0; j < 8; j++) acc += s_rec[(b[j] * 16 + j) & 8191].x;
+        } else if (MODE == 5) {     // random 4-byte write
+            #pragma unroll
+            for (int j = 0; j < 8; j++) s_hist[b[j]] = x;
+        } else if (MODE == 6) {     // returning atomic on a 16-bit-packed pair: two bins per word (64-bit add with return)
+            unsigned long long *h64 = reinterpret_cast<unsigned long long *>(s_hist);
+            unsigned long long r[8];
+            #pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = atomicAdd(&h64[b[j] >> 1], (b[j] & 1) ? (1ull << 32) : 1ull);
+            #pragma unroll
+            for (int j = 0; j < 8; j++) acc += (uint32_t)r[j];
+        } else if (MODE == 7) {     // no LDS at all: the loop overhead
+            #pragma unroll
+            for (int j = 0; j < 8; j++) acc += b[j];
+        }
+        if (MODE == 0 || MODE == 1 || MODE == 6) { if ((it & 63) == 63) { __syncthreads(); for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0; __syncthreads(); } }
+    }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (tid == 0) cyc[blockIdx.x] = t1 - t0;
+    out[blockIdx.x * 1024 + tid] = acc + s_hist[tid] + s_rec[tid].x;
+}
+
+template <int MODE, int NBINS> int run(const char *what, uint32_t *out, unsigned long long *cyc, int iters)
+{
+    const int grid = 256;
+    hipLaunchKernelGGL((k<MODE, NBINS>), dim3(grid), dim3(1024), 0, 0, out, cyc, 16);
+    CHK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    CHK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((k<MODE, NBINS>), dim3(grid), dim3(1024), 0, 0, out, cyc, iters);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipDeviceSynchronize());
+    float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+    std::vector<unsigned long long> h(grid);
+    CHK(hipMemcpy(h.data(), cyc, grid * 8, hipMemcpyDeviceToHost));
+    double avg = 0; for (auto v : h) avg += (double)v; avg /= grid;
+    // per CU: 16 waves x 8 instructions per iteration
+    printf("%-52s bins %4d: %7.3f ms, %9.0f counter ticks per workgroup, %.2f ns per wave-instruction per CU (16 waves x 8 per iteration)\n",
+           what, NBINS, ms, avg, ms * 1e6 / ((double)iters * 128.0));
+    return 0;
+}
+
+int main()
+{
+    uint32_t *out; unsigned long long *cyc;
+    CHK(hipMalloc(&out, 256 * 1024 * 4)); CHK(hipMalloc(&cyc, 256 * 8));
+    const int iters = 20000;
+    run<7, 512>("loop overhead (no LDS)", out, cyc, iters);
+    run<0, 512>("ds_add_rtn_u32 random", out, cyc, iters);
+    run<0, 128>("ds_add_rtn_u32 random", out, cyc, iters);
+    run<0, 2048>("ds_add_rtn_u32 random", out, cyc, iters);
+    run<1, 512>("ds_add_u32 (no return) random", out, cyc, iters);
+    run<6, 512>("ds_add_rtn_u64 (two bins per word) random", out, cyc, iters);
+    run<2, 512>("ds_write_b64 random scatter", out, cyc, iters);
+    run<5, 512>("ds_write_b32 random", out, cyc, iters);
+    run<3, 512>("ds_read_b32 random", out, cyc, iters);
+    run<4, 512>("ds_read_b64 random", out, cyc, iters);
+    return 0;
+}
