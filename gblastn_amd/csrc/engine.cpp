@@ -625,7 +625,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             int nwriters = (int)std::max<int64_t>(8, std::min<int64_t>((int64_t)E.num_cu * wg_per_cu, ts.ntiles));
             if (const char *e = getenv("GBN_BIN_WRITERS")) nwriters = std::max(8, std::min(nwriters, atoi(e)));     // experiments
             const size_t nstream = (size_t)nb * nwriters;
-            double expect = (double)npos / (double)nstream + 3.0 * ((double)ts.ntiles / nwriters + 1);   // + pads
+            double expect = (double)npos / (double)nstream + 2.0 * GBN_OPEN_LINE;   // + the pads of the stream's last line
             size_t subcap = (size_t)(expect * slack) + 256;
             subcap = (subcap + 511) & ~(size_t)511;       // whole record blocks, whole probe pieces
             if (subcap > 0x7ffffff0u) { set_error("bin capacity overflow: split the range"); return GBN_ERR_NOMEM; }

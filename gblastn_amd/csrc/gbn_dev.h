@@ -44,13 +44,14 @@ struct GbnScanParams {
 #define GBN_SORT_THREADS 1024       // binning kernel workgroup: one per CU (two of 512 threads were measured 15-50 % slower)
 #define GBN_BIN_WG_PER_CU 1
 #ifndef GBN_OPEN_LINE
-#define GBN_OPEN_LINE 16        // records per stored piece of the binning kernel (64 bytes of hi words + 32 of indices)
+#define GBN_OPEN_LINE 32        // records per stored piece of the binning kernel (128 bytes of hi words + 64 of indices)
 #endif
 // cursor table resolution: one entry per 2^GBN_TCUR_SHIFT tiles of a (bin, writer) stream; the low bits of the
 // tile's sequence number then travel in the spare top bits of every record's 16-bit index
 #define GBN_TCUR_SHIFT 3
 #define GBN_BIN_TILE_BITS 13
 #define GBN_BIN_TILE_POS (1 << GBN_BIN_TILE_BITS)   // scan positions per tile (posid = tile << GBN_BIN_TILE_BITS | i)
+#define GBN_BIN_STAGE GBN_BIN_TILE_POS   // LDS staging slots of the binning kernel (the lines a bin completes beyond its first one in a tile)
 #define GBN_BIN_GROUPS   8          // probe workgroups with equal (blockIdx & 7) share a bin (and an XCD)
 #define GBN_BIN_MAXNB    512
 #define GBN_BIN_CELLS    32768      // most cells a bin can have (LDS table entries)

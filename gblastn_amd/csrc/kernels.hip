@@ -1009,19 +1009,21 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
 {
     const GbnScanParams &P = B.S;
     constexpr int TILE = GBN_BIN_TILE_POS, PER = TILE / GBN_SORT_THREADS, LINE = GBN_OPEN_LINE, LP = LINE / 4;    // LP lanes store one line
-    static_assert(PER == 8 && GBN_SORT_THREADS == 1024 && LINE == 16, "8192-position tiles, 1024 threads, 16-record lines");
+    constexpr int STAGE = GBN_BIN_STAGE;
+    static_assert(PER == 8 && GBN_SORT_THREADS == 1024 && LINE == 32, "8192-position tiles, 1024 threads, 32-record lines");
     static_assert(GBN_BIN_MAXNB <= GBN_SORT_THREADS, "one owner thread per bin");
-    // records in LDS are 8 bytes: .x = hi word, .y = index in the tile.  [0, TILE): staging, bin-sorted;
-    // [TILE, TILE + bins * LINE): one line under construction per bin
-    __shared__ __attribute__((aligned(16))) uint2 s_all[TILE + GBN_BIN_MAXNB * LINE];
+    // records in LDS: hi word and 16-bit index in the tile, in two arrays with the same slot numbers.
+    // [0, STAGE): staging, bin-sorted (the lines a bin completes beyond its first one in a tile: rare with 512
+    // bins, the rule with 128); [STAGE, STAGE + bins * LINE): one line under construction per bin
+    __shared__ __attribute__((aligned(16))) uint32_t s_hi[STAGE + GBN_BIN_MAXNB * LINE];
+    __shared__ __attribute__((aligned(16))) uint16_t s_ix[STAGE + GBN_BIN_MAXNB * LINE];
     __shared__ uint32_t s_hist[GBN_BIN_MAXNB];
     __shared__ uint32_t s_wtot[GBN_BIN_MAXNB / 64];
     // scatter descriptor of a bin (r = rank of a record among the tile's records of the bin):
     //   .x [15:0]  slot of r = 0 while the open line has room     [31:16] the same for the staging area (signed)
     //   .y [15:0]  first r that lies past the bin's last complete line (0xffff: none)   [31:16] room in the open line
     __shared__ uint2 s_pk[GBN_BIN_MAXNB];
-    __shared__ uint2 s_line[TILE / LINE + GBN_BIN_MAXNB];     // complete line of this tile: .x = stream line (16 records) it becomes, .y = its first LDS record
-    __shared__ uint2 s_fin[GBN_BIN_MAXNB];                    // at the end: records stored, records in the open line
+    __shared__ uint2 s_line[TILE / LINE + GBN_BIN_MAXNB];     // complete line of this tile: .x = stream line (32 records) it becomes, .y = its first LDS slot
     __shared__ uint32_t s_nlines;
     const int tid = threadIdx.x;
     const int lut = LUT > 0 ? LUT : P.lut;
@@ -1094,13 +1096,17 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         t.npos = __builtin_amdgcn_readfirstlane(t.npos); t.off16 = __builtin_amdgcn_readfirstlane(t.off16);
         return t;
     };
-    // a quarter of a line (4 records: 16 bytes of hi words, 8 bytes of indices) to stream line `dl`
+    // an eighth of a line (4 records: 16 bytes of hi words, 8 bytes of indices) from LDS slot `src` to stream line
+    // `dl`: the 8 lanes of a line write 128 aligned bytes of hi words and 64 of indices -- scattered writes cost
+    // by the piece below 128 bytes (tools/write_microbench.hip: 64 + 32 byte pieces 3.5 TB/s, 128 + 64: 6+)
     uint32_t *const rec32 = B.rec; uint16_t *const rec16 = reinterpret_cast<uint16_t *>(B.rec);
-    auto store_quarter = [&](uint32_t dl, uint32_t p, const uint2 &r0, const uint2 &r1, const uint2 &r2, const uint2 &r3) {
-        // = GBN_REC_HI / GBN_REC_IDX16 of record dl * 16 + p * 4 (blocks of 64 records: 64 hi words, 64 indices)
-        const size_t blk = (size_t)(dl >> 2) * 96, in = (size_t)((dl & 3u) * 16u + p * 4u);
-        if (!(B.dbg & 4)) *reinterpret_cast<uint4 *>(rec32 + blk + in) = make_uint4(r0.x, r1.x, r2.x, r3.x);
-        if (!(B.dbg & 8)) *reinterpret_cast<uint2 *>(rec16 + (blk + 64) * 2 + in) = make_uint2(r0.y | (r1.y << 16), r2.y | (r3.y << 16));
+    auto store_part = [&](uint32_t dl, uint32_t p, uint32_t src) {
+        const uint4 h = *reinterpret_cast<const uint4 *>(&s_hi[src]);
+        const uint2 x = *reinterpret_cast<const uint2 *>(&s_ix[src]);
+        // = GBN_REC_HI / GBN_REC_IDX16 of record dl * 32 + p * 4 (blocks of 64 records: 64 hi words, 64 indices)
+        const size_t blk = (size_t)(dl >> 1) * 96, in = (size_t)((dl & 1u) * 32u + p * 4u);
+        if (!(B.dbg & 4)) *reinterpret_cast<uint4 *>(rec32 + blk + in) = h;
+        if (!(B.dbg & 8)) *reinterpret_cast<uint2 *>(rec16 + (blk + 64) * 2 + in) = x;
     };
 
     if (tid < GBN_BIN_MAXNB) s_hist[tid] = 0;
@@ -1116,8 +1122,8 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     }
     // owner thread of bin `tid`: its stream's state lives in registers
     uint32_t wpos = 0, cc = 0;                                  // records stored so far (multiple of LINE), records in the open line (< LINE)
-    const uint32_t sline0 = (uint32_t)((GBN_STREAM(B, (tid < nb ? tid : 0), wid) * (size_t)B.subcap) >> 4);    // first line of the stream (subcap is a multiple of 512)
-    const uint32_t open0 = (uint32_t)(TILE + tid * LINE);       // the bin's open line in s_all
+    const uint32_t sline0 = (uint32_t)((GBN_STREAM(B, (tid < nb ? tid : 0), wid) * (size_t)B.subcap) >> 5);    // first line of the stream (subcap is a multiple of 512)
+    const uint32_t open0 = (uint32_t)(STAGE + tid * LINE);      // the bin's open line
     uint32_t *const tcur = B.tcur + ((size_t)(tid < nb ? tid : 0) * B.nwriters + wid) * B.nseq;
 
     GbnTile T = uniform(P.tiles[tile]);
@@ -1127,7 +1133,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         Raw r0; fetch(T, r0);
         keys_all(T, r0, bin, hi);
     }
-    int32_t stay[PER];                                          // slot (in s_all) of a record that waits for its open line to be stored, else -1
+    int32_t stay[PER];                                          // slot of a record that waits for its open line to be stored, else -1
     uint32_t keep_hi[PER];
     #pragma unroll
     for (int k = 0; k < PER; k++) { stay[k] = -1; keep_hi[k] = 0; }
@@ -1146,11 +1152,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         const uint32_t i = (uint32_t)tid + GBN_SORT_THREADS;
         if (i < ntask && !(B.dbg & 2)) {
             const uint2 d = s_line[i / LP];
-            if (d.y != 0xffffffffu) {
-                const uint32_t p = i % LP, src = d.y + p * 4;
-                const uint2 a0 = s_all[src], a1 = s_all[src + 1], a2 = s_all[src + 2], a3 = s_all[src + 3];
-                store_quarter(d.x, p, a0, a1, a2, a3);
-            }
+            if (d.y != 0xffffffffu) store_part(d.x, i % LP, d.y + (i % LP) * 4);
         }
     };
     uint32_t seq = 0;
@@ -1178,7 +1180,8 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
             if (tid < nb) {
                 tot = cc + s_hist[tid];
                 my_nl = tot / LINE; my_cc = tot & (LINE - 1);
-                v = (tot > LINE ? tot - LINE : 0u) | (my_nl << 16);
+                // staging: the complete lines after the bin's first one
+                v = (my_nl > 1 ? (my_nl - 1) * LINE : 0u) | (my_nl << 16);
             }
             incl = wave_scan_incl(v);
             if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
@@ -1194,10 +1197,10 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
             const uint32_t first_past = my_nl ? my_nl * LINE - cc : 0xffffu;
             s_pk[tid] = make_uint2((open0 + cc) | ((off + cc - LINE) << 16), first_past | ((LINE - cc) << 16));
             if ((seq & 7u) == 0) tcur[seq >> 3] = wpos + cc;    // stream index of this tile's first record
-            if (wpos + my_nl * LINE > B.subcap) atomicExch(B.overflow, 1u);
+            if (wpos + my_nl * LINE > B.subcap) atomicOr(B.overflow, 1u);
             for (uint32_t l = 0; l < my_nl; l++) {
                 const bool fits = wpos + (l + 1) * LINE <= B.subcap;
-                s_line[l0 + l] = make_uint2(sline0 + (wpos >> 4) + l, fits ? (l == 0 ? open0 : off + (l - 1) * LINE) : 0xffffffffu);
+                s_line[l0 + l] = make_uint2(sline0 + (wpos >> 5) + l, fits ? (l == 0 ? open0 : off + (l - 1) * LINE) : 0xffffffffu);
             }
             if (tid == nb - 1) s_nlines = l0 + my_nl;
             wpos += my_nl * LINE; cc = my_cc;
@@ -1214,7 +1217,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
             // the records of the previous tile that waited: their open lines were stored in that tile's [4]
             #pragma unroll
             for (int k = 0; k < PER; k++)
-                if (stay[k] >= 0) s_all[stay[k]] = make_uint2(keep_hi[k], idx_of(k) | (((seq - 1u) & 7u) << 13));
+                if (stay[k] >= 0) { s_hi[stay[k]] = keep_hi[k]; s_ix[stay[k]] = (uint16_t)(idx_of(k) | (((seq - 1u) & 7u) << 13)); }
             #pragma unroll
             for (int k = 0; k < PER; k++) {
                 const uint32_t r = rank[k];
@@ -1224,9 +1227,11 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
                 // waits in registers until the open line has been stored
                 const uint32_t slot = (r < room ? open_at : (uint32_t)stage_at) + r;
                 const bool waits = valid[k] && r >= past;
-                stay[k] = waits ? (int32_t)((uint32_t)TILE + bin[k] * LINE + (r - past)) : -1;
+                stay[k] = waits ? (int32_t)((uint32_t)STAGE + bin[k] * LINE + (r - past)) : -1;
                 keep_hi[k] = hi[k];
-                if (valid[k] && !waits) s_all[slot] = make_uint2(hi[k], idx_of(k) | ((seq & 7u) << 13));
+                if (valid[k] && !waits) {
+                    s_hi[slot] = hi[k]; s_ix[slot] = (uint16_t)(idx_of(k) | ((seq & 7u) << 13));
+                }
             }
         }
         GBN_LAP2(6);
@@ -1244,9 +1249,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         for (uint32_t i = tid; i < ntask; i += (i == (uint32_t)tid ? 2u : 1u) * GBN_SORT_THREADS) {
             const uint2 d = s_line[i / LP];
             if (d.y == 0xffffffffu) continue;
-            const uint32_t p = i % LP, src = d.y + p * 4;
-            const uint2 a0 = s_all[src], a1 = s_all[src + 1], a2 = s_all[src + 2], a3 = s_all[src + 3];
-            store_quarter(d.x, p, a0, a1, a2, a3);
+            store_part(d.x, i % LP, d.y + (i % LP) * 4);
         }
         // (no barrier here: the open lines just read are next written in [3] of the next tile, after (A)..(B))
     }
@@ -1262,27 +1265,26 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     // the records of the last tile that waited
     #pragma unroll
     for (int k = 0; k < PER; k++)
-        if (stay[k] >= 0) s_all[stay[k]] = make_uint2(keep_hi[k], idx_of(k) | (((seq - 1u) & 7u) << 13));
+        if (stay[k] >= 0) { s_hi[stay[k]] = keep_hi[k]; s_ix[stay[k]] = (uint16_t)(idx_of(k) | (((seq - 1u) & 7u) << 13)); }
+    uint2 *const s_fin = s_pk;                                  // at the end: records stored, records in the open line
     if (tid < nb) s_fin[tid] = make_uint2(wpos, cc);
     __syncthreads();
     // the last, incomplete line of every stream: padded with flagged records
     for (uint32_t i = tid; i < (uint32_t)nb * LINE; i += GBN_SORT_THREADS) {
-        const uint32_t b = i / LINE, s = i % LINE;
-        if (s >= s_fin[b].y) s_all[TILE + b * LINE + s] = make_uint2(GBN_REC_PAD, 0xffffu);
+        const uint32_t b = i / LINE, sl = i % LINE;
+        if (sl >= s_fin[b].y) { s_hi[STAGE + b * LINE + sl] = GBN_REC_PAD; s_ix[STAGE + b * LINE + sl] = 0xffffu; }
     }
     __syncthreads();
     for (uint32_t i = tid; i < (uint32_t)nb * LP; i += GBN_SORT_THREADS) {
         const uint32_t b = i / LP, p = i % LP;
         const uint2 f = s_fin[b];
-        if (f.y && f.x + LINE <= B.subcap && !(B.dbg & 2)) {
-            const uint32_t src = TILE + b * LINE + p * 4;
-            store_quarter((uint32_t)((GBN_STREAM(B, b, wid) * (size_t)B.subcap + f.x) >> 4), p, s_all[src], s_all[src + 1], s_all[src + 2], s_all[src + 3]);
-        }
+        if (f.y && f.x + LINE <= B.subcap && !(B.dbg & 2))
+            store_part((uint32_t)((GBN_STREAM(B, b, wid) * (size_t)B.subcap + f.x) >> 5), p, STAGE + b * LINE + p * 4);
     }
     for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
         const uint2 f = s_fin[b];
         const uint32_t total = f.x + (f.y ? LINE : 0u);
-        if (total > B.subcap) atomicExch(B.overflow, 1u);
+        if (total > B.subcap) atomicOr(B.overflow, 1u);
         B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(total, B.subcap);
     }
 }
