@@ -1357,7 +1357,8 @@ probe_bin_kernel(GbnBinParams B)
     uint2 *s_q = reinterpret_cast<uint2 *>(s_dyn + GBN_BIN_TABW);    // [16 waves][QCAP]; a wave's queue is touched by that wave only
     uint16_t *s_side = reinterpret_cast<uint16_t *>(s_dyn + GBN_BIN_TABW + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2);
     uint32_t *s_rcount = s_dyn + GBN_BIN_TABW + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2 + GBN_BIN_SIDE / 2;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the stream bookkeeping below stays in scalar registers
     const int grp = blockIdx.x & (GBN_BIN_GROUPS - 1);
     // tables of fewer slices than groups (2 or 4 bins): the groups that share a bin split its streams
     const int bstep = B.nb < GBN_BIN_GROUPS ? B.nb : GBN_BIN_GROUPS, sub = grp / bstep, nsub = GBN_BIN_GROUPS / bstep;
@@ -1437,22 +1438,29 @@ probe_bin_kernel(GbnBinParams B)
             const uint32_t rbase = (uint32_t)w * B.subcap + lo;     // of this piece inside the bin's region
             // software pipeline: the loads of the next round are in flight while this round's
             // records are looked up
-            const uint4 padv = make_uint4(GBN_REC_PAD, GBN_REC_PAD, GBN_REC_PAD, GBN_REC_PAD);
             uint4 cur[U], nxt[U];
+            // hi words of the piece: blocks of 64 records = 96 words; a round of BLK records starts at a block
+            // boundary (lo and BLK are multiples of 512), so a lane's words of round r sit at a fixed offset from
+            // the piece's first block + r * (BLK / 64 * 96)
+            const uint32_t *__restrict__ pbase = recb + GBN_REC_HI(GBN_RECIDX(B, b, w, lo));
+            uint32_t loff[U];
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) { const uint32_t j = u * 256u + (uint32_t)lane * 4u; loff[u] = (j >> 6) * 96u + (j & 63u); }
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t j = u * 256u + (uint32_t)lane * 4u;
-                const uint32_t jj = (j < n) ? j : 0u;              // always a valid address: keeps the load a global load
-                const uint4 v = *reinterpret_cast<const uint4 *>(recb + GBN_REC_HI(GBN_RECIDX(B, b, w, lo + (jj & ~511u))) + GBN_REC_HI(jj & 511u));
-                cur[u] = (j < n) ? v : padv;
+                const uint4 v = *reinterpret_cast<const uint4 *>(pbase + ((j < n) ? loff[u] : 0u));     // always a valid address: keeps the load a global load
+                cur[u].x = (j < n) ? v.x : GBN_REC_PAD; cur[u].y = (j < n) ? v.y : GBN_REC_PAD;
+                cur[u].z = (j < n) ? v.z : GBN_REC_PAD; cur[u].w = (j < n) ? v.w : GBN_REC_PAD;
             }
             for (uint32_t j0 = 0; j0 < n; j0 += BLK) {
+                const uint32_t rnext = ((j0 + BLK) >> 6) * 96u;       // word offset of the next round (a stream is far below 2^32 bytes)
                 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) {
                     const uint32_t j = j0 + BLK + u * 256u + (uint32_t)lane * 4u;
-                    const uint32_t jj = (j < n) ? j : 0u;
-                    const uint4 v = *reinterpret_cast<const uint4 *>(recb + GBN_REC_HI(GBN_RECIDX(B, b, w, lo + (jj & ~511u))) + GBN_REC_HI(jj & 511u));
-                    nxt[u] = (j < n) ? v : padv;
+                    const uint4 v = *reinterpret_cast<const uint4 *>(pbase + ((j < n) ? rnext + loff[u] : 0u));
+                    nxt[u].x = (j < n) ? v.x : GBN_REC_PAD; nxt[u].y = (j < n) ? v.y : GBN_REC_PAD;
+                    nxt[u].z = (j < n) ? v.z : GBN_REC_PAD; nxt[u].w = (j < n) ? v.w : GBN_REC_PAD;
                 }
                 uint32_t hv[NR], tv[NR];
                 #pragma unroll
