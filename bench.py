@@ -34,7 +34,7 @@ if ROOT not in sys.path:
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=160, help="timed passes (default: > 2 s of timed region on C2)")
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
                     help="C2 (the metric's config): megablast W=28 vs 50 Gbp; C3: blastn W=11 vs 5 Gbp, 100 kb batches")
@@ -51,6 +51,8 @@ def parse():
                     help="NOT the headline metric: keep the query-independent scan records of the shard in HBM and "
                          "skip the binning kernel for later batches with the same table shape (a database index)")
     a = ap.parse_args()
+    if a.workload == "C3" and "--steps" not in " ".join(sys.argv):
+        a.steps = 16
     if a.subjects is None:
         a.subjects = 50_000 if a.workload == "C2" else 5_000
     if a.batch_queries is None:
@@ -174,6 +176,22 @@ def main():
             el = float(t.item())
         return r, el
 
+    # what this box's HBM does on a plain device-to-device copy (boxes differ by 10 % and more: recorded next to
+    # the roofline so that box variance can be told from kernel changes)
+    def copy_bandwidth():
+        n = 1 << 30
+        a = torch.empty(n, dtype=torch.uint8, device=dev); b = torch.empty_like(a)
+        b.copy_(a); torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(8):
+            b.copy_(a)
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1)
+        del a, b
+        return 8 * 2 * n / (ms * 1e-3) / 1e9
+    box_copy = copy_bandwidth()
+
     # allocator warm-up, whatever --warmup says: three batches exist at a time in the pipeline below, and the
     # library keeps freed device blocks in a pool
     for b in [make(k) for k in range(3)]:
@@ -254,6 +272,7 @@ def main():
                             % (args.workload, len(queries), nsub * slen / 1e9, task, opt.word_size),
                 "stage_ms_per_pass": {k: sum(getattr(d, k) for d in diags) / max(launches, 1)
                                       for k in ["scan_stage_ms", "seed_stage_ms", "gapped_stage_ms", "host_stage_ms"]},
+                "config_wall_ms": npass_config * elapsed / args.steps * 1e3,
                 "batch_setup_ms": batch_setup_ms, "engine_only": engine_only, "init_hits_per_pass": sum(d.good_init_extends for d in diags) / max(launches, 1),
                 "batch_plan": {"queries_per_batch": args.batch_queries, "passes_per_config": npass_config,
                                "lut": info["lut_width"], "scan_step": info["scan_step"],
@@ -270,6 +289,7 @@ def main():
             },
             "roofline": {"bound": "hbm", "kernel": dom_label,
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "box_copy_GBps": box_copy,
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
                          "avg_launch_ms": dom_ms / max(launches, 1), "launches": launches,
@@ -310,9 +330,10 @@ def _cpu_worker(job):
 
 
 def cpu_baseline(args, batch_queries, gopt, layout):
-    """The oracle (a scalar C port of the reference algorithm) on this box's host cores: the same
-    query batch, a bounded sample of the same shard's subjects, one process per core (the reference
-    shares OID chunks among threads the same way, x_LaunchMultiThreadedSearch)."""
+    """The oracle (a scalar C port of the reference algorithm: lookup word cut from the packed bytes,
+    presence-vector test before the table, as the reference's scanners do) on this box's host cores:
+    the same query batch, a bounded sample of the same shard's subjects, one process per core (the
+    reference shares OID chunks among threads the same way, x_LaunchMultiThreadedSearch)."""
     import multiprocessing as mp
     from gblastn_amd import api
     cores = args.cpu_cores if args.cpu_cores > 0 else max(1, min(64, (os.cpu_count() or 1) // 2))

@@ -32,6 +32,9 @@ typedef struct OrcLookup {
     int32_t *cell_start;    /* ncells+1 prefix */
     int32_t *cell_offs;
     int32_t longest_chain;
+    /* presence vector of the megablast table: one bit per 2^pv_bts cells (CORE/blast_nalookup.c:951-1004;
+     * tested by the scanners before the table is touched, CORE/blast_nascan.c:1413-1461) */
+    uint32_t *pv; int32_t pv_bts;
 } OrcLookup;
 
 typedef struct OrcSeg { int32_t left, right; } OrcSeg;     /* SSeqRange of a lookup segment */

@@ -81,6 +81,7 @@ static void mb_add(void *arg, int32_t cell, int32_t q_off)
     int32_t index = q_off + 1;          /* 1-based, :893-898 */
     l->next_pos[index] = l->hashtable[cell];
     l->hashtable[cell] = index;
+    if (l->pv) l->pv[(uint32_t)cell >> l->pv_bts >> 5] |= 1u << (((uint32_t)cell >> l->pv_bts) & 31);   /* PV_SET, :921-923 */
 }
 static void na_add(void *arg, int32_t cell, int32_t q_off)
 {
@@ -110,6 +111,14 @@ OrcLookup *orc_lookup_new(const OrcOptions *opt, const uint8_t *query,
     if (l->type == ORC_LUT_MB) {
         l->hashtable = (int32_t *)calloc((size_t)l->ncells, sizeof(int32_t));
         l->next_pos = (int32_t *)calloc((size_t)qlen + 2, sizeof(int32_t));
+        {   /* size of the presence vector, CORE/blast_nalookup.c:951-1004 */
+            const int32_t kTargetPVSize = 131072, kSmallQueryCutoff = 15000, kLargeQueryCutoff = 800000;
+            int32_t pv_size = (l->ncells <= 8 * kTargetPVSize) ? (l->ncells >> 5) : kTargetPVSize / 4, bts = 0;
+            if (entries <= kSmallQueryCutoff || entries >= kLargeQueryCutoff) pv_size /= 2;
+            while ((1 << (bts + 1)) <= l->ncells / pv_size) bts++;          /* ilog2 */
+            l->pv_bts = bts;
+            l->pv = (uint32_t *)calloc((size_t)pv_size, 4);
+        }
         for (c = 0; c < nseg; c++)
             for_each_word(query, seg[c].left, seg[c].right, l->word_length, lut_width, mb_add, &b);
     } else {
@@ -159,6 +168,6 @@ int orc_lookup_has(const OrcLookup *l, int32_t index, int32_t q_pos)
 void orc_lookup_free(OrcLookup *l)
 {
     if (!l) return;
-    free(l->hashtable); free(l->next_pos); free(l->cell_start); free(l->cell_offs);
+    free(l->hashtable); free(l->next_pos); free(l->cell_start); free(l->cell_offs); free(l->pv);
     free(l);
 }

@@ -382,12 +382,18 @@ void orc_word_finder(OrcSearch *S, const uint8_t *subj, int32_t slen, OrcStats *
     else memset(S->diag_last_hit, 0, (size_t)S->diag_len * sizeof(int32_t));
 
     for (s_off = 0; s_off <= last; s_off += step) {
-        uint32_t idx = 0; int32_t k, nh, j;
-        for (k = 0; k < lut; k++) idx = (idx << 2) | ORC_BASE(subj, s_off + k);
-        idx &= mask;
+        uint32_t idx; int32_t nh, j;
+        {   /* the lookup word from the packed bytes with shifts and a mask, as the reference's scanners cut it
+             * (CORE/blast_nascan.c:1489-1591; lut <= 12: at most 4 + 1 bytes; the caller pads the subject) */
+            const uint8_t *sp = subj + (s_off >> 2);
+            const uint64_t w = ((uint64_t)sp[0] << 32) | ((uint64_t)sp[1] << 24) | ((uint64_t)sp[2] << 16) | ((uint64_t)sp[3] << 8) | sp[4];
+            idx = (uint32_t)(w >> (40 - 2 * (s_off & 3) - 2 * lut)) & mask;
+        }
         if (l->type == ORC_LUT_MB) {
-            /* CORE/blast_nascan.c:1413-1427: chain yields descending q */
-            int32_t qp = l->hashtable[idx];
+            /* CORE/blast_nascan.c:1413-1427: presence bit first, then the chain, which yields descending q */
+            int32_t qp;
+            if (!(l->pv[idx >> l->pv_bts >> 5] & (1u << ((idx >> l->pv_bts) & 31)))) continue;
+            qp = l->hashtable[idx];
             while (qp) {
                 int32_t q = qp - 1, sb = s_off, ok = 1;
                 st->lookup_hits++;
