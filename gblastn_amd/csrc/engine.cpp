@@ -804,7 +804,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         GbnExtParams X; std::memset(&X, 0, sizeof(X));
         X.db = db.d_packed; X.byte_off = db.d_byte_off; X.len = db.d_len;
         X.seeds = seeds; X.idx = E.idx_a; X.key_group = E.key_b; X.n = n;
-        X.q8 = d->q8; X.qlen = b.qlen;
+        X.q8 = d->q8; X.qlen = b.qlen; X.q2 = d->q2; X.qinv = d->qinv;
         X.ctx_off = d->ctx_off; X.ctx_len = d->ctx_len; X.ctx_xdrop = d->ctx_xdrop;
         X.ctx_cutoff = d->ctx_cutoff; X.ctx_reduced = d->ctx_reduced; X.nctx = (int32_t)b.ctx.size();
         X.matrix = d->matrix; X.score_table = d->score_table;
@@ -975,7 +975,12 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     }
     G.scratch = E.gap_scratch_s[slot];
     G.first = 0; G.n = (int64_t)nih; G.max_blocks = (int32_t)blocks;
+    if (getenv("GBN_DP_STATS")) HIPCHK(hipMemsetAsync(G.scratch, 0, 64, st));
     HIPCHK(launch_gapped(G, b.opt.greedy != 0, st));
+    if (getenv("GBN_DP_STATS")) {
+        unsigned long long c[5]; HIPCHK(hipMemcpyAsync(c, G.scratch, 40, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+        fprintf(stderr, "[gbn dbg] wave DP: %llu extensions (%llu left to the scratch kernel), %llu rows, %llu rounds, mean window %.1f\n", c[2], c[3], c[0], c[1], c[0] ? (double)c[4] / c[0] : 0.0);
+    }
     std::vector<GbnDevInitHit> hih((size_t)nih); std::vector<GbnDevGapped> hg((size_t)nih);
     HIPCHK(hipMemcpyAsync(hih.data(), E.ihits_s[slot], (size_t)nih * sizeof(GbnDevInitHit), hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(hg.data(), E.gapped_s[slot], (size_t)nih * sizeof(GbnDevGapped), hipMemcpyDeviceToHost, st));

@@ -128,6 +128,9 @@ struct GbnExtParams {
     int32_t *cell_diag, *cell_level;    // hash emulation scratch, n entries each
     // re-check of seeds against the soft query masks (s_TypeOfWord): table membership tests
     const uint32_t *cell_start; const unsigned long long *ent; uint32_t cell_mask; int lut, masked;
+    // the query 2 bits per base and the bitmap of codes that match nothing (as in GbnGapParams): the 4-bases-per-step
+    // ungapped extension reads 32 bases at a time from them; null: byte-wise path only
+    const uint8_t *q2, *qinv;
     uint32_t *run_heads, *run_count;    // scratch: index of the first seed of every (subject, slot) run (n entries), their number
     int32_t group_bits;                 // key_group = subject << group_bits | slot (0 is read as 32)
     GbnDevInitHit *ihits; unsigned long long *ihit_count; unsigned long long ihit_cap;
@@ -145,4 +148,6 @@ struct GbnGapParams {
     int32_t *scratch; int32_t scratch_per_thread, row_len;      // scratch: one slot per thread of the grid
     GbnDevGapped *out;
     int32_t max_blocks;             // grid cap in 64-thread blocks (0: one thread per initial hit); the threads stride over the hits
+    int32_t redo_only;              // dynprog_kernel: only the extensions the wave kernel marked GBN_GAP_REDO
 };
+#define GBN_GAP_REDO (INT32_MIN + 1)    // GbnDevGapped::score of an extension the wave-per-extension kernel left to dynprog_kernel

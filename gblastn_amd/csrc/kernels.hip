@@ -25,6 +25,9 @@
 #include <stdint.h>
 #include <algorithm>
 #include "gbn_dev.h"
+#ifndef GBN_DIAG_ABL
+#define GBN_DIAG_ABL 0      // timing experiments only (1: no ungapped extension, 2: no strand search): wrong results
+#endif
 #ifndef GBN_PROBE_U
 #define GBN_PROBE_U 2        // 16-byte loads per lane and round of the probe kernel (4 records each)
 #endif
@@ -53,6 +56,23 @@ __device__ __forceinline__ uint32_t window16(const uint8_t *__restrict__ p, int6
     const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + w;
     uint32_t hi = bswap32(d[0]), lo = bswap32(d[1]);
     int sh = 2 * (int)(pos & 15);
+    return sh ? ((hi << sh) | (lo >> (32 - sh))) : hi;
+}
+
+// 32 consecutive bases of a 2-bit packed sequence starting at base index `pos` (may be negative:
+// both the subject slab and the packed query carry padding in front), big-endian in 64 bits
+__device__ __forceinline__ uint64_t bases32(const uint8_t *__restrict__ p, int64_t pos) {
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + (pos >> 4);
+    const uint64_t hi = ((uint64_t)bswap32(d[0]) << 32) | bswap32(d[1]);
+    const uint32_t lo = bswap32(d[2]);
+    const int sh = 2 * (int)(pos & 15);
+    return sh ? ((hi << sh) | ((uint64_t)lo >> (32 - sh))) : hi;
+}
+// 32 consecutive bits of a bitmap (most significant bit first) starting at bit index `pos`
+__device__ __forceinline__ uint32_t bits32(const uint8_t *__restrict__ p, int64_t pos) {
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + (pos >> 5);
+    const uint32_t hi = bswap32(d[0]), lo = bswap32(d[1]);
+    const int sh = (int)(pos & 31);
     return sh ? ((hi << sh) | (lo >> (32 - sh))) : hi;
 }
 
@@ -297,34 +317,71 @@ __device__ void ungapped_exact(const GbnExtParams &P, const uint8_t *__restrict_
     u.length = q_end - q_beg; u.score = score;
 }
 
+// s_NuclUngappedExtend (CORE/na_ungapped.c:262-351): 4 bases per step, score of a step = table[q_byte ^ s_byte]
+// = matches * reward + mismatches * penalty of the four 2-bit groups (CORE/blast_parameters.c:237-262).  A step's
+// query byte is built from the unpacked codes, so a code above 3 (ambiguity, sentinel between the strands) spills
+// into its neighbours' bits: such groups go through the byte-wise formula; all others are taken 8 steps at a time
+// from the 2-bit copy of the query (three dwords of query, three of subject, two of the "matches nothing" bitmap
+// per 32 bases instead of six dependent loads per step).
 __device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
                                 int32_t q_off, int32_t s_match_end, int32_t s_off, int32_t X,
                                 int32_t reduced_cutoff, Ungapped &u)
 {
     const uint8_t *qs = P.q8;
+    const int32_t t4 = P.score_table[0], dt = P.score_table[1] - t4;      // 4 * reward, penalty - reward
+    auto step_score = [&](uint32_t q_byte, uint32_t s_byte) -> int32_t {
+        const uint32_t x = q_byte ^ s_byte;
+        return t4 + dt * (int32_t)__popc((x | (x >> 1)) & 0x55u);
+    };
     int32_t len = (4 - (s_off & 3)) & 3;
     const int32_t q_ext = q_off + len, s_ext = s_off + len;
-    int32_t qi = q_ext, sb = s_ext >> 2;
-    len = min(q_ext, s_ext) >> 2;
     int32_t score = 0, sum = 0, new_q = q_ext;
-    for (int32_t i = 0; i < len; sb--, qi -= 4, i++) {
-        uint8_t s_byte = subj[sb - 1];
-        uint8_t q_byte = (uint8_t)((qs[qi - 4] << 6) | (qs[qi - 3] << 4) | (qs[qi - 2] << 2) | qs[qi - 1]);
-        sum += P.score_table[q_byte ^ s_byte];
-        if (sum > 0) { new_q = qi - 4; score += sum; sum = 0; }
-        if (sum < X) break;
+    {   // left
+        const int32_t n = min(q_ext, s_ext) >> 2;
+        bool stop = false;
+        for (int32_t c = 0; c * 8 < n && !stop; c++) {
+            const int64_t sa = (int64_t)s_ext - 32 * (c + 1), qa = (int64_t)q_ext - 32 * (c + 1);
+            const uint64_t S = bases32(subj, sa);
+            const bool packed = P.q2 != nullptr;
+            const uint64_t Q = packed ? bases32(P.q2, qa) : 0ull;
+            const uint32_t I = packed ? bits32(P.qinv, qa) : 0xffffffffu;
+            const int32_t steps = min(8, n - c * 8);
+            for (int32_t t = 0; t < steps; t++) {
+                const int32_t qi = q_ext - 4 * (c * 8 + t);             // the step covers query bases qi-4 .. qi-1
+                const uint32_t s_byte = (uint32_t)(S >> (8 * t)) & 0xffu;
+                uint32_t q_byte;
+                if ((I >> (4 * t)) & 0xfu) q_byte = (uint8_t)((qs[qi - 4] << 6) | (qs[qi - 3] << 4) | (qs[qi - 2] << 2) | qs[qi - 1]);
+                else q_byte = (uint32_t)(Q >> (8 * t)) & 0xffu;
+                sum += step_score(q_byte, s_byte);
+                if (sum > 0) { new_q = qi - 4; score += sum; sum = 0; }
+                if (sum < X) { stop = true; break; }
+            }
+        }
     }
     u.q_start = new_q;
     u.s_start = s_ext - (q_ext - u.q_start);
-    qi = q_ext; sb = s_ext >> 2;
-    len = min(P.qlen - q_ext, slen - s_ext) >> 2;
     sum = 0; new_q = q_ext;
-    for (int32_t i = 0; i < len; sb++, qi += 4, i++) {
-        uint8_t s_byte = subj[sb];
-        uint8_t q_byte = (uint8_t)((qs[qi] << 6) | (qs[qi + 1] << 4) | (qs[qi + 2] << 2) | qs[qi + 3]);
-        sum += P.score_table[q_byte ^ s_byte];
-        if (sum > 0) { new_q = qi + 3; score += sum; sum = 0; }
-        if (sum < X) break;
+    {   // right
+        const int32_t n = min(P.qlen - q_ext, slen - s_ext) >> 2;
+        bool stop = false;
+        for (int32_t c = 0; c * 8 < n && !stop; c++) {
+            const int64_t sa = (int64_t)s_ext + 32 * c, qa = (int64_t)q_ext + 32 * c;
+            const uint64_t S = bases32(subj, sa);
+            const bool packed = P.q2 != nullptr;
+            const uint64_t Q = packed ? bases32(P.q2, qa) : 0ull;
+            const uint32_t I = packed ? bits32(P.qinv, qa) : 0xffffffffu;
+            const int32_t steps = min(8, n - c * 8);
+            for (int32_t t = 0; t < steps; t++) {
+                const int32_t qi = q_ext + 4 * (c * 8 + t);             // the step covers query bases qi .. qi+3
+                const uint32_t s_byte = (uint32_t)(S >> (56 - 8 * t)) & 0xffu;
+                uint32_t q_byte;
+                if ((I >> (28 - 4 * t)) & 0xfu) q_byte = (uint8_t)((qs[qi] << 6) | (qs[qi + 1] << 4) | (qs[qi + 2] << 2) | qs[qi + 3]);
+                else q_byte = (uint32_t)(Q >> (56 - 8 * t)) & 0xffu;
+                sum += step_score(q_byte, s_byte);
+                if (sum > 0) { new_q = qi + 3; score += sum; sum = 0; }
+                if (sum < X) { stop = true; break; }
+            }
+        }
     }
     if (score >= reduced_cutoff) {
         ungapped_exact(P, subj, slen, q_off, s_off, X, u);
@@ -441,11 +498,17 @@ extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
         }
         // strand of the seed
         int lo = 0, hi = P.nctx;
+#if GBN_DIAG_ABL != 2
         while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > q_off) hi = m; else lo = m; }
+#endif
         const int32_t X = -P.ctx_xdrop[lo];
         Ungapped u;
+#if GBN_DIAG_ABL == 1
+        u.score = 0; u.length = word; u.q_start = q_off; u.s_start = s_off;
+#else
         if (!P.container_hash && word < 11) ungapped_exact(P, subj, slen, q_off, s_off, X, u);
         else ungapped_approx(P, subj, slen, q_off, s_match_end, s_off, X, P.ctx_reduced[lo], u);
+#endif
         if (u.score >= P.ctx_cutoff[lo]) {
             unsigned long long o = atomicAdd(P.ihit_count, 1ull);
             if (o < P.ihit_cap) {
@@ -475,23 +538,6 @@ extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
 // gapped extensions, one thread per initial hit (score-only)
 // ---------------------------------------------------------------------------
 namespace {
-// 32 consecutive bases of a 2-bit packed sequence starting at base index `pos` (may be negative:
-// both the subject slab and the packed query carry padding in front), big-endian in 64 bits
-__device__ __forceinline__ uint64_t bases32(const uint8_t *__restrict__ p, int64_t pos) {
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + (pos >> 4);
-    const uint64_t hi = ((uint64_t)bswap32(d[0]) << 32) | bswap32(d[1]);
-    const uint32_t lo = bswap32(d[2]);
-    const int sh = 2 * (int)(pos & 15);
-    return sh ? ((hi << sh) | ((uint64_t)lo >> (32 - sh))) : hi;
-}
-// 32 consecutive bits of a bitmap (most significant bit first) starting at bit index `pos`
-__device__ __forceinline__ uint32_t bits32(const uint8_t *__restrict__ p, int64_t pos) {
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + (pos >> 5);
-    const uint32_t hi = bswap32(d[0]), lo = bswap32(d[1]);
-    const int sh = (int)(pos & 31);
-    return sh ? ((hi << sh) | (lo >> (32 - sh))) : hi;
-}
-
 // query as the gapped kernels see it: 2 bits per base plus a bitmap of the codes that can
 // never match a subject base (ambiguity codes, sentinels); a0 = index of "q[0]"
 struct GQ { const uint8_t *q2; const uint8_t *qinv; int64_t a0; };
@@ -849,7 +895,208 @@ __device__ void dynprog_hit(const GbnGapParams &P, int64_t i)
 extern "C" __global__ void dynprog_kernel(GbnGapParams P)
 {
     const int64_t total = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += total) dynprog_hit(P, i);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < P.n; i += total) {
+        if (P.redo_only && P.out[P.first + i].score != GBN_GAP_REDO) continue;     // second launch: what the wave kernel left
+        dynprog_hit(P, i);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same extension (s_BlastAlignPackedNucl, CORE/blast_gapalign.c:2842-3056), one extension per WAVE:
+// lane l holds the DP cell {best, best_gap} of the query column b with b mod 64 == l inside the active
+// window [first_b, b_size) -- the band lives in registers, no scratch memory -- and a subject row is
+// evaluated by all lanes at once.  The reference walks a row left to right with three running values;
+// they become prefix operations over the lanes, in the row's own order (the window is circular in the
+// lanes), with exactly the reference's results:
+//   score entering column b     = old best[b-1] + match(b-1): one lane rotation
+//   score_gap_row entering b    = max over KEPT columns b' < b of S[b'] - gap_open_extend - gap_extend * (kept
+//                                 columns between b' and b): the running value only decays on columns that pass the
+//                                 X-drop test.  Opening a gap out of a gap never beats extending it, so S[b'] may be
+//                                 replaced by H[b'] = max(diagonal, vertical gap), which does not depend on the row's
+//                                 horizontal gaps: a prefix maximum of H[b'] + gap_extend * K(b'+1), K = kept columns
+//                                 before a column (a population count of the kept mask)
+//   best_score seen by column b = max(best so far, S of the kept columns b' < b): a prefix maximum
+//   kept(b)                     = best seen - S[b] <= X
+// kept depends on S and the running best, S on kept: the row is iterated from "all kept" until the kept mask
+// repeats.  Column j of the window is final after j rounds (its inputs lie left of it), so the loop ends with the
+// one solution the sequential walk has; two rounds are typical.  Query letters: a lane keeps the four match
+// scores of its column of the current 64-column block and of the next two, reloaded a block ahead.  Subject bases:
+// 256 at a time in the lanes, read with v_readlane.  A window wider than 62 columns (or gap_extend 0) is left to
+// dynprog_kernel (GBN_GAP_REDO).
+namespace {
+constexpr int32_t kDpNeg = GBN_MININT;
+// inclusive prefix maximum over the 64 lanes of a fully active wave: six v_max_i32_dpp steps (row shifts, then row
+// broadcasts; a lane without a source keeps its value).  Written as assembly: the compiler turns the same steps
+// into three instructions each.  (s_nop 1: a DPP source needs two wait states after the VALU write before it.)
+__device__ __forceinline__ int32_t wave_scan_max_incl(int32_t v)
+{
+    asm volatile("s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xe\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xc\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"
+                 "s_nop 1\n\tv_max_i32_dpp %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"
+                 "s_nop 1" : "+v"(v));
+    return v;
+}
+// value of the lane below (lane 0: kDpNeg)
+__device__ __forceinline__ int32_t lane_below(int32_t v) { return __builtin_amdgcn_update_dpp(kDpNeg, v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+
+__device__ int32_t align_packed_wave(const GbnGapParams &P, const uint8_t *q, const uint8_t *subj,
+                                     int32_t q0, int32_t s0, int32_t N, int32_t M, int32_t *b_off, int32_t *a_off,
+                                     bool reverse, int *redo)
+{
+    const int lane = (int)(threadIdx.x & 63);
+    const int32_t gap_extend = P.gap_extend, goe = P.gap_open + P.gap_extend;
+    int32_t x = P.xdrop;
+    *a_off = 0; *b_off = 0;
+    if (x < goe) x = goe;
+    if (N <= 0 || M <= 0) return 0;
+    if (gap_extend <= 0) { *redo = 1; return 0; }
+    constexpr int32_t W = 62;                                   // widest window kept here (64 lanes: the window, one sentinel, one spare)
+    // match scores of a column against the four subject bases
+    auto load_scores = [&](int32_t col, int32_t (&m)[4]) {
+        const int32_t c = min(col, N);                          // column N is the sentinel cell: the letter past the query end
+        const uint8_t letter = reverse ? q[N - 1 - c] : q[q0 + c];
+        #pragma unroll
+        for (int t = 0; t < 4; t++) m[t] = P.matrix[t * 16 + letter];
+    };
+    // scores of column cb * 64 + lane, of the block after it (the window straddles two blocks) and, loaded a block
+    // ahead of its first use, of the one after that
+    int32_t mA[4], mB[4], mC[4]; int32_t cb = 0;
+    load_scores(lane, mA); load_scores(64 + lane, mB); load_scores(128 + lane, mC);
+    // row 0
+    const int32_t ninit = min(N, (x - goe) / gap_extend + 1);
+    int32_t first_b = 0, b_size = ninit + 1;
+    if (b_size > W) { *redo = 1; return 0; }
+    int32_t best = lane == 0 ? 0 : -goe - (lane - 1) * gap_extend, bgap = best - goe;     // lane l: column b with b mod 64 == l
+    int32_t best_score = 0;
+    // subject bytes: 64 at a time (256 bases), byte `sb_lo + l` of the subject in lane l
+    int32_t sb_lo = INT32_MIN; uint32_t sbytes = 0;
+    for (int32_t a = 1; a <= M; a++) {
+        const int32_t pos = reverse ? (M - a) : (s0 + a - 1), byte = pos >> 2;
+        if (byte < sb_lo || byte >= sb_lo + 64) {
+            sb_lo = reverse ? max(byte - 63, 0) : byte;
+            sbytes = subj[(int64_t)sb_lo + lane];
+        }
+        const int ab = (int)((__builtin_amdgcn_readlane((int)sbytes, byte - sb_lo) >> (2 * (3 - (pos & 3)))) & 3);
+        const int f = first_b & 63, width = b_size - first_b;
+        const int32_t col = first_b + ((lane - f) & 63);
+        const bool inwin_p = col < b_size;
+        const bool blkA = (col >> 6) == cb;
+        const int32_t m0 = blkA ? mA[0] : mB[0], m1 = blkA ? mA[1] : mB[1], m2 = blkA ? mA[2] : mB[2], m3 = blkA ? mA[3] : mB[3];
+        const int32_t msel = (ab & 2) ? ((ab & 1) ? m3 : m2) : ((ab & 1) ? m1 : m0);
+        // score entering a column = what the column before it hands on (lane rotation; the window's first column: none)
+        int32_t D = __builtin_amdgcn_update_dpp(kDpNeg, inwin_p ? best + msel : kDpNeg, 0x13C, 0xf, 0xf, false);   // wave_ror:1
+        if (lane == f) D = kDpNeg;
+        const int32_t C = bgap;
+        // from here to the state update: lane j = column first_b + j (one crossbar move in, one out)
+        const int32_t H = __builtin_amdgcn_ds_bpermute(((lane + f) & 63) << 2, inwin_p ? max(max(D, C), kDpNeg) : kDpNeg);
+        const bool inwin = lane < width;
+        unsigned long long km = width >= 64 ? ~0ull : ((1ull << width) - 1ull);
+        int32_t S = kDpNeg, Ttot = kDpNeg, Stot = kDpNeg; bool kept = false;
+        for (int round = 0; round < 66; round++) {
+            kept = (km >> lane) & 1ull;
+            const int32_t K = (int32_t)__builtin_amdgcn_mbcnt_hi((uint32_t)(km >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)km, 0u));   // kept columns before this one
+            const int32_t Ti = wave_scan_max_incl(kept ? max(H + gap_extend * (K + 1), kDpNeg) : kDpNeg);
+            Ttot = __builtin_amdgcn_readlane(Ti, 63);
+            const int32_t PM = lane_below(Ti);
+            const int32_t G = PM <= kDpNeg ? kDpNeg : PM - goe - gap_extend * K;
+            S = max(H, G);
+            const int32_t Si = wave_scan_max_incl(kept ? S : kDpNeg);
+            Stot = __builtin_amdgcn_readlane(Si, 63);
+            const bool keep = inwin && !(max(best_score, lane_below(Si)) - S > x);
+            const unsigned long long km2 = __ballot(keep);
+#if GBN_DP_STATS
+            if (lane == 0) atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 1, 1ull);
+#endif
+            if (km2 == km) break;
+            km = km2;
+        }
+#if GBN_DP_STATS
+        if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch), 1ull); atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 4, (unsigned long long)(b_size - first_b)); }
+#endif
+        if (Stot > best_score) {
+            best_score = Stot; *a_off = a;
+            *b_off = first_b + (int32_t)__builtin_ctzll(__ballot(kept && S == Stot));
+        }
+        {   // back to the lanes the columns live in
+            const int j = (lane - f) & 63;
+            const int32_t Sp = __builtin_amdgcn_ds_bpermute(j << 2, S);
+            const bool kept_p = (km >> j) & 1ull;
+            if (kept_p) { bgap = max(Sp - goe, C - gap_extend); best = Sp; }
+            else if (inwin_p) best = kDpNeg;
+        }
+        if (km == 0) break;                                     // every column failed: first_b == b_size
+        const int32_t new_first = first_b + (int32_t)__builtin_ctzll(km), last_b = first_b + 63 - (int32_t)__builtin_clzll(km);
+        if (last_b < b_size - 1) {
+            b_size = last_b + 1;
+        } else {
+            // the horizontal gap runs on past the window
+            const int32_t Gfin = Ttot - goe - gap_extend * (int32_t)__popcll(km), thr = best_score - x;
+            int32_t k = Gfin >= thr ? (Gfin - thr) / gap_extend + 1 : 0;
+            k = min(k, max(N - b_size + 1, 0));
+            if (b_size + k + 1 - new_first > W) { *redo = 1; return 0; }
+            const int32_t cn = new_first + ((lane - new_first) & 63);
+            if (cn >= b_size && cn < b_size + k) { best = Gfin - (cn - b_size) * gap_extend; bgap = best - goe; }
+            b_size += k;
+        }
+        if (b_size <= N) {
+            if (b_size + 1 - new_first > W + 1) { *redo = 1; return 0; }
+            if (lane == (b_size & 63)) { best = kDpNeg; bgap = kDpNeg; }
+            b_size++;
+        }
+        first_b = new_first;
+        if ((first_b >> 6) > cb) {                              // the window has left block cb
+            cb++;
+            #pragma unroll
+            for (int t = 0; t < 4; t++) { mA[t] = mB[t]; mB[t] = mC[t]; }
+            load_scores((cb + 2) * 64 + lane, mC);
+        }
+    }
+    return best_score;
+}
+
+__device__ void dynprog_hit_wave(const GbnGapParams &P, int64_t i)
+{
+    const GbnDevInitHit h = P.ihits[P.first + i];
+    const int32_t subj_id = __builtin_amdgcn_readfirstlane(h.subj), h_q_off = __builtin_amdgcn_readfirstlane(h.q_off),
+                  h_s_off = __builtin_amdgcn_readfirstlane(h.s_off), h_s_start = __builtin_amdgcn_readfirstlane(h.s_start),
+                  h_length = __builtin_amdgcn_readfirstlane(h.length);
+    const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
+    const int32_t slen = P.len[subj_id];
+    int lo = 0, hi = P.nctx;
+    while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > h_q_off) hi = m; else lo = m; }
+    const int32_t qstart = P.ctx_off[lo], qlen = P.ctx_len[lo];
+    const uint8_t *q = P.q8 + qstart;
+    int32_t q_off = h_q_off - qstart, s_off = h_s_off;
+    const int32_t s_end = h_s_start + h_length;
+    if (s_end >= s_off + 8) { s_off += 3; q_off += 3; }       // CORE/blast_gapalign.c:3494-3497
+    int redo = 0;
+    const int32_t adj = 4 - (s_off & 3);
+    int32_t q_length = q_off + adj, s_length = s_off + adj;
+    if (q_length > qlen || s_length > slen) { q_length -= 4; s_length -= 4; }
+    int32_t pq, ps;
+    GbnDevGapped g; g.context = lo; g.seed_q = q_off; g.seed_s = s_off;
+    const int32_t left = align_packed_wave(P, q, subj, 0, 0, q_length, s_length, &pq, &ps, true, &redo);
+    g.q_start = q_length - pq; g.s_start = s_length - ps;
+    int32_t right = 0;
+    if (!redo && q_length < qlen && s_length < slen) {
+        right = align_packed_wave(P, q, subj, q_length, s_length, qlen - q_length, slen - s_length, &pq, &ps, false, &redo);
+        g.q_stop = pq + q_length; g.s_stop = ps + s_length;
+    } else { g.q_stop = q_length; g.s_stop = s_length; }
+    g.score = redo ? GBN_GAP_REDO : left + right;
+#if GBN_DP_STATS
+    if ((threadIdx.x & 63) == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 2, 1ull); if (redo) atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 3, 1ull); }
+#endif
+    if ((threadIdx.x & 63) == 0) P.out[P.first + i] = g;
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(256) dynprog_wave_kernel(GbnGapParams P)
+{
+    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    for (int64_t i = wave; i < P.n; i += nwaves) dynprog_hit_wave(P, i);
 }
 
 // ---------------------------------------------------------------------------
@@ -920,8 +1167,17 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
     if (p.n <= 0) return hipSuccess;
     const int64_t need = (p.n + 63) / 64;
     const unsigned blocks = (unsigned)std::max<int64_t>(1, p.max_blocks > 0 ? std::min<int64_t>(need, p.max_blocks) : need);
-    if (greedy) hipLaunchKernelGGL(greedy_kernel, dim3(blocks), dim3(64), 0, st, p);
-    else hipLaunchKernelGGL(dynprog_kernel, dim3(blocks), dim3(64), 0, st, p);
+    if (greedy) { hipLaunchKernelGGL(greedy_kernel, dim3(blocks), dim3(64), 0, st, p); return hipGetLastError(); }
+    // blastn: one extension per wave with the band in registers; the few it leaves (GBN_GAP_REDO: a band wider
+    // than a wave, gap_extend 0) go through the thread-per-extension kernel with its band in scratch memory
+    if (!p.redo_only) {
+        const int64_t wblocks = std::max<int64_t>(1, std::min<int64_t>((p.n + 3) / 4, p.max_blocks > 0 ? (int64_t)p.max_blocks * 2 : (p.n + 3) / 4));
+        hipLaunchKernelGGL(dynprog_wave_kernel, dim3((unsigned)wblocks), dim3(256), 0, st, p);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    GbnGapParams r = p; r.redo_only = 1;
+    hipLaunchKernelGGL(dynprog_kernel, dim3(blocks), dim3(64), 0, st, r);
     return hipGetLastError();
 }
 
