@@ -167,6 +167,34 @@ int orc_greedy_extend(const uint8_t *query, int32_t qlen,
                       int32_t reward, int32_t penalty,
                       int32_t gap_open, int32_t gap_extend, OrcHSP *out);
 
+/* ---- traceback stage (orc_traceback.c) ---- */
+typedef struct OrcEditScript { uint8_t *op; int32_t *num; int32_t size; } OrcEditScript;    /* op: 0 deletion (gap in query), 3 substitution, 6 insertion */
+typedef struct OrcTbHSP {
+    OrcHSP hsp;                 /* final coordinates, score, e-value */
+    OrcEditScript esp;
+    int32_t num_ident, align_length, gaps, gap_opens;
+    double bit_score;
+} OrcTbHSP;
+/* Blast_TracebackFromHSPList + s_HSPListPostTracebackUpdate (CORE/blast_traceback.c:336-790, :278-334) for the
+ * preliminary HSPs of ONE query (both strands) against one subject, sorted by score.  subject: BLASTNA codes,
+ * one per base.  Returns the number of final HSPs in *out (orc_traceback_free). */
+int32_t orc_traceback_hsp_list(const OrcSearch *S, const uint8_t *subject, int32_t subject_length,
+                               const OrcHSP *in, int32_t nin, OrcTbHSP **out);
+void orc_traceback_free(OrcTbHSP *h, int32_t n);
+/* the aligners on their own (known-answer and definition-level tests) */
+typedef struct OrcGapOut { int32_t q_start, q_stop, s_start, s_stop, score, seed_q, seed_s; } OrcGapOut;
+int orc_tb_dynprog(const OrcSearch *S, int32_t context, const uint8_t *subject, int32_t subject_length,
+                   int32_t q_start, int32_t s_start, int32_t x_dropoff, OrcGapOut *r, OrcEditScript *esp);
+int orc_tb_greedy(const OrcSearch *S, int32_t context, const uint8_t *subject, int32_t subject_length,
+                  int32_t q_start, int32_t s_start, int32_t x_dropoff, OrcGapOut *r, OrcEditScript *esp);
+/* Blast_SemiGappedAlign, score only (CORE/blast_gapalign.c:745-937): A rows, B columns, letters A[a], B[b + 1]
+ * forward / A[M - a], B[N - 1 - b] reversed */
+int32_t orc_semi_gapped_score(const int32_t matrix[16][16], const uint8_t *A, const uint8_t *B, int32_t M, int32_t N,
+                              int32_t *a_offset, int32_t *b_offset, int32_t x_dropoff, int32_t gap_open,
+                              int32_t gap_extend, int reverse_sequence);
+const int32_t *orc_matrix(const OrcSearch *S);      /* 16 x 16 */
+void orc_esp_free(OrcEditScript *e);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,20 @@ class OrcKarlin(C.Structure):
     _fields_ = [("Lambda", C.c_double), ("K", C.c_double), ("logK", C.c_double), ("H", C.c_double)]
 
 
+class OrcEditScript(C.Structure):
+    _fields_ = [("op", C.POINTER(C.c_uint8)), ("num", C.POINTER(C.c_int32)), ("size", C.c_int32)]
+
+
+class OrcTbHSP(C.Structure):
+    _fields_ = [("hsp", OrcHSP), ("esp", OrcEditScript), ("num_ident", C.c_int32), ("align_length", C.c_int32),
+                ("gaps", C.c_int32), ("gap_opens", C.c_int32), ("bit_score", C.c_double)]
+
+
+class OrcGapOut(C.Structure):
+    _fields_ = [("q_start", C.c_int32), ("q_stop", C.c_int32), ("s_start", C.c_int32), ("s_stop", C.c_int32),
+                ("score", C.c_int32), ("seed_q", C.c_int32), ("seed_s", C.c_int32)]
+
+
 def build(force=False):
     """Compile oracle/liborc.so with the committed Makefile."""
     so = os.path.join(_HERE, "liborc.so")
@@ -120,6 +134,18 @@ def lib():
         L.orc_greedy_extend.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.POINTER(OrcHSP)]
+        L.orc_traceback_hsp_list.restype = C.c_int32
+        L.orc_traceback_hsp_list.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(OrcHSP), C.c_int32,
+                                             C.POINTER(C.POINTER(OrcTbHSP))]
+        L.orc_traceback_free.argtypes = [C.POINTER(OrcTbHSP), C.c_int32]
+        for f in (L.orc_tb_dynprog, L.orc_tb_greedy):
+            f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                          C.POINTER(OrcGapOut), C.POINTER(OrcEditScript)]
+        L.orc_semi_gapped_score.restype = C.c_int32
+        L.orc_semi_gapped_score.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_int32),
+                                            C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_int32, C.c_int]
+        L.orc_matrix.restype = C.POINTER(C.c_int32); L.orc_matrix.argtypes = [C.c_void_p]
+        L.orc_esp_free.argtypes = [C.POINTER(OrcEditScript)]
         _LIB = L
     return _LIB
 
@@ -276,6 +302,51 @@ class Search:
         ih = grab(L.orc_num_init_hits, L.orc_init_hits, OrcInitHit, IHIT_DT)
         hs = grab(L.orc_num_hsps, L.orc_hsps, OrcHSP, HSP_DT)
         return dict(seeds=seeds, init_hits=ih, hsps=hs)
+
+
+    # ---- traceback stage (orc_traceback.c) ----
+    def matrix(self):
+        return np.ctypeslib.as_array(self._L.orc_matrix(self._h), shape=(16, 16)).copy()
+
+    def traceback(self, subject_blastna, hsps):
+        """Blast_TracebackFromHSPList for the preliminary HSPs (records of HSP_DT, sorted by score) of ONE query
+        against one subject given as BLASTNA codes.  -> list of dicts (HSP fields + ops, num_ident, ...)."""
+        sub = np.ascontiguousarray(subject_blastna, dtype=np.uint8)
+        arr = (OrcHSP * max(len(hsps), 1))()
+        for i, h in enumerate(hsps):
+            for f in Collector.FIELDS:
+                setattr(arr[i], f, h[f].item() if hasattr(h[f], "item") else h[f])
+        out = C.POINTER(OrcTbHSP)()
+        n = self._L.orc_traceback_hsp_list(self._h, sub.ctypes.data, len(sub), arr, len(hsps), C.byref(out))
+        res = []
+        for i in range(n):
+            t = out[i]
+            d = {f: getattr(t.hsp, f) for f in Collector.FIELDS}
+            d.update(num_ident=t.num_ident, align_length=t.align_length, gaps=t.gaps, gap_opens=t.gap_opens,
+                     bit_score=t.bit_score, ops=[(int(t.esp.op[k]), int(t.esp.num[k])) for k in range(t.esp.size)])
+            res.append(d)
+        self._L.orc_traceback_free(out, n)
+        return res
+
+    def align_traceback(self, context, subject_blastna, q_start, s_start, x_dropoff, greedy=False):
+        """One gapped extension with traceback from (q_start, s_start) (context-relative query offset)."""
+        sub = np.ascontiguousarray(subject_blastna, dtype=np.uint8)
+        r, e = OrcGapOut(), OrcEditScript()
+        f = self._L.orc_tb_greedy if greedy else self._L.orc_tb_dynprog
+        f(self._h, context, sub.ctypes.data, len(sub), q_start, s_start, x_dropoff, C.byref(r), C.byref(e))
+        ops = [(int(e.op[k]), int(e.num[k])) for k in range(e.size)]
+        self._L.orc_esp_free(C.byref(e))
+        return dict(q_start=r.q_start, q_stop=r.q_stop, s_start=r.s_start, s_stop=r.s_stop, score=r.score, ops=ops)
+
+
+def semi_gapped_score(matrix, A, B, M, N, x_dropoff, gap_open, gap_extend, reverse):
+    """Blast_SemiGappedAlign, score only -> (score, a_offset, b_offset)"""
+    m = np.ascontiguousarray(matrix, dtype=np.int32)
+    a = np.ascontiguousarray(A, dtype=np.uint8); b = np.ascontiguousarray(B, dtype=np.uint8)
+    ao, bo = C.c_int32(), C.c_int32()
+    sc = lib().orc_semi_gapped_score(m.ctypes.data, a.ctypes.data, b.ctypes.data, M, N, C.byref(ao), C.byref(bo),
+                                     x_dropoff, gap_open, gap_extend, 1 if reverse else 0)
+    return sc, ao.value, bo.value
 
 
 SEED_DT = np.dtype([("q_off", "<i4"), ("s_off", "<i4")])

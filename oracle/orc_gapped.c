@@ -262,6 +262,33 @@ static int itree_contains(const ITree *t, const OrcHSP *hsp, int32_t mds)
     return hsp_contained(hsp, query_start, &t->pool[t->n[node].hsp], t->n[node].leftptr, mds);
 }
 
+/* the tree for the traceback stage (orc_traceback.c): the HSP pool is the caller's array */
+void *orc_itree_new(const OrcSearch *S, int32_t q_end, int32_t s_end)
+{
+    ITree *t = (ITree *)calloc(1, sizeof(ITree));
+    itree_init(t, S, q_end, s_end);
+    return t;
+}
+void orc_itree_reset(void *tv, int32_t q_end, int32_t s_end)     /* Blast_IntervalTreeReset */
+{
+    ITree *t = (ITree *)tv;
+    t->used = 0; t->s_max = s_end;
+    iroot_new(t, 0, q_end);
+}
+int orc_itree_contains_hsp(void *tv, const OrcHSP *pool, const OrcHSP *hsp, int32_t mds)
+{
+    ITree *t = (ITree *)tv;
+    t->pool = pool;
+    return itree_contains(t, hsp, mds);
+}
+void orc_itree_add_hsp(void *tv, const OrcHSP *pool, int32_t idx)
+{
+    ITree *t = (ITree *)tv;
+    t->pool = pool;
+    itree_add(t, idx);
+}
+void orc_itree_free(void *tv) { ITree *t = (ITree *)tv; free(t->n); free(t); }
+
 /* ---------------- HSP list post-processing (CORE/blast_hits.c) ---------------- */
 static int cmp_qoff(const void *v1, const void *v2)     /* :2037-2090 */
 {
