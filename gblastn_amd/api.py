@@ -54,6 +54,11 @@ HSP_DT = np.dtype([("oid", "<i4"), ("context", "<i4"), ("q_offset", "<i4"), ("q_
                    ("q_gapped_start", "<i4"), ("s_offset", "<i4"), ("s_end", "<i4"),
                    ("s_gapped_start", "<i4"), ("score", "<i4"), ("pad_", "<i4"),
                    ("evalue", "<f8")])
+TB_DT = np.dtype([("oid", "<i4"), ("context", "<i4"), ("q_offset", "<i4"), ("q_end", "<i4"),
+                  ("q_gapped_start", "<i4"), ("s_offset", "<i4"), ("s_end", "<i4"),
+                  ("s_gapped_start", "<i4"), ("score", "<i4"), ("pad_", "<i4"), ("evalue", "<f8"),
+                  ("num_ident", "<i4"), ("align_length", "<i4"), ("gaps", "<i4"), ("gap_opens", "<i4"),
+                  ("ops_first", "<i8"), ("ops_count", "<i4"), ("pad2_", "<i4"), ("bit_score", "<f8")])
 SEED_DT = np.dtype([("oid", "<i4"), ("s_off", "<i4"), ("q_off", "<i4"), ("pad_", "<i4")])
 IHIT_DT = np.dtype([("oid", "<i4"), ("q_off", "<i4"), ("s_off", "<i4"), ("q_start", "<i4"),
                     ("s_start", "<i4"), ("length", "<i4"), ("score", "<i4"), ("pad_", "<i4")])
@@ -74,7 +79,9 @@ EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_de
            "gbn_blastdb_total_length", "gbn_blastdb_max_length", "gbn_blastdb_stat_num_seqs",
            "gbn_blastdb_stat_length", "gbn_blastdb_title", "gbn_blastdb_volume_range", "gbn_blastdb_seq_length",
            "gbn_blastdb_get_ncbi2na", "gbn_blastdb_num_ambiguities", "gbn_blastdb_get_ambiguities",
-           "gbn_blastdb_get_blastna", "gbn_blastdb_load_shard"]
+           "gbn_blastdb_get_blastna", "gbn_blastdb_load_shard",
+           "gbn_traceback_new", "gbn_traceback_free", "gbn_traceback_run", "gbn_traceback_num_hsps", "gbn_traceback_hsps",
+           "gbn_traceback_ops", "gbn_traceback_op_lengths", "gbn_traceback_query_starts"]
 
 _LIB = None
 
@@ -131,6 +138,12 @@ def lib():
         for nm in ["gbn_collector_num_lists", "gbn_collector_num_hsps"]:
             getattr(L, nm).restype = C.c_int64; getattr(L, nm).argtypes = [C.c_void_p]
         for nm in ["gbn_collector_list_starts", "gbn_collector_list_queries", "gbn_collector_hsps"]:
+            getattr(L, nm).restype = C.c_void_p; getattr(L, nm).argtypes = [C.c_void_p]
+        L.gbn_traceback_new.argtypes = [C.POINTER(C.c_void_p)]
+        L.gbn_traceback_free.argtypes = [C.c_void_p]
+        L.gbn_traceback_run.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p]
+        L.gbn_traceback_num_hsps.restype = C.c_int64; L.gbn_traceback_num_hsps.argtypes = [C.c_void_p]
+        for nm in ["gbn_traceback_hsps", "gbn_traceback_ops", "gbn_traceback_op_lengths", "gbn_traceback_query_starts"]:
             getattr(L, nm).restype = C.c_void_p; getattr(L, nm).argtypes = [C.c_void_p]
         L.gbn_blastdb_open.argtypes = [C.POINTER(C.c_void_p), C.c_char_p]
         L.gbn_blastdb_close.argtypes = [C.c_void_p]
@@ -338,6 +351,44 @@ class BlastPrelimSearch:
             L.gbn_batch_free(self._b); self._b = None
         if self._r:
             L.gbn_results_free(self._r); self._r = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class BlastTracebackSearch:
+    """CBlastTracebackSearch analogue (API/traceback_stage.cpp:198-306): final alignments of the lists a
+    BlastHSPCollector kept for one query batch.  Host threads; the shard is read back from HBM."""
+
+    def __init__(self, prelim, seqsrc=None):
+        self._p = prelim
+        self._src = seqsrc or prelim.seqsrc
+        self._t = C.c_void_p()
+        _check(lib().gbn_traceback_new(C.byref(self._t)))
+
+    def run(self, hsps, list_starts, threads=0):
+        """hsps, list_starts: BlastHSPCollector.close()[0:2].  -> (records TB_DT, ops list per record, query_starts)"""
+        L = lib()
+        h = np.ascontiguousarray(hsps, dtype=HSP_DT); st = np.ascontiguousarray(list_starts, dtype="<i8")
+        _check(L.gbn_traceback_run(self._p._b, self._src._h, h.ctypes.data, st.ctypes.data, len(st) - 1, threads, self._t))
+        n = L.gbn_traceback_num_hsps(self._t)
+        nq = len(self._p._q)
+        qs = np.frombuffer(C.string_at(L.gbn_traceback_query_starts(self._t), (nq + 1) * 8), dtype="<i8").copy()
+        if n == 0:
+            return np.zeros(0, dtype=TB_DT), [], qs
+        rec = np.frombuffer(C.string_at(L.gbn_traceback_hsps(self._t), n * TB_DT.itemsize), dtype=TB_DT).copy()
+        nops = int(rec["ops_first"][-1] + rec["ops_count"][-1])
+        op = np.frombuffer(C.string_at(L.gbn_traceback_ops(self._t), nops), dtype=np.uint8)
+        ln = np.frombuffer(C.string_at(L.gbn_traceback_op_lengths(self._t), nops * 4), dtype="<i4")
+        ops = [[(int(op[k]), int(ln[k])) for k in range(int(r["ops_first"]), int(r["ops_first"] + r["ops_count"]))] for r in rec]
+        return rec, ops, qs
+
+    def close(self):
+        if self._t:
+            lib().gbn_traceback_free(self._t); self._t = None
 
     def __del__(self):
         try:

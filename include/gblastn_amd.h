@@ -255,7 +255,31 @@ int  gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag
  * CORE/blast_hspstream.c:136-209,232-300).  Host only.  With several shards, rank 0
  * writes the gathered records of all shards in ascending oid order. ---- */
 typedef struct GbnCollector GbnCollector;
-int32_t gbn_prelim_hitlist_size(int32_t hitlist_size);      /* min(2N, N+50), >= 10 */
+int32_t gbn_prelim_hitlist_size(int32_t hitlist_size);      /* ---- traceback stage (host): CORE/blast_traceback.c:336-790, :1375-1639 -------------------------------------
+ * Final alignments of the (subject, query) lists the collector kept: gapped extension with the final X-drop and
+ * an edit script (ALIGN_EX / greedy with traceback), list rules, identities, e-values, bit scores; per query the
+ * subjects in the order of the reference's results (best e-value, best score, oid), at most hitlist_size.
+ * The reference runs this stage on the CPU as well; in pipeline mode it is the consumer next to the GPU's
+ * preliminary stage (GB/work_thread.cpp:86-107). */
+typedef struct GbnTbHSP {
+    GbnHSP  hsp;                    /* final coordinates (context-relative query), score, e-value */
+    int32_t num_ident, align_length, gaps, gap_opens;
+    int64_t ops_first; int32_t ops_count, pad_;     /* edit script: ops[ops_first .. +ops_count): 0 gap in query, 3 aligned pair, 6 gap in subject */
+    double  bit_score;
+} GbnTbHSP;
+typedef struct GbnTraceback GbnTraceback;
+int  gbn_traceback_new(GbnTraceback **out);
+void gbn_traceback_free(GbnTraceback *t);
+/* hsps / list_start: as gbn_collector_hsps / gbn_collector_list_starts give them (nlists + 1 offsets) */
+int  gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int64_t *list_start, int64_t nlists,
+                       int32_t threads, GbnTraceback *out);
+int64_t gbn_traceback_num_hsps(const GbnTraceback *t);
+const GbnTbHSP *gbn_traceback_hsps(const GbnTraceback *t);
+const uint8_t *gbn_traceback_ops(const GbnTraceback *t);
+const int32_t *gbn_traceback_op_lengths(const GbnTraceback *t);
+const int64_t *gbn_traceback_query_starts(const GbnTraceback *t);      /* [num_queries + 1] offsets into hsps */
+
+/* min(2N, N+50), >= 10 */
 int  gbn_collector_new(GbnCollector **out, int32_t num_queries, int32_t hitlist_size);
 void gbn_collector_free(GbnCollector *c);
 /* records grouped by oid, each group sorted by score (what gbn_results_hsps yields) */
