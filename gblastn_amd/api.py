@@ -81,7 +81,9 @@ EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_de
            "gbn_blastdb_get_ncbi2na", "gbn_blastdb_num_ambiguities", "gbn_blastdb_get_ambiguities",
            "gbn_blastdb_get_blastna", "gbn_blastdb_load_shard",
            "gbn_traceback_new", "gbn_traceback_free", "gbn_traceback_run", "gbn_traceback_num_hsps", "gbn_traceback_hsps",
-           "gbn_traceback_ops", "gbn_traceback_op_lengths", "gbn_traceback_query_starts"]
+           "gbn_traceback_ops", "gbn_traceback_op_lengths", "gbn_traceback_query_starts",
+           "gbn_pipeline_new", "gbn_pipeline_free", "gbn_pipeline_submit", "gbn_pipeline_finish", "gbn_pipeline_next",
+           "gbn_pipeline_diagnostics"]
 
 _LIB = None
 
@@ -145,6 +147,14 @@ def lib():
         L.gbn_traceback_num_hsps.restype = C.c_int64; L.gbn_traceback_num_hsps.argtypes = [C.c_void_p]
         for nm in ["gbn_traceback_hsps", "gbn_traceback_ops", "gbn_traceback_op_lengths", "gbn_traceback_query_starts"]:
             getattr(L, nm).restype = C.c_void_p; getattr(L, nm).argtypes = [C.c_void_p]
+        L.gbn_pipeline_new.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GbnOptions), C.c_void_p, C.c_int32, C.c_int, C.c_int]
+        L.gbn_pipeline_free.argtypes = [C.c_void_p]
+        L.gbn_pipeline_submit.restype = C.c_int64
+        L.gbn_pipeline_submit.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int32), C.c_int32,
+                                          C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.gbn_pipeline_finish.argtypes = [C.c_void_p]
+        L.gbn_pipeline_next.argtypes = [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+        L.gbn_pipeline_diagnostics.argtypes = [C.c_void_p, C.POINTER(GbnDiagnostics)]
         L.gbn_blastdb_open.argtypes = [C.POINTER(C.c_void_p), C.c_char_p]
         L.gbn_blastdb_close.argtypes = [C.c_void_p]
         for nm in ["gbn_blastdb_num_volumes", "gbn_blastdb_num_seqs", "gbn_blastdb_max_length", "gbn_blastdb_stat_num_seqs"]:
@@ -374,21 +384,75 @@ class BlastTracebackSearch:
         L = lib()
         h = np.ascontiguousarray(hsps, dtype=HSP_DT); st = np.ascontiguousarray(list_starts, dtype="<i8")
         _check(L.gbn_traceback_run(self._p._b, self._src._h, h.ctypes.data, st.ctypes.data, len(st) - 1, threads, self._t))
-        n = L.gbn_traceback_num_hsps(self._t)
-        nq = len(self._p._q)
-        qs = np.frombuffer(C.string_at(L.gbn_traceback_query_starts(self._t), (nq + 1) * 8), dtype="<i8").copy()
-        if n == 0:
-            return np.zeros(0, dtype=TB_DT), [], qs
-        rec = np.frombuffer(C.string_at(L.gbn_traceback_hsps(self._t), n * TB_DT.itemsize), dtype=TB_DT).copy()
-        nops = int(rec["ops_first"][-1] + rec["ops_count"][-1])
-        op = np.frombuffer(C.string_at(L.gbn_traceback_ops(self._t), nops), dtype=np.uint8)
-        ln = np.frombuffer(C.string_at(L.gbn_traceback_op_lengths(self._t), nops * 4), dtype="<i4")
-        ops = [[(int(op[k]), int(ln[k])) for k in range(int(r["ops_first"]), int(r["ops_first"] + r["ops_count"]))] for r in rec]
-        return rec, ops, qs
+        return _read_traceback(self._t, len(self._p._q))
 
     def close(self):
         if self._t:
             lib().gbn_traceback_free(self._t); self._t = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _read_traceback(t, nq):
+    """(records TB_DT, ops per record, query_starts) of a GbnTraceback handle"""
+    L = lib()
+    n = L.gbn_traceback_num_hsps(t)
+    qs = np.frombuffer(C.string_at(L.gbn_traceback_query_starts(t), (nq + 1) * 8), dtype="<i8").copy()
+    if n == 0:
+        return np.zeros(0, dtype=TB_DT), [], qs
+    rec = np.frombuffer(C.string_at(L.gbn_traceback_hsps(t), n * TB_DT.itemsize), dtype=TB_DT).copy()
+    nops = int(rec["ops_first"][-1] + rec["ops_count"][-1])
+    op = np.frombuffer(C.string_at(L.gbn_traceback_ops(t), nops), dtype=np.uint8)
+    ln = np.frombuffer(C.string_at(L.gbn_traceback_op_lengths(t), nops * 4), dtype="<i4")
+    ops = [[(int(op[k]), int(ln[k])) for k in range(int(r["ops_first"]), int(r["ops_first"] + r["ops_count"]))] for r in rec]
+    return rec, ops, qs
+
+
+class SearchPipeline:
+    """The host pipeline of gblastn_amd_host.hpp (CSearchPipeline) through its C ABI: query batches in,
+    finished batches (traceback results) out in submission order; set-up, preliminary search and traceback
+    run on their own host threads and overlap."""
+
+    def __init__(self, options, seqsrc, trace_threads=2, traceback=True, overlap=True):
+        self._p = C.c_void_p()
+        self._src = seqsrc
+        self._nq = {}
+        _check(lib().gbn_pipeline_new(C.byref(self._p), C.byref(options), seqsrc._h, trace_threads, 1 if traceback else 0, 1 if overlap else 0))
+
+    def submit(self, queries, masks=None):
+        qs = queries if isinstance(queries, QuerySet) else QuerySet(queries)
+        masks = sorted(masks or [])
+        n = len(masks)
+        mq = (C.c_int32 * max(n, 1))(*[m[0] for m in masks]); mf = (C.c_int32 * max(n, 1))(*[m[1] for m in masks])
+        mt = (C.c_int32 * max(n, 1))(*[m[2] for m in masks])
+        i = lib().gbn_pipeline_submit(self._p, len(qs), qs.ptrs, qs.lens, n, mq, mf, mt)
+        if i < 0:
+            raise BlastError(lib().gbn_last_error().decode())
+        self._nq[i] = len(qs)
+        return i
+
+    def finish(self):
+        lib().gbn_pipeline_finish(self._p)
+
+    def next(self, read=True):
+        """-> (batch number, (records, ops, query_starts) or None, diagnostics) or None when nothing is left"""
+        L = lib()
+        i, tb, col = C.c_int64(), C.c_void_p(), C.c_void_p()
+        rc = L.gbn_pipeline_next(self._p, C.byref(i), C.byref(tb), C.byref(col))
+        if rc == 1:
+            return None
+        _check(rc)
+        d = GbnDiagnostics(); L.gbn_pipeline_diagnostics(self._p, C.byref(d))
+        res = _read_traceback(tb, self._nq[i.value]) if (read and tb) else None
+        return i.value, res, d
+
+    def close(self):
+        if self._p:
+            lib().gbn_pipeline_free(self._p); self._p = None
 
     def __del__(self):
         try:

@@ -255,7 +255,21 @@ int  gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag
  * CORE/blast_hspstream.c:136-209,232-300).  Host only.  With several shards, rank 0
  * writes the gathered records of all shards in ascending oid order. ---- */
 typedef struct GbnCollector GbnCollector;
-int32_t gbn_prelim_hitlist_size(int32_t hitlist_size);      /* ---- traceback stage (host): CORE/blast_traceback.c:336-790, :1375-1639 -------------------------------------
+int32_t gbn_prelim_hitlist_size(int32_t hitlist_size);      /* ---- host pipeline: set-up -> preliminary search -> traceback on their own threads --------------------------
+ * (GB/work_thread.cpp:60-156, APP/blastn_app.cpp:725-989 "Method2"; the C++ classes are in gblastn_amd_host.hpp).
+ * Query batches are submitted, finished batches come back in submission order. */
+typedef struct GbnPipeline GbnPipeline;
+int  gbn_pipeline_new(GbnPipeline **out, const GbnOptions *opt, GbnDb *db, int32_t trace_threads, int with_traceback, int overlap);
+void gbn_pipeline_free(GbnPipeline *p);
+int64_t gbn_pipeline_submit(GbnPipeline *p, int32_t nq, const uint8_t *const *seqs, const int32_t *lens,
+                            int32_t nmask, const int32_t *mask_query, const int32_t *mask_from, const int32_t *mask_to);
+void gbn_pipeline_finish(GbnPipeline *p);       /* no more batches will be submitted */
+struct GbnTraceback; struct GbnCollector;
+/* 0: a batch (its number in *id; results valid until the next call), 1: none left, < 0: that batch failed */
+int  gbn_pipeline_next(GbnPipeline *p, int64_t *id, const struct GbnTraceback **tb, const struct GbnCollector **col);
+int  gbn_pipeline_diagnostics(const GbnPipeline *p, GbnDiagnostics *d);
+
+/* ---- traceback stage (host): CORE/blast_traceback.c:336-790, :1375-1639 -------------------------------------
  * Final alignments of the (subject, query) lists the collector kept: gapped extension with the final X-drop and
  * an edit script (ALIGN_EX / greedy with traceback), list rules, identities, e-values, bit scores; per query the
  * subjects in the order of the reference's results (best e-value, best score, oid), at most hitlist_size.

@@ -91,3 +91,33 @@ def test_traceback_option_sweep():
         ora, _ = oracle_final(opt, queries, subjects)
         prod, *_ = product_final(opt, queries, subjects)
         assert compare(prod, ora) >= 3
+
+
+def test_pipeline_streams_batches_with_traceback_overlapped():
+    """C4 shape in small: 24 query batches streamed through the host pipeline (set-up, preliminary search on
+    the GPU, traceback consumer threads, all overlapped); every batch's rows equal the oracle's."""
+    nsub, slen, nbatch, per = 4, 120_000, 24, 6
+    db, queries, plants, subjects, opt = util.small_case(nsub, slen, nbatch * per, planted_fraction=0.6)
+    src = api.BlastSeqSrc.from_packed(subjects)
+    pipe = api.SearchPipeline(opt, src, trace_threads=3, traceback=True, overlap=True)
+    for k in range(nbatch):
+        assert pipe.submit(queries[k * per:(k + 1) * per]) == k
+    pipe.finish()
+    got = {}
+    while True:
+        r = pipe.next()
+        if r is None:
+            break
+        k, (rec, ops, qstarts), d = r
+        assert k == len(got)                                  # submission order
+        got[k] = (rec, ops)
+    assert len(got) == nbatch
+    pipe.close()
+    total = 0
+    for k in range(nbatch):
+        ora, _ = oracle_final(opt, queries[k * per:(k + 1) * per], subjects)
+        prod = {}
+        for r, o in zip(*got[k]):
+            prod.setdefault((int(r["context"]) // 2, int(r["oid"])), []).append((r, o))
+        total += compare(prod, ora)
+    assert total >= nbatch * per // 3
