@@ -1,15 +1,18 @@
-// blastn_prelim -- the reference's `blastn` command line for the stage this library replaces.
+// blastn_prelim -- the reference's `blastn` command line on this library's stages.
 //
 // Same flag spelling as G-BLASTN's blastn (c++/src/algo/blast/blastinput/cmdline_flags.cpp:40-230,
-// blast_args.cpp:2473-2550 for -use_gpu / -gpu_id / -mode / -query_list; shell/g.m.sh is the usage
-// the reference documents): FASTA queries against a BLAST nucleotide database (v4 .nal/.nin/.nsq),
-// default DUST soft masking, reference batch sizes (5 Mb megablast, 100 kb blastn:
-// API/blast_options_cxx / split_query "GetQueryBatchSize"), database volumes loaded as one HBM shard.
-// It stops where the preliminary search stops: the table it prints holds the score-only gapped HSPs
-// that survive the per-query top-N collector (CBlastPrelimSearch::Run + BlastHSPStream), not the
-// traceback alignments -- identities, mismatches and gap counts do not exist at this stage.
-// Everything goes through the C ABI of include/gblastn_amd.h; no CPU fallback (-use_gpu false is refused).
-#include "gblastn_amd.h"
+// blast_args.cpp:2473-2550 for -use_gpu / -gpu_id / -mode / -query_list / -trace_t_num; shell/g.m.sh is the
+// usage the reference documents): FASTA queries against a BLAST nucleotide database (v4 .nal/.nin/.nsq),
+// default DUST soft masking, reference batch sizes (5 Mb megablast, 100 kb blastn), database volumes loaded as
+// one HBM shard.  Written on the C++ host classes of include/gblastn_amd_host.hpp (CBlastPrelimSearch,
+// CBlastTracebackSearch, CSearchPipeline = the reference's query / prelim / traceback thread pipeline): -mode 1
+// runs a batch to completion before the next starts (APP/blastn_app.cpp Method1), -mode 0 / 2 overlap set-up,
+// GPU search and CPU traceback of consecutive batches (Method2 / Method3).
+// -outfmt 6 / 7: the twelve standard tabular columns of the FINAL alignments (traceback stage: identities,
+// mismatches, gap openings).  -stage prelim stops after the preliminary search and prints its score-only HSPs
+// (subject oid, coordinates, e-value, bit score, raw score, strand).
+// No CPU fallback (-use_gpu false is refused).
+#include "gblastn_amd_host.hpp"
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -70,8 +73,31 @@ void check(int rc, const char *what) { if (rc) die(std::string(what) + ": " + gb
 const char *kUsage =
     "usage: blastn_prelim -db NAME (-query FASTA | -query_list FILE) -use_gpu true [-gpu_id N] [-out FILE]\n"
     "       [-task megablast|blastn] [-word_size N] [-evalue X] [-reward N] [-penalty N] [-gapopen N]\n"
-    "       [-gapextend N] [-dust yes|no|'level window linker'] [-max_target_seqs N] [-outfmt 6|7] [-mode 1|2]\n"
-    "       [-num_threads N (ignored)] [-strand both]; environment BATCH_SIZE overrides the query batch size\n";
+    "       [-gapextend N] [-dust yes|no|'level window linker'] [-max_target_seqs N] [-outfmt 6|7] [-mode 0|1|2]\n"
+    "       [-stage traceback|prelim] [-trace_t_num N] [-num_threads N (ignored)] [-strand both]\n"
+    "       environment BATCH_SIZE overrides the query batch size\n";
+
+// e-value and bit score as the reference's formatter prints them (objtools/align_format/align_format_util.cpp:669-723)
+std::string evalue_string(double e)
+{
+    char b[64];
+    if (e < 1.0e-180) std::snprintf(b, sizeof b, "0.0");
+    else if (e < 1.0e-99) std::snprintf(b, sizeof b, "%2.0le", e);
+    else if (e < 0.0009) std::snprintf(b, sizeof b, "%3.0le", e);
+    else if (e < 0.1) std::snprintf(b, sizeof b, "%4.3lf", e);
+    else if (e < 1.0) std::snprintf(b, sizeof b, "%3.2lf", e);
+    else if (e < 10.0) std::snprintf(b, sizeof b, "%2.1lf", e);
+    else std::snprintf(b, sizeof b, "%5.0lf", e);
+    return b;
+}
+std::string bits_string(double s)
+{
+    char b[64];
+    if (s > 9999) std::snprintf(b, sizeof b, "%4.3le", s);
+    else if (s > 99.9) std::snprintf(b, sizeof b, "%4.0ld", (long)s);
+    else std::snprintf(b, sizeof b, "%4.1lf", s);
+    return b;
+}
 
 }  // namespace
 
@@ -137,13 +163,12 @@ int main(int argc, char **argv)
         }
     }
     const int outfmt = std::atoi(get("outfmt", "6").c_str());
-    if (outfmt != 6 && outfmt != 7) die("-outfmt 6 or 7 (tabular, preliminary HSPs)");
-    const bool pipelined = get("mode", "1") != "1";
-    if (get("strand", "both") != "both") die("-strand: only both strands are searched (the batch always holds the two contexts of a query)");
-    // accepted for command-line compatibility, without effect here: the host side has no per-thread OID chunks
-    // (-num_threads), and window masker databases (-window_masker_db, shell/g.m.sh) are not read
-    for (const char *k : {"window_masker_db", "window_masker_taxid"}) if (a.count(k)) std::fprintf(stderr, "blastn_prelim: -%s is ignored (only DUST masking is built in)\n", k);
-
+    if (outfmt != 6 && outfmt != 7) die("-outfmt 6 or 7 (tabular)");
+    const bool overlapped = get("mode", "1") != "1";                 // 0 and 2: the reference's pipelined methods
+    const std::string stage = get("stage", "traceback");
+    if (stage != "traceback" && stage != "prelim") die("-stage traceback or prelim");
+    const bool with_traceback = stage == "traceback";
+    const int trace_threads = std::max(1, std::atoi(get("trace_t_num", "2").c_str()));
     FILE *out = stdout;
     if (a.count("out")) { out = std::fopen(a["out"].c_str(), "w"); if (!out) die("cannot write " + a["out"]); }
 
@@ -151,7 +176,7 @@ int main(int argc, char **argv)
     // GetQueryBatchSize (blastinput/blast_input_aux.cpp:66-124), including its BATCH_SIZE override
     int64_t batch_bases = task == "megablast" ? 5000000 : 100000;
     if (const char *e = std::getenv("BATCH_SIZE")) batch_bases = std::max(1, std::atoi(e));
-    struct Batch { size_t first, count; GbnBatch *b = nullptr; GbnResults *r = nullptr; };
+    struct Batch { size_t first, count; };
     std::vector<Batch> batches;
     for (size_t i = 0; i < queries.size();) {
         Batch bt; bt.first = i; int64_t acc = 0;
@@ -159,30 +184,54 @@ int main(int argc, char **argv)
         bt.count = i - bt.first;
         batches.push_back(bt);
     }
-    auto build = [&](Batch &bt) {
-        std::vector<const uint8_t *> seqs; std::vector<int32_t> lens, mq, mf, mt;
+    auto make_batch = [&](const Batch &bt) {
+        gbn::SQueryBatch q;
         for (size_t k = 0; k < bt.count; k++) {
-            const Query &q = queries[bt.first + k];
-            seqs.push_back(q.seq.data()); lens.push_back((int32_t)q.seq.size());
-            if (dust && !q.seq.empty()) {
-                std::vector<int32_t> f(q.seq.size() / 2 + 2), t(f.size());
-                const int32_t n = gbn_dust_mask(q.seq.data(), (int32_t)q.seq.size(), dust_level, dust_window, dust_linker, f.data(), t.data(), (int32_t)f.size());
-                for (int32_t j = 0; j < n && j < (int32_t)f.size(); j++) { mq.push_back((int32_t)k); mf.push_back(f[(size_t)j]); mt.push_back(t[(size_t)j]); }
+            const Query &qq = queries[bt.first + k];
+            q.seqs.push_back(qq.seq);
+            if (dust && !qq.seq.empty()) {
+                std::vector<int32_t> f(qq.seq.size() / 2 + 2), t(f.size());
+                const int32_t n = gbn_dust_mask(qq.seq.data(), (int32_t)qq.seq.size(), dust_level, dust_window, dust_linker, f.data(), t.data(), (int32_t)f.size());
+                for (int32_t j = 0; j < n && j < (int32_t)f.size(); j++) q.masks.push_back(gbn::SQueryBatch::Mask{(int32_t)k, f[(size_t)j], t[(size_t)j]});
             }
         }
-        check(gbn_batch_new_masked(&bt.b, &opt, (int32_t)bt.count, seqs.data(), lens.data(), (int32_t)mq.size(), mq.data(), mf.data(), mt.data(), 1), "gbn_batch_new_masked");
-        check(gbn_results_new(&bt.r), "gbn_results_new");
+        return q;
     };
-    // rows of one batch: the collector keeps the best lists per query; printed per query, best first
-    auto emit = [&](Batch &bt) {
-        GbnCollector *col = nullptr;
-        check(gbn_collector_new(&col, (int32_t)bt.count, opt.hitlist_size), "gbn_collector_new");
-        check(gbn_collector_write(col, gbn_results_hsps(bt.r), gbn_results_num_hsps(bt.r)), "gbn_collector_write");
-        check(gbn_collector_close(col), "gbn_collector_close");
+    // the twelve standard columns of a final alignment: qseqid sseqid pident length mismatch gapopen qstart qend sstart send evalue bitscore
+    auto emit_final = [&](const Batch &bt, const gbn::CSearchPipeline::SWorkItem &it) {
+        const GbnTraceback *tb = it.traceback->Results();
+        const GbnTbHSP *h = gbn_traceback_hsps(tb); const int64_t *qs = gbn_traceback_query_starts(tb);
+        const GbnContext *ctx = gbn_batch_contexts(it.prelim->Batch());
+        for (size_t k = 0; k < bt.count; k++) {
+            const Query &q = queries[bt.first + k];
+            if (outfmt == 7) {
+                int64_t subjects = 0;
+                for (int64_t i = qs[k]; i < qs[k + 1]; i++) subjects += (i == qs[k] || h[i].hsp.oid != h[i - 1].hsp.oid);
+                std::fprintf(out, "# BLASTN (gblastn_amd)\n# Query: %s\n# Database: %s\n", q.id.c_str(), a["db"].c_str());
+                std::fprintf(out, "# Fields: query id, subject id, %% identity, alignment length, mismatches, gap opens, q. start, q. end, s. start, s. end, evalue, bit score\n# %lld hits found\n", (long long)(qs[k + 1] - qs[k]));
+                (void)subjects;
+            }
+            for (int64_t i = qs[k]; i < qs[k + 1]; i++) {
+                const GbnTbHSP &x = h[i]; const GbnHSP &p = x.hsp;
+                const bool minus = (p.context & 1) != 0;
+                const int32_t qlen = ctx[p.context].query_length;
+                // query always forward; a minus-strand hit shows the subject reversed
+                const int32_t qst = minus ? qlen - p.q_end + 1 : p.q_offset + 1, qen = minus ? qlen - p.q_offset : p.q_end;
+                const int32_t sst = minus ? p.s_end : p.s_offset + 1, sen = minus ? p.s_offset + 1 : p.s_end;
+                std::fprintf(out, "%s\tgnl|BL_ORD_ID|%d\t%.2f\t%d\t%d\t%d\t%d\t%d\t%d\t%d\t%s\t%s\n", q.id.c_str(), p.oid,
+                             x.align_length ? 100.0 * x.num_ident / x.align_length : 0.0, x.align_length,
+                             x.align_length - x.num_ident - x.gaps, x.gap_opens, qst, qen, sst, sen,
+                             evalue_string(p.evalue).c_str(), bits_string(x.bit_score).c_str());
+            }
+        }
+    };
+    // -stage prelim: the score-only HSPs the collector kept, per query best subject first
+    auto emit_prelim = [&](const Batch &bt, const gbn::CSearchPipeline::SWorkItem &it) {
+        const GbnCollector *col = it.stream->Get();
         const int64_t nl = gbn_collector_num_lists(col); const int64_t *st = gbn_collector_list_starts(col);
         const int32_t *lq = gbn_collector_list_queries(col); const GbnHSP *h = gbn_collector_hsps(col);
-        const GbnContext *ctx = gbn_batch_contexts(bt.b);
-        double lambda = 0, K = 0; gbn_batch_karlin_gapped(bt.b, &lambda, &K);
+        const GbnContext *ctx = gbn_batch_contexts(it.prelim->Batch());
+        double lambda = 0, K = 0; gbn_batch_karlin_gapped(it.prelim->Batch(), &lambda, &K);
         std::vector<std::vector<int64_t>> per((size_t)bt.count);
         for (int64_t l = 0; l < nl; l++) per[(size_t)lq[l]].push_back(l);
         for (size_t k = 0; k < bt.count; k++) {
@@ -202,7 +251,6 @@ int main(int argc, char **argv)
                     const GbnHSP &x = h[i];
                     const bool minus = (x.context & 1) != 0;
                     const int32_t qlen = ctx[x.context].query_length;
-                    // plus/minus presentation of the formatter: query always forward, subject reversed for minus hits
                     const int32_t qs = minus ? qlen - x.q_end + 1 : x.q_offset + 1, qe = minus ? qlen - x.q_offset : x.q_end;
                     const int32_t ss = minus ? x.s_end : x.s_offset + 1, se = minus ? x.s_offset + 1 : x.s_end;
                     const double bits = (lambda * x.score - std::log(K)) / std::log(2.0);
@@ -210,34 +258,29 @@ int main(int argc, char **argv)
                                  x.evalue, bits, x.score, minus ? "minus" : "plus");
                 }
         }
-        gbn_collector_free(col);
     };
 
     GbnDiagnostics diag; std::memset(&diag, 0, sizeof(diag));
-    if (!pipelined) {
-        for (auto &bt : batches) {
-            build(bt);
-            check(gbn_prelim_search(bt.b, shard, bt.r, &diag, 0, nullptr, nullptr), "gbn_prelim_search");
-            emit(bt);
-            gbn_batch_free(bt.b); gbn_results_free(bt.r);
+    try {
+        gbn::CBlastSeqSrc src(shard, false);
+        gbn::CSearchPipeline pipe(opt, src, trace_threads, with_traceback, overlapped);
+        // batches enter a few ahead of the results coming out (a batch holds its lookup tables in HBM until printed)
+        size_t submitted = 0, printed = 0;
+        const size_t ahead = overlapped ? 4 : 1;
+        while (printed < batches.size()) {
+            while (submitted < batches.size() && submitted < printed + ahead) { pipe.Submit(make_batch(batches[submitted])); submitted++; }
+            if (submitted == batches.size()) pipe.Finish();
+            gbn::CSearchPipeline::TItem it = pipe.Next();
+            if (!it) die("the pipeline ended early");
+            if (it->status != GBN_OK) die(it->error);
+            const GbnDiagnostics &d = it->prelim->diagnostics;
+            diag.subject_bases_scanned += d.subject_bases_scanned; diag.seeds += d.seeds; diag.gapped_extensions += d.gapped_extensions; diag.total_ms += d.total_ms;
+            if (with_traceback) emit_final(batches[printed], *it); else emit_prelim(batches[printed], *it);
+            printed++;
         }
-    } else {
-        // -mode 2: the extension stages of batch k run underneath the scan of batch k+1
-        // ... and batch k+1 is set up (host work + lookup structures on the device) on another thread meanwhile
-        Batch *prev = nullptr;
-        std::future<void> next;
-        build(batches[0]);
-        for (size_t i = 0; i < batches.size(); i++) {
-            Batch &bt = batches[i];
-            if (i + 1 < batches.size()) next = std::async(std::launch::async, [&, i] { build(batches[i + 1]); });
-            check(gbn_prelim_search_begin(bt.b, shard, bt.r, &diag, nullptr, nullptr), "gbn_prelim_search_begin");
-            if (prev) { check(gbn_prelim_search_end(prev->r), "gbn_prelim_search_end"); emit(*prev); gbn_batch_free(prev->b); gbn_results_free(prev->r); }
-            prev = &bt;
-            if (i + 1 < batches.size()) next.get();
-        }
-        if (prev) { check(gbn_prelim_search_end(prev->r), "gbn_prelim_search_end"); emit(*prev); gbn_batch_free(prev->b); gbn_results_free(prev->r); }
-    }
-    std::fprintf(stderr, "blastn_prelim: %zu queries in %zu batches, %lld subject bases scanned, %lld seeds, %lld gapped extensions, %.1f ms\n",
+        pipe.Close();
+    } catch (const gbn::CBlastException &e) { die(e.what()); }
+    std::fprintf(stderr, "blastn_prelim: %zu queries in %zu batches, %lld subject bases scanned, %lld seeds, %lld gapped extensions, %.1f ms in the preliminary stage\n",
                  queries.size(), batches.size(), (long long)diag.subject_bases_scanned, (long long)diag.seeds,
                  (long long)diag.gapped_extensions, diag.total_ms);
     if (out != stdout) std::fclose(out);

@@ -1,6 +1,8 @@
-"""blastn_prelim: the reference's blastn command line for the preliminary stage (C++ over the C ABI).
-CPU: it is built and refuses what it cannot do.  GPU: FASTA queries against the reference's own `seqn`
-test database give exactly the rows the library calls give (same masks, same statistics, same collector)."""
+"""blastn_prelim: the reference's blastn command line on this library's stages (C++ host classes over the C ABI).
+CPU: it is built and refuses what it cannot do.  GPU: FASTA queries against the reference's own `seqn` test
+database -- the twelve standard tabular columns of the final alignments equal the rows the ORACLE produces
+(its DUST, preliminary search, collector and traceback), in all three -mode settings; `-stage prelim` gives
+exactly the rows the library calls give (a consistency property, not oracle parity)."""
 import os
 import subprocess
 import numpy as np
@@ -51,7 +53,7 @@ def test_cli_rows_equal_the_library_calls(tmp_path, task, mode, batch):
     env = dict(os.environ)
     if batch:
         env["BATCH_SIZE"] = batch
-    p = subprocess.run([CLI, "-db", DB, "-query", str(fa), "-task", task, "-use_gpu", "true", "-mode", mode,
+    p = subprocess.run([CLI, "-db", DB, "-query", str(fa), "-task", task, "-use_gpu", "true", "-mode", mode, "-stage", "prelim",
                         "-evalue", "1e-3", "-max_target_seqs", "5", "-out", str(out)], capture_output=True, text=True, timeout=600, env=env)
     if batch:
         assert " in 1 batches" not in p.stderr and "batches" in p.stderr, p.stderr
@@ -90,3 +92,91 @@ def test_cli_rows_equal_the_library_calls(tmp_path, task, mode, batch):
     assert f(ps._b, C.byref(lam), C.byref(K)) == 0 and lam.value > 0 and K.value > 0
     for r in rows:
         assert abs(float(r[7]) - (lam.value * int(r[8]) - math.log(K.value)) / math.log(2.0)) < 0.051
+
+
+def _evalue_string(e):
+    """objtools/align_format/align_format_util.cpp:694-713"""
+    if e < 1.0e-180: return "0.0"
+    if e < 1.0e-99: return "%2.0e" % e
+    if e < 0.0009: return "%3.0e" % e
+    if e < 0.1: return "%4.3f" % e
+    if e < 1.0: return "%3.2f" % e
+    if e < 10.0: return "%2.1f" % e
+    return "%5.0f" % e
+
+
+def _bits_string(s):
+    if s > 9999: return "%4.3e" % s
+    if s > 99.9: return "%4d" % int(s)
+    return "%4.1f" % s
+
+
+def _oracle_rows(db, qs, task, evalue, hitlist):
+    """the whole search on the CPU oracle: DUST masks, every subject, collector, traceback, result order"""
+    from oracle import orc
+    from tests import util
+    seqs = [s for _, s in qs]
+    masks = []
+    for i, s in enumerate(seqs):
+        masks += [(i, f, t) for f, t in orc.dust(s)]
+    gopt = api.default_options(task, db_length=db.total_length, db_num_seqs=db.num_seqs, evalue=evalue, hitlist_size=hitlist)
+    S = orc.Search(util.oracle_options(gopt), seqs, masks=masks)
+    col = orc.Collector(len(seqs), hitlist)
+    subj = {}
+    for oid in range(db.num_seqs):
+        packed, n = db.ncbi2na(oid)
+        r = S.subject(np.concatenate([packed, np.zeros(16, np.uint8)]), n)
+        if len(r["hsps"]):
+            col.write(oid, [dict(zip(r["hsps"].dtype.names, x)) for x in r["hsps"]])
+            subj[oid] = orc.unpack_ncbi2na(packed, n)
+    per_query = {}
+    for oid, q, hs in col.close():
+        fin = S.traceback(subj[oid], [dict(zip(orc.Collector.FIELDS, h)) for h in hs])
+        if fin:
+            per_query.setdefault(q, []).append((oid, fin))
+    rows = []
+    ctxs = S.contexts
+    for q in sorted(per_query):
+        lists = per_query[q]
+        # CORE/blast_hits.c:2757-2788: best e-value (exact ties broken by score, then higher oid first)
+        lists.sort(key=lambda l: (min(f["evalue"] for f in l[1]), -l[1][0]["score"], -l[0]))
+        for oid, fin in lists[:hitlist]:
+            for f in fin:
+                minus = f["context"] & 1
+                qlen = ctxs[f["context"]].query_length
+                qs_, qe_ = (qlen - f["q_end"] + 1, qlen - f["q_offset"]) if minus else (f["q_offset"] + 1, f["q_end"])
+                ss_, se_ = (f["s_end"], f["s_offset"] + 1) if minus else (f["s_offset"] + 1, f["s_end"])
+                al = f["align_length"]
+                rows.append([qs[q][0], "gnl|BL_ORD_ID|%d" % oid, "%.2f" % (100.0 * f["num_ident"] / al), str(al),
+                             str(al - f["num_ident"] - f["gaps"]), str(f["gap_opens"]), str(qs_), str(qe_), str(ss_), str(se_),
+                             _evalue_string(f["evalue"]), _bits_string(f["bit_score"])])
+    return rows
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,mode,batch", [("megablast", "1", None), ("blastn", "1", None), ("megablast", "2", "900"),
+                                             ("blastn", "0", "900")])
+def test_cli_final_rows_equal_the_oracle(tmp_path, task, mode, batch):
+    db = api.BlastDb(DB)
+    qs = _queries(db)
+    fa = tmp_path / "q.fa"
+    fa.write_text("".join(">%s some description\n%s\n" % (n, "".join(IUPAC[int(x)] for x in s)) for n, s in qs))
+    out = tmp_path / "out.tsv"
+    env = dict(os.environ)
+    if batch:
+        env["BATCH_SIZE"] = batch
+    p = subprocess.run([CLI, "-db", DB, "-query", str(fa), "-task", task, "-use_gpu", "true", "-mode", mode,
+                        "-evalue", "1e-3", "-max_target_seqs", "5", "-out", str(out), "-trace_t_num", "3"],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    got = [l.split("\t") for l in out.read_text().splitlines()]
+    want = _oracle_rows(db, qs, task, 1e-3, 5)
+    assert got == want
+    assert len(got) >= 4 and all(len(r) == 12 for r in got)
+    first = {}
+    for r in got:
+        first.setdefault(r[0], r)
+    # (subject 1500 carries ambiguity codes: the query keeps them, the 2-bit shard does not)
+    assert first["exact_1500"][1] == "gnl|BL_ORD_ID|1500" and float(first["exact_1500"][2]) > 99.0 and first["exact_1500"][5] == "0"
+    assert first["mutated_10"][1] == "gnl|BL_ORD_ID|10" and int(first["mutated_10"][5]) >= 1 and int(first["mutated_10"][4]) >= 8
+    assert first["revcomp_777"][1] == "gnl|BL_ORD_ID|777" and int(first["revcomp_777"][8]) > int(first["revcomp_777"][9])
