@@ -36,8 +36,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=160, help="timed passes (default: > 2 s of timed region on C2)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["C2", "C3"], default="C2",
-                    help="C2 (the metric's config): megablast W=28 vs 50 Gbp; C3: blastn W=11 vs 5 Gbp, 100 kb batches")
+    ap.add_argument("--workload", choices=["C2", "C3", "C4"], default="C2",
+                    help="C2 (the metric's config): megablast W=28 vs 50 Gbp; C3: blastn W=11 vs 5 Gbp, 100 kb batches; "
+                         "C4: 100k queries streamed in 5 Mb batches through the host pipeline, CPU traceback overlapped with the GPU stages")
+    ap.add_argument("--trace-threads", type=int, default=4, help="C4: traceback consumer threads")
+    ap.add_argument("--no-traceback", action="store_true", help="C4 diagnostics: the pipeline without its traceback stage")
     ap.add_argument("--subjects", type=int, default=None, help="subjects per GPU shard")
     ap.add_argument("--subject-len", type=int, default=1_000_000)
     ap.add_argument("--queries", type=int, default=10_000)
@@ -53,10 +56,12 @@ def parse():
     a = ap.parse_args()
     if a.workload == "C3" and "--steps" not in " ".join(sys.argv):
         a.steps = 16
+    if a.workload == "C4" and "--steps" not in " ".join(sys.argv):
+        a.steps = 20                                    # 100,000 queries = 20 batches of 5,000
     if a.subjects is None:
-        a.subjects = 50_000 if a.workload == "C2" else 5_000
+        a.subjects = 5_000 if a.workload == "C3" else 50_000
     if a.batch_queries is None:
-        a.batch_queries = 5_000 if a.workload == "C2" else 100     # 5 Mb megablast / 100 kb blastn batches
+        a.batch_queries = 100 if a.workload == "C3" else 5_000     # 5 Mb megablast / 100 kb blastn batches
     return a
 
 
@@ -104,13 +109,16 @@ def main():
                 self._cache[g] = layouts[g // nsub].subject_bases(g % nsub)
             return self._cache[g]
     queries, plants = synth.make_queries(args.queries, AnyShard())
-    task = "megablast" if args.workload == "C2" else "blastn"
+    task = "blastn" if args.workload == "C3" else "megablast"
     opt = api.default_options(task, db_length=total_bases_global, db_num_seqs=world * nsub)
     nbatch = (len(queries) + args.batch_queries - 1) // args.batch_queries
     npass_config = nbatch
     nbatch = min(nbatch, max(args.steps, args.warmup, 1))       # only the batches the run touches
     # query batches as the caller would hand them over: one contiguous BLASTNA array per query
     qsets = [api.QuerySet(queries[i * args.batch_queries:(i + 1) * args.batch_queries]) for i in range(nbatch)]
+
+    if args.workload == "C4":
+        return bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, total_bases_global, nsub, slen, queries)
 
     def make(k):
         """set-up of the query batch of pass k from scratch: concatenation, Karlin-Altschul parameters,
@@ -305,6 +313,63 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, total_bases_global, nsub, slen, queries):
+    """C4: query batches streamed through the C++ host pipeline (gblastn_amd_host.hpp CSearchPipeline behind its C
+    ABI): set-up thread, preliminary search on the GPU, `--trace-threads` traceback consumers -- a step is one
+    5 Mb batch from the caller's arrays to its final alignments (edit scripts, identities, e-values)."""
+    def run(count):
+        pipe = api.SearchPipeline(opt, src, trace_threads=args.trace_threads, traceback=not args.no_traceback, overlap=not args.no_overlap)
+        sub = got = 0; nfinal = 0; diags = []
+        while got < count:
+            while sub < count and sub < got + 8:
+                pipe.submit(qsets[sub % nbatch]); sub += 1
+            if sub == count:
+                pipe.finish()
+            k, res, d = pipe.next(read=False)
+            diags.append(d); got += 1
+        pipe.close()
+        return diags
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    run(max(args.warmup, 2))
+    sync(); t0 = time.perf_counter()
+    diags = run(args.steps)
+    sync(); elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    # final alignments of one batch, counted once outside the timed region
+    pipe = api.SearchPipeline(opt, src, trace_threads=args.trace_threads, traceback=True, overlap=False)
+    pipe.submit(qsets[0]); pipe.finish(); _, res, _ = pipe.next(); pipe.close()
+    rec = res[0]
+    scan_ms = sum(d.scan_kernel_ms for d in diags); launches = sum(d.scan_launches for d in diags)
+    bin_ms = sum(d.bin_kernel_ms for d in diags); probe_ms = sum(d.probe_kernel_ms for d in diags); rare_ms = sum(d.rare_kernel_ms for d in diags)
+    scanned = sum(d.subject_bases_scanned for d in diags)
+    algo = 0.25 * scanned
+    if rank == 0:
+        line = {
+            "metric": "subject Gbp scanned/sec (megablast, query batches streamed through preliminary search + overlapped CPU traceback)",
+            "value": total_bases_global * args.steps / elapsed / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 (2-bit packed bases, int32 scores)", "data": "synthetic",
+            "config": {"workload": "C4: %d queries streamed in %d batches of %d x 1 kb (cycling over %d distinct queries) vs %.1f Gbp per GPU, megablast W=%d, traceback on %d host threads"
+                                   % (args.steps * args.batch_queries, args.steps, args.batch_queries, len(queries), nsub * slen / 1e9, opt.word_size, args.trace_threads),
+                       "pipeline": "set-up thread -> preliminary search (GPU) -> traceback threads; overlapped" if not args.no_overlap else "one batch at a time",
+                       "final_hsps_per_batch": int(len(rec)), "final_identity_mean": float((rec["num_ident"] / np.maximum(rec["align_length"], 1)).mean()) if len(rec) else None,
+                       "gapped_alignments_per_batch": int((rec["gaps"] > 0).sum()) if len(rec) else 0},
+            "roofline": {"bound": "hbm", "kernel": "scan_bin_kernel_s17", "achieved": algo / (bin_ms * 1e-3) / 1e9 if bin_ms else 0.0, "peak": 8000.0, "unit": "GB/s",
+                         "frac": (algo / (bin_ms * 1e-3) / 1e9 / 8000.0) if bin_ms else 0.0, "traffic": None,
+                         "avg_launch_ms": bin_ms / max(launches, 1), "launches": launches,
+                         "scan_stage": {"avg_ms": scan_ms / max(launches, 1), "avg_ms_by_kernel": [bin_ms / max(launches, 1), probe_ms / max(launches, 1), rare_ms / max(launches, 1)]}},
+            "cpu_baseline": None,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier(); dist.destroy_process_group()
 
 
 def _cpu_worker(job):

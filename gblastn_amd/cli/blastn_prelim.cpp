@@ -266,7 +266,7 @@ int main(int argc, char **argv)
         gbn::CSearchPipeline pipe(opt, src, trace_threads, with_traceback, overlapped);
         // batches enter a few ahead of the results coming out (a batch holds its lookup tables in HBM until printed)
         size_t submitted = 0, printed = 0;
-        const size_t ahead = overlapped ? 4 : 1;
+        const size_t ahead = overlapped ? 8 : 1;
         while (printed < batches.size()) {
             while (submitted < batches.size() && submitted < printed + ahead) { pipe.Submit(make_batch(batches[submitted])); submitted++; }
             if (submitted == batches.size()) pipe.Finish();

@@ -33,6 +33,8 @@ hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st);
 hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st);
 hipError_t launch_synth_fill(void *dev, int64_t nbytes, uint64_t seed, hipStream_t st);
+hipError_t launch_gather_bytes(const uint8_t *src, const int64_t *src_off, const int64_t *dst_off, const int32_t *nbytes,
+                               int32_t n, uint8_t *dst, hipStream_t st);
 hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
                           const uint32_t *vin, uint32_t *vout, int64_t n, int end_bit, hipStream_t st);
 
@@ -1058,6 +1060,35 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     }
     if (diag) diag->host_stage_ms += ms_since(t_stage);
     trace_mark("gapped: host replay done");
+    return GBN_OK;
+}
+
+// Stretches [src_off, src_off + nbytes) of the shard's packed bytes, back to back in `out` (traceback stage): one
+// gather kernel and one copy on a stream of its own, next to whatever the search streams are doing.
+int gather_shard_bytes(const GbnDb &db, const std::vector<int64_t> &src_off, const std::vector<int32_t> &nbytes, std::vector<uint8_t> &out)
+{
+    static std::mutex mu; static hipStream_t st = nullptr;
+    int rc = ensure_init();
+    if (rc) return rc;
+    use_engine_device();
+    const int32_t n = (int32_t)src_off.size();
+    std::vector<int64_t> dst_off((size_t)n); int64_t total = 0;
+    for (int32_t i = 0; i < n; i++) { dst_off[(size_t)i] = total; total += nbytes[(size_t)i]; }
+    out.resize((size_t)total);
+    if (n == 0) return GBN_OK;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!st) HIPCHK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    int64_t *d_so = nullptr, *d_do = nullptr; int32_t *d_nb = nullptr; uint8_t *d_out = nullptr;
+    auto cleanup = [&]() { dev_free(d_so); dev_free(d_do); dev_free(d_nb); dev_free(d_out); };
+    if ((rc = dev_alloc(d_so, (size_t)n)) || (rc = dev_alloc(d_do, (size_t)n)) || (rc = dev_alloc(d_nb, (size_t)n)) || (rc = dev_alloc(d_out, (size_t)total))) { cleanup(); return rc; }
+    hipError_t e = hipMemcpyAsync(d_so, src_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_do, dst_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_nb, nbytes.data(), (size_t)n * 4, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = launch_gather_bytes(db.d_packed, d_so, d_do, d_nb, n, d_out, st);
+    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, (size_t)total, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    cleanup();
+    if (e != hipSuccess) { set_error(std::string("gather_shard_bytes: ") + hipGetErrorString(e)); return GBN_ERR_HIP; }
     return GBN_OK;
 }
 

@@ -94,4 +94,5 @@ int  build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq,
 void fill_lookup_host(GbnBatch &b);     // the host-side table builder (host-only set-up, GBN_HOST_LOOKUP=1)
 int  upload_batch(GbnBatch &b);
 void free_device_batch(DeviceBatch *d);
+int  gather_shard_bytes(const GbnDb &db, const std::vector<int64_t> &src_off, const std::vector<int32_t> &nbytes, std::vector<uint8_t> &out);
 }

@@ -1118,6 +1118,14 @@ extern "C" __global__ void synth_fill_kernel(uint64_t *out, int64_t nwords, uint
     }
 }
 
+// stretches of the shard packed back to back (the traceback stage reads back what its extensions can reach:
+// one kernel and one copy per query batch instead of a copy per subject)
+extern "C" __global__ void gather_bytes_kernel(const uint8_t *src, const int64_t *src_off, const int64_t *dst_off, const int32_t *nbytes, uint8_t *dst)
+{
+    const int64_t so = src_off[blockIdx.x], d0 = dst_off[blockIdx.x];
+    for (int32_t i = threadIdx.x; i < nbytes[blockIdx.x]; i += blockDim.x) dst[d0 + i] = src[so + i];
+}
+
 // ---------------------------------------------------------------------------
 // host launchers (thin; the C ABI in abi.cpp re-exports them)
 // ---------------------------------------------------------------------------
@@ -1178,6 +1186,14 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
     }
     GbnGapParams r = p; r.redo_only = 1;
     hipLaunchKernelGGL(dynprog_kernel, dim3(blocks), dim3(64), 0, st, r);
+    return hipGetLastError();
+}
+
+hipError_t launch_gather_bytes(const uint8_t *src, const int64_t *src_off, const int64_t *dst_off, const int32_t *nbytes,
+                               int32_t n, uint8_t *dst, hipStream_t st)
+{
+    if (n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(gather_bytes_kernel, dim3((unsigned)n), dim3(256), 0, st, src, src_off, dst_off, nbytes, dst);
     return hipGetLastError();
 }
 

@@ -173,13 +173,13 @@ int32_t greedy_half(const uint8_t *a, int32_t la, const uint8_t *b, int32_t lb, 
     int32_t run = run_of_matches(a, b, la, lb, 0, 0, backwards);
     used_a = used_b = run;
     if (run == la || run == lb) { append_op(path, kSub, run); return 0; }
-    // furthest subject offset per (distance, diagonal); the rows of distance 0 and 1 span all diagonals, later
-    // ones the diagonals their distance can reach plus two either side (the reference's allocation, :677-683)
+    // furthest subject offset per (distance, diagonal); a row spans the diagonals its distance can reach plus two
+    // either side (the reference's allocation for the rows it adds, :677-683; its first two rows span everything)
     std::vector<int32_t> store; struct RowRef { size_t at; int32_t lo; };
     std::vector<RowRef> rows;
     auto new_row = [&](int32_t lo, int32_t n) { rows.push_back(RowRef{store.size(), lo}); store.resize(store.size() + (size_t)n, 0); };
     auto at = [&](int32_t d, int32_t k) -> int32_t & { return store[rows[(size_t)d].at + (size_t)(k - rows[(size_t)d].lo)]; };
-    new_row(0, 2 * dmax + 8); new_row(0, 2 * dmax + 8);
+    new_row(origin - 2, 7); new_row(origin - 3, 9);
     std::vector<int32_t> top((size_t)(dmax + 2 + lookback), 0);     // best score per distance, `lookback` zeros in front
     auto best_at = [&](int32_t d) -> int32_t & { return top[(size_t)(d + lookback)]; };
     at(0, origin) = run;
@@ -572,8 +572,10 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
     if (!batch || !db || !out || nlists < 0 || (nlists > 0 && (!hsps || !list_start))) { set_error("gbn_traceback_run: bad argument"); return GBN_ERR_ARG; }
     out->hsps.clear(); out->op.clear(); out->op_len.clear(); out->query_start.assign((size_t)batch->nq + 1, 0);
     if (nlists == 0) return GBN_OK;
-    // subjects that have lists, each fetched once
-    struct Work { int32_t local; int64_t first_list, end_list; std::vector<uint8_t> bases; };
+    trace_mark("traceback: starts");
+    // subjects that have lists, each fetched once -- of a long subject only the stretch the extensions can reach
+    // (AdjustSubjectRange: query length + 3000 either side of an HSP) is read back and unpacked
+    struct Work { int32_t local; int64_t first_list, end_list; int32_t lo; std::vector<uint8_t> bases; };
     std::vector<Work> work;
     for (int64_t l = 0; l < nlists;) {
         const int32_t oid = hsps[list_start[l]].oid;
@@ -581,25 +583,39 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
         while (e < nlists && hsps[list_start[e]].oid == oid) e++;
         const int32_t local = oid - db->first_oid;
         if (local < 0 || local >= db->num_seqs) { set_error("gbn_traceback_run: subject id outside this shard"); return GBN_ERR_ARG; }
-        work.push_back(Work{local, l, e, {}});
+        work.push_back(Work{local, l, e, 0, {}});
         l = e;
     }
     {
-        int dev = 0; (void)hipGetDevice(&dev);
-        std::vector<uint8_t> packed;
+        std::vector<int64_t> src_off; std::vector<int32_t> nbytes; std::vector<int32_t> his;
         for (Work &w : work) {
             const int32_t len = db->len[(size_t)w.local];
-            packed.resize((size_t)(len + 3) / 4);
-            hipPointerAttribute_t attr;
-            const uint8_t *src = db->d_packed + db->byte_off[(size_t)w.local];
-            if (hipPointerGetAttributes(&attr, src) == hipSuccess && attr.type == hipMemoryTypeDevice) {
-                if (hipMemcpy(packed.data(), src, packed.size(), hipMemcpyDeviceToHost) != hipSuccess) { set_error("gbn_traceback_run: reading a subject back failed"); return GBN_ERR_HIP; }
-            } else {
-                (void)hipGetLastError();
-                std::memcpy(packed.data(), src, packed.size());
+            int32_t lo = 0, hi = len;
+            if (len >= 90000) {
+                lo = len; hi = 0;
+                for (int64_t i = list_start[w.first_list]; i < list_start[w.end_list]; i++) {
+                    const int32_t reach = batch->ctx[(size_t)hsps[i].context].query_length + 3000 + 64;
+                    lo = std::min(lo, std::max(0, std::min(hsps[i].s_offset, hsps[i].s_gapped_start) - reach));
+                    hi = std::max(hi, std::min(len, std::max(hsps[i].s_end, hsps[i].s_gapped_start) + reach));
+                }
+                lo &= ~3;
             }
-            w.bases.resize((size_t)len + 4);
-            for (int32_t i = 0; i < len; i++) w.bases[(size_t)i] = (packed[(size_t)i >> 2] >> (2 * (3 - (i & 3)))) & 3;
+            w.lo = lo; his.push_back(hi);
+            src_off.push_back(db->byte_off[(size_t)w.local] + (lo >> 2));
+            nbytes.push_back((hi - lo + 3) / 4);
+        }
+        std::vector<uint8_t> packed;
+        const int rc = gather_shard_bytes(*db, src_off, nbytes, packed);
+        if (rc != GBN_OK) return rc;
+        trace_mark("traceback: subject stretches read back");
+        size_t at = 0;
+        for (size_t k = 0; k < work.size(); k++) {
+            Work &w = work[k];
+            const int32_t n = his[k] - w.lo; const uint8_t *p = packed.data() + at;
+            w.bases.resize(((size_t)n + 3) / 4 * 4 + 4);
+            uint8_t *o = w.bases.data();
+            for (int32_t i = 0; i < (n + 3) / 4; i++, o += 4) { const uint8_t c = p[i]; o[0] = c >> 6; o[1] = (c >> 4) & 3; o[2] = (c >> 2) & 3; o[3] = c & 3; }
+            at += (size_t)nbytes[k];
         }
     }
     struct Done { int32_t oid, query; std::vector<Item> items; };
@@ -612,7 +628,8 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
             for (int64_t l = w.first_list; l < w.end_list; l++) {
                 const GbnHSP *first = hsps + list_start[l]; const size_t n = (size_t)(list_start[l + 1] - list_start[l]);
                 Done d; d.oid = first->oid; d.query = first->context / 2;
-                const int rc = traceback_list(*batch, w.bases.data(), db->len[(size_t)w.local], first, n, d.items);
+                // (base 0 of the subject sits at w.bases - w.lo; nothing outside the stretch read back is touched)
+                const int rc = traceback_list(*batch, w.bases.data() - w.lo, db->len[(size_t)w.local], first, n, d.items);
                 if (rc != GBN_OK) { std::lock_guard<std::mutex> lk(err_mu); failed = rc; err = gbn_last_error(); return; }
                 for (Item &it : d.items) it.h.oid = d.oid;
                 if (!d.items.empty()) per_work[k].push_back(std::move(d));
@@ -624,6 +641,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
     if (nthreads <= 1) body();
     else { std::vector<std::thread> pool; for (unsigned t = 0; t < nthreads; t++) pool.emplace_back(body); for (auto &th : pool) th.join(); }
     if (failed != GBN_OK) { set_error(err); return failed; }
+    trace_mark("traceback: lists aligned");
     // per query: subjects by (best e-value, best score, oid descending), at most hitlist_size of them
     std::vector<std::vector<Done *>> by_query((size_t)batch->nq);
     for (auto &v : per_work) for (Done &d : v) by_query[(size_t)d.query].push_back(&d);
@@ -652,6 +670,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
         }
     }
     out->query_start[(size_t)batch->nq] = (int64_t)out->hsps.size();
+    trace_mark("traceback: done");
     return GBN_OK;
 }
 

@@ -118,9 +118,11 @@ public:
     CSearchPipeline(const GbnOptions &opt, const CBlastSeqSrc &src, int trace_threads, bool with_traceback, bool overlap)
         : opt_(opt), src_(src), traceback_(with_traceback), overlap_(overlap)
     {
-        setup_ = std::thread([this] { SetupThread(); });
+        for (int i = 0; i < kSetupThreads; i++) setup_.emplace_back([this] { SetupThread(); });
         prelim_ = std::thread([this] { PrelimSearchThread(); });
-        for (int i = 0; i < std::max(1, trace_threads); i++) trace_.emplace_back([this] { TraceBackThread(); });
+        // two batches in the traceback stage at a time, each on half of the traceback threads
+        inner_threads_ = std::max(1, (trace_threads + 1) / 2);
+        for (int i = 0; i < (trace_threads > 1 ? 2 : 1); i++) trace_.emplace_back([this] { TraceBackThread(); });
     }
     ~CSearchPipeline() { Close(); }
     // a query batch enters the pipeline; returns its number
@@ -145,7 +147,8 @@ public:
     }
     void Close() {
         { std::unique_lock<std::mutex> lk(mu_); no_more_ = true; closing_ = true; cv_.notify_all(); }
-        if (setup_.joinable()) setup_.join();
+        for (auto &t : setup_) if (t.joinable()) t.join();
+        setup_.clear();
         if (prelim_.joinable()) prelim_.join();
         for (auto &t : trace_) if (t.joinable()) t.join();
         trace_.clear();
@@ -153,28 +156,33 @@ public:
 private:
     GbnOptions opt_; const CBlastSeqSrc &src_; bool traceback_, overlap_;
     std::mutex mu_; std::condition_variable cv_;
-    std::deque<TItem> query_queue_, prelim_queue_, trace_queue_; std::map<int64_t, TItem> done_;
-    int64_t submitted_ = 0, delivered_ = 0; bool no_more_ = false, closing_ = false, setup_done_ = false, prelim_done_ = false;
-    std::thread setup_, prelim_; std::vector<std::thread> trace_;
+    int inner_threads_ = 1;
+    static const int kSetupThreads = 2;                  // a 5 Mb batch takes longer to set up than the GPU takes to scan it
+    std::deque<TItem> query_queue_, trace_queue_; std::map<int64_t, TItem> prelim_queue_, done_;   // prelim_queue_: set up, by number
+    int64_t submitted_ = 0, delivered_ = 0, next_search_ = 0; int in_setup_ = 0, setup_exited_ = 0;
+    bool no_more_ = false, closing_ = false, setup_done_ = false, prelim_done_ = false;
+    std::thread prelim_; std::vector<std::thread> setup_, trace_;
 
     void Deliver(TItem it) { std::unique_lock<std::mutex> lk(mu_); done_[it->id] = std::move(it); cv_.notify_all(); }
     static void Guard(SWorkItem &it, const std::function<void()> &f) {
         if (it.status != GBN_OK) return;
         try { f(); } catch (const CBlastException &e) { it.status = e.code; it.error = e.what(); }
     }
-    // set-up of a batch (host part + lookup structures on the device), at most two ahead of the search
+    // set-up of a batch (host part + lookup structures on the device) on two threads, at most three batches ahead of the search
     void SetupThread() {
         for (;;) {
             TItem it;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return closing_ || (!query_queue_.empty() && prelim_queue_.size() < 2) || (no_more_ && query_queue_.empty()); });
-                if (closing_ || query_queue_.empty()) { setup_done_ = true; cv_.notify_all(); return; }
-                it = std::move(query_queue_.front()); query_queue_.pop_front();
+                cv_.wait(lk, [&] { return closing_ || (!query_queue_.empty() && (int)prelim_queue_.size() + in_setup_ < 3) || (no_more_ && query_queue_.empty()); });
+                if (closing_ || query_queue_.empty()) { if (++setup_exited_ == kSetupThreads) setup_done_ = true; cv_.notify_all(); return; }
+                it = std::move(query_queue_.front()); query_queue_.pop_front(); in_setup_++;
             }
             Guard(*it, [&] { it->prelim.reset(new CBlastPrelimSearch(it->queries, opt_, src_)); });
             std::unique_lock<std::mutex> lk(mu_);
-            prelim_queue_.push_back(std::move(it));
+            in_setup_--;
+            const int64_t id = it->id;
+            prelim_queue_[id] = std::move(it);
             cv_.notify_all();
         }
     }
@@ -192,9 +200,12 @@ private:
             {
                 std::unique_lock<std::mutex> lk(mu_);
                 // nothing to scan next: the batch in flight is finished now instead of underneath a scan
-                if (prelim_queue_.empty() && prev && !closing_ && !setup_done_) { lk.unlock(); CloseStream(*prev); PushTrace(std::move(prev)); lk.lock(); }
-                cv_.wait(lk, [&] { return closing_ || !prelim_queue_.empty() || setup_done_; });
-                if (!prelim_queue_.empty()) { it = std::move(prelim_queue_.front()); prelim_queue_.pop_front(); cv_.notify_all(); }
+                if (!prelim_queue_.count(next_search_) && in_setup_ == 0 && query_queue_.empty() && prev && !closing_ && !setup_done_) {
+                    lk.unlock(); CloseStream(*prev); PushTrace(std::move(prev)); lk.lock();
+                }
+                cv_.wait(lk, [&] { return closing_ || prelim_queue_.count(next_search_) || setup_done_; });
+                auto f = prelim_queue_.find(next_search_);
+                if (f != prelim_queue_.end()) { it = std::move(f->second); prelim_queue_.erase(f); next_search_++; cv_.notify_all(); }
                 else if (closing_ || setup_done_) break;
             }
             if (!it) continue;
@@ -217,7 +228,7 @@ private:
                 else if (prelim_done_ || closing_) return;
             }
             if (!it) continue;
-            if (traceback_) Guard(*it, [&] { it->traceback.reset(new CBlastTracebackSearch()); it->traceback->Run(*it->prelim, src_, *it->stream, 1); });
+            if (traceback_) Guard(*it, [&] { it->traceback.reset(new CBlastTracebackSearch()); it->traceback->Run(*it->prelim, src_, *it->stream, inner_threads_); });
             Deliver(std::move(it));
         }
     }
