@@ -83,7 +83,49 @@ EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_de
            "gbn_traceback_new", "gbn_traceback_free", "gbn_traceback_run", "gbn_traceback_num_hsps", "gbn_traceback_hsps",
            "gbn_traceback_ops", "gbn_traceback_op_lengths", "gbn_traceback_query_starts",
            "gbn_pipeline_new", "gbn_pipeline_free", "gbn_pipeline_submit", "gbn_pipeline_finish", "gbn_pipeline_next",
-           "gbn_pipeline_diagnostics"]
+           "gbn_pipeline_diagnostics",
+           "gbn_batch_scan_params", "gbn_batch_ext_params", "gbn_batch_gap_params", "gbn_batch_diag_layout",
+           "gbn_prelim_search_lists", "gbn_db_cache_find", "gbn_db_cache_insert",
+           "gbn_shard_builder_new", "gbn_shard_builder_add", "gbn_shard_builder_finish", "gbn_shard_builder_free"]
+
+# ---- include/gblastn_amd_kernels.h: parameter blocks of the gbn_launch_* entry points (device pointers as integers)
+_P, _I, _L, _U, _UL = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
+TILE_DT = np.dtype([("subj", "<i4"), ("first_pos", "<i4"), ("npos", "<i4"), ("off16", "<i4")])
+DEV_SEED_DT = np.dtype([("subj", "<i4"), ("s_scan", "<i4"), ("q_pos", "<i4"), ("ext_left", "<i4")])
+DEV_IHIT_DT = np.dtype([("subj", "<i4"), ("q_off", "<i4"), ("s_off", "<i4"), ("q_start", "<i4"), ("s_start", "<i4"),
+                        ("length", "<i4"), ("score", "<i4"), ("seq", "<u4")])
+DEV_GAPPED_DT = np.dtype([("q_start", "<i4"), ("q_stop", "<i4"), ("s_start", "<i4"), ("s_stop", "<i4"), ("score", "<i4"),
+                          ("seed_q", "<i4"), ("seed_s", "<i4"), ("context", "<i4")])
+GBN_TILE_POS = 2048
+
+
+class GbnScanParams(C.Structure):
+    _fields_ = [("db", _P), ("byte_off", _P), ("len", _P), ("tiles", _P), ("ntiles", _L),
+                ("pv", _P), ("cellw", _P), ("cell_start", _P), ("ent", _P), ("ncells", _L),
+                ("lut", C.c_int), ("word", C.c_int), ("step", C.c_int), ("mode", C.c_int), ("fl", C.c_int), ("fr", C.c_int),
+                ("q8", _P), ("qlen", _I), ("ctx_off", _P), ("ctx_len", _P), ("nctx", _I),
+                ("seeds", _P), ("seed_count", _P), ("seed_cap", _UL), ("raw_hits", _P)]
+
+
+class GbnExtParams(C.Structure):
+    _fields_ = [("db", _P), ("byte_off", _P), ("len", _P), ("seeds", _P), ("idx", _P), ("key_group", _P), ("n", _L),
+                ("q8", _P), ("qlen", _I), ("ctx_off", _P), ("ctx_len", _P), ("ctx_xdrop", _P), ("ctx_cutoff", _P),
+                ("ctx_reduced", _P), ("nctx", _I), ("matrix", _P), ("score_table", _P), ("word", C.c_int),
+                ("container_hash", C.c_int), ("cell_diag", _P), ("cell_level", _P), ("cell_start", _P), ("ent", _P),
+                ("cell_mask", _U), ("lut", C.c_int), ("masked", C.c_int), ("q2", _P), ("qinv", _P),
+                ("run_heads", _P), ("run_count", _P), ("group_bits", _I),
+                ("ihits", _P), ("ihit_count", _P), ("ihit_cap", _UL)]
+
+
+class GbnGapParams(C.Structure):
+    _fields_ = [("db", _P), ("byte_off", _P), ("len", _P), ("ihits", _P), ("first", _L), ("n", _L),
+                ("q8", _P), ("ctx_off", _P), ("ctx_len", _P), ("nctx", _I), ("q2", _P), ("qinv", _P), ("matrix", _P),
+                ("reward", _I), ("penalty", _I), ("gap_open", _I), ("gap_extend", _I), ("xdrop", _I),
+                ("scratch", _P), ("scratch_per_thread", _I), ("row_len", _I), ("out", _P),
+                ("max_blocks", _I), ("redo_only", _I)]
+
+
+GbnHspListFn = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32)
 
 _LIB = None
 
@@ -102,6 +144,19 @@ def lib():
         L.gbn_db_new.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
         L.gbn_db_free.argtypes = [C.c_void_p]
+        for f, t in (("gbn_batch_scan_params", GbnScanParams), ("gbn_batch_ext_params", GbnExtParams), ("gbn_batch_gap_params", GbnGapParams)):
+            getattr(L, f).argtypes = [C.c_void_p, C.c_void_p, C.POINTER(t)]
+        L.gbn_batch_diag_layout.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        L.gbn_launch_scan_seed.argtypes = [C.POINTER(GbnScanParams), C.c_int, C.c_void_p]
+        L.gbn_launch_ungapped.argtypes = [C.POINTER(GbnExtParams), C.c_void_p]
+        L.gbn_launch_gapped.argtypes = [C.POINTER(GbnGapParams), C.c_int, C.c_void_p]
+        L.gbn_prelim_search_lists.argtypes = [C.c_void_p, C.c_void_p, GbnHspListFn, C.c_void_p, C.POINTER(GbnDiagnostics), C.c_void_p, C.c_void_p]
+        L.gbn_db_cache_find.restype = C.c_void_p; L.gbn_db_cache_find.argtypes = [C.c_void_p]
+        L.gbn_db_cache_insert.argtypes = [C.c_void_p, C.c_void_p]
+        L.gbn_shard_builder_new.argtypes = [C.POINTER(C.c_void_p), C.c_int32]
+        L.gbn_shard_builder_add.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+        L.gbn_shard_builder_finish.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+        L.gbn_shard_builder_free.argtypes = [C.c_void_p]
         L.gbn_db_total_bases.restype = C.c_int64; L.gbn_db_total_bases.argtypes = [C.c_void_p]
         L.gbn_db_num_seqs.restype = C.c_int32; L.gbn_db_num_seqs.argtypes = [C.c_void_p]
         L.gbn_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]

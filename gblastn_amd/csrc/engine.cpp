@@ -543,6 +543,35 @@ static int take_failure(const GbnResults *res) {
     return rc;
 }
 
+// ints of scratch one thread of the gapped kernels needs (GbnGapParams::scratch_per_thread) and the greedy row length
+static int64_t gap_scratch_ints(const GbnBatch &b, int32_t max_len, int32_t max_ctx, int32_t *row_len) {
+    size_t per_thread;
+    *row_len = 0;
+    if (b.opt.greedy) {
+        int32_t max_dist = std::min(10000, max_len / 2 + 1);
+        int32_t X2 = (b.opt.reward % 2 == 1) ? 2 * b.gap_x_dropoff : b.gap_x_dropoff;
+        int32_t mc = (b.opt.reward % 2 == 1) ? 2 * b.opt.reward : b.opt.reward;
+        int32_t mm = (b.opt.reward % 2 == 1) ? -2 * b.opt.penalty : -b.opt.penalty;
+        int32_t xoff = (X2 + mc / 2) / (mc + mm) + 1;
+        *row_len = 2 * max_dist + 8;
+        per_thread = 2 * (size_t)*row_len + (size_t)max_dist + 4 + (size_t)xoff;
+        if (!(b.opt.gap_open == 0 && b.opt.gap_extend == 0)) {
+            // affine greedy: (max_penalty + 1) rows of 3 offsets, diagonal bounds and max_score per scaled distance
+            int32_t go = b.opt.gap_open, ge = b.opt.gap_extend;
+            if (b.opt.reward % 2 == 1) { go *= 2; ge *= 2; }
+            int32_t half = mc / 2, opc = mc + mm, gex = ge + half;
+            auto gcd2 = [](int a, int c) { c = std::abs(c); if (c > a) std::swap(a, c); while (c) { int t = a % c; a = c; c = t; } return a; };
+            int32_t g = go == 0 ? gcd2(opc, gex) : gcd2(opc, gcd2(go, gex));
+            if (g > 1) { opc /= g; go /= g; gex /= g; }
+            int32_t max_penalty = std::max(opc, go + gex), scaled = max_dist * gex, xo = (X2 + half) / g + 1;
+            per_thread = (size_t)(max_penalty + 1) * *row_len * 3 + 2 * (size_t)(scaled + 1 + max_penalty) + (size_t)scaled + 4 + xo;
+        }
+    } else {
+        per_thread = 2 * ((size_t)max_ctx + 16);
+    }
+    return (int64_t)((per_thread + 3) & ~(size_t)3);
+}
+
 static void fill_scan_params(GbnScanParams &P, const GbnBatch &b, const GbnDb &db, const TileSet &ts) {
     const DeviceBatch *d = b.dev;
     std::memset(&P, 0, sizeof(P));
@@ -937,31 +966,9 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     G.matrix = d->matrix; G.reward = b.opt.reward; G.penalty = b.opt.penalty;
     G.gap_open = b.opt.gap_open; G.gap_extend = b.opt.gap_extend; G.xdrop = b.gap_x_dropoff;
     G.out = E.gapped_s[slot];
-    size_t per_thread;
-    if (b.opt.greedy) {
-        int32_t max_dist = std::min(10000, max_len / 2 + 1);
-        int32_t X2 = (b.opt.reward % 2 == 1) ? 2 * b.gap_x_dropoff : b.gap_x_dropoff;
-        int32_t mc = (b.opt.reward % 2 == 1) ? 2 * b.opt.reward : b.opt.reward;
-        int32_t mm = (b.opt.reward % 2 == 1) ? -2 * b.opt.penalty : -b.opt.penalty;
-        int32_t xoff = (X2 + mc / 2) / (mc + mm) + 1;
-        G.row_len = 2 * max_dist + 8;
-        per_thread = 2 * (size_t)G.row_len + (size_t)max_dist + 4 + (size_t)xoff;
-        if (!(b.opt.gap_open == 0 && b.opt.gap_extend == 0)) {
-            // affine greedy: (max_penalty + 1) rows of 3 offsets, diagonal bounds and max_score per scaled distance
-            int32_t go = b.opt.gap_open, ge = b.opt.gap_extend;
-            if (b.opt.reward % 2 == 1) { go *= 2; ge *= 2; }
-            int32_t half = mc / 2, opc = mc + mm, gex = ge + half;
-            auto gcd2 = [](int a, int c) { c = std::abs(c); if (c > a) std::swap(a, c); while (c) { int t = a % c; a = c; c = t; } return a; };
-            int32_t g = go == 0 ? gcd2(opc, gex) : gcd2(opc, gcd2(go, gex));
-            if (g > 1) { opc /= g; go /= g; gex /= g; }
-            int32_t max_penalty = std::max(opc, go + gex), scaled = max_dist * gex, xo = (X2 + half) / g + 1;
-            per_thread = (size_t)(max_penalty + 1) * G.row_len * 3 + 2 * (size_t)(scaled + 1 + max_penalty) + (size_t)scaled + 4 + xo;
-        }
-    } else {
-        G.row_len = 0;
-        per_thread = 2 * ((size_t)max_ctx + 16);
-    }
-    per_thread = (per_thread + 3) & ~(size_t)3;
+    int32_t row_len = 0;
+    const size_t per_thread = (size_t)gap_scratch_ints(b, max_len, max_ctx, &row_len);
+    G.row_len = row_len;
     G.scratch_per_thread = (int32_t)per_thread;
     // grid: at most 24 waves per CU (measured on the blastn shape: 12-20 make the gapped stage the longer one, 28+ starve the scan; the scan kernels of the next range need room, see greedy_kernel) and at
     // most 4 GiB of scratch; the threads stride over the initial hits
@@ -1132,7 +1139,31 @@ int Blast_gpu_Init(int use_gpu, int gpu_id) {
     return GBN_OK;
 }
 
-void gpu_ReleaseDBMemory(void) { /* shards are owned by their GbnDb handles */ }
+// Shards a caller keeps per database handle (the shim: per BlastSeqSrc).  The reference caches every subject it
+// has uploaded for the life of the process and gpu_ReleaseDBMemory drops that cache
+// (GB/gpu_blastn_MB_and_smallNa.cu:1462-1468, gpu_blastn_na_ungapped_v3.cpp:27-60); here the cache holds whole
+// shards, keyed by the caller's handle, and gpu_ReleaseDBMemory frees them.  Shards the caller made with
+// gbn_db_from_* and did not insert stay the caller's.
+static std::mutex g_cache_mu;
+static std::map<const void *, GbnDb *> g_db_cache;
+GbnDb *gbn_db_cache_find(const void *key) {
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    auto it = g_db_cache.find(key);
+    return it == g_db_cache.end() ? nullptr : it->second;
+}
+int gbn_db_cache_insert(const void *key, GbnDb *db) {
+    if (!db) return GBN_ERR_ARG;
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    auto it = g_db_cache.find(key);
+    if (it != g_db_cache.end()) { set_error("gbn_db_cache_insert: key already holds a shard"); return GBN_ERR_ARG; }
+    g_db_cache[key] = db;
+    return GBN_OK;
+}
+void gpu_ReleaseDBMemory(void) {
+    std::map<const void *, GbnDb *> drop;
+    { std::lock_guard<std::mutex> lk(g_cache_mu); drop.swap(g_db_cache); }
+    for (auto &kv : drop) gbn_db_free(kv.second);
+}
 
 void Blast_gpu_Release(void) {
     std::lock_guard<std::mutex> lk(E.mu);
@@ -1156,6 +1187,36 @@ void Blast_gpu_Release(void) {
     pool_drain();
     E.ev0 = E.ev1 = nullptr; E.stream = E.stream2 = nullptr; E.ready = false;
 }
+
+// subjects appended one at a time (the shim: what BlastSeqSrcGetSequence hands out) into the slab layout of gbn_db_new
+struct GbnShardBuilder { std::vector<uint8_t> bytes; std::vector<int64_t> off; std::vector<int32_t> len; };
+int gbn_shard_builder_new(GbnShardBuilder **out, int32_t expected_seqs) {
+    if (!out) return GBN_ERR_ARG;
+    GbnShardBuilder *b = new (std::nothrow) GbnShardBuilder();
+    if (!b) return GBN_ERR_NOMEM;
+    if (expected_seqs > 0) { b->off.reserve(expected_seqs); b->len.reserve(expected_seqs); }
+    *out = b;
+    return GBN_OK;
+}
+int gbn_shard_builder_add(GbnShardBuilder *b, const uint8_t *ncbi2na, int32_t length) {
+    if (!b || length < 0 || (length > 0 && !ncbi2na)) { set_error("gbn_shard_builder_add: bad argument"); return GBN_ERR_ARG; }
+    const size_t at = (b->bytes.size() + 15) & ~(size_t)15, nb = ((size_t)length + 3) / 4;
+    try { b->bytes.resize(at + nb, 0); b->off.push_back((int64_t)at); b->len.push_back(length); }
+    catch (const std::bad_alloc &) { set_error("out of host memory"); return GBN_ERR_NOMEM; }
+    if (nb) std::memcpy(b->bytes.data() + at, ncbi2na, nb);
+    // the last byte of a stored sequence carries the remainder count in its low bits (sequence_files.txt:60-90): bases only
+    if (length & 3) b->bytes[at + nb - 1] &= (uint8_t)(0xff << (2 * (4 - (length & 3))));
+    return GBN_OK;
+}
+int gbn_shard_builder_finish(GbnShardBuilder *b, GbnDb **out) {
+    if (!b || !out || b->len.empty()) { set_error("gbn_shard_builder_finish: no subjects"); return GBN_ERR_ARG; }
+    try { b->bytes.resize(((b->bytes.size() + 15) & ~(size_t)15) + 128, 0); }
+    catch (const std::bad_alloc &) { set_error("out of host memory"); return GBN_ERR_NOMEM; }
+    int rc = gbn_db_new(out, b->bytes.data(), (int64_t)b->bytes.size(), (int32_t)b->len.size(), b->off.data(), b->len.data(), 0, 0);
+    std::vector<uint8_t>().swap(b->bytes);
+    return rc;
+}
+void gbn_shard_builder_free(GbnShardBuilder *b) { delete b; }
 
 int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_seqs,
                const int64_t *byte_off, const int32_t *len, int32_t first_oid, int is_device) {
@@ -1235,6 +1296,60 @@ int gbn_batch_new_ex(GbnBatch **out, const GbnOptions *opt, int32_t nq, const ui
 
 int gbn_batch_new(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs, const int32_t *lens) {
     return gbn_batch_new_ex(out, opt, nq, seqs, lens, 1);
+}
+// the launchers' parameter blocks for a caller that holds a batch and a shard: database, lookup and query members
+// (everything marked [caller] in gblastn_amd_kernels.h stays zero)
+static int params_ready(const GbnBatch *b, const GbnDb *db) {
+    if (!b || !db || !b->dev) { set_error("batch without device structures (gbn_batch_new_ex upload = 0?)"); return GBN_ERR_ARG; }
+    use_engine_device();
+    if (b->dev->ready) HIPCHK(hipEventSynchronize(b->dev->ready));     // deferred lookup build
+    return GBN_OK;
+}
+int gbn_batch_scan_params(const GbnBatch *b, const GbnDb *db, GbnScanParams *out) {
+    int rc = params_ready(b, db); if (rc) return rc;
+    if (!out) return GBN_ERR_ARG;
+    TileSet none;
+    fill_scan_params(*out, *b, *db, none);
+    out->seeds = nullptr; out->seed_count = nullptr; out->seed_cap = 0; out->raw_hits = nullptr;
+    return GBN_OK;
+}
+int gbn_batch_ext_params(const GbnBatch *b, const GbnDb *db, GbnExtParams *X) {
+    int rc = params_ready(b, db); if (rc) return rc;
+    if (!X) return GBN_ERR_ARG;
+    const DeviceBatch *d = b->dev;
+    std::memset(X, 0, sizeof(*X));
+    X->db = db->d_packed; X->byte_off = db->d_byte_off; X->len = db->d_len;
+    X->q8 = d->q8; X->qlen = b->qlen; X->q2 = d->q2; X->qinv = d->qinv;
+    X->ctx_off = d->ctx_off; X->ctx_len = d->ctx_len; X->ctx_xdrop = d->ctx_xdrop;
+    X->ctx_cutoff = d->ctx_cutoff; X->ctx_reduced = d->ctx_reduced; X->nctx = (int32_t)b->ctx.size();
+    X->matrix = d->matrix; X->score_table = d->score_table;
+    X->word = b->lut.word; X->container_hash = b->container;
+    X->cell_start = d->cell_start; X->ent = d->ent; X->cell_mask = (uint32_t)(b->lut.ncells - 1); X->lut = b->lut.lut;
+    X->masked = b->lut.masked ? 1 : 0;
+    return GBN_OK;
+}
+int gbn_batch_gap_params(const GbnBatch *b, const GbnDb *db, GbnGapParams *G) {
+    int rc = params_ready(b, db); if (rc) return rc;
+    if (!G) return GBN_ERR_ARG;
+    const DeviceBatch *d = b->dev;
+    std::memset(G, 0, sizeof(*G));
+    G->db = db->d_packed; G->byte_off = db->d_byte_off; G->len = db->d_len;
+    G->q8 = d->q8; G->q2 = d->q2; G->qinv = d->qinv; G->ctx_off = d->ctx_off; G->ctx_len = d->ctx_len; G->nctx = (int32_t)b->ctx.size();
+    G->matrix = d->matrix; G->reward = b->opt.reward; G->penalty = b->opt.penalty;
+    G->gap_open = b->opt.gap_open; G->gap_extend = b->opt.gap_extend; G->xdrop = b->gap_x_dropoff;
+    int32_t max_len = 0, max_ctx = 0, row_len = 0;
+    for (int32_t l : db->len) max_len = std::max(max_len, l);
+    for (auto &c : b->ctx) max_ctx = std::max(max_ctx, c.query_length);
+    G->scratch_per_thread = (int32_t)gap_scratch_ints(*b, max_len, max_ctx, &row_len);
+    G->row_len = row_len;
+    return GBN_OK;
+}
+int gbn_batch_diag_layout(const GbnBatch *b, int32_t *container_hash, int32_t *diag_len, int32_t *q_descending) {
+    if (!b) return GBN_ERR_ARG;
+    if (container_hash) *container_hash = b->container;
+    if (diag_len) *diag_len = b->diag_len;
+    if (q_descending) *q_descending = b->lut.type == GBN_LUT_MB ? 1 : 0;
+    return GBN_OK;
 }
 int gbn_launch_scan_seed(const GbnScanParams *p, int grid, void *stream) {
     if (!p) return GBN_ERR_ARG;
@@ -1356,6 +1471,28 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     (void)wait_pending();                               // of an earlier gbn_prelim_search_begin (its status stays with its results)
     const int rc2 = take_failure(results);
     return rc ? rc : rc2;
+}
+
+// the same search delivered the way BlastHSPStreamWrite wants it: one call per subject that has HSPs
+int gbn_prelim_search_lists(GbnBatch *batch, GbnDb *db, GbnHspListFn sink, void *sink_arg, GbnDiagnostics *diag,
+                            GbnInterruptFn interrupt, void *progress) {
+    if (!sink) { set_error("gbn_prelim_search_lists: no sink"); return GBN_ERR_ARG; }
+    GbnResults *res = nullptr;
+    int rc = gbn_results_new(&res);
+    if (rc) return rc;
+    rc = gbn_prelim_search(batch, db, res, diag, 0, interrupt, progress);
+    if (rc == GBN_OK) {
+        const GbnHSP *h = res->hsps.data();
+        const int64_t n = (int64_t)res->hsps.size();
+        for (int64_t i = 0; i < n && rc == GBN_OK; ) {
+            int64_t j = i;
+            while (j < n && h[j].oid == h[i].oid) j++;
+            if (sink(sink_arg, h[i].oid, h + i, (int32_t)(j - i))) { set_error("gbn_prelim_search_lists: the sink failed"); rc = GBN_ERR_ARG; }
+            i = j;
+        }
+    }
+    gbn_results_free(res);
+    return rc;
 }
 
 int gbn_prelim_search_begin(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,

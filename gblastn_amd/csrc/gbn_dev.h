@@ -2,39 +2,9 @@
 #pragma once
 #include <stdint.h>
 
+#include "../../include/gblastn_amd_kernels.h"    // GbnTile, GbnDevSeed / InitHit / Gapped, GbnScanParams, GbnExtParams, GbnGapParams
+
 #define GBN_SCAN_THREADS 256
-#define GBN_TILE_POS     2048       // scan positions per tile (8 per lane)
-
-// mini-extension flavours (CORE/na_ungapped.c:1753-1795)
-#define GBN_EXT_DIRECT        0     // lut == word_size
-#define GBN_EXT_NA            1     // s_BlastNaExtend / s_BlastNaExtendAligned
-#define GBN_EXT_SMALL         2     // s_BlastSmallNaExtend
-#define GBN_EXT_SMALL_ONEBYTE 3     // s_BlastSmallNaExtendAlignedOneByte
-
-struct GbnTile { int32_t subj; int32_t first_pos; int32_t npos; int32_t off16; };    // off16 = byte_off[subj] / 16
-
-struct GbnDevSeed { int32_t subj, s_scan, q_pos, ext_left; };
-struct GbnDevInitHit { int32_t subj, q_off, s_off, q_start, s_start, length, score; uint32_t seq; };
-struct GbnDevGapped { int32_t q_start, q_stop, s_start, s_stop, score, seed_q, seed_s, context; };
-
-struct GbnScanParams {
-    // database slab
-    const uint8_t *db; const int64_t *byte_off; const int32_t *len;
-    const GbnTile *tiles; int64_t ntiles;
-    // lookup structures
-    const uint32_t *pv;             // 1 bit per cell
-    const uint32_t *cellw;          // bit31 = more than one entry, [30:15] left-8, [14:1] right-7, bit0 force
-    const uint32_t *cell_start;     // ncells + 1
-    const unsigned long long *ent;  // low 32 = query offset, high 32 = fingerprint word
-    int64_t ncells;
-    int lut, word, step, mode, fl, fr;
-    // query (one byte per base, index 0 = first base of strand 0)
-    const uint8_t *q8; int32_t qlen;
-    const int32_t *ctx_off, *ctx_len; int32_t nctx;
-    // outputs
-    GbnDevSeed *seeds; unsigned long long *seed_count; unsigned long long seed_cap;
-    unsigned long long *raw_hits;
-};
 
 // ---- key-range partitioned scan: phase 1 bins EVERY scan position by the top
 // bits of its lookup word (8-byte records, no table access at all); phase 2
@@ -116,38 +86,3 @@ struct GbnKeyParams {
 #ifndef GBN_DIAG_COMPACT_MIN
 #define GBN_DIAG_COMPACT_MIN (1 << 20)
 #endif
-
-struct GbnExtParams {
-    const uint8_t *db; const int64_t *byte_off; const int32_t *len;
-    const GbnDevSeed *seeds; const uint32_t *idx; const uint64_t *key_group; int64_t n;
-    const uint8_t *q8; int32_t qlen;
-    const int32_t *ctx_off, *ctx_len, *ctx_xdrop, *ctx_cutoff, *ctx_reduced; int32_t nctx;
-    const int32_t *matrix;          // 16 x 16
-    const int32_t *score_table;     // 256
-    int word, container_hash;
-    int32_t *cell_diag, *cell_level;    // hash emulation scratch, n entries each
-    // re-check of seeds against the soft query masks (s_TypeOfWord): table membership tests
-    const uint32_t *cell_start; const unsigned long long *ent; uint32_t cell_mask; int lut, masked;
-    // the query 2 bits per base and the bitmap of codes that match nothing (as in GbnGapParams): the 4-bases-per-step
-    // ungapped extension reads 32 bases at a time from them; null: byte-wise path only
-    const uint8_t *q2, *qinv;
-    uint32_t *run_heads, *run_count;    // scratch: index of the first seed of every (subject, slot) run (n entries), their number
-    int32_t group_bits;                 // key_group = subject << group_bits | slot (0 is read as 32)
-    GbnDevInitHit *ihits; unsigned long long *ihit_count; unsigned long long ihit_cap;
-};
-
-struct GbnGapParams {
-    const uint8_t *db; const int64_t *byte_off; const int32_t *len;
-    const GbnDevInitHit *ihits; int64_t first, n;
-    const uint8_t *q8; const int32_t *ctx_off, *ctx_len; int32_t nctx;
-    // greedy only: the query 2 bits per base (same packing as the subjects) and a bitmap (MSB first)
-    // of the codes that match nothing; both indexed from base 0 and readable 256 bases either side
-    const uint8_t *q2, *qinv;
-    const int32_t *matrix;
-    int32_t reward, penalty, gap_open, gap_extend, xdrop;
-    int32_t *scratch; int32_t scratch_per_thread, row_len;      // scratch: one slot per thread of the grid
-    GbnDevGapped *out;
-    int32_t max_blocks;             // grid cap in 64-thread blocks (0: one thread per initial hit); the threads stride over the hits
-    int32_t redo_only;              // dynprog_kernel: only the extensions the wave kernel marked GBN_GAP_REDO
-};
-#define GBN_GAP_REDO (INT32_MIN + 1)    // GbnDevGapped::score of an extension the wave-per-extension kernel left to dynprog_kernel

@@ -130,7 +130,11 @@ typedef int (*GbnInterruptFn)(void *progress);   /* TInterruptFnPtr analogue */
 /* ---- process-level ---- */
 int  Blast_gpu_Init(int use_gpu, int gpu_id);
 void Blast_gpu_Release(void);
-void gpu_ReleaseDBMemory(void);
+void gpu_ReleaseDBMemory(void);     /* frees every shard held by the cache below (GB/gpu_blastn_na_ungapped_v3.h:21) */
+/* shards kept per caller handle (the shim keys them by BlastSeqSrc*): the cache owns what is inserted */
+struct GbnDb;
+struct GbnDb *gbn_db_cache_find(const void *key);
+int  gbn_db_cache_insert(const void *key, struct GbnDb *db);
 
 /* ---- database shard resident in HBM ---- */
 typedef struct GbnDb GbnDb;
@@ -143,6 +147,13 @@ int  gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_
                 const int64_t *byte_off, const int32_t *len, int32_t first_oid,
                 int is_device);
 void gbn_db_free(GbnDb *db);
+/* the same shard from subjects handed over one at a time, as BlastSeqSrcGetSequence yields them (NCBI2na,
+ * `length` bases; OIDs = order of the calls); _finish uploads the slab and leaves the builder empty */
+typedef struct GbnShardBuilder GbnShardBuilder;
+int  gbn_shard_builder_new(GbnShardBuilder **out, int32_t expected_seqs);
+int  gbn_shard_builder_add(GbnShardBuilder *b, const uint8_t *ncbi2na, int32_t length);
+int  gbn_shard_builder_finish(GbnShardBuilder *b, GbnDb **out);
+void gbn_shard_builder_free(GbnShardBuilder *b);
 int64_t gbn_db_total_bases(const GbnDb *db);
 int32_t gbn_db_num_seqs(const GbnDb *db);
 /* deterministic synthetic DB bytes generated on the device (bench/tests) */
@@ -233,6 +244,13 @@ const GbnInitHit *gbn_results_init_hits(const GbnResults *r);
 int  gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results,
                        GbnDiagnostics *diag, int keep_stages,
                        GbnInterruptFn interrupt, void *progress);
+/* The same search delivered as the reference's HSP stream takes it (BlastHSPStreamWrite, CORE/blast_hspstream.c:
+ * one BlastHSPList per subject): `sink` is called once per subject that has HSPs, oids ascending, with that
+ * subject's HSPs in list order (score descending as Blast_HSPListSortByScore leaves them); a non-zero return
+ * of the sink stops the delivery and fails the call.  The pointers are valid during the call only. */
+typedef int (*GbnHspListFn)(void *arg, int32_t oid, const GbnHSP *hsps, int32_t n);
+int  gbn_prelim_search_lists(GbnBatch *batch, GbnDb *db, GbnHspListFn sink, void *sink_arg, GbnDiagnostics *diag,
+                             GbnInterruptFn interrupt, void *progress);
 /* Pipelined form (the reference's "-mode 1" PrelimSearchThread / TraceBackThread split,
  * GB/work_thread.cpp:60-107, moved one stage down): _begin returns once the scan of the LAST subject
  * range is done.  For ranges with few seeds (megablast shapes) everything after the scan -- seed order,
@@ -306,9 +324,16 @@ const int32_t *gbn_collector_list_queries(const GbnCollector *c);
 int64_t gbn_collector_num_hsps(const GbnCollector *c);
 const GbnHSP *gbn_collector_hsps(const GbnCollector *c);
 
-/* ---- thin kernel launchers: device pointers in the parameter blocks of
- * gblastn_amd_kernels.h, hipStream_t passed as void* ---- */
+/* ---- thin kernel launchers: device pointers in the parameter blocks of gblastn_amd_kernels.h (public,
+ * self-contained), hipStream_t passed as void*.  gbn_batch_*_params fill in what a batch and a shard determine
+ * (waiting for the batch's deferred lookup build); the work list and the output / scratch buffers marked
+ * [caller] in that header are the caller's.  gbn_batch_diag_layout: the diagonal container the batch's
+ * word finder uses (CORE/blast_extend.c:85-140) -- what a caller needs to order seeds for gbn_launch_ungapped. ---- */
 struct GbnScanParams; struct GbnExtParams; struct GbnGapParams;
+int  gbn_batch_scan_params(const GbnBatch *b, const GbnDb *db, struct GbnScanParams *out);
+int  gbn_batch_ext_params(const GbnBatch *b, const GbnDb *db, struct GbnExtParams *out);
+int  gbn_batch_gap_params(const GbnBatch *b, const GbnDb *db, struct GbnGapParams *out);
+int  gbn_batch_diag_layout(const GbnBatch *b, int32_t *container_hash, int32_t *diag_len, int32_t *q_descending);
 int  gbn_launch_scan_seed(const struct GbnScanParams *p, int grid, void *stream);
 int  gbn_launch_ungapped(const struct GbnExtParams *p, void *stream);
 int  gbn_launch_gapped(const struct GbnGapParams *p, int greedy, void *stream);

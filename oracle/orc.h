@@ -167,6 +167,10 @@ int orc_greedy_extend(const uint8_t *query, int32_t qlen,
                       int32_t reward, int32_t penalty,
                       int32_t gap_open, int32_t gap_extend, OrcHSP *out);
 
+/* s_BlastDynProgNtGappedAlignment from (q_off, s_off), CORE/blast_gapalign.c:2762-2826 */
+int orc_dynprog_extend(const uint8_t *query, int32_t qlen, const uint8_t *subj_packed, int32_t slen,
+                       int32_t q_off, int32_t s_off, int32_t xdrop, int32_t reward, int32_t penalty,
+                       int32_t gap_open, int32_t gap_extend, OrcHSP *out);
 /* ---- traceback stage (orc_traceback.c) ---- */
 typedef struct OrcEditScript { uint8_t *op; int32_t *num; int32_t size; } OrcEditScript;    /* op: 0 deletion (gap in query), 3 substitution, 6 insertion */
 typedef struct OrcTbHSP {

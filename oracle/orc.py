@@ -134,6 +134,8 @@ def lib():
         L.orc_greedy_extend.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_int32, C.POINTER(OrcHSP)]
+        L.orc_dynprog_extend.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.POINTER(OrcHSP)]
         L.orc_traceback_hsp_list.restype = C.c_int32
         L.orc_traceback_hsp_list.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.POINTER(OrcHSP), C.c_int32,
                                              C.POINTER(C.POINTER(OrcTbHSP))]
@@ -337,6 +339,17 @@ class Search:
         ops = [(int(e.op[k]), int(e.num[k])) for k in range(e.size)]
         self._L.orc_esp_free(C.byref(e))
         return dict(q_start=r.q_start, q_stop=r.q_stop, s_start=r.s_start, s_stop=r.s_stop, score=r.score, ops=ops)
+
+
+def gapped_extend(query, subj_bases, q_off, s_off, xdrop, reward, penalty, gap_open, gap_extend, greedy=False):
+    """one score-only gapped extension (the preliminary stage's aligners) -> dict of the HSP fields"""
+    q = np.ascontiguousarray(query, dtype=np.uint8)
+    packed = pack_ncbi2na(subj_bases)
+    h = OrcHSP()
+    f = lib().orc_greedy_extend if greedy else lib().orc_dynprog_extend
+    rc = f(q.ctypes.data, len(q), packed.ctypes.data, len(subj_bases), q_off, s_off, xdrop, reward, penalty, gap_open, gap_extend, C.byref(h))
+    assert rc == 0
+    return dict(q_offset=h.q_offset, q_end=h.q_end, s_offset=h.s_offset, s_end=h.s_end, score=h.score)
 
 
 def semi_gapped_score(matrix, A, B, M, N, x_dropoff, gap_open, gap_extend, reverse):

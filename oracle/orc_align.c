@@ -440,3 +440,18 @@ int orc_dynprog_gapped(const int32_t matrix[16][16], const uint8_t *query, const
     r->seed_q = q_off; r->seed_s = s_off;
     return 0;
 }
+
+/* the packed-subject X-drop DP on its own (definition-level tests): reward / penalty matrix over BLASTNA codes */
+int orc_dynprog_extend(const uint8_t *query, int32_t qlen, const uint8_t *subj_packed, int32_t slen,
+                       int32_t q_off, int32_t s_off, int32_t xdrop, int32_t reward, int32_t penalty,
+                       int32_t gap_open, int32_t gap_extend, OrcHSP *out)
+{
+    int32_t matrix[16][16]; OrcGapResult r; int rc;
+    orc_nucl_matrix(reward, penalty, matrix);
+    rc = orc_dynprog_gapped((const int32_t (*)[16])matrix, query, subj_packed, qlen, slen, q_off, s_off, xdrop, gap_open, gap_extend, &r);
+    if (rc) return rc;
+    memset(out, 0, sizeof(*out));
+    out->q_offset = r.q_start; out->q_end = r.q_stop; out->s_offset = r.s_start; out->s_end = r.s_stop;
+    out->q_gapped_start = r.seed_q; out->s_gapped_start = r.seed_s; out->score = r.score;
+    return 0;
+}

@@ -1,0 +1,225 @@
+"""GPU: the three kernel launchers driven through the C ABI (gbn_launch_scan_seed / _ungapped / _gapped with the
+parameter blocks of include/gblastn_amd_kernels.h, device buffers owned by this test), checked against the
+DEFINITIONS of tests/test_oracle_definitions.py (brute-force seeds, whole-matrix X-drop DP) and against the oracle;
+plus the shim-side pieces of the boundary: gbn_prelim_search_lists, the shard builder and the shard cache."""
+import ctypes as C
+import numpy as np
+import pytest
+import torch
+from gblastn_amd import api
+from oracle import orc
+from tests import util
+from tests.test_oracle_definitions import brute_force_seeds, seed_case, dp_pairs, dp_by_definition
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def scan_through_the_launcher(ps, src, lens):
+    """every subject of the shard tiled by the rule of gblastn_amd_kernels.h -> seeds (DEV_SEED_DT, launch order)"""
+    L = api.lib()
+    P = api.GbnScanParams()
+    api._check(L.gbn_batch_scan_params(ps._b, src._h, C.byref(P)))
+    offs, _ = api.layout_slab(lens)
+    tiles = []
+    for s, n in enumerate(lens):
+        if n < P.lut:
+            continue
+        npos = (n - P.lut) // P.step + 1
+        for p in range(0, npos, api.GBN_TILE_POS):
+            tiles.append((s, p * P.step, min(api.GBN_TILE_POS, npos - p), offs[s] >> 4))
+    t = dev(np.array(tiles, dtype=api.TILE_DT).view(np.int32))
+    cap = 1 << 20
+    seeds = torch.zeros(cap * 4, dtype=torch.int32, device="cuda")
+    ctr = torch.zeros(2, dtype=torch.int64, device="cuda")
+    P.tiles = t.data_ptr(); P.ntiles = len(tiles)
+    P.seeds = seeds.data_ptr(); P.seed_cap = cap; P.seed_count = ctr.data_ptr(); P.raw_hits = ctr.data_ptr() + 8
+    api._check(L.gbn_launch_scan_seed(C.byref(P), min(len(tiles), 2048), stream()))
+    torch.cuda.synchronize()
+    n, raw = (int(x) for x in ctr.cpu())
+    assert 0 < n <= cap and raw >= n
+    return seeds.cpu().numpy().view(api.DEV_SEED_DT)[:n].copy(), seeds, P
+
+
+def scan_order(sd, descending):
+    return np.lexsort((-sd["q_pos"] if descending else sd["q_pos"], sd["s_scan"], sd["subj"]))
+
+
+@pytest.mark.parametrize("nq,lut,step", [(16, 11, 18), (160, 12, 17)])
+def test_scan_launcher_seeds_equal_the_definition(nq, lut, step):
+    sub, queries = seed_case(nq, 40 + nq)
+    sub2 = np.random.default_rng(3).integers(0, 4, 9000).astype(np.uint8)
+    sub2[4000:4700] = queries[0][150:850]
+    subjects = [sub, sub2]
+    opt = api.default_options("megablast", db_length=10**7, db_num_seqs=10)
+    src = api.BlastSeqSrc.from_packed([(orc.pack_ncbi2na(s), len(s)) for s in subjects])
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    assert (ps.info()["lut_width"], ps.info()["scan_step"]) == (lut, step)
+    sd, _, _ = scan_through_the_launcher(ps, src, [len(s) for s in subjects])
+    sd = sd[scan_order(sd, True)]
+    S = orc.Search(util.oracle_options(opt), queries)
+    qcat = S.query_concat()
+    for k, s in enumerate(subjects):
+        want = brute_force_seeds(qcat, S.contexts, s, 28, lut, step, descending=True)
+        g = sd[sd["subj"] == k]
+        got = list(zip((g["q_pos"] - g["ext_left"]).tolist(), (g["s_scan"] - g["ext_left"]).tolist()))
+        assert got == want and len(want) > 0
+    # the whole search reports the same seeds (keep_stages)
+    r = ps.run(keep_stages=True)
+    assert len(r["seeds"]) == len(sd)
+
+
+@pytest.mark.parametrize("task,nq", [("megablast", 12), ("megablast", 200), ("blastn", 4)])
+def test_ungapped_launcher_equals_the_oracle(task, nq):
+    """seeds from the scan launcher, ordered here as gblastn_amd_kernels.h prescribes, through gbn_launch_ungapped:
+    the initial hits equal the oracle's word finder (diagonal array for few queries, hash container for many)"""
+    L = api.lib()
+    db, queries, plants, subjects, opt = util.small_case(6, 30000, nq, qlen=600, seed=21, task=task)
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    sd, d_seeds, _ = scan_through_the_launcher(ps, src, [n for _, n in subjects])
+    hashc, diag_len, desc = C.c_int32(), C.c_int32(), C.c_int32()
+    api._check(L.gbn_batch_diag_layout(ps._b, C.byref(hashc), C.byref(diag_len), C.byref(desc)))
+    assert hashc.value == (1 if nq == 200 else 0)
+    order = scan_order(sd, bool(desc.value))
+    o = sd[order]
+    q0, s0 = o["q_pos"] - o["ext_left"], o["s_scan"] - o["ext_left"]
+    slot = ((s0 - q0) & 511) if hashc.value else ((s0 + diag_len.value - q0) & (diag_len.value - 1))
+    gbits = 9 if hashc.value else int(diag_len.value).bit_length() - 1
+    key = (o["subj"].astype(np.uint64) << np.uint64(gbits)) | slot.astype(np.uint64)
+    grp = np.argsort(key, kind="stable")
+    n = len(sd)
+    X = api.GbnExtParams()
+    api._check(L.gbn_batch_ext_params(ps._b, src._h, C.byref(X)))
+    idx = dev(order[grp].astype(np.uint32).view(np.int32)); kg = dev(key[grp].view(np.int64))
+    cd = torch.zeros(n, dtype=torch.int32, device="cuda"); cl = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rh = torch.zeros(n + 1, dtype=torch.int32, device="cuda"); ctr = torch.zeros(2, dtype=torch.int64, device="cuda")
+    cap = n
+    ih = torch.zeros(cap * 8, dtype=torch.int32, device="cuda")
+    X.seeds = d_seeds.data_ptr(); X.idx = idx.data_ptr(); X.key_group = kg.data_ptr(); X.n = n
+    X.cell_diag = cd.data_ptr(); X.cell_level = cl.data_ptr(); X.run_heads = rh.data_ptr(); X.run_count = ctr.data_ptr() + 8
+    X.group_bits = gbits
+    X.ihits = ih.data_ptr(); X.ihit_count = ctr.data_ptr(); X.ihit_cap = cap
+    api._check(L.gbn_launch_ungapped(C.byref(X), stream()))
+    torch.cuda.synchronize()
+    nih = int(ctr.cpu()[0])
+    got = ih.cpu().numpy().view(api.DEV_IHIT_DT)[:nih]
+    ora, _ = util.oracle_run(opt, queries, subjects)
+    total = 0
+    for k, r in enumerate(ora):
+        g = got[got["subj"] == k]
+        g = g[np.lexsort((g["seq"], g["q_start"], -g["length"], g["s_start"], -g["score"]))]    # Blast_InitHitListSortByScore
+        w = r["init_hits"]
+        assert len(g) == len(w), k
+        for f in ("q_off", "s_off", "q_start", "s_start", "length", "score"):
+            assert np.array_equal(g[f], w[f]), (k, f)
+        total += len(w)
+    assert total > 0
+
+
+def gapped_through_the_launcher(queries, subjects, hits, opt, greedy):
+    """hits: (pair index, q offset inside its query, s offset); one query / one subject per pair"""
+    L = api.lib()
+    src = api.BlastSeqSrc.from_packed([(orc.pack_ncbi2na(s), len(s)) for s in subjects])
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    ctx = ps.contexts()
+    G = api.GbnGapParams()
+    api._check(L.gbn_batch_gap_params(ps._b, src._h, C.byref(G)))
+    ih = np.zeros(len(hits), dtype=api.DEV_IHIT_DT)
+    for i, (p, qo, so) in enumerate(hits):
+        ih[i] = (p, ctx[2 * p].query_offset + qo, so, ctx[2 * p].query_offset + qo, so, 4, 8, i)
+    d_ih = dev(ih.view(np.int32)); out = torch.zeros(len(hits) * 8, dtype=torch.int32, device="cuda")
+    blocks = (len(hits) + 63) // 64
+    scratch = torch.zeros(blocks * 64 * G.scratch_per_thread, dtype=torch.int32, device="cuda")
+    G.ihits = d_ih.data_ptr(); G.first = 0; G.n = len(hits); G.out = out.data_ptr(); G.scratch = scratch.data_ptr(); G.max_blocks = blocks
+    api._check(L.gbn_launch_gapped(C.byref(G), 1 if greedy else 0, stream()))
+    torch.cuda.synchronize()
+    return out.cpu().numpy().view(api.DEV_GAPPED_DT), G
+
+
+@pytest.mark.parametrize("X_bits,go,ge", [(30, 5, 2), (12, 5, 2), (30, 2, 1), (30, 2, 2)])
+def test_gapped_launcher_dp_equals_the_matrix_definition(X_bits, go, ge):
+    """>= 200 pairs through dynprog_wave_kernel (+ the scratch kernel for the ones it leaves);
+    each extension equals the whole-matrix X-drop definition and the oracle's packed DP"""
+    pairs = dp_pairs(240, 5)
+    assert len(pairs) >= 200
+    opt = api.default_options("blastn", db_length=10**7, db_num_seqs=10, xdrop_gap_bits=float(X_bits))
+    if (go, ge) != (5, 2):
+        opt.reward, opt.penalty, opt.gap_open, opt.gap_extend = 1, -2, go, ge
+    queries = [p[0] for p in pairs]; subjects = [p[1] for p in pairs]
+    hits = [(i, p[2], p[3]) for i, p in enumerate(pairs)]
+    got, G = gapped_through_the_launcher(queries, subjects, hits, opt, greedy=False)
+    assert not (got["score"] == -2**31 + 1).any()           # GBN_GAP_REDO never leaves the launcher
+    long_ones = 0
+    for i, (q, s, qo, so) in enumerate(pairs):
+        want = dp_by_definition(q, s, qo, so, opt.reward, opt.penalty, G.gap_open, G.gap_extend, G.xdrop)
+        o = orc.gapped_extend(q, s, qo, so, G.xdrop, opt.reward, opt.penalty, G.gap_open, G.gap_extend)
+        g = dict(q_offset=int(got[i]["q_start"]), q_end=int(got[i]["q_stop"]), s_offset=int(got[i]["s_start"]),
+                 s_end=int(got[i]["s_stop"]), score=int(got[i]["score"]))
+        assert g == want == o, i
+        long_ones += g["q_end"] - g["q_offset"] > 60
+    assert long_ones >= 50
+
+
+def test_gapped_launcher_greedy_equals_the_oracle():
+    pairs = dp_pairs(220, 6)
+    for kw in (dict(), dict(reward=1, penalty=-2, gap_open=2, gap_extend=2)):
+        opt = api.default_options("megablast", db_length=10**7, db_num_seqs=10, **kw)
+        queries = [p[0] for p in pairs]; subjects = [p[1] for p in pairs]
+        got, G = gapped_through_the_launcher(queries, subjects, [(i, p[2], p[3]) for i, p in enumerate(pairs)], opt, greedy=True)
+        for i, (q, s, qo, so) in enumerate(pairs):
+            o = orc.gapped_extend(q, s, qo, so, G.xdrop, opt.reward, opt.penalty, G.gap_open, G.gap_extend, greedy=True)
+            g = dict(q_offset=int(got[i]["q_start"]), q_end=int(got[i]["q_stop"]), s_offset=int(got[i]["s_start"]),
+                     s_end=int(got[i]["s_stop"]), score=int(got[i]["score"]))
+            assert g == o, (i, kw)
+
+
+def test_search_lists_shard_builder_and_cache():
+    """the library side of the shim: subjects handed over one by one, the shard kept per caller handle, HSPs delivered
+    as one list per subject -- equal to gbn_prelim_search on a shard made the usual way"""
+    L = api.lib()
+    db, queries, plants, subjects, opt = util.small_case(12, 20000, 8, qlen=700, seed=5)
+    sb = C.c_void_p()
+    api._check(L.gbn_shard_builder_new(C.byref(sb), len(subjects)))
+    for p, n in subjects:
+        a = np.ascontiguousarray(p[:(n + 3) // 4])
+        api._check(L.gbn_shard_builder_add(sb, a.ctypes.data, n))
+    h = C.c_void_p()
+    api._check(L.gbn_shard_builder_finish(sb, C.byref(h)))
+    L.gbn_shard_builder_free(sb)
+    key = C.c_void_p(0xBEEF0)
+    assert L.gbn_db_cache_find(key) is None
+    api._check(L.gbn_db_cache_insert(key, h))
+    assert L.gbn_db_cache_insert(key, h) != 0
+    assert L.gbn_db_cache_find(key) == h.value
+
+    ps = api.BlastPrelimSearch(queries, opt)
+    lists = []
+
+    @api.GbnHspListFn
+    def sink(arg, oid, hsps, n):
+        a = np.ctypeslib.as_array(C.cast(hsps, C.POINTER(C.c_uint8)), shape=(n * api.HSP_DT.itemsize,)).view(api.HSP_DT).copy()
+        lists.append((oid, a))
+        return 0
+    d = api.GbnDiagnostics()
+    api._check(L.gbn_prelim_search_lists(ps._b, h, sink, None, C.byref(d), None, None))
+    want = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed(subjects)).run()["hsps"]
+    assert len(want) > 0 and [o for o, _ in lists] == sorted(set(want["oid"].tolist()))
+    got = np.concatenate([a for _, a in lists])
+    assert got.tobytes() == want.tobytes()
+    for oid, a in lists:
+        assert (a["oid"] == oid).all() and (np.diff(a["score"]) <= 0).all()
+
+    @api.GbnHspListFn
+    def failing(arg, oid, hsps, n):
+        return 1
+    assert L.gbn_prelim_search_lists(ps._b, h, failing, None, None, None, None) != 0
+    L.gpu_ReleaseDBMemory()                     # frees the cached shard
+    assert L.gbn_db_cache_find(key) is None
