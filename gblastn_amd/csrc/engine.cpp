@@ -1200,7 +1200,8 @@ int gbn_shard_builder_new(GbnShardBuilder **out, int32_t expected_seqs) {
 }
 int gbn_shard_builder_add(GbnShardBuilder *b, const uint8_t *ncbi2na, int32_t length) {
     if (!b || length < 0 || (length > 0 && !ncbi2na)) { set_error("gbn_shard_builder_add: bad argument"); return GBN_ERR_ARG; }
-    const size_t at = (b->bytes.size() + 15) & ~(size_t)15, nb = ((size_t)length + 3) / 4;
+    const size_t at = std::max<size_t>(16, (b->bytes.size() + 15) & ~(size_t)15), nb      // 16 readable bytes in front of the first subject
+         = ((size_t)length + 3) / 4;
     try { b->bytes.resize(at + nb, 0); b->off.push_back((int64_t)at); b->len.push_back(length); }
     catch (const std::bad_alloc &) { set_error("out of host memory"); return GBN_ERR_NOMEM; }
     if (nb) std::memcpy(b->bytes.data() + at, ncbi2na, nb);

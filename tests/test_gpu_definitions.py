@@ -56,7 +56,7 @@ def scan_order(sd, descending):
 def test_scan_launcher_seeds_equal_the_definition(nq, lut, step):
     sub, queries = seed_case(nq, 40 + nq)
     sub2 = np.random.default_rng(3).integers(0, 4, 9000).astype(np.uint8)
-    sub2[4000:4700] = queries[0][150:850]
+    sub2[4000:4700] = queries[0][150:850] & 3          # (the query's ambiguity code becomes a base: extensions stop there)
     subjects = [sub, sub2]
     opt = api.default_options("megablast", db_length=10**7, db_num_seqs=10)
     src = api.BlastSeqSrc.from_packed([(orc.pack_ncbi2na(s), len(s)) for s in subjects])
@@ -76,7 +76,7 @@ def test_scan_launcher_seeds_equal_the_definition(nq, lut, step):
     assert len(r["seeds"]) == len(sd)
 
 
-@pytest.mark.parametrize("task,nq", [("megablast", 12), ("megablast", 200), ("blastn", 4)])
+@pytest.mark.parametrize("task,nq", [("megablast", 2), ("megablast", 200), ("blastn", 4)])
 def test_ungapped_launcher_equals_the_oracle(task, nq):
     """seeds from the scan launcher, ordered here as gblastn_amd_kernels.h prescribes, through gbn_launch_ungapped:
     the initial hits equal the oracle's word finder (diagonal array for few queries, hash container for many)"""
@@ -87,7 +87,7 @@ def test_ungapped_launcher_equals_the_oracle(task, nq):
     sd, d_seeds, _ = scan_through_the_launcher(ps, src, [n for _, n in subjects])
     hashc, diag_len, desc = C.c_int32(), C.c_int32(), C.c_int32()
     api._check(L.gbn_batch_diag_layout(ps._b, C.byref(hashc), C.byref(diag_len), C.byref(desc)))
-    assert hashc.value == (1 if nq == 200 else 0)
+    assert hashc.value == (1 if nq == 200 else 0)       # CORE/blast_extend.c:85-140: hash container from 8000 query bases up
     order = scan_order(sd, bool(desc.value))
     o = sd[order]
     q0, s0 = o["q_pos"] - o["ext_left"], o["s_scan"] - o["ext_left"]
@@ -129,7 +129,7 @@ def gapped_through_the_launcher(queries, subjects, hits, opt, greedy):
     L = api.lib()
     src = api.BlastSeqSrc.from_packed([(orc.pack_ncbi2na(s), len(s)) for s in subjects])
     ps = api.BlastPrelimSearch(queries, opt, src)
-    ctx = ps.contexts()
+    ctx = ps.contexts
     G = api.GbnGapParams()
     api._check(L.gbn_batch_gap_params(ps._b, src._h, C.byref(G)))
     ih = np.zeros(len(hits), dtype=api.DEV_IHIT_DT)
