@@ -77,12 +77,21 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d" % args.gpus)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = max(torch.cuda.device_count(), 1)
+    dev = torch.device("cuda", local_rank % ndev)
+    torch.cuda.set_device(dev)
+    shared_device = world > ndev
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if shared_device:
+            # more ranks than devices (the builder's one-GPU box): NOT a scaling measurement, only a way to run the
+            # RCCL exchange for real -- RCCL refuses two ranks of one host on one device, so each rank presents
+            # itself as its own host and RCCL connects them through its socket transport (see gblastn_amd/blastn_sharded.py)
+            os.environ.setdefault("NCCL_HOSTID", "gbn-rank-%d" % rank)
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
+            os.environ.setdefault("NCCL_IB_DISABLE", "1")
         dist.init_process_group("nccl", device_id=dev)
-    rc = api.lib().Blast_gpu_Init(1, local_rank)
+    rc = api.lib().Blast_gpu_Init(1, dev.index)
     if rc:
         raise SystemExit("Blast_gpu_Init failed: %s" % api.lib().gbn_last_error().decode())
 
@@ -132,7 +141,7 @@ def main():
 
     from concurrent.futures import ThreadPoolExecutor
     pin = lambda: torch.cuda.set_device(dev)
-    merger = ThreadPoolExecutor(max_workers=1, initializer=pin)
+    merger = shard.Exchange(dev)          # the rank's one ordered channel for collectives: worker thread + its own stream
     setup_pool = ThreadPoolExecutor(max_workers=2, initializer=pin)     # two set-ups in flight
 
     def run_passes(count, diags):
@@ -286,7 +295,8 @@ def main():
                                "lut": info["lut_width"], "scan_step": info["scan_step"],
                                "lut_type": info["lut_type"], "diag_container": info["container"]},
                 "subjects_per_gpu": nsub, "subject_len": slen,
-                "parallelism": "db-shard x%d (volumes by rank, RCCL gather of HSP records)" % world,
+                "parallelism": "db-shard x%d (volumes by rank, RCCL gather of HSP records)%s" % (
+                    world, " -- %d ranks SHARE one device: exchange exercised, not a scaling number" % world if shared_device else ""),
                 "binning_reused_across_batches": bool(args.reuse_binning),
                 "query_batches": "set up from scratch in every step (inside the timed region); nothing reused between steps",
                 "pipeline": "off" if args.no_overlap else

@@ -674,4 +674,40 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
     return GBN_OK;
 }
 
+// Final results of several shards of one database (one gbn_traceback_run per shard, same query batch) -> the
+// results of the whole database: per query the subjects of all parts by (best e-value, best score, oid
+// descending), at most hitlist_size (CORE/blast_hits.c:2757-2788, 3093-3131: the order and the cut the
+// single-shard stage applies).  Edit scripts stay with the parts (ops_first / ops_count are cleared).
+// out must hold the sum of the parts' HSPs; out_query_start nq + 1 offsets.  Returns the number written.
+int64_t gbn_traceback_merge(int32_t nparts, const GbnTbHSP *const *hsps, const int64_t *const *query_start, int32_t nq,
+                            int32_t hitlist_size, GbnTbHSP *out, int64_t *out_query_start)
+{
+    if (nparts < 0 || nq < 0 || !out_query_start || (nparts > 0 && (!hsps || !query_start))) { set_error("gbn_traceback_merge: bad argument"); return -1; }
+    struct List { const GbnTbHSP *first; int64_t n; double best_e; };
+    int64_t w = 0;
+    std::vector<List> lists;
+    for (int32_t qi = 0; qi < nq; qi++) {
+        lists.clear();
+        for (int32_t p = 0; p < nparts; p++) {
+            const int64_t a = query_start[p][qi], e = query_start[p][qi + 1];
+            for (int64_t i = a; i < e;) {
+                int64_t j = i; double be = hsps[p][i].hsp.evalue;
+                while (j < e && hsps[p][j].hsp.oid == hsps[p][i].hsp.oid) { be = std::min(be, hsps[p][j].hsp.evalue); j++; }
+                lists.push_back(List{hsps[p] + i, j - i, be});
+                i = j;
+            }
+        }
+        std::sort(lists.begin(), lists.end(), [](const List &a, const List &c) { return a.first->hsp.oid < c.first->hsp.oid; });
+        std::stable_sort(lists.begin(), lists.end(), [](const List &a, const List &c) {
+            if (int r = fuzzy_order(a.best_e, c.best_e)) return r < 0;
+            if (a.first->hsp.score != c.first->hsp.score) return a.first->hsp.score > c.first->hsp.score;
+            return a.first->hsp.oid > c.first->hsp.oid; });
+        if (hitlist_size > 0 && (int64_t)lists.size() > hitlist_size) lists.resize((size_t)hitlist_size);
+        out_query_start[qi] = w;
+        for (const List &l : lists) for (int64_t i = 0; i < l.n; i++) { out[w] = l.first[i]; out[w].ops_first = 0; out[w].ops_count = 0; w++; }
+    }
+    out_query_start[nq] = w;
+    return w;
+}
+
 }  // extern "C"

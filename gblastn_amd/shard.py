@@ -1,15 +1,23 @@
 """Database sharding across the GPUs of one node.
 
-Subjects (BLAST volumes) are independent work units: each rank keeps its own
-contiguous block of volumes resident in HBM, queries are replicated, every
-rank uses the GLOBAL database length / sequence count for its statistics, and
-global OID = shard base + local OID.  The only exchange is one variable-length
-gather of per-shard preliminary HSP records to rank 0 per query batch
-(counts first, then payload) over torch.distributed -- RCCL on GPUs ("nccl"
-backend), gloo in the CPU tests.  The reference has no counterpart: its
-threads merge through one mutex-guarded BlastHSPStream
-(CORE/blast_hspstream.c:316-365).
+Subjects (BLAST volumes) are independent work units: each rank keeps its own contiguous block of volumes resident in
+HBM, queries are replicated, every rank uses the GLOBAL database length / sequence count for its statistics, and
+global OID = shard base + local OID.  Per query batch the ranks exchange, over torch.distributed -- RCCL on GPUs
+("nccl" backend), gloo in the CPU tests:
+
+  1. a variable-length gather of the per-shard preliminary HSP records to rank 0 (counts first, then payload);
+     rank 0 replays them in ascending OID order through the per-query top-N collector;
+  2. a broadcast of the lists that survived: every rank runs the traceback of ITS subjects (the sequences are in
+     its HBM, the host work spreads over the ranks);
+  3. a gather of the final records; rank 0 merges them per query (gbn_traceback_merge).
+
+Every rank issues these collectives from ONE worker thread in submission order (Exchange), on that thread's own
+device stream, so that they overlap the next batch's preliminary search without ever reordering between ranks.
+The reference has no counterpart: its threads merge through one mutex-guarded BlastHSPStream
+(CORE/blast_hspstream.c:316-365) and map host threads to GPUs (GB/gpu_blast_multi_gpu_utils.cpp:105-139).
 """
+import ctypes as C
+from concurrent.futures import ThreadPoolExecutor
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -22,12 +30,16 @@ def shard_bounds(num_volumes, world_size, rank):
     return lo, lo + base + (1 if rank < extra else 0)
 
 
-def gather_records(records, dst=0, device=None, group=None):
+def _active(group):
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+
+
+def gather_records(records, dst=0, device=None, group=None, force=False):
     """Gather a 1-D structured numpy array from every rank to `dst`.
 
-    Returns the concatenation in rank order on `dst` (ascending global OID when
-    shards are contiguous blocks of OIDs), None elsewhere."""
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    Returns the concatenation in rank order on `dst` (ascending global OID when shards are contiguous blocks of
+    OIDs), None elsewhere.  force: run the collectives even in a group of one (exercises the backend)."""
+    if not (_active(group) or (force and dist.is_initialized())):
         return records
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = device if device is not None else torch.device("cpu")
@@ -50,10 +62,39 @@ def gather_records(records, dst=0, device=None, group=None):
     return None
 
 
+def gather_parts(records, dst=0, device=None, group=None):
+    """as gather_records, but `dst` gets the list of the ranks' arrays"""
+    if not _active(group):
+        return [records]
+    n = np.array([len(records)], dtype=np.int64)
+    counts = gather_records(n, dst=dst, device=device, group=group)
+    cat = gather_records(records, dst=dst, device=device, group=group)
+    if cat is None:
+        return None
+    cut = np.concatenate([[0], np.cumsum(counts)])
+    return [cat[cut[i]:cut[i + 1]] for i in range(len(counts))]
+
+
+def broadcast_records(records, dtype, src=0, device=None, group=None):
+    """A 1-D structured array from `src` to every rank (size first, then payload); `records` is ignored elsewhere."""
+    if not _active(group):
+        return records
+    rank = dist.get_rank(group)
+    dev = device if device is not None else torch.device("cpu")
+    raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1) if rank == src else np.zeros(0, dtype=np.uint8)
+    n = torch.tensor([raw.size], dtype=torch.int64, device=dev)
+    dist.broadcast(n, src=src, group=group)
+    size = int(n.item())
+    buf = torch.from_numpy(raw.copy()).to(dev) if rank == src else torch.zeros(size, dtype=torch.uint8, device=dev)
+    if size:
+        dist.broadcast(buf, src=src, group=group)
+    return buf.cpu().numpy().view(dtype) if size else np.zeros(0, dtype=dtype)
+
+
 def collect_on_root(records, num_queries, hitlist_size, dst=0, device=None, group=None):
-    """One query batch's exchange + merge step: gather every shard's preliminary HSP records to
-    `dst` and replay them there, in ascending global OID order, through the per-query top-N
-    collector (CORE/blast_hspstream.c:316-365 is the reference's merge point).
+    """One query batch's first exchange + merge step: gather every shard's preliminary HSP records to `dst` and
+    replay them there, in ascending global OID order, through the per-query top-N collector (SURVEY.md 8e;
+    CORE/blast_hspstream.c:316-365 is the reference's merge point).
 
     Returns (hsps, list_starts, list_queries) on `dst`, None elsewhere."""
     from . import api
@@ -66,3 +107,160 @@ def collect_on_root(records, num_queries, hitlist_size, dst=0, device=None, grou
         return col.close()
     finally:
         col.free()
+
+
+def merge_final(parts, num_queries, hitlist_size):
+    """parts: [(records TB_DT, query_starts)] of the shards' traceback stages -> (records, query_starts) of the
+    whole database (gbn_traceback_merge: per query by best e-value, best score, oid; at most hitlist_size)"""
+    from . import api
+    L = api.lib()
+    recs = [np.ascontiguousarray(r, dtype=api.TB_DT) for r, _ in parts]
+    qss = [np.ascontiguousarray(q, dtype="<i8") for _, q in parts]
+    n = len(parts)
+    hp = (C.c_void_p * max(n, 1))(*[r.ctypes.data for r in recs]); qp = (C.c_void_p * max(n, 1))(*[q.ctypes.data for q in qss])
+    out = np.zeros(sum(len(r) for r in recs), dtype=api.TB_DT)
+    oqs = np.zeros(num_queries + 1, dtype="<i8")
+    L.gbn_traceback_merge.restype = C.c_int64
+    L.gbn_traceback_merge.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    w = L.gbn_traceback_merge(n, hp, qp, num_queries, hitlist_size, out.ctypes.data, oqs.ctypes.data)
+    if w < 0:
+        raise api.BlastError(L.gbn_last_error().decode())
+    return out[:w], oqs
+
+
+class Exchange:
+    """The one ordered channel a rank uses for its collectives: a single worker thread (FIFO) with its own device
+    stream.  Whatever the main thread does meanwhile (the next batch's kernels run on the engine's own streams),
+    every rank issues the collectives of batch k before those of batch k + 1."""
+
+    def __init__(self, device=None, group=None):
+        self.device, self.group = device, group
+        self.stream = None
+
+        def pin():
+            if device is not None and device.type == "cuda":
+                torch.cuda.set_device(device)
+                self.stream = torch.cuda.Stream(device)
+        self._pool = ThreadPoolExecutor(max_workers=1, initializer=pin)
+
+    def submit(self, fn, *args, **kw):
+        def run():
+            if self.stream is not None:
+                with torch.cuda.stream(self.stream):
+                    r = fn(*args, **kw)
+                    self.stream.synchronize()
+                    return r
+            return fn(*args, **kw)
+        return self._pool.submit(run)
+
+    def close(self):
+        self._pool.shutdown(wait=True)
+
+
+class VolumeShard:
+    """This rank's block of the volumes of a BLAST database (.nal alias or a single volume), resident in HBM, with
+    the statistics of the WHOLE database (BlastSeqSrcGetTotLen / GetNumSeqs span all volumes,
+    GB/gpu_blastn_pre_search_engine.cpp:1242; NSEQ / LENGTH of the alias file win when given)."""
+
+    def __init__(self, name, world_size=1, rank=0, load=True):
+        from . import api
+        self.db = api.BlastDb(name)
+        self.world_size, self.rank = world_size, rank
+        v0, v1 = shard_bounds(self.db.num_volumes, world_size, rank)
+        self.volumes = (v0, v1)
+        if v1 > v0:
+            first, _ = self.db.volume_range(v0)
+            last, n = self.db.volume_range(v1 - 1)
+            self.first_oid, self.num_oids = first, last + n - first
+        else:       # more ranks than volumes: nothing to search here, the rank still takes part in the exchanges
+            self.first_oid, self.num_oids = self.db.num_seqs, 0
+        self.db_length, self.db_num_seqs = self.db.stat_length, self.db.stat_num_seqs
+        self.src = self.db.load_shard(self.first_oid, self.num_oids) if (load and self.num_oids) else None
+
+    def owns(self, oid):
+        return self.first_oid <= oid < self.first_oid + self.num_oids
+
+
+class ShardedSearch:
+    """Query batches against a database sharded by volume: preliminary search and traceback on every rank's own
+    subjects, results of the whole database on rank 0, batch by batch in submission order.
+
+    search / trace are the two local stages -- by default the library's (BlastPrelimSearch / BlastTracebackSearch
+    on shard.src); the gloo tests replace them with record generators to exercise the exchanges without a GPU:
+        search(queries, masks) -> (token, preliminary records HSP_DT grouped by oid)
+        trace(token, hsps, list_starts) -> (records TB_DT, query_starts)"""
+
+    def __init__(self, shard, options, device=None, group=None, trace_threads=0, search=None, trace=None):
+        from . import api
+        self.api, self.shard, self.opt = api, shard, options
+        self.opt.db_length, self.opt.db_num_seqs = shard.db_length, shard.db_num_seqs      # global statistics on every rank
+        self.device, self.group, self.trace_threads = device, group, trace_threads
+        self.ex = Exchange(device, group)
+        self._search = search or self._local_search
+        self._trace = trace or self._local_trace
+        self._pending = []
+
+    # ---- the local stages
+    def _local_search(self, queries, masks):
+        if self.shard.src is None:
+            return None, np.zeros(0, dtype=self.api.HSP_DT)
+        ps = self.api.BlastPrelimSearch(queries, self.opt, self.shard.src, masks=masks)
+        return ps, ps.run()["hsps"]
+
+    def _local_trace(self, ps, hsps, starts):
+        nq = len(ps._q) if ps is not None else 0
+        if ps is None or len(starts) <= 1:
+            return np.zeros(0, dtype=self.api.TB_DT), None
+        tb = self.api.BlastTracebackSearch(ps, self.shard.src)
+        try:
+            rec, _, qs = tb.run(hsps, starts, threads=self.trace_threads)
+        finally:
+            tb.close()
+        return rec, qs
+
+    # ---- the exchanges of one batch (worker thread)
+    def _finish(self, token, local, nq):
+        api, dev, grp = self.api, self.device, self.group
+        got = collect_on_root(local, nq, self.opt.hitlist_size, dst=0, device=dev, group=grp)
+        root = got is not None
+        hsps = broadcast_records(got[0] if root else None, api.HSP_DT, src=0, device=dev, group=grp)
+        starts = broadcast_records(np.asarray(got[1], dtype="<i8") if root else None, np.dtype("<i8"), src=0, device=dev, group=grp)
+        # the lists of this rank's subjects: contiguous, the collector orders lists by (oid, query)
+        if len(starts) > 1:
+            first_oid = hsps["oid"][starts[:-1]]
+            mine = np.nonzero((first_oid >= self.shard.first_oid) & (first_oid < self.shard.first_oid + self.shard.num_oids))[0]
+        else:
+            mine = np.zeros(0, dtype=np.int64)
+        if len(mine):
+            a, b = int(mine[0]), int(mine[-1]) + 1
+            assert b - a == len(mine)
+            sel_h = hsps[starts[a]:starts[b]]; sel_s = starts[a:b + 1] - starts[a]
+        else:
+            sel_h = hsps[:0]; sel_s = np.zeros(1, dtype="<i8")
+        rec, qs = self._trace(token, sel_h, sel_s)
+        if qs is None:
+            qs = np.zeros(nq + 1, dtype="<i8")
+        recs = gather_parts(np.ascontiguousarray(rec, dtype=api.TB_DT), dst=0, device=dev, group=grp)
+        qss = gather_parts(np.ascontiguousarray(qs, dtype="<i8"), dst=0, device=dev, group=grp)
+        if hasattr(token, "close"):
+            token.close()
+        if recs is None:
+            return None
+        return merge_final(list(zip(recs, qss)), nq, self.opt.hitlist_size)
+
+    def submit(self, queries, masks=None, num_queries=None):
+        """preliminary search of this batch now (caller's thread); its exchanges, traceback and merge are queued
+        behind those of the batches before it and overlap whatever the caller does next"""
+        token, local = self._search(queries, masks)
+        fut = self.ex.submit(self._finish, token, local, len(queries) if num_queries is None else num_queries)
+        self._pending.append(fut)
+        return fut
+
+    def results(self):
+        """finished batches in submission order: (records TB_DT, query_starts) on rank 0, None elsewhere"""
+        out = [f.result() for f in self._pending]
+        self._pending = []
+        return out
+
+    def close(self):
+        self.ex.close()

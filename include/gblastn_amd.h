@@ -273,7 +273,9 @@ int  gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag
  * CORE/blast_hspstream.c:136-209,232-300).  Host only.  With several shards, rank 0
  * writes the gathered records of all shards in ascending oid order. ---- */
 typedef struct GbnCollector GbnCollector;
-int32_t gbn_prelim_hitlist_size(int32_t hitlist_size);      /* ---- host pipeline: set-up -> preliminary search -> traceback on their own threads --------------------------
+int32_t gbn_prelim_hitlist_size(int32_t hitlist_size);      /* min(2N, N+50), >= 10 */
+
+/* ---- host pipeline: set-up -> preliminary search -> traceback on their own threads --------------------------
  * (GB/work_thread.cpp:60-156, APP/blastn_app.cpp:725-989 "Method2"; the C++ classes are in gblastn_amd_host.hpp).
  * Query batches are submitted, finished batches come back in submission order. */
 typedef struct GbnPipeline GbnPipeline;
@@ -310,8 +312,13 @@ const GbnTbHSP *gbn_traceback_hsps(const GbnTraceback *t);
 const uint8_t *gbn_traceback_ops(const GbnTraceback *t);
 const int32_t *gbn_traceback_op_lengths(const GbnTraceback *t);
 const int64_t *gbn_traceback_query_starts(const GbnTraceback *t);      /* [num_queries + 1] offsets into hsps */
+/* The final results of several shards of ONE database (a gbn_traceback_run per shard, same query batch, global
+ * statistics) -> the results of the whole database: per query the subjects of all parts in the order above, at most
+ * hitlist_size.  Edit scripts stay with the parts (ops_first / ops_count cleared).  `out`: room for the sum of the
+ * parts' HSPs; out_query_start: nq + 1 offsets.  Returns the number of HSPs written, < 0 on a bad argument. */
+int64_t gbn_traceback_merge(int32_t nparts, const GbnTbHSP *const *hsps, const int64_t *const *query_start, int32_t nq,
+                            int32_t hitlist_size, GbnTbHSP *out, int64_t *out_query_start);
 
-/* min(2N, N+50), >= 10 */
 int  gbn_collector_new(GbnCollector **out, int32_t num_queries, int32_t hitlist_size);
 void gbn_collector_free(GbnCollector *c);
 /* records grouped by oid, each group sorted by score (what gbn_results_hsps yields) */

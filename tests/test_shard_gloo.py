@@ -100,3 +100,126 @@ def test_gather_two_ranks_gloo():
 
 def test_gather_with_an_empty_shard():
     run({"EMPTY_RANK1": "1"})
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the whole per-batch protocol of ShardedSearch (gather -> collector -> broadcast of the surviving lists ->
+# traceback by the owner -> gather -> merge) with record generators in place of the two GPU stages; batches are
+# pipelined through the Exchange thread and must come back in submission order, equal to one rank doing it all
+PROTOCOL_WORKER = r'''
+import os, sys, types
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch.distributed as dist
+from gblastn_amd import shard, api
+world = int(os.environ.get("WORLD_SIZE", "1"))
+import datetime, threading
+if world > 1:
+    dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+r = dist.get_rank() if world > 1 else 0
+NOID = 90
+def excepthook(t, v, tb):                                 # a failed rank must not leave the others waiting
+    import traceback; traceback.print_exception(t, v, tb); sys.stdout.flush(); sys.stderr.flush(); os._exit(1)
+sys.excepthook = excepthook
+
+def make_shard(w, rank):
+    lo, hi = shard.shard_bounds(9, w, rank)               # 9 volumes of 10 subjects
+    return types.SimpleNamespace(first_oid=lo * 10, num_oids=(hi - lo) * 10, db_length=10**9, db_num_seqs=NOID, src=None)
+
+def stages(sh):
+    def search(queries, masks):
+        b, nq = queries                                    # (batch number, number of queries): the test's "queries"
+        rng_all = np.random.default_rng(100 + b)
+        recs = []
+        for oid in range(NOID):                            # every rank draws the same stream, keeps its own subjects
+            k = int(rng_all.integers(0, 4))
+            a = np.zeros(k, dtype=api.HSP_DT)
+            a["oid"] = oid; a["context"] = rng_all.integers(0, 2 * nq, k)
+            a["score"] = np.sort(rng_all.integers(30, 90, k))[::-1]
+            a["q_offset"] = rng_all.integers(0, 50, k); a["q_end"] = a["q_offset"] + 40
+            a["s_offset"] = rng_all.integers(0, 500, k); a["s_end"] = a["s_offset"] + 40
+            a["evalue"] = 10.0 ** (-(a["score"] - 20.0) / 4)
+            if sh.first_oid <= oid < sh.first_oid + sh.num_oids:
+                recs.append(a)
+        return (b, nq), (np.concatenate(recs) if recs else np.zeros(0, dtype=api.HSP_DT))
+    def trace(token, hsps, starts):
+        b, nq = token
+        per_q = [[] for _ in range(nq)]
+        for l in range(len(starts) - 1):
+            for h in hsps[starts[l]:starts[l + 1]]:
+                assert sh.first_oid <= h["oid"] < sh.first_oid + sh.num_oids      # only the owner traces a subject
+                t = np.zeros(1, dtype=api.TB_DT)
+                for f in api.HSP_DT.names:
+                    t[f] = h[f]
+                t["score"] = h["score"] + 1; t["num_ident"] = 39; t["align_length"] = 40; t["bit_score"] = 2.0 * h["score"]
+                per_q[int(h["context"]) // 2].append(t)
+        qs = np.zeros(nq + 1, dtype="<i8"); out = []
+        for q in range(nq):
+            out += per_q[q]; qs[q + 1] = qs[q] + len(per_q[q])
+        return (np.concatenate(out) if out else np.zeros(0, dtype=api.TB_DT)), qs
+    return search, trace
+
+opt = api.default_options("megablast", hitlist_size=6)
+batches = [(0, 3), (1, 7), (2, 1), (3, 5)]
+sh = make_shard(world, r)
+se, tr = stages(sh)
+S = shard.ShardedSearch(sh, opt, search=se, trace=tr)
+for bq in batches:
+    S.submit(bq, num_queries=bq[1])                       # all four in flight behind one another
+res = S.results()
+S.close()
+if r == 0:
+    one = make_shard(1, 0)
+    se1, tr1 = stages(one)
+    for bq, got in zip(batches, res):
+        tok, local = se1(bq, None)
+        col = api.BlastHSPCollector(bq[1], opt.hitlist_size); col.write(local); hs, st, lq = col.close(); col.free()
+        rec, qs = tr1(tok, hs, np.asarray(st, dtype="<i8"))
+        want = shard.merge_final([(rec, qs)], bq[1], opt.hitlist_size)
+        assert np.array_equal(got[1], want[1]), (bq, got[1], want[1])
+        assert got[0].tobytes() == want[0].tobytes(), bq
+        assert len(want[0]) > 0
+        # at most hitlist_size subjects per query, best e-value first
+        for q in range(bq[1]):
+            rows = got[0][got[1][q]:got[1][q + 1]]
+            oids = [int(o) for i, o in enumerate(rows["oid"]) if i == 0 or rows["oid"][i - 1] != o]
+            assert len(oids) == len(set(oids)) <= opt.hitlist_size
+    print("PROTOCOL_OK", world, sum(len(g[0]) for g in res))
+else:
+    assert all(g is None for g in res)
+if world > 1:
+    dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def run_protocol(nproc, port):
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(PROTOCOL_WORKER)
+        path = f.name
+    env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), path, root]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    os.unlink(path)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "PROTOCOL_OK %d" % nproc in p.stdout
+
+
+def test_sharded_search_protocol_two_ranks_gloo():
+    run_protocol(2, 29621)
+
+
+def test_sharded_search_protocol_more_ranks_than_some_volumes_gloo():
+    run_protocol(4, 29623)          # 9 volumes over 4 ranks: 3 + 2 + 2 + 2
+
+
+def test_volume_shards_cover_the_database():
+    from gblastn_amd import api
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "two_vols")
+    parts = [shard.VolumeShard(G, 2, r, load=False) for r in range(2)]
+    assert [(p.first_oid, p.num_oids) for p in parts] == [(0, 2004), (2004, 1)]
+    assert all((p.db_length, p.db_num_seqs) == (947242, 2005) for p in parts)      # NSEQ / LENGTH of the alias: global
+    three = [shard.VolumeShard(G, 3, r, load=False) for r in range(3)]
+    assert [p.num_oids for p in three] == [2004, 1, 0] and three[2].src is None
+    assert parts[0].owns(2003) and not parts[0].owns(2004) and parts[1].owns(2004)
