@@ -984,11 +984,14 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     }
     G.scratch = E.gap_scratch_s[slot];
     G.first = 0; G.n = (int64_t)nih; G.max_blocks = (int32_t)blocks;
-    if (getenv("GBN_DP_STATS")) HIPCHK(hipMemsetAsync(G.scratch, 0, 64, st));
+    if (getenv("GBN_DP_STATS")) HIPCHK(hipMemsetAsync(G.scratch, 0, 256, st));
     HIPCHK(launch_gapped(G, b.opt.greedy != 0, st));
-    if (getenv("GBN_DP_STATS")) {
-        unsigned long long c[5]; HIPCHK(hipMemcpyAsync(c, G.scratch, 40, hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
+    if (getenv("GBN_DP_STATS")) {       // (-DGBN_DP_STATS=1 builds only)
+        unsigned long long c[24]; HIPCHK(hipMemcpyAsync(c, G.scratch, sizeof(c), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
         fprintf(stderr, "[gbn dbg] wave DP: %llu extensions (%llu left to the scratch kernel), %llu rows, %llu rounds, mean window %.1f\n", c[2], c[3], c[0], c[1], c[0] ? (double)c[4] / c[0] : 0.0);
+        fprintf(stderr, "[gbn dbg]   rows by window / 8:"); for (int k = 0; k < 8; k++) fprintf(stderr, " %llu", c[8 + k]);
+        fprintf(stderr, "\n[gbn dbg]   extensions by widest window / 8:"); for (int k = 0; k < 8; k++) fprintf(stderr, " %llu", c[16 + k]);
+        fprintf(stderr, "\n");
     }
     std::vector<GbnDevInitHit> hih((size_t)nih); std::vector<GbnDevGapped> hg((size_t)nih);
     HIPCHK(hipMemcpyAsync(hih.data(), E.ihits_s[slot], (size_t)nih * sizeof(GbnDevInitHit), hipMemcpyDeviceToHost, st));

@@ -944,7 +944,7 @@ __device__ __forceinline__ int32_t lane_below(int32_t v) { return __builtin_amdg
 
 __device__ int32_t align_packed_wave(const GbnGapParams &P, const uint8_t *q, const uint8_t *subj,
                                      int32_t q0, int32_t s0, int32_t N, int32_t M, int32_t *b_off, int32_t *a_off,
-                                     bool reverse, int *redo)
+                                     bool reverse, int *redo, int32_t *maxw_stat = nullptr)
 {
     const int lane = (int)(threadIdx.x & 63);
     const int32_t gap_extend = P.gap_extend, goe = P.gap_open + P.gap_extend;
@@ -1014,7 +1014,9 @@ __device__ int32_t align_packed_wave(const GbnGapParams &P, const uint8_t *q, co
             km = km2;
         }
 #if GBN_DP_STATS
-        if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch), 1ull); atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 4, (unsigned long long)(b_size - first_b)); }
+        if (lane == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch), 1ull); atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 4, (unsigned long long)(b_size - first_b));
+            const int wd = b_size - first_b; atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 8 + min(wd / 8, 7), 1ull);
+            if (maxw_stat && wd > *maxw_stat) *maxw_stat = wd; }
 #endif
         if (Stot > best_score) {
             best_score = Stot; *a_off = a;
@@ -1078,16 +1080,18 @@ __device__ void dynprog_hit_wave(const GbnGapParams &P, int64_t i)
     if (q_length > qlen || s_length > slen) { q_length -= 4; s_length -= 4; }
     int32_t pq, ps;
     GbnDevGapped g; g.context = lo; g.seed_q = q_off; g.seed_s = s_off;
-    const int32_t left = align_packed_wave(P, q, subj, 0, 0, q_length, s_length, &pq, &ps, true, &redo);
+    int32_t maxw = 0;
+    const int32_t left = align_packed_wave(P, q, subj, 0, 0, q_length, s_length, &pq, &ps, true, &redo, &maxw);
     g.q_start = q_length - pq; g.s_start = s_length - ps;
     int32_t right = 0;
     if (!redo && q_length < qlen && s_length < slen) {
-        right = align_packed_wave(P, q, subj, q_length, s_length, qlen - q_length, slen - s_length, &pq, &ps, false, &redo);
+        right = align_packed_wave(P, q, subj, q_length, s_length, qlen - q_length, slen - s_length, &pq, &ps, false, &redo, &maxw);
         g.q_stop = pq + q_length; g.s_stop = ps + s_length;
     } else { g.q_stop = q_length; g.s_stop = s_length; }
     g.score = redo ? GBN_GAP_REDO : left + right;
 #if GBN_DP_STATS
-    if ((threadIdx.x & 63) == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 2, 1ull); if (redo) atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 3, 1ull); }
+    if ((threadIdx.x & 63) == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 2, 1ull); if (redo) atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 3, 1ull);
+        atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 16 + min(maxw / 8, 7), 1ull); }
 #endif
     if ((threadIdx.x & 63) == 0) P.out[P.first + i] = g;
 }
@@ -1096,7 +1100,279 @@ __device__ void dynprog_hit_wave(const GbnGapParams &P, int64_t i)
 extern "C" __global__ void __launch_bounds__(256) dynprog_wave_kernel(GbnGapParams P)
 {
     const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t i = wave; i < P.n; i += nwaves) dynprog_hit_wave(P, i);
+    for (int64_t i = wave; i < P.n; i += nwaves) {
+        if (P.redo_only && P.out[P.first + i].score != GBN_GAP_REDO) continue;     // after dynprog_lane_kernel: what it left
+        dynprog_hit_wave(P, i);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// The same extension once more, one extension per LANE: the reference's own sequential walk of a row
+// (CORE/blast_gapalign.c:2957-3052) as a per-lane state machine, every lane of a wave on an extension of its own.
+// What makes the thread-per-extension form slow in dynprog_kernel -- the band in scratch memory, rows of different
+// lengths in lock step -- is avoided: the band {best, best_gap} and the column's four match scores live in LDS
+// (a circular window of GBN_LANE_W columns per lane), one loop iteration is one CELL of whatever row the lane is
+// in (or one column appended at the end of a row), and a lane that finishes its extension takes the next one from
+// a counter -- no lane waits for its neighbours' rows.  The chance hits that make up the blastn workload (some
+// 40 rows of 20 columns either side) keep all 64 lanes busy; an extension whose window outgrows the LDS slots or
+// that runs longer than GBN_LANE_ROWS rows in one direction (a real homolog: better on a whole wave) is left to
+// dynprog_wave_kernel (GBN_GAP_REDO).  Global loads never sit in the cell loop: query letters arrive through a
+// four-deep FIFO ahead of the window's right edge, subject bases 16 at a time with the next word in flight, and
+// the set-up of new work (hit, context, first letters) is done for several lanes at once.
+// ---------------------------------------------------------------------------------------------------
+#ifndef GBN_LANE_W
+#define GBN_LANE_W 32
+#endif
+#ifndef GBN_LANE_ROWS
+#define GBN_LANE_ROWS 192
+#endif
+#ifndef GBN_LANE_BATCH
+#define GBN_LANE_BATCH 8            // lanes waiting for set-up before the (long-latency) set-up code runs
+#endif
+
+// context of every initial hit, found once by a thread of its own (a binary search = a chain of dependent loads)
+extern "C" __global__ void gap_context_kernel(GbnGapParams P, int32_t *ctx_of)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= P.n) return;
+    const int32_t q_off = P.ihits[P.first + i].q_off;
+    int lo = 0, hi = P.nctx;
+    while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > q_off) hi = m; else lo = m; }
+    ctx_of[i] = lo;
+}
+
+extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParams P, unsigned long long *counter, const int32_t *ctx_of)
+{
+    constexpr int W = GBN_LANE_W;
+    constexpr int32_t NEG = GBN_MININT;
+    enum { RUN = 0, START = 1, DONE = 2 };
+    __shared__ int2 s_cell[W][64];              // {best, best_gap} of column c at [c mod W][lane]
+    __shared__ uint8_t s_let[W][64];            // its query letter
+    __shared__ uint32_t s_pm[16];               // per query letter: the match scores against the four subject bases, a byte each (-128: the sentinel's NEG)
+    const int lane = threadIdx.x;
+    if (lane < 16) {
+        uint32_t v = 0;
+        for (int t = 0; t < 4; t++) { const int32_t m = P.matrix[t * 16 + lane]; v |= (uint32_t)((m < -127 ? -128 : m) & 0xff) << (8 * t); }
+        s_pm[lane] = v;
+    }
+    __syncthreads();
+    const int32_t ge = P.gap_extend, goe = P.gap_open + P.gap_extend;
+    const int32_t x = P.xdrop < goe ? goe : P.xdrop;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+
+    // ---- per-lane state
+    int mode = START;
+    bool need_new = true, reverse = false, row0 = false;
+    int est = 2;                                                      // the row's end: 0 the gap run goes on, 1 the sentinel column is due, 2 nothing (left) to do
+    int64_t i = -1;
+    const uint8_t *q = P.q8; const uint32_t *sp = reinterpret_cast<const uint32_t *>(P.db);   // context's query, subject (as words); always readable
+    int32_t qlen = 0, slen = 0, q_length = 0, s_length = 0, ctx = 0, seed_q = 0, seed_s = 0, left_score = 0, g_q_start = 0, g_s_start = 0;
+    const uint8_t *qp = P.q8; int32_t qs = 1;                         // letter of column c = qp[qs * c]
+    int32_t s0 = 0, N = 0, M = 0;
+    int32_t a = 0, first_b = 0, b_size = 0, hw = 0;
+    int fix = 0, six = 0;                                             // first_b, b_size modulo W
+    int32_t best_score = 0, a_off = 0, b_off = 0, sgr = NEG;
+    // Global loads are issued once per round of the loop below by all lanes at once and taken over a round later,
+    // when they have long arrived: nothing in between waits on memory.  Letters of the columns hw .. hw + ln - 1
+    // wait in `lq` (4 bits each), eight more are fetched when eight or fewer are left; the subject word after the
+    // one in use is fetched as soon as that one is taken.
+    unsigned long long lq = 0; int ln = 0;
+    uint32_t pb[8]; bool pend_l = false;
+    uint32_t sw = 0, swn = 0, pw = 0; int32_t wi = 0, wmax = 0; bool have_next = false, pend_w = false;
+    auto inc = [](int v) { return (W & (W - 1)) == 0 ? ((v + 1) & (W - 1)) : (v + 1 == W ? 0 : v + 1); };
+    auto letter_at = [&](int32_t c) -> uint32_t { return qp[(int64_t)qs * max(min(c, N), 0)]; };
+    auto subject_word = [&](int32_t w) -> uint32_t { return sp[min(max(w, 0), wmax)]; };
+
+    // One round = one subject row of every running lane, in three phases the lanes go through together:
+    //   rows begin (or a half ends) -> the cells of the row, as many steps as the widest window of the wave has
+    //   columns -> the row's end: the horizontal gap runs on, one column per step, and the sentinel column.
+    for (;;) {
+        const unsigned long long m_start = __ballot(mode == START), m_run = __ballot(mode == RUN);
+        if (!m_start && !m_run) break;                                 // every lane is DONE
+
+        // ---------------- set-up: a new extension (left half) or the right half of the current one
+        if (m_start && (__popcll(m_start) >= GBN_LANE_BATCH || !m_run)) {
+            const unsigned long long m_new = __ballot(mode == START && need_new);
+            unsigned long long base = 0;
+            if (m_new) {
+                if (lane == (int)__builtin_ctzll(m_new)) base = atomicAdd(counter, (unsigned long long)__popcll(m_new));
+                base = __shfl(base, (int)__builtin_ctzll(m_new));
+            }
+            if (mode == START) {
+                bool go = true;
+                if (need_new) {
+                    i = (int64_t)(base + (unsigned long long)__popcll(m_new & lt));
+                    if (i >= P.n) { mode = DONE; go = false; }
+                    else {
+                        const GbnDevInitHit h = P.ihits[P.first + i];
+                        ctx = ctx_of[i];
+                        const int32_t qstart = P.ctx_off[ctx];
+                        qlen = P.ctx_len[ctx]; slen = P.len[h.subj];
+                        q = P.q8 + qstart; sp = reinterpret_cast<const uint32_t *>(P.db + P.byte_off[h.subj]);
+                        wmax = max(slen - 1, 0) >> 4;
+                        int32_t q_off = h.q_off - qstart, s_off = h.s_off;
+                        if (h.s_start + h.length >= s_off + 8) { s_off += 3; q_off += 3; }      // CORE/blast_gapalign.c:3494-3497
+                        const int32_t adj = 4 - (s_off & 3);
+                        q_length = q_off + adj; s_length = s_off + adj;
+                        if (q_length > qlen || s_length > slen) { q_length -= 4; s_length -= 4; }
+                        seed_q = q_off; seed_s = s_off;
+                        reverse = true; N = q_length; M = s_length; s0 = 0; qp = q + N - 1; qs = -1;
+                    }
+                } else {
+                    reverse = false; N = qlen - q_length; M = slen - s_length; s0 = s_length; qp = q + q_length; qs = 1;
+                }
+                if (go) {
+                    best_score = 0; a_off = 0; b_off = 0; pend_l = false; pend_w = false;
+                    mode = RUN;
+                    if (N <= 0 || M <= 0) {
+                        a = M; first_b = 0; b_size = 0; row0 = false; est = 2; sgr = NEG; ln = 16;      // nothing to align on this side: over at the next row begin
+                    } else {
+                        a = 0; first_b = 0; fix = 0; b_size = 1; six = 1; hw = 1;
+                        lq = 0;
+                        #pragma unroll
+                        for (int k = 0; k < 16; k++) lq |= (unsigned long long)(letter_at(k) & 15u) << (4 * k);
+                        s_cell[0][lane] = make_int2(0, -goe);
+                        s_let[0][lane] = (uint8_t)(lq & 15u);
+                        lq >>= 4; ln = 15;
+                        const int32_t pos1 = reverse ? (M - 1) : s0;      // row 1's base
+                        wi = pos1 >> 4; sw = subject_word(wi); swn = subject_word(wi + (reverse ? -1 : 1)); have_next = true;
+                        sgr = -goe; row0 = true; est = 0;                   // row 0 = a gap run from column 1 on, no sentinel
+                    }
+                }
+            }
+            // nothing of the set-up stays in flight: a load left pending into a register the row code reads makes
+            // that code wait for whatever else is outstanding, the loads of the memory point included
+            __builtin_amdgcn_s_waitcnt(0x0f70);                         // vmcnt(0)
+        }
+
+        // ---------------- the memory point: take over last round's loads, issue this round's
+        {
+            if (pend_l) {
+                uint32_t add = 0;
+                #pragma unroll
+                for (int k = 0; k < 8; k++) add |= (pb[k] & 15u) << (4 * k);
+                lq |= (unsigned long long)add << (4 * ln); ln += 8; pend_l = false;
+            }
+            if (pend_w) { swn = pw; have_next = true; pend_w = false; }
+            // every lane loads (clamped, always valid addresses): a conditional load ends in a register copy behind
+            // it and with that in a wait right here; the flags say whose results count
+            pend_l = mode == RUN && ln <= 8; pend_w = mode == RUN && !have_next;
+            const int32_t c0 = hw + ln;
+            #pragma unroll
+            for (int k = 0; k < 8; k++) pb[k] = letter_at(c0 + k);
+            pw = subject_word(wi + (reverse ? -1 : 1));
+        }
+
+        // ---------------- rows begin
+        bool over = false, redo = false;
+        int32_t width = 0; int ab = 0;
+        bool in_row = false;                                            // this lane walks a row in this round
+        if (mode == RUN && est == 2) {
+            const int32_t an = a + 1;
+            if (an > M) over = true;
+            else if (an > GBN_LANE_ROWS) { over = true; redo = true; }  // a long one: a whole wave does it faster
+            else {
+                const int32_t pos = reverse ? (M - an) : (s0 + an - 1);
+                const int32_t w = pos >> 4;
+                bool ready = true;
+                if (w != wi) {
+                    if (have_next) { sw = swn; wi = w; have_next = false; } else ready = false;      // (not yet: next round)
+                }
+                if (ready) {
+                    a = an; in_row = true; width = b_size - first_b;
+                    ab = (int)((sw >> (8 * ((pos >> 2) & 3) + 6 - 2 * (pos & 3))) & 3u);
+                }
+            }
+        }
+
+        // ---------------- the cells of the row (CORE/blast_gapalign.c:2957-3020): as many steps as the widest window
+        // of the wave has columns
+        int32_t last_b = first_b; int lix = fix;
+        {
+            const int32_t reward = P.reward, penalty = P.penalty;
+            int32_t sc = NEG, b = first_b; int ix = fix;
+            if (in_row) sgr = NEG;
+            // (straight-line selects: the divergent if / else of the reference's loop body costs three times the
+            // instructions once the compiler has structurized it)
+            int2 c = s_cell[ix][lane]; uint32_t letter = s_let[ix][lane];
+            for (int32_t t = 0; t < width; t++) {                       // (a lane leaves the loop after its last column)
+                {
+                    // the next column's cell is on its way while this one is worked on (its slot is not written here)
+                    const int ixn = inc(ix);
+                    const int2 cn = s_cell[ixn][lane]; const uint32_t letter_n = s_let[ixn][lane];
+                    int32_t msel = (int)letter == ab ? reward : penalty;
+                    if (__ballot(letter >= 4u)) {                       // ambiguity codes, the sentinel: from the matrix
+                        const uint32_t mm = s_pm[letter];
+                        int32_t m2 = (int32_t)(int8_t)(mm >> (8 * ab));
+                        m2 = m2 == -128 ? NEG : m2;
+                        msel = letter >= 4u ? m2 : msel;
+                    }
+                    const int32_t next = c.x + msel;
+                    sc = max(sc, max(c.y, sgr));
+                    const bool keep = !(best_score - sc > x);
+                    const bool drop_first = !keep && b == first_b;
+                    const bool better = keep && sc > best_score;
+                    const int32_t open = sc - goe;
+                    s_cell[ix][lane] = make_int2(keep ? sc : NEG, keep ? max(open, c.y - ge) : c.y);   // (a failed first column leaves the window: what is stored there does not matter)
+                    sgr = keep ? max(open, sgr - ge) : sgr;
+                    last_b = keep ? b : last_b; lix = keep ? ix : lix;
+                    best_score = better ? sc : best_score; a_off = better ? a : a_off; b_off = better ? b : b_off;
+                    first_b += drop_first ? 1 : 0; fix = drop_first ? inc(fix) : fix;
+                    sc = next; b++; ix = ixn; c = cn; letter = letter_n;
+                }
+            }
+        }
+
+        // ---------------- the row's end (CORE/blast_gapalign.c:3022-3052): every column failed -> the half is over;
+        // the window shrinks, or the horizontal gap runs on past it, one column per step; then the sentinel column
+        if (in_row) {
+            if (first_b == b_size) over = true;
+            else {
+                if (last_b < b_size - 1) { b_size = last_b + 1; six = inc(lix); sgr = NEG; }
+                est = 0;
+            }
+        }
+        for (;;) {
+            const bool more = sgr >= best_score - x && b_size <= N;
+            est = (est == 0 && !more) ? ((!row0 && b_size <= N) ? 1 : 2) : est;
+            // column c lives in slot c mod W: [first_b, max(b_size, hw)) must stay within W columns
+            const bool full = est < 2 && max(b_size + 1, hw) - first_b > W;       // no slot left: leave it to the wave kernel
+            over = over || full; redo = redo || full; est = full ? 2 : est;
+            const bool fresh = b_size == hw;
+            const bool step = est < 2 && !(fresh && ln == 0);           // (its letter has not arrived yet: next round)
+            if (!__ballot(step)) break;
+            if (step) {
+                s_cell[six][lane] = est == 0 ? make_int2(sgr, sgr - goe) : make_int2(NEG, NEG);
+                if (fresh) { s_let[six][lane] = (uint8_t)(lq & 15u); lq >>= 4; ln--; hw++; }
+                sgr -= ge; b_size++; six = inc(six);
+                est = est == 1 ? 2 : est;
+            }
+        }
+        if (est == 2) row0 = false;
+
+        // ---------------- a half is over
+        if (over) {
+            est = 2;
+            if (redo) {                                                 // given up: dynprog_wave_kernel redoes the whole extension
+                P.out[P.first + i].score = GBN_GAP_REDO;
+                need_new = true; mode = START;
+            } else if (reverse) {
+                left_score = best_score; g_q_start = q_length - b_off; g_s_start = s_length - a_off;
+                if (q_length < qlen && s_length < slen) { need_new = false; mode = START; }
+                else {
+                    GbnDevGapped g; g.q_start = g_q_start; g.s_start = g_s_start; g.q_stop = q_length; g.s_stop = s_length;
+                    g.score = left_score; g.seed_q = seed_q; g.seed_s = seed_s; g.context = ctx;
+                    P.out[P.first + i] = g;
+                    need_new = true; mode = START;
+                }
+            } else {
+                GbnDevGapped g; g.q_start = g_q_start; g.s_start = g_s_start; g.q_stop = b_off + q_length; g.s_stop = a_off + s_length;
+                g.score = left_score + best_score; g.seed_q = seed_q; g.seed_s = seed_s; g.context = ctx;
+                P.out[P.first + i] = g;
+                need_new = true; mode = START;
+            }
+        }
+    }
 }
 
 // ---------------------------------------------------------------------------
@@ -1176,11 +1452,29 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
     const int64_t need = (p.n + 63) / 64;
     const unsigned blocks = (unsigned)std::max<int64_t>(1, p.max_blocks > 0 ? std::min<int64_t>(need, p.max_blocks) : need);
     if (greedy) { hipLaunchKernelGGL(greedy_kernel, dim3(blocks), dim3(64), 0, st, p); return hipGetLastError(); }
-    // blastn: one extension per wave with the band in registers; the few it leaves (GBN_GAP_REDO: a band wider
-    // than a wave, gap_extend 0) go through the thread-per-extension kernel with its band in scratch memory
+    // blastn, three kernels: one extension per LANE with the band in LDS (dynprog_lane_kernel: the many short
+    // extensions of chance hits); what it leaves (GBN_GAP_REDO: a window wider than its LDS slots, a long run) one
+    // extension per WAVE with the band in registers; what that leaves (a band wider than a wave, gap_extend 0) the
+    // thread-per-extension kernel with its band in scratch memory.  GBN_GAP_LANE=0: start with the wave kernel.
     if (!p.redo_only) {
+        static const bool lane_on = !(getenv("GBN_GAP_LANE") && atoi(getenv("GBN_GAP_LANE")) == 0);
+        const bool lane = lane_on && p.gap_extend > 0 && std::abs(p.reward) <= 127 && std::abs(p.penalty) <= 127 &&
+                          (int64_t)p.scratch_per_thread * 64 * blocks >= p.n + 16;
+        GbnGapParams w = p;
+        if (lane) {
+            // scratch: [0, 1] the work counter, [16, 16 + n) the context of every hit (the third kernel reuses it later)
+            hipError_t e = hipMemsetAsync(p.scratch, 0, 16 * sizeof(int32_t), st);
+            if (e != hipSuccess) return e;
+            int32_t *ctx_of = p.scratch + 16;
+            hipLaunchKernelGGL(gap_context_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p, ctx_of);
+            const int64_t lblocks = std::max<int64_t>(1, std::min<int64_t>(need, p.max_blocks > 0 ? std::max(1, p.max_blocks / 3) : need));   // 8 of its workgroups fit a CU (LDS)
+            hipLaunchKernelGGL(dynprog_lane_kernel, dim3((unsigned)lblocks), dim3(64), 0, st, p, reinterpret_cast<unsigned long long *>(p.scratch), ctx_of);
+            e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            w.redo_only = 1;
+        }
         const int64_t wblocks = std::max<int64_t>(1, std::min<int64_t>((p.n + 3) / 4, p.max_blocks > 0 ? (int64_t)p.max_blocks * 2 : (p.n + 3) / 4));
-        hipLaunchKernelGGL(dynprog_wave_kernel, dim3((unsigned)wblocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(dynprog_wave_kernel, dim3((unsigned)wblocks), dim3(256), 0, st, w);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
