@@ -53,6 +53,7 @@ void trace_mark(const char *what) {
 #define HIPCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return GBN_ERR_HIP; } } while (0)
 
+constexpr int kCtxHintShift = 6;
 struct DeviceBatch {
     uint8_t *q8_base = nullptr;     // device copy of qbuf
     const uint8_t *q8 = nullptr;    // q8_base + qpad
@@ -62,7 +63,7 @@ struct DeviceBatch {
     uint16_t *sidet = nullptr;
     unsigned long long *ent = nullptr;
     int32_t *ctx_off = nullptr, *ctx_len = nullptr, *ctx_xdrop = nullptr, *ctx_cutoff = nullptr,
-            *ctx_reduced = nullptr;
+            *ctx_reduced = nullptr, *ctx_hint = nullptr;    // ctx_hint[q >> kCtxHintShift]: the context position (q & ~mask) lies in
     int32_t *matrix = nullptr, *score_table = nullptr;
     int mode = 0, fl = 0, fr = 0;
     // lookup structures still being built on the builder's stream: the event they are complete at, and the
@@ -77,6 +78,7 @@ struct Engine {
     GbnDevSeed *seeds = nullptr; size_t seed_cap = 0;
     uint64_t *key_a = nullptr, *key_b = nullptr; uint32_t *idx_a = nullptr, *idx_b = nullptr;
     int32_t *cell_diag = nullptr, *cell_level = nullptr; size_t key_cap = 0;
+    int32_t *ext_rec = nullptr;     // 8 ints per seed: seed_ext_kernel -> diag_replay_kernel
     void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
     // initial hits / gapped extensions / gapped scratch exist twice: the gapped stage of one range
     // (stream2 + a host thread) overlaps the scan of the next range or query batch
@@ -191,7 +193,7 @@ void free_device_batch(DeviceBatch *d) {
     finish_build(d);
     dev_free(d->q8_base); dev_free(d->q2_base); dev_free(d->qinv_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent);
     dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff);
-    dev_free(d->ctx_reduced); dev_free(d->matrix); dev_free(d->score_table);
+    dev_free(d->ctx_reduced); dev_free(d->ctx_hint); dev_free(d->matrix); dev_free(d->score_table);
     delete d;
 }
 
@@ -433,6 +435,16 @@ int upload_batch(GbnBatch &b) {
     if ((rc = dev_alloc(d->ctx_cutoff, off.size()))) return rc;
     if ((rc = dev_alloc(d->ctx_reduced, off.size()))) return rc;
     if ((rc = upload_ctx_cutoffs(b))) return rc;
+    {   // context of every kCtxHintShift-aligned query position (the kernels walk on from there: contexts are rarely shorter)
+        std::vector<int32_t> hint(((size_t)b.qlen >> kCtxHintShift) + 2);
+        size_t c = 0;
+        for (size_t k = 0; k < hint.size(); k++) {
+            const int64_t qpos = (int64_t)k << kCtxHintShift;
+            while (c + 1 < off.size() && off[c + 1] <= qpos) c++;
+            hint[k] = (int32_t)c;
+        }
+        if ((rc = dev_upload(d->ctx_hint, hint.data(), hint.size()))) return rc;
+    }
     if ((rc = dev_upload(d->matrix, &b.matrix[0][0], 256))) return rc;
     if ((rc = dev_upload(d->score_table, b.score_table, 256))) return rc;
     trace_mark("upload: done");
@@ -498,12 +510,14 @@ static int grow_seed_buffers(size_t want) {
 static int grow_key_buffers(size_t n) {
     if (n <= E.key_cap) return GBN_OK;
     dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
-    dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.sort_tmp);
+    dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.ext_rec); dev_free(E.sort_tmp);
     size_t cap = std::max<size_t>(n, 1 << 16);
     int rc;
     if ((rc = dev_alloc(E.key_a, cap)) || (rc = dev_alloc(E.key_b, cap)) || (rc = dev_alloc(E.idx_a, cap)) ||
         (rc = dev_alloc(E.idx_b, cap)) || (rc = dev_alloc(E.cell_diag, cap)) || (rc = dev_alloc(E.cell_level, cap)))
         return rc;
+    static const size_t compact_min = getenv("GBN_DIAG_COMPACT_MIN") ? (size_t)atoll(getenv("GBN_DIAG_COMPACT_MIN")) : (size_t)GBN_DIAG_COMPACT_MIN;
+    if (cap >= compact_min && (rc = dev_alloc(E.ext_rec, cap * 8))) return rc;
     size_t bytes = 0;
     HIPCHK(sort_pairs_u64(nullptr, bytes, E.key_a, E.key_b, E.idx_a, E.idx_b, (int64_t)cap, 64, E.stream));
     HIPCHK(pool_alloc(&E.sort_tmp, bytes));
@@ -844,6 +858,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         X.cell_start = d->cell_start; X.ent = d->ent; X.cell_mask = (uint32_t)(b.lut.ncells - 1); X.lut = b.lut.lut;
         X.masked = b.lut.masked ? 1 : 0;
         X.run_heads = E.idx_b; X.run_count = reinterpret_cast<uint32_t *>(ctr + 1); X.group_bits = K.group_bits;
+        X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = E.ext_rec;
         X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
         HIPCHK(launch_diag_ungapped(X, st));
         HIPCHK(hipMemcpyAsync(&nih, ctr, sizeof(nih), hipMemcpyDeviceToHost, st));
@@ -1175,7 +1190,7 @@ void Blast_gpu_Release(void) {
     g_binkey.valid = false;
     dev_free(E.seeds_async); E.seeds_async_cap = 0; if (E.ev_seed) { (void)hipEventDestroy(E.ev_seed); E.ev_seed = nullptr; }
     dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
-    dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.sort_tmp); for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
+    dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.ext_rec); dev_free(E.sort_tmp); for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
     dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_tcur); E.bin_tcur_cap = 0; dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
     E.bin_rec_cap = 0; E.bin_count_cap = 0;
     E.seed_cap = E.key_cap = 0;
@@ -1330,6 +1345,7 @@ int gbn_batch_ext_params(const GbnBatch *b, const GbnDb *db, GbnExtParams *X) {
     X->word = b->lut.word; X->container_hash = b->container;
     X->cell_start = d->cell_start; X->ent = d->ent; X->cell_mask = (uint32_t)(b->lut.ncells - 1); X->lut = b->lut.lut;
     X->masked = b->lut.masked ? 1 : 0;
+    X->ctx_hint = d->ctx_hint; X->ctx_hint_shift = kCtxHintShift;
     return GBN_OK;
 }
 int gbn_batch_gap_params(const GbnBatch *b, const GbnDb *db, GbnGapParams *G) {

@@ -534,6 +534,143 @@ extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The same stage for many seeds (blastn word sizes: ~10 M seeds per launch, ~18 per run with the hash container),
+// in two kernels.  What a seed's ungapped extension yields does not depend on the container's state -- only
+// whether it is looked at does -- so seed_ext_kernel extends EVERY seed, a thread each (the memory latency of the
+// extension's gathers hidden by ten million threads instead of sitting in the 18-step chain of a run), and
+// diag_replay_kernel walks the runs over the finished records: per seed a sequential read, the container update
+// and nothing else.  (~20 % of the extensions are of seeds the replay then skips.)
+// ---------------------------------------------------------------------------------------------------
+struct GbnSeedExt { int32_t q_off, s_off, s_orig, q_start, s_start, length, score, flags; };    // flags: 1 = dropped by the mask re-check, 2 = reaches the cutoff, [31:8] = bases the re-check added on the right
+
+__device__ __forceinline__ int context_of(const GbnExtParams &P, int32_t q)
+{
+    int lo;
+    if (P.ctx_hint) { lo = P.ctx_hint[q >> P.ctx_hint_shift]; while (lo + 1 < P.nctx && P.ctx_off[lo + 1] <= q) lo++; }
+    else { lo = 0; int hi = P.nctx; while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > q) hi = m; else lo = m; } }
+    return lo;
+}
+
+extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P)
+{
+    const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= P.n) return;
+    const int32_t subj_id = (int32_t)(P.key_group[j] >> (P.group_bits ? P.group_bits : 32));
+    const GbnDevSeed sd = P.seeds[P.idx[j]];
+    const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
+    const int32_t slen = P.len[subj_id];
+    GbnSeedExt r;
+    int32_t q_off = sd.q_pos - sd.ext_left, s_off = sd.s_scan - sd.ext_left;
+    r.s_orig = s_off; r.flags = 0; r.q_start = 0; r.s_start = 0; r.length = 0; r.score = 0;
+    int32_t s_match_end = s_off + P.word;
+    bool ok = true;
+    if (P.masked) {                                     // without masks s_TypeOfWord changes nothing
+        int32_t extended;
+        ok = type_of_word(P, subj, slen, q_off, s_off, extended);
+        s_match_end += extended; r.flags = ok ? (extended << 8) : 1;
+    }
+    if (ok) {
+        const int lo = context_of(P, q_off);
+        Ungapped u;
+        if (!P.container_hash && P.word < 11) ungapped_exact(P, subj, slen, q_off, s_off, -P.ctx_xdrop[lo], u);
+        else ungapped_approx(P, subj, slen, q_off, s_match_end, s_off, -P.ctx_xdrop[lo], P.ctx_reduced[lo], u);
+        r.q_start = u.q_start; r.s_start = u.s_start; r.length = u.length; r.score = u.score;
+        if (u.score >= P.ctx_cutoff[lo]) r.flags |= 2;
+    }
+    r.q_off = q_off; r.s_off = s_off;
+    reinterpret_cast<GbnSeedExt *>(P.ext_rec)[j] = r;
+}
+
+extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams P)
+{
+    // initial hits of the wave's 64 runs are collected in LDS and handed over with one atomic on the global counter
+    constexpr uint32_t CAP = 192;
+    __shared__ GbnDevInitHit s_hit[CAP];
+    __shared__ uint32_t s_n, s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t nruns = (int64_t)*P.run_count;
+    if (t < nruns) {
+        const int64_t i = P.run_heads[t];
+        const uint64_t key = P.key_group[i];                    // (run_heads is not in run order: the run ends where the key changes)
+        const int32_t subj_id = (int32_t)(key >> (P.group_bits ? P.group_bits : 32));
+        const GbnSeedExt *__restrict__ rec = reinterpret_cast<const GbnSeedExt *>(P.ext_rec);
+        const int word = P.word;
+        const int32_t win = min(0, -word) + 1;                  // s_BlastDiagHashInsert with window = 0 + MIN(0, -word) + 1
+        const bool hash = P.container_hash != 0;
+        int32_t last_hit = 0;           // array container: one slot per run
+        // hash container: the chain of the run's bucket, newest cell last.  The first KC cells live in registers
+        // (cells expire as the scan moves on and are reused: a chain is one or two cells long), the rest in the
+        // run's slice of the scratch arrays
+        constexpr int KC = 4;
+        int32_t cd[KC], cl[KC];
+        #pragma unroll
+        for (int c = 0; c < KC; c++) { cd[c] = 0; cl[c] = 0; }
+        int32_t ncell = 0;
+        GbnSeedExt r = rec[i];
+        for (int64_t j = i;;) {
+            // the next seed's key and record are on their way while this one is looked at
+            const int64_t jn = j + 1 < P.n ? j + 1 : j;
+            const uint64_t key_n = P.key_group[jn];
+            const GbnSeedExt rn = rec[jn];
+            const int32_t diag = r.s_off - r.q_off, s_off_pos = r.s_orig;       // the container is keyed by the word as the scan delivered it
+            if (hash) {
+                last_hit = 0; bool found = false;
+                for (int32_t c = ncell - 1; c >= KC && !found; c--)
+                    if (P.cell_diag[i + c] == diag) { last_hit = P.cell_level[i + c]; found = true; }
+                #pragma unroll
+                for (int c = KC - 1; c >= 0; c--)
+                    if (!found && c < ncell && cd[c] == diag) { last_hit = cl[c]; found = true; }
+            }
+            if (!(s_off_pos < last_hit) && !(r.flags & 1)) {
+                int32_t s_end_pos = s_off_pos + word + (r.flags >> 8);
+                if (r.flags & 2) {
+                    GbnDevInitHit h; h.subj = subj_id; h.q_off = r.q_off; h.s_off = r.s_off;
+                    h.q_start = r.q_start; h.s_start = r.s_start; h.length = r.length; h.score = r.score;
+                    h.seq = (uint32_t)j;
+                    const uint32_t slot = atomicAdd(&s_n, 1u);
+                    if (slot < CAP) s_hit[slot] = h;
+                    else { const unsigned long long o = atomicAdd(P.ihit_count, 1ull); if (o < P.ihit_cap) P.ihits[o] = h; }
+                    s_end_pos = r.length + r.s_start;
+                }
+                if (hash) {
+                    // newest to oldest: the cell of this diagonal, else the first expired one; none: a new cell
+                    bool placed = false;
+                    for (int32_t c = ncell - 1; c >= KC && !placed; c--) {
+                        if (P.cell_diag[i + c] == diag) { P.cell_level[i + c] = s_end_pos; placed = true; }
+                        else if (s_off_pos - P.cell_level[i + c] > win) { P.cell_diag[i + c] = diag; P.cell_level[i + c] = s_end_pos; placed = true; }
+                    }
+                    #pragma unroll
+                    for (int c = KC - 1; c >= 0; c--) {
+                        const bool here = !placed && c < ncell && (cd[c] == diag || s_off_pos - cl[c] > win);
+                        cd[c] = here ? diag : cd[c]; cl[c] = here ? s_end_pos : cl[c]; placed = placed || here;
+                    }
+                    if (!placed) {
+                        #pragma unroll
+                        for (int c = 0; c < KC; c++) { const bool here = c == ncell; cd[c] = here ? diag : cd[c]; cl[c] = here ? s_end_pos : cl[c]; }
+                        if (ncell >= KC) { P.cell_diag[i + ncell] = diag; P.cell_level[i + ncell] = s_end_pos; }
+                        ncell++;
+                    }
+                } else {
+                    last_hit = s_end_pos;
+                }
+            }
+            if (jn == j || key_n != key) break;
+            j = jn; r = rn;
+        }
+    }
+    __syncthreads();
+    const uint32_t have = min(s_n, CAP);
+    if (have) {
+        if (threadIdx.x == 0) { const unsigned long long o = atomicAdd(P.ihit_count, (unsigned long long)have); s_base = (uint32_t)min(o, (unsigned long long)0xffffffffu); }
+        __syncthreads();
+        const unsigned long long base = s_base;
+        for (uint32_t k = threadIdx.x; k < have; k += blockDim.x) if (base + k < P.ihit_cap) P.ihits[base + k] = s_hit[k];
+    }
+}
+
 // ---------------------------------------------------------------------------
 // gapped extensions, one thread per initial hit (score-only)
 // ---------------------------------------------------------------------------
@@ -1437,12 +1574,18 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
     if (e != hipSuccess) return e;
     // Compacting the run heads first pays once most seeds are not heads (blastn word sizes: 6x on
     // C3); for the few ten thousand seeds of a megablast pass the direct form is 2x faster.
-    if (p.n < GBN_DIAG_COMPACT_MIN) { GbnExtParams q = p; q.run_heads = nullptr;
+    // GBN_DIAG_COMPACT_MIN (environment): the threshold, for tests that send small inputs through the two-kernel form
+    static const int64_t compact_min = getenv("GBN_DIAG_COMPACT_MIN") ? atoll(getenv("GBN_DIAG_COMPACT_MIN")) : (int64_t)GBN_DIAG_COMPACT_MIN;
+    if (p.n < compact_min) { GbnExtParams q = p; q.run_heads = nullptr;
         hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, q);
         return hipGetLastError(); }
     hipLaunchKernelGGL(run_heads_kernel, dim3((unsigned)((p.n + 1023) / 1024)), dim3(1024), 0, st, p);
     // grid for the worst case (every seed its own run); threads past the run count leave at once
-    hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
+    if (p.ext_rec) {        // every seed extended by a thread of its own, then the runs replayed over the records
+        hipLaunchKernelGGL(seed_ext_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(diag_replay_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
+    } else
+        hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
     return hipGetLastError();
 }
 

@@ -28,6 +28,9 @@ extern "C" {
 #endif
 
 #define GBN_TILE_POS     2048       /* most scan positions in one tile of gbn_launch_scan_seed */
+#ifndef GBN_DIAG_COMPACT_MIN
+#define GBN_DIAG_COMPACT_MIN (1 << 20)  /* seeds per gbn_launch_ungapped from which the runs are compacted first (run_heads) */
+#endif
 
 /* mini-extension flavours (CORE/na_ungapped.c:1753-1795) */
 #define GBN_EXT_DIRECT        0     /* lut == word_size */
@@ -93,6 +96,12 @@ typedef struct GbnExtParams {
     /* [caller] initial hits that reached the cutoff, in no particular order (GbnDevInitHit::seq orders them);
      * *ihit_count counts all of them (zero it first) */
     GbnDevInitHit *ihits; unsigned long long *ihit_count; unsigned long long ihit_cap;
+    /* optional: ctx_hint[q >> ctx_hint_shift] = a context starting at or before query position q, not more than a
+     * few contexts before the one q lies in (null: binary search over ctx_off) */
+    const int32_t *ctx_hint; int32_t ctx_hint_shift;
+    /* [caller] optional scratch, 32 bytes per seed: with it, launches of GBN_DIAG_COMPACT_MIN seeds and more
+     * extend every seed in a kernel of its own and replay the runs over the records (null: one kernel) */
+    void *ext_rec;
 } GbnExtParams;
 
 typedef struct GbnGapParams {

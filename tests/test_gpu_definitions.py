@@ -223,3 +223,16 @@ def test_search_lists_shard_builder_and_cache():
     assert L.gbn_prelim_search_lists(ps._b, h, failing, None, None, None, None) != 0
     L.gpu_ReleaseDBMemory()                     # frees the cached shard
     assert L.gbn_db_cache_find(key) is None
+
+
+def test_parity_suite_through_the_two_kernel_seed_stage():
+    """seed_ext_kernel + diag_replay_kernel take over from GBN_DIAG_COMPACT_MIN seeds per launch (2^20): the parity
+    cases are far smaller, so the whole stage-by-stage comparison with the oracle runs once more with the threshold
+    at 1 (every launch goes through the two kernels: hash and array containers, masked queries, short words)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["GBN_DIAG_COMPACT_MIN"] = "1"
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu"], cwd=root, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout
