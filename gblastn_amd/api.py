@@ -114,7 +114,8 @@ class GbnExtParams(C.Structure):
                 ("container_hash", C.c_int), ("cell_diag", _P), ("cell_level", _P), ("cell_start", _P), ("ent", _P),
                 ("cell_mask", _U), ("lut", C.c_int), ("masked", C.c_int), ("q2", _P), ("qinv", _P),
                 ("run_heads", _P), ("run_count", _P), ("group_bits", _I),
-                ("ihits", _P), ("ihit_count", _P), ("ihit_cap", _UL), ("ctx_hint", _P), ("ctx_hint_shift", _I), ("ext_rec", _P)]
+                ("ihits", _P), ("ihit_count", _P), ("ihit_cap", _UL), ("ctx_hint", _P), ("ctx_hint_shift", _I), ("ext_rec", _P),
+                ("ck_shift", _I), ("ck_s_bits", _I), ("ck_qh_bits", _I), ("ck_q_bits", _I), ("ck_q_desc", _I)]
 
 
 class GbnGapParams(C.Structure):

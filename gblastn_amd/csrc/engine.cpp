@@ -30,6 +30,7 @@ hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hip
 hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts, hipEvent_t tables_ready);
 hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
+hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st);
 hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st);
 hipError_t launch_synth_fill(void *dev, int64_t nbytes, uint64_t seed, hipStream_t st);
@@ -816,16 +817,20 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     K.group_bits = b.container ? 9 : bits_for((uint64_t)std::max(b.diag_len, 2));
     const int scan_bits = std::min(64, K.q_bits + bits_for((uint64_t)max_len + 1));
     const int group_key_bits = std::min(64, K.group_bits + bits_for((uint64_t)db.num_seqs + 1));
-    HIPCHK(launch_seed_keys(K, st));
-    size_t tb = E.sort_tmp_bytes;
-    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, scan_bits, st));
-    // idx_b = seed indices in scan order (s_scan, chain order), subjects interleaved
-    K.idx = E.idx_b; K.key_group = E.key_a;
-    HIPCHK(launch_group_keys(K, st));
-    tb = E.sort_tmp_bytes;
-    HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_b, E.idx_a, n, group_key_bits, st));
-    // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
-
+    // Many seeds (blastn shapes): ONE sort of a composite key, the seed itself travels in the key (seed_ckeys_kernel) --
+    // when subject | slot | s_scan | query key fit 64 bits; else, and for the few seeds of megablast shapes, two
+    // stable sorts of (rank, index) pairs
+    static const int64_t compact_min = getenv("GBN_DIAG_COMPACT_MIN") ? atoll(getenv("GBN_DIAG_COMPACT_MIN")) : (int64_t)GBN_DIAG_COMPACT_MIN;
+    static const bool ck_on = !(getenv("GBN_SEED_CKEYS") && atoi(getenv("GBN_SEED_CKEYS")) == 0);
+    K.s_bits = bits_for((uint64_t)max_len + 1); K.qh_bits = std::max(0, K.q_bits - K.group_bits);
+    const int ck_bits = group_key_bits + K.s_bits + K.qh_bits;
+    const bool composite = ck_on && E.ext_rec && n >= compact_min && ck_bits <= 64 && K.group_bits < 32;
+    if (!composite || keep_stages) {
+        HIPCHK(launch_seed_keys(K, st));
+        size_t tb = E.sort_tmp_bytes;
+        HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, scan_bits, st));
+        // idx_b = seed indices in scan order (s_scan, chain order), subjects interleaved
+    }
     if (keep_stages) {
         std::vector<GbnDevSeed> hs((size_t)n); std::vector<uint32_t> order((size_t)n);
         HIPCHK(hipMemcpyAsync(hs.data(), seeds, (size_t)n * sizeof(GbnDevSeed), hipMemcpyDeviceToHost, st));
@@ -839,6 +844,19 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         }
         std::stable_sort(tmp.begin(), tmp.end(), [](const GbnSeed &a, const GbnSeed &c) { return a.oid < c.oid; });
         res.seeds.insert(res.seeds.end(), tmp.begin(), tmp.end());
+    }
+    if (composite) {
+        K.key_scan = E.key_a; K.idx = E.idx_a;
+        HIPCHK(launch_seed_ckeys(K, st));
+        size_t tb = E.sort_tmp_bytes;
+        HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, ck_bits, st));
+        // key_b = sorted composite keys, idx_b = ext_left of the seeds in that order
+    } else {
+        K.idx = E.idx_b; K.key_group = E.key_a;
+        HIPCHK(launch_group_keys(K, st));
+        size_t tb = E.sort_tmp_bytes;
+        HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_b, E.idx_a, n, group_key_bits, st));
+        // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
     }
 
     if ((rc = grow_ihit_buffers(slot, std::max<size_t>(E.ihit_cap_s[slot], 1 << 16)))) return rc;
@@ -859,6 +877,10 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         X.masked = b.lut.masked ? 1 : 0;
         X.run_heads = E.idx_b; X.run_count = reinterpret_cast<uint32_t *>(ctr + 1); X.group_bits = K.group_bits;
         X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = E.ext_rec;
+        if (composite) {
+            X.idx = E.idx_b; X.run_heads = E.idx_a;
+            X.ck_shift = K.s_bits + K.qh_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending;
+        }
         X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
         HIPCHK(launch_diag_ungapped(X, st));
         HIPCHK(hipMemcpyAsync(&nih, ctr, sizeof(nih), hipMemcpyDeviceToHost, st));

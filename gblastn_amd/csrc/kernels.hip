@@ -276,6 +276,27 @@ extern "C" __global__ void seed_keys_kernel(GbnKeyParams K)
     K.idx[i] = (uint32_t)i;
 }
 
+// One 64-bit key per seed that orders the seeds the way the two sorts below do, in a single sort:
+// subject | slot | s_scan | query key >> group_bits.  Two seeds of one (subject, slot, s_scan) have query positions
+// that agree modulo the number of slots, so the low bits of the query key decide nothing and are left out; the
+// rest of the seed follows from the key (q_pos's low bits = (s_scan - slot) mod slots), only ext_left travels as
+// the sort's value: no second sort, no gathers of seeds by rank afterwards.
+extern "C" __global__ void seed_ckeys_kernel(GbnKeyParams K)
+{
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K.n) return;
+    const GbnDevSeed sd = K.seeds[i];
+    const uint32_t qmax = (K.q_bits >= 32) ? 0xffffffffu : ((1u << K.q_bits) - 1u);
+    const uint32_t qkey = K.q_descending ? (qmax - (uint32_t)sd.q_pos) : (uint32_t)sd.q_pos;
+    const uint32_t slot = K.container_hash ? ((uint32_t)(sd.s_scan - sd.q_pos) & 511u)
+                                           : ((uint32_t)(sd.s_scan + K.diag_len - sd.q_pos) & (uint32_t)(K.diag_len - 1));
+    uint64_t key = ((uint64_t)(uint32_t)sd.subj << K.group_bits) | slot;
+    key = (key << K.s_bits) | (uint32_t)sd.s_scan;
+    key = (key << K.qh_bits) | (K.qh_bits ? (uint64_t)(qkey >> K.group_bits) : 0ull);
+    K.key_scan[i] = key;
+    K.idx[i] = (uint32_t)sd.ext_left;
+}
+
 extern "C" __global__ void group_keys_kernel(GbnKeyParams K)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -555,9 +576,50 @@ __device__ __forceinline__ int context_of(const GbnExtParams &P, int32_t q)
 extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P)
 {
     const int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (j >= P.n) return;
-    const int32_t subj_id = (int32_t)(P.key_group[j] >> (P.group_bits ? P.group_bits : 32));
-    const GbnDevSeed sd = P.seeds[P.idx[j]];
+    const bool live = j < P.n;
+    const int gb = P.group_bits ? P.group_bits : 32;
+    int32_t subj_id = 0; GbnDevSeed sd; sd.subj = 0; sd.s_scan = 0; sd.q_pos = 0; sd.ext_left = 0;
+    bool head = false, last = false;
+    if (live) {
+        const uint64_t key = P.key_group[j];
+        if (P.ck_shift > 0) {
+            // composite keys: the seed is in the key; the run's ends show in the neighbours' keys
+            const uint64_t run = key >> P.ck_shift;
+            head = j == 0 || (P.key_group[j - 1] >> P.ck_shift) != run;
+            last = j + 1 >= P.n || (P.key_group[j + 1] >> P.ck_shift) != run;
+            subj_id = (int32_t)(run >> gb);
+            const uint32_t mask = (gb >= 32) ? 0xffffffffu : ((1u << gb) - 1u);
+            const uint32_t slot = (uint32_t)run & mask;
+            sd.s_scan = (int32_t)((key >> P.ck_qh_bits) & ((1ull << P.ck_s_bits) - 1ull));
+            const uint32_t qk = (uint32_t)(key & ((1ull << P.ck_qh_bits) - 1ull));
+            const uint32_t ql = ((uint32_t)sd.s_scan - slot) & mask;                      // q_pos modulo the number of slots
+            if (P.ck_q_desc) {
+                const uint32_t qmax = (P.ck_q_bits >= 32) ? 0xffffffffu : ((1u << P.ck_q_bits) - 1u);
+                const uint32_t t = (P.ck_qh_bits ? (qk << gb) : 0u) | ((qmax - ql) & mask);
+                sd.q_pos = (int32_t)(qmax - t);
+            } else sd.q_pos = (int32_t)((P.ck_qh_bits ? (qk << gb) : 0u) | ql);
+            sd.ext_left = (int32_t)P.idx[j];
+        } else {
+            subj_id = (int32_t)(key >> gb);
+            sd = P.seeds[P.idx[j]];
+        }
+    }
+    if (P.ck_shift > 0) {
+        // the run heads, compacted (what run_heads_kernel does for the other form): one atomic per workgroup
+        __shared__ uint32_t s_cnt[4], s_base;
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const unsigned long long m = __ballot(head);
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint32_t tot = 0;
+            for (int w = 0; w < 4; w++) { const uint32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
+            s_base = tot ? atomicAdd(P.run_count, tot) : 0u;
+        }
+        __syncthreads();
+        if (head) P.run_heads[s_base + s_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)j;
+    }
+    if (!live) return;
     const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
     const int32_t slen = P.len[subj_id];
     GbnSeedExt r;
@@ -578,6 +640,7 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
         r.q_start = u.q_start; r.s_start = u.s_start; r.length = u.length; r.score = u.score;
         if (u.score >= P.ctx_cutoff[lo]) r.flags |= 2;
     }
+    if (last) r.flags |= 4;
     r.q_off = q_off; r.s_off = s_off;
     reinterpret_cast<GbnSeedExt *>(P.ext_rec)[j] = r;
 }
@@ -594,7 +657,8 @@ extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams
     const int64_t nruns = (int64_t)*P.run_count;
     if (t < nruns) {
         const int64_t i = P.run_heads[t];
-        const uint64_t key = P.key_group[i];                    // (run_heads is not in run order: the run ends where the key changes)
+        const bool ck = P.ck_shift > 0;                          // composite keys: the records carry the run's end, no key is read on the way
+        const uint64_t key = P.key_group[i] >> (ck ? P.ck_shift : 0);    // (run_heads is not in run order: the run ends where the key changes)
         const int32_t subj_id = (int32_t)(key >> (P.group_bits ? P.group_bits : 32));
         const GbnSeedExt *__restrict__ rec = reinterpret_cast<const GbnSeedExt *>(P.ext_rec);
         const int word = P.word;
@@ -613,7 +677,7 @@ extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams
         for (int64_t j = i;;) {
             // the next seed's key and record are on their way while this one is looked at
             const int64_t jn = j + 1 < P.n ? j + 1 : j;
-            const uint64_t key_n = P.key_group[jn];
+            const uint64_t key_n = ck ? key : P.key_group[jn];
             const GbnSeedExt rn = rec[jn];
             const int32_t diag = r.s_off - r.q_off, s_off_pos = r.s_orig;       // the container is keyed by the word as the scan delivered it
             if (hash) {
@@ -657,7 +721,7 @@ extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams
                     last_hit = s_end_pos;
                 }
             }
-            if (jn == j || key_n != key) break;
+            if (jn == j || key_n != key || (r.flags & 4)) break;
             j = jn; r = rn;
         }
     }
@@ -1560,6 +1624,13 @@ hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st)
     return hipGetLastError();
 }
 
+hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st)
+{
+    if (k.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_ckeys_kernel, dim3((unsigned)((k.n + 255) / 256)), dim3(256), 0, st, k);
+    return hipGetLastError();
+}
+
 hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st)
 {
     if (k.n <= 0) return hipSuccess;
@@ -1579,6 +1650,11 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
     if (p.n < compact_min) { GbnExtParams q = p; q.run_heads = nullptr;
         hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, q);
         return hipGetLastError(); }
+    if (p.ck_shift > 0 && p.ext_rec) {      // composite keys: the extension kernel finds the run heads on its way
+        hipLaunchKernelGGL(seed_ext_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(diag_replay_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(run_heads_kernel, dim3((unsigned)((p.n + 1023) / 1024)), dim3(1024), 0, st, p);
     // grid for the worst case (every seed its own run); threads past the run count leave at once
     if (p.ext_rec) {        // every seed extended by a thread of its own, then the runs replayed over the records

@@ -102,6 +102,11 @@ typedef struct GbnExtParams {
     /* [caller] optional scratch, 32 bytes per seed: with it, launches of GBN_DIAG_COMPACT_MIN seeds and more
      * extend every seed in a kernel of its own and replay the runs over the records (null: one kernel) */
     void *ext_rec;
+    /* composite-key form (ck_shift > 0; needs ext_rec): key_group[i] = subj << (group_bits + ck_shift) | slot << ck_shift
+     * | s_scan << ck_qh_bits | (query key >> group_bits), sorted as ONE 64-bit key; idx[i] = the seed's ext_left;
+     * `seeds` is not read (a seed follows from its key: q_pos = query key's low bits from (s_scan - slot)).  query key
+     * = q_pos, or 2^ck_q_bits - 1 - q_pos when ck_q_desc (megablast tables: chains are reported last position first) */
+    int32_t ck_shift, ck_s_bits, ck_qh_bits, ck_q_bits, ck_q_desc;
 } GbnExtParams;
 
 typedef struct GbnGapParams {
