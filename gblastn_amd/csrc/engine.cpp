@@ -797,9 +797,11 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
 // seeds of a range -> scan order (two stable sorts) -> diagonal filter + ungapped extension on stream `st`;
 // the initial hits are left in the slot's buffers.  ctr: [0] initial hits, [1] runs (device counters).
 static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *diag, int keep_stages, int slot,
-                      const GbnDevSeed *seeds, int64_t n, unsigned long long *ctr, hipStream_t st, unsigned long long *nih_out)
+                      const GbnDevSeed *seeds, int64_t n, unsigned long long *ctr, hipStream_t st, unsigned long long *nih_out,
+                      int32_t s0 = 0, int32_t s1 = -1)
 {
     const DeviceBatch *d = b.dev;
+    if (s1 < 0) s1 = db.num_seqs;
     int rc;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) {
@@ -823,7 +825,8 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     static const int64_t compact_min = getenv("GBN_DIAG_COMPACT_MIN") ? atoll(getenv("GBN_DIAG_COMPACT_MIN")) : (int64_t)GBN_DIAG_COMPACT_MIN;
     static const bool ck_on = !(getenv("GBN_SEED_CKEYS") && atoi(getenv("GBN_SEED_CKEYS")) == 0);
     K.s_bits = bits_for((uint64_t)max_len + 1); K.qh_bits = std::max(0, K.q_bits - K.group_bits);
-    const int ck_bits = group_key_bits + K.s_bits + K.qh_bits;
+    K.subj_base = s0;
+    const int ck_bits = K.group_bits + bits_for((uint64_t)(s1 - s0) + 1) + K.s_bits + K.qh_bits;
     const bool composite = ck_on && E.ext_rec && n >= compact_min && ck_bits <= 64 && K.group_bits < 32;
     if (!composite || keep_stages) {
         HIPCHK(launch_seed_keys(K, st));
@@ -879,7 +882,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = E.ext_rec;
         if (composite) {
             X.idx = E.idx_b; X.run_heads = E.idx_a;
-            X.ck_shift = K.s_bits + K.qh_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending;
+            X.ck_shift = K.s_bits + K.qh_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending; X.ck_subj_base = K.subj_base;
         }
         X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
         HIPCHK(launch_diag_ungapped(X, st));
@@ -953,7 +956,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
             unsigned long long nih2 = 0;
             if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the extension thread"; return GBN_ERR_HIP; }
             if (hipStreamWaitEvent(E.stream2, E.ev_seed, 0) != hipSuccess) { E.pending_err = "hipStreamWaitEvent failed"; return GBN_ERR_HIP; }
-            r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n, E.counters + 4, E.stream2, &nih2);
+            r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n, E.counters + 4, E.stream2, &nih2, s0, s1);
             if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2);
             if (r) E.pending_err = gbn_last_error();      // the error text is per thread
             return r;
@@ -963,7 +966,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     }
     if (E.pending_uses_keys && (rc = wait_pending())) return rc;     // the sort buffers exist once
     unsigned long long nih = 0;
-    if ((rc = seed_stage(b, db, res, diag, keep_stages, slot, E.seeds, n, E.counters + 2, E.stream, &nih))) return rc;
+    if ((rc = seed_stage(b, db, res, diag, keep_stages, slot, E.seeds, n, E.counters + 2, E.stream, &nih, s0, s1))) return rc;
     trace_mark("seed stage done (inline)");
     if (nih == 0) return GBN_OK;
     if ((rc = wait_pending())) return rc;                   // one gapped stage in flight at most

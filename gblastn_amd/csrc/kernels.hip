@@ -290,7 +290,7 @@ extern "C" __global__ void seed_ckeys_kernel(GbnKeyParams K)
     const uint32_t qkey = K.q_descending ? (qmax - (uint32_t)sd.q_pos) : (uint32_t)sd.q_pos;
     const uint32_t slot = K.container_hash ? ((uint32_t)(sd.s_scan - sd.q_pos) & 511u)
                                            : ((uint32_t)(sd.s_scan + K.diag_len - sd.q_pos) & (uint32_t)(K.diag_len - 1));
-    uint64_t key = ((uint64_t)(uint32_t)sd.subj << K.group_bits) | slot;
+    uint64_t key = ((uint64_t)(uint32_t)(sd.subj - K.subj_base) << K.group_bits) | slot;
     key = (key << K.s_bits) | (uint32_t)sd.s_scan;
     key = (key << K.qh_bits) | (K.qh_bits ? (uint64_t)(qkey >> K.group_bits) : 0ull);
     K.key_scan[i] = key;
@@ -587,7 +587,7 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
             const uint64_t run = key >> P.ck_shift;
             head = j == 0 || (P.key_group[j - 1] >> P.ck_shift) != run;
             last = j + 1 >= P.n || (P.key_group[j + 1] >> P.ck_shift) != run;
-            subj_id = (int32_t)(run >> gb);
+            subj_id = (int32_t)(run >> gb) + P.ck_subj_base;
             const uint32_t mask = (gb >= 32) ? 0xffffffffu : ((1u << gb) - 1u);
             const uint32_t slot = (uint32_t)run & mask;
             sd.s_scan = (int32_t)((key >> P.ck_qh_bits) & ((1ull << P.ck_s_bits) - 1ull));
@@ -659,7 +659,7 @@ extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams
         const int64_t i = P.run_heads[t];
         const bool ck = P.ck_shift > 0;                          // composite keys: the records carry the run's end, no key is read on the way
         const uint64_t key = P.key_group[i] >> (ck ? P.ck_shift : 0);    // (run_heads is not in run order: the run ends where the key changes)
-        const int32_t subj_id = (int32_t)(key >> (P.group_bits ? P.group_bits : 32));
+        const int32_t subj_id = (int32_t)(key >> (P.group_bits ? P.group_bits : 32)) + (ck ? P.ck_subj_base : 0);
         const GbnSeedExt *__restrict__ rec = reinterpret_cast<const GbnSeedExt *>(P.ext_rec);
         const int word = P.word;
         const int32_t win = min(0, -word) + 1;                  // s_BlastDiagHashInsert with window = 0 + MIN(0, -word) + 1

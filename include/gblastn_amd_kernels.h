@@ -106,7 +106,7 @@ typedef struct GbnExtParams {
      * | s_scan << ck_qh_bits | (query key >> group_bits), sorted as ONE 64-bit key; idx[i] = the seed's ext_left;
      * `seeds` is not read (a seed follows from its key: q_pos = query key's low bits from (s_scan - slot)).  query key
      * = q_pos, or 2^ck_q_bits - 1 - q_pos when ck_q_desc (megablast tables: chains are reported last position first) */
-    int32_t ck_shift, ck_s_bits, ck_qh_bits, ck_q_bits, ck_q_desc;
+    int32_t ck_shift, ck_s_bits, ck_qh_bits, ck_q_bits, ck_q_desc, ck_subj_base;   /* subj in the key counts from ck_subj_base */
 } GbnExtParams;
 
 typedef struct GbnGapParams {
