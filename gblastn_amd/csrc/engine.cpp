@@ -842,7 +842,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         std::vector<GbnSeed> tmp; tmp.reserve((size_t)n);
         for (int64_t i = 0; i < n; i++) {
             const GbnDevSeed &s = hs[order[i]];
-            GbnSeed o; o.oid = db.first_oid + s.subj; o.s_off = s.s_scan - s.ext_left; o.q_off = s.q_pos - s.ext_left; o.pad_ = 0;
+            GbnSeed o; o.oid = db.oid_of(s.subj); o.s_off = s.s_scan - s.ext_left; o.q_off = s.q_pos - s.ext_left; o.pad_ = 0;
             tmp.push_back(o);
         }
         std::stable_sort(tmp.begin(), tmp.end(), [](const GbnSeed &a, const GbnSeed &c) { return a.oid < c.oid; });
@@ -1080,13 +1080,17 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
                 return a.seq < c.seq;
             });
             for (auto &pr : sorted) {
-                GbnInitHit o; o.oid = db.first_oid + subj; o.q_off = pr.first.q_off; o.s_off = pr.first.s_off;
+                GbnInitHit o; o.oid = db.oid_of(subj); o.q_off = pr.first.q_off; o.s_off = pr.first.s_off;
                 o.q_start = pr.first.q_start; o.s_start = pr.first.s_start; o.length = pr.first.length;
                 o.score = pr.first.score; o.pad_ = 0;
                 ihs[k].push_back(o);
             }
         }
-        finish_subject(b, db.first_oid + subj, db.len[subj], hits, outs[k], dg);
+        finish_subject(b, db.oid_of(subj), db.len[subj], hits, outs[k], dg);
+        if (!db.real_of.empty()) {      // a chunk's list: sequence coordinates (Blast_HSPListAdjustOffsets), marked for the merge at the end of the search
+            const int32_t ord = db.chunk_of(subj), off = (int32_t)((int64_t)ord * (db.chunk_len - kDbseqChunkOverlap));
+            for (GbnHSP &h : outs[k]) { h.s_offset += off; h.s_end += off; h.s_gapped_start += off; h.pad_ = ord + 1; }
+        }
     };
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const unsigned nthreads = (nih < 20000 || spans.size() < 2) ? 1u : std::min({hw, 16u, (unsigned)spans.size()});
@@ -1262,6 +1266,15 @@ int gbn_shard_builder_finish(GbnShardBuilder *b, GbnDb **out) {
 }
 void gbn_shard_builder_free(GbnShardBuilder *b) { delete b; }
 
+// MAX_DBSEQ_LEN of the build the results are to equal: 200,000,000 in G-BLASTN (COREI/blast_gapalign.h:54-55;
+// 5,000,000 in stock BLAST+).  A multiple of 4; tests lower it to exercise the chunk path on small subjects.
+static int32_t g_max_dbseq_len = 200000000;
+int gbn_set_max_dbseq_len(int32_t n) {
+    if (n < 1000 || (n & 3)) { set_error("gbn_set_max_dbseq_len: a multiple of 4, at least 1000"); return GBN_ERR_ARG; }
+    g_max_dbseq_len = n;
+    return GBN_OK;
+}
+
 int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_seqs,
                const int64_t *byte_off, const int32_t *len, int32_t first_oid, int is_device) {
     if (!out || !packed || num_seqs < 0 || (num_seqs > 0 && (!byte_off || !len))) { set_error("bad argument"); return GBN_ERR_ARG; }
@@ -1269,27 +1282,67 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
     if (rc) return rc;
     use_engine_device();
     GbnDb *db = new GbnDb();
-    db->num_seqs = num_seqs; db->first_oid = first_oid; db->nbytes = nbytes;
-    db->byte_off.assign(byte_off, byte_off + num_seqs); db->len.assign(len, len + num_seqs);
+    db->first_oid = first_oid; db->real_seqs = num_seqs; db->chunk_len = g_max_dbseq_len;
+    bool chunked = false;
     for (int32_t i = 0; i < num_seqs; i++) {
         if (byte_off[i] < 16 || (byte_off[i] & 15) || byte_off[i] + (len[i] + 3) / 4 + 128 > nbytes) {
             delete db; set_error("subject offsets must be 16-byte aligned, >= 16, and leave 128 pad bytes"); return GBN_ERR_ARG;
         }
         db->total_bases += len[i];
+        chunked = chunked || len[i] > g_max_dbseq_len;
     }
-    if (is_device) { db->d_packed = packed; db->owns = false; }
-    else {
+    if (!chunked) {
+        db->num_seqs = num_seqs; db->nbytes = nbytes;
+        db->byte_off.assign(byte_off, byte_off + num_seqs); db->len.assign(len, len + num_seqs);
+        if (is_device) { db->d_packed = packed; db->owns = false; }
+        else {
+            uint8_t *p = nullptr;
+            if (hipMalloc((void **)&p, (size_t)nbytes) != hipSuccess) { delete db; set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
+            if (hipMemcpy(p, packed, (size_t)nbytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); delete db; set_error("H2D(db) failed"); return GBN_ERR_HIP; }
+            db->d_packed = p; db->owns = true;
+        }
+    } else {
+        // s_GetNextSubjectChunk (CORE/blast_engine.c:218-262) without hard masks: chunk k of a sequence starts at
+        // k * (MAX_DBSEQ_LEN - DBSEQ_CHUNK_OVERLAP) and is MAX_DBSEQ_LEN long, the last one runs to the end.  Every
+        // chunk gets a 16-byte aligned copy in a slab of this shard's own.
+        const int64_t stride = (int64_t)g_max_dbseq_len - kDbseqChunkOverlap;
+        std::vector<int64_t> src;       // byte offset of every chunk in the caller's slab
+        int64_t pos = 16;
+        for (int32_t i = 0; i < num_seqs; i++) {
+            db->first_virt.push_back((int32_t)db->len.size()); db->real_len.push_back(len[i]);
+            int32_t ord = 0;
+            for (int64_t off = 0;; off += stride, ord++) {
+                const bool last = off + g_max_dbseq_len >= len[i];
+                const int32_t clen = last ? (int32_t)(len[i] - off) : g_max_dbseq_len;
+                db->real_of.push_back(i); db->chunk_ord.push_back(ord);
+                db->len.push_back(clen); db->byte_off.push_back(pos); src.push_back(byte_off[i] + off / 4);
+                pos += (((int64_t)clen + 3) / 4 + 15) / 16 * 16;
+                if (last) break;
+            }
+        }
+        db->num_seqs = (int32_t)db->len.size(); db->nbytes = pos + 128;
         uint8_t *p = nullptr;
-        if (hipMalloc((void **)&p, (size_t)nbytes) != hipSuccess) { delete db; set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
-        if (hipMemcpy(p, packed, (size_t)nbytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); delete db; set_error("H2D(db) failed"); return GBN_ERR_HIP; }
+        if (hipMalloc((void **)&p, (size_t)db->nbytes) != hipSuccess) { delete db; set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
         db->d_packed = p; db->owns = true;
+        hipError_t e = hipMemset(p, 0, (size_t)db->nbytes);
+        for (size_t v = 0; v < db->len.size() && e == hipSuccess; v++) {
+            const size_t nb = ((size_t)db->len[v] + 3) / 4;
+            e = hipMemcpy(p + db->byte_off[v], packed + src[v], nb, is_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice);
+            // a chunk ends inside its sequence's byte: the bases past its end are the next chunk's, not padding
+            if (e == hipSuccess && (db->len[v] & 3)) {
+                uint8_t lastb = 0;
+                e = hipMemcpy(&lastb, p + db->byte_off[v] + nb - 1, 1, hipMemcpyDeviceToHost);
+                lastb &= (uint8_t)(0xff << (2 * (4 - (db->len[v] & 3))));
+                if (e == hipSuccess) e = hipMemcpy(p + db->byte_off[v] + nb - 1, &lastb, 1, hipMemcpyHostToDevice);
+            }
+        }
+        if (e != hipSuccess) { gbn_db_free(db); set_error("copying subject chunks failed"); return GBN_ERR_HIP; }
     }
     if ((rc = dev_upload(db->d_byte_off, db->byte_off.data(), db->byte_off.size())) ||
         (rc = dev_upload(db->d_len, db->len.data(), db->len.size()))) { gbn_db_free(db); return rc; }
     *out = db;
     return GBN_OK;
 }
-
 void gbn_db_free(GbnDb *db) {
     if (!db) return;
     use_engine_device();
@@ -1304,7 +1357,7 @@ void gbn_db_free(GbnDb *db) {
     delete db;
 }
 int64_t gbn_db_total_bases(const GbnDb *db) { return db ? db->total_bases : 0; }
-int32_t gbn_db_num_seqs(const GbnDb *db) { return db ? db->num_seqs : 0; }
+int32_t gbn_db_num_seqs(const GbnDb *db) { return db ? db->real_seqs : 0; }
 
 int gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream) {
     int rc = ensure_init();
@@ -1460,6 +1513,7 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     std::lock_guard<std::mutex> lk(E.mu);
     auto t0 = std::chrono::steady_clock::now();
     trace_mark("search: entered");
+    if (!db->real_of.empty()) results->chunk_len = db->chunk_len;
     if (batch->opt.db_num_seqs == 0) {
         // "db_length == 0" branch of the engine: effective lengths and cut-offs are
         // recomputed for every subject (CORE/blast_setup.c:905-932)
@@ -1515,6 +1569,7 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     std::lock_guard<std::mutex> lk(E.mu);
     (void)wait_pending();                               // of an earlier gbn_prelim_search_begin (its status stays with its results)
     const int rc2 = take_failure(results);
+    if (!rc && !rc2 && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len); results->chunk_len = 0; }
     return rc ? rc : rc2;
 }
 
@@ -1549,9 +1604,11 @@ int gbn_prelim_search_end(GbnResults *results) {
     std::lock_guard<std::mutex> lk(E.mu);
     // a stage that belongs to other results stays in flight: these results were completed when that
     // stage was queued (one in flight at most)
-    if (results && E.has_pending && E.pending_res != results) return take_failure(results);
-    (void)wait_pending();
-    return results ? take_failure(results) : GBN_OK;
+    int rc;
+    if (results && E.has_pending && E.pending_res != results) rc = take_failure(results);
+    else { (void)wait_pending(); rc = results ? take_failure(results) : GBN_OK; }
+    if (!rc && results && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len); results->chunk_len = 0; }
+    return rc;
 }
 
 int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag) {

@@ -77,12 +77,23 @@ struct GbnDb {
     int64_t *d_byte_off = nullptr;
     int32_t *d_len = nullptr;
     void *tile_cache = nullptr;         // engine-private (tile tables per lut/step)
+    // Sequences longer than the engine's MAX_DBSEQ_LEN are held and searched as chunks of that length overlapping
+    // by DBSEQ_CHUNK_OVERLAP (CORE/blast_engine.c:218-262, :455-540): num_seqs / byte_off / len above describe the
+    // chunks -- subjects of their own to every kernel -- and these map them back.  Empty: nothing is chunked.
+    int32_t real_seqs = 0;                      // sequences in the shard (= num_seqs when nothing is chunked)
+    std::vector<int32_t> real_of, chunk_ord;    // per chunk: its sequence, its ordinal in it
+    std::vector<int32_t> real_len, first_virt;  // per sequence: its length, its first chunk
+    int32_t chunk_len = 0;                      // MAX_DBSEQ_LEN the shard was built with
+    int32_t oid_of(int32_t v) const { return first_oid + (real_of.empty() ? v : real_of[(size_t)v]); }
+    int32_t chunk_of(int32_t v) const { return real_of.empty() ? 0 : chunk_ord[(size_t)v]; }
 };
+constexpr int32_t kDbseqChunkOverlap = 100;     // COREI/blast_hits.h:169
 
 struct GbnResults {
     std::vector<GbnHSP> hsps;
     std::vector<GbnSeed> seeds;
     std::vector<GbnInitHit> init_hits;
+    int32_t chunk_len = 0;              // > 0: hsps holds chunk lists (pad_ = ordinal + 1) that merge_chunk_lists has yet to join
 };
 
 namespace gbn {
@@ -94,5 +105,7 @@ int  build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq,
 void fill_lookup_host(GbnBatch &b);     // the host-side table builder (host-only set-up, GBN_HOST_LOOKUP=1)
 int  upload_batch(GbnBatch &b);
 void free_device_batch(DeviceBatch *d);
+// chunk lists of one sequence (GbnHSP::pad_ = chunk ordinal + 1) -> one list per sequence (Blast_HSPListsMerge)
+void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len);
 int  gather_shard_bytes(const GbnDb &db, const std::vector<int64_t> &src_off, const std::vector<int32_t> &nbytes, std::vector<uint8_t> &out);
 }

@@ -58,6 +58,62 @@ void purge_common_endpoints(std::vector<GbnHSP> &v) {
     v.erase(std::unique(v.begin(), v.end(), same_end), v.end());
 }
 
+// Blast_HSPListsMerge (CORE/blast_hits.c:2545-2716) for a subject searched in chunks: `cur` = the list of the chunk
+// that starts at `split` (sequence coordinates already), `comb` = what the chunks before it left.  HSPs that reach
+// into the overlap strip come to the front of either list (in the reference's swap order, which fixes the order the
+// pairs are tried in); a pair of one context whose end / start diagonals are closer than OVERLAP_DIAG_CLOSE and
+// that touch (s_BlastMergeTwoHSPs, :1337-1378) becomes one HSP with the joint extent and the better score.
+static void merge_two_lists(std::vector<GbnHSP> &comb, std::vector<GbnHSP> &cur, int32_t split, int32_t overlap)
+{
+    if (cur.empty()) return;
+    if (comb.empty()) { comb.swap(cur); return; }
+    size_t n1 = 0, n2 = 0;
+    for (size_t i = 0; i < comb.size(); i++) if (comb[i].s_end > split) { std::swap(comb[n1], comb[i]); n1++; }
+    for (size_t i = 0; i < cur.size(); i++) if (cur[i].s_offset < split + overlap) { std::swap(cur[n2], cur[i]); n2++; }
+    std::vector<char> gone(cur.size(), 0);
+    auto inside = [](int32_t a, int32_t b, int32_t c, int32_t d, int32_t e, int32_t f) { return a <= c && b >= c && d <= f && e >= f; };
+    for (size_t i = 0; i < n1; i++) {
+        GbnHSP &h1 = comb[i];
+        for (size_t j = 0; j < n2; j++) {
+            if (gone[j] || h1.context != cur[j].context) continue;
+            const GbnHSP &h2 = cur[j];
+            const int32_t end_diag = h1.q_end - h1.s_end, start_diag = h2.q_offset - h2.s_offset;
+            if (std::abs(end_diag - start_diag) >= 10) continue;                     // OVERLAP_DIAG_CLOSE
+            if (inside(h1.q_offset, h1.q_end, h2.q_offset, h1.s_offset, h1.s_end, h2.s_offset) ||
+                inside(h1.q_offset, h1.q_end, h2.q_end, h1.s_offset, h1.s_end, h2.s_end)) {
+                h1.q_offset = std::min(h1.q_offset, h2.q_offset); h1.s_offset = std::min(h1.s_offset, h2.s_offset);
+                h1.q_end = std::max(h1.q_end, h2.q_end); h1.s_end = std::max(h1.s_end, h2.s_end);
+                if (h2.score > h1.score) { h1.q_gapped_start = h2.q_gapped_start; h1.s_gapped_start = h2.s_gapped_start; h1.score = h2.score; h1.evalue = h2.evalue; }
+                gone[j] = 1;
+            }
+        }
+    }
+    for (size_t j = 0; j < cur.size(); j++) if (!gone[j]) comb.push_back(cur[j]);
+    std::stable_sort(comb.begin(), comb.end(), by_score);
+    cur.clear();
+}
+
+void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len)
+{
+    std::vector<GbnHSP> out; out.reserve(hsps.size());
+    const int32_t stride = chunk_len - kDbseqChunkOverlap;
+    for (size_t i = 0; i < hsps.size();) {
+        if (hsps[i].pad_ == 0) { out.push_back(hsps[i++]); continue; }
+        // the chunk lists of one sequence follow each other in chunk order
+        const int32_t oid = hsps[i].oid;
+        std::vector<GbnHSP> comb;
+        while (i < hsps.size() && hsps[i].pad_ != 0 && hsps[i].oid == oid) {
+            const int32_t ord = hsps[i].pad_ - 1;
+            std::vector<GbnHSP> cur;
+            while (i < hsps.size() && hsps[i].oid == oid && hsps[i].pad_ == ord + 1) { cur.push_back(hsps[i]); cur.back().pad_ = 0; i++; }
+            // the first chunk starts where its range does: no overlap strip on its left (CORE/blast_engine.c:532-533)
+            merge_two_lists(comb, cur, ord * stride, ord == 0 ? 0 : kDbseqChunkOverlap);
+        }
+        out.insert(out.end(), comb.begin(), comb.end());
+    }
+    hsps.swap(out);
+}
+
 void sort_by_score(std::vector<GbnHSP> &v) {
     if (!std::is_sorted(v.begin(), v.end(), by_score)) std::stable_sort(v.begin(), v.end(), by_score);
 }

@@ -581,15 +581,17 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
         const int32_t oid = hsps[list_start[l]].oid;
         int64_t e = l;
         while (e < nlists && hsps[list_start[e]].oid == oid) e++;
-        const int32_t local = oid - db->first_oid;
-        if (local < 0 || local >= db->num_seqs) { set_error("gbn_traceback_run: subject id outside this shard"); return GBN_ERR_ARG; }
+        const int32_t local = oid - db->first_oid;         // the sequence's index in the shard (not a chunk's: db->real_*)
+        if (local < 0 || local >= db->real_seqs) { set_error("gbn_traceback_run: subject id outside this shard"); return GBN_ERR_ARG; }
         work.push_back(Work{local, l, e, 0, {}});
         l = e;
     }
     {
-        std::vector<int64_t> src_off; std::vector<int32_t> nbytes; std::vector<int32_t> his;
+        std::vector<int64_t> src_off; std::vector<int32_t> nbytes; std::vector<int32_t> his, wbytes;
+        const bool chunked = !db->real_of.empty();
+        auto seq_len = [&](int32_t local) { return chunked ? db->real_len[(size_t)local] : db->len[(size_t)local]; };
         for (Work &w : work) {
-            const int32_t len = db->len[(size_t)w.local];
+            const int32_t len = seq_len(w.local);
             int32_t lo = 0, hi = len;
             if (len >= 90000) {
                 lo = len; hi = 0;
@@ -601,8 +603,25 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
                 lo &= ~3;
             }
             w.lo = lo; his.push_back(hi);
-            src_off.push_back(db->byte_off[(size_t)w.local] + (lo >> 2));
-            nbytes.push_back((hi - lo + 3) / 4);
+            if (!chunked) {
+                src_off.push_back(db->byte_off[(size_t)w.local] + (lo >> 2));
+                nbytes.push_back((hi - lo + 3) / 4); wbytes.push_back(nbytes.back());
+            } else {
+                // the sequence exists as overlapping chunk copies (a chunk starts on a byte of its sequence): the
+                // stretch is put together from the chunks it crosses
+                const int64_t stride = (int64_t)db->chunk_len - kDbseqChunkOverlap;
+                int32_t total = 0;
+                for (int64_t pos = lo; pos < hi;) {
+                    int64_t c = std::min<int64_t>(pos / stride, (int64_t)(w.local + 1 < db->real_seqs ? db->first_virt[(size_t)w.local + 1] : db->num_seqs) - db->first_virt[(size_t)w.local] - 1);
+                    const int32_t v = db->first_virt[(size_t)w.local] + (int32_t)c;
+                    const int64_t coff = c * stride, cend = coff + db->len[(size_t)v];
+                    const int64_t upto = std::min<int64_t>(hi, cend);
+                    const int32_t nb = (int32_t)((upto - pos + 3) / 4);
+                    src_off.push_back(db->byte_off[(size_t)v] + ((pos - coff) >> 2)); nbytes.push_back(nb); total += nb;
+                    pos = upto;                                             // (a multiple of 4 unless it is `hi`)
+                }
+                wbytes.push_back(total);
+            }
         }
         std::vector<uint8_t> packed;
         const int rc = gather_shard_bytes(*db, src_off, nbytes, packed);
@@ -615,7 +634,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
             w.bases.resize(((size_t)n + 3) / 4 * 4 + 4);
             uint8_t *o = w.bases.data();
             for (int32_t i = 0; i < (n + 3) / 4; i++, o += 4) { const uint8_t c = p[i]; o[0] = c >> 6; o[1] = (c >> 4) & 3; o[2] = (c >> 2) & 3; o[3] = c & 3; }
-            at += (size_t)nbytes[k];
+            at += (size_t)wbytes[k];
         }
     }
     struct Done { int32_t oid, query; std::vector<Item> items; };
@@ -629,7 +648,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
                 const GbnHSP *first = hsps + list_start[l]; const size_t n = (size_t)(list_start[l + 1] - list_start[l]);
                 Done d; d.oid = first->oid; d.query = first->context / 2;
                 // (base 0 of the subject sits at w.bases - w.lo; nothing outside the stretch read back is touched)
-                const int rc = traceback_list(*batch, w.bases.data() - w.lo, db->len[(size_t)w.local], first, n, d.items);
+                const int rc = traceback_list(*batch, w.bases.data() - w.lo, db->real_of.empty() ? db->len[(size_t)w.local] : db->real_len[(size_t)w.local], first, n, d.items);
                 if (rc != GBN_OK) { std::lock_guard<std::mutex> lk(err_mu); failed = rc; err = gbn_last_error(); return; }
                 for (Item &it : d.items) it.h.oid = d.oid;
                 if (!d.items.empty()) per_work[k].push_back(std::move(d));

@@ -147,6 +147,12 @@ int  gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_
                 const int64_t *byte_off, const int32_t *len, int32_t first_oid,
                 int is_device);
 void gbn_db_free(GbnDb *db);
+/* Sequences longer than MAX_DBSEQ_LEN are searched in chunks of that length overlapping by DBSEQ_CHUNK_OVERLAP (100),
+ * the chunks' HSP lists merged (CORE/blast_engine.c:218-262, :455-540; Blast_HSPListsMerge CORE/blast_hits.c:2545):
+ * a shard made after this call holds such sequences as chunk copies, everything a caller sees stays in sequence
+ * coordinates.  Default 200,000,000 = G-BLASTN's build (COREI/blast_gapalign.h:54-55; stock BLAST+: 5,000,000);
+ * a multiple of 4, >= 1000 (tests lower it). */
+int  gbn_set_max_dbseq_len(int32_t max_len);
 /* the same shard from subjects handed over one at a time, as BlastSeqSrcGetSequence yields them (NCBI2na,
  * `length` bases; OIDs = order of the calls); _finish uploads the slab and leaves the builder empty */
 typedef struct GbnShardBuilder GbnShardBuilder;

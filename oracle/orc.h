@@ -128,6 +128,13 @@ const uint8_t *orc_query_concat(const OrcSearch *s); /* points past 1st sentinel
  * packed: NCBI2na, 4 bases/byte, base 0 in bits 7..6 (ceil(len/4) bytes,
  * plus >= 4 readable pad bytes).  Outputs are malloc'd arrays owned by the
  * OrcSearch and valid until the next call. */
+/* the same for a subject the engine takes in chunks of max_len bases (MAX_DBSEQ_LEN: 200,000,000 in G-BLASTN's
+ * build, COREI/blast_gapalign.h:54-55) overlapping by DBSEQ_CHUNK_OVERLAP, chunk lists merged as Blast_HSPListsMerge
+ * does; only the HSPs are left to read */
+int orc_search_subject_chunked(OrcSearch *s, const uint8_t *packed, int32_t len, int32_t max_len, OrcStats *stats);
+/* 1: the diagonal container survives from one orc_search_subject call to the next, as in the reference
+ * (Blast_ExtendWordExit, CORE/blast_extend.c:166-190); 0 (default): fresh per subject */
+void orc_search_carry_diag(OrcSearch *s, int on);
 int orc_search_subject(OrcSearch *s, const uint8_t *packed, int32_t len,
                        OrcStats *stats);
 int32_t orc_num_seeds(const OrcSearch *s);

@@ -287,6 +287,22 @@ class Search:
         p = self._L.orc_query_concat(self._h)
         return np.ctypeslib.as_array(p, shape=(n,)).copy()
 
+    def subject_chunked(self, packed, length, max_len):
+        """a subject longer than the engine's MAX_DBSEQ_LEN: searched in chunks, lists merged -> hsps only"""
+        packed = np.ascontiguousarray(packed, dtype=np.uint8)
+        self._L.orc_search_subject_chunked.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(OrcStats)]
+        rc = self._L.orc_search_subject_chunked(self._h, packed.ctypes.data, length, max_len, C.byref(self.stats))
+        assert rc == 0
+        n = self._L.orc_num_hsps(self._h)
+        if n == 0:
+            return np.zeros(0, dtype=HSP_DT)
+        return np.frombuffer(C.string_at(self._L.orc_hsps(self._h), n * C.sizeof(OrcHSP)), dtype=HSP_DT).copy()
+
+    def carry_diag(self, on=True):
+        """the diagonal container carried across subjects (reference behaviour) instead of fresh per subject"""
+        self._L.orc_search_carry_diag.argtypes = [C.c_void_p, C.c_int]
+        self._L.orc_search_carry_diag(self._h, 1 if on else 0)
+
     def subject(self, packed, length):
         """Run one subject; returns dict(seeds, init_hits, hsps) as numpy structured arrays."""
         packed = np.ascontiguousarray(packed, dtype=np.uint8)

@@ -67,6 +67,9 @@ struct OrcSearch {
     /* diag containers (fresh per subject; see DESIGN.md on the stale-slot rule) */
     int32_t *diag_last_hit; int32_t diag_len, diag_mask;
     void *diag_hash;
+    /* the diagonal container carried from subject to subject as the reference does (Blast_ExtendWordExit,
+     * CORE/blast_extend.c:166-190) instead of starting fresh: off by default, see orc_search_carry_diag */
+    int carry_diag, carry_started; int32_t diag_offset;
 };
 
 int  orc_context_of(const OrcSearch *s, int32_t q_off);   /* BSearchContextInfo */

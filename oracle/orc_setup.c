@@ -336,3 +336,74 @@ int orc_search_subject(OrcSearch *s, const uint8_t *packed, int32_t len, OrcStat
     }
     return 0;
 }
+
+/* ---------------- a subject searched in chunks: s_GetNextSubjectChunk + the chunk loop of
+ * s_BlastSearchEngineCore (CORE/blast_engine.c:218-262, :455-540) and Blast_HSPListsMerge with
+ * s_BlastMergeTwoHSPs (CORE/blast_hits.c:2545-2716, :1337-1378), no hard or soft subject masks ---------------- */
+#define ORC_CHUNK_OVERLAP 100      /* DBSEQ_CHUNK_OVERLAP, COREI/blast_hits.h:169 */
+#define ORC_DIAG_CLOSE 10          /* OVERLAP_DIAG_CLOSE, CORE/blast_hits.c:1386 */
+#define ORC_CONTAINED(a,b,c,d,e,f) (((a) <= (c) && (b) >= (c)) && ((d) <= (f) && (e) >= (f)))   /* CORE/blast_hits_priv.h:68 */
+
+static int merge_two(OrcHSP *h1, const OrcHSP *h2)
+{
+    if (ORC_CONTAINED(h1->q_offset, h1->q_end, h2->q_offset, h1->s_offset, h1->s_end, h2->s_offset) ||
+        ORC_CONTAINED(h1->q_offset, h1->q_end, h2->q_end, h1->s_offset, h1->s_end, h2->s_end)) {
+        h1->q_offset = ORC_MIN(h1->q_offset, h2->q_offset); h1->s_offset = ORC_MIN(h1->s_offset, h2->s_offset);
+        h1->q_end = ORC_MAX(h1->q_end, h2->q_end); h1->s_end = ORC_MAX(h1->s_end, h2->s_end);
+        if (h2->score > h1->score) {
+            h1->q_gapped_start = h2->q_gapped_start; h1->s_gapped_start = h2->s_gapped_start;
+            h1->score = h2->score; h1->evalue = h2->evalue;     /* (the e-value belongs to the score) */
+        }
+        return 1;
+    }
+    return 0;
+}
+
+/* comb[0..*ncomb) += cur[0..ncur) of the chunk that starts at split_offset; comb has room for both */
+static void lists_merge(OrcHSP *comb, int32_t *ncomb, OrcHSP *cur, int32_t ncur, int32_t split_offset, int32_t overlap)
+{
+    int32_t i1, i2, n1 = 0, n2 = 0, n = *ncomb;
+    OrcHSP t;
+    if (ncur == 0) return;
+    if (n == 0) { memcpy(comb, cur, (size_t)ncur * sizeof(OrcHSP)); *ncomb = ncur; return; }
+    for (i1 = 0; i1 < n; i1++)
+        if (comb[i1].s_end > split_offset) { t = comb[n1]; comb[n1] = comb[i1]; comb[i1] = t; n1++; }
+    for (i2 = 0; i2 < ncur; i2++)
+        if (cur[i2].s_offset < split_offset + overlap) { t = cur[n2]; cur[n2] = cur[i2]; cur[i2] = t; n2++; }
+    for (i1 = 0; i1 < n1; i1++)
+        for (i2 = 0; i2 < n2; i2++) {
+            int32_t end_diag, start_diag;
+            if (cur[i2].score == ORC_INT4_MIN || comb[i1].context != cur[i2].context) continue;    /* (deleted) */
+            end_diag = comb[i1].q_end - comb[i1].s_end; start_diag = cur[i2].q_offset - cur[i2].s_offset;
+            if (abs(end_diag - start_diag) < ORC_DIAG_CLOSE && merge_two(&comb[i1], &cur[i2])) cur[i2].score = ORC_INT4_MIN;
+        }
+    for (i2 = 0; i2 < ncur; i2++) if (cur[i2].score != ORC_INT4_MIN) comb[n++] = cur[i2];
+    *ncomb = n;
+    orc_hsplist_sort_by_score(comb, n);
+}
+
+int orc_search_subject_chunked(OrcSearch *s, const uint8_t *packed, int32_t len, int32_t max_len, OrcStats *stats)
+{
+    OrcHSP *comb = NULL; int32_t ncomb = 0, ccomb = 0, next = 0, first = 1;
+    if (max_len < 1000 || (max_len & 3)) return -1;
+    while (next < len) {
+        const int32_t offset = next;                /* a multiple of 4: residual 0 */
+        int32_t clen, i;
+        if (offset + max_len < len) { clen = max_len; next = offset + max_len - ORC_CHUNK_OVERLAP; }
+        else { clen = len - offset; next = len; }
+        orc_search_subject(s, packed + offset / 4, clen, stats);
+        if (s->nhsps == 0) { first = 0; continue; }
+        for (i = 0; i < s->nhsps; i++) {            /* Blast_HSPListAdjustOffsets */
+            s->hsps[i].s_offset += offset; s->hsps[i].s_end += offset; s->hsps[i].s_gapped_start += offset;
+        }
+        if (ncomb + s->nhsps > ccomb) { ccomb = 2 * (ncomb + s->nhsps) + 16; comb = (OrcHSP *)realloc(comb, (size_t)ccomb * sizeof(OrcHSP)); }
+        lists_merge(comb, &ncomb, s->hsps, s->nhsps, offset, offset == 0 ? 0 : ORC_CHUNK_OVERLAP);
+        first = 0;
+    }
+    (void)first;
+    if (ncomb > s->chsps) { s->chsps = ncomb; s->hsps = (OrcHSP *)realloc(s->hsps, (size_t)ncomb * sizeof(OrcHSP)); }
+    if (ncomb) memcpy(s->hsps, comb, (size_t)ncomb * sizeof(OrcHSP));
+    s->nhsps = ncomb; s->nseeds = 0; s->nihits = 0;
+    free(comb);
+    return 0;
+}

@@ -213,7 +213,7 @@ static int diag_extend(OrcSearch *S, const uint8_t *subj, int32_t slen,
         diag = s_off + S->diag_len - q_off;
         real_diag = diag & S->diag_mask;
         last_hit = S->diag_last_hit[real_diag];
-        s_off_pos = s_off; s_end_pos = s_end;       /* offset 0: fresh per subject */
+        s_off_pos = s_off + S->diag_offset; s_end_pos = s_end + S->diag_offset;       /* offset 0 unless carried */
     }
     if (s_off_pos < last_hit) return 0;
 
@@ -236,7 +236,7 @@ static int diag_extend(OrcSearch *S, const uint8_t *subj, int32_t slen,
         ih.q_off = q_off; ih.s_off = s_off;
         ih.q_start = u.q_start; ih.s_start = u.s_start; ih.length = u.length; ih.score = u.score;
         orc_push_ihit(S, &ih);
-        s_end_pos = u.length + u.s_start + (h ? h->offset : 0);
+        s_end_pos = u.length + u.s_start + (h ? h->offset : S->diag_offset);
     } else {
         hit_ready = 0;
     }
@@ -378,8 +378,11 @@ void orc_word_finder(OrcSearch *S, const uint8_t *subj, int32_t slen, OrcStats *
         mode = (lut % 4 == 0 && step % 4 == 0 && word - lut <= 4) ? 3 : 2;
     else mode = 1;
 
-    if (S->container == ORC_DIAG_HASH) dhash_reset(dhash_get(S));
-    else memset(S->diag_last_hit, 0, (size_t)S->diag_len * sizeof(int32_t));
+    if (!S->carry_diag || !S->carry_started) {
+        if (S->container == ORC_DIAG_HASH) dhash_reset(dhash_get(S));
+        else { memset(S->diag_last_hit, 0, (size_t)S->diag_len * sizeof(int32_t)); S->diag_offset = 0; }
+        S->carry_started = 1;
+    }
 
     for (s_off = 0; s_off <= last; s_off += step) {
         uint32_t idx; int32_t nh, j;
@@ -421,4 +424,16 @@ void orc_word_finder(OrcSearch *S, const uint8_t *subj, int32_t slen, OrcStats *
     }
     st->good_init_extends += S->nihits;
     ihit_sort(S->ihits, S->nihits);
+    if (S->carry_diag) {                /* Blast_ExtendWordExit (CORE/blast_extend.c:166-190), window 0 */
+        if (S->container == ORC_DIAG_HASH) {
+            DHash *h = dhash_get(S);
+            if (h->offset >= INT32_MAX / 4) dhash_reset(h); else h->offset += slen;
+        } else if (S->diag_offset >= INT32_MAX / 4) {
+            memset(S->diag_last_hit, 0, (size_t)S->diag_len * sizeof(int32_t)); S->diag_offset = 0;
+        } else S->diag_offset += slen;
+    }
 }
+
+/* carry the diagonal container across subjects as the reference does (1), or start every subject with a fresh
+ * one (0, the default and what the HIP path does -- DESIGN.md "a6") */
+void orc_search_carry_diag(OrcSearch *S, int on) { S->carry_diag = on; S->carry_started = 0; }
