@@ -1,0 +1,89 @@
+"""a6, the one documented deviation: the reference keeps ONE diagonal container per thread and carries it from
+subject to subject (Blast_ExtendWordExit moves an offset past the subject, CORE/blast_extend.c:166-190); the HIP path
+and, by default, the oracle start every subject with a fresh one (subjects are searched in parallel).
+
+* Array container (queries of fewer than 8000 bases in all): the two are the same function -- a carried entry is
+  always below the new subject's first position.  Checked here on every subject of a multi-subject case.
+* Hash container: stale cells never match a lookup, but they sit in the bucket chains and are recycled before a new
+  cell is appended, so the ORDER of a chain can differ, and with it which of two expired cells the next insert
+  overwrites.  The oracle can run either way (Search.carry_diag); the tests compare the two on the committed
+  databases and on repeat-rich constructions built to stress one bucket (diverged copies of one element at query
+  offsets congruent modulo 512): no difference in initial hits or HSPs on any of them -- the deviation needs three
+  congruent diagonals interleaved within a word length AND an extension whose outcome depends on which seed of a
+  diagonal is extended first; DESIGN.md "a6" has the analysis."""
+import os
+import numpy as np
+import pytest
+from oracle import orc
+
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def run(queries, subjects, carry, megablast=False):
+    S = orc.Search(orc.default_options(megablast, db_length=10**7, db_num_seqs=10), queries)
+    if carry:
+        S.carry_diag(True)
+    out = []
+    for s in subjects:
+        r = S.subject(np.concatenate([orc.pack_ncbi2na(s), np.zeros(16, np.uint8)]), len(s))
+        out.append((r["init_hits"].tobytes(), r["hsps"].tobytes(), len(r["init_hits"])))
+    return out, S.info()["container"]
+
+
+def repeat_rich(seed, nq=9):
+    """diverged copies of one 300-base element: in the queries at offsets congruent modulo 512 (their diagonals
+    against one subject copy share a hash bucket), and three times in every subject"""
+    rng = np.random.default_rng(seed)
+    E = rng.integers(0, 4, 300).astype(np.uint8)
+
+    def copy(div):
+        c = E.copy(); m = rng.random(300) < div
+        c[m] = (c[m] + 1 + rng.integers(0, 3, int(m.sum()))) % 4
+        return c
+    qs = [rng.integers(0, 4, 1100).astype(np.uint8) for _ in range(nq)]
+    S = orc.Search(orc.default_options(False, db_length=10**7, db_num_seqs=10), qs)
+    off = [S.contexts[2 * k].query_offset for k in range(nq)]
+    base = off[0] + 100
+    for k in range(nq):
+        ak = (int(rng.integers(0, 6)) + base - off[k]) % 512
+        if ak < 20:
+            ak += 512
+        qs[k][ak:ak + 300] = copy(rng.uniform(0.05, 0.2))
+    subs = []
+    for _ in range(3):
+        s = rng.integers(0, 4, 4000).astype(np.uint8)
+        for p in (500, 1500 + int(rng.integers(0, 8)), 2600):
+            s[p:p + 300] = copy(rng.uniform(0.03, 0.15))
+        subs.append(s)
+    return qs, subs
+
+
+def test_array_container_carried_equals_fresh():
+    for seed in range(6):
+        qs, subs = repeat_rich(seed, nq=3)              # 3 x 1100 x 2 strands < 8000: the diagonal array
+        a, ca = run(qs, subs, False); b, cb = run(qs, subs, True)
+        assert ca == cb == 0
+        assert a == b and sum(x[2] for x in a) > 0
+
+
+def test_hash_container_carried_equals_fresh_on_repeat_rich_subjects():
+    hits = 0
+    for seed in range(40):
+        qs, subs = repeat_rich(seed)
+        a, ca = run(qs, subs, False); b, cb = run(qs, subs, True)
+        assert ca == cb == 1
+        assert a == b, seed
+        hits += sum(x[2] for x in a)
+    assert hits > 1000                                  # the bucket under stress produced initial hits throughout
+
+
+def test_hash_container_carried_equals_fresh_on_the_unit_test_database():
+    from gblastn_amd import api
+    db = api.BlastDb(os.path.join(G, "seqn"))
+    rng = np.random.default_rng(5)
+    oids = list(range(5, 2000, 67))
+    queries = [np.minimum(db.blastna(o)[:1500], 3).astype(np.uint8) for o in oids]      # 30 queries, > 8000 bases in all: the hash
+    subjects = [orc.unpack_ncbi2na(*db.ncbi2na(o)) for o in list(range(0, 400)) + oids]
+    a, ca = run(queries, subjects, False, megablast=True); b, cb = run(queries, subjects, True, megablast=True)
+    assert ca == cb == 1 and a == b
+    assert sum(x[2] for x in a) >= len(oids)
