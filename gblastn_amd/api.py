@@ -86,7 +86,7 @@ EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_de
            "gbn_pipeline_diagnostics",
            "gbn_batch_scan_params", "gbn_batch_ext_params", "gbn_batch_gap_params", "gbn_batch_diag_layout",
            "gbn_prelim_search_lists", "gbn_db_cache_find", "gbn_db_cache_insert",
-           "gbn_set_max_dbseq_len", "gbn_traceback_merge", "gbn_shard_builder_new", "gbn_shard_builder_add", "gbn_shard_builder_finish", "gbn_shard_builder_free"]
+           "gbn_set_max_dbseq_len", "gbn_db_set_ambiguities", "gbn_traceback_merge", "gbn_shard_builder_new", "gbn_shard_builder_add", "gbn_shard_builder_finish", "gbn_shard_builder_free"]
 
 # ---- include/gblastn_amd_kernels.h: parameter blocks of the gbn_launch_* entry points (device pointers as integers)
 _P, _I, _L, _U, _UL = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64

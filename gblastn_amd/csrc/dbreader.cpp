@@ -264,7 +264,19 @@ int gbn_blastdb_load_shard(const GbnBlastDb *db, int32_t first_oid, int32_t num_
         int rc = gbn_blastdb_get_ncbi2na(db, first_oid + i, slab.data() + off[i], ((int64_t)len[i] + 3) / 4);
         if (rc) return rc;
     }
-    return gbn_db_new(out, slab.data(), nbytes, num_oids, off.data(), len.data(), first_oid, 0);
+    int rc = gbn_db_new(out, slab.data(), nbytes, num_oids, off.data(), len.data(), first_oid, 0);
+    if (rc) return rc;
+    // the ambiguity runs travel with the shard: the traceback stage needs the codes the 2-bit data cannot hold
+    std::vector<int32_t> st, ln; std::vector<uint8_t> val;
+    for (int32_t i = 0; i < num_oids && !rc; i++) {
+        const int32_t k = gbn_blastdb_num_ambiguities(db, first_oid + i);
+        if (k <= 0) continue;
+        st.resize((size_t)k); ln.resize((size_t)k); val.resize((size_t)k);
+        rc = gbn_blastdb_get_ambiguities(db, first_oid + i, st.data(), ln.data(), val.data(), k);
+        if (!rc) rc = gbn_db_set_ambiguities(*out, i, k, st.data(), ln.data(), val.data());
+    }
+    if (rc) { gbn_db_free(*out); *out = nullptr; }
+    return rc;
 }
 
 }  // extern "C"

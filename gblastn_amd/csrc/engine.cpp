@@ -1343,6 +1343,18 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
     *out = db;
     return GBN_OK;
 }
+// ambiguity runs of sequence `local` (0-based in the shard), values in NCBI4na as the database stores them
+// (gbn_blastdb_get_ambiguities); gbn_blastdb_load_shard calls this for every sequence that has runs
+int gbn_db_set_ambiguities(GbnDb *db, int32_t local, int32_t n, const int32_t *start, const int32_t *length, const uint8_t *ncbi4na) {
+    static const uint8_t kNa4ToBlastna[16] = {15, 0, 1, 6, 2, 4, 9, 13, 3, 8, 5, 12, 7, 11, 10, 14};    // CORE/blast_encoding.c:42-59
+    if (!db || local < 0 || local >= db->real_seqs || n < 0 || (n > 0 && (!start || !length || !ncbi4na))) { set_error("gbn_db_set_ambiguities: bad argument"); return GBN_ERR_ARG; }
+    if (db->amb.empty()) db->amb.resize((size_t)db->real_seqs);
+    auto &v = db->amb[(size_t)local];
+    v.clear();
+    for (int32_t i = 0; i < n; i++) v.push_back(GbnDb::AmbRun{start[i], length[i], kNa4ToBlastna[ncbi4na[i] & 15]});
+    return GBN_OK;
+}
+
 void gbn_db_free(GbnDb *db) {
     if (!db) return;
     use_engine_device();

@@ -84,6 +84,11 @@ struct GbnDb {
     std::vector<int32_t> real_of, chunk_ord;    // per chunk: its sequence, its ordinal in it
     std::vector<int32_t> real_len, first_virt;  // per sequence: its length, its first chunk
     int32_t chunk_len = 0;                      // MAX_DBSEQ_LEN the shard was built with
+    // ambiguity runs of the sequences (BLASTNA code 4..15 over [start, start + length)): the shard holds 2 bits per
+    // base, the traceback stage puts the codes back before it aligns (CORE/blast_traceback.c: the subject is
+    // fetched as eBlastEncodingNucleotide there).  Empty: no sequence has any.
+    struct AmbRun { int32_t start, length; uint8_t code; };
+    std::vector<std::vector<AmbRun>> amb;       // per sequence (sized on first use)
     int32_t oid_of(int32_t v) const { return first_oid + (real_of.empty() ? v : real_of[(size_t)v]); }
     int32_t chunk_of(int32_t v) const { return real_of.empty() ? 0 : chunk_ord[(size_t)v]; }
 };

@@ -635,6 +635,11 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
             uint8_t *o = w.bases.data();
             for (int32_t i = 0; i < (n + 3) / 4; i++, o += 4) { const uint8_t c = p[i]; o[0] = c >> 6; o[1] = (c >> 4) & 3; o[2] = (c >> 2) & 3; o[3] = c & 3; }
             at += (size_t)wbytes[k];
+            if (!db->amb.empty())               // the codes the 2-bit data cannot hold
+                for (const GbnDb::AmbRun &r : db->amb[(size_t)w.local]) {
+                    const int32_t a = std::max(r.start, w.lo), e = std::min(r.start + r.length, his[k]);
+                    for (int32_t x = a; x < e; x++) w.bases[(size_t)(x - w.lo)] = r.code;
+                }
         }
     }
     struct Done { int32_t oid, query; std::vector<Item> items; };

@@ -147,6 +147,12 @@ int  gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_
                 const int64_t *byte_off, const int32_t *len, int32_t first_oid,
                 int is_device);
 void gbn_db_free(GbnDb *db);
+/* Ambiguity runs of sequence `local` (0-based in the shard; values in NCBI4na as gbn_blastdb_get_ambiguities gives
+ * them): the slab holds 2 bits per base, the traceback stage puts these codes back before it aligns, as the
+ * reference fetches the subject with its ambiguities there (CORE/blast_traceback.c:1375-1639).
+ * gbn_blastdb_load_shard attaches them by itself. */
+int  gbn_db_set_ambiguities(GbnDb *db, int32_t local, int32_t n, const int32_t *start, const int32_t *length,
+                            const uint8_t *ncbi4na);
 /* Sequences longer than MAX_DBSEQ_LEN are searched in chunks of that length overlapping by DBSEQ_CHUNK_OVERLAP (100),
  * the chunks' HSP lists merged (CORE/blast_engine.c:218-262, :455-540; Blast_HSPListsMerge CORE/blast_hits.c:2545):
  * a shard made after this call holds such sequences as chunk copies, everything a caller sees stays in sequence
