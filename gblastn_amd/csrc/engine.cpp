@@ -98,6 +98,16 @@ struct Engine {
     uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;             // per-run stream cursors (6-byte records)
     GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
     uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;   // [nb][nwriters] + overflow flag
+    // a second set of the five buffers above: the rare kernel of pass k reads one set on stream2 while the binning
+    // and probe kernels of pass k + 1 fill the other (search_range, deferred rare path); swapped when a pass is handed over
+    struct ScanSet { unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0; uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;
+                     GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr; uint32_t *bin_count = nullptr; size_t bin_count_cap = 0; } alt;
+    void swap_scan_sets() {
+        std::swap(bin_rec, alt.bin_rec); std::swap(bin_rec_cap, alt.bin_rec_cap); std::swap(bin_tcur, alt.bin_tcur); std::swap(bin_tcur_cap, alt.bin_tcur_cap);
+        std::swap(rareq, alt.rareq); std::swap(rareq_cap, alt.rareq_cap); std::swap(rare_counts, alt.rare_counts);
+        std::swap(bin_count, alt.bin_count); std::swap(bin_count_cap, alt.bin_count_cap);
+    }
+    hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;       // around a deferred rare kernel (stream2)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk[4] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex mu;
 };
@@ -615,8 +625,10 @@ static int choose_bins(const GbnBatch &b) {
 
 // one scan of the subjects [s0, s1): fills E.seeds / cnt[0] seeds, cnt[1] raw hits;
 // dispatches to the direct-probe kernel (small tables) or the partitioned pair
+// the rare kernel of a scan, left for another stream to run (search_range): its parameter block and launch shape
+struct DeferredRare { bool valid = false; GbnBinParams B; int grid2 = 0; };
 static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
-                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed);
+                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed, DeferredRare *defer = nullptr);
 
 // The partitioned scan sizes its streams for lookup words spread evenly over the bins (x1.25, x2.5).
 // Subjects dominated by one repeat (satellite arrays, poly-A) put most positions of a range into a
@@ -624,10 +636,10 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
 static const int kSkewedRange = -1000;       // internal: split this subject range and try again
 
 static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
-                    unsigned long long cnt[2], int64_t *bases_out)
+                    unsigned long long cnt[2], int64_t *bases_out, DeferredRare *defer = nullptr)
 {
     bool skewed = false;
-    int rc = run_scan_impl(b, db, s0, s1, diag, cnt, bases_out, false, &skewed);
+    int rc = run_scan_impl(b, db, s0, s1, diag, cnt, bases_out, false, &skewed, defer);
     if (rc != GBN_OK || !skewed) return rc;
     int64_t bases = 0;
     for (int32_t s = s0; s < s1; s++) bases += db.len[s];
@@ -638,9 +650,11 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
 }
 
 static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
-                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed)
+                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed, DeferredRare *defer)
 {
     const int nb = direct ? 1 : choose_bins(b);
+    if (nb == 1) defer = nullptr;                           // the direct-probe kernel has no rare kernel
+    if (defer) defer->valid = false;
     const TileSet *tsp = nullptr;
     int rc = get_tiles(db, b.lut.lut, b.lut.step, nb > 1 ? GBN_BIN_TILE_POS : GBN_TILE_POS, s0, s1, &tsp);
     if (rc) return rc;
@@ -723,9 +737,10 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                              have.step == want_key.step && have.nb == nb && have.nwriters == nwriters && have.subcap == subcap;
             have.valid = false;
             HIPCHK(hipEventRecord(E.ev0, E.stream));
-            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, hit ? 2 : 3, b.dev->ready));
+            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, (hit ? 2 : 3) | (defer ? 0 : 4), b.dev->ready));
             have = want_key;                                    // invalidated below if this launch overflowed
             binned = true;
+            if (defer) { defer->B = B; defer->grid2 = grid2; }
             HIPCHK(hipEventRecord(E.ev1, E.stream));
             HIPCHK(hipMemcpyAsync(&overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
         }
@@ -784,6 +799,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             if (slack > 3.0) { *skewed = true; return GBN_OK; }
             continue;
         }
+        if (defer) { defer->valid = true; break; }          // (the seeds do not exist yet: whoever runs the rare kernel sizes their buffer)
         if (cnt[0] <= E.seed_cap) break;
         if ((rc = grow_seed_buffers((size_t)cnt[0] + (cnt[0] >> 3)))) return rc;
     }
@@ -911,7 +927,14 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_stage = now();
     trace_mark("range: scan starts");
-    int rc = run_scan(b, db, s0, s1, diag, cnt, &bases);
+    // Megablast shapes (lookup words shorter than the word size: a handful of seeds per million lookup hits) with the
+    // next batch already waiting: the rare kernel -- random sectors, latency bound -- is left to the asynchronous
+    // stage, where it runs on stream2 next to the HBM-bound binning kernel of the next pass.  GBN_DEFER_RARE=0: off.
+    static const bool defer_on = !(getenv("GBN_DEFER_RARE") && atoi(getenv("GBN_DEFER_RARE")) == 0);
+    static const bool reuse_on = getenv("GBN_REUSE_BINNING") && atoi(getenv("GBN_REUSE_BINNING")) != 0;
+    DeferredRare defer;
+    const bool want_defer = defer_on && !reuse_on && overlap && !keep_stages && b.lut.lut != b.lut.word;
+    int rc = run_scan(b, db, s0, s1, diag, cnt, &bases, want_defer ? &defer : nullptr);
     trace_mark("scan done");
     if (rc == kSkewedRange) {
         // lookup words of this range pile up in a few bins: halve it (by packed size) until the repeat-rich
@@ -928,6 +951,57 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     if (rc) return rc;
     if (diag) diag->scan_stage_ms += ms_since(t_stage);
     t_stage = now();
+    if (defer.valid) {
+        if (diag) diag->subject_bases_scanned += bases;
+        if ((rc = wait_pending())) return rc;               // one asynchronous stage in flight at most; its buffer set is free again
+        if (E.seeds_async_cap < ((size_t)1 << 22)) {
+            dev_free(E.seeds_async); E.seeds_async_cap = 0;
+            if ((rc = dev_alloc(E.seeds_async, (size_t)1 << 22))) return rc;
+            E.seeds_async_cap = (size_t)1 << 22;
+        }
+        if (!E.ev_r0) { HIPCHK(hipEventCreate(&E.ev_r0)); HIPCHK(hipEventCreate(&E.ev_r1)); }
+        E.swap_scan_sets();                                 // the next scan fills the other set
+        E.slot ^= 1;
+        E.pending_err.clear();
+        const int dev = E.device;
+        const unsigned long long raw_probe = cnt[1];
+        GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
+        E.pending = std::async(std::launch::async, [=]() -> int {
+            auto fail = [](int code, const char *what) { E.pending_err = what; return code; };
+            if (hipSetDevice(dev) != hipSuccess) return fail(GBN_ERR_HIP, "hipSetDevice failed in the extension thread");
+            GbnBinParams B = defer.B;
+            unsigned long long c2[2] = {0, 0};
+            for (;;) {
+                if (hipMemsetAsync(E.counters + 6, 0, 2 * sizeof(unsigned long long), E.stream2) != hipSuccess) return fail(GBN_ERR_HIP, "memset failed");
+                B.S.seeds = E.seeds_async; B.S.seed_count = E.counters + 6; B.S.seed_cap = E.seeds_async_cap; B.S.raw_hits = E.counters + 7;
+                (void)hipEventRecord(E.ev_r0, E.stream2);
+                if (launch_scan_bin_parts(B, defer.grid2, E.stream2, nullptr, 4, nullptr) != hipSuccess) return fail(GBN_ERR_HIP, "rare kernel launch failed");
+                (void)hipEventRecord(E.ev_r1, E.stream2);
+                if (hipMemcpyAsync(c2, E.counters + 6, sizeof(c2), hipMemcpyDeviceToHost, E.stream2) != hipSuccess ||
+                    hipStreamSynchronize(E.stream2) != hipSuccess) return fail(GBN_ERR_HIP, "rare kernel failed");
+                if (c2[0] <= E.seeds_async_cap) break;
+                dev_free(E.seeds_async); E.seeds_async_cap = 0;     // more seeds than room: once more with room
+                const size_t want = (size_t)c2[0] + (size_t)(c2[0] >> 3);
+                if (dev_alloc(E.seeds_async, want)) return fail(GBN_ERR_NOMEM, "out of device memory (seeds)");
+                E.seeds_async_cap = want;
+            }
+            if (diag) {
+                float ms = 0; (void)hipEventElapsedTime(&ms, E.ev_r0, E.ev_r1);
+                diag->rare_kernel_ms += ms; diag->scan_kernel_ms += ms;
+                diag->lookup_hits += (int64_t)(raw_probe + c2[1]); diag->seeds += (int64_t)c2[0];
+            }
+            const int64_t n2 = (int64_t)c2[0];
+            if (n2 == 0) return GBN_OK;
+            if (n2 > INT32_MAX) return fail(GBN_ERR_NOMEM, "too many seeds in one range");
+            unsigned long long nih2 = 0;
+            int r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n2, E.counters + 4, E.stream2, &nih2, s0, s1);
+            if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2);
+            if (r) E.pending_err = gbn_last_error();      // the error text is per thread
+            return r;
+        });
+        E.has_pending = true; E.pending_res = rp; E.pending_uses_keys = true; E.pending_batch = bp;
+        return GBN_OK;
+    }
     if (diag) { diag->lookup_hits += (int64_t)cnt[1]; diag->seeds += (int64_t)cnt[0]; diag->subject_bases_scanned += bases; }
     const int64_t n = (int64_t)cnt[0];
     if (n == 0) return GBN_OK;
@@ -1221,6 +1295,8 @@ void Blast_gpu_Release(void) {
     dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
     dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.ext_rec); dev_free(E.sort_tmp); for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
     dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_tcur); E.bin_tcur_cap = 0; dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
+    dev_free(E.alt.bin_rec); dev_free(E.alt.bin_tcur); dev_free(E.alt.bin_count); dev_free(E.alt.rareq); dev_free(E.alt.rare_counts); E.alt = Engine::ScanSet();
+    if (E.ev_r0) { (void)hipEventDestroy(E.ev_r0); (void)hipEventDestroy(E.ev_r1); E.ev_r0 = E.ev_r1 = nullptr; }
     E.bin_rec_cap = 0; E.bin_count_cap = 0;
     E.seed_cap = E.key_cap = 0;
     use_engine_device();

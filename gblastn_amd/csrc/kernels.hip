@@ -2375,7 +2375,8 @@ probe_rare_kernel(GbnBinParams B, int nseg)
 }
 
 namespace gbn {
-// parts: 1 = binning kernel, 2 = probe + rare kernels, 3 = all
+// parts: 1 = binning kernel, 2 = probe kernel, 4 = rare kernel (7 = all; the rare kernel of a pass may run on another
+// stream next to the binning kernel of the next pass: engine.cpp, deferred rare path)
 hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts, hipEvent_t tables_ready)
 {
     // ev[0..3]: before bin, after bin, after probe, after rare (optional)
@@ -2410,10 +2411,12 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
         hipLaunchKernelGGL(probe_bin_kernel, dim3(grid2), dim3(GBN_BIN_THREADS), lds, st, b);
         e = hipGetLastError();
         if (e != hipSuccess) return e;
-        if (ev) (void)hipEventRecord(ev[2], st);
+    }
+    if (ev) (void)hipEventRecord(ev[2], st);
+    if (parts & 4) {
         if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * 8), dim3(256), 0, st, b, grid2);
         e = hipGetLastError();
-    } else if (ev) (void)hipEventRecord(ev[2], st);
+    }
     if (ev) (void)hipEventRecord(ev[3], st);
     return e;
 }
