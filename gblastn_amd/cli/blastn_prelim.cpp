@@ -75,6 +75,10 @@ const char *kUsage =
     "       [-task megablast|blastn] [-word_size N] [-evalue X] [-reward N] [-penalty N] [-gapopen N]\n"
     "       [-gapextend N] [-dust yes|no|'level window linker'] [-max_target_seqs N] [-outfmt 6|7] [-mode 0|1|2]\n"
     "       [-stage traceback|prelim] [-trace_t_num N] [-num_threads N (ignored)] [-strand both]\n"
+    "       -gpu_id -1 (the default) = the first device; the reference's \"-gpu_id -1 = all devices\" is a launcher here:\n"
+    "         python -m torch.distributed.run --nproc-per-node N -m gblastn_amd.blastn_sharded -db NAME -query FASTA ...\n"
+    "         (one process per GPU, the database sharded by volume, the same rows)\n"
+    "       -num_threads: the GPU replaces the search threads; host threads: -mode 2 set-up threads, -trace_t_num\n"
     "       environment BATCH_SIZE overrides the query batch size\n";
 
 // e-value and bit score as the reference's formatter prints them (objtools/align_format/align_format_util.cpp:669-723)
