@@ -9,9 +9,9 @@
 // CORE/blast_gapalign.c:350-708, :3994-4155, :2619-2751; CORE/greedy_align.c:385-753) and the final order of the
 // results (CORE/blast_hits.c:2757-2788, CORE/blast_traceback.c:907-922).
 //
-// Limits, stated: affine greedy traceback (megablast with explicit gap costs, CORE/greedy_align.c:1170-1233)
-// is not built -- gbn_traceback returns GBN_ERR_UNSUPPORTED for it; subjects are taken from the 2-bit shard, so
-// ambiguity codes of a real database (kept by the reader in its ambiguity runs) are not restored here.
+// Greedy traceback covers both forms (gap costs 0 / 0 and BLAST_AffineGreedyAlign with explicit costs).  Subjects
+// come from the 2-bit shard; the ambiguity codes of a real database travel with the shard as runs
+// (gbn_db_set_ambiguities) and are put back over the stretch read from HBM before anything is aligned.
 #include <hip/hip_runtime.h>
 #include "gbn_host.hpp"
 #include "envelope_index.hpp"
@@ -255,16 +255,124 @@ void reduce_gaps(Script &sc, const uint8_t *q, const uint8_t *s)
     }
     sc.swap(out);
 }
-Extent greedy_traceback(const uint8_t *q, const uint8_t *s, int32_t qlen, int32_t slen, int32_t q0, int32_t s0, int32_t X,
-                        int32_t reward, int32_t penalty, Script &script)
+// The affine form (BLAST_AffineGreedyAlign with an edit block, CORE/greedy_align.c:755-1236): per (distance, diagonal)
+// the furthest subject offset of a path ending in a match run, in a gap in the subject ("ins") and in a gap in the
+// query ("del"); distances are in units of the costs' common factor, a step back reaches max(mismatch, open + extend)
+// distances.  Every row is kept; the script is read back from the best cell by asking, state by state, which
+// predecessor reaches furthest (s_GetNextAffineTbackFromMatch / FromIndel, :153-262).  Returns the half's score.
+int32_t greedy_affine_half(const uint8_t *a, int32_t la, const uint8_t *b, int32_t lb, bool backwards, int32_t xdrop,
+                           int32_t match2, int32_t mismatch2, int32_t open_in, int32_t extend_in,
+                           int32_t &used_a, int32_t &used_b, Script &path)
 {
-    int32_t m2 = reward, mm2 = -penalty, x2 = X;
-    if (m2 % 2 == 1) { m2 *= 2; mm2 *= 2; x2 *= 2; }
+    const int32_t kNone = -2, kNoDiag = 100000000;
+    const int32_t half = match2 / 2;
+    int32_t sub = match2 + mismatch2, open = open_in, ext = extend_in + half;
+    auto gcd = [](int32_t x, int32_t y) { y = std::abs(y); if (y > x) std::swap(x, y); while (y) { const int32_t t = x % y; x = y; y = t; } return x; };
+    const int32_t unit = open == 0 ? gcd(sub, ext) : gcd(sub, gcd(open, ext));       // BLAST_Gdb3
+    if (unit > 1) { sub /= unit; open /= unit; ext /= unit; }
+    const int32_t open_ext = open + ext, reach = std::max(sub, open_ext);
+    const int32_t dmax = std::min(10000, lb / 2 + 1), dlast = dmax * ext, origin = dmax + 2;
+    const int32_t lookback = (xdrop + half) / unit + 1;
+    const int32_t run = run_of_matches(a, b, la, lb, 0, 0, backwards);
+    used_a = used_b = run;
+    if (run == la || run == lb) { append_op(path, kSub, run); return run * match2; }
+    struct Cell { int32_t ins, match, del; };
+    std::vector<Cell> store; struct RowRef { size_t at; int32_t lo; };
+    std::vector<RowRef> rows;
+    auto new_row = [&](int32_t lo, int32_t n) { rows.push_back(RowRef{store.size(), lo}); store.resize(store.size() + (size_t)std::max(n, 1)); };
+    auto at = [&](int32_t d, int32_t k) -> Cell & { return store[rows[(size_t)d].at + (size_t)(k - rows[(size_t)d].lo)]; };
+    // bounds of the diagonals alive at a distance; `reach` empty ones in front stand for negative distances
+    std::vector<int32_t> lo_of((size_t)(dlast + 2 + reach), kNoDiag), hi_of((size_t)(dlast + 2 + reach), -kNoDiag);
+    auto lo = [&](int32_t d) -> int32_t & { return lo_of[(size_t)(d + reach)]; };
+    auto hi = [&](int32_t d) -> int32_t & { return hi_of[(size_t)(d + reach)]; };
+    auto alive = [&](int32_t d, int32_t k) { return k >= lo(d) && k <= hi(d); };
+    std::vector<int32_t> top((size_t)(dlast + 2 + lookback), 0);
+    auto best_at = [&](int32_t d) -> int32_t & { return top[(size_t)(d + lookback)]; };
+    new_row(origin, 1);
+    at(0, origin) = Cell{kNone, run, kNone};
+    best_at(0) = run * match2; lo(0) = hi(0) = origin;
+    int32_t from = origin - 1, to = origin + 1, end_a = 0, end_b = 0, live = 1, best_d = 0, best_k = 0;
+    for (int32_t d = 1; d <= dlast;) {
+        const int32_t first = from, last = to;
+        new_row(first, last - first + 1);
+        int32_t floor_sum = best_at(d - lookback) + unit * d - xdrop;
+        floor_sum = std::max(0, (int32_t)std::ceil((double)floor_sum / half));
+        int32_t far = 0, far_j = 0, far_k = 0;
+        for (int32_t k = first; k <= last; k++) {
+            Cell &c = at(d, k);
+            int32_t j = alive(d - open_ext, k + 1) ? at(d - open_ext, k + 1).match : kNone;
+            if (alive(d - ext, k + 1)) j = std::max(j, at(d - ext, k + 1).del);
+            c.del = j == kNone ? kNone : j + 1;
+            j = alive(d - open_ext, k - 1) ? at(d - open_ext, k - 1).match : kNone;
+            if (alive(d - ext, k - 1)) j = std::max(j, at(d - ext, k - 1).ins);
+            c.ins = j;
+            j = std::max(c.ins, c.del);
+            if (alive(d - sub, k)) j = std::max(j, at(d - sub, k).match + 1);
+            int32_t i = j + k - origin;
+            if (j < 0 || i + j < floor_sum) { if (k == from) from++; else c.match = kNone; continue; }
+            to = k;
+            const int32_t more = run_of_matches(a, b, la, lb, i, j, backwards);
+            i += more; j += more;
+            c.match = j;
+            if (i + j > far) { far = i + j; far_j = j; far_k = k; }
+            if (i == la) { to = k; end_a = k - 1; }
+            if (j == lb) { from = k; end_b = k + 1; }
+        }
+        const int32_t sc = far * half - d * unit;
+        if (sc > best_at(d - 1)) { best_at(d) = sc; best_d = d; best_k = far_k; used_b = far_j; used_a = far_j + far_k - origin; }
+        else best_at(d) = best_at(d - 1);
+        if (from <= to) { live++; lo(d) = from; hi(d) = to; }
+        if (lo(d - reach) <= hi(d - reach)) live--;
+        if (live == 0) break;
+        d++;
+        from = std::min({lo(d - open_ext) - 1, lo(d - ext) - 1, lo(d - sub)});
+        if (end_b > 0) from = std::max(from, end_b);
+        to = std::max({hi(d - open_ext) + 1, hi(d - ext) + 1, hi(d - sub)});
+        if (end_a > 0) to = std::min(to, end_a);
+    }
+    // back from the best cell
+    int32_t j = used_b, k = best_k, d = best_d;
+    enum { InMatch, InIns, InDel } state = InMatch;
+    while (d > 0) {
+        if (state == InMatch) {
+            const Cell &c = at(d, k);
+            int32_t prev;
+            if (alive(d - sub, k) && at(d - sub, k).match >= std::max(c.ins, c.del)) { prev = at(d - sub, k).match; d -= sub; }
+            else if (c.ins > c.del) { prev = c.ins; state = InIns; }
+            else { prev = c.del; state = InDel; }
+            append_op(path, kSub, j - prev);
+            j = prev;
+        } else {
+            const bool ins = state == InIns;
+            const int32_t nk = ins ? k - 1 : k + 1;
+            append_op(path, ins ? kIns : kDel, 1);
+            int32_t through_gap = kNone;
+            if (alive(d - ext, nk)) through_gap = ins ? at(d - ext, nk).ins : at(d - ext, nk).del;
+            if (alive(d - open_ext, nk) && through_gap < at(d - open_ext, nk).match) { d -= open_ext; state = InMatch; }
+            else d -= ext;
+            if (ins) k--; else { k++; j--; }
+        }
+    }
+    append_op(path, kSub, at(0, origin).match);
+    return best_at(best_d);
+}
+
+Extent greedy_traceback(const uint8_t *q, const uint8_t *s, int32_t qlen, int32_t slen, int32_t q0, int32_t s0, int32_t X,
+                        int32_t reward, int32_t penalty, int32_t gap_open, int32_t gap_extend, Script &script)
+{
+    int32_t m2 = reward, mm2 = -penalty, x2 = X, go2 = gap_open, ge2 = gap_extend;
+    if (m2 % 2 == 1) { m2 *= 2; mm2 *= 2; x2 *= 2; go2 *= 2; ge2 *= 2; }
     Script left, right; int32_t qr, sr, ql, sl;
-    int32_t dist = greedy_half(q + q0, qlen - q0, s + s0, slen - s0, false, x2, m2, mm2, qr, sr, right);
-    dist += greedy_half(q, q0, s, s0, true, x2, m2, mm2, ql, sl, left);
     Extent e;
-    e.score = (qr + sr + ql + sl) * reward / 2 - dist * (reward - penalty);
+    if (go2 == 0 && ge2 == 0) {
+        int32_t dist = greedy_half(q + q0, qlen - q0, s + s0, slen - s0, false, x2, m2, mm2, qr, sr, right);
+        dist += greedy_half(q, q0, s, s0, true, x2, m2, mm2, ql, sl, left);
+        e.score = (qr + sr + ql + sl) * reward / 2 - dist * (reward - penalty);
+    } else {
+        int32_t sc = greedy_affine_half(q + q0, qlen - q0, s + s0, slen - s0, false, x2, m2, mm2, go2, ge2, qr, sr, right);
+        sc += greedy_affine_half(q, q0, s, s0, true, x2, m2, mm2, go2, ge2, ql, sl, left);
+        e.score = (reward % 2 == 1) ? sc / 2 : sc;
+    }
     e.q_start = q0 - ql; e.s_start = s0 - sl; e.q_stop = q0 + qr; e.s_stop = s0 + sr;
     script = join_halves(left, right);
     if (!script.empty()) reduce_gaps(script, q + e.q_start, s + e.s_start);
@@ -472,7 +580,6 @@ int traceback_list(const GbnBatch &b, const uint8_t *subject, int32_t slen, cons
 {
     const GbnOptions &o = b.opt;
     const bool greedy = o.greedy != 0;
-    if (greedy && (o.gap_open || o.gap_extend)) { set_error("traceback: affine greedy traceback is not built"); return GBN_ERR_UNSUPPORTED; }
     const int32_t X = b.gap_x_dropoff_final;
     std::vector<Item> items(nin);
     for (size_t i = 0; i < nin; i++) items[i].h = in[i];
@@ -501,7 +608,7 @@ int traceback_list(const GbnBatch &b, const uint8_t *subject, int32_t slen, cons
             }
             const uint8_t *sub = subject + shift;
             h.s_gapped_start = s0;
-            Extent e = greedy ? greedy_traceback(q, sub, cx.query_length, sub_len, q0, s0, X, o.reward, o.penalty, it.sc)
+            Extent e = greedy ? greedy_traceback(q, sub, cx.query_length, sub_len, q0, s0, X, o.reward, o.penalty, o.gap_open, o.gap_extend, it.sc)
                               : gapped_traceback(b.matrix, q, sub, cx.query_length, sub_len, q0, s0, X, o.gap_open, o.gap_extend, it.sc);
             h.score = e.score; h.q_offset = e.q_start; h.q_end = e.q_stop; h.s_offset = e.s_start; h.s_end = e.s_stop;
             if (!greedy) count_identities(q, sub, it);

@@ -377,6 +377,172 @@ static int32_t greedy_align_tb(const uint8_t *seq1, int32_t len1, const uint8_t 
     return best_dist;
 }
 
+/* ---------------- affine greedy with traceback (BLAST_AffineGreedyAlign, CORE/greedy_align.c:755-1236, uncompressed
+ * subject): three furthest-reaching offsets per (distance, diagonal); with an edit block every row is kept
+ * (:1166-1177) and the script is walked back through s_GetNextAffineTbackFromMatch / FromIndel (:153-262) ---------------- */
+typedef struct { int32_t insert_off, match_off, delete_off; } AOff;
+typedef struct { AOff *base; int32_t lo; } ARow;
+#define AR(r, k) ((r).base[(k) - (r).lo])
+
+static int32_t gcd3(int32_t *a, int32_t *b, int32_t *c);
+
+static int32_t greedy_affine_tb(const uint8_t *seq1, int32_t len1, const uint8_t *seq2, int32_t len2, int reverse,
+                                int32_t xdrop_threshold, int32_t match_score, int32_t mismatch_score,
+                                int32_t in_gap_open, int32_t in_gap_extend,
+                                int32_t *seq1_align_len, int32_t *seq2_align_len, Prelim *edit_block)
+{
+    int32_t seq1_index, seq2_index, index, d, k, max_dist, scaled_max_dist, diag_origin, best_dist = 0, best_diag = 0;
+    int32_t xdrop_offset, end1_diag, end2_diag, op_cost, gap_open, gap_extend, gap_open_extend, max_penalty, score_common_factor;
+    int32_t match_score_half, curr_diag_lower, curr_diag_upper, num_nonempty_dist, result, nrows = 0;
+    int32_t *bounds, *diag_lower, *diag_upper, *max_score_base, *max_score;
+    ARow *rows;
+    const int32_t kInvalidDiag = 100000000;
+
+    match_score_half = match_score / 2;
+    op_cost = match_score + mismatch_score;
+    gap_open = in_gap_open; gap_extend = in_gap_extend + match_score_half;
+    score_common_factor = gcd3(&op_cost, &gap_open, &gap_extend);
+    gap_open_extend = gap_open + gap_extend;
+    max_penalty = ORC_MAX(op_cost, gap_open_extend);
+    max_dist = ORC_MIN(10000, len2 / 2 + 1);
+    scaled_max_dist = max_dist * gap_extend;
+    diag_origin = max_dist + 2;
+    xdrop_offset = (xdrop_threshold + match_score_half) / score_common_factor + 1;
+
+    index = first_mismatch_u(seq1, seq2, len1, len2, 0, 0, reverse);
+    *seq1_align_len = index; *seq2_align_len = index;
+    seq1_index = index;
+    if (index == len1 || index == len2) { prelim_add(edit_block, OP_SUB, index); return index * match_score; }
+
+    rows = (ARow *)calloc((size_t)scaled_max_dist + 2, sizeof(ARow));
+    bounds = (int32_t *)malloc((size_t)2 * (scaled_max_dist + 1 + max_penalty) * sizeof(int32_t));
+    max_score_base = (int32_t *)malloc((size_t)(scaled_max_dist + 2 + xdrop_offset) * sizeof(int32_t));
+    max_score = max_score_base + xdrop_offset;
+    for (index = 0; index < xdrop_offset; index++) max_score_base[index] = 0;
+    diag_lower = bounds; diag_upper = bounds + scaled_max_dist + 1 + max_penalty;
+    for (index = 0; index < max_penalty; index++) { diag_lower[index] = kInvalidDiag; diag_upper[index] = -kInvalidDiag; }
+    diag_lower += max_penalty; diag_upper += max_penalty;
+
+    rows[0].base = (AOff *)malloc(sizeof(AOff)); rows[0].lo = diag_origin; nrows = 1;
+    AR(rows[0], diag_origin).match_off = seq1_index;
+    AR(rows[0], diag_origin).insert_off = kInvalidOffset;
+    AR(rows[0], diag_origin).delete_off = kInvalidOffset;
+    max_score[0] = seq1_index * match_score;
+    diag_lower[0] = diag_origin; diag_upper[0] = diag_origin;
+    curr_diag_lower = diag_origin - 1; curr_diag_upper = diag_origin + 1;
+    end1_diag = 0; end2_diag = 0; num_nonempty_dist = 1; d = 1;
+
+    while (d <= scaled_max_dist) {
+        int32_t xdrop_score, curr_score, curr_extent = 0, curr_seq2_index = 0, curr_diag = 0;
+        const int32_t tmp_diag_lower = curr_diag_lower, tmp_diag_upper = curr_diag_upper;
+        /* the row of this distance: every diagonal the loop below visits (a row is read later only inside the
+         * bounds saved for its distance, which lie inside these) */
+        rows[d].lo = tmp_diag_lower;
+        rows[d].base = (AOff *)malloc((size_t)ORC_MAX(tmp_diag_upper - tmp_diag_lower + 1, 1) * sizeof(AOff));
+        nrows = d + 1;
+        xdrop_score = max_score[d - xdrop_offset] + score_common_factor * d - xdrop_threshold;
+        xdrop_score = (int32_t)ceil((double)xdrop_score / match_score_half);
+        if (xdrop_score < 0) xdrop_score = 0;
+        for (k = tmp_diag_lower; k <= tmp_diag_upper; k++) {
+            AOff *cur = &AR(rows[d], k);
+            seq2_index = kInvalidOffset;
+            if (k + 1 <= diag_upper[d - gap_open_extend] && k + 1 >= diag_lower[d - gap_open_extend])
+                seq2_index = AR(rows[d - gap_open_extend], k + 1).match_off;
+            if (k + 1 <= diag_upper[d - gap_extend] && k + 1 >= diag_lower[d - gap_extend] &&
+                seq2_index < AR(rows[d - gap_extend], k + 1).delete_off)
+                seq2_index = AR(rows[d - gap_extend], k + 1).delete_off;
+            cur->delete_off = seq2_index == kInvalidOffset ? kInvalidOffset : seq2_index + 1;
+            seq2_index = kInvalidOffset;
+            if (k - 1 <= diag_upper[d - gap_open_extend] && k - 1 >= diag_lower[d - gap_open_extend])
+                seq2_index = AR(rows[d - gap_open_extend], k - 1).match_off;
+            if (k - 1 <= diag_upper[d - gap_extend] && k - 1 >= diag_lower[d - gap_extend] &&
+                seq2_index < AR(rows[d - gap_extend], k - 1).insert_off)
+                seq2_index = AR(rows[d - gap_extend], k - 1).insert_off;
+            cur->insert_off = seq2_index;
+            seq2_index = ORC_MAX(cur->insert_off, cur->delete_off);
+            if (k <= diag_upper[d - op_cost] && k >= diag_lower[d - op_cost])
+                seq2_index = ORC_MAX(seq2_index, AR(rows[d - op_cost], k).match_off + 1);
+            seq1_index = seq2_index + k - diag_origin;
+            if (seq2_index < 0 || seq1_index + seq2_index < xdrop_score) {
+                if (k == curr_diag_lower) curr_diag_lower++;
+                else cur->match_off = kInvalidOffset;
+                continue;
+            }
+            curr_diag_upper = k;
+            index = first_mismatch_u(seq1, seq2, len1, len2, seq1_index, seq2_index, reverse);
+            seq1_index += index; seq2_index += index;
+            cur->match_off = seq2_index;
+            if (seq1_index + seq2_index > curr_extent) { curr_extent = seq1_index + seq2_index; curr_seq2_index = seq2_index; curr_diag = k; }
+            if (seq1_index == len1) { curr_diag_upper = k; end1_diag = k - 1; }
+            if (seq2_index == len2) { curr_diag_lower = k; end2_diag = k + 1; }
+        }
+        curr_score = curr_extent * match_score_half - d * score_common_factor;
+        if (curr_score > max_score[d - 1]) {
+            max_score[d] = curr_score; best_dist = d; best_diag = curr_diag;
+            *seq2_align_len = curr_seq2_index; *seq1_align_len = curr_seq2_index + best_diag - diag_origin;
+        } else max_score[d] = max_score[d - 1];
+        if (curr_diag_lower <= curr_diag_upper) { num_nonempty_dist++; diag_lower[d] = curr_diag_lower; diag_upper[d] = curr_diag_upper; }
+        else { diag_lower[d] = kInvalidDiag; diag_upper[d] = -kInvalidDiag; }
+        if (diag_lower[d - max_penalty] <= diag_upper[d - max_penalty]) num_nonempty_dist--;
+        if (num_nonempty_dist == 0) break;
+        d++;
+        curr_diag_lower = ORC_MIN(diag_lower[d - gap_open_extend], diag_lower[d - gap_extend]) - 1;
+        curr_diag_lower = ORC_MIN(curr_diag_lower, diag_lower[d - op_cost]);
+        if (end2_diag > 0) curr_diag_lower = ORC_MAX(curr_diag_lower, end2_diag);
+        curr_diag_upper = ORC_MAX(diag_upper[d - gap_open_extend], diag_upper[d - gap_extend]) + 1;
+        curr_diag_upper = ORC_MAX(curr_diag_upper, diag_upper[d - op_cost]);
+        if (end1_diag > 0) curr_diag_upper = ORC_MIN(curr_diag_upper, end1_diag);
+    }
+    {   /* the traceback (:1187-1233) */
+        int state = OP_SUB;
+        d = best_dist; seq2_index = *seq2_align_len;
+        while (d > 0) {
+            if (state == OP_SUB) {
+                /* s_GetNextAffineTbackFromMatch (:153-183) */
+                int32_t new_seq2_index; const AOff *c = &AR(rows[d], best_diag);
+                int taken = 0;
+                if (best_diag >= diag_lower[d - op_cost] && best_diag <= diag_upper[d - op_cost]) {
+                    new_seq2_index = AR(rows[d - op_cost], best_diag).match_off;
+                    if (new_seq2_index >= ORC_MAX(c->insert_off, c->delete_off)) { d -= op_cost; state = OP_SUB; taken = 1; }
+                }
+                if (!taken) {
+                    if (c->insert_off > c->delete_off) { new_seq2_index = c->insert_off; state = OP_INS; }
+                    else { new_seq2_index = c->delete_off; state = OP_DEL; }
+                }
+                prelim_add(edit_block, OP_SUB, seq2_index - new_seq2_index);
+                seq2_index = new_seq2_index;
+            } else {
+                /* s_GetNextAffineTbackFromIndel (:203-262) */
+                const int ins = state == OP_INS;
+                const int32_t new_diag = ins ? best_diag - 1 : best_diag + 1;
+                int32_t new_seq2_index = kInvalidOffset, last_d = d - gap_extend;
+                prelim_add(edit_block, ins ? OP_INS : OP_DEL, 1);
+                if (new_diag >= diag_lower[last_d] && new_diag <= diag_upper[last_d])
+                    new_seq2_index = ins ? AR(rows[last_d], new_diag).insert_off : AR(rows[last_d], new_diag).delete_off;
+                last_d = d - gap_open_extend;
+                if (new_diag >= diag_lower[last_d] && new_diag <= diag_upper[last_d] &&
+                    new_seq2_index < AR(rows[last_d], new_diag).match_off) { d -= gap_open_extend; state = OP_SUB; }
+                else d -= gap_extend;
+                if (ins) best_diag--; else { best_diag++; seq2_index--; }
+            }
+        }
+        prelim_add(edit_block, OP_SUB, AR(rows[0], diag_origin).match_off);
+    }
+    result = max_score[best_dist];
+    for (d = 0; d < nrows; d++) free(rows[d].base);
+    free(rows); free(bounds); free(max_score_base);
+    return result;
+}
+/* BLAST_Gdb3 (CORE/ncbi_math.c:405-431) */
+static int32_t gcd2(int32_t a, int32_t b) { int32_t c; b = abs(b); if (b > a) { c = a; a = b; b = c; } while (b != 0) { c = a % b; a = b; b = c; } return a; }
+static int32_t gcd3(int32_t *a, int32_t *b, int32_t *c)
+{
+    int32_t g;
+    if (*b == 0) g = gcd2(*a, *c); else g = gcd2(*a, gcd2(*b, *c));
+    if (g > 1) { *a /= g; *b /= g; *c /= g; }
+    return g;
+}
+
 /* s_ReduceGaps (CORE/blast_gapalign.c:2547-2617) */
 static void reduce_gaps(OrcEditScript *esp, const uint8_t *q, const uint8_t *s)
 {
@@ -412,16 +578,23 @@ static void reduce_gaps(OrcEditScript *esp, const uint8_t *q, const uint8_t *s)
 /* BLAST_GreedyGappedAlignment with do_traceback (CORE/blast_gapalign.c:2619-2751), gap costs 0 / 0 */
 static int orc_greedy_with_traceback(const uint8_t *query, const uint8_t *subject, int32_t query_length, int32_t subject_length,
                               int32_t q_off, int32_t s_off, int32_t X, int32_t reward, int32_t penalty,
-                              OrcGapResult *r, OrcEditScript *esp)
+                              int32_t gap_open, int32_t gap_extend, OrcGapResult *r, OrcEditScript *esp)
 {
     Prelim fwd = {0, 0, 0, 0, OP_INVALID}, rev = {0, 0, 0, 0, OP_INVALID};
-    int32_t score, q_ext_l, q_ext_r, s_ext_l, s_ext_r, mc = reward, mm = -penalty, x = X;
+    int32_t score, q_ext_l, q_ext_r, s_ext_l, s_ext_r, mc = reward, mm = -penalty, x = X, go = gap_open, ge = gap_extend;
     prelim_reset(&fwd); prelim_reset(&rev);
-    if (mc % 2 == 1) { mc *= 2; mm *= 2; x *= 2; }          /* CORE/greedy_align.c:795-801 */
-    score = greedy_align_tb(query + q_off, query_length - q_off, subject + s_off, subject_length - s_off, 0, x, mc, mm,
-                            &q_ext_r, &s_ext_r, &fwd);
-    score += greedy_align_tb(query, q_off, subject, s_off, 1, x, mc, mm, &q_ext_l, &s_ext_l, &rev);
-    score = (q_ext_r + s_ext_r + q_ext_l + s_ext_l) * reward / 2 - score * (reward - penalty);
+    if (mc % 2 == 1) { mc *= 2; mm *= 2; x *= 2; go *= 2; ge *= 2; }          /* CORE/greedy_align.c:795-806 */
+    if (go == 0 && ge == 0) {
+        score = greedy_align_tb(query + q_off, query_length - q_off, subject + s_off, subject_length - s_off, 0, x, mc, mm,
+                                &q_ext_r, &s_ext_r, &fwd);
+        score += greedy_align_tb(query, q_off, subject, s_off, 1, x, mc, mm, &q_ext_l, &s_ext_l, &rev);
+        score = (q_ext_r + s_ext_r + q_ext_l + s_ext_l) * reward / 2 - score * (reward - penalty);
+    } else {
+        score = greedy_affine_tb(query + q_off, query_length - q_off, subject + s_off, subject_length - s_off, 0, x, mc, mm, go, ge,
+                                 &q_ext_r, &s_ext_r, &fwd);
+        score += greedy_affine_tb(query, q_off, subject, s_off, 1, x, mc, mm, go, ge, &q_ext_l, &s_ext_l, &rev);
+        if (reward % 2 == 1) score /= 2;                                        /* CORE/blast_gapalign.c:2683-2685 */
+    }
     prelim_to_esp(&rev, &fwd, esp);
     if (esp->size) reduce_gaps(esp, query + q_off - q_ext_l, subject + s_off - s_ext_l);
     r->q_start = q_off - q_ext_l; r->s_start = s_off - s_ext_l; r->q_stop = q_off + q_ext_r; r->s_stop = s_off + s_ext_r;
@@ -762,9 +935,8 @@ int32_t orc_traceback_hsp_list(const OrcSearch *S, const uint8_t *subject, int32
         cutoff = S->ctx[ctx].gap_cutoff_score;
         (void)cutoff;
         if (greedy_tb) {
-            if (o->gap_open || o->gap_extend) { t->alive = 0; continue; }      /* affine greedy traceback: not restated */
             orc_greedy_with_traceback(query, adjusted_subject, query_length, adjusted_s_length, q_start, s_start, X,
-                                      o->reward, o->penalty, &r, &t->e);
+                                      o->reward, o->penalty, o->gap_open, o->gap_extend, &r, &t->e);
         } else {
             orc_gapped_with_traceback(S->matrix, query, adjusted_subject, query_length, adjusted_s_length, q_start, s_start,
                                       X, o->gap_open, o->gap_extend, &r, &t->e);
@@ -852,7 +1024,7 @@ int orc_tb_greedy(const OrcSearch *S, int32_t context, const uint8_t *subject, i
 {
     OrcGapResult r;
     int rc = orc_greedy_with_traceback(S->query + S->ctx[context].query_offset, subject, S->ctx[context].query_length, subject_length,
-                                       q_start, s_start, x_dropoff, S->opt.reward, S->opt.penalty, &r, esp);
+                                       q_start, s_start, x_dropoff, S->opt.reward, S->opt.penalty, S->opt.gap_open, S->opt.gap_extend, &r, esp);
     o->q_start = r.q_start; o->q_stop = r.q_stop; o->s_start = r.s_start; o->s_stop = r.s_stop; o->score = r.score; o->seed_q = r.seed_q; o->seed_s = r.seed_s;
     return rc;
 }

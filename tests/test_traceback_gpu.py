@@ -86,7 +86,10 @@ def test_traceback_long_subject_uses_a_window():
 
 def test_traceback_option_sweep():
     for kw in [dict(reward=2, penalty=-3, gap_open=5, gap_extend=2, greedy=0, xdrop_gap_bits=30.0),
-               dict(reward=1, penalty=-3), dict(reward=1, penalty=-1, gap_open=3, gap_extend=2, greedy=0, xdrop_gap_bits=30.0)]:
+               dict(reward=1, penalty=-3), dict(reward=1, penalty=-1, gap_open=3, gap_extend=2, greedy=0, xdrop_gap_bits=30.0),
+               # megablast with explicit gap costs: affine greedy, preliminary (HIP) and with traceback (host)
+               dict(reward=1, penalty=-2, gap_open=2, gap_extend=2), dict(reward=1, penalty=-3, gap_open=5, gap_extend=2),
+               dict(reward=2, penalty=-3, gap_open=5, gap_extend=2, greedy=1)]:
         db, queries, plants, subjects, opt = util.small_case(3, 120_000, 10, planted_fraction=0.9, **kw)
         ora, _ = oracle_final(opt, queries, subjects)
         prod, *_ = product_final(opt, queries, subjects)

@@ -207,3 +207,33 @@ def test_traceback_lists_are_consistent(megablast):
             assert (qe, se) == (f["q_end"], f["s_end"]) and ident == f["num_ident"]
         assert [f["score"] for f in fin] == sorted([f["score"] for f in fin], reverse=True)
     assert total >= 6
+
+
+@pytest.mark.parametrize("seed", range(6))
+@pytest.mark.parametrize("costs", [(1, -2, 2, 2), (1, -3, 5, 2), (2, -3, 5, 2), (1, -2, 0, 2)])
+def test_affine_greedy_traceback_twin_rescoring_and_optimum(seed, costs):
+    """BLAST_AffineGreedyAlign with an edit block (CORE/greedy_align.c:755-1236): the same score and end points as
+    its score-only twin on the packed subject (the preliminary stage's aligner, pinned in test_oracle_definitions),
+    the score of its own edit script, and -- under an X-drop nothing is pruned by -- the optimum of the whole affine
+    matrix on either side of the start point"""
+    reward, penalty, go, ge = costs
+    rng = np.random.default_rng(900 + seed)
+    q = rng.integers(0, 4, 700).astype(np.uint8)
+    s_core = mutate(rng, q[80:620], subs=int(rng.integers(0, 20)), indels=int(rng.integers(0, 5)))
+    s = np.concatenate([rng.integers(0, 4, 90).astype(np.uint8), s_core, rng.integers(0, 4, 90).astype(np.uint8)])
+    opt = orc.default_options(True, db_length=10**6, db_num_seqs=10)
+    opt.reward, opt.penalty, opt.gap_open, opt.gap_extend = reward, penalty, go, ge
+    S = orc.Search(opt, [q])
+    qs, ss = find_anchor(q, s, 350)
+    for X in (30, 10000):
+        r = S.align_traceback(0, s, qs, ss, X, greedy=True)
+        twin = orc.gapped_extend(q, s, qs, ss, X, reward, penalty, go, ge, greedy=True)
+        assert (r["q_start"], r["q_stop"], r["s_start"], r["s_stop"], r["score"]) == \
+               (twin["q_offset"], twin["q_end"], twin["s_offset"], twin["s_end"], twin["score"])
+        sc2, qe, se, _ = rescore(q, s, r, reward, penalty, go, ge)
+        assert (qe, se) == (r["q_stop"], r["s_stop"])
+        # (s_ReduceGaps may trade a pair of opposite gaps for mismatches: the script never scores below the aligner's)
+        assert sc2 >= r["score"]
+        assert any(op != SUB for op, _ in r["ops"]) or r["score"] == sc2
+    full = affine_full_dp(q[:qs][::-1], s[:ss][::-1], reward, penalty, go, ge) + affine_full_dp(q[qs:], s[ss:], reward, penalty, go, ge)
+    assert r["score"] == full
