@@ -236,3 +236,16 @@ def test_parity_suite_through_the_two_kernel_seed_stage():
                        capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout and "failed" not in p.stdout
+
+
+def test_pipelined_searches_with_the_deferred_rare_kernel():
+    """GBN_DEFER_RARE=1 (opt-in): the rare kernel of a pass runs on the second stream, on its own set of record
+    buffers, next to the binning kernel of the next pass.  The pipelined tests -- begin / end against run, and 24
+    batches streamed through the host pipeline against the oracle's rows -- once more with it on."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["GBN_DEFER_RARE"] = "1"
+    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_traceback_gpu.py", "tests/test_chunking.py", "-x", "-q",
+                        "-m", "gpu", "-k", "pipelin or begin_end or chunks_equal"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert p.returncode == 0, p.stdout[-3000:]
+    assert " passed" in p.stdout and "failed" not in p.stdout
