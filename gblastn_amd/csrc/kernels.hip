@@ -1260,7 +1260,11 @@ __device__ int32_t align_packed_wave(const GbnGapParams &P, const uint8_t *q, co
     return best_score;
 }
 
-__device__ void dynprog_hit_wave(const GbnGapParams &P, int64_t i)
+// one half of an extension (side 0: left of the start point, reversed; side 1: right of it) by one wave; the two waves
+// of a 128-thread workgroup take the two halves of the same initial hit -- what this kernel is left with are the
+// long extensions, and a launch lasts as long as its longest wave
+struct HalfOut { int32_t score, pq, ps, redo; };
+__device__ HalfOut dynprog_half_wave(const GbnGapParams &P, int64_t i, int side, GbnDevGapped &g, int32_t &q_length, int32_t &s_length)
 {
     const GbnDevInitHit h = P.ihits[P.first + i];
     const int32_t subj_id = __builtin_amdgcn_readfirstlane(h.subj), h_q_off = __builtin_amdgcn_readfirstlane(h.q_off),
@@ -1275,35 +1279,41 @@ __device__ void dynprog_hit_wave(const GbnGapParams &P, int64_t i)
     int32_t q_off = h_q_off - qstart, s_off = h_s_off;
     const int32_t s_end = h_s_start + h_length;
     if (s_end >= s_off + 8) { s_off += 3; q_off += 3; }       // CORE/blast_gapalign.c:3494-3497
-    int redo = 0;
     const int32_t adj = 4 - (s_off & 3);
-    int32_t q_length = q_off + adj, s_length = s_off + adj;
+    q_length = q_off + adj; s_length = s_off + adj;
     if (q_length > qlen || s_length > slen) { q_length -= 4; s_length -= 4; }
-    int32_t pq, ps;
-    GbnDevGapped g; g.context = lo; g.seed_q = q_off; g.seed_s = s_off;
+    g.context = lo; g.seed_q = q_off; g.seed_s = s_off;
+    HalfOut o; o.score = 0; o.pq = 0; o.ps = 0; o.redo = 0;
     int32_t maxw = 0;
-    const int32_t left = align_packed_wave(P, q, subj, 0, 0, q_length, s_length, &pq, &ps, true, &redo, &maxw);
-    g.q_start = q_length - pq; g.s_start = s_length - ps;
-    int32_t right = 0;
-    if (!redo && q_length < qlen && s_length < slen) {
-        right = align_packed_wave(P, q, subj, q_length, s_length, qlen - q_length, slen - s_length, &pq, &ps, false, &redo, &maxw);
-        g.q_stop = pq + q_length; g.s_stop = ps + s_length;
-    } else { g.q_stop = q_length; g.s_stop = s_length; }
-    g.score = redo ? GBN_GAP_REDO : left + right;
+    if (side == 0) o.score = align_packed_wave(P, q, subj, 0, 0, q_length, s_length, &o.pq, &o.ps, true, &o.redo, &maxw);
+    else if (q_length < qlen && s_length < slen)
+        o.score = align_packed_wave(P, q, subj, q_length, s_length, qlen - q_length, slen - s_length, &o.pq, &o.ps, false, &o.redo, &maxw);
 #if GBN_DP_STATS
-    if ((threadIdx.x & 63) == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 2, 1ull); if (redo) atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 3, 1ull);
+    if ((threadIdx.x & 63) == 0 && side == 0) { atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 2, 1ull); if (o.redo) atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 3, 1ull);
         atomicAdd(reinterpret_cast<unsigned long long *>(P.scratch) + 16 + min(maxw / 8, 7), 1ull); }
 #endif
-    if ((threadIdx.x & 63) == 0) P.out[P.first + i] = g;
+    return o;
 }
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(256) dynprog_wave_kernel(GbnGapParams P)
+extern "C" __global__ void __launch_bounds__(128) dynprog_wave_kernel(GbnGapParams P)
 {
-    const int64_t wave = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
-    for (int64_t i = wave; i < P.n; i += nwaves) {
+    __shared__ HalfOut s_half[2];
+    const int side = threadIdx.x >> 6;
+    for (int64_t i = blockIdx.x; i < P.n; i += gridDim.x) {
         if (P.redo_only && P.out[P.first + i].score != GBN_GAP_REDO) continue;     // after dynprog_lane_kernel: what it left
-        dynprog_hit_wave(P, i);
+        GbnDevGapped g; int32_t q_length, s_length;
+        const HalfOut o = dynprog_half_wave(P, i, side, g, q_length, s_length);
+        if ((threadIdx.x & 63) == 0) s_half[side] = o;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const HalfOut l = s_half[0], r = s_half[1];
+            g.q_start = q_length - l.pq; g.s_start = s_length - l.ps;
+            g.q_stop = q_length + r.pq; g.s_stop = s_length + r.ps;
+            g.score = (l.redo || r.redo) ? GBN_GAP_REDO : l.score + r.score;
+            P.out[P.first + i] = g;
+        }
+        __syncthreads();
     }
 }
 
@@ -1692,8 +1702,9 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
             if (e != hipSuccess) return e;
             w.redo_only = 1;
         }
-        const int64_t wblocks = std::max<int64_t>(1, std::min<int64_t>((p.n + 3) / 4, p.max_blocks > 0 ? (int64_t)p.max_blocks * 2 : (p.n + 3) / 4));
-        hipLaunchKernelGGL(dynprog_wave_kernel, dim3((unsigned)wblocks), dim3(256), 0, st, w);
+        // a workgroup of two waves per extension (its two halves)
+        const int64_t wblocks = std::max<int64_t>(1, std::min<int64_t>(p.n, p.max_blocks > 0 ? (int64_t)p.max_blocks * 4 : p.n));
+        hipLaunchKernelGGL(dynprog_wave_kernel, dim3((unsigned)wblocks), dim3(128), 0, st, w);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
