@@ -1357,7 +1357,15 @@ extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParam
     constexpr int W = GBN_LANE_W;
     constexpr int32_t NEG = GBN_MININT;
     enum { RUN = 0, START = 1, DONE = 2 };
-    __shared__ int2 s_cell[W][64];              // {best, best_gap} of column c at [c mod W][lane]
+    // {best, best_gap} of column c at [c mod W][lane], 16 bits each: 10 KB of LDS per wave instead of 18, i.e. 16
+    // waves per CU instead of 8.  Scores of this kernel's extensions fit (the launcher checks reward x the longest
+    // context); "dead" is -32768: a dead value is never the larger operand of a maximum that is kept, and whatever is
+    // added to it stays below every live score, so it acts exactly as the reference's INT4_MIN / 2 does.
+    __shared__ uint32_t s_cell[W][64];
+    auto pack_cell = [](int32_t best, int32_t gap) -> uint32_t {
+        return ((uint32_t)max(best, -32768) & 0xffffu) | ((uint32_t)max(gap, -32768) << 16); };
+    auto cell_best = [](uint32_t w) -> int32_t { return (int32_t)(int16_t)(w & 0xffffu); };
+    auto cell_gap = [](uint32_t w) -> int32_t { return (int32_t)w >> 16; };
     __shared__ uint8_t s_let[W][64];            // its query letter
     __shared__ uint32_t s_pm[16];               // per query letter: the match scores against the four subject bases, a byte each (-128: the sentinel's NEG)
     const int lane = threadIdx.x;
@@ -1442,7 +1450,7 @@ extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParam
                         lq = 0;
                         #pragma unroll
                         for (int k = 0; k < 16; k++) lq |= (unsigned long long)(letter_at(k) & 15u) << (4 * k);
-                        s_cell[0][lane] = make_int2(0, -goe);
+                        s_cell[0][lane] = pack_cell(0, -goe);
                         s_let[0][lane] = (uint8_t)(lq & 15u);
                         lq >>= 4; ln = 15;
                         const int32_t pos1 = reverse ? (M - 1) : s0;      // row 1's base
@@ -1505,12 +1513,13 @@ extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParam
             if (in_row) sgr = NEG;
             // (straight-line selects: the divergent if / else of the reference's loop body costs three times the
             // instructions once the compiler has structurized it)
-            int2 c = s_cell[ix][lane]; uint32_t letter = s_let[ix][lane];
+            uint32_t cw = s_cell[ix][lane]; uint32_t letter = s_let[ix][lane];
             for (int32_t t = 0; t < width; t++) {                       // (a lane leaves the loop after its last column)
                 {
                     // the next column's cell is on its way while this one is worked on (its slot is not written here)
                     const int ixn = inc(ix);
-                    const int2 cn = s_cell[ixn][lane]; const uint32_t letter_n = s_let[ixn][lane];
+                    const uint32_t cwn = s_cell[ixn][lane]; const uint32_t letter_n = s_let[ixn][lane];
+                    const int32_t c_best = cell_best(cw), c_gap = cell_gap(cw);
                     int32_t msel = (int)letter == ab ? reward : penalty;
                     if (__ballot(letter >= 4u)) {                       // ambiguity codes, the sentinel: from the matrix
                         const uint32_t mm = s_pm[letter];
@@ -1518,18 +1527,18 @@ extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParam
                         m2 = m2 == -128 ? NEG : m2;
                         msel = letter >= 4u ? m2 : msel;
                     }
-                    const int32_t next = c.x + msel;
-                    sc = max(sc, max(c.y, sgr));
+                    const int32_t next = c_best + msel;
+                    sc = max(sc, max(c_gap, sgr));
                     const bool keep = !(best_score - sc > x);
                     const bool drop_first = !keep && b == first_b;
                     const bool better = keep && sc > best_score;
                     const int32_t open = sc - goe;
-                    s_cell[ix][lane] = make_int2(keep ? sc : NEG, keep ? max(open, c.y - ge) : c.y);   // (a failed first column leaves the window: what is stored there does not matter)
+                    s_cell[ix][lane] = pack_cell(keep ? sc : NEG, keep ? max(open, c_gap - ge) : c_gap);   // (a failed first column leaves the window: what is stored there does not matter)
                     sgr = keep ? max(open, sgr - ge) : sgr;
                     last_b = keep ? b : last_b; lix = keep ? ix : lix;
                     best_score = better ? sc : best_score; a_off = better ? a : a_off; b_off = better ? b : b_off;
                     first_b += drop_first ? 1 : 0; fix = drop_first ? inc(fix) : fix;
-                    sc = next; b++; ix = ixn; c = cn; letter = letter_n;
+                    sc = next; b++; ix = ixn; cw = cwn; letter = letter_n;
                 }
             }
         }
@@ -1553,7 +1562,7 @@ extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParam
             const bool step = est < 2 && !(fresh && ln == 0);           // (its letter has not arrived yet: next round)
             if (!__ballot(step)) break;
             if (step) {
-                s_cell[six][lane] = est == 0 ? make_int2(sgr, sgr - goe) : make_int2(NEG, NEG);
+                s_cell[six][lane] = est == 0 ? pack_cell(sgr, sgr - goe) : pack_cell(NEG, NEG);
                 if (fresh) { s_let[six][lane] = (uint8_t)(lq & 15u); lq >>= 4; ln--; hw++; }
                 sgr -= ge; b_size++; six = inc(six);
                 est = est == 1 ? 2 : est;
@@ -1687,7 +1696,9 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
     // thread-per-extension kernel with its band in scratch memory.  GBN_GAP_LANE=0: start with the wave kernel.
     if (!p.redo_only) {
         static const bool lane_on = !(getenv("GBN_GAP_LANE") && atoi(getenv("GBN_GAP_LANE")) == 0);
+        // (16-bit band cells: no score of an extension may reach 30000; scratch_per_thread / 2 bounds the longest context)
         const bool lane = lane_on && p.gap_extend > 0 && std::abs(p.reward) <= 127 && std::abs(p.penalty) <= 127 &&
+                          (int64_t)std::abs(p.reward) * (p.scratch_per_thread / 2) < 30000 &&
                           (int64_t)p.scratch_per_thread * 64 * blocks >= p.n + 16;
         GbnGapParams w = p;
         if (lane) {
@@ -1696,7 +1707,7 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
             if (e != hipSuccess) return e;
             int32_t *ctx_of = p.scratch + 16;
             hipLaunchKernelGGL(gap_context_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p, ctx_of);
-            const int64_t lblocks = std::max<int64_t>(1, std::min<int64_t>(need, p.max_blocks > 0 ? std::max(1, p.max_blocks / 3) : need));   // 8 of its workgroups fit a CU (LDS)
+            const int64_t lblocks = std::max<int64_t>(1, std::min<int64_t>(need, p.max_blocks > 0 ? std::max(1, p.max_blocks * 2 / 3) : need));   // 16 of its workgroups fit a CU (LDS)
             hipLaunchKernelGGL(dynprog_lane_kernel, dim3((unsigned)lblocks), dim3(64), 0, st, p, reinterpret_cast<unsigned long long *>(p.scratch), ctx_of);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
