@@ -842,8 +842,8 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     static const bool ck_on = !(getenv("GBN_SEED_CKEYS") && atoi(getenv("GBN_SEED_CKEYS")) == 0);
     K.s_bits = bits_for((uint64_t)max_len + 1); K.qh_bits = std::max(0, K.q_bits - K.group_bits);
     K.subj_base = s0;
-    const int ck_bits = K.group_bits + bits_for((uint64_t)(s1 - s0) + 1) + K.s_bits + K.qh_bits;
-    const bool composite = ck_on && E.ext_rec && n >= compact_min && ck_bits <= 64 && K.group_bits < 32;
+    const int ck_bits = K.group_bits + bits_for((uint64_t)(s1 - s0) + 1) + K.s_bits;        // (the query key's high bits travel in the value)
+    const bool composite = ck_on && E.ext_rec && n >= compact_min && ck_bits <= 64 && K.group_bits < 32 && K.qh_bits <= 24 && b.lut.word - b.lut.lut < 256;
     if (!composite || keep_stages) {
         HIPCHK(launch_seed_keys(K, st));
         size_t tb = E.sort_tmp_bytes;
@@ -898,7 +898,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = E.ext_rec;
         if (composite) {
             X.idx = E.idx_b; X.run_heads = E.idx_a;
-            X.ck_shift = K.s_bits + K.qh_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending; X.ck_subj_base = K.subj_base;
+            X.ck_shift = K.s_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending; X.ck_subj_base = K.subj_base;
         }
         X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
         HIPCHK(launch_diag_ungapped(X, st));

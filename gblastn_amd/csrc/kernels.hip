@@ -276,11 +276,11 @@ extern "C" __global__ void seed_keys_kernel(GbnKeyParams K)
     K.idx[i] = (uint32_t)i;
 }
 
-// One 64-bit key per seed that orders the seeds the way the two sorts below do, in a single sort:
-// subject | slot | s_scan | query key >> group_bits.  Two seeds of one (subject, slot, s_scan) have query positions
-// that agree modulo the number of slots, so the low bits of the query key decide nothing and are left out; the
-// rest of the seed follows from the key (q_pos's low bits = (s_scan - slot) mod slots), only ext_left travels as
-// the sort's value: no second sort, no gathers of seeds by rank afterwards.
+// One 64-bit key per seed that orders the seeds the way the two sorts below do, in a single sort: subject | slot |
+// s_scan, and inside one (subject, slot, s_scan) -- seeds whose query positions agree modulo the number of slots,
+// a handful per million -- by the high bits of the query key, which seed_ext_kernel applies.  The seed follows from
+// key and value (q_pos's low bits = (s_scan - slot) mod slots; value = ext_left | high bits of the query key << 8):
+// no second sort, no gathers of seeds by rank afterwards.
 extern "C" __global__ void seed_ckeys_kernel(GbnKeyParams K)
 {
     int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -292,9 +292,10 @@ extern "C" __global__ void seed_ckeys_kernel(GbnKeyParams K)
                                            : ((uint32_t)(sd.s_scan + K.diag_len - sd.q_pos) & (uint32_t)(K.diag_len - 1));
     uint64_t key = ((uint64_t)(uint32_t)(sd.subj - K.subj_base) << K.group_bits) | slot;
     key = (key << K.s_bits) | (uint32_t)sd.s_scan;
-    key = (key << K.qh_bits) | (K.qh_bits ? (uint64_t)(qkey >> K.group_bits) : 0ull);
+    // the high bits of the query key order the (rare) seeds of one (subject, slot, scan position): they travel in
+    // the value, and seed_ext_kernel puts such a group into their order -- nine bits less to sort
     K.key_scan[i] = key;
-    K.idx[i] = (uint32_t)sd.ext_left;
+    K.idx[i] = (uint32_t)sd.ext_left | ((K.qh_bits ? (qkey >> K.group_bits) : 0u) << 8);
 }
 
 extern "C" __global__ void group_keys_kernel(GbnKeyParams K)
@@ -580,25 +581,35 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
     const int gb = P.group_bits ? P.group_bits : 32;
     int32_t subj_id = 0; GbnDevSeed sd; sd.subj = 0; sd.s_scan = 0; sd.q_pos = 0; sd.ext_left = 0;
     bool head = false, last = false;
+    int64_t pos = j;                                    // where this seed's record goes
     if (live) {
         const uint64_t key = P.key_group[j];
         if (P.ck_shift > 0) {
-            // composite keys: the seed is in the key; the run's ends show in the neighbours' keys
+            // composite keys: the seed is in key and value.  Seeds with one key (same subject, slot and scan position)
+            // come out of the sort in no particular order: each finds its place among them by the high bits of its
+            // query key and works for the position it lands on.
+            const uint32_t val = P.idx[j];
+            const uint32_t qk = val >> 8;
+            int64_t a = j, e = j + 1;
+            while (a > 0 && P.key_group[a - 1] == key) a--;
+            while (e < P.n && P.key_group[e] == key) e++;
+            int64_t rank = 0;
+            for (int64_t m = a; m < e; m++) { if (m == j) continue; const uint32_t qm = P.idx[m] >> 8; rank += (qm < qk || (qm == qk && m < j)) ? 1 : 0; }
+            pos = a + rank;
             const uint64_t run = key >> P.ck_shift;
-            head = j == 0 || (P.key_group[j - 1] >> P.ck_shift) != run;
-            last = j + 1 >= P.n || (P.key_group[j + 1] >> P.ck_shift) != run;
+            head = pos == a && (a == 0 || (P.key_group[a - 1] >> P.ck_shift) != run);
+            last = pos == e - 1 && (e >= P.n || (P.key_group[e] >> P.ck_shift) != run);
             subj_id = (int32_t)(run >> gb) + P.ck_subj_base;
             const uint32_t mask = (gb >= 32) ? 0xffffffffu : ((1u << gb) - 1u);
             const uint32_t slot = (uint32_t)run & mask;
-            sd.s_scan = (int32_t)((key >> P.ck_qh_bits) & ((1ull << P.ck_s_bits) - 1ull));
-            const uint32_t qk = (uint32_t)(key & ((1ull << P.ck_qh_bits) - 1ull));
+            sd.s_scan = (int32_t)(key & ((1ull << P.ck_s_bits) - 1ull));
             const uint32_t ql = ((uint32_t)sd.s_scan - slot) & mask;                      // q_pos modulo the number of slots
             if (P.ck_q_desc) {
                 const uint32_t qmax = (P.ck_q_bits >= 32) ? 0xffffffffu : ((1u << P.ck_q_bits) - 1u);
                 const uint32_t t = (P.ck_qh_bits ? (qk << gb) : 0u) | ((qmax - ql) & mask);
                 sd.q_pos = (int32_t)(qmax - t);
             } else sd.q_pos = (int32_t)((P.ck_qh_bits ? (qk << gb) : 0u) | ql);
-            sd.ext_left = (int32_t)P.idx[j];
+            sd.ext_left = (int32_t)(val & 0xffu);
         } else {
             subj_id = (int32_t)(key >> gb);
             sd = P.seeds[P.idx[j]];
@@ -617,7 +628,7 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
             s_base = tot ? atomicAdd(P.run_count, tot) : 0u;
         }
         __syncthreads();
-        if (head) P.run_heads[s_base + s_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)j;
+        if (head) P.run_heads[s_base + s_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)pos;
     }
     if (!live) return;
     const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
@@ -642,7 +653,7 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
     }
     if (last) r.flags |= 4;
     r.q_off = q_off; r.s_off = s_off;
-    reinterpret_cast<GbnSeedExt *>(P.ext_rec)[j] = r;
+    reinterpret_cast<GbnSeedExt *>(P.ext_rec)[pos] = r;
 }
 
 extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams P)

@@ -103,9 +103,10 @@ typedef struct GbnExtParams {
      * extend every seed in a kernel of its own and replay the runs over the records (null: one kernel) */
     void *ext_rec;
     /* composite-key form (ck_shift > 0; needs ext_rec): key_group[i] = subj << (group_bits + ck_shift) | slot << ck_shift
-     * | s_scan << ck_qh_bits | (query key >> group_bits), sorted as ONE 64-bit key; idx[i] = the seed's ext_left;
-     * `seeds` is not read (a seed follows from its key: q_pos = query key's low bits from (s_scan - slot)).  query key
-     * = q_pos, or 2^ck_q_bits - 1 - q_pos when ck_q_desc (megablast tables: chains are reported last position first) */
+     * | s_scan (ck_shift = ck_s_bits), sorted as ONE 64-bit key; idx[i] = the seed's ext_left | (query key >> group_bits)
+     * << 8; `seeds` is not read (a seed follows from key and value: q_pos's low bits = (s_scan - slot) mod slots).
+     * Seeds with equal keys may come in any order: the kernel orders them by the value's high bits.  query key = q_pos,
+     * or 2^ck_q_bits - 1 - q_pos when ck_q_desc (megablast tables: chains are reported last position first) */
     int32_t ck_shift, ck_s_bits, ck_qh_bits, ck_q_bits, ck_q_desc, ck_subj_base;   /* subj in the key counts from ck_subj_base */
 } GbnExtParams;
 

@@ -249,3 +249,51 @@ def test_pipelined_searches_with_the_deferred_rare_kernel():
                         "-m", "gpu", "-k", "pipelin or begin_end or chunks_equal"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stdout[-3000:]
     assert " passed" in p.stdout and "failed" not in p.stdout
+
+
+TIE_CASE = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from gblastn_amd import api
+from oracle import orc
+from tests import util
+rng = np.random.default_rng(8)
+R = rng.integers(0, 4, 60).astype(np.uint8)
+nq = 12
+qs = [rng.integers(0, 4, 900).astype(np.uint8) for _ in range(nq)]
+opt = api.default_options(sys.argv[1], db_length=10**7, db_num_seqs=10)
+S0 = orc.Search(util.oracle_options(opt), qs)
+off = [S0.contexts[2 * k].query_offset for k in range(nq)]
+for k in range(nq):                                    # the same 60-mer at concatenated offsets congruent modulo 512
+    a = (100 + off[0] - off[k]) %% 512
+    if a < 10: a += 512
+    if a + 60 > 900: a -= 512
+    assert 0 <= a <= 840
+    qs[k][a:a + 60] = R
+subs = []
+for j in range(3):
+    s = rng.integers(0, 4, 20000).astype(np.uint8)
+    for p in (1000, 7000 + j, 15000): s[p:p + 60] = R
+    subs.append(s)
+subjects = [(orc.pack_ncbi2na(s), len(s)) for s in subs]
+src = api.BlastSeqSrc.from_packed(subjects)
+got = api.BlastPrelimSearch(qs, opt, src).run(keep_stages=True)
+ora, S = util.oracle_run(opt, qs, [(np.concatenate([p, np.zeros(16, np.uint8)]), n) for p, n in subjects])
+assert S.info()["container"] == 1
+sd = ora[0]["seeds"]
+ties = sum(1 for i in range(1, len(sd)) if sd["s_off"][i] == sd["s_off"][i - 1] and (sd["q_off"][i] - sd["q_off"][i - 1]) %% 512 == 0)
+assert ties >= 20, ties                               # seeds of one (subject, slot, scan position): the sort leaves them unordered
+util.compare_stages(got, ora)
+print("TIES_OK", ties, len(got["init_hits"]), len(got["hsps"]))
+'''
+
+
+@pytest.mark.parametrize("task", ["megablast", "blastn"])
+def test_seeds_of_one_slot_and_position_are_ordered_after_the_sort(task):
+    """the composite-key sort stops at (subject, slot, scan position); seeds that agree on all three -- the same word
+    at query positions congruent modulo the slot count -- are put into table order by seed_ext_kernel"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["GBN_DIAG_COMPACT_MIN"] = "1"
+    p = subprocess.run([sys.executable, "-c", TIE_CASE % root, task], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "TIES_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
