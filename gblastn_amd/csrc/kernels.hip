@@ -345,9 +345,11 @@ __device__ void ungapped_exact(const GbnExtParams &P, const uint8_t *__restrict_
 // into its neighbours' bits: such groups go through the byte-wise formula; all others are taken 8 steps at a time
 // from the 2-bit copy of the query (three dwords of query, three of subject, two of the "matches nothing" bitmap
 // per 32 bases instead of six dependent loads per step).
-__device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
+// defer_exact: do not run the exact pass here, report that it is due (seed_ext_kernel hands those seeds to
+// seed_exact_kernel: a few per wave, each a byte-wise walk the other lanes would wait for)
+__device__ bool ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
                                 int32_t q_off, int32_t s_match_end, int32_t s_off, int32_t X,
-                                int32_t reduced_cutoff, Ungapped &u)
+                                int32_t reduced_cutoff, Ungapped &u, bool defer_exact = false)
 {
     const uint8_t *qs = P.q8;
     const int32_t t4 = P.score_table[0], dt = P.score_table[1] - t4;      // 4 * reward, penalty - reward
@@ -406,11 +408,13 @@ __device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict
         }
     }
     if (score >= reduced_cutoff) {
+        if (defer_exact) return true;
         ungapped_exact(P, subj, slen, q_off, s_off, X, u);
     } else {
         u.score = score;
         u.length = max(s_match_end - u.s_start, new_q - u.q_start + 1);
     }
+    return false;
 }
 }  // namespace
 
@@ -615,45 +619,74 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
             sd = P.seeds[P.idx[j]];
         }
     }
+    bool exact_due = false;
+    if (live) {
+        const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
+        const int32_t slen = P.len[subj_id];
+        GbnSeedExt r;
+        int32_t q_off = sd.q_pos - sd.ext_left, s_off = sd.s_scan - sd.ext_left;
+        r.s_orig = s_off; r.flags = 0; r.q_start = 0; r.s_start = 0; r.length = 0; r.score = 0;
+        int32_t s_match_end = s_off + P.word;
+        bool ok = true;
+        if (P.masked) {                                     // without masks s_TypeOfWord changes nothing
+            int32_t extended;
+            ok = type_of_word(P, subj, slen, q_off, s_off, extended);
+            s_match_end += extended; r.flags = ok ? (extended << 8) : 1;
+        }
+        if (ok) {
+            const int lo = context_of(P, q_off);
+            Ungapped u; u.q_start = 0; u.s_start = 0; u.length = 0; u.score = 0;
+            if (!P.container_hash && P.word < 11) ungapped_exact(P, subj, slen, q_off, s_off, -P.ctx_xdrop[lo], u);
+            else exact_due = ungapped_approx(P, subj, slen, q_off, s_match_end, s_off, -P.ctx_xdrop[lo], P.ctx_reduced[lo], u, P.ck_shift > 0);
+            r.q_start = u.q_start; r.s_start = u.s_start; r.length = u.length; r.score = u.score;
+            if (!exact_due && u.score >= P.ctx_cutoff[lo]) r.flags |= 2;
+        }
+        if (last) r.flags |= 4;
+        r.q_off = q_off; r.s_off = s_off;
+        reinterpret_cast<GbnSeedExt *>(P.ext_rec)[pos] = r;
+    }
     if (P.ck_shift > 0) {
-        // the run heads, compacted (what run_heads_kernel does for the other form): one atomic per workgroup
-        __shared__ uint32_t s_cnt[4], s_base;
+        // The run heads (what run_heads_kernel does for the other form) and the seeds whose 4-bases-per-step score
+        // reaches the reduced cut-off -- those are extended exactly by seed_exact_kernel; their list goes to cell_diag,
+        // which the replay kernel does not touch before that kernel is through -- compacted with ONE 64-bit atomic per
+        // workgroup for both counts (a counter that every wave increments serialises them: +4.5 ms).
+        __shared__ uint32_t s_cnt[2][4], s_base[2];
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const unsigned long long m = __ballot(head);
-        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
+        const unsigned long long mh = __ballot(head), mx = __ballot(exact_due);
+        if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(mh); s_cnt[1][wave] = (uint32_t)__popcll(mx); }
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t tot = 0;
-            for (int w = 0; w < 4; w++) { const uint32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
-            s_base = tot ? atomicAdd(P.run_count, tot) : 0u;
+            uint32_t th = 0, tx = 0;
+            for (int w = 0; w < 4; w++) { const uint32_t c = s_cnt[0][w]; s_cnt[0][w] = th; th += c; const uint32_t d = s_cnt[1][w]; s_cnt[1][w] = tx; tx += d; }
+            unsigned long long at = 0;
+            if (th | tx) at = atomicAdd(reinterpret_cast<unsigned long long *>(P.run_count), (unsigned long long)th | ((unsigned long long)tx << 32));
+            s_base[0] = (uint32_t)at; s_base[1] = (uint32_t)(at >> 32);
         }
         __syncthreads();
-        if (head) P.run_heads[s_base + s_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)pos;
+        const unsigned long long below = (1ull << lane) - 1;
+        if (head) P.run_heads[s_base[0] + s_cnt[0][wave] + (uint32_t)__popcll(mh & below)] = (uint32_t)pos;
+        if (exact_due) P.cell_diag[s_base[1] + s_cnt[1][wave] + (uint32_t)__popcll(mx & below)] = (int32_t)pos;
     }
-    if (!live) return;
+}
+
+// s_NuclUngappedExtendExact for the seeds seed_ext_kernel listed: dense waves instead of a few lanes per wave
+extern "C" __global__ void __launch_bounds__(256) seed_exact_kernel(GbnExtParams P)
+{
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)P.run_count[1]) return;
+    const int64_t pos = P.cell_diag[t];
+    GbnSeedExt *rec = reinterpret_cast<GbnSeedExt *>(P.ext_rec);
+    GbnSeedExt r = rec[pos];
+    // the subject of the record's run: the run key of its position
+    const int gb = P.group_bits ? P.group_bits : 32;
+    const int32_t subj_id = (int32_t)((P.key_group[pos] >> P.ck_shift) >> gb) + P.ck_subj_base;
     const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
-    const int32_t slen = P.len[subj_id];
-    GbnSeedExt r;
-    int32_t q_off = sd.q_pos - sd.ext_left, s_off = sd.s_scan - sd.ext_left;
-    r.s_orig = s_off; r.flags = 0; r.q_start = 0; r.s_start = 0; r.length = 0; r.score = 0;
-    int32_t s_match_end = s_off + P.word;
-    bool ok = true;
-    if (P.masked) {                                     // without masks s_TypeOfWord changes nothing
-        int32_t extended;
-        ok = type_of_word(P, subj, slen, q_off, s_off, extended);
-        s_match_end += extended; r.flags = ok ? (extended << 8) : 1;
-    }
-    if (ok) {
-        const int lo = context_of(P, q_off);
-        Ungapped u;
-        if (!P.container_hash && P.word < 11) ungapped_exact(P, subj, slen, q_off, s_off, -P.ctx_xdrop[lo], u);
-        else ungapped_approx(P, subj, slen, q_off, s_match_end, s_off, -P.ctx_xdrop[lo], P.ctx_reduced[lo], u);
-        r.q_start = u.q_start; r.s_start = u.s_start; r.length = u.length; r.score = u.score;
-        if (u.score >= P.ctx_cutoff[lo]) r.flags |= 2;
-    }
-    if (last) r.flags |= 4;
-    r.q_off = q_off; r.s_off = s_off;
-    reinterpret_cast<GbnSeedExt *>(P.ext_rec)[pos] = r;
+    const int lo = context_of(P, r.q_off);
+    Ungapped u;
+    ungapped_exact(P, subj, P.len[subj_id], r.q_off, r.s_off, -P.ctx_xdrop[lo], u);
+    r.q_start = u.q_start; r.s_start = u.s_start; r.length = u.length; r.score = u.score;
+    if (u.score >= P.ctx_cutoff[lo]) r.flags |= 2;
+    rec[pos] = r;
 }
 
 extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams P)
@@ -1671,7 +1704,7 @@ hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st)
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
 {
     if (p.n <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(p.run_count, 0, sizeof(uint32_t), st);
+    hipError_t e = hipMemsetAsync(p.run_count, 0, 2 * sizeof(uint32_t), st);      // [0] runs, [1] seeds due for the exact pass
     if (e != hipSuccess) return e;
     // Compacting the run heads first pays once most seeds are not heads (blastn word sizes: 6x on
     // C3); for the few ten thousand seeds of a megablast pass the direct form is 2x faster.
@@ -1682,6 +1715,7 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
         return hipGetLastError(); }
     if (p.ck_shift > 0 && p.ext_rec) {      // composite keys: the extension kernel finds the run heads on its way
         hipLaunchKernelGGL(seed_ext_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(seed_exact_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
         hipLaunchKernelGGL(diag_replay_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
         return hipGetLastError();
     }
