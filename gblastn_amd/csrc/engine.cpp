@@ -522,7 +522,7 @@ static int grow_key_buffers(size_t n) {
     if (n <= E.key_cap) return GBN_OK;
     dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
     dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.ext_rec); dev_free(E.sort_tmp);
-    size_t cap = std::max<size_t>(n, 1 << 16);
+    size_t cap = std::max<size_t>(n + n / 8, 1 << 16);      // (room to spare: seed counts of consecutive ranges differ by a fraction of a percent, and a regrow frees and allocates gigabytes)
     int rc;
     if ((rc = dev_alloc(E.key_a, cap)) || (rc = dev_alloc(E.key_b, cap)) || (rc = dev_alloc(E.idx_a, cap)) ||
         (rc = dev_alloc(E.idx_b, cap)) || (rc = dev_alloc(E.cell_diag, cap)) || (rc = dev_alloc(E.cell_level, cap)))

@@ -315,6 +315,9 @@ extern "C" __global__ void group_keys_kernel(GbnKeyParams K)
 namespace {
 struct Ungapped { int32_t q_start, s_start, length, score; };
 
+// s_NuclUngappedExtendExact (CORE/na_ungapped.c:152-244): base by base with the X-drop rule.  32 bases at a time
+// from the 2-bit copies of query and subject (a real homolog's thousand bases were a thousand dependent byte loads);
+// a stretch of the query with a code above 3 (ambiguity, the sentinel between contexts) goes byte by byte.
 __device__ void ungapped_exact(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
                                int32_t q_off, int32_t s_off, int32_t X, Ungapped &u)
 {
@@ -322,19 +325,38 @@ __device__ void ungapped_exact(const GbnExtParams &P, const uint8_t *__restrict_
     int32_t sum = 0, score = 0, q_beg = q_off, q_end = q_off;
     const int32_t nleft = min(q_off, s_off);
     const int32_t nright = min(P.qlen - q_off, slen - s_off);
-    for (int32_t i = 1; i <= nleft; i++) {
-        int32_t qi = q_off - i;
-        sum += P.matrix[q[qi] * 16 + base_at(subj, s_off - i)];
-        if (sum > 0) { q_beg = qi; score += sum; sum = 0; }
-        else if (sum < X) break;
+    const bool packed = P.q2 != nullptr;
+    const int32_t reward = P.matrix[0], penalty = P.matrix[1];
+    bool stop = false;
+    for (int32_t c = 0; c < nleft && !stop; c += 32) {
+        const int32_t steps = min(32, nleft - c);
+        uint64_t x = 0; uint32_t amb = 1;
+        if (packed) {
+            x = bases32(subj, (int64_t)s_off - c - 32) ^ bases32(P.q2, (int64_t)q_off - c - 32);
+            amb = bits32(P.qinv, (int64_t)q_off - c - 32) & (steps == 32 ? 0xffffffffu : ((1u << steps) - 1u));
+        }
+        for (int32_t t = 0; t < steps; t++) {
+            const int32_t qi = q_off - c - 1 - t;
+            sum += amb ? P.matrix[q[qi] * 16 + base_at(subj, s_off - c - 1 - t)] : (((x >> (2 * t)) & 3) ? penalty : reward);
+            if (sum > 0) { q_beg = qi; score += sum; sum = 0; }
+            else if (sum < X) { stop = true; break; }
+        }
     }
     u.q_start = q_beg; u.s_start = s_off - (q_off - q_beg);
-    sum = 0;
-    for (int32_t i = 0; i < nright; i++) {
-        int32_t qi = q_off + i;
-        sum += P.matrix[q[qi] * 16 + base_at(subj, s_off + i)];
-        if (sum > 0) { q_end = qi + 1; score += sum; sum = 0; }
-        else if (sum < X) break;
+    sum = 0; stop = false;
+    for (int32_t c = 0; c < nright && !stop; c += 32) {
+        const int32_t steps = min(32, nright - c);
+        uint64_t x = 0; uint32_t amb = 1;
+        if (packed) {
+            x = bases32(subj, (int64_t)s_off + c) ^ bases32(P.q2, (int64_t)q_off + c);
+            amb = bits32(P.qinv, (int64_t)q_off + c) >> (32 - steps);
+        }
+        for (int32_t t = 0; t < steps; t++) {
+            const int32_t qi = q_off + c + t;
+            sum += amb ? P.matrix[q[qi] * 16 + base_at(subj, s_off + c + t)] : (((x >> (62 - 2 * t)) & 3) ? penalty : reward);
+            if (sum > 0) { q_end = qi + 1; score += sum; sum = 0; }
+            else if (sum < X) { stop = true; break; }
+        }
     }
     u.length = q_end - q_beg; u.score = score;
 }
@@ -345,11 +367,9 @@ __device__ void ungapped_exact(const GbnExtParams &P, const uint8_t *__restrict_
 // into its neighbours' bits: such groups go through the byte-wise formula; all others are taken 8 steps at a time
 // from the 2-bit copy of the query (three dwords of query, three of subject, two of the "matches nothing" bitmap
 // per 32 bases instead of six dependent loads per step).
-// defer_exact: do not run the exact pass here, report that it is due (seed_ext_kernel hands those seeds to
-// seed_exact_kernel: a few per wave, each a byte-wise walk the other lanes would wait for)
-__device__ bool ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
+__device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
                                 int32_t q_off, int32_t s_match_end, int32_t s_off, int32_t X,
-                                int32_t reduced_cutoff, Ungapped &u, bool defer_exact = false)
+                                int32_t reduced_cutoff, Ungapped &u)
 {
     const uint8_t *qs = P.q8;
     const int32_t t4 = P.score_table[0], dt = P.score_table[1] - t4;      // 4 * reward, penalty - reward
@@ -408,13 +428,11 @@ __device__ bool ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict
         }
     }
     if (score >= reduced_cutoff) {
-        if (defer_exact) return true;
         ungapped_exact(P, subj, slen, q_off, s_off, X, u);
     } else {
         u.score = score;
         u.length = max(s_match_end - u.s_start, new_q - u.q_start + 1);
     }
-    return false;
 }
 }  // namespace
 
@@ -619,7 +637,6 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
             sd = P.seeds[P.idx[j]];
         }
     }
-    bool exact_due = false;
     if (live) {
         const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
         const int32_t slen = P.len[subj_id];
@@ -637,56 +654,31 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
             const int lo = context_of(P, q_off);
             Ungapped u; u.q_start = 0; u.s_start = 0; u.length = 0; u.score = 0;
             if (!P.container_hash && P.word < 11) ungapped_exact(P, subj, slen, q_off, s_off, -P.ctx_xdrop[lo], u);
-            else exact_due = ungapped_approx(P, subj, slen, q_off, s_match_end, s_off, -P.ctx_xdrop[lo], P.ctx_reduced[lo], u, P.ck_shift > 0);
+            // (the exact pass stays inline: handing its seeds to a kernel of their own -- dense waves -- gained 0.1 ms per
+            // 47 M seeds once that pass read 32 bases per load, not worth a kernel)
+            else ungapped_approx(P, subj, slen, q_off, s_match_end, s_off, -P.ctx_xdrop[lo], P.ctx_reduced[lo], u);
             r.q_start = u.q_start; r.s_start = u.s_start; r.length = u.length; r.score = u.score;
-            if (!exact_due && u.score >= P.ctx_cutoff[lo]) r.flags |= 2;
+            if (u.score >= P.ctx_cutoff[lo]) r.flags |= 2;
         }
         if (last) r.flags |= 4;
         r.q_off = q_off; r.s_off = s_off;
         reinterpret_cast<GbnSeedExt *>(P.ext_rec)[pos] = r;
     }
     if (P.ck_shift > 0) {
-        // The run heads (what run_heads_kernel does for the other form) and the seeds whose 4-bases-per-step score
-        // reaches the reduced cut-off -- those are extended exactly by seed_exact_kernel; their list goes to cell_diag,
-        // which the replay kernel does not touch before that kernel is through -- compacted with ONE 64-bit atomic per
-        // workgroup for both counts (a counter that every wave increments serialises them: +4.5 ms).
-        __shared__ uint32_t s_cnt[2][4], s_base[2];
+        // the run heads, compacted (what run_heads_kernel does for the other form): one atomic per workgroup
+        __shared__ uint32_t s_cnt[4], s_base;
         const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-        const unsigned long long mh = __ballot(head), mx = __ballot(exact_due);
-        if (lane == 0) { s_cnt[0][wave] = (uint32_t)__popcll(mh); s_cnt[1][wave] = (uint32_t)__popcll(mx); }
+        const unsigned long long mh = __ballot(head);
+        if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(mh);
         __syncthreads();
         if (threadIdx.x == 0) {
-            uint32_t th = 0, tx = 0;
-            for (int w = 0; w < 4; w++) { const uint32_t c = s_cnt[0][w]; s_cnt[0][w] = th; th += c; const uint32_t d = s_cnt[1][w]; s_cnt[1][w] = tx; tx += d; }
-            unsigned long long at = 0;
-            if (th | tx) at = atomicAdd(reinterpret_cast<unsigned long long *>(P.run_count), (unsigned long long)th | ((unsigned long long)tx << 32));
-            s_base[0] = (uint32_t)at; s_base[1] = (uint32_t)(at >> 32);
+            uint32_t th = 0;
+            for (int w = 0; w < 4; w++) { const uint32_t c = s_cnt[w]; s_cnt[w] = th; th += c; }
+            s_base = th ? atomicAdd(P.run_count, th) : 0u;
         }
         __syncthreads();
-        const unsigned long long below = (1ull << lane) - 1;
-        if (head) P.run_heads[s_base[0] + s_cnt[0][wave] + (uint32_t)__popcll(mh & below)] = (uint32_t)pos;
-        if (exact_due) P.cell_diag[s_base[1] + s_cnt[1][wave] + (uint32_t)__popcll(mx & below)] = (int32_t)pos;
+        if (head) P.run_heads[s_base + s_cnt[wave] + (uint32_t)__popcll(mh & ((1ull << lane) - 1))] = (uint32_t)pos;
     }
-}
-
-// s_NuclUngappedExtendExact for the seeds seed_ext_kernel listed: dense waves instead of a few lanes per wave
-extern "C" __global__ void __launch_bounds__(256) seed_exact_kernel(GbnExtParams P)
-{
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)P.run_count[1]) return;
-    const int64_t pos = P.cell_diag[t];
-    GbnSeedExt *rec = reinterpret_cast<GbnSeedExt *>(P.ext_rec);
-    GbnSeedExt r = rec[pos];
-    // the subject of the record's run: the run key of its position
-    const int gb = P.group_bits ? P.group_bits : 32;
-    const int32_t subj_id = (int32_t)((P.key_group[pos] >> P.ck_shift) >> gb) + P.ck_subj_base;
-    const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
-    const int lo = context_of(P, r.q_off);
-    Ungapped u;
-    ungapped_exact(P, subj, P.len[subj_id], r.q_off, r.s_off, -P.ctx_xdrop[lo], u);
-    r.q_start = u.q_start; r.s_start = u.s_start; r.length = u.length; r.score = u.score;
-    if (u.score >= P.ctx_cutoff[lo]) r.flags |= 2;
-    rec[pos] = r;
 }
 
 extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams P)
@@ -1704,7 +1696,7 @@ hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st)
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
 {
     if (p.n <= 0) return hipSuccess;
-    hipError_t e = hipMemsetAsync(p.run_count, 0, 2 * sizeof(uint32_t), st);      // [0] runs, [1] seeds due for the exact pass
+    hipError_t e = hipMemsetAsync(p.run_count, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
     // Compacting the run heads first pays once most seeds are not heads (blastn word sizes: 6x on
     // C3); for the few ten thousand seeds of a megablast pass the direct form is 2x faster.
@@ -1715,7 +1707,6 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
         return hipGetLastError(); }
     if (p.ck_shift > 0 && p.ext_rec) {      // composite keys: the extension kernel finds the run heads on its way
         hipLaunchKernelGGL(seed_ext_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
-        hipLaunchKernelGGL(seed_exact_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
         hipLaunchKernelGGL(diag_replay_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
         return hipGetLastError();
     }

@@ -91,7 +91,7 @@ typedef struct GbnExtParams {
     const uint32_t *cell_start; const unsigned long long *ent; uint32_t cell_mask; int lut, masked;
     /* the query 2 bits per base and the bitmap of codes that match nothing (as in GbnGapParams) */
     const uint8_t *q2, *qinv;
-    uint32_t *run_heads, *run_count;    /* [caller] scratch: n entries / two counters (8 bytes, 8-byte aligned) */
+    uint32_t *run_heads, *run_count;    /* [caller] scratch: n entries / one counter */
     int32_t group_bits;                 /* [caller] see key_group (0 is read as 32) */
     /* [caller] initial hits that reached the cutoff, in no particular order (GbnDevInitHit::seq orders them);
      * *ihit_count counts all of them (zero it first) */

@@ -297,3 +297,41 @@ def test_seeds_of_one_slot_and_position_are_ordered_after_the_sort(task):
     env = dict(os.environ); env["GBN_DIAG_COMPACT_MIN"] = "1"
     p = subprocess.run([sys.executable, "-c", TIE_CASE % root, task], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0 and "TIES_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+
+
+BIG_N = r'''
+import sys, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+from gblastn_amd import api, synth
+nsub = 120
+api.lib().Blast_gpu_Init(1, 0)
+lay = synth.SynthDb(nsub, 1_000_000, seed=777)
+slab = torch.empty(lay.nbytes, dtype=torch.uint8, device="cuda")
+api._check(api.lib().gbn_synth_fill(slab.data_ptr(), lay.nbytes, lay.seed, None))
+src = api.BlastSeqSrc.from_slab((slab.data_ptr(), lay.nbytes), lay.byte_off, lay.lens, is_device=True, keep=slab)
+qs, _ = synth.make_queries(100, lay)
+ps = api.BlastPrelimSearch(qs, api.default_options("blastn", db_length=nsub * 10**6, db_num_seqs=nsub), src)
+out = []
+for k in range(int(sys.argv[1])):
+    r = ps.run(keep_stages=True)
+    ih = np.sort(r["init_hits"], order=["oid", "q_off", "s_off", "score"])
+    out.append((len(r["seeds"]), len(ih), hashlib.sha1(ih.tobytes()).hexdigest(), hashlib.sha1(r["hsps"].tobytes()).hexdigest()))
+assert all(o == out[0] for o in out), out
+print("BIGN", *out[0])
+'''
+
+
+def test_many_seeds_composite_sort_is_deterministic_and_equals_the_two_sort_path():
+    """5.6 million seeds in one launch (blastn shape): the composite-key path (one sort, seed_ext_kernel +
+    diag_replay_kernel) gives the same initial hits and HSPs run after run -- a race here once changed 8 % of the
+    exact ungapped extensions from run to run -- and the same as the two-sort path (GBN_SEED_CKEYS=0)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for name, env_add, runs in (("composite", {}, "3"), ("two sorts", {"GBN_SEED_CKEYS": "0"}, "1")):
+        env = dict(os.environ); env.update(env_add)
+        p = subprocess.run([sys.executable, "-c", BIG_N % root, runs], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+        assert p.returncode == 0 and "BIGN" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+        res[name] = p.stdout.split("BIGN", 1)[1].split()
+    assert int(res["composite"][0]) > (1 << 22) and int(res["composite"][1]) > 10000
+    assert res["composite"] == res["two sorts"]
