@@ -1371,7 +1371,7 @@ extern "C" __global__ void __launch_bounds__(128) dynprog_wave_kernel(GbnGapPara
 #define GBN_LANE_W 32
 #endif
 #ifndef GBN_LANE_ROWS
-#define GBN_LANE_ROWS 192
+#define GBN_LANE_ROWS 96          // measured: 192 rows 2.45 + 0.72 ms (lane + wave kernel), 128: 2.18 + 0.72, 96: 2.10 + 0.71, 64: 2.02 + 1.01
 #endif
 #ifndef GBN_LANE_BATCH
 #define GBN_LANE_BATCH 8            // lanes waiting for set-up before the (long-latency) set-up code runs
