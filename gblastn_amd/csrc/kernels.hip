@@ -1332,12 +1332,15 @@ __device__ HalfOut dynprog_half_wave(const GbnGapParams &P, int64_t i, int side,
 }
 }  // namespace
 
-extern "C" __global__ void __launch_bounds__(128) dynprog_wave_kernel(GbnGapParams P)
+extern "C" __global__ void __launch_bounds__(128) dynprog_wave_kernel(GbnGapParams P, const unsigned long long *redo_count, const int32_t *redo_list)
 {
     __shared__ HalfOut s_half[2];
     const int side = threadIdx.x >> 6;
-    for (int64_t i = blockIdx.x; i < P.n; i += gridDim.x) {
-        if (P.redo_only && P.out[P.first + i].score != GBN_GAP_REDO) continue;     // after dynprog_lane_kernel: what it left
+    // after dynprog_lane_kernel: the extensions it listed; else every one
+    const int64_t todo = redo_list ? (int64_t)*redo_count : P.n;
+    for (int64_t k = blockIdx.x; k < todo; k += gridDim.x) {
+        const int64_t i = redo_list ? (int64_t)redo_list[k] : k;
+        if (!redo_list && P.redo_only && P.out[P.first + i].score != GBN_GAP_REDO) continue;
         GbnDevGapped g; int32_t q_length, s_length;
         const HalfOut o = dynprog_half_wave(P, i, side, g, q_length, s_length);
         if ((threadIdx.x & 63) == 0) s_half[side] = o;
@@ -1388,7 +1391,7 @@ extern "C" __global__ void gap_context_kernel(GbnGapParams P, int32_t *ctx_of)
     ctx_of[i] = lo;
 }
 
-extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParams P, unsigned long long *counter, const int32_t *ctx_of)
+extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParams P, unsigned long long *counter, const int32_t *ctx_of, int32_t *redo_list)
 {
     constexpr int W = GBN_LANE_W;
     constexpr int32_t NEG = GBN_MININT;
@@ -1611,6 +1614,7 @@ extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParam
             est = 2;
             if (redo) {                                                 // given up: dynprog_wave_kernel redoes the whole extension
                 P.out[P.first + i].score = GBN_GAP_REDO;
+                redo_list[atomicAdd(counter + 1, 1ull)] = (int32_t)i;  // (a few per cent: listed, so that nobody has to look for them)
                 need_new = true; mode = START;
             } else if (reverse) {
                 left_score = best_score; g_q_start = q_length - b_off; g_s_start = s_length - a_off;
@@ -1735,23 +1739,27 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
         // (16-bit band cells: no score of an extension may reach 30000; scratch_per_thread / 2 bounds the longest context)
         const bool lane = lane_on && p.gap_extend > 0 && std::abs(p.reward) <= 127 && std::abs(p.penalty) <= 127 &&
                           (int64_t)std::abs(p.reward) * (p.scratch_per_thread / 2) < 30000 &&
-                          (int64_t)p.scratch_per_thread * 64 * blocks >= p.n + 16;
+                          (int64_t)p.scratch_per_thread * 64 * blocks >= 2 * p.n + 16;
         GbnGapParams w = p;
+        int32_t *redo_list = nullptr;
         if (lane) {
-            // scratch: [0, 1] the work counter, [16, 16 + n) the context of every hit (the third kernel reuses it later)
+            // scratch: [0, 1] the work counter, [2, 3] the number of extensions left to the wave kernel, [16, 16 + n) the
+            // context of every hit, [16 + n, 16 + 2 n) the list of those extensions (the third kernel reuses it all later)
             hipError_t e = hipMemsetAsync(p.scratch, 0, 16 * sizeof(int32_t), st);
             if (e != hipSuccess) return e;
             int32_t *ctx_of = p.scratch + 16;
             hipLaunchKernelGGL(gap_context_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p, ctx_of);
             const int64_t lblocks = std::max<int64_t>(1, std::min<int64_t>(need, p.max_blocks > 0 ? std::max(1, p.max_blocks * 2 / 3) : need));   // 16 of its workgroups fit a CU (LDS)
-            hipLaunchKernelGGL(dynprog_lane_kernel, dim3((unsigned)lblocks), dim3(64), 0, st, p, reinterpret_cast<unsigned long long *>(p.scratch), ctx_of);
+            redo_list = p.scratch + 16 + p.n;
+            hipLaunchKernelGGL(dynprog_lane_kernel, dim3((unsigned)lblocks), dim3(64), 0, st, p, reinterpret_cast<unsigned long long *>(p.scratch), ctx_of, redo_list);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             w.redo_only = 1;
         }
         // a workgroup of two waves per extension (its two halves)
         const int64_t wblocks = std::max<int64_t>(1, std::min<int64_t>(p.n, p.max_blocks > 0 ? (int64_t)p.max_blocks * 4 : p.n));
-        hipLaunchKernelGGL(dynprog_wave_kernel, dim3((unsigned)wblocks), dim3(128), 0, st, w);
+        hipLaunchKernelGGL(dynprog_wave_kernel, dim3((unsigned)(redo_list ? std::min<int64_t>(wblocks, 16384) : wblocks)), dim3(128), 0, st, w,
+                           reinterpret_cast<const unsigned long long *>(p.scratch) + 1, (const int32_t *)redo_list);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
