@@ -266,9 +266,14 @@ def main():
     traffic = None
     tf = os.path.join(ROOT, "profiles", "scan_traffic.json")
     # the committed PMC passes were taken on the default workload (C2, full shard); other shapes: null
-    if os.path.exists(tf) and args.workload == "C2" and abs(algo_bytes / max(launches, 1) - 12.5e9) < 1e6:
+    per_launch = algo_bytes / max(launches, 1)
+    if os.path.exists(tf):
         try:
-            traffic = json.load(open(tf)).get(dom_name, {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tf))
+            if args.workload == "C2" and abs(per_launch - 12.5e9) < 1e6:
+                traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
+            elif args.workload == "C3" and abs(per_launch - 2.5e8) < 1e6:       # a launch = one subject range of 1,000 x 1 Mb
+                traffic = tj.get(dom_label, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
 
