@@ -123,7 +123,7 @@ static int ensure_init() {
 static inline void use_engine_device() { if (E.ready && E.device >= 0) (void)hipSetDevice(E.device); }
 
 // Device memory of query batches and of the table builder comes from a small pool: freed blocks are kept
-// (up to kPoolCap bytes) and handed out again for requests of about their size.  hipFree waits for the
+// (up to pool_cap() bytes) and handed out again for requests of about their size.  hipFree waits for the
 // whole device, which would stall a running search every time a finished batch is released.
 namespace {
 struct DevPool {
@@ -133,7 +133,17 @@ struct DevPool {
     size_t held = 0;
 };
 DevPool g_pool;
-const size_t kPoolCap = (size_t)24 << 30;
+// idle blocks kept: an eighth of the device's memory, 24 GiB at most (GBN_POOL_GIB overrides); when an allocation fails
+// the idle blocks are given back and it is tried again
+size_t pool_cap() {
+    static const size_t cap = [] {
+        if (const char *e = getenv("GBN_POOL_GIB")) return (size_t)std::max(0, atoi(e)) << 30;
+        size_t fr = 0, tot = 0;
+        if (hipMemGetInfo(&fr, &tot) != hipSuccess || tot == 0) return (size_t)24 << 30;
+        return std::min<size_t>(tot / 8, (size_t)24 << 30);
+    }();
+    return cap;
+}
 size_t pool_round(size_t bytes) { const size_t g = bytes >= ((size_t)1 << 20) ? ((size_t)1 << 20) : 4096; return (bytes + g - 1) / g * g; }
 hipError_t pool_alloc(void **p, size_t bytes) {
     bytes = pool_round(std::max<size_t>(bytes, 1));
@@ -164,7 +174,7 @@ void pool_free(void *p) {
         auto it = g_pool.size_of.find(p);
         if (it != g_pool.size_of.end()) {
             bytes = it->second; g_pool.size_of.erase(it);
-            if (g_pool.held + bytes <= kPoolCap) { g_pool.idle.emplace(bytes, p); g_pool.held += bytes; return; }
+            if (g_pool.held + bytes <= pool_cap()) { g_pool.idle.emplace(bytes, p); g_pool.held += bytes; return; }
         }
     }
     (void)hipFree(p);
