@@ -145,13 +145,22 @@ size_t pool_cap() {
     return cap;
 }
 size_t pool_round(size_t bytes) { const size_t g = bytes >= ((size_t)1 << 20) ? ((size_t)1 << 20) : 4096; return (bytes + g - 1) / g * g; }
+// GBN_POISON=<byte> (tests): every block handed out is filled with that byte first, so that a kernel reading
+// memory nobody wrote shows up whatever the device memory happened to hold
+int pool_poison() { static const int v = getenv("GBN_POISON") ? (atoi(getenv("GBN_POISON")) & 255) : -1; return v; }
+hipError_t poison_block(void *p, size_t bytes) {           // (before anything queued on a stream afterwards touches the block)
+    hipError_t e = hipMemset(p, pool_poison(), bytes);
+    return e != hipSuccess ? e : hipDeviceSynchronize();
+}
 hipError_t pool_alloc(void **p, size_t bytes) {
     bytes = pool_round(std::max<size_t>(bytes, 1));
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
         auto it = g_pool.idle.lower_bound(bytes);
         if (it != g_pool.idle.end() && it->first <= bytes + bytes / 4) {
-            *p = it->second; g_pool.held -= it->first; g_pool.size_of[*p] = it->first; g_pool.idle.erase(it);
+            *p = it->second; g_pool.held -= it->first; g_pool.size_of[*p] = it->first;
+            const size_t got = it->first; g_pool.idle.erase(it);
+            if (pool_poison() >= 0) return poison_block(*p, got);
             return hipSuccess;
         }
     }
@@ -164,6 +173,7 @@ hipError_t pool_alloc(void **p, size_t bytes) {
         e = hipMalloc(p, bytes);
     }
     if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.size_of[*p] = bytes; }
+    if (e == hipSuccess && pool_poison() >= 0) e = poison_block(*p, bytes);
     return e;
 }
 void pool_free(void *p) {
@@ -1411,6 +1421,8 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
         db->num_seqs = (int32_t)db->len.size(); db->nbytes = pos + 128;
         uint8_t *p = nullptr;
         if (hipMalloc((void **)&p, (size_t)db->nbytes) != hipSuccess) { delete db; set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
+        // (the bytes between the chunk copies: defined, like the pad bytes of a caller's slab)
+        if (hipMemset(p, pool_poison() >= 0 ? pool_poison() : 0, (size_t)db->nbytes) != hipSuccess) { (void)hipFree(p); delete db; set_error("hipMemset(db) failed"); return GBN_ERR_HIP; }
         db->d_packed = p; db->owns = true;
         hipError_t e = hipMemset(p, 0, (size_t)db->nbytes);
         for (size_t v = 0; v < db->len.size() && e == hipSuccess; v++) {

@@ -16,3 +16,4 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "spawns: starts child processes of its own (left out when a test re-runs a whole file in a child)")

@@ -232,10 +232,23 @@ def test_parity_suite_through_the_two_kernel_seed_stage():
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ); env["GBN_DIAG_COMPACT_MIN"] = "1"
-    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu"], cwd=root, env=env,
-                       capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-3000:]
+    # (the tests that start child processes of their own stay out: they carry their own two-kernel cases)
+    p = util.run_child([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu and not spawns"], cwd=root, env=env, timeout=900)
     assert " passed" in p.stdout and "failed" not in p.stdout
+
+
+def test_parity_cases_with_poisoned_device_blocks():
+    """GBN_POISON=<byte>: every device block the engine's pool hands out is filled with that byte first.  The randomised
+    shapes, the ragged inputs and the pipelined cases once more with it: a kernel that reads memory nobody wrote would
+    depend on what the device memory held before."""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for byte, compact in (("165", None), ("255", "1")):
+        env = dict(os.environ); env["GBN_POISON"] = byte
+        if compact: env["GBN_DIAG_COMPACT_MIN"] = compact
+        p = util.run_child([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu and not spawns",
+                            "-k", "randomised or ragged or begin_end or known_answers"], cwd=root, env=env, timeout=900)
+        assert " passed" in p.stdout and "failed" not in p.stdout
 
 
 def test_pipelined_searches_with_the_deferred_rare_kernel():
@@ -245,9 +258,8 @@ def test_pipelined_searches_with_the_deferred_rare_kernel():
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ); env["GBN_DEFER_RARE"] = "1"
-    p = subprocess.run([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_traceback_gpu.py", "tests/test_chunking.py", "-x", "-q",
-                        "-m", "gpu", "-k", "pipelin or begin_end or chunks_equal"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stdout[-3000:]
+    p = util.run_child([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_traceback_gpu.py", "tests/test_chunking.py", "-x", "-q",
+                        "-m", "gpu and not spawns", "-k", "pipelin or begin_end or chunks_equal"], cwd=root, env=env, timeout=900)
     assert " passed" in p.stdout and "failed" not in p.stdout
 
 
@@ -295,8 +307,8 @@ def test_seeds_of_one_slot_and_position_are_ordered_after_the_sort(task):
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ); env["GBN_DIAG_COMPACT_MIN"] = "1"
-    p = subprocess.run([sys.executable, "-c", TIE_CASE % root, task], cwd=root, env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0 and "TIES_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+    p = util.run_child([sys.executable, "-c", TIE_CASE % root, task], cwd=root, env=env, timeout=600)
+    assert "TIES_OK" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
 
 
 BIG_N = r'''
@@ -330,8 +342,8 @@ def test_many_seeds_composite_sort_is_deterministic_and_equals_the_two_sort_path
     res = {}
     for name, env_add, runs in (("composite", {}, "3"), ("two sorts", {"GBN_SEED_CKEYS": "0"}, "1")):
         env = dict(os.environ); env.update(env_add)
-        p = subprocess.run([sys.executable, "-c", BIG_N % root, runs], cwd=root, env=env, capture_output=True, text=True, timeout=900)
-        assert p.returncode == 0 and "BIGN" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
+        p = util.run_child([sys.executable, "-c", BIG_N % root, runs], cwd=root, env=env, timeout=900)
+        assert "BIGN" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
         res[name] = p.stdout.split("BIGN", 1)[1].split()
     assert int(res["composite"][0]) > (1 << 22) and int(res["composite"][1]) > 10000
     assert res["composite"] == res["two sorts"]

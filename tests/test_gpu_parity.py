@@ -258,6 +258,7 @@ def test_option_sweep(task, kw):
         assert nh >= 1
 
 
+@pytest.mark.spawns
 def test_reused_binning_gives_identical_results(monkeypatch):
     # opt-in database-side index: the scan records of a shard serve several query batches
     import subprocess, sys, os, json
@@ -281,14 +282,14 @@ print(json.dumps(out))
     res = {}
     for flag in ("0", "1"):
         env = dict(os.environ); env["GBN_REUSE_BINNING"] = flag; env.pop("GBN_SCAN_BINS", None)
-        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
+        p = util.run_child([sys.executable, "-c", code], env=env, timeout=600)
         res[flag] = json.loads(p.stdout.strip().splitlines()[-1])
     assert [r[0] for r in res["0"]] == [r[0] for r in res["1"]]
     # with reuse only the first pass runs the binning kernel
     assert sum(r[1] for r in res["1"][1:]) < 0.6 * sum(r[1] for r in res["0"][1:])
 
 
+@pytest.mark.spawns
 def test_subject_ranges_do_not_change_results():
     # the engine cuts a shard into subject ranges (GBN_RANGE_GIB, position-id width); results must not depend on it
     import subprocess, sys, os, json
@@ -309,13 +310,16 @@ assert h2.tobytes() == h.tobytes()
 print(json.dumps([h.tobytes().hex(), launches, hits]))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = {}
-    for tag, env_add in (("one", {}), ("many", {"GBN_RANGE_MIB": "1"}), ("tiles", {"GBN_RANGE_TILES": "3"})):
+    # (the last two: every launch of the seed stage through seed_ext_kernel + diag_replay_kernel, see
+    # test_parity_suite_through_the_two_kernel_seed_stage -- that run leaves the tests with child processes to this file)
+    for tag, env_add in (("one", {}), ("many", {"GBN_RANGE_MIB": "1"}), ("tiles", {"GBN_RANGE_TILES": "3"}),
+                         ("one-2k", {"GBN_DIAG_COMPACT_MIN": "1"}), ("tiles-2k", {"GBN_RANGE_TILES": "3", "GBN_DIAG_COMPACT_MIN": "1"})):
         env = dict(os.environ); env.update(env_add)
-        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
-        assert p.returncode == 0, p.stderr[-2000:]
+        p = util.run_child([sys.executable, "-c", code], env=env, timeout=600)
         out[tag] = json.loads(p.stdout.strip().splitlines()[-1])
     assert out["one"][1] == 1 and out["many"][1] > 3 and out["tiles"][1] > 3
     assert out["one"][0] == out["many"][0] and out["one"][2] == out["many"][2]
+    assert out["one"] == out["one-2k"] and out["tiles"] == out["tiles-2k"]
     assert out["one"][0] == out["tiles"][0] and out["one"][2] == out["tiles"][2]
 
 
@@ -468,6 +472,7 @@ def test_skewed_subjects_fill_few_bins(split_mb, monkeypatch):
     assert ps.diagnostics.lookup_hits == s.stats.lookup_hits and len(gpu["hsps"]) >= 50
 
 
+@pytest.mark.spawns
 def test_device_built_lookup_tables_equal_the_host_builder():
     """The lookup structures are built on the device (lutbuild.hip); GBN_HOST_LOOKUP=1 selects the host
     builder they replaced.  Same HSPs, seeds and lookup-hit counts for every table kind: megablast chains
@@ -499,8 +504,7 @@ print(json.dumps(out))
     res = {}
     for flag in ("0", "1"):
         env = dict(os.environ); env["GBN_HOST_LOOKUP"] = flag
-        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
-        assert p.returncode == 0, p.stderr[-2000:]
+        p = util.run_child([sys.executable, "-c", code], env=env, timeout=900)
         res[flag] = json.loads(p.stdout.strip().splitlines()[-1])
     kinds = set()
     for dev, host in zip(res["0"], res["1"]):
