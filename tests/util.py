@@ -68,7 +68,7 @@ def run_child(cmd, env=None, timeout=600, cwd=None):
     for attempt in (0, 1):
         p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=cwd)
         if p.returncode < 0 and "HSA_STATUS_ERROR" in p.stderr and attempt == 0:
-            warnings.warn("child process aborted by the GPU runtime, run once more: " + p.stderr[-600:])
+            warnings.warn("child process aborted by the GPU runtime, run once more; stdout ends %r, stderr ends %r" % (p.stdout[-200:], p.stderr[-600:]))
             continue
         break
     assert p.returncode == 0, (p.returncode, p.stdout[-3000:], p.stderr[-6000:])
