@@ -105,3 +105,36 @@ def test_product_chunks_equal_the_oracle(task):
                 assert int(r[k]) == int(f[k]), k
     finally:
         api.set_max_dbseq_len()
+
+
+@pytest.mark.gpu
+def test_a_subject_longer_than_the_reference_limit_at_full_size():
+    """MAX_DBSEQ_LEN as G-BLASTN builds it (200,000,000): one subject of 230 Mbp is two chunks, the second one
+    starting DBSEQ_CHUNK_OVERLAP bases before the limit.  Alignments inside either chunk, across the boundary and
+    at the very end of the subject equal the oracle's chunked search (the largest single subject the tests hold)."""
+    from gblastn_amd import api
+    from tests import util
+    rng = np.random.default_rng(77)
+    L, n = 200_000_000, 230_000_000
+    queries = [rng.integers(0, 4, 1000).astype(np.uint8) for _ in range(4)]
+    subj = rng.integers(0, 4, n, dtype=np.uint8)
+    subj[5_000_000:5_000_700] = mutate(rng, queries[0][100:800], subs=10, indels=0)
+    subj[L - 300:L + 400] = mutate(rng, queries[1][150:850], subs=12, indels=0)       # across the end of chunk 0
+    subj[L + 20_000_000:L + 20_000_600] = (3 - queries[2][200:800])[::-1]             # minus strand, chunk 1
+    subj[n - 500:n] = queries[3][400:900]                                             # runs to the last base
+    small = rng.integers(0, 4, 50_000, dtype=np.uint8); small[1000:1600] = queries[0][300:900]
+    subjects = [small, subj]
+    api.set_max_dbseq_len()
+    src = api.BlastSeqSrc.from_packed([(orc.pack_ncbi2na(s), len(s)) for s in subjects])
+    opt = api.default_options("megablast", db_length=n + 50_000, db_num_seqs=2)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    got = ps.run()["hsps"]
+    S = orc.Search(util.oracle_options(opt), queries)
+    want = [S.subject_chunked(pad(s), len(s), L) for s in subjects]
+    want_oid = np.concatenate([[i] * len(h) for i, h in enumerate(want)]); want = np.concatenate(want)
+    assert len(want) >= 5 and (want["s_end"][want_oid == 1] > L).any()
+    assert np.array_equal(got["oid"], want_oid)
+    for f in ("context", "q_offset", "q_end", "q_gapped_start", "s_offset", "s_end", "s_gapped_start", "score"):
+        assert np.array_equal(got[f], want[f]), f
+    assert np.array_equal(got["evalue"].view(np.uint64), want["evalue"].view(np.uint64))
+    ps.begin(); assert ps.end()["hsps"].tobytes() == got.tobytes()
