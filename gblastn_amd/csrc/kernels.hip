@@ -402,8 +402,7 @@ __device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict
             }
         }
     }
-    u.q_start = new_q;
-    u.s_start = s_ext - (q_ext - u.q_start);
+    const int32_t uq = new_q, us = s_ext - (q_ext - new_q);
     sum = 0; new_q = q_ext;
     {   // right
         const int32_t n = min(P.qlen - q_ext, slen - s_ext) >> 2;
@@ -427,12 +426,18 @@ __device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict
             }
         }
     }
+    // (the result is put together in values and stored once: with stores to u's fields on both paths the compiler
+    // kept them in private memory -- the only scratch use of the two kernels that extend seeds)
+    Ungapped r;
     if (score >= reduced_cutoff) {
-        ungapped_exact(P, subj, slen, q_off, s_off, X, u);
+        Ungapped e; e.q_start = 0; e.s_start = 0; e.length = 0; e.score = 0;
+        ungapped_exact(P, subj, slen, q_off, s_off, X, e);
+        r = e;
     } else {
-        u.score = score;
-        u.length = max(s_match_end - u.s_start, new_q - u.q_start + 1);
+        r.q_start = uq; r.s_start = us; r.score = score;
+        r.length = max(s_match_end - us, new_q - uq + 1);
     }
+    u.q_start = r.q_start; u.s_start = r.s_start; u.length = r.length; u.score = r.score;
 }
 }  // namespace
 
@@ -449,11 +454,14 @@ __device__ bool seed_masked(const GbnExtParams &P, const uint8_t *__restrict__ s
 
 // s_TypeOfWord (CORE/na_ungapped.c:488-587), one-hit mode: re-check of the mini-extended word against the
 // query masks; may move the left end of the word right and extend its right end.  false: drop the seed.
-__device__ bool type_of_word(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
-                             int32_t &q_off, int32_t &s_off, int32_t &extended)
+__device__ __forceinline__ bool type_of_word(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
+                                             int32_t &q_off_io, int32_t &s_off_io, int32_t &extended_out)
 {
+    // (the offsets live in values of this function's own and are handed back once: taken by reference throughout, the
+    // compiler kept them in private memory, the only scratch use of the two kernels that call this)
     const int32_t word = P.word, lut = P.lut;
-    extended = 0;
+    int32_t q_off = q_off_io, s_off = s_off_io, extended = 0;
+    extended_out = 0;
     if (word == lut) return true;
     int32_t q_end = q_off + word, s_end = s_off + word;
     int lo = 0, hi = P.nctx;
@@ -472,6 +480,7 @@ __device__ bool type_of_word(const GbnExtParams &P, const uint8_t *__restrict__ 
             if (seed_masked(P, subj, s_pos, q_pos)) return false;
         extended = ext_to;
     }
+    q_off_io = q_off; s_off_io = s_off; extended_out = extended;
     return true;
 }
 }  // namespace
