@@ -38,6 +38,7 @@ hipError_t launch_gather_bytes(const uint8_t *src, const int64_t *src_off, const
                                int32_t n, uint8_t *dst, hipStream_t st);
 hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
                           const uint32_t *vin, uint32_t *vout, int64_t n, int end_bit, hipStream_t st);
+hipError_t sort_keys_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, int64_t n, int begin_bit, int end_bit, hipStream_t st);
 
 static thread_local std::string g_err;
 void set_error(const std::string &m) { g_err = m; }
@@ -551,6 +552,9 @@ static int grow_key_buffers(size_t n) {
     if (cap >= compact_min && (rc = dev_alloc(E.ext_rec, cap * 8))) return rc;
     size_t bytes = 0;
     HIPCHK(sort_pairs_u64(nullptr, bytes, E.key_a, E.key_b, E.idx_a, E.idx_b, (int64_t)cap, 64, E.stream));
+    size_t bytes_keys = 0;
+    HIPCHK(sort_keys_u64(nullptr, bytes_keys, E.key_a, E.key_b, (int64_t)cap, 0, 64, E.stream));
+    bytes = std::max(bytes, bytes_keys);
     HIPCHK(pool_alloc(&E.sort_tmp, bytes));
     E.sort_tmp_bytes = bytes; E.key_cap = cap;
     return GBN_OK;
@@ -884,12 +888,18 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         std::stable_sort(tmp.begin(), tmp.end(), [](const GbnSeed &a, const GbnSeed &c) { return a.oid < c.oid; });
         res.seeds.insert(res.seeds.end(), tmp.begin(), tmp.end());
     }
+    // ... and when the value (ext_left and the query key's high bits) fits underneath the key too, it travels in the
+    // key's low bits: a sort of keys only, on the bits above the value (GBN_SEED_CKEYS=2: always pairs)
+    static const bool ck_pack = !(getenv("GBN_SEED_CKEYS") && atoi(getenv("GBN_SEED_CKEYS")) == 2);
+    const int v_bits = 8 + K.qh_bits;
+    const bool packed = composite && ck_pack && ck_bits + v_bits <= 64;
     if (composite) {
-        K.key_scan = E.key_a; K.idx = E.idx_a;
+        K.key_scan = E.key_a; K.idx = E.idx_a; K.v_bits = packed ? v_bits : 0;
         HIPCHK(launch_seed_ckeys(K, st));
         size_t tb = E.sort_tmp_bytes;
-        HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, ck_bits, st));
-        // key_b = sorted composite keys, idx_b = ext_left of the seeds in that order
+        if (packed) HIPCHK(sort_keys_u64(E.sort_tmp, tb, E.key_a, E.key_b, n, v_bits, v_bits + ck_bits, st));
+        else HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, ck_bits, st));
+        // key_b = sorted composite keys, idx_b = ext_left of the seeds in that order (packed: both in key_b)
     } else {
         K.idx = E.idx_b; K.key_group = E.key_a;
         HIPCHK(launch_group_keys(K, st));
@@ -918,7 +928,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = E.ext_rec;
         if (composite) {
             X.idx = E.idx_b; X.run_heads = E.idx_a;
-            X.ck_shift = K.s_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending; X.ck_subj_base = K.subj_base;
+            X.ck_shift = K.s_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending; X.ck_subj_base = K.subj_base; X.ck_vbits = K.v_bits;
         }
         X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
         HIPCHK(launch_diag_ungapped(X, st));

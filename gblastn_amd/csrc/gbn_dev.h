@@ -82,6 +82,7 @@ struct GbnKeyParams {
     int q_bits, group_bits;     // key widths: query offsets < 2^q_bits, slots < 2^group_bits (the sorts stop at the keys' top bit)
     int s_bits, qh_bits;        // composite key (seed_ckeys_kernel): subject offsets < 2^s_bits, qh_bits = max(0, q_bits - group_bits)
     int subj_base;              // ... its subject field counts from the first subject of the launch
+    int v_bits;                 // > 0: key_scan[i] = composite key << v_bits | value (no idx): one sort of keys only
 };
 
 // seeds per launch below which the diagonal kernel runs thread-per-seed instead of on compacted run heads

@@ -294,8 +294,9 @@ extern "C" __global__ void seed_ckeys_kernel(GbnKeyParams K)
     key = (key << K.s_bits) | (uint32_t)sd.s_scan;
     // the high bits of the query key order the (rare) seeds of one (subject, slot, scan position): they travel in
     // the value, and seed_ext_kernel puts such a group into their order -- nine bits less to sort
-    K.key_scan[i] = key;
-    K.idx[i] = (uint32_t)sd.ext_left | ((K.qh_bits ? (qkey >> K.group_bits) : 0u) << 8);
+    const uint32_t val = (uint32_t)sd.ext_left | ((K.qh_bits ? (qkey >> K.group_bits) : 0u) << 8);
+    if (K.v_bits > 0) K.key_scan[i] = (key << K.v_bits) | val;         // key and value in one word: a sort of keys only, on the bits above the value
+    else { K.key_scan[i] = key; K.idx[i] = val; }
 }
 
 extern "C" __global__ void group_keys_kernel(GbnKeyParams K)
@@ -614,22 +615,29 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
     bool head = false, last = false;
     int64_t pos = j;                                    // where this seed's record goes
     if (live) {
-        const uint64_t key = P.key_group[j];
+        const int vb = P.ck_vbits;                          // > 0: the value sits in the key's low bits
+        const uint64_t vmask = (1ull << vb) - 1ull;
+        const uint64_t word64 = P.key_group[j];
+        const uint64_t key = word64 >> vb;
         if (P.ck_shift > 0) {
             // composite keys: the seed is in key and value.  Seeds with one key (same subject, slot and scan position)
             // come out of the sort in no particular order: each finds its place among them by the high bits of its
             // query key and works for the position it lands on.
-            const uint32_t val = P.idx[j];
+            const uint32_t val = vb ? (uint32_t)(word64 & vmask) : P.idx[j];
             const uint32_t qk = val >> 8;
             int64_t a = j, e = j + 1;
-            while (a > 0 && P.key_group[a - 1] == key) a--;
-            while (e < P.n && P.key_group[e] == key) e++;
+            while (a > 0 && (P.key_group[a - 1] >> vb) == key) a--;
+            while (e < P.n && (P.key_group[e] >> vb) == key) e++;
             int64_t rank = 0;
-            for (int64_t m = a; m < e; m++) { if (m == j) continue; const uint32_t qm = P.idx[m] >> 8; rank += (qm < qk || (qm == qk && m < j)) ? 1 : 0; }
+            for (int64_t m = a; m < e; m++) {
+                if (m == j) continue;
+                const uint32_t qm = (vb ? (uint32_t)(P.key_group[m] & vmask) : P.idx[m]) >> 8;
+                rank += (qm < qk || (qm == qk && m < j)) ? 1 : 0;
+            }
             pos = a + rank;
             const uint64_t run = key >> P.ck_shift;
-            head = pos == a && (a == 0 || (P.key_group[a - 1] >> P.ck_shift) != run);
-            last = pos == e - 1 && (e >= P.n || (P.key_group[e] >> P.ck_shift) != run);
+            head = pos == a && (a == 0 || (P.key_group[a - 1] >> (vb + P.ck_shift)) != run);
+            last = pos == e - 1 && (e >= P.n || (P.key_group[e] >> (vb + P.ck_shift)) != run);
             subj_id = (int32_t)(run >> gb) + P.ck_subj_base;
             const uint32_t mask = (gb >= 32) ? 0xffffffffu : ((1u << gb) - 1u);
             const uint32_t slot = (uint32_t)run & mask;
@@ -703,7 +711,7 @@ extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams
     if (t < nruns) {
         const int64_t i = P.run_heads[t];
         const bool ck = P.ck_shift > 0;                          // composite keys: the records carry the run's end, no key is read on the way
-        const uint64_t key = P.key_group[i] >> (ck ? P.ck_shift : 0);    // (run_heads is not in run order: the run ends where the key changes)
+        const uint64_t key = P.key_group[i] >> (ck ? P.ck_shift + P.ck_vbits : 0);    // (run_heads is not in run order: the run ends where the key changes)
         const int32_t subj_id = (int32_t)(key >> (P.group_bits ? P.group_bits : 32)) + (ck ? P.ck_subj_base : 0);
         const GbnSeedExt *__restrict__ rec = reinterpret_cast<const GbnSeedExt *>(P.ext_rec);
         const int word = P.word;
@@ -1793,6 +1801,12 @@ hipError_t launch_synth_fill(void *dev, int64_t nbytes, uint64_t seed, hipStream
     hipLaunchKernelGGL(synth_fill_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st,
                        (uint64_t *)dev, nwords, seed);
     return hipGetLastError();
+}
+
+// stable LSD radix sort of u64 keys on bits [begin_bit, end_bit)
+hipError_t sort_keys_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, int64_t n, int begin_bit, int end_bit, hipStream_t st)
+{
+    return hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, kin, kout, (int)n, begin_bit, end_bit, st);
 }
 
 // stable LSD radix sort of (u64 key, u32 value) pairs

@@ -108,6 +108,9 @@ typedef struct GbnExtParams {
      * Seeds with equal keys may come in any order: the kernel orders them by the value's high bits.  query key = q_pos,
      * or 2^ck_q_bits - 1 - q_pos when ck_q_desc (megablast tables: chains are reported last position first) */
     int32_t ck_shift, ck_s_bits, ck_qh_bits, ck_q_bits, ck_q_desc, ck_subj_base;   /* subj in the key counts from ck_subj_base */
+    /* ck_vbits > 0: the value travels in the key's low ck_vbits bits (key_group[i] = composite key << ck_vbits | value,
+     * sorted on the bits above them: a sort of keys only) and idx is not read */
+    int32_t ck_vbits;
 } GbnExtParams;
 
 typedef struct GbnGapParams {

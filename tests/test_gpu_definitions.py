@@ -334,16 +334,17 @@ print("BIGN", *out[0])
 
 
 def test_many_seeds_composite_sort_is_deterministic_and_equals_the_two_sort_path():
-    """5.6 million seeds in one launch (blastn shape): the composite-key path (one sort, seed_ext_kernel +
-    diag_replay_kernel) gives the same initial hits and HSPs run after run -- a race here once changed 8 % of the
+    """5.6 million seeds in one launch (blastn shape): the composite-key path (one sort -- of keys that carry their value in
+    the low bits, or of (key, value) pairs with GBN_SEED_CKEYS=2 --, seed_ext_kernel + diag_replay_kernel) gives the same
+    initial hits and HSPs run after run -- a race here once changed 8 % of the
     exact ungapped extensions from run to run -- and the same as the two-sort path (GBN_SEED_CKEYS=0)"""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
-    for name, env_add, runs in (("composite", {}, "3"), ("two sorts", {"GBN_SEED_CKEYS": "0"}, "1")):
+    for name, env_add, runs in (("composite", {}, "3"), ("pairs", {"GBN_SEED_CKEYS": "2"}, "1"), ("two sorts", {"GBN_SEED_CKEYS": "0"}, "1")):
         env = dict(os.environ); env.update(env_add)
         p = util.run_child([sys.executable, "-c", BIG_N % root, runs], cwd=root, env=env, timeout=900)
         assert "BIGN" in p.stdout, p.stdout[-1500:] + p.stderr[-3000:]
         res[name] = p.stdout.split("BIGN", 1)[1].split()
     assert int(res["composite"][0]) > (1 << 22) and int(res["composite"][1]) > 10000
-    assert res["composite"] == res["two sorts"]
+    assert res["composite"] == res["two sorts"] and res["pairs"] == res["two sorts"]
