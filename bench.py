@@ -258,7 +258,7 @@ def main():
     probe_ms = sum(d.probe_kernel_ms for d in diags)
     rare_ms = sum(d.rare_kernel_ms for d in diags)
     # dominant kernel: the binning kernel when the partitioned scan is used, else the direct scan
-    dom_name, dom_ms = ("scan_bin_kernel", bin_ms) if bin_ms > 0 else ("scan_seed_kernel", scan_ms)
+    dom_name, dom_ms = ("scan_bin_kernel", bin_ms) if bin_ms > 0 else ("scan_slice_kernel" if info.get("scan_path") == 2 else "scan_seed_kernel", scan_ms)
     # the binning kernel has stride-specialised variants; this is the name rocprof shows
     dom_label = dom_name + ("_s%d" % info["scan_step"] if bin_ms > 0 and info["scan_step"] in (1, 2, 4, 17, 18, 21) else "")
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -317,7 +317,7 @@ def main():
                          "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
                          "avg_launch_ms": dom_ms / max(launches, 1), "launches": launches,
                          "scan_stage": {"kernels": dom_label + " + probe_bin_kernel + probe_rare_kernel"
-                                        if bin_ms > 0 else "scan_seed_kernel",
+                                        if bin_ms > 0 else dom_name,
                                         "avg_ms": scan_ms / max(launches, 1),
                                         "avg_ms_by_kernel": [bin_ms / max(launches, 1), probe_ms / max(launches, 1),
                                                              rare_ms / max(launches, 1)],

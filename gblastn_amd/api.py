@@ -66,7 +66,7 @@ IHIT_DT = np.dtype([("oid", "<i4"), ("q_off", "<i4"), ("s_off", "<i4"), ("q_star
 EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_default_options",
            "gbn_db_new", "gbn_db_free", "gbn_db_total_bases", "gbn_db_num_seqs", "gbn_synth_fill",
            "gbn_batch_new", "gbn_batch_new_ex", "gbn_batch_new_masked", "gbn_dust_mask", "gbn_batch_free", "gbn_batch_num_contexts", "gbn_batch_contexts",
-           "gbn_batch_lut_type", "gbn_batch_lut_width", "gbn_batch_scan_step",
+           "gbn_batch_lut_type", "gbn_batch_lut_width", "gbn_batch_scan_step", "gbn_batch_scan_path",
            "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff", "gbn_results_new",
            "gbn_results_free", "gbn_results_clear", "gbn_results_num_hsps", "gbn_results_hsps",
            "gbn_results_num_seeds", "gbn_results_seeds", "gbn_results_num_init_hits",
@@ -172,7 +172,7 @@ def lib():
         L.gbn_dust_mask.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
         L.gbn_batch_free.argtypes = [C.c_void_p]
         for nm in ["gbn_batch_num_contexts", "gbn_batch_lut_type", "gbn_batch_lut_width",
-                   "gbn_batch_scan_step", "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff"]:
+                   "gbn_batch_scan_step", "gbn_batch_scan_path", "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff"]:
             getattr(L, nm).restype = C.c_int32; getattr(L, nm).argtypes = [C.c_void_p]
         L.gbn_batch_contexts.restype = C.POINTER(GbnContext); L.gbn_batch_contexts.argtypes = [C.c_void_p]
         L.gbn_results_new.argtypes = [C.POINTER(C.c_void_p)]
@@ -369,7 +369,7 @@ class BlastPrelimSearch:
     def info(self):
         L, b = lib(), self._b
         return dict(lut_type=L.gbn_batch_lut_type(b), lut_width=L.gbn_batch_lut_width(b),
-                    scan_step=L.gbn_batch_scan_step(b), container=L.gbn_batch_diag_container(b),
+                    scan_step=L.gbn_batch_scan_step(b), scan_path=L.gbn_batch_scan_path(b), container=L.gbn_batch_diag_container(b),
                     gap_x_dropoff=L.gbn_batch_gap_x_dropoff(b))
 
     @property

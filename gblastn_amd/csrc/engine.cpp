@@ -38,6 +38,10 @@ hipError_t launch_gather_bytes(const uint8_t *src, const int64_t *src_off, const
                                int32_t n, uint8_t *dst, hipStream_t st);
 hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
                           const uint32_t *vin, uint32_t *vout, int64_t n, int end_bit, hipStream_t st);
+int scan_slice_count(const GbnScanParams &p);
+int scan_slice_blocks(const GbnScanParams &p, int num_cu);
+hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
+                             unsigned long long *seg_max, hipStream_t st);
 hipError_t sort_keys_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, int64_t n, int begin_bit, int end_bit, hipStream_t st);
 
 static thread_local std::string g_err;
@@ -93,6 +97,7 @@ struct Engine {
     std::map<const GbnResults *, std::pair<int, std::string>> failed;
     const GbnBatch *pending_batch = nullptr;   // the batch the stage in flight reads (its device memory must outlive the stage)
     unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits, [3] runs; [4], [5]: init hits, runs of an asynchronous seed stage
+    GbnDevSeed *slice_seg = nullptr; size_t slice_seg_cap = 0;        // scan_slice_kernel: the workgroups' seed segments
     GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
     hipEvent_t ev_seed = nullptr; bool pending_uses_keys = false;
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
@@ -647,6 +652,15 @@ static int choose_bins(const GbnBatch &b) {
     return (int)nb;
 }
 
+// slices scan_slice_kernel would cut this batch's presence bits into (0: another kernel scans for this batch)
+static int scan_slices(const GbnBatch &b) {
+    static const bool on = !(getenv("GBN_SCAN_SLICE") && atoi(getenv("GBN_SCAN_SLICE")) == 0);
+    if (!on || !b.dev || choose_bins(b) == 1) return 0;     // (tables of one bin: the direct kernel as before; GBN_SCAN_BINS=1 forces it)
+    GbnScanParams P; std::memset(&P, 0, sizeof(P));
+    P.mode = b.dev->mode; P.step = b.lut.step; P.lut = b.lut.lut; P.word = b.lut.word; P.ncells = b.lut.ncells;
+    return scan_slice_count(P);
+}
+
 // one scan of the subjects [s0, s1): fills E.seeds / cnt[0] seeds, cnt[1] raw hits;
 // dispatches to the direct-probe kernel (small tables) or the partitioned pair
 // the rare kernel of a scan, left for another stream to run (search_range): its parameter block and launch shape
@@ -676,7 +690,10 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
 static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
                          unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed, DeferredRare *defer)
 {
-    const int nb = direct ? 1 : choose_bins(b);
+    // tables as wide as the word (stride 1, every lookup hit a seed): the presence bits are sliced through the LDS
+    // instead of the scan positions being written out by key range (scan_slice_kernel); GBN_SCAN_SLICE=0: off
+    const bool sliced = !direct && scan_slices(b) > 0;
+    const int nb = (direct || sliced) ? 1 : choose_bins(b);
     if (nb == 1) defer = nullptr;                           // the direct-probe kernel has no rare kernel
     if (defer) defer->valid = false;
     const TileSet *tsp = nullptr;
@@ -692,7 +709,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     if (nb > 1)
         for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) npos += (db.len[s] - b.lut.lut) / b.lut.step + 1;
     double slack = 1.25;
-    size_t rare_seg_hint = 0;
+    size_t rare_seg_hint = 0, slice_seg_cap = 0;
     for (;;) {
         HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream));
         GbnScanParams P; fill_scan_params(P, b, db, ts);
@@ -701,7 +718,26 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         if (nb == 1) {
             HIPCHK(hipEventRecord(E.ev0, E.stream));
             if (b.dev->ready) HIPCHK(hipStreamWaitEvent(E.stream, b.dev->ready, 0));
-            HIPCHK(launch_scan_seed(P, scan_grid(ts.ntiles), E.stream));
+            if (sliced) {
+                // every workgroup writes its seeds into a segment of its own (no global counter), a second kernel puts
+                // the segments back to back.  Segments: 1.5 x the seeds a random subject gives, twice as long after an overflow
+                const int blocks = scan_slice_blocks(P, E.num_cu);
+                if (slice_seg_cap == 0) {
+                    int64_t np = 0;
+                    for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) np += db.len[s] - b.lut.lut + 1;
+                    const double expect = (double)np * std::min(1.0, (double)b.qlen / (double)b.lut.ncells) / blocks;
+                    slice_seg_cap = (size_t)(expect * 1.5) + 8192;
+                }
+                if (slice_seg_cap > 0x7fffff00u) { set_error("too many seeds in one range"); return GBN_ERR_NOMEM; }
+                const size_t need = slice_seg_cap * (size_t)blocks;
+                if (need > E.slice_seg_cap) {
+                    dev_free(E.slice_seg); E.slice_seg_cap = 0;
+                    if ((rc = dev_alloc(E.slice_seg, need + need / 8))) return rc;
+                    E.slice_seg_cap = need + need / 8;
+                }
+                if (!E.rare_counts && (rc = dev_alloc(E.rare_counts, (size_t)2048))) return rc;
+                HIPCHK(launch_scan_slice(P, E.num_cu, E.slice_seg, (uint32_t)slice_seg_cap, E.rare_counts, E.counters + 2, E.stream));
+            } else HIPCHK(launch_scan_seed(P, scan_grid(ts.ntiles), E.stream));
             HIPCHK(hipEventRecord(E.ev1, E.stream));
         } else {
             // private output stream per (bin, binning workgroup): no reservation atomics
@@ -769,6 +805,8 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             HIPCHK(hipMemcpyAsync(&overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
         }
         HIPCHK(hipMemcpyAsync(cnt, E.counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, E.stream));
+        unsigned long long seg_max = 0;
+        if (sliced) HIPCHK(hipMemcpyAsync(&seg_max, E.counters + 2, sizeof(seg_max), hipMemcpyDeviceToHost, E.stream));
         trace_mark("scan: kernels queued");
         HIPCHK(hipStreamSynchronize(E.stream));
         trace_mark("scan: kernels done");
@@ -817,6 +855,10 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 rare_seg_hint = (size_t)mx + (mx >> 2);
                 continue;
             }
+        }
+        if (sliced && seg_max > slice_seg_cap) {            // a workgroup's segment was too short: seeds are missing
+            slice_seg_cap = std::max<size_t>(2 * slice_seg_cap, (size_t)seg_max + (size_t)(seg_max >> 2));
+            continue;
         }
         if (overflow) {     // the records are incomplete: once more with twice the room, then give the range to the direct kernel
             slack *= 2;
@@ -1323,6 +1365,7 @@ void Blast_gpu_Release(void) {
     if (!E.ready) return;
     (void)wait_pending();
     g_binkey.valid = false;
+    dev_free(E.slice_seg); E.slice_seg_cap = 0;
     dev_free(E.seeds_async); E.seeds_async_cap = 0; if (E.ev_seed) { (void)hipEventDestroy(E.ev_seed); E.ev_seed = nullptr; }
     dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
     dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.ext_rec); dev_free(E.sort_tmp); for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
@@ -1605,6 +1648,7 @@ int gbn_batch_karlin_gapped(const GbnBatch *b, double *lambda, double *K) {
 int32_t gbn_batch_lut_type(const GbnBatch *b) { return b->lut.type; }
 int32_t gbn_batch_lut_width(const GbnBatch *b) { return b->lut.lut; }
 int32_t gbn_batch_scan_step(const GbnBatch *b) { return b->lut.step; }
+int32_t gbn_batch_scan_path(const GbnBatch *b) { return scan_slices(*b) > 0 ? 2 : (choose_bins(*b) == 1 ? 1 : 0); }
 int32_t gbn_batch_diag_container(const GbnBatch *b) { return b->container; }
 int32_t gbn_batch_gap_x_dropoff(const GbnBatch *b) { return b->gap_x_dropoff; }
 

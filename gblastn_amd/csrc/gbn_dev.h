@@ -85,6 +85,14 @@ struct GbnKeyParams {
     int v_bits;                 // > 0: key_scan[i] = composite key << v_bits | value (no idx): one sort of keys only
 };
 
+// scan_slice_kernel: a slice of the presence bits per workgroup
+#define GBN_SLICE_THREADS   1024
+#define GBN_SLICE_CELL_BITS 20          // cells per slice: 2^20 bits = 128 KB of LDS
+#define GBN_SLICE_WORDS     (1 << (GBN_SLICE_CELL_BITS - 5))
+#define GBN_SLICE_QCAP      128         // per-wave queue of present positions
+#define GBN_SLICE_MAX       16          // most slices (passes over the subjects) it is used with
+#define GBN_SLICE_SEGS      256         // most workgroups (= output segments) of a launch
+
 // seeds per launch below which the diagonal kernel runs thread-per-seed instead of on compacted run heads
 #ifndef GBN_DIAG_COMPACT_MIN
 #define GBN_DIAG_COMPACT_MIN (1 << 20)

@@ -262,6 +262,134 @@ scan_seed_kernel(GbnScanParams P)
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Scan for tables as wide as the word (blastn word sizes 7 .. 12: stride 1, every lookup hit is a seed, a query batch
+// of 100 kb fills 5 % of the 4^11 cells).  The partitioned scan writes a record per scan position and reads it back
+// (6 + 4 bytes per position) to find the one position in a hundred whose word is present; here the presence bits
+// themselves are the LDS resident: the bit array is cut into slices of 2^20 cells (128 KB), a workgroup keeps ONE
+// slice and streams the subjects past it, so the subjects are read once per slice (4 times for lut 11 -- 1 GB per
+// Gbp, mostly from L2 since the workgroups of all slices walk the tiles in step) and nothing is written but seeds.
+// A wave takes a tile of 2048 positions on its own (no barrier in the loop): 32 consecutive positions per lane out of
+// three dwords of subject, one LDS read per position; the present ones wait in a per-wave queue until 64 are
+// together, then a lane each walks its cell's entries.
+// ---------------------------------------------------------------------------------------------------
+extern "C" __global__ void __launch_bounds__(GBN_SLICE_THREADS)
+scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_slice[];
+    uint32_t *s_pv = s_slice;                                           // GBN_SLICE_WORDS presence words
+    uint32_t *s_q = s_slice + GBN_SLICE_WORDS;                          // [waves][3][GBN_SLICE_QCAP]: position, cell, subject
+    __shared__ uint32_t s_used;                                         // seeds this workgroup has put into its segment
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int k = (int)(blockIdx.x % (unsigned)nslices);                // this workgroup's slice
+    const int64_t g = blockIdx.x / (unsigned)nslices, G = gridDim.x / (unsigned)nslices;
+    const uint32_t slice_words = (1u << slice_cell_bits) >> 5;
+    for (uint32_t i = tid; i < slice_words; i += GBN_SLICE_THREADS) s_pv[i] = P.pv[(size_t)k * slice_words + i];
+    if (tid == 0) s_used = 0;
+    __syncthreads();
+    uint32_t *q_pos = s_q + wave * 3 * GBN_SLICE_QCAP, *q_cell = q_pos + GBN_SLICE_QCAP, *q_subj = q_cell + GBN_SLICE_QCAP;
+    GbnDevSeed *__restrict__ myseg = seg + (size_t)blockIdx.x * seg_cap;
+    int qn = 0;                                                         // wave-uniform
+    unsigned long long raw = 0;
+    const unsigned long long lt = (1ull << lane) - 1;
+    const int top = 64 - 2 * P.lut;
+    const uint32_t in_mask = (1u << slice_cell_bits) - 1u;
+
+    // `cnt` queued lookup hits, a lane each: the cell's entries become seeds in the workgroup's own segment of the
+    // output (one LDS atomic per wave; a global counter took 6 of 9 ms: 700,000 atomics on one address per launch)
+    auto flush = [&](int first, int cnt) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");          // queue slots written by other lanes of this wave
+        uint32_t start = 0, n = 0; int32_t s = 0, subj = 0;
+        if (lane < cnt) {
+            s = (int32_t)q_pos[first + lane]; subj = (int32_t)q_subj[first + lane];
+            const uint32_t cell = q_cell[first + lane];
+            start = P.cell_start[cell]; n = P.cell_start[cell + 1] - start;
+        }
+        raw += n;
+        uint32_t incl = n;                                              // inclusive prefix sum over the lanes
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); incl += (lane >= d) ? v : 0u; }
+        const uint32_t total = __shfl(incl, 63);
+        uint32_t base = 0;
+        if (lane == 0 && total) base = atomicAdd(&s_used, total);
+        base = __shfl(base, 0) + (incl - n);
+        for (uint32_t e = 0; e < n; e++) {
+            if (base + e < seg_cap) {
+                GbnDevSeed sd; sd.subj = subj; sd.s_scan = s; sd.q_pos = (int32_t)(uint32_t)(P.ent[start + e] & 0xffffffffull); sd.ext_left = 0;
+                myseg[base + e] = sd;
+            }
+        }
+    };
+
+    for (int64_t t = g * (GBN_SLICE_THREADS / 64) + wave; t < P.ntiles; t += G * (GBN_SLICE_THREADS / 64)) {
+        const GbnTile T = P.tiles[t];
+        const uint8_t *__restrict__ subj = P.db + P.byte_off[T.subj];
+        const int32_t nl = min(32, T.npos - 32 * lane);                 // positions of this lane (<= 0: none)
+        const int32_t p0 = T.first_pos + (nl > 0 ? 32 * lane : 0);      // always a readable address
+        const uint64_t hi0 = bases32(subj, p0);
+        const uint32_t lo0 = window16(subj, (int64_t)p0 + 32);
+        // the lane's 32 presence tests, independent of each other (the LDS reads go out back to back) ...
+        uint32_t hm = 0;
+        {
+            uint64_t hi = hi0; uint32_t lo = lo0;
+            #pragma unroll
+            for (int i = 0; i < 32; i++) {
+                const uint32_t cell = (uint32_t)(hi >> top);
+                const uint32_t w = s_pv[(cell & in_mask) >> 5];
+                const uint32_t hit = ((int)(cell >> slice_cell_bits) == k) ? ((w >> (cell & 31u)) & 1u) : 0u;
+                hm |= hit << i;
+                hi = (hi << 2) | (lo >> 30); lo <<= 2;
+            }
+            hm &= (nl >= 32) ? 0xffffffffu : ((nl > 0) ? ((1u << nl) - 1u) : 0u);
+        }
+        // ... then the present ones join the wave's queue, a round per position a lane still holds (two or three)
+        while (true) {
+            const unsigned long long m = __ballot(hm != 0);
+            if (!m) break;
+            if (hm) {
+                const int i = __ffs(hm) - 1;
+                hm &= hm - 1;
+                const uint64_t x = i ? ((hi0 << (2 * i)) | (((uint64_t)lo0 << 32) >> (64 - 2 * i))) : hi0;
+                const int at = qn + __popcll(m & lt);
+                q_pos[at] = (uint32_t)(p0 + i); q_cell[at] = (uint32_t)(x >> top); q_subj[at] = (uint32_t)T.subj;
+            }
+            qn += __popcll(m);
+            if (qn >= 64) { qn -= 64; flush(qn, 64); }
+        }
+    }
+    if (qn > 0) flush(0, qn);
+    if (P.raw_hits) {
+        for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
+        if (lane == 0 && raw) atomicAdd(P.raw_hits, raw);
+    }
+    __syncthreads();
+    if (tid == 0) seg_count[blockIdx.x] = s_used;
+}
+
+// the segments of scan_slice_kernel, back to back: seeds[0 .. sum of counts); *seed_count = that sum, *seg_max = the
+// fullest segment's count (above seg_cap: seeds were dropped, the caller scans again with longer segments)
+extern "C" __global__ void __launch_bounds__(256)
+seed_compact_kernel(const GbnDevSeed *__restrict__ seg, const uint32_t *__restrict__ seg_count, int nseg, uint32_t seg_cap,
+                    GbnDevSeed *__restrict__ out, unsigned long long out_cap, unsigned long long *seed_count, unsigned long long *seg_max)
+{
+    __shared__ unsigned long long s_at[GBN_SLICE_SEGS + 1];
+    __shared__ uint32_t s_have[GBN_SLICE_SEGS];
+    const int sg = blockIdx.x % nseg, part = blockIdx.x / nseg, nparts = gridDim.x / nseg;
+    if (threadIdx.x == 0) {
+        unsigned long long at = 0, tot = 0; uint32_t mx = 0;
+        for (int i = 0; i < nseg; i++) { const uint32_t c = seg_count[i]; s_at[i] = at; s_have[i] = min(c, seg_cap); at += s_have[i]; tot += c; mx = max(mx, c); }
+        s_at[nseg] = at;
+        if (blockIdx.x == 0) { *seed_count = (mx > seg_cap) ? tot : at; *seg_max = mx; }
+    }
+    __syncthreads();
+    const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(seg + (size_t)sg * seg_cap);
+    uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(out);
+    const unsigned long long at = s_at[sg];
+    for (uint32_t i = (uint32_t)part * 256u + threadIdx.x; i < s_have[sg]; i += (uint32_t)nparts * 256u)
+        if (at + i < out_cap) dst[at + i] = src[i];
+}
+
 // ---------------------------------------------------------------------------
 // seed keys for the two stable radix sorts done by the host with hipCUB
 // ---------------------------------------------------------------------------
@@ -1690,6 +1818,48 @@ hipError_t launch_scan_seed(const GbnScanParams &p, int grid, hipStream_t st)
 {
     if (p.ntiles <= 0) return hipSuccess;
     hipLaunchKernelGGL(scan_seed_kernel, dim3(grid), dim3(GBN_SCAN_THREADS), 0, st, p);
+    return hipGetLastError();
+}
+
+// slices of the presence bits scan_slice_kernel needs for this table (0: not a table it takes)
+int scan_slice_count(const GbnScanParams &p)
+{
+    if (p.mode != GBN_EXT_DIRECT || p.step != 1 || p.lut != p.word || p.lut < 3 || p.ncells < 32) return 0;
+    const int cell_bits = std::min(2 * p.lut, GBN_SLICE_CELL_BITS);
+    const int64_t n = p.ncells >> cell_bits;
+    return (n >= 1 && n <= GBN_SLICE_MAX) ? (int)n : 0;
+}
+
+// workgroups scan_slice_kernel is launched with for this table on a chip of num_cu CUs (= segments of its output)
+int scan_slice_blocks(const GbnScanParams &p, int num_cu)
+{
+    const int nslices = scan_slice_count(p);
+    if (nslices <= 0) return 0;
+    // one workgroup per CU (its slice fills the LDS); every slice gets the same number of workgroups
+    const int64_t waves_needed = (p.ntiles + (GBN_SLICE_THREADS / 64) - 1) / (GBN_SLICE_THREADS / 64);
+    const int per_slice = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, std::min(num_cu, GBN_SLICE_SEGS) / nslices), waves_needed));
+    return per_slice * nslices;
+}
+
+// seg: scan_slice_blocks() segments of seg_cap seeds each (scratch), seg_count: as many counters; p.seeds / p.seed_count
+// receive the seeds back to back and their number, *seg_max the fullest segment's count (see seed_compact_kernel)
+hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
+                             unsigned long long *seg_max, hipStream_t st)
+{
+    if (p.ntiles <= 0) return hipSuccess;
+    const int nslices = scan_slice_count(p), blocks = scan_slice_blocks(p, num_cu);
+    if (nslices <= 0 || blocks <= 0) return hipErrorInvalidValue;
+    const int cell_bits = std::min(2 * p.lut, GBN_SLICE_CELL_BITS);
+    const size_t lds = ((size_t)GBN_SLICE_WORDS + (size_t)(GBN_SLICE_THREADS / 64) * 3 * GBN_SLICE_QCAP) * 4;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void *)scan_slice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(scan_slice_kernel, dim3((unsigned)blocks), dim3(GBN_SLICE_THREADS), lds, st, p, nslices, cell_bits, seg, seg_cap, seg_count);
+    hipLaunchKernelGGL(seed_compact_kernel, dim3((unsigned)(blocks * 8)), dim3(256), 0, st, seg, seg_count, blocks, seg_cap,
+                       p.seeds, p.seed_cap, p.seed_count, seg_max);
     return hipGetLastError();
 }
 

@@ -237,6 +237,7 @@ int  gbn_batch_karlin_gapped(const GbnBatch *b, double *lambda, double *K);
 int32_t gbn_batch_lut_type(const GbnBatch *b);
 int32_t gbn_batch_lut_width(const GbnBatch *b);
 int32_t gbn_batch_scan_step(const GbnBatch *b);
+int32_t gbn_batch_scan_path(const GbnBatch *b);         /* which kernels scan for this batch: 0 scan_bin + probe_bin + probe_rare (key-range partitioned), 1 scan_seed (direct probing), 2 scan_slice (presence bits sliced through the LDS) */
 int32_t gbn_batch_diag_container(const GbnBatch *b);    /* 0 array, 1 hash */
 int32_t gbn_batch_gap_x_dropoff(const GbnBatch *b);
 

@@ -1,4 +1,5 @@
 """-m gpu: the HIP path, called through the C ABI, against the CPU oracle."""
+import os
 import numpy as np
 import pytest
 from gblastn_amd import api, synth
@@ -554,3 +555,40 @@ def test_randomised_shapes_against_the_oracle(seed, monkeypatch):
         ps.begin()
         assert np.array_equal(ps.end()["hsps"], got["hsps"]), (task, kw, ps.info())
         monkeypatch.delenv("GBN_RANGE_TILES")
+
+
+def test_slice_scan_with_repeats_that_overflow_a_segment():
+    """blastn W=11 with a table as wide as the word: scan_slice_kernel (the presence bits sliced through the LDS, every
+    workgroup writing seeds into a segment of its own sized for random subjects).  A subject that is mostly one
+    short-period repeat which the queries carry too gives a hundred times the seeds a random subject would: the
+    segments overflow, the engine scans again with longer ones.  Stage by stage against the oracle; a second search
+    over random subjects only takes the short segments again."""
+    from oracle import orc
+    rng = np.random.default_rng(2024)
+    unit = rng.integers(0, 4, 7, dtype=np.uint8)
+    queries = [rng.integers(0, 4, 1000, dtype=np.uint8) for _ in range(12)]
+    for qi in (0, 3, 7):
+        queries[qi][200:500] = np.tile(unit, 50)[:300]
+    rep = rng.integers(0, 4, 60_000, dtype=np.uint8)
+    rep[5_000:45_000] = np.tile(unit, 6000)[:40_000]                     # 40 kb of the repeat
+    rep[50_000:50_600] = queries[5][100:700]
+    plain = [rng.integers(0, 4, 40_000, dtype=np.uint8) for _ in range(3)]
+    plain[1][1000:1700] = queries[9][200:900]
+    subs = [plain[0], rep, plain[1], plain[2]]
+    subjects = [(orc.pack_ncbi2na(s), len(s)) for s in subs]
+    opt = api.default_options("blastn", db_length=sum(len(s) for s in subs), db_num_seqs=len(subs))
+    ps = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed(subjects))
+    info = ps.info()
+    sliced = os.environ.get("GBN_SCAN_BINS") != "1"                    # (the fixture's other leg: the direct-probe kernel)
+    assert (info["lut_width"], info["scan_step"], info["scan_path"]) == (11, 1, 2 if sliced else 1), info
+    gpu = ps.run(keep_stages=True)
+    ora, s = util.oracle_run(opt, queries, subjects)
+    util.compare_stages(gpu, ora)
+    assert len(gpu["seeds"]) > 1_000_000 and ps.diagnostics.lookup_hits == s.stats.lookup_hits
+    assert ps.diagnostics.scan_launches >= (2 if sliced else 1)         # the repeat made the engine scan twice
+    ps.begin(); assert ps.end()["hsps"].tobytes() == gpu["hsps"].tobytes()
+    ps2 = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed([subjects[0], subjects[2], subjects[3]]))
+    gpu2 = ps2.run(keep_stages=True)
+    ora2, s2 = util.oracle_run(opt, queries, [subjects[0], subjects[2], subjects[3]])
+    util.compare_stages(gpu2, ora2)
+    assert ps2.diagnostics.scan_launches == 1
