@@ -93,6 +93,9 @@ struct Engine {
     int slot = 0; hipStream_t stream2 = nullptr;
     hipStream_t stream_build = nullptr;      // lookup structures of the next query batch are built next to a running search
     std::future<int> pending; bool has_pending = false; std::string pending_err; const GbnResults *pending_res = nullptr;
+    // host replays of finished gapped stages, one after the other in the order they were queued (each waits for its
+    // predecessor): the stage's thread hands its copies over and is free for the next range's kernels
+    std::shared_future<void> host_tail; std::mutex host_mu, failed_mu;
     // stages that failed, by the results they were filling: reported by gbn_prelim_search_end for THOSE results
     std::map<const GbnResults *, std::pair<int, std::string>> failed;
     const GbnBatch *pending_batch = nullptr;   // the batch the stage in flight reads (its device memory must outlive the stage)
@@ -581,14 +584,31 @@ static int grow_ihit_buffers(int slot, size_t n) {
 // wait for the extension stage that is still in flight (if any).  Its failure belongs to the results it was
 // filling, not to whoever happens to wait for it: it is kept in E.failed and returned by
 // gbn_prelim_search_end(those results) (take_failure).
-static int wait_pending() {
+static void record_failure(const GbnResults *res, int rc, const std::string &what) {
+    std::lock_guard<std::mutex> lk(E.failed_mu);
+    if (!E.failed.count(res)) E.failed[res] = std::make_pair(rc, what);
+}
+// the device side of the stage in flight: its kernels and copies are done, its device buffers free again (the host
+// replay of its extensions may still be running: wait_host)
+static int wait_pending_gpu() {
     if (!E.has_pending) return GBN_OK;
     int rc = E.pending.get();
-    if (rc) E.failed[E.pending_res] = std::make_pair(rc, E.pending_err);
+    if (rc) record_failure(E.pending_res, rc, E.pending_err);
     E.has_pending = false; E.pending_uses_keys = false; E.pending_batch = nullptr;
     return GBN_OK;
 }
+static void wait_host() {
+    std::shared_future<void> f;
+    { std::lock_guard<std::mutex> lk(E.host_mu); f = E.host_tail; }
+    if (f.valid()) f.wait();
+}
+static int wait_pending() {
+    const int rc = wait_pending_gpu();
+    wait_host();
+    return rc;
+}
 static int take_failure(const GbnResults *res) {
+    std::lock_guard<std::mutex> lk(E.failed_mu);
     auto it = E.failed.find(res);
     if (it == E.failed.end()) return GBN_OK;
     const int rc = it->second.first;
@@ -874,7 +894,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
 
 // one range of subjects [s0, s1) through the whole pipeline
 static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag,
-                        int keep_stages, int slot, unsigned long long nih, hipStream_t st);
+                        int keep_stages, int slot, unsigned long long nih, hipStream_t st, bool detach_host = false);
 
 // seeds of a range -> scan order (two stable sorts) -> diagonal filter + ungapped extension on stream `st`;
 // the initial hits are left in the slot's buffers.  ctr: [0] initial hits, [1] runs (device counters).
@@ -1027,7 +1047,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     t_stage = now();
     if (defer.valid) {
         if (diag) diag->subject_bases_scanned += bases;
-        if ((rc = wait_pending())) return rc;               // one asynchronous stage in flight at most; its buffer set is free again
+        if ((rc = wait_pending_gpu())) return rc;           // one asynchronous stage in flight at most; its buffer set is free again
         if (E.seeds_async_cap < ((size_t)1 << 22)) {
             dev_free(E.seeds_async); E.seeds_async_cap = 0;
             if ((rc = dev_alloc(E.seeds_async, (size_t)1 << 22))) return rc;
@@ -1069,7 +1089,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
             if (n2 > INT32_MAX) return fail(GBN_ERR_NOMEM, "too many seeds in one range");
             unsigned long long nih2 = 0;
             int r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n2, E.counters + 4, E.stream2, &nih2, s0, s1);
-            if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2);
+            if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2, true);
             if (r) E.pending_err = gbn_last_error();      // the error text is per thread
             return r;
         });
@@ -1087,7 +1107,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     // on the engine's stream (it is as long as the scan) and only the gapped stage is asynchronous.
     const bool async_seed = overlap && !keep_stages && n < ((int64_t)1 << 20);
     if (async_seed) {
-        if ((rc = wait_pending())) return rc;               // one asynchronous stage in flight at most
+        if ((rc = wait_pending_gpu())) return rc;           // one asynchronous stage in flight at most
         if ((size_t)n > E.seeds_async_cap) {
             dev_free(E.seeds_async); E.seeds_async_cap = 0;
             if ((rc = dev_alloc(E.seeds_async, std::max<size_t>((size_t)n + (size_t)n / 4, 1 << 16)))) return rc;
@@ -1105,28 +1125,28 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
             if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the extension thread"; return GBN_ERR_HIP; }
             if (hipStreamWaitEvent(E.stream2, E.ev_seed, 0) != hipSuccess) { E.pending_err = "hipStreamWaitEvent failed"; return GBN_ERR_HIP; }
             r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n, E.counters + 4, E.stream2, &nih2, s0, s1);
-            if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2);
+            if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2, true);
             if (r) E.pending_err = gbn_last_error();      // the error text is per thread
             return r;
         });
         E.has_pending = true; E.pending_res = rp; E.pending_uses_keys = true; E.pending_batch = bp;
         return GBN_OK;
     }
-    if (E.pending_uses_keys && (rc = wait_pending())) return rc;     // the sort buffers exist once
+    if (E.pending_uses_keys && (rc = wait_pending_gpu())) return rc; // the sort buffers exist once
     unsigned long long nih = 0;
     if ((rc = seed_stage(b, db, res, diag, keep_stages, slot, E.seeds, n, E.counters + 2, E.stream, &nih, s0, s1))) return rc;
     trace_mark("seed stage done (inline)");
     if (nih == 0) return GBN_OK;
-    if ((rc = wait_pending())) return rc;                   // one gapped stage in flight at most
+    if ((rc = wait_pending_gpu())) return rc;               // one gapped stage in flight at most
     trace_mark("previous asynchronous stage finished");
-    if (!overlap || keep_stages) return gapped_stage(b, db, s0, s1, res, diag, keep_stages, slot, nih, E.stream);
+    if (!overlap || keep_stages) { wait_host(); return gapped_stage(b, db, s0, s1, res, diag, keep_stages, slot, nih, E.stream); }
     E.slot ^= 1;
     E.pending_err.clear();
     const int dev = E.device;
     GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
     E.pending = std::async(std::launch::async, [=]() -> int {
         if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the gapped-stage thread"; return GBN_ERR_HIP; }
-        const int r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih, E.stream2);
+        const int r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih, E.stream2, true);
         if (r) E.pending_err = gbn_last_error();      // the error text is per thread
         return r;
     });
@@ -1136,8 +1156,11 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
 
 // gapped extension of every initial hit of a range (slot buffers), D2H, host replay of the acceptance
 // rules per subject.  Touches only the slot's buffers, the results and the gapped fields of `diag`.
+static int gapped_host(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag, int keep_stages,
+                       const std::vector<GbnDevInitHit> &hih, const std::vector<GbnDevGapped> &hg);
+
 static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag,
-                        int keep_stages, int slot, unsigned long long nih, hipStream_t st)
+                        int keep_stages, int slot, unsigned long long nih, hipStream_t st, bool detach_host)
 {
     const DeviceBatch *d = b.dev;
     int rc;
@@ -1188,7 +1211,36 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     HIPCHK(hipStreamSynchronize(st));
     trace_mark("gapped: kernels + copies done");
     if (diag) diag->gapped_stage_ms += ms_since(t_stage);
-    t_stage = now();
+    static const bool detach_on = !(getenv("GBN_HOST_DETACH") && atoi(getenv("GBN_HOST_DETACH")) == 0);
+    // (a few thousand extensions -- megablast shapes -- are replayed in less time than handing them over takes)
+    if (!detach_host || !detach_on || nih < 20000) { if (detach_host) wait_host(); return gapped_host(b, db, s0, s1, res, diag, keep_stages, hih, hg); }
+    // the replay of this range's extensions joins the queue of host replays (in range order: the lists are appended to
+    // the results); this thread, the slot's device buffers and the second stream are free for the next range
+    {
+        auto ih = std::make_shared<std::vector<GbnDevInitHit>>(std::move(hih));
+        auto gg = std::make_shared<std::vector<GbnDevGapped>>(std::move(hg));
+        GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
+        std::lock_guard<std::mutex> lk(E.host_mu);
+        std::shared_future<void> prev = E.host_tail;
+        E.host_tail = std::async(std::launch::async, [=]() {
+            if (prev.valid()) prev.wait();
+            const int r = gapped_host(*bp, *dbp, s0, s1, *rp, diag, 0, *ih, *gg);
+            if (r) record_failure(rp, r, gbn_last_error());
+        }).share();
+    }
+    return GBN_OK;
+}
+
+// the acceptance rules of BLAST_GetGappedScore replayed per subject over the extensions of a range, the HSP lists
+// appended to the results (ascending oid)
+static int gapped_host(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag, int keep_stages,
+                       const std::vector<GbnDevInitHit> &hih, const std::vector<GbnDevGapped> &hg)
+{
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms_since = [&](std::chrono::steady_clock::time_point t) {
+        return std::chrono::duration<double, std::milli>(now() - t).count(); };
+    auto t_stage = now();
+    const size_t nih = hih.size();
 
     // ---- host replay per subject, ascending oid ----
     // group the hits by subject (counting sort; the order inside a subject does not matter,
@@ -1514,6 +1566,7 @@ void gbn_db_free(GbnDb *db) {
     {   // a stage in flight may still read this shard
         std::lock_guard<std::mutex> lk(E.mu);
         if (E.has_pending) (void)wait_pending();
+        wait_host();
     }
     if (g_binkey.db == (const void *)db) g_binkey.valid = false;
     free_tile_cache(*db);
@@ -1635,6 +1688,7 @@ void gbn_batch_free(GbnBatch *b) {
     {   // an extension stage still reading this batch finishes first (its memory goes back to the pool, not to hipFree)
         std::lock_guard<std::mutex> lk(E.mu);
         if (E.has_pending && E.pending_batch == b) (void)wait_pending();
+        wait_host();                                        // (a queued host replay reads the batch's options and contexts)
     }
     free_device_batch(b->dev); delete b;
 }
@@ -1658,7 +1712,8 @@ void gbn_results_free(GbnResults *r) {
     {
         std::lock_guard<std::mutex> lk(E.mu);
         if (E.has_pending && E.pending_res == r) (void)wait_pending();
-        E.failed.erase(r);
+        wait_host();
+        { std::lock_guard<std::mutex> lk2(E.failed_mu); E.failed.erase(r); }
     }
     delete r;
 }
@@ -1771,7 +1826,7 @@ int gbn_prelim_search_end(GbnResults *results) {
     // a stage that belongs to other results stays in flight: these results were completed when that
     // stage was queued (one in flight at most)
     int rc;
-    if (results && E.has_pending && E.pending_res != results) rc = take_failure(results);
+    if (results && E.has_pending && E.pending_res != results) { wait_host(); rc = take_failure(results); }    // (its last host replay may still run)
     else { (void)wait_pending(); rc = results ? take_failure(results) : GBN_OK; }
     if (!rc && results && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len); results->chunk_len = 0; }
     return rc;
