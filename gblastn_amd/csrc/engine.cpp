@@ -42,6 +42,8 @@ int scan_slice_count(const GbnScanParams &p);
 int scan_slice_blocks(const GbnScanParams &p, int num_cu);
 hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
                              unsigned long long *seg_max, hipStream_t st);
+hipError_t launch_seed_compact(const GbnDevSeed *seg, const uint32_t *seg_count, int nseg, uint32_t seg_cap, GbnDevSeed *out,
+                               unsigned long long out_cap, hipStream_t st);
 hipError_t sort_keys_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, int64_t n, int begin_bit, int end_bit, hipStream_t st);
 
 static thread_local std::string g_err;
@@ -101,6 +103,7 @@ struct Engine {
     const GbnBatch *pending_batch = nullptr;   // the batch the stage in flight reads (its device memory must outlive the stage)
     unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits, [3] runs; [4], [5]: init hits, runs of an asynchronous seed stage
     GbnDevSeed *slice_seg = nullptr; size_t slice_seg_cap = 0;        // scan_slice_kernel: the workgroups' seed segments
+    bool seg_valid = false; int seg_n = 0; uint32_t seg_len = 0;       // the last scan left its seeds there (seg_n segments of seg_len slots, counts in rare_counts), not in `seeds`
     GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
     hipEvent_t ev_seed = nullptr; bool pending_uses_keys = false;
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
@@ -713,6 +716,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     // tables as wide as the word (stride 1, every lookup hit a seed): the presence bits are sliced through the LDS
     // instead of the scan positions being written out by key range (scan_slice_kernel); GBN_SCAN_SLICE=0: off
     const bool sliced = !direct && scan_slices(b) > 0;
+    E.seg_valid = false;
     const int nb = (direct || sliced) ? 1 : choose_bins(b);
     if (nb == 1) defer = nullptr;                           // the direct-probe kernel has no rare kernel
     if (defer) defer->valid = false;
@@ -729,7 +733,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     if (nb > 1)
         for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) npos += (db.len[s] - b.lut.lut) / b.lut.step + 1;
     double slack = 1.25;
-    size_t rare_seg_hint = 0, slice_seg_cap = 0;
+    size_t rare_seg_hint = 0, slice_seg_cap = 0; int slice_blocks = 0;
     for (;;) {
         HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream));
         GbnScanParams P; fill_scan_params(P, b, db, ts);
@@ -742,6 +746,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 // every workgroup writes its seeds into a segment of its own (no global counter), a second kernel puts
                 // the segments back to back.  Segments: 1.5 x the seeds a random subject gives, twice as long after an overflow
                 const int blocks = scan_slice_blocks(P, E.num_cu);
+                slice_blocks = blocks;
                 if (slice_seg_cap == 0) {
                     int64_t np = 0;
                     for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) np += db.len[s] - b.lut.lut + 1;
@@ -886,6 +891,11 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             continue;
         }
         if (defer) { defer->valid = true; break; }          // (the seeds do not exist yet: whoever runs the rare kernel sizes their buffer)
+        if (sliced) {       // the seeds sit in the workgroups' segments; E.seeds only has to be long enough for compact_seeds
+            if (cnt[0] > E.seed_cap && (rc = grow_seed_buffers((size_t)cnt[0] + (cnt[0] >> 3)))) return rc;
+            E.seg_valid = cnt[0] > 0; E.seg_n = slice_blocks; E.seg_len = (uint32_t)slice_seg_cap;
+            break;
+        }
         if (cnt[0] <= E.seed_cap) break;
         if ((rc = grow_seed_buffers((size_t)cnt[0] + (cnt[0] >> 3)))) return rc;
     }
@@ -895,6 +905,14 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
 // one range of subjects [s0, s1) through the whole pipeline
 static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag,
                         int keep_stages, int slot, unsigned long long nih, hipStream_t st, bool detach_host = false);
+
+// the seeds of the last scan in one array (E.seeds), for the consumers that do not read scan_slice_kernel's segments
+static int compact_seeds(hipStream_t st) {
+    if (!E.seg_valid) return GBN_OK;
+    HIPCHK(launch_seed_compact(E.slice_seg, E.rare_counts, E.seg_n, E.seg_len, E.seeds, E.seed_cap, st));
+    E.seg_valid = false;
+    return GBN_OK;
+}
 
 // seeds of a range -> scan order (two stable sorts) -> diagonal filter + ungapped extension on stream `st`;
 // the initial hits are left in the slot's buffers.  ctr: [0] initial hits, [1] runs (device counters).
@@ -930,6 +948,9 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     K.subj_base = s0;
     const int ck_bits = K.group_bits + bits_for((uint64_t)(s1 - s0) + 1) + K.s_bits;        // (the query key's high bits travel in the value)
     const bool composite = ck_on && E.ext_rec && n >= compact_min && ck_bits <= 64 && K.group_bits < 32 && K.qh_bits <= 24 && b.lut.word - b.lut.lut < 256;
+    const bool segmented = seeds == E.seeds && E.seg_valid;           // (an asynchronous stage works on a copy of its own)
+    const bool from_segments = segmented && composite && !keep_stages;  // seed_ckeys_kernel reads the segments as they are
+    if (segmented && !from_segments && (rc = compact_seeds(st))) return rc;
     if (!composite || keep_stages) {
         HIPCHK(launch_seed_keys(K, st));
         size_t tb = E.sort_tmp_bytes;
@@ -957,6 +978,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     const bool packed = composite && ck_pack && ck_bits + v_bits <= 64;
     if (composite) {
         K.key_scan = E.key_a; K.idx = E.idx_a; K.v_bits = packed ? v_bits : 0;
+        if (from_segments) { K.seg = E.slice_seg; K.seg_count = E.rare_counts; K.nseg = E.seg_n; K.seg_cap = E.seg_len; }
         HIPCHK(launch_seed_ckeys(K, st));
         size_t tb = E.sort_tmp_bytes;
         if (packed) HIPCHK(sort_keys_u64(E.sort_tmp, tb, E.key_a, E.key_b, n, v_bits, v_bits + ck_bits, st));
@@ -1113,6 +1135,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
             if ((rc = dev_alloc(E.seeds_async, std::max<size_t>((size_t)n + (size_t)n / 4, 1 << 16)))) return rc;
             E.seeds_async_cap = std::max<size_t>((size_t)n + (size_t)n / 4, 1 << 16);
         }
+        if ((rc = compact_seeds(E.stream))) return rc;
         HIPCHK(hipMemcpyAsync(E.seeds_async, E.seeds, (size_t)n * sizeof(GbnDevSeed), hipMemcpyDeviceToDevice, E.stream));
         HIPCHK(hipEventRecord(E.ev_seed, E.stream));
         E.slot ^= 1;

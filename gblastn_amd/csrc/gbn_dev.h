@@ -83,6 +83,9 @@ struct GbnKeyParams {
     int s_bits, qh_bits;        // composite key (seed_ckeys_kernel): subject offsets < 2^s_bits, qh_bits = max(0, q_bits - group_bits)
     int subj_base;              // ... its subject field counts from the first subject of the launch
     int v_bits;                 // > 0: key_scan[i] = composite key << v_bits | value (no idx): one sort of keys only
+    // nseg > 0 (seed_ckeys_kernel): the seeds are not in `seeds` but in nseg segments of seg_cap slots, seg_count[s] of
+    // them in segment s (scan_slice_kernel's output as it is); seed i = the i-th of the segments read one after the other
+    const GbnDevSeed *seg; const uint32_t *seg_count; int nseg; uint32_t seg_cap;
 };
 
 // scan_slice_kernel: a slice of the presence bits per workgroup

@@ -274,7 +274,8 @@ scan_seed_kernel(GbnScanParams P)
 // together, then a lane each walks its cell's entries.
 // ---------------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(GBN_SLICE_THREADS)
-scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count)
+scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
+                  unsigned long long *seg_max)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_slice[];
     uint32_t *s_pv = s_slice;                                           // GBN_SLICE_WORDS presence words
@@ -364,23 +365,25 @@ scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed 
         if (lane == 0 && raw) atomicAdd(P.raw_hits, raw);
     }
     __syncthreads();
-    if (tid == 0) seg_count[blockIdx.x] = s_used;
+    if (tid == 0) {
+        seg_count[blockIdx.x] = s_used;
+        if (s_used) { atomicAdd(P.seed_count, (unsigned long long)s_used); atomicMax(seg_max, (unsigned long long)s_used); }
+    }
 }
 
-// the segments of scan_slice_kernel, back to back: seeds[0 .. sum of counts); *seed_count = that sum, *seg_max = the
-// fullest segment's count (above seg_cap: seeds were dropped, the caller scans again with longer segments)
+// the segments of scan_slice_kernel, back to back: seeds[0 .. sum of counts) -- for the consumers that want the seeds
+// in one array (the composite-key seed stage reads the segments as they are)
 extern "C" __global__ void __launch_bounds__(256)
 seed_compact_kernel(const GbnDevSeed *__restrict__ seg, const uint32_t *__restrict__ seg_count, int nseg, uint32_t seg_cap,
-                    GbnDevSeed *__restrict__ out, unsigned long long out_cap, unsigned long long *seed_count, unsigned long long *seg_max)
+                    GbnDevSeed *__restrict__ out, unsigned long long out_cap)
 {
     __shared__ unsigned long long s_at[GBN_SLICE_SEGS + 1];
     __shared__ uint32_t s_have[GBN_SLICE_SEGS];
     const int sg = blockIdx.x % nseg, part = blockIdx.x / nseg, nparts = gridDim.x / nseg;
     if (threadIdx.x == 0) {
-        unsigned long long at = 0, tot = 0; uint32_t mx = 0;
-        for (int i = 0; i < nseg; i++) { const uint32_t c = seg_count[i]; s_at[i] = at; s_have[i] = min(c, seg_cap); at += s_have[i]; tot += c; mx = max(mx, c); }
+        unsigned long long at = 0;
+        for (int i = 0; i < nseg; i++) { const uint32_t c = seg_count[i]; s_at[i] = at; s_have[i] = min(c, seg_cap); at += s_have[i]; }
         s_at[nseg] = at;
-        if (blockIdx.x == 0) { *seed_count = (mx > seg_cap) ? tot : at; *seg_max = mx; }
     }
     __syncthreads();
     const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(seg + (size_t)sg * seg_cap);
@@ -409,11 +412,33 @@ extern "C" __global__ void seed_keys_kernel(GbnKeyParams K)
 // a handful per million -- by the high bits of the query key, which seed_ext_kernel applies.  The seed follows from
 // key and value (q_pos's low bits = (s_scan - slot) mod slots; value = ext_left | high bits of the query key << 8):
 // no second sort, no gathers of seeds by rank afterwards.
-extern "C" __global__ void seed_ckeys_kernel(GbnKeyParams K)
+extern "C" __global__ void __launch_bounds__(256) seed_ckeys_kernel(GbnKeyParams K)
 {
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= K.n) return;
-    const GbnDevSeed sd = K.seeds[i];
+    __shared__ unsigned long long s_first[GBN_SLICE_SEGS + 1];          // segmented input: index of a segment's first seed
+    if (K.nseg > 0) {
+        if (threadIdx.x < 64) {                                         // one wave: prefix sums of the segment counts, 64 at a time
+            unsigned long long carry = 0;
+            for (int b0 = 0; b0 < K.nseg; b0 += 64) {
+                const int sgi = b0 + (int)threadIdx.x;
+                const unsigned long long c = sgi < K.nseg ? (unsigned long long)min(K.seg_count[sgi], K.seg_cap) : 0ull;
+                unsigned long long incl = c;
+                #pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const unsigned long long v = __shfl_up(incl, d); incl += ((int)threadIdx.x >= d) ? v : 0ull; }
+                if (sgi < K.nseg) s_first[sgi] = carry + incl - c;
+                carry += __shfl(incl, 63);
+            }
+            if (threadIdx.x == 0) s_first[K.nseg] = carry;
+        }
+        __syncthreads();
+    }
+    // (a workgroup takes many pieces of 256 seeds: with the segmented input the prefix sums above are its set-up)
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < K.n; i += (int64_t)gridDim.x * blockDim.x) {
+    GbnDevSeed sd;
+    if (K.nseg > 0) {
+        int lo = 0, hi = K.nseg;                                        // the segment seed i lies in
+        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (s_first[m] <= (unsigned long long)i) lo = m; else hi = m; }
+        sd = K.seg[(size_t)lo * K.seg_cap + (size_t)((unsigned long long)i - s_first[lo])];
+    } else sd = K.seeds[i];
     const uint32_t qmax = (K.q_bits >= 32) ? 0xffffffffu : ((1u << K.q_bits) - 1u);
     const uint32_t qkey = K.q_descending ? (qmax - (uint32_t)sd.q_pos) : (uint32_t)sd.q_pos;
     const uint32_t slot = K.container_hash ? ((uint32_t)(sd.s_scan - sd.q_pos) & 511u)
@@ -425,6 +450,7 @@ extern "C" __global__ void seed_ckeys_kernel(GbnKeyParams K)
     const uint32_t val = (uint32_t)sd.ext_left | ((K.qh_bits ? (qkey >> K.group_bits) : 0u) << 8);
     if (K.v_bits > 0) K.key_scan[i] = (key << K.v_bits) | val;         // key and value in one word: a sort of keys only, on the bits above the value
     else { K.key_scan[i] = key; K.idx[i] = val; }
+    }
 }
 
 extern "C" __global__ void group_keys_kernel(GbnKeyParams K)
@@ -1841,8 +1867,17 @@ int scan_slice_blocks(const GbnScanParams &p, int num_cu)
     return per_slice * nslices;
 }
 
-// seg: scan_slice_blocks() segments of seg_cap seeds each (scratch), seg_count: as many counters; p.seeds / p.seed_count
-// receive the seeds back to back and their number, *seg_max the fullest segment's count (see seed_compact_kernel)
+// seg: scan_slice_blocks() segments of seg_cap seeds each, seg_count: as many counters; *p.seed_count receives the number
+// of seeds, *seg_max the fullest segment's count (above seg_cap: seeds were dropped, scan again with longer segments).
+// p.seeds is not written: launch_seed_compact puts the segments back to back for whoever wants them in one array
+hipError_t launch_seed_compact(const GbnDevSeed *seg, const uint32_t *seg_count, int nseg, uint32_t seg_cap, GbnDevSeed *out,
+                               unsigned long long out_cap, hipStream_t st)
+{
+    if (nseg <= 0) return hipSuccess;
+    hipLaunchKernelGGL(seed_compact_kernel, dim3((unsigned)(nseg * 8)), dim3(256), 0, st, seg, seg_count, nseg, seg_cap, out, out_cap);
+    return hipGetLastError();
+}
+
 hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
                              unsigned long long *seg_max, hipStream_t st)
 {
@@ -1857,9 +1892,7 @@ hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg
         if (e != hipSuccess) return e;
         attr_set = true;
     }
-    hipLaunchKernelGGL(scan_slice_kernel, dim3((unsigned)blocks), dim3(GBN_SLICE_THREADS), lds, st, p, nslices, cell_bits, seg, seg_cap, seg_count);
-    hipLaunchKernelGGL(seed_compact_kernel, dim3((unsigned)(blocks * 8)), dim3(256), 0, st, seg, seg_count, blocks, seg_cap,
-                       p.seeds, p.seed_cap, p.seed_count, seg_max);
+    hipLaunchKernelGGL(scan_slice_kernel, dim3((unsigned)blocks), dim3(GBN_SLICE_THREADS), lds, st, p, nslices, cell_bits, seg, seg_cap, seg_count, seg_max);
     return hipGetLastError();
 }
 
@@ -1873,7 +1906,7 @@ hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st)
 hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st)
 {
     if (k.n <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_ckeys_kernel, dim3((unsigned)((k.n + 255) / 256)), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(seed_ckeys_kernel, dim3((unsigned)std::min<int64_t>((k.n + 255) / 256, 4096)), dim3(256), 0, st, k);
     return hipGetLastError();
 }
 
