@@ -431,13 +431,21 @@ extern "C" __global__ void __launch_bounds__(256) seed_ckeys_kernel(GbnKeyParams
         }
         __syncthreads();
     }
-    // (a workgroup takes many pieces of 256 seeds: with the segmented input the prefix sums above are its set-up)
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < K.n; i += (int64_t)gridDim.x * blockDim.x) {
+    // a workgroup takes a stretch of consecutive seeds, 256 at a time: with the segmented input the prefix sums above are
+    // its set-up, and a thread's segment only ever moves forward (one search at the start, then a comparison per seed)
+    const int64_t per = ((K.n + gridDim.x - 1) / gridDim.x + 255) / 256 * 256;
+    const int64_t i_end = min(K.n, (int64_t)(blockIdx.x + 1) * per);
+    int sgi = 0;
+    if (K.nseg > 0) {
+        const unsigned long long i0 = (unsigned long long)((int64_t)blockIdx.x * per + threadIdx.x);
+        int hi = K.nseg;
+        while (hi - sgi > 1) { const int m = (sgi + hi) >> 1; if (s_first[m] <= i0) sgi = m; else hi = m; }
+    }
+    for (int64_t i = (int64_t)blockIdx.x * per + threadIdx.x; i < i_end; i += blockDim.x) {
     GbnDevSeed sd;
     if (K.nseg > 0) {
-        int lo = 0, hi = K.nseg;                                        // the segment seed i lies in
-        while (hi - lo > 1) { const int m = (lo + hi) >> 1; if (s_first[m] <= (unsigned long long)i) lo = m; else hi = m; }
-        sd = K.seg[(size_t)lo * K.seg_cap + (size_t)((unsigned long long)i - s_first[lo])];
+        while (sgi + 1 < K.nseg && s_first[sgi + 1] <= (unsigned long long)i) sgi++;      // (empty segments are stepped over)
+        sd = K.seg[(size_t)sgi * K.seg_cap + (size_t)((unsigned long long)i - s_first[sgi])];
     } else sd = K.seeds[i];
     const uint32_t qmax = (K.q_bits >= 32) ? 0xffffffffu : ((1u << K.q_bits) - 1u);
     const uint32_t qkey = K.q_descending ? (qmax - (uint32_t)sd.q_pos) : (uint32_t)sd.q_pos;
