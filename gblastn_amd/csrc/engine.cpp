@@ -1245,10 +1245,13 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
         std::lock_guard<std::mutex> lk(E.host_mu);
         std::shared_future<void> prev = E.host_tail;
-        E.host_tail = std::async(std::launch::async, [=]() {
+        E.host_tail = std::async(std::launch::async, [=]() mutable {
             if (prev.valid()) prev.wait();
             const int r = gapped_host(*bp, *dbp, s0, s1, *rp, diag, 0, *ih, *gg);
             if (r) record_failure(rp, r, gbn_last_error());
+            // (the task's state lives as long as its successor refers to it: let go of the predecessor and of the
+            // copies, or every replay ever queued stays reachable from the newest one)
+            prev = std::shared_future<void>(); ih.reset(); gg.reset();
         }).share();
     }
     return GBN_OK;

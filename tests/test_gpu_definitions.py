@@ -348,3 +348,14 @@ def test_many_seeds_composite_sort_is_deterministic_and_equals_the_two_sort_path
         res[name] = p.stdout.split("BIGN", 1)[1].split()
     assert int(res["composite"][0]) > (1 << 22) and int(res["composite"][1]) > 10000
     assert res["composite"] == res["two sorts"] and res["pairs"] == res["two sorts"]
+
+
+def test_queue_of_host_replays_keeps_nothing_alive():
+    """pipelined blastn passes hand the replay of their gapped extensions to a queue of host tasks, each waiting for its
+    predecessor: a finished task must let go of it (and of its copies of the extensions), or the peak resident memory grows
+    by megabytes per pass.  60 passes over a 1 Gbp shard (87,000 extensions each): flat after the first."""
+    import os, re, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = util.run_child([sys.executable, os.path.join(root, "tools", "rss_check.py"), "60"], cwd=root, timeout=600)
+    rss = [float(x) for x in re.findall(r"max RSS (\d+) MB", p.stdout)]
+    assert len(rss) == 3 and rss[2] - rss[0] < 100, p.stdout
