@@ -1180,7 +1180,38 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
 // gapped extension of every initial hit of a range (slot buffers), D2H, host replay of the acceptance
 // rules per subject.  Touches only the slot's buffers, the results and the gapped fields of `diag`.
 static int gapped_host(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag, int keep_stages,
-                       const std::vector<GbnDevInitHit> &hih, const std::vector<GbnDevGapped> &hg);
+                       const GbnDevInitHit *hih, const GbnDevGapped *hg, size_t nih);
+
+// Host copies of a range's initial hits and gapped extensions: pinned buffers that are handed out again.  (Vectors
+// allocated and freed per range cost more than their pages: freeing memory the copy engine has just written to, while
+// the next range's kernels and copies run, stalls the device's queues -- the lane DP took 8.9 instead of 3.4 ms.)
+struct HitBuf { GbnDevInitHit *hih = nullptr; GbnDevGapped *hg = nullptr; size_t cap = 0; };
+static std::mutex g_hitbuf_mu; static std::vector<HitBuf> g_hitbuf_idle;
+static int hitbuf_get(size_t n, HitBuf &out) {
+    {
+        std::lock_guard<std::mutex> lk(g_hitbuf_mu);
+        for (size_t i = 0; i < g_hitbuf_idle.size(); i++)
+            if (g_hitbuf_idle[i].cap >= n) { out = g_hitbuf_idle[i]; g_hitbuf_idle.erase(g_hitbuf_idle.begin() + (long)i); return GBN_OK; }
+        if (!g_hitbuf_idle.empty()) {           // too short: let one go, its successor is longer
+            HitBuf old = g_hitbuf_idle.back(); g_hitbuf_idle.pop_back();
+            (void)hipHostFree(old.hih); (void)hipHostFree(old.hg);
+        }
+    }
+    HitBuf b; b.cap = std::max<size_t>(n + n / 4, 1 << 16);
+    if (hipHostMalloc((void **)&b.hih, b.cap * sizeof(GbnDevInitHit)) != hipSuccess ||
+        hipHostMalloc((void **)&b.hg, b.cap * sizeof(GbnDevGapped)) != hipSuccess) {
+        if (b.hih) (void)hipHostFree(b.hih);
+        set_error("out of pinned host memory (gapped stage)"); return GBN_ERR_NOMEM;
+    }
+    out = b;
+    return GBN_OK;
+}
+static void hitbuf_put(const HitBuf &b) { if (b.hih) { std::lock_guard<std::mutex> lk(g_hitbuf_mu); g_hitbuf_idle.push_back(b); } }
+static void hitbuf_drain() {
+    std::lock_guard<std::mutex> lk(g_hitbuf_mu);
+    for (HitBuf &b : g_hitbuf_idle) { (void)hipHostFree(b.hih); (void)hipHostFree(b.hg); }
+    g_hitbuf_idle.clear();
+}
 
 static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag,
                         int keep_stages, int slot, unsigned long long nih, hipStream_t st, bool detach_host)
@@ -1227,31 +1258,35 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         fprintf(stderr, "\n[gbn dbg]   extensions by widest window / 8:"); for (int k = 0; k < 8; k++) fprintf(stderr, " %llu", c[16 + k]);
         fprintf(stderr, "\n");
     }
-    std::vector<GbnDevInitHit> hih((size_t)nih); std::vector<GbnDevGapped> hg((size_t)nih);
-    HIPCHK(hipMemcpyAsync(hih.data(), E.ihits_s[slot], (size_t)nih * sizeof(GbnDevInitHit), hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(hg.data(), E.gapped_s[slot], (size_t)nih * sizeof(GbnDevGapped), hipMemcpyDeviceToHost, st));
+    HitBuf hb;
+    if ((rc = hitbuf_get((size_t)nih, hb))) return rc;
+    struct PutBack { HitBuf b; bool armed = true; ~PutBack() { if (armed) hitbuf_put(b); } } putback{hb};
+    GbnDevInitHit *hih = hb.hih; GbnDevGapped *hg = hb.hg;
+    HIPCHK(hipMemcpyAsync(hih, E.ihits_s[slot], (size_t)nih * sizeof(GbnDevInitHit), hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(hg, E.gapped_s[slot], (size_t)nih * sizeof(GbnDevGapped), hipMemcpyDeviceToHost, st));
     trace_mark("gapped: kernels + copies queued");
     HIPCHK(hipStreamSynchronize(st));
     trace_mark("gapped: kernels + copies done");
     if (diag) diag->gapped_stage_ms += ms_since(t_stage);
     static const bool detach_on = !(getenv("GBN_HOST_DETACH") && atoi(getenv("GBN_HOST_DETACH")) == 0);
     // (a few thousand extensions -- megablast shapes -- are replayed in less time than handing them over takes)
-    if (!detach_host || !detach_on || nih < 20000) { if (detach_host) wait_host(); return gapped_host(b, db, s0, s1, res, diag, keep_stages, hih, hg); }
+    if (!detach_host || !detach_on || nih < 20000) { if (detach_host) wait_host(); return gapped_host(b, db, s0, s1, res, diag, keep_stages, hih, hg, (size_t)nih); }
     // the replay of this range's extensions joins the queue of host replays (in range order: the lists are appended to
     // the results); this thread, the slot's device buffers and the second stream are free for the next range
     {
-        auto ih = std::make_shared<std::vector<GbnDevInitHit>>(std::move(hih));
-        auto gg = std::make_shared<std::vector<GbnDevGapped>>(std::move(hg));
+        putback.armed = false;                              // the buffers go back when the replay is done
+        const size_t n_hits = (size_t)nih;
         GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
         std::lock_guard<std::mutex> lk(E.host_mu);
         std::shared_future<void> prev = E.host_tail;
         E.host_tail = std::async(std::launch::async, [=]() mutable {
             if (prev.valid()) prev.wait();
-            const int r = gapped_host(*bp, *dbp, s0, s1, *rp, diag, 0, *ih, *gg);
+            const int r = gapped_host(*bp, *dbp, s0, s1, *rp, diag, 0, hb.hih, hb.hg, n_hits);
             if (r) record_failure(rp, r, gbn_last_error());
-            // (the task's state lives as long as its successor refers to it: let go of the predecessor and of the
-            // copies, or every replay ever queued stays reachable from the newest one)
-            prev = std::shared_future<void>(); ih.reset(); gg.reset();
+            hitbuf_put(hb);
+            // (the task's state lives as long as its successor refers to it: let go of the predecessor, or every
+            // replay ever queued stays reachable from the newest one)
+            prev = std::shared_future<void>();
         }).share();
     }
     return GBN_OK;
@@ -1260,13 +1295,12 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
 // the acceptance rules of BLAST_GetGappedScore replayed per subject over the extensions of a range, the HSP lists
 // appended to the results (ascending oid)
 static int gapped_host(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag, int keep_stages,
-                       const std::vector<GbnDevInitHit> &hih, const std::vector<GbnDevGapped> &hg)
+                       const GbnDevInitHit *hih, const GbnDevGapped *hg, size_t nih)
 {
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms_since = [&](std::chrono::steady_clock::time_point t) {
         return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_stage = now();
-    const size_t nih = hih.size();
 
     // ---- host replay per subject, ascending oid ----
     // group the hits by subject (counting sort; the order inside a subject does not matter,
@@ -1444,6 +1478,7 @@ void Blast_gpu_Release(void) {
     (void)wait_pending();
     g_binkey.valid = false;
     dev_free(E.slice_seg); E.slice_seg_cap = 0;
+    hitbuf_drain();
     dev_free(E.seeds_async); E.seeds_async_cap = 0; if (E.ev_seed) { (void)hipEventDestroy(E.ev_seed); E.ev_seed = nullptr; }
     dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
     dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.ext_rec); dev_free(E.sort_tmp); for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }

@@ -758,7 +758,12 @@ extern "C" __global__ void diag_ungapped_kernel(GbnExtParams P)
 // diag_replay_kernel walks the runs over the finished records: per seed a sequential read, the container update
 // and nothing else.  (~20 % of the extensions are of seeds the replay then skips.)
 // ---------------------------------------------------------------------------------------------------
-struct GbnSeedExt { int32_t q_off, s_off, s_orig, q_start, s_start, length, score, flags; };    // flags: 1 = dropped by the mask re-check, 2 = reaches the cutoff, [31:8] = bases the re-check added on the right
+// what the replay reads of every seed (16 bytes) ...; flags: 1 = dropped by the mask re-check, 2 = reaches the cutoff, 4 = last
+// of its run, [31:8] = bases the re-check added on the right
+struct GbnSeedExt { int32_t q_off, s_off, s_orig, flags; };
+// ... and the extension itself, which it needs of the few that reach the cutoff (one in 500 on C3): written and read for
+// those only, in the second half of ext_rec (records of all n seeds first, then n slots of these)
+struct GbnSeedHsp { int32_t q_start, s_start, length, score; };
 
 __device__ __forceinline__ int context_of(const GbnExtParams &P, int32_t q)
 {
@@ -819,9 +824,9 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
     if (live) {
         const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
         const int32_t slen = P.len[subj_id];
-        GbnSeedExt r;
+        GbnSeedExt r; GbnSeedHsp hs;
         int32_t q_off = sd.q_pos - sd.ext_left, s_off = sd.s_scan - sd.ext_left;
-        r.s_orig = s_off; r.flags = 0; r.q_start = 0; r.s_start = 0; r.length = 0; r.score = 0;
+        r.s_orig = s_off; r.flags = 0; hs.q_start = 0; hs.s_start = 0; hs.length = 0; hs.score = 0;
         int32_t s_match_end = s_off + P.word;
         bool ok = true;
         if (P.masked) {                                     // without masks s_TypeOfWord changes nothing
@@ -836,12 +841,13 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
             // (the exact pass stays inline: handing its seeds to a kernel of their own -- dense waves -- gained 0.1 ms per
             // 47 M seeds once that pass read 32 bases per load, not worth a kernel)
             else ungapped_approx(P, subj, slen, q_off, s_match_end, s_off, -P.ctx_xdrop[lo], P.ctx_reduced[lo], u);
-            r.q_start = u.q_start; r.s_start = u.s_start; r.length = u.length; r.score = u.score;
+            hs.q_start = u.q_start; hs.s_start = u.s_start; hs.length = u.length; hs.score = u.score;
             if (u.score >= P.ctx_cutoff[lo]) r.flags |= 2;
         }
         if (last) r.flags |= 4;
         r.q_off = q_off; r.s_off = s_off;
         reinterpret_cast<GbnSeedExt *>(P.ext_rec)[pos] = r;
+        if (r.flags & 2) (reinterpret_cast<GbnSeedHsp *>(reinterpret_cast<GbnSeedExt *>(P.ext_rec) + P.n))[pos] = hs;
     }
     if (P.ck_shift > 0) {
         // the run heads, compacted (what run_heads_kernel does for the other form): one atomic per workgroup
@@ -906,13 +912,14 @@ extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams
             if (!(s_off_pos < last_hit) && !(r.flags & 1)) {
                 int32_t s_end_pos = s_off_pos + word + (r.flags >> 8);
                 if (r.flags & 2) {
+                    const GbnSeedHsp hs = (reinterpret_cast<const GbnSeedHsp *>(rec + P.n))[j];
                     GbnDevInitHit h; h.subj = subj_id; h.q_off = r.q_off; h.s_off = r.s_off;
-                    h.q_start = r.q_start; h.s_start = r.s_start; h.length = r.length; h.score = r.score;
+                    h.q_start = hs.q_start; h.s_start = hs.s_start; h.length = hs.length; h.score = hs.score;
                     h.seq = (uint32_t)j;
                     const uint32_t slot = atomicAdd(&s_n, 1u);
                     if (slot < CAP) s_hit[slot] = h;
                     else { const unsigned long long o = atomicAdd(P.ihit_count, 1ull); if (o < P.ihit_cap) P.ihits[o] = h; }
-                    s_end_pos = r.length + r.s_start;
+                    s_end_pos = hs.length + hs.s_start;
                 }
                 if (hash) {
                     // newest to oldest: the cell of this diagonal, else the first expired one; none: a new cell
