@@ -173,6 +173,8 @@ def lib():
         L.gbn_batch_free.argtypes = [C.c_void_p]
         for nm in ["gbn_batch_num_contexts", "gbn_batch_lut_type", "gbn_batch_lut_width",
                    "gbn_batch_scan_step", "gbn_batch_scan_path", "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff"]:
+            if nm == "gbn_batch_scan_path" and not hasattr(L, nm):
+                continue                                    # (an older build loaded through GBN_AMD_LIB for an A/B)
             getattr(L, nm).restype = C.c_int32; getattr(L, nm).argtypes = [C.c_void_p]
         L.gbn_batch_contexts.restype = C.POINTER(GbnContext); L.gbn_batch_contexts.argtypes = [C.c_void_p]
         L.gbn_results_new.argtypes = [C.POINTER(C.c_void_p)]
@@ -369,7 +371,7 @@ class BlastPrelimSearch:
     def info(self):
         L, b = lib(), self._b
         return dict(lut_type=L.gbn_batch_lut_type(b), lut_width=L.gbn_batch_lut_width(b),
-                    scan_step=L.gbn_batch_scan_step(b), scan_path=L.gbn_batch_scan_path(b), container=L.gbn_batch_diag_container(b),
+                    scan_step=L.gbn_batch_scan_step(b), scan_path=L.gbn_batch_scan_path(b) if hasattr(L, "gbn_batch_scan_path") else -1, container=L.gbn_batch_diag_container(b),
                     gap_x_dropoff=L.gbn_batch_gap_x_dropoff(b))
 
     @property
