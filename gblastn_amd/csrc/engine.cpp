@@ -1281,8 +1281,12 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         std::shared_future<void> prev = E.host_tail;
         E.host_tail = std::async(std::launch::async, [=]() mutable {
             if (prev.valid()) prev.wait();
-            const int r = gapped_host(*bp, *dbp, s0, s1, *rp, diag, 0, hb.hih, hb.hg, n_hits);
-            if (r) record_failure(rp, r, gbn_last_error());
+            try {
+                const int r = gapped_host(*bp, *dbp, s0, s1, *rp, diag, 0, hb.hih, hb.hg, n_hits);
+                if (r) record_failure(rp, r, gbn_last_error());
+            } catch (const std::exception &e) {             // (nobody calls get() on this future: the failure is reported through the results)
+                record_failure(rp, GBN_ERR_NOMEM, std::string("host replay of a range failed: ") + e.what());
+            }
             hitbuf_put(hb);
             // (the task's state lives as long as its successor refers to it: let go of the predecessor, or every
             // replay ever queued stays reachable from the newest one)
