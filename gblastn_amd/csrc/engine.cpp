@@ -1403,8 +1403,19 @@ int gather_shard_bytes(const GbnDb &db, const std::vector<int64_t> &src_off, con
     if (e == hipSuccess) e = hipMemcpyAsync(d_do, dst_off.data(), (size_t)n * 8, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = hipMemcpyAsync(d_nb, nbytes.data(), (size_t)n * 4, hipMemcpyHostToDevice, st);
     if (e == hipSuccess) e = launch_gather_bytes(db.d_packed, d_so, d_do, d_nb, n, d_out, st);
-    if (e == hipSuccess) e = hipMemcpyAsync(out.data(), d_out, (size_t)total, hipMemcpyDeviceToHost, st);
+    // (through a pinned buffer that stays: a copy straight into the caller's fresh vector makes the runtime register those
+    // pages, and their release next to running kernels stalls the device's queues -- see HitBuf)
+    static uint8_t *stage = nullptr; static size_t stage_cap = 0;
+    if (e == hipSuccess && (size_t)total > stage_cap) {
+        if (stage) (void)hipHostFree(stage);
+        stage = nullptr; stage_cap = 0;
+        const size_t want = (size_t)total + (size_t)total / 4 + (1 << 20);
+        e = hipHostMalloc((void **)&stage, want);
+        if (e == hipSuccess) stage_cap = want;
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(stage, d_out, (size_t)total, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e == hipSuccess) std::memcpy(out.data(), stage, (size_t)total);
     cleanup();
     if (e != hipSuccess) { set_error(std::string("gather_shard_bytes: ") + hipGetErrorString(e)); return GBN_ERR_HIP; }
     return GBN_OK;
