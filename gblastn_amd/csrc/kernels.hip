@@ -9,13 +9,20 @@
 //                        CORE/blast_nascan.c, CORE/na_ungapped.c:1025-1555)
 //   scan_seed_kernel     the same work by direct table probes, without streams (fallback for
 //                        repeat-dominated subject ranges)
+//   scan_slice_kernel    the same work for tables as wide as the word (blastn shapes: stride 1, every
+//                        lookup hit a seed): the presence bits sliced through the LDS, the subjects
+//                        streamed past them; seeds into per-workgroup segments (seed_compact_kernel
+//                        puts them back to back for the consumers that want one array)
 //   seed_keys / group_keys / run_heads kernels: the scan order and the (subject, diagonal slot) runs
+//                        (few seeds); seed_ckeys_kernel: both in one 64-bit key (many seeds)
 //   diag_ungapped_kernel per-diagonal one-hit filter + X-drop ungapped extension
-//                        (CORE/na_ungapped.c:152-351, :611-922)
+//                        (CORE/na_ungapped.c:152-351, :611-922); for many seeds in two kernels:
+//                        seed_ext_kernel (every seed extended) + diag_replay_kernel (the runs replayed)
 //   greedy_kernel        megablast score-only greedy gapped extension, linear and affine
 //                        (CORE/greedy_align.c:385-753, CORE/blast_gapalign.c:2619-2751)
-//   dynprog_kernel       blastn score-only X-drop DP on the packed subject
-//                        (CORE/blast_gapalign.c:2762-3056)
+//   dynprog_lane_kernel / dynprog_wave_kernel / dynprog_kernel: blastn score-only X-drop DP on the
+//                        packed subject (CORE/blast_gapalign.c:2762-3056): an extension per lane with the
+//                        band in LDS, per wave with the band in registers, per thread with it in scratch
 // (lookup tables of a query batch: lutbuild.hip)
 //
 // Data layout: subjects are NCBI2na (4 bases/byte, base 0 in
