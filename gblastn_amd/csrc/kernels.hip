@@ -302,7 +302,6 @@ scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed 
     unsigned long long raw = 0;
     const unsigned long long lt = (1ull << lane) - 1;
     const int top = 64 - 2 * P.lut;
-    const uint32_t in_mask = (1u << slice_cell_bits) - 1u;
 
     // `cnt` queued lookup hits, a lane each: the cell's entries become seeds in the workgroup's own segment of the
     // output (one LDS atomic per wave; a global counter took 6 of 9 ms: 700,000 atomics on one address per launch)
@@ -335,19 +334,41 @@ scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed 
         const uint8_t *__restrict__ subj = P.db + P.byte_off[T.subj];
         const int32_t nl = min(32, T.npos - 32 * lane);                 // positions of this lane (<= 0: none)
         const int32_t p0 = T.first_pos + (nl > 0 ? 32 * lane : 0);      // always a readable address
-        const uint64_t hi0 = bases32(subj, p0);
-        const uint32_t lo0 = window16(subj, (int64_t)p0 + 32);
+        // (p0 is a multiple of 32 bases: tiles start at multiples of 2048 positions, stride 1 -- the lane's 48 bases are
+        // three aligned dwords)
+        const uint32_t *__restrict__ dw = reinterpret_cast<const uint32_t *>(subj) + (p0 >> 4);
+        const uint32_t W[3] = {bswap32(dw[0]), bswap32(dw[1]), bswap32(dw[2])};
+        const uint64_t hi0 = ((uint64_t)W[0] << 32) | W[1];
+        const uint32_t lo0 = W[2];
         // the lane's 32 presence tests, independent of each other (the LDS reads go out back to back) ...
         uint32_t hm = 0;
         {
-            uint64_t hi = hi0; uint32_t lo = lo0;
+            // The kernel is bound by VALU issue (a wave's instruction takes a SIMD four cycles: 4 slices x 10^9 positions x
+            // 14 instructions = 1.7 of its 2.2 ms), so a position's word is cut out of two of the three dwords with one
+            // funnel shift (v_alignbit, constant amount) instead of a 64-bit window shifted along.
+            // Sixteen at a time: all cells, then all LDS reads, then all tests (written as one loop, the compiler waited
+            // for every read before it issued the next one: 32 LDS round trips per tile)
+            const int top32 = 32 - 2 * P.lut;                           // x = the 32 bits that start with the word: cell = x >> top32
+            const bool one_slice = nslices == 1;                        // (then top32 + slice_cell_bits = 32: nothing to shift by)
+            const int sl_shift = min(31, top32 + slice_cell_bits);      // x >> sl_shift = the slice of the word's cell
+            const int wd_shift = top32 + 5, wd_bits = slice_cell_bits - 5;   // bits of x: index of the presence word inside the slice
             #pragma unroll
-            for (int i = 0; i < 32; i++) {
-                const uint32_t cell = (uint32_t)(hi >> top);
-                const uint32_t w = s_pv[(cell & in_mask) >> 5];
-                const uint32_t hit = ((int)(cell >> slice_cell_bits) == k) ? ((w >> (cell & 31u)) & 1u) : 0u;
-                hm |= hit << i;
-                hi = (hi << 2) | (lo >> 30); lo <<= 2;
+            for (int i0 = 0; i0 < 32; i0 += 16) {
+                uint32_t x[16], w[16];
+                #pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    const int o = 2 * (i0 + j), wi = o >> 5, r = o & 31;
+                    x[j] = r ? __builtin_amdgcn_alignbit(W[wi], W[wi + 1], 32 - r) : W[wi];
+                }
+                // only the lanes whose word lies in this slice read (a quarter of them with four slices): what a random
+                // LDS read of a wave costs is its bank conflicts, and those come with the number of lanes
+                #pragma unroll
+                for (int j = 0; j < 16; j++) {
+                    w[j] = 0;
+                    if (one_slice || (int)(x[j] >> sl_shift) == k) w[j] = s_pv[__builtin_amdgcn_ubfe(x[j], wd_shift, wd_bits)];
+                }
+                #pragma unroll
+                for (int j = 0; j < 16; j++) hm |= __builtin_amdgcn_ubfe(w[j], __builtin_amdgcn_ubfe(x[j], top32, 5), 1) << (i0 + j);
             }
             hm &= (nl >= 32) ? 0xffffffffu : ((nl > 0) ? ((1u << nl) - 1u) : 0u);
         }
