@@ -91,9 +91,9 @@ def main():
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             os.environ.setdefault("NCCL_IB_DISABLE", "1")
         dist.init_process_group("nccl", device_id=dev)
-    rc = api.lib().Blast_gpu_Init(1, dev.index)
+    rc = api.lib().gbn_init(1, dev.index)
     if rc:
-        raise SystemExit("Blast_gpu_Init failed: %s" % api.lib().gbn_last_error().decode())
+        raise SystemExit("gbn_init failed: %s" % api.lib().gbn_last_error().decode())
 
     # ---- database shard of this rank, generated in HBM ----
     nsub, slen = args.subjects, args.subject_len

@@ -63,7 +63,7 @@ SEED_DT = np.dtype([("oid", "<i4"), ("s_off", "<i4"), ("q_off", "<i4"), ("pad_",
 IHIT_DT = np.dtype([("oid", "<i4"), ("q_off", "<i4"), ("s_off", "<i4"), ("q_start", "<i4"),
                     ("s_start", "<i4"), ("length", "<i4"), ("score", "<i4"), ("pad_", "<i4")])
 
-EXPORTS = ["Blast_gpu_Init", "Blast_gpu_Release", "gpu_ReleaseDBMemory", "gbn_default_options",
+EXPORTS = ["gbn_init", "gbn_release", "gbn_release_db_memory", "gbn_debug_check_guards", "gbn_device_count", "gbn_use_device", "gbn_current_device", "gbn_db_device", "gbn_shard_builder_add_oid", "gbn_default_options",
            "gbn_db_new", "gbn_db_free", "gbn_db_total_bases", "gbn_db_num_seqs", "gbn_synth_fill",
            "gbn_batch_new", "gbn_batch_new_ex", "gbn_batch_new_masked", "gbn_dust_mask", "gbn_batch_free", "gbn_batch_num_contexts", "gbn_batch_contexts",
            "gbn_batch_lut_type", "gbn_batch_lut_width", "gbn_batch_scan_step", "gbn_batch_scan_path",
@@ -141,7 +141,9 @@ def lib():
         L = C.CDLL(_SO)
         L.gbn_last_error.restype = C.c_char_p
         L.gbn_default_options.argtypes = [C.POINTER(GbnOptions), C.c_int]
-        L.Blast_gpu_Init.argtypes = [C.c_int, C.c_int]
+        L.gbn_init.argtypes = [C.c_int, C.c_int]
+        L.gbn_use_device.argtypes = [C.c_int]; L.gbn_db_device.argtypes = [C.c_void_p]
+        L.gbn_shard_builder_add_oid.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
         L.gbn_db_new.argtypes = [C.POINTER(C.c_void_p), C.c_void_p, C.c_int64, C.c_int32,
                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int]
         L.gbn_db_free.argtypes = [C.c_void_p]
@@ -361,6 +363,8 @@ class BlastPrelimSearch:
         mq = (C.c_int32 * max(n, 1))(*[m[0] for m in masks])
         mf = (C.c_int32 * max(n, 1))(*[m[1] for m in masks])
         mt = (C.c_int32 * max(n, 1))(*[m[2] for m in masks])
+        if upload and seqsrc is not None and seqsrc._h:
+            _check(L.gbn_use_device(L.gbn_db_device(seqsrc._h)))     # the batch lives on the shard's GPU, whatever thread sets it up
         _check(L.gbn_batch_new_masked(C.byref(self._b), C.byref(options), len(self._q), ptrs, lens,
                                       n, mq, mf, mt, 1 if upload else 0))
         self._r = C.c_void_p()

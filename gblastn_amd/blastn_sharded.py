@@ -100,7 +100,7 @@ def main(argv=None):
             os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")
             os.environ.setdefault("NCCL_IB_DISABLE", "1")
         dist.init_process_group(a.backend, device_id=dev if a.backend == "nccl" else None)
-    api._check(api.lib().Blast_gpu_Init(1, dev.index))
+    api._check(api.lib().gbn_init(1, dev.index))
     sh = shard.VolumeShard(a.db, world, rank)
     opt = api.default_options(a.task, evalue=a.evalue, hitlist_size=a.max_target_seqs)
     S = shard.ShardedSearch(sh, opt, device=dev if a.backend == "nccl" else None, trace_threads=a.trace_t_num)

@@ -134,7 +134,7 @@ int main(int argc, char **argv)
     if (queries.empty()) die("no query sequences");
 
     // ---- database: every volume into one resident shard ----
-    check(Blast_gpu_Init(1, std::atoi(get("gpu_id", "-1").c_str())), "Blast_gpu_Init");
+    check(gbn_init(1, std::atoi(get("gpu_id", "-1").c_str())), "gbn_init");
     GbnBlastDb *bdb = nullptr;
     check(gbn_blastdb_open(&bdb, a["db"].c_str()), "gbn_blastdb_open");
     GbnDb *shard = nullptr;
@@ -288,6 +288,6 @@ int main(int argc, char **argv)
                  queries.size(), batches.size(), (long long)diag.subject_bases_scanned, (long long)diag.seeds,
                  (long long)diag.gapped_extensions, diag.total_ms);
     if (out != stdout) std::fclose(out);
-    gbn_db_free(shard); gbn_blastdb_close(bdb); Blast_gpu_Release();
+    gbn_db_free(shard); gbn_blastdb_close(bdb); gbn_release();
     return 0;
 }

@@ -77,6 +77,7 @@ struct DeviceBatch {
     // lookup structures still being built on the builder's stream: the event they are complete at, and the
     // builder's scratch, which goes back to the pool once it has fired
     hipEvent_t ready = nullptr; std::vector<void *> build_scratch;
+    struct Engine *eng = nullptr;   // the device context the batch lives on
 };
 
 struct Engine {
@@ -122,17 +123,47 @@ struct Engine {
     hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;       // around a deferred rare kernel (stream2)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk[4] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex mu;
+    // which scan records bin_rec holds (GBN_REUSE_BINNING)
+    struct BinKey { const void *db; int32_t s0, s1; int lut, step, nb, nwriters; size_t subcap; bool valid; } binkey = {nullptr, 0, 0, 0, 0, 0, 0, 0, false};
+    // pinned host copies of a range's initial hits and gapped extensions, handed out again (hitbuf_get)
+    struct HitBuf { GbnDevInitHit *hih = nullptr; GbnDevGapped *hg = nullptr; size_t cap = 0; };
+    std::mutex hitbuf_mu; std::vector<HitBuf> hitbuf_idle;
+    // traceback stage: stream and pinned staging buffer of gather_shard_bytes
+    std::mutex gather_mu; hipStream_t gather_stream = nullptr; uint8_t *gather_stage = nullptr; size_t gather_stage_cap = 0;
 };
-static Engine E;
+typedef Engine::BinKey BinKey;
+typedef Engine::HitBuf HitBuf;
 
-static int ensure_init() {
-    if (E.ready) return GBN_OK;
-    return Blast_gpu_Init(1, -1);
+// One engine per device, created by gbn_init / gbn_use_device (or by the first call that needs one) and alive
+// until gbn_release.  Every entry point works with exactly one of them: the one its GbnBatch / GbnDb / GbnResults
+// lives on, or -- for calls that create such an object -- the calling thread's device (gbn_use_device; default:
+// the device of the first gbn_init).  Searches on different devices run concurrently (the reference leases its
+// GPUs to search threads the same way, GB/gpu_blast_multi_gpu_utils.cpp:105-139); calls on one device are
+// serialised by that engine's mutex.
+constexpr int kMaxDevices = 64;
+static Engine *g_eng[kMaxDevices];
+static std::mutex g_eng_mu;
+static int g_default_dev = -1;
+static thread_local Engine *tl_eng = nullptr;       // the engine the calling thread is working with (set by enter)
+static thread_local int tl_sel = -1;                // gbn_use_device
+#define E (*tl_eng)
+
+static int engine_init(int dev, Engine **out);
+static inline void enter(Engine *e) { tl_eng = e; if (e && e->device >= 0) (void)hipSetDevice(e->device); }
+// the calling thread's engine for calls that create batches / shards: its chosen device, else the process default,
+// else the thread's current HIP device (first use without gbn_init)
+static int enter_current() {
+    int dev = tl_sel;
+    if (dev < 0) { std::lock_guard<std::mutex> lk(g_eng_mu); dev = g_default_dev; }
+    Engine *e = nullptr;
+    const int rc = engine_init(dev, &e);
+    if (rc) return rc;
+    enter(e);
+    return GBN_OK;
 }
 
-// The HIP current device is per host thread: every C-ABI entry point that touches HIP (callers use worker
-// threads for set-up and extension stages) selects the engine's device first.
-static inline void use_engine_device() { if (E.ready && E.device >= 0) (void)hipSetDevice(E.device); }
+// (The HIP current device is per host thread: every C-ABI entry point that touches HIP -- callers use worker
+// threads for set-up and extension stages -- goes through enter(), which selects the engine's device first.)
 
 // Device memory of query batches and of the table builder comes from a small pool: freed blocks are kept
 // (up to pool_cap() bytes) and handed out again for requests of about their size.  hipFree waits for the
@@ -140,10 +171,11 @@ static inline void use_engine_device() { if (E.ready && E.device >= 0) (void)hip
 namespace {
 struct DevPool {
     std::mutex mu;
-    std::multimap<size_t, void *> idle;         // size -> block
-    std::map<void *, size_t> size_of;           // every block handed out by the pool
-    size_t held = 0;
+    std::multimap<size_t, void *> idle[kMaxDevices];        // per device: size -> block
+    std::map<void *, std::pair<size_t, int>> size_of;       // every block handed out by the pool: size, device
+    size_t held[kMaxDevices] = {};
 };
+int cur_dev() { int d = 0; if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= kMaxDevices) d = 0; return d; }
 DevPool g_pool;
 // idle blocks kept: an eighth of the device's memory, 24 GiB at most (GBN_POOL_GIB overrides); when an allocation fails
 // the idle blocks are given back and it is tried again
@@ -164,47 +196,104 @@ hipError_t poison_block(void *p, size_t bytes) {           // (before anything q
     hipError_t e = hipMemset(p, pool_poison(), bytes);
     return e != hipSuccess ? e : hipDeviceSynchronize();
 }
+// GBN_GUARD=1 (tests): every block gets kGuard bytes of a known pattern in front and behind; they are checked when the
+// block comes back (and by gbn_debug_check_guards): a kernel that writes past either end of its buffer is named by
+// the block's size instead of showing up as whatever the neighbouring allocation -- possibly a code object -- does next
+constexpr size_t kGuard = 4096;
+bool pool_guard() { static const bool v = getenv("GBN_GUARD") && atoi(getenv("GBN_GUARD")) != 0; return v; }
+std::atomic<long> g_guard_violations{0};
+hipError_t guard_fill(void *raw, size_t bytes) {
+    hipError_t e = hipMemset(raw, 0xA5, kGuard);
+    if (e == hipSuccess) e = hipMemset((char *)raw + kGuard + bytes, 0xA5, kGuard);
+    return e != hipSuccess ? e : hipDeviceSynchronize();
+}
+bool guard_check(void *user, size_t bytes, const char *when) {
+    std::vector<uint8_t> h(2 * kGuard);
+    (void)hipDeviceSynchronize();
+    if (hipMemcpy(h.data(), (char *)user - kGuard, kGuard, hipMemcpyDeviceToHost) != hipSuccess ||
+        hipMemcpy(h.data() + kGuard, (char *)user + bytes, kGuard, hipMemcpyDeviceToHost) != hipSuccess) return true;
+    bool ok = true;
+    for (size_t i = 0; i < 2 * kGuard; i++) if (h[i] != 0xA5) {
+        fprintf(stderr, "[gbn guard] %s: block of %zu bytes at %p: byte %ld %s the block is 0x%02x\n", when, bytes, user,
+                i < kGuard ? (long)(kGuard - i) : (long)(i - kGuard), i < kGuard ? "in front of" : "behind", h[i]);
+        ok = false; g_guard_violations++;
+        break;
+    }
+    if (!ok) { fflush(stderr); abort(); }       // a test run: nothing after an out-of-bounds write can be trusted
+    return ok;
+}
+hipError_t raw_alloc(void **p, size_t bytes) {
+    if (!pool_guard()) return hipMalloc(p, bytes);
+    void *raw = nullptr;
+    hipError_t e = hipMalloc(&raw, bytes + 2 * kGuard);
+    if (e != hipSuccess) return e;
+    if ((e = guard_fill(raw, bytes)) != hipSuccess) { (void)hipFree(raw); return e; }
+    *p = (char *)raw + kGuard;
+    return hipSuccess;
+}
+void raw_free(void *p, size_t bytes) {
+    if (!pool_guard()) { (void)hipFree(p); return; }
+    guard_check(p, bytes, "free");
+    (void)hipFree((char *)p - kGuard);
+}
+void raw_free_on(void *p, size_t bytes, int dev) {       // (a block is released on the device it was allocated on)
+    const int cur = cur_dev();
+    if (cur != dev) (void)hipSetDevice(dev);
+    raw_free(p, bytes);
+    if (cur != dev) (void)hipSetDevice(cur);
+}
 hipError_t pool_alloc(void **p, size_t bytes) {
     bytes = pool_round(std::max<size_t>(bytes, 1));
+    const int dev = cur_dev();
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
-        auto it = g_pool.idle.lower_bound(bytes);
-        if (it != g_pool.idle.end() && it->first <= bytes + bytes / 4) {
-            *p = it->second; g_pool.held -= it->first; g_pool.size_of[*p] = it->first;
-            const size_t got = it->first; g_pool.idle.erase(it);
+        auto &idle = g_pool.idle[dev];
+        auto it = idle.lower_bound(bytes);
+        if (it != idle.end() && it->first <= bytes + bytes / 4) {
+            *p = it->second; g_pool.held[dev] -= it->first; g_pool.size_of[*p] = std::make_pair(it->first, dev);
+            const size_t got = it->first; idle.erase(it);
             if (pool_poison() >= 0) return poison_block(*p, got);
             return hipSuccess;
         }
     }
-    hipError_t e = hipMalloc(p, bytes);
+    hipError_t e = raw_alloc(p, bytes);
     if (e != hipSuccess) {                      // give the idle blocks back and try again
-        std::vector<void *> drop;
-        { std::lock_guard<std::mutex> lk(g_pool.mu); for (auto &kv : g_pool.idle) drop.push_back(kv.second); g_pool.idle.clear(); g_pool.held = 0; }
-        for (void *q : drop) (void)hipFree(q);
+        std::vector<std::pair<void *, size_t>> drop;
+        { std::lock_guard<std::mutex> lk(g_pool.mu); for (auto &kv : g_pool.idle[dev]) drop.emplace_back(kv.second, kv.first); g_pool.idle[dev].clear(); g_pool.held[dev] = 0; }
+        for (auto &q : drop) raw_free(q.first, q.second);
         (void)hipGetLastError();
-        e = hipMalloc(p, bytes);
+        e = raw_alloc(p, bytes);
     }
-    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.size_of[*p] = bytes; }
+    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(g_pool.mu); g_pool.size_of[*p] = std::make_pair(bytes, dev); }
     if (e == hipSuccess && pool_poison() >= 0) e = poison_block(*p, bytes);
     return e;
 }
 void pool_free(void *p) {
     if (!p) return;
-    size_t bytes = 0;
+    size_t bytes = 0; int dev = cur_dev();
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
         auto it = g_pool.size_of.find(p);
         if (it != g_pool.size_of.end()) {
-            bytes = it->second; g_pool.size_of.erase(it);
-            if (g_pool.held + bytes <= pool_cap()) { g_pool.idle.emplace(bytes, p); g_pool.held += bytes; return; }
+            bytes = it->second.first; dev = it->second.second; g_pool.size_of.erase(it);
+            if (pool_guard()) guard_check(p, bytes, "release");
+            if (g_pool.held[dev] + bytes <= pool_cap()) { g_pool.idle[dev].emplace(bytes, p); g_pool.held[dev] += bytes; return; }
         }
     }
-    (void)hipFree(p);
+    raw_free_on(p, bytes, dev);
 }
-void pool_drain() {
-    std::vector<void *> drop;
-    { std::lock_guard<std::mutex> lk(g_pool.mu); for (auto &kv : g_pool.idle) drop.push_back(kv.second); g_pool.idle.clear(); g_pool.held = 0; }
-    for (void *q : drop) (void)hipFree(q);
+// every block the pool knows (handed out or idle): guards intact?  Returns the violations seen so far.
+long pool_check_guards() {
+    if (!pool_guard()) return 0;
+    std::lock_guard<std::mutex> lk(g_pool.mu);
+    for (auto &kv : g_pool.size_of) guard_check(kv.first, kv.second.first, "check");
+    for (int d = 0; d < kMaxDevices; d++) for (auto &kv : g_pool.idle[d]) guard_check(kv.second, kv.first, "check (idle)");
+    return g_guard_violations.load();
+}
+void pool_drain(int dev) {
+    std::vector<std::pair<void *, size_t>> drop;
+    { std::lock_guard<std::mutex> lk(g_pool.mu); for (auto &kv : g_pool.idle[dev]) drop.emplace_back(kv.second, kv.first); g_pool.idle[dev].clear(); g_pool.held[dev] = 0; }
+    for (auto &q : drop) raw_free_on(q.first, q.second, dev);
 }
 }  // namespace
 
@@ -430,10 +519,10 @@ static int build_tables_on_device(GbnBatch &b) {
 }
 
 int upload_batch(GbnBatch &b) {
-    int rc = ensure_init();
+    int rc = enter_current();
     if (rc) return rc;
-    use_engine_device();
     DeviceBatch *d = new DeviceBatch();
+    d->eng = tl_eng;
     b.dev = d;
     trace_mark("upload: starts");
     HostLookup &L = b.lut;
@@ -570,9 +659,6 @@ static int grow_key_buffers(size_t n) {
     E.sort_tmp_bytes = bytes; E.key_cap = cap;
     return GBN_OK;
 }
-// which scan records E.bin_rec holds (GBN_REUSE_BINNING)
-struct BinKey { const void *db; int32_t s0, s1; int lut, step, nb, nwriters; size_t subcap; bool valid; };
-static BinKey g_binkey = {nullptr, 0, 0, 0, 0, 0, 0, 0, false};
 
 static int grow_ihit_buffers(int slot, size_t n) {
     if (n <= E.ihit_cap_s[slot]) return GBN_OK;
@@ -777,13 +863,13 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             size_t need = subcap * nstream;
             const size_t need_u64 = (GBN_REC_WORDS(need) + 1) / 2;
             if (need_u64 > E.bin_rec_cap) {
-                dev_free(E.bin_rec); E.bin_rec_cap = 0; g_binkey.valid = false;
+                dev_free(E.bin_rec); E.bin_rec_cap = 0; E.binkey.valid = false;
                 if ((rc = dev_alloc(E.bin_rec, need_u64))) return rc;
                 E.bin_rec_cap = need_u64;
             }
             const size_t nseq = ((size_t)((ts.ntiles + nwriters - 1) / nwriters) + ((size_t)1 << GBN_TCUR_SHIFT) - 1) >> GBN_TCUR_SHIFT;    // cursor entries per stream
             if (nstream * nseq > E.bin_tcur_cap) {
-                dev_free(E.bin_tcur); E.bin_tcur_cap = 0; g_binkey.valid = false;
+                dev_free(E.bin_tcur); E.bin_tcur_cap = 0; E.binkey.valid = false;
                 if ((rc = dev_alloc(E.bin_tcur, nstream * nseq))) return rc;
                 E.bin_tcur_cap = nstream * nseq;
             }
@@ -815,7 +901,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             // The scan records depend on the shard and on (lut width, stride) only, not on the queries.
             // GBN_REUSE_BINNING=1 (off by default; bench.py never sets it for the headline number) keeps
             // them for the next query batch with the same table shape: a database-side index held in HBM.
-            BinKey &have = g_binkey;
+            BinKey &have = E.binkey;
             const BinKey want_key = {(const void *)&db, s0, s1, b.lut.lut, b.lut.step, nb, nwriters, subcap, true};
             static const bool reuse = getenv("GBN_REUSE_BINNING") && atoi(getenv("GBN_REUSE_BINNING")) != 0;
             const bool hit = reuse && have.valid && have.db == want_key.db && have.s0 == s0 && have.s1 == s1 && have.lut == want_key.lut &&
@@ -1082,7 +1168,9 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         const int dev = E.device;
         const unsigned long long raw_probe = cnt[1];
         GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
+        Engine *eng = tl_eng;
         E.pending = std::async(std::launch::async, [=]() -> int {
+            tl_eng = eng;
             auto fail = [](int code, const char *what) { E.pending_err = what; return code; };
             if (hipSetDevice(dev) != hipSuccess) return fail(GBN_ERR_HIP, "hipSetDevice failed in the extension thread");
             GbnBinParams B = defer.B;
@@ -1142,7 +1230,9 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         E.pending_err.clear();
         const int dev = E.device;
         GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
+        Engine *eng = tl_eng;
         E.pending = std::async(std::launch::async, [=]() -> int {
+            tl_eng = eng;
             int r = GBN_OK;
             unsigned long long nih2 = 0;
             if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the extension thread"; return GBN_ERR_HIP; }
@@ -1167,7 +1257,9 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     E.pending_err.clear();
     const int dev = E.device;
     GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
+    Engine *eng = tl_eng;
     E.pending = std::async(std::launch::async, [=]() -> int {
+        tl_eng = eng;
         if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the gapped-stage thread"; return GBN_ERR_HIP; }
         const int r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih, E.stream2, true);
         if (r) E.pending_err = gbn_last_error();      // the error text is per thread
@@ -1185,15 +1277,13 @@ static int gapped_host(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResult
 // Host copies of a range's initial hits and gapped extensions: pinned buffers that are handed out again.  (Vectors
 // allocated and freed per range cost more than their pages: freeing memory the copy engine has just written to, while
 // the next range's kernels and copies run, stalls the device's queues -- the lane DP took 8.9 instead of 3.4 ms.)
-struct HitBuf { GbnDevInitHit *hih = nullptr; GbnDevGapped *hg = nullptr; size_t cap = 0; };
-static std::mutex g_hitbuf_mu; static std::vector<HitBuf> g_hitbuf_idle;
 static int hitbuf_get(size_t n, HitBuf &out) {
     {
-        std::lock_guard<std::mutex> lk(g_hitbuf_mu);
-        for (size_t i = 0; i < g_hitbuf_idle.size(); i++)
-            if (g_hitbuf_idle[i].cap >= n) { out = g_hitbuf_idle[i]; g_hitbuf_idle.erase(g_hitbuf_idle.begin() + (long)i); return GBN_OK; }
-        if (!g_hitbuf_idle.empty()) {           // too short: let one go, its successor is longer
-            HitBuf old = g_hitbuf_idle.back(); g_hitbuf_idle.pop_back();
+        std::lock_guard<std::mutex> lk(E.hitbuf_mu);
+        for (size_t i = 0; i < E.hitbuf_idle.size(); i++)
+            if (E.hitbuf_idle[i].cap >= n) { out = E.hitbuf_idle[i]; E.hitbuf_idle.erase(E.hitbuf_idle.begin() + (long)i); return GBN_OK; }
+        if (!E.hitbuf_idle.empty()) {           // too short: let one go, its successor is longer
+            HitBuf old = E.hitbuf_idle.back(); E.hitbuf_idle.pop_back();
             (void)hipHostFree(old.hih); (void)hipHostFree(old.hg);
         }
     }
@@ -1206,11 +1296,11 @@ static int hitbuf_get(size_t n, HitBuf &out) {
     out = b;
     return GBN_OK;
 }
-static void hitbuf_put(const HitBuf &b) { if (b.hih) { std::lock_guard<std::mutex> lk(g_hitbuf_mu); g_hitbuf_idle.push_back(b); } }
+static void hitbuf_put(const HitBuf &b) { if (b.hih) { std::lock_guard<std::mutex> lk(E.hitbuf_mu); E.hitbuf_idle.push_back(b); } }
 static void hitbuf_drain() {
-    std::lock_guard<std::mutex> lk(g_hitbuf_mu);
-    for (HitBuf &b : g_hitbuf_idle) { (void)hipHostFree(b.hih); (void)hipHostFree(b.hg); }
-    g_hitbuf_idle.clear();
+    std::lock_guard<std::mutex> lk(E.hitbuf_mu);
+    for (HitBuf &b : E.hitbuf_idle) { (void)hipHostFree(b.hih); (void)hipHostFree(b.hg); }
+    E.hitbuf_idle.clear();
 }
 
 static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag,
@@ -1277,9 +1367,11 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         putback.armed = false;                              // the buffers go back when the replay is done
         const size_t n_hits = (size_t)nih;
         GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
+        Engine *eng = tl_eng;
         std::lock_guard<std::mutex> lk(E.host_mu);
         std::shared_future<void> prev = E.host_tail;
         E.host_tail = std::async(std::launch::async, [=]() mutable {
+            enter(eng);
             if (prev.valid()) prev.wait();
             try {
                 const int r = gapped_host(*bp, *dbp, s0, s1, *rp, diag, 0, hb.hih, hb.hg, n_hits);
@@ -1385,10 +1477,10 @@ static int gapped_host(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResult
 // gather kernel and one copy on a stream of its own, next to whatever the search streams are doing.
 int gather_shard_bytes(const GbnDb &db, const std::vector<int64_t> &src_off, const std::vector<int32_t> &nbytes, std::vector<uint8_t> &out)
 {
-    static std::mutex mu; static hipStream_t st = nullptr;
-    int rc = ensure_init();
-    if (rc) return rc;
-    use_engine_device();
+    int rc = GBN_OK;
+    if (!db.engine) { set_error("gather_shard_bytes: shard without a device"); return GBN_ERR_ARG; }
+    enter(static_cast<Engine *>(db.engine));
+    std::mutex &mu = E.gather_mu; hipStream_t &st = E.gather_stream;
     const int32_t n = (int32_t)src_off.size();
     std::vector<int64_t> dst_off((size_t)n); int64_t total = 0;
     for (int32_t i = 0; i < n; i++) { dst_off[(size_t)i] = total; total += nbytes[(size_t)i]; }
@@ -1405,7 +1497,7 @@ int gather_shard_bytes(const GbnDb &db, const std::vector<int64_t> &src_off, con
     if (e == hipSuccess) e = launch_gather_bytes(db.d_packed, d_so, d_do, d_nb, n, d_out, st);
     // (through a pinned buffer that stays: a copy straight into the caller's fresh vector makes the runtime register those
     // pages, and their release next to running kernels stalls the device's queues -- see HitBuf)
-    static uint8_t *stage = nullptr; static size_t stage_cap = 0;
+    uint8_t *&stage = E.gather_stage; size_t &stage_cap = E.gather_stage_cap;
     if (e == hipSuccess && (size_t)total > stage_cap) {
         if (stage) (void)hipHostFree(stage);
         stage = nullptr; stage_cap = 0;
@@ -1432,39 +1524,70 @@ extern "C" {
 
 const char *gbn_last_error(void) { return g_err.c_str(); }
 
-int Blast_gpu_Init(int use_gpu, int gpu_id) {
-    std::lock_guard<std::mutex> lk(E.mu);
-    if (!use_gpu) { set_error("this engine has no CPU path: use_gpu must be true"); return GBN_ERR_NO_DEVICE; }
-    if (E.ready) return GBN_OK;
+}  // extern "C"
+namespace gbn {
+// the engine of device `dev` (< 0: the calling thread's current HIP device), created and initialised on first use
+static int engine_init(int dev, Engine **out) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device visible"); return GBN_ERR_NO_DEVICE; }
-    int dev = gpu_id;
     if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
-    if (dev >= n) { set_error("gpu_id out of range"); return GBN_ERR_ARG; }
+    if (dev >= n || dev >= kMaxDevices) { set_error("gpu_id out of range"); return GBN_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(g_eng_mu);
+    if (g_eng[dev] && g_eng[dev]->ready) { *out = g_eng[dev]; return GBN_OK; }
+    if (!g_eng[dev]) g_eng[dev] = new Engine();         // (after gbn_release the object is still there: armed again)
+    Engine &N = *g_eng[dev];
     HIPCHK(hipSetDevice(dev));
     hipDeviceProp_t prop;
     HIPCHK(hipGetDeviceProperties(&prop, dev));
-    E.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    N.num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     {   // the scan stream outranks the extension and table-builder streams: its kernels need whole CUs
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least, hi = greatest priority
         const bool prio = getenv("GBN_STREAM_PRIORITY") ? atoi(getenv("GBN_STREAM_PRIORITY")) != 0 : true;
-        HIPCHK(hipStreamCreateWithPriority(&E.stream, hipStreamNonBlocking, prio ? hi : 0));
-        HIPCHK(hipStreamCreateWithPriority(&E.stream2, hipStreamNonBlocking, prio ? lo : 0));
-        HIPCHK(hipStreamCreateWithPriority(&E.stream_build, hipStreamNonBlocking, prio ? lo : 0));
+        HIPCHK(hipStreamCreateWithPriority(&N.stream, hipStreamNonBlocking, prio ? hi : 0));
+        HIPCHK(hipStreamCreateWithPriority(&N.stream2, hipStreamNonBlocking, prio ? lo : 0));
+        HIPCHK(hipStreamCreateWithPriority(&N.stream_build, hipStreamNonBlocking, prio ? lo : 0));
     }
-    HIPCHK(hipEventCreate(&E.ev0)); HIPCHK(hipEventCreate(&E.ev1));
-    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&E.evk[i]));
-    HIPCHK(hipEventCreateWithFlags(&E.ev_seed, hipEventDisableTiming));
-    HIPCHK(pool_alloc((void **)&E.counters, 8 * sizeof(unsigned long long)));
-    E.device = dev; E.ready = true;
+    HIPCHK(hipEventCreate(&N.ev0)); HIPCHK(hipEventCreate(&N.ev1));
+    for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&N.evk[i]));
+    HIPCHK(hipEventCreateWithFlags(&N.ev_seed, hipEventDisableTiming));
+    HIPCHK(pool_alloc((void **)&N.counters, 8 * sizeof(unsigned long long)));
+    N.device = dev; N.ready = true;
+    if (g_default_dev < 0) g_default_dev = dev;
+    *out = g_eng[dev];
     return GBN_OK;
 }
+}  // namespace gbn
+extern "C" {
+
+int gbn_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0; }
+
+int gbn_init(int use_gpu, int gpu_id) {
+    if (!use_gpu) { set_error("this engine has no CPU path: use_gpu must be true"); return GBN_ERR_NO_DEVICE; }
+    Engine *e = nullptr;
+    const int rc = engine_init(gpu_id, &e);
+    if (rc) return rc;
+    tl_sel = e->device;
+    enter(e);
+    return GBN_OK;
+}
+// the device the calling thread's later gbn_db_new / gbn_batch_new* / gbn_blastdb_load_shard calls work on (the GPU
+// lease of GB/gpu_blast_multi_gpu_utils.cpp:105-139: ThreadFetchGPU does cudaSetDevice for the search thread)
+int gbn_use_device(int gpu_id) {
+    if (gpu_id < 0) { set_error("gbn_use_device: a device number"); return GBN_ERR_ARG; }
+    return gbn_init(1, gpu_id);
+}
+int gbn_current_device(void) {
+    if (tl_sel >= 0) return tl_sel;
+    std::lock_guard<std::mutex> lk(g_eng_mu);
+    return g_default_dev;
+}
+int gbn_db_device(const GbnDb *db) { return db && db->engine ? static_cast<const Engine *>(db->engine)->device : -1; }
 
 // Shards a caller keeps per database handle (the shim: per BlastSeqSrc).  The reference caches every subject it
-// has uploaded for the life of the process and gpu_ReleaseDBMemory drops that cache
+// has uploaded for the life of the process and gpu_ReleaseDBMemory (here: gbn_release_db_memory) drops that cache
 // (GB/gpu_blastn_MB_and_smallNa.cu:1462-1468, gpu_blastn_na_ungapped_v3.cpp:27-60); here the cache holds whole
-// shards, keyed by the caller's handle, and gpu_ReleaseDBMemory frees them.  Shards the caller made with
+// shards, keyed by the caller's handle, and gbn_release_db_memory frees them.  Shards the caller made with
 // gbn_db_from_* and did not insert stay the caller's.
 static std::mutex g_cache_mu;
 static std::map<const void *, GbnDb *> g_db_cache;
@@ -1481,17 +1604,19 @@ int gbn_db_cache_insert(const void *key, GbnDb *db) {
     g_db_cache[key] = db;
     return GBN_OK;
 }
-void gpu_ReleaseDBMemory(void) {
+void gbn_release_db_memory(void) {
     std::map<const void *, GbnDb *> drop;
     { std::lock_guard<std::mutex> lk(g_cache_mu); drop.swap(g_db_cache); }
     for (auto &kv : drop) gbn_db_free(kv.second);
 }
 
-void Blast_gpu_Release(void) {
+static void release_engine() {              // (the calling thread has entered it)
     std::lock_guard<std::mutex> lk(E.mu);
     if (!E.ready) return;
     (void)wait_pending();
-    g_binkey.valid = false;
+    (void)hipDeviceSynchronize();                       // nothing of ours is queued or running when buffers, streams and events go
+    (void)pool_check_guards();
+    E.binkey.valid = false;
     dev_free(E.slice_seg); E.slice_seg_cap = 0;
     hitbuf_drain();
     dev_free(E.seeds_async); E.seeds_async_cap = 0; if (E.ev_seed) { (void)hipEventDestroy(E.ev_seed); E.ev_seed = nullptr; }
@@ -1502,7 +1627,10 @@ void Blast_gpu_Release(void) {
     if (E.ev_r0) { (void)hipEventDestroy(E.ev_r0); (void)hipEventDestroy(E.ev_r1); E.ev_r0 = E.ev_r1 = nullptr; }
     E.bin_rec_cap = 0; E.bin_count_cap = 0;
     E.seed_cap = E.key_cap = 0;
-    use_engine_device();
+    if (E.gather_stage) (void)hipHostFree(E.gather_stage);
+    E.gather_stage = nullptr; E.gather_stage_cap = 0;
+    if (E.gather_stream) (void)hipStreamDestroy(E.gather_stream);
+    E.gather_stream = nullptr;
     if (E.ev0) (void)hipEventDestroy(E.ev0);
     if (E.ev1) (void)hipEventDestroy(E.ev1);
     for (int i = 0; i < 4; i++) { if (E.evk[i]) (void)hipEventDestroy(E.evk[i]); E.evk[i] = nullptr; }
@@ -1510,12 +1638,22 @@ void Blast_gpu_Release(void) {
     if (E.stream2) (void)hipStreamDestroy(E.stream2);
     if (E.stream_build) (void)hipStreamDestroy(E.stream_build);
     E.stream_build = nullptr;
-    pool_drain();
+    pool_drain(E.device);
     E.ev0 = E.ev1 = nullptr; E.stream = E.stream2 = nullptr; E.ready = false;
+}
+// every engine of the process: its stages finished, its device idle, its buffers, streams and events freed.  Batches,
+// shards and results made before stay valid handles to free, nothing else (as after the reference's ReleaseGPUs).
+void gbn_release(void) {
+    std::vector<Engine *> all;
+    { std::lock_guard<std::mutex> lk(g_eng_mu); for (int d = 0; d < kMaxDevices; d++) if (g_eng[d]) all.push_back(g_eng[d]); }
+    for (Engine *e : all) { enter(e); release_engine(); }
+    // (the Engine objects stay: handles made before the release still point at them; a later gbn_init re-arms them)
+    { std::lock_guard<std::mutex> lk(g_eng_mu); g_default_dev = -1; }
+    tl_eng = nullptr; tl_sel = -1;
 }
 
 // subjects appended one at a time (the shim: what BlastSeqSrcGetSequence hands out) into the slab layout of gbn_db_new
-struct GbnShardBuilder { std::vector<uint8_t> bytes; std::vector<int64_t> off; std::vector<int32_t> len; };
+struct GbnShardBuilder { std::vector<uint8_t> bytes; std::vector<int64_t> off; std::vector<int32_t> len, oid; bool explicit_oids = false; };
 int gbn_shard_builder_new(GbnShardBuilder **out, int32_t expected_seqs) {
     if (!out) return GBN_ERR_ARG;
     GbnShardBuilder *b = new (std::nothrow) GbnShardBuilder();
@@ -1523,6 +1661,13 @@ int gbn_shard_builder_new(GbnShardBuilder **out, int32_t expected_seqs) {
     if (expected_seqs > 0) { b->off.reserve(expected_seqs); b->len.reserve(expected_seqs); }
     *out = b;
     return GBN_OK;
+}
+int gbn_shard_builder_add_oid(GbnShardBuilder *b, int32_t oid, const uint8_t *ncbi2na, int32_t length) {
+    if (!b || oid < 0 || (!b->oid.empty() && oid <= b->oid.back()) || (b->oid.empty() && !b->len.empty())) {
+        set_error("gbn_shard_builder_add_oid: OIDs must ascend, and every subject of the shard needs one"); return GBN_ERR_ARG; }
+    const int rc = gbn_shard_builder_add(b, ncbi2na, length);
+    if (rc == GBN_OK) { b->oid.push_back(oid); b->explicit_oids = true; }
+    return rc;
 }
 int gbn_shard_builder_add(GbnShardBuilder *b, const uint8_t *ncbi2na, int32_t length) {
     if (!b || length < 0 || (length > 0 && !ncbi2na)) { set_error("gbn_shard_builder_add: bad argument"); return GBN_ERR_ARG; }
@@ -1539,8 +1684,10 @@ int gbn_shard_builder_finish(GbnShardBuilder *b, GbnDb **out) {
     if (!b || !out || b->len.empty()) { set_error("gbn_shard_builder_finish: no subjects"); return GBN_ERR_ARG; }
     try { b->bytes.resize(((b->bytes.size() + 15) & ~(size_t)15) + 128, 0); }
     catch (const std::bad_alloc &) { set_error("out of host memory"); return GBN_ERR_NOMEM; }
-    int rc = gbn_db_new(out, b->bytes.data(), (int64_t)b->bytes.size(), (int32_t)b->len.size(), b->off.data(), b->len.data(), 0, 0);
+    if (b->explicit_oids && b->oid.size() != b->len.size()) { set_error("gbn_shard_builder_finish: _add and _add_oid were mixed"); return GBN_ERR_ARG; }
+    int rc = gbn_db_new(out, b->bytes.data(), (int64_t)b->bytes.size(), (int32_t)b->len.size(), b->off.data(), b->len.data(), b->explicit_oids ? b->oid[0] : 0, 0);
     std::vector<uint8_t>().swap(b->bytes);
+    if (rc == GBN_OK && b->explicit_oids && b->oid.back() - b->oid[0] + 1 != (int32_t)b->oid.size()) (*out)->oid_map = b->oid;    // holes: the map
     return rc;
 }
 void gbn_shard_builder_free(GbnShardBuilder *b) { delete b; }
@@ -1557,10 +1704,10 @@ int gbn_set_max_dbseq_len(int32_t n) {
 int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_seqs,
                const int64_t *byte_off, const int32_t *len, int32_t first_oid, int is_device) {
     if (!out || !packed || num_seqs < 0 || (num_seqs > 0 && (!byte_off || !len))) { set_error("bad argument"); return GBN_ERR_ARG; }
-    int rc = ensure_init();
+    int rc = enter_current();
     if (rc) return rc;
-    use_engine_device();
     GbnDb *db = new GbnDb();
+    db->engine = tl_eng;
     db->first_oid = first_oid; db->real_seqs = num_seqs; db->chunk_len = g_max_dbseq_len;
     bool chunked = false;
     for (int32_t i = 0; i < num_seqs; i++) {
@@ -1638,13 +1785,14 @@ int gbn_db_set_ambiguities(GbnDb *db, int32_t local, int32_t n, const int32_t *s
 
 void gbn_db_free(GbnDb *db) {
     if (!db) return;
-    use_engine_device();
+    if (!db->engine) { delete db; return; }
+    enter(static_cast<Engine *>(db->engine));
     {   // a stage in flight may still read this shard
         std::lock_guard<std::mutex> lk(E.mu);
         if (E.has_pending) (void)wait_pending();
         wait_host();
+        if (E.binkey.db == (const void *)db) E.binkey.valid = false;
     }
-    if (g_binkey.db == (const void *)db) g_binkey.valid = false;
     free_tile_cache(*db);
     if (db->owns && db->d_packed) (void)hipFree((void *)db->d_packed);
     dev_free(db->d_byte_off); dev_free(db->d_len);
@@ -1654,9 +1802,8 @@ int64_t gbn_db_total_bases(const GbnDb *db) { return db ? db->total_bases : 0; }
 int32_t gbn_db_num_seqs(const GbnDb *db) { return db ? db->real_seqs : 0; }
 
 int gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream) {
-    int rc = ensure_init();
+    int rc = enter_current();
     if (rc) return rc;
-    use_engine_device();
     hipStream_t st = stream ? (hipStream_t)stream : E.stream;
     HIPCHK(launch_synth_fill(dev_ptr, nbytes, seed, st));
     HIPCHK(hipStreamSynchronize(st));
@@ -1692,7 +1839,8 @@ int gbn_batch_new(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8
 // (everything marked [caller] in gblastn_amd_kernels.h stays zero)
 static int params_ready(const GbnBatch *b, const GbnDb *db) {
     if (!b || !db || !b->dev) { set_error("batch without device structures (gbn_batch_new_ex upload = 0?)"); return GBN_ERR_ARG; }
-    use_engine_device();
+    if (b->dev->eng != db->engine) { set_error("the batch and the shard live on different devices"); return GBN_ERR_ARG; }
+    enter(b->dev->eng);
     if (b->dev->ready) HIPCHK(hipEventSynchronize(b->dev->ready));     // deferred lookup build
     return GBN_OK;
 }
@@ -1760,8 +1908,9 @@ int gbn_launch_gapped(const GbnGapParams *p, int greedy, void *stream) {
 }
 void gbn_batch_free(GbnBatch *b) {
     if (!b) return;
-    use_engine_device();
-    {   // an extension stage still reading this batch finishes first (its memory goes back to the pool, not to hipFree)
+    if (b->dev && b->dev->eng) {
+        enter(b->dev->eng);
+        // an extension stage still reading this batch finishes first (its memory goes back to the pool, not to hipFree)
         std::lock_guard<std::mutex> lk(E.mu);
         if (E.has_pending && E.pending_batch == b) (void)wait_pending();
         wait_host();                                        // (a queued host replay reads the batch's options and contexts)
@@ -1785,7 +1934,8 @@ int32_t gbn_batch_gap_x_dropoff(const GbnBatch *b) { return b->gap_x_dropoff; }
 int gbn_results_new(GbnResults **out) { if (!out) return GBN_ERR_ARG; *out = new GbnResults(); return GBN_OK; }
 void gbn_results_free(GbnResults *r) {
     if (!r) return;
-    {
+    if (r->engine) {                                        // a stage of the engine that filled them may still write to them
+        enter(static_cast<Engine *>(r->engine));
         std::lock_guard<std::mutex> lk(E.mu);
         if (E.has_pending && E.pending_res == r) (void)wait_pending();
         wait_host();
@@ -1801,13 +1951,21 @@ const GbnSeed *gbn_results_seeds(const GbnResults *r) { return r->seeds.data(); 
 int64_t gbn_results_num_init_hits(const GbnResults *r) { return (int64_t)r->init_hits.size(); }
 const GbnInitHit *gbn_results_init_hits(const GbnResults *r) { return r->init_hits.data(); }
 
+// argument checks of the search entry points; the calling thread enters the engine the batch and the shard live on
+static int search_enter(GbnBatch *batch, GbnDb *db, GbnResults *results) {
+    if (!batch || !db || !results) { set_error("bad argument"); return GBN_ERR_ARG; }
+    if (!batch->dev || !batch->dev->eng) { set_error("batch without device structures (gbn_batch_new_ex upload = 0?)"); return GBN_ERR_ARG; }
+    if (batch->dev->eng != db->engine) { set_error("the batch and the shard live on different devices"); return GBN_ERR_ARG; }
+    if (!batch->dev->eng->ready) { set_error("the engine was released (gbn_release) after this batch was made"); return GBN_ERR_ARG; }
+    if (results->engine && results->engine != db->engine) { set_error("results in use on another device"); return GBN_ERR_ARG; }
+    enter(batch->dev->eng);
+    return GBN_OK;
+}
 static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
                       int keep_stages, GbnInterruptFn interrupt, void *progress, int overlap) {
-    if (!batch || !db || !results) { set_error("bad argument"); return GBN_ERR_ARG; }
-    int rc = ensure_init();
-    if (rc) return rc;
-    use_engine_device();
-    std::lock_guard<std::mutex> lk(E.mu);
+    int rc = GBN_OK;
+    std::lock_guard<std::mutex> lk(E.mu);                   // (the caller has entered the engine: search_enter)
+    results->engine = tl_eng;
     auto t0 = std::chrono::steady_clock::now();
     trace_mark("search: entered");
     if (!db->real_of.empty()) results->chunk_len = db->chunk_len;
@@ -1862,7 +2020,9 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
 
 int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
                       int keep_stages, GbnInterruptFn interrupt, void *progress) {
-    int rc = run_search(batch, db, results, diag, keep_stages, interrupt, progress, 0);
+    int rc = search_enter(batch, db, results);
+    if (rc) return rc;
+    rc = run_search(batch, db, results, diag, keep_stages, interrupt, progress, 0);
     std::lock_guard<std::mutex> lk(E.mu);
     (void)wait_pending();                               // of an earlier gbn_prelim_search_begin (its status stays with its results)
     const int rc2 = take_failure(results);
@@ -1894,10 +2054,21 @@ int gbn_prelim_search_lists(GbnBatch *batch, GbnDb *db, GbnHspListFn sink, void 
 
 int gbn_prelim_search_begin(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
                             GbnInterruptFn interrupt, void *progress) {
-    return run_search(batch, db, results, diag, 0, interrupt, progress, 1);
+    const int rc = search_enter(batch, db, results);
+    return rc ? rc : run_search(batch, db, results, diag, 0, interrupt, progress, 1);
 }
 
 int gbn_prelim_search_end(GbnResults *results) {
+    // the engine that is filling these results; without results: whatever the calling thread's engine has in flight
+    if (results && results->engine) enter(static_cast<Engine *>(results->engine));
+    else if (results) return GBN_OK;                        // never searched: nothing in flight for them
+    else if (!tl_eng) {
+        Engine *e = nullptr;
+        { std::lock_guard<std::mutex> lk(g_eng_mu); const int d = tl_sel >= 0 ? tl_sel : g_default_dev; if (d >= 0) e = g_eng[d]; }
+        if (!e) return GBN_OK;
+        enter(e);
+    }
+    if (!E.ready) return GBN_OK;
     std::lock_guard<std::mutex> lk(E.mu);
     // a stage that belongs to other results stays in flight: these results were completed when that
     // stage was queued (one in flight at most)
@@ -1910,9 +2081,8 @@ int gbn_prelim_search_end(GbnResults *results) {
 
 int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag) {
     if (!batch || !db || repeats <= 0) { set_error("bad argument"); return GBN_ERR_ARG; }
-    int rc = ensure_init();
+    int rc = params_ready(batch, db);                       // (enters the engine both live on)
     if (rc) return rc;
-    use_engine_device();
     std::lock_guard<std::mutex> lk(E.mu);
     auto t0 = std::chrono::steady_clock::now();
     unsigned long long cnt[2] = {0, 0};
@@ -1929,5 +2099,8 @@ int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag)
     }
     return GBN_OK;
 }
+
+// tests (GBN_GUARD=1): guard zones of every pool block intact?  Aborts on the first violation, returns 0 otherwise.
+long gbn_debug_check_guards(void) { return pool_check_guards(); }
 
 }  // extern "C"

@@ -77,6 +77,7 @@ struct GbnDb {
     int64_t *d_byte_off = nullptr;
     int32_t *d_len = nullptr;
     void *tile_cache = nullptr;         // engine-private (tile tables per lut/step)
+    void *engine = nullptr;             // the device context (engine.cpp: Engine) the shard is resident on
     // Sequences longer than the engine's MAX_DBSEQ_LEN are held and searched as chunks of that length overlapping
     // by DBSEQ_CHUNK_OVERLAP (CORE/blast_engine.c:218-262, :455-540): num_seqs / byte_off / len above describe the
     // chunks -- subjects of their own to every kernel -- and these map them back.  Empty: nothing is chunked.
@@ -89,7 +90,16 @@ struct GbnDb {
     // fetched as eBlastEncodingNucleotide there).  Empty: no sequence has any.
     struct AmbRun { int32_t start, length; uint8_t code; };
     std::vector<std::vector<AmbRun>> amb;       // per sequence (sized on first use)
-    int32_t oid_of(int32_t v) const { return first_oid + (real_of.empty() ? v : real_of[(size_t)v]); }
+    // OIDs of the sequences when they are not first_oid, first_oid + 1, ... (a shard built from what a BlastSeqSrc
+    // iterator handed out: OID lists / GI filters leave holes); ascending.  Empty: contiguous from first_oid.
+    std::vector<int32_t> oid_map;
+    int32_t oid_of(int32_t v) const { const int32_t r = real_of.empty() ? v : real_of[(size_t)v]; return oid_map.empty() ? first_oid + r : oid_map[(size_t)r]; }
+    int32_t local_of(int32_t oid) const {       // the sequence's index in the shard, -1: not here
+        if (oid_map.empty()) { const int32_t l = oid - first_oid; return l >= 0 && l < real_seqs ? l : -1; }
+        size_t lo = 0, hi = oid_map.size();
+        while (lo < hi) { const size_t m = (lo + hi) / 2; if (oid_map[m] < oid) lo = m + 1; else hi = m; }
+        return lo < oid_map.size() && oid_map[lo] == oid ? (int32_t)lo : -1;
+    }
     int32_t chunk_of(int32_t v) const { return real_of.empty() ? 0 : chunk_ord[(size_t)v]; }
 };
 constexpr int32_t kDbseqChunkOverlap = 100;     // COREI/blast_hits.h:169
@@ -98,6 +108,7 @@ struct GbnResults {
     std::vector<GbnHSP> hsps;
     std::vector<GbnSeed> seeds;
     std::vector<GbnInitHit> init_hits;
+    void *engine = nullptr;             // the device context that fills / filled them (set by the search entry points)
     int32_t chunk_len = 0;              // > 0: hsps holds chunk lists (pad_ = ordinal + 1) that merge_chunk_lists has yet to join
 };
 

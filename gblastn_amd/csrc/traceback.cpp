@@ -688,8 +688,8 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
         const int32_t oid = hsps[list_start[l]].oid;
         int64_t e = l;
         while (e < nlists && hsps[list_start[e]].oid == oid) e++;
-        const int32_t local = oid - db->first_oid;         // the sequence's index in the shard (not a chunk's: db->real_*)
-        if (local < 0 || local >= db->real_seqs) { set_error("gbn_traceback_run: subject id outside this shard"); return GBN_ERR_ARG; }
+        const int32_t local = db->local_of(oid);           // the sequence's index in the shard (not a chunk's: db->real_*)
+        if (local < 0) { set_error("gbn_traceback_run: subject id outside this shard"); return GBN_ERR_ARG; }
         work.push_back(Work{local, l, e, 0, {}});
         l = e;
     }

@@ -5,11 +5,14 @@
  * Reference interface each entry point replaces (paths relative to
  * /root/reference/c++):
  *
- *   Blast_gpu_Init / Blast_gpu_Release
+ *   gbn_init / gbn_release      replace Blast_gpu_Init(bool, int) / Blast_gpu_Release()
  *       include/algo/blast/gpu_blast/gpu_blastn.h:50-51
  *       (defined src/algo/blast/gpu_blast/gpu_blast_multi_gpu_utils.cpp:176-183)
- *   gpu_ReleaseDBMemory
+ *   gbn_release_db_memory       replaces gpu_ReleaseDBMemory()
  *       include/algo/blast/gpu_blast/gpu_blastn_na_ungapped_v3.h:21
+ *       The reference declares those three with C++ linkage (no extern "C" anywhere in its tree), so a C library
+ *       cannot export them under their own names: gblastn_amd/shim/gpu_blastn_amd_shim.cpp defines them, with the
+ *       reference's signatures, as forwarders to the three functions above.
  *   gbn_db_*            replaces gpu_InitDBMemroy + the per-OID cudaMalloc cache
  *       src/algo/blast/gpu_blast/gpu_blastn_MB_and_smallNa.cu:140-146,1462-1468
  *       (one contiguous HBM slab per volume instead of one allocation per OID)
@@ -128,9 +131,20 @@ typedef struct GbnDiagnostics {
 typedef int (*GbnInterruptFn)(void *progress);   /* TInterruptFnPtr analogue */
 
 /* ---- process-level ---- */
-int  Blast_gpu_Init(int use_gpu, int gpu_id);
-void Blast_gpu_Release(void);
-void gpu_ReleaseDBMemory(void);     /* frees every shard held by the cache below (GB/gpu_blastn_na_ungapped_v3.h:21) */
+/* One engine (streams, scratch, device pool) per GPU, made on first use.  gbn_init arms the engine of `gpu_id`
+ * (< 0: the calling thread's current HIP device) and makes it the calling thread's device; the first one armed is
+ * the default of threads that never chose.  gbn_use_device = the same for a worker thread: the GPU lease of the
+ * reference's search threads (GB/gpu_blast_multi_gpu_utils.cpp:105-139 ThreadFetchGPU).  Objects remember their
+ * device: gbn_db_new / gbn_blastdb_load_shard / gbn_batch_new* create on the calling thread's device, every other
+ * call works on the device of the handles it is given, whatever thread makes it; a batch is searched against shards
+ * of its own device only.  Searches on different devices run concurrently, calls on one device are serialised. */
+int  gbn_init(int use_gpu, int gpu_id);
+int  gbn_device_count(void);
+int  gbn_use_device(int gpu_id);
+int  gbn_current_device(void);              /* of the calling thread; -1: none armed yet */
+void gbn_release(void);                     /* every engine: stages finished, device idle, buffers / streams / events freed */
+void gbn_release_db_memory(void);   /* frees every shard held by the cache below (GB/gpu_blastn_na_ungapped_v3.h:21) */
+long gbn_debug_check_guards(void);  /* tests, GBN_GUARD=1: guard zones around every device block of the pool intact? */
 /* shards kept per caller handle (the shim keys them by BlastSeqSrc*): the cache owns what is inserted */
 struct GbnDb;
 struct GbnDb *gbn_db_cache_find(const void *key);
@@ -164,9 +178,13 @@ int  gbn_set_max_dbseq_len(int32_t max_len);
 typedef struct GbnShardBuilder GbnShardBuilder;
 int  gbn_shard_builder_new(GbnShardBuilder **out, int32_t expected_seqs);
 int  gbn_shard_builder_add(GbnShardBuilder *b, const uint8_t *ncbi2na, int32_t length);
+/* ... with the subject's OID given (ascending; a BlastSeqSrc iterator over an OID list or a GI filter leaves holes,
+ * BlastSeqSrcIteratorNext COREI/blast_seqsrc.h:438): the HSPs carry these OIDs */
+int  gbn_shard_builder_add_oid(GbnShardBuilder *b, int32_t oid, const uint8_t *ncbi2na, int32_t length);
 int  gbn_shard_builder_finish(GbnShardBuilder *b, GbnDb **out);
 void gbn_shard_builder_free(GbnShardBuilder *b);
 int64_t gbn_db_total_bases(const GbnDb *db);
+int  gbn_db_device(const GbnDb *db);       /* the GPU the shard is resident on */
 int32_t gbn_db_num_seqs(const GbnDb *db);
 /* deterministic synthetic DB bytes generated on the device (bench/tests) */
 int  gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream);

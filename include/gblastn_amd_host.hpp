@@ -59,6 +59,7 @@ public:
         std::vector<const uint8_t *> p; std::vector<int32_t> len, mq, mf, mt;
         for (auto &s : q.seqs) { p.push_back(s.data()); len.push_back((int32_t)s.size()); }
         for (auto &m : q.masks) { mq.push_back(m.query); mf.push_back(m.from); mt.push_back(m.to); }
+        Check(gbn_use_device(gbn_db_device(db_)), "gbn_use_device");        // the batch lives on the shard's GPU, whatever thread sets it up
         Check(gbn_batch_new_masked(&b_, &opt, nq_, p.data(), len.data(), (int32_t)mq.size(), mq.data(), mf.data(), mt.data(), 1), "gbn_batch_new_masked");
         Check(gbn_results_new(&r_), "gbn_results_new");
     }
@@ -166,7 +167,9 @@ private:
     void Deliver(TItem it) { std::unique_lock<std::mutex> lk(mu_); done_[it->id] = std::move(it); cv_.notify_all(); }
     static void Guard(SWorkItem &it, const std::function<void()> &f) {
         if (it.status != GBN_OK) return;
-        try { f(); } catch (const CBlastException &e) { it.status = e.code; it.error = e.what(); }
+        try { f(); }
+        catch (const CBlastException &e) { it.status = e.code; it.error = e.what(); }
+        catch (const std::exception &e) { it.status = GBN_ERR_NOMEM; it.error = e.what(); }      // (std::bad_alloc in a worker thread is the item's status, not std::terminate)
     }
     // set-up of a batch (host part + lookup structures on the device) on two threads, at most three batches ahead of the search
     void SetupThread() {

@@ -65,6 +65,79 @@ def test_shim_translation_unit_is_shipped():
     assert "Blast_gpu_RunPreliminarySearchWithInterrupt" in txt and "Blast_RunPreliminarySearchWithInterrupt" in txt
 
 
+REF_INC = "/root/reference/c++/include"
+# what ./configure would have written into ncbiconf_unix.h for this platform (the reference tree ships none): macros on
+# the command line of THIS check only, over an empty file of that name in the test's temporary directory
+CONFIG_MACROS = ["NCBI_OS_UNIX=1", "NCBI_OS_LINUX=1", "NCBI_COMPILER_GCC=1", "HAVE_STRDUP=1", "HAVE_INTTYPES_H=1", "HAVE_STDINT_H=1",
+                 "HAVE_SYS_TYPES_H=1", "SIZEOF_CHAR=1", "SIZEOF_SHORT=2", "SIZEOF_INT=4", "SIZEOF_LONG=8", "SIZEOF_LONG_LONG=8",
+                 "SIZEOF_VOIDP=8", "SIZEOF___INT64=0", "SIZEOF_FLOAT=4", "SIZEOF_DOUBLE=8", "SIZEOF_LONG_DOUBLE=16", "SIZEOF_SIZE_T=8",
+                 "NCBI_PLATFORM_BITS=64"]
+# include/algo/blast/gpu_blast/gpu_blastn.h:31-51 -- its three prototypes without the includes of the work-thread
+# classes above them (those pull in the toolkit's generated object headers, which exist only in a configured build)
+GPU_BLASTN_H = """#ifndef __GPU_BLAST_H__
+#define __GPU_BLAST_H__
+#include <algo/blast/core/blast_hspstream.h>
+#include <algo/blast/core/blast_engine.h>
+Int2 Blast_gpu_RunPreliminarySearchWithInterrupt(EBlastProgramType program, BLAST_SequenceBlk* query,
+    BlastQueryInfo* query_info, const BlastSeqSrc* seq_src, const BlastScoringOptions* score_options, BlastScoreBlk* sbp,
+    LookupTableWrap* lookup_wrap, const BlastInitialWordOptions* word_options, const BlastExtensionOptions* ext_options,
+    const BlastHitSavingOptions* hit_options, const BlastEffectiveLengthsOptions* eff_len_options,
+    const PSIBlastOptions* psi_options, const BlastDatabaseOptions* db_options, const BlastGPUOptions* gpu_options,
+    BlastHSPStream* hsp_stream, BlastDiagnostics* diagnostics, TInterruptFnPtr interrupt_search, SBlastProgress* progress_info);
+int Blast_gpu_Init(bool isInit, int gpu_id);
+void Blast_gpu_Release();
+#endif
+"""
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_INC), reason="the reference tree is not on this machine")
+def test_shim_compiles_against_the_reference_headers_with_the_reference_linkage(tmp_path):
+    """The shim is the one file that binds to the reference interface: it must compile against the reference's own
+    core headers (blast_engine.h, blast_hspstream.h, blast_seqsrc.h, blast_nalookup.h, blast_hits.h, blast_util.h,
+    blast_diagnostics.h, gpu_blastn_na_ungapped_v3.h as they lie in /root/reference) and DEFINE the four entry points
+    with the C++ linkage those headers declare.  Pins no parity; stops the shim from rotting."""
+    (tmp_path / "ncbiconf_unix.h").write_text("")
+    d = tmp_path / "algo" / "blast" / "gpu_blast"
+    d.mkdir(parents=True)
+    (d / "gpu_blastn.h").write_text(GPU_BLASTN_H)
+    obj = tmp_path / "shim.o"
+    cmd = ["g++", "-std=c++11", "-Wall", "-Werror", "-c", "-o", str(obj), "-I", str(tmp_path), "-I", REF_INC, "-I", INC]
+    cmd += ["-D" + m for m in CONFIG_MACROS] + [os.path.join(ROOT, "gblastn_amd", "shim", "gpu_blastn_amd_shim.cpp")]
+    p = subprocess.run(cmd, capture_output=True, text=True)
+    assert p.returncode == 0, p.stderr[-4000:]
+    syms = subprocess.run(["nm", str(obj)], capture_output=True, text=True, check=True).stdout.split("\n")
+    defined = [l.split()[-1] for l in syms if " T " in l]
+    undefined = [l.split()[-1] for l in syms if l.strip().startswith("U ")]
+    # Itanium-mangled = C++ linkage, as src/app/blast/blastn_app.cpp:462-491 and prelim_search_runner.hpp:96 will look them up
+    for want in ("_Z14Blast_gpu_Initbi", "_Z17Blast_gpu_Releasev", "_Z19gpu_ReleaseDBMemoryv"):
+        assert want in defined, (want, defined)
+    assert any(s.startswith("_Z43Blast_gpu_RunPreliminarySearchWithInterrupt") for s in defined), defined
+    # everything it takes from this repository is a C symbol the library exports
+    L = api.lib()
+    ours = [s for s in undefined if s.startswith("gbn_")]
+    assert len(ours) >= 10
+    for s in ours:
+        assert hasattr(L, s), s
+
+
+def test_shard_builder_explicit_oids_host_checks():
+    L = api.lib()
+    sb = C.c_void_p()
+    assert L.gbn_shard_builder_new(C.byref(sb), 4) == 0
+    import numpy as np
+    a = np.zeros(8, dtype=np.uint8)
+    assert L.gbn_shard_builder_add_oid(sb, 5, a.ctypes.data, 20) == 0
+    assert L.gbn_shard_builder_add_oid(sb, 5, a.ctypes.data, 20) != 0     # OIDs ascend
+    assert L.gbn_shard_builder_add_oid(sb, 3, a.ctypes.data, 20) != 0
+    assert L.gbn_shard_builder_add_oid(sb, 9, a.ctypes.data, 20) == 0
+    L.gbn_shard_builder_free(sb)
+    sb = C.c_void_p()
+    assert L.gbn_shard_builder_new(C.byref(sb), 4) == 0
+    assert L.gbn_shard_builder_add(sb, a.ctypes.data, 20) == 0
+    assert L.gbn_shard_builder_add_oid(sb, 7, a.ctypes.data, 20) != 0     # not after a subject without one
+    L.gbn_shard_builder_free(sb)
+
+
 def test_shard_builder_rejects_bad_input():
     L = api.lib()
     sb = C.c_void_p()
@@ -74,4 +147,4 @@ def test_shard_builder_rejects_bad_input():
     assert L.gbn_shard_builder_finish(sb, C.byref(out)) != 0       # no subjects
     L.gbn_shard_builder_free(sb)
     assert L.gbn_db_cache_find(C.c_void_p(12345)) is None
-    L.gpu_ReleaseDBMemory()                                          # empty cache: nothing to do
+    L.gbn_release_db_memory()                                          # empty cache: nothing to do

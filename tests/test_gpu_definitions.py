@@ -221,8 +221,85 @@ def test_search_lists_shard_builder_and_cache():
     def failing(arg, oid, hsps, n):
         return 1
     assert L.gbn_prelim_search_lists(ps._b, h, failing, None, None, None, None) != 0
-    L.gpu_ReleaseDBMemory()                     # frees the cached shard
+    L.gbn_release_db_memory()                     # frees the cached shard
     assert L.gbn_db_cache_find(key) is None
+
+
+def test_shard_with_explicit_oids_and_holes():
+    """what the shim builds from a BlastSeqSrc iterator over an OID list: the HSPs carry the OIDs that were given, the
+    traceback stage finds its subjects by them"""
+    L = api.lib()
+    db, queries, plants, subjects, opt = util.small_case(10, 20000, 8, qlen=700, seed=11)
+    oids = [3, 4, 9, 20, 21, 22, 40, 41, 77, 100]
+    sb = C.c_void_p()
+    api._check(L.gbn_shard_builder_new(C.byref(sb), len(subjects)))
+    for (p, n), oid in zip(subjects, oids):
+        a = np.ascontiguousarray(p[:(n + 3) // 4])
+        api._check(L.gbn_shard_builder_add_oid(sb, oid, a.ctypes.data, n))
+    h = C.c_void_p()
+    api._check(L.gbn_shard_builder_finish(sb, C.byref(h)))
+    L.gbn_shard_builder_free(sb)
+    src = api.BlastSeqSrc(h)
+    assert L.gbn_db_device(h) == L.gbn_current_device() >= 0
+    got = api.BlastPrelimSearch(queries, opt, src).run()["hsps"]
+    want = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed(subjects)).run()["hsps"].copy()
+    assert len(want) > 0
+    want["oid"] = np.array(oids, dtype=np.int32)[want["oid"]]
+    assert got.tobytes() == want.tobytes()
+    # traceback over the same shard: subjects are looked up by OID
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    col = api.BlastHSPCollector(len(queries), opt.hitlist_size)
+    col.write(ps.run()["hsps"])
+    kept, starts, _ = col.close()
+    rec, ops, qs = api.BlastTracebackSearch(ps, src).run(kept, starts)
+    ref_src = api.BlastSeqSrc.from_packed(subjects)
+    ps2 = api.BlastPrelimSearch(queries, opt, ref_src)
+    col2 = api.BlastHSPCollector(len(queries), opt.hitlist_size)
+    col2.write(ps2.run()["hsps"])
+    kept2, starts2, _ = col2.close()
+    rec2, ops2, qs2 = api.BlastTracebackSearch(ps2, ref_src).run(kept2, starts2)
+    assert len(rec) == len(rec2) > 0 and ops == ops2
+    assert rec["oid"].tolist() == [oids[o] for o in rec2["oid"].tolist()]
+    assert rec["score"].tolist() == rec2["score"].tolist()
+    src.close(); ref_src.close()
+
+
+def test_two_host_threads_search_two_shards_concurrently():
+    """the re-entrant contract of the reference's entry point (N search threads, API/prelim_search_runner.hpp:135-166):
+    two threads, each with a shard and batches of its own, in flight at the same time == the same searches one after
+    the other.  (One GPU here: both threads lease device 0 and the engine serialises them call by call; with two
+    GPUs each thread calls gbn_use_device for its own.)"""
+    import threading
+    L = api.lib()
+    cases = [util.small_case(12, 60000, 10, qlen=800, seed=21), util.small_case(9, 80000, 12, qlen=600, seed=22, task="blastn", word_size=11)]
+    serial = []
+    for db, queries, plants, subjects, opt in cases:
+        src = api.BlastSeqSrc.from_packed(subjects)
+        serial.append(api.BlastPrelimSearch(queries, opt, src).run()["hsps"].tobytes())
+        src.close()
+    assert all(len(x) > 0 for x in serial)
+    out = [None, None]; err = []
+
+    def work(k):
+        try:
+            api._check(L.gbn_use_device(L.gbn_current_device()))
+            db, queries, plants, subjects, opt = cases[k]
+            src = api.BlastSeqSrc.from_packed(subjects)
+            res = []
+            for it in range(6):
+                ps = api.BlastPrelimSearch(queries, opt, src)
+                if it % 2: ps.begin(); res.append(ps.end()["hsps"].tobytes())
+                else: res.append(ps.run()["hsps"].tobytes())
+            out[k] = res
+            src.close()
+        except Exception as e:      # noqa
+            err.append(repr(e))
+    th = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in th: t.start()
+    for t in th: t.join()
+    assert not err, err
+    for k in range(2):
+        assert all(r == serial[k] for r in out[k]), k
 
 
 def test_parity_suite_through_the_two_kernel_seed_stage():
@@ -316,7 +393,7 @@ import sys, hashlib, numpy as np, torch
 sys.path.insert(0, %r)
 from gblastn_amd import api, synth
 nsub = 120
-api.lib().Blast_gpu_Init(1, 0)
+api.lib().gbn_init(1, 0)
 lay = synth.SynthDb(nsub, 1_000_000, seed=777)
 slab = torch.empty(lay.nbytes, dtype=torch.uint8, device="cuda")
 api._check(api.lib().gbn_synth_fill(slab.data_ptr(), lay.nbytes, lay.seed, None))

@@ -73,9 +73,9 @@ def test_no_gpu_is_reported_not_emulated():
     if torch.cuda.is_available():
         pytest.skip("GPU present")
     L = api.lib()
-    assert L.Blast_gpu_Init(1, -1) != 0
+    assert L.gbn_init(1, -1) != 0
     assert b"HIP device" in L.gbn_last_error()
-    assert L.Blast_gpu_Init(0, -1) != 0          # use_gpu = false is refused as well
+    assert L.gbn_init(0, -1) != 0          # use_gpu = false is refused as well
     with pytest.raises(api.BlastError):
         api.BlastPrelimSearch([np.zeros(64, dtype=np.uint8)], api.default_options("megablast"))
 

@@ -3,7 +3,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from gblastn_amd import api, synth
 nsub = 1000
-api.lib().Blast_gpu_Init(1, 0)
+api.lib().gbn_init(1, 0)
 lay = synth.SynthDb(nsub, 1_000_000, seed=12345)
 slab = torch.empty(lay.nbytes, dtype=torch.uint8, device="cuda")
 api._check(api.lib().gbn_synth_fill(slab.data_ptr(), lay.nbytes, lay.seed, None))

@@ -7,7 +7,7 @@ from gblastn_amd import api, synth
 
 passes = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 nsub = 1000
-api.lib().Blast_gpu_Init(1, 0)
+api.lib().gbn_init(1, 0)
 lay = synth.SynthDb(nsub, 1_000_000, seed=4242)
 slab = torch.empty(lay.nbytes, dtype=torch.uint8, device="cuda")
 api._check(api.lib().gbn_synth_fill(slab.data_ptr(), lay.nbytes, lay.seed, None))

@@ -8,7 +8,7 @@ from gblastn_amd import api, synth
 
 nsub = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
 nq = int(sys.argv[2]) if len(sys.argv) > 2 else 5000
-api.lib().Blast_gpu_Init(1, 0)
+api.lib().gbn_init(1, 0)
 lay = synth.SynthDb(nsub, 1_000_000, seed=12345)
 slab = torch.empty(lay.nbytes, dtype=torch.uint8, device="cuda")
 api._check(api.lib().gbn_synth_fill(slab.data_ptr(), lay.nbytes, lay.seed, None))
