@@ -74,11 +74,13 @@ const char *kUsage =
     "usage: blastn_prelim -db NAME (-query FASTA | -query_list FILE) -use_gpu true [-gpu_id N] [-out FILE]\n"
     "       [-task megablast|blastn] [-word_size N] [-evalue X] [-reward N] [-penalty N] [-gapopen N]\n"
     "       [-gapextend N] [-dust yes|no|'level window linker'] [-max_target_seqs N] [-outfmt 6|7] [-mode 0|1|2]\n"
-    "       [-stage traceback|prelim] [-trace_t_num N] [-num_threads N (ignored)] [-strand both]\n"
-    "       -gpu_id -1 (the default) = the first device; the reference's \"-gpu_id -1 = all devices\" is a launcher here:\n"
-    "         python -m torch.distributed.run --nproc-per-node N -m gblastn_amd.blastn_sharded -db NAME -query FASTA ...\n"
-    "         (one process per GPU, the database sharded by volume, the same rows)\n"
-    "       -num_threads: the GPU replaces the search threads; host threads: -mode 2 set-up threads, -trace_t_num\n"
+    "       [-stage traceback|prelim] [-trace_t_num N] [-num_threads N] [-strand both]\n"
+    "       -gpu_id N: that device; -gpu_id -1 (the default): every device of the node, as in the reference\n"
+    "         (GB/gpu_blast_multi_gpu_utils.cpp:43-68): the database's volumes are dealt to the GPUs in contiguous runs,\n"
+    "         one search thread (pipeline) per GPU in this process, results merged per query\n"
+    "       -num_threads N: search threads = database parts (default: one per GPU used); more parts than GPUs share them\n"
+    "         round robin (N > 1 on one GPU exercises the same merge); host threads besides: -mode 2 set-up threads, -trace_t_num\n"
+    "       (one process per GPU instead: python -m torch.distributed.run --nproc-per-node N -m gblastn_amd.blastn_sharded ...)\n"
     "       environment BATCH_SIZE overrides the query batch size\n";
 
 // e-value and bit score as the reference's formatter prints them (objtools/align_format/align_format_util.cpp:669-723)
@@ -133,12 +135,35 @@ int main(int argc, char **argv)
     for (auto &f : files) if (!read_fasta(f, queries, err)) die(err);
     if (queries.empty()) die("no query sequences");
 
-    // ---- database: every volume into one resident shard ----
-    check(gbn_init(1, std::atoi(get("gpu_id", "-1").c_str())), "gbn_init");
+    // ---- database: its volumes dealt to the GPUs in contiguous runs (one resident shard per search thread), global OIDs ----
+    const int gpu_id = std::atoi(get("gpu_id", "-1").c_str());
+    const int ndev_all = gbn_device_count();
+    if (ndev_all < 1) die("no HIP device visible");
+    std::vector<int> devices;
+    if (gpu_id >= 0) devices.push_back(gpu_id); else for (int d = 0; d < ndev_all; d++) devices.push_back(d);
+    for (int d : devices) check(gbn_init(1, d), "gbn_init");
     GbnBlastDb *bdb = nullptr;
     check(gbn_blastdb_open(&bdb, a["db"].c_str()), "gbn_blastdb_open");
-    GbnDb *shard = nullptr;
-    check(gbn_blastdb_load_shard(bdb, 0, gbn_blastdb_num_seqs(bdb), &shard), "gbn_blastdb_load_shard");
+    const int32_t nvol = gbn_blastdb_num_volumes(bdb);
+    int nparts = a.count("num_threads") ? std::max(1, std::atoi(a["num_threads"].c_str())) : (int)devices.size();
+    nparts = std::max(1, std::min(nparts, (int)nvol));                  // (a volume is not split)
+    struct Part { int device; GbnDb *shard = nullptr; };
+    std::vector<Part> parts((size_t)nparts);
+    {   // shard_bounds of gblastn_amd/shard.py: part p holds volumes [p * V / P, (p + 1) * V / P); loaded in parallel
+        std::vector<std::future<std::string>> loads;
+        for (int p = 0; p < nparts; p++) {
+            parts[(size_t)p].device = devices[(size_t)p % devices.size()];
+            loads.push_back(std::async(std::launch::async, [&, p]() -> std::string {
+                const int32_t v0 = (int32_t)((int64_t)p * nvol / nparts), v1 = (int32_t)((int64_t)(p + 1) * nvol / nparts);
+                int32_t first = 0, n0 = 0, last_first = 0, last_n = 0;
+                if (gbn_blastdb_volume_range(bdb, v0, &first, &n0) || gbn_blastdb_volume_range(bdb, v1 - 1, &last_first, &last_n)) return "gbn_blastdb_volume_range failed";
+                if (gbn_use_device(parts[(size_t)p].device)) return std::string("gbn_use_device: ") + gbn_last_error();
+                if (gbn_blastdb_load_shard(bdb, first, last_first + last_n - first, &parts[(size_t)p].shard)) return std::string("gbn_blastdb_load_shard: ") + gbn_last_error();
+                return "";
+            }));
+        }
+        for (auto &f : loads) { const std::string e = f.get(); if (!e.empty()) die(e); }
+    }
 
     // ---- options (API/blast_nucl_options.cpp defaults of the task, then the flags) ----
     GbnOptions opt; gbn_default_options(&opt, task == "megablast");
@@ -202,10 +227,7 @@ int main(int argc, char **argv)
         return q;
     };
     // the twelve standard columns of a final alignment: qseqid sseqid pident length mismatch gapopen qstart qend sstart send evalue bitscore
-    auto emit_final = [&](const Batch &bt, const gbn::CSearchPipeline::SWorkItem &it) {
-        const GbnTraceback *tb = it.traceback->Results();
-        const GbnTbHSP *h = gbn_traceback_hsps(tb); const int64_t *qs = gbn_traceback_query_starts(tb);
-        const GbnContext *ctx = gbn_batch_contexts(it.prelim->Batch());
+    auto emit_final = [&](const Batch &bt, const GbnTbHSP *h, const int64_t *qs, const GbnContext *ctx) {
         for (size_t k = 0; k < bt.count; k++) {
             const Query &q = queries[bt.first + k];
             if (outfmt == 7) {
@@ -230,8 +252,7 @@ int main(int argc, char **argv)
         }
     };
     // -stage prelim: the score-only HSPs the collector kept, per query best subject first
-    auto emit_prelim = [&](const Batch &bt, const gbn::CSearchPipeline::SWorkItem &it) {
-        const GbnCollector *col = it.stream->Get();
+    auto emit_prelim = [&](const Batch &bt, const GbnCollector *col, const gbn::CSearchPipeline::SWorkItem &it) {
         const int64_t nl = gbn_collector_num_lists(col); const int64_t *st = gbn_collector_list_starts(col);
         const int32_t *lq = gbn_collector_list_queries(col); const GbnHSP *h = gbn_collector_hsps(col);
         const GbnContext *ctx = gbn_batch_contexts(it.prelim->Batch());
@@ -266,28 +287,67 @@ int main(int argc, char **argv)
 
     GbnDiagnostics diag; std::memset(&diag, 0, sizeof(diag));
     try {
-        gbn::CBlastSeqSrc src(shard, false);
-        gbn::CSearchPipeline pipe(opt, src, trace_threads, with_traceback, overlapped);
+        // one pipeline (set-up threads -> search thread -> traceback consumers) per part, each on its part's GPU: the
+        // search threads of the reference with a GPU each (API/prelim_search_runner.hpp:135-166, GB/gpu_blast_multi_gpu_utils.cpp:105-139)
+        std::vector<std::unique_ptr<gbn::CBlastSeqSrc>> srcs; std::vector<std::unique_ptr<gbn::CSearchPipeline>> pipes;
+        for (Part &pt : parts) {
+            srcs.emplace_back(new gbn::CBlastSeqSrc(pt.shard, false));
+            pipes.emplace_back(new gbn::CSearchPipeline(opt, *srcs.back(), trace_threads, with_traceback, overlapped));
+        }
         // batches enter a few ahead of the results coming out (a batch holds its lookup tables in HBM until printed)
         size_t submitted = 0, printed = 0;
         const size_t ahead = overlapped ? 8 : 1;
         while (printed < batches.size()) {
-            while (submitted < batches.size() && submitted < printed + ahead) { pipe.Submit(make_batch(batches[submitted])); submitted++; }
-            if (submitted == batches.size()) pipe.Finish();
-            gbn::CSearchPipeline::TItem it = pipe.Next();
-            if (!it) die("the pipeline ended early");
-            if (it->status != GBN_OK) die(it->error);
-            const GbnDiagnostics &d = it->prelim->diagnostics;
-            diag.subject_bases_scanned += d.subject_bases_scanned; diag.seeds += d.seeds; diag.gapped_extensions += d.gapped_extensions; diag.total_ms += d.total_ms;
-            if (with_traceback) emit_final(batches[printed], *it); else emit_prelim(batches[printed], *it);
+            while (submitted < batches.size() && submitted < printed + ahead) {
+                for (auto &pp : pipes) pp->Submit(make_batch(batches[submitted]));
+                submitted++;
+            }
+            if (submitted == batches.size()) for (auto &pp : pipes) pp->Finish();
+            std::vector<gbn::CSearchPipeline::TItem> items;
+            for (auto &pp : pipes) {
+                gbn::CSearchPipeline::TItem it = pp->Next();
+                if (!it) die("the pipeline ended early");
+                if (it->status != GBN_OK) die(it->error);
+                const GbnDiagnostics &d = it->prelim->diagnostics;
+                diag.subject_bases_scanned += d.subject_bases_scanned; diag.seeds += d.seeds; diag.gapped_extensions += d.gapped_extensions;
+                diag.total_ms = std::max(diag.total_ms, d.total_ms);
+                items.push_back(std::move(it));
+            }
+            const Batch &bt = batches[printed];
+            const GbnContext *ctx = gbn_batch_contexts(items[0]->prelim->Batch());
+            if (with_traceback) {
+                if (items.size() == 1) {
+                    const GbnTraceback *tb = items[0]->traceback->Results();
+                    emit_final(bt, gbn_traceback_hsps(tb), gbn_traceback_query_starts(tb), ctx);
+                } else {        // the parts' final lists -> the database's: per query best e-value, score, OID; hit-list cut
+                    std::vector<const GbnTbHSP *> hp; std::vector<const int64_t *> qp; int64_t total = 0;
+                    for (auto &it : items) {
+                        const GbnTraceback *tb = it->traceback->Results();
+                        hp.push_back(gbn_traceback_hsps(tb)); qp.push_back(gbn_traceback_query_starts(tb)); total += gbn_traceback_num_hsps(tb);
+                    }
+                    std::vector<GbnTbHSP> merged((size_t)std::max<int64_t>(total, 1)); std::vector<int64_t> mq(bt.count + 1);
+                    if (gbn_traceback_merge((int32_t)items.size(), hp.data(), qp.data(), (int32_t)bt.count, opt.hitlist_size, merged.data(), mq.data()) < 0) die("gbn_traceback_merge failed");
+                    emit_final(bt, merged.data(), mq.data(), ctx);
+                }
+            } else if (items.size() == 1) emit_prelim(bt, items[0]->stream->Get(), *items[0]);
+            else {              // the lists every part's collector kept, through one collector in ascending OID order (parts ascend)
+                gbn::CBlastHSPStream all((int32_t)bt.count, opt.hitlist_size);
+                for (auto &it : items) {
+                    const GbnCollector *c = it->stream->Get();
+                    gbn::Check(gbn_collector_write(all.Get(), gbn_collector_hsps(c), gbn_collector_num_hsps(c)), "gbn_collector_write");
+                }
+                all.Close();
+                emit_prelim(bt, all.Get(), *items[0]);
+            }
             printed++;
         }
-        pipe.Close();
+        for (auto &pp : pipes) pp->Close();
     } catch (const gbn::CBlastException &e) { die(e.what()); }
     std::fprintf(stderr, "blastn_prelim: %zu queries in %zu batches, %lld subject bases scanned, %lld seeds, %lld gapped extensions, %.1f ms in the preliminary stage\n",
                  queries.size(), batches.size(), (long long)diag.subject_bases_scanned, (long long)diag.seeds,
                  (long long)diag.gapped_extensions, diag.total_ms);
     if (out != stdout) std::fclose(out);
-    gbn_db_free(shard); gbn_blastdb_close(bdb); gbn_release();
+    for (Part &pt : parts) gbn_db_free(pt.shard);
+    gbn_blastdb_close(bdb); gbn_release();
     return 0;
 }

@@ -181,3 +181,29 @@ def test_cli_final_rows_equal_the_oracle(tmp_path, task, mode, batch):
     assert first["exact_1500"][1] == "gnl|BL_ORD_ID|1500" and first["exact_1500"][2] == "100.00" and first["exact_1500"][5] == "0"
     assert first["mutated_10"][1] == "gnl|BL_ORD_ID|10" and int(first["mutated_10"][5]) >= 1 and int(first["mutated_10"][4]) >= 8
     assert first["revcomp_777"][1] == "gnl|BL_ORD_ID|777" and int(first["revcomp_777"][8]) > int(first["revcomp_777"][9])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,stage,mode,batch", [("megablast", "traceback", "1", None), ("blastn", "traceback", "2", "900"),
+                                                   ("megablast", "prelim", "2", "900"), ("blastn", "prelim", "1", None)])
+def test_cli_search_threads_over_database_parts_give_the_rows_of_one(tmp_path, task, stage, mode, batch):
+    """-gpu_id -1 / -num_threads N: the volumes of the alias dealt to N search threads (one pipeline and one resident
+    shard each, on the node's GPUs round robin -- both on the one GPU of this box), per-part results merged per query in
+    the process (gbn_traceback_merge / one collector): the rows of one thread over the whole database."""
+    db = api.BlastDb(DB)
+    qs = _queries(db)
+    fa = tmp_path / "q.fa"
+    fa.write_text("".join(">%s some description\n%s\n" % (n, "".join(IUPAC[int(x)] for x in s)) for n, s in qs))
+    two = os.path.join(ROOT, "tests", "golden", "two_vols")
+    env = dict(os.environ)
+    if batch:
+        env["BATCH_SIZE"] = batch
+    rows = {}
+    for n in ("1", "2"):
+        out = tmp_path / ("out%s.tsv" % n)
+        p = subprocess.run([CLI, "-db", two, "-query", str(fa), "-task", task, "-use_gpu", "true", "-gpu_id", "-1", "-num_threads", n,
+                            "-mode", mode, "-stage", stage, "-evalue", "1e-3", "-max_target_seqs", "5", "-out", str(out)],
+                           capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        rows[n] = out.read_text().splitlines()
+    assert len(rows["1"]) >= 4 and rows["1"] == rows["2"]
