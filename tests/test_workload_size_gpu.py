@@ -1,0 +1,142 @@
+"""-m gpu: oracle parity AT WORKLOAD SIZE with the engine's default thresholds (nothing forced by the environment).
+
+C3 (BASELINE.json configs[2]): one full subject range of the blastn shape -- 1,000 x 1 Mb subjects on the device, one
+100-query batch, W=11 (lut 11 = word size, stride 1): 4.7e7 seeds in one launch, i.e. scan_slice_kernel, the
+composite-key sort (seed_ckeys_kernel + one radix sort), seed_ext_kernel + diag_replay_kernel, the lane / wave DP
+kernels, and the host replay on up to 16 threads -- detached behind the stage's thread in the pipelined form.  Every
+subject of the range goes through the oracle (0.04 s each).
+
+C4 (configs[3]): three 5 Mb query batches streamed through the host pipeline against the 50 Gbp shard, traceback
+overlapped; the final rows (coordinates, scores, e-value and bit-score bits, identities, edit scripts) of every
+(query, subject) list of every subject that has one, plus sampled subjects that have none, against the oracle's
+preliminary search + traceback of that subject.
+
+Reference edges: CORE/na_ungapped.c:778-922 (hash container + ungapped extension), CORE/blast_gapalign.c:3351-3548
+(acceptance loop), CORE/blast_traceback.c:336-790."""
+import numpy as np
+import pytest
+from gblastn_amd import api, synth
+from oracle import orc
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+HSP_FIELDS = ["oid", "context", "q_offset", "q_end", "q_gapped_start", "s_offset", "s_end", "s_gapped_start", "score"]
+
+
+def device_db(nsub, slen, seed):
+    import torch
+    db = synth.SynthDb(nsub, slen, seed=seed)
+    slab = torch.empty(db.nbytes, dtype=torch.uint8, device="cuda")
+    api._check(api.lib().gbn_synth_fill(slab.data_ptr(), db.nbytes, db.seed, None))
+    src = api.BlastSeqSrc.from_slab((slab.data_ptr(), db.nbytes), db.byte_off, db.lens, is_device=True, keep=slab)
+    return db, src
+
+
+def test_full_size_c3_range_with_default_thresholds_against_the_oracle(monkeypatch):
+    for k in ("GBN_DIAG_COMPACT_MIN", "GBN_SEED_CKEYS", "GBN_SCAN_SLICE", "GBN_SCAN_BINS", "GBN_HOST_DETACH", "GBN_GAP_LANE",
+              "GBN_RANGE_MIB", "GBN_RANGE_TILES", "GBN_RANGE_GIB"):
+        monkeypatch.delenv(k, raising=False)
+    nsub, slen, nq = 1000, 1_000_000, 100
+    db, src = device_db(nsub, slen, 0x9E3779B97F4A7C15 ^ 3)
+    queries, plants = synth.make_queries(nq, db)
+    assert len(plants) >= 10
+    # the statistics of the whole 5 Gbp database this range is a fifth of (global lengths: CORE/blast_setup.c:638)
+    opt = api.default_options("blastn", db_length=5000 * slen, db_num_seqs=5000, word_size=11)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    info = ps.info()
+    assert (info["lut_width"], info["scan_step"], info["container"], info["scan_path"]) == (11, 1, 1, 2), info
+
+    first = ps.run()["hsps"]
+    d = ps.diagnostics
+    got_diag = (int(d.lookup_hits), int(d.seeds), int(d.init_extends), int(d.good_init_extends), int(d.gapped_extensions), int(d.good_extensions))
+    assert int(d.scan_launches) == 1 and int(d.seeds) > (1 << 20)          # ONE launch far above the two-kernel threshold
+    assert int(d.gapped_extensions) > 20000                                # ... and above the multi-thread replay's
+    again = ps.run()["hsps"]
+    assert first.tobytes() == again.tobytes()                              # deterministic
+    # pipelined form: the range's gapped stage on the second stream, its host replay detached on a queue of its own
+    ps.begin(); piped = ps.end()["hsps"]
+    assert piped.tobytes() == first.tobytes()
+    ps2 = api.BlastPrelimSearch(queries, opt, src)                         # a second batch scanned while the first one's stages run
+    ps.begin(); ps2.begin()
+    a = ps.end()["hsps"]; b = ps2.end()["hsps"]
+    assert a.tobytes() == first.tobytes() and b.tobytes() == first.tobytes()
+
+    s = orc.Search(util.oracle_options(opt), queries)
+    oi = s.info()
+    assert (oi["lut_type"], oi["lut_width"], oi["scan_step"], oi["container"]) == (info["lut_type"], 11, 1, 1)
+    nseeds = nih = 0
+    want = []
+    for oid in range(nsub):
+        o = s.subject(db.subject_packed(oid), slen)
+        nseeds += len(o["seeds"]); nih += len(o["init_hits"])
+        g = first[first["oid"] == oid]
+        assert len(g) == len(o["hsps"]), (oid, len(g), len(o["hsps"]))
+        for f in HSP_FIELDS[1:]:
+            assert np.array_equal(g[f], o["hsps"][f]), (oid, f)
+        assert np.array_equal(g["evalue"].view(np.uint64), o["hsps"]["evalue"].view(np.uint64)), oid
+        want.append(len(o["hsps"]))
+    st = s.stats
+    assert got_diag == (int(st.lookup_hits), nseeds, nih, int(st.good_init_extends), int(st.gapped_extensions), int(st.good_extensions)), \
+        (got_diag, (int(st.lookup_hits), nseeds, nih, int(st.good_init_extends), int(st.gapped_extensions), int(st.good_extensions)))
+    assert sum(want) == len(first) and sum(1 for w in want if w) >= len(plants) * 0.9
+    found = set(first["oid"].tolist())
+    assert sum(1 for p in plants if p["subject"] in found) >= 0.9 * len(plants)
+
+
+def test_full_size_c4_streamed_batches_final_rows_against_the_oracle(monkeypatch):
+    for k in ("GBN_DIAG_COMPACT_MIN", "GBN_RANGE_MIB", "GBN_RANGE_TILES", "GBN_RANGE_GIB", "GBN_SCAN_BINS", "GBN_DEFER_RARE", "GBN_REUSE_BINNING"):
+        monkeypatch.delenv(k, raising=False)
+    nsub, slen, per, nbatch = 50_000, 1_000_000, 5_000, 3
+    db, src = device_db(nsub, slen, 0x9E3779B97F4A7C15 ^ 1)
+    opt = api.default_options("megablast", db_length=nsub * slen, db_num_seqs=nsub)
+    batches = []
+    for k in range(nbatch):
+        q, plants = synth.make_queries(per, db, first_query_id=k * per)
+        batches.append((q, plants))
+    pipe = api.SearchPipeline(opt, src, trace_threads=4, traceback=True, overlap=True)
+    for k in range(nbatch):
+        assert pipe.submit(batches[k][0]) == k
+    pipe.finish()
+    got = {}
+    while True:
+        r = pipe.next()
+        if r is None:
+            break
+        k, (rec, ops, qstarts), dg = r
+        assert k == len(got)                                    # submission order
+        assert int(dg.subject_bases_scanned) == nsub * slen and int(dg.scan_launches) == 1
+        got[k] = (rec, ops)
+    pipe.close()
+    assert len(got) == nbatch
+    from tests.test_traceback_gpu import compare
+    rng = np.random.default_rng(5)
+    total = 0
+    for k in range(nbatch):
+        queries, plants = batches[k]
+        rec, ops = got[k]
+        prod = {}
+        for r, o in zip(rec, ops):
+            prod.setdefault((int(r["context"]) // 2, int(r["oid"])), []).append((r, o))
+        hit = sorted(set(int(o) for o in rec["oid"]))
+        assert len(set(p["subject"] for p in plants) & set(hit)) >= 0.9 * len(set(p["subject"] for p in plants))
+        sample = sorted(set(hit) | set(rng.choice(nsub, 10, replace=False).tolist()) | set(p["subject"] for p in plants))
+        s = orc.Search(util.oracle_options(opt), queries)
+        ora = {}
+        for oid in sample:
+            packed = db.subject_packed(oid)
+            o = s.subject(packed, slen)
+            if not len(o["hsps"]):
+                continue
+            # (hit lists are far from full at this shape -- at most a few subjects per query against 550 kept -- so the
+            # collector keeps every list; it is applied all the same)
+            col = orc.Collector(len(queries), opt.hitlist_size)
+            col.write(oid, [dict(zip(o["hsps"].dtype.names, x)) for x in o["hsps"]])
+            bases = orc.unpack_ncbi2na(packed, slen)
+            for _, q, hs in col.close():
+                fin = s.traceback(bases, [dict(zip(orc.Collector.FIELDS, h)) for h in hs])
+                if fin:
+                    ora[(q, oid)] = fin
+        total += compare(prod, ora)                             # same set of (query, subject) lists, same rows, same scripts
+        s.close()
+    assert total >= 0.15 * per * nbatch                         # ~20 % of the queries carry a planted homolog
