@@ -50,6 +50,12 @@ def parse():
     ap.add_argument("--cpu-cores", type=int, default=0, help="processes of the CPU baseline (0: half of the host cores, at most 64)")
     ap.add_argument("--no-overlap", action="store_true", help="run every pass to completion before the next starts")
     ap.add_argument("--engine-steps", type=int, default=8, help="passes of the side measurement on reused query batches (engine entry point alone); 0: skip")
+    ap.add_argument("--min-seconds", type=float, default=2.0,
+                    help="the timed region of --steps passes is repeated until this much time has been measured; the line reports the "
+                         "median region (ms_per_step, value) and the spread (ms_per_step_minmax, regions)")
+    ap.add_argument("--no-side-workloads", action="store_true",
+                    help="skip the short C3 / C4 side measurements (config.other_workloads) of the default C2 run")
+    ap.add_argument("--side", action="store_true", help=argparse.SUPPRESS)    # this process IS a side measurement
     ap.add_argument("--reuse-binning", action="store_true",
                     help="NOT the headline metric: keep the query-independent scan records of the shard in HBM and "
                          "skip the binning kernel for later batches with the same table shape (a database index)")
@@ -220,8 +226,26 @@ def main():
     batch_setup_ms = (time.perf_counter() - t_setup) * 1e3      # one set-up alone, lookup structures complete
     probe_batch.close()
     run_passes(args.warmup, [])
-    diags = []
-    nhsp, elapsed = timed(lambda: run_passes(args.steps, diags))
+    # The timed region = exactly --steps passes between barrier + synchronize on both sides.  A short region (the driver's
+    # 20 steps = 0.3 s) is mostly the pipeline's ramp -- first set-up alone, last extension stage and merge -- and one
+    # box-noise sample: it is repeated until --min-seconds are measured, the MEDIAN region is the line's ms_per_step /
+    # value, minimum and maximum are reported beside it.
+    regions = []
+    while True:
+        dg = []
+        nh, el = timed(lambda: run_passes(args.steps, dg))
+        regions.append((el, nh, dg))
+        spent = sum(r[0] for r in regions)
+        more = spent < args.min_seconds and len(regions) < 64
+        if world > 1:                                           # every rank takes the same decision
+            t = torch.tensor([1.0 if more else 0.0], dtype=torch.float64, device=dev)
+            dist.broadcast(t, src=0)
+            more = bool(t.item() > 0.5)
+        if not more:
+            break
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    elapsed, nhsp, diags = regions[order[(len(order) - 1) // 2]]
+    region_ms = [r[0] / args.steps * 1e3 for r in regions]
 
     # ---- beside it: the engine entry point alone, on query batches set up once and reused (their lookup
     # tables are inputs of the entry point).  Not the headline number.
@@ -263,13 +287,14 @@ def main():
     dom_label = dom_name + ("_s%d" % info["scan_step"] if bin_ms > 0 and info["scan_step"] in (1, 2, 4, 17, 18, 21) else "")
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
     stage_achieved = algo_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms > 0 else 0.0
-    traffic = None
+    traffic = None; traffic_tag = ""
     tf = os.path.join(ROOT, "profiles", "scan_traffic.json")
     # the committed PMC passes were taken on the default workload (C2, full shard); other shapes: null
     per_launch = algo_bytes / max(launches, 1)
     if os.path.exists(tf):
         try:
             tj = json.load(open(tf))
+            traffic_tag = str(tj.get("_source", "")).split(":")[0] or "PMC passes"
             if args.workload == "C2" and abs(per_launch - 12.5e9) < 1e6:
                 traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
             elif args.workload == "C3" and abs(per_launch - 2.5e8) < 1e6:       # a launch = one subject range of 1,000 x 1 Mb
@@ -281,12 +306,20 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_seconds > 0:
         cpu = cpu_baseline(args, queries[:args.batch_queries], opt, mine)
 
+    # ---- the other single-GPU configs beside it (BASELINE.json configs[2], [3]): short runs of this same script in
+    # processes of their own once this one's passes are done, their key figures under config.other_workloads
+    others = None
+    if rank == 0 and world == 1 and args.workload == "C2" and not args.no_side_workloads and not args.side:
+        others = side_workloads(dev.index)
+
     if rank == 0:
         value = total_bases_global * args.steps / elapsed / 1e9
         line = {
             "metric": "subject Gbp scanned/sec (%s preliminary search, DB bases x passes / wall)" % task,
             "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "ms_per_step_minmax": [min(region_ms), max(region_ms)], "regions": len(regions),
+            "regions_what": "timed regions of exactly `steps` passes each (barrier + synchronize either side); ms_per_step and value are the median region's",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (2-bit packed bases, int32 scores)", "data": "synthetic",
             "config": {
@@ -309,11 +342,15 @@ def main():
                 "hsps_per_pass": nhsp / max(args.steps, 1),
                 "seeds_per_pass": seeds / max(launches, 1),
                 "lookup_hits_per_pass": lookup_hits / max(launches, 1),
+                "other_workloads": others,
             },
             "roofline": {"bound": "hbm", "kernel": dom_label,
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "box_copy_GBps": box_copy,
                          "frac": achieved / 8000.0, "traffic": traffic,
+                         "traffic_source": ("profiles/scan_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
+                                            "corrected as MI355X_MICROARCH.md prescribes; a constant of that profile, not a counter of this run"
+                                            % traffic_tag) if traffic is not None else None,
                          "algorithmic_bytes_per_launch": algo_bytes / max(launches, 1),
                          "avg_launch_ms": dom_ms / max(launches, 1), "launches": launches,
                          "scan_stage": {"kernels": dom_label + " + probe_bin_kernel + probe_rare_kernel"
@@ -328,6 +365,35 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def side_workloads(device_index):
+    """C3 (blastn W=11, 100 kb batches vs 5 Gbp) and C4 (5 Mb batches streamed through the host pipeline with the
+    traceback overlapped) for >= 1 s of timed region each: ms per pass / batch, Gbp/s, dominant kernel and its fraction of
+    the HBM roofline.  Each is `python bench.py --workload ...` in a process of its own (its full line is what that command
+    prints); a failure is reported, it does not fail the C2 line."""
+    import subprocess
+    out = {}
+    for wl, steps in (("C3", "32"), ("C4", "80")):
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", steps, "--warmup", "2", "--no-cpu-baseline",
+               "--engine-steps", "0", "--min-seconds", "1.0", "--side"]
+        env = dict(os.environ); env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", "")
+        if not env["HIP_VISIBLE_DEVICES"]:
+            del env["HIP_VISIBLE_DEVICES"]
+        try:
+            p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+            j = json.loads(p.stdout.strip().splitlines()[-1])
+            r = j["roofline"]
+            out[wl] = {"workload": j["config"]["workload"], "ms_per_step": j["ms_per_step"], "ms_per_step_minmax": j.get("ms_per_step_minmax"),
+                       "steps": j["steps"], "regions": j.get("regions"), "value": j["value"], "unit": j["unit"],
+                       "step_is": "one 100-query batch over the 5 Gbp shard (5 subject ranges)" if wl == "C3" else "one 5,000-query batch from the caller's arrays to its final alignments",
+                       "dominant_kernel": r.get("kernel"), "dominant_kernel_avg_launch_ms": r.get("avg_launch_ms"),
+                       "dominant_kernel_launches_per_step": (r.get("launches") or 0) / max(j["steps"], 1),
+                       "frac": r.get("frac"), "stage_ms_per_launch": j["config"].get("stage_ms_per_pass"),
+                       "command": "python bench.py --workload %s --steps %s" % (wl, steps)}
+        except Exception as e:      # noqa
+            out[wl] = {"error": repr(e)[:300]}
+    return out
 
 
 def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, total_bases_global, nsub, slen, queries):
@@ -352,11 +418,19 @@ def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, 
             dist.barrier()
         torch.cuda.synchronize()
     run(max(args.warmup, 2))
-    sync(); t0 = time.perf_counter()
-    diags = run(args.steps)
-    sync(); elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    regions = []
+    while True:
+        sync(); t0 = time.perf_counter()
+        dg = run(args.steps)
+        sync(); el = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([el], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); el = float(t.item())
+        regions.append((el, dg))
+        if sum(r[0] for r in regions) >= args.min_seconds or len(regions) >= 64 or world > 1:
+            break
+    order = sorted(range(len(regions)), key=lambda i: regions[i][0])
+    elapsed, diags = regions[order[(len(order) - 1) // 2]]
+    region_ms = [r[0] / args.steps * 1e3 for r in regions]
     # final alignments of one batch, counted once outside the timed region
     pipe = api.SearchPipeline(opt, src, trace_threads=args.trace_threads, traceback=True, overlap=False)
     pipe.submit(qsets[0]); pipe.finish(); _, res, _ = pipe.next(); pipe.close()
@@ -369,7 +443,8 @@ def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, 
         line = {
             "metric": "subject Gbp scanned/sec (megablast, query batches streamed through preliminary search + overlapped CPU traceback)",
             "value": total_bases_global * args.steps / elapsed / 1e9, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "ms_per_step_minmax": [min(region_ms), max(region_ms)], "regions": len(regions),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (2-bit packed bases, int32 scores)", "data": "synthetic",
             "config": {"workload": "C4: %d queries streamed in %d batches of %d x 1 kb (cycling over %d distinct queries) vs %.1f Gbp per GPU, megablast W=%d, traceback on %d host threads"
                                    % (args.steps * args.batch_queries, args.steps, args.batch_queries, len(queries), nsub * slen / 1e9, opt.word_size, args.trace_threads),
