@@ -67,6 +67,7 @@ struct DeviceBatch {
     const uint8_t *q8 = nullptr;    // q8_base + qpad
     uint8_t *q2_base = nullptr, *qinv_base = nullptr;   // 2-bit packed query + "matches nothing" bitmap
     const uint8_t *q2 = nullptr, *qinv = nullptr;       // ... at base 0 (256 bases of padding either side)
+    uint8_t *q4_base = nullptr; const uint8_t *q4 = nullptr;   // four bases per byte at every offset (lut_q4_kernel), q4[0] = query position 0
     uint32_t *pv = nullptr, *cellw = nullptr, *cell_start = nullptr, *cellt = nullptr, *side_start = nullptr;
     uint16_t *sidet = nullptr;
     unsigned long long *ent = nullptr;
@@ -323,7 +324,7 @@ static void finish_build(DeviceBatch *d) {
 void free_device_batch(DeviceBatch *d) {
     if (!d) return;
     finish_build(d);
-    dev_free(d->q8_base); dev_free(d->q2_base); dev_free(d->qinv_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent);
+    dev_free(d->q8_base); dev_free(d->q2_base); dev_free(d->qinv_base); dev_free(d->q4_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent);
     dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff);
     dev_free(d->ctx_reduced); dev_free(d->ctx_hint); dev_free(d->matrix); dev_free(d->score_table);
     delete d;
@@ -548,6 +549,9 @@ int upload_batch(GbnBatch &b) {
         HIPCHK(hipMemsetAsync(d->qinv_base, 0xff, qi_bytes, E.stream_build));
         HIPCHK(lut_pack_query(d->q8_base, (int64_t)b.qbuf.size(), (int64_t)b.qpad - pad, n, d->q2_base, d->qinv_base, E.stream_build));
         d->q2 = d->q2_base + pad / 4; d->qinv = d->qinv_base + pad / 8;
+        if ((rc = dev_alloc(d->q4_base, b.qbuf.size() + 64))) return rc;
+        HIPCHK(lut_pack_q4(d->q8_base, (int64_t)b.qbuf.size(), d->q4_base, E.stream_build));
+        d->q4 = d->q4_base + b.qpad;
     }
     if (host_lookup) {
         HIPCHK(hipStreamSynchronize(E.stream_build));       // q2 / qinv packed: no event travels with a host-built batch
@@ -1086,7 +1090,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         GbnExtParams X; std::memset(&X, 0, sizeof(X));
         X.db = db.d_packed; X.byte_off = db.d_byte_off; X.len = db.d_len;
         X.seeds = seeds; X.idx = E.idx_a; X.key_group = E.key_b; X.n = n;
-        X.q8 = d->q8; X.qlen = b.qlen; X.q2 = d->q2; X.qinv = d->qinv;
+        X.q8 = d->q8; X.qlen = b.qlen; X.q2 = d->q2; X.qinv = d->qinv; X.q4 = d->q4;
         X.ctx_off = d->ctx_off; X.ctx_len = d->ctx_len; X.ctx_xdrop = d->ctx_xdrop;
         X.ctx_cutoff = d->ctx_cutoff; X.ctx_reduced = d->ctx_reduced; X.nctx = (int32_t)b.ctx.size();
         X.matrix = d->matrix; X.score_table = d->score_table;
@@ -1442,7 +1446,7 @@ static int gapped_host(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResult
                 ihs[k].push_back(o);
             }
         }
-        finish_subject(b, db.oid_of(subj), db.len[subj], hits, outs[k], dg);
+        finish_subject(b, db.oid_of(subj), db.len[subj], hits, outs[k], dg, /* chunk = */ !db.real_of.empty());
         if (!db.real_of.empty()) {      // a chunk's list: sequence coordinates (Blast_HSPListAdjustOffsets), marked for the merge at the end of the search
             const int32_t ord = db.chunk_of(subj), off = (int32_t)((int64_t)ord * (db.chunk_len - kDbseqChunkOverlap));
             for (GbnHSP &h : outs[k]) { h.s_offset += off; h.s_end += off; h.s_gapped_start += off; h.pad_ = ord + 1; }
@@ -1858,7 +1862,7 @@ int gbn_batch_ext_params(const GbnBatch *b, const GbnDb *db, GbnExtParams *X) {
     const DeviceBatch *d = b->dev;
     std::memset(X, 0, sizeof(*X));
     X->db = db->d_packed; X->byte_off = db->d_byte_off; X->len = db->d_len;
-    X->q8 = d->q8; X->qlen = b->qlen; X->q2 = d->q2; X->qinv = d->qinv;
+    X->q8 = d->q8; X->qlen = b->qlen; X->q2 = d->q2; X->qinv = d->qinv; X->q4 = d->q4;
     X->ctx_off = d->ctx_off; X->ctx_len = d->ctx_len; X->ctx_xdrop = d->ctx_xdrop;
     X->ctx_cutoff = d->ctx_cutoff; X->ctx_reduced = d->ctx_reduced; X->nctx = (int32_t)b->ctx.size();
     X->matrix = d->matrix; X->score_table = d->score_table;
@@ -1965,7 +1969,7 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
                       int keep_stages, GbnInterruptFn interrupt, void *progress, int overlap) {
     int rc = GBN_OK;
     std::lock_guard<std::mutex> lk(E.mu);                   // (the caller has entered the engine: search_enter)
-    results->engine = tl_eng;
+    results->engine = tl_eng; results->batch = batch; results->diag = diag;
     auto t0 = std::chrono::steady_clock::now();
     trace_mark("search: entered");
     if (!db->real_of.empty()) results->chunk_len = db->chunk_len;
@@ -1974,10 +1978,19 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
         // recomputed for every subject (CORE/blast_setup.c:905-932)
         if ((rc = wait_pending())) return rc;           // this mode rewrites the batch's cut-offs per subject
         for (int32_t s = 0; s < db->num_seqs; s++) {
-            batch->set_effective_lengths(db->len[s], 1);
-            batch->update_cutoffs();
-            if ((rc = upload_ctx_cutoffs(*batch))) return rc;
+            // (a chunk of a long sequence: the parameters follow the sequence's length, GB/...engine.cpp:1283-1293, and its
+            // chunk lists are merged -- e-values with THESE effective lengths -- before the next sequence changes them)
+            const bool chunked = !db->real_of.empty();
+            if (!chunked || db->chunk_ord[(size_t)s] == 0) {
+                batch->set_effective_lengths(chunked ? db->real_len[(size_t)db->real_of[(size_t)s]] : db->len[s], 1);
+                batch->update_cutoffs();
+                if ((rc = upload_ctx_cutoffs(*batch))) return rc;
+            }
             if ((rc = search_range(*batch, *db, s, s + 1, *results, diag, keep_stages))) return rc;
+            if (chunked && (s + 1 == db->num_seqs || db->chunk_ord[(size_t)s + 1] == 0)) {
+                wait_host();
+                merge_chunk_lists(results->hsps, results->chunk_len, *batch, diag);     // (lists merged before carry pad_ = 0: left as they are)
+            }
             if (interrupt && interrupt(progress)) { set_error("interrupted"); return GBN_ERR_INTERRUPTED; }
         }
     } else {
@@ -2026,7 +2039,7 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     std::lock_guard<std::mutex> lk(E.mu);
     (void)wait_pending();                               // of an earlier gbn_prelim_search_begin (its status stays with its results)
     const int rc2 = take_failure(results);
-    if (!rc && !rc2 && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len); results->chunk_len = 0; }
+    if (!rc && !rc2 && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, *results->batch, results->diag); results->chunk_len = 0; }
     return rc ? rc : rc2;
 }
 
@@ -2075,7 +2088,7 @@ int gbn_prelim_search_end(GbnResults *results) {
     int rc;
     if (results && E.has_pending && E.pending_res != results) { wait_host(); rc = take_failure(results); }    // (its last host replay may still run)
     else { (void)wait_pending(); rc = results ? take_failure(results) : GBN_OK; }
-    if (!rc && results && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len); results->chunk_len = 0; }
+    if (!rc && results && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, *results->batch, results->diag); results->chunk_len = 0; }
     return rc;
 }
 

@@ -109,6 +109,7 @@ struct GbnResults {
     std::vector<GbnSeed> seeds;
     std::vector<GbnInitHit> init_hits;
     void *engine = nullptr;             // the device context that fills / filled them (set by the search entry points)
+    const GbnBatch *batch = nullptr; GbnDiagnostics *diag = nullptr;   // of the search that is filling them (chunk lists: e-values and counters after the merge)
     int32_t chunk_len = 0;              // > 0: hsps holds chunk lists (pad_ = ordinal + 1) that merge_chunk_lists has yet to join
 };
 
@@ -122,6 +123,6 @@ void fill_lookup_host(GbnBatch &b);     // the host-side table builder (host-onl
 int  upload_batch(GbnBatch &b);
 void free_device_batch(DeviceBatch *d);
 // chunk lists of one sequence (GbnHSP::pad_ = chunk ordinal + 1) -> one list per sequence (Blast_HSPListsMerge)
-void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len);
+void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len, const GbnBatch &b, GbnDiagnostics *diag);
 int  gather_shard_bytes(const GbnDb &db, const std::vector<int64_t> &src_off, const std::vector<int32_t> &nbytes, std::vector<uint8_t> &out);
 }

@@ -93,7 +93,9 @@ static void merge_two_lists(std::vector<GbnHSP> &comb, std::vector<GbnHSP> &cur,
     cur.clear();
 }
 
-void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len)
+// The chunk lists of a sequence -> its one list: merged in chunk order, then what the engine does with a subject's
+// list after its chunk loop (GB/gpu_blastn_pre_search_engine.cpp:772-810): e-values, e-value reap, counters.
+void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len, const GbnBatch &b, GbnDiagnostics *diag)
 {
     std::vector<GbnHSP> out; out.reserve(hsps.size());
     const int32_t stride = chunk_len - kDbseqChunkOverlap;
@@ -109,7 +111,13 @@ void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len)
             // the first chunk starts where its range does: no overlap strip on its left (CORE/blast_engine.c:532-533)
             merge_two_lists(comb, cur, ord * stride, ord == 0 ? 0 : kDbseqChunkOverlap);
         }
-        out.insert(out.end(), comb.begin(), comb.end());
+        size_t kept = 0;
+        for (GbnHSP &h : comb) {
+            h.evalue = evalue_for_score(h.score, b.kbp_gap, b.ctx[h.context].eff_searchsp);
+            if (h.evalue > b.opt.evalue) continue;
+            out.push_back(h); kept++;
+        }
+        if (diag && kept) { diag->seqs_passed++; diag->good_extensions += (int64_t)kept; }
     }
     hsps.swap(out);
 }
@@ -130,7 +138,7 @@ static bool ihit_before(const GbnDevInitHit &a, const GbnDevInitHit &b) {
 
 void finish_subject(const GbnBatch &b, int32_t oid, int32_t slen,
                     std::vector<std::pair<GbnDevInitHit, GbnDevGapped>> &hits,
-                    std::vector<GbnHSP> &out, GbnDiagnostics *diag)
+                    std::vector<GbnHSP> &out, GbnDiagnostics *diag, bool chunk)
 {
     std::sort(hits.begin(), hits.end(), [](const auto &x, const auto &y) { return ihit_before(x.first, y.first); });
     std::vector<GbnHSP> accepted;
@@ -156,6 +164,7 @@ void finish_subject(const GbnBatch &b, int32_t oid, int32_t slen,
     purge_common_endpoints(accepted);
     if (b.round_down) for (auto &h : accepted) h.score &= ~1;
     sort_by_score(accepted);
+    if (chunk) { out.insert(out.end(), accepted.begin(), accepted.end()); return; }
     size_t kept = 0;
     for (auto &h : accepted) {
         h.evalue = evalue_for_score(h.score, b.kbp_gap, b.ctx[h.context].eff_searchsp);

@@ -558,7 +558,7 @@ __device__ void ungapped_exact(const GbnExtParams &P, const uint8_t *__restrict_
 // into its neighbours' bits: such groups go through the byte-wise formula; all others are taken 8 steps at a time
 // from the 2-bit copy of the query (three dwords of query, three of subject, two of the "matches nothing" bitmap
 // per 32 bases instead of six dependent loads per step).
-__device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
+__device__ void ungapped_approx_steps(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
                                 int32_t q_off, int32_t s_match_end, int32_t s_off, int32_t X,
                                 int32_t reduced_cutoff, Ungapped &u)
 {
@@ -619,6 +619,94 @@ __device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict
     }
     // (the result is put together in values and stored once: with stores to u's fields on both paths the compiler
     // kept them in private memory -- the only scratch use of the two kernels that extend seeds)
+    Ungapped r;
+    if (score >= reduced_cutoff) {
+        Ungapped e; e.q_start = 0; e.s_start = 0; e.length = 0; e.score = 0;
+        ungapped_exact(P, subj, slen, q_off, s_off, X, e);
+        r = e;
+    } else {
+        r.q_start = uq; r.s_start = us; r.score = score;
+        r.length = max(s_match_end - us, new_q - uq + 1);
+    }
+    u.q_start = r.q_start; u.s_start = r.s_start; u.length = r.length; u.score = r.score;
+}
+
+// The same function eight steps per round (needs GbnExtParams::q4).  The subject position the steps start from is a
+// multiple of 4, so a round's eight subject bytes are one 8-byte load, its eight query bytes every fourth byte of 32
+// consecutive q4 bytes (ambiguity codes and the sentinel between the strands are already folded in there the way the
+// reference's byte-wise formula folds them: no special case), the eight mismatch counts one XOR and a byte-wise
+// population count.  What stays per step is the X-drop recurrence itself, without branches: a lane that has dropped
+// out keeps a sum that can never recover, the wave goes round as long as one of its lanes is alive (the step-by-step
+// form above ran every lane for as many steps as the longest of 64 took, at 15 instructions a step).
+// Only rounds that are cut short by the end of the query or the subject go step by step.
+template <bool LEFT>
+__device__ __forceinline__ void approx_side(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t q_ext, int32_t s_ext,
+                                            int32_t n, int32_t X, int32_t t4, int32_t dt, int32_t &score, int32_t &best)
+{
+    constexpr int32_t kDead = INT32_MIN / 2;
+    const uint8_t *__restrict__ q4 = P.q4;
+    int32_t sum = 0;
+    best = 0;                                                   // steps the best prefix covers
+    for (int32_t c = 0; c * 8 < n; c++) {
+        const int32_t steps = min(8, n - c * 8);
+        const int32_t qa = LEFT ? q_ext - 32 * (c + 1) : q_ext + 32 * c;
+        const int32_t sa = LEFT ? s_ext - 32 * (c + 1) : s_ext + 32 * c;
+        int32_t bt = -1;
+        if (steps == 8) {
+            uint32_t sw[2], qd[8];
+            __builtin_memcpy(sw, subj + (sa >> 2), 8);
+            __builtin_memcpy(qd, q4 + qa, 32);
+            // byte k (address order) of S and Q = the four bases qa + 4k .. qa + 4k + 3
+            const uint32_t qlo = __builtin_amdgcn_perm(__builtin_amdgcn_perm(qd[3], qd[2], 0x0c0c0400u), __builtin_amdgcn_perm(qd[1], qd[0], 0x0c0c0400u), 0x05040100u);
+            const uint32_t qhi = __builtin_amdgcn_perm(__builtin_amdgcn_perm(qd[7], qd[6], 0x0c0c0400u), __builtin_amdgcn_perm(qd[5], qd[4], 0x0c0c0400u), 0x05040100u);
+            uint32_t m[2] = {qlo ^ sw[0], qhi ^ sw[1]};
+            #pragma unroll
+            for (int h = 0; h < 2; h++) {                       // mismatching 2-bit groups per byte
+                uint32_t v = (m[h] | (m[h] >> 1)) & 0x55555555u;
+                v = (v & 0x33333333u) + ((v >> 2) & 0x33333333u);
+                m[h] = (v + (v >> 4)) & 0x0f0f0f0fu;
+            }
+            #pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const int k = LEFT ? 7 - t : t;
+                const int32_t cnt = (int32_t)((m[k >> 2] >> (8 * (k & 3))) & 0xffu);
+                sum += t4 + dt * cnt;
+                const bool pos = sum > 0;
+                bt = pos ? t : bt;
+                score += pos ? sum : 0;
+                sum = pos ? 0 : sum;
+                sum = sum < X ? kDead : sum;
+            }
+        } else {
+            const uint8_t *qs = P.q8;
+            for (int32_t t = 0; t < steps; t++) {
+                const int32_t qi = qa + (LEFT ? 4 * (7 - t) : 4 * t);   // the step covers query bases qi .. qi + 3
+                const uint32_t s_byte = subj[(sa >> 2) + (LEFT ? 7 - t : t)];
+                const uint32_t x = (uint8_t)((qs[qi] << 6) | (qs[qi + 1] << 4) | (qs[qi + 2] << 2) | qs[qi + 3]) ^ s_byte;
+                sum += t4 + dt * (int32_t)__popc((x | (x >> 1)) & 0x55u);
+                if (sum > 0) { bt = t; score += sum; sum = 0; }
+                if (sum < X) { sum = kDead; break; }
+            }
+        }
+        if (bt >= 0) best = c * 8 + bt + 1;
+        if (sum < X) break;
+    }
+}
+
+__device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
+                                int32_t q_off, int32_t s_match_end, int32_t s_off, int32_t X,
+                                int32_t reduced_cutoff, Ungapped &u)
+{
+    const int32_t t4 = P.score_table[0], dt = P.score_table[1] - t4;      // 4 * reward, penalty - reward
+    // (a dead lane's sum must stay below X whatever follows: eight steps add at most 8 * t4 per round, rounds < 2^26)
+    if (P.q4 == nullptr || X < -(1 << 24) || t4 > (1 << 20) || t4 < 0) { ungapped_approx_steps(P, subj, slen, q_off, s_match_end, s_off, X, reduced_cutoff, u); return; }
+    const int32_t len = (4 - (s_off & 3)) & 3;
+    const int32_t q_ext = q_off + len, s_ext = s_off + len;
+    int32_t score = 0, bl = 0, br = 0;
+    approx_side<true>(P, subj, q_ext, s_ext, min(q_ext, s_ext) >> 2, X, t4, dt, score, bl);
+    approx_side<false>(P, subj, q_ext, s_ext, min(P.qlen - q_ext, slen - s_ext) >> 2, X, t4, dt, score, br);
+    const int32_t uq = q_ext - 4 * bl, us = s_ext - 4 * bl;
+    const int32_t new_q = br ? q_ext + 4 * br - 1 : q_ext;     // the reference's new_q: last base of the best step, or where the loop began
     Ungapped r;
     if (score >= reduced_cutoff) {
         Ungapped e; e.q_start = 0; e.s_start = 0; e.length = 0; e.score = 0;
@@ -1999,9 +2087,14 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
     // thread-per-extension kernel with its band in scratch memory.  GBN_GAP_LANE=0: start with the wave kernel.
     if (!p.redo_only) {
         static const bool lane_on = !(getenv("GBN_GAP_LANE") && atoi(getenv("GBN_GAP_LANE")) == 0);
-        // (16-bit band cells: no score of an extension may reach 30000; scratch_per_thread / 2 bounds the longest context)
+        // 16-bit band cells, "dead" = -32768.  A half of a lane extension has at most GBN_LANE_ROWS rows, so no live value
+        // exceeds GBN_LANE_ROWS * reward, none that is kept lies more than xdrop below the best, and what is stored beside
+        // it (a gap opened or extended from a kept cell) at most gap_open + gap_extend lower still: all of it, and the
+        // distance from the best score to a dead cell, must fit 16 bits -- whatever the length of the queries
+        // (a bound by the longest context sent every batch with a 15 kb query through the wave kernel).
+        const int64_t live_top = (int64_t)GBN_LANE_ROWS * std::max(std::abs(p.reward), std::abs(p.penalty));
         const bool lane = lane_on && p.gap_extend > 0 && std::abs(p.reward) <= 127 && std::abs(p.penalty) <= 127 &&
-                          (int64_t)std::abs(p.reward) * (p.scratch_per_thread / 2) < 30000 &&
+                          live_top + (int64_t)std::max(p.xdrop, p.gap_open + p.gap_extend) + p.gap_open + p.gap_extend < 30000 &&
                           (int64_t)p.scratch_per_thread * 64 * blocks >= 2 * p.n + 16;
         GbnGapParams w = p;
         int32_t *redo_list = nullptr;

@@ -111,6 +111,11 @@ typedef struct GbnExtParams {
     /* ck_vbits > 0: the value travels in the key's low ck_vbits bits (key_group[i] = composite key << ck_vbits | value,
      * sorted on the bits above them: a sort of keys only) and idx is not read */
     int32_t ck_vbits;
+    /* optional: the query four bases per byte at EVERY offset, q4[k] = (uint8_t)((q8[k] << 6) | (q8[k+1] << 4) | (q8[k+2] << 2)
+     * | q8[k+3]) -- the byte s_NuclUngappedExtend builds per step (CORE/na_ungapped.c:296, :323), ambiguity codes and
+     * sentinels spilling as they do there; readable from q4 - 64 to q4 + qlen + 64.  With it the approximate extension
+     * takes eight steps per round from two loads (null: step by step from q8 / q2) */
+    const uint8_t *q4;
 } GbnExtParams;
 
 typedef struct GbnGapParams {

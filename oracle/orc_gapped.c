@@ -444,6 +444,7 @@ void orc_gapped_stage(OrcSearch *S, const uint8_t *subj, int32_t slen, OrcStats 
         for (index = 0; index < S->nhsps; index++) S->hsps[index].score &= ~1;
     }
     orc_hsplist_sort_by_score(S->hsps, S->nhsps);
+    if (S->chunk_mode) return;                  /* the rest after the merge of the sequence's chunk lists */
     {
         int32_t n = 0;
         for (index = 0; index < S->nhsps; index++) {    /* :1655-1738, :1807-1839 */

@@ -70,6 +70,10 @@ struct OrcSearch {
     /* the diagonal container carried from subject to subject as the reference does (Blast_ExtendWordExit,
      * CORE/blast_extend.c:166-190) instead of starting fresh: off by default, see orc_search_carry_diag */
     int carry_diag, carry_started; int32_t diag_offset;
+    /* a chunk of a long subject is being searched (orc_search_subject_chunked): the list stops after purge, odd-score
+     * rounding and sort; e-values, the e-value reap and the per-sequence counters follow the merge of the chunk lists
+     * (GB/gpu_blastn_pre_search_engine.cpp:460-548 vs :772-810) */
+    int chunk_mode;
 };
 
 int  orc_context_of(const OrcSearch *s, int32_t q_off);   /* BSearchContextInfo */

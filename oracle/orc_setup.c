@@ -322,7 +322,7 @@ int orc_search_subject(OrcSearch *s, const uint8_t *packed, int32_t len, OrcStat
 {
     OrcStats local; memset(&local, 0, sizeof(local));
     s->nseeds = s->nihits = s->nhsps = 0;
-    if (s->opt.db_num_seqs == 0)    /* "db_length == 0" branch of the engine */
+    if (s->opt.db_num_seqs == 0 && !s->chunk_mode)  /* "db_length == 0" branch of the engine (a chunked sequence: once, by its caller) */
         orc_update_for_subject(s, len);
     orc_word_finder(s, packed, len, &local);
     if (s->nihits > 0) orc_gapped_stage(s, packed, len, &local);
@@ -386,6 +386,9 @@ int orc_search_subject_chunked(OrcSearch *s, const uint8_t *packed, int32_t len,
 {
     OrcHSP *comb = NULL; int32_t ncomb = 0, ccomb = 0, next = 0, first = 1;
     if (max_len < 1000 || (max_len & 3)) return -1;
+    /* parameters of a subject-by-subject search follow the SEQUENCE's length (GB/...engine.cpp:1283-1293, before the chunks) */
+    if (s->opt.db_num_seqs == 0) orc_update_for_subject(s, len);
+    s->chunk_mode = 1;
     while (next < len) {
         const int32_t offset = next;                /* a multiple of 4: residual 0 */
         int32_t clen, i;
@@ -401,6 +404,17 @@ int orc_search_subject_chunked(OrcSearch *s, const uint8_t *packed, int32_t len,
         first = 0;
     }
     (void)first;
+    s->chunk_mode = 0;
+    {   /* e-values and the e-value reap on the merged list, the per-sequence counters (:772-810) */
+        int32_t i, n = 0;
+        for (i = 0; i < ncomb; i++) {
+            comb[i].evalue = orc_karlin_StoE(comb[i].score, &s->kbp_gap, s->ctx[comb[i].context].eff_searchsp);
+            if (comb[i].evalue > s->opt.evalue) continue;
+            comb[n++] = comb[i];
+        }
+        ncomb = n;
+        if (stats && ncomb > 0) { stats->seqs_passed++; stats->good_extensions += ncomb; }
+    }
     if (ncomb > s->chsps) { s->chsps = ncomb; s->hsps = (OrcHSP *)realloc(s->hsps, (size_t)ncomb * sizeof(OrcHSP)); }
     if (ncomb) memcpy(s->hsps, comb, (size_t)ncomb * sizeof(OrcHSP));
     s->nhsps = ncomb; s->nseeds = 0; s->nihits = 0;

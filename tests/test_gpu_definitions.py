@@ -225,6 +225,29 @@ def test_search_lists_shard_builder_and_cache():
     assert L.gbn_db_cache_find(key) is None
 
 
+@pytest.mark.parametrize("task,nq,seed", [("megablast", 24, 3), ("blastn", 9, 5), ("blastn", 6, 8)])
+def test_hash_path_of_the_hip_kernels_equals_the_definitions(task, nq, seed):
+    """the checkers of tests/hash_path_definitions.py (exact per-diagonal map + prefix-sum ungapped extension; brute-force
+    containment) against what the HIP path delivers: seed list, initial-hit list, HSP list, extension counter -- with the
+    engine's own kernel choice and with the two-kernel seed stage (seed_ext_kernel + diag_replay_kernel) forced"""
+    from oracle import orc
+    from tests.test_hash_path_oracle import hash_case, check_filter_and_extension, check_acceptance
+    sub, queries, oopt, S = hash_case(task, nq, seed)
+    kw = dict(task="blastn", word_size=11) if task == "blastn" else {}
+    gopt = api.default_options(task if task == "megablast" else "blastn", db_length=10**7, db_num_seqs=10, **({"word_size": 11} if task == "blastn" else {}))
+    packed = orc.pack_ncbi2na(sub)
+    src = api.BlastSeqSrc.from_packed([(packed, len(sub))])
+    ps = api.BlastPrelimSearch(queries, gopt, src)
+    assert ps.info()["container"] == 1
+    g = ps.run(keep_stages=True)
+    seeds = list(zip(g["seeds"]["q_off"].tolist(), g["seeds"]["s_off"].tolist()))
+    nwin, want = check_filter_and_extension(S, oopt, sub, g["init_hits"])            # seeds by brute force
+    check_filter_and_extension(S, oopt, sub, g["init_hits"], seeds=seeds)            # ... and from the kernel's own seed list
+    assert len(want) >= 3
+    nacc, nshared = check_acceptance(S, oopt, sub, g["init_hits"], g["hsps"], got_extensions=int(ps.diagnostics.gapped_extensions))
+    assert nacc >= 2
+
+
 def test_shard_with_explicit_oids_and_holes():
     """what the shim builds from a BlastSeqSrc iterator over an OID list: the HSPs carry the OIDs that were given, the
     traceback stage finds its subjects by them"""
