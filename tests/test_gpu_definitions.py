@@ -333,7 +333,9 @@ def test_parity_suite_through_the_two_kernel_seed_stage():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ); env["GBN_DIAG_COMPACT_MIN"] = "1"
     # (the tests that start child processes of their own stay out: they carry their own two-kernel cases)
-    p = util.run_child([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu and not spawns"], cwd=root, env=env, timeout=900)
+    p = util.run_child([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py",
+                        "tests/test_gpu_definitions.py::test_hash_path_of_the_hip_kernels_equals_the_definitions",
+                        "-x", "-q", "-m", "gpu and not spawns"], cwd=root, env=env, timeout=900)
     assert " passed" in p.stdout and "failed" not in p.stdout
 
 
