@@ -219,40 +219,91 @@ class ShardedSearch:
         return rec, qs
 
     # ---- the exchanges of one batch (worker thread)
-    def _finish(self, token, local, nq):
+    def _any_failed(self, failed):
+        """one status word per batch: a rank whose local stage failed has taken part in every collective with an empty
+        payload; here every rank learns of it"""
+        if not _active(self.group):
+            return failed
+        dev = self.device if self.device is not None else torch.device("cpu")
+        t = torch.tensor([1 if failed else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return bool(int(t.item()))
+
+    def _finish(self, token, local, nq, err=None):
+        """The collectives of a batch are issued by every rank whatever happens to its LOCAL stages (collector on rank 0,
+        selection and traceback of its own lists, final merge): a failure there is kept, the rank goes on with empty
+        payloads, and after the last exchange an all-reduce of the status makes every rank raise -- nobody is left
+        waiting in a gather or a broadcast for a rank that has dropped out."""
         api, dev, grp = self.api, self.device, self.group
-        got = collect_on_root(local, nq, self.opt.hitlist_size, dst=0, device=dev, group=grp)
-        root = got is not None
+        empty_h, empty_s = np.zeros(0, dtype=api.HSP_DT), np.zeros(1, dtype="<i8")
+        # 1: preliminary records -> rank 0 -> per-query top-N
+        merged = gather_records(local, dst=0, device=dev, group=grp)
+        root = merged is not None
+        got = None
+        if root:
+            try:
+                if err is None:
+                    col = api.BlastHSPCollector(nq, self.opt.hitlist_size)
+                    try:
+                        col.write(merged); got = col.close()
+                    finally:
+                        col.free()
+            except Exception as e:      # noqa
+                err = "collector on rank 0: %r" % (e,)
+            if got is None:
+                got = (empty_h, empty_s, None)
+        # 2: the lists that survived -> every rank
         hsps = broadcast_records(got[0] if root else None, api.HSP_DT, src=0, device=dev, group=grp)
         starts = broadcast_records(np.asarray(got[1], dtype="<i8") if root else None, np.dtype("<i8"), src=0, device=dev, group=grp)
-        # the lists of this rank's subjects: contiguous, the collector orders lists by (oid, query)
-        if len(starts) > 1:
-            first_oid = hsps["oid"][starts[:-1]]
-            mine = np.nonzero((first_oid >= self.shard.first_oid) & (first_oid < self.shard.first_oid + self.shard.num_oids))[0]
-        else:
-            mine = np.zeros(0, dtype=np.int64)
-        if len(mine):
-            a, b = int(mine[0]), int(mine[-1]) + 1
-            assert b - a == len(mine)
-            sel_h = hsps[starts[a]:starts[b]]; sel_s = starts[a:b + 1] - starts[a]
-        else:
-            sel_h = hsps[:0]; sel_s = np.zeros(1, dtype="<i8")
-        rec, qs = self._trace(token, sel_h, sel_s)
+        rec, qs = np.zeros(0, dtype=api.TB_DT), None
+        try:
+            if err is None:
+                # the lists of this rank's subjects: contiguous, the collector orders lists by (oid, query)
+                if len(starts) > 1:
+                    first_oid = hsps["oid"][starts[:-1]]
+                    mine = np.nonzero((first_oid >= self.shard.first_oid) & (first_oid < self.shard.first_oid + self.shard.num_oids))[0]
+                else:
+                    mine = np.zeros(0, dtype=np.int64)
+                if len(mine):
+                    a, b = int(mine[0]), int(mine[-1]) + 1
+                    if b - a != len(mine):
+                        raise api.BlastError("the lists of this rank's subjects are not contiguous")
+                    sel_h = hsps[starts[a]:starts[b]]; sel_s = starts[a:b + 1] - starts[a]
+                else:
+                    sel_h = hsps[:0]; sel_s = empty_s
+                rec, qs = self._trace(token, sel_h, sel_s)
+        except Exception as e:      # noqa
+            err = "traceback stage: %r" % (e,); rec, qs = np.zeros(0, dtype=api.TB_DT), None
         if qs is None:
             qs = np.zeros(nq + 1, dtype="<i8")
+        # 3: final records -> rank 0 -> per-query merge
         recs = gather_parts(np.ascontiguousarray(rec, dtype=api.TB_DT), dst=0, device=dev, group=grp)
         qss = gather_parts(np.ascontiguousarray(qs, dtype="<i8"), dst=0, device=dev, group=grp)
-        if hasattr(token, "close"):
-            token.close()
-        if recs is None:
-            return None
-        return merge_final(list(zip(recs, qss)), nq, self.opt.hitlist_size)
+        try:
+            if hasattr(token, "close"):
+                token.close()
+        except Exception:           # noqa
+            pass
+        out = None
+        if recs is not None and err is None:
+            try:
+                out = merge_final(list(zip(recs, qss)), nq, self.opt.hitlist_size)
+            except Exception as e:  # noqa
+                err = "final merge: %r" % (e,)
+        if self._any_failed(err is not None):
+            raise api.BlastError(err if err is not None else "this batch failed on another rank")
+        return out
 
     def submit(self, queries, masks=None, num_queries=None):
         """preliminary search of this batch now (caller's thread); its exchanges, traceback and merge are queued
-        behind those of the batches before it and overlap whatever the caller does next"""
-        token, local = self._search(queries, masks)
-        fut = self.ex.submit(self._finish, token, local, len(queries) if num_queries is None else num_queries)
+        behind those of the batches before it and overlap whatever the caller does next.  A search that fails here is
+        reported by the batch's future (on every rank), not by this call: the rank still owes the others its exchanges."""
+        err = None
+        try:
+            token, local = self._search(queries, masks)
+        except Exception as e:      # noqa
+            token, local, err = None, np.zeros(0, dtype=self.api.HSP_DT), "preliminary search: %r" % (e,)
+        fut = self.ex.submit(self._finish, token, local, len(queries) if num_queries is None else num_queries, err)
         self._pending.append(fut)
         return fut
 

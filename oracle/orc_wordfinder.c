@@ -389,8 +389,13 @@ void orc_word_finder(OrcSearch *S, const uint8_t *subj, int32_t slen, OrcStats *
         {   /* the lookup word from the packed bytes with shifts and a mask, as the reference's scanners cut it
              * (CORE/blast_nascan.c:1489-1591; lut <= 12: at most 4 + 1 bytes; the caller pads the subject) */
             const uint8_t *sp = subj + (s_off >> 2);
-            const uint64_t w = ((uint64_t)sp[0] << 32) | ((uint64_t)sp[1] << 24) | ((uint64_t)sp[2] << 16) | ((uint64_t)sp[3] << 8) | sp[4];
-            idx = (uint32_t)(w >> (40 - 2 * (s_off & 3) - 2 * lut)) & mask;
+            if (lut <= 12) {        /* four bytes hold the word at any offset: the load of s_MBScanSubject_Any (:1562-1568) */
+                const uint32_t w = ((uint32_t)sp[0] << 24) | ((uint32_t)sp[1] << 16) | ((uint32_t)sp[2] << 8) | sp[3];
+                idx = (w >> (2 * (16 - ((s_off & 3) + lut)))) & mask;
+            } else {
+                const uint64_t w = ((uint64_t)sp[0] << 32) | ((uint64_t)sp[1] << 24) | ((uint64_t)sp[2] << 16) | ((uint64_t)sp[3] << 8) | sp[4];
+                idx = (uint32_t)(w >> (40 - 2 * (s_off & 3) - 2 * lut)) & mask;
+            }
         }
         if (l->type == ORC_LUT_MB) {
             /* CORE/blast_nascan.c:1413-1427: presence bit first, then the chain, which yields descending q */

@@ -162,6 +162,27 @@ opt = api.default_options("megablast", hitlist_size=6)
 batches = [(0, 3), (1, 7), (2, 1), (3, 5)]
 sh = make_shard(world, r)
 se, tr = stages(sh)
+if os.environ.get("FAIL_STAGE"):
+    # a local stage fails on ONE rank for ONE batch: every rank's future of that batch raises, the batches around it
+    # come through, nobody hangs in a collective (the process group's timeout is 60 s: a hang fails the test)
+    which, bad_rank, bad_batch = os.environ["FAIL_STAGE"], world - 1, 1
+    def se_f(queries, masks):
+        if which == "search" and r == bad_rank and queries[0] == bad_batch: raise RuntimeError("injected search failure")
+        return se(queries, masks)
+    def tr_f(token, hsps, starts):
+        if which == "trace" and r == bad_rank and token[0] == bad_batch: raise MemoryError("injected traceback failure")
+        return tr(token, hsps, starts)
+    S = shard.ShardedSearch(sh, opt, search=se_f, trace=tr_f)
+    futs = [S.submit(bq, num_queries=bq[1]) for bq in batches]
+    outcome = []
+    for f in futs:
+        try: f.result(); outcome.append("ok")
+        except api.BlastError as e: outcome.append("failed: " + str(e))
+    S._pending = []; S.close()
+    assert [o.startswith("failed") for o in outcome] == [False, True, False, False], outcome
+    assert ("injected" in outcome[1]) == (r == bad_rank), outcome
+    print("FAILURE_OK", world, r); sys.stdout.flush()
+    dist.barrier(); dist.destroy_process_group(); sys.exit(0)
 S = shard.ShardedSearch(sh, opt, search=se, trace=tr)
 for bq in batches:
     S.submit(bq, num_queries=bq[1])                       # all four in flight behind one another
@@ -191,19 +212,29 @@ if world > 1:
 '''
 
 
-def run_protocol(nproc, port):
+def run_protocol(nproc, port, fail_stage=None):
     import tempfile
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
         f.write(PROTOCOL_WORKER)
         path = f.name
     env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"
+    if fail_stage:
+        env["FAIL_STAGE"] = fail_stage
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc,
            "--master-addr", "127.0.0.1", "--master-port", str(port), path, root]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
     os.unlink(path)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
-    assert "PROTOCOL_OK %d" % nproc in p.stdout
+    if fail_stage:
+        assert p.stdout.count("FAILURE_OK %d" % nproc) == nproc, p.stdout[-2000:]
+    else:
+        assert "PROTOCOL_OK %d" % nproc in p.stdout
+
+
+def test_a_failing_local_stage_is_reported_on_every_rank_and_nobody_hangs():
+    run_protocol(2, 29625, fail_stage="trace")
+    run_protocol(3, 29627, fail_stage="search")
 
 
 def test_sharded_search_protocol_two_ranks_gloo():
