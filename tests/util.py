@@ -61,15 +61,26 @@ def small_case(nsub, slen, nq, qlen=1000, seed=7, planted_fraction=0.5, task="me
 
 def run_child(cmd, env=None, timeout=600, cwd=None):
     """A child process of a test (a search under other environment settings), its stderr in the assertion message.
-    A child the GPU runtime aborted with a queue error (HSA_STATUS_ERROR_*: seen about once in a hundred spawns on the
-    test pool when three processes deep, never reproduced by tools/stress_ranges.py) is run once more, with a warning
-    that stays in the pytest summary; a second abort, or any other failure, fails the test."""
-    import subprocess, warnings
-    for attempt in (0, 1):
-        p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=cwd)
-        if p.returncode < 0 and "HSA_STATUS_ERROR" in p.stderr and attempt == 0:
-            warnings.warn("child process aborted by the GPU runtime, run once more; stdout ends %r, stderr ends %r" % (p.stdout[-200:], p.stderr[-600:]))
-            continue
-        break
-    assert p.returncode == 0, (p.returncode, p.stdout[-3000:], p.stderr[-6000:])
+    No second try: a child the GPU runtime aborts (HSA_STATUS_ERROR_* on its queue) fails the test.  The runtime
+    writes a GPU core dump on such an exception; the child is pointed at a directory of this run for it, and what
+    rocgdb says about the dump (the waves and the code at their program counters) goes into the failure message --
+    the evidence DESIGN.md section 5b is still waiting for."""
+    import glob, os, subprocess, tempfile
+    env = dict(os.environ if env is None else env)
+    dump_dir = tempfile.mkdtemp(prefix="gbn_gpucore_")
+    env.setdefault("HSA_COREDUMP_PATTERN", os.path.join(dump_dir, "gpucore.%p"))
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout, cwd=cwd)
+    extra = ""
+    if p.returncode != 0 and "HSA_STATUS_ERROR" in p.stderr:
+        for core in glob.glob(os.path.join(dump_dir, "gpucore.*"))[:1]:
+            try:
+                g = subprocess.run(["/opt/rocm/bin/rocgdb", "-batch", "-ex", "info threads", "-ex", "thread apply all bt 3",
+                                    "-ex", "thread apply all x/6i $pc", cmd[0], core], capture_output=True, text=True, timeout=300)
+                extra = "\n==== rocgdb on the GPU core dump ====\n" + g.stdout[-6000:] + g.stderr[-1000:]
+            except Exception as e:      # noqa
+                extra = "\n(rocgdb on %s failed: %r)" % (core, e)
+    assert p.returncode == 0, (p.returncode, p.stdout[-3000:], p.stderr[-6000:] + extra)
+    for f in glob.glob(os.path.join(dump_dir, "*")):
+        os.remove(f)
+    os.rmdir(dump_dir)
     return p
