@@ -72,7 +72,7 @@ struct DeviceBatch {
     uint16_t *sidet = nullptr;
     unsigned long long *ent = nullptr;
     int32_t *ctx_off = nullptr, *ctx_len = nullptr, *ctx_xdrop = nullptr, *ctx_cutoff = nullptr,
-            *ctx_reduced = nullptr, *ctx_hint = nullptr;    // ctx_hint[q >> kCtxHintShift]: the context position (q & ~mask) lies in
+            *ctx_reduced = nullptr, *ctx_hint = nullptr, *ctx_blk = nullptr;    // ctx_hint[q >> kCtxHintShift]: the context position (q & ~mask) lies in
     int32_t *matrix = nullptr, *score_table = nullptr;
     int mode = 0, fl = 0, fr = 0;
     // lookup structures still being built on the builder's stream: the event they are complete at, and the
@@ -326,7 +326,7 @@ void free_device_batch(DeviceBatch *d) {
     finish_build(d);
     dev_free(d->q8_base); dev_free(d->q2_base); dev_free(d->qinv_base); dev_free(d->q4_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent);
     dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff);
-    dev_free(d->ctx_reduced); dev_free(d->ctx_hint); dev_free(d->matrix); dev_free(d->score_table);
+    dev_free(d->ctx_reduced); dev_free(d->ctx_hint); dev_free(d->ctx_blk); dev_free(d->matrix); dev_free(d->score_table);
     delete d;
 }
 
@@ -580,6 +580,16 @@ int upload_batch(GbnBatch &b) {
             hint[k] = (int32_t)c;
         }
         if ((rc = dev_upload(d->ctx_hint, hint.data(), hint.size()))) return rc;
+        // ... and per block: that context and where the next one begins (GbnExtParams::ctx_blk)
+        std::vector<int32_t> blk(2 * hint.size());
+        for (size_t k = 0; k < hint.size(); k++) {
+            const size_t ci = (size_t)hint[k];
+            const int64_t last = ((int64_t)k << kCtxHintShift) + ((int64_t)1 << kCtxHintShift) - 1;
+            blk[2 * k] = hint[k];
+            blk[2 * k + 1] = ci + 1 < off.size() ? off[ci + 1] : INT32_MAX;
+            if (ci + 2 < off.size() && off[ci + 2] <= last) blk[2 * k + 1] = INT32_MIN;
+        }
+        if ((rc = dev_upload(d->ctx_blk, blk.data(), blk.size()))) return rc;
     }
     if ((rc = dev_upload(d->matrix, &b.matrix[0][0], 256))) return rc;
     if ((rc = dev_upload(d->score_table, b.score_table, 256))) return rc;
@@ -1099,7 +1109,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         X.cell_start = d->cell_start; X.ent = d->ent; X.cell_mask = (uint32_t)(b.lut.ncells - 1); X.lut = b.lut.lut;
         X.masked = b.lut.masked ? 1 : 0;
         X.run_heads = E.idx_b; X.run_count = reinterpret_cast<uint32_t *>(ctr + 1); X.group_bits = K.group_bits;
-        X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = E.ext_rec;
+        X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = E.ext_rec; X.ctx_blk = d->ctx_blk;
         if (composite) {
             X.idx = E.idx_b; X.run_heads = E.idx_a;
             X.ck_shift = K.s_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending; X.ck_subj_base = K.subj_base; X.ck_vbits = K.v_bits;
@@ -1869,7 +1879,7 @@ int gbn_batch_ext_params(const GbnBatch *b, const GbnDb *db, GbnExtParams *X) {
     X->word = b->lut.word; X->container_hash = b->container;
     X->cell_start = d->cell_start; X->ent = d->ent; X->cell_mask = (uint32_t)(b->lut.ncells - 1); X->lut = b->lut.lut;
     X->masked = b->lut.masked ? 1 : 0;
-    X->ctx_hint = d->ctx_hint; X->ctx_hint_shift = kCtxHintShift;
+    X->ctx_hint = d->ctx_hint; X->ctx_hint_shift = kCtxHintShift; X->ctx_blk = d->ctx_blk;
     return GBN_OK;
 }
 int gbn_batch_gap_params(const GbnBatch *b, const GbnDb *db, GbnGapParams *G) {

@@ -35,6 +35,9 @@
 #ifndef GBN_DIAG_ABL
 #define GBN_DIAG_ABL 0      // timing experiments only (1: no ungapped extension, 2: no strand search): wrong results
 #endif
+#ifndef GBN_EXT_ABL
+#define GBN_EXT_ABL 0       // timing experiments only (seed_ext_kernel), bits: 1 no exact pass, 2 no extension, 4 no reservation of run heads, 8 no context lookup, 16 no record store: wrong results
+#endif
 #ifndef GBN_PROBE_U
 #define GBN_PROBE_U 2        // 16-byte loads per lane and round of the probe kernel (4 records each)
 #endif
@@ -509,7 +512,7 @@ struct Ungapped { int32_t q_start, s_start, length, score; };
 // s_NuclUngappedExtendExact (CORE/na_ungapped.c:152-244): base by base with the X-drop rule.  32 bases at a time
 // from the 2-bit copies of query and subject (a real homolog's thousand bases were a thousand dependent byte loads);
 // a stretch of the query with a code above 3 (ambiguity, the sentinel between contexts) goes byte by byte.
-__device__ void ungapped_exact(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
+__device__ __forceinline__ void ungapped_exact(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen,
                                int32_t q_off, int32_t s_off, int32_t X, Ungapped &u)
 {
     const uint8_t *q = P.q8;
@@ -639,9 +642,19 @@ __device__ void ungapped_approx_steps(const GbnExtParams &P, const uint8_t *__re
 // out keeps a sum that can never recover, the wave goes round as long as one of its lanes is alive (the step-by-step
 // form above ran every lane for as many steps as the longest of 64 took, at 15 instructions a step).
 // Only rounds that are cut short by the end of the query or the subject go step by step.
+// first round of a side, loaded ahead by the caller (seed_ext_ck_kernel issues the loads of both sides before it
+// looks at either): the eight subject bytes and the 32 q4 bytes of the round
+struct ApproxPre { uint32_t s0, s1, q0, q1; };      // subject bytes, query bytes (every fourth q4 byte, packed), address order
+// every fourth byte of 32 consecutive q4 bytes (eight dwords' low bytes) -> two dwords
+__device__ __forceinline__ void pack_q4(const uint32_t (&qd)[8], uint32_t &lo, uint32_t &hi)
+{
+    lo = __builtin_amdgcn_perm(__builtin_amdgcn_perm(qd[3], qd[2], 0x0c0c0400u), __builtin_amdgcn_perm(qd[1], qd[0], 0x0c0c0400u), 0x05040100u);
+    hi = __builtin_amdgcn_perm(__builtin_amdgcn_perm(qd[7], qd[6], 0x0c0c0400u), __builtin_amdgcn_perm(qd[5], qd[4], 0x0c0c0400u), 0x05040100u);
+}
 template <bool LEFT>
 __device__ __forceinline__ void approx_side(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t q_ext, int32_t s_ext,
-                                            int32_t n, int32_t X, int32_t t4, int32_t dt, int32_t &score, int32_t &best)
+                                            int32_t n, int32_t X, int32_t t4, int32_t dt, int32_t &score, int32_t &best,
+                                            bool have_pre = false, ApproxPre pre = ApproxPre{0, 0, 0, 0})
 {
     constexpr int32_t kDead = INT32_MIN / 2;
     const uint8_t *__restrict__ q4 = P.q4;
@@ -653,12 +666,15 @@ __device__ __forceinline__ void approx_side(const GbnExtParams &P, const uint8_t
         const int32_t sa = LEFT ? s_ext - 32 * (c + 1) : s_ext + 32 * c;
         int32_t bt = -1;
         if (steps == 8) {
-            uint32_t sw[2], qd[8];
-            __builtin_memcpy(sw, subj + (sa >> 2), 8);
-            __builtin_memcpy(qd, q4 + qa, 32);
+            uint32_t sw[2], qlo, qhi;
+            if (have_pre && c == 0) { sw[0] = pre.s0; sw[1] = pre.s1; qlo = pre.q0; qhi = pre.q1; }
+            else {
+                uint32_t qd[8];
+                __builtin_memcpy(sw, subj + (sa >> 2), 8);
+                __builtin_memcpy(qd, q4 + qa, 32);
+                pack_q4(qd, qlo, qhi);
+            }
             // byte k (address order) of S and Q = the four bases qa + 4k .. qa + 4k + 3
-            const uint32_t qlo = __builtin_amdgcn_perm(__builtin_amdgcn_perm(qd[3], qd[2], 0x0c0c0400u), __builtin_amdgcn_perm(qd[1], qd[0], 0x0c0c0400u), 0x05040100u);
-            const uint32_t qhi = __builtin_amdgcn_perm(__builtin_amdgcn_perm(qd[7], qd[6], 0x0c0c0400u), __builtin_amdgcn_perm(qd[5], qd[4], 0x0c0c0400u), 0x05040100u);
             uint32_t m[2] = {qlo ^ sw[0], qhi ^ sw[1]};
             #pragma unroll
             for (int h = 0; h < 2; h++) {                       // mismatching 2-bit groups per byte
@@ -708,7 +724,7 @@ __device__ void ungapped_approx(const GbnExtParams &P, const uint8_t *__restrict
     const int32_t uq = q_ext - 4 * bl, us = s_ext - 4 * bl;
     const int32_t new_q = br ? q_ext + 4 * br - 1 : q_ext;     // the reference's new_q: last base of the best step, or where the loop began
     Ungapped r;
-    if (score >= reduced_cutoff) {
+    if (score >= reduced_cutoff && !(GBN_EXT_ABL & 1)) {
         Ungapped e; e.q_start = 0; e.s_start = 0; e.length = 0; e.score = 0;
         ungapped_exact(P, subj, slen, q_off, s_off, X, e);
         r = e;
@@ -951,9 +967,10 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
             s_match_end += extended; r.flags = ok ? (extended << 8) : 1;
         }
         if (ok) {
-            const int lo = context_of(P, q_off);
+            const int lo = (GBN_EXT_ABL & 8) ? 0 : context_of(P, q_off);
             Ungapped u; u.q_start = 0; u.s_start = 0; u.length = 0; u.score = 0;
-            if (!P.container_hash && P.word < 11) ungapped_exact(P, subj, slen, q_off, s_off, -P.ctx_xdrop[lo], u);
+            if (GBN_EXT_ABL & 2) { }
+            else if (!P.container_hash && P.word < 11) ungapped_exact(P, subj, slen, q_off, s_off, -P.ctx_xdrop[lo], u);
             // (the exact pass stays inline: handing its seeds to a kernel of their own -- dense waves -- gained 0.1 ms per
             // 47 M seeds once that pass read 32 bases per load, not worth a kernel)
             else ungapped_approx(P, subj, slen, q_off, s_match_end, s_off, -P.ctx_xdrop[lo], P.ctx_reduced[lo], u);
@@ -962,7 +979,7 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
         }
         if (last) r.flags |= 4;
         r.q_off = q_off; r.s_off = s_off;
-        reinterpret_cast<GbnSeedExt *>(P.ext_rec)[pos] = r;
+        if (!(GBN_EXT_ABL & 16)) reinterpret_cast<GbnSeedExt *>(P.ext_rec)[pos] = r;
         if (r.flags & 2) (reinterpret_cast<GbnSeedHsp *>(reinterpret_cast<GbnSeedExt *>(P.ext_rec) + P.n))[pos] = hs;
     }
     if (P.ck_shift > 0) {
@@ -975,11 +992,256 @@ extern "C" __global__ void __launch_bounds__(256) seed_ext_kernel(GbnExtParams P
         if (threadIdx.x == 0) {
             uint32_t th = 0;
             for (int w = 0; w < 4; w++) { const uint32_t c = s_cnt[w]; s_cnt[w] = th; th += c; }
-            s_base = th ? atomicAdd(P.run_count, th) : 0u;
+            s_base = (GBN_EXT_ABL & 4) ? 0u : (th ? atomicAdd(P.run_count, th) : 0u);
         }
         __syncthreads();
-        if (head) P.run_heads[s_base + s_cnt[wave] + (uint32_t)__popcll(mh & ((1ull << lane) - 1))] = (uint32_t)pos;
+        if (head && !(GBN_EXT_ABL & 4)) P.run_heads[s_base + s_cnt[wave] + (uint32_t)__popcll(mh & ((1ull << lane) - 1))] = (uint32_t)pos;
     }
+}
+
+// ---- the exact pass from what the approximate pass already holds -------------------------------------------------
+// s_NuclUngappedExtendExact walks base by base from (q_off, s_off); its first ~30 bases either way are the bases of the
+// two rounds the approximate pass started with (32 left of q_ext, 32 right of it), which are in registers.  The walk is
+// taken from a mask of the "special" bases -- mismatches and query codes above 3 -- instead of base by base: a run of k
+// matches between two special bases adds k x reward in one step (inside it the running sum only rises, so the rule
+// `sum > 0 -> take it over, best end here` needs looking at once, at the run's end), a mismatch adds the penalty and is
+// where the walk can drop out; an ambiguity code or the sentinel goes through the matrix.  A walk that uses up the
+// window without dropping out (a real homolog) goes on base by base from memory (exact_walk_from).
+// Only what the exact walk decides is different from ungapped_exact: nothing.  Only how it gets there.
+namespace {
+// mismatching bases of a 32-base window, bit 31 - j for base j: x0 / x1 = XOR of query and subject bytes 0..3 / 4..7
+__device__ __forceinline__ uint32_t mism_mask32(uint32_t x0, uint32_t x1)
+{
+    uint32_t m[2] = {bswap32(x0), bswap32(x1)};                 // base 0 in the top two bits of m[0]
+    #pragma unroll
+    for (int h = 0; h < 2; h++) {
+        uint32_t v = (m[h] | (m[h] >> 1)) & 0x55555555u;        // bit 30 - 2j' of the half's base j'
+        v = (v | (v >> 1)) & 0x33333333u; v = (v | (v >> 2)) & 0x0f0f0f0fu; v = (v | (v >> 4)) & 0x00ff00ffu; v = (v | (v >> 8)) & 0xffffu;
+        m[h] = v;                                               // bit 15 - j'
+    }
+    return (m[0] << 16) | m[1];
+}
+// base j (0..31) of a window held as two dwords in address order
+__device__ __forceinline__ int win_base(uint32_t w0, uint32_t w1, int j)
+{
+    const uint32_t w = (j & 16) ? w1 : w0;
+    return (int)((w >> (8 * ((j >> 2) & 3) + 6 - 2 * (j & 3))) & 3u);
+}
+// base by base from memory, starting with base number t0 (0 = next to the seed) of n: the loop of ungapped_exact with its
+// state handed in.  best = bases of the best prefix.  Returns true when the walk dropped out.
+template <bool LEFT>
+__device__ __forceinline__ bool exact_walk_from(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t q_off, int32_t s_off,
+                                                int32_t n, int32_t X, int32_t t0, int32_t &sum, int32_t &score, int32_t &best)
+{
+    const uint8_t *q = P.q8;
+    const int32_t reward = P.matrix[0], penalty = P.matrix[1];
+    for (int32_t c = t0; c < n; c += 32) {
+        const int32_t steps = min(32, n - c);
+        const int64_t sa = LEFT ? (int64_t)s_off - c - 32 : (int64_t)s_off + c, qa = LEFT ? (int64_t)q_off - c - 32 : (int64_t)q_off + c;
+        const uint64_t x = bases32(subj, sa) ^ bases32(P.q2, qa);
+        const uint32_t amb = LEFT ? (bits32(P.qinv, qa) & (steps == 32 ? 0xffffffffu : ((1u << steps) - 1u))) : (bits32(P.qinv, qa) >> (32 - steps));
+        for (int32_t t = 0; t < steps; t++) {
+            const int32_t qi = LEFT ? q_off - c - 1 - t : q_off + c + t, si = LEFT ? s_off - c - 1 - t : s_off + c + t;
+            sum += amb ? P.matrix[q[qi] * 16 + base_at(subj, si)] : (((x >> (LEFT ? 2 * t : 62 - 2 * t)) & 3) ? penalty : reward);
+            if (sum > 0) { best = c + t + 1; score += sum; sum = 0; }
+            else if (sum < X) return true;
+        }
+    }
+    return false;
+}
+// One side of the exact walk over the bases the windows hold.  special / amb: LEFT bit t, RIGHT bit 63 - t for the base
+// at distance t from the seed; avail = bases of the side the windows cover (and the sequences have).
+template <bool LEFT>
+__device__ __forceinline__ bool exact_walk_window(const GbnExtParams &P, uint64_t special, uint64_t amb, int32_t avail, int32_t q_off, int32_t X,
+                                                  const ApproxPre &pl, const ApproxPre &pr, int32_t len4,
+                                                  int32_t &sum, int32_t &score, int32_t &best)
+{
+    const int32_t reward = P.matrix[0], penalty = P.matrix[1];
+    int32_t prev = 0;
+    while (special) {
+        const int32_t t = LEFT ? (int32_t)__builtin_ctzll(special) : (int32_t)__builtin_clzll(special);
+        if (t >= avail) break;
+        const unsigned long long bit = LEFT ? (1ull << t) : (0x8000000000000000ull >> t);
+        special &= ~bit;
+        sum += (t - prev) * reward;                             // the matches up to here
+        if (sum > 0) { best = t; score += sum; sum = 0; }
+        int32_t v = penalty;
+        if (amb & bit) {                                        // (a handful of lanes: near a query's end, at an N)
+            const int32_t qi = LEFT ? q_off - 1 - t : q_off + t;
+            const int j = LEFT ? 31 - len4 - t : 32 - len4 + t;                    // index in the 64-base window
+            const int sb = j < 32 ? win_base(pl.s0, pl.s1, j) : win_base(pr.s0, pr.s1, j - 32);
+            v = P.matrix[P.q8[qi] * 16 + sb];
+        }
+        sum += v;
+        if (sum > 0) { best = t + 1; score += sum; sum = 0; }
+        else if (sum < X) return true;
+        prev = t + 1;
+    }
+    sum += (avail - prev) * reward;                             // matches to the end of what is there
+    if (sum > 0) { best = avail; score += sum; sum = 0; }
+    return false;
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------
+// seed_ext_kernel for the shape it is launched on at scale (composite keys, hash container, q4 and ctx_blk present, no
+// mask re-check).  Two things bounded the general kernel above on 47 M seeds, 2.1 ms each on their own
+// (ablations of round 3): (1) one reservation on the global run counter per 256 seeds = 183,000 atomics on one
+// address at ~90 per microsecond; (2) a chain of a dozen dependent memory round trips per seed -- key, its neighbours,
+// subject offsets, context hint, context offsets, drop-offs, subject left, query left, subject right, query right, ...
+// -- with every wave slot of the chip already taken.  Here a WAVE walks a contiguous stretch of the seeds 64 at a
+// time: run heads wait in a buffer of its own in LDS (one reservation per ~60 heads, no barrier anywhere), and the
+// loads of a seed are issued in three batches -- the keys; then everything the keys determine; then the subject -- before
+// any of them is looked at.
+// ---------------------------------------------------------------------------------------------------
+#ifndef GBN_CK_OCC
+#define GBN_CK_OCC 8        // waves per SIMD seed_ext_ck_kernel is compiled for
+#endif
+extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel(GbnExtParams P)
+{
+    constexpr int HB = 128;
+    __shared__ uint32_t s_hb[4][HB];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    uint32_t *hb = s_hb[wave];
+    int nh = 0;                                                 // wave-uniform: heads waiting in hb
+    auto flush = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(P.run_count, (uint32_t)nh);
+        base = __shfl(base, 0);
+        for (int k = lane; k < nh; k += 64) P.run_heads[base + (uint32_t)k] = hb[k];
+        nh = 0;
+    };
+    // round r of wave w takes the 64 seeds of chunk r * waves + w: what the waves in flight work on at any moment is ONE
+    // window of a few hundred thousand consecutive seeds -- a dozen subjects, which stay in every XCD's L2 (a contiguous
+    // stretch per wave had 256 subjects in flight at once and every subject line came from HBM: 2.6 instead of ... ms)
+    const int64_t nwaves = (int64_t)gridDim.x * 4, w = (int64_t)blockIdx.x * 4 + wave;
+    const int64_t j_hi = P.n;
+    const int gb = P.group_bits ? P.group_bits : 32;
+    const int vb = P.ck_vbits;
+    const uint64_t vmask = (1ull << vb) - 1ull;
+    const uint32_t gmask = (gb >= 32) ? 0xffffffffu : ((1u << gb) - 1u);
+    const int32_t t4 = P.score_table[0], dt = P.score_table[1] - t4;
+    const uint8_t *__restrict__ q4 = P.q4;
+    GbnSeedExt *__restrict__ rec = reinterpret_cast<GbnSeedExt *>(P.ext_rec);
+    for (int64_t jb = w * 64; jb < j_hi; jb += nwaves * 64) {
+        const int64_t j = min(jb + lane, j_hi - 1);             // (lanes past the end redo the last seed and store nothing)
+        const bool live = jb + lane < j_hi;
+        // ---- batch 1: the key and its neighbours
+        const uint64_t w0 = P.key_group[j], wm = P.key_group[j > 0 ? j - 1 : 0], wp = P.key_group[j + 1 < P.n ? j + 1 : j];
+        const uint64_t key = w0 >> vb;
+        const uint32_t val = vb ? (uint32_t)(w0 & vmask) : P.idx[j];
+        const uint32_t qk = val >> 8;
+        int64_t a = j, e = j + 1;
+        int64_t pos = j;
+        const bool tie = (j > 0 && (wm >> vb) == key) || (j + 1 < P.n && (wp >> vb) == key);
+        uint64_t before = wm, after = wp;                       // the keys in front of / behind the group of equal keys
+        if (tie) {      // seeds of one (subject, slot, scan position): a handful per million, ordered by the query key's high bits
+            while (a > 0 && (P.key_group[a - 1] >> vb) == key) a--;
+            while (e < P.n && (P.key_group[e] >> vb) == key) e++;
+            int64_t rank = 0;
+            for (int64_t m = a; m < e; m++) {
+                if (m == j) continue;
+                const uint32_t qm = (vb ? (uint32_t)(P.key_group[m] & vmask) : P.idx[m]) >> 8;
+                rank += (qm < qk || (qm == qk && m < j)) ? 1 : 0;
+            }
+            pos = a + rank;
+            before = P.key_group[a > 0 ? a - 1 : 0]; after = P.key_group[e < P.n ? e : P.n - 1];
+        }
+        const uint64_t run = key >> P.ck_shift;
+        const bool head = live && pos == a && (a == 0 || (before >> (vb + P.ck_shift)) != run);
+        const bool last = pos == e - 1 && (e >= P.n || (after >> (vb + P.ck_shift)) != run);
+        const int32_t subj_id = (int32_t)(run >> gb) + P.ck_subj_base;
+        const uint32_t slot = (uint32_t)run & gmask;
+        const int32_t s_scan = (int32_t)(key & ((1ull << P.ck_s_bits) - 1ull));
+        const uint32_t ql = ((uint32_t)s_scan - slot) & gmask;  // q_pos modulo the number of slots
+        int32_t q_pos;
+        if (P.ck_q_desc) {
+            const uint32_t qmax = (P.ck_q_bits >= 32) ? 0xffffffffu : ((1u << P.ck_q_bits) - 1u);
+            q_pos = (int32_t)(qmax - ((P.ck_qh_bits ? (qk << gb) : 0u) | ((qmax - ql) & gmask)));
+        } else q_pos = (int32_t)((P.ck_qh_bits ? (qk << gb) : 0u) | ql);
+        const int32_t ext_left = (int32_t)(val & 0xffu);
+        const int32_t q_off = q_pos - ext_left, s_off = s_scan - ext_left;
+        // ---- batch 2: what the key determines -- subject offsets, the context block, the first round of query bytes either side
+        const int32_t len4 = (4 - (s_off & 3)) & 3;
+        const int32_t q_ext = q_off + len4, s_ext = s_off + len4;
+        const int64_t boff = P.byte_off[subj_id];
+        const int32_t slen = P.len[subj_id];
+        int32_t cb[2];
+        __builtin_memcpy(cb, P.ctx_blk + 2 * (q_off >> P.ctx_hint_shift), 8);
+        uint32_t qdl[8], qdr[8], qiv[3];
+        __builtin_memcpy(qdl, q4 + (q_ext - 32), 32);           // (readable whatever the seed: 64 bytes of padding either side)
+        __builtin_memcpy(qdr, q4 + q_ext, 32);
+        // the "matches nothing" bits of the same 64 bases, for the exact pass (three aligned dwords hold them at any offset)
+        __builtin_memcpy(qiv, P.qinv + 4 * ((int64_t)(q_ext - 32) >> 5), 12);
+        // ---- batch 3: the subject's first rounds (16 padding bytes in front of every subject, 64 behind), the context's numbers
+        const uint8_t *__restrict__ subj = P.db + boff;
+        uint32_t swl[2], swr[2];
+        __builtin_memcpy(swl, subj + ((s_ext - 32) >> 2), 8);
+        __builtin_memcpy(swr, subj + (s_ext >> 2), 8);
+        ApproxPre pl, pr;
+        pack_q4(qdl, pl.q0, pl.q1); pack_q4(qdr, pr.q0, pr.q1);
+        pl.s0 = swl[0]; pl.s1 = swl[1]; pr.s0 = swr[0]; pr.s1 = swr[1];
+        int lo;
+        if (cb[1] == INT32_MIN) lo = context_of(P, q_off);
+        else lo = cb[0] + (q_off >= cb[1] ? 1 : 0);
+        // (a lane that has dropped out keeps a sum of INT32_MIN / 2 for the rest of its round: any drop-off a score of
+        // this path can reach -- |penalty| <= 127 over sequences of < 2^21 bases -- is far above it)
+        const int32_t X = max(-P.ctx_xdrop[lo], -(1 << 28)), reduced = P.ctx_reduced[lo], cutoff = P.ctx_cutoff[lo];
+        // ---- the extension
+        GbnSeedExt r; GbnSeedHsp hs;
+        r.q_off = q_off; r.s_off = s_off; r.s_orig = s_off; r.flags = last ? 4 : 0;
+        const int32_t s_match_end = s_off + P.word;
+        {
+            int32_t score = 0, bl = 0, br = 0;
+            approx_side<true>(P, subj, q_ext, s_ext, min(q_ext, s_ext) >> 2, X, t4, dt, score, bl, true, pl);
+            approx_side<false>(P, subj, q_ext, s_ext, min(P.qlen - q_ext, slen - s_ext) >> 2, X, t4, dt, score, br, true, pr);
+            const int32_t uq = q_ext - 4 * bl, us = s_ext - 4 * bl;
+            const int32_t new_q = br ? q_ext + 4 * br - 1 : q_ext;
+            if (score >= reduced) {
+                // the exact pass, from the two windows (see exact_walk_window)
+                const int ish = (q_ext - 32) & 31;
+                const uint32_t i0 = bswap32(qiv[0]), i1 = bswap32(qiv[1]), i2 = bswap32(qiv[2]);
+                const uint32_t ambl = ish ? __builtin_amdgcn_alignbit(i0, i1, 32 - ish) : i0, ambr = ish ? __builtin_amdgcn_alignbit(i1, i2, 32 - ish) : i1;
+                // (a code above 3 spills into the two bits of the base in FRONT of it when the byte of its group is put
+                // together -- (q[k] << 6) | (q[k+1] << 4) | ... -- so that base is read from q8 as well; groups do not
+                // straddle the windows' ends)
+                uint64_t amb64 = ((uint64_t)ambl << 32) | ambr;                 // bit 63 - j for base j of the 64
+                amb64 |= amb64 << 1;
+                const uint64_t sp64 = (((uint64_t)mism_mask32(pl.q0 ^ pl.s0, pl.q1 ^ pl.s1) << 32) | mism_mask32(pr.q0 ^ pr.s0, pr.q1 ^ pr.s1)) | amb64;
+                const int32_t n_l = min(q_off, s_off), n_r = min(P.qlen - q_off, slen - s_off);
+                const int32_t a_l = min(32 - len4, n_l), a_r = min(32 + len4, n_r);
+                int32_t xs = 0, sum = 0, b_l = 0, b_r = 0;
+                // left: base at distance t is window base 31 - len4 - t, i.e. bit 32 + len4 + t of the 64-bit masks
+                bool stop = exact_walk_window<true>(P, sp64 >> (32 + len4), amb64 >> (32 + len4), a_l, q_off, X, pl, pr, len4, sum, xs, b_l);
+                if (!stop && a_l < n_l) exact_walk_from<true>(P, subj, q_off, s_off, n_l, X, a_l, sum, xs, b_l);
+                sum = 0;
+                // right: base at distance t is window base 32 - len4 + t, i.e. bit 63 - t after a shift by 32 - len4
+                stop = exact_walk_window<false>(P, sp64 << (32 - len4), amb64 << (32 - len4), a_r, q_off, X, pl, pr, len4, sum, xs, b_r);
+                if (!stop && a_r < n_r) exact_walk_from<false>(P, subj, q_off, s_off, n_r, X, a_r, sum, xs, b_r);
+                hs.q_start = q_off - b_l; hs.s_start = s_off - b_l; hs.length = b_l + b_r; hs.score = xs;
+            } else {
+                hs.q_start = uq; hs.s_start = us; hs.score = score;
+                hs.length = max(s_match_end - us, new_q - uq + 1);
+            }
+        }
+        if (hs.score >= cutoff) r.flags |= 2;
+#ifdef GBN_DBG_SEED
+        if (live && q_off == 986 && s_off == 359220) printf("dbg seed: lo %d X %d red %d cut %d len4 %d score %d len %d qs %d pl %08x %08x %08x %08x pr %08x %08x %08x %08x qiv %08x %08x %08x\n", lo, X, reduced, cutoff, len4, hs.score, hs.length, hs.q_start, pl.s0, pl.s1, pl.q0, pl.q1, pr.s0, pr.s1, pr.q0, pr.q1, qiv[0], qiv[1], qiv[2]);
+#endif
+        if (live) {
+            rec[pos] = r;
+            if (r.flags & 2) (reinterpret_cast<GbnSeedHsp *>(rec + P.n))[pos] = hs;
+        }
+        // ---- run heads: into the wave's buffer, out of it when the next 64 seeds might not fit
+        const unsigned long long mh = __ballot(head);
+        if (mh) {
+            if (head) hb[nh + __popcll(mh & lt)] = (uint32_t)pos;
+            nh += __popcll(mh);
+            if (nh > HB - 64) flush();
+        }
+    }
+    if (nh) flush();
 }
 
 extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams P)
@@ -2061,6 +2323,13 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
         hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, q);
         return hipGetLastError(); }
     if (p.ck_shift > 0 && p.ext_rec) {      // composite keys: the extension kernel finds the run heads on its way
+        // (hash container, word sizes from 11 up: the approximate extension; the mask re-check stays with the general kernel)
+        static const bool ck2 = !(getenv("GBN_SEED_EXT_CK") && atoi(getenv("GBN_SEED_EXT_CK")) == 0);
+        if (ck2 && p.q4 && p.ctx_blk && !p.masked && (p.container_hash || p.word >= 11)) {
+            // a stretch of 64 x k seeds per wave: every wave slot of the chip taken, eight or more rounds per wave
+            const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((p.n + 2047) / 2048, 256 * 32));
+            hipLaunchKernelGGL(seed_ext_ck_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+        } else
         hipLaunchKernelGGL(seed_ext_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
         hipLaunchKernelGGL(diag_replay_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
         return hipGetLastError();

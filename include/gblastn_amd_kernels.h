@@ -116,6 +116,10 @@ typedef struct GbnExtParams {
      * sentinels spilling as they do there; readable from q4 - 64 to q4 + qlen + 64.  With it the approximate extension
      * takes eight steps per round from two loads (null: step by step from q8 / q2) */
     const uint8_t *q4;
+    /* optional: ctx_blk[2 * (q >> ctx_hint_shift)] = the context the block's first position lies in, [.. + 1] = the query
+     * offset at which the next context begins (INT32_MAX: none; INT32_MIN: more than one context begins inside the block,
+     * look it up through ctx_hint / ctx_off) -- a seed's context from one 8-byte load */
+    const int32_t *ctx_blk;
 } GbnExtParams;
 
 typedef struct GbnGapParams {
