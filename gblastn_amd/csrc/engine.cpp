@@ -67,7 +67,7 @@ struct DeviceBatch {
     const uint8_t *q8 = nullptr;    // q8_base + qpad
     uint8_t *q2_base = nullptr, *qinv_base = nullptr;   // 2-bit packed query + "matches nothing" bitmap
     const uint8_t *q2 = nullptr, *qinv = nullptr;       // ... at base 0 (256 bases of padding either side)
-    uint8_t *q4_base = nullptr; const uint8_t *q4 = nullptr;   // four bases per byte at every offset (lut_q4_kernel), q4[0] = query position 0
+    uint8_t *q4_base = nullptr; int64_t q4_plane = 0;   // four bases per byte at every offset, in four planes by offset mod 4 (lut_q4_kernel)
     uint32_t *pv = nullptr, *cellw = nullptr, *cell_start = nullptr, *cellt = nullptr, *side_start = nullptr;
     uint16_t *sidet = nullptr;
     unsigned long long *ent = nullptr;
@@ -549,9 +549,10 @@ int upload_batch(GbnBatch &b) {
         HIPCHK(hipMemsetAsync(d->qinv_base, 0xff, qi_bytes, E.stream_build));
         HIPCHK(lut_pack_query(d->q8_base, (int64_t)b.qbuf.size(), (int64_t)b.qpad - pad, n, d->q2_base, d->qinv_base, E.stream_build));
         d->q2 = d->q2_base + pad / 4; d->qinv = d->qinv_base + pad / 8;
-        if ((rc = dev_alloc(d->q4_base, b.qbuf.size() + 64))) return rc;
-        HIPCHK(lut_pack_q4(d->q8_base, (int64_t)b.qbuf.size(), d->q4_base, E.stream_build));
-        d->q4 = d->q4_base + b.qpad;
+        d->q4_plane = ((int64_t)b.qbuf.size() + 3) / 4 + 64;          // (an 8- or 16-byte load may start at a plane's last byte)
+        if ((rc = dev_alloc(d->q4_base, (size_t)(4 * d->q4_plane)))) return rc;
+        HIPCHK(hipMemsetAsync(d->q4_base, 0xff, (size_t)(4 * d->q4_plane), E.stream_build));
+        HIPCHK(lut_pack_q4(d->q8_base, (int64_t)b.qbuf.size(), d->q4_base, d->q4_plane, E.stream_build));
     }
     if (host_lookup) {
         HIPCHK(hipStreamSynchronize(E.stream_build));       // q2 / qinv packed: no event travels with a host-built batch
@@ -1100,7 +1101,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         GbnExtParams X; std::memset(&X, 0, sizeof(X));
         X.db = db.d_packed; X.byte_off = db.d_byte_off; X.len = db.d_len;
         X.seeds = seeds; X.idx = E.idx_a; X.key_group = E.key_b; X.n = n;
-        X.q8 = d->q8; X.qlen = b.qlen; X.q2 = d->q2; X.qinv = d->qinv; X.q4 = d->q4;
+        X.q8 = d->q8; X.qlen = b.qlen; X.q2 = d->q2; X.qinv = d->qinv; X.q4 = d->q4_base; X.q4_plane = d->q4_plane; X.q4_origin = b.qpad;
         X.ctx_off = d->ctx_off; X.ctx_len = d->ctx_len; X.ctx_xdrop = d->ctx_xdrop;
         X.ctx_cutoff = d->ctx_cutoff; X.ctx_reduced = d->ctx_reduced; X.nctx = (int32_t)b.ctx.size();
         X.matrix = d->matrix; X.score_table = d->score_table;
@@ -1872,7 +1873,7 @@ int gbn_batch_ext_params(const GbnBatch *b, const GbnDb *db, GbnExtParams *X) {
     const DeviceBatch *d = b->dev;
     std::memset(X, 0, sizeof(*X));
     X->db = db->d_packed; X->byte_off = db->d_byte_off; X->len = db->d_len;
-    X->q8 = d->q8; X->qlen = b->qlen; X->q2 = d->q2; X->qinv = d->qinv; X->q4 = d->q4;
+    X->q8 = d->q8; X->qlen = b->qlen; X->q2 = d->q2; X->qinv = d->qinv; X->q4 = d->q4_base; X->q4_plane = d->q4_plane; X->q4_origin = b->qpad;
     X->ctx_off = d->ctx_off; X->ctx_len = d->ctx_len; X->ctx_xdrop = d->ctx_xdrop;
     X->ctx_cutoff = d->ctx_cutoff; X->ctx_reduced = d->ctx_reduced; X->nctx = (int32_t)b->ctx.size();
     X->matrix = d->matrix; X->score_table = d->score_table;

@@ -644,12 +644,12 @@ __device__ void ungapped_approx_steps(const GbnExtParams &P, const uint8_t *__re
 // Only rounds that are cut short by the end of the query or the subject go step by step.
 // first round of a side, loaded ahead by the caller (seed_ext_ck_kernel issues the loads of both sides before it
 // looks at either): the eight subject bytes and the 32 q4 bytes of the round
-struct ApproxPre { uint32_t s0, s1, q0, q1; };      // subject bytes, query bytes (every fourth q4 byte, packed), address order
-// every fourth byte of 32 consecutive q4 bytes (eight dwords' low bytes) -> two dwords
-__device__ __forceinline__ void pack_q4(const uint32_t (&qd)[8], uint32_t &lo, uint32_t &hi)
+struct ApproxPre { uint32_t s0, s1, q0, q1; };      // subject bytes, query bytes (q4 bytes of eight consecutive steps), address order
+// where the q4 bytes of the steps that start at query position p lie (GbnExtParams::q4: four planes by offset mod 4)
+__device__ __forceinline__ const uint8_t *q4_at(const GbnExtParams &P, int32_t p)
 {
-    lo = __builtin_amdgcn_perm(__builtin_amdgcn_perm(qd[3], qd[2], 0x0c0c0400u), __builtin_amdgcn_perm(qd[1], qd[0], 0x0c0c0400u), 0x05040100u);
-    hi = __builtin_amdgcn_perm(__builtin_amdgcn_perm(qd[7], qd[6], 0x0c0c0400u), __builtin_amdgcn_perm(qd[5], qd[4], 0x0c0c0400u), 0x05040100u);
+    const int32_t k = p + P.q4_origin;
+    return P.q4 + (int64_t)(k & 3) * P.q4_plane + (k >> 2);
 }
 template <bool LEFT>
 __device__ __forceinline__ void approx_side(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t q_ext, int32_t s_ext,
@@ -657,7 +657,6 @@ __device__ __forceinline__ void approx_side(const GbnExtParams &P, const uint8_t
                                             bool have_pre = false, ApproxPre pre = ApproxPre{0, 0, 0, 0})
 {
     constexpr int32_t kDead = INT32_MIN / 2;
-    const uint8_t *__restrict__ q4 = P.q4;
     int32_t sum = 0;
     best = 0;                                                   // steps the best prefix covers
     for (int32_t c = 0; c * 8 < n; c++) {
@@ -669,10 +668,10 @@ __device__ __forceinline__ void approx_side(const GbnExtParams &P, const uint8_t
             uint32_t sw[2], qlo, qhi;
             if (have_pre && c == 0) { sw[0] = pre.s0; sw[1] = pre.s1; qlo = pre.q0; qhi = pre.q1; }
             else {
-                uint32_t qd[8];
+                uint32_t qq[2];
                 __builtin_memcpy(sw, subj + (sa >> 2), 8);
-                __builtin_memcpy(qd, q4 + qa, 32);
-                pack_q4(qd, qlo, qhi);
+                __builtin_memcpy(qq, q4_at(P, qa), 8);
+                qlo = qq[0]; qhi = qq[1];
             }
             // byte k (address order) of S and Q = the four bases qa + 4k .. qa + 4k + 3
             uint32_t m[2] = {qlo ^ sw[0], qhi ^ sw[1]};
@@ -1122,7 +1121,6 @@ extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel
     const uint64_t vmask = (1ull << vb) - 1ull;
     const uint32_t gmask = (gb >= 32) ? 0xffffffffu : ((1u << gb) - 1u);
     const int32_t t4 = P.score_table[0], dt = P.score_table[1] - t4;
-    const uint8_t *__restrict__ q4 = P.q4;
     GbnSeedExt *__restrict__ rec = reinterpret_cast<GbnSeedExt *>(P.ext_rec);
     for (int64_t jb = w * 64; jb < j_hi; jb += nwaves * 64) {
         const int64_t j = min(jb + lane, j_hi - 1);             // (lanes past the end redo the last seed and store nothing)
@@ -1169,19 +1167,19 @@ extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel
         const int32_t slen = P.len[subj_id];
         int32_t cb[2];
         __builtin_memcpy(cb, P.ctx_blk + 2 * (q_off >> P.ctx_hint_shift), 8);
-        uint32_t qdl[8], qdr[8], qiv[3];
-        __builtin_memcpy(qdl, q4 + (q_ext - 32), 32);           // (readable whatever the seed: 64 bytes of padding either side)
-        __builtin_memcpy(qdr, q4 + q_ext, 32);
+        // (the sixteen steps of the two rounds either side of q_ext: sixteen consecutive bytes of one plane; readable
+        // whatever the seed: 64 positions of padding either side)
+        uint32_t qq[4], qiv[3];
+        __builtin_memcpy(qq, q4_at(P, q_ext - 32), 16);
         // the "matches nothing" bits of the same 64 bases, for the exact pass (three aligned dwords hold them at any offset)
         __builtin_memcpy(qiv, P.qinv + 4 * ((int64_t)(q_ext - 32) >> 5), 12);
         // ---- batch 3: the subject's first rounds (16 padding bytes in front of every subject, 64 behind), the context's numbers
         const uint8_t *__restrict__ subj = P.db + boff;
-        uint32_t swl[2], swr[2];
-        __builtin_memcpy(swl, subj + ((s_ext - 32) >> 2), 8);
-        __builtin_memcpy(swr, subj + (s_ext >> 2), 8);
+        uint32_t sw[4];
+        __builtin_memcpy(sw, subj + ((s_ext - 32) >> 2), 16);  // the 64 subject bases of the same two rounds
         ApproxPre pl, pr;
-        pack_q4(qdl, pl.q0, pl.q1); pack_q4(qdr, pr.q0, pr.q1);
-        pl.s0 = swl[0]; pl.s1 = swl[1]; pr.s0 = swr[0]; pr.s1 = swr[1];
+        pl.q0 = qq[0]; pl.q1 = qq[1]; pr.q0 = qq[2]; pr.q1 = qq[3];
+        pl.s0 = sw[0]; pl.s1 = sw[1]; pr.s0 = sw[2]; pr.s1 = sw[3];
         int lo;
         if (cb[1] == INT32_MIN) lo = context_of(P, q_off);
         else lo = cb[0] + (q_off >= cb[1] ? 1 : 0);

@@ -28,7 +28,7 @@ hipError_t lut_cells(const LutBuild &b, hipStream_t st);
 hipError_t lut_side(const LutBuild &b, hipStream_t st);
 hipError_t lut_pv(const LutBuild &b, hipStream_t st);
 // 2-bit packed copy of the query (4 bases per byte, base 0 in bits 7..6) and its "matches nothing" bitmap (MSB first)
-hipError_t lut_pack_q4(const uint8_t *qbuf, int64_t qbuf_len, uint8_t *q4, hipStream_t st);
+hipError_t lut_pack_q4(const uint8_t *qbuf, int64_t qbuf_len, uint8_t *q4, int64_t plane, hipStream_t st);
 hipError_t lut_pack_query(const uint8_t *qbuf, int64_t qbuf_len, int64_t first, int64_t n, uint8_t *q2, uint8_t *qinv, hipStream_t st);
 
 }  // namespace gbn

@@ -160,27 +160,30 @@ __global__ void lut_pack_query_kernel(const uint8_t *qbuf, int64_t qbuf_len, int
     qinv[t] = (uint8_t)inv;
 }
 
-// "four bases per byte at every offset" copy of the query for the approximate ungapped extension: q4[k] = the byte
-// s_NuclUngappedExtend puts together from the unpacked codes at query offset k, (q[k] << 6) | (q[k+1] << 4) | (q[k+2] << 2)
+// "four bases per byte at every offset" copy of the query for the approximate ungapped extension: the byte
+// s_NuclUngappedExtend puts together from the unpacked codes at buffer offset k, (q[k] << 6) | (q[k+1] << 4) | (q[k+2] << 2)
 // | q[k+3] truncated to 8 bits (CORE/na_ungapped.c:296, :323) -- codes above 3 (ambiguity, the sentinel between
-// the strands) spill into their neighbours' bits exactly as they do there.  15 beyond the buffer.
-__global__ void lut_q4_kernel(const uint8_t *qbuf, int64_t qbuf_len, uint8_t *q4)
+// the strands) spill into their neighbours' bits exactly as they do there; 15 beyond the buffer.  Stored in FOUR PLANES by
+// k mod 4 (byte of offset k at plane k & 3, index k >> 2): an extension steps through the query four bases at a time, so
+// the bytes of consecutive steps -- offsets k, k + 4, k + 8, ... -- are consecutive bytes of one plane, eight steps one
+// 8-byte load (from one array they were every fourth byte of 32: two 16-byte gathers per round).
+__global__ void lut_q4_kernel(const uint8_t *qbuf, int64_t qbuf_len, uint8_t *q4, int64_t plane)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= qbuf_len) return;
     uint32_t v = 0;
     for (int j = 0; j < 4; j++) v |= (uint32_t)(k + j < qbuf_len ? qbuf[k + j] : 15) << (6 - 2 * j);
-    q4[k] = (uint8_t)v;
+    q4[(k & 3) * plane + (k >> 2)] = (uint8_t)v;
 }
 
 }  // namespace
 
 namespace gbn {
 
-hipError_t lut_pack_q4(const uint8_t *qbuf, int64_t qbuf_len, uint8_t *q4, hipStream_t st)
+hipError_t lut_pack_q4(const uint8_t *qbuf, int64_t qbuf_len, uint8_t *q4, int64_t plane, hipStream_t st)
 {
     if (qbuf_len <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_q4_kernel, dim3((unsigned)((qbuf_len + 255) / 256)), dim3(256), 0, st, qbuf, qbuf_len, q4);
+    hipLaunchKernelGGL(lut_q4_kernel, dim3((unsigned)((qbuf_len + 255) / 256)), dim3(256), 0, st, qbuf, qbuf_len, q4, plane);
     return hipGetLastError();
 }
 

@@ -111,11 +111,13 @@ typedef struct GbnExtParams {
     /* ck_vbits > 0: the value travels in the key's low ck_vbits bits (key_group[i] = composite key << ck_vbits | value,
      * sorted on the bits above them: a sort of keys only) and idx is not read */
     int32_t ck_vbits;
-    /* optional: the query four bases per byte at EVERY offset, q4[k] = (uint8_t)((q8[k] << 6) | (q8[k+1] << 4) | (q8[k+2] << 2)
-     * | q8[k+3]) -- the byte s_NuclUngappedExtend builds per step (CORE/na_ungapped.c:296, :323), ambiguity codes and
-     * sentinels spilling as they do there; readable from q4 - 64 to q4 + qlen + 64.  With it the approximate extension
-     * takes eight steps per round from two loads (null: step by step from q8 / q2) */
-    const uint8_t *q4;
+    /* optional: the query four bases per byte at EVERY offset -- for query position p the byte s_NuclUngappedExtend
+     * builds per step, (uint8_t)((q8[p] << 6) | (q8[p+1] << 4) | (q8[p+2] << 2) | q8[p+3]) (CORE/na_ungapped.c:296, :323;
+     * ambiguity codes and sentinels spill as they do there) -- in four planes by offset: with k = p + q4_origin the byte is
+     * q4[(k & 3) * q4_plane + (k >> 2)], so that the bytes of consecutive 4-base steps are consecutive in memory.
+     * Positions -64 .. qlen + 64 must be there, and 16 readable bytes behind every plane.  With it the approximate
+     * extension takes eight steps per round from two 8-byte loads (null: step by step from q8 / q2) */
+    const uint8_t *q4; int64_t q4_plane; int32_t q4_origin;
     /* optional: ctx_blk[2 * (q >> ctx_hint_shift)] = the context the block's first position lies in, [.. + 1] = the query
      * offset at which the next context begins (INT32_MAX: none; INT32_MIN: more than one context begins inside the block,
      * look it up through ctx_hint / ctx_off) -- a seed's context from one 8-byte load */
