@@ -86,10 +86,16 @@ struct Engine {
     int num_cu = 256;
     // growable scratch
     GbnDevSeed *seeds = nullptr; size_t seed_cap = 0;
-    uint64_t *key_a = nullptr, *key_b = nullptr; uint32_t *idx_a = nullptr, *idx_b = nullptr;
-    int32_t *cell_diag = nullptr, *cell_level = nullptr; size_t key_cap = 0;
-    int32_t *ext_rec = nullptr;     // 8 ints per seed: seed_ext_kernel -> diag_replay_kernel
-    void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    // sort keys, run heads, container scratch and extension records of a range's seed stage.  Two sets: the second half
+    // of the stage (extension + replay) of range k runs on the second stream next to the scan of range k + 1, whose sort
+    // fills the other set (search_range)
+    struct KeySet {
+        uint64_t *key_a = nullptr, *key_b = nullptr; uint32_t *idx_a = nullptr, *idx_b = nullptr;
+        int32_t *cell_diag = nullptr, *cell_level = nullptr; size_t key_cap = 0;
+        int32_t *ext_rec = nullptr;     // 8 ints per seed: seed_ext_kernel -> diag_replay_kernel
+        void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+    } ks[2];
+    int pending_ks = -1;            // the set the stage in flight works on (-1: none)
     // initial hits / gapped extensions / gapped scratch exist twice: the gapped stage of one range
     // (stream2 + a host thread) overlaps the scan of the next range or query batch
     GbnDevInitHit *ihits_s[2] = {nullptr, nullptr}; GbnDevGapped *gapped_s[2] = {nullptr, nullptr}; size_t ihit_cap_s[2] = {0, 0};
@@ -107,7 +113,7 @@ struct Engine {
     GbnDevSeed *slice_seg = nullptr; size_t slice_seg_cap = 0;        // scan_slice_kernel: the workgroups' seed segments
     bool seg_valid = false; int seg_n = 0; uint32_t seg_len = 0;       // the last scan left its seeds there (seg_n segments of seg_len slots, counts in rare_counts), not in `seeds`
     GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
-    hipEvent_t ev_seed = nullptr; bool pending_uses_keys = false;
+    hipEvent_t ev_seed = nullptr;
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
     uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;             // per-run stream cursors (6-byte records)
     GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
@@ -654,24 +660,24 @@ static int grow_seed_buffers(size_t want) {
     E.seed_cap = want;
     return GBN_OK;
 }
-static int grow_key_buffers(size_t n) {
-    if (n <= E.key_cap) return GBN_OK;
-    dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
-    dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.ext_rec); dev_free(E.sort_tmp);
+static int grow_key_buffers(Engine::KeySet &KS, size_t n) {
+    if (n <= KS.key_cap) return GBN_OK;
+    dev_free(KS.key_a); dev_free(KS.key_b); dev_free(KS.idx_a); dev_free(KS.idx_b);
+    dev_free(KS.cell_diag); dev_free(KS.cell_level); dev_free(KS.ext_rec); dev_free(KS.sort_tmp);
     size_t cap = std::max<size_t>(n + n / 8, 1 << 16);      // (room to spare: seed counts of consecutive ranges differ by a fraction of a percent, and a regrow frees and allocates gigabytes)
     int rc;
-    if ((rc = dev_alloc(E.key_a, cap)) || (rc = dev_alloc(E.key_b, cap)) || (rc = dev_alloc(E.idx_a, cap)) ||
-        (rc = dev_alloc(E.idx_b, cap)) || (rc = dev_alloc(E.cell_diag, cap)) || (rc = dev_alloc(E.cell_level, cap)))
+    if ((rc = dev_alloc(KS.key_a, cap)) || (rc = dev_alloc(KS.key_b, cap)) || (rc = dev_alloc(KS.idx_a, cap)) ||
+        (rc = dev_alloc(KS.idx_b, cap)) || (rc = dev_alloc(KS.cell_diag, cap)) || (rc = dev_alloc(KS.cell_level, cap)))
         return rc;
     static const size_t compact_min = getenv("GBN_DIAG_COMPACT_MIN") ? (size_t)atoll(getenv("GBN_DIAG_COMPACT_MIN")) : (size_t)GBN_DIAG_COMPACT_MIN;
-    if (cap >= compact_min && (rc = dev_alloc(E.ext_rec, cap * 8))) return rc;
+    if (cap >= compact_min && (rc = dev_alloc(KS.ext_rec, cap * 8))) return rc;
     size_t bytes = 0;
-    HIPCHK(sort_pairs_u64(nullptr, bytes, E.key_a, E.key_b, E.idx_a, E.idx_b, (int64_t)cap, 64, E.stream));
+    HIPCHK(sort_pairs_u64(nullptr, bytes, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, (int64_t)cap, 64, E.stream));
     size_t bytes_keys = 0;
-    HIPCHK(sort_keys_u64(nullptr, bytes_keys, E.key_a, E.key_b, (int64_t)cap, 0, 64, E.stream));
+    HIPCHK(sort_keys_u64(nullptr, bytes_keys, KS.key_a, KS.key_b, (int64_t)cap, 0, 64, E.stream));
     bytes = std::max(bytes, bytes_keys);
-    HIPCHK(pool_alloc(&E.sort_tmp, bytes));
-    E.sort_tmp_bytes = bytes; E.key_cap = cap;
+    HIPCHK(pool_alloc(&KS.sort_tmp, bytes));
+    KS.sort_tmp_bytes = bytes; KS.key_cap = cap;
     return GBN_OK;
 }
 
@@ -698,7 +704,7 @@ static int wait_pending_gpu() {
     if (!E.has_pending) return GBN_OK;
     int rc = E.pending.get();
     if (rc) record_failure(E.pending_res, rc, E.pending_err);
-    E.has_pending = false; E.pending_uses_keys = false; E.pending_batch = nullptr;
+    E.has_pending = false; E.pending_ks = -1; E.pending_batch = nullptr;
     return GBN_OK;
 }
 static void wait_host() {
@@ -1019,8 +1025,11 @@ static int compact_seeds(hipStream_t st) {
 // the initial hits are left in the slot's buffers.  ctr: [0] initial hits, [1] runs (device counters).
 static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *diag, int keep_stages, int slot,
                       const GbnDevSeed *seeds, int64_t n, unsigned long long *ctr, hipStream_t st, unsigned long long *nih_out,
-                      int32_t s0 = 0, int32_t s1 = -1)
+                      int32_t s0, int32_t s1, int ksi, int phase = 0)
 {
+    // phase 0: the whole stage on `st`.  1: keys + sort only (queued, nothing waited for); 2: extension + replay of what a
+    // phase-1 call with the same arguments sorted into the same key set
+    Engine::KeySet &KS = E.ks[ksi];
     const DeviceBatch *d = b.dev;
     if (s1 < 0) s1 = db.num_seqs;
     int rc;
@@ -1028,9 +1037,9 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     auto ms_since = [&](std::chrono::steady_clock::time_point t) {
         return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_stage = now();
-    if ((rc = grow_key_buffers((size_t)n))) return rc;
+    if (phase != 2 && (rc = grow_key_buffers(KS, (size_t)n))) return rc;
     GbnKeyParams K; std::memset(&K, 0, sizeof(K));
-    K.seeds = seeds; K.n = n; K.key_scan = E.key_a; K.idx = E.idx_a;
+    K.seeds = seeds; K.n = n; K.key_scan = KS.key_a; K.idx = KS.idx_a;
     K.q_descending = (b.lut.type == GBN_LUT_MB); K.container_hash = b.container; K.diag_len = b.diag_len;
     // key widths: the radix sorts stop at the top bit a key can have
     auto bits_for = [](uint64_t below) { int k = 1; while (k < 63 && ((uint64_t)1 << k) < below) k++; return k; };
@@ -1048,20 +1057,20 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     K.s_bits = bits_for((uint64_t)max_len + 1); K.qh_bits = std::max(0, K.q_bits - K.group_bits);
     K.subj_base = s0;
     const int ck_bits = K.group_bits + bits_for((uint64_t)(s1 - s0) + 1) + K.s_bits;        // (the query key's high bits travel in the value)
-    const bool composite = ck_on && E.ext_rec && n >= compact_min && ck_bits <= 64 && K.group_bits < 32 && K.qh_bits <= 24 && b.lut.word - b.lut.lut < 256;
+    const bool composite = ck_on && KS.ext_rec && n >= compact_min && ck_bits <= 64 && K.group_bits < 32 && K.qh_bits <= 24 && b.lut.word - b.lut.lut < 256;
     const bool segmented = seeds == E.seeds && E.seg_valid;           // (an asynchronous stage works on a copy of its own)
     const bool from_segments = segmented && composite && !keep_stages;  // seed_ckeys_kernel reads the segments as they are
-    if (segmented && !from_segments && (rc = compact_seeds(st))) return rc;
-    if (!composite || keep_stages) {
+    if (phase != 2 && segmented && !from_segments && (rc = compact_seeds(st))) return rc;
+    if (phase != 2 && (!composite || keep_stages)) {
         HIPCHK(launch_seed_keys(K, st));
-        size_t tb = E.sort_tmp_bytes;
-        HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, scan_bits, st));
+        size_t tb = KS.sort_tmp_bytes;
+        HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, n, scan_bits, st));
         // idx_b = seed indices in scan order (s_scan, chain order), subjects interleaved
     }
     if (keep_stages) {
         std::vector<GbnDevSeed> hs((size_t)n); std::vector<uint32_t> order((size_t)n);
         HIPCHK(hipMemcpyAsync(hs.data(), seeds, (size_t)n * sizeof(GbnDevSeed), hipMemcpyDeviceToHost, st));
-        HIPCHK(hipMemcpyAsync(order.data(), E.idx_b, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(hipMemcpyAsync(order.data(), KS.idx_b, (size_t)n * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
         std::vector<GbnSeed> tmp; tmp.reserve((size_t)n);
         for (int64_t i = 0; i < n; i++) {
@@ -1078,21 +1087,26 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     const int v_bits = 8 + K.qh_bits;
     const bool packed = composite && ck_pack && ck_bits + v_bits <= 64;
     if (composite) {
-        K.key_scan = E.key_a; K.idx = E.idx_a; K.v_bits = packed ? v_bits : 0;
+        K.key_scan = KS.key_a; K.idx = KS.idx_a; K.v_bits = packed ? v_bits : 0;
         if (from_segments) { K.seg = E.slice_seg; K.seg_count = E.rare_counts; K.nseg = E.seg_n; K.seg_cap = E.seg_len; }
-        HIPCHK(launch_seed_ckeys(K, st));
-        size_t tb = E.sort_tmp_bytes;
-        if (packed) HIPCHK(sort_keys_u64(E.sort_tmp, tb, E.key_a, E.key_b, n, v_bits, v_bits + ck_bits, st));
-        else HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_a, E.idx_b, n, ck_bits, st));
+        if (phase != 2) {
+            HIPCHK(launch_seed_ckeys(K, st));
+            size_t tb = KS.sort_tmp_bytes;
+            if (packed) HIPCHK(sort_keys_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, n, v_bits, v_bits + ck_bits, st));
+            else HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, n, ck_bits, st));
+        }
         // key_b = sorted composite keys, idx_b = ext_left of the seeds in that order (packed: both in key_b)
     } else {
-        K.idx = E.idx_b; K.key_group = E.key_a;
-        HIPCHK(launch_group_keys(K, st));
-        size_t tb = E.sort_tmp_bytes;
-        HIPCHK(sort_pairs_u64(E.sort_tmp, tb, E.key_a, E.key_b, E.idx_b, E.idx_a, n, group_key_bits, st));
+        K.idx = KS.idx_b; K.key_group = KS.key_a;
+        if (phase != 2) {
+            HIPCHK(launch_group_keys(K, st));
+            size_t tb = KS.sort_tmp_bytes;
+            HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_b, KS.idx_a, n, group_key_bits, st));
+        }
         // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
     }
 
+    if (phase == 1) { *nih_out = composite ? 1 : 0; return GBN_OK; }      // (tells the caller whether the second half can run without `seeds`)
     if ((rc = grow_ihit_buffers(slot, std::max<size_t>(E.ihit_cap_s[slot], 1 << 16)))) return rc;
     unsigned long long nih = 0;
     *nih_out = 0;
@@ -1100,19 +1114,19 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         HIPCHK(hipMemsetAsync(ctr, 0, 2 * sizeof(unsigned long long), st));      // initial hits, runs
         GbnExtParams X; std::memset(&X, 0, sizeof(X));
         X.db = db.d_packed; X.byte_off = db.d_byte_off; X.len = db.d_len;
-        X.seeds = seeds; X.idx = E.idx_a; X.key_group = E.key_b; X.n = n;
+        X.seeds = seeds; X.idx = KS.idx_a; X.key_group = KS.key_b; X.n = n;
         X.q8 = d->q8; X.qlen = b.qlen; X.q2 = d->q2; X.qinv = d->qinv; X.q4 = d->q4_base; X.q4_plane = d->q4_plane; X.q4_origin = b.qpad;
         X.ctx_off = d->ctx_off; X.ctx_len = d->ctx_len; X.ctx_xdrop = d->ctx_xdrop;
         X.ctx_cutoff = d->ctx_cutoff; X.ctx_reduced = d->ctx_reduced; X.nctx = (int32_t)b.ctx.size();
         X.matrix = d->matrix; X.score_table = d->score_table;
         X.word = b.lut.word; X.container_hash = b.container;
-        X.cell_diag = E.cell_diag; X.cell_level = E.cell_level;
+        X.cell_diag = KS.cell_diag; X.cell_level = KS.cell_level;
         X.cell_start = d->cell_start; X.ent = d->ent; X.cell_mask = (uint32_t)(b.lut.ncells - 1); X.lut = b.lut.lut;
         X.masked = b.lut.masked ? 1 : 0;
-        X.run_heads = E.idx_b; X.run_count = reinterpret_cast<uint32_t *>(ctr + 1); X.group_bits = K.group_bits;
-        X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = E.ext_rec; X.ctx_blk = d->ctx_blk;
+        X.run_heads = KS.idx_b; X.run_count = reinterpret_cast<uint32_t *>(ctr + 1); X.group_bits = K.group_bits;
+        X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = KS.ext_rec; X.ctx_blk = d->ctx_blk;
         if (composite) {
-            X.idx = E.idx_b; X.run_heads = E.idx_a;
+            X.idx = KS.idx_b; X.run_heads = KS.idx_a;
             X.ck_shift = K.s_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending; X.ck_subj_base = K.subj_base; X.ck_vbits = K.v_bits;
         }
         X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
@@ -1180,7 +1194,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         E.swap_scan_sets();                                 // the next scan fills the other set
         E.slot ^= 1;
         E.pending_err.clear();
-        const int dev = E.device;
+        const int dev = E.device, ksi = 0;                  // (no stage is in flight: either key set)
         const unsigned long long raw_probe = cnt[1];
         GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
         Engine *eng = tl_eng;
@@ -1213,12 +1227,12 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
             if (n2 == 0) return GBN_OK;
             if (n2 > INT32_MAX) return fail(GBN_ERR_NOMEM, "too many seeds in one range");
             unsigned long long nih2 = 0;
-            int r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n2, E.counters + 4, E.stream2, &nih2, s0, s1);
+            int r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n2, E.counters + 4, E.stream2, &nih2, s0, s1, ksi);
             if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2, true);
             if (r) E.pending_err = gbn_last_error();      // the error text is per thread
             return r;
         });
-        E.has_pending = true; E.pending_res = rp; E.pending_uses_keys = true; E.pending_batch = bp;
+        E.has_pending = true; E.pending_res = rp; E.pending_ks = ksi; E.pending_batch = bp;
         return GBN_OK;
     }
     if (diag) { diag->lookup_hits += (int64_t)cnt[1]; diag->seeds += (int64_t)cnt[0]; diag->subject_bases_scanned += bases; }
@@ -1243,7 +1257,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         HIPCHK(hipEventRecord(E.ev_seed, E.stream));
         E.slot ^= 1;
         E.pending_err.clear();
-        const int dev = E.device;
+        const int dev = E.device, ksi = 0;                  // (no stage is in flight: either key set)
         GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
         Engine *eng = tl_eng;
         E.pending = std::async(std::launch::async, [=]() -> int {
@@ -1252,17 +1266,23 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
             unsigned long long nih2 = 0;
             if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the extension thread"; return GBN_ERR_HIP; }
             if (hipStreamWaitEvent(E.stream2, E.ev_seed, 0) != hipSuccess) { E.pending_err = "hipStreamWaitEvent failed"; return GBN_ERR_HIP; }
-            r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n, E.counters + 4, E.stream2, &nih2, s0, s1);
+            r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n, E.counters + 4, E.stream2, &nih2, s0, s1, ksi);
             if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2, true);
             if (r) E.pending_err = gbn_last_error();      // the error text is per thread
             return r;
         });
-        E.has_pending = true; E.pending_res = rp; E.pending_uses_keys = true; E.pending_batch = bp;
+        E.has_pending = true; E.pending_res = rp; E.pending_ks = ksi; E.pending_batch = bp;
         return GBN_OK;
     }
-    if (E.pending_uses_keys && (rc = wait_pending_gpu())) return rc; // the sort buffers exist once
+    // the key set no stage in flight is working on
+    const int ksi = (E.has_pending && E.pending_ks == 0) ? 1 : 0;
+    // (Tried in round 3 and not kept: the stage in two halves -- keys + sort on the engine's stream, extension + replay with
+    // the gapped stage on the second one, so that the extension of range k runs next to the scan of range k + 1, the only
+    // kernels that fit beside the slice scan's 152 KB of LDS.  The second stream then carries 7.4 ms per range
+    // (extension + replay 3.8 next to the scan, gapped stage 3.6) against 7.6 ms for the whole range before: 38.4 - 39.2 vs
+    // 38.8 - 39.0 ms per pass.  A third stream would be needed, and two processes on one GPU gain 8 %: the chip is busy.)
     unsigned long long nih = 0;
-    if ((rc = seed_stage(b, db, res, diag, keep_stages, slot, E.seeds, n, E.counters + 2, E.stream, &nih, s0, s1))) return rc;
+    if ((rc = seed_stage(b, db, res, diag, keep_stages, slot, E.seeds, n, E.counters + 2, E.stream, &nih, s0, s1, ksi))) return rc;
     trace_mark("seed stage done (inline)");
     if (nih == 0) return GBN_OK;
     if ((rc = wait_pending_gpu())) return rc;               // one gapped stage in flight at most
@@ -1635,13 +1655,14 @@ static void release_engine() {              // (the calling thread has entered i
     dev_free(E.slice_seg); E.slice_seg_cap = 0;
     hitbuf_drain();
     dev_free(E.seeds_async); E.seeds_async_cap = 0; if (E.ev_seed) { (void)hipEventDestroy(E.ev_seed); E.ev_seed = nullptr; }
-    dev_free(E.seeds); dev_free(E.key_a); dev_free(E.key_b); dev_free(E.idx_a); dev_free(E.idx_b);
-    dev_free(E.cell_diag); dev_free(E.cell_level); dev_free(E.ext_rec); dev_free(E.sort_tmp); for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
+    dev_free(E.seeds);
+    for (auto &KS : E.ks) { dev_free(KS.key_a); dev_free(KS.key_b); dev_free(KS.idx_a); dev_free(KS.idx_b); dev_free(KS.cell_diag); dev_free(KS.cell_level); dev_free(KS.ext_rec); dev_free(KS.sort_tmp); KS.key_cap = 0; KS.sort_tmp_bytes = 0; }
+    for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
     dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_tcur); E.bin_tcur_cap = 0; dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
     dev_free(E.alt.bin_rec); dev_free(E.alt.bin_tcur); dev_free(E.alt.bin_count); dev_free(E.alt.rareq); dev_free(E.alt.rare_counts); E.alt = Engine::ScanSet();
     if (E.ev_r0) { (void)hipEventDestroy(E.ev_r0); (void)hipEventDestroy(E.ev_r1); E.ev_r0 = E.ev_r1 = nullptr; }
     E.bin_rec_cap = 0; E.bin_count_cap = 0;
-    E.seed_cap = E.key_cap = 0;
+    E.seed_cap = 0;
     if (E.gather_stage) (void)hipHostFree(E.gather_stage);
     E.gather_stage = nullptr; E.gather_stage_cap = 0;
     if (E.gather_stream) (void)hipStreamDestroy(E.gather_stream);
