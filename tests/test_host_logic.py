@@ -78,6 +78,13 @@ def test_no_gpu_is_reported_not_emulated():
     assert L.gbn_init(0, -1) != 0          # use_gpu = false is refused as well
     with pytest.raises(api.BlastError):
         api.BlastPrelimSearch([np.zeros(64, dtype=np.uint8)], api.default_options("megablast"))
+    # the per-device entry points: nothing to lease, nothing in flight, nothing to release
+    assert L.gbn_device_count() == 0
+    assert L.gbn_use_device(0) != 0 and L.gbn_use_device(-1) != 0
+    assert L.gbn_current_device() == -1
+    assert L.gbn_prelim_search_end(None) == 0
+    assert L.gbn_debug_check_guards() == 0
+    L.gbn_release(); L.gbn_release_db_memory()
 
 
 def test_product_never_imports_oracle():
