@@ -104,7 +104,7 @@ class GbnScanParams(C.Structure):
                 ("pv", _P), ("cellw", _P), ("cell_start", _P), ("ent", _P), ("ncells", _L),
                 ("lut", C.c_int), ("word", C.c_int), ("step", C.c_int), ("mode", C.c_int), ("fl", C.c_int), ("fr", C.c_int),
                 ("q8", _P), ("qlen", _I), ("ctx_off", _P), ("ctx_len", _P), ("nctx", _I),
-                ("seeds", _P), ("seed_count", _P), ("seed_cap", _UL), ("raw_hits", _P)]
+                ("seeds", _P), ("seed_count", _P), ("seed_cap", _UL), ("raw_hits", _P), ("pvx", _P), ("pstart", _P)]
 
 
 class GbnExtParams(C.Structure):

@@ -71,6 +71,7 @@ struct DeviceBatch {
     uint32_t *pv = nullptr, *cellw = nullptr, *cell_start = nullptr, *cellt = nullptr, *side_start = nullptr;
     uint16_t *sidet = nullptr;
     unsigned long long *ent = nullptr;
+    uint32_t *pvx = nullptr, *pstart = nullptr;         // rank form of pv / cell_start for the folded slice scan (lut_rank_fill)
     int32_t *ctx_off = nullptr, *ctx_len = nullptr, *ctx_xdrop = nullptr, *ctx_cutoff = nullptr,
             *ctx_reduced = nullptr, *ctx_hint = nullptr, *ctx_blk = nullptr;    // ctx_hint[q >> kCtxHintShift]: the context position (q & ~mask) lies in
     int32_t *matrix = nullptr, *score_table = nullptr;
@@ -330,7 +331,7 @@ static void finish_build(DeviceBatch *d) {
 void free_device_batch(DeviceBatch *d) {
     if (!d) return;
     finish_build(d);
-    dev_free(d->q8_base); dev_free(d->q2_base); dev_free(d->qinv_base); dev_free(d->q4_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent);
+    dev_free(d->q8_base); dev_free(d->q2_base); dev_free(d->qinv_base); dev_free(d->q4_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent); dev_free(d->pvx); dev_free(d->pstart);
     dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff);
     dev_free(d->ctx_reduced); dev_free(d->ctx_hint); dev_free(d->ctx_blk); dev_free(d->matrix); dev_free(d->score_table);
     delete d;
@@ -414,6 +415,33 @@ static int upload_host_tables(GbnBatch &b) {
     return GBN_OK;
 }
 
+// The rank form of the presence bits and entry starts, for batches the folded slice scan takes (more than one slice
+// of presence bits): queued on `st` behind the structures it reads.  keep: where the scratch goes while the stream
+// runs (the batch's build_scratch), null: finished and freed here.
+static int scan_slices(const GbnBatch &b);
+static int build_rank_table(GbnBatch &b, hipStream_t st, std::vector<void *> *keep) {
+    DeviceBatch *d = b.dev;
+    if (scan_slices(b) <= 1) return GBN_OK;
+    const int64_t ncells = b.lut.ncells, nwords = (ncells + 31) / 32;
+    uint32_t *popc = nullptr, *prefix = nullptr; void *tmp = nullptr; size_t tb = 0;
+    int rc;
+    auto fail = [&](int code) { (void)hipStreamSynchronize(st); dev_free(popc); dev_free(prefix); if (tmp) pool_free(tmp); return code; };
+    if ((rc = dev_alloc(popc, (size_t)nwords + 1)) || (rc = dev_alloc(prefix, (size_t)nwords + 1))) return fail(rc);
+    if ((rc = dev_alloc(d->pvx, 2 * (size_t)nwords)) || (rc = dev_alloc(d->pstart, (size_t)std::max(b.qlen, 1) + 2))) return fail(rc);
+#define RANKCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); return fail(GBN_ERR_HIP); } } while (0)
+    RANKCHK(lut_rank_count(d->pv, nwords, popc, st));
+    RANKCHK(lut_scan(nullptr, tb, popc, prefix, nwords + 1, st));
+    RANKCHK(pool_alloc(&tmp, tb + 256));
+    tb += 256;
+    RANKCHK(lut_scan(tmp, tb, popc, prefix, nwords + 1, st));
+    RANKCHK(lut_rank_fill(d->pv, prefix, d->cell_start, ncells, nwords, d->pvx, d->pstart, st));
+    if (keep) { keep->push_back(popc); keep->push_back(prefix); keep->push_back(tmp); return GBN_OK; }
+    RANKCHK(hipStreamSynchronize(st));
+#undef RANKCHK
+    dev_free(popc); dev_free(prefix); pool_free(tmp);
+    return GBN_OK;
+}
+
 // lookup structures built on the device from the uploaded query (lutbuild.hip)
 static int build_tables_on_device(GbnBatch &b) {
     DeviceBatch *d = b.dev;
@@ -474,6 +502,7 @@ static int build_tables_on_device(GbnBatch &b) {
         LUTCHK(lut_scan(tmp, tb, many, many_prefix, (int64_t)nc1, st));
         LUTCHK(lut_side(B, st));
         LUTCHK(lut_pv(B, st));
+        LUTRC(build_rank_table(b, st, &d->build_scratch));
         LUTCHK(hipEventCreateWithFlags(&d->ready, hipEventDisableTiming));
         LUTCHK(hipEventRecord(d->ready, st));
         for (void *p : {(void *)d_sl, (void *)d_sr, (void *)count, (void *)many, (void *)many_prefix, (void *)vals_a, (void *)vals_b,
@@ -518,6 +547,7 @@ static int build_tables_on_device(GbnBatch &b) {
     B.sidet = d->sidet; B.side_start = d->side_start;
     LUTCHK(lut_side(B, st));
     LUTCHK(lut_pv(B, st));
+    LUTRC(build_rank_table(b, st, nullptr));
     LUTCHK(hipStreamSynchronize(st));
 #undef LUTCHK
 #undef LUTRC
@@ -566,6 +596,7 @@ int upload_batch(GbnBatch &b) {
         // (the host builder may have turned a small-NA table into a standard one)
         if (L.lut != L.word) d->mode = (L.type == GBN_LUT_SMALL_NA) ? ((L.lut % 4 == 0 && L.step % 4 == 0 && L.word - L.lut <= 4) ? GBN_EXT_SMALL_ONEBYTE : GBN_EXT_SMALL) : GBN_EXT_NA;
         if ((rc = upload_host_tables(b))) return rc;
+        if ((rc = build_rank_table(b, E.stream_build, nullptr))) return rc;
     } else {
         if ((rc = build_tables_on_device(b))) return rc;
     }
@@ -761,7 +792,7 @@ static void fill_scan_params(GbnScanParams &P, const GbnBatch &b, const GbnDb &d
     std::memset(&P, 0, sizeof(P));
     P.db = db.d_packed; P.byte_off = db.d_byte_off; P.len = db.d_len;
     P.tiles = ts.d_tiles; P.ntiles = ts.ntiles;
-    P.pv = d->pv; P.cellw = d->cellw; P.cell_start = d->cell_start; P.ent = d->ent;
+    P.pv = d->pv; P.cellw = d->cellw; P.cell_start = d->cell_start; P.ent = d->ent; P.pvx = d->pvx; P.pstart = d->pstart;
     P.ncells = b.lut.ncells; P.lut = b.lut.lut; P.word = b.lut.word; P.step = b.lut.step;
     P.mode = d->mode; P.fl = d->fl; P.fr = d->fr;
     P.q8 = d->q8; P.qlen = b.qlen; P.ctx_off = d->ctx_off; P.ctx_len = d->ctx_len; P.nctx = (int32_t)b.ctx.size();

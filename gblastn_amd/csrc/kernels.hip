@@ -31,9 +31,26 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <algorithm>
+#include <atomic>
 #include "gbn_dev.h"
+
+// Function attributes belong to the (kernel, device) pair: one bit per device, set on the first launch there.
+static hipError_t raise_dynamic_lds(const void *fn, size_t lds, std::atomic<uint64_t> &done)
+{
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
+    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
+    return e;
+}
 #ifndef GBN_DIAG_ABL
 #define GBN_DIAG_ABL 0      // timing experiments only (1: no ungapped extension, 2: no strand search): wrong results
+#endif
+#ifndef GBN_BIN_ABL
+#define GBN_BIN_ABL 0       // timing experiments only (scan_bin_kernel), bits: 2 no record stores, 4 no `hi` stores, 8 no index stores: wrong results
 #endif
 #ifndef GBN_EXT_ABL
 #define GBN_EXT_ABL 0       // timing experiments only (seed_ext_kernel), bits: 1 no exact pass, 2 no extension, 4 no reservation of run heads, 8 no context lookup, 16 no record store: wrong results
@@ -282,20 +299,33 @@ scan_seed_kernel(GbnScanParams P)
 // A wave takes a tile of 2048 positions on its own (no barrier in the loop): 32 consecutive positions per lane out of
 // three dwords of subject, one LDS read per position; the present ones wait in a per-wave queue until 64 are
 // together, then a lane each walks its cell's entries.
+//
+// FOLD (more than one slice): the workgroup keeps the OR of all slices instead of one of them -- a filter over the low
+// 2^20 cell bits, 18 % full for the same batch -- and streams the subjects past it ONCE.  What passes the filter is
+// looked up in the presence bits themselves (GbnScanParams::pvx: the word and the rank of its first cell in one
+// 8-byte read, 1 MB for lut 11, L2-resident); the present ones are queued as before, by RANK, and a queued lane
+// finds its entry list by rank (pstart: 4 bytes per present cell, L2-resident too -- cell_start's 16 MB cost a random
+// HBM sector per hit).  A position costs one word extraction and one LDS read instead of one per slice: the sliced
+// form spent 13.6 wave-instructions per position and slice.
 // ---------------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(GBN_SLICE_THREADS)
-scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
-                  unsigned long long *seg_max)
+template <bool FOLD>
+__device__ __forceinline__ void scan_slice_body(const GbnScanParams &P, int nslices, int slice_cell_bits, GbnDevSeed *seg, uint32_t seg_cap,
+                                                uint32_t *seg_count, unsigned long long *seg_max, uint32_t *s_slice, uint32_t &s_used)
 {
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_slice[];
     uint32_t *s_pv = s_slice;                                           // GBN_SLICE_WORDS presence words
     uint32_t *s_q = s_slice + GBN_SLICE_WORDS;                          // [waves][3][GBN_SLICE_QCAP]: position, cell, subject
-    __shared__ uint32_t s_used;                                         // seeds this workgroup has put into its segment
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int k = (int)(blockIdx.x % (unsigned)nslices);                // this workgroup's slice
-    const int64_t g = blockIdx.x / (unsigned)nslices, G = gridDim.x / (unsigned)nslices;
+    const int k = FOLD ? 0 : (int)(blockIdx.x % (unsigned)nslices);     // this workgroup's slice
+    const int64_t g = FOLD ? blockIdx.x : blockIdx.x / (unsigned)nslices, G = FOLD ? gridDim.x : gridDim.x / (unsigned)nslices;
     const uint32_t slice_words = (1u << slice_cell_bits) >> 5;
+    if (FOLD) {
+        for (uint32_t i = tid; i < slice_words; i += GBN_SLICE_THREADS) {
+            uint32_t v = 0;
+            for (int f = 0; f < nslices; f++) v |= P.pv[(size_t)f * slice_words + i];
+            s_pv[i] = v;
+        }
+    } else
     for (uint32_t i = tid; i < slice_words; i += GBN_SLICE_THREADS) s_pv[i] = P.pv[(size_t)k * slice_words + i];
     if (tid == 0) s_used = 0;
     __syncthreads();
@@ -314,7 +344,9 @@ scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed 
         if (lane < cnt) {
             s = (int32_t)q_pos[first + lane]; subj = (int32_t)q_subj[first + lane];
             const uint32_t cell = q_cell[first + lane];
-            start = P.cell_start[cell]; n = P.cell_start[cell + 1] - start;
+            // (FOLD: the queue holds the RANK of the cell among the present ones, and the entry starts by rank)
+            const uint32_t *__restrict__ starts = FOLD ? P.pstart : P.cell_start;
+            start = starts[cell]; n = starts[cell + 1] - start;
         }
         raw += n;
         uint32_t incl = n;                                              // inclusive prefix sum over the lanes
@@ -332,15 +364,29 @@ scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed 
         }
     };
 
-    for (int64_t t = g * (GBN_SLICE_THREADS / 64) + wave; t < P.ntiles; t += G * (GBN_SLICE_THREADS / 64)) {
-        const GbnTile T = P.tiles[t];
-        const uint8_t *__restrict__ subj = P.db + P.byte_off[T.subj];
-        const int32_t nl = min(32, T.npos - 32 * lane);                 // positions of this lane (<= 0: none)
-        const int32_t p0 = T.first_pos + (nl > 0 ? 32 * lane : 0);      // always a readable address
+    // a tile's three dwords per lane are asked for while the tile before is being worked on
+    struct Fetch { GbnTile T; int32_t nl, p0; uint32_t d0, d1, d2; };
+    auto fetch = [&](int64_t t) {
+        Fetch f;
+        f.T = P.tiles[t];
+        const uint8_t *__restrict__ subj = P.db + P.byte_off[f.T.subj];
+        f.nl = min(32, f.T.npos - 32 * lane);                           // positions of this lane (<= 0: none)
+        f.p0 = f.T.first_pos + (f.nl > 0 ? 32 * lane : 0);              // always a readable address
         // (p0 is a multiple of 32 bases: tiles start at multiples of 2048 positions, stride 1 -- the lane's 48 bases are
         // three aligned dwords)
-        const uint32_t *__restrict__ dw = reinterpret_cast<const uint32_t *>(subj) + (p0 >> 4);
-        const uint32_t W[3] = {bswap32(dw[0]), bswap32(dw[1]), bswap32(dw[2])};
+        const uint32_t *__restrict__ dw = reinterpret_cast<const uint32_t *>(subj) + (f.p0 >> 4);
+        f.d0 = dw[0]; f.d1 = dw[1]; f.d2 = dw[2];
+        return f;
+    };
+    const int64_t t_first = g * (GBN_SLICE_THREADS / 64) + wave, t_step = G * (GBN_SLICE_THREADS / 64);
+    Fetch nx;
+    if (t_first < P.ntiles) nx = fetch(t_first);
+    for (int64_t t = t_first; t < P.ntiles; t += t_step) {
+        const Fetch cur = nx;
+        if (t + t_step < P.ntiles) nx = fetch(t + t_step);
+        const GbnTile T = cur.T;
+        const int32_t nl = cur.nl, p0 = cur.p0;
+        const uint32_t W[3] = {bswap32(cur.d0), bswap32(cur.d1), bswap32(cur.d2)};
         const uint64_t hi0 = ((uint64_t)W[0] << 32) | W[1];
         const uint32_t lo0 = W[2];
         // the lane's 32 presence tests, independent of each other (the LDS reads go out back to back) ...
@@ -352,7 +398,7 @@ scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed 
             // Sixteen at a time: all cells, then all LDS reads, then all tests (written as one loop, the compiler waited
             // for every read before it issued the next one: 32 LDS round trips per tile)
             const int top32 = 32 - 2 * P.lut;                           // x = the 32 bits that start with the word: cell = x >> top32
-            const bool one_slice = nslices == 1;                        // (then top32 + slice_cell_bits = 32: nothing to shift by)
+            const bool one_slice = FOLD || nslices == 1;                // (one slice: top32 + slice_cell_bits = 32, nothing to shift by)
             const int sl_shift = min(31, top32 + slice_cell_bits);      // x >> sl_shift = the slice of the word's cell
             const int wd_shift = top32 + 5, wd_bits = slice_cell_bits - 5;   // bits of x: index of the presence word inside the slice
             #pragma unroll
@@ -374,6 +420,37 @@ scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed 
                 for (int j = 0; j < 16; j++) hm |= __builtin_amdgcn_ubfe(w[j], __builtin_amdgcn_ubfe(x[j], top32, 5), 1) << (i0 + j);
             }
             hm &= (nl >= 32) ? 0xffffffffu : ((nl > 0) ? ((1u << nl) - 1u) : 0u);
+        }
+        // FOLD: what passed the filter is looked up in the presence bits themselves, four positions of a lane at a time
+        // (four gathers in flight: 512 KB for lut 11, L2-resident), and what is present joins the wave's queue
+        if (FOLD) {
+            while (__ballot(hm != 0)) {
+                uint32_t pos4[4], cell4[4]; uint2 pw[4];
+                const uint2 *__restrict__ pvx = reinterpret_cast<const uint2 *>(P.pvx);
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const bool have = hm != 0;
+                    const int i = have ? __ffs(hm) - 1 : 0;
+                    hm &= hm - 1;
+                    const uint64_t x = i ? ((hi0 << (2 * i)) | (((uint64_t)lo0 << 32) >> (64 - 2 * i))) : hi0;
+                    cell4[u] = (uint32_t)(x >> top); pos4[u] = (uint32_t)(p0 + i);
+                    pw[u] = have ? pvx[cell4[u] >> 5] : make_uint2(0u, 0u);
+                }
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t bit = cell4[u] & 31u;
+                    const bool present = (pw[u].x >> bit) & 1u;
+                    const unsigned long long m = __ballot(present);
+                    if (!m) continue;
+                    if (present) {
+                        const int at = qn + __popcll(m & lt);
+                        q_pos[at] = pos4[u]; q_cell[at] = pw[u].y + (uint32_t)__popc(pw[u].x & ((1u << bit) - 1u)); q_subj[at] = (uint32_t)T.subj;
+                    }
+                    qn += __popcll(m);
+                    if (qn >= 64) { qn -= 64; flush(qn, 64); }
+                }
+            }
+            continue;
         }
         // ... then the present ones join the wave's queue, a round per position a lane still holds (two or three)
         while (true) {
@@ -400,6 +477,24 @@ scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed 
         seg_count[blockIdx.x] = s_used;
         if (s_used) { atomicAdd(P.seed_count, (unsigned long long)s_used); atomicMax(seg_max, (unsigned long long)s_used); }
     }
+}
+
+extern "C" __global__ void __launch_bounds__(GBN_SLICE_THREADS)
+scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
+                  unsigned long long *seg_max)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_slice[];
+    __shared__ uint32_t s_used;                                         // seeds this workgroup has put into its segment
+    scan_slice_body<false>(P, nslices, slice_cell_bits, seg, seg_cap, seg_count, seg_max, s_slice, s_used);
+}
+
+extern "C" __global__ void __launch_bounds__(GBN_SLICE_THREADS)
+scan_fold_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
+                 unsigned long long *seg_max)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_slice[];
+    __shared__ uint32_t s_used;
+    scan_slice_body<true>(P, nslices, slice_cell_bits, seg, seg_cap, seg_count, seg_max, s_slice, s_used);
 }
 
 // the segments of scan_slice_kernel, back to back: seeds[0 .. sum of counts) -- for the consumers that want the seeds
@@ -2277,12 +2372,15 @@ hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg
     if (nslices <= 0 || blocks <= 0) return hipErrorInvalidValue;
     const int cell_bits = std::min(2 * p.lut, GBN_SLICE_CELL_BITS);
     const size_t lds = ((size_t)GBN_SLICE_WORDS + (size_t)(GBN_SLICE_THREADS / 64) * 3 * GBN_SLICE_QCAP) * 4;
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void *)scan_slice_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-        attr_set = true;
+    static std::atomic<uint64_t> attr_set{0}, attr_set_fold{0};
+    // GBN_SLICE_FOLD=0: a pass over the subjects per slice (the form before the folded filter), for comparisons
+    static const bool fold = !(getenv("GBN_SLICE_FOLD") && atoi(getenv("GBN_SLICE_FOLD")) == 0);
+    if (fold && nslices > 1 && p.pvx && p.pstart) {
+        if (hipError_t e = raise_dynamic_lds((const void *)scan_fold_kernel, lds, attr_set_fold)) return e;
+        hipLaunchKernelGGL(scan_fold_kernel, dim3((unsigned)blocks), dim3(GBN_SLICE_THREADS), lds, st, p, nslices, cell_bits, seg, seg_cap, seg_count, seg_max);
+        return hipGetLastError();
     }
+    if (hipError_t e = raise_dynamic_lds((const void *)scan_slice_kernel, lds, attr_set)) return e;
     hipLaunchKernelGGL(scan_slice_kernel, dim3((unsigned)blocks), dim3(GBN_SLICE_THREADS), lds, st, p, nslices, cell_bits, seg, seg_cap, seg_count, seg_max);
     return hipGetLastError();
 }
@@ -2585,8 +2683,8 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         const uint2 x = *reinterpret_cast<const uint2 *>(&s_ix[src]);
         // = GBN_REC_HI / GBN_REC_IDX16 of record dl * 32 + p * 4 (blocks of 64 records: 64 hi words, 64 indices)
         const size_t blk = (size_t)(dl >> 1) * 96, in = (size_t)((dl & 1u) * 32u + p * 4u);
-        if (!(B.dbg & 4)) *reinterpret_cast<uint4 *>(rec32 + blk + in) = h;
-        if (!(B.dbg & 8)) *reinterpret_cast<uint2 *>(rec16 + (blk + 64) * 2 + in) = x;
+        if (!(GBN_BIN_ABL & 4)) *reinterpret_cast<uint4 *>(rec32 + blk + in) = h;
+        if (!(GBN_BIN_ABL & 8)) *reinterpret_cast<uint2 *>(rec16 + (blk + 64) * 2 + in) = x;
     };
 
     if (tid < GBN_BIN_MAXNB) s_hist[tid] = 0;
@@ -2630,7 +2728,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     uint32_t ntask = 0;                                         // quarter lines of the tile before (for late_stores)
     auto late_stores = [&]() {
         const uint32_t i = (uint32_t)tid + GBN_SORT_THREADS;
-        if (i < ntask && !(B.dbg & 2)) {
+        if (i < ntask && !(GBN_BIN_ABL & 2)) {
             const uint2 d = s_line[i / LP];
             if (d.y != 0xffffffffu) store_part(d.x, i % LP, d.y + (i % LP) * 4);
         }
@@ -2725,7 +2823,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         // here; the next 1024 wait until [0] of the next tile (behind its loads, next to its atomics: spreading
         // the stores over the tile keeps the store queue from stalling every wave at once); the rare rest here.
         ntask = s_nlines * (uint32_t)LP;
-        if (!(B.dbg & 2))
+        if (!(GBN_BIN_ABL & 2))
         for (uint32_t i = tid; i < ntask; i += (i == (uint32_t)tid ? 2u : 1u) * GBN_SORT_THREADS) {
             const uint2 d = s_line[i / LP];
             if (d.y == 0xffffffffu) continue;
@@ -2758,7 +2856,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     for (uint32_t i = tid; i < (uint32_t)nb * LP; i += GBN_SORT_THREADS) {
         const uint32_t b = i / LP, p = i % LP;
         const uint2 f = s_fin[b];
-        if (f.y && f.x + LINE <= B.subcap && !(B.dbg & 2))
+        if (f.y && f.x + LINE <= B.subcap && !(GBN_BIN_ABL & 2))
             store_part((uint32_t)((GBN_STREAM(B, b, wid) * (size_t)B.subcap + f.x) >> 5), p, STAGE + b * LINE + p * 4);
     }
     for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
@@ -3097,12 +3195,9 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
     if (tables_ready && (parts & 2)) { e = hipStreamWaitEvent(st, tables_ready, 0); if (e != hipSuccess) return e; }
     if (parts & 2) {
         const size_t lds = (size_t)GBN_BIN_TABW * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8 + (size_t)GBN_BIN_SIDE * 2 + 16;
-        static bool attr_set = false;
-        if (!attr_set) {
-            e = hipFuncSetAttribute((const void *)probe_bin_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return e;
-            attr_set = true;
-        }
+        static std::atomic<uint64_t> attr_set{0};
+        e = raise_dynamic_lds((const void *)probe_bin_kernel, lds, attr_set);
+        if (e != hipSuccess) return e;
         hipLaunchKernelGGL(probe_bin_kernel, dim3(grid2), dim3(GBN_BIN_THREADS), lds, st, b);
         e = hipGetLastError();
         if (e != hipSuccess) return e;

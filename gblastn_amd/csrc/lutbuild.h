@@ -27,6 +27,11 @@ hipError_t lut_entries(const LutBuild &b, int64_t n, hipStream_t st);
 hipError_t lut_cells(const LutBuild &b, hipStream_t st);
 hipError_t lut_side(const LutBuild &b, hipStream_t st);
 hipError_t lut_pv(const LutBuild &b, hipStream_t st);
+// rank form of the cell table (scan_fold_kernel): popc[0 .. nwords] = set bits per presence word (0 at nwords), then --
+// with prefix = their exclusive sums -- pvx[w] = {pv[w], prefix[w]} and pstart[rank of a present cell] = its cell_start
+hipError_t lut_rank_count(const uint32_t *pv, int64_t nwords, uint32_t *popc, hipStream_t st);
+hipError_t lut_rank_fill(const uint32_t *pv, const uint32_t *prefix, const uint32_t *cell_start, int64_t ncells, int64_t nwords,
+                         uint32_t *pvx, uint32_t *pstart, hipStream_t st);
 // 2-bit packed copy of the query (4 bases per byte, base 0 in bits 7..6) and its "matches nothing" bitmap (MSB first)
 hipError_t lut_pack_q4(const uint8_t *qbuf, int64_t qbuf_len, uint8_t *q4, int64_t plane, hipStream_t st);
 hipError_t lut_pack_query(const uint8_t *qbuf, int64_t qbuf_len, int64_t first, int64_t n, uint8_t *q2, uint8_t *qinv, hipStream_t st);

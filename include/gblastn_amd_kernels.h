@@ -72,6 +72,10 @@ typedef struct GbnScanParams {
      * mini-extension.  Both counters must be zeroed before the launch. */
     GbnDevSeed *seeds; unsigned long long *seed_count; unsigned long long seed_cap;
     unsigned long long *raw_hits;
+    /* optional (NULL: not used): rank form of pv / cell_start for tables of more than 2^20 cells that are as wide as the
+     * word -- pvx[2 w], pvx[2 w + 1] = pv[w], number of present cells in words < w; pstart[r], pstart[r + 1] = the entry
+     * list of the r-th present cell.  With them the subjects are read once instead of once per 2^20 cells. */
+    const uint32_t *pvx, *pstart;
 } GbnScanParams;
 
 typedef struct GbnExtParams {
