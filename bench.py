@@ -282,7 +282,7 @@ def main():
     probe_ms = sum(d.probe_kernel_ms for d in diags)
     rare_ms = sum(d.rare_kernel_ms for d in diags)
     # dominant kernel: the binning kernel when the partitioned scan is used, else the direct scan
-    dom_name, dom_ms = ("scan_bin_kernel", bin_ms) if bin_ms > 0 else ("scan_slice_kernel" if info.get("scan_path") == 2 else "scan_seed_kernel", scan_ms)
+    dom_name, dom_ms = ("scan_bin_kernel", bin_ms) if bin_ms > 0 else (slice_kernel_name(info) if info.get("scan_path") == 2 else "scan_seed_kernel", scan_ms)
     # the binning kernel has stride-specialised variants; this is the name rocprof shows
     dom_label = dom_name + ("_s%d" % info["scan_step"] if bin_ms > 0 and info["scan_step"] in (1, 2, 4, 17, 18, 21) else "")
     achieved = algo_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -299,6 +299,10 @@ def main():
                 traffic = tj.get(dom_name, {}).get("hbm_bytes_per_launch")
             elif args.workload == "C3" and abs(per_launch - 2.5e8) < 1e6:       # a launch = one subject range of 1,000 x 1 Mb
                 traffic = tj.get(dom_label, {}).get("hbm_bytes_per_launch")
+                import re
+                m = re.search(r"profiles/[A-Za-z0-9_]+\.csv", str(tj.get(dom_label, {}).get("_note", "")))
+                if m:
+                    traffic_tag = m.group(0)
         except Exception:
             traffic = None
 
@@ -365,6 +369,13 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def slice_kernel_name(info):
+    """the slice scan's kernel as rocprof names it: tables of more than 2^20 cells (lut 11, 12) are scanned through the folded
+    filter + rank tables (scan_fold_kernel) unless GBN_SLICE_FOLD=0 asks for a pass per slice"""
+    folded = 2 * int(info.get("lut_width", 0)) > 20 and os.environ.get("GBN_SLICE_FOLD", "1") != "0"
+    return "scan_fold_kernel" if folded else "scan_slice_kernel"
 
 
 def side_workloads(device_index):

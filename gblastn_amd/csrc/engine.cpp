@@ -1119,7 +1119,8 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     const bool packed = composite && ck_pack && ck_bits + v_bits <= 64;
     if (composite) {
         K.key_scan = KS.key_a; K.idx = KS.idx_a; K.v_bits = packed ? v_bits : 0;
-        if (from_segments) { K.seg = E.slice_seg; K.seg_count = E.rare_counts; K.nseg = E.seg_n; K.seg_cap = E.seg_len; }
+        if (from_segments) { K.seg = E.slice_seg; K.seg_count = E.rare_counts; K.nseg = E.seg_n; K.seg_cap = E.seg_len;
+                             K.seg_first = reinterpret_cast<unsigned long long *>(E.rare_counts + 1024); }    // (rare_counts: 2048 words, the segment counts are its first 256)
         if (phase != 2) {
             HIPCHK(launch_seed_ckeys(K, st));
             size_t tb = KS.sort_tmp_bytes;

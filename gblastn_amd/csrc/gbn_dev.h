@@ -86,6 +86,7 @@ struct GbnKeyParams {
     // nseg > 0 (seed_ckeys_kernel): the seeds are not in `seeds` but in nseg segments of seg_cap slots, seg_count[s] of
     // them in segment s (scan_slice_kernel's output as it is); seed i = the i-th of the segments read one after the other
     const GbnDevSeed *seg; const uint32_t *seg_count; int nseg; uint32_t seg_cap;
+    unsigned long long *seg_first;      // nseg + 1 entries of scratch (launch_seed_ckeys fills them: index of a segment's first seed)
 };
 
 // scan_slice_kernel: a slice of the presence bits per workgroup

@@ -339,6 +339,18 @@ def test_parity_suite_through_the_two_kernel_seed_stage():
     assert " passed" in p.stdout and "failed" not in p.stdout
 
 
+def test_slice_scan_cases_with_a_pass_per_slice():
+    """GBN_SLICE_FOLD=0: tables of more than one slice of presence bits (lut 11, 12 as wide as the word) are scanned a
+    slice per pass (scan_slice_kernel, the form before the folded filter): the blastn cases of the parity suite once more
+    through it, stage by stage against the oracle"""
+    import os, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env["GBN_SLICE_FOLD"] = "0"
+    p = util.run_child([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu and not spawns",
+                        "-k", "slice or lut11_stride1 or word12 or randomised or ragged"], cwd=root, env=env, timeout=900)
+    assert " passed" in p.stdout and "failed" not in p.stdout
+
+
 def test_parity_cases_with_poisoned_device_blocks():
     """GBN_POISON=<byte>: every device block the engine's pool hands out is filled with that byte first.  The randomised
     shapes, the ragged inputs and the pipelined cases once more with it: a kernel that reads memory nobody wrote would

@@ -79,6 +79,15 @@ def test_blastn_mb_lut11_stride1():
     assert nh >= 1
 
 
+def test_blastn_word12_lut12_sixteen_slices_folded():
+    """blastn W=12 with 460 kb of query: a lut-12 table as wide as the word (CORE/blast_nalookup.c:130-180: from 900,000
+    entries up), sixteen slices of presence bits -- scan_fold_kernel keeps their OR in LDS (more than half full here) and
+    finds the entry lists through the rank tables (GbnScanParams::pvx / pstart)"""
+    nh, _ = run_case(3, 50_000, 460, task="blastn", word_size=12, planted_fraction=0.05,
+                     expect=dict(lut_width=12, scan_step=1, container=1))
+    assert nh >= 1
+
+
 def test_reference_known_answers_on_gpu():
     """The reference's own known answers through the HIP path."""
     import os

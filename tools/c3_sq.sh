@@ -8,4 +8,4 @@ timeout 600 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VM
 python tools/prof_summary.py $(find $O/a -name "*.db" | head -1) --counters > $O/sq_counters.csv
 python tools/prof_summary.py $(find $O/b -name "*.db" | head -1) --counters | tail -n +2 >> $O/sq_counters.csv
 rm -rf $O/a $O/b
-grep -E "seed_ext|scan_slice|dynprog_lane|diag_replay|dynprog_wave|seed_ckeys" $O/sq_counters.csv | sort
+grep -E "seed_ext|scan_slice|scan_fold|dynprog_lane|diag_replay|dynprog_wave|seed_ckeys" $O/sq_counters.csv | sort
