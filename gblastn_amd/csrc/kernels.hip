@@ -1336,9 +1336,6 @@ extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel
             }
         }
         if (hs.score >= cutoff) r.flags |= 2;
-#ifdef GBN_DBG_SEED
-        if (live && q_off == 986 && s_off == 359220) printf("dbg seed: lo %d X %d red %d cut %d len4 %d score %d len %d qs %d pl %08x %08x %08x %08x pr %08x %08x %08x %08x qiv %08x %08x %08x\n", lo, X, reduced, cutoff, len4, hs.score, hs.length, hs.q_start, pl.s0, pl.s1, pl.q0, pl.q1, pr.s0, pr.s1, pr.q0, pr.q1, qiv[0], qiv[1], qiv[2]);
-#endif
         if (live) {
             rec[pos] = r;
             if (r.flags & 2) (reinterpret_cast<GbnSeedHsp *>(rec + P.n))[pos] = hs;
