@@ -2047,6 +2047,9 @@ extern "C" __global__ void __launch_bounds__(128) dynprog_wave_kernel(GbnGapPara
 #ifndef GBN_LANE_ROWS
 #define GBN_LANE_ROWS 96          // measured: 192 rows 2.45 + 0.72 ms (lane + wave kernel), 128: 2.18 + 0.72, 96: 2.10 + 0.71, 64: 2.02 + 1.01
 #endif
+#ifndef GBN_LANE_LOOP_V1
+#define GBN_LANE_LOOP_V1 0       // 1: the cell loop as it was before round 3's instruction diet (A/B builds)
+#endif
 #ifndef GBN_LANE_BATCH
 #define GBN_LANE_BATCH 8            // lanes waiting for set-up before the (long-latency) set-up code runs
 #endif
@@ -2217,6 +2220,7 @@ extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParam
         // ---------------- the cells of the row (CORE/blast_gapalign.c:2957-3020): as many steps as the widest window
         // of the wave has columns
         int32_t last_b = first_b; int lix = fix;
+#if GBN_LANE_LOOP_V1 || (GBN_LANE_W & (GBN_LANE_W - 1))
         {
             const int32_t reward = P.reward, penalty = P.penalty;
             int32_t sc = NEG, b = first_b; int ix = fix;
@@ -2252,6 +2256,53 @@ extern "C" __global__ void __launch_bounds__(64) dynprog_lane_kernel(GbnGapParam
                 }
             }
         }
+
+#else
+        {
+            // The kernel is bound by VALU issue (93 % of the SIMDs' issue slots, 1.18e9 instructions per range), so the loop
+            // carries only what cannot be had afterwards: the slots follow from the columns (slot = column mod W), the row of
+            // the best score from whether the best score moved in this row, "the window's first column failed" is a flag
+            // that stays up while the columns fail from the left.
+            int32_t rew_v = P.reward, pen_v = P.penalty;
+            asm volatile("" : "+v"(rew_v), "+v"(pen_v));                // (kept in VGPRs: the select below needs them there every step)
+            const int32_t first_b0 = first_b, b_end = first_b + width, best_before = best_score;
+            int32_t sc = NEG, b = first_b;
+            bool lead = true;
+            if (in_row) sgr = NEG;
+            int ix = fix;
+            uint32_t cw = s_cell[ix][lane]; uint32_t letter = s_let[ix][lane];
+            // (written out twice per turn, or with the slot's LDS address carried instead of the slot, the compiler turns
+            // the selects below into divergent branches and the loop is no faster than it was: measured)
+            while (b < b_end) {                                         // (a lane leaves the loop after its last column)
+                // the next column's cell is on its way while this one is worked on (its slot is not written here)
+                const int ixn = inc(ix);
+                const uint32_t cwn = s_cell[ixn][lane]; const uint32_t letter_n = s_let[ixn][lane];
+                const int32_t c_best = cell_best(cw), c_gap = cell_gap(cw);
+                int32_t msel = (int)letter == ab ? rew_v : pen_v;
+                if (__ballot(letter >= 4u)) {                           // ambiguity codes, the sentinel: from the matrix
+                    const uint32_t mm = s_pm[letter];
+                    int32_t m2 = (int32_t)(int8_t)(mm >> (8 * ab));
+                    m2 = m2 == -128 ? NEG : m2;
+                    msel = letter >= 4u ? m2 : msel;
+                }
+                const int32_t next = c_best + msel;
+                sc = max(sc, max(c_gap, sgr));
+                const bool keep = !(best_score - sc > x);
+                const bool better = keep & (sc > best_score);
+                const int32_t open = sc - goe;
+                lead = lead & !keep;
+                s_cell[ix][lane] = pack_cell(keep ? sc : NEG, keep ? max(open, c_gap - ge) : c_gap);   // (a failed first column leaves the window: what is stored there does not matter)
+                sgr = keep ? max(open, sgr - ge) : sgr;
+                last_b = keep ? b : last_b;
+                best_score = better ? sc : best_score; b_off = better ? b : b_off;
+                first_b += lead ? 1 : 0;
+                sc = next; b++; ix = ixn; cw = cwn; letter = letter_n;
+            }
+            a_off = best_score > best_before ? a : a_off;
+            lix = (fix + (last_b - first_b0)) & (W - 1);
+            fix = (fix + (first_b - first_b0)) & (W - 1);
+        }
+#endif
 
         // ---------------- the row's end (CORE/blast_gapalign.c:3022-3052): every column failed -> the half is over;
         // the window shrinks, or the horizontal gap runs on past it, one column per step; then the sentinel column
