@@ -115,7 +115,7 @@ class GbnExtParams(C.Structure):
                 ("cell_mask", _U), ("lut", C.c_int), ("masked", C.c_int), ("q2", _P), ("qinv", _P),
                 ("run_heads", _P), ("run_count", _P), ("group_bits", _I),
                 ("ihits", _P), ("ihit_count", _P), ("ihit_cap", _UL), ("ctx_hint", _P), ("ctx_hint_shift", _I), ("ext_rec", _P),
-                ("ck_shift", _I), ("ck_s_bits", _I), ("ck_qh_bits", _I), ("ck_q_bits", _I), ("ck_q_desc", _I), ("ck_subj_base", _I), ("ck_vbits", _I), ("q4", _P), ("q4_plane", _L), ("q4_origin", _I), ("ctx_blk", _P)]
+                ("ck_shift", _I), ("ck_s_bits", _I), ("ck_qh_bits", _I), ("ck_q_bits", _I), ("ck_q_desc", _I), ("ck_subj_base", _I), ("ck_vbits", _I), ("q4", _P), ("q4_plane", _L), ("q4_origin", _I), ("ctx_blk", _P), ("ctx_pack", _P), ("exact_list", _P), ("exact_count", _P)]
 
 
 class GbnGapParams(C.Structure):

@@ -73,7 +73,7 @@ struct DeviceBatch {
     unsigned long long *ent = nullptr;
     uint32_t *pvx = nullptr, *pstart = nullptr;         // rank form of pv / cell_start for the folded slice scan (lut_rank_fill)
     int32_t *ctx_off = nullptr, *ctx_len = nullptr, *ctx_xdrop = nullptr, *ctx_cutoff = nullptr,
-            *ctx_reduced = nullptr, *ctx_hint = nullptr, *ctx_blk = nullptr;    // ctx_hint[q >> kCtxHintShift]: the context position (q & ~mask) lies in
+            *ctx_reduced = nullptr, *ctx_hint = nullptr, *ctx_blk = nullptr, *ctx_pack = nullptr;   // ctx_pack[4 c ..]: x_dropoff, reduced cut-off, cut-off of context c in one 16-byte read    // ctx_hint[q >> kCtxHintShift]: the context position (q & ~mask) lies in
     int32_t *matrix = nullptr, *score_table = nullptr;
     int mode = 0, fl = 0, fr = 0;
     // lookup structures still being built on the builder's stream: the event they are complete at, and the
@@ -332,7 +332,7 @@ void free_device_batch(DeviceBatch *d) {
     if (!d) return;
     finish_build(d);
     dev_free(d->q8_base); dev_free(d->q2_base); dev_free(d->qinv_base); dev_free(d->q4_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent); dev_free(d->pvx); dev_free(d->pstart);
-    dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff);
+    dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff); dev_free(d->ctx_pack);
     dev_free(d->ctx_reduced); dev_free(d->ctx_hint); dev_free(d->ctx_blk); dev_free(d->matrix); dev_free(d->score_table);
     delete d;
 }
@@ -353,6 +353,9 @@ static int upload_ctx_cutoffs(GbnBatch &b) {
     HIPCHK(hipMemcpy(d->ctx_xdrop, xd.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d->ctx_cutoff, cu.data(), n * 4, hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(d->ctx_reduced, rd.data(), n * 4, hipMemcpyHostToDevice));
+    std::vector<int32_t> pk(4 * n);
+    for (size_t c = 0; c < n; c++) { pk[4 * c] = xd[c]; pk[4 * c + 1] = rd[c]; pk[4 * c + 2] = cu[c]; pk[4 * c + 3] = 0; }
+    HIPCHK(hipMemcpy(d->ctx_pack, pk.data(), 4 * n * 4, hipMemcpyHostToDevice));
     return GBN_OK;
 }
 
@@ -606,6 +609,7 @@ int upload_batch(GbnBatch &b) {
     if ((rc = dev_upload(d->ctx_off, off.data(), off.size()))) return rc;
     if ((rc = dev_upload(d->ctx_len, len.data(), len.size()))) return rc;
     if ((rc = dev_alloc(d->ctx_xdrop, off.size()))) return rc;
+    if ((rc = dev_alloc(d->ctx_pack, 4 * off.size()))) return rc;
     if ((rc = dev_alloc(d->ctx_cutoff, off.size()))) return rc;
     if ((rc = dev_alloc(d->ctx_reduced, off.size()))) return rc;
     if ((rc = upload_ctx_cutoffs(b))) return rc;
@@ -1156,9 +1160,12 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         X.cell_start = d->cell_start; X.ent = d->ent; X.cell_mask = (uint32_t)(b.lut.ncells - 1); X.lut = b.lut.lut;
         X.masked = b.lut.masked ? 1 : 0;
         X.run_heads = KS.idx_b; X.run_count = reinterpret_cast<uint32_t *>(ctr + 1); X.group_bits = K.group_bits;
-        X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = KS.ext_rec; X.ctx_blk = d->ctx_blk;
+        X.ctx_hint = d->ctx_hint; X.ctx_hint_shift = kCtxHintShift; X.ext_rec = KS.ext_rec; X.ctx_blk = d->ctx_blk; X.ctx_pack = d->ctx_pack;
         if (composite) {
             X.idx = KS.idx_b; X.run_heads = KS.idx_a;
+            // (values packed under the keys: idx_b is free, and lists the seeds of the exact pass; GBN_EXT_SPLIT=0: inline as before)
+            static const bool split = !(getenv("GBN_EXT_SPLIT") && atoi(getenv("GBN_EXT_SPLIT")) == 0);
+            if (split && packed) { X.exact_list = KS.idx_b; X.exact_count = reinterpret_cast<uint32_t *>(ctr + 1) + 1; }
             X.ck_shift = K.s_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending; X.ck_subj_base = K.subj_base; X.ck_vbits = K.v_bits;
         }
         X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
@@ -1933,7 +1940,7 @@ int gbn_batch_ext_params(const GbnBatch *b, const GbnDb *db, GbnExtParams *X) {
     X->word = b->lut.word; X->container_hash = b->container;
     X->cell_start = d->cell_start; X->ent = d->ent; X->cell_mask = (uint32_t)(b->lut.ncells - 1); X->lut = b->lut.lut;
     X->masked = b->lut.masked ? 1 : 0;
-    X->ctx_hint = d->ctx_hint; X->ctx_hint_shift = kCtxHintShift; X->ctx_blk = d->ctx_blk;
+    X->ctx_hint = d->ctx_hint; X->ctx_hint_shift = kCtxHintShift; X->ctx_blk = d->ctx_blk; X->ctx_pack = d->ctx_pack;
     return GBN_OK;
 }
 int gbn_batch_gap_params(const GbnBatch *b, const GbnDb *db, GbnGapParams *G) {

@@ -1205,17 +1205,57 @@ __device__ __forceinline__ bool exact_walk_window(const GbnExtParams &P, uint64_
 // loads of a seed are issued in three batches -- the keys; then everything the keys determine; then the subject -- before
 // any of them is looked at.
 // ---------------------------------------------------------------------------------------------------
+// The exact pass of a seed whose approximate score reached the reduced cut-off (s_NuclUngappedExtendExact), from the two
+// 32-base windows either side of q_ext that the approximate pass has loaded (see exact_walk_window)
+__device__ __forceinline__ GbnSeedHsp exact_from_windows(const GbnExtParams &P, const uint8_t *__restrict__ subj, int32_t slen, int32_t q_off, int32_t s_off,
+                                                         int32_t len4, int32_t q_ext, int32_t X, const ApproxPre &pl, const ApproxPre &pr)
+{
+    // the exact pass, from the two windows (see exact_walk_window); the "matches nothing" bits of the same 64
+    // bases are read here, by the one seed in six that gets this far (three aligned dwords hold them at any offset)
+    uint32_t qiv[3];
+    __builtin_memcpy(qiv, P.qinv + 4 * ((int64_t)(q_ext - 32) >> 5), 12);
+    const int ish = (q_ext - 32) & 31;
+    const uint32_t i0 = bswap32(qiv[0]), i1 = bswap32(qiv[1]), i2 = bswap32(qiv[2]);
+    const uint32_t ambl = ish ? __builtin_amdgcn_alignbit(i0, i1, 32 - ish) : i0, ambr = ish ? __builtin_amdgcn_alignbit(i1, i2, 32 - ish) : i1;
+    // (a code above 3 spills into the two bits of the base in FRONT of it when the byte of its group is put
+    // together -- (q[k] << 6) | (q[k+1] << 4) | ... -- so that base is read from q8 as well; groups do not
+    // straddle the windows' ends)
+    uint64_t amb64 = ((uint64_t)ambl << 32) | ambr;                 // bit 63 - j for base j of the 64
+    amb64 |= amb64 << 1;
+    const uint64_t sp64 = (((uint64_t)mism_mask32(pl.q0 ^ pl.s0, pl.q1 ^ pl.s1) << 32) | mism_mask32(pr.q0 ^ pr.s0, pr.q1 ^ pr.s1)) | amb64;
+    const int32_t n_l = min(q_off, s_off), n_r = min(P.qlen - q_off, slen - s_off);
+    const int32_t a_l = min(32 - len4, n_l), a_r = min(32 + len4, n_r);
+    int32_t xs = 0, sum = 0, b_l = 0, b_r = 0;
+    // left: base at distance t is window base 31 - len4 - t, i.e. bit 32 + len4 + t of the 64-bit masks
+    bool stop = exact_walk_window<true>(P, sp64 >> (32 + len4), amb64 >> (32 + len4), a_l, q_off, X, pl, pr, len4, sum, xs, b_l);
+    if (!stop && a_l < n_l) exact_walk_from<true>(P, subj, q_off, s_off, n_l, X, a_l, sum, xs, b_l);
+    sum = 0;
+    // right: base at distance t is window base 32 - len4 + t, i.e. bit 63 - t after a shift by 32 - len4
+    stop = exact_walk_window<false>(P, sp64 << (32 - len4), amb64 << (32 - len4), a_r, q_off, X, pl, pr, len4, sum, xs, b_r);
+    if (!stop && a_r < n_r) exact_walk_from<false>(P, subj, q_off, s_off, n_r, X, a_r, sum, xs, b_r);
+    GbnSeedHsp hs;
+    hs.q_start = q_off - b_l; hs.s_start = s_off - b_l; hs.length = b_l + b_r; hs.score = xs;
+    return hs;
+}
+
 #ifndef GBN_CK_OCC
 #define GBN_CK_OCC 8        // waves per SIMD seed_ext_ck_kernel is compiled for
 #endif
 extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel(GbnExtParams P)
 {
     constexpr int HB = 128;
-    __shared__ uint32_t s_hb[4][HB];
+    __shared__ uint32_t s_hb[4][HB], s_xb[4][HB];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned long long lt = (1ull << lane) - 1ull;
-    uint32_t *hb = s_hb[wave];
-    int nh = 0;                                                 // wave-uniform: heads waiting in hb
+    uint32_t *hb = s_hb[wave], *xb = s_xb[wave];
+    int nh = 0, nx = 0;                                         // wave-uniform: heads waiting in hb, seeds for the exact pass in xb
+    auto flush_exact = [&]() {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(P.exact_count, (uint32_t)nx);
+        base = __shfl(base, 0);
+        for (int k = lane; k < nx; k += 64) P.exact_list[base + (uint32_t)k] = xb[k];
+        nx = 0;
+    };
     auto flush = [&]() {
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(P.run_count, (uint32_t)nh);
@@ -1238,7 +1278,13 @@ extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel
         const int64_t j = min(jb + lane, j_hi - 1);             // (lanes past the end redo the last seed and store nothing)
         const bool live = jb + lane < j_hi;
         // ---- batch 1: the key and its neighbours
-        const uint64_t w0 = P.key_group[j], wm = P.key_group[j > 0 ? j - 1 : 0], wp = P.key_group[j + 1 < P.n ? j + 1 : j];
+        // (the neighbours' keys from the neighbouring lanes; the two outer lanes read theirs, in one load)
+        const uint64_t w0 = P.key_group[j];
+        uint64_t wm = __shfl_up(w0, 1), wp = __shfl_down(w0, 1);
+        if (lane == 0 || lane == 63) {
+            const uint64_t edge = P.key_group[lane == 0 ? (j > 0 ? j - 1 : 0) : (j + 1 < P.n ? j + 1 : j)];
+            if (lane == 0) wm = edge; else wp = edge;
+        }
         const uint64_t key = w0 >> vb;
         const uint32_t val = vb ? (uint32_t)(w0 & vmask) : P.idx[j];
         const uint32_t qk = val >> 8;
@@ -1281,10 +1327,8 @@ extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel
         __builtin_memcpy(cb, P.ctx_blk + 2 * (q_off >> P.ctx_hint_shift), 8);
         // (the sixteen steps of the two rounds either side of q_ext: sixteen consecutive bytes of one plane; readable
         // whatever the seed: 64 positions of padding either side)
-        uint32_t qq[4], qiv[3];
+        uint32_t qq[4];
         __builtin_memcpy(qq, q4_at(P, q_ext - 32), 16);
-        // the "matches nothing" bits of the same 64 bases, for the exact pass (three aligned dwords hold them at any offset)
-        __builtin_memcpy(qiv, P.qinv + 4 * ((int64_t)(q_ext - 32) >> 5), 12);
         // ---- batch 3: the subject's first rounds (16 padding bytes in front of every subject, 64 behind), the context's numbers
         const uint8_t *__restrict__ subj = P.db + boff;
         uint32_t sw[4];
@@ -1297,11 +1341,15 @@ extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel
         else lo = cb[0] + (q_off >= cb[1] ? 1 : 0);
         // (a lane that has dropped out keeps a sum of INT32_MIN / 2 for the rest of its round: any drop-off a score of
         // this path can reach -- |penalty| <= 127 over sequences of < 2^21 bases -- is far above it)
-        const int32_t X = max(-P.ctx_xdrop[lo], -(1 << 28)), reduced = P.ctx_reduced[lo], cutoff = P.ctx_cutoff[lo];
+        int32_t cx[4];
+        if (P.ctx_pack) __builtin_memcpy(cx, P.ctx_pack + 4 * lo, 16);
+        else { cx[0] = P.ctx_xdrop[lo]; cx[1] = P.ctx_reduced[lo]; cx[2] = P.ctx_cutoff[lo]; }
+        const int32_t X = max(-cx[0], -(1 << 28)), reduced = cx[1], cutoff = cx[2];
         // ---- the extension
         GbnSeedExt r; GbnSeedHsp hs;
         r.q_off = q_off; r.s_off = s_off; r.s_orig = s_off; r.flags = last ? 4 : 0;
         const int32_t s_match_end = s_off + P.word;
+        bool want_exact = false;
         {
             int32_t score = 0, bl = 0, br = 0;
             approx_side<true>(P, subj, q_ext, s_ext, min(q_ext, s_ext) >> 2, X, t4, dt, score, bl, true, pl);
@@ -1309,27 +1357,11 @@ extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel
             const int32_t uq = q_ext - 4 * bl, us = s_ext - 4 * bl;
             const int32_t new_q = br ? q_ext + 4 * br - 1 : q_ext;
             if (score >= reduced) {
-                // the exact pass, from the two windows (see exact_walk_window)
-                const int ish = (q_ext - 32) & 31;
-                const uint32_t i0 = bswap32(qiv[0]), i1 = bswap32(qiv[1]), i2 = bswap32(qiv[2]);
-                const uint32_t ambl = ish ? __builtin_amdgcn_alignbit(i0, i1, 32 - ish) : i0, ambr = ish ? __builtin_amdgcn_alignbit(i1, i2, 32 - ish) : i1;
-                // (a code above 3 spills into the two bits of the base in FRONT of it when the byte of its group is put
-                // together -- (q[k] << 6) | (q[k+1] << 4) | ... -- so that base is read from q8 as well; groups do not
-                // straddle the windows' ends)
-                uint64_t amb64 = ((uint64_t)ambl << 32) | ambr;                 // bit 63 - j for base j of the 64
-                amb64 |= amb64 << 1;
-                const uint64_t sp64 = (((uint64_t)mism_mask32(pl.q0 ^ pl.s0, pl.q1 ^ pl.s1) << 32) | mism_mask32(pr.q0 ^ pr.s0, pr.q1 ^ pr.s1)) | amb64;
-                const int32_t n_l = min(q_off, s_off), n_r = min(P.qlen - q_off, slen - s_off);
-                const int32_t a_l = min(32 - len4, n_l), a_r = min(32 + len4, n_r);
-                int32_t xs = 0, sum = 0, b_l = 0, b_r = 0;
-                // left: base at distance t is window base 31 - len4 - t, i.e. bit 32 + len4 + t of the 64-bit masks
-                bool stop = exact_walk_window<true>(P, sp64 >> (32 + len4), amb64 >> (32 + len4), a_l, q_off, X, pl, pr, len4, sum, xs, b_l);
-                if (!stop && a_l < n_l) exact_walk_from<true>(P, subj, q_off, s_off, n_l, X, a_l, sum, xs, b_l);
-                sum = 0;
-                // right: base at distance t is window base 32 - len4 + t, i.e. bit 63 - t after a shift by 32 - len4
-                stop = exact_walk_window<false>(P, sp64 << (32 - len4), amb64 << (32 - len4), a_r, q_off, X, pl, pr, len4, sum, xs, b_r);
-                if (!stop && a_r < n_r) exact_walk_from<false>(P, subj, q_off, s_off, n_r, X, a_r, sum, xs, b_r);
-                hs.q_start = q_off - b_l; hs.s_start = s_off - b_l; hs.length = b_l + b_r; hs.score = xs;
+                if (P.exact_list) {                             // left to seed_exact_kernel: listed below, not saved here
+                    want_exact = live;
+                    hs.q_start = uq; hs.s_start = us; hs.score = INT32_MIN; hs.length = 0;
+                } else
+                hs = exact_from_windows(P, subj, slen, q_off, s_off, len4, q_ext, X, pl, pr);
             } else {
                 hs.q_start = uq; hs.s_start = us; hs.score = score;
                 hs.length = max(s_match_end - us, new_q - uq + 1);
@@ -1340,6 +1372,13 @@ extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel
             rec[pos] = r;
             if (r.flags & 2) (reinterpret_cast<GbnSeedHsp *>(rec + P.n))[pos] = hs;
         }
+        // ---- seeds for the exact pass (seed_exact_kernel), listed like the run heads
+        const unsigned long long mx = __ballot(want_exact);
+        if (mx) {
+            if (want_exact) xb[nx + __popcll(mx & lt)] = (uint32_t)pos;
+            nx += __popcll(mx);
+            if (nx > HB - 64) flush_exact();
+        }
         // ---- run heads: into the wave's buffer, out of it when the next 64 seeds might not fit
         const unsigned long long mh = __ballot(head);
         if (mh) {
@@ -1349,6 +1388,43 @@ extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel
         }
     }
     if (nh) flush();
+    if (nx) flush_exact();
+}
+
+// The exact pass of the seeds seed_ext_ck_kernel listed (one in six on C3), a thread each: inside that kernel the pass
+// was half of its instructions with a sixth of the lanes at work, and the kernel is bound by VALU issue.  Saved seeds get
+// their record's flag and their extension here, before the replay reads them.
+extern "C" __global__ void __launch_bounds__(256) seed_exact_kernel(GbnExtParams P)
+{
+    const uint32_t n = *P.exact_count;
+    const int gb = P.group_bits ? P.group_bits : 32;
+    GbnSeedExt *__restrict__ rec = reinterpret_cast<GbnSeedExt *>(P.ext_rec);
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < n; t += gridDim.x * 256u) {
+        const uint32_t pos = P.exact_list[t];
+        const GbnSeedExt r = rec[pos];
+        const uint64_t run = (P.key_group[pos] >> P.ck_vbits) >> P.ck_shift;       // (a group of equal keys shares subject and slot)
+        const int32_t subj_id = (int32_t)(run >> gb) + P.ck_subj_base;
+        const int32_t q_off = r.q_off, s_off = r.s_off;
+        const int32_t len4 = (4 - (s_off & 3)) & 3;
+        const int32_t q_ext = q_off + len4, s_ext = s_off + len4;
+        const uint8_t *__restrict__ subj = P.db + P.byte_off[subj_id];
+        const int32_t slen = P.len[subj_id];
+        int32_t cb[2];
+        __builtin_memcpy(cb, P.ctx_blk + 2 * (q_off >> P.ctx_hint_shift), 8);
+        uint32_t qq[4], sw[4];
+        __builtin_memcpy(qq, q4_at(P, q_ext - 32), 16);
+        __builtin_memcpy(sw, subj + ((s_ext - 32) >> 2), 16);
+        ApproxPre pl, pr;
+        pl.q0 = qq[0]; pl.q1 = qq[1]; pr.q0 = qq[2]; pr.q1 = qq[3];
+        pl.s0 = sw[0]; pl.s1 = sw[1]; pr.s0 = sw[2]; pr.s1 = sw[3];
+        const int lo = cb[1] == INT32_MIN ? context_of(P, q_off) : cb[0] + (q_off >= cb[1] ? 1 : 0);
+        const int32_t X = max(-P.ctx_xdrop[lo], -(1 << 28)), cutoff = P.ctx_cutoff[lo];
+        const GbnSeedHsp hs = exact_from_windows(P, subj, slen, q_off, s_off, len4, q_ext, X, pl, pr);
+        if (hs.score >= cutoff) {
+            (reinterpret_cast<GbnSeedHsp *>(rec + P.n))[pos] = hs;
+            rec[pos].flags = r.flags | 2;
+        }
+    }
 }
 
 extern "C" __global__ void __launch_bounds__(64) diag_replay_kernel(GbnExtParams P)
@@ -2513,7 +2589,9 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
         if (ck2 && p.q4 && p.ctx_blk && !p.masked && (p.container_hash || p.word >= 11)) {
             // a stretch of 64 x k seeds per wave: every wave slot of the chip taken, eight or more rounds per wave
             const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((p.n + 2047) / 2048, 256 * 32));
+            if (p.exact_list) { e = hipMemsetAsync(p.exact_count, 0, sizeof(uint32_t), st); if (e != hipSuccess) return e; }
             hipLaunchKernelGGL(seed_ext_ck_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+            if (p.exact_list) hipLaunchKernelGGL(seed_exact_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((p.n + 1535) / 1536, 4096))), dim3(256), 0, st, p);
         } else
         hipLaunchKernelGGL(seed_ext_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
         hipLaunchKernelGGL(diag_replay_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);

@@ -126,6 +126,11 @@ typedef struct GbnExtParams {
      * offset at which the next context begins (INT32_MAX: none; INT32_MIN: more than one context begins inside the block,
      * look it up through ctx_hint / ctx_off) -- a seed's context from one 8-byte load */
     const int32_t *ctx_blk;
+    /* optional: ctx_pack[4 c], [4 c + 1], [4 c + 2] = ctx_xdrop[c], ctx_reduced[c], ctx_cutoff[c] (one 16-byte read per seed) */
+    const int32_t *ctx_pack;
+    /* optional [caller] scratch: n entries and a counter.  With them the seeds whose approximate score reaches the reduced
+     * cut-off are listed and extended exactly by a kernel of their own (composite keys only) */
+    uint32_t *exact_list, *exact_count;
 } GbnExtParams;
 
 typedef struct GbnGapParams {
