@@ -375,6 +375,8 @@ def slice_kernel_name(info):
     """the slice scan's kernel as rocprof names it: tables of more than 2^20 cells (lut 11, 12) are scanned through the folded
     filter + rank tables (scan_fold_kernel) unless GBN_SLICE_FOLD=0 asks for a pass per slice"""
     folded = 2 * int(info.get("lut_width", 0)) > 20 and os.environ.get("GBN_SLICE_FOLD", "1") != "0"
+    if folded and os.environ.get("GBN_SCAN_ORDERED", "1") != "0":
+        return "scan_fold_ordered_kernel"       # ... with the seeds in scan order
     return "scan_fold_kernel" if folded else "scan_slice_kernel"
 
 

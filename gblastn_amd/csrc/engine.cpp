@@ -42,8 +42,9 @@ int scan_slice_count(const GbnScanParams &p);
 int scan_slice_blocks(const GbnScanParams &p, int num_cu);
 hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
                              unsigned long long *seg_max, hipStream_t st);
-hipError_t launch_seed_compact(const GbnDevSeed *seg, const uint32_t *seg_count, int nseg, uint32_t seg_cap, GbnDevSeed *out,
-                               unsigned long long out_cap, hipStream_t st);
+int scan_slice_segments(const GbnScanParams &p, int num_cu, int *ordered);
+hipError_t launch_seed_compact(const GbnDevSeed *seg, const uint32_t *seg_count, unsigned long long *seg_first, int nseg, uint32_t seg_cap,
+                               GbnDevSeed *out, unsigned long long out_cap, hipStream_t st);
 hipError_t sort_keys_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, int64_t n, int begin_bit, int end_bit, hipStream_t st);
 
 static thread_local std::string g_err;
@@ -112,7 +113,9 @@ struct Engine {
     const GbnBatch *pending_batch = nullptr;   // the batch the stage in flight reads (its device memory must outlive the stage)
     unsigned long long *counters = nullptr;     // [0] seeds, [1] raw hits, [2] init hits, [3] runs; [4], [5]: init hits, runs of an asynchronous seed stage
     GbnDevSeed *slice_seg = nullptr; size_t slice_seg_cap = 0;        // scan_slice_kernel: the workgroups' seed segments
-    bool seg_valid = false; int seg_n = 0; uint32_t seg_len = 0;       // the last scan left its seeds there (seg_n segments of seg_len slots, counts in rare_counts), not in `seeds`
+    bool seg_valid = false; int seg_n = 0; uint32_t seg_len = 0;       // the last scan left its seeds there (seg_n segments of seg_len slots, counts in seg_counts), not in `seeds`
+    bool seg_ordered = false;       // ... and the segments read one after the other are in scan order (subject, position, entry)
+    uint32_t *seg_counts = nullptr; unsigned long long *seg_firsts = nullptr;     // GBN_SLICE_SEGS counts / + 1 prefix sums (scratch of the consumers)
     GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
     hipEvent_t ev_seed = nullptr;
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
@@ -875,7 +878,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     if (nb > 1)
         for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) npos += (db.len[s] - b.lut.lut) / b.lut.step + 1;
     double slack = 1.25;
-    size_t rare_seg_hint = 0, slice_seg_cap = 0; int slice_blocks = 0;
+    size_t rare_seg_hint = 0, slice_seg_cap = 0; int slice_blocks = 0; bool slice_ordered = false;
     for (;;) {
         HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream));
         GbnScanParams P; fill_scan_params(P, b, db, ts);
@@ -887,13 +890,15 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             if (sliced) {
                 // every workgroup writes its seeds into a segment of its own (no global counter), a second kernel puts
                 // the segments back to back.  Segments: 1.5 x the seeds a random subject gives, twice as long after an overflow
-                const int blocks = scan_slice_blocks(P, E.num_cu);
-                slice_blocks = blocks;
+                // (with the seeds in scan order a segment belongs to a wave, sixteen per workgroup)
+                int ordered = 0;
+                const int blocks = scan_slice_segments(P, E.num_cu, &ordered);
+                slice_blocks = blocks; slice_ordered = ordered != 0;
                 if (slice_seg_cap == 0) {
                     int64_t np = 0;
                     for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) np += db.len[s] - b.lut.lut + 1;
                     const double expect = (double)np * std::min(1.0, (double)b.qlen / (double)b.lut.ncells) / blocks;
-                    slice_seg_cap = (size_t)(expect * 1.5) + 8192;
+                    slice_seg_cap = (size_t)(expect * 1.5) + (ordered ? 1024 : 8192);
                 }
                 if (slice_seg_cap > 0x7fffff00u) { set_error("too many seeds in one range"); return GBN_ERR_NOMEM; }
                 const size_t need = slice_seg_cap * (size_t)blocks;
@@ -902,8 +907,8 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                     if ((rc = dev_alloc(E.slice_seg, need + need / 8))) return rc;
                     E.slice_seg_cap = need + need / 8;
                 }
-                if (!E.rare_counts && (rc = dev_alloc(E.rare_counts, (size_t)2048))) return rc;
-                HIPCHK(launch_scan_slice(P, E.num_cu, E.slice_seg, (uint32_t)slice_seg_cap, E.rare_counts, E.counters + 2, E.stream));
+                if (!E.seg_counts && ((rc = dev_alloc(E.seg_counts, (size_t)GBN_SLICE_SEGS)) || (rc = dev_alloc(E.seg_firsts, (size_t)GBN_SLICE_SEGS + 1)))) return rc;
+                HIPCHK(launch_scan_slice(P, E.num_cu, E.slice_seg, (uint32_t)slice_seg_cap, E.seg_counts, E.counters + 2, E.stream));
             } else HIPCHK(launch_scan_seed(P, scan_grid(ts.ntiles), E.stream));
             HIPCHK(hipEventRecord(E.ev1, E.stream));
         } else {
@@ -1035,7 +1040,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         if (defer) { defer->valid = true; break; }          // (the seeds do not exist yet: whoever runs the rare kernel sizes their buffer)
         if (sliced) {       // the seeds sit in the workgroups' segments; E.seeds only has to be long enough for compact_seeds
             if (cnt[0] > E.seed_cap && (rc = grow_seed_buffers((size_t)cnt[0] + (cnt[0] >> 3)))) return rc;
-            E.seg_valid = cnt[0] > 0; E.seg_n = slice_blocks; E.seg_len = (uint32_t)slice_seg_cap;
+            E.seg_valid = cnt[0] > 0; E.seg_n = slice_blocks; E.seg_len = (uint32_t)slice_seg_cap; E.seg_ordered = slice_ordered;
             break;
         }
         if (cnt[0] <= E.seed_cap) break;
@@ -1051,7 +1056,7 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
 // the seeds of the last scan in one array (E.seeds), for the consumers that do not read scan_slice_kernel's segments
 static int compact_seeds(hipStream_t st) {
     if (!E.seg_valid) return GBN_OK;
-    HIPCHK(launch_seed_compact(E.slice_seg, E.rare_counts, E.seg_n, E.seg_len, E.seeds, E.seed_cap, st));
+    HIPCHK(launch_seed_compact(E.slice_seg, E.seg_counts, E.seg_firsts, E.seg_n, E.seg_len, E.seeds, E.seed_cap, st));
     E.seg_valid = false;
     return GBN_OK;
 }
@@ -1123,12 +1128,14 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     const bool packed = composite && ck_pack && ck_bits + v_bits <= 64;
     if (composite) {
         K.key_scan = KS.key_a; K.idx = KS.idx_a; K.v_bits = packed ? v_bits : 0;
-        if (from_segments) { K.seg = E.slice_seg; K.seg_count = E.rare_counts; K.nseg = E.seg_n; K.seg_cap = E.seg_len;
-                             K.seg_first = reinterpret_cast<unsigned long long *>(E.rare_counts + 1024); }    // (rare_counts: 2048 words, the segment counts are its first 256)
+        if (from_segments) { K.seg = E.slice_seg; K.seg_count = E.seg_counts; K.nseg = E.seg_n; K.seg_cap = E.seg_len; K.seg_first = E.seg_firsts; }
         if (phase != 2) {
             HIPCHK(launch_seed_ckeys(K, st));
             size_t tb = KS.sort_tmp_bytes;
-            if (packed) HIPCHK(sort_keys_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, n, v_bits, v_bits + ck_bits, st));
+            // (seeds that come in scan order -- scan_fold_ordered_kernel's segments -- are in the order of the key's scan-position
+            // bits already: the stable sort has subject | slot left to do)
+            const int s_done = (from_segments && E.seg_ordered) ? K.s_bits : 0;
+            if (packed) HIPCHK(sort_keys_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, n, v_bits + s_done, v_bits + ck_bits, st));
             else HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, n, ck_bits, st));
         }
         // key_b = sorted composite keys, idx_b = ext_left of the seeds in that order (packed: both in key_b)
@@ -1691,7 +1698,7 @@ static void release_engine() {              // (the calling thread has entered i
     (void)hipDeviceSynchronize();                       // nothing of ours is queued or running when buffers, streams and events go
     (void)pool_check_guards();
     E.binkey.valid = false;
-    dev_free(E.slice_seg); E.slice_seg_cap = 0;
+    dev_free(E.slice_seg); E.slice_seg_cap = 0; dev_free(E.seg_counts); dev_free(E.seg_firsts);
     hitbuf_drain();
     dev_free(E.seeds_async); E.seeds_async_cap = 0; if (E.ev_seed) { (void)hipEventDestroy(E.ev_seed); E.ev_seed = nullptr; }
     dev_free(E.seeds);

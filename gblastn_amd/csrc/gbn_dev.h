@@ -95,7 +95,7 @@ struct GbnKeyParams {
 #define GBN_SLICE_WORDS     (1 << (GBN_SLICE_CELL_BITS - 5))
 #define GBN_SLICE_QCAP      128         // per-wave queue of present positions
 #define GBN_SLICE_MAX       16          // most slices (passes over the subjects) it is used with
-#define GBN_SLICE_SEGS      256         // most workgroups (= output segments) of a launch
+#define GBN_SLICE_SEGS      4096        // most output segments of a launch (a workgroup's, or a wave's when the seeds come in scan order)
 
 // seeds per launch below which the diagonal kernel runs thread-per-seed instead of on compacted run heads
 #ifndef GBN_DIAG_COMPACT_MIN

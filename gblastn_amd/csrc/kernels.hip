@@ -479,6 +479,249 @@ __device__ __forceinline__ void scan_slice_body(const GbnScanParams &P, int nsli
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The folded scan with its seeds IN SCAN ORDER (round 3).  What the seed stage's sort restores -- subject, diagonal slot,
+// scan position -- is mostly an order the scan knows and throws away: here a wave takes a contiguous stretch of tiles and
+// owns an output segment, a tile's hits enter the wave's queue in position order (lane-major: the lanes hold 32 consecutive
+// positions each, so a hit's place follows from the prefix sums of the lanes' hit counts), and the queue is emptied from
+// its old end.  The segments read one after the other are then the seeds ordered by (subject, scan position, entry), and
+// the composite-key sort has only subject | slot left to do: 19 instead of 39 bits for C3, three passes instead of five.
+// Two looks at the presence bits per hit (pvx: once to learn which candidates are hits, once more -- by the hits only, a
+// sixth of the first look's reads -- for their ranks when their places are known): cheaper than keeping 32 ranks per lane.
+// ---------------------------------------------------------------------------------------------------
+#ifndef GBN_OQ_STRIDED
+#define GBN_OQ_STRIDED 0
+#endif
+#define GBN_SLICE_OQ 192            // ring of (position, rank) pairs per wave: 64 left over + 128 of a tile's hits at a time
+extern "C" __global__ void __launch_bounds__(GBN_SLICE_THREADS)
+scan_fold_ordered_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
+                         unsigned long long *seg_max)
+{
+    extern __shared__ __attribute__((aligned(16))) uint32_t s_slice[];
+    uint32_t *s_pv = s_slice;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const uint32_t slice_words = (1u << slice_cell_bits) >> 5;
+    for (uint32_t i = tid; i < slice_words; i += GBN_SLICE_THREADS) {
+        uint32_t v = 0;
+        for (int f = 0; f < nslices; f++) v |= P.pv[(size_t)f * slice_words + i];
+        s_pv[i] = v;
+    }
+    __syncthreads();
+    constexpr int QO = GBN_SLICE_OQ;
+    static_assert(2 * GBN_SLICE_OQ <= 3 * GBN_SLICE_QCAP, "the ordered queue lives in the unordered one's LDS");
+    uint32_t *q_pos = s_slice + GBN_SLICE_WORDS + wave * 3 * GBN_SLICE_QCAP, *q_rank = q_pos + QO;
+    const int64_t gw = (int64_t)blockIdx.x * (GBN_SLICE_THREADS / 64) + wave, NW = (int64_t)gridDim.x * (GBN_SLICE_THREADS / 64);
+    const int64_t tpw = (P.ntiles + NW - 1) / NW;
+#if GBN_OQ_STRIDED      // timing experiment only (wrong order): tiles dealt round-robin as in scan_slice_body
+    const int64_t t_first = gw, t_end = P.ntiles, t_inc = NW; (void)tpw;
+#else
+    const int64_t t_first = gw * tpw, t_end = min(P.ntiles, t_first + tpw), t_inc = 1;
+#endif
+    GbnDevSeed *__restrict__ myseg = seg + (size_t)gw * seg_cap;
+    uint32_t used = 0;                                                  // wave-uniform: seeds in the wave's segment
+    int head = 0, qn = 0;                                               // wave-uniform: the ring's oldest entry, its length
+    const unsigned long long lt = (1ull << lane) - 1;
+    int32_t cur_subj = -1;
+    unsigned long long raw = 0;
+    const int top = 64 - 2 * P.lut, top32 = 32 - 2 * P.lut;
+    const int wd_shift = top32 + 5, wd_bits = slice_cell_bits - 5;
+    const uint2 *__restrict__ pvx = reinterpret_cast<const uint2 *>(P.pvx);
+
+    // the `cnt` oldest queued hits, a lane each: their cells' entries become seeds at the end of the wave's segment
+    auto flush = [&](int cnt) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        uint32_t start = 0, n = 0; int32_t sp = 0;
+        if (lane < cnt) {
+            int idx = head + lane; idx -= idx >= QO ? QO : 0;
+            sp = (int32_t)q_pos[idx];
+            const uint32_t rank = q_rank[idx];
+            start = P.pstart[rank]; n = P.pstart[rank + 1] - start;
+        }
+        raw += n;
+        uint32_t incl = n;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); incl += (lane >= d) ? v : 0u; }
+        const uint32_t total = __shfl(incl, 63);
+        const uint32_t base = used + (incl - n);
+        for (uint32_t e = 0; e < n; e++) {
+            if (base + e < seg_cap) {
+                GbnDevSeed sd; sd.subj = cur_subj; sd.s_scan = sp; sd.q_pos = (int32_t)(uint32_t)(P.ent[start + e] & 0xffffffffull); sd.ext_left = 0;
+                myseg[base + e] = sd;
+            }
+        }
+        used += total;
+        head += cnt; head -= head >= QO ? QO : 0; qn -= cnt;
+    };
+
+    struct Fetch { GbnTile T; int32_t nl, p0; uint32_t d0, d1, d2; };
+    auto fetch = [&](int64_t t) {
+        Fetch f;
+        f.T = P.tiles[t];
+        const uint8_t *__restrict__ subj = P.db + P.byte_off[f.T.subj];
+        f.nl = min(32, f.T.npos - 32 * lane);
+        f.p0 = f.T.first_pos + (f.nl > 0 ? 32 * lane : 0);
+        const uint32_t *__restrict__ dw = reinterpret_cast<const uint32_t *>(subj) + (f.p0 >> 4);
+        f.d0 = dw[0]; f.d1 = dw[1]; f.d2 = dw[2];
+        return f;
+    };
+    Fetch nx;
+    if (t_first < t_end) nx = fetch(t_first);
+    for (int64_t t = t_first; t < t_end; t += t_inc) {
+        const Fetch cur = nx;
+        if (t + t_inc < t_end) nx = fetch(t + t_inc);
+        const GbnTile T = cur.T;
+        const int32_t nl = cur.nl, p0 = cur.p0;
+        const uint32_t W[3] = {bswap32(cur.d0), bswap32(cur.d1), bswap32(cur.d2)};
+        const uint64_t hi0 = ((uint64_t)W[0] << 32) | W[1];
+        const uint32_t lo0 = W[2];
+        if (T.subj != cur_subj) {                                       // (the queue's entries carry no subject)
+            while (qn > 0) flush(min(qn, 64));
+            cur_subj = T.subj;
+        }
+        // the filter: 32 LDS reads per lane, as in scan_slice_body
+        uint32_t hm = 0;
+        #pragma unroll
+        for (int i0 = 0; i0 < 32; i0 += 16) {
+            uint32_t x[16], w[16];
+            #pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int o = 2 * (i0 + j), wi = o >> 5, r = o & 31;
+                x[j] = r ? __builtin_amdgcn_alignbit(W[wi], W[wi + 1], 32 - r) : W[wi];
+            }
+            #pragma unroll
+            for (int j = 0; j < 16; j++) w[j] = s_pv[__builtin_amdgcn_ubfe(x[j], wd_shift, wd_bits)];
+            #pragma unroll
+            for (int j = 0; j < 16; j++) hm |= __builtin_amdgcn_ubfe(w[j], __builtin_amdgcn_ubfe(x[j], top32, 5), 1) << (i0 + j);
+        }
+        hm &= (nl >= 32) ? 0xffffffffu : ((nl > 0) ? ((1u << nl) - 1u) : 0u);
+        auto cell_at = [&](int i) -> uint32_t {
+            const uint64_t x = i ? ((hi0 << (2 * i)) | (((uint64_t)lo0 << 32) >> (64 - 2 * i))) : hi0;
+            return (uint32_t)(x >> top);
+        };
+        // The candidates that are hits, four of a lane's at a time.  A hit joins the ring at once, behind what is queued, with
+        // its rank -- in the order the hits turn up; their places follow below.  (More hits than the ring has room for --
+        // a tile of repeats --: the slow way further down, which looks the ranks up a second time.)
+        uint32_t tm = 0;
+        int np = 0; bool ovf = false;                                   // wave-uniform: hits written, gave up
+        const int room = min(QO - qn, 128), pbase = head + qn;
+        while (__ballot(hm != 0)) {
+            uint32_t bit4[4]; uint2 pw[4]; int i4[4];
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool have = hm != 0;
+                i4[u] = have ? __ffs(hm) - 1 : 0;
+                hm &= hm - 1;
+                const uint32_t cell = cell_at(i4[u]);
+                bit4[u] = cell & 31u;
+                pw[u] = have ? pvx[cell >> 5] : make_uint2(0u, 0u);
+            }
+            #pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool present = (pw[u].x >> bit4[u]) & 1u;
+                tm |= (present ? 1u : 0u) << i4[u];
+                const unsigned long long m = __ballot(present);
+                if (!m) continue;
+                const int cm = __popcll(m);
+                if (!ovf && np + cm <= room) {
+                    if (present) {
+                        int idx = pbase + np + __popcll(m & lt); idx -= idx >= QO ? QO : 0;
+                        q_pos[idx] = (uint32_t)(p0 + i4[u]); q_rank[idx] = pw[u].y + (uint32_t)__popc(pw[u].x & ((1u << bit4[u]) - 1u));
+                    }
+                    np += cm;
+                } else ovf = true;
+            }
+        }
+        // their places: lane-major = position order
+        const uint32_t cnt_l = (uint32_t)__popc(tm);
+        uint32_t incl = cnt_l;
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); incl += (lane >= d) ? v : 0u; }
+        const uint32_t excl = incl - cnt_l, total = __shfl(incl, 63);
+        if (!total) continue;
+        if (!ovf) {
+            // every entry to its place: the lane that owns a hit's position knows how many hits lie in front of it
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            uint32_t ep[2], er[2]; int dst[2];
+            #pragma unroll
+            for (int k = 0; k < 2; k++) {
+                const int j = lane + 64 * k;
+                int idx = pbase + min(j, max(np - 1, 0)); idx -= idx >= QO ? QO : 0;
+                ep[k] = q_pos[idx]; er[k] = q_rank[idx];
+                const uint32_t rel = ep[k] - (uint32_t)T.first_pos;
+                const int owner = (int)(rel >> 5) & 63;
+                const uint32_t o_excl = __shfl(excl, owner), o_tm = __shfl(tm, owner);
+                int d = pbase + (int)(o_excl + (uint32_t)__popc(o_tm & ((1u << (rel & 31u)) - 1u))); d -= d >= QO ? QO : 0;
+                dst[k] = j < np ? d : -1;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            #pragma unroll
+            for (int k = 0; k < 2; k++) if (dst[k] >= 0) { q_pos[dst[k]] = ep[k]; q_rank[dst[k]] = er[k]; }
+            qn += np;
+            while (qn >= 64) flush(64);
+            continue;
+        }
+        // second look, by the hits only: their ranks -- the first four of a lane asked for at once, before the places are
+        // worked out (a lane with more goes on two at a time below)
+        uint32_t tmc = tm;
+        uint32_t hpos[4], hbit[4]; uint2 hw[4];
+        #pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool have = tmc != 0;
+            const int i = have ? __ffs(tmc) - 1 : 0;
+            tmc &= tmc - 1;
+            const uint32_t cell = cell_at(i);
+            hpos[u] = (uint32_t)(p0 + i); hbit[u] = cell & 31u;
+            hw[u] = have ? pvx[cell >> 5] : make_uint2(0u, 0u);
+        }
+        // at most QO - 64 hits join the queue at a time: lanes in chunks by their place (a tile full of hits takes 22 rounds)
+        constexpr uint32_t CH = QO - 64 - 32;
+        const uint32_t chunk = excl / CH, cmax = __shfl(chunk, 63);
+        for (uint32_t c = 0; c <= cmax; c++) {
+            const unsigned long long in_c = __ballot(chunk == c);
+            if (!in_c) continue;
+            const int f = (int)__builtin_ctzll(in_c), g = 63 - (int)__builtin_clzll(in_c);
+            const uint32_t first_excl = __shfl(excl, f), c_total = __shfl(incl, g) - first_excl;
+            if (chunk == c) {
+                int at = head + qn + (int)(excl - first_excl);
+                #pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    if ((uint32_t)u < cnt_l) {
+                        int a0 = at + u; a0 -= a0 >= QO ? QO : 0;
+                        q_pos[a0] = hpos[u]; q_rank[a0] = hw[u].y + (uint32_t)__popc(hw[u].x & ((1u << hbit[u]) - 1u));
+                    }
+                }
+                at += 4;
+                while (tmc) {
+                    const int i0 = __ffs(tmc) - 1; tmc &= tmc - 1;
+                    const bool two = tmc != 0;
+                    const int i1 = two ? __ffs(tmc) - 1 : i0; tmc &= tmc - 1;      // (0 & anything: stays 0)
+                    const uint32_t c0 = cell_at(i0), c1 = cell_at(i1);
+                    const uint2 w0 = pvx[c0 >> 5], w1 = pvx[c1 >> 5];
+                    int a0 = at; a0 -= a0 >= QO ? QO : 0;
+                    q_pos[a0] = (uint32_t)(p0 + i0); q_rank[a0] = w0.y + (uint32_t)__popc(w0.x & ((1u << (c0 & 31u)) - 1u));
+                    if (two) {
+                        int a1 = at + 1; a1 -= a1 >= QO ? QO : 0;
+                        q_pos[a1] = (uint32_t)(p0 + i1); q_rank[a1] = w1.y + (uint32_t)__popc(w1.x & ((1u << (c1 & 31u)) - 1u));
+                    }
+                    at += 2;
+                }
+            }
+            qn += (int)c_total;
+            while (qn >= 64) flush(64);
+        }
+    }
+    while (qn > 0) flush(min(qn, 64));
+    if (P.raw_hits) {
+        for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
+        if (lane == 0 && raw) atomicAdd(P.raw_hits, raw);
+    }
+    if (lane == 0) {
+        seg_count[gw] = used;
+        if (used) { atomicAdd(P.seed_count, (unsigned long long)used); atomicMax(seg_max, (unsigned long long)used); }
+    }
+}
+
 extern "C" __global__ void __launch_bounds__(GBN_SLICE_THREADS)
 scan_slice_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
                   unsigned long long *seg_max)
@@ -500,22 +743,16 @@ scan_fold_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed *
 // the segments of scan_slice_kernel, back to back: seeds[0 .. sum of counts) -- for the consumers that want the seeds
 // in one array (the composite-key seed stage reads the segments as they are)
 extern "C" __global__ void __launch_bounds__(256)
-seed_compact_kernel(const GbnDevSeed *__restrict__ seg, const uint32_t *__restrict__ seg_count, int nseg, uint32_t seg_cap,
-                    GbnDevSeed *__restrict__ out, unsigned long long out_cap)
+seed_compact_kernel(const GbnDevSeed *__restrict__ seg, const uint32_t *__restrict__ seg_count, const unsigned long long *__restrict__ seg_first,
+                    int nseg, uint32_t seg_cap, GbnDevSeed *__restrict__ out, unsigned long long out_cap)
 {
-    __shared__ unsigned long long s_at[GBN_SLICE_SEGS + 1];
-    __shared__ uint32_t s_have[GBN_SLICE_SEGS];
+    // (seg_first: seg_first_kernel's prefix sums, launched in front)
     const int sg = blockIdx.x % nseg, part = blockIdx.x / nseg, nparts = gridDim.x / nseg;
-    if (threadIdx.x == 0) {
-        unsigned long long at = 0;
-        for (int i = 0; i < nseg; i++) { const uint32_t c = seg_count[i]; s_at[i] = at; s_have[i] = min(c, seg_cap); at += s_have[i]; }
-        s_at[nseg] = at;
-    }
-    __syncthreads();
     const uint4 *__restrict__ src = reinterpret_cast<const uint4 *>(seg + (size_t)sg * seg_cap);
     uint4 *__restrict__ dst = reinterpret_cast<uint4 *>(out);
-    const unsigned long long at = s_at[sg];
-    for (uint32_t i = (uint32_t)part * 256u + threadIdx.x; i < s_have[sg]; i += (uint32_t)nparts * 256u)
+    const unsigned long long at = seg_first[sg];
+    const uint32_t have = min(seg_count[sg], seg_cap);
+    for (uint32_t i = (uint32_t)part * 256u + threadIdx.x; i < have; i += (uint32_t)nparts * 256u)
         if (at + i < out_cap) dst[at + i] = src[i];
 }
 
@@ -538,20 +775,27 @@ extern "C" __global__ void seed_keys_kernel(GbnKeyParams K)
 // a handful per million -- by the high bits of the query key, which seed_ext_kernel applies.  The seed follows from
 // key and value (q_pos's low bits = (s_scan - slot) mod slots; value = ext_left | high bits of the query key << 8):
 // no second sort, no gathers of seeds by rank afterwards.
-// (segmented input: the index of every segment's first seed, first[nseg] = their number -- one wave, 64 counts at a time)
-extern "C" __global__ void __launch_bounds__(64) seg_first_kernel(const uint32_t *seg_count, int nseg, uint32_t seg_cap, unsigned long long *first)
+// (segmented input: the index of every segment's first seed, first[nseg] = their number -- one workgroup, up to
+// GBN_SLICE_SEGS / 1024 consecutive counts per thread)
+extern "C" __global__ void __launch_bounds__(1024) seg_first_kernel(const uint32_t *seg_count, int nseg, uint32_t seg_cap, unsigned long long *first)
 {
-    unsigned long long carry = 0;
-    for (int b0 = 0; b0 < nseg; b0 += 64) {
-        const int sgi = b0 + (int)threadIdx.x;
-        const unsigned long long c = sgi < nseg ? (unsigned long long)min(seg_count[sgi], seg_cap) : 0ull;
-        unsigned long long incl = c;
-        #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const unsigned long long v = __shfl_up(incl, d); incl += ((int)threadIdx.x >= d) ? v : 0ull; }
-        if (sgi < nseg) first[sgi] = carry + incl - c;
-        carry += __shfl(incl, 63);
-    }
-    if (threadIdx.x == 0) first[nseg] = carry;
+    constexpr int PER = (GBN_SLICE_SEGS + 1023) / 1024;
+    __shared__ unsigned long long s_wave[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    unsigned long long c[PER], sum = 0;
+    #pragma unroll
+    for (int k = 0; k < PER; k++) { const int sg = tid * PER + k; c[k] = sg < nseg ? (unsigned long long)min(seg_count[sg], seg_cap) : 0ull; sum += c[k]; }
+    unsigned long long incl = sum;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned long long v = __shfl_up(incl, d); incl += (lane >= d) ? v : 0ull; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    unsigned long long at = incl - sum, total = 0;
+    #pragma unroll
+    for (int w = 0; w < 16; w++) { at += (w < wave) ? s_wave[w] : 0ull; total += s_wave[w]; }
+    #pragma unroll
+    for (int k = 0; k < PER; k++) { const int sg = tid * PER + k; if (sg < nseg) first[sg] = at; at += c[k]; }
+    if (tid == 0) first[nseg] = total;
 }
 
 extern "C" __global__ void __launch_bounds__(256) seed_ckeys_kernel(GbnKeyParams K)
@@ -2517,12 +2761,35 @@ int scan_slice_blocks(const GbnScanParams &p, int num_cu)
 // seg: scan_slice_blocks() segments of seg_cap seeds each, seg_count: as many counters; *p.seed_count receives the number
 // of seeds, *seg_max the fullest segment's count (above seg_cap: seeds were dropped, scan again with longer segments).
 // p.seeds is not written: launch_seed_compact puts the segments back to back for whoever wants them in one array
-hipError_t launch_seed_compact(const GbnDevSeed *seg, const uint32_t *seg_count, int nseg, uint32_t seg_cap, GbnDevSeed *out,
-                               unsigned long long out_cap, hipStream_t st)
+hipError_t launch_seed_compact(const GbnDevSeed *seg, const uint32_t *seg_count, unsigned long long *seg_first, int nseg, uint32_t seg_cap,
+                               GbnDevSeed *out, unsigned long long out_cap, hipStream_t st)
 {
     if (nseg <= 0) return hipSuccess;
-    hipLaunchKernelGGL(seed_compact_kernel, dim3((unsigned)(nseg * 8)), dim3(256), 0, st, seg, seg_count, nseg, seg_cap, out, out_cap);
+    if (!seg_first || nseg > GBN_SLICE_SEGS) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(seg_first_kernel, dim3(1), dim3(1024), 0, st, seg_count, nseg, seg_cap, seg_first);
+    hipLaunchKernelGGL(seed_compact_kernel, dim3((unsigned)(nseg * (nseg > 1024 ? 1 : 8))), dim3(256), 0, st, seg, seg_count, seg_first, nseg, seg_cap, out, out_cap);
     return hipGetLastError();
+}
+
+// the form launch_scan_slice takes for this table: 0 a pass per slice, 1 folded, 2 folded with the seeds in scan order
+static int scan_slice_form(const GbnScanParams &p, int nslices)
+{
+    // GBN_SLICE_FOLD=0: a pass over the subjects per slice (the form before the folded filter); GBN_SCAN_ORDERED=0: folded,
+    // seeds in no particular order (the form before the ordered one) -- for comparisons
+    static const bool fold = !(getenv("GBN_SLICE_FOLD") && atoi(getenv("GBN_SLICE_FOLD")) == 0);
+    static const bool ordered = !(getenv("GBN_SCAN_ORDERED") && atoi(getenv("GBN_SCAN_ORDERED")) == 0);
+    if (!(fold && nslices > 1 && p.pvx && p.pstart)) return 0;
+    return ordered ? 2 : 1;
+}
+
+// output segments of launch_scan_slice for this table (one per workgroup, or one per wave with the seeds in scan order:
+// then the segments read one after the other are ordered by subject, scan position, entry -- *ordered says which)
+int scan_slice_segments(const GbnScanParams &p, int num_cu, int *ordered)
+{
+    const int nslices = scan_slice_count(p), blocks = scan_slice_blocks(p, num_cu);
+    const int form = nslices > 0 ? scan_slice_form(p, nslices) : 0;
+    if (ordered) *ordered = form == 2;
+    return form == 2 ? blocks * (GBN_SLICE_THREADS / 64) : blocks;
 }
 
 hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
@@ -2533,10 +2800,14 @@ hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg
     if (nslices <= 0 || blocks <= 0) return hipErrorInvalidValue;
     const int cell_bits = std::min(2 * p.lut, GBN_SLICE_CELL_BITS);
     const size_t lds = ((size_t)GBN_SLICE_WORDS + (size_t)(GBN_SLICE_THREADS / 64) * 3 * GBN_SLICE_QCAP) * 4;
-    static std::atomic<uint64_t> attr_set{0}, attr_set_fold{0};
-    // GBN_SLICE_FOLD=0: a pass over the subjects per slice (the form before the folded filter), for comparisons
-    static const bool fold = !(getenv("GBN_SLICE_FOLD") && atoi(getenv("GBN_SLICE_FOLD")) == 0);
-    if (fold && nslices > 1 && p.pvx && p.pstart) {
+    static std::atomic<uint64_t> attr_set{0}, attr_set_fold{0}, attr_set_ord{0};
+    const int form = scan_slice_form(p, nslices);
+    if (form == 2) {
+        if (hipError_t e = raise_dynamic_lds((const void *)scan_fold_ordered_kernel, lds, attr_set_ord)) return e;
+        hipLaunchKernelGGL(scan_fold_ordered_kernel, dim3((unsigned)blocks), dim3(GBN_SLICE_THREADS), lds, st, p, nslices, cell_bits, seg, seg_cap, seg_count, seg_max);
+        return hipGetLastError();
+    }
+    if (form == 1) {
         if (hipError_t e = raise_dynamic_lds((const void *)scan_fold_kernel, lds, attr_set_fold)) return e;
         hipLaunchKernelGGL(scan_fold_kernel, dim3((unsigned)blocks), dim3(GBN_SLICE_THREADS), lds, st, p, nslices, cell_bits, seg, seg_cap, seg_count, seg_max);
         return hipGetLastError();
@@ -2558,7 +2829,7 @@ hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st)
     if (k.n <= 0) return hipSuccess;
     if (k.nseg > 0) {
         if (!k.seg_first || k.nseg > GBN_SLICE_SEGS) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(seg_first_kernel, dim3(1), dim3(64), 0, st, k.seg_count, k.nseg, k.seg_cap, const_cast<unsigned long long *>(k.seg_first));
+        hipLaunchKernelGGL(seg_first_kernel, dim3(1), dim3(1024), 0, st, k.seg_count, k.nseg, k.seg_cap, const_cast<unsigned long long *>(k.seg_first));
     }
     hipLaunchKernelGGL(seed_ckeys_kernel, dim3((unsigned)std::min<int64_t>((k.n + 255) / 256, 4096)), dim3(256), 0, st, k);
     return hipGetLastError();

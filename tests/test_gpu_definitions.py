@@ -339,16 +339,19 @@ def test_parity_suite_through_the_two_kernel_seed_stage():
     assert " passed" in p.stdout and "failed" not in p.stdout
 
 
-def test_slice_scan_cases_with_a_pass_per_slice():
-    """GBN_SLICE_FOLD=0: tables of more than one slice of presence bits (lut 11, 12 as wide as the word) are scanned a
-    slice per pass (scan_slice_kernel, the form before the folded filter): the blastn cases of the parity suite once more
-    through it, stage by stage against the oracle"""
+def test_slice_scan_cases_in_the_forms_before_the_ordered_one():
+    """Tables of more than one slice of presence bits (lut 11, 12 as wide as the word) are scanned through the folded filter
+    with the seeds in scan order (scan_fold_ordered_kernel).  GBN_SCAN_ORDERED=0: folded, seeds in no particular order
+    (scan_fold_kernel, the full composite-key sort behind it); GBN_SLICE_FOLD=0: a slice per pass (scan_slice_kernel).  The
+    blastn cases of the parity suite once more through each, stage by stage against the oracle -- with the threshold of
+    the composite-key stage at 1 in a third leg, so that the small cases take the shortened sort as well"""
     import os, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ); env["GBN_SLICE_FOLD"] = "0"
-    p = util.run_child([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu and not spawns",
-                        "-k", "slice or lut11_stride1 or word12 or randomised or ragged"], cwd=root, env=env, timeout=900)
-    assert " passed" in p.stdout and "failed" not in p.stdout
+    for setting in ({"GBN_SCAN_ORDERED": "0"}, {"GBN_SLICE_FOLD": "0"}, {"GBN_DIAG_COMPACT_MIN": "1"}):
+        env = dict(os.environ); env.update(setting)
+        p = util.run_child([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "-x", "-q", "-m", "gpu and not spawns",
+                            "-k", "slice or lut11_stride1 or word12 or randomised or ragged"], cwd=root, env=env, timeout=900)
+        assert " passed" in p.stdout and "failed" not in p.stdout, setting
 
 
 def test_parity_cases_with_poisoned_device_blocks():
