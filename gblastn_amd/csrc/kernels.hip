@@ -775,16 +775,19 @@ extern "C" __global__ void seed_keys_kernel(GbnKeyParams K)
 // a handful per million -- by the high bits of the query key, which seed_ext_kernel applies.  The seed follows from
 // key and value (q_pos's low bits = (s_scan - slot) mod slots; value = ext_left | high bits of the query key << 8):
 // no second sort, no gathers of seeds by rank afterwards.
-// (segmented input: the index of every segment's first seed, first[nseg] = their number -- one workgroup, up to
-// GBN_SLICE_SEGS / 1024 consecutive counts per thread)
-extern "C" __global__ void __launch_bounds__(1024) seg_first_kernel(const uint32_t *seg_count, int nseg, uint32_t seg_cap, unsigned long long *first)
+// (segmented input: the index of every segment's first seed, first[nseg] = their number -- one small workgroup, so that it
+// finds room next to the gapped stage of the range before, whose waves fill the CUs: a 1024-thread workgroup waited
+// 0.8 ms for a CU to itself)
+extern "C" __global__ void __launch_bounds__(256) seg_first_kernel(const uint32_t *seg_count, int nseg, uint32_t seg_cap, unsigned long long *first)
 {
-    constexpr int PER = (GBN_SLICE_SEGS + 1023) / 1024;
-    __shared__ unsigned long long s_wave[16];
+    constexpr int PER = (GBN_SLICE_SEGS + 255) / 256;
+    __shared__ unsigned long long s_wave[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    unsigned long long c[PER], sum = 0;
+    uint32_t c[PER]; unsigned long long sum = 0;
     #pragma unroll
-    for (int k = 0; k < PER; k++) { const int sg = tid * PER + k; c[k] = sg < nseg ? (unsigned long long)min(seg_count[sg], seg_cap) : 0ull; sum += c[k]; }
+    for (int k = 0; k < PER; k++) { const int sg = tid * PER + k; c[k] = sg < nseg ? min(seg_count[sg], seg_cap) : 0u; }
+    #pragma unroll
+    for (int k = 0; k < PER; k++) sum += c[k];
     unsigned long long incl = sum;
     #pragma unroll
     for (int d = 1; d < 64; d <<= 1) { const unsigned long long v = __shfl_up(incl, d); incl += (lane >= d) ? v : 0ull; }
@@ -792,7 +795,7 @@ extern "C" __global__ void __launch_bounds__(1024) seg_first_kernel(const uint32
     __syncthreads();
     unsigned long long at = incl - sum, total = 0;
     #pragma unroll
-    for (int w = 0; w < 16; w++) { at += (w < wave) ? s_wave[w] : 0ull; total += s_wave[w]; }
+    for (int w = 0; w < 4; w++) { at += (w < wave) ? s_wave[w] : 0ull; total += s_wave[w]; }
     #pragma unroll
     for (int k = 0; k < PER; k++) { const int sg = tid * PER + k; if (sg < nseg) first[sg] = at; at += c[k]; }
     if (tid == 0) first[nseg] = total;
@@ -2766,7 +2769,7 @@ hipError_t launch_seed_compact(const GbnDevSeed *seg, const uint32_t *seg_count,
 {
     if (nseg <= 0) return hipSuccess;
     if (!seg_first || nseg > GBN_SLICE_SEGS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(seg_first_kernel, dim3(1), dim3(1024), 0, st, seg_count, nseg, seg_cap, seg_first);
+    hipLaunchKernelGGL(seg_first_kernel, dim3(1), dim3(256), 0, st, seg_count, nseg, seg_cap, seg_first);
     hipLaunchKernelGGL(seed_compact_kernel, dim3((unsigned)(nseg * (nseg > 1024 ? 1 : 8))), dim3(256), 0, st, seg, seg_count, seg_first, nseg, seg_cap, out, out_cap);
     return hipGetLastError();
 }
@@ -2829,7 +2832,7 @@ hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st)
     if (k.n <= 0) return hipSuccess;
     if (k.nseg > 0) {
         if (!k.seg_first || k.nseg > GBN_SLICE_SEGS) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(seg_first_kernel, dim3(1), dim3(1024), 0, st, k.seg_count, k.nseg, k.seg_cap, const_cast<unsigned long long *>(k.seg_first));
+        hipLaunchKernelGGL(seg_first_kernel, dim3(1), dim3(256), 0, st, k.seg_count, k.nseg, k.seg_cap, const_cast<unsigned long long *>(k.seg_first));
     }
     hipLaunchKernelGGL(seed_ckeys_kernel, dim3((unsigned)std::min<int64_t>((k.n + 255) / 256, 4096)), dim3(256), 0, st, k);
     return hipGetLastError();
