@@ -1486,7 +1486,7 @@ __device__ __forceinline__ GbnSeedHsp exact_from_windows(const GbnExtParams &P, 
 }
 
 #ifndef GBN_CK_OCC
-#define GBN_CK_OCC 8        // waves per SIMD seed_ext_ck_kernel is compiled for
+#define GBN_CK_OCC 7        // waves per SIMD seed_ext_ck_kernel is compiled for (8: the keys asked for a round ahead do not fit 64 VGPRs and spill)
 #endif
 extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel(GbnExtParams P)
 {
@@ -1521,17 +1521,25 @@ extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel
     const uint32_t gmask = (gb >= 32) ? 0xffffffffu : ((1u << gb) - 1u);
     const int32_t t4 = P.score_table[0], dt = P.score_table[1] - t4;
     GbnSeedExt *__restrict__ rec = reinterpret_cast<GbnSeedExt *>(P.ext_rec);
+    // the keys of a round are asked for a round ahead: everything else a seed loads hangs on its key, and the keys stream
+    // from HBM (the neighbours' keys come from the neighbouring lanes; the two outer lanes read theirs, in one load)
+    auto keys_of = [&](int64_t jb, uint64_t &w0, uint64_t &edge) {
+        const int64_t j = min(jb + lane, j_hi - 1);
+        w0 = P.key_group[j];
+        edge = 0;
+        if (lane == 0 || lane == 63) edge = P.key_group[lane == 0 ? (j > 0 ? j - 1 : 0) : (j + 1 < P.n ? j + 1 : j)];
+    };
+    uint64_t w0n = 0, edgen = 0;
+    if (w * 64 < j_hi) keys_of(w * 64, w0n, edgen);
     for (int64_t jb = w * 64; jb < j_hi; jb += nwaves * 64) {
         const int64_t j = min(jb + lane, j_hi - 1);             // (lanes past the end redo the last seed and store nothing)
         const bool live = jb + lane < j_hi;
         // ---- batch 1: the key and its neighbours
-        // (the neighbours' keys from the neighbouring lanes; the two outer lanes read theirs, in one load)
-        const uint64_t w0 = P.key_group[j];
+        const uint64_t w0 = w0n, edge = edgen;
+        if (jb + nwaves * 64 < j_hi) keys_of(jb + nwaves * 64, w0n, edgen);
         uint64_t wm = __shfl_up(w0, 1), wp = __shfl_down(w0, 1);
-        if (lane == 0 || lane == 63) {
-            const uint64_t edge = P.key_group[lane == 0 ? (j > 0 ? j - 1 : 0) : (j + 1 < P.n ? j + 1 : j)];
-            if (lane == 0) wm = edge; else wp = edge;
-        }
+        if (lane == 0) wm = edge;
+        if (lane == 63) wp = edge;
         const uint64_t key = w0 >> vb;
         const uint32_t val = vb ? (uint32_t)(w0 & vmask) : P.idx[j];
         const uint32_t qk = val >> 8;
