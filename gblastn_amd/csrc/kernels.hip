@@ -1486,7 +1486,7 @@ __device__ __forceinline__ GbnSeedHsp exact_from_windows(const GbnExtParams &P, 
 }
 
 #ifndef GBN_CK_OCC
-#define GBN_CK_OCC 7        // waves per SIMD seed_ext_ck_kernel is compiled for (8: the keys asked for a round ahead do not fit 64 VGPRs and spill)
+#define GBN_CK_OCC 6        // waves per SIMD seed_ext_ck_kernel is compiled for (8, 7: the keys asked for a round ahead do not fit the registers and spill; 6 runs as fast as 7)
 #endif
 extern "C" __global__ void __launch_bounds__(256, GBN_CK_OCC) seed_ext_ck_kernel(GbnExtParams P)
 {
