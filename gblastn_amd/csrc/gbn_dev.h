@@ -29,8 +29,14 @@
 // of bins is a queue of LDS atomics on the same addresses (2 bins: binning 10.5 instead of 8 ms per 50 Gbp),
 // 512 bins where 128 do cost more stream ends and cursors (lut 11: +10 %); never below 128 cells per bin
 #define GBN_BIN_CBITS(lut) ((2 * (lut) - 7) < 7 ? 7 : ((2 * (lut) - 7) > 15 ? 15 : (2 * (lut) - 7)))
-#define GBN_BIN_TABW     (GBN_BIN_CELLS + 4)   // words of the probe kernel's LDS table: the cells + one always-empty cell (+ alignment)
-#define GBN_REC_PAD      0x40000000u  // hi word of a pad record: "cell" GBN_BIN_CELLS, the always-empty one -- needs no special case
+// words of the probe kernel's LDS table: [GBN_BIN_TAB0 - 1] an always-empty cell, [GBN_BIN_TAB0, + cells) the bin's cells,
+// [GBN_BIN_TAB0 + GBN_BIN_CELLS] another always-empty cell.  Records of a table with 2^15 cells per bin carry the lowest
+// bit of their bin number in bit 15 of the hi word (scan_bin3_body): the probe kernel indexes with the low 16 bits and
+// subtracts GBN_REC_PAR(cbits, bin) << 15; a pad record names the empty cell on the far side -- needs no special case
+#define GBN_BIN_TAB0     4
+#define GBN_BIN_TABW     (GBN_BIN_CELLS + 8)
+#define GBN_REC_PAR(cbits, bin) (((cbits) == 15) ? ((uint32_t)(bin) & 1u) : 0u)
+#define GBN_REC_PAD(cbits, bin) (GBN_REC_PAR(cbits, bin) ? 0x00007fffu : 0x00008000u)
 #define GBN_BIN_QCAP     128        // per-wave queue of rare-path items in the probe kernel
 #define GBN_BIN_SIDE     4096       // LDS side-list capacity (u16 fingerprints) per bin
 
@@ -60,7 +66,7 @@ struct GbnBinParams {
     // records = 128 bytes of `hi` words followed by 128 bytes of `posid` words (GBN_REC_HI/POS below).
     // The probe kernel streams the hi lines only and fetches posid for the ~1 % of records that reach
     // the rare path; a run of the binning kernel still lands in one contiguous stretch of memory.
-    //   hi:    bit 30 = pad (GBN_REC_PAD), [29:15] cell inside the bin, [14:0] fp15 of the subject position
+    //   hi:    [30:16] fp15 of the subject position, [15:0] cell inside the bin (bit 15: GBN_REC_PAR; bit 31 undefined)
     //   posid: tile << GBN_BIN_TILE_BITS | index
     uint32_t *rec;
     // 6-byte records: stream cursor of (bin, writer) at the start of its seq-th tile,

@@ -28,24 +28,8 @@
 // Data layout: subjects are NCBI2na (4 bases/byte, base 0 in
 // bits 7..6) back to back in one HBM slab, 16-byte aligned each; the query is
 // one byte per base (BLASTNA) with sentinel padding on both sides.
-#include <hip/hip_runtime.h>
-#include <stdint.h>
-#include <algorithm>
-#include <atomic>
-#include "gbn_dev.h"
+#include "scan_dev.hpp"
 
-// Function attributes belong to the (kernel, device) pair: one bit per device, set on the first launch there.
-static hipError_t raise_dynamic_lds(const void *fn, size_t lds, std::atomic<uint64_t> &done)
-{
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    const uint64_t bit = 1ull << (dev & 63);
-    if (done.load(std::memory_order_acquire) & bit) return hipSuccess;
-    e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e == hipSuccess) done.fetch_or(bit, std::memory_order_release);
-    return e;
-}
 #ifndef GBN_DIAG_ABL
 #define GBN_DIAG_ABL 0      // timing experiments only (1: no ungapped extension, 2: no strand search): wrong results
 #endif
@@ -55,132 +39,7 @@ static hipError_t raise_dynamic_lds(const void *fn, size_t lds, std::atomic<uint
 #ifndef GBN_EXT_ABL
 #define GBN_EXT_ABL 0       // timing experiments only (seed_ext_kernel), bits: 1 no exact pass, 2 no extension, 4 no reservation of run heads, 8 no context lookup, 16 no record store: wrong results
 #endif
-#ifndef GBN_PROBE_U
-#define GBN_PROBE_U 2        // 16-byte loads per lane and round of the probe kernel (4 records each)
-#endif
-// stream of (bin, writer): writer-major keeps the 512 streams a binning workgroup appends to
-// inside one ~100 MB stretch instead of spreading them over the whole buffer
-#define GBN_STREAM(B, bin, writer) ((size_t)(writer) * (B).nb + (bin))
-// linear index of record j of stream (bin, writer)
-#define GBN_RECIDX(B, bin, writer, j) (GBN_STREAM(B, bin, writer) * (B).subcap + (size_t)(j))
-#ifndef GBN_BIN_OCC
-#define GBN_BIN_OCC 4       // waves per SIMD the binning kernel is compiled for
-#endif
 
-namespace {
-
-__device__ __forceinline__ uint32_t bswap32(uint32_t x) { return __builtin_bswap32(x); }
-
-// base `pos` of a packed sequence
-__device__ __forceinline__ int base_at(const uint8_t *__restrict__ p, int64_t pos) {
-    return (p[pos >> 2] >> (2 * (3 - (int)(pos & 3)))) & 3;
-}
-
-// 16 consecutive bases starting at base index `pos` (may be negative relative
-// to `p`; the slab is padded) as a big-endian 32-bit word: base pos in bits 31..30
-__device__ __forceinline__ uint32_t window16(const uint8_t *__restrict__ p, int64_t pos) {
-    int64_t w = pos >> 4;                       // dword index (floor)
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + w;
-    uint32_t hi = bswap32(d[0]), lo = bswap32(d[1]);
-    int sh = 2 * (int)(pos & 15);
-    return sh ? ((hi << sh) | (lo >> (32 - sh))) : hi;
-}
-
-// 32 consecutive bases of a 2-bit packed sequence starting at base index `pos` (may be negative:
-// both the subject slab and the packed query carry padding in front), big-endian in 64 bits
-__device__ __forceinline__ uint64_t bases32(const uint8_t *__restrict__ p, int64_t pos) {
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + (pos >> 4);
-    const uint64_t hi = ((uint64_t)bswap32(d[0]) << 32) | bswap32(d[1]);
-    const uint32_t lo = bswap32(d[2]);
-    const int sh = 2 * (int)(pos & 15);
-    return sh ? ((hi << sh) | ((uint64_t)lo >> (32 - sh))) : hi;
-}
-// 32 consecutive bits of a bitmap (most significant bit first) starting at bit index `pos`
-__device__ __forceinline__ uint32_t bits32(const uint8_t *__restrict__ p, int64_t pos) {
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(p) + (pos >> 5);
-    const uint32_t hi = bswap32(d[0]), lo = bswap32(d[1]);
-    const int sh = (int)(pos & 31);
-    return sh ? ((hi << sh) | (lo >> (32 - sh))) : hi;
-}
-
-// ---------------------------------------------------------------------------
-// exact verification of one lookup hit to word_size; returns ext_left or -1
-// ---------------------------------------------------------------------------
-__device__ int verify_hit(const GbnScanParams &P, const uint8_t *__restrict__ subj, int32_t slen,
-                          int32_t q_off, int32_t s_off)
-{
-    const uint8_t *q = P.q8;
-    const int word = P.word, lut = P.lut, ext_to = word - lut;
-    if (P.mode == GBN_EXT_DIRECT) return 0;
-    if (P.mode == GBN_EXT_NA) {
-        // s_BlastNaExtend: sentinel bytes never equal a 2-bit base
-        int ext_left = 0, ext_max = min(ext_to, s_off);
-        for (; ext_left < ext_max; ++ext_left)
-            if (base_at(subj, s_off - ext_left - 1) != q[q_off - ext_left - 1]) break;
-        if (ext_left < ext_to) {
-            int need = ext_to - ext_left, so = s_off + lut, r = 0;
-            if (so + need > slen) return -1;
-            for (; r < need; ++r)
-                if (base_at(subj, so + r) != q[q_off + lut + r]) break;
-            if (ext_left + r < ext_to) return -1;
-        }
-        return ext_left;
-    }
-    // small-query tables compare (code & 3) and clamp at the strand boundaries
-    int lo = 0, hi = P.nctx;
-    while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > q_off) hi = m; else lo = m; }
-    const int q_start = P.ctx_off[lo], q_range = q_start + P.ctx_len[lo];
-    if (P.mode == GBN_EXT_SMALL) {
-        int ext_max = min(min(ext_to, s_off), q_off - q_start);
-        int rsdl = 4 - (s_off & 3);
-        int so = s_off + rsdl, qo = q_off + rsdl, ext_left = 0, ext_right = 0;
-        ext_max += rsdl;
-        while (ext_left < ext_max && (q[qo - ext_left - 1] & 3) == base_at(subj, so - ext_left - 1)) ext_left++;
-        ext_max = min(min(word - ext_left, slen - so), q_range - qo);
-        while (ext_right < ext_max && (q[qo + ext_right] & 3) == base_at(subj, so + ext_right)) ext_right++;
-        if (ext_left + ext_right < word) return -1;
-        return ext_left - rsdl;
-    }
-    // GBN_EXT_SMALL_ONEBYTE (s_BlastSmallNaExtendAlignedOneByte)
-    {
-        int ext_left = 0;
-        if (s_off > 0 && q_off > 0) {
-            int k = 0;
-            while (k < 4 && (q[q_off - k - 1] & 3) == base_at(subj, s_off - k - 1)) k++;
-            ext_left = min(min(k, ext_to), q_off - q_start);
-        }
-        if (ext_left < ext_to && (q_off + lut) < P.qlen) {
-            int k = 0, so = s_off + lut, qo = q_off + lut;
-            while (k < 4) {
-                int qb = (qo + k < P.qlen) ? (q[qo + k] & 3) : 0;
-                if (qb != base_at(subj, so + k)) break;
-                k++;
-            }
-            int ext_right = min(min(k, slen - so), q_range - qo);
-            if (ext_left + ext_right < ext_to) return -1;
-        }
-        return ext_left;
-    }
-}
-
-// fingerprint test: a seed that verifies must match the `fl` query bases left
-// of the lookup word or the `fr` bases right of it
-__device__ __forceinline__ bool fp_pass(uint32_t fp, uint32_t s_left16, uint32_t s_right16, int fl, int fr)
-{
-    // fp bits [30:15] = 8 bases left of the word (base q-1 in the low pair),
-    //    bits [14:1]  = 7 bases right of the word (base q+lut in the high pair)
-    if (fp & 1u) return true;                   // forced (see upload: one-byte quirk entries)
-    uint32_t ql = (fp >> 15) & 0xffffu;
-    uint32_t qr = (fp >> 1) & 0x3fffu;
-    uint32_t lmask = (fl >= 8) ? 0xffffu : ((1u << (2 * fl)) - 1);
-    bool left = fl > 0 ? (((ql ^ s_left16) & lmask) == 0) : true;
-    uint32_t sr = s_right16 >> 18;              // top 7 bases
-    uint32_t rmask = (fr >= 7) ? 0x3fffu : (((1u << (2 * fr)) - 1) << (2 * (7 - fr)));
-    bool right = fr > 0 ? (((qr ^ sr) & rmask) == 0) : true;
-    return left || right;
-}
-
-}  // namespace
 
 // ---------------------------------------------------------------------------
 // Scan + seed kernel.
@@ -2971,696 +2830,3 @@ hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uin
 
 }  // namespace gbn
 
-// ===========================================================================
-// Key-range partitioned scan (lookup tables too large for L2).
-//
-// Direct probing costs one L2 request per scan position for the presence bit
-// (2.9e9 per 50 Gbp pass: the L2 request rate, not HBM, is the wall) plus one
-// 64-byte HBM sector per present word.  Here phase 1 touches no table at all:
-// it streams the subject once and writes every scan position as a 6-byte
-// record {cell inside the bin + 15 neighbouring subject bits, 16-bit index} into
-// the stream of (bin given by the top bits of its lookup word, workgroup), in
-// complete aligned pieces.  Phase 2 walks bin by bin with the bin's cell table
-// resident in LDS (one workgroup per CU, all workgroups with the same
-// blockIdx & 7 -- observed to share an XCD and its L2 -- on the same bin).
-// Only ~0.7 % of the records (fingerprint survivors and cells with >= 3 entries)
-// leave LDS, through per-workgroup queues, for phase 3 (exact verification).
-// ===========================================================================
-
-// ---------------------------------------------------------------------------------------------------
-// Binning kernel, line-exact.  Measured on MI355X: the same bytes cost 3-4x more when a stream's lines are
-// written in pieces by consecutive tiles (partial-line writes) than when every store completes whole, aligned
-// 64-byte pieces.  So each workgroup keeps, per bin, one "open line" of 16 records in LDS and only ever
-// stores complete lines: 64 bytes of `hi` words, aligned, with their 32 bytes of indices; no pad records
-// exist except in the last line of a stream.  Records sit in LDS as 8-byte {hi, index} pairs; the scatter
-// fills a bin's open line first and puts the rest into the bin-sorted staging area, so every complete line
-// is 16 consecutive LDS records -- the open line or a run of the staging area.  64 KB staging (8192-position
-// tiles) + 64 KB open lines.
-//
-// Round 2: the kernel is bound by VALU issue and by LDS round-trip latency, not by LDS throughput (a
-// returning LDS atomic costs ~3 cycles per wave-instruction with 16 waves issuing, tools/lds_microbench.hip;
-// the round-1 build waited for every bin descriptor before the next record's branchy slot computation, ran
-// the bin scan through six dependent ds_bpermute round trips and followed three dependent LDS reads per
-// stored line).  Now: four barriers per tile instead of five, every group of LDS reads issued back to back,
-// the prefix sums over the bins with DPP row shifts, one 8-byte descriptor per complete line, per-bin
-// stream state in the owner thread's registers, lookup width a compile-time constant in the specialised
-// variants:
-//   [0] histogram atomics of tile t (rank inside the bin), requests for the bytes of t+1
-//   (A)
-//   [1] owner thread of a bin: records + open line -> complete lines, wave-level DPP scan
-//   (B0)
-//   [2] owner: staging offset, scatter descriptor, one descriptor per complete line, cursor
-//   (B)
-//   [3] the records of t-1 that waited in registers move into the (now stored) open lines; scatter of t into
-//       open lines / staging -- records past a bin's last complete line wait in registers in turn
-//   (C)
-//   [4] keys of t+1, then stores of the complete lines of t
-// The tile of a record is not stored: every 8th tile leaves a cursor (stream index of its first record) per
-// bin, and the low 3 bits of the tile's sequence number ride in the spare top bits of the 16-bit index.
-namespace {
-// inclusive prefix sum over the 64 lanes of a fully active wave: DPP row shifts and row broadcasts
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);     // row_shr:4, lanes 4.. of a row
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);     // row_shr:8, lanes 8.. of a row
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
-    return v;
-}
-}  // namespace
-
-template <int STEP, int LUT>
-__device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
-{
-    const GbnScanParams &P = B.S;
-    constexpr int TILE = GBN_BIN_TILE_POS, PER = TILE / GBN_SORT_THREADS, LINE = GBN_OPEN_LINE, LP = LINE / 4;    // LP lanes store one line
-    constexpr int STAGE = GBN_BIN_STAGE;
-    static_assert(PER == 8 && GBN_SORT_THREADS == 1024 && LINE == 32, "8192-position tiles, 1024 threads, 32-record lines");
-    static_assert(GBN_BIN_MAXNB <= GBN_SORT_THREADS, "one owner thread per bin");
-    // records in LDS: hi word and 16-bit index in the tile, in two arrays with the same slot numbers.
-    // [0, STAGE): staging, bin-sorted (the lines a bin completes beyond its first one in a tile: rare with 512
-    // bins, the rule with 128); [STAGE, STAGE + bins * LINE): one line under construction per bin
-    __shared__ __attribute__((aligned(16))) uint32_t s_hi[STAGE + GBN_BIN_MAXNB * LINE];
-    __shared__ __attribute__((aligned(16))) uint16_t s_ix[STAGE + GBN_BIN_MAXNB * LINE];
-    __shared__ uint32_t s_hist[GBN_BIN_MAXNB];
-    __shared__ uint32_t s_wtot[GBN_BIN_MAXNB / 64];
-    // scatter descriptor of a bin (r = rank of a record among the tile's records of the bin):
-    //   .x [15:0]  slot of r = 0 while the open line has room     [31:16] the same for the staging area (signed)
-    //   .y [15:0]  first r that lies past the bin's last complete line (0xffff: none)   [31:16] room in the open line
-    __shared__ uint2 s_pk[GBN_BIN_MAXNB];
-    __shared__ uint2 s_line[TILE / LINE + GBN_BIN_MAXNB];     // complete line of this tile: .x = stream line (32 records) it becomes, .y = its first LDS slot
-    __shared__ uint32_t s_nlines;
-    const int tid = threadIdx.x;
-    const int lut = LUT > 0 ? LUT : P.lut;
-    const uint32_t mask = LUT > 0 ? (uint32_t)((1ull << (2 * LUT)) - 1) : (uint32_t)(P.ncells - 1);
-    const int cbits = LUT > 0 ? GBN_BIN_CBITS(LUT) : B.cbits;
-    const int nb = LUT > 0 ? (int)(((int64_t)1 << (2 * LUT)) >> GBN_BIN_CBITS(LUT)) : B.nb;
-    const uint32_t lowmask = (1u << cbits) - 1;
-    const int cshift = 56 - 2 * lut, rshift = 49 - 2 * lut;
-    const uint32_t ustep = (uint32_t)P.step;
-    const int64_t stride = gridDim.x, last = P.ntiles - 1;
-    const uint32_t wid = blockIdx.x;
-
-    // a lane owns PER consecutive positions = 16 * STEP bits of subject: a whole number of dwords for
-    // even strides, half a dword extra for odd lanes of odd strides (the raw dwords are then shifted by
-    // 16 bits first, after which every window is cut out with compile-time shifts as before)
-    constexpr int NDW = STEP > 0 ? ((2 * STEP * (PER - 1) - 8 + 38) >> 5) + 4 : 2 * PER;
-    struct Raw { uint32_t d[NDW]; };
-    auto idx_of = [&](int k) -> uint32_t { return STEP > 0 ? (uint32_t)(tid * PER + k) : (uint32_t)(tid + k * GBN_SORT_THREADS); };
-    auto upos_of = [&](const GbnTile &t, int k) -> uint32_t {
-        const uint32_t i = min(idx_of(k), (uint32_t)t.npos - 1u);
-        return (uint32_t)t.first_pos + i * ustep + 60u;
-    };
-    auto lane_half = [&](const GbnTile &t) -> uint32_t {    // lane's first base, in units of 8 bases (16 bits), from the tile start
-        return min((uint32_t)tid, ((uint32_t)t.npos - 1u) / PER) * (uint32_t)STEP;
-    };
-    auto fetch = [&](const GbnTile &t, Raw &r) {
-        if constexpr (STEP > 0) {
-            const uint8_t *p = P.db + ((size_t)(uint32_t)t.off16 << 4) + 4 * ((size_t)((uint32_t)t.first_pos >> 4) + (size_t)(lane_half(t) >> 1)) - 4;
-            #pragma unroll
-            for (int i = 0; i + 4 <= NDW; i += 4) __builtin_memcpy(&r.d[i], p + 4 * i, 16);
-            if constexpr (NDW % 4 == 3) { __builtin_memcpy(&r.d[NDW - 3], p + 4 * (NDW - 3), 12); }
-            else if constexpr (NDW % 4 == 2) { __builtin_memcpy(&r.d[NDW - 2], p + 4 * (NDW - 2), 8); }
-            else if constexpr (NDW % 4 == 1) { __builtin_memcpy(&r.d[NDW - 1], p + 4 * (NDW - 1), 4); }
-        } else {
-            #pragma unroll
-            for (int k = 0; k < PER; k++)
-                __builtin_memcpy(&r.d[2 * k], P.db + ((size_t)(uint32_t)t.off16 << 4) - 16 + (upos_of(t, k) >> 2), 8);
-        }
-    };
-    auto keys_all = [&](const GbnTile &t, const Raw &r, uint32_t (&bin)[PER], uint32_t (&hi)[PER]) {
-        uint32_t x[NDW];
-        if constexpr (STEP > 0) {
-            #pragma unroll
-            for (int i = 0; i < NDW; i++) x[i] = bswap32(r.d[i]);
-            if ((STEP & 1) && (lane_half(t) & 1u)) {
-                #pragma unroll
-                for (int i = 0; i + 1 < NDW; i++) x[i] = (x[i] << 16) | (x[i + 1] >> 16);
-            }
-        }
-        #pragma unroll
-        for (int k = 0; k < PER; k++) {
-            uint64_t w;
-            if constexpr (STEP > 0) {
-                const int bit = 2 * STEP * k - 8 + 32, a = bit >> 5, o = bit & 31;
-                const uint32_t x2 = x[a + 2 < NDW ? a + 2 : NDW - 1];
-                const uint32_t hi32 = o ? ((x[a] << o) | (x[a + 1] >> (32 - o))) : x[a];
-                const uint32_t lo32 = o ? ((x[a + 1] << o) | (x2 >> (32 - o))) : x[a + 1];
-                w = ((uint64_t)hi32 << 32) | lo32;
-            } else {
-                uint64_t raw; __builtin_memcpy(&raw, &r.d[2 * k], 8);
-                w = __builtin_bswap64(raw) << (2 * (upos_of(t, k) & 3));
-            }
-            const uint32_t c = (uint32_t)(w >> cshift) & mask;
-            bin[k] = c >> cbits;
-            hi[k] = ((c & lowmask) << 15) | (((uint32_t)(w >> rshift) & 0x7fu) << 8) | (uint32_t)(w >> 56);
-        }
-    };
-    auto uniform = [](GbnTile t) -> GbnTile {
-        t.subj = __builtin_amdgcn_readfirstlane(t.subj); t.first_pos = __builtin_amdgcn_readfirstlane(t.first_pos);
-        t.npos = __builtin_amdgcn_readfirstlane(t.npos); t.off16 = __builtin_amdgcn_readfirstlane(t.off16);
-        return t;
-    };
-    // an eighth of a line (4 records: 16 bytes of hi words, 8 bytes of indices) from LDS slot `src` to stream line
-    // `dl`: the 8 lanes of a line write 128 aligned bytes of hi words and 64 of indices -- scattered writes cost
-    // by the piece below 128 bytes (tools/write_microbench.hip: 64 + 32 byte pieces 3.5 TB/s, 128 + 64: 6+)
-    uint32_t *const rec32 = B.rec; uint16_t *const rec16 = reinterpret_cast<uint16_t *>(B.rec);
-    auto store_part = [&](uint32_t dl, uint32_t p, uint32_t src) {
-        const uint4 h = *reinterpret_cast<const uint4 *>(&s_hi[src]);
-        const uint2 x = *reinterpret_cast<const uint2 *>(&s_ix[src]);
-        // = GBN_REC_HI / GBN_REC_IDX16 of record dl * 32 + p * 4 (blocks of 64 records: 64 hi words, 64 indices)
-        const size_t blk = (size_t)(dl >> 1) * 96, in = (size_t)((dl & 1u) * 32u + p * 4u);
-        if (!(GBN_BIN_ABL & 4)) *reinterpret_cast<uint4 *>(rec32 + blk + in) = h;
-        if (!(GBN_BIN_ABL & 8)) *reinterpret_cast<uint2 *>(rec16 + (blk + 64) * 2 + in) = x;
-    };
-
-    if (tid < GBN_BIN_MAXNB) s_hist[tid] = 0;
-    // Tile of (writer w, round k) = k * writers + (w + k) mod writers: the rotation keeps tiles of one kind
-    // (the short last tile of every subject, when the tiles per subject divide the grid) from always
-    // landing on the same workgroups (GBN_TILE_OF in gbn_dev.h; the rare kernel inverts it).
-    uint32_t rot = wid;                                          // (wid + seq) mod stride
-    auto rot_next = [&](uint32_t r) -> uint32_t { return r + 1u == (uint32_t)stride ? 0u : r + 1u; };
-    int64_t tile = blockIdx.x;
-    if (tile > last) {
-        for (int b = tid; b < nb; b += GBN_SORT_THREADS) B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0;
-        return;
-    }
-    // owner thread of bin `tid`: its stream's state lives in registers
-    uint32_t wpos = 0, cc = 0;                                  // records stored so far (multiple of LINE), records in the open line (< LINE)
-    const uint32_t sline0 = (uint32_t)((GBN_STREAM(B, (tid < nb ? tid : 0), wid) * (size_t)B.subcap) >> 5);    // first line of the stream (subcap is a multiple of 512)
-    const uint32_t open0 = (uint32_t)(STAGE + tid * LINE);      // the bin's open line
-    uint32_t *const tcur = B.tcur + ((size_t)(tid < nb ? tid : 0) * B.nwriters + wid) * B.nseq;
-
-    GbnTile T = uniform(P.tiles[tile]);
-    GbnTile T1 = uniform(P.tiles[min(stride + (int64_t)rot_next(rot), last)]);
-    uint32_t bin[PER], hi[PER];
-    {
-        Raw r0; fetch(T, r0);
-        keys_all(T, r0, bin, hi);
-    }
-    int32_t stay[PER];                                          // slot of a record that waits for its open line to be stored, else -1
-    uint32_t keep_hi[PER];
-    #pragma unroll
-    for (int k = 0; k < PER; k++) { stay[k] = -1; keep_hi[k] = 0; }
-    __syncthreads();
-
-#if GBN_BIN_TIMING   // phase timer of workgroup 0 (tools/build_variant.sh t "-DGBN_BIN_TIMING=1", GBN_DBG=32)
-    const bool timed = blockIdx.x == 0 && tid == 0;
-    const unsigned long long wg_t0 = __builtin_amdgcn_s_memrealtime();
-    unsigned long long tph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tprev = __builtin_readcyclecounter();
-#define GBN_LAP2(ph) do { if (timed) { const unsigned long long t_ = __builtin_readcyclecounter(); tph[ph] += t_ - tprev; tprev = t_; } } while (0)
-#else
-#define GBN_LAP2(ph) do { } while (0)
-#endif
-    uint32_t ntask = 0;                                         // quarter lines of the tile before (for late_stores)
-    auto late_stores = [&]() {
-        const uint32_t i = (uint32_t)tid + GBN_SORT_THREADS;
-        if (i < ntask && !(GBN_BIN_ABL & 2)) {
-            const uint2 d = s_line[i / LP];
-            if (d.y != 0xffffffffu) store_part(d.x, i % LP, d.y + (i % LP) * 4);
-        }
-    };
-    uint32_t seq = 0;
-    for (; tile <= last; ++seq, rot = rot_next(rot), tile = (int64_t)seq * stride + rot) {
-        // ---- [0] rank of every record inside its bin; the bytes of the next tile ----
-        uint32_t rank[PER]; bool valid[PER];
-        #pragma unroll
-        for (int k = 0; k < PER; k++) valid[k] = idx_of(k) < (uint32_t)T.npos;
-        #pragma unroll
-        for (int k = 0; k < PER; k++) {     // (positions past the end of a partial tile all carry the same key: they must not touch the histogram)
-            rank[k] = 0;
-            if (valid[k]) rank[k] = atomicAdd(&s_hist[bin[k]], 1u);
-        }
-        Raw R;
-        if constexpr (STEP > 0) fetch(T1, R);
-        GbnTile T2 = P.tiles[min((int64_t)(seq + 2) * stride + (int64_t)rot_next(rot_next(rot)), last)];
-        late_stores();                                          // second quarter-line round of the previous tile
-        GBN_LAP2(0);
-        __syncthreads();                                        // (A) histogram complete
-        GBN_LAP2(1);
-        // ---- [1] + [2] owner threads: complete lines, staging offsets (both sums in one word: records
-        // that go to the staging area < 2^14, complete lines < 2^10), descriptors ----
-        uint32_t v = 0, incl = 0, my_nl = 0, my_cc = 0, tot = 0;
-        if (tid < GBN_BIN_MAXNB) {
-            if (tid < nb) {
-                tot = cc + s_hist[tid];
-                my_nl = tot / LINE; my_cc = tot & (LINE - 1);
-                // staging: the complete lines after the bin's first one
-                v = (my_nl > 1 ? (my_nl - 1) * LINE : 0u) | (my_nl << 16);
-            }
-            incl = wave_scan_incl(v);
-            if ((tid & 63) == 63) s_wtot[tid >> 6] = incl;
-        }
-        GBN_LAP2(2);
-        __syncthreads();                                        // (B0) wave totals
-        GBN_LAP2(3);
-        if (tid < nb) {
-            uint32_t run = incl - v;
-            #pragma unroll
-            for (int w = 0; w < GBN_BIN_MAXNB / 64 - 1; w++) run += (tid >> 6) > w ? s_wtot[w] : 0u;
-            const uint32_t off = run & 0xffffu, l0 = run >> 16;
-            const uint32_t first_past = my_nl ? my_nl * LINE - cc : 0xffffu;
-            s_pk[tid] = make_uint2((open0 + cc) | ((off + cc - LINE) << 16), first_past | ((LINE - cc) << 16));
-            if ((seq & 7u) == 0) tcur[seq >> 3] = wpos + cc;    // stream index of this tile's first record
-            if (wpos + my_nl * LINE > B.subcap) atomicOr(B.overflow, 1u);
-            for (uint32_t l = 0; l < my_nl; l++) {
-                const bool fits = wpos + (l + 1) * LINE <= B.subcap;
-                s_line[l0 + l] = make_uint2(sline0 + (wpos >> 5) + l, fits ? (l == 0 ? open0 : off + (l - 1) * LINE) : 0xffffffffu);
-            }
-            if (tid == nb - 1) s_nlines = l0 + my_nl;
-            wpos += my_nl * LINE; cc = my_cc;
-            s_hist[tid] = 0;                                    // for the next tile: its atomics come after (C)
-        }
-        GBN_LAP2(4);
-        __syncthreads();                                        // (B) descriptors known
-        GBN_LAP2(5);
-        // ---- [3] scatter ----
-        {
-            uint2 pk[PER];
-            #pragma unroll
-            for (int k = 0; k < PER; k++) pk[k] = s_pk[bin[k]];
-            // the records of the previous tile that waited: their open lines were stored in that tile's [4]
-            #pragma unroll
-            for (int k = 0; k < PER; k++)
-                if (stay[k] >= 0) { s_hi[stay[k]] = keep_hi[k]; s_ix[stay[k]] = (uint16_t)(idx_of(k) | (((seq - 1u) & 7u) << 13)); }
-            #pragma unroll
-            for (int k = 0; k < PER; k++) {
-                const uint32_t r = rank[k];
-                const uint32_t open_at = pk[k].x & 0xffffu, room = pk[k].y >> 16, past = pk[k].y & 0xffffu;
-                const int32_t stage_at = (int32_t)pk[k].x >> 16;
-                // the bin's open line first, then the staging area; what lies past the last complete line
-                // waits in registers until the open line has been stored
-                const uint32_t slot = (r < room ? open_at : (uint32_t)stage_at) + r;
-                const bool waits = valid[k] && r >= past;
-                stay[k] = waits ? (int32_t)((uint32_t)STAGE + bin[k] * LINE + (r - past)) : -1;
-                keep_hi[k] = hi[k];
-                if (valid[k] && !waits) {
-                    s_hi[slot] = hi[k]; s_ix[slot] = (uint16_t)(idx_of(k) | ((seq & 7u) << 13));
-                }
-            }
-        }
-        GBN_LAP2(6);
-        __syncthreads();                                        // (C) open lines and staging filled
-        // ---- [4] keys of t+1 before the stores: the wait for the loads of t+1 counts every outstanding
-        // memory operation and would otherwise sit behind this tile's stores ----
-        T = T1; T1 = uniform(T2);
-        if constexpr (STEP == 0) fetch(T, R);
-        keys_all(T, R, bin, hi);
-        // Stores of the complete lines, a quarter line per thread and step.  The first 1024 quarter lines leave
-        // here; the next 1024 wait until [0] of the next tile (behind its loads, next to its atomics: spreading
-        // the stores over the tile keeps the store queue from stalling every wave at once); the rare rest here.
-        ntask = s_nlines * (uint32_t)LP;
-        if (!(GBN_BIN_ABL & 2))
-        for (uint32_t i = tid; i < ntask; i += (i == (uint32_t)tid ? 2u : 1u) * GBN_SORT_THREADS) {
-            const uint2 d = s_line[i / LP];
-            if (d.y == 0xffffffffu) continue;
-            store_part(d.x, i % LP, d.y + (i % LP) * 4);
-        }
-        // (no barrier here: the open lines just read are next written in [3] of the next tile, after (A)..(B))
-    }
-#if GBN_BIN_TIMING
-    if (timed) for (int i = 0; i < 8; i++) B.rare_counts[512 + i] = (uint32_t)(tph[i] >> 4);
-    if (tid == 0 && blockIdx.x < 512) {     // wall clock (100 MHz) of every workgroup: start, duration
-        B.rare_counts[1024 + blockIdx.x] = (uint32_t)wg_t0;
-        B.rare_counts[1536 + blockIdx.x] = (uint32_t)(__builtin_amdgcn_s_memrealtime() - wg_t0);
-    }
-#endif
-    late_stores();
-    __syncthreads();
-    // the records of the last tile that waited
-    #pragma unroll
-    for (int k = 0; k < PER; k++)
-        if (stay[k] >= 0) { s_hi[stay[k]] = keep_hi[k]; s_ix[stay[k]] = (uint16_t)(idx_of(k) | (((seq - 1u) & 7u) << 13)); }
-    uint2 *const s_fin = s_pk;                                  // at the end: records stored, records in the open line
-    if (tid < nb) s_fin[tid] = make_uint2(wpos, cc);
-    __syncthreads();
-    // the last, incomplete line of every stream: padded with flagged records
-    for (uint32_t i = tid; i < (uint32_t)nb * LINE; i += GBN_SORT_THREADS) {
-        const uint32_t b = i / LINE, sl = i % LINE;
-        if (sl >= s_fin[b].y) { s_hi[STAGE + b * LINE + sl] = GBN_REC_PAD; s_ix[STAGE + b * LINE + sl] = 0xffffu; }
-    }
-    __syncthreads();
-    for (uint32_t i = tid; i < (uint32_t)nb * LP; i += GBN_SORT_THREADS) {
-        const uint32_t b = i / LP, p = i % LP;
-        const uint2 f = s_fin[b];
-        if (f.y && f.x + LINE <= B.subcap && !(GBN_BIN_ABL & 2))
-            store_part((uint32_t)((GBN_STREAM(B, b, wid) * (size_t)B.subcap + f.x) >> 5), p, STAGE + b * LINE + p * 4);
-    }
-    for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
-        const uint2 f = s_fin[b];
-        const uint32_t total = f.x + (f.y ? LINE : 0u);
-        if (total > B.subcap) atomicOr(B.overflow, 1u);
-        B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(total, B.subcap);
-    }
-}
-
-// stride- and width-specialised variants: megablast (word 28: lut 12 / 11 / 8) and blastn (word 11: lut 11 / 10 / 8);
-// every other (stride, lut) pair takes the generic kernel
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel(GbnBinParams B) { scan_bin_line_body<0, 0>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s17(GbnBinParams B) { scan_bin_line_body<17, 12>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s18(GbnBinParams B) { scan_bin_line_body<18, 11>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s1(GbnBinParams B) { scan_bin_line_body<1, 11>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s2(GbnBinParams B) { scan_bin_line_body<2, 10>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s4(GbnBinParams B) { scan_bin_line_body<4, 8>(B); }
-extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s21(GbnBinParams B) { scan_bin_line_body<21, 8>(B); }
-
-namespace {
-// rare path of the probe kernel: full fingerprints, chain walk, exact verification
-// Seeds go to P.seeds through one wave-aggregated reservation per loop round, or -- when the caller passes
-// an LDS staging buffer (`s_buf`, `s_n`, capacity `cap`) -- are collected there first and flushed by the
-// whole workgroup (dense-seed shapes: a single counter takes only ~90 reservations per microsecond).
-__device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell, bool count_raw,
-                           unsigned long long &raw, GbnDevSeed *s_buf = nullptr, uint32_t *s_n = nullptr, uint32_t cap = 0)
-{
-    const uint32_t start = P.cell_start[cell], end = P.cell_start[cell + 1];
-    if (count_raw) raw += end - start;
-    const GbnTile T = P.tiles[posid >> GBN_BIN_TILE_BITS];
-    const int32_t s = T.first_pos + (int32_t)(posid & (uint32_t)(GBN_BIN_TILE_POS - 1)) * P.step;
-    const uint8_t *__restrict__ subj = P.db + ((size_t)(uint32_t)T.off16 << 4);     // = byte_off[T.subj], one load less
-    // one 32-base window from s - 8 holds the 8 bases left of the word and (lut <= 16) at least 8 right of it
-    const uint64_t w32 = (P.fl > 0 || P.fr > 0) ? bases32(subj, (int64_t)s - 8) : 0ull;     // lut == word: nothing to compare
-    const uint32_t sl = (uint32_t)(w32 >> 48);
-    const uint32_t sr = (uint32_t)((w32 << (2 * (8 + P.lut))) >> 32);
-    for (uint32_t e = start; e < end; e++) {
-        const unsigned long long ent = P.ent[e];
-        if (!fp_pass((uint32_t)(ent >> 32), sl, sr, P.fl, P.fr)) continue;
-        const int32_t slen = (P.mode == GBN_EXT_DIRECT) ? 0 : P.len[T.subj];
-        const int32_t q = (int32_t)(ent & 0xffffffffu);
-        const int el = verify_hit(P, subj, slen, q, s);
-        // one reservation per wave and round: the lanes still in this loop that verified a hit
-        const unsigned long long okm = __ballot(el >= 0);
-        if (okm) {
-            const int lane = (int)(threadIdx.x & 63), leader = __ffsll((long long)okm) - 1;
-            const uint32_t mine = (uint32_t)__popcll(okm & ((1ull << lane) - 1)), cnt = (uint32_t)__popcll(okm);
-            GbnDevSeed sd; sd.subj = T.subj; sd.s_scan = s; sd.q_pos = q; sd.ext_left = el;
-            // staging: the wave's seeds take slots [lbase, lbase + cnt); whatever falls past the capacity
-            // goes straight to the global array, so the staged part never has holes
-            uint32_t lbase = cap;
-            if (s_buf) {
-                if (lane == leader) lbase = atomicAdd(s_n, cnt);
-                lbase = min(__shfl(lbase, leader), cap);
-            }
-            const uint32_t staged_n = min(cnt, cap - lbase);
-            if (el >= 0 && mine < staged_n) s_buf[lbase + mine] = sd;
-            if (staged_n < cnt) {
-                unsigned long long base = 0;
-                if (lane == leader) base = atomicAdd(P.seed_count, (unsigned long long)(cnt - staged_n));
-                base = __shfl(base, leader);
-                if (el >= 0 && mine >= staged_n) { const unsigned long long o = base + (mine - staged_n); if (o < P.seed_cap) P.seeds[o] = sd; }
-            }
-        }
-    }
-}
-}  // namespace
-
-extern "C" __global__ void __launch_bounds__(GBN_BIN_THREADS)
-probe_bin_kernel(GbnBinParams B)
-{
-    const GbnScanParams &P = B.S;
-    extern __shared__ __attribute__((aligned(16))) uint32_t s_dyn[];
-    uint32_t *s_tab = s_dyn;                                        // GBN_BIN_CELLS entries
-    uint2 *s_q = reinterpret_cast<uint2 *>(s_dyn + GBN_BIN_TABW);    // [16 waves][QCAP]; a wave's queue is touched by that wave only
-    uint16_t *s_side = reinterpret_cast<uint16_t *>(s_dyn + GBN_BIN_TABW + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2);
-    uint32_t *s_rcount = s_dyn + GBN_BIN_TABW + (GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 2 + GBN_BIN_SIDE / 2;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // wave-uniform: the stream bookkeeping below stays in scalar registers
-    const int grp = blockIdx.x & (GBN_BIN_GROUPS - 1);
-    // tables of fewer slices than groups (2 or 4 bins): the groups that share a bin split its streams
-    const int bstep = B.nb < GBN_BIN_GROUPS ? B.nb : GBN_BIN_GROUPS, sub = grp / bstep, nsub = GBN_BIN_GROUPS / bstep;
-    const int wi = (int)(blockIdx.x >> 3) + sub * (int)(gridDim.x >> 3), nw = (int)(gridDim.x >> 3) * nsub;   // workgroup index among those on the bin
-    const int cbits = B.cbits;
-    const uint32_t ncell_bin = 1u << cbits;
-    GbnU2 *myq = B.rareq + (size_t)blockIdx.x * B.rare_seg;          // this workgroup's segment: no global atomics
-    if (tid == 0) { *s_rcount = 0; s_tab[GBN_BIN_CELLS] = 0; }      // the empty cell pad records point at
-    // masks of the reduced fingerprint test; a zero mask makes that side "always matches"
-    const uint32_t lmask = (B.rfl <= 0) ? 0u : ((1u << (2 * B.rfl)) - 1);                               // byte 0 of an fp15
-    const uint32_t rmask = (B.rfrbits <= 0) ? 0u : (((1u << B.rfrbits) - 1) << (7 - B.rfrbits));      // byte 1
-    const uint32_t m4 = (lmask | (rmask << 8)) * 0x10001u;          // both fingerprints of a cell word at once
-    uint2 *q = s_q + wave * GBN_BIN_QCAP;
-    int qn = 0;                                                     // wave-uniform
-    unsigned long long raw = 0;
-    const unsigned long long lt = (1ull << lane) - 1;
-
-    // Flush `cnt` queued items (one per lane): cells with a side list get their reduced
-    // fingerprints checked here, densely; survivors go to the global rare-path queue.
-    auto flush = [&](int first, int cnt, int bin) {
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // queue slots written by other lanes of this wave
-        bool keep = false; uint32_t at_rec = 0, cv = 0;
-        if (lane < cnt) {
-            at_rec = q[first + lane].x;                             // record index inside the bin's region
-            const uint32_t y = q[first + lane].y;
-            const uint32_t low = y & 0x7fffu, sf = (y >> 15) & 0x7fffu;
-            cv = ((uint32_t)bin << cbits) | low;
-            keep = true;
-            if (y >> 31) {                                          // cell with >= 3 entries
-                const uint32_t t = s_tab[low];
-                const uint32_t n3 = (t >> 16) & 0x7fffu, so = t & 0x7fffu;
-                if (n3 == 0) cv |= 0x80000000u;                     // always-rare cell: raw hits counted later
-                else {
-                    raw += n3; keep = false;
-                    for (uint32_t e = 0; e < n3; e++) {
-                        const uint32_t x = (uint32_t)s_side[so + e] ^ sf;
-                        keep = keep || ((x & lmask) == 0) || (((x >> 8) & rmask) == 0);
-                    }
-                }
-            }
-        }
-        const unsigned long long m = __ballot(keep);
-        if (m) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(s_rcount, (uint32_t)__popcll(m));
-            base = __shfl(base, 0);
-            if (keep) {
-                const uint32_t at = base + (uint32_t)__popcll(m & lt);
-                const uint32_t pid = at_rec;                        // resolved to a position id by the rare kernel
-                if (at < B.rare_seg) { myq[at].x = pid; myq[at].y = cv; }
-            }
-        }
-    };
-
-    for (int b = grp % bstep; b < B.nb; b += GBN_BIN_GROUPS) {
-        __syncthreads();
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(B.cellt + ((size_t)b << cbits));
-            uint4 *dst = reinterpret_cast<uint4 *>(s_tab);
-            for (uint32_t i = tid; i < ncell_bin / 4; i += GBN_BIN_THREADS) dst[i] = src[i];
-            const uint32_t s0 = B.side_start[b], s1 = B.side_start[b + 1];
-            for (uint32_t i = tid; i < s1 - s0 && i < GBN_BIN_SIDE; i += GBN_BIN_THREADS) s_side[i] = B.sidet[s0 + i];
-        }
-        __syncthreads();
-        // one piece of a writer stream per wave at a time; streams are cut into `split` pieces
-        // (multiples of 512 records) when there are fewer streams than waves working on the bin
-        const int nwaves = nw * (GBN_BIN_THREADS / 64);
-        const int split = (nwaves + B.nwriters - 1) / B.nwriters;
-        for (int v = wi + nw * wave; v < B.nwriters * split; v += nwaves) {
-            const int w = v / split, part = v - w * split;
-            const uint32_t ntot = B.gcount[(size_t)b * B.nwriters + w];
-            constexpr uint32_t U = GBN_PROBE_U, BLK = 256u * U, NR = 4 * U;    // records per wave and per lane and round
-            const uint32_t piece = ((ntot + (uint32_t)split * BLK - 1u) / ((uint32_t)split * BLK)) * BLK;
-            const uint32_t lo = min((uint32_t)part * piece, ntot), n = min(piece, ntot - lo);
-            // lo and every round start are multiples of 512 (one chunk per round in the chunked layout)
-            const uint32_t *__restrict__ recb = B.rec;
-            const uint32_t rbase = (uint32_t)w * B.subcap + lo;     // of this piece inside the bin's region
-            // software pipeline: the loads of the next round are in flight while this round's
-            // records are looked up
-            uint4 cur[U], nxt[U];
-            // hi words of the piece: blocks of 64 records = 96 words; a round of BLK records starts at a block
-            // boundary (lo and BLK are multiples of 512), so a lane's words of round r sit at a fixed offset from
-            // the piece's first block + r * (BLK / 64 * 96)
-            const uint32_t *__restrict__ pbase = recb + GBN_REC_HI(GBN_RECIDX(B, b, w, lo));
-            uint32_t loff[U];
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) { const uint32_t j = u * 256u + (uint32_t)lane * 4u; loff[u] = (j >> 6) * 96u + (j & 63u); }
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t j = u * 256u + (uint32_t)lane * 4u;
-                const uint4 v = *reinterpret_cast<const uint4 *>(pbase + ((j < n) ? loff[u] : 0u));     // always a valid address: keeps the load a global load
-                cur[u].x = (j < n) ? v.x : GBN_REC_PAD; cur[u].y = (j < n) ? v.y : GBN_REC_PAD;
-                cur[u].z = (j < n) ? v.z : GBN_REC_PAD; cur[u].w = (j < n) ? v.w : GBN_REC_PAD;
-            }
-            for (uint32_t j0 = 0; j0 < n; j0 += BLK) {
-                const uint32_t rnext = ((j0 + BLK) >> 6) * 96u;       // word offset of the next round (a stream is far below 2^32 bytes)
-                #pragma unroll
-                for (uint32_t u = 0; u < U; u++) {
-                    const uint32_t j = j0 + BLK + u * 256u + (uint32_t)lane * 4u;
-                    const uint4 v = *reinterpret_cast<const uint4 *>(pbase + ((j < n) ? rnext + loff[u] : 0u));
-                    nxt[u].x = (j < n) ? v.x : GBN_REC_PAD; nxt[u].y = (j < n) ? v.y : GBN_REC_PAD;
-                    nxt[u].z = (j < n) ? v.z : GBN_REC_PAD; nxt[u].w = (j < n) ? v.w : GBN_REC_PAD;
-                }
-                uint32_t hv[NR], tv[NR];
-                #pragma unroll
-                for (uint32_t u = 0; u < U; u++) { hv[4 * u] = cur[u].x; hv[4 * u + 1] = cur[u].y; hv[4 * u + 2] = cur[u].z; hv[4 * u + 3] = cur[u].w; }
-                #pragma unroll
-                for (uint32_t r = 0; r < NR; r++) tv[r] = s_tab[(hv[r] >> 15) & 0xffffu];   // all LDS lookups first (a pad reads the empty extra cell)
-                // Both fingerprints of the cell word against the subject's in one go: a masked byte of
-                // (t ^ sf:sf) is zero iff that side matches; (x - 0x01010101) & ~x & 0x80808080 is nonzero
-                // iff some byte is zero.  One-entry cells hold their fingerprint twice.
-                // lookup hits = entries of the cells hit: cells with one (c0) or two (c0 and c1) entries are
-                // counted as #c0 + #c1 - #(c1 only); the c1-only cells (three or more entries) all take the
-                // queue below, where they are subtracted again and their true size is added in flush()
-                uint32_t flags = 0, slowm = 0;
-                #pragma unroll
-                for (uint32_t r = 0; r < NR; r++) {
-                    const uint32_t t = tv[r];
-                    const uint32_t x = (t ^ ((hv[r] & 0x7fffu) * 0x10001u)) & m4;
-                    const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;
-                    const bool c0 = (t & 0x8000u) != 0, c1 = (int32_t)t < 0;
-                    const bool slow = c0 ? (z != 0) : c1;
-                    flags += (t >> 15) & 0x10001u;              // c0 in the low half, c1 in the high half
-                    slowm |= slow ? (1u << r) : 0u;
-                }
-                uint32_t raw32 = (flags & 0xffffu) + (flags >> 16);
-                // queue the (few) records that need the rare path: one per lane and round
-                while (true) {
-                    const unsigned long long m = __ballot(slowm != 0);
-                    if (!m) break;
-                    if (slowm) {
-                        const uint32_t r = (uint32_t)__ffs(slowm) - 1u;
-                        slowm &= slowm - 1;
-                        uint32_t hi32 = 0;
-                        #pragma unroll
-                        for (uint32_t k = 0; k < NR; k++) hi32 = (r == k) ? hv[k] : hi32;
-                        const uint32_t t = s_tab[(hi32 >> 15) & 0x7fffu];
-                        const bool many = ((t & 0x8000u) == 0);                         // only c1: three or more entries
-                        raw32 -= many ? 1u : 0u;
-                        const int at = qn + __popcll(m & lt);
-                        q[at].x = rbase + j0 + (r >> 2) * 256u + (uint32_t)lane * 4u + (r & 3u);
-                        q[at].y = ((hi32 >> 15) & 0x7fffu) | ((hi32 & 0x7fffu) << 15) | (many ? 0x80000000u : 0u);
-                    }
-                    qn += __popcll(m);
-                    if (qn >= 64) { qn -= 64; flush(qn, 64, b); }
-                }
-                raw += raw32;
-                #pragma unroll
-                for (uint32_t u = 0; u < U; u++) cur[u] = nxt[u];
-            }
-        }
-        if (qn > 0) { flush(0, qn, b); qn = 0; }                    // the side list changes with the bin
-    }
-    if (P.raw_hits) {
-        for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
-        if (lane == 0 && raw) atomicAdd(P.raw_hits, raw);
-    }
-    __syncthreads();
-    if (tid == 0) B.rare_counts[blockIdx.x] = *s_rcount;
-}
-
-// rare path of the partitioned scan: one queued item per thread
-extern "C" __global__ void __launch_bounds__(256)
-probe_rare_kernel(GbnBinParams B, int nseg)
-{
-    const GbnScanParams &P = B.S;
-    unsigned long long raw = 0;
-    // blockIdx.x % nseg = segment (probe workgroup), blockIdx.x / nseg = part
-    const int seg = blockIdx.x % nseg, part = blockIdx.x / nseg, nparts = gridDim.x / nseg;
-    const uint32_t n = min(B.rare_counts[seg], B.rare_seg);
-    const GbnU2 *qs = B.rareq + (size_t)seg * B.rare_seg;
-    // dense-seed shapes (lut == word: every lookup hit is a seed) stage their seeds in LDS
-    constexpr uint32_t CAP = 1536;
-    __shared__ GbnDevSeed s_buf[CAP];
-    __shared__ uint32_t s_n, s_flush_at;
-    const bool staged = (P.fl == 0 && P.fr == 0);
-    if (threadIdx.x == 0) s_n = 0;
-    __syncthreads();
-    auto flush = [&]() {                                        // whole workgroup, after a barrier
-        const uint32_t have = min(s_n, CAP);
-        if (threadIdx.x == 0 && have) {
-            const unsigned long long at = atomicAdd(P.seed_count, (unsigned long long)have);
-            s_flush_at = (uint32_t)min(at, (unsigned long long)0xffffffffu);
-        }
-        __syncthreads();
-        if (have) {
-            const unsigned long long at = s_flush_at;
-            for (uint32_t k = threadIdx.x; k < have; k += blockDim.x) if (at + k < P.seed_cap) P.seeds[at + k] = s_buf[k];
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
-    };
-    for (uint32_t i0 = (uint32_t)part * 256u; i0 < n; i0 += (uint32_t)nparts * 256u) {     // uniform over the workgroup
-        if (staged) { __syncthreads(); if (s_n > CAP - 512u) flush(); }      // s_n is stable between the barriers
-        const uint32_t i = i0 + threadIdx.x;
-        if (i >= n) continue;
-        uint32_t pid = qs[i].x; const uint32_t cv = qs[i].y;
-        {   // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
-            const uint32_t bin = (cv & 0x7fffffffu) >> B.cbits;
-            const uint32_t wr = pid / B.subcap, j = pid - wr * B.subcap;
-            const uint32_t *__restrict__ cur = B.tcur + ((size_t)bin * B.nwriters + wr) * B.nseq;
-            // tiles of this writer: one per full round, and one of the last, incomplete round if its rotated index falls into it
-            const uint32_t full_rounds = (uint32_t)(P.ntiles / B.nwriters), rest = (uint32_t)(P.ntiles % B.nwriters);
-            const uint32_t ntiles_w = full_rounds + (((wr + full_rounds) % (uint32_t)B.nwriters) < rest ? 1u : 0u);
-            const uint32_t nt = (ntiles_w + (1u << GBN_TCUR_SHIFT) - 1u) >> GBN_TCUR_SHIFT;          // cursor entries
-            uint32_t lo = 0, hi = nt;
-            {   // the cursors grow almost linearly: look around the interpolated run first
-                const uint32_t total = B.gcount[(size_t)bin * B.nwriters + wr];
-                const uint32_t g = (uint32_t)(((unsigned long long)j * nt) / (total ? total : 1u));
-                constexpr uint32_t W = 3u;
-                const uint32_t a = g > W ? g - W : 0u, z = min(nt, g + W);
-                const uint32_t ca = cur[a], cz = (z < nt) ? cur[z] : 0xffffffffu;
-                if (ca <= j && cz > j) { lo = a; hi = z; }
-            }
-            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] <= j) lo = mid; else hi = mid; }
-            const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, j))];
-            const uint32_t seqn = (lo << GBN_TCUR_SHIFT) | (idx >> GBN_BIN_TILE_BITS);
-            pid = (GBN_TILE_OF(wr, seqn, (uint32_t)B.nwriters) << GBN_BIN_TILE_BITS) | (idx & (uint32_t)(GBN_BIN_TILE_POS - 1));
-        }
-        if (staged) probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw, s_buf, &s_n, CAP);
-        else probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
-    }
-    if (staged) { __syncthreads(); flush(); }
-    if (P.raw_hits) {
-        for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
-        if ((threadIdx.x & 63) == 0 && raw) atomicAdd(P.raw_hits, raw);
-    }
-}
-
-namespace gbn {
-// parts: 1 = binning kernel, 2 = probe kernel, 4 = rare kernel (7 = all; the rare kernel of a pass may run on another
-// stream next to the binning kernel of the next pass: engine.cpp, deferred rare path)
-hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts, hipEvent_t tables_ready)
-{
-    // ev[0..3]: before bin, after bin, after probe, after rare (optional)
-    if (b.S.ntiles <= 0) return hipSuccess;
-    hipError_t e = hipSuccess;
-    if (ev) (void)hipEventRecord(ev[0], st);
-    if (parts & 1) {
-        // stride-specialised variants: megablast (word 28 with lut 12 / 11 / 8) and blastn (word 11 with lut 11 / 10 / 8)
-        const bool generic = (b.dbg & 64) != 0;
-        const int step = b.S.step, lut = b.S.lut;
-        if (step == 1 && lut == 11 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s1, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else if (step == 2 && lut == 10 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s2, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else if (step == 4 && lut == 8 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s4, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else if (step == 21 && lut == 8 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s21, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else if (step == 17 && lut == 12 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s17, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else if (step == 18 && lut == 11 && !generic) hipLaunchKernelGGL(scan_bin_kernel_s18, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        else hipLaunchKernelGGL(scan_bin_kernel, dim3(b.nwriters), dim3(GBN_SORT_THREADS), 0, st, b);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    if (ev) (void)hipEventRecord(ev[1], st);
-    // the binning kernel needs no table: a batch whose lookup structures are still being built is waited for here
-    if (tables_ready && (parts & 2)) { e = hipStreamWaitEvent(st, tables_ready, 0); if (e != hipSuccess) return e; }
-    if (parts & 2) {
-        const size_t lds = (size_t)GBN_BIN_TABW * 4 + (size_t)(GBN_BIN_THREADS / 64) * GBN_BIN_QCAP * 8 + (size_t)GBN_BIN_SIDE * 2 + 16;
-        static std::atomic<uint64_t> attr_set{0};
-        e = raise_dynamic_lds((const void *)probe_bin_kernel, lds, attr_set);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(probe_bin_kernel, dim3(grid2), dim3(GBN_BIN_THREADS), lds, st, b);
-        e = hipGetLastError();
-        if (e != hipSuccess) return e;
-    }
-    if (ev) (void)hipEventRecord(ev[2], st);
-    if (parts & 4) {
-        if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * 8), dim3(256), 0, st, b, grid2);
-        e = hipGetLastError();
-    }
-    if (ev) (void)hipEventRecord(ev[3], st);
-    return e;
-}
-hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev)
-{
-    return launch_scan_bin_parts(b, grid2, st, ev, 3, nullptr);
-}
-}  // namespace gbn

@@ -73,12 +73,14 @@ static void for_each_word(const uint8_t *q, int32_t from, int32_t to, int32_t wo
     }
 }
 
-typedef struct { OrcLookup *l; int32_t *count; int32_t *fill; int pass; } BuildCtx;
+typedef struct { OrcLookup *l; int32_t *count; int32_t *fill; int pass; uint32_t *helper; } BuildCtx;
 
 static void mb_add(void *arg, int32_t cell, int32_t q_off)
 {
     OrcLookup *l = ((BuildCtx *)arg)->l;
     int32_t index = q_off + 1;          /* 1-based, :893-898 */
+    /* the reference's estimate of the longest chain counts, per 2048 cells, the words that found their cell taken (:915-924) */
+    if (l->hashtable[cell] != 0 && ((BuildCtx *)arg)->helper) ((BuildCtx *)arg)->helper[cell / 2048]++;
     l->next_pos[index] = l->hashtable[cell];
     l->hashtable[cell] = index;
     if (l->pv) l->pv[(uint32_t)cell >> l->pv_bts >> 5] |= 1u << (((uint32_t)cell >> l->pv_bts) & 31);   /* PV_SET, :921-923 */
@@ -107,7 +109,7 @@ OrcLookup *orc_lookup_new(const OrcOptions *opt, const uint8_t *query,
     l->lut_word_length = lut_width;
     l->scan_step = l->word_length - l->lut_word_length + 1;  /* :403, :572, :1018 */
     l->ncells = 1 << (2 * lut_width);
-    b.l = l; b.count = NULL; b.fill = NULL; b.pass = 0;
+    b.l = l; b.count = NULL; b.fill = NULL; b.pass = 0; b.helper = NULL;
     if (l->type == ORC_LUT_MB) {
         l->hashtable = (int32_t *)calloc((size_t)l->ncells, sizeof(int32_t));
         l->next_pos = (int32_t *)calloc((size_t)qlen + 2, sizeof(int32_t));
@@ -119,8 +121,15 @@ OrcLookup *orc_lookup_new(const OrcOptions *opt, const uint8_t *query,
             l->pv_bts = bts;
             l->pv = (uint32_t *)calloc((size_t)pv_size, 4);
         }
+        if (l->ncells >= 2048) b.helper = (uint32_t *)calloc((size_t)l->ncells / 2048, sizeof(uint32_t));
         for (c = 0; c < nseg; c++)
             for_each_word(query, seg[c].left, seg[c].right, l->word_length, lut_width, mb_add, &b);
+        {   /* :931-935: never below 2 */
+            int32_t i; uint32_t longest = 2;
+            for (i = 0; b.helper && i < l->ncells / 2048; i++) longest = ORC_MAX(longest, b.helper[i]);
+            l->longest_chain = (int32_t)longest;
+            free(b.helper);
+        }
     } else {
         int32_t i, acc = 0, longest = 0, overflow_cells = 2;
         b.count = (int32_t *)calloc((size_t)l->ncells, sizeof(int32_t));
@@ -170,4 +179,24 @@ void orc_lookup_free(OrcLookup *l)
     if (!l) return;
     free(l->hashtable); free(l->next_pos); free(l->cell_start); free(l->cell_offs); free(l->pv);
     free(l);
+}
+
+/* CORE/lookup_util.c:100-190 (fkm_output, fkm, debruijn): the (n, k) de Bruijn sequence as the concatenation, in
+ * lexicographic order, of the Lyndon words whose length divides n (Fredricksen, Kessler, Maiorana); k^n letters 0..k-1
+ * into `output`.  The reference's lookup-table unit tests index this sequence (UT/ntlookup_unit_test.cpp:147-170). */
+void orc_debruijn(int32_t n, int32_t k, uint8_t *output)
+{
+    int32_t *a = (int32_t *)calloc((size_t)n + 1, sizeof(int32_t));     /* indexed from one */
+    int64_t cursor = 0; int32_t i, j, p;
+    for (p = 1, i = 1; n % p == 0 && i <= p; i++) output[cursor++] = (uint8_t)a[i];     /* fkm_output(a, n, 1) */
+    i = n;
+    do {
+        a[i] = a[i] + 1;
+        for (j = 1; j <= n - i; j++) a[j + i] = a[j];
+        p = i;
+        if (n % p == 0) for (j = 1; j <= p; j++) output[cursor++] = (uint8_t)a[j];
+        i = n;
+        while (a[i] == k - 1) i--;
+    } while (i > 0);
+    free(a);
 }

@@ -110,6 +110,16 @@ void orc_update_for_subject(OrcSearch *s, int32_t subject_length)
     update_cutoffs(s);
 }
 
+/* CORE/blast_parameters.c:422-470 (BlastExtensionParametersNew): the gapped X-drop values from bits to raw scores with
+ * the (smallest) gapped Lambda; the final one is never below the preliminary one.  Known answers:
+ * UT/blastoptions_unit_test.cpp:761-810 (Lambda 1.30: 20 / 22 bits -> 10 / 11, 25 / 22 -> 13 / 13). */
+void orc_extension_params(double min_lambda, double gap_x_dropoff_bits, double gap_x_dropoff_final_bits,
+                          int32_t *gap_x_dropoff, int32_t *gap_x_dropoff_final)
+{
+    *gap_x_dropoff = (int32_t)(gap_x_dropoff_bits * ORC_LN2 / min_lambda);
+    *gap_x_dropoff_final = (int32_t)ORC_MAX(gap_x_dropoff_final_bits * ORC_LN2 / min_lambda, (double)*gap_x_dropoff);
+}
+
 OrcSearch *orc_search_new(const OrcOptions *opt, int nq,
                           const uint8_t *const *seqs, const int32_t *lens)
 {
@@ -230,12 +240,7 @@ OrcSearch *orc_search_new_masked(const OrcOptions *opt, int nq,
             return NULL;
         }
     }
-    /* CORE/blast_parameters.c:422-470 (BlastExtensionParametersNew) */
-    s->gap_x_dropoff = (int32_t)(opt->xdrop_gap_bits * ORC_LN2 / s->kbp_gap.Lambda);
-    {
-        double f = opt->xdrop_gap_final_bits * ORC_LN2 / s->kbp_gap.Lambda;
-        s->gap_x_dropoff_final = (int32_t)ORC_MAX(f, (double)s->gap_x_dropoff);
-    }
+    orc_extension_params(s->kbp_gap.Lambda, opt->xdrop_gap_bits, opt->xdrop_gap_final_bits, &s->gap_x_dropoff, &s->gap_x_dropoff_final);
     /* x_dropoff per context, CORE/blast_parameters.c:203-225 */
     for (c = 0; c < s->nctx; c++) {
         OrcContext *x = &s->ctx[c];

@@ -475,6 +475,21 @@ static int nucl_values(int reward, int penalty, int *n_normal, Row8 *normal,
     return 0;
 }
 
+/* CORE/blast_stat.c:3373-3424 (BLAST_GetNucleotideGapExistenceExtendParams): are these gap costs in the table of the
+ * reward / penalty pair (or the linear pair 0 / 0 where it has one)?  If not and they lie below the table's largest,
+ * they are replaced by the largest.  -1: no table for the pair.  Known answers: UT/blastoptions_unit_test.cpp:184-231. */
+int orc_nucl_gap_params(int reward, int penalty, int *gap_existence, int *gap_extension)
+{
+    Row8 normal[16], linear; int n, has_lin, gom, gem, rd, st, i;
+    st = nucl_values(reward, penalty, &n, normal, &has_lin, linear, &gom, &gem, &rd);
+    if (st) return st;
+    if (*gap_existence == 0 && *gap_extension == 0 && has_lin) return 0;
+    for (i = 0; i < n; i++)
+        if (normal[i][0] == *gap_existence && normal[i][1] == *gap_extension) return 0;
+    if (*gap_existence < gom || *gap_extension < gem) { *gap_existence = gom; *gap_extension = gem; }
+    return 0;
+}
+
 /* CORE/blast_stat.c:3806-3901 (Blast_KarlinBlkNuclGappedCalc) */
 int orc_karlin_nucl_gapped(int gap_open, int gap_extend, int reward, int penalty,
                            const OrcKarlin *ungapped, OrcKarlin *kbp, int *round_down)

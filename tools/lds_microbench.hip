@@ -50,11 +50,18 @@ __global__ void __launch_bounds__(1024) k(uint32_t *out, unsigned long long *cyc
             for (int j = 0; j < 8; j++) r[j] = atomicAdd(&h64[b[j] >> 1], (b[j] & 1) ? (1ull << 32) : 1ull);
             #pragma unroll
             for (int j = 0; j < 8; j++) acc += (uint32_t)r[j];
+        } else if (MODE == 8 || MODE == 9) {     // returning atomic add, then a barrier (8) or a barrier every 4th time (9): waves in lockstep, as between the phases of a kernel
+            uint32_t r[8];
+            #pragma unroll
+            for (int j = 0; j < 8; j++) r[j] = atomicAdd(&s_hist[b[j]], 1u);
+            #pragma unroll
+            for (int j = 0; j < 8; j++) acc += r[j];
+            if (MODE == 8 || (it & 3) == 3) __syncthreads();
         } else if (MODE == 7) {     // no LDS at all: the loop overhead
             #pragma unroll
             for (int j = 0; j < 8; j++) acc += b[j];
         }
-        if (MODE == 0 || MODE == 1 || MODE == 6) { if ((it & 63) == 63) { __syncthreads(); for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0; __syncthreads(); } }
+        if (MODE == 0 || MODE == 1 || MODE == 6 || MODE == 8 || MODE == 9) { if ((it & 63) == 63) { __syncthreads(); for (int i = tid; i < 2048; i += 1024) s_hist[i] = 0; __syncthreads(); } }
     }
     const unsigned long long t1 = __builtin_readcyclecounter();
     if (tid == 0) cyc[blockIdx.x] = t1 - t0;
@@ -88,6 +95,8 @@ int main()
     const int iters = 20000;
     run<7, 512>("loop overhead (no LDS)", out, cyc, iters);
     run<0, 512>("ds_add_rtn_u32 random", out, cyc, iters);
+    run<8, 512>("ds_add_rtn_u32 random + barrier per 8", out, cyc, iters);
+    run<9, 512>("ds_add_rtn_u32 random + barrier per 32", out, cyc, iters);
     run<0, 128>("ds_add_rtn_u32 random", out, cyc, iters);
     run<0, 2048>("ds_add_rtn_u32 random", out, cyc, iters);
     run<1, 512>("ds_add_u32 (no return) random", out, cyc, iters);
