@@ -11,6 +11,7 @@
 // 1470-1521): std::make_heap / pop_heap would be a different, equally valid heap
 // and would evict different lists when e-values tie within 1e-6.
 #include "gbn_host.hpp"
+#include "gbn_guard.hpp"
 #include <algorithm>
 #include <climits>
 #include <memory>
@@ -111,17 +112,21 @@ struct GbnCollector {
 extern "C" {
 
 int32_t gbn_prelim_hitlist_size(int32_t hitlist_size) {
+    return gbn::guard_as<int32_t>(__func__, (int32_t)-1, (int32_t)-1, [&]() -> int32_t {
     // SBlastHitsParametersNew, CORE/blast_hits.c:45-76 (gapped, no composition statistics)
     return std::max(std::min(2 * hitlist_size, hitlist_size + 50), 10);
+    });
 }
 
 int gbn_collector_new(GbnCollector **out, int32_t num_queries, int32_t hitlist_size) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!out || num_queries <= 0 || hitlist_size <= 0) { gbn::set_error("gbn_collector_new: bad argument"); return GBN_ERR_ARG; }
     auto *c = new GbnCollector();
     c->nq = num_queries; c->cap = (size_t)gbn_prelim_hitlist_size(hitlist_size);
     c->per_query.resize((size_t)num_queries);
     *out = c;
     return GBN_OK;
+    });
 }
 
 void gbn_collector_free(GbnCollector *c) { delete c; }
@@ -129,6 +134,7 @@ void gbn_collector_free(GbnCollector *c) { delete c; }
 // records grouped by oid (as gbn_results_hsps yields them); every oid group is one
 // BlastHSPStreamWrite.  Writing after close is an error (CORE/blast_hspstream.c:332-335).
 int gbn_collector_write(GbnCollector *c, const GbnHSP *h, int64_t n) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!c || (n > 0 && !h)) { gbn::set_error("gbn_collector_write: bad argument"); return GBN_ERR_ARG; }
     if (c->closed) { gbn::set_error("gbn_collector_write: collector already closed"); return GBN_ERR_ARG; }
     std::vector<std::unique_ptr<SubjectHits>> split((size_t)c->nq);
@@ -147,11 +153,13 @@ int gbn_collector_write(GbnCollector *c, const GbnHSP *h, int64_t n) {
         i = j;
     }
     return GBN_OK;
+    });
 }
 
 // surviving lists in (oid, query) ascending order -- the order BlastHSPStreamRead hands
 // them to the traceback stage (ascending oid)
 int gbn_collector_close(GbnCollector *c) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!c) return GBN_ERR_ARG;
     if (c->closed) return GBN_OK;
     std::vector<const SubjectHits *> all;
@@ -166,6 +174,7 @@ int gbn_collector_close(GbnCollector *c) {
     c->list_start.push_back((int64_t)c->out.size());
     c->closed = true;
     return GBN_OK;
+    });
 }
 
 int64_t gbn_collector_num_lists(const GbnCollector *c) { return c && c->closed ? (int64_t)c->list_query.size() : 0; }

@@ -7,6 +7,7 @@
 // through API/seqsrc_seqdb.cpp:283-382 (s_SeqDbGetSequence & co) -> CSeqDB / seqdbvol.cpp.
 // Host only; no third-party code.
 #include "gbn_host.hpp"
+#include "gbn_guard.hpp"
 #include <algorithm>
 #include <cstring>
 #include <fcntl.h>
@@ -153,6 +154,7 @@ const uint8_t kNa4ToBlastna[16] = {15, 0, 1, 6, 2, 4, 9, 13, 3, 8, 5, 12, 7, 11,
 extern "C" {
 
 int gbn_blastdb_open(GbnBlastDb **out, const char *name) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!out || !name) { gbn::set_error("gbn_blastdb_open: bad argument"); return GBN_ERR_ARG; }
     auto *db = new GbnBlastDb();
     int rc = open_name(*db, name, 0, true);
@@ -160,6 +162,7 @@ int gbn_blastdb_open(GbnBlastDb **out, const char *name) {
     if (db->title.empty() && !db->vols.empty()) db->title = db->vols[0].title;
     *out = db;
     return GBN_OK;
+    });
 }
 
 void gbn_blastdb_close(GbnBlastDb *db) { delete db; }
@@ -173,19 +176,24 @@ int32_t gbn_blastdb_max_length(const GbnBlastDb *db) { return db->max_len; }
 const char *gbn_blastdb_title(const GbnBlastDb *db) { return db->title.c_str(); }
 
 int gbn_blastdb_volume_range(const GbnBlastDb *db, int32_t vol, int32_t *first_oid, int32_t *num_oids) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!db || vol < 0 || vol >= (int32_t)db->vols.size()) { gbn::set_error("volume index out of range"); return GBN_ERR_ARG; }
     if (first_oid) *first_oid = db->vols[vol].first_oid;
     if (num_oids) *num_oids = db->vols[vol].noids;
     return GBN_OK;
+    });
 }
 
 int32_t gbn_blastdb_seq_length(const GbnBlastDb *db, int32_t oid) {
+    return gbn::guard_as<int32_t>(__func__, (int32_t)-1, (int32_t)-1, [&]() -> int32_t {
     int32_t local; const Volume *v = db->find(oid, local);
     return v ? v->length(local) : -1;
+    });
 }
 
 // ceil(len / 4) bytes of NCBI2na; the bits behind the last base are zero
 int gbn_blastdb_get_ncbi2na(const GbnBlastDb *db, int32_t oid, uint8_t *dst, int64_t dst_bytes) {
+    return gbn::guard(__func__, [&]() -> int {
     int32_t local; const Volume *v = db->find(oid, local);
     const int32_t len = v ? v->length(local) : -1;
     if (len < 0) { gbn::set_error("oid out of range or corrupt offsets"); return GBN_ERR_ARG; }
@@ -195,18 +203,22 @@ int gbn_blastdb_get_ncbi2na(const GbnBlastDb *db, int32_t oid, uint8_t *dst, int
     std::memcpy(dst, src, (size_t)nb);
     if (len & 3) dst[nb - 1] &= (uint8_t)(0xff << (2 * (4 - (len & 3))));
     return GBN_OK;
+    });
 }
 
 // ambiguity runs of a sequence, decoded from either on-disk format (sequence_files.txt:131-170)
 int32_t gbn_blastdb_num_ambiguities(const GbnBlastDb *db, int32_t oid) {
+    return gbn::guard_as<int32_t>(__func__, (int32_t)-1, (int32_t)-1, [&]() -> int32_t {
     int32_t local; const Volume *v = db->find(oid, local);
     if (!v) return -1;
     const uint32_t a = v->amb_off(local), e = v->seq_off(local + 1);
     if (e < a + 4 || e > v->nsq.n) return 0;
     return (int32_t)(be32(v->nsq.p + a) & 0x7fffffffu);
+    });
 }
 
 int gbn_blastdb_get_ambiguities(const GbnBlastDb *db, int32_t oid, int32_t *start, int32_t *length, uint8_t *na4, int32_t cap) {
+    return gbn::guard(__func__, [&]() -> int {
     int32_t local; const Volume *v = db->find(oid, local);
     if (!v) { gbn::set_error("oid out of range"); return GBN_ERR_ARG; }
     const uint32_t a = v->amb_off(local), e = v->seq_off(local + 1);
@@ -220,11 +232,13 @@ int gbn_blastdb_get_ambiguities(const GbnBlastDb *db, int32_t oid, int32_t *star
         else { na4[i] = (uint8_t)(w0 >> 28); length[i] = (int32_t)((w0 >> 24) & 0xf) + 1; start[i] = (int32_t)(w0 & 0xffffff); }
     }
     return GBN_OK;
+    });
 }
 
 // one BLASTNA code per base with the ambiguities applied (the traceback stage's encoding,
 // eBlastEncodingNucleotide); sentinels != 0 puts the code 15 in front and behind
 int gbn_blastdb_get_blastna(const GbnBlastDb *db, int32_t oid, uint8_t *dst, int64_t dst_bytes, int sentinels) {
+    return gbn::guard(__func__, [&]() -> int {
     int32_t local; const Volume *v = db->find(oid, local);
     const int32_t len = v ? v->length(local) : -1;
     if (len < 0) { gbn::set_error("oid out of range or corrupt offsets"); return GBN_ERR_ARG; }
@@ -242,11 +256,13 @@ int gbn_blastdb_get_blastna(const GbnBlastDb *db, int32_t oid, uint8_t *dst, int
     }
     if (sentinels) { dst[0] = 15; dst[len + 1] = 15; }
     return GBN_OK;
+    });
 }
 
 // subjects [first_oid, first_oid + num_oids) -> one slab (16-byte aligned subjects, 16 bytes in front,
 // 128 behind) -> resident shard whose global OIDs start at first_oid
 int gbn_blastdb_load_shard(const GbnBlastDb *db, int32_t first_oid, int32_t num_oids, GbnDb **out) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!db || !out || first_oid < 0 || num_oids < 0 || first_oid + (int64_t)num_oids > db->total_seqs) {
         gbn::set_error("gbn_blastdb_load_shard: bad oid range"); return GBN_ERR_ARG;
     }
@@ -277,6 +293,7 @@ int gbn_blastdb_load_shard(const GbnBlastDb *db, int32_t first_oid, int32_t num_
     }
     if (rc) { gbn_db_free(*out); *out = nullptr; }
     return rc;
+    });
 }
 
 }  // extern "C"

@@ -10,6 +10,7 @@
 // Finally sorted, overlapping and abutting intervals are fused (api/dust_filter.cpp:119-127).
 // Host only.
 #include "gbn_host.hpp"
+#include "gbn_guard.hpp"
 #include <algorithm>
 #include <cstring>
 
@@ -118,6 +119,7 @@ private:
 extern "C" int32_t gbn_dust_mask(const uint8_t *seq, int32_t len, int32_t level, int32_t window, int32_t linker,
                                  int32_t *from, int32_t *to, int32_t cap)
 {
+    return gbn::guard_as<int32_t>(__func__, (int32_t)-1, (int32_t)-1, [&]() -> int32_t {
     if (!seq || len <= 0 || (cap > 0 && (!from || !to))) return 0;
     if (level < 2 || level > 64) level = 20;
     if (window < 8 || window > 64) window = 64;
@@ -170,4 +172,5 @@ extern "C" int32_t gbn_dust_mask(const uint8_t *seq, int32_t len, int32_t level,
     const int32_t n = (int32_t)fused.size();
     for (int32_t i = 0; i < n && i < cap; i++) { from[i] = (int32_t)fused[(size_t)i].first; to[i] = (int32_t)fused[(size_t)i].second; }
     return n;
+    });
 }

@@ -9,6 +9,8 @@
 // dynprog_kernel (all initial hits) -> D2H of initial hits + gapped results -> host replay (hsp_host.cpp).
 #include <hip/hip_runtime.h>
 #include "gbn_host.hpp"
+#include "gbn_guard.hpp"
+#include <memory>
 #include "lutbuild.h"
 #include "gbn_dev.h"
 #include "hsp_host.hpp"
@@ -1646,6 +1648,7 @@ extern "C" {
 int gbn_device_count(void) { int n = 0; return hipGetDeviceCount(&n) == hipSuccess && n > 0 ? n : 0; }
 
 int gbn_init(int use_gpu, int gpu_id) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!use_gpu) { set_error("this engine has no CPU path: use_gpu must be true"); return GBN_ERR_NO_DEVICE; }
     Engine *e = nullptr;
     const int rc = engine_init(gpu_id, &e);
@@ -1653,17 +1656,22 @@ int gbn_init(int use_gpu, int gpu_id) {
     tl_sel = e->device;
     enter(e);
     return GBN_OK;
+    });
 }
 // the device the calling thread's later gbn_db_new / gbn_batch_new* / gbn_blastdb_load_shard calls work on (the GPU
 // lease of GB/gpu_blast_multi_gpu_utils.cpp:105-139: ThreadFetchGPU does cudaSetDevice for the search thread)
 int gbn_use_device(int gpu_id) {
+    return gbn::guard(__func__, [&]() -> int {
     if (gpu_id < 0) { set_error("gbn_use_device: a device number"); return GBN_ERR_ARG; }
     return gbn_init(1, gpu_id);
+    });
 }
 int gbn_current_device(void) {
+    return gbn::guard(__func__, [&]() -> int {
     if (tl_sel >= 0) return tl_sel;
     std::lock_guard<std::mutex> lk(g_eng_mu);
     return g_default_dev;
+    });
 }
 int gbn_db_device(const GbnDb *db) { return db && db->engine ? static_cast<const Engine *>(db->engine)->device : -1; }
 
@@ -1680,12 +1688,14 @@ GbnDb *gbn_db_cache_find(const void *key) {
     return it == g_db_cache.end() ? nullptr : it->second;
 }
 int gbn_db_cache_insert(const void *key, GbnDb *db) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!db) return GBN_ERR_ARG;
     std::lock_guard<std::mutex> lk(g_cache_mu);
     auto it = g_db_cache.find(key);
     if (it != g_db_cache.end()) { set_error("gbn_db_cache_insert: key already holds a shard"); return GBN_ERR_ARG; }
     g_db_cache[key] = db;
     return GBN_OK;
+    });
 }
 void gbn_release_db_memory(void) {
     std::map<const void *, GbnDb *> drop;
@@ -1739,21 +1749,26 @@ void gbn_release(void) {
 // subjects appended one at a time (the shim: what BlastSeqSrcGetSequence hands out) into the slab layout of gbn_db_new
 struct GbnShardBuilder { std::vector<uint8_t> bytes; std::vector<int64_t> off; std::vector<int32_t> len, oid; bool explicit_oids = false; };
 int gbn_shard_builder_new(GbnShardBuilder **out, int32_t expected_seqs) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!out) return GBN_ERR_ARG;
     GbnShardBuilder *b = new (std::nothrow) GbnShardBuilder();
     if (!b) return GBN_ERR_NOMEM;
     if (expected_seqs > 0) { b->off.reserve(expected_seqs); b->len.reserve(expected_seqs); }
     *out = b;
     return GBN_OK;
+    });
 }
 int gbn_shard_builder_add_oid(GbnShardBuilder *b, int32_t oid, const uint8_t *ncbi2na, int32_t length) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!b || oid < 0 || (!b->oid.empty() && oid <= b->oid.back()) || (b->oid.empty() && !b->len.empty())) {
         set_error("gbn_shard_builder_add_oid: OIDs must ascend, and every subject of the shard needs one"); return GBN_ERR_ARG; }
     const int rc = gbn_shard_builder_add(b, ncbi2na, length);
     if (rc == GBN_OK) { b->oid.push_back(oid); b->explicit_oids = true; }
     return rc;
+    });
 }
 int gbn_shard_builder_add(GbnShardBuilder *b, const uint8_t *ncbi2na, int32_t length) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!b || length < 0 || (length > 0 && !ncbi2na)) { set_error("gbn_shard_builder_add: bad argument"); return GBN_ERR_ARG; }
     const size_t at = std::max<size_t>(16, (b->bytes.size() + 15) & ~(size_t)15), nb      // 16 readable bytes in front of the first subject
          = ((size_t)length + 3) / 4;
@@ -1763,8 +1778,10 @@ int gbn_shard_builder_add(GbnShardBuilder *b, const uint8_t *ncbi2na, int32_t le
     // the last byte of a stored sequence carries the remainder count in its low bits (sequence_files.txt:60-90): bases only
     if (length & 3) b->bytes[at + nb - 1] &= (uint8_t)(0xff << (2 * (4 - (length & 3))));
     return GBN_OK;
+    });
 }
 int gbn_shard_builder_finish(GbnShardBuilder *b, GbnDb **out) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!b || !out || b->len.empty()) { set_error("gbn_shard_builder_finish: no subjects"); return GBN_ERR_ARG; }
     try { b->bytes.resize(((b->bytes.size() + 15) & ~(size_t)15) + 128, 0); }
     catch (const std::bad_alloc &) { set_error("out of host memory"); return GBN_ERR_NOMEM; }
@@ -1773,6 +1790,7 @@ int gbn_shard_builder_finish(GbnShardBuilder *b, GbnDb **out) {
     std::vector<uint8_t>().swap(b->bytes);
     if (rc == GBN_OK && b->explicit_oids && b->oid.back() - b->oid[0] + 1 != (int32_t)b->oid.size()) (*out)->oid_map = b->oid;    // holes: the map
     return rc;
+    });
 }
 void gbn_shard_builder_free(GbnShardBuilder *b) { delete b; }
 
@@ -1780,13 +1798,16 @@ void gbn_shard_builder_free(GbnShardBuilder *b) { delete b; }
 // 5,000,000 in stock BLAST+).  A multiple of 4; tests lower it to exercise the chunk path on small subjects.
 static int32_t g_max_dbseq_len = 200000000;
 int gbn_set_max_dbseq_len(int32_t n) {
+    return gbn::guard(__func__, [&]() -> int {
     if (n < 1000 || (n & 3)) { set_error("gbn_set_max_dbseq_len: a multiple of 4, at least 1000"); return GBN_ERR_ARG; }
     g_max_dbseq_len = n;
     return GBN_OK;
+    });
 }
 
 int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_seqs,
                const int64_t *byte_off, const int32_t *len, int32_t first_oid, int is_device) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!out || !packed || num_seqs < 0 || (num_seqs > 0 && (!byte_off || !len))) { set_error("bad argument"); return GBN_ERR_ARG; }
     int rc = enter_current();
     if (rc) return rc;
@@ -1854,10 +1875,12 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
         (rc = dev_upload(db->d_len, db->len.data(), db->len.size()))) { gbn_db_free(db); return rc; }
     *out = db;
     return GBN_OK;
+    });
 }
 // ambiguity runs of sequence `local` (0-based in the shard), values in NCBI4na as the database stores them
 // (gbn_blastdb_get_ambiguities); gbn_blastdb_load_shard calls this for every sequence that has runs
 int gbn_db_set_ambiguities(GbnDb *db, int32_t local, int32_t n, const int32_t *start, const int32_t *length, const uint8_t *ncbi4na) {
+    return gbn::guard(__func__, [&]() -> int {
     static const uint8_t kNa4ToBlastna[16] = {15, 0, 1, 6, 2, 4, 9, 13, 3, 8, 5, 12, 7, 11, 10, 14};    // CORE/blast_encoding.c:42-59
     if (!db || local < 0 || local >= db->real_seqs || n < 0 || (n > 0 && (!start || !length || !ncbi4na))) { set_error("gbn_db_set_ambiguities: bad argument"); return GBN_ERR_ARG; }
     if (db->amb.empty()) db->amb.resize((size_t)db->real_seqs);
@@ -1865,6 +1888,7 @@ int gbn_db_set_ambiguities(GbnDb *db, int32_t local, int32_t n, const int32_t *s
     v.clear();
     for (int32_t i = 0; i < n; i++) v.push_back(GbnDb::AmbRun{start[i], length[i], kNa4ToBlastna[ncbi4na[i] & 15]});
     return GBN_OK;
+    });
 }
 
 void gbn_db_free(GbnDb *db) {
@@ -1886,38 +1910,46 @@ int64_t gbn_db_total_bases(const GbnDb *db) { return db ? db->total_bases : 0; }
 int32_t gbn_db_num_seqs(const GbnDb *db) { return db ? db->real_seqs : 0; }
 
 int gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream) {
+    return gbn::guard(__func__, [&]() -> int {
     int rc = enter_current();
     if (rc) return rc;
     hipStream_t st = stream ? (hipStream_t)stream : E.stream;
     HIPCHK(launch_synth_fill(dev_ptr, nbytes, seed, st));
     HIPCHK(hipStreamSynchronize(st));
     return GBN_OK;
+    });
 }
 
 int gbn_batch_new_masked(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs,
                          const int32_t *lens, int32_t nmask, const int32_t *mask_query, const int32_t *mask_from,
                          const int32_t *mask_to, int upload) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!out || !opt || nq <= 0 || !seqs || !lens || nmask < 0 || (nmask > 0 && (!mask_query || !mask_from || !mask_to))) {
         set_error("bad argument"); return GBN_ERR_ARG;
     }
     std::vector<QueryMask> masks((size_t)nmask);
     for (int32_t i = 0; i < nmask; i++) masks[(size_t)i] = QueryMask{mask_query[i], mask_from[i], mask_to[i]};
-    GbnBatch *b = new GbnBatch();
+    std::unique_ptr<GbnBatch, void (*)(GbnBatch *)> b(new GbnBatch(), gbn_batch_free);      // (freed if the set-up throws)
     // with a device the lookup tables are built there (upload_batch); a host-only set-up fills them here
     int rc = build_batch(*b, *opt, nq, seqs, lens, masks, /* host_tables = */ upload == 0);
     if (rc == GBN_OK && upload) rc = upload_batch(*b);
-    if (rc != GBN_OK) { gbn_batch_free(b); return rc; }
-    *out = b;
+    if (rc != GBN_OK) return rc;
+    *out = b.release();
     return GBN_OK;
+    });
 }
 
 int gbn_batch_new_ex(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs,
                      const int32_t *lens, int upload) {
+    return gbn::guard(__func__, [&]() -> int {
     return gbn_batch_new_masked(out, opt, nq, seqs, lens, 0, nullptr, nullptr, nullptr, upload);
+    });
 }
 
 int gbn_batch_new(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs, const int32_t *lens) {
+    return gbn::guard(__func__, [&]() -> int {
     return gbn_batch_new_ex(out, opt, nq, seqs, lens, 1);
+    });
 }
 // the launchers' parameter blocks for a caller that holds a batch and a shard: database, lookup and query members
 // (everything marked [caller] in gblastn_amd_kernels.h stays zero)
@@ -1929,14 +1961,17 @@ static int params_ready(const GbnBatch *b, const GbnDb *db) {
     return GBN_OK;
 }
 int gbn_batch_scan_params(const GbnBatch *b, const GbnDb *db, GbnScanParams *out) {
+    return gbn::guard(__func__, [&]() -> int {
     int rc = params_ready(b, db); if (rc) return rc;
     if (!out) return GBN_ERR_ARG;
     TileSet none;
     fill_scan_params(*out, *b, *db, none);
     out->seeds = nullptr; out->seed_count = nullptr; out->seed_cap = 0; out->raw_hits = nullptr;
     return GBN_OK;
+    });
 }
 int gbn_batch_ext_params(const GbnBatch *b, const GbnDb *db, GbnExtParams *X) {
+    return gbn::guard(__func__, [&]() -> int {
     int rc = params_ready(b, db); if (rc) return rc;
     if (!X) return GBN_ERR_ARG;
     const DeviceBatch *d = b->dev;
@@ -1951,8 +1986,10 @@ int gbn_batch_ext_params(const GbnBatch *b, const GbnDb *db, GbnExtParams *X) {
     X->masked = b->lut.masked ? 1 : 0;
     X->ctx_hint = d->ctx_hint; X->ctx_hint_shift = kCtxHintShift; X->ctx_blk = d->ctx_blk; X->ctx_pack = d->ctx_pack;
     return GBN_OK;
+    });
 }
 int gbn_batch_gap_params(const GbnBatch *b, const GbnDb *db, GbnGapParams *G) {
+    return gbn::guard(__func__, [&]() -> int {
     int rc = params_ready(b, db); if (rc) return rc;
     if (!G) return GBN_ERR_ARG;
     const DeviceBatch *d = b->dev;
@@ -1967,28 +2004,37 @@ int gbn_batch_gap_params(const GbnBatch *b, const GbnDb *db, GbnGapParams *G) {
     G->scratch_per_thread = (int32_t)gap_scratch_ints(*b, max_len, max_ctx, &row_len);
     G->row_len = row_len;
     return GBN_OK;
+    });
 }
 int gbn_batch_diag_layout(const GbnBatch *b, int32_t *container_hash, int32_t *diag_len, int32_t *q_descending) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!b) return GBN_ERR_ARG;
     if (container_hash) *container_hash = b->container;
     if (diag_len) *diag_len = b->diag_len;
     if (q_descending) *q_descending = b->lut.type == GBN_LUT_MB ? 1 : 0;
     return GBN_OK;
+    });
 }
 int gbn_launch_scan_seed(const GbnScanParams *p, int grid, void *stream) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!p) return GBN_ERR_ARG;
     HIPCHK(launch_scan_seed(*p, grid, (hipStream_t)stream));
     return GBN_OK;
+    });
 }
 int gbn_launch_ungapped(const GbnExtParams *p, void *stream) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!p) return GBN_ERR_ARG;
     HIPCHK(launch_diag_ungapped(*p, (hipStream_t)stream));
     return GBN_OK;
+    });
 }
 int gbn_launch_gapped(const GbnGapParams *p, int greedy, void *stream) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!p) return GBN_ERR_ARG;
     HIPCHK(launch_gapped(*p, greedy != 0, (hipStream_t)stream));
     return GBN_OK;
+    });
 }
 void gbn_batch_free(GbnBatch *b) {
     if (!b) return;
@@ -2004,9 +2050,11 @@ void gbn_batch_free(GbnBatch *b) {
 int32_t gbn_batch_num_contexts(const GbnBatch *b) { return (int32_t)b->ctx.size(); }
 const GbnContext *gbn_batch_contexts(const GbnBatch *b) { return b->ctx.data(); }
 int gbn_batch_karlin_gapped(const GbnBatch *b, double *lambda, double *K) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!b || !lambda || !K) { set_error("bad argument"); return GBN_ERR_ARG; }
     *lambda = b->kbp_gap.lambda; *K = b->kbp_gap.K;
     return GBN_OK;
+    });
 }
 int32_t gbn_batch_lut_type(const GbnBatch *b) { return b->lut.type; }
 int32_t gbn_batch_lut_width(const GbnBatch *b) { return b->lut.lut; }
@@ -2015,7 +2063,7 @@ int32_t gbn_batch_scan_path(const GbnBatch *b) { return scan_slices(*b) > 0 ? 2 
 int32_t gbn_batch_diag_container(const GbnBatch *b) { return b->container; }
 int32_t gbn_batch_gap_x_dropoff(const GbnBatch *b) { return b->gap_x_dropoff; }
 
-int gbn_results_new(GbnResults **out) { if (!out) return GBN_ERR_ARG; *out = new GbnResults(); return GBN_OK; }
+int gbn_results_new(GbnResults **out) { return gbn::guard(__func__, [&]() -> int { if (!out) return GBN_ERR_ARG; *out = new GbnResults(); return GBN_OK; }); }
 void gbn_results_free(GbnResults *r) {
     if (!r) return;
     if (r->engine) {                                        // a stage of the engine that filled them may still write to them
@@ -2113,6 +2161,7 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
 
 int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
                       int keep_stages, GbnInterruptFn interrupt, void *progress) {
+    return gbn::guard(__func__, [&]() -> int {
     int rc = search_enter(batch, db, results);
     if (rc) return rc;
     rc = run_search(batch, db, results, diag, keep_stages, interrupt, progress, 0);
@@ -2121,11 +2170,13 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     const int rc2 = take_failure(results);
     if (!rc && !rc2 && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, *results->batch, results->diag); results->chunk_len = 0; }
     return rc ? rc : rc2;
+    });
 }
 
 // the same search delivered the way BlastHSPStreamWrite wants it: one call per subject that has HSPs
 int gbn_prelim_search_lists(GbnBatch *batch, GbnDb *db, GbnHspListFn sink, void *sink_arg, GbnDiagnostics *diag,
                             GbnInterruptFn interrupt, void *progress) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!sink) { set_error("gbn_prelim_search_lists: no sink"); return GBN_ERR_ARG; }
     GbnResults *res = nullptr;
     int rc = gbn_results_new(&res);
@@ -2143,15 +2194,19 @@ int gbn_prelim_search_lists(GbnBatch *batch, GbnDb *db, GbnHspListFn sink, void 
     }
     gbn_results_free(res);
     return rc;
+    });
 }
 
 int gbn_prelim_search_begin(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
                             GbnInterruptFn interrupt, void *progress) {
+    return gbn::guard(__func__, [&]() -> int {
     const int rc = search_enter(batch, db, results);
     return rc ? rc : run_search(batch, db, results, diag, 0, interrupt, progress, 1);
+    });
 }
 
 int gbn_prelim_search_end(GbnResults *results) {
+    return gbn::guard(__func__, [&]() -> int {
     // the engine that is filling these results; without results: whatever the calling thread's engine has in flight
     if (results && results->engine) enter(static_cast<Engine *>(results->engine));
     else if (results) return GBN_OK;                        // never searched: nothing in flight for them
@@ -2170,9 +2225,11 @@ int gbn_prelim_search_end(GbnResults *results) {
     else { (void)wait_pending(); rc = results ? take_failure(results) : GBN_OK; }
     if (!rc && results && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, *results->batch, results->diag); results->chunk_len = 0; }
     return rc;
+    });
 }
 
 int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag) {
+    return gbn::guard(__func__, [&]() -> int {
     if (!batch || !db || repeats <= 0) { set_error("bad argument"); return GBN_ERR_ARG; }
     int rc = params_ready(batch, db);                       // (enters the engine both live on)
     if (rc) return rc;
@@ -2191,6 +2248,7 @@ int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag)
         diag->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     }
     return GBN_OK;
+    });
 }
 
 // tests (GBN_GUARD=1): guard zones of every pool block intact?  Aborts on the first violation, returns 0 otherwise.

@@ -727,11 +727,12 @@ namespace {
 // Seeds go to P.seeds through one wave-aggregated reservation per loop round, or -- when the caller passes
 // an LDS staging buffer (`s_buf`, `s_n`, capacity `cap`) -- are collected there first and flushed by the
 // whole workgroup (dense-seed shapes: a single counter takes only ~90 reservations per microsecond).
-__device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell, bool count_raw,
+// cw: the cell's direct-probe word (GbnScanParams::cellw: the full fingerprint of the cell's first entry, bit 31 = more
+// entries), asked for by the caller next to its other loads: a cell with ONE entry whose fingerprint fails is done
+// without its entry list -- one random HBM sector (cell_start) fewer for nearly every queued record, and none for `ent`
+__device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell, bool count_raw, uint32_t cw,
                            unsigned long long &raw, GbnDevSeed *s_buf = nullptr, uint32_t *s_n = nullptr, uint32_t cap = 0)
 {
-    const uint32_t start = P.cell_start[cell], end = P.cell_start[cell + 1];
-    if (count_raw) raw += end - start;
     const GbnTile T = P.tiles[posid >> GBN_BIN_TILE_BITS];
     const int32_t s = T.first_pos + (int32_t)(posid & (uint32_t)(GBN_BIN_TILE_POS - 1)) * P.step;
     const uint8_t *__restrict__ subj = P.db + ((size_t)(uint32_t)T.off16 << 4);     // = byte_off[T.subj], one load less
@@ -739,6 +740,9 @@ __device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell
     const uint64_t w32 = (P.fl > 0 || P.fr > 0) ? bases32(subj, (int64_t)s - 8) : 0ull;     // lut == word: nothing to compare
     const uint32_t sl = (uint32_t)(w32 >> 48);
     const uint32_t sr = (uint32_t)((w32 << (2 * (8 + P.lut))) >> 32);
+    if (!count_raw && !(cw >> 31) && !fp_pass(cw, sl, sr, P.fl, P.fr)) return;
+    const uint32_t start = P.cell_start[cell], end = P.cell_start[cell + 1];
+    if (count_raw) raw += end - start;
     for (uint32_t e = start; e < end; e++) {
         const unsigned long long ent = P.ent[e];
         if (!fp_pass((uint32_t)(ent >> 32), sl, sr, P.fl, P.fr)) continue;
@@ -983,10 +987,14 @@ probe_rare_kernel(GbnBinParams B, int nseg)
         const uint32_t i = i0 + threadIdx.x;
         if (i >= n) continue;
         uint32_t pid = qs[i].x; const uint32_t cv = qs[i].y;
+        uint32_t cw;
         {   // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
             const uint32_t bin = (cv & 0x7fffffffu) >> B.cbits;
             const uint32_t wr = pid / B.subcap, j = pid - wr * B.subcap;
             const uint32_t *__restrict__ cur = B.tcur + ((size_t)bin * B.nwriters + wr) * B.nseq;
+            // everything that hangs on the queue item alone is asked for here, in front of the cursor search
+            const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, j))];
+            cw = P.cellw[cv & 0x7fffffffu];
             // tiles of this writer: one per full round, and one of the last, incomplete round if its rotated index falls into it
             const uint32_t full_rounds = (uint32_t)(P.ntiles / B.nwriters), rest = (uint32_t)(P.ntiles % B.nwriters);
             const uint32_t ntiles_w = full_rounds + (((wr + full_rounds) % (uint32_t)B.nwriters) < rest ? 1u : 0u);
@@ -1001,12 +1009,11 @@ probe_rare_kernel(GbnBinParams B, int nseg)
                 if (ca <= j && cz > j) { lo = a; hi = z; }
             }
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] <= j) lo = mid; else hi = mid; }
-            const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, j))];
             const uint32_t seqn = (lo << GBN_TCUR_SHIFT) | (idx >> GBN_BIN_TILE_BITS);
             pid = (GBN_TILE_OF(wr, seqn, (uint32_t)B.nwriters) << GBN_BIN_TILE_BITS) | (idx & (uint32_t)(GBN_BIN_TILE_POS - 1));
         }
-        if (staged) probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw, s_buf, &s_n, CAP);
-        else probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, raw);
+        if (staged) probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, cw, raw, s_buf, &s_n, CAP);
+        else probe_slow(P, pid, cv & 0x7fffffffu, (cv >> 31) != 0, cw, raw);
     }
     if (staged) { __syncthreads(); flush(); }
     if (P.raw_hits) {

@@ -14,6 +14,7 @@
 // (gbn_db_set_ambiguities) and are put back over the stretch read from HBM before anything is aligned.
 #include <hip/hip_runtime.h>
 #include "gbn_host.hpp"
+#include "gbn_guard.hpp"
 #include "envelope_index.hpp"
 #include <algorithm>
 #include <atomic>
@@ -662,7 +663,7 @@ struct GbnTraceback {
 
 extern "C" {
 
-int gbn_traceback_new(GbnTraceback **out) { if (!out) return GBN_ERR_ARG; *out = new GbnTraceback(); return GBN_OK; }
+int gbn_traceback_new(GbnTraceback **out) { return gbn::guard(__func__, [&]() -> int { if (!out) return GBN_ERR_ARG; *out = new GbnTraceback(); return GBN_OK; }); }
 void gbn_traceback_free(GbnTraceback *t) { delete t; }
 int64_t gbn_traceback_num_hsps(const GbnTraceback *t) { return t ? (int64_t)t->hsps.size() : 0; }
 const GbnTbHSP *gbn_traceback_hsps(const GbnTraceback *t) { return t->hsps.data(); }
@@ -676,6 +677,7 @@ const int64_t *gbn_traceback_query_starts(const GbnTraceback *t) { return t->que
 int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int64_t *list_start, int64_t nlists,
                       int32_t threads, GbnTraceback *out)
 {
+    return gbn::guard(__func__, [&]() -> int {
     if (!batch || !db || !out || nlists < 0 || (nlists > 0 && (!hsps || !list_start))) { set_error("gbn_traceback_run: bad argument"); return GBN_ERR_ARG; }
     out->hsps.clear(); out->op.clear(); out->op_len.clear(); out->query_start.assign((size_t)batch->nq + 1, 0);
     if (nlists == 0) return GBN_OK;
@@ -803,6 +805,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
     out->query_start[(size_t)batch->nq] = (int64_t)out->hsps.size();
     trace_mark("traceback: done");
     return GBN_OK;
+    });
 }
 
 // Final results of several shards of one database (one gbn_traceback_run per shard, same query batch) -> the
@@ -813,6 +816,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
 int64_t gbn_traceback_merge(int32_t nparts, const GbnTbHSP *const *hsps, const int64_t *const *query_start, int32_t nq,
                             int32_t hitlist_size, GbnTbHSP *out, int64_t *out_query_start)
 {
+    return gbn::guard_as<int64_t>(__func__, (int64_t)-1, (int64_t)-1, [&]() -> int64_t {
     if (nparts < 0 || nq < 0 || !out_query_start || (nparts > 0 && (!hsps || !query_start))) { set_error("gbn_traceback_merge: bad argument"); return -1; }
     struct List { const GbnTbHSP *first; int64_t n; double best_e; };
     int64_t w = 0;
@@ -839,6 +843,7 @@ int64_t gbn_traceback_merge(int32_t nparts, const GbnTbHSP *const *hsps, const i
     }
     out_query_start[nq] = w;
     return w;
+    });
 }
 
 }  // extern "C"

@@ -53,6 +53,7 @@ extern "C" {
 #define GBN_ERR_NOMEM          5
 #define GBN_ERR_INTERRUPTED    6   /* BLASTERR_INTERRUPTED analogue */
 #define GBN_ERR_SETUP          7   /* no valid Karlin-Altschul block etc. */
+#define GBN_ERR_INTERNAL       8   /* an exception inside the library, caught at the boundary (text: gbn_last_error) */
 
 /* lookup table kinds (ELookupTableType subset) */
 #define GBN_LUT_SMALL_NA 1

@@ -151,6 +151,17 @@ typedef struct OrcKarlin { double Lambda, K, logK, H; } OrcKarlin;
 int orc_karlin_ungapped(int reward, int penalty, const double *p1,
                         const double *p2, OrcKarlin *out);
 int orc_karlin_ideal(int reward, int penalty, OrcKarlin *out);
+/* CORE/blast_stat.c:3373-3424 (BLAST_GetNucleotideGapExistenceExtendParams); known answers UT/blastoptions_unit_test.cpp:184-231 */
+int orc_nucl_gap_params(int reward, int penalty, int *gap_existence, int *gap_extension);
+/* CORE/blast_parameters.c:422-470 (BlastExtensionParametersNew); known answers UT/blastoptions_unit_test.cpp:761-810 */
+void orc_extension_params(double min_lambda, double gap_x_dropoff_bits, double gap_x_dropoff_final_bits,
+                          int32_t *gap_x_dropoff, int32_t *gap_x_dropoff_final);
+/* CORE/lookup_util.c:100-190: the (n, k) de Bruijn sequence, k^n letters */
+void orc_debruijn(int32_t n, int32_t k, uint8_t *output);
+/* the lookup table of one sequence, one strand, as the reference's lookup-table unit tests build it; out[12]: see orc_lookup.c */
+int orc_lookup_probe(const OrcOptions *opt, const uint8_t *seq, int32_t len, int64_t *out);
+/* Blast_ExtendWordExit (CORE/blast_extend.c:166-190); known answers UT/blastdiag_unit_test.cpp:45-150 */
+int orc_extend_word_exit(int32_t *offset, int32_t window, int32_t subject_length, int32_t *last_hit, uint32_t *flag, int32_t n);
 /* CORE/blast_stat.c:3806 */
 int orc_karlin_nucl_gapped(int gap_open, int gap_extend, int reward, int penalty,
                            const OrcKarlin *ungapped, OrcKarlin *out,

@@ -200,3 +200,45 @@ void orc_debruijn(int32_t n, int32_t k, uint8_t *output)
     } while (i > 0);
     free(a);
 }
+
+/* Test access to the table builder the way the reference's lookup-table unit tests drive it: ONE sequence, one lookup
+ * segment [0, len - 1], i.e. one strand (UT/ntlookup_unit_test.cpp:147-170, :468-556).  seq: BLASTNA codes with a
+ * sentinel byte in front of seq[0] and one behind seq[len - 1].
+ * out: [0] table type, [1] cells, [2] word length, [3] lookup word length, [4] scan step, [5] pv_array_bts (megablast
+ * table; 5 = PV_ARRAY_BTS for the others), [6] longest chain, [7] cells with exactly one entry, [8] empty cells,
+ * [9] nonzero next_pos entries (megablast table: chained words), [10] presence words that are not all ones,
+ * [11] entries that would live in the overflow array (cells with more than NA_HITS_PER_CELL = 3 entries) */
+int orc_lookup_probe(const OrcOptions *opt, const uint8_t *seq, int32_t len, int64_t *out)
+{
+    OrcSeg seg; OrcLookup *l; int32_t c, i;
+    seg.left = 0; seg.right = len - 1;
+    l = orc_lookup_new(opt, seq, 1, &seg);
+    if (!l) return -1;
+    for (i = 0; i < 12; i++) out[i] = 0;
+    out[0] = l->type; out[1] = l->ncells; out[2] = l->word_length; out[3] = l->lut_word_length; out[4] = l->scan_step;
+    out[6] = l->longest_chain;
+    if (l->type == ORC_LUT_MB) {
+        const int32_t pv_words = (l->ncells >> l->pv_bts) >> 5;
+        out[5] = l->pv_bts;
+        for (c = 0; c < l->ncells; c++) {
+            const int32_t head = l->hashtable[c];
+            if (!head) out[8]++; else if (!l->next_pos[head]) out[7]++;
+        }
+        for (i = 0; i <= len; i++) if (l->next_pos[i]) out[9]++;
+        for (i = 0; i < pv_words; i++) if (l->pv[i] != 0xffffffffu) out[10]++;
+    } else {
+        out[5] = 5;
+        for (c = 0; c < l->ncells; c++) {
+            const int32_t n = l->cell_start[c + 1] - l->cell_start[c];
+            if (n == 1) out[7]++; else if (n == 0) out[8]++;
+            if (n > 3) out[11] += n;
+        }
+        for (c = 0; c < l->ncells; c += 32) {       /* PV_SET per cell, CORE/blast_nalookup.c:234-245 */
+            uint32_t w = 0;
+            for (i = 0; i < 32 && c + i < l->ncells; i++) if (l->cell_start[c + i + 1] > l->cell_start[c + i]) w |= 1u << i;
+            if (w != 0xffffffffu) out[10]++;
+        }
+    }
+    orc_lookup_free(l);
+    return 0;
+}

@@ -432,11 +432,28 @@ void orc_word_finder(OrcSearch *S, const uint8_t *subj, int32_t slen, OrcStats *
     if (S->carry_diag) {                /* Blast_ExtendWordExit (CORE/blast_extend.c:166-190), window 0 */
         if (S->container == ORC_DIAG_HASH) {
             DHash *h = dhash_get(S);
-            if (h->offset >= INT32_MAX / 4) dhash_reset(h); else h->offset += slen;
-        } else if (S->diag_offset >= INT32_MAX / 4) {
-            memset(S->diag_last_hit, 0, (size_t)S->diag_len * sizeof(int32_t)); S->diag_offset = 0;
-        } else S->diag_offset += slen;
+            if (orc_extend_word_exit(&h->offset, 0, slen, NULL, NULL, 0)) dhash_reset(h);
+        } else orc_extend_word_exit(&S->diag_offset, 0, slen, S->diag_last_hit, NULL, S->diag_len);
     }
+}
+
+/* Blast_ExtendWordExit (CORE/blast_extend.c:166-190) with s_BlastDiagClear (:92-112): what happens to a diagonal
+ * container when a subject is done and the container is carried on to the next one.  Positions stored in it are
+ * subject offsets + *offset, so that everything the finished subject left is below anything the next one can produce;
+ * past INT4_MAX / 4 the container is emptied instead and the offset starts again at the window.  Returns 1 when it
+ * was emptied (the hash container's buckets are the caller's).  last_hit / flag: the array container's cells (NULL:
+ * none).  Known answers: UT/blastdiag_unit_test.cpp:45-150. */
+int orc_extend_word_exit(int32_t *offset, int32_t window, int32_t subject_length, int32_t *last_hit, uint32_t *flag, int32_t n)
+{
+    int32_t i;
+    if (*offset >= INT32_MAX / 4) {
+        *offset = window;
+        for (i = 0; last_hit && i < n; i++) last_hit[i] = -window;
+        for (i = 0; flag && i < n; i++) flag[i] = 0;
+        return 1;
+    }
+    *offset += subject_length + window;
+    return 0;
 }
 
 /* carry the diagonal container across subjects as the reference does (1), or start every subject with a fresh

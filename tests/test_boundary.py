@@ -148,3 +148,42 @@ def test_shard_builder_rejects_bad_input():
     L.gbn_shard_builder_free(sb)
     assert L.gbn_db_cache_find(C.c_void_p(12345)) is None
     L.gbn_release_db_memory()                                          # empty cache: nothing to do
+
+
+def test_no_exception_crosses_the_c_abi(tmp_path):
+    """"no exceptions may cross the C boundary".  tests/firewall_probe.cpp replaces the process's operator new
+    by one that throws std::bad_alloc at the k-th allocation and calls gbn_batch_new_ex (host set-up), gbn_pipeline_new,
+    the collector, the shard builder and the database reader for k = 1, 2, ... until each gets through: every failure
+    must come back as GBN_ERR_NOMEM with a text in gbn_last_error() -- an exception unwinding through an extern "C" frame
+    would end the process instead (csrc/gbn_guard.hpp wraps every status-returning entry point)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "firewall_probe")
+    subprocess.run(["g++", "-std=c++17", "-O1", "-I" + os.path.join(root, "include"), "-o", exe,
+                    os.path.join(root, "tests", "firewall_probe.cpp"), "-L" + os.path.join(root, "gblastn_amd"),
+                    "-lgblastn_amd", "-Wl,-rpath," + os.path.join(root, "gblastn_amd")], check=True)
+    p = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout + p.stderr
+    assert "firewall probe ok" in p.stdout
+    for name in ("gbn_batch_new_ex", "gbn_pipeline_new", "gbn_collector_new", "gbn_shard_builder_new", "gbn_blastdb_open"):
+        assert name in p.stdout
+
+
+def test_every_status_returning_entry_point_runs_behind_the_firewall():
+    """Source check: every multi-line `int gbn_*(...)` definition of the C ABI translation units hands its body to
+    gbn::guard / gbn::guard_as."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    missing = []
+    for f in ("engine.cpp", "collector.cpp", "dbreader.cpp", "traceback.cpp", "pipeline.cpp", "dust.cpp"):
+        lines = open(os.path.join(root, "gblastn_amd", "csrc", f)).read().split("\n")
+        for i, line in enumerate(lines):
+            m = re.match(r'^(?:extern "C" )?(int|int64_t|int32_t|long) (gbn_\w+)\(', line)
+            if not m or line.rstrip().endswith("}"):
+                continue
+            j = i
+            while not lines[j].rstrip().endswith("{"):
+                j += 1
+            if "gbn::guard" not in lines[j + 1]:
+                missing.append((f, m.group(2)))
+    assert not missing, missing

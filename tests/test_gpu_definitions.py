@@ -476,3 +476,31 @@ def test_queue_of_host_replays_keeps_nothing_alive():
     p = util.run_child([sys.executable, os.path.join(root, "tools", "rss_check.py"), "60"], cwd=root, timeout=600)
     rss = [float(x) for x in re.findall(r"max RSS (\d+) MB", p.stdout)]
     assert len(rss) == 3 and rss[2] - rss[0] < 100, p.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("task,n,kw", [("megablast", 12, {}), ("blastn", 8, {"word_size": 8})])
+def test_device_built_tables_of_the_de_bruijn_queries(task, n, kw):
+    """The reference's lookup-table known answers (UT/ntlookup_unit_test.cpp:468-556) through the HIP table builder: the
+    (n, 4) de Bruijn query holds every n-mer exactly once per strand, so the table is the megablast one with 4^12 cells
+    (the standard one with 4^8 for blastn, word 8), and EVERY scan position of any subject finds exactly two entries,
+    one per strand -- a count the scan reports.  Results equal the oracle's as everywhere else."""
+    from tests.test_oracle_golden import _debruijn_query
+    buf, ln = _debruijn_query(n)
+    q = buf[1:1 + ln].copy()
+    rng = np.random.default_rng(5)
+    slen = 400_000 if task == "megablast" else 30_000
+    subj = rng.integers(0, 4, slen, dtype=np.uint8)
+    subj[1000:1400] = q[5000:5400]
+    packed = orc.pack_ncbi2na(subj)
+    opt = api.default_options(task, db_length=slen, db_num_seqs=1, **kw)
+    ps = api.BlastPrelimSearch([q], opt, api.BlastSeqSrc.from_packed([(packed, slen)]))
+    gpu = ps.run(keep_stages=True)
+    info = ps.info()
+    want = (3, 12, 17) if task == "megablast" else (2, 8, 1)
+    assert (info["lut_type"], info["lut_width"], info["scan_step"]) == want
+    positions = (slen - info["lut_width"]) // info["scan_step"] + 1
+    assert int(ps.diagnostics.lookup_hits) == 2 * positions
+    ora, s = util.oracle_run(opt, [q], [(packed, slen)])
+    util.compare_stages(gpu, ora)
+    assert len(gpu["hsps"]) >= 1

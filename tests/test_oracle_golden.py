@@ -220,3 +220,119 @@ def test_affine_greedy_reduces_to_linear_when_costs_coincide():
                                    2, -4, 0, 5, C.byref(b)) == 0
         for f in ["q_offset", "q_end", "s_offset", "s_end", "score", "q_gapped_start", "s_gapped_start"]:
             assert getattr(a, f) == getattr(b, f), (trial, f, getattr(a, f), getattr(b, f))
+
+
+# ---- the reference's offline known answers for the tables and containers C2 / C3 run on ------------------------------
+
+def _debruijn_query(n):
+    """UT/ntlookup_unit_test.cpp:147-170 (debruijnInit): the (n, 4) de Bruijn sequence followed by its first n - 1
+    letters, 4^n + n - 1 bases holding every n-mer exactly once, with a sentinel byte either side."""
+    L = orc.lib()
+    L.orc_debruijn.argtypes = [C.c_int32, C.c_int32, C.c_void_p]
+    ln = 4 ** n + n - 1
+    buf = np.full(ln + 2, 15, dtype=np.uint8)
+    L.orc_debruijn(n, 4, buf.ctypes.data + 1)
+    buf[1 + 4 ** n:1 + ln] = buf[1:n]
+    return buf, ln
+
+
+def _lookup_probe(opt, buf, ln):
+    L = orc.lib()
+    L.orc_lookup_probe.argtypes = [C.POINTER(orc.OrcOptions), C.c_void_p, C.c_int32, C.c_void_p]
+    out = np.zeros(12, dtype=np.int64)
+    assert L.orc_lookup_probe(C.byref(opt), buf.ctypes.data + 1, ln, out.ctypes.data) == 0
+    return dict(zip(["type", "cells", "word", "lut", "step", "pv_bts", "longest_chain", "single", "empty",
+                     "chained", "pv_not_full", "overflow"], [int(v) for v in out]))
+
+
+def test_debruijn_generator_holds_every_word_once():
+    # CORE/lookup_util.c:100-190 restated (orc_debruijn): every n-mer of the cyclic sequence is distinct
+    for n in (2, 3, 5, 8):
+        buf, ln = _debruijn_query(n)
+        seq = buf[1:1 + ln].astype(np.int64)
+        assert seq.max() <= 3
+        code = np.zeros(4 ** n, dtype=np.int64)
+        for k in range(n):
+            code = code * 4 + seq[k:k + 4 ** n]
+        assert len(np.unique(code)) == 4 ** n
+
+
+def test_ntlookup_testStdLookupTableDebruijn():
+    # UT/ntlookup_unit_test.cpp:468-509: blastn, word_size 8, the (8, 4) de Bruijn query of 65,543 bases ->
+    # eNaLookupTable, 65,536 cells, every cell exactly one entry, longest chain 1, nothing in the overflow array,
+    # every presence bit set
+    buf, ln = _debruijn_query(8)
+    assert ln == 65536 + 7
+    t = _lookup_probe(orc.default_options(False, word_size=8), buf, ln)
+    assert t["type"] == 2                       # ORC_LUT_NA = eNaLookupTable
+    assert t["cells"] == 65536 and t["lut"] == 8 and t["word"] == 8
+    assert t["single"] == 65536 and t["empty"] == 0
+    assert t["longest_chain"] == 1 and t["overflow"] == 0
+    assert t["pv_not_full"] == 0
+
+
+def test_ntlookup_testMegablastLookupTableDebruijn():
+    # UT/ntlookup_unit_test.cpp:511-556: megablast defaults, the (12, 4) de Bruijn query of 16,777,227 bases ->
+    # eMBLookupTable, 4^12 cells, word 28, the reference's chain estimate 2 ("an overestimate, should be 1"),
+    # pv_array_bts 10, next_pos all 0 (no word shares a cell), every presence bit set
+    buf, ln = _debruijn_query(12)
+    assert ln == 4 ** 12 + 11
+    t = _lookup_probe(orc.default_options(True), buf, ln)
+    assert t["type"] == 3                       # ORC_LUT_MB = eMBLookupTable
+    assert t["cells"] == 16777216 and t["word"] == 28 and t["lut"] == 12 and t["step"] == 17
+    assert t["longest_chain"] == 2
+    assert t["pv_bts"] == 10
+    assert t["chained"] == 0 and t["single"] == 16777216 and t["empty"] == 0
+    assert t["pv_not_full"] == 0
+
+
+def test_blastdiag_ExtendWordExit_known_answers():
+    # UT/blastdiag_unit_test.cpp:45-150 (testDiagClear, testDiagUpdateFull, testDiagUpdateNotFull): query 100,
+    # window 20 -> array of 128 cells; what Blast_ExtendWordExit does to the offset and the cells, i.e. the
+    # bookkeeping orc_search_carry_diag runs on (oracle/orc_wordfinder.c: orc_extend_word_exit)
+    L = orc.lib()
+    L.orc_extend_word_exit.argtypes = [C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    INT4_MAX, window, slen, n = 2 ** 31 - 1, 20, 100, 128
+    assert n == 1 << int(np.ceil(np.log2(100 + window)))     # s_BlastDiagTableNew: the power of two past qlen + window
+    for start, cleared in [(INT4_MAX // 4, True), (INT4_MAX // 4 + 1000, True), (100, False)]:
+        last_hit = np.full(n, 40, dtype=np.int32); flag = np.ones(n, dtype=np.uint32)
+        off = C.c_int32(start)
+        r = L.orc_extend_word_exit(C.byref(off), window, slen, last_hit.ctypes.data, flag.ctypes.data, n)
+        if cleared:
+            assert r == 1 and off.value == window
+            assert (last_hit == -window).all() and (flag == 0).all()
+        else:
+            assert r == 0 and off.value == start + slen + window
+            assert (last_hit == 40).all() and (flag == 1).all()
+
+
+def test_blastoptions_testExtensionParamsNew():
+    # UT/blastoptions_unit_test.cpp:761-810: gapped Lambda 1.30 (MakeSomeValidKBP :741-757), X-drop 20 / 22 bits ->
+    # 10 / 11 raw; 25 / 22 -> 13 / 13 (the final value is never below the preliminary one)
+    L = orc.lib()
+    L.orc_extension_params.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+    x, xf = C.c_int32(), C.c_int32()
+    L.orc_extension_params(1.30, 20.0, 22.0, C.byref(x), C.byref(xf))
+    assert (x.value, xf.value) == (10, 11)
+    L.orc_extension_params(1.30, 25.0, 22.0, C.byref(x), C.byref(xf))
+    assert (x.value, xf.value) == (13, 13)
+    # and through the search set-up: blastn defaults 30 / 100 bits at the gapped Lambda of 2 / -3, 5 / 2
+    s = orc.Search(orc.default_options(False, db_length=10**6, db_num_seqs=1), [np.zeros(50, dtype=np.uint8)])
+    lam = orc.lib().orc_gap_lambda(s._h)
+    assert s.info()["gap_x_dropoff"] == int(30 * math.log(2) / lam)
+
+
+def test_blastoptions_GetNucleotideGapExistenceExtendParams():
+    # UT/blastoptions_unit_test.cpp:184-231
+    L = orc.lib()
+    L.orc_nucl_gap_params.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+
+    def params(reward, penalty, ex, ext):
+        a, b = C.c_int(ex), C.c_int(ext)
+        st = L.orc_nucl_gap_params(reward, penalty, C.byref(a), C.byref(b))
+        return st, a.value, b.value
+    assert params(0, 3, -1, -1)[0] == -1
+    assert params(1, -3, 0, 0) == (0, 0, 0)         # megablast linear values
+    assert params(1, -3, -1, -1) == (0, 2, 2)
+    assert params(2, -5, -1, -1) == (0, 4, 4)
+    assert params(1, -2, -1, -1) == (0, 2, 2)

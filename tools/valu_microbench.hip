@@ -21,6 +21,19 @@
 #define BODY_LSHLOR(i) "v_lshl_or_b32 %" #i ", %" #i ", 3, %8\n"
 #define BODY_PERM(i)  "v_perm_b32 %" #i ", %" #i ", %8, %9\n"
 #define BODY_CND(i)   "v_cndmask_b32 %" #i ", %" #i ", %8, vcc\n"
+#define BODY_CND64(i) "v_cndmask_b32_e64 %" #i ", %" #i ", %8, s[10:11]\n"
+#define BODY_CMPCND(i) "v_cmp_lt_u32 vcc, %" #i ", %8\nv_cndmask_b32 %" #i ", %" #i ", %9, vcc\n"
+#define BODY_OR(i)    "v_or_b32 %" #i ", %" #i ", %8\n"
+#define BODY_XOR(i)   "v_xor_b32 %" #i ", %" #i ", %8\n"
+#define BODY_SUB(i)   "v_sub_u32 %" #i ", %" #i ", %8\n"
+#define BODY_MOV(i)   "v_mov_b32 %" #i ", %8\n"
+#define BODY_LSHR(i)  "v_lshrrev_b32 %" #i ", 1, %" #i "\n"
+#define BODY_BFI(i)   "v_bfi_b32 %" #i ", %8, %" #i ", %9\n"
+#define BODY_MIN(i)   "v_min_u32 %" #i ", %" #i ", %8\n"
+#define BODY_ANDOR(i) "v_and_or_b32 %" #i ", %" #i ", %8, %9\n"
+#define BODY_LSHLADD(i) "v_lshl_add_u32 %" #i ", %" #i ", 2, %8\n"
+#define BODY_FMA(i)   "v_fma_f32 %" #i ", %" #i ", %8, %9\n"
+#define BODY_ADDF(i)  "v_add_f32 %" #i ", %" #i ", %8\n"
 #define BODY_MAD24(i) "v_mad_u32_u24 %" #i ", %" #i ", %8, %9\n"
 #define BODY_MULLO(i) "v_mul_lo_u32 %" #i ", %" #i ", %8\n"
 #define BODY_CMP(i)   "v_cmp_lt_u32 vcc, %" #i ", %8\n"
@@ -40,7 +53,7 @@ __global__ void __launch_bounds__(1024) NAME(uint32_t *out, unsigned long long *
     for (int it = 0; it < iters; it++) {                                                                            \
         asm volatile(REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY) REP8(BODY)       \
                      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)               \
-                     : "v"(b), "v"(c), "v"(w) : "vcc");                                                             \
+                     : "v"(b), "v"(c), "v"(w) : "vcc", "s10", "s11");                                                             \
     }                                                                                                               \
     const unsigned long long t1 = __builtin_readcyclecounter();                                                     \
     if ((threadIdx.x & 63) == 0) cyc[blockIdx.x * 16 + (threadIdx.x >> 6)] = t1 - t0;                              \
@@ -62,12 +75,25 @@ KERNEL(k_cmp, BODY_CMP)
 KERNEL(k_max, BODY_MAX)
 KERNEL(k_dpp, BODY_DPP)
 KERNEL(k_chain, BODY_CHAIN)
+KERNEL(k_cnd64, BODY_CND64)
+KERNEL(k_cmpcnd, BODY_CMPCND)
+KERNEL(k_or, BODY_OR)
+KERNEL(k_xor, BODY_XOR)
+KERNEL(k_sub, BODY_SUB)
+KERNEL(k_mov, BODY_MOV)
+KERNEL(k_lshr, BODY_LSHR)
+KERNEL(k_bfi, BODY_BFI)
+KERNEL(k_min, BODY_MIN)
+KERNEL(k_andor, BODY_ANDOR)
+KERNEL(k_lshladd, BODY_LSHLADD)
+KERNEL(k_fma, BODY_FMA)
+KERNEL(k_addf, BODY_ADDF)
 
 typedef void (*kern_t)(uint32_t *, unsigned long long *, int);
 
 static int run(const char *what, kern_t k, uint32_t *out, unsigned long long *cyc)
 {
-    const int grid = 256, iters = 4000;
+    const int grid = 256, iters = 40000;
     for (int threads = 256; threads <= 1024; threads *= 2) {
         hipLaunchKernelGGL(k, dim3(grid), dim3(threads), 0, 0, out, cyc, 16);
         CHK(hipDeviceSynchronize());
@@ -110,5 +136,18 @@ int main()
     run("v_max_i32", k_max, out, cyc);
     run("v_add_u32_dpp row_shr:1", k_dpp, out, cyc);
     run("v_add_u32 dependent chain", k_chain, out, cyc);
+    run("v_cndmask_b32_e64 (sgpr pair mask)", k_cnd64, out, cyc);
+    run("v_cmp_lt_u32 + v_cndmask_b32 (2 instr)", k_cmpcnd, out, cyc);
+    run("v_or_b32", k_or, out, cyc);
+    run("v_xor_b32", k_xor, out, cyc);
+    run("v_sub_u32", k_sub, out, cyc);
+    run("v_mov_b32", k_mov, out, cyc);
+    run("v_lshrrev_b32", k_lshr, out, cyc);
+    run("v_bfi_b32", k_bfi, out, cyc);
+    run("v_min_u32", k_min, out, cyc);
+    run("v_and_or_b32", k_andor, out, cyc);
+    run("v_lshl_add_u32", k_lshladd, out, cyc);
+    run("v_fma_f32", k_fma, out, cyc);
+    run("v_add_f32", k_addf, out, cyc);
     return 0;
 }
