@@ -149,6 +149,7 @@ def main():
     pin = lambda: torch.cuda.set_device(dev)
     merger = shard.Exchange(dev)          # the rank's one ordered channel for collectives: worker thread + its own stream
     setup_pool = ThreadPoolExecutor(max_workers=2, initializer=pin)     # two set-ups in flight
+    primed, keep_primed = [], [False]     # set-ups started by one run_passes call for the next one (futures); on between timed regions
 
     def run_passes(count, diags):
         """`count` passes.  Nothing is carried over between passes: every pass sets its query batch up
@@ -169,18 +170,29 @@ def main():
             b.close()
             return got
         prev, futs = None, []
-        # the first set-up runs alone (nothing to hide behind yet); from then on two are in flight
-        ahead, queued = [setup_pool.submit(make, 0)], 1
+        # Two set-ups are in flight at any time.  The pipeline stays primed from one call to the next: the set-ups of the
+        # first two passes of the NEXT region are started (and waited for) inside this one -- a region of K passes still
+        # holds K set-ups, K scans, K extension stages and K merges, but a 20-pass region no longer begins with a set-up
+        # that has nothing to hide behind (the very first call pays it, outside the timed regions: the warm-up).
+        ahead = primed[:]; del primed[:]
+        queued = len(ahead)
+        if not ahead:
+            ahead, queued = [setup_pool.submit(make, 0)], 1
+        total = count + (2 if keep_primed[0] else 0)
         for k in range(count):
             b = ahead.pop(0).result()
-            while queued < count and queued <= k + 2:
+            while queued < total and queued <= k + 2:
                 ahead.append(setup_pool.submit(make, queued)); queued += 1
             b.begin()                       # waits for prev's extension stages before queueing its own
             if prev is not None:
                 futs.append(merger.submit(finish, prev, prev.end())); diags.append(prev.diagnostics)
             prev = b
         futs.append(merger.submit(finish, prev, prev.end())); diags.append(prev.diagnostics)
-        return n + sum(f.result() for f in futs)
+        got = n + sum(f.result() for f in futs)
+        for f in ahead:                     # the next region's first batches: set up, lookup structures queued on the builder's stream
+            f.result()
+        primed.extend(ahead)
+        return got
 
     def sync():
         if world > 1:
@@ -225,7 +237,8 @@ def main():
     torch.cuda.synchronize()
     batch_setup_ms = (time.perf_counter() - t_setup) * 1e3      # one set-up alone, lookup structures complete
     probe_batch.close()
-    run_passes(args.warmup, [])
+    keep_primed[0] = not args.no_overlap
+    run_passes(max(args.warmup, 1), [])
     # The timed region = exactly --steps passes between barrier + synchronize on both sides.  A short region (the driver's
     # 20 steps = 0.3 s) is mostly the pipeline's ramp -- first set-up alone, last extension stage and merge -- and one
     # box-noise sample: it is repeated until --min-seconds are measured, the MEDIAN region is the line's ms_per_step /
@@ -243,6 +256,10 @@ def main():
             more = bool(t.item() > 0.5)
         if not more:
             break
+    keep_primed[0] = False
+    for f in primed:                        # what the last region prepared for a region that does not come
+        f.result().close()
+    del primed[:]
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     elapsed, nhsp, diags = regions[order[(len(order) - 1) // 2]]
     region_ms = [r[0] / args.steps * 1e3 for r in regions]
@@ -306,6 +323,18 @@ def main():
         except Exception:
             traffic = None
 
+    # GPU time per kernel (class) and launch of the scan: HIP events of the library around every kernel of the scan stage and
+    # around the kernel classes of the stages behind it (GbnDiagnostics.kernel_ms)
+    by_kernel = {dom_label: dom_ms / max(launches, 1)}
+    if bin_ms > 0:
+        by_kernel["probe_bin_kernel"] = probe_ms / max(launches, 1); by_kernel["probe_rare_kernel"] = rare_ms / max(launches, 1)
+    for i, name in enumerate(api.GbnDiagnostics.KERNEL_CLASSES):
+        t = sum(d.kernel_ms[i] for d in diags) / max(launches, 1)
+        if t > 0:
+            by_kernel[name] = t
+    top_name = max(by_kernel, key=by_kernel.get)
+    valu = valu_roofline(args.workload, elapsed / args.steps * 1e3, launches / max(args.steps, 1))
+
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.cpu_seconds > 0:
         cpu = cpu_baseline(args, queries[:args.batch_queries], opt, mine)
@@ -316,6 +345,9 @@ def main():
     if rank == 0 and world == 1 and args.workload == "C2" and not args.no_side_workloads and not args.side:
         others = side_workloads(dev.index)
 
+    shared = None
+    if rank == 0 and world == 1 and args.workload == "C2" and not args.no_side_workloads and not args.side and not args.reuse_binning:
+        shared = shared_binning_pass(dev.index)
     if rank == 0:
         value = total_bases_global * args.steps / elapsed / 1e9
         line = {
@@ -323,7 +355,8 @@ def main():
             "value": value, "unit": "Gbp/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "ms_per_step_minmax": [min(region_ms), max(region_ms)], "regions": len(regions),
-            "regions_what": "timed regions of exactly `steps` passes each (barrier + synchronize either side); ms_per_step and value are the median region's",
+            "regions_what": "timed regions of exactly `steps` passes each (barrier + synchronize either side); ms_per_step and value are the median region's; "
+                            "the pipeline stays primed between regions: each region also sets up the first two query batches of the next one (and finds its own first two set up)",
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u8 (2-bit packed bases, int32 scores)", "data": "synthetic",
             "config": {
@@ -332,6 +365,13 @@ def main():
                 "stage_ms_per_pass": {k: sum(getattr(d, k) for d in diags) / max(launches, 1)
                                       for k in ["scan_stage_ms", "seed_stage_ms", "gapped_stage_ms", "host_stage_ms"]},
                 "config_wall_ms": npass_config * elapsed / args.steps * 1e3,
+                "config_wall_ms_shared_binning": None if not shared or "error" in shared else
+                    elapsed / args.steps * 1e3 + (npass_config - 1) * shared["ms_per_step"],
+                "config_wall_ms_shared_binning_what": None if not shared else dict(shared, what=
+                    "NOT the headline: the binning records depend on the shard and the table shape only, so the config's batches can be probed against "
+                    "ONE binning pass (GBN_REUSE_BINNING=1, results identical: tests/test_gpu_parity.py, tests/test_workload_size_gpu.py); "
+                    "config_wall_ms_shared_binning = one full pass of this run + (passes - 1) x the probe-only pass measured by "
+                    "`python bench.py --reuse-binning` in a process of its own"),
                 "batch_setup_ms": batch_setup_ms, "engine_only": engine_only, "init_hits_per_pass": sum(d.good_init_extends for d in diags) / max(launches, 1),
                 "batch_plan": {"queries_per_batch": args.batch_queries, "passes_per_config": npass_config,
                                "lut": info["lut_width"], "scan_step": info["scan_step"],
@@ -362,13 +402,55 @@ def main():
                                         "avg_ms": scan_ms / max(launches, 1),
                                         "avg_ms_by_kernel": [bin_ms / max(launches, 1), probe_ms / max(launches, 1),
                                                              rare_ms / max(launches, 1)],
-                                        "achieved": stage_achieved, "frac": stage_achieved / 8000.0}},
+                                        "achieved": stage_achieved, "frac": stage_achieved / 8000.0},
+                         "gpu_ms_per_launch_by_kernel": by_kernel,
+                         "dominant_kernel_by_gpu_time": {"kernel": top_name, "avg_ms_per_launch": by_kernel[top_name],
+                                                         "what": "HIP-event time per scan launch (= subject range), kernels running next to other streams' work included"},
+                         "valu": valu},
             "cpu_baseline": cpu,
         }
         print(json.dumps(line))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def shared_binning_pass(device_index):
+    """ms per pass when the scan records of the shard are kept (GBN_REUSE_BINNING=1): every timed pass is probe + rare kernels + the
+    stages behind them; in a process of its own (the switch is read once per process)"""
+    import subprocess
+    cmd = [sys.executable, os.path.abspath(__file__), "--reuse-binning", "--steps", "20", "--warmup", "2", "--no-cpu-baseline",
+           "--engine-steps", "0", "--min-seconds", "1.0", "--side", "--no-side-workloads"]
+    try:
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        j = json.loads(p.stdout.strip().splitlines()[-1])
+        return {"ms_per_step": j["ms_per_step"], "ms_per_step_minmax": j.get("ms_per_step_minmax"), "steps": j["steps"],
+                "command": "python bench.py --reuse-binning --steps 20"}
+    except Exception as e:      # noqa
+        return {"error": repr(e)[:300]}
+
+
+def valu_roofline(workload, ms_per_step, launches_per_step):
+    """VALU issue roofline of a whole step: wave-instructions per step (SQ_INSTS_VALU summed over the kernels of the committed
+    rocprofv3 --pmc pass named in profiles/valu_counts.json -- a constant of that profile, not a counter of this run) against
+    what 1,024 SIMDs issue in ms_per_step.  tools/valu_microbench.hip (profiles/r04_valu_microbench.txt): a wave64 add / sub /
+    and / or / xor / mov / lshr issues every 2.4 cycles, everything else integer (shifts left, bfe, alignbit, perm, cmp, min /
+    max, cndmask, three-operand forms, DPP) every 4.4; the fraction is given for both."""
+    tf = os.path.join(ROOT, "profiles", "valu_counts.json")
+    if not os.path.exists(tf):
+        return None
+    try:
+        e = json.load(open(tf)).get(workload)
+        if not e:
+            return None
+        n = float(e["valu_wave_instructions_per_launch"]) * launches_per_step
+        clock = 2.4e9
+        per_ms = lambda cyc: 1024 * clock / cyc * 1e-3
+        return {"bound": "valu issue", "wave_instructions_per_step": n, "source": e.get("source"),
+                "frac_at_4.4_cycles": n / (per_ms(4.4) * ms_per_step), "frac_at_2.4_cycles": n / (per_ms(2.4) * ms_per_step),
+                "peak_wave_instructions_per_ms": [per_ms(4.4), per_ms(2.4)], "by_kernel_per_launch": e.get("by_kernel")}
+    except Exception:
+        return None
 
 
 def slice_kernel_name(info):
@@ -400,9 +482,12 @@ def side_workloads(device_index):
             out[wl] = {"workload": j["config"]["workload"], "ms_per_step": j["ms_per_step"], "ms_per_step_minmax": j.get("ms_per_step_minmax"),
                        "steps": j["steps"], "regions": j.get("regions"), "value": j["value"], "unit": j["unit"],
                        "step_is": "one 100-query batch over the 5 Gbp shard (5 subject ranges)" if wl == "C3" else "one 5,000-query batch from the caller's arrays to its final alignments",
-                       "dominant_kernel": r.get("kernel"), "dominant_kernel_avg_launch_ms": r.get("avg_launch_ms"),
-                       "dominant_kernel_launches_per_step": (r.get("launches") or 0) / max(j["steps"], 1),
-                       "frac": r.get("frac"), "stage_ms_per_launch": j["config"].get("stage_ms_per_pass"),
+                       "dominant_kernel": (r.get("dominant_kernel_by_gpu_time") or {}).get("kernel", r.get("kernel")),
+                       "dominant_kernel_avg_launch_ms": (r.get("dominant_kernel_by_gpu_time") or {}).get("avg_ms_per_launch", r.get("avg_launch_ms")),
+                       "gpu_ms_per_launch_by_kernel": r.get("gpu_ms_per_launch_by_kernel"),
+                       "launches_per_step": (r.get("launches") or 0) / max(j["steps"], 1),
+                       "scan_kernel": r.get("kernel"), "scan_kernel_hbm_frac": r.get("frac"), "valu": r.get("valu"),
+                       "stage_ms_per_launch": j["config"].get("stage_ms_per_pass"),
                        "command": "python bench.py --workload %s --steps %s" % (wl, steps)}
         except Exception as e:      # noqa
             out[wl] = {"error": repr(e)[:300]}

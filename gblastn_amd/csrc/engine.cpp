@@ -33,8 +33,8 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
 hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st);
-hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st);
-hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st);
+hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st, GbnKernelTimer *kt = nullptr);
+hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st, GbnKernelTimer *kt = nullptr);
 hipError_t launch_synth_fill(void *dev, int64_t nbytes, uint64_t seed, hipStream_t st);
 hipError_t launch_gather_bytes(const uint8_t *src, const int64_t *src_off, const int64_t *dst_off, const int32_t *nbytes,
                                int32_t n, uint8_t *dst, hipStream_t st);
@@ -98,7 +98,9 @@ struct Engine {
         int32_t *cell_diag = nullptr, *cell_level = nullptr; size_t key_cap = 0;
         int32_t *ext_rec = nullptr;     // 8 ints per seed: seed_ext_kernel -> diag_replay_kernel
         void *sort_tmp = nullptr; size_t sort_tmp_bytes = 0;
+        GbnKernelTimer kt;              // GPU time per kernel class of the seed stage that works on this set
     } ks[2];
+    GbnKernelTimer kt_gap[2];       // ... of the gapped stage, per slot
     int pending_ks = -1;            // the set the stage in flight works on (-1: none)
     // initial hits / gapped extensions / gapped scratch exist twice: the gapped stage of one range
     // (stream2 + a host thread) overlaps the scan of the next range or query batch
@@ -1106,9 +1108,12 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     const bool from_segments = segmented && composite && !keep_stages;  // seed_ckeys_kernel reads the segments as they are
     if (phase != 2 && segmented && !from_segments && (rc = compact_seeds(st))) return rc;
     if (phase != 2 && (!composite || keep_stages)) {
+        KS.kt.mark(GBN_KT_KEYS, st);
         HIPCHK(launch_seed_keys(K, st));
         size_t tb = KS.sort_tmp_bytes;
+        KS.kt.mark(GBN_KT_SORT, st);
         HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, n, scan_bits, st));
+        KS.kt.mark(-1, st);
         // idx_b = seed indices in scan order (s_scan, chain order), subjects interleaved
     }
     if (keep_stages) {
@@ -1134,21 +1139,27 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         K.key_scan = KS.key_a; K.idx = KS.idx_a; K.v_bits = packed ? v_bits : 0;
         if (from_segments) { K.seg = E.slice_seg; K.seg_count = E.seg_counts; K.nseg = E.seg_n; K.seg_cap = E.seg_len; K.seg_first = E.seg_firsts; }
         if (phase != 2) {
+            KS.kt.mark(GBN_KT_KEYS, st);
             HIPCHK(launch_seed_ckeys(K, st));
             size_t tb = KS.sort_tmp_bytes;
+            KS.kt.mark(GBN_KT_SORT, st);
             // (seeds that come in scan order -- scan_fold_ordered_kernel's segments -- are in the order of the key's scan-position
             // bits already: the stable sort has subject | slot left to do)
             const int s_done = (from_segments && E.seg_ordered) ? K.s_bits : 0;
             if (packed) HIPCHK(sort_keys_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, n, v_bits + s_done, v_bits + ck_bits, st));
             else HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, n, ck_bits, st));
+            KS.kt.mark(-1, st);
         }
         // key_b = sorted composite keys, idx_b = ext_left of the seeds in that order (packed: both in key_b)
     } else {
         K.idx = KS.idx_b; K.key_group = KS.key_a;
         if (phase != 2) {
+            KS.kt.mark(GBN_KT_KEYS, st);
             HIPCHK(launch_group_keys(K, st));
             size_t tb = KS.sort_tmp_bytes;
+            KS.kt.mark(GBN_KT_SORT, st);
             HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_b, KS.idx_a, n, group_key_bits, st));
+            KS.kt.mark(-1, st);
         }
         // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
     }
@@ -1180,9 +1191,10 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
             X.ck_shift = K.s_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending; X.ck_subj_base = K.subj_base; X.ck_vbits = K.v_bits;
         }
         X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
-        HIPCHK(launch_diag_ungapped(X, st));
+        HIPCHK(launch_diag_ungapped(X, st, &KS.kt));
         HIPCHK(hipMemcpyAsync(&nih, ctr, sizeof(nih), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
+        { double km[GBN_KT_N] = {0}; KS.kt.collect(km); if (diag) for (int i = 0; i < GBN_KT_N; i++) diag->kernel_ms[i] += km[i]; }
         if (nih <= E.ihit_cap_s[slot]) break;
         if ((rc = grow_ihit_buffers(slot, (size_t)nih + (nih >> 3)))) return rc;
     }
@@ -1425,7 +1437,7 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     G.scratch = E.gap_scratch_s[slot];
     G.first = 0; G.n = (int64_t)nih; G.max_blocks = (int32_t)blocks;
     if (getenv("GBN_DP_STATS")) HIPCHK(hipMemsetAsync(G.scratch, 0, 256, st));
-    HIPCHK(launch_gapped(G, b.opt.greedy != 0, st));
+    HIPCHK(launch_gapped(G, b.opt.greedy != 0, st, &E.kt_gap[slot]));
     if (getenv("GBN_DP_STATS")) {       // (-DGBN_DP_STATS=1 builds only)
         unsigned long long c[24]; HIPCHK(hipMemcpyAsync(c, G.scratch, sizeof(c), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
         fprintf(stderr, "[gbn dbg] wave DP: %llu extensions (%llu left to the scratch kernel), %llu rows, %llu rounds, mean window %.1f\n", c[2], c[3], c[0], c[1], c[0] ? (double)c[4] / c[0] : 0.0);
@@ -1442,6 +1454,7 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     trace_mark("gapped: kernels + copies queued");
     HIPCHK(hipStreamSynchronize(st));
     trace_mark("gapped: kernels + copies done");
+    { double km[GBN_KT_N] = {0}; E.kt_gap[slot].collect(km); if (diag) for (int i = 0; i < GBN_KT_N; i++) diag->kernel_ms[i] += km[i]; }
     if (diag) diag->gapped_stage_ms += ms_since(t_stage);
     static const bool detach_on = !(getenv("GBN_HOST_DETACH") && atoi(getenv("GBN_HOST_DETACH")) == 0);
     // (a few thousand extensions -- megablast shapes -- are replayed in less time than handing them over takes)
@@ -1719,6 +1732,7 @@ static void release_engine() {              // (the calling thread has entered i
     dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_tcur); E.bin_tcur_cap = 0; dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
     dev_free(E.alt.bin_rec); dev_free(E.alt.bin_tcur); dev_free(E.alt.bin_count); dev_free(E.alt.rareq); dev_free(E.alt.rare_counts); E.alt = Engine::ScanSet();
     if (E.ev_r0) { (void)hipEventDestroy(E.ev_r0); (void)hipEventDestroy(E.ev_r1); E.ev_r0 = E.ev_r1 = nullptr; }
+    for (int i = 0; i < 2; i++) { E.ks[i].kt.destroy(); E.kt_gap[i].destroy(); }
     E.bin_rec_cap = 0; E.bin_count_cap = 0;
     E.seed_cap = 0;
     if (E.gather_stage) (void)hipHostFree(E.gather_stage);

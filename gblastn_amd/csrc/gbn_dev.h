@@ -107,3 +107,29 @@ struct GbnKeyParams {
 #ifndef GBN_DIAG_COMPACT_MIN
 #define GBN_DIAG_COMPACT_MIN (1 << 20)
 #endif
+
+// ---- GPU time per kernel class of the stages behind the scan (GbnDiagnostics::kernel_ms): the launchers record a HIP
+// event wherever the class of the kernels they queue changes, the engine reads the intervals after the stage's stream
+// synchronisation.  Indices = GBN_KT_* of include/gblastn_amd.h.
+#ifdef __cplusplus
+#include <hip/hip_runtime_api.h>
+#include "../../include/gblastn_amd.h"     // GBN_KT_*
+struct GbnKernelTimer {
+    enum { CAP = 24 };
+    hipEvent_t ev[CAP]; int tag[CAP]; int n = 0; bool made = false;
+    // an event on `st`; what is queued behind it belongs to class `t` (-1: nothing that is timed)
+    void mark(int t, hipStream_t st) {
+        if (!made) { for (int i = 0; i < CAP; i++) if (hipEventCreate(&ev[i]) != hipSuccess) return; made = true; }
+        if (n < CAP) { if (hipEventRecord(ev[n], st) == hipSuccess) tag[n++] = t; }
+    }
+    // after the stream was synchronised: the intervals added to kernel_ms[class]; ready for the next stage
+    void collect(double *kernel_ms) {
+        for (int i = 0; i + 1 < n; i++) {
+            float ms = 0;
+            if (tag[i] >= 0 && hipEventElapsedTime(&ms, ev[i], ev[i + 1]) == hipSuccess) kernel_ms[tag[i]] += ms;
+        }
+        n = 0;
+    }
+    void destroy() { if (made) for (int i = 0; i < CAP; i++) (void)hipEventDestroy(ev[i]); made = false; n = 0; }
+};
+#endif

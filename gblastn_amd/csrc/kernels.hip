@@ -2712,8 +2712,9 @@ hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st)
     return hipGetLastError();
 }
 
-hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
+hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st, GbnKernelTimer *kt)
 {
+    auto mark = [&](int t) { if (kt) kt->mark(t, st); };
     if (p.n <= 0) return hipSuccess;
     hipError_t e = hipMemsetAsync(p.run_count, 0, sizeof(uint32_t), st);
     if (e != hipSuccess) return e;
@@ -2722,7 +2723,9 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
     // GBN_DIAG_COMPACT_MIN (environment): the threshold, for tests that send small inputs through the two-kernel form
     static const int64_t compact_min = getenv("GBN_DIAG_COMPACT_MIN") ? atoll(getenv("GBN_DIAG_COMPACT_MIN")) : (int64_t)GBN_DIAG_COMPACT_MIN;
     if (p.n < compact_min) { GbnExtParams q = p; q.run_heads = nullptr;
+        mark(GBN_KT_DIAG);
         hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, q);
+        mark(-1);
         return hipGetLastError(); }
     if (p.ck_shift > 0 && p.ext_rec) {      // composite keys: the extension kernel finds the run heads on its way
         // (hash container, word sizes from 11 up: the approximate extension; the mask re-check stays with the general kernel)
@@ -2731,29 +2734,41 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st)
             // a stretch of 64 x k seeds per wave: every wave slot of the chip taken, eight or more rounds per wave
             const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((p.n + 2047) / 2048, 256 * 32));
             if (p.exact_list) { e = hipMemsetAsync(p.exact_count, 0, sizeof(uint32_t), st); if (e != hipSuccess) return e; }
+            mark(GBN_KT_SEED_EXT);
             hipLaunchKernelGGL(seed_ext_ck_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
             if (p.exact_list) hipLaunchKernelGGL(seed_exact_kernel, dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((p.n + 1535) / 1536, 4096))), dim3(256), 0, st, p);
-        } else
+        } else {
+        mark(GBN_KT_SEED_EXT);
         hipLaunchKernelGGL(seed_ext_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+        }
+        mark(GBN_KT_REPLAY);
         hipLaunchKernelGGL(diag_replay_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
+        mark(-1);
         return hipGetLastError();
     }
+    mark(GBN_KT_REPLAY);
     hipLaunchKernelGGL(run_heads_kernel, dim3((unsigned)((p.n + 1023) / 1024)), dim3(1024), 0, st, p);
     // grid for the worst case (every seed its own run); threads past the run count leave at once
     if (p.ext_rec) {        // every seed extended by a thread of its own, then the runs replayed over the records
+        mark(GBN_KT_SEED_EXT);
         hipLaunchKernelGGL(seed_ext_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p);
+        mark(GBN_KT_REPLAY);
         hipLaunchKernelGGL(diag_replay_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
-    } else
+    } else {
+        mark(GBN_KT_DIAG);
         hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, p);
+    }
+    mark(-1);
     return hipGetLastError();
 }
 
-hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
+hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st, GbnKernelTimer *kt)
 {
+    auto mark = [&](int t) { if (kt) kt->mark(t, st); };
     if (p.n <= 0) return hipSuccess;
     const int64_t need = (p.n + 63) / 64;
     const unsigned blocks = (unsigned)std::max<int64_t>(1, p.max_blocks > 0 ? std::min<int64_t>(need, p.max_blocks) : need);
-    if (greedy) { hipLaunchKernelGGL(greedy_kernel, dim3(blocks), dim3(64), 0, st, p); return hipGetLastError(); }
+    if (greedy) { mark(GBN_KT_THREAD_GAP); hipLaunchKernelGGL(greedy_kernel, dim3(blocks), dim3(64), 0, st, p); mark(-1); return hipGetLastError(); }
     // blastn, three kernels: one extension per LANE with the band in LDS (dynprog_lane_kernel: the many short
     // extensions of chance hits); what it leaves (GBN_GAP_REDO: a window wider than its LDS slots, a long run) one
     // extension per WAVE with the band in registers; what that leaves (a band wider than a wave, gap_extend 0) the
@@ -2777,6 +2792,7 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
             hipError_t e = hipMemsetAsync(p.scratch, 0, 16 * sizeof(int32_t), st);
             if (e != hipSuccess) return e;
             int32_t *ctx_of = p.scratch + 16;
+            mark(GBN_KT_LANE_DP);
             hipLaunchKernelGGL(gap_context_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p, ctx_of);
             const int64_t lblocks = std::max<int64_t>(1, std::min<int64_t>(need, p.max_blocks > 0 ? std::max(1, p.max_blocks * 2 / 3) : need));   // 16 of its workgroups fit a CU (LDS)
             redo_list = p.scratch + 16 + p.n;
@@ -2787,13 +2803,16 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st)
         }
         // a workgroup of two waves per extension (its two halves)
         const int64_t wblocks = std::max<int64_t>(1, std::min<int64_t>(p.n, p.max_blocks > 0 ? (int64_t)p.max_blocks * 4 : p.n));
+        mark(GBN_KT_WAVE_DP);
         hipLaunchKernelGGL(dynprog_wave_kernel, dim3((unsigned)(redo_list ? std::min<int64_t>(wblocks, 16384) : wblocks)), dim3(128), 0, st, w,
                            reinterpret_cast<const unsigned long long *>(p.scratch) + 1, (const int32_t *)redo_list);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
     GbnGapParams r = p; r.redo_only = 1;
+    mark(GBN_KT_THREAD_GAP);
     hipLaunchKernelGGL(dynprog_kernel, dim3(blocks), dim3(64), 0, st, r);
+    mark(-1);
     return hipGetLastError();
 }
 

@@ -111,6 +111,16 @@ typedef struct GbnInitHit {
 } GbnInitHit;
 
 /* BlastDiagnostics subset (COREI/blast_diagnostics.h) */
+/* kernel classes of GbnDiagnostics::kernel_ms */
+#define GBN_KT_KEYS        0   /* seed keys (seed_keys / seed_ckeys / group_keys kernels) */
+#define GBN_KT_SORT        1   /* radix sorts of the seed keys */
+#define GBN_KT_SEED_EXT    2   /* seed_ext(_ck)_kernel + seed_exact_kernel: every seed extended */
+#define GBN_KT_REPLAY      3   /* run_heads_kernel + diag_replay_kernel */
+#define GBN_KT_DIAG        4   /* diag_ungapped_kernel (few seeds: filter + extension in one) */
+#define GBN_KT_LANE_DP     5   /* gap_context_kernel + dynprog_lane_kernel */
+#define GBN_KT_WAVE_DP     6   /* dynprog_wave_kernel */
+#define GBN_KT_THREAD_GAP  7   /* dynprog_kernel / greedy_kernel */
+#define GBN_KT_N           8
 typedef struct GbnDiagnostics {
     int64_t lookup_hits;            /* raw table hits before mini-extension */
     int64_t init_extends, good_init_extends;
@@ -127,6 +137,8 @@ typedef struct GbnDiagnostics {
     double  seed_stage_ms;          /* key build, two radix sorts, diagonal filter + ungapped kernel */
     double  gapped_stage_ms;        /* gapped kernels + D2H of initial hits and extensions */
     double  host_stage_ms;          /* replay of the acceptance rules, HSP list rules */
+    /* GPU time (HIP events on the stage's stream) per kernel class of the stages behind the scan, GBN_KT_* */
+    double  kernel_ms[GBN_KT_N];
 } GbnDiagnostics;
 
 typedef int (*GbnInterruptFn)(void *progress);   /* TInterruptFnPtr analogue */
