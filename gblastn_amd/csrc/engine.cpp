@@ -1710,10 +1710,48 @@ int gbn_db_cache_insert(const void *key, GbnDb *db) {
     return GBN_OK;
     });
 }
+// The block cache: the database on a device as resident shards of one OID chunk each, keyed by what the chunk IS --
+// (device, database name, the OIDs) -- not by who asked: the reference caches every subject per OID
+// (GB/gpu_blastn_MB_and_smallNa.cu:1461-1467), so whichever of its N search threads gets whichever chunk of whichever
+// query batch (API/prelim_search_runner.hpp:135-166), nothing is uploaded twice.  The key holds the OIDs themselves:
+// no hash that could collide.  An insert that finds the block already there (two threads built it at the same time)
+// frees the newcomer and hands back the one that stays.
+typedef std::tuple<int, std::string, std::vector<int32_t>> BlockKey;
+static std::map<BlockKey, GbnDb *> g_block_cache;
+static std::atomic<long long> g_db_bytes_uploaded{0};       // slab bytes copied to a device by gbn_db_new / the shard builder
+int gbn_block_cache_find(const char *db_name, const int32_t *oids, int32_t n, GbnDb **out) {
+    return gbn::guard(__func__, [&]() -> int {
+    if (!out || n <= 0 || !oids) return GBN_ERR_ARG;
+    const int device = gbn_current_device();
+    BlockKey key(device, std::string(db_name ? db_name : ""), std::vector<int32_t>(oids, oids + n));
+    std::lock_guard<std::mutex> lk(g_cache_mu);
+    auto it = g_block_cache.find(key);
+    *out = it == g_block_cache.end() ? nullptr : it->second;
+    return GBN_OK;
+    });
+}
+int gbn_block_cache_insert(const char *db_name, const int32_t *oids, int32_t n, GbnDb *db, GbnDb **kept) {
+    return gbn::guard(__func__, [&]() -> int {
+    if (!db || !kept || n <= 0 || !oids) return GBN_ERR_ARG;
+    BlockKey key(gbn_db_device(db), std::string(db_name ? db_name : ""), std::vector<int32_t>(oids, oids + n));
+    GbnDb *loser = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_block_cache.find(key);
+        if (it == g_block_cache.end()) { g_block_cache.emplace(std::move(key), db); *kept = db; }
+        else { *kept = it->second; if (it->second != db) loser = db; }
+    }
+    if (loser) gbn_db_free(loser);
+    return GBN_OK;
+    });
+}
+long long gbn_debug_db_bytes_uploaded(void) { return g_db_bytes_uploaded.load(); }
 void gbn_release_db_memory(void) {
     std::map<const void *, GbnDb *> drop;
-    { std::lock_guard<std::mutex> lk(g_cache_mu); drop.swap(g_db_cache); }
+    std::map<BlockKey, GbnDb *> drop_blocks;
+    { std::lock_guard<std::mutex> lk(g_cache_mu); drop.swap(g_db_cache); drop_blocks.swap(g_block_cache); }
     for (auto &kv : drop) gbn_db_free(kv.second);
+    for (auto &kv : drop_blocks) gbn_db_free(kv.second);
 }
 
 static void release_engine() {              // (the calling thread has entered it)
@@ -1844,6 +1882,7 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
             uint8_t *p = nullptr;
             if (hipMalloc((void **)&p, (size_t)nbytes) != hipSuccess) { delete db; set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
             if (hipMemcpy(p, packed, (size_t)nbytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); delete db; set_error("H2D(db) failed"); return GBN_ERR_HIP; }
+            g_db_bytes_uploaded += (long long)nbytes;
             db->d_packed = p; db->owns = true;
         }
     } else {

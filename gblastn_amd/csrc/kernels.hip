@@ -2624,7 +2624,11 @@ int scan_slice_blocks(const GbnScanParams &p, int num_cu)
     if (nslices <= 0) return 0;
     // one workgroup per CU (its slice fills the LDS); every slice gets the same number of workgroups
     const int64_t waves_needed = (p.ntiles + (GBN_SLICE_THREADS / 64) - 1) / (GBN_SLICE_THREADS / 64);
-    const int per_slice = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, std::min(num_cu, GBN_SLICE_SEGS) / nslices), waves_needed));
+    // (the ordered form has a segment per WAVE: sixteen per workgroup, GBN_SLICE_SEGS in all -- a part with more than
+    // GBN_SLICE_SEGS / 16 = 256 CUs gets 256 workgroups, whichever form the launch takes, so that the segment tables
+    // of the engine and of seg_first_kernel always hold them)
+    const int max_blocks = std::min(num_cu, GBN_SLICE_SEGS / (GBN_SLICE_THREADS / 64));
+    const int per_slice = (int)std::max<int64_t>(1, std::min<int64_t>(std::max(1, max_blocks / nslices), waves_needed));
     return per_slice * nslices;
 }
 

@@ -16,7 +16,7 @@
 //
 // Everything that does not need a toolkit type lives in the library and is tested there:
 //   gbn_prelim_search_lists    grouping of the HSPs into per-subject lists, ascending oid
-//   gbn_db_cache_find/_insert  the shard cache that gpu_ReleaseDBMemory() empties
+//   gbn_db_cache_find/_insert  the cache of resident OID blocks that gpu_ReleaseDBMemory() empties
 //   gbn_shard_builder_*        subjects appended one by one into a 16-byte aligned slab, with their OIDs
 //   gbn_use_device             the calling thread's GPU (the lease of GB/gpu_blast_multi_gpu_utils.cpp:105-139)
 // so what remains here is field-by-field translation between the toolkit's structures and the PODs of
@@ -27,6 +27,7 @@
 #include <algo/blast/core/blast_engine.h>
 #include <algo/blast/core/blast_hspstream.h>
 #include <algo/blast/core/blast_seqsrc.h>
+#include <algo/blast/core/blast_seqsrc_impl.h>      // BlastSeqSrcIterator::current_pos: where a chunk of the source ends
 #include <algo/blast/core/blast_nalookup.h>
 #include <algo/blast/core/blast_hits.h>
 #include <algo/blast/core/blast_util.h>
@@ -63,19 +64,19 @@ void s_ReplaceGpu(int id)
 // word_length / lut_word_length / masked_locations live in a different structure for every nucleotide table kind
 // (COREI/blast_nalookup.h:63-77, 132-153, 237-264); BlastNaWordFinder's callers switch on lut_type the same way
 // (CORE/na_ungapped.c:1753-1795)
-bool s_TableShape(const LookupTableWrap* w, Int4* word, bool* discontiguous, const BlastSeqLoc** masked)
+bool s_TableShape(const LookupTableWrap* w, Int4* word, Int4* lut_word, bool* discontiguous, const BlastSeqLoc** masked)
 {
     *discontiguous = false; *masked = NULL;
     switch (w->lut_type) {
     case eMBLookupTable: {
         const BlastMBLookupTable* t = (const BlastMBLookupTable*)w->lut;
-        *word = t->word_length; *discontiguous = t->discontiguous != 0; *masked = t->masked_locations; return true; }
+        *word = t->word_length; *lut_word = t->lut_word_length; *discontiguous = t->discontiguous != 0; *masked = t->masked_locations; return true; }
     case eSmallNaLookupTable: {
         const BlastSmallNaLookupTable* t = (const BlastSmallNaLookupTable*)w->lut;
-        *word = t->word_length; *masked = t->masked_locations; return true; }
+        *word = t->word_length; *lut_word = t->lut_word_length; *masked = t->masked_locations; return true; }
     case eNaLookupTable: {
         const BlastNaLookupTable* t = (const BlastNaLookupTable*)w->lut;
-        *word = t->word_length; *masked = t->masked_locations; return true; }
+        *word = t->word_length; *lut_word = t->lut_word_length; *masked = t->masked_locations; return true; }
     default:
         return false;
     }
@@ -104,45 +105,82 @@ void s_QueryMasks(const BlastSeqLoc* masked, const BlastQueryInfo* qi,
     // (the list ascends in concatenated coordinates and the contexts ascend: sorted by (query, from) already)
 }
 
-// 64-bit FNV-1a over what identifies a resident shard: device, database name, the OIDs it holds
-uint64_t s_Mix(uint64_t h, const void* p, size_t n)
+// When the lookup word is as long as the search word (blastn with many queries: word 11 = lut 11; every small word
+// size) the reference needs no seed re-check and keeps NO masked_locations (CORE/blast_nalookup.c:413-417, :585,
+// :977-981) -- yet the table was built from the lookup segments, masked stretches left out.  What was indexed is in
+// the table itself: a query position p is covered iff a word [p, p + lut) of the table contains it, and with
+// lut == word the segments that can hold a word are exactly the unions of their words.  The complement of the cover
+// (per plus-strand context, as above) is handed over as masks: the library then indexes the same words.  (Bases the
+// reference left out for an ambiguity code fall into the complement as well; the library leaves those words out anyway.)
+void s_MarkWord(std::vector<unsigned char>& cover, Int4 q_off, Int4 lut)
 {
-    const unsigned char* b = (const unsigned char*)p;
-    for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
-    return h;
+    for (Int4 k = 0; k < lut && (size_t)(q_off + k) < cover.size(); ++k) if (q_off + k >= 0) cover[(size_t)(q_off + k)] = 1;
+}
+bool s_MasksFromTable(const LookupTableWrap* w, const BlastQueryInfo* qi,
+                      std::vector<int32_t>& mq, std::vector<int32_t>& mfrom, std::vector<int32_t>& mto)
+{
+    const BlastContextInfo& lastc = qi->contexts[qi->last_context];
+    std::vector<unsigned char> cover((size_t)(lastc.query_offset + lastc.query_length), 0);
+    switch (w->lut_type) {
+    case eMBLookupTable: {          // chains: hashtable[cell] -> next_pos[...], 1-based (CORE/blast_nalookup.c:893-926)
+        const BlastMBLookupTable* t = (const BlastMBLookupTable*)w->lut;
+        for (Int4 c = 0; c < t->hashsize; ++c)
+            for (Int4 i = t->hashtable[c]; i; i = t->next_pos[i]) s_MarkWord(cover, i - 1, t->lut_word_length);
+        break; }
+    case eSmallNaLookupTable: {     // final_backbone: -1 empty, >= 0 one offset, else -(start of a list that a negative value ends) (CORE/na_ungapped.c:82-104)
+        const BlastSmallNaLookupTable* t = (const BlastSmallNaLookupTable*)w->lut;
+        for (Int4 c = 0; c < t->backbone_size; ++c) {
+            const Int4 v = t->final_backbone[c];
+            if (v == -1) continue;
+            if (v >= 0) { s_MarkWord(cover, v, t->lut_word_length); continue; }
+            for (Int4 src = -v; t->overflow[src] >= 0; ++src) s_MarkWord(cover, t->overflow[src], t->lut_word_length);
+        }
+        break; }
+    case eNaLookupTable: {          // thick backbone: up to NA_HITS_PER_CELL offsets in the cell, else a stretch of the overflow array (CORE/na_ungapped.c:113-138)
+        const BlastNaLookupTable* t = (const BlastNaLookupTable*)w->lut;
+        for (Int4 c = 0; c < t->backbone_size; ++c) {
+            const NaLookupBackboneCell& cell = t->thick_backbone[c];
+            const Int4* pos = cell.num_used <= NA_HITS_PER_CELL ? cell.payload.entries : t->overflow + cell.payload.overflow_cursor;
+            for (Int4 i = 0; i < cell.num_used; ++i) s_MarkWord(cover, pos[i], t->lut_word_length);
+        }
+        break; }
+    default:
+        return false;
+    }
+    for (Int4 c = qi->first_context; c <= qi->last_context; c += 2) {           // plus strands; the minus strand mirrors them
+        const Int4 first = qi->contexts[c].query_offset, len = qi->contexts[c].query_length;
+        for (Int4 p = 0; p < len; ) {
+            if (cover[(size_t)(first + p)]) { ++p; continue; }
+            Int4 e = p;
+            while (e + 1 < len && !cover[(size_t)(first + e + 1)]) ++e;
+            mq.push_back((c - qi->first_context) / 2); mfrom.push_back(p); mto.push_back(e);
+            p = e + 1;
+        }
+    }
+    return true;
 }
 
-// The resident shard of this call: the OIDs the iterator hands THIS thread (BlastSeqSrcIteratorNext honours OID
-// lists / GI filters and, with several search threads on one database, gives every thread chunks of its own:
-// GB/gpu_blastn_pre_search_engine.cpp:1243-1252), as stored = 2 bits per base (eBlastEncodingProtein is the toolkit's
-// name for that, CORE/blast_engine.c:1043-1050).  Kept in the library's cache under (device, database name, OIDs)
-// until gpu_ReleaseDBMemory(): the next query batch of the same thread layout finds it there -- the reference's
-// per-OID device cache (GB/gpu_blastn_MB_and_smallNa.cu:1462-1468) as one slab.
-GbnDb* s_GetShard(const BlastSeqSrc* seq_src, int device, Int2* status)
+// The database on the device is a set of BLOCKS: one per chunk of OIDs the sequence source hands out.  The shim asks
+// the source for chunks of the reference's own size (a hundredth of the database, GB/gpu_blastn_pre_search_engine.cpp:1243;
+// the stock CPU threads take the same: CORE/blast_engine.c), so every chunk any thread ever gets is the same stretch
+// [k * chunk, (k + 1) * chunk) of the source's bookmark (CSeqDB::GetNextOIDChunk), whichever of the N search threads
+// asks and whichever query batch is running: the reference's per-OID device cache
+// (GB/gpu_blastn_MB_and_smallNa.cu:1461-1467) at chunk granularity.  A block is uploaded once per device and kept
+// in the library's block cache (gbn_block_cache_*: keyed by device, database name and the OIDs themselves -- no hash
+// that could collide) until gpu_ReleaseDBMemory(); OID lists and GI filters give chunks with holes, cached the same way.
+GbnDb* s_GetBlock(const BlastSeqSrc* seq_src, const std::vector<Int4>& oids, Int2* status)
 {
     *status = 0;
-    std::vector<Int4> oids;
-    BlastSeqSrcIterator* itr = BlastSeqSrcIteratorNewEx(MAX(BlastSeqSrcGetNumSeqs(seq_src) / 100, 1));
-    if (!itr) { *status = -1; return NULL; }
-    for (Int4 oid; (oid = BlastSeqSrcIteratorNext(seq_src, itr)) != BLAST_SEQSRC_EOF; ) {
-        if (oid == BLAST_SEQSRC_ERROR) break;
-        oids.push_back(oid);
-    }
-    BlastSeqSrcIteratorFree(itr);
-    if (oids.empty()) return NULL;                      // nothing left for this thread: not an error
-    uint64_t key = 14695981039346656037ull;
     const char* name = BlastSeqSrcGetName(seq_src);
-    key = s_Mix(key, &device, sizeof device);
-    if (name) key = s_Mix(key, name, strlen(name));
-    key = s_Mix(key, oids.data(), oids.size() * sizeof(Int4));
-    const void* handle = (const void*)(uintptr_t)key;
-    if (GbnDb* db = gbn_db_cache_find(handle)) return db;
+    GbnDb* db = NULL;
+    if (gbn_block_cache_find(name, oids.data(), (int32_t)oids.size(), &db) != GBN_OK) { *status = -1; return NULL; }
+    if (db) return db;
 
     GbnShardBuilder* sb = NULL;
     if (gbn_shard_builder_new(&sb, (int32_t)oids.size()) != GBN_OK) { *status = -1; return NULL; }
     BlastSeqSrcGetSeqArg arg;
     memset(&arg, 0, sizeof arg);
-    arg.encoding = eBlastEncodingProtein;
+    arg.encoding = eBlastEncodingProtein;               // = as stored, 2 bits per base (CORE/blast_engine.c:1043-1050)
     int rc = GBN_OK;
     for (size_t i = 0; i < oids.size() && rc == GBN_OK; ++i) {
         arg.oid = oids[i];
@@ -151,12 +189,12 @@ GbnDb* s_GetShard(const BlastSeqSrc* seq_src, int device, Int2* status)
         BlastSeqSrcReleaseSequence(seq_src, &arg);
     }
     if (arg.seq) BlastSequenceBlkFree(arg.seq);
-    GbnDb* db = NULL;
     if (rc == GBN_OK) rc = gbn_shard_builder_finish(sb, &db);      // uploads the slab, frees the builder's host copy
     gbn_shard_builder_free(sb);
     if (rc != GBN_OK) { *status = -1; return NULL; }
-    if (gbn_db_cache_insert(handle, db) != GBN_OK) { gbn_db_free(db); return gbn_db_cache_find(handle); }
-    return db;
+    GbnDb* kept = NULL;             // (two threads of one device may have built the same block at the same time: the first stays)
+    if (gbn_block_cache_insert(name, oids.data(), (int32_t)oids.size(), db, &kept) != GBN_OK) { gbn_db_free(db); *status = -1; return NULL; }
+    return kept;
 }
 
 struct SListSink { BlastHSPStream* stream; const BlastQueryInfo* query_info; };
@@ -201,9 +239,11 @@ Int2 Blast_gpu_RunPreliminarySearchWithInterrupt(EBlastProgramType program,
         BlastHSPStream* hsp_stream, BlastDiagnostics* diagnostics,
         TInterruptFnPtr interrupt_search, SBlastProgress* progress_info)
 {
-    Int4 word = 0; bool discontiguous = false; const BlastSeqLoc* masked = NULL;
+    Int4 word = 0, lut_word = 0; bool discontiguous = false; const BlastSeqLoc* masked = NULL;
     const bool ours = program == eBlastTypeBlastn && gpu_options && gpu_options->use_gpu &&
-                      lookup_wrap && s_TableShape(lookup_wrap, &word, &discontiguous, &masked) && !discontiguous;
+                      lookup_wrap && s_TableShape(lookup_wrap, &word, &lut_word, &discontiguous, &masked) && !discontiguous;
+    // (psi_options and db_options play no part in a blastn preliminary search: PSSMs are protein, the genetic code is
+    // for translated subjects.  They are passed on untouched to the stock CPU function below and otherwise ignored.)
     const int gpu = ours ? s_FetchGpu() : -1;           // this thread's GPU for the length of the call, -1: none free
     if (gpu < 0)                                        // everything else: the stock CPU path
         return Blast_RunPreliminarySearchWithInterrupt(program, query, query_info, seq_src, score_options,
@@ -235,18 +275,40 @@ Int2 Blast_gpu_RunPreliminarySearchWithInterrupt(EBlastProgramType program,
         lens.push_back(query_info->contexts[c].query_length);
     }
     std::vector<int32_t> mq, mfrom, mto;
-    s_QueryMasks(masked, query_info, mq, mfrom, mto);
+    if (masked) s_QueryMasks(masked, query_info, mq, mfrom, mto);
+    else if (lut_word == word && !s_MasksFromTable(lookup_wrap, query_info, mq, mfrom, mto)) return -1;
+    // (word > lut and no masked_locations: the table was built from the whole query, CORE/blast_nalookup.c:413-417)
 
-    Int2 status = 0;
-    GbnDb* shard = s_GetShard(seq_src, gpu, &status);
-    if (!shard) return status;                          // (no OIDs left for this thread: success, nothing to write)
+    // Chunks of OIDs are fetched and searched one after the other, as the reference's loop does (GB/...engine.cpp:
+    // 1243-1290): N search threads (GPU-leased or on the stock CPU path) share the source's bookmark, nobody drains it.
+    // The query batch is set up once per call; every chunk is a resident block (s_GetBlock).
     GbnBatch* batch = NULL; GbnDiagnostics d; memset(&d, 0, sizeof d);
     SListSink sink = { hsp_stream, query_info };
     SInterrupt intr = { interrupt_search, progress_info };
-    int rc = gbn_batch_new_masked(&batch, &o, (int32_t)seqs.size(), seqs.data(), lens.data(),
-                                  (int32_t)mq.size(), mq.data(), mfrom.data(), mto.data(), 1);
-    if (rc == GBN_OK)
-        rc = gbn_prelim_search_lists(batch, shard, s_WriteList, &sink, &d, interrupt_search ? s_Interrupt : NULL, &intr);
+    int rc = GBN_OK;
+    BlastSeqSrcIterator* itr = BlastSeqSrcIteratorNewEx(MAX(BlastSeqSrcGetNumSeqs(seq_src) / 100, 1));
+    if (!itr) return -1;
+    std::vector<Int4> oids;
+    for (bool more = true; more && rc == GBN_OK; ) {
+        oids.clear();
+        for (;;) {                                      // one chunk: until the iterator has used up what the source gave it
+            const Int4 oid = BlastSeqSrcIteratorNext(seq_src, itr);
+            if (oid == BLAST_SEQSRC_EOF) { more = false; break; }
+            if (oid == BLAST_SEQSRC_ERROR) { more = false; rc = GBN_ERR_ARG; break; }
+            oids.push_back(oid);
+            if (itr->current_pos == UINT4_MAX) break;
+        }
+        if (oids.empty() || rc != GBN_OK) break;
+        Int2 status = 0;
+        GbnDb* block = s_GetBlock(seq_src, oids, &status);
+        if (!block) { rc = status ? GBN_ERR_HIP : GBN_OK; if (status) break; continue; }
+        if (!batch)
+            rc = gbn_batch_new_masked(&batch, &o, (int32_t)seqs.size(), seqs.data(), lens.data(),
+                                      (int32_t)mq.size(), mq.data(), mfrom.data(), mto.data(), 1);
+        if (rc == GBN_OK)
+            rc = gbn_prelim_search_lists(batch, block, s_WriteList, &sink, &d, interrupt_search ? s_Interrupt : NULL, &intr);
+    }
+    BlastSeqSrcIteratorFree(itr);
     if (rc == GBN_OK && diagnostics) {                  // (per-thread counters; the caller's structure may be shared: COREI/blast_diagnostics.h:118-126)
         if (diagnostics->ungapped_stat) {
             diagnostics->ungapped_stat->lookup_hits += d.lookup_hits;
@@ -259,7 +321,7 @@ Int2 Blast_gpu_RunPreliminarySearchWithInterrupt(EBlastProgramType program,
             diagnostics->gapped_stat->num_seqs_passed += (Int4)d.seqs_passed;
         }
     }
-    gbn_batch_free(batch);                              // the derived search parameters are the callee's; the shard stays cached
+    if (batch) gbn_batch_free(batch);                   // the derived search parameters are the callee's; the blocks stay cached
     return rc == GBN_OK ? 0 : (rc == GBN_ERR_INTERRUPTED ? BLASTERR_INTERRUPTED : -1);
 }
 

@@ -162,6 +162,14 @@ long gbn_debug_check_guards(void);  /* tests, GBN_GUARD=1: guard zones around ev
 struct GbnDb;
 struct GbnDb *gbn_db_cache_find(const void *key);
 int  gbn_db_cache_insert(const void *key, struct GbnDb *db);
+/* The block cache (the shim's resident database: one shard per OID chunk of the sequence source, replacing the reference's
+ * per-OID device cache GB/gpu_blastn_MB_and_smallNa.cu:1461-1467): keyed by (device, database name, the OIDs
+ * themselves), whatever thread or query batch asks.  find: *out = the resident block on the calling thread's device or
+ * NULL.  insert: the cache takes `db`; if the block is there already (built twice at the same time) `db` is freed and
+ * *kept is the one that stays.  gbn_release_db_memory frees the blocks too. */
+int  gbn_block_cache_find(const char *db_name, const int32_t *oids, int32_t n, struct GbnDb **out);
+int  gbn_block_cache_insert(const char *db_name, const int32_t *oids, int32_t n, struct GbnDb *db, struct GbnDb **kept);
+long long gbn_debug_db_bytes_uploaded(void);    /* tests: slab bytes copied host -> device by gbn_db_new / the shard builder so far */
 
 /* ---- database shard resident in HBM ---- */
 typedef struct GbnDb GbnDb;

@@ -504,3 +504,81 @@ def test_device_built_tables_of_the_de_bruijn_queries(task, n, kw):
     ora, s = util.oracle_run(opt, [q], [(packed, slen)])
     util.compare_stages(gpu, ora)
     assert len(gpu["hsps"]) >= 1
+
+
+@pytest.mark.gpu
+def test_block_cache_under_two_threads_and_changing_chunkings():
+    """The shim's resident database (gbn_block_cache_*): N search threads pull OID chunks from ONE shared
+    bookmark, as the reference's CPrelimSearchThreads do (API/prelim_search_runner.hpp:135-166), so which thread gets which
+    chunk changes from query batch to query batch.  Blocks are keyed by what they hold: the first batch uploads every block
+    once, the second -- other threads, other order -- uploads NOTHING, and the lists of both equal one search over the
+    whole database."""
+    import threading
+    L = api.lib()
+    L.gbn_release_db_memory()
+    nsub, slen, chunk = 23, 30000, 4
+    db, queries, plants, subjects, opt = util.small_case(nsub, slen, 10, qlen=800, seed=21)
+    want = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed(subjects)).run()["hsps"]
+    assert len(want) > 0
+
+    def get_block(oids):
+        arr = np.asarray(oids, dtype=np.int32)
+        h = C.c_void_p()
+        api._check(L.gbn_block_cache_find(b"synthetic_db", arr.ctypes.data, len(arr), C.byref(h)))
+        if h.value:
+            return h
+        sb = C.c_void_p()
+        api._check(L.gbn_shard_builder_new(C.byref(sb), len(arr)))
+        for o in oids:
+            p, n = subjects[o]
+            a = np.ascontiguousarray(p[:(n + 3) // 4])
+            api._check(L.gbn_shard_builder_add_oid(sb, int(o), a.ctypes.data, n))
+        api._check(L.gbn_shard_builder_finish(sb, C.byref(h)))
+        L.gbn_shard_builder_free(sb)
+        kept = C.c_void_p()
+        api._check(L.gbn_block_cache_insert(b"synthetic_db", arr.ctypes.data, len(arr), h, C.byref(kept)))
+        return kept
+
+    def one_batch(nthreads, delays):
+        bookmark = [0]; mu = threading.Lock(); lists = []; errs = []
+
+        def worker(t):
+            try:
+                L.gbn_use_device(0)
+                ps = api.BlastPrelimSearch(queries, opt)            # the thread's own query batch, as in the shim
+                got = []
+
+                @api.GbnHspListFn
+                def sink(arg, oid, hsps, n):
+                    a = np.ctypeslib.as_array(C.cast(hsps, C.POINTER(C.c_uint8)), shape=(n * api.HSP_DT.itemsize,)).view(api.HSP_DT).copy()
+                    got.append((oid, a))
+                    return 0
+                import time
+                while True:
+                    with mu:
+                        first = bookmark[0]; bookmark[0] += chunk
+                    if first >= nsub:
+                        break
+                    time.sleep(delays[t])                           # (shifts which thread is back first for the next chunk)
+                    blk = get_block(list(range(first, min(first + chunk, nsub))))
+                    api._check(L.gbn_prelim_search_lists(ps._b, blk, sink, None, None, None, None))
+                with mu:
+                    lists.extend(got)
+                ps.close()
+            except Exception as e:      # noqa
+                errs.append(repr(e))
+        th = [threading.Thread(target=worker, args=(t,)) for t in range(nthreads)]
+        [t.start() for t in th]; [t.join() for t in th]
+        assert not errs, errs
+        lists.sort(key=lambda x: x[0])
+        return np.concatenate([a for _, a in lists]) if lists else np.zeros(0, dtype=api.HSP_DT)
+
+    up0 = L.gbn_debug_db_bytes_uploaded()
+    first = one_batch(2, [0.0, 0.02])
+    up1 = L.gbn_debug_db_bytes_uploaded()
+    second = one_batch(3, [0.03, 0.0, 0.01])
+    up2 = L.gbn_debug_db_bytes_uploaded()
+    assert up1 - up0 >= nsub * slen // 4            # every block went up once ...
+    assert up2 == up1                               # ... and never again
+    assert first.tobytes() == want.tobytes() and second.tobytes() == want.tobytes()
+    L.gbn_release_db_memory()
