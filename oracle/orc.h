@@ -160,6 +160,8 @@ void orc_extension_params(double min_lambda, double gap_x_dropoff_bits, double g
 void orc_debruijn(int32_t n, int32_t k, uint8_t *output);
 /* the lookup table of one sequence, one strand, as the reference's lookup-table unit tests build it; out[12]: see orc_lookup.c */
 int orc_lookup_probe(const OrcOptions *opt, const uint8_t *seq, int32_t len, int64_t *out);
+/* positions of the concatenated query inside a word of the lookup table (cover[orc_query_concat_len]) */
+void orc_search_indexed_cover(const OrcSearch *s, uint8_t *cover);
 /* Blast_ExtendWordExit (CORE/blast_extend.c:166-190); known answers UT/blastdiag_unit_test.cpp:45-150 */
 int orc_extend_word_exit(int32_t *offset, int32_t window, int32_t subject_length, int32_t *last_hit, uint32_t *flag, int32_t n);
 /* CORE/blast_stat.c:3806 */

@@ -242,3 +242,22 @@ int orc_lookup_probe(const OrcOptions *opt, const uint8_t *seq, int32_t len, int
     orc_lookup_free(l);
     return 0;
 }
+
+/* Which positions of the concatenated query lie inside a word of the table: cover[p] = 1.  With lut = word this is what
+ * the reference's table still knows about the soft masks it was built with when it keeps no masked_locations
+ * (CORE/blast_nalookup.c:413-417): the shim rebuilds the masks from it (gblastn_amd/shim: s_MasksFromTable, walking
+ * the table the way the lookup callbacks of CORE/na_ungapped.c:51-138 do), tests/test_oracle_golden.py checks the idea. */
+void orc_search_indexed_cover(const OrcSearch *S, uint8_t *cover)
+{
+    const OrcLookup *l = S->lut; int32_t c, i, k;
+    for (i = 0; i < S->qlen; i++) cover[i] = 0;
+    for (c = 0; c < l->ncells; c++) {
+        if (l->type == ORC_LUT_MB) {
+            for (i = l->hashtable[c]; i; i = l->next_pos[i])
+                for (k = 0; k < l->lut_word_length && i - 1 + k < S->qlen; k++) cover[i - 1 + k] = 1;
+        } else {
+            for (i = l->cell_start[c]; i < l->cell_start[c + 1]; i++)
+                for (k = 0; k < l->lut_word_length && l->cell_offs[i] + k < S->qlen; k++) cover[l->cell_offs[i] + k] = 1;
+        }
+    }
+}

@@ -336,3 +336,54 @@ def test_blastoptions_GetNucleotideGapExistenceExtendParams():
     assert params(1, -3, -1, -1) == (0, 2, 2)
     assert params(2, -5, -1, -1) == (0, 4, 4)
     assert params(1, -2, -1, -1) == (0, 2, 2)
+
+
+def masks_from_table_cover(s, queries):
+    """what gblastn_amd/shim s_MasksFromTable does with the reference's table when it keeps no masked_locations
+    (lookup word = search word): the complement, per plus strand, of the positions inside an indexed word"""
+    L = orc.lib()
+    L.orc_search_indexed_cover.argtypes = [C.c_void_p, C.c_void_p]
+    L.orc_query_concat_len.restype = C.c_int32; L.orc_query_concat_len.argtypes = [C.c_void_p]
+    cover = np.zeros(L.orc_query_concat_len(s._h), dtype=np.uint8)
+    L.orc_search_indexed_cover(s._h, cover.ctypes.data)
+    ctx = s.contexts
+    masks = []
+    for qi in range(len(queries)):
+        c = ctx[2 * qi]
+        cov = cover[c.query_offset:c.query_offset + c.query_length]
+        p = 0
+        while p < len(cov):
+            if cov[p]:
+                p += 1; continue
+            e = p
+            while e + 1 < len(cov) and not cov[e + 1]:
+                e += 1
+            masks.append((qi, p, e)); p = e + 1
+    return masks
+
+
+def test_masks_rebuilt_from_the_table_give_the_table_back():
+    # blastn, 16 queries: word 11 = lut 11 (the C3 shape), where the reference keeps no masked_locations.  Soft masks
+    # (DUST-like intervals, one short stretch between two masks, one next to an ambiguity code) -> table -> cover ->
+    # masks' -> the same seeds, initial hits and HSPs
+    rng = np.random.default_rng(17)
+    queries = [rng.integers(0, 4, 1000, dtype=np.uint8) for _ in range(16)]
+    queries[3][500] = 14                                  # an ambiguity code
+    subj = rng.integers(0, 4, 60000, dtype=np.uint8)
+    for k, q in enumerate(queries[:8]):
+        subj[2000 + 3000 * k:2000 + 3000 * k + 600] = np.where(q[200:800] > 3, 0, q[200:800])
+    masks = [(0, 250, 330), (0, 336, 400), (1, 0, 120), (2, 900, 999), (3, 480, 495), (5, 300, 700)]
+    opt = orc.default_options(False, db_length=len(subj), db_num_seqs=1)
+    a = orc.Search(opt, queries, masks=masks)
+    assert (a.info()["lut_width"], a.info()["scan_step"]) == (11, 1)
+    rebuilt = masks_from_table_cover(a, queries)
+    assert rebuilt != sorted(masks)                       # (short stretches and the ambiguity widen them)
+    b = orc.Search(opt, queries, masks=rebuilt)
+    packed = orc.pack_ncbi2na(subj)
+    ra, rb = a.subject(packed, len(subj)), b.subject(packed, len(subj))
+    assert len(ra["seeds"]) > 1000 and len(ra["hsps"]) >= 8
+    for k in ("seeds", "init_hits", "hsps"):
+        assert ra[k].tobytes() == rb[k].tobytes(), k
+    # and an unmasked search differs: the masks matter in this case
+    rc = orc.Search(opt, queries).subject(packed, len(subj))
+    assert len(rc["seeds"]) != len(ra["seeds"])
