@@ -38,28 +38,40 @@ def gather_records(records, dst=0, device=None, group=None, force=False):
     """Gather a 1-D structured numpy array from every rank to `dst`.
 
     Returns the concatenation in rank order on `dst` (ascending global OID when shards are contiguous blocks of
-    OIDs), None elsewhere.  force: run the collectives even in a group of one (exercises the backend)."""
+    OIDs), None elsewhere.  force: run the collectives even in a group of one (exercises the backend).
+
+    One all-gather of the byte counts (ONE read-back per exchange: the sizes are needed on the host to size the
+    receive buffer), then point-to-point transfers of exactly those sizes into their places of one buffer on `dst`
+    -- nothing is padded to the largest shard, nothing is sent by a rank that found nothing (round 3: a padded
+    `gather` sized by the largest shard and a `.item()` per rank)."""
     if not (_active(group) or (force and dist.is_initialized())):
         return records
     world, rank = dist.get_world_size(group), dist.get_rank(group)
     dev = device if device is not None else torch.device("cpu")
     raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
-    count = torch.tensor([raw.size], dtype=torch.int64, device=dev)
-    counts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
-    dist.all_gather(counts, count, group=group)
-    sizes = [int(c.item()) for c in counts]
-    cap = max(max(sizes), 1)
-    buf = torch.zeros(cap, dtype=torch.uint8, device=dev)
+    mine = torch.tensor([raw.size], dtype=torch.int64, device=dev)
+    counts = torch.zeros(world, dtype=torch.int64, device=dev)
+    try:
+        dist.all_gather_into_tensor(counts, mine, group=group)
+    except (RuntimeError, NotImplementedError):        # a backend without the flat form
+        parts = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(world)]
+        dist.all_gather(parts, mine, group=group)
+        counts = torch.cat(parts)
+    sizes = [int(v) for v in counts.tolist()]
+    peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
+    if rank != dst:
+        if raw.size:
+            dist.send(torch.from_numpy(raw.copy()).to(dev), dst=peer(dst), group=group)
+        return None
+    out = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device=dev)
+    offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     if raw.size:
-        buf[:raw.size] = torch.from_numpy(raw.copy()).to(dev)
-    if rank == dst:
-        parts = [torch.zeros(cap, dtype=torch.uint8, device=dev) for _ in range(world)]
-        dist.gather(buf, parts, dst=dst, group=group)
-        out = [p[:n].cpu().numpy() for p, n in zip(parts, sizes)]
-        cat = np.concatenate(out) if out else np.zeros(0, dtype=np.uint8)
-        return cat.view(records.dtype)
-    dist.gather(buf, None, dst=dst, group=group)
-    return None
+        out[int(offs[rank]):int(offs[rank + 1])] = torch.from_numpy(raw.copy()).to(dev)
+    reqs = [dist.irecv(out[int(offs[r]):int(offs[r + 1])], src=peer(r), group=group)
+            for r in range(world) if r != dst and sizes[r] > 0]
+    for q in reqs:
+        q.wait()
+    return out[:int(offs[world])].cpu().numpy().view(records.dtype)
 
 
 def gather_parts(records, dst=0, device=None, group=None):

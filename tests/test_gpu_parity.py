@@ -601,3 +601,28 @@ def test_slice_scan_with_repeats_that_overflow_a_segment():
     ora2, s2 = util.oracle_run(opt, queries, [subjects[0], subjects[2], subjects[3]])
     util.compare_stages(gpu2, ora2)
     assert ps2.diagnostics.scan_launches == 1
+
+
+@pytest.mark.parametrize("task,period", [("megablast", 5), ("megablast", 13), ("blastn", 3)])
+def test_repeats_in_the_queries_give_long_cells(task, period):
+    """Queries that carry a short-period repeat put hundreds of offsets into a few cells of the table, in descending
+    order for the megablast table and ascending for the others (the device builder's sort key: lutbuild.hip); the seed
+    list -- in the reference's order, which is the order inside the cells -- the initial hits and the HSPs equal the
+    oracle's.  (Written with round 4's counting-sort builder, which passed it and was not kept: profiles/r04_lut_builder.txt.)"""
+    from oracle import orc
+    rng = np.random.default_rng(100 + period)
+    unit = rng.integers(0, 4, period, dtype=np.uint8)
+    nq = 24 if task == "megablast" else 14
+    queries = [rng.integers(0, 4, 1000, dtype=np.uint8) for _ in range(nq)]
+    for qi in range(0, nq, 3):
+        queries[qi][100:900] = np.tile(unit, 800 // period + 1)[:800]
+    subj = rng.integers(0, 4, 120_000, dtype=np.uint8)
+    subj[10_000:10_400] = np.tile(unit, 400 // period + 1)[:400]         # the repeat: every seed of it hits the long cells
+    subj[50_000:50_700] = queries[1][150:850]
+    subjects = [(orc.pack_ncbi2na(subj), len(subj))]
+    opt = api.default_options(task, db_length=len(subj), db_num_seqs=1)
+    ps = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed(subjects))
+    gpu = ps.run(keep_stages=True)
+    ora, s = util.oracle_run(opt, queries, subjects)
+    util.compare_stages(gpu, ora)
+    assert ps.diagnostics.lookup_hits == s.stats.lookup_hits and len(gpu["seeds"]) > 500
