@@ -811,12 +811,17 @@ probe_bin_kernel(GbnBinParams B)
         bool keep = false; uint32_t at_rec = 0, cv = 0;
         if (lane < cnt) {
             at_rec = q[first + lane].x;                             // record index inside the bin's region
-            const uint32_t y = q[first + lane].y;
-            const uint32_t low = y & 0x7fffu, sf = (y >> 15) & 0x7fffu;
+            // The queue holds nothing but that index: the record itself is read again here, once per 64 queued records
+            // (the main loop picked it out of its eight registers with a chain of selects and looked its cell up a
+            // second time for every queued record -- a third of the loop's instructions for 0.7 % of the records).
+            const uint32_t wr = at_rec / B.subcap, jr = at_rec - wr * B.subcap;
+            const uint32_t hv = B.rec[GBN_REC_HI(GBN_RECIDX(B, bin, wr, jr))];
+            const uint32_t low = hv & 0x7fffu, sf = (hv >> 16) & 0x7fffu;
             cv = ((uint32_t)bin << cbits) | low;
             keep = true;
-            if (y >> 31) {                                          // cell with >= 3 entries
-                const uint32_t t = tab[low];
+            const uint32_t t = tab[low];
+            if ((t & 0x8000u) == 0) {                               // queued and not a one- or two-entry cell: three or more entries
+                raw -= 1;                                           // (the main loop counted it as one lookup hit)
                 const uint32_t n3 = (t >> 16) & 0x7fffu, so = t & 0x7fffu;
                 if (n3 == 0) cv |= 0x80000000u;                     // always-rare cell: raw hits counted later
                 else {
@@ -922,15 +927,7 @@ probe_bin_kernel(GbnBinParams B)
                     if (slowm) {
                         const uint32_t r = (uint32_t)__ffs(slowm) - 1u;
                         slowm &= slowm - 1;
-                        uint32_t hi32 = 0;
-                        #pragma unroll
-                        for (uint32_t k = 0; k < NR; k++) hi32 = (r == k) ? hv[k] : hi32;
-                        const uint32_t t = s_tab[(int32_t)(hi32 & 0xffffu) + tadj];
-                        const bool many = ((t & 0x8000u) == 0);                         // only c1: three or more entries
-                        raw32 -= many ? 1u : 0u;
-                        const int at = qn + __popcll(m & lt);
-                        q[at].x = rbase + j0 + (r >> 2) * 256u + (uint32_t)lane * 4u + (r & 3u);
-                        q[at].y = (hi32 & 0x7fffu) | (((hi32 >> 16) & 0x7fffu) << 15) | (many ? 0x80000000u : 0u);
+                        q[qn + __popcll(m & lt)].x = rbase + j0 + (r >> 2) * 256u + (uint32_t)lane * 4u + (r & 3u);
                     }
                     qn += __popcll(m);
                     if (qn >= 64) { qn -= 64; flush(qn, 64, b); }
