@@ -15,6 +15,7 @@
 #include "gblastn_amd_host.hpp"
 #include <algorithm>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -147,7 +148,9 @@ int main(int argc, char **argv)
     const int32_t nvol = gbn_blastdb_num_volumes(bdb);
     int nparts = a.count("num_threads") ? std::max(1, std::atoi(a["num_threads"].c_str())) : (int)devices.size();
     nparts = std::max(1, std::min(nparts, (int)nvol));                  // (a volume is not split)
-    struct Part { int device; GbnDb *shard = nullptr; };
+    // (per part, for the table -stage prelim prints at the end: bases its shard holds, what its search thread scanned, the
+    // wall time of its preliminary searches added up, and the time spent waiting for its results)
+    struct Part { int device; GbnDb *shard = nullptr; long long scanned = 0; double prelim_ms = 0, scan_kernel_ms = 0; long long batches = 0; };
     std::vector<Part> parts((size_t)nparts);
     {   // shard_bounds of gblastn_amd/shard.py: part p holds volumes [p * V / P, (p + 1) * V / P); loaded in parallel
         std::vector<std::future<std::string>> loads;
@@ -286,6 +289,7 @@ int main(int argc, char **argv)
     };
 
     GbnDiagnostics diag; std::memset(&diag, 0, sizeof(diag));
+    const auto t_search = std::chrono::steady_clock::now();
     try {
         // one pipeline (set-up threads -> search thread -> traceback consumers) per part, each on its part's GPU: the
         // search threads of the reference with a GPU each (API/prelim_search_runner.hpp:135-166, GB/gpu_blast_multi_gpu_utils.cpp:105-139)
@@ -304,11 +308,13 @@ int main(int argc, char **argv)
             }
             if (submitted == batches.size()) for (auto &pp : pipes) pp->Finish();
             std::vector<gbn::CSearchPipeline::TItem> items;
-            for (auto &pp : pipes) {
+            for (size_t pi = 0; pi < pipes.size(); pi++) {
+                auto &pp = pipes[pi];
                 gbn::CSearchPipeline::TItem it = pp->Next();
                 if (!it) die("the pipeline ended early");
                 if (it->status != GBN_OK) die(it->error);
                 const GbnDiagnostics &d = it->prelim->diagnostics;
+                parts[pi].scanned += d.subject_bases_scanned; parts[pi].prelim_ms += d.total_ms; parts[pi].scan_kernel_ms += d.scan_kernel_ms; parts[pi].batches++;
                 diag.subject_bases_scanned += d.subject_bases_scanned; diag.seeds += d.seeds; diag.gapped_extensions += d.gapped_extensions;
                 diag.total_ms = std::max(diag.total_ms, d.total_ms);
                 items.push_back(std::move(it));
@@ -343,9 +349,23 @@ int main(int argc, char **argv)
         }
         for (auto &pp : pipes) pp->Close();
     } catch (const gbn::CBlastException &e) { die(e.what()); }
+    const double wall_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_search).count();
     std::fprintf(stderr, "blastn_prelim: %zu queries in %zu batches, %lld subject bases scanned, %lld seeds, %lld gapped extensions, %.1f ms in the preliminary stage\n",
                  queries.size(), batches.size(), (long long)diag.subject_bases_scanned, (long long)diag.seeds,
                  (long long)diag.gapped_extensions, diag.total_ms);
+    if (!with_traceback) {
+        // -stage prelim: the scaling self-check.  One line per part (= search thread, on its device), then the whole run:
+        // run it with -gpu_id 0 and with -gpu_id -1 on a node of N GPUs and the last lines give the 1 / N table.
+        std::fprintf(stderr, "# part device shard_Mbp batches scanned_Gbp prelim_search_ms scan_kernels_ms Gbp_per_s_of_its_searches\n");
+        long long all = 0;
+        for (size_t pi = 0; pi < parts.size(); pi++) {
+            const Part &pt = parts[pi]; all += pt.scanned;
+            std::fprintf(stderr, "# %zu %d %.1f %lld %.3f %.1f %.1f %.1f\n", pi, pt.device, gbn_db_total_bases(pt.shard) / 1e6, pt.batches,
+                         pt.scanned / 1e9, pt.prelim_ms, pt.scan_kernel_ms, pt.prelim_ms > 0 ? pt.scanned / 1e9 / (pt.prelim_ms * 1e-3) : 0.0);
+        }
+        std::fprintf(stderr, "# total: %zu parts on %zu devices, %.3f Gbp scanned in %.1f ms wall (first batch submitted to last batch printed) = %.1f Gbp/s\n",
+                     parts.size(), devices.size(), all / 1e9, wall_ms, wall_ms > 0 ? all / 1e9 / (wall_ms * 1e-3) : 0.0);
+    }
     if (out != stdout) std::fclose(out);
     for (Part &pt : parts) gbn_db_free(pt.shard);
     gbn_blastdb_close(bdb); gbn_release();

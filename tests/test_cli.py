@@ -206,4 +206,10 @@ def test_cli_search_threads_over_database_parts_give_the_rows_of_one(tmp_path, t
                            capture_output=True, text=True, timeout=600, env=env)
         assert p.returncode == 0, p.stderr[-2000:]
         rows[n] = out.read_text().splitlines()
+        if stage == "prelim":       # the scaling self-check: a line per part and the run's total (what a node of N GPUs prints its 1 / N table with)
+            tab = [l for l in p.stderr.splitlines() if l.startswith("# ")]
+            parts = [l.split() for l in tab if l[2].isdigit()]
+            assert len(parts) == int(n) and all(int(x[4]) >= 1 and float(x[6]) > 0 for x in parts), p.stderr[-1500:]
+            total = [l for l in tab if l.startswith("# total:")]
+            assert len(total) == 1 and ("%d parts" % int(n)) in total[0] and "Gbp/s" in total[0]
     assert len(rows["1"]) >= 4 and rows["1"] == rows["2"]

@@ -140,3 +140,42 @@ def test_full_size_c4_streamed_batches_final_rows_against_the_oracle(monkeypatch
         total += compare(prod, ora)                             # same set of (query, subject) lists, same rows, same scripts
         s.close()
     assert total >= 0.15 * per * nbatch                         # ~20 % of the queries carry a planted homolog
+
+
+def test_two_batch_c2_config_with_one_shared_binning_pass_gives_identical_results():
+    """bench.py's config_wall_ms_shared_binning: the two 5,000-query batches of the C2 config (10,000 x 1 kb vs the 50 Gbp
+    shard) probed against ONE binning pass (GBN_REUSE_BINNING=1: the scan records depend on the shard and the table shape
+    only) -- at full size, the HSPs of both batches equal those of two full passes, and the second batch runs no binning
+    kernel."""
+    import json, os, sys
+    code = r'''
+import sys, json, hashlib, numpy as np, torch
+sys.path.insert(0, %r)
+from gblastn_amd import api, synth
+nsub, slen = 50000, 1000000
+db = synth.SynthDb(nsub, slen, seed=0x9E3779B97F4A7C15 ^ 1)
+slab = torch.empty(db.nbytes, dtype=torch.uint8, device="cuda")
+api._check(api.lib().gbn_synth_fill(slab.data_ptr(), db.nbytes, db.seed, None))
+src = api.BlastSeqSrc.from_slab((slab.data_ptr(), db.nbytes), db.byte_off, db.lens, is_device=True, keep=slab)
+queries, plants = synth.make_queries(10000, db)
+opt = api.default_options("megablast", db_length=nsub * slen, db_num_seqs=nsub)
+out = []
+for k in range(2):
+    ps = api.BlastPrelimSearch(queries[k * 5000:(k + 1) * 5000], opt, src)
+    assert (ps.info()["lut_width"], ps.info()["scan_step"]) == (12, 17)
+    h = ps.run()["hsps"]
+    out.append([hashlib.sha256(h.tobytes()).hexdigest(), int(len(h)), float(ps.diagnostics.bin_kernel_ms), float(ps.diagnostics.probe_kernel_ms)])
+    ps.close()
+print(json.dumps(out))
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ); env["GBN_REUSE_BINNING"] = flag
+        for k in ("GBN_SCAN_BINS", "GBN_RANGE_MIB", "GBN_RANGE_TILES", "GBN_RANGE_GIB"):
+            env.pop(k, None)
+        p = util.run_child([sys.executable, "-c", code], env=env, timeout=900)
+        res[flag] = json.loads(p.stdout.strip().splitlines()[-1])
+    assert [r[:2] for r in res["0"]] == [r[:2] for r in res["1"]]
+    assert res["0"][0][1] > 100 and res["0"][1][1] > 100           # both batches find their planted homologs
+    assert res["1"][0][2] > 1.0 and res["1"][1][2] < 0.5           # shared: the second batch ran no binning kernel (an empty event interval)
+    assert res["0"][1][2] > 1.0                                    # two full passes: it did
