@@ -1,13 +1,9 @@
 // kernels.hip -- hand-written HIP kernels (gfx950 / CDNA4) for the blastn /
 // megablast preliminary search.  Integer work only: no MFMA.
 //
-//   scan_bin_kernel*     phase 1 of the key-range partitioned scan: every scan position of the
-//                        subjects becomes a 6-byte record in the stream of its lookup word's bin
-//   probe_bin_kernel     phase 2: a bin's slice of the cell table in LDS, its records streamed through
-//   probe_rare_kernel    phase 3: exact verification of the survivors to word_size
-//                        (together: TNaScanSubjectFunction + TNaExtendFunction mini-extension;
-//                        CORE/blast_nascan.c, CORE/na_ungapped.c:1025-1555)
-//   scan_seed_kernel     the same work by direct table probes, without streams (fallback for
+//   (the key-range partitioned scan -- scan_bin_kernel*, probe_bin_kernel, probe_rare_kernel: TNaScanSubjectFunction +
+//   the TNaExtendFunction mini-extension for tables too large for L2 -- lives in scan_bin.hip since round 4)
+//   scan_seed_kernel     that work by direct table probes, without streams (fallback for
 //                        repeat-dominated subject ranges)
 //   scan_slice_kernel    the same work for tables as wide as the word (blastn shapes: stride 1, every
 //                        lookup hit a seed): the presence bits sliced through the LDS, the subjects
