@@ -52,6 +52,21 @@ hipError_t sort_keys_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint
 static thread_local std::string g_err;
 void set_error(const std::string &m) { g_err = m; }
 
+// the switch table (gbn_dev.h)
+static std::mutex g_switch_mu;
+static std::map<std::string, std::pair<bool, long long>> g_switches;
+static std::pair<bool, long long> switch_entry(const char *name) {
+    std::lock_guard<std::mutex> lk(g_switch_mu);
+    auto it = g_switches.find(name);
+    if (it == g_switches.end()) {
+        const char *e = getenv(name);
+        it = g_switches.emplace(name, std::make_pair(e != nullptr, e ? atoll(e) : 0ll)).first;
+    }
+    return it->second;
+}
+long long switch_value(const char *name, long long dflt) { const auto e = switch_entry(name); return e.first ? e.second : dflt; }
+bool switch_is_set(const char *name) { return switch_entry(name).first; }
+
 // GBN_TRACE=1: wall-clock marks of the host-side pipeline on stderr (ms since the first mark)
 void trace_mark(const char *what) {
     static const bool on = getenv("GBN_TRACE") && atoi(getenv("GBN_TRACE")) != 0;
@@ -488,7 +503,7 @@ static int build_tables_on_device(GbnBatch &b) {
     // Megablast / standard tables need nothing back on the host: the whole build is queued on the builder's
     // stream, sized by upper bounds (at most one word per query position), and the batch carries an event;
     // the engine lets the probe kernel wait for it -- the binning kernel of the search starts at once.
-    static const bool sync_build = getenv("GBN_SYNC_BUILD") && atoi(getenv("GBN_SYNC_BUILD")) != 0;
+    const bool sync_build = gbn::switch_value("GBN_SYNC_BUILD", 0) != 0;
     if (L.type != GBN_LUT_SMALL_NA && !sync_build) {
         LUTCHK(hipMemsetAsync(keys_a, 0xff, qn * 8, st));           // positions without a word sort behind the words
         LUTCHK(lut_enumerate(B, st));
@@ -584,7 +599,7 @@ int upload_batch(GbnBatch &b) {
         d->fl = std::min(8, h); d->fr = std::min(7, e - h + 1);
         if (e == 0) { d->fl = 0; d->fr = 0; }
     }
-    static const bool host_lookup = getenv("GBN_HOST_LOOKUP") && atoi(getenv("GBN_HOST_LOOKUP")) != 0;
+    const bool host_lookup = gbn::switch_value("GBN_HOST_LOOKUP", 0) != 0;
     if ((rc = dev_upload(d->q8_base, b.qbuf.data(), b.qbuf.size()))) return rc;
     d->q8 = d->q8_base + b.qpad;
     {   // packed copy for the greedy kernel's 32-bases-per-step match runs, made on the device from q8
@@ -711,7 +726,7 @@ static int grow_key_buffers(Engine::KeySet &KS, size_t n) {
     if ((rc = dev_alloc(KS.key_a, cap)) || (rc = dev_alloc(KS.key_b, cap)) || (rc = dev_alloc(KS.idx_a, cap)) ||
         (rc = dev_alloc(KS.idx_b, cap)) || (rc = dev_alloc(KS.cell_diag, cap)) || (rc = dev_alloc(KS.cell_level, cap)))
         return rc;
-    static const size_t compact_min = getenv("GBN_DIAG_COMPACT_MIN") ? (size_t)atoll(getenv("GBN_DIAG_COMPACT_MIN")) : (size_t)GBN_DIAG_COMPACT_MIN;
+    const size_t compact_min = (size_t)gbn::switch_value("GBN_DIAG_COMPACT_MIN", (long long)GBN_DIAG_COMPACT_MIN);
     if (cap >= compact_min && (rc = dev_alloc(KS.ext_rec, cap * 8))) return rc;
     size_t bytes = 0;
     HIPCHK(sort_pairs_u64(nullptr, bytes, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, (int64_t)cap, 64, E.stream));
@@ -820,13 +835,13 @@ static int scan_grid(int64_t ntiles) {
 static int choose_bins(const GbnBatch &b) {
     int64_t nb = b.lut.ncells >> GBN_BIN_CBITS(b.lut.lut);
     if (nb < 2 || nb > GBN_BIN_MAXNB) nb = 1;
-    if (const char *e = getenv("GBN_SCAN_BINS")) { if (atoi(e) == 1) nb = 1; }
+    if (gbn::switch_value("GBN_SCAN_BINS", 0) == 1) nb = 1;
     return (int)nb;
 }
 
 // slices scan_slice_kernel would cut this batch's presence bits into (0: another kernel scans for this batch)
 static int scan_slices(const GbnBatch &b) {
-    static const bool on = !(getenv("GBN_SCAN_SLICE") && atoi(getenv("GBN_SCAN_SLICE")) == 0);
+    const bool on = gbn::switch_value("GBN_SCAN_SLICE", 1) != 0;
     if (!on || !b.dev || choose_bins(b) == 1) return 0;     // (tables of one bin: the direct kernel as before; GBN_SCAN_BINS=1 forces it)
     GbnScanParams P; std::memset(&P, 0, sizeof(P));
     P.mode = b.dev->mode; P.step = b.lut.step; P.lut = b.lut.lut; P.word = b.lut.word; P.ncells = b.lut.ncells;
@@ -854,7 +869,7 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
     int64_t bases = 0;
     for (int32_t s = s0; s < s1; s++) bases += db.len[s];
     int64_t split_mb = 256;
-    if (const char *e = getenv("GBN_SKEW_SPLIT_MB")) split_mb = std::max(1, atoi(e));       // tests
+    if (gbn::switch_is_set("GBN_SKEW_SPLIT_MB")) split_mb = (int)std::max<long long>(1, gbn::switch_value("GBN_SKEW_SPLIT_MB", 0));       // tests
     if (s1 - s0 > 1 && bases > (split_mb << 20)) return kSkewedRange;         // the caller halves the range
     return run_scan_impl(b, db, s0, s1, diag, cnt, bases_out, true, &skewed);
 }
@@ -919,7 +934,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             // private output stream per (bin, binning workgroup): no reservation atomics
             const int wg_per_cu = GBN_BIN_WG_PER_CU;
             int nwriters = (int)std::max<int64_t>(8, std::min<int64_t>((int64_t)E.num_cu * wg_per_cu, ts.ntiles));
-            if (const char *e = getenv("GBN_BIN_WRITERS")) nwriters = std::max(8, std::min(nwriters, atoi(e)));     // experiments
+            if (gbn::switch_is_set("GBN_BIN_WRITERS")) nwriters = std::max(8, std::min(nwriters, (int)gbn::switch_value("GBN_BIN_WRITERS", 0)));     // experiments
             const size_t nstream = (size_t)nb * nwriters;
             double expect = (double)npos / (double)nstream + 2.0 * GBN_OPEN_LINE;   // + the pads of the stream's last line
             size_t subcap = (size_t)(expect * slack) + 256;
@@ -949,7 +964,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfrbits = std::min(7, 2 * b.dev->fr);
             B.rec = reinterpret_cast<uint32_t *>(E.bin_rec); B.tcur = E.bin_tcur; B.nseq = (uint32_t)nseq; B.gcount = E.bin_count; B.subcap = (uint32_t)subcap;
             B.overflow = E.bin_count + nstream;
-            if (const char *e = getenv("GBN_DBG")) B.dbg = atoi(e);
+            B.dbg = (int)gbn::switch_value("GBN_DBG", 0);
             int grid2 = std::max(8, E.num_cu & ~7);   // one 1024-thread workgroup per CU; group = blockIdx & 7
             {   // rare-path queue: one segment per probe workgroup (~1.2 % of scan positions in total)
                 size_t seg = std::max<size_t>(rare_seg_hint, (size_t)(npos / 40 / grid2) + 4096);
@@ -968,7 +983,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             // them for the next query batch with the same table shape: a database-side index held in HBM.
             BinKey &have = E.binkey;
             const BinKey want_key = {(const void *)&db, s0, s1, b.lut.lut, b.lut.step, nb, nwriters, subcap, true};
-            static const bool reuse = getenv("GBN_REUSE_BINNING") && atoi(getenv("GBN_REUSE_BINNING")) != 0;
+            const bool reuse = gbn::switch_value("GBN_REUSE_BINNING", 0) != 0;
             const bool hit = reuse && have.valid && have.db == want_key.db && have.s0 == s0 && have.s1 == s1 && have.lut == want_key.lut &&
                              have.step == want_key.step && have.nb == nb && have.nwriters == nwriters && have.subcap == subcap;
             have.valid = false;
@@ -1003,8 +1018,8 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             HIPCHK(hipMemcpy(rc_host.data(), E.rare_counts, (size_t)grid2 * 4, hipMemcpyDeviceToHost));
             unsigned long long sc = 0; uint32_t mx = 0;
             for (uint32_t v : rc_host) { sc += v; mx = std::max(mx, v); }
-            if (getenv("GBN_DBG")) fprintf(stderr, "[gbn dbg] rare-path items %llu, seeds %llu, raw %llu\n", sc, cnt[0], cnt[1]);
-            if (getenv("GBN_DBG") && (atoi(getenv("GBN_DBG")) & 32)) {
+            if (gbn::switch_is_set("GBN_DBG")) fprintf(stderr, "[gbn dbg] rare-path items %llu, seeds %llu, raw %llu\n", sc, cnt[0], cnt[1]);
+            if (gbn::switch_value("GBN_DBG", 0) & 32) {
                 {   // stream fill statistics
                     const size_t ns = (size_t)nb * (size_t)dbg_nwriters;
                     std::vector<uint32_t> gc(ns);
@@ -1019,7 +1034,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                     uint32_t s_min = ~0u, d_min = ~0u, d_max = 0, s_max = 0; const int nw = std::min(dbg_nwriters, 512);
                     for (int i = 0; i < nw; i++) s_min = std::min(s_min, w[i]);
                     for (int i = 0; i < nw; i++) { s_max = std::max(s_max, w[i] - s_min); d_min = std::min(d_min, w[512 + i]); d_max = std::max(d_max, w[512 + i]); }
-                    if (getenv("GBN_DBG_WG")) { for (int i = 0; i < nw; i++) fprintf(stderr, "%u%c", w[512 + i] / 100, (i & 31) == 31 ? '\n' : ' '); }
+                    if (gbn::switch_is_set("GBN_DBG_WG")) { for (int i = 0; i < nw; i++) fprintf(stderr, "%u%c", w[512 + i] / 100, (i & 31) == 31 ? '\n' : ' '); }
                     fprintf(stderr, "[gbn dbg] scan_bin workgroups: start spread %.1f us, duration min %.1f max %.1f us\n", s_max / 100.0, d_min / 100.0, d_max / 100.0);
                 }
                 uint32_t ph[24]; HIPCHK(hipMemcpy(ph, E.rare_counts + 512, sizeof(ph), hipMemcpyDeviceToHost));
@@ -1098,8 +1113,8 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     // Many seeds (blastn shapes): ONE sort of a composite key, the seed itself travels in the key (seed_ckeys_kernel) --
     // when subject | slot | s_scan | query key fit 64 bits; else, and for the few seeds of megablast shapes, two
     // stable sorts of (rank, index) pairs
-    static const int64_t compact_min = getenv("GBN_DIAG_COMPACT_MIN") ? atoll(getenv("GBN_DIAG_COMPACT_MIN")) : (int64_t)GBN_DIAG_COMPACT_MIN;
-    static const bool ck_on = !(getenv("GBN_SEED_CKEYS") && atoi(getenv("GBN_SEED_CKEYS")) == 0);
+    const int64_t compact_min = (int64_t)gbn::switch_value("GBN_DIAG_COMPACT_MIN", (long long)GBN_DIAG_COMPACT_MIN);
+    const bool ck_on = gbn::switch_value("GBN_SEED_CKEYS", 1) != 0;
     K.s_bits = bits_for((uint64_t)max_len + 1); K.qh_bits = std::max(0, K.q_bits - K.group_bits);
     K.subj_base = s0;
     const int ck_bits = K.group_bits + bits_for((uint64_t)(s1 - s0) + 1) + K.s_bits;        // (the query key's high bits travel in the value)
@@ -1132,7 +1147,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     }
     // ... and when the value (ext_left and the query key's high bits) fits underneath the key too, it travels in the
     // key's low bits: a sort of keys only, on the bits above the value (GBN_SEED_CKEYS=2: always pairs)
-    static const bool ck_pack = !(getenv("GBN_SEED_CKEYS") && atoi(getenv("GBN_SEED_CKEYS")) == 2);
+    const bool ck_pack = gbn::switch_value("GBN_SEED_CKEYS", 1) != 2;
     const int v_bits = 8 + K.qh_bits;
     const bool packed = composite && ck_pack && ck_bits + v_bits <= 64;
     if (composite) {
@@ -1186,7 +1201,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         if (composite) {
             X.idx = KS.idx_b; X.run_heads = KS.idx_a;
             // (values packed under the keys: idx_b is free, and lists the seeds of the exact pass; GBN_EXT_SPLIT=0: inline as before)
-            static const bool split = !(getenv("GBN_EXT_SPLIT") && atoi(getenv("GBN_EXT_SPLIT")) == 0);
+            const bool split = gbn::switch_value("GBN_EXT_SPLIT", 1) != 0;
             if (split && packed) { X.exact_list = KS.idx_b; X.exact_count = reinterpret_cast<uint32_t *>(ctr + 1) + 1; }
             X.ck_shift = K.s_bits; X.ck_s_bits = K.s_bits; X.ck_qh_bits = K.qh_bits; X.ck_q_bits = K.q_bits; X.ck_q_desc = K.q_descending; X.ck_subj_base = K.subj_base; X.ck_vbits = K.v_bits;
         }
@@ -1223,8 +1238,8 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     // stage, where it runs on stream2 next to the HBM-bound binning kernel of the next pass.  Opt-in (GBN_DEFER_RARE=1):
     // measured +1.2 .. 3.4 % Gbp/s on C2, while the binning kernel, sharing the chip, runs 8.0 -> 9.05 ms -- the GPU is
     // busy either way, and the default keeps the dominant kernel's launch duration what the kernel itself takes.
-    static const bool defer_on = getenv("GBN_DEFER_RARE") && atoi(getenv("GBN_DEFER_RARE")) != 0;
-    static const bool reuse_on = getenv("GBN_REUSE_BINNING") && atoi(getenv("GBN_REUSE_BINNING")) != 0;
+    const bool defer_on = gbn::switch_value("GBN_DEFER_RARE", 0) != 0;
+    const bool reuse_on = gbn::switch_value("GBN_REUSE_BINNING", 0) != 0;
     DeferredRare defer;
     const bool want_defer = defer_on && !reuse_on && overlap && !keep_stages && b.lut.lut != b.lut.word;
     int rc = run_scan(b, db, s0, s1, diag, cnt, &bases, want_defer ? &defer : nullptr);
@@ -1425,7 +1440,7 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     // grid: at most 24 waves per CU (measured on the blastn shape: 12-20 make the gapped stage the longer one, 28+ starve the scan; the scan kernels of the next range need room, see greedy_kernel) and at
     // most 4 GiB of scratch; the threads stride over the initial hits
     const size_t budget_ints = (size_t)1 << 30;
-    static const int waves_per_cu = getenv("GBN_GAP_WAVES") ? std::max(1, atoi(getenv("GBN_GAP_WAVES"))) : 24;
+    const int waves_per_cu = (int)std::max<long long>(1, gbn::switch_value("GBN_GAP_WAVES", 24));
     const size_t by_budget = std::max<size_t>(1, budget_ints / per_thread / 64);
     const size_t blocks = std::max<size_t>(1, std::min({((size_t)nih + 63) / 64, (size_t)E.num_cu * (size_t)waves_per_cu, by_budget}));
     const size_t scratch_ints = blocks * 64 * per_thread;
@@ -1436,9 +1451,9 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     }
     G.scratch = E.gap_scratch_s[slot];
     G.first = 0; G.n = (int64_t)nih; G.max_blocks = (int32_t)blocks;
-    if (getenv("GBN_DP_STATS")) HIPCHK(hipMemsetAsync(G.scratch, 0, 256, st));
+    if (gbn::switch_is_set("GBN_DP_STATS")) HIPCHK(hipMemsetAsync(G.scratch, 0, 256, st));
     HIPCHK(launch_gapped(G, b.opt.greedy != 0, st, &E.kt_gap[slot]));
-    if (getenv("GBN_DP_STATS")) {       // (-DGBN_DP_STATS=1 builds only)
+    if (gbn::switch_is_set("GBN_DP_STATS")) {       // (-DGBN_DP_STATS=1 builds only)
         unsigned long long c[24]; HIPCHK(hipMemcpyAsync(c, G.scratch, sizeof(c), hipMemcpyDeviceToHost, st)); HIPCHK(hipStreamSynchronize(st));
         fprintf(stderr, "[gbn dbg] wave DP: %llu extensions (%llu left to the scratch kernel), %llu rows, %llu rounds, mean window %.1f\n", c[2], c[3], c[0], c[1], c[0] ? (double)c[4] / c[0] : 0.0);
         fprintf(stderr, "[gbn dbg]   rows by window / 8:"); for (int k = 0; k < 8; k++) fprintf(stderr, " %llu", c[8 + k]);
@@ -1456,7 +1471,7 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     trace_mark("gapped: kernels + copies done");
     { double km[GBN_KT_N] = {0}; E.kt_gap[slot].collect(km); if (diag) for (int i = 0; i < GBN_KT_N; i++) diag->kernel_ms[i] += km[i]; }
     if (diag) diag->gapped_stage_ms += ms_since(t_stage);
-    static const bool detach_on = !(getenv("GBN_HOST_DETACH") && atoi(getenv("GBN_HOST_DETACH")) == 0);
+    const bool detach_on = gbn::switch_value("GBN_HOST_DETACH", 1) != 0;
     // (a few thousand extensions -- megablast shapes -- are replayed in less time than handing them over takes)
     if (!detach_host || !detach_on || nih < 20000) { if (detach_host) wait_host(); return gapped_host(b, db, s0, s1, res, diag, keep_stages, hih, hg, (size_t)nih); }
     // the replay of this range's extensions joins the queue of host replays (in range order: the lists are appended to
@@ -1641,7 +1656,7 @@ static int engine_init(int dev, Engine **out) {
     {   // the scan stream outranks the extension and table-builder streams: its kernels need whole CUs
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);           // lo = least, hi = greatest priority
-        const bool prio = getenv("GBN_STREAM_PRIORITY") ? atoi(getenv("GBN_STREAM_PRIORITY")) != 0 : true;
+        const bool prio = gbn::switch_value("GBN_STREAM_PRIORITY", 1) != 0;
         HIPCHK(hipStreamCreateWithPriority(&N.stream, hipStreamNonBlocking, prio ? hi : 0));
         HIPCHK(hipStreamCreateWithPriority(&N.stream2, hipStreamNonBlocking, prio ? lo : 0));
         HIPCHK(hipStreamCreateWithPriority(&N.stream_build, hipStreamNonBlocking, prio ? lo : 0));
@@ -1746,6 +1761,7 @@ int gbn_block_cache_insert(const char *db_name, const int32_t *oids, int32_t n, 
     });
 }
 long long gbn_debug_db_bytes_uploaded(void) { return g_db_bytes_uploaded.load(); }
+void gbn_debug_reload_switches(void) { std::lock_guard<std::mutex> lk(g_switch_mu); g_switches.clear(); }
 void gbn_release_db_memory(void) {
     std::map<const void *, GbnDb *> drop;
     std::map<BlockKey, GbnDb *> drop_blocks;
@@ -2177,9 +2193,9 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     } else {
         // ranges of subjects bounded by packed size so that scratch stays modest
         int64_t range_gib = 16;
-        if (const char *e = getenv("GBN_RANGE_GIB")) range_gib = std::max(1, atoi(e));
+        if (gbn::switch_is_set("GBN_RANGE_GIB")) range_gib = (int)std::max<long long>(1, gbn::switch_value("GBN_RANGE_GIB", 0));
         int64_t range_bytes = range_gib << 30;
-        if (const char *e = getenv("GBN_RANGE_MIB")) range_bytes = (int64_t)std::max(1, atoi(e)) << 20;    // tests
+        if (gbn::switch_is_set("GBN_RANGE_MIB")) range_bytes = (int64_t)std::max<long long>(1, gbn::switch_value("GBN_RANGE_MIB", 0)) << 20;    // tests
         // Hard limits of a range: packed bytes (scratch) and 32-bit position ids.  Seed-rich shapes (small
         // stride) are cut into ~1 G scan positions, so that the seed / extension stages of one range run
         // underneath the scan of the next.  Whatever number of ranges that takes, they are made equal:
@@ -2187,7 +2203,7 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
         const int step = batch->lut.step;
         int64_t tile_limit = ((int64_t)1 << (32 - GBN_BIN_TILE_BITS)) - 1;
         if (step <= 4) tile_limit = std::min<int64_t>(tile_limit, (int64_t)1 << 17);
-        if (const char *e = getenv("GBN_RANGE_TILES")) tile_limit = std::max(1, atoi(e));                  // tests
+        if (gbn::switch_is_set("GBN_RANGE_TILES")) tile_limit = (int)std::max<long long>(1, gbn::switch_value("GBN_RANGE_TILES", 0));                  // tests
         auto tiles_of = [&](int32_t s) { return (int64_t)(db->len[s] / step) / GBN_BIN_TILE_POS + 1; };
         int64_t all_bytes = 0, all_tiles = 0;
         for (int32_t s = 0; s < db->num_seqs; s++) { all_bytes += (db->len[s] + 3) / 4; all_tiles += tiles_of(s); }

@@ -133,3 +133,14 @@ struct GbnKernelTimer {
     void destroy() { if (made) for (int i = 0; i < CAP; i++) (void)hipEventDestroy(ev[i]); made = false; n = 0; }
 };
 #endif
+
+// ---- switches (the library's environment variables): ONE table, read at a switch's first use and again after
+// gbn_debug_reload_switches() -- a test changes them inside its process instead of spawning a child per setting.  (The
+// device pool's GBN_POOL_GIB / GBN_GUARD / GBN_POISON and GBN_TRACE stay process-wide: blocks handed out under one setting
+// cannot be checked under another.)
+#ifdef __cplusplus
+namespace gbn {
+long long switch_value(const char *name, long long dflt);   // the variable as an integer, dflt if it is not set
+bool switch_is_set(const char *name);
+}
+#endif

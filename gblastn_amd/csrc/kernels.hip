@@ -2646,8 +2646,8 @@ static int scan_slice_form(const GbnScanParams &p, int nslices)
 {
     // GBN_SLICE_FOLD=0: a pass over the subjects per slice (the form before the folded filter); GBN_SCAN_ORDERED=0: folded,
     // seeds in no particular order (the form before the ordered one) -- for comparisons
-    static const bool fold = !(getenv("GBN_SLICE_FOLD") && atoi(getenv("GBN_SLICE_FOLD")) == 0);
-    static const bool ordered = !(getenv("GBN_SCAN_ORDERED") && atoi(getenv("GBN_SCAN_ORDERED")) == 0);
+    const bool fold = gbn::switch_value("GBN_SLICE_FOLD", 1) != 0;
+    const bool ordered = gbn::switch_value("GBN_SCAN_ORDERED", 1) != 0;
     if (!(fold && nslices > 1 && p.pvx && p.pstart)) return 0;
     return ordered ? 2 : 1;
 }
@@ -2721,7 +2721,7 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st, GbnKernel
     // Compacting the run heads first pays once most seeds are not heads (blastn word sizes: 6x on
     // C3); for the few ten thousand seeds of a megablast pass the direct form is 2x faster.
     // GBN_DIAG_COMPACT_MIN (environment): the threshold, for tests that send small inputs through the two-kernel form
-    static const int64_t compact_min = getenv("GBN_DIAG_COMPACT_MIN") ? atoll(getenv("GBN_DIAG_COMPACT_MIN")) : (int64_t)GBN_DIAG_COMPACT_MIN;
+    const int64_t compact_min = (int64_t)gbn::switch_value("GBN_DIAG_COMPACT_MIN", (long long)GBN_DIAG_COMPACT_MIN);
     if (p.n < compact_min) { GbnExtParams q = p; q.run_heads = nullptr;
         mark(GBN_KT_DIAG);
         hipLaunchKernelGGL(diag_ungapped_kernel, dim3((unsigned)((p.n + 63) / 64)), dim3(64), 0, st, q);
@@ -2729,7 +2729,7 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st, GbnKernel
         return hipGetLastError(); }
     if (p.ck_shift > 0 && p.ext_rec) {      // composite keys: the extension kernel finds the run heads on its way
         // (hash container, word sizes from 11 up: the approximate extension; the mask re-check stays with the general kernel)
-        static const bool ck2 = !(getenv("GBN_SEED_EXT_CK") && atoi(getenv("GBN_SEED_EXT_CK")) == 0);
+        const bool ck2 = gbn::switch_value("GBN_SEED_EXT_CK", 1) != 0;
         if (ck2 && p.q4 && p.ctx_blk && !p.masked && (p.container_hash || p.word >= 11)) {
             // a stretch of 64 x k seeds per wave: every wave slot of the chip taken, eight or more rounds per wave
             const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((p.n + 2047) / 2048, 256 * 32));
@@ -2774,7 +2774,7 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st, Gbn
     // extension per WAVE with the band in registers; what that leaves (a band wider than a wave, gap_extend 0) the
     // thread-per-extension kernel with its band in scratch memory.  GBN_GAP_LANE=0: start with the wave kernel.
     if (!p.redo_only) {
-        static const bool lane_on = !(getenv("GBN_GAP_LANE") && atoi(getenv("GBN_GAP_LANE")) == 0);
+        const bool lane_on = gbn::switch_value("GBN_GAP_LANE", 1) != 0;
         // 16-bit band cells, "dead" = -32768.  A half of a lane extension has at most GBN_LANE_ROWS rows, so no live value
         // exceeds GBN_LANE_ROWS * reward, none that is kept lies more than xdrop below the best, and what is stored beside
         // it (a gap opened or extended from a kept cell) at most gap_open + gap_extend lower still: all of it, and the

@@ -582,3 +582,31 @@ def test_block_cache_under_two_threads_and_changing_chunkings():
     assert up2 == up1                               # ... and never again
     assert first.tobytes() == want.tobytes() and second.tobytes() == want.tobytes()
     L.gbn_release_db_memory()
+
+
+@pytest.mark.gpu
+def test_switches_are_read_again_after_a_reload(monkeypatch):
+    """The library's A/B switches live in one table (gbn_dev.h: gbn::switch_value) that gbn_debug_reload_switches() empties:
+    a process can run the same search under several settings -- here the two-kernel seed stage forced on small inputs with the
+    composite-key sort on and off, and the direct-probe scan -- and gets the same stages every time, equal to the oracle's."""
+    L = api.lib()
+    db, queries, plants, subjects, opt = util.small_case(6, 150_000, 16, task="blastn")
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ora, s = util.oracle_run(opt, queries, subjects)
+    seen = []
+    for env in ({}, {"GBN_DIAG_COMPACT_MIN": "1"}, {"GBN_DIAG_COMPACT_MIN": "1", "GBN_SEED_CKEYS": "0"}, {"GBN_SCAN_BINS": "1"}, {}):
+        for k in ("GBN_DIAG_COMPACT_MIN", "GBN_SEED_CKEYS", "GBN_SCAN_BINS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        L.gbn_debug_reload_switches()
+        ps = api.BlastPrelimSearch(queries, opt, src)
+        gpu = ps.run(keep_stages=True)
+        util.compare_stages(gpu, ora)
+        seen.append((ps.info()["scan_path"], gpu["hsps"].tobytes()))
+        ps.close()
+    assert len(set(h for _, h in seen)) == 1
+    assert seen[3][0] != seen[0][0]                  # the direct-probe scan did run in the fourth round
+    for k in ("GBN_DIAG_COMPACT_MIN", "GBN_SEED_CKEYS", "GBN_SCAN_BINS"):
+        monkeypatch.delenv(k, raising=False)
+    L.gbn_debug_reload_switches()
