@@ -52,6 +52,11 @@ hipError_t sort_keys_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint
 static thread_local std::string g_err;
 void set_error(const std::string &m) { g_err = m; }
 
+// Stages of one search run on several threads (the inline seed stage, the stage in flight on the second stream, the
+// detached host replays) and all add to the caller's GbnDiagnostics: every such update holds this lock.
+static std::mutex g_diag_mu;
+#define GBN_DIAG_LOCKED(stmt) do { std::lock_guard<std::mutex> dl_(g_diag_mu); stmt; } while (0)
+
 // the switch table (gbn_dev.h)
 static std::mutex g_switch_mu;
 static std::map<std::string, std::pair<bool, long long>> g_switches;
@@ -1209,11 +1214,11 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         HIPCHK(launch_diag_ungapped(X, st, &KS.kt));
         HIPCHK(hipMemcpyAsync(&nih, ctr, sizeof(nih), hipMemcpyDeviceToHost, st));
         HIPCHK(hipStreamSynchronize(st));
-        { double km[GBN_KT_N] = {0}; KS.kt.collect(km); if (diag) for (int i = 0; i < GBN_KT_N; i++) diag->kernel_ms[i] += km[i]; }
+        { double km[GBN_KT_N] = {0}; KS.kt.collect(km); if (diag) GBN_DIAG_LOCKED(for (int i = 0; i < GBN_KT_N; i++) diag->kernel_ms[i] += km[i]); }
         if (nih <= E.ihit_cap_s[slot]) break;
         if ((rc = grow_ihit_buffers(slot, (size_t)nih + (nih >> 3)))) return rc;
     }
-    if (diag) { diag->init_extends += (int64_t)nih; diag->good_init_extends += (int64_t)nih; diag->seed_stage_ms += ms_since(t_stage); }
+    if (diag) GBN_DIAG_LOCKED(diag->init_extends += (int64_t)nih; diag->good_init_extends += (int64_t)nih; diag->seed_stage_ms += ms_since(t_stage));
     *nih_out = nih;
     return GBN_OK;
 
@@ -1469,8 +1474,7 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     trace_mark("gapped: kernels + copies queued");
     HIPCHK(hipStreamSynchronize(st));
     trace_mark("gapped: kernels + copies done");
-    { double km[GBN_KT_N] = {0}; E.kt_gap[slot].collect(km); if (diag) for (int i = 0; i < GBN_KT_N; i++) diag->kernel_ms[i] += km[i]; }
-    if (diag) diag->gapped_stage_ms += ms_since(t_stage);
+    { double km[GBN_KT_N] = {0}; E.kt_gap[slot].collect(km); if (diag) GBN_DIAG_LOCKED(for (int i = 0; i < GBN_KT_N; i++) diag->kernel_ms[i] += km[i]; diag->gapped_stage_ms += ms_since(t_stage)); }
     const bool detach_on = gbn::switch_value("GBN_HOST_DETACH", 1) != 0;
     // (a few thousand extensions -- megablast shapes -- are replayed in less time than handing them over takes)
     if (!detach_host || !detach_on || nih < 20000) { if (detach_host) wait_host(); return gapped_host(b, db, s0, s1, res, diag, keep_stages, hih, hg, (size_t)nih); }
@@ -1579,9 +1583,9 @@ static int gapped_host(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResult
         if (keep_stages) res.init_hits.insert(res.init_hits.end(), ihs[k].begin(), ihs[k].end());
     }
     if (diag) for (auto &dl : dloc) {
-        diag->gapped_extensions += dl.gapped_extensions; diag->good_extensions += dl.good_extensions; diag->seqs_passed += dl.seqs_passed;
+        GBN_DIAG_LOCKED(diag->gapped_extensions += dl.gapped_extensions; diag->good_extensions += dl.good_extensions; diag->seqs_passed += dl.seqs_passed);
     }
-    if (diag) diag->host_stage_ms += ms_since(t_stage);
+    if (diag) GBN_DIAG_LOCKED(diag->host_stage_ms += ms_since(t_stage));
     trace_mark("gapped: host replay done");
     return GBN_OK;
 }
@@ -2166,7 +2170,9 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
                       int keep_stages, GbnInterruptFn interrupt, void *progress, int overlap) {
     int rc = GBN_OK;
     std::lock_guard<std::mutex> lk(E.mu);                   // (the caller has entered the engine: search_enter)
-    results->engine = tl_eng; results->batch = batch; results->diag = diag;
+    results->engine = tl_eng; results->diag = diag;
+    results->merge.kbp_gap = batch->kbp_gap; results->merge.evalue = batch->opt.evalue; results->merge.eff_searchsp.clear();
+    for (const GbnContext &c : batch->ctx) results->merge.eff_searchsp.push_back(c.eff_searchsp);
     auto t0 = std::chrono::steady_clock::now();
     trace_mark("search: entered");
     if (!db->real_of.empty()) results->chunk_len = db->chunk_len;
@@ -2186,7 +2192,7 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
             if ((rc = search_range(*batch, *db, s, s + 1, *results, diag, keep_stages))) return rc;
             if (chunked && (s + 1 == db->num_seqs || db->chunk_ord[(size_t)s + 1] == 0)) {
                 wait_host();
-                merge_chunk_lists(results->hsps, results->chunk_len, *batch, diag);     // (lists merged before carry pad_ = 0: left as they are)
+                merge_chunk_lists(results->hsps, results->chunk_len, results->merge, diag);     // (lists merged before carry pad_ = 0: left as they are)
             }
             if (interrupt && interrupt(progress)) { set_error("interrupted"); return GBN_ERR_INTERRUPTED; }
         }
@@ -2237,7 +2243,7 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     std::lock_guard<std::mutex> lk(E.mu);
     (void)wait_pending();                               // of an earlier gbn_prelim_search_begin (its status stays with its results)
     const int rc2 = take_failure(results);
-    if (!rc && !rc2 && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, *results->batch, results->diag); results->chunk_len = 0; }
+    if (!rc && !rc2 && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, results->merge, results->diag); results->chunk_len = 0; }
     return rc ? rc : rc2;
     });
 }
@@ -2292,7 +2298,7 @@ int gbn_prelim_search_end(GbnResults *results) {
     int rc;
     if (results && E.has_pending && E.pending_res != results) { wait_host(); rc = take_failure(results); }    // (its last host replay may still run)
     else { (void)wait_pending(); rc = results ? take_failure(results) : GBN_OK; }
-    if (!rc && results && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, *results->batch, results->diag); results->chunk_len = 0; }
+    if (!rc && results && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, results->merge, results->diag); results->chunk_len = 0; }
     return rc;
     });
 }

@@ -109,7 +109,11 @@ struct GbnResults {
     std::vector<GbnSeed> seeds;
     std::vector<GbnInitHit> init_hits;
     void *engine = nullptr;             // the device context that fills / filled them (set by the search entry points)
-    const GbnBatch *batch = nullptr; GbnDiagnostics *diag = nullptr;   // of the search that is filling them (chunk lists: e-values and counters after the merge)
+    // of the search that is filling them.  What the merge of chunk lists needs of the query batch (e-values after the
+    // merge: CORE/blast_engine.c:455-540) is COPIED here when the search starts: gbn_prelim_search_end may run after
+    // the caller has freed the batch.  `diag` is the caller's and must outlive the search, as the API says.
+    struct ChunkMerge { gbn::Karlin kbp_gap; std::vector<int64_t> eff_searchsp; double evalue = 0; } merge;
+    GbnDiagnostics *diag = nullptr;
     int32_t chunk_len = 0;              // > 0: hsps holds chunk lists (pad_ = ordinal + 1) that merge_chunk_lists has yet to join
 };
 
@@ -123,6 +127,6 @@ void fill_lookup_host(GbnBatch &b);     // the host-side table builder (host-onl
 int  upload_batch(GbnBatch &b);
 void free_device_batch(DeviceBatch *d);
 // chunk lists of one sequence (GbnHSP::pad_ = chunk ordinal + 1) -> one list per sequence (Blast_HSPListsMerge)
-void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len, const GbnBatch &b, GbnDiagnostics *diag);
+void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len, const GbnResults::ChunkMerge &b, GbnDiagnostics *diag);
 int  gather_shard_bytes(const GbnDb &db, const std::vector<int64_t> &src_off, const std::vector<int32_t> &nbytes, std::vector<uint8_t> &out);
 }

@@ -95,7 +95,7 @@ static void merge_two_lists(std::vector<GbnHSP> &comb, std::vector<GbnHSP> &cur,
 
 // The chunk lists of a sequence -> its one list: merged in chunk order, then what the engine does with a subject's
 // list after its chunk loop (GB/gpu_blastn_pre_search_engine.cpp:772-810): e-values, e-value reap, counters.
-void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len, const GbnBatch &b, GbnDiagnostics *diag)
+void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len, const GbnResults::ChunkMerge &b, GbnDiagnostics *diag)
 {
     std::vector<GbnHSP> out; out.reserve(hsps.size());
     const int32_t stride = chunk_len - kDbseqChunkOverlap;
@@ -113,8 +113,8 @@ void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len, const GbnBa
         }
         size_t kept = 0;
         for (GbnHSP &h : comb) {
-            h.evalue = evalue_for_score(h.score, b.kbp_gap, b.ctx[h.context].eff_searchsp);
-            if (h.evalue > b.opt.evalue) continue;
+            h.evalue = evalue_for_score(h.score, b.kbp_gap, b.eff_searchsp[(size_t)h.context]);
+            if (h.evalue > b.evalue) continue;
             out.push_back(h); kept++;
         }
         if (diag && kept) { diag->seqs_passed++; diag->good_extensions += (int64_t)kept; }
