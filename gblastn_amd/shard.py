@@ -60,16 +60,17 @@ def gather_records(records, dst=0, device=None, group=None, force=False):
     sizes = [int(v) for v in counts.tolist()]
     peer = (lambda r: dist.get_global_rank(group, r)) if group is not None else (lambda r: r)
     if rank != dst:
-        if raw.size:
-            dist.send(torch.from_numpy(raw.copy()).to(dev), dst=peer(dst), group=group)
+        if raw.size:        # (a batched point-to-point op: RCCL runs it next to the group's other work instead of serialising it)
+            for q in dist.batch_isend_irecv([dist.P2POp(dist.isend, torch.from_numpy(raw.copy()).to(dev), peer(dst), group)]):
+                q.wait()
         return None
     out = torch.empty(max(sum(sizes), 1), dtype=torch.uint8, device=dev)
     offs = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int64)
     if raw.size:
         out[int(offs[rank]):int(offs[rank + 1])] = torch.from_numpy(raw.copy()).to(dev)
-    reqs = [dist.irecv(out[int(offs[r]):int(offs[r + 1])], src=peer(r), group=group)
-            for r in range(world) if r != dst and sizes[r] > 0]
-    for q in reqs:
+    ops = [dist.P2POp(dist.irecv, out[int(offs[r]):int(offs[r + 1])], peer(r), group)
+           for r in range(world) if r != dst and sizes[r] > 0]
+    for q in (dist.batch_isend_irecv(ops) if ops else []):
         q.wait()
     return out[:int(offs[world])].cpu().numpy().view(records.dtype)
 
