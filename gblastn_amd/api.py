@@ -88,7 +88,7 @@ EXPORTS = ["gbn_init", "gbn_release", "gbn_release_db_memory", "gbn_debug_check_
            "gbn_pipeline_diagnostics",
            "gbn_batch_scan_params", "gbn_batch_ext_params", "gbn_batch_gap_params", "gbn_batch_diag_layout",
            "gbn_prelim_search_lists", "gbn_db_cache_find", "gbn_db_cache_insert", "gbn_block_cache_find", "gbn_block_cache_insert",
-           "gbn_debug_db_bytes_uploaded", "gbn_debug_reload_switches",
+           "gbn_debug_db_bytes_uploaded",
            "gbn_set_max_dbseq_len", "gbn_db_set_ambiguities", "gbn_traceback_merge", "gbn_shard_builder_new", "gbn_shard_builder_add", "gbn_shard_builder_finish", "gbn_shard_builder_free"]
 
 # ---- include/gblastn_amd_kernels.h: parameter blocks of the gbn_launch_* entry points (device pointers as integers)

@@ -57,20 +57,9 @@ void set_error(const std::string &m) { g_err = m; }
 static std::mutex g_diag_mu;
 #define GBN_DIAG_LOCKED(stmt) do { std::lock_guard<std::mutex> dl_(g_diag_mu); stmt; } while (0)
 
-// the switch table (gbn_dev.h)
-static std::mutex g_switch_mu;
-static std::map<std::string, std::pair<bool, long long>> g_switches;
-static std::pair<bool, long long> switch_entry(const char *name) {
-    std::lock_guard<std::mutex> lk(g_switch_mu);
-    auto it = g_switches.find(name);
-    if (it == g_switches.end()) {
-        const char *e = getenv(name);
-        it = g_switches.emplace(name, std::make_pair(e != nullptr, e ? atoll(e) : 0ll)).first;
-    }
-    return it->second;
-}
-long long switch_value(const char *name, long long dflt) { const auto e = switch_entry(name); return e.first ? e.second : dflt; }
-bool switch_is_set(const char *name) { return switch_entry(name).first; }
+// the switches (gbn_dev.h): read from the environment at every use
+long long switch_value(const char *name, long long dflt) { const char *e = getenv(name); return e ? atoll(e) : dflt; }
+bool switch_is_set(const char *name) { return getenv(name) != nullptr; }
 
 // GBN_TRACE=1: wall-clock marks of the host-side pipeline on stderr (ms since the first mark)
 void trace_mark(const char *what) {
@@ -482,7 +471,7 @@ static int build_tables_on_device(GbnBatch &b) {
     for (auto &sg : L.segments) if (sg.second >= sg.first) { sl.push_back(sg.first); sr.push_back(sg.second); }
     int32_t *d_sl = nullptr, *d_sr = nullptr;
     uint32_t *count = nullptr, *many = nullptr, *many_prefix = nullptr, *vals_a = nullptr, *vals_b = nullptr;
-    uint64_t *keys_a = nullptr, *keys_b = nullptr; unsigned long long *ctr = nullptr; void *tmp = nullptr;
+    uint32_t *keys_a = nullptr, *keys_b = nullptr; unsigned long long *ctr = nullptr; void *tmp = nullptr;
     auto cleanup = [&]() { dev_free(d_sl); dev_free(d_sr); dev_free(count); dev_free(many); dev_free(many_prefix);
                            dev_free(vals_a); dev_free(vals_b); dev_free(keys_a); dev_free(keys_b); dev_free(ctr); if (tmp) pool_free(tmp); tmp = nullptr; };
     // (on an error kernels may already be queued on the builder's stream: they finish before their scratch goes back to the pool)
@@ -500,7 +489,7 @@ static int build_tables_on_device(GbnBatch &b) {
     LutBuild B; std::memset(&B, 0, sizeof(B));
     B.q8 = d->q8; B.qlen = b.qlen; B.seg_left = d_sl; B.seg_right = d_sr; B.nseg = (int32_t)sl.size();
     B.lut = L.lut; B.word = L.word; B.q_bits = std::min(31, bits_for((uint64_t)b.qlen + 1)); B.ncells = L.ncells;
-    B.count = count; B.n_words = ctr; B.keys_a = keys_a; B.keys_b = keys_b; B.vals_a = vals_a; B.vals_b = vals_b;
+    B.count = count; B.keys_a = keys_a; B.keys_b = keys_b; B.vals_a = vals_a; B.vals_b = vals_b;
     B.cell_start = d->cell_start; B.cellw = d->cellw; B.cellt = d->cellt; B.pv = d->pv; B.many = many; B.many_prefix = many_prefix;
     B.cbits = GBN_BIN_CBITS(L.lut);
     B.nbins = (int32_t)std::max<int64_t>(1, L.ncells >> B.cbits);
@@ -510,14 +499,13 @@ static int build_tables_on_device(GbnBatch &b) {
     // the engine lets the probe kernel wait for it -- the binning kernel of the search starts at once.
     const bool sync_build = gbn::switch_value("GBN_SYNC_BUILD", 0) != 0;
     if (L.type != GBN_LUT_SMALL_NA && !sync_build) {
-        LUTCHK(hipMemsetAsync(keys_a, 0xff, qn * 8, st));           // positions without a word sort behind the words
         LUTCHK(lut_enumerate(B, st));
         B.onebyte_mode = 0;
         LUTRC(dev_alloc(d->ent, qn + 1));
         LUTRC(dev_alloc(d->sidet, qn + 1)); LUTRC(dev_alloc(d->side_start, (size_t)B.nbins + 1));
         LUTCHK(hipMemsetAsync(d->sidet, 0, (qn + 1) * 2, st));
         size_t b1 = 0, b2 = 0;
-        const int key_bits = std::min(64, 2 * L.lut + B.q_bits);
+        const int key_bits = 2 * L.lut + 1;                         // (the cell; one bit more: "no word at this position" sorts last)
         LUTCHK(lut_sort(nullptr, b1, B, (int64_t)qn, key_bits, st));
         LUTCHK(lut_scan(nullptr, b2, count, d->cell_start, (int64_t)nc1, st));
         LUTCHK(pool_alloc(&tmp, std::max(b1, b2) + 256));
@@ -541,10 +529,18 @@ static int build_tables_on_device(GbnBatch &b) {
     }
     LUTCHK(lut_enumerate(B, st));
     if (L.type == GBN_LUT_SMALL_NA) LUTCHK(lut_overflow_cells(B, ctr + 1, st));
-    unsigned long long h[2] = {0, 0};
+    size_t b1 = 0, b2 = 0;
+    const int key_bits = 2 * L.lut + 1;
+    LUTCHK(lut_sort(nullptr, b1, B, (int64_t)qn, key_bits, st));
+    LUTCHK(lut_scan(nullptr, b2, count, d->cell_start, (int64_t)nc1, st));
+    LUTCHK(pool_alloc(&tmp, std::max(b1, b2) + 256));
+    size_t tb = std::max(b1, b2) + 256;
+    LUTCHK(lut_scan(tmp, tb, count, d->cell_start, (int64_t)nc1, st));
+    unsigned long long h[2] = {0, 0}; uint32_t n_words = 0;
     LUTCHK(hipMemcpyAsync(h, ctr, 16, hipMemcpyDeviceToHost, st));
+    LUTCHK(hipMemcpyAsync(&n_words, d->cell_start + L.ncells, 4, hipMemcpyDeviceToHost, st));
     LUTCHK(hipStreamSynchronize(st));
-    const int64_t n = (int64_t)h[0];
+    const int64_t n = (int64_t)n_words;
     // small-NA table whose overflow array would not fit 15 bits: the standard table (CORE/blast_nalookup.c:184-187)
     if (L.type == GBN_LUT_SMALL_NA && 2 + h[1] >= 32768) L.type = GBN_LUT_NA;
     // (extension flavour and chain order depend on the final table kind)
@@ -555,15 +551,8 @@ static int build_tables_on_device(GbnBatch &b) {
     B.onebyte_mode = (d->mode == GBN_EXT_SMALL_ONEBYTE) ? 1 : 0;
     LUTRC(dev_alloc(d->ent, (size_t)n + 1));
     LUTCHK(hipMemsetAsync(d->ent + n, 0, 8, st));
-    size_t b1 = 0, b2 = 0;
-    const int key_bits = std::min(64, 2 * L.lut + B.q_bits);
-    LUTCHK(lut_sort(nullptr, b1, B, std::max<int64_t>(n, 1), key_bits, st));
-    LUTCHK(lut_scan(nullptr, b2, count, d->cell_start, (int64_t)nc1, st));
-    LUTCHK(pool_alloc(&tmp, std::max(b1, b2) + 256));
-    size_t tb = std::max(b1, b2) + 256;
-    if (n > 0) LUTCHK(lut_sort(tmp, tb, B, n, key_bits, st));
     tb = std::max(b1, b2) + 256;
-    LUTCHK(lut_scan(tmp, tb, count, d->cell_start, (int64_t)nc1, st));
+    LUTCHK(lut_sort(tmp, tb, B, (int64_t)qn, key_bits, st));
     B.ent = d->ent;
     LUTCHK(lut_entries(B, n, st));
     LUTCHK(lut_cells(B, st));
@@ -1765,7 +1754,6 @@ int gbn_block_cache_insert(const char *db_name, const int32_t *oids, int32_t n, 
     });
 }
 long long gbn_debug_db_bytes_uploaded(void) { return g_db_bytes_uploaded.load(); }
-void gbn_debug_reload_switches(void) { std::lock_guard<std::mutex> lk(g_switch_mu); g_switches.clear(); }
 void gbn_release_db_memory(void) {
     std::map<const void *, GbnDb *> drop;
     std::map<BlockKey, GbnDb *> drop_blocks;

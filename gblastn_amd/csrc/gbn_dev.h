@@ -134,10 +134,10 @@ struct GbnKernelTimer {
 };
 #endif
 
-// ---- switches (the library's environment variables): ONE table, read at a switch's first use and again after
-// gbn_debug_reload_switches() -- a test changes them inside its process instead of spawning a child per setting.  (The
-// device pool's GBN_POOL_GIB / GBN_GUARD / GBN_POISON and GBN_TRACE stay process-wide: blocks handed out under one setting
-// cannot be checked under another.)
+// ---- switches (the library's environment variables): read through these two functions at EVERY use (rounds
+// 1-3 cached several in function-local statics: a process could not change them after their first use and the tests
+// spawned a child per setting).  The device pool's GBN_POOL_GIB / GBN_GUARD / GBN_POISON and GBN_TRACE stay process-wide:
+// blocks handed out under one setting cannot be checked under another.
 #ifdef __cplusplus
 namespace gbn {
 long long switch_value(const char *name, long long dflt);   // the variable as an integer, dflt if it is not set

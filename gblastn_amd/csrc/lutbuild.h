@@ -11,8 +11,7 @@ struct LutBuild {                           // device pointers throughout
     int32_t lut, word, q_bits, descending, onebyte_mode;
     int64_t ncells;
     uint32_t *count;                        // ncells + 1, zero on entry
-    unsigned long long *n_words;            // zero on entry
-    uint64_t *keys_a, *keys_b; uint32_t *vals_a, *vals_b;   // qlen entries each
+    uint32_t *keys_a, *keys_b, *vals_a, *vals_b;            // qlen entries each: {cell (1 << 2 lut: no word here), offset} by list index, sorted on the cell
     uint32_t *cell_start;                   // ncells + 1
     uint32_t *cellw, *cellt, *pv; unsigned long long *ent;
     uint32_t *many, *many_prefix;           // ncells + 1

@@ -27,14 +27,15 @@ __device__ __forceinline__ uint32_t fingerprint_dev(const uint8_t *__restrict__ 
 // 15-bit reduced fingerprint: 3.5 bases to the right (7 bits, high) and 4 bases to the left (8 bits, low)
 __device__ __forceinline__ uint32_t reduce_fp(uint32_t fp) { return ((((fp >> 1) & 0x3fffu) >> 7) << 8) | ((fp >> 15) & 0xffu); }
 
-// one thread per query position: is a lookup word indexed here?
-__global__ void __launch_bounds__(1024) lut_enumerate_kernel(gbn::LutBuild B)
+// one thread per query position: is a lookup word indexed here?  Position p leaves {its cell, p} at list index p
+// (megablast chains, reported in descending offset order: qlen - 1 - p), positions without a word a key past every
+// cell: a STABLE sort of the list on the cell alone then has every cell's offsets in the reference's order -- 32-bit
+// keys, 2 * lut + 1 bits to sort, where rounds 1-3 sorted 64-bit (cell, offset) keys on 2 * lut + 24 bits (half the
+// passes, two thirds of the bytes per pass, no memset of the key array, no list reservation per block).
+__global__ void __launch_bounds__(256) lut_enumerate_kernel(gbn::LutBuild B)
 {
-    __shared__ uint32_t s_cnt[16], s_base;
-    for (int64_t chunk = blockIdx.x; chunk * 1024 < B.qlen; chunk += gridDim.x) {    // uniform over the workgroup
-    const int32_t p = (int32_t)(chunk * 1024 + threadIdx.x);
-    bool ok = false; uint32_t cell = 0;
-    if (p < B.qlen) {
+    for (int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; p < B.qlen; p += (int64_t)gridDim.x * blockDim.x) {
+        bool ok = false; uint32_t cell = 0;
         int lo = 0, hi = B.nseg;                    // last stretch that starts at or before p
         while (lo < hi) { const int m = (lo + hi) >> 1; if (B.seg_left[m] <= p) lo = m + 1; else hi = m; }
         if (lo > 0) {
@@ -48,26 +49,10 @@ __global__ void __launch_bounds__(1024) lut_enumerate_kernel(gbn::LutBuild B)
                 }
             }
         }
-    }
-    if (ok) atomicAdd(&B.count[cell], 1u);
-    // dense (key, offset) list: one reservation per block
-    const unsigned long long m = __ballot(ok);
-    const int lane = (int)(threadIdx.x & 63), wave = (int)(threadIdx.x >> 6);
-    if (lane == 0) s_cnt[wave] = (uint32_t)__popcll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        uint32_t tot = 0;
-        for (int w = 0; w < 16; w++) { const uint32_t c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
-        s_base = tot ? (uint32_t)atomicAdd(B.n_words, (unsigned long long)tot) : 0u;
-    }
-    __syncthreads();
-    if (ok) {
-        const uint32_t at = s_base + s_cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1));
-        const uint32_t qmax = (B.q_bits >= 32) ? 0xffffffffu : ((1u << B.q_bits) - 1u);
-        B.keys_a[at] = ((uint64_t)cell << B.q_bits) | (B.descending ? (qmax - (uint32_t)p) : (uint32_t)p);
+        if (ok) atomicAdd(&B.count[cell], 1u);
+        const int64_t at = B.descending ? (int64_t)B.qlen - 1 - p : p;
+        B.keys_a[at] = ok ? cell : (1u << (2 * B.lut));
         B.vals_a[at] = (uint32_t)p;
-    }
-    __syncthreads();                                // s_cnt / s_base are reused by the next chunk
     }
 }
 
@@ -83,7 +68,7 @@ __global__ void lut_overflow_kernel(const uint32_t *count, int64_t ncells, unsig
 // entries in chain order: fingerprint + offset
 __global__ void lut_entries_kernel(gbn::LutBuild B, int64_t n)
 {
-    const int64_t nn = n >= 0 ? n : (int64_t)*B.n_words;           // n < 0: the word count is still on the device only
+    const int64_t nn = n >= 0 ? n : (int64_t)B.cell_start[B.ncells];       // n < 0: the word count is still on the device only
     if (blockIdx.x == 0 && threadIdx.x == 0) B.ent[nn] = 0;         // pad entry: an empty list still has a valid pointer
     for (int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; k < nn; k += (int64_t)gridDim.x * blockDim.x) {
         const int32_t off = (int32_t)B.vals_b[k];
@@ -231,7 +216,7 @@ hipError_t lut_pack_query(const uint8_t *qbuf, int64_t qbuf_len, int64_t first, 
 hipError_t lut_enumerate(const LutBuild &b, hipStream_t st)
 {
     if (b.qlen <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_enumerate_kernel, dim3(polite_grid(b.qlen, 1024)), dim3(1024), 0, st, b);
+    hipLaunchKernelGGL(lut_enumerate_kernel, dim3(polite_grid(b.qlen, 256)), dim3(256), 0, st, b);
     return hipGetLastError();
 }
 hipError_t lut_overflow_cells(const LutBuild &b, unsigned long long *out, hipStream_t st)
@@ -249,7 +234,7 @@ hipError_t lut_scan(void *tmp, size_t &bytes, const uint32_t *in, uint32_t *out,
 }
 hipError_t lut_entries(const LutBuild &b, int64_t n, hipStream_t st)
 {
-    // n < 0: count on the device (B.n_words), at most b.qlen
+    // n < 0: count on the device (cell_start[ncells]), at most b.qlen
     hipLaunchKernelGGL(lut_entries_kernel, dim3(polite_grid(n >= 0 ? std::max<int64_t>(n, 1) : b.qlen, 256)), dim3(256), 0, st, b, n);
     return hipGetLastError();
 }

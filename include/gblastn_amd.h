@@ -170,7 +170,6 @@ int  gbn_db_cache_insert(const void *key, struct GbnDb *db);
 int  gbn_block_cache_find(const char *db_name, const int32_t *oids, int32_t n, struct GbnDb **out);
 int  gbn_block_cache_insert(const char *db_name, const int32_t *oids, int32_t n, struct GbnDb *db, struct GbnDb **kept);
 long long gbn_debug_db_bytes_uploaded(void);    /* tests: slab bytes copied host -> device by gbn_db_new / the shard builder so far */
-void gbn_debug_reload_switches(void);        /* tests: the GBN_* environment switches are read again at their next use */
 
 /* ---- database shard resident in HBM ---- */
 typedef struct GbnDb GbnDb;
