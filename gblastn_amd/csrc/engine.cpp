@@ -33,6 +33,8 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
 hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st);
+hipError_t launch_seed_order(const GbnKeyParams &k, int nsubj, uint32_t *scratch, hipStream_t st);       // seed_order.hip
+size_t seed_order_scratch_words(int64_t n, int nsubj, int group_bits);
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st, GbnKernelTimer *kt = nullptr);
 hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st, GbnKernelTimer *kt = nullptr);
 hipError_t launch_synth_fill(void *dev, int64_t nbytes, uint64_t seed, hipStream_t st);
@@ -763,6 +765,17 @@ static void wait_host() {
     { std::lock_guard<std::mutex> lk(E.host_mu); f = E.host_tail; }
     if (f.valid()) f.wait();
 }
+// the host replays queued up to the one `tail` stands for (a batch's or a set of results' last: replays run in the order
+// they were queued, so theirs are done when that one is) -- not the replays of LATER searches, which a pipelined caller
+// has queued behind them (round 4: gbn_prelim_search_end / gbn_batch_free of pass k waited for the replays of pass k + 1,
+// with the engine locked: 3.4 ms per blastn pass in which the next pass's scan could not be queued)
+static void wait_tail(std::shared_future<void> &slot) {
+    std::shared_future<void> f;
+    { std::lock_guard<std::mutex> lk(E.host_mu); f = slot; }
+    if (f.valid()) f.wait();
+    std::lock_guard<std::mutex> lk(E.host_mu);
+    if (slot.valid() && slot.wait_for(std::chrono::seconds(0)) == std::future_status::ready) slot = std::shared_future<void>();
+}
 static int wait_pending() {
     const int rc = wait_pending_gpu();
     wait_host();
@@ -1147,13 +1160,25 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     if (composite) {
         K.key_scan = KS.key_a; K.idx = KS.idx_a; K.v_bits = packed ? v_bits : 0;
         if (from_segments) { K.seg = E.slice_seg; K.seg_count = E.seg_counts; K.nseg = E.seg_n; K.seg_cap = E.seg_len; K.seg_first = E.seg_firsts; }
-        if (phase != 2) {
+        // Seeds that come in scan order, subject by subject (scan_fold_ordered_kernel's segments): a stable partition of every
+        // subject's seeds by slot is all that is left, and seed_order.hip does it as a counting sort that builds the keys
+        // on its way -- no key kernel, no radix passes (GBN_SEED_ORDER=0: keys + the library sort, as rounds 2-3)
+        const int nsubj = s1 - s0;
+        const bool order = from_segments && E.seg_ordered && packed && nsubj <= GBN_ORDER_MAX_SUBJ && (1 << K.group_bits) <= GBN_ORDER_MAX_SLOTS &&
+                           n >= (int64_t)nsubj * 64 && n < ((int64_t)1 << 31) && gbn::switch_value("GBN_SEED_ORDER", 1) != 0 &&
+                           seed_order_scratch_words(n, nsubj, K.group_bits) * sizeof(uint32_t) <= KS.sort_tmp_bytes;
+        if (phase != 2 && order) {
+            K.key_scan = KS.key_b;
+            KS.kt.mark(GBN_KT_SORT, st);
+            HIPCHK(launch_seed_order(K, nsubj, static_cast<uint32_t *>(KS.sort_tmp), st));
+            KS.kt.mark(-1, st);
+        } else if (phase != 2) {
             KS.kt.mark(GBN_KT_KEYS, st);
             HIPCHK(launch_seed_ckeys(K, st));
             size_t tb = KS.sort_tmp_bytes;
             KS.kt.mark(GBN_KT_SORT, st);
-            // (seeds that come in scan order -- scan_fold_ordered_kernel's segments -- are in the order of the key's scan-position
-            // bits already: the stable sort has subject | slot left to do)
+            // (seeds that come in scan order are in the order of the key's scan-position bits already: the stable sort has
+            // subject | slot left to do)
             const int s_done = (from_segments && E.seg_ordered) ? K.s_bits : 0;
             if (packed) HIPCHK(sort_keys_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, n, v_bits + s_done, v_bits + ck_bits, st));
             else HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, n, ck_bits, st));
@@ -1490,6 +1515,7 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
             // replay ever queued stays reachable from the newest one)
             prev = std::shared_future<void>();
         }).share();
+        bp->host_tail = E.host_tail; rp->host_tail = E.host_tail;
     }
     return GBN_OK;
 }
@@ -1754,6 +1780,39 @@ int gbn_block_cache_insert(const char *db_name, const int32_t *oids, int32_t n, 
     });
 }
 long long gbn_debug_db_bytes_uploaded(void) { return g_db_bytes_uploaded.load(); }
+
+// tests: seed_order.hip on segments given in host memory.  The keys of the seeds ordered by (subject, slot), scan order
+// inside, as the engine's seed stage builds them for the composite-key form (q_bits from qlen, s_bits from max_len;
+// container_hash: 512 slots, else diag_len slots).
+int gbn_debug_seed_order(const GbnDevSeed *seg, const uint32_t *seg_count, int nseg, uint32_t seg_cap, int nsubj, int subj_base,
+                         int container_hash, int diag_len, int32_t qlen, int32_t max_len, int q_descending, uint64_t *keys_out, int64_t *n_out)
+{
+    return gbn::guard(__func__, [&]() -> int {
+    if (!seg || !seg_count || nseg <= 0 || nseg > GBN_SLICE_SEGS || !keys_out || !n_out) { set_error("gbn_debug_seed_order: bad arguments"); return GBN_ERR_ARG; }
+    int rc = GBN_OK;
+    auto bits_for = [](uint64_t below) { int k = 1; while (k < 63 && ((uint64_t)1 << k) < below) k++; return k; };
+    GbnKeyParams K; std::memset(&K, 0, sizeof(K));
+    int64_t n = 0;
+    for (int g = 0; g < nseg; g++) n += std::min(seg_count[g], seg_cap);
+    *n_out = n;
+    if (n == 0) return GBN_OK;
+    K.n = n; K.q_descending = q_descending; K.container_hash = container_hash; K.diag_len = diag_len;
+    K.q_bits = std::min(32, bits_for((uint64_t)qlen + 1));
+    K.group_bits = container_hash ? 9 : bits_for((uint64_t)std::max(diag_len, 2));
+    K.s_bits = bits_for((uint64_t)max_len + 1); K.qh_bits = std::max(0, K.q_bits - K.group_bits);
+    K.subj_base = subj_base; K.v_bits = 8 + K.qh_bits;
+    if (K.group_bits + bits_for((uint64_t)nsubj + 1) + K.s_bits + K.v_bits > 64) { set_error("gbn_debug_seed_order: the key does not fit 64 bits"); return GBN_ERR_ARG; }
+    GbnDevSeed *d_seg = nullptr; uint32_t *d_cnt = nullptr, *d_tmp = nullptr; unsigned long long *d_first = nullptr; uint64_t *d_keys = nullptr;
+    auto done = [&](int code) { dev_free(d_seg); dev_free(d_cnt); dev_free(d_tmp); dev_free(d_first); dev_free(d_keys); return code; };
+    if ((rc = dev_upload(d_seg, seg, (size_t)nseg * seg_cap)) || (rc = dev_upload(d_cnt, seg_count, (size_t)nseg)) ||
+        (rc = dev_alloc(d_first, (size_t)nseg + 1)) || (rc = dev_alloc(d_keys, (size_t)n)) ||
+        (rc = dev_alloc(d_tmp, seed_order_scratch_words(n, nsubj, K.group_bits)))) return done(rc);
+    K.seg = d_seg; K.seg_count = d_cnt; K.nseg = nseg; K.seg_cap = seg_cap; K.seg_first = d_first; K.key_scan = d_keys;
+    if (launch_seed_order(K, nsubj, d_tmp, nullptr) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess ||
+        hipMemcpy(keys_out, d_keys, (size_t)n * 8, hipMemcpyDeviceToHost) != hipSuccess) { set_error("gbn_debug_seed_order: launch failed"); return done(GBN_ERR_HIP); }
+    return done(GBN_OK);
+    });
+}
 void gbn_release_db_memory(void) {
     std::map<const void *, GbnDb *> drop;
     std::map<BlockKey, GbnDb *> drop_blocks;
@@ -2102,9 +2161,8 @@ void gbn_batch_free(GbnBatch *b) {
     if (b->dev && b->dev->eng) {
         enter(b->dev->eng);
         // an extension stage still reading this batch finishes first (its memory goes back to the pool, not to hipFree)
-        std::lock_guard<std::mutex> lk(E.mu);
-        if (E.has_pending && E.pending_batch == b) (void)wait_pending();
-        wait_host();                                        // (a queued host replay reads the batch's options and contexts)
+        { std::lock_guard<std::mutex> lk(E.mu); if (E.has_pending && E.pending_batch == b) (void)wait_pending_gpu(); }
+        wait_tail(b->host_tail);                            // (a queued host replay reads the batch's options and contexts; the engine is not locked meanwhile)
     }
     free_device_batch(b->dev); delete b;
 }
@@ -2129,9 +2187,8 @@ void gbn_results_free(GbnResults *r) {
     if (!r) return;
     if (r->engine) {                                        // a stage of the engine that filled them may still write to them
         enter(static_cast<Engine *>(r->engine));
-        std::lock_guard<std::mutex> lk(E.mu);
-        if (E.has_pending && E.pending_res == r) (void)wait_pending();
-        wait_host();
+        { std::lock_guard<std::mutex> lk(E.mu); if (E.has_pending && E.pending_res == r) (void)wait_pending_gpu(); }
+        wait_tail(r->host_tail);
         { std::lock_guard<std::mutex> lk2(E.failed_mu); E.failed.erase(r); }
     }
     delete r;
@@ -2284,8 +2341,11 @@ int gbn_prelim_search_end(GbnResults *results) {
     // a stage that belongs to other results stays in flight: these results were completed when that
     // stage was queued (one in flight at most)
     int rc;
-    if (results && E.has_pending && E.pending_res != results) { wait_host(); rc = take_failure(results); }    // (its last host replay may still run)
-    else { (void)wait_pending(); rc = results ? take_failure(results) : GBN_OK; }
+    if (results) {
+        if (E.has_pending && E.pending_res == results) (void)wait_pending_gpu();
+        wait_tail(results->host_tail);                      // (its last host replay may still run; those of later searches are not waited for)
+        rc = take_failure(results);
+    } else { (void)wait_pending(); rc = GBN_OK; }
     if (!rc && results && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, results->merge, results->diag); results->chunk_len = 0; }
     return rc;
     });

@@ -103,6 +103,19 @@ struct GbnKeyParams {
 #define GBN_SLICE_MAX       16          // most slices (passes over the subjects) it is used with
 #define GBN_SLICE_SEGS      4096        // most output segments of a launch (a workgroup's, or a wave's when the seeds come in scan order)
 
+// seed_order.hip: the seeds of an ordered scan by (subject, slot) without a radix sort
+#define GBN_ORDER_CHUNK     4096        // seeds per histogram (a chunk never crosses a subject)
+#define GBN_ORDER_MAX_SUBJ  4096        // most subjects of a launch
+#define GBN_ORDER_MAX_SLOTS 2048        // most slots of the diagonal container (the hash container has 512)
+struct GbnOrderParams {
+    GbnKeyParams K;                     // the segments, the key layout; key_scan = the ordered keys
+    int nsubj;
+    int32_t *seg_next;                  // GBN_SLICE_SEGS words of scratch
+    uint32_t *subj_first, *chunk_first; // nsubj + 1 each: first seed / first chunk of a subject
+    uint32_t *counts;                   // [chunk][slot]
+    uint32_t *slot_base;                // [subject][slot]
+};
+
 // seeds per launch below which the diagonal kernel runs thread-per-seed instead of on compacted run heads
 #ifndef GBN_DIAG_COMPACT_MIN
 #define GBN_DIAG_COMPACT_MIN (1 << 20)
@@ -132,6 +145,23 @@ struct GbnKernelTimer {
     }
     void destroy() { if (made) for (int i = 0; i < CAP; i++) (void)hipEventDestroy(ev[i]); made = false; n = 0; }
 };
+#endif
+
+#ifdef __HIPCC__
+// The composite key of a seed (seed_ckeys_kernel, seed_order_scatter_kernel): subject | slot | s_scan, and the value that
+// travels with it (ext_left | high bits of the query key << 8).  slot = the seed's cell of the diagonal container.
+__device__ __forceinline__ uint64_t gbn_composite_key(const GbnKeyParams &K, const GbnDevSeed &sd, uint32_t qmax, uint32_t &slot, uint32_t &val)
+{
+    const uint32_t qkey = K.q_descending ? (qmax - (uint32_t)sd.q_pos) : (uint32_t)sd.q_pos;
+    slot = K.container_hash ? ((uint32_t)(sd.s_scan - sd.q_pos) & 511u)
+                            : ((uint32_t)(sd.s_scan + K.diag_len - sd.q_pos) & (uint32_t)(K.diag_len - 1));
+    uint64_t key = ((uint64_t)(uint32_t)(sd.subj - K.subj_base) << K.group_bits) | slot;
+    key = (key << K.s_bits) | (uint32_t)sd.s_scan;
+    // the high bits of the query key order the (rare) seeds of one (subject, slot, scan position): they travel in
+    // the value, and seed_ext_kernel puts such a group into their order -- nine bits less to sort
+    val = (uint32_t)sd.ext_left | ((K.qh_bits ? (qkey >> K.group_bits) : 0u) << 8);
+    return key;
+}
 #endif
 
 // ---- switches (the library's environment variables): read through these two functions at EVERY use (rounds

@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/gblastn_amd.h"
 #include <cstdint>
+#include <future>
 #include <string>
 #include <utility>
 #include <vector>
@@ -46,6 +47,8 @@ void trace_mark(const char *what);   // GBN_TRACE=1: wall-clock marks on stderr 
 }  // namespace gbn
 
 struct GbnBatch {
+    // the last host replay queued that reads this batch (engine.cpp: under the engine's host_mu); freeing the batch waits for it
+    std::shared_future<void> host_tail;
     GbnOptions opt{};
     int32_t nq = 0;
     std::vector<GbnContext> ctx;
@@ -114,6 +117,7 @@ struct GbnResults {
     // the caller has freed the batch.  `diag` is the caller's and must outlive the search, as the API says.
     struct ChunkMerge { gbn::Karlin kbp_gap; std::vector<int64_t> eff_searchsp; double evalue = 0; } merge;
     GbnDiagnostics *diag = nullptr;
+    std::shared_future<void> host_tail; // the last host replay queued that appends to these results (under the engine's host_mu)
     int32_t chunk_len = 0;              // > 0: hsps holds chunk lists (pad_ = ordinal + 1) that merge_chunk_lists has yet to join
 };
 

@@ -630,32 +630,7 @@ extern "C" __global__ void seed_keys_kernel(GbnKeyParams K)
 // a handful per million -- by the high bits of the query key, which seed_ext_kernel applies.  The seed follows from
 // key and value (q_pos's low bits = (s_scan - slot) mod slots; value = ext_left | high bits of the query key << 8):
 // no second sort, no gathers of seeds by rank afterwards.
-// (segmented input: the index of every segment's first seed, first[nseg] = their number -- one small workgroup, so that it
-// finds room next to the gapped stage of the range before, whose waves fill the CUs: a 1024-thread workgroup waited
-// 0.8 ms for a CU to itself)
-extern "C" __global__ void __launch_bounds__(256) seg_first_kernel(const uint32_t *seg_count, int nseg, uint32_t seg_cap, unsigned long long *first)
-{
-    constexpr int PER = (GBN_SLICE_SEGS + 255) / 256;
-    __shared__ unsigned long long s_wave[4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    uint32_t c[PER]; unsigned long long sum = 0;
-    #pragma unroll
-    for (int k = 0; k < PER; k++) { const int sg = tid * PER + k; c[k] = sg < nseg ? min(seg_count[sg], seg_cap) : 0u; }
-    #pragma unroll
-    for (int k = 0; k < PER; k++) sum += c[k];
-    unsigned long long incl = sum;
-    #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const unsigned long long v = __shfl_up(incl, d); incl += (lane >= d) ? v : 0ull; }
-    if (lane == 63) s_wave[wave] = incl;
-    __syncthreads();
-    unsigned long long at = incl - sum, total = 0;
-    #pragma unroll
-    for (int w = 0; w < 4; w++) { at += (w < wave) ? s_wave[w] : 0ull; total += s_wave[w]; }
-    #pragma unroll
-    for (int k = 0; k < PER; k++) { const int sg = tid * PER + k; if (sg < nseg) first[sg] = at; at += c[k]; }
-    if (tid == 0) first[nseg] = total;
-}
-
+// (segmented input: seed_order.hip's seg_first_kernel gives the index of every segment's first seed)
 extern "C" __global__ void __launch_bounds__(256) seed_ckeys_kernel(GbnKeyParams K)
 {
     // (no LDS and no barrier in here: the kernel runs next to the gapped stage of the range before, whose waves keep the
@@ -692,14 +667,8 @@ extern "C" __global__ void __launch_bounds__(256) seed_ckeys_kernel(GbnKeyParams
         for (int u = 0; u < 4; u++) {
             const int64_t iu = i + 256 * u;
             if (iu >= i_end) continue;
-            const uint32_t qkey = K.q_descending ? (qmax - (uint32_t)sd[u].q_pos) : (uint32_t)sd[u].q_pos;
-            const uint32_t slot = K.container_hash ? ((uint32_t)(sd[u].s_scan - sd[u].q_pos) & 511u)
-                                                   : ((uint32_t)(sd[u].s_scan + K.diag_len - sd[u].q_pos) & (uint32_t)(K.diag_len - 1));
-            uint64_t key = ((uint64_t)(uint32_t)(sd[u].subj - K.subj_base) << K.group_bits) | slot;
-            key = (key << K.s_bits) | (uint32_t)sd[u].s_scan;
-            // the high bits of the query key order the (rare) seeds of one (subject, slot, scan position): they travel in
-            // the value, and seed_ext_kernel puts such a group into their order -- nine bits less to sort
-            const uint32_t val = (uint32_t)sd[u].ext_left | ((K.qh_bits ? (qkey >> K.group_bits) : 0u) << 8);
+            uint32_t slot, val;
+            const uint64_t key = gbn_composite_key(K, sd[u], qmax, slot, val);
             if (K.v_bits > 0) K.key_scan[iu] = (key << K.v_bits) | val;        // key and value in one word: a sort of keys only, on the bits above the value
             else { K.key_scan[iu] = key; K.idx[iu] = val; }
         }
@@ -2614,6 +2583,7 @@ int scan_slice_count(const GbnScanParams &p)
 }
 
 // workgroups scan_slice_kernel is launched with for this table on a chip of num_cu CUs (= segments of its output)
+hipError_t launch_seg_first(const GbnKeyParams &k, hipStream_t st);       // seed_order.hip
 int scan_slice_blocks(const GbnScanParams &p, int num_cu)
 {
     const int nslices = scan_slice_count(p);
@@ -2636,7 +2606,8 @@ hipError_t launch_seed_compact(const GbnDevSeed *seg, const uint32_t *seg_count,
 {
     if (nseg <= 0) return hipSuccess;
     if (!seg_first || nseg > GBN_SLICE_SEGS) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(seg_first_kernel, dim3(1), dim3(256), 0, st, seg_count, nseg, seg_cap, seg_first);
+    GbnKeyParams k; std::memset(&k, 0, sizeof(k)); k.seg_count = seg_count; k.nseg = nseg; k.seg_cap = seg_cap; k.seg_first = seg_first;
+    if (hipError_t e = launch_seg_first(k, st)) return e;
     hipLaunchKernelGGL(seed_compact_kernel, dim3((unsigned)(nseg * (nseg > 1024 ? 1 : 8))), dim3(256), 0, st, seg, seg_count, seg_first, nseg, seg_cap, out, out_cap);
     return hipGetLastError();
 }
@@ -2699,7 +2670,7 @@ hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st)
     if (k.n <= 0) return hipSuccess;
     if (k.nseg > 0) {
         if (!k.seg_first || k.nseg > GBN_SLICE_SEGS) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(seg_first_kernel, dim3(1), dim3(256), 0, st, k.seg_count, k.nseg, k.seg_cap, const_cast<unsigned long long *>(k.seg_first));
+        if (hipError_t e = launch_seg_first(k, st)) return e;
     }
     hipLaunchKernelGGL(seed_ckeys_kernel, dim3((unsigned)std::min<int64_t>((k.n + 255) / 256, 4096)), dim3(256), 0, st, k);
     return hipGetLastError();
@@ -2796,7 +2767,8 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st, Gbn
             hipLaunchKernelGGL(gap_context_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p, ctx_of);
             const int64_t lblocks = std::max<int64_t>(1, std::min<int64_t>(need, p.max_blocks > 0 ? std::max(1, p.max_blocks * 2 / 3) : need));   // 16 of its workgroups fit a CU (LDS)
             redo_list = p.scratch + 16 + p.n;
-            hipLaunchKernelGGL(dynprog_lane_kernel, dim3((unsigned)lblocks), dim3(64), 0, st, p, reinterpret_cast<unsigned long long *>(p.scratch), ctx_of, redo_list);
+            const size_t lane_pad = (size_t)gbn::switch_value("GBN_LANE_LDS_PAD", 0);
+            hipLaunchKernelGGL(dynprog_lane_kernel, dim3((unsigned)lblocks), dim3(64), lane_pad, st, p, reinterpret_cast<unsigned long long *>(p.scratch), ctx_of, redo_list);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             w.redo_only = 1;

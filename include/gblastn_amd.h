@@ -113,7 +113,7 @@ typedef struct GbnInitHit {
 /* BlastDiagnostics subset (COREI/blast_diagnostics.h) */
 /* kernel classes of GbnDiagnostics::kernel_ms */
 #define GBN_KT_KEYS        0   /* seed keys (seed_keys / seed_ckeys / group_keys kernels) */
-#define GBN_KT_SORT        1   /* radix sorts of the seed keys */
+#define GBN_KT_SORT        1   /* the seeds put into the diagonal filter's order: radix sorts of the keys, or the seed_order kernels (which build the keys too) */
 #define GBN_KT_SEED_EXT    2   /* seed_ext(_ck)_kernel + seed_exact_kernel: every seed extended */
 #define GBN_KT_REPLAY      3   /* run_heads_kernel + diag_replay_kernel */
 #define GBN_KT_DIAG        4   /* diag_ungapped_kernel (few seeds: filter + extension in one) */
@@ -169,6 +169,11 @@ int  gbn_db_cache_insert(const void *key, struct GbnDb *db);
  * *kept is the one that stays.  gbn_release_db_memory frees the blocks too. */
 int  gbn_block_cache_find(const char *db_name, const int32_t *oids, int32_t n, struct GbnDb **out);
 int  gbn_block_cache_insert(const char *db_name, const int32_t *oids, int32_t n, struct GbnDb *db, struct GbnDb **kept);
+struct GbnDevSeed;
+/* tests: the seed-order kernels (csrc/seed_order.hip) on segments of seeds given in HOST memory: keys_out[0 .. *n_out) =
+ * the composite keys of the seeds ordered by (subject, slot), scan order inside (see GbnExtParams::ck_*) */
+int gbn_debug_seed_order(const struct GbnDevSeed *seg, const uint32_t *seg_count, int nseg, uint32_t seg_cap, int nsubj, int subj_base,
+                         int container_hash, int diag_len, int32_t qlen, int32_t max_len, int q_descending, uint64_t *keys_out, int64_t *n_out);
 long long gbn_debug_db_bytes_uploaded(void);    /* tests: slab bytes copied host -> device by gbn_db_new / the shard builder so far */
 
 /* ---- database shard resident in HBM ---- */

@@ -606,3 +606,65 @@ def test_switches_are_read_at_every_use(monkeypatch):
         ps.close()
     assert len(set(h for _, h in seen)) == 1
     assert seen[3][0] != seen[0][0]                  # the direct-probe scan did run in the fourth round
+
+
+def _bits_for(below):
+    k = 1
+    while k < 63 and (1 << k) < below:
+        k += 1
+    return k
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nsubj,nseg,mean,container_hash,diag_len,q_desc", [
+    (7, 64, 30_000, 1, 0, 0),            # a few subjects of many chunks each
+    (300, 4096, 3_000, 1, 0, 1),         # every segment table entry in use, most subjects inside one chunk
+    (5, 16, 50_000, 0, 2048, 0),         # diagonal array: 2,048 slots
+    (4096, 700, 70, 1, 0, 0),            # as many subjects as a launch takes, most with a handful of seeds, many without
+    (1, 3, 4096, 1, 0, 0),               # one subject, exactly one chunk ...
+    (1, 3, 4097, 1, 0, 1),               # ... and one seed more
+    (3, 4096, 2, 1, 0, 0),               # nearly all segments empty
+])
+def test_seed_order_kernels_equal_a_stable_sort(nsubj, nseg, mean, container_hash, diag_len, q_desc):
+    """csrc/seed_order.hip (the seeds of an ordered scan by (subject, slot), scan order inside -- the order in which the diagonal
+    container meets them, CORE/na_ungapped.c:611-922) against numpy's stable sort of the same composite keys: segments of
+    uneven length, empty ones, subjects without seeds, subjects across many segments and segments across many subjects."""
+    rng = np.random.default_rng(nsubj * 1000 + nseg)
+    qlen, max_len, subj_base = 200_001, 1_000_000, 17
+    counts = rng.poisson(mean, nsubj) if mean > 100 else rng.integers(0, 2 * mean + 1, nsubj)
+    if nsubj in (1,):
+        counts[:] = mean
+    counts[rng.random(nsubj) < 0.2] = 0 if nsubj > 1 else counts[0]
+    n = int(counts.sum())
+    subj = np.repeat(np.arange(nsubj, dtype=np.int32) + subj_base, counts)
+    s_scan = np.concatenate([np.sort(rng.integers(0, max_len, c)) for c in counts]).astype(np.int32) if n else np.zeros(0, np.int32)
+    q_pos = rng.integers(0, qlen, n).astype(np.int32)
+    ext_left = rng.integers(0, 17, n).astype(np.int32)
+    seeds = np.stack([subj, s_scan, q_pos, ext_left], axis=1).astype(np.int32)
+    cuts = np.sort(rng.integers(0, n + 1, nseg - 1)) if n else np.zeros(nseg - 1, np.int64)
+    if nseg > 1000:
+        cuts[: nseg // 2] = cuts[nseg // 2]           # a run of empty segments in front
+    bounds = np.concatenate([[0], cuts, [n]])
+    seg_count = np.diff(bounds).astype(np.uint32)
+    seg_cap = int(max(seg_count.max(), 1)) + 5
+    seg = np.full((nseg, seg_cap, 4), -7, np.int32)
+    for g in range(nseg):
+        seg[g, : seg_count[g]] = seeds[bounds[g]: bounds[g + 1]]
+    reported = seg_count.copy()
+    out = np.zeros(max(n, 1), np.uint64)
+    n_out = C.c_int64(0)
+    L = api.lib()
+    api._check(L.gbn_debug_seed_order(seg.ctypes.data, reported.ctypes.data, nseg, seg_cap, nsubj, subj_base, container_hash, diag_len,
+                                      qlen, max_len, q_desc, out.ctypes.data, C.byref(n_out)))
+    assert n_out.value == n
+    q_bits, s_bits = min(32, _bits_for(qlen + 1)), _bits_for(max_len + 1)
+    gb = 9 if container_hash else _bits_for(max(diag_len, 2))
+    qh_bits = max(0, q_bits - gb)
+    v_bits = 8 + qh_bits
+    qkey = ((1 << q_bits) - 1 - q_pos.astype(np.int64)) if q_desc else q_pos.astype(np.int64)
+    slot = ((s_scan.astype(np.int64) - q_pos) & 511) if container_hash else ((s_scan.astype(np.int64) + diag_len - q_pos) & (diag_len - 1))
+    group = ((subj.astype(np.int64) - subj_base) << gb) | slot
+    val = ext_left.astype(np.int64) | ((qkey >> gb if qh_bits else 0) << 8)
+    key = ((((group << s_bits) | s_scan) << v_bits) | val).astype(np.uint64)
+    expect = key[np.argsort(group, kind="stable")]
+    assert np.array_equal(out[:n], expect)

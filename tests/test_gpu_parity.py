@@ -603,6 +603,42 @@ def test_slice_scan_with_repeats_that_overflow_a_segment():
     assert ps2.diagnostics.scan_launches == 1
 
 
+def test_seeds_ordered_by_the_counting_sort_and_by_the_library_sort(monkeypatch):
+    """blastn W=11, table as wide as the word: the ordered scan's seeds go to the diagonal filter through seed_order.hip (a
+    counting sort per subject and slot, keys built on the way; default) or through seed_ckeys_kernel + the library's radix
+    sort (GBN_SEED_ORDER=0, rounds 2-3).  Subjects of very different lengths, some too short for a word, a homolog in every
+    fifth: the HSPs of both ways are the oracle's, and the kernel-class timers say which way ran."""
+    from oracle import orc
+    rng = np.random.default_rng(77)
+    queries = [rng.integers(0, 4, int(n), dtype=np.uint8) for n in rng.integers(600, 1400, 14)]
+    lens = [int(x) for x in rng.integers(3, 30_000, 40)]
+    lens[3], lens[17], lens[39] = 5, 10, 11
+    subs = [rng.integers(0, 4, n, dtype=np.uint8) for n in lens]
+    for i in range(0, 40, 5):
+        if lens[i] > 2000:
+            q = queries[i % len(queries)]
+            subs[i][500:500 + 400] = q[100:500]
+    subjects = [(orc.pack_ncbi2na(x), len(x)) for x in subs]
+    opt = api.default_options("blastn", db_length=sum(lens), db_num_seqs=len(subs))
+    ora, osearch = util.oracle_run(opt, queries, subjects)
+    monkeypatch.setenv("GBN_DIAG_COMPACT_MIN", "1")
+    monkeypatch.delenv("GBN_SCAN_BINS", raising=False)
+    seen = {}
+    for order in ("1", "0"):
+        monkeypatch.setenv("GBN_SEED_ORDER", order)
+        ps = api.BlastPrelimSearch(queries, opt, api.BlastSeqSrc.from_packed(subjects))
+        info = ps.info()
+        assert (info["lut_width"], info["scan_step"], info["scan_path"]) == (11, 1, 2), info
+        gpu = ps.run(keep_stages=False)
+        util.compare_stages(gpu, ora)
+        km = dict(zip(api.GbnDiagnostics.KERNEL_CLASSES, list(ps.diagnostics.kernel_ms)))
+        seen[order] = (gpu["hsps"].tobytes(), km)
+        ps.close()
+    assert seen["1"][0] == seen["0"][0] and len(seen["1"][0]) > 0
+    keys = [k for k in api.GbnDiagnostics.KERNEL_CLASSES if "key" in k][0]
+    assert seen["1"][1][keys] == 0.0 and seen["0"][1][keys] > 0.0, (seen["1"][1], seen["0"][1])
+
+
 @pytest.mark.parametrize("task,period", [("megablast", 5), ("megablast", 13), ("blastn", 3)])
 def test_repeats_in_the_queries_give_long_cells(task, period):
     """Queries that carry a short-period repeat put hundreds of offsets into a few cells of the table, in descending
