@@ -136,6 +136,9 @@ struct Engine {
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
     uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;             // per-run stream cursors (6-byte records)
     GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
+    // what the host reads after a scan, in ONE pinned block filled by asynchronous copies behind the kernels (round 4: the
+    // counters, the overflow word and the rare-path counts came back through three blocking copies to pageable memory)
+    struct ScanBack { unsigned long long cnt[2], seg_max; uint32_t overflow, pad_; uint32_t rare_counts[2048]; } *scan_back = nullptr;
     uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;   // [nb][nwriters] + overflow flag
     // a second set of the five buffers above: the rare kernel of pass k reads one set on stream2 while the binning
     // and probe kernels of pass k + 1 fill the other (search_range, deferred rare path); swapped when a pass is handed over
@@ -900,6 +903,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     if (ts.ntiles == 0) return GBN_OK;
     if (nb > 1 && ts.ntiles > (1 << 19)) { set_error("subject range too large for 32-bit position ids"); return GBN_ERR_ARG; }
     if ((rc = grow_seed_buffers(std::max<size_t>(E.seed_cap, (size_t)1 << 22)))) return rc;
+    if (!E.scan_back) { HIPCHK(hipHostMalloc((void **)&E.scan_back, sizeof(*E.scan_back))); std::memset(E.scan_back, 0, sizeof(*E.scan_back)); }
     int64_t npos = 0;
     if (nb > 1)
         for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) npos += (db.len[s] - b.lut.lut) / b.lut.step + 1;
@@ -1000,14 +1004,16 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             binned = true;
             if (defer) { defer->B = B; defer->grid2 = grid2; }
             HIPCHK(hipEventRecord(E.ev1, E.stream));
-            HIPCHK(hipMemcpyAsync(&overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
+            HIPCHK(hipMemcpyAsync(&E.scan_back->overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
+            HIPCHK(hipMemcpyAsync(E.scan_back->rare_counts, E.rare_counts, (size_t)grid2 * 4, hipMemcpyDeviceToHost, E.stream));
         }
-        HIPCHK(hipMemcpyAsync(cnt, E.counters, 2 * sizeof(unsigned long long), hipMemcpyDeviceToHost, E.stream));
-        unsigned long long seg_max = 0;
-        if (sliced) HIPCHK(hipMemcpyAsync(&seg_max, E.counters + 2, sizeof(seg_max), hipMemcpyDeviceToHost, E.stream));
+        HIPCHK(hipMemcpyAsync(E.scan_back->cnt, E.counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, E.stream));     // seeds, raw hits, the fullest segment
         trace_mark("scan: kernels queued");
         HIPCHK(hipStreamSynchronize(E.stream));
         trace_mark("scan: kernels done");
+        cnt[0] = E.scan_back->cnt[0]; cnt[1] = E.scan_back->cnt[1];
+        const unsigned long long seg_max = sliced ? E.scan_back->seg_max : 0;
+        if (binned) overflow = E.scan_back->overflow;
         finish_build(b.dev);                                // (the scan has waited for the builder's event)
         if (diag) {
             float ms = 0; (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
@@ -1021,10 +1027,8 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         }
         if (nb > 1) {
             const int grid2 = std::max(8, E.num_cu & ~7);
-            std::vector<uint32_t> rc_host((size_t)grid2);
-            HIPCHK(hipMemcpy(rc_host.data(), E.rare_counts, (size_t)grid2 * 4, hipMemcpyDeviceToHost));
             unsigned long long sc = 0; uint32_t mx = 0;
-            for (uint32_t v : rc_host) { sc += v; mx = std::max(mx, v); }
+            for (int i = 0; i < grid2; i++) { const uint32_t v = E.scan_back->rare_counts[i]; sc += v; mx = std::max(mx, v); }
             if (gbn::switch_is_set("GBN_DBG")) fprintf(stderr, "[gbn dbg] rare-path items %llu, seeds %llu, raw %llu\n", sc, cnt[0], cnt[1]);
             if (gbn::switch_value("GBN_DBG", 0) & 32) {
                 {   // stream fill statistics
@@ -1829,6 +1833,7 @@ static void release_engine() {              // (the calling thread has entered i
     (void)pool_check_guards();
     E.binkey.valid = false;
     dev_free(E.slice_seg); E.slice_seg_cap = 0; dev_free(E.seg_counts); dev_free(E.seg_firsts);
+    if (E.scan_back) { (void)hipHostFree(E.scan_back); E.scan_back = nullptr; }
     hitbuf_drain();
     dev_free(E.seeds_async); E.seeds_async_cap = 0; if (E.ev_seed) { (void)hipEventDestroy(E.ev_seed); E.ev_seed = nullptr; }
     dev_free(E.seeds);
@@ -2337,16 +2342,18 @@ int gbn_prelim_search_end(GbnResults *results) {
         enter(e);
     }
     if (!E.ready) return GBN_OK;
-    std::lock_guard<std::mutex> lk(E.mu);
     // a stage that belongs to other results stays in flight: these results were completed when that
-    // stage was queued (one in flight at most)
+    // stage was queued (one in flight at most).  The engine is locked for the look at the stage in flight only: a caller's
+    // other thread may be inside gbn_prelim_search_begin of the next pass meanwhile.
     int rc;
-    if (results) {
+    {
+        std::lock_guard<std::mutex> lk(E.mu);
+        if (!results) { (void)wait_pending(); return GBN_OK; }
         if (E.has_pending && E.pending_res == results) (void)wait_pending_gpu();
-        wait_tail(results->host_tail);                      // (its last host replay may still run; those of later searches are not waited for)
-        rc = take_failure(results);
-    } else { (void)wait_pending(); rc = GBN_OK; }
-    if (!rc && results && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, results->merge, results->diag); results->chunk_len = 0; }
+    }
+    wait_tail(results->host_tail);                          // (its last host replay may still run; those of later searches are not waited for)
+    rc = take_failure(results);
+    if (!rc && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, results->merge, results->diag); results->chunk_len = 0; }
     return rc;
     });
 }

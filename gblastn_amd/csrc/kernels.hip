@@ -2767,8 +2767,7 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st, Gbn
             hipLaunchKernelGGL(gap_context_kernel, dim3((unsigned)((p.n + 255) / 256)), dim3(256), 0, st, p, ctx_of);
             const int64_t lblocks = std::max<int64_t>(1, std::min<int64_t>(need, p.max_blocks > 0 ? std::max(1, p.max_blocks * 2 / 3) : need));   // 16 of its workgroups fit a CU (LDS)
             redo_list = p.scratch + 16 + p.n;
-            const size_t lane_pad = (size_t)gbn::switch_value("GBN_LANE_LDS_PAD", 0);
-            hipLaunchKernelGGL(dynprog_lane_kernel, dim3((unsigned)lblocks), dim3(64), lane_pad, st, p, reinterpret_cast<unsigned long long *>(p.scratch), ctx_of, redo_list);
+            hipLaunchKernelGGL(dynprog_lane_kernel, dim3((unsigned)lblocks), dim3(64), 0, st, p, reinterpret_cast<unsigned long long *>(p.scratch), ctx_of, redo_list);
             e = hipGetLastError();
             if (e != hipSuccess) return e;
             w.redo_only = 1;
