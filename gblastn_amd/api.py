@@ -88,7 +88,7 @@ EXPORTS = ["gbn_init", "gbn_release", "gbn_release_db_memory", "gbn_debug_check_
            "gbn_pipeline_diagnostics",
            "gbn_batch_scan_params", "gbn_batch_ext_params", "gbn_batch_gap_params", "gbn_batch_diag_layout",
            "gbn_prelim_search_lists", "gbn_db_cache_find", "gbn_db_cache_insert", "gbn_block_cache_find", "gbn_block_cache_insert",
-           "gbn_debug_db_bytes_uploaded", "gbn_debug_seed_order",
+           "gbn_debug_db_bytes_uploaded", "gbn_debug_seed_order", "gbn_debug_bin_ahead_hits",
            "gbn_set_max_dbseq_len", "gbn_db_set_ambiguities", "gbn_traceback_merge", "gbn_shard_builder_new", "gbn_shard_builder_add", "gbn_shard_builder_finish", "gbn_shard_builder_free"]
 
 # ---- include/gblastn_amd_kernels.h: parameter blocks of the gbn_launch_* entry points (device pointers as integers)
@@ -162,6 +162,7 @@ def lib():
         L.gbn_block_cache_find.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.POINTER(C.c_void_p)]
         L.gbn_block_cache_insert.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gbn_debug_db_bytes_uploaded.restype = C.c_longlong; L.gbn_debug_db_bytes_uploaded.argtypes = []
+        L.gbn_debug_bin_ahead_hits.restype = C.c_longlong; L.gbn_debug_bin_ahead_hits.argtypes = []
         L.gbn_debug_seed_order.restype = C.c_int
         L.gbn_debug_seed_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int32,
                                            C.c_int, C.c_void_p, C.POINTER(C.c_int64)]

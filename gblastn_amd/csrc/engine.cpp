@@ -149,6 +149,18 @@ struct Engine {
         std::swap(rareq, alt.rareq); std::swap(rareq_cap, alt.rareq_cap); std::swap(rare_counts, alt.rare_counts);
         std::swap(bin_count, alt.bin_count); std::swap(bin_count_cap, alt.bin_count_cap);
     }
+    // Binning ahead (pipelined passes over one range of one shard, GBN_BIN_AHEAD=0: off): the binning kernel reads the
+    // subjects only, so a pass queues the binning kernel of the NEXT pass -- into the other set of buffers -- behind its own
+    // kernels and in front of its host synchronisation; the next pass, if its records are to be the same (same shard, range,
+    // table shape, stream geometry), finds them there and queues probe + rare kernel only.  Every pass still bins once; what
+    // goes is the idle time of the GPU between a pass's last kernel and the next pass's first (0.5 ms of 13.5 on C2).
+    struct BinAhead { bool valid = false; const void *db = nullptr; int32_t s0 = 0, s1 = 0; int lut = 0, step = 0, nb = 0, nwriters = 0, rfl = 0, rfrbits = 0, cbits = 0;
+                      size_t subcap = 0; const void *tiles = nullptr;
+                      hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; int pair = 0; } ahead;     // (two pairs of events around the kernel: a pass reads one pair while it records the other)
+    bool want_ahead = false;            // the pass being scanned may bin ahead (set by run_search)
+    bool seed_copy_pending = false;     // ev_seed stands for a copy of the seeds on stream2 that the next scan must not overtake
+    long long ahead_hits = 0;
+    hipEvent_t ev_back = nullptr;       // behind the read-back copies of a scan
     hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;       // around a deferred rare kernel (stream2)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk[4] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex mu;
@@ -909,7 +921,11 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) npos += (db.len[s] - b.lut.lut) / b.lut.step + 1;
     double slack = 1.25;
     size_t rare_seg_hint = 0, slice_seg_cap = 0; int slice_blocks = 0; bool slice_ordered = false;
+    const bool reuse_binning = gbn::switch_value("GBN_REUSE_BINNING", 0) != 0;
+    GbnBinParams last_B; std::memset(&last_B, 0, sizeof(last_B)); int last_grid2 = 0;
+    if (E.seed_copy_pending) { HIPCHK(hipStreamWaitEvent(E.stream, E.ev_seed, 0)); E.seed_copy_pending = false; }
     for (;;) {
+        bool binned_ahead = false; int hit_pair = -1;
         HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream));
         GbnScanParams P; fill_scan_params(P, b, db, ts);
         uint32_t overflow = 0; int dbg_nwriters = 0; uint32_t dbg_subcap = 0;
@@ -951,6 +967,15 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             size_t subcap = (size_t)(expect * slack) + 256;
             subcap = (subcap + 511) & ~(size_t)511;       // whole record blocks, whole probe pieces
             if (subcap > 0x7ffffff0u) { set_error("bin capacity overflow: split the range"); return GBN_ERR_NOMEM; }
+            const int rfl_now = std::min(4, b.dev->fl), rfrbits_now = std::min(7, 2 * b.dev->fr);
+            Engine::BinAhead &AH = E.ahead;
+            const bool ahead_hit = AH.valid && !defer && AH.db == (const void *)&db && AH.s0 == s0 && AH.s1 == s1 && AH.lut == b.lut.lut && AH.step == b.lut.step &&
+                                   AH.nb == nb && AH.nwriters == nwriters && AH.subcap == subcap && AH.rfl == rfl_now && AH.rfrbits == rfrbits_now &&
+                                   AH.cbits == GBN_BIN_CBITS(b.lut.lut) && AH.tiles == (const void *)P.tiles;
+            if (AH.valid) {
+                AH.valid = false;
+                if (ahead_hit) { E.swap_scan_sets(); E.binkey.valid = false; E.ahead_hits++; hit_pair = AH.pair; }     // the records of this pass are in the other set: that one is the current set now
+            }
             size_t need = subcap * nstream;
             const size_t need_u64 = (GBN_REC_WORDS(need) + 1) / 2;
             if (need_u64 > E.bin_rec_cap) {
@@ -998,29 +1023,57 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             const bool hit = reuse && have.valid && have.db == want_key.db && have.s0 == s0 && have.s1 == s1 && have.lut == want_key.lut &&
                              have.step == want_key.step && have.nb == nb && have.nwriters == nwriters && have.subcap == subcap;
             have.valid = false;
+            last_B = B; last_grid2 = grid2;
             HIPCHK(hipEventRecord(E.ev0, E.stream));
-            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, (hit ? 2 : 3) | (defer ? 0 : 4), b.dev->ready));
+            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, ((hit || ahead_hit) ? 2 : 3) | (defer ? 0 : 4), b.dev->ready));
             have = want_key;                                    // invalidated below if this launch overflowed
-            binned = true;
+            binned = true; binned_ahead = ahead_hit;
             if (defer) { defer->B = B; defer->grid2 = grid2; }
             HIPCHK(hipEventRecord(E.ev1, E.stream));
             HIPCHK(hipMemcpyAsync(&E.scan_back->overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
             HIPCHK(hipMemcpyAsync(E.scan_back->rare_counts, E.rare_counts, (size_t)grid2 * 4, hipMemcpyDeviceToHost, E.stream));
         }
         HIPCHK(hipMemcpyAsync(E.scan_back->cnt, E.counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, E.stream));     // seeds, raw hits, the fullest segment
+        if (!E.ev_back) HIPCHK(hipEventCreate(&E.ev_back));
+        HIPCHK(hipEventRecord(E.ev_back, E.stream));
+        if (binned && E.want_ahead && !defer && !reuse_binning && slack <= 1.25) {
+            // the next pass's binning kernel, into the other set (sized like this one)
+            Engine::ScanSet &A = E.alt;
+            const size_t nstream = (size_t)last_B.nb * (size_t)last_B.nwriters, need_u64 = E.bin_rec_cap, need_tcur = nstream * last_B.nseq;
+            int arc = GBN_OK;
+            if (A.bin_rec_cap < need_u64) { dev_free(A.bin_rec); A.bin_rec_cap = 0; if (!(arc = dev_alloc(A.bin_rec, need_u64))) A.bin_rec_cap = need_u64; }
+            if (!arc && A.bin_tcur_cap < need_tcur) { dev_free(A.bin_tcur); A.bin_tcur_cap = 0; if (!(arc = dev_alloc(A.bin_tcur, need_tcur))) A.bin_tcur_cap = need_tcur; }
+            if (!arc && A.bin_count_cap < nstream + 4) { dev_free(A.bin_count); A.bin_count_cap = 0; if (!(arc = dev_alloc(A.bin_count, nstream + 4))) A.bin_count_cap = nstream + 4; }
+            if (!arc) {                                     // (no room for a second set: no binning ahead)
+                GbnBinParams A2 = last_B;
+                A2.rec = reinterpret_cast<uint32_t *>(A.bin_rec); A2.tcur = A.bin_tcur; A2.gcount = A.bin_count; A2.overflow = A.bin_count + nstream;
+                A2.rareq = nullptr; A2.rare_counts = nullptr;
+                Engine::BinAhead &AH = E.ahead;
+                if (!AH.ev[0][0]) for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&AH.ev[i >> 1][i & 1]));
+                AH.pair = hit_pair >= 0 ? (hit_pair ^ 1) : (AH.pair ^ 1);
+                HIPCHK(hipMemsetAsync(A.bin_count + nstream, 0, 16, E.stream));
+                HIPCHK(hipEventRecord(AH.ev[AH.pair][0], E.stream));
+                HIPCHK(launch_scan_bin_parts(A2, last_grid2, E.stream, nullptr, 1, nullptr));
+                HIPCHK(hipEventRecord(AH.ev[AH.pair][1], E.stream));
+                AH.valid = true; AH.db = (const void *)&db; AH.s0 = s0; AH.s1 = s1; AH.lut = b.lut.lut; AH.step = b.lut.step; AH.nb = last_B.nb; AH.nwriters = last_B.nwriters;
+                AH.subcap = last_B.subcap; AH.rfl = last_B.rfl; AH.rfrbits = last_B.rfrbits; AH.cbits = last_B.cbits; AH.tiles = (const void *)last_B.S.tiles;
+            }
+        }
         trace_mark("scan: kernels queued");
-        HIPCHK(hipStreamSynchronize(E.stream));
+        HIPCHK(hipEventSynchronize(E.ev_back));
         trace_mark("scan: kernels done");
         cnt[0] = E.scan_back->cnt[0]; cnt[1] = E.scan_back->cnt[1];
         const unsigned long long seg_max = sliced ? E.scan_back->seg_max : 0;
         if (binned) overflow = E.scan_back->overflow;
         finish_build(b.dev);                                // (the scan has waited for the builder's event)
         if (diag) {
-            float ms = 0; (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
-            diag->scan_kernel_ms += ms; diag->scan_launches++;
+            float ms = 0, ahead_ms = 0; (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
+            if (binned_ahead && hit_pair >= 0) (void)hipEventElapsedTime(&ahead_ms, E.ahead.ev[hit_pair][0], E.ahead.ev[hit_pair][1]);    // this pass's binning kernel ran ahead
+            diag->scan_kernel_ms += ms + ahead_ms; diag->scan_launches++;
             if (binned) {
                 float a = 0, c = 0, r = 0;
                 (void)hipEventElapsedTime(&a, E.evk[0], E.evk[1]); (void)hipEventElapsedTime(&c, E.evk[1], E.evk[2]);
+                a += ahead_ms;
                 (void)hipEventElapsedTime(&r, E.evk[2], E.evk[3]);
                 diag->bin_kernel_ms += a; diag->probe_kernel_ms += c; diag->rare_kernel_ms += r;
             }
@@ -1353,8 +1406,12 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
             E.seeds_async_cap = std::max<size_t>((size_t)n + (size_t)n / 4, 1 << 16);
         }
         if ((rc = compact_seeds(E.stream))) return rc;
-        HIPCHK(hipMemcpyAsync(E.seeds_async, E.seeds, (size_t)n * sizeof(GbnDevSeed), hipMemcpyDeviceToDevice, E.stream));
-        HIPCHK(hipEventRecord(E.ev_seed, E.stream));
+        // (a binning kernel queued ahead sits on the engine's stream: the copy goes to the stage's own stream -- the host has
+        // seen the scan finish -- and the next scan's kernels wait for it before they write seeds again: run_scan_impl)
+        hipStream_t copy_st = E.ahead.valid ? E.stream2 : E.stream;
+        HIPCHK(hipMemcpyAsync(E.seeds_async, E.seeds, (size_t)n * sizeof(GbnDevSeed), hipMemcpyDeviceToDevice, copy_st));
+        HIPCHK(hipEventRecord(E.ev_seed, copy_st));
+        E.seed_copy_pending = copy_st == E.stream2;
         E.slot ^= 1;
         E.pending_err.clear();
         const int dev = E.device, ksi = 0;                  // (no stage is in flight: either key set)
@@ -1784,6 +1841,7 @@ int gbn_block_cache_insert(const char *db_name, const int32_t *oids, int32_t n, 
     });
 }
 long long gbn_debug_db_bytes_uploaded(void) { return g_db_bytes_uploaded.load(); }
+long long gbn_debug_bin_ahead_hits(void) { return tl_eng ? E.ahead_hits : 0; }
 
 // tests: seed_order.hip on segments given in host memory.  The keys of the seeds ordered by (subject, slot), scan order
 // inside, as the engine's seed stage builds them for the composite-key form (q_bits from qlen, s_bits from max_len;
@@ -1834,6 +1892,9 @@ static void release_engine() {              // (the calling thread has entered i
     E.binkey.valid = false;
     dev_free(E.slice_seg); E.slice_seg_cap = 0; dev_free(E.seg_counts); dev_free(E.seg_firsts);
     if (E.scan_back) { (void)hipHostFree(E.scan_back); E.scan_back = nullptr; }
+    E.ahead.valid = false;
+    for (int i = 0; i < 4; i++) if (E.ahead.ev[i >> 1][i & 1]) { (void)hipEventDestroy(E.ahead.ev[i >> 1][i & 1]); E.ahead.ev[i >> 1][i & 1] = nullptr; }
+    if (E.ev_back) { (void)hipEventDestroy(E.ev_back); E.ev_back = nullptr; }
     hitbuf_drain();
     dev_free(E.seeds_async); E.seeds_async_cap = 0; if (E.ev_seed) { (void)hipEventDestroy(E.ev_seed); E.ev_seed = nullptr; }
     dev_free(E.seeds);
@@ -2025,6 +2086,7 @@ void gbn_db_free(GbnDb *db) {
         if (E.has_pending) (void)wait_pending();
         wait_host();
         if (E.binkey.db == (const void *)db) E.binkey.valid = false;
+        if (E.ahead.valid && E.ahead.db == (const void *)db) { (void)hipStreamSynchronize(E.stream); E.ahead.valid = false; }    // (a binning kernel queued ahead reads the shard)
     }
     free_tile_cache(*db);
     if (db->owns && db->d_packed) (void)hipFree((void *)db->d_packed);
@@ -2274,7 +2336,10 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
                 if (s1 > s0 && (acc >= want_bytes || tiles >= want_tiles)) break;                // equal shares
                 acc += nb; tiles += nt; s1++;
             }
-            if ((rc = search_range(*batch, *db, s0, s1, *results, diag, keep_stages, overlap))) return rc;
+            E.want_ahead = overlap && !keep_stages && s0 == 0 && s1 == db->num_seqs && batch->lut.lut != batch->lut.word && gbn::switch_value("GBN_BIN_AHEAD", 1) != 0;    // the pass is ONE range (the next pass of a pipelined caller bins the same) of a megablast shape (a handful of seeds: their stages run on the second stream)
+            rc = search_range(*batch, *db, s0, s1, *results, diag, keep_stages, overlap);
+            E.want_ahead = false;
+            if (rc) return rc;
             if (interrupt && interrupt(progress)) { set_error("interrupted"); return GBN_ERR_INTERRUPTED; }
             s0 = s1;
         }

@@ -174,6 +174,7 @@ struct GbnDevSeed;
  * the composite keys of the seeds ordered by (subject, slot), scan order inside (see GbnExtParams::ck_*) */
 int gbn_debug_seed_order(const struct GbnDevSeed *seg, const uint32_t *seg_count, int nseg, uint32_t seg_cap, int nsubj, int subj_base,
                          int container_hash, int diag_len, int32_t qlen, int32_t max_len, int q_descending, uint64_t *keys_out, int64_t *n_out);
+long long gbn_debug_bin_ahead_hits(void);       /* tests: passes of the calling thread's engine whose binning kernel had been queued by the pass before (GBN_BIN_AHEAD) */
 long long gbn_debug_db_bytes_uploaded(void);    /* tests: slab bytes copied host -> device by gbn_db_new / the shard builder so far */
 
 /* ---- database shard resident in HBM ---- */

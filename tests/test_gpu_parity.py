@@ -603,6 +603,43 @@ def test_slice_scan_with_repeats_that_overflow_a_segment():
     assert ps2.diagnostics.scan_launches == 1
 
 
+def test_pipelined_passes_bin_ahead_for_one_another(monkeypatch):
+    """gbn_prelim_search_begin over one range of a shard with a megablast-shaped batch queues the NEXT pass's binning kernel
+    (the records depend on the shard and the table's shape only) behind its own kernels; a next pass of the same shape finds
+    its records there, one of another shape does not and bins for itself.  Passes of two shapes in turn: every pass gives
+    what a search on its own gives, and the passes that could use the records binned ahead did (GBN_BIN_AHEAD=0: none)."""
+    db, queries, plants, subjects, opt = util.small_case(8, 300_000, 40, task="megablast", seed=11)
+    src = api.BlastSeqSrc.from_packed(subjects)
+    qa, qb, qc = queries[:18], queries[18:36], queries[36:40]        # 18 kb, 18 kb (lut 11, stride 18) and 4 kb (another table)
+    want = {}
+    shapes = {}
+    for name, q in (("a", qa), ("b", qb), ("c", qc)):
+        ps = api.BlastPrelimSearch(q, opt, src)
+        shapes[name] = (ps.info()["lut_width"], ps.info()["scan_step"], ps.info()["scan_path"])
+        want[name] = ps.run()["hsps"].tobytes()
+        ps.close()
+    assert shapes["a"] == shapes["b"] != shapes["c"], shapes
+    binned = shapes["a"][2] == 0 and os.environ.get("GBN_SCAN_BINS") != "1"
+    L = api.lib()
+    for ahead in ("1", "0"):
+        monkeypatch.setenv("GBN_BIN_AHEAD", ahead)
+        h0 = L.gbn_debug_bin_ahead_hits()
+        prev = None
+        for name, q in (("a", qa), ("b", qb), ("a", qa), ("c", qc), ("b", qb), ("a", qa)):
+            ps = api.BlastPrelimSearch(q, opt, src)
+            ps.begin()
+            if prev is not None:
+                assert prev[1].end()["hsps"].tobytes() == want[prev[0]], (ahead, prev[0])
+                prev[1].close()
+            prev = (name, ps)
+        assert prev[1].end()["hsps"].tobytes() == want[prev[0]]
+        prev[1].close()
+        hits = L.gbn_debug_bin_ahead_hits() - h0
+        # a -> b, b -> a and (after c, which binned ahead for a pass of ITS shape) b -> a; with the switch off only the records
+        # the first leg's last pass left behind are used
+        assert hits == ((3 if ahead == "1" else 1) if binned else 0), (ahead, hits, shapes)
+
+
 def test_seeds_ordered_by_the_counting_sort_and_by_the_library_sort(monkeypatch):
     """blastn W=11, table as wide as the word: the ordered scan's seeds go to the diagonal filter through seed_order.hip (a
     counting sort per subject and slot, keys built on the way; default) or through seed_ckeys_kernel + the library's radix
