@@ -994,7 +994,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 if ((rc = dev_alloc(E.bin_count, nstream + 4))) return rc;
                 E.bin_count_cap = nstream + 4;
             }
-            HIPCHK(hipMemsetAsync(E.bin_count + nstream, 0, 16, E.stream));
+            if (!ahead_hit) HIPCHK(hipMemsetAsync(E.bin_count + nstream, 0, 16, E.stream));     // (binned ahead: the flag of THAT launch is read back below)
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
             B.S = P; B.nb = nb; B.cbits = GBN_BIN_CBITS(b.lut.lut); B.nwriters = nwriters; dbg_nwriters = nwriters; dbg_subcap = (uint32_t)subcap;
             B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfrbits = std::min(7, 2 * b.dev->fr);
