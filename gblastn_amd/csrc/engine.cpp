@@ -158,6 +158,7 @@ struct Engine {
                       size_t subcap = 0; const void *tiles = nullptr;
                       hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; int pair = 0; } ahead;     // (two pairs of events around the kernel: a pass reads one pair while it records the other)
     bool want_ahead = false;            // the pass being scanned may bin ahead (set by run_search)
+    bool counters_zeroed = false;       // counters[0 .. 3] are zero and nothing is queued that writes them (the pass before binned ahead)
     bool seed_copy_pending = false;     // ev_seed stands for a copy of the seeds on stream2 that the next scan must not overtake
     long long ahead_hits = 0;
     hipEvent_t ev_back = nullptr;       // behind the read-back copies of a scan
@@ -926,7 +927,8 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     if (E.seed_copy_pending) { HIPCHK(hipStreamWaitEvent(E.stream, E.ev_seed, 0)); E.seed_copy_pending = false; }
     for (;;) {
         bool binned_ahead = false; int hit_pair = -1;
-        HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream));
+        if (!E.counters_zeroed) HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream));    // (a pass that binned ahead zeroed them behind its read-back)
+        E.counters_zeroed = false;
         GbnScanParams P; fill_scan_params(P, b, db, ts);
         uint32_t overflow = 0; int dbg_nwriters = 0; uint32_t dbg_subcap = 0;
         bool binned = false;
@@ -1024,12 +1026,10 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                              have.step == want_key.step && have.nb == nb && have.nwriters == nwriters && have.subcap == subcap;
             have.valid = false;
             last_B = B; last_grid2 = grid2;
-            HIPCHK(hipEventRecord(E.ev0, E.stream));
-            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, ((hit || ahead_hit) ? 2 : 3) | (defer ? 0 : 4), b.dev->ready));
+            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, ((hit || ahead_hit) ? 2 : 3) | (defer ? 0 : 4) | (ahead_hit ? 8 : 0), b.dev->ready));
             have = want_key;                                    // invalidated below if this launch overflowed
             binned = true; binned_ahead = ahead_hit;
             if (defer) { defer->B = B; defer->grid2 = grid2; }
-            HIPCHK(hipEventRecord(E.ev1, E.stream));
             HIPCHK(hipMemcpyAsync(&E.scan_back->overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
             HIPCHK(hipMemcpyAsync(E.scan_back->rare_counts, E.rare_counts, (size_t)grid2 * 4, hipMemcpyDeviceToHost, E.stream));
         }
@@ -1052,6 +1052,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 if (!AH.ev[0][0]) for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&AH.ev[i >> 1][i & 1]));
                 AH.pair = hit_pair >= 0 ? (hit_pair ^ 1) : (AH.pair ^ 1);
                 HIPCHK(hipMemsetAsync(A.bin_count + nstream, 0, 16, E.stream));
+                HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream)); E.counters_zeroed = true;      // (read back above; the next scan's)
                 HIPCHK(hipEventRecord(AH.ev[AH.pair][0], E.stream));
                 HIPCHK(launch_scan_bin_parts(A2, last_grid2, E.stream, nullptr, 1, nullptr));
                 HIPCHK(hipEventRecord(AH.ev[AH.pair][1], E.stream));
@@ -1067,12 +1068,15 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         if (binned) overflow = E.scan_back->overflow;
         finish_build(b.dev);                                // (the scan has waited for the builder's event)
         if (diag) {
-            float ms = 0, ahead_ms = 0; (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
+            float ms = 0, ahead_ms = 0;
+            if (binned) (void)hipEventElapsedTime(&ms, E.evk[binned_ahead ? 1 : 0], E.evk[3]);     // (the launcher's own events bracket the stage)
+            else (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
             if (binned_ahead && hit_pair >= 0) (void)hipEventElapsedTime(&ahead_ms, E.ahead.ev[hit_pair][0], E.ahead.ev[hit_pair][1]);    // this pass's binning kernel ran ahead
             diag->scan_kernel_ms += ms + ahead_ms; diag->scan_launches++;
             if (binned) {
                 float a = 0, c = 0, r = 0;
-                (void)hipEventElapsedTime(&a, E.evk[0], E.evk[1]); (void)hipEventElapsedTime(&c, E.evk[1], E.evk[2]);
+                if (!binned_ahead) (void)hipEventElapsedTime(&a, E.evk[0], E.evk[1]);
+                (void)hipEventElapsedTime(&c, E.evk[1], E.evk[2]);
                 a += ahead_ms;
                 (void)hipEventElapsedTime(&r, E.evk[2], E.evk[3]);
                 diag->bin_kernel_ms += a; diag->probe_kernel_ms += c; diag->rare_kernel_ms += r;
@@ -1439,6 +1443,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     // (extension + replay 3.8 next to the scan, gapped stage 3.6) against 7.6 ms for the whole range before: 38.4 - 39.2 vs
     // 38.8 - 39.0 ms per pass.  A third stream would be needed, and two processes on one GPU gain 8 %: the chip is busy.)
     unsigned long long nih = 0;
+    E.counters_zeroed = false;                              // (the stage counts in counters[2], [3])
     if ((rc = seed_stage(b, db, res, diag, keep_stages, slot, E.seeds, n, E.counters + 2, E.stream, &nih, s0, s1, ksi))) return rc;
     trace_mark("seed stage done (inline)");
     if (nih == 0) return GBN_OK;

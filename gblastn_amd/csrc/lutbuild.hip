@@ -9,7 +9,6 @@
 // (radix sort, prefix sums) on data that never leaves HBM.
 #include <hip/hip_runtime.h>
 #include <algorithm>
-#include <hipcub/hipcub.hpp>
 #include "gbn_dev.h"
 #include "lutbuild.h"
 
@@ -243,13 +242,188 @@ hipError_t lut_overflow_cells(const LutBuild &b, unsigned long long *out, hipStr
     hipLaunchKernelGGL(lut_overflow_kernel, dim3((unsigned)((b.ncells + 255) / 256)), dim3(256), 0, st, b.count, b.ncells, out);
     return hipGetLastError();
 }
-hipError_t lut_sort(void *tmp, size_t &bytes, const LutBuild &b, int64_t n, int key_bits, hipStream_t st)
+// Exclusive prefix sums of n counters in three plain kernels -- sums of 4,096-element blocks, their prefix sums (one
+// workgroup), the blocks again with their offsets -- instead of the library's single-pass scan: that one chains its
+// workgroups through look-back flags, and next to a probe kernel that leaves a few wave slots per CU a workgroup waits for
+// a predecessor that has not been scheduled yet: 2.5 ms per scan of 16.7 M cells (two per table build) against 0.1 alone,
+// which kept the builder's stream busy past the next pass's binning kernel and made that pass's probe kernel wait for its
+// tables (round 4, `profiles/r04_c2_timeline.txt`).
+namespace {
+constexpr int SCAN_BLOCK = 4096, SCAN_THREADS = 256, SCAN_PER = SCAN_BLOCK / SCAN_THREADS;
+
+__device__ __forceinline__ uint32_t block_exclusive(uint32_t v, uint32_t *s_wave, uint32_t &total)
 {
-    return hipcub::DeviceRadixSort::SortPairs(tmp, bytes, b.keys_a, b.keys_b, b.vals_a, b.vals_b, (int)n, 0, key_bits, st);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    uint32_t incl = v;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t x = __shfl_up(incl, d); incl += (lane >= d) ? x : 0u; }
+    if (lane == 63) s_wave[wave] = incl;
+    __syncthreads();
+    uint32_t before = 0; total = 0;
+    for (int w = 0; w < nwaves; w++) { before += (w < wave) ? s_wave[w] : 0u; total += s_wave[w]; }
+    __syncthreads();
+    return before + incl - v;
 }
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_sums_kernel(const uint32_t *__restrict__ in, int64_t n, uint32_t *__restrict__ sums)
+{
+    __shared__ uint32_t s_wave[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_PER;
+    uint32_t v = 0;
+    #pragma unroll
+    for (int k = 0; k < SCAN_PER; k++) v += (base + k < n) ? in[base + k] : 0u;
+    uint32_t total;
+    (void)block_exclusive(v, s_wave, total);
+    if (threadIdx.x == 0) sums[blockIdx.x] = total;
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_offsets_kernel(uint32_t *sums, int64_t nblocks)
+{
+    __shared__ uint32_t s_wave[SCAN_THREADS / 64];
+    uint32_t carry = 0;
+    for (int64_t b0 = 0; b0 < nblocks; b0 += SCAN_THREADS) {    // (4,097 blocks for 2^24 + 1 cells: seventeen rounds of a small workgroup, which finds a CU at once)
+        const int64_t i = b0 + threadIdx.x;
+        const uint32_t v = i < nblocks ? sums[i] : 0u;
+        uint32_t total;
+        const uint32_t ex = block_exclusive(v, s_wave, total);
+        if (i < nblocks) sums[i] = carry + ex;
+        carry += total;
+    }
+    if (threadIdx.x == 0) sums[nblocks] = carry;                // the sum of everything
+}
+
+__global__ void __launch_bounds__(SCAN_THREADS) scan_apply_kernel(const uint32_t *in, int64_t n, const uint32_t *__restrict__ sums, uint32_t *out)      // (in may be out)
+{
+    __shared__ uint32_t s_wave[SCAN_THREADS / 64];
+    const int64_t base = (int64_t)blockIdx.x * SCAN_BLOCK + (int64_t)threadIdx.x * SCAN_PER;
+    uint32_t x[SCAN_PER], v = 0;
+    #pragma unroll
+    for (int k = 0; k < SCAN_PER; k++) { x[k] = (base + k < n) ? in[base + k] : 0u; v += x[k]; }
+    uint32_t total;
+    uint32_t at = sums[blockIdx.x] + block_exclusive(v, s_wave, total);
+    #pragma unroll
+    for (int k = 0; k < SCAN_PER; k++) { if (base + k < n) out[base + k] = at; at += x[k]; }
+}
+}  // namespace
+
+// tmp == nullptr: the scratch it needs; in and out may be the same array
 hipError_t lut_scan(void *tmp, size_t &bytes, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st)
 {
-    return hipcub::DeviceScan::ExclusiveSum(tmp, bytes, in, out, (int)n, st);
+    const int64_t nblocks = (n + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    if (!tmp) { bytes = (size_t)(nblocks + 1) * sizeof(uint32_t); return hipSuccess; }
+    if (n <= 0) return hipSuccess;
+    if (bytes < (size_t)(nblocks + 1) * sizeof(uint32_t)) return hipErrorInvalidValue;
+    uint32_t *sums = static_cast<uint32_t *>(tmp);
+    hipLaunchKernelGGL(scan_sums_kernel, dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, st, in, n, sums);
+    hipLaunchKernelGGL(scan_offsets_kernel, dim3(1), dim3(SCAN_THREADS), 0, st, sums, nblocks);
+    hipLaunchKernelGGL(scan_apply_kernel, dim3((unsigned)nblocks), dim3(SCAN_THREADS), 0, st, in, n, sums, out);
+    return hipGetLastError();
+}
+
+// The (cell, offset) list sorted on the cell by a radix sort of our own: stable passes over 8-bit digits, each a count per
+// 4,096-element chunk, the scan above over (digit, chunk), and a scatter in which a wave ranks the 64 elements of a round
+// among themselves with a ballot per digit bit (lane order = list order) and the waves follow one another through per-wave
+// counters in LDS -- the pattern of seed_order.hip.  Pass 0 also DROPS the positions without a word (key = `none`), so
+// 2 * lut bits are sorted, not 2 * lut + 1.  No look-back chains between workgroups and 1-4 KB of LDS per workgroup: next to a
+// probe kernel that owns the CUs the library's onesweep sort took 4.1 ms per 5 Mb batch (its histogram 2.2, the pass that met
+// the rare kernel 1.6), this one a third of that.
+namespace {
+constexpr int RS_CHUNK = 4096, RS_THREADS = 256, RS_WAVES = RS_THREADS / 64, RS_ROUNDS = RS_CHUNK / RS_THREADS;
+
+__global__ void __launch_bounds__(RS_THREADS) radix_count_kernel(const uint32_t *__restrict__ keys, int64_t n_cap, const uint32_t *__restrict__ n_dev,
+                                                                 uint32_t none, int shift, uint32_t *__restrict__ counts, int64_t nchunks)
+{
+    __shared__ uint32_t s_hist[256];
+    const int tid = threadIdx.x;
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap, base = (int64_t)blockIdx.x * RS_CHUNK;
+    s_hist[tid] = 0;
+    __syncthreads();
+    uint32_t k[RS_ROUNDS];
+    #pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) { const int64_t i = base + r * RS_THREADS + tid; k[r] = i < n ? keys[i] : none; }
+    #pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) if (k[r] != none) atomicAdd(&s_hist[(k[r] >> shift) & 255u], 1u);
+    __syncthreads();
+    counts[(int64_t)tid * nchunks + blockIdx.x] = s_hist[tid];          // digit-major: one scan over the whole table gives every (digit, chunk) its place
+}
+
+__global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+                                                                   uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, int64_t n_cap,
+                                                                   const uint32_t *__restrict__ n_dev, uint32_t none, int shift,
+                                                                   const uint32_t *__restrict__ offsets, int64_t nchunks)
+{
+    __shared__ uint32_t s_cnt[RS_WAVES][256];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
+    const int64_t w0 = (int64_t)blockIdx.x * RS_CHUNK + (int64_t)wave * (RS_CHUNK / RS_WAVES) + lane;
+    #pragma unroll
+    for (int w = 0; w < RS_WAVES; w++) s_cnt[w][tid] = 0;
+    __syncthreads();
+    uint32_t k[RS_ROUNDS], v[RS_ROUNDS], sr[RS_ROUNDS];
+    #pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) { const int64_t i = w0 + r * 64; k[r] = i < n ? keys_in[i] : none; v[r] = i < n ? vals_in[i] : 0u; }
+    uint32_t *mine = s_cnt[wave];
+    #pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++) {
+        const bool valid = k[r] != none;
+        const uint32_t digit = (k[r] >> shift) & 255u;
+        unsigned long long peers = __ballot(valid);
+        #pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (digit >> b) & 1u;
+            const unsigned long long m = __ballot(valid && bit);
+            peers &= bit ? m : ~m;
+        }
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(peers >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)peers, 0u));
+        sr[r] = 0xffffffffu;
+        if (valid) {
+            const uint32_t prior = mine[digit];
+            if (before == 0) mine[digit] = prior + (uint32_t)__popcll(peers);
+            sr[r] = digit << 16 | (prior + before);
+        }
+    }
+    __syncthreads();
+    {
+        uint32_t run = offsets[(int64_t)tid * nchunks + blockIdx.x];
+        #pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
+    }
+    __syncthreads();
+    #pragma unroll
+    for (int r = 0; r < RS_ROUNDS; r++)
+        if (sr[r] != 0xffffffffu) { const uint32_t at = mine[sr[r] >> 16] + (sr[r] & 0xffffu); keys_out[at] = k[r]; vals_out[at] = v[r]; }
+}
+}  // namespace
+
+// keys_a / vals_a -> keys_b / vals_b: the elements whose key is not 1 << (key_bits - 1), ordered by key, stable
+hipError_t lut_sort(void *tmp, size_t &bytes, const LutBuild &b, int64_t n, int key_bits, hipStream_t st)
+{
+    const int64_t nchunks = (n + RS_CHUNK - 1) / RS_CHUNK, ncounts = 256 * std::max<int64_t>(nchunks, 1);
+    size_t scan_bytes = 0;
+    (void)lut_scan(nullptr, scan_bytes, nullptr, nullptr, ncounts, st);
+    const size_t need = (size_t)ncounts * 4 + scan_bytes + 64;
+    if (!tmp) { bytes = need; return hipSuccess; }
+    if (n <= 0) return hipSuccess;
+    if (bytes < need || key_bits < 2 || key_bits > 32) return hipErrorInvalidValue;
+    uint32_t *counts = static_cast<uint32_t *>(tmp), *scan_tmp = counts + ncounts, *n_valid = scan_tmp + scan_bytes / 4 + 2;
+    const uint32_t none = 1u << (key_bits - 1);
+    const int npass = std::max(1, (key_bits - 1 + 7) / 8);
+    uint32_t *const K[2] = {b.keys_a, b.keys_b}, *const V[2] = {b.vals_a, b.vals_b};
+    const int64_t scan_blocks = (ncounts + SCAN_BLOCK - 1) / SCAN_BLOCK;
+    for (int p = 0; p < npass; p++) {
+        const uint32_t *nd = p ? n_valid : nullptr;             // (pass 0 drops the keys that are `none`: the passes behind it see the rest)
+        const int in = p & 1, out = in ^ 1;
+        hipLaunchKernelGGL(radix_count_kernel, dim3((unsigned)nchunks), dim3(RS_THREADS), 0, st, K[in], n, nd, none, 8 * p, counts, nchunks);
+        size_t sb = scan_bytes;
+        if (hipError_t e = lut_scan(scan_tmp, sb, counts, counts, ncounts, st)) return e;
+        if (p == 0) { if (hipError_t e = hipMemcpyAsync(n_valid, scan_tmp + scan_blocks, 4, hipMemcpyDeviceToDevice, st)) return e; }
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nchunks), dim3(RS_THREADS), 0, st, K[in], V[in], K[out], V[out], n, nd, none, 8 * p, counts, nchunks);
+    }
+    if (npass % 2 == 0) {       // the result sits in keys_a / vals_a: the callers read keys_b / vals_b
+        if (hipError_t e = hipMemcpyAsync(b.keys_b, b.keys_a, (size_t)n * 4, hipMemcpyDeviceToDevice, st)) return e;
+        if (hipError_t e = hipMemcpyAsync(b.vals_b, b.vals_a, (size_t)n * 4, hipMemcpyDeviceToDevice, st)) return e;
+    }
+    return hipGetLastError();
 }
 hipError_t lut_entries(const LutBuild &b, int64_t n, hipStream_t st)
 {

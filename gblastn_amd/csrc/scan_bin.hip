@@ -1024,10 +1024,11 @@ namespace gbn {
 // stream next to the binning kernel of the next pass: engine.cpp, deferred rare path)
 hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts, hipEvent_t tables_ready)
 {
-    // ev[0..3]: before bin, after bin, after probe, after rare (optional)
+    // ev[0..3]: before bin, after bin, after probe, after rare (optional); parts: 1 binning, 2 probe, 4 rare kernel, 8 no
+    // ev[0] (the records were binned ahead: every packet between that kernel and the probe kernel is time the GPU idles)
     if (b.S.ntiles <= 0) return hipSuccess;
     hipError_t e = hipSuccess;
-    if (ev) (void)hipEventRecord(ev[0], st);
+    if (ev && !(parts & 8)) (void)hipEventRecord(ev[0], st);
     if (parts & 1) {
         // stride-specialised variants: megablast (word 28 with lut 12 / 11 / 8) and blastn (word 11 with lut 11 / 10 / 8)
         const bool generic = (b.dbg & 64) != 0;
