@@ -640,6 +640,18 @@ def test_pipelined_passes_bin_ahead_for_one_another(monkeypatch):
         # a -> b, b -> a and (after c, which binned ahead for a pass of ITS shape) b -> a; with the switch off only the records
         # the first leg's last pass left behind are used
         assert hits == ((3 if ahead == "1" else 1) if binned else 0), (ahead, hits, shapes)
+    # the shard goes away while a binning kernel queued ahead may still read it; a search over another shard follows at once
+    monkeypatch.setenv("GBN_BIN_AHEAD", "1")
+    ps = api.BlastPrelimSearch(qa, opt, src)
+    ps.begin(); assert ps.end()["hsps"].tobytes() == want["a"]
+    ps.close(); src.close()
+    db2, queries2, _, subjects2, opt2 = util.small_case(5, 200_000, 18, task="megablast", seed=12)
+    src2 = api.BlastSeqSrc.from_packed(subjects2)
+    ps2 = api.BlastPrelimSearch(queries2, opt2, src2)
+    ps2.begin(); got2 = ps2.end()
+    ora2, _ = util.oracle_run(opt2, queries2, subjects2)
+    util.compare_stages(got2, ora2)
+    ps2.close()
 
 
 def test_seeds_ordered_by_the_counting_sort_and_by_the_library_sort(monkeypatch):
