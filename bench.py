@@ -281,9 +281,14 @@ def main():
             futs.append(merger.submit(merge, len(prev._q), prev.end()))
             return sum(f.result() for f in futs)
         reuse(2)
+        k0 = [(b.diagnostics.bin_kernel_ms, b.diagnostics.probe_kernel_ms, b.diagnostics.rare_kernel_ms, b.diagnostics.scan_launches) for b in held]
         _, el = timed(lambda: reuse(args.engine_steps))
+        k1 = [(b.diagnostics.bin_kernel_ms, b.diagnostics.probe_kernel_ms, b.diagnostics.rare_kernel_ms, b.diagnostics.scan_launches) for b in held]
+        nl = max(1, sum(a[3] - c[3] for a, c in zip(k1, k0)))
         engine_only = {"ms_per_pass": el / args.engine_steps * 1e3, "value": world * nsub * slen * args.engine_steps / el / 1e9,
                        "unit": "Gbp/s", "passes": args.engine_steps,
+                       # (HIP-event time per launch of the three scan kernels with no set-up running beside them)
+                       "scan_kernels_ms": [sum(a[i] - c[i] for a, c in zip(k1, k0)) / nl for i in range(3)],
                        "what": "gbn_prelim_search_begin/_end on two query batches set up once and reused alternately"}
         for b in held:
             b.close()

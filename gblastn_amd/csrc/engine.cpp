@@ -1087,6 +1087,14 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             unsigned long long sc = 0; uint32_t mx = 0;
             for (int i = 0; i < grid2; i++) { const uint32_t v = E.scan_back->rare_counts[i]; sc += v; mx = std::max(mx, v); }
             if (gbn::switch_is_set("GBN_DBG")) fprintf(stderr, "[gbn dbg] rare-path items %llu, seeds %llu, raw %llu\n", sc, cnt[0], cnt[1]);
+            if (gbn::switch_value("GBN_DBG", 0) & 128) {    // where the probe workgroups ran: blockIdx & 7 against the XCD they report
+                std::vector<uint32_t> x((size_t)grid2);
+                HIPCHK(hipMemcpy(x.data(), E.rare_counts + 1024, (size_t)grid2 * 4, hipMemcpyDeviceToHost));
+                int off = 0, per[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cnt8[8][8] = {{0}};
+                for (int i = 0; i < grid2; i++) { cnt8[i & 7][x[(size_t)i] & 7u]++; per[x[(size_t)i] & 7u]++; }
+                for (int g = 0; g < 8; g++) { int best = 0, tot = 0; for (int c = 0; c < 8; c++) { best = std::max(best, cnt8[g][c]); tot += cnt8[g][c]; } off += tot - best; }
+                fprintf(stderr, "[gbn dbg] probe workgroups away from their group's XCD: %d of %d; per XCD %d %d %d %d %d %d %d %d\n", off, grid2, per[0], per[1], per[2], per[3], per[4], per[5], per[6], per[7]);
+            }
             if (gbn::switch_value("GBN_DBG", 0) & 32) {
                 {   // stream fill statistics
                     const size_t ns = (size_t)nb * (size_t)dbg_nwriters;

@@ -794,6 +794,7 @@ probe_bin_kernel(GbnBinParams B)
     const uint32_t ncell_bin = 1u << cbits;
     GbnU2 *myq = B.rareq + (size_t)blockIdx.x * B.rare_seg;          // this workgroup's segment: no global atomics
     if (tid == 0) { *s_rcount = 0; s_tab[GBN_BIN_TAB0 - 1] = 0; s_tab[GBN_BIN_TAB0 + GBN_BIN_CELLS] = 0; }      // the empty cells pad records point at
+    if ((B.dbg & 128) && tid == 0) B.rare_counts[1024 + blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20);    // GBN_DBG=128: the XCD (HW_REG_XCC_ID) this workgroup runs on
     // masks of the reduced fingerprint test; a zero mask makes that side "always matches"
     const uint32_t lmask = (B.rfl <= 0) ? 0u : ((1u << (2 * B.rfl)) - 1);                               // byte 0 of an fp15
     const uint32_t rmask = (B.rfrbits <= 0) ? 0u : (((1u << B.rfrbits) - 1) << (7 - B.rfrbits));      // byte 1
