@@ -502,7 +502,7 @@ static int build_tables_on_device(GbnBatch &b) {
     LUTRC(dev_alloc(ctr, 2));
     LUTRC(dev_alloc(d->cell_start, nc1)); LUTRC(dev_alloc(d->cellw, (size_t)L.ncells)); LUTRC(dev_alloc(d->cellt, (size_t)L.ncells));
     LUTRC(dev_alloc(d->pv, (size_t)((L.ncells + 31) / 32)));
-    LUTCHK(hipMemsetAsync(count, 0, nc1 * 4, st)); LUTCHK(hipMemsetAsync(ctr, 0, 16, st));
+    LUTCHK(hipMemsetAsync(ctr, 0, 16, st));
     auto bits_for = [](uint64_t below) { int k = 1; while (k < 63 && ((uint64_t)1 << k) < below) k++; return k; };
     LutBuild B; std::memset(&B, 0, sizeof(B));
     B.q8 = d->q8; B.qlen = b.qlen; B.seg_left = d_sl; B.seg_right = d_sr; B.nseg = (int32_t)sl.size();
@@ -517,6 +517,9 @@ static int build_tables_on_device(GbnBatch &b) {
     // the engine lets the probe kernel wait for it -- the binning kernel of the search starts at once.
     const bool sync_build = gbn::switch_value("GBN_SYNC_BUILD", 0) != 0;
     if (L.type != GBN_LUT_SMALL_NA && !sync_build) {
+        // (no count per cell here: the sorted list gives cell_start -- a gigabyte less per 5 Mb build than counting with
+        // atomics, clearing the counters first and scanning them afterwards)
+        B.count = nullptr;
         LUTCHK(lut_enumerate(B, st));
         B.onebyte_mode = 0;
         LUTRC(dev_alloc(d->ent, qn + 1));
@@ -525,12 +528,12 @@ static int build_tables_on_device(GbnBatch &b) {
         size_t b1 = 0, b2 = 0;
         const int key_bits = 2 * L.lut + 1;                         // (the cell; one bit more: "no word at this position" sorts last)
         LUTCHK(lut_sort(nullptr, b1, B, (int64_t)qn, key_bits, st));
-        LUTCHK(lut_scan(nullptr, b2, count, d->cell_start, (int64_t)nc1, st));
+        LUTCHK(lut_scan(nullptr, b2, many, many_prefix, (int64_t)nc1, st));
         LUTCHK(pool_alloc(&tmp, std::max(b1, b2) + 256));
         size_t tb = std::max(b1, b2) + 256;
-        LUTCHK(lut_sort(tmp, tb, B, (int64_t)qn, key_bits, st));
-        tb = std::max(b1, b2) + 256;
-        LUTCHK(lut_scan(tmp, tb, count, d->cell_start, (int64_t)nc1, st));
+        uint32_t *n_valid = reinterpret_cast<uint32_t *>(ctr);           // (the counters' first word: nothing else uses it in this branch)
+        LUTCHK(lut_sort(tmp, tb, B, (int64_t)qn, key_bits, st, n_valid));
+        LUTCHK(lut_cell_starts(B, n_valid, st));
         B.ent = d->ent; B.sidet = d->sidet; B.side_start = d->side_start;
         LUTCHK(lut_entries(B, -1, st));
         LUTCHK(lut_cells(B, st));
@@ -545,6 +548,7 @@ static int build_tables_on_device(GbnBatch &b) {
                         (void *)keys_a, (void *)keys_b, (void *)ctr, tmp}) d->build_scratch.push_back(p);
         return GBN_OK;
     }
+    LUTCHK(hipMemsetAsync(count, 0, nc1 * 4, st));
     LUTCHK(lut_enumerate(B, st));
     if (L.type == GBN_LUT_SMALL_NA) LUTCHK(lut_overflow_cells(B, ctr + 1, st));
     size_t b1 = 0, b2 = 0;

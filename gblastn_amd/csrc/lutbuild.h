@@ -3,14 +3,21 @@
 #include <hip/hip_runtime.h>
 #include <cstdint>
 
+#ifndef GBN_LUT_RADIX_BITS
+#define GBN_LUT_RADIX_BITS 6        // digit of the builder's radix sort (lutbuild.hip)
+#endif
+
 namespace gbn {
+
+// passes lut_sort takes for keys of key_bits bits (the top bit is the "no word here" flag, dropped by the first pass)
+__host__ __device__ inline int lut_sort_passes(int key_bits) { const int p = (key_bits - 1 + GBN_LUT_RADIX_BITS - 1) / GBN_LUT_RADIX_BITS; return p < 1 ? 1 : p; }
 
 struct LutBuild {                           // device pointers throughout
     const uint8_t *q8; int32_t qlen;        // concatenated query, position 0 (sentinel padding either side)
     const int32_t *seg_left, *seg_right; int32_t nseg;      // indexed stretches, ascending, non-empty
     int32_t lut, word, q_bits, descending, onebyte_mode;
     int64_t ncells;
-    uint32_t *count;                        // ncells + 1, zero on entry
+    uint32_t *count;                        // ncells + 1, zero on entry; nullptr: no counting (cell_start comes from lut_cell_starts)
     uint32_t *keys_a, *keys_b, *vals_a, *vals_b;            // qlen entries each: {cell (1 << 2 lut: no word here), offset} by list index, sorted on the cell
     uint32_t *cell_start;                   // ncells + 1
     uint32_t *cellw, *cellt, *pv; unsigned long long *ent;
@@ -20,7 +27,8 @@ struct LutBuild {                           // device pointers throughout
 
 hipError_t lut_enumerate(const LutBuild &b, hipStream_t st);
 hipError_t lut_overflow_cells(const LutBuild &b, unsigned long long *out, hipStream_t st);
-hipError_t lut_sort(void *tmp, size_t &bytes, const LutBuild &b, int64_t n, int key_bits, hipStream_t st);
+hipError_t lut_sort(void *tmp, size_t &bytes, const LutBuild &b, int64_t n, int key_bits, hipStream_t st, uint32_t *n_valid_out = nullptr);
+hipError_t lut_cell_starts(const LutBuild &b, const uint32_t *n_valid, hipStream_t st);       // cell_start from keys_b sorted (count == nullptr builds)
 hipError_t lut_scan(void *tmp, size_t &bytes, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st);
 hipError_t lut_entries(const LutBuild &b, int64_t n, hipStream_t st);
 hipError_t lut_cells(const LutBuild &b, hipStream_t st);

@@ -34,43 +34,61 @@ __device__ __forceinline__ uint32_t reduce_fp(uint32_t fp) { return ((((fp >> 1)
 // (Sixteen consecutive positions per thread: one search for the stretch, the word rolled on base by base -- 27 byte loads
 // instead of 192 and one binary search instead of sixteen; a thread per position with its chain of 26 dependent loads took
 // 2.3 ms per 5 Mb batch next to a running scan, the longest kernel of a build.)
-__global__ void __launch_bounds__(256) lut_enumerate_kernel(gbn::LutBuild B)
+__global__ void __launch_bounds__(64) lut_enumerate_kernel(gbn::LutBuild B)
 {
-    constexpr int PER = 16;
-    const int64_t nchunk = ((int64_t)B.qlen + PER - 1) / PER;
+    constexpr int PER = 16, NT = 64, BLOCK = NT * PER;
+    // a workgroup's 1,024 keys (one wave: 4 KB of LDS, so that several fit into what the probe kernel leaves of a CU's) cross the LDS on their way out: a thread computes sixteen CONSECUTIVE positions (the rolled word),
+    // a store instruction should write 64 consecutive ones -- stored thread by thread the list took 450 MB of partial sectors per
+    // 5 Mb batch for its 80 MB (profiles/r04i_pmc.csv)
+    __shared__ uint32_t s_key[NT * (PER + 1)];
+    const int64_t nblock = ((int64_t)B.qlen + BLOCK - 1) / BLOCK;
     const uint32_t none = 1u << (2 * B.lut), cmask = none - 1u;
-    const int lut = B.lut;
-    for (int64_t ch = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; ch < nchunk; ch += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t p0 = ch * PER;
-        const int n = (int)min((int64_t)PER, (int64_t)B.qlen - p0);
-        int lo = 0, hi = B.nseg;                    // last stretch that starts at or before p0
-        while (lo < hi) { const int m = (lo + hi) >> 1; if (B.seg_left[m] <= p0) lo = m + 1; else hi = m; }
-        int si = lo - 1;
-        int32_t left = si >= 0 ? B.seg_left[si] : 0, right = si >= 0 ? B.seg_right[si] : -1;
-        int32_t next_left = (si + 1 < B.nseg) ? B.seg_left[si + 1] : INT32_MAX;
-        // the word at p is made of the bases p .. p + lut - 1 (the query has 64 bytes of sentinels past its end); `run` =
-        // bases without an ambiguity code or a sentinel that end at the newest one
-        uint32_t cell = 0; int run = 0;
-        for (int k = 0; k < lut - 1; k++) {
-            const uint8_t b = B.q8[p0 + k];
-            run = (b & 0xfc) ? 0 : run + 1;
-            cell = (cell << 2) | (b & 3u);
-        }
-        for (int i = 0; i < n; i++) {
-            const int64_t p = p0 + i;
-            const uint8_t b = B.q8[p + lut - 1];
-            run = (b & 0xfc) ? 0 : run + 1;
-            cell = ((cell << 2) | (b & 3u)) & cmask;
-            while (p >= (int64_t)next_left) {
-                si++; left = next_left; right = B.seg_right[si];
-                next_left = (si + 1 < B.nseg) ? B.seg_left[si + 1] : INT32_MAX;
+    const int lut = B.lut, tid = threadIdx.x;
+    // the list's first home: whichever array leaves the sorted list in keys_b / vals_b after lut_sort's passes
+    uint32_t *__restrict__ keys0 = (gbn::lut_sort_passes(2 * lut + 1) & 1) ? B.keys_a : B.keys_b, *__restrict__ vals0 = (gbn::lut_sort_passes(2 * lut + 1) & 1) ? B.vals_a : B.vals_b;
+    for (int64_t blk = blockIdx.x; blk < nblock; blk += gridDim.x) {
+        const int64_t b0 = blk * BLOCK, p0 = b0 + (int64_t)tid * PER;
+        const int n = (int)max((int64_t)0, min((int64_t)PER, (int64_t)B.qlen - p0));
+        if (n > 0) {
+            int lo = 0, hi = B.nseg;                    // last stretch that starts at or before p0
+            while (lo < hi) { const int m = (lo + hi) >> 1; if (B.seg_left[m] <= p0) lo = m + 1; else hi = m; }
+            int si = lo - 1;
+            int32_t left = si >= 0 ? B.seg_left[si] : 0, right = si >= 0 ? B.seg_right[si] : -1;
+            int32_t next_left = (si + 1 < B.nseg) ? B.seg_left[si + 1] : INT32_MAX;
+            // the word at p is made of the bases p .. p + lut - 1 (the query has 64 bytes of sentinels past its end); `run` =
+            // bases without an ambiguity code or a sentinel that end at the newest one
+            uint32_t cell = 0; int run = 0;
+            for (int k = 0; k < lut - 1; k++) {
+                const uint8_t b = B.q8[p0 + k];
+                run = (b & 0xfc) ? 0 : run + 1;
+                cell = (cell << 2) | (b & 3u);
             }
-            const bool ok = si >= 0 && right - left + 1 >= B.word && p + lut - 1 <= (int64_t)right && run >= lut;
-            if (ok) atomicAdd(&B.count[cell], 1u);
-            const int64_t at = B.descending ? (int64_t)B.qlen - 1 - p : p;
-            B.keys_a[at] = ok ? cell : none;
-            B.vals_a[at] = (uint32_t)p;
+            for (int i = 0; i < n; i++) {
+                const int64_t p = p0 + i;
+                const uint8_t b = B.q8[p + lut - 1];
+                run = (b & 0xfc) ? 0 : run + 1;
+                cell = ((cell << 2) | (b & 3u)) & cmask;
+                while (p >= (int64_t)next_left) {
+                    si++; left = next_left; right = B.seg_right[si];
+                    next_left = (si + 1 < B.nseg) ? B.seg_left[si + 1] : INT32_MAX;
+                }
+                const bool ok = si >= 0 && right - left + 1 >= B.word && p + lut - 1 <= (int64_t)right && run >= lut;
+                if (ok && B.count) atomicAdd(&B.count[cell], 1u);       // (null: the cells' sizes follow from the sorted list, lut_cell_starts_kernel)
+                s_key[tid * (PER + 1) + i] = ok ? cell : none;
+            }
         }
+        __syncthreads();
+        #pragma unroll
+        for (int r = 0; r < PER; r++) {
+            const int e = r * NT + tid;                 // the block's e-th position
+            const int64_t p = b0 + e;
+            if (p < B.qlen) {
+                const int64_t at = B.descending ? (int64_t)B.qlen - 1 - p : p;
+                keys0[at] = s_key[(e / PER) * (PER + 1) + (e % PER)];
+                vals0[at] = (uint32_t)p;
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -135,12 +153,27 @@ __global__ void lut_side_kernel(gbn::LutBuild B)
     }
 }
 
-__global__ void lut_pv_kernel(const uint32_t *count, int64_t ncells, uint32_t *pv)
+// cell_start from the list sorted on the cell (n valid entries, the number on the device): entry i that opens a cell writes
+// the start of that cell and of the empty cells in front of it; i = n closes the table.  Every cell_start is written exactly
+// once, in ascending order: 67 MB for 16.7 M cells -- where rounds 1-3 counted the words per cell with an atomic per query
+// position (0.8 GB of sectors written back per 5 Mb batch, `profiles/r04i_pmc.csv`), cleared that array first and ran a scan
+// over it afterwards: a gigabyte per build that the probe kernel next to it paid for.
+__global__ void lut_cell_starts_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ n_dev, int64_t ncells, uint32_t *__restrict__ cell_start)
+{
+    const int64_t n = (int64_t)*n_dev;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t prev = i == 0 ? -1 : (int64_t)keys[i - 1], cur = i == n ? ncells : (int64_t)keys[i];
+        for (int64_t c = prev + 1; c <= cur; c++) cell_start[c] = (uint32_t)i;
+    }
+}
+
+// count == nullptr: a cell is present when its list is not empty (starts = cell_start)
+__global__ void lut_pv_kernel(const uint32_t *count, const uint32_t *starts, int64_t ncells, uint32_t *pv)
 {
     const int lane = (int)(threadIdx.x & 63);
     const int64_t span = (ncells + 63) & ~(int64_t)63;      // whole waves: the ballot needs every lane of a wave
     for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < span; c += (int64_t)gridDim.x * blockDim.x) {
-        const bool present = c < ncells && count[c] != 0;
+        const bool present = c < ncells && (count ? count[c] != 0 : starts[c + 1] != starts[c]);
         const unsigned long long m = __ballot(present);
         if (c < ncells && (lane & 31) == 0) pv[c >> 5] = (uint32_t)(m >> (lane & 32));
     }
@@ -234,7 +267,7 @@ hipError_t lut_pack_query(const uint8_t *qbuf, int64_t qbuf_len, int64_t first, 
 hipError_t lut_enumerate(const LutBuild &b, hipStream_t st)
 {
     if (b.qlen <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_enumerate_kernel, dim3(polite_grid(((int64_t)b.qlen + 15) / 16, 256)), dim3(256), 0, st, b);
+    hipLaunchKernelGGL(lut_enumerate_kernel, dim3(4 * polite_grid(((int64_t)b.qlen + 15) / 16, 256)), dim3(64), 0, st, b);    // (a one-wave workgroup per 1,024 positions, grid-stride: as many waves as 256-thread workgroups would have brought)
     return hipGetLastError();
 }
 hipError_t lut_overflow_cells(const LutBuild &b, unsigned long long *out, hipStream_t st)
@@ -329,22 +362,26 @@ hipError_t lut_scan(void *tmp, size_t &bytes, const uint32_t *in, uint32_t *out,
 // the rare kernel 1.6), this one a third of that.
 namespace {
 constexpr int RS_CHUNK = 4096, RS_THREADS = 256, RS_WAVES = RS_THREADS / 64, RS_ROUNDS = RS_CHUNK / RS_THREADS;
+// digits of 6 bits: a chunk leaves runs of 64 elements (256 bytes) per digit instead of 16 (64 bytes, most of them across two
+// sectors and written a few bytes at a time: four times the bytes written, `profiles/r04i_pmc.csv`) -- four passes for 24 bits
+// instead of three, and fewer bytes all the same
+constexpr int RS_BITS = GBN_LUT_RADIX_BITS, RS_DIGITS = 1 << RS_BITS;
 
 __global__ void __launch_bounds__(RS_THREADS) radix_count_kernel(const uint32_t *__restrict__ keys, int64_t n_cap, const uint32_t *__restrict__ n_dev,
                                                                  uint32_t none, int shift, uint32_t *__restrict__ counts, int64_t nchunks)
 {
-    __shared__ uint32_t s_hist[256];
+    __shared__ uint32_t s_hist[RS_DIGITS];
     const int tid = threadIdx.x;
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap, base = (int64_t)blockIdx.x * RS_CHUNK;
-    s_hist[tid] = 0;
+    if (tid < RS_DIGITS) s_hist[tid] = 0;
     __syncthreads();
     uint32_t k[RS_ROUNDS];
     #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) { const int64_t i = base + r * RS_THREADS + tid; k[r] = i < n ? keys[i] : none; }
     #pragma unroll
-    for (int r = 0; r < RS_ROUNDS; r++) if (k[r] != none) atomicAdd(&s_hist[(k[r] >> shift) & 255u], 1u);
+    for (int r = 0; r < RS_ROUNDS; r++) if (k[r] != none) atomicAdd(&s_hist[(k[r] >> shift) & (uint32_t)(RS_DIGITS - 1)], 1u);
     __syncthreads();
-    counts[(int64_t)tid * nchunks + blockIdx.x] = s_hist[tid];          // digit-major: one scan over the whole table gives every (digit, chunk) its place
+    if (tid < RS_DIGITS) counts[(int64_t)tid * nchunks + blockIdx.x] = s_hist[tid];          // digit-major: one scan over the whole table gives every (digit, chunk) its place
 }
 
 __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
@@ -352,12 +389,14 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_
                                                                    const uint32_t *__restrict__ n_dev, uint32_t none, int shift,
                                                                    const uint32_t *__restrict__ offsets, int64_t nchunks)
 {
-    __shared__ uint32_t s_cnt[RS_WAVES][256];
+    __shared__ uint32_t s_cnt[RS_WAVES][RS_DIGITS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int64_t n = n_dev ? min((int64_t)*n_dev, n_cap) : n_cap;
     const int64_t w0 = (int64_t)blockIdx.x * RS_CHUNK + (int64_t)wave * (RS_CHUNK / RS_WAVES) + lane;
-    #pragma unroll
-    for (int w = 0; w < RS_WAVES; w++) s_cnt[w][tid] = 0;
+    if (tid < RS_DIGITS) {
+        #pragma unroll
+        for (int w = 0; w < RS_WAVES; w++) s_cnt[w][tid] = 0;
+    }
     __syncthreads();
     uint32_t k[RS_ROUNDS], v[RS_ROUNDS], sr[RS_ROUNDS];
     #pragma unroll
@@ -366,10 +405,10 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_
     #pragma unroll
     for (int r = 0; r < RS_ROUNDS; r++) {
         const bool valid = k[r] != none;
-        const uint32_t digit = (k[r] >> shift) & 255u;
+        const uint32_t digit = (k[r] >> shift) & (uint32_t)(RS_DIGITS - 1);
         unsigned long long peers = __ballot(valid);
         #pragma unroll
-        for (int b = 0; b < 8; b++) {
+        for (int b = 0; b < RS_BITS; b++) {
             const bool bit = (digit >> b) & 1u;
             const unsigned long long m = __ballot(valid && bit);
             peers &= bit ? m : ~m;
@@ -383,7 +422,7 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_
         }
     }
     __syncthreads();
-    {
+    if (tid < RS_DIGITS) {
         uint32_t run = offsets[(int64_t)tid * nchunks + blockIdx.x];
         #pragma unroll
         for (int w = 0; w < RS_WAVES; w++) { const uint32_t c = s_cnt[w][tid]; s_cnt[w][tid] = run; run += c; }
@@ -396,9 +435,16 @@ __global__ void __launch_bounds__(RS_THREADS) radix_scatter_kernel(const uint32_
 }  // namespace
 
 // keys_a / vals_a -> keys_b / vals_b: the elements whose key is not 1 << (key_bits - 1), ordered by key, stable
-hipError_t lut_sort(void *tmp, size_t &bytes, const LutBuild &b, int64_t n, int key_bits, hipStream_t st)
+hipError_t lut_cell_starts(const LutBuild &b, const uint32_t *n_valid, hipStream_t st)
 {
-    const int64_t nchunks = (n + RS_CHUNK - 1) / RS_CHUNK, ncounts = 256 * std::max<int64_t>(nchunks, 1);
+    hipLaunchKernelGGL(lut_cell_starts_kernel, dim3(polite_grid((int64_t)b.qlen + 1, 256)), dim3(256), 0, st, b.keys_b, n_valid, b.ncells, b.cell_start);
+    return hipGetLastError();
+}
+
+// n_valid_out (optional, device): receives the number of elements kept
+hipError_t lut_sort(void *tmp, size_t &bytes, const LutBuild &b, int64_t n, int key_bits, hipStream_t st, uint32_t *n_valid_out)
+{
+    const int64_t nchunks = (n + RS_CHUNK - 1) / RS_CHUNK, ncounts = RS_DIGITS * std::max<int64_t>(nchunks, 1);
     size_t scan_bytes = 0;
     (void)lut_scan(nullptr, scan_bytes, nullptr, nullptr, ncounts, st);
     const size_t need = (size_t)ncounts * 4 + scan_bytes + 64;
@@ -407,21 +453,22 @@ hipError_t lut_sort(void *tmp, size_t &bytes, const LutBuild &b, int64_t n, int 
     if (bytes < need || key_bits < 2 || key_bits > 32) return hipErrorInvalidValue;
     uint32_t *counts = static_cast<uint32_t *>(tmp), *scan_tmp = counts + ncounts, *n_valid = scan_tmp + scan_bytes / 4 + 2;
     const uint32_t none = 1u << (key_bits - 1);
-    const int npass = std::max(1, (key_bits - 1 + 7) / 8);
-    uint32_t *const K[2] = {b.keys_a, b.keys_b}, *const V[2] = {b.vals_a, b.vals_b};
+    const int npass = lut_sort_passes(key_bits);
+    // (the list starts where lut_enumerate put it: in keys_a / vals_a for an odd number of passes, in keys_b / vals_b for an even one)
+    uint32_t *const K[2] = {npass & 1 ? b.keys_a : b.keys_b, npass & 1 ? b.keys_b : b.keys_a};
+    uint32_t *const V[2] = {npass & 1 ? b.vals_a : b.vals_b, npass & 1 ? b.vals_b : b.vals_a};
     const int64_t scan_blocks = (ncounts + SCAN_BLOCK - 1) / SCAN_BLOCK;
     for (int p = 0; p < npass; p++) {
         const uint32_t *nd = p ? n_valid : nullptr;             // (pass 0 drops the keys that are `none`: the passes behind it see the rest)
         const int in = p & 1, out = in ^ 1;
-        hipLaunchKernelGGL(radix_count_kernel, dim3((unsigned)nchunks), dim3(RS_THREADS), 0, st, K[in], n, nd, none, 8 * p, counts, nchunks);
+        hipLaunchKernelGGL(radix_count_kernel, dim3((unsigned)nchunks), dim3(RS_THREADS), 0, st, K[in], n, nd, none, RS_BITS * p, counts, nchunks);
         size_t sb = scan_bytes;
         if (hipError_t e = lut_scan(scan_tmp, sb, counts, counts, ncounts, st)) return e;
-        if (p == 0) { if (hipError_t e = hipMemcpyAsync(n_valid, scan_tmp + scan_blocks, 4, hipMemcpyDeviceToDevice, st)) return e; }
-        hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nchunks), dim3(RS_THREADS), 0, st, K[in], V[in], K[out], V[out], n, nd, none, 8 * p, counts, nchunks);
-    }
-    if (npass % 2 == 0) {       // the result sits in keys_a / vals_a: the callers read keys_b / vals_b
-        if (hipError_t e = hipMemcpyAsync(b.keys_b, b.keys_a, (size_t)n * 4, hipMemcpyDeviceToDevice, st)) return e;
-        if (hipError_t e = hipMemcpyAsync(b.vals_b, b.vals_a, (size_t)n * 4, hipMemcpyDeviceToDevice, st)) return e;
+        if (p == 0) {
+            if (hipError_t e = hipMemcpyAsync(n_valid, scan_tmp + scan_blocks, 4, hipMemcpyDeviceToDevice, st)) return e;
+            if (n_valid_out) { if (hipError_t e = hipMemcpyAsync(n_valid_out, scan_tmp + scan_blocks, 4, hipMemcpyDeviceToDevice, st)) return e; }
+        }
+        hipLaunchKernelGGL(radix_scatter_kernel, dim3((unsigned)nchunks), dim3(RS_THREADS), 0, st, K[in], V[in], K[out], V[out], n, nd, none, RS_BITS * p, counts, nchunks);
     }
     return hipGetLastError();
 }
@@ -455,7 +502,7 @@ hipError_t lut_rank_fill(const uint32_t *pv, const uint32_t *prefix, const uint3
 }
 hipError_t lut_pv(const LutBuild &b, hipStream_t st)
 {
-    hipLaunchKernelGGL(lut_pv_kernel, dim3(polite_grid(b.ncells, 256)), dim3(256), 0, st, b.count, b.ncells, b.pv);
+    hipLaunchKernelGGL(lut_pv_kernel, dim3(polite_grid(b.ncells, 256)), dim3(256), 0, st, b.count, b.cell_start, b.ncells, b.pv);
     return hipGetLastError();
 }
 
