@@ -158,12 +158,27 @@ __global__ void lut_side_kernel(gbn::LutBuild B)
 // once, in ascending order: 67 MB for 16.7 M cells -- where rounds 1-3 counted the words per cell with an atomic per query
 // position (0.8 GB of sectors written back per 5 Mb batch, `profiles/r04i_pmc.csv`), cleared that array first and ran a scan
 // over it afterwards: a gigabyte per build that the probe kernel next to it paid for.
-__global__ void lut_cell_starts_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ n_dev, int64_t ncells, uint32_t *__restrict__ cell_start)
+__global__ void __launch_bounds__(256) lut_cell_starts_kernel(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ n_dev, int64_t ncells, uint32_t *__restrict__ cell_start)
 {
     const int64_t n = (int64_t)*n_dev;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i <= n; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t prev = i == 0 ? -1 : (int64_t)keys[i - 1], cur = i == n ? ncells : (int64_t)keys[i];
-        for (int64_t c = prev + 1; c <= cur; c++) cell_start[c] = (uint32_t)i;
+    const int lane = (int)(threadIdx.x & 63);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    // (wave-uniform trip count: the lanes of a wave fill a LONG run of empty cells together -- a batch of few words in a table of
+    // 16.7 M cells, or of none at all, would leave millions of stores to one lane)
+    for (int64_t i0 = (int64_t)blockIdx.x * blockDim.x + (threadIdx.x & ~63u); i0 <= n; i0 += stride) {
+        const int64_t i = i0 + lane;
+        int64_t prev = 0, cur = -1;                             // (nothing to write past the list's end)
+        if (i <= n) { prev = i == 0 ? -1 : (int64_t)keys[i - 1]; cur = i == n ? ncells : (int64_t)keys[i]; }
+        const bool lng = cur - prev > 32;
+        if (!lng) for (int64_t c = prev + 1; c <= cur; c++) cell_start[c] = (uint32_t)i;
+        unsigned long long m = __ballot(lng);
+        while (m) {
+            const int src = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const int64_t p = __shfl(prev, src), q = __shfl(cur, src);
+            const uint32_t v = (uint32_t)(i0 + src);
+            for (int64_t c = p + 1 + lane; c <= q; c += 64) cell_start[c] = v;
+        }
     }
 }
 

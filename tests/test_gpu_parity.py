@@ -603,6 +603,39 @@ def test_slice_scan_with_repeats_that_overflow_a_segment():
     assert ps2.diagnostics.scan_launches == 1
 
 
+@pytest.mark.parametrize("task", ["megablast", "blastn"])
+def test_tables_of_many_cells_and_few_words(task):
+    """A batch long enough for a table of 4^11 cells in which most queries are nothing but N: a few thousand words among four
+    million cells, long runs of empty cells (the device builder reads cell_start off the sorted word list and fills the
+    runs a wave at a time, lutbuild.hip), and one query batch without a single word.  Stages and counters equal the oracle's."""
+    rng = np.random.default_rng(5 if task == "megablast" else 6)
+    db, queries, plants, subjects, opt = util.small_case(5, 120_000, 30, task=task, seed=21)
+    for i in range(len(queries)):
+        if i % 6:
+            queries[i] = np.full(len(queries[i]), 14, dtype=np.uint8)            # N throughout
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    if task == "megablast":                                                     # (blastn counts the words before it chooses: a table of 4^8 cells)
+        assert ps.info()["lut_width"] >= 10, ps.info()
+    gpu = ps.run(keep_stages=True)
+    ora, s = util.oracle_run(opt, queries, subjects)
+    util.compare_stages(gpu, ora)
+    assert ps.diagnostics.lookup_hits == s.stats.lookup_hits and len(gpu["hsps"]) > 0
+    ps.close()
+    # (a batch of nothing but N has no valid context: the set-up refuses it as BLAST_MainSetUp does; one query of 29 good bases
+    # among them makes a batch whose table has two words)
+    nothing = [np.full(1000, 14, dtype=np.uint8) for _ in range(30)]
+    with pytest.raises(api.BlastError):
+        api.BlastPrelimSearch(nothing, opt, src)
+    nothing[7] = nothing[7].copy(); nothing[7][400:429] = rng.integers(0, 4, 29, dtype=np.uint8)
+    ps = api.BlastPrelimSearch(nothing, opt, src)
+    gpu = ps.run(keep_stages=True)
+    ora, s = util.oracle_run(opt, nothing, subjects)
+    util.compare_stages(gpu, ora)
+    assert ps.diagnostics.lookup_hits == s.stats.lookup_hits
+    ps.close()
+
+
 def test_pipelined_passes_bin_ahead_for_one_another(monkeypatch):
     """gbn_prelim_search_begin over one range of a shard with a megablast-shaped batch queues the NEXT pass's binning kernel
     (the records depend on the shard and the table's shape only) behind its own kernels; a next pass of the same shape finds
