@@ -723,6 +723,14 @@ extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan
 extern "C" __global__ void __launch_bounds__(GBN_SORT_THREADS, GBN_BIN_OCC) scan_bin_kernel_s21(GbnBinParams B) { GBN_BIN_BODY<21, 8>(B); }
 
 namespace {
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+// sixteen bytes from a dword-aligned address with ONE load instruction, waited for on the spot (every load of the wave with it)
+__device__ __forceinline__ u32x4 load16_now(const void *p)
+{
+    u32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 // rare path of the probe kernel: full fingerprints, chain walk, exact verification
 // Seeds go to P.seeds through one wave-aggregated reservation per loop round, or -- when the caller passes
 // an LDS staging buffer (`s_buf`, `s_n`, capacity `cap`) -- are collected there first and flushed by the
@@ -733,11 +741,18 @@ namespace {
 __device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell, bool count_raw, uint32_t cw,
                            unsigned long long &raw, GbnDevSeed *s_buf = nullptr, uint32_t *s_n = nullptr, uint32_t cap = 0)
 {
-    const GbnTile T = P.tiles[posid >> GBN_BIN_TILE_BITS];
+    // (the four words of a tile in ONE load: the rare kernel is bound by the number of scattered requests its records make)
+    // (written as it is executed: the compiler cuts a 16-byte load of which three words are used into two loads)
+    const u32x4 tw = load16_now(P.tiles + (posid >> GBN_BIN_TILE_BITS));
+    GbnTile T; T.subj = (int32_t)tw.x; T.first_pos = (int32_t)tw.y; T.npos = (int32_t)tw.z; T.off16 = (int32_t)tw.w;
     const int32_t s = T.first_pos + (int32_t)(posid & (uint32_t)(GBN_BIN_TILE_POS - 1)) * P.step;
     const uint8_t *__restrict__ subj = P.db + ((size_t)(uint32_t)T.off16 << 4);     // = byte_off[T.subj], one load less
     // one 32-base window from s - 8 holds the 8 bases left of the word and (lut <= 16) at least 8 right of it
+#if GBN_RARE_ABL & 1
+    const uint64_t w32 = (uint64_t)(uintptr_t)subj * 0x9e3779b97f4a7c15ull;   // ablation: no subject read (wrong results)
+#else
     const uint64_t w32 = (P.fl > 0 || P.fr > 0) ? bases32(subj, (int64_t)s - 8) : 0ull;     // lut == word: nothing to compare
+#endif
     const uint32_t sl = (uint32_t)(w32 >> 48);
     const uint32_t sr = (uint32_t)((w32 << (2 * (8 + P.lut))) >> 32);
     if (!count_raw && !(cw >> 31) && !fp_pass(cw, sl, sr, P.fl, P.fr)) return;
@@ -802,6 +817,9 @@ probe_bin_kernel(GbnBinParams B)
     uint2 *q = s_q + wave * GBN_BIN_QCAP;
     int qn = 0;                                                     // wave-uniform
     unsigned long long raw = 0;
+    unsigned long long rawu = 0;                                    // wave-uniform part of the lookup-hit count (GBN_PROBE_MASKS)
+    int16_t opaque_zero;
+    asm("s_mov_b32 %0, 0" : "=s"(opaque_zero));
     const unsigned long long lt = (1ull << lane) - 1;
 
     // Flush `cnt` queued items (one per lane): cells with a side list get their reduced
@@ -859,6 +877,7 @@ probe_bin_kernel(GbnBinParams B)
         __syncthreads();
         const uint32_t pad = GBN_REC_PAD(cbits, b);
         const int32_t tadj = GBN_BIN_TAB0 - (int32_t)(GBN_REC_PAR(cbits, b) << 15);     // s_tab index = low 16 bits of the hi word + tadj
+        const uint32_t tab_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)s_tab + (uint32_t)(tadj * 4);   // LDS byte address of index 0
         // one piece of a writer stream per wave at a time; streams are cut into `split` pieces
         // (multiples of 512 records) when there are fewer streams than waves working on the bin
         const int nwaves = nw * (GBN_BIN_THREADS / 64);
@@ -901,6 +920,34 @@ probe_bin_kernel(GbnBinParams B)
                 uint32_t hv[NR], tv[NR];
                 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) { hv[4 * u] = cur[u].x; hv[4 * u + 1] = cur[u].y; hv[4 * u + 2] = cur[u].z; hv[4 * u + 3] = cur[u].w; }
+#if GBN_PROBE_MASKS
+                // all LDS lookups first (a pad reads one of the two empty extra cells); the byte address of a record's cell =
+                // low half of the hi word x 4 + the table's base in one v_mad_u32_u16
+                #pragma unroll
+                for (uint32_t r = 0; r < NR; r++) {
+                    uint32_t a;
+                    asm("v_mad_u32_u16 %0, %1, 4, %2" : "=v"(a) : "v"(hv[r]), "v"(tab_addr));
+                    tv[r] = *(const __attribute__((address_space(3))) uint32_t *)(uintptr_t)a;
+                }
+                __builtin_amdgcn_sched_barrier(0);              // (the tests below are not to be scheduled between the lookups)
+                // The tests of a record leave lane masks in scalar registers and are combined there: the vector unit is what
+                // bounds this kernel (round 4: 35 instructions per record, a third of them the select chains of `slow` and the
+                // packed counters of c0 / c1), the scalar unit idles.  Lookup hits (as below: #c0 + #c1, three and more entries
+                // corrected in flush()) are population counts of the same masks.
+                uint32_t slowm = 0, raw32 = 0;                  // raw32: wave-uniform
+                #pragma unroll
+                for (uint32_t r = 0; r < NR; r++) {
+                    const uint32_t t = tv[r];
+                    const uint32_t x = (t ^ __builtin_amdgcn_perm(hv[r], hv[r], 0x07060706u)) & m4;
+                    const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;
+                    // (against a zero the compiler does not know, bit 15 is ONE compare of the sign-extended low half)
+                    const unsigned long long m0 = __ballot((int16_t)(uint16_t)t < opaque_zero), m1 = __ballot((int32_t)t < 0), mz = __ballot(z != 0);
+                    const unsigned long long ms = (m0 & mz) | (m1 & ~m0);         // c0 ? some side matches : c1
+                    raw32 += (uint32_t)__popcll(m0) + (uint32_t)__popcll(m1);
+                    slowm |= __builtin_amdgcn_inverse_ballot_w64(ms) ? (1u << r) : 0u;
+                }
+                rawu += raw32;
+#else
                 #pragma unroll
                 for (uint32_t r = 0; r < NR; r++) tv[r] = s_tab[(int32_t)(hv[r] & 0xffffu) + tadj];   // all LDS lookups first (a pad reads one of the two empty extra cells)
                 // Both fingerprints of the cell word against the subject's in one go: a masked byte of
@@ -920,7 +967,8 @@ probe_bin_kernel(GbnBinParams B)
                     flags += (t >> 15) & 0x10001u;              // c0 in the low half, c1 in the high half
                     slowm |= slow ? (1u << r) : 0u;
                 }
-                uint32_t raw32 = (flags & 0xffffu) + (flags >> 16);
+                raw += (flags & 0xffffu) + (flags >> 16);
+#endif
                 // queue the (few) records that need the rare path: one per lane and round
                 while (true) {
                     const unsigned long long m = __ballot(slowm != 0);
@@ -933,7 +981,6 @@ probe_bin_kernel(GbnBinParams B)
                     qn += __popcll(m);
                     if (qn >= 64) { qn -= 64; flush(qn, 64, b); }
                 }
-                raw += raw32;
                 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) cur[u] = nxt[u];
             }
@@ -942,6 +989,7 @@ probe_bin_kernel(GbnBinParams B)
     }
     if (P.raw_hits) {
         for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
+        raw += rawu;
         if (lane == 0 && raw) atomicAdd(P.raw_hits, raw);
     }
     __syncthreads();
@@ -991,21 +1039,50 @@ probe_rare_kernel(GbnBinParams B, int nseg)
             const uint32_t wr = pid / B.subcap, j = pid - wr * B.subcap;
             const uint32_t *__restrict__ cur = B.tcur + ((size_t)bin * B.nwriters + wr) * B.nseq;
             // everything that hangs on the queue item alone is asked for here, in front of the cursor search
+#if GBN_RARE_ABL & 2
+            const uint32_t idx = j & 0xffffu;                   // ablation: no index read (wrong results)
+#else
             const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, j))];
+#endif
+#if GBN_RARE_ABL & 4
+            cw = (cv * 2654435761u) & 0x7fffffffu;              // ablation: no cell word read (wrong results)
+#else
             cw = P.cellw[cv & 0x7fffffffu];
+#endif
             // tiles of this writer: one per full round, and one of the last, incomplete round if its rotated index falls into it
             const uint32_t full_rounds = (uint32_t)(P.ntiles / B.nwriters), rest = (uint32_t)(P.ntiles % B.nwriters);
             const uint32_t ntiles_w = full_rounds + (((wr + full_rounds) % (uint32_t)B.nwriters) < rest ? 1u : 0u);
             const uint32_t nt = (ntiles_w + (1u << GBN_TCUR_SHIFT) - 1u) >> GBN_TCUR_SHIFT;          // cursor entries
             uint32_t lo = 0, hi = nt;
+            const uint32_t total = B.gcount[(size_t)bin * B.nwriters + wr];
+#if GBN_RARE_CUR4
+            // The cursors grow almost linearly (a group of eight tiles leaves ~128 +- 11 records in a stream): FOUR cursors around
+            // the interpolated one, fetched with one 16-byte load, name the run for nearly every record; the binary search below
+            // is what is left for the others.  (Round 4 counted the kernel's requests: some twelve scattered loads per record -- two
+            // cursors around a wider window and three steps of the search among them -- at the ~140 G requests per second the L2s
+            // take ARE its 1.7 ms; the sectors behind them mostly sit in the Infinity Cache.)
+            if (B.nseq >= 4u) {
+                const uint32_t g = min((uint32_t)((float)j * ((float)nt / (float)(total ? total : 1u))), nt - 1u);
+                const uint32_t a = min(g > 0u ? g - 1u : 0u, B.nseq - 4u);
+                const u32x4 cq = load16_now(cur + a);
+                struct { uint32_t c[4]; } c4 = {{cq.x, cq.y, cq.z, cq.w}};
+                // entries from nt on are not cursors
+                const uint32_t v1 = (a + 1u < nt) ? c4.c[1] : 0xffffffffu, v2 = (a + 2u < nt) ? c4.c[2] : 0xffffffffu, v3 = (a + 3u < nt) ? c4.c[3] : 0xffffffffu;
+                if (a >= nt || c4.c[0] > j) hi = min(a, nt);
+                else if (j < v1) { lo = a; hi = a + 1u; }
+                else if (j < v2) { lo = a + 1u; hi = a + 2u; }
+                else if (j < v3) { lo = a + 2u; hi = a + 3u; }
+                else lo = a + 3u;
+            }
+#else
             {   // the cursors grow almost linearly: look around the interpolated run first
-                const uint32_t total = B.gcount[(size_t)bin * B.nwriters + wr];
                 const uint32_t g = (uint32_t)(((unsigned long long)j * nt) / (total ? total : 1u));
                 constexpr uint32_t W = 3u;
                 const uint32_t a = g > W ? g - W : 0u, z = min(nt, g + W);
                 const uint32_t ca = cur[a], cz = (z < nt) ? cur[z] : 0xffffffffu;
                 if (ca <= j && cz > j) { lo = a; hi = z; }
             }
+#endif
             while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cur[mid] <= j) lo = mid; else hi = mid; }
             const uint32_t seqn = (lo << GBN_TCUR_SHIFT) | (idx >> GBN_BIN_TILE_BITS);
             pid = (GBN_TILE_OF(wr, seqn, (uint32_t)B.nwriters) << GBN_BIN_TILE_BITS) | (idx & (uint32_t)(GBN_BIN_TILE_POS - 1));
@@ -1058,7 +1135,12 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
     }
     if (ev) (void)hipEventRecord(ev[2], st);
     if (parts & 4) {
-        if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * 8), dim3(256), 0, st, b, grid2);
+        // parts per segment (workgroups per queue segment).  Same box, C2, kernel alone / in the pipeline: 2 parts 1.95 / 2.09 ms,
+        // 3: 1.60 / 1.72, 4: 1.49-1.52 / 1.61-1.69, 5: 1.47 / 1.86, 6: 1.81 / 1.91-1.93, 8 (rounds 1-4): 1.61 / 1.69-1.71,
+        // 12: 1.62 / 1.70-1.72, 24: 1.55 / 1.63 (profiles/r04k_rare_kernel.txt) -- the kernel is bound by the rate at which HBM
+        // takes its scattered sectors, and more waves in flight do not raise it
+        const int parts = (int)std::max(1ll, std::min(64ll, gbn::switch_value("GBN_RARE_PARTS", 4)));
+        if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * parts), dim3(256), 0, st, b, grid2);
         e = hipGetLastError();
     }
     if (ev) (void)hipEventRecord(ev[3], st);

@@ -21,6 +21,15 @@ static inline hipError_t raise_dynamic_lds(const void *fn, size_t lds, std::atom
     return e;
 }
 
+#ifndef GBN_PROBE_MASKS
+#define GBN_PROBE_MASKS 1   // probe kernel: the tests of a record combined as lane masks in scalar registers (0: the round-3 select chains, A/B)
+#endif
+#ifndef GBN_RARE_ABL
+#define GBN_RARE_ABL 0      // ablations of the rare kernel (timing only, wrong results): 1 no subject read, 2 no index read, 4 no cell word read
+#endif
+#ifndef GBN_RARE_CUR4
+#define GBN_RARE_CUR4 1     // rare kernel: the run of a record from four cursors in one load (0: two cursors + binary search, A/B)
+#endif
 #ifndef GBN_PROBE_U
 #define GBN_PROBE_U 2        // 16-byte loads per lane and round of the probe kernel (4 records each)
 #endif
