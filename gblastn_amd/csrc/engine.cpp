@@ -135,7 +135,7 @@ struct Engine {
     hipEvent_t ev_seed = nullptr;
     unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
     uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;             // per-run stream cursors (6-byte records)
-    GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
+    GbnRareItem *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
     // what the host reads after a scan, in ONE pinned block filled by asynchronous copies behind the kernels (round 4: the
     // counters, the overflow word and the rare-path counts came back through three blocking copies to pageable memory)
     struct ScanBack { unsigned long long cnt[2], seg_max; uint32_t overflow, pad_; uint32_t rare_counts[2048]; } *scan_back = nullptr;
@@ -143,7 +143,7 @@ struct Engine {
     // a second set of the five buffers above: the rare kernel of pass k reads one set on stream2 while the binning
     // and probe kernels of pass k + 1 fill the other (search_range, deferred rare path); swapped when a pass is handed over
     struct ScanSet { unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0; uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;
-                     GbnU2 *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr; uint32_t *bin_count = nullptr; size_t bin_count_cap = 0; } alt;
+                     GbnRareItem *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr; uint32_t *bin_count = nullptr; size_t bin_count_cap = 0; } alt;
     void swap_scan_sets() {
         std::swap(bin_rec, alt.bin_rec); std::swap(bin_rec_cap, alt.bin_rec_cap); std::swap(bin_tcur, alt.bin_tcur); std::swap(bin_tcur_cap, alt.bin_tcur_cap);
         std::swap(rareq, alt.rareq); std::swap(rareq_cap, alt.rareq_cap); std::swap(rare_counts, alt.rare_counts);

@@ -44,6 +44,11 @@
 #define GBN_TILE_OF(w, k, n) ((uint32_t)(k) * (uint32_t)(n) + (((uint32_t)(w) + (uint32_t)(k)) % (uint32_t)(n)))
 
 struct GbnU2 { uint32_t x, y; };
+// an item of the rare-path queue: x = record index inside its bin's region, y = cell (bit 31: a cell whose lookup hits are
+// counted by the rare kernel), z = the record's 16-bit index, w = the cell's direct-probe word (GbnScanParams::cellw) -- both
+// fetched by the probe kernel when it queues the item, next to its streams, so that the rare kernel, which is bound by the
+// rate at which HBM takes scattered sectors, has one sector per item left to fetch (the subject's)
+struct GbnRareItem { uint32_t x, y, z, w; };
 // Scan records: blocks of 64 records = 256 bytes of `hi` words followed by 128 bytes of 16-bit indices
 // (13 bits: position inside the tile, 3 bits: the tile's sequence number mod 8); the tile itself is not
 // stored -- the few records that reach the rare path find it in the cursor table (GbnBinParams::tcur).
@@ -77,7 +82,7 @@ struct GbnBinParams {
     uint32_t *overflow;             // set to 1 if any stream did not fit
     int rfl, rfrbits;               // reduced fingerprint: bases on the left (<= 4), BITS on the right (<= 7 = 3.5 bases)
     int dbg;                        // host-side launch switches of tools/scan_ablate.py (1: no rare kernel, 32: timing print, 64: any-stride binning kernel); never read on the device
-    GbnU2 *rareq; uint32_t rare_seg;    // rare-path queue: one segment of rare_seg items per probe workgroup
+    GbnRareItem *rareq; uint32_t rare_seg;    // rare-path queue: one segment of rare_seg items per probe workgroup
     uint32_t *rare_counts;              // [probe workgroups] items queued (may exceed rare_seg: overflow)
 };
 

@@ -748,11 +748,7 @@ __device__ void probe_slow(const GbnScanParams &P, uint32_t posid, uint32_t cell
     const int32_t s = T.first_pos + (int32_t)(posid & (uint32_t)(GBN_BIN_TILE_POS - 1)) * P.step;
     const uint8_t *__restrict__ subj = P.db + ((size_t)(uint32_t)T.off16 << 4);     // = byte_off[T.subj], one load less
     // one 32-base window from s - 8 holds the 8 bases left of the word and (lut <= 16) at least 8 right of it
-#if GBN_RARE_ABL & 1
-    const uint64_t w32 = (uint64_t)(uintptr_t)subj * 0x9e3779b97f4a7c15ull;   // ablation: no subject read (wrong results)
-#else
     const uint64_t w32 = (P.fl > 0 || P.fr > 0) ? bases32(subj, (int64_t)s - 8) : 0ull;     // lut == word: nothing to compare
-#endif
     const uint32_t sl = (uint32_t)(w32 >> 48);
     const uint32_t sr = (uint32_t)((w32 << (2 * (8 + P.lut))) >> 32);
     if (!count_raw && !(cw >> 31) && !fp_pass(cw, sl, sr, P.fl, P.fr)) return;
@@ -807,7 +803,7 @@ probe_bin_kernel(GbnBinParams B)
     const int wi = (int)(blockIdx.x >> 3) + sub * (int)(gridDim.x >> 3), nw = (int)(gridDim.x >> 3) * nsub;   // workgroup index among those on the bin
     const int cbits = B.cbits;
     const uint32_t ncell_bin = 1u << cbits;
-    GbnU2 *myq = B.rareq + (size_t)blockIdx.x * B.rare_seg;          // this workgroup's segment: no global atomics
+    GbnRareItem *myq = B.rareq + (size_t)blockIdx.x * B.rare_seg;          // this workgroup's segment: no global atomics
     if (tid == 0) { *s_rcount = 0; s_tab[GBN_BIN_TAB0 - 1] = 0; s_tab[GBN_BIN_TAB0 + GBN_BIN_CELLS] = 0; }      // the empty cells pad records point at
     if ((B.dbg & 128) && tid == 0) B.rare_counts[1024 + blockIdx.x] = __builtin_amdgcn_s_getreg((3 << 11) | 20);    // GBN_DBG=128: the XCD (HW_REG_XCC_ID) this workgroup runs on
     // masks of the reduced fingerprint test; a zero mask makes that side "always matches"
@@ -829,12 +825,12 @@ probe_bin_kernel(GbnBinParams B)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // queue slots written by other lanes of this wave
         bool keep = false; uint32_t at_rec = 0, cv = 0;
         if (lane < cnt) {
-            at_rec = q[first + lane].x;                             // record index inside the bin's region
-            // The queue holds nothing but that index: the record itself is read again here, once per 64 queued records
-            // (the main loop picked it out of its eight registers with a chain of selects and looked its cell up a
-            // second time for every queued record -- a third of the loop's instructions for 0.7 % of the records).
-            const uint32_t wr = at_rec / B.subcap, jr = at_rec - wr * B.subcap;
-            const uint32_t hv = B.rec[GBN_REC_HI(GBN_RECIDX(B, bin, wr, jr))];
+            // the queue holds the record's index inside the bin's region and its hi word (picked out of the lane's eight
+            // registers by a select tree when it was queued: round 4 read the record again here, a scattered load and a wait of
+            // its full latency per 64 queued records -- affordable now that the main loop's tests run on the scalar unit)
+            const uint2 qe = q[first + lane];
+            at_rec = qe.x;
+            const uint32_t hv = qe.y;
             const uint32_t low = hv & 0x7fffu, sf = (hv >> 16) & 0x7fffu;
             cv = ((uint32_t)bin << cbits) | low;
             keep = true;
@@ -859,8 +855,19 @@ probe_bin_kernel(GbnBinParams B)
             base = __shfl(base, 0);
             if (keep) {
                 const uint32_t at = base + (uint32_t)__popcll(m & lt);
-                const uint32_t pid = at_rec;                        // resolved to a position id by the rare kernel
-                if (at < B.rare_seg) { myq[at].x = pid; myq[at].y = cv; }
+                if (at < B.rare_seg) {
+#if GBN_PROBE_FETCH
+                    // the record's index and the cell's direct-probe word travel with the item (GbnRareItem): two scattered
+                    // sectors per item fetched here, by the few lanes that keep one, underneath the streams of the other waves
+                    const uint32_t wr = at_rec / B.subcap, jr = at_rec - wr * B.subcap;
+                    const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, jr))];
+                    const uint32_t cw = P.cellw[cv & 0x7fffffffu];
+#else
+                    const uint32_t idx = 0, cw = 0;                 // (fetched by the rare kernel)
+#endif
+                    uint4 it; it.x = at_rec; it.y = cv; it.z = idx; it.w = cw;      // at_rec: resolved to a position id by the rare kernel
+                    *reinterpret_cast<uint4 *>(myq + at) = it;
+                }
             }
         }
     };
@@ -920,7 +927,15 @@ probe_bin_kernel(GbnBinParams B)
                 uint32_t hv[NR], tv[NR];
                 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) { hv[4 * u] = cur[u].x; hv[4 * u + 1] = cur[u].y; hv[4 * u + 2] = cur[u].z; hv[4 * u + 3] = cur[u].w; }
-#if GBN_PROBE_MASKS
+#if GBN_PROBE_ABL & 1
+                // ablation (timing only, wrong results): the streams alone -- no table lookup, no test
+                uint32_t slowm = 0, raw32 = 0;
+                { uint32_t acc = 0;
+                  #pragma unroll
+                  for (uint32_t r = 0; r < NR; r++) acc ^= hv[r];
+                  slowm = (acc == 0x12345678u) ? 1u : 0u; (void)tv; }
+                rawu += raw32;
+#elif GBN_PROBE_MASKS
                 // all LDS lookups first (a pad reads one of the two empty extra cells); the byte address of a record's cell =
                 // low half of the hi word x 4 + the table's base in one v_mad_u32_u16
                 #pragma unroll
@@ -976,7 +991,22 @@ probe_bin_kernel(GbnBinParams B)
                     if (slowm) {
                         const uint32_t r = (uint32_t)__ffs(slowm) - 1u;
                         slowm &= slowm - 1;
-                        q[qn + __popcll(m & lt)].x = rbase + j0 + (r >> 2) * 256u + (uint32_t)lane * 4u + (r & 3u);
+                        // hi word of record r: a tree of bit-field inserts under masks of r's bits (written as selects, the
+                        // compiler makes it an indexed load from a copy of hv[] in scratch memory: 2.8 -> 4.05 ms)
+                        uint32_t hsel;
+                        if constexpr (NR == 8) {
+                            const uint32_t m0 = 0u - (r & 1u), m1 = 0u - ((r >> 1) & 1u), m2 = 0u - ((r >> 2) & 1u);
+                            const uint32_t a0 = (hv[1] & m0) | (hv[0] & ~m0), a1 = (hv[3] & m0) | (hv[2] & ~m0);
+                            const uint32_t a2 = (hv[5] & m0) | (hv[4] & ~m0), a3 = (hv[7] & m0) | (hv[6] & ~m0);
+                            const uint32_t c0 = (a1 & m1) | (a0 & ~m1), c1 = (a3 & m1) | (a2 & ~m1);
+                            hsel = (c1 & m2) | (c0 & ~m2);
+                        } else {
+                            hsel = 0;
+                            #pragma unroll
+                            for (uint32_t k = 0; k < NR; k++) hsel |= hv[k] & (0u - (uint32_t)(r == k));
+                        }
+                        uint2 qe; qe.x = rbase + j0 + (r >> 2) * 256u + (uint32_t)lane * 4u + (r & 3u); qe.y = hsel;
+                        q[qn + __popcll(m & lt)] = qe;
                     }
                     qn += __popcll(m);
                     if (qn >= 64) { qn -= 64; flush(qn, 64, b); }
@@ -1005,7 +1035,7 @@ probe_rare_kernel(GbnBinParams B, int nseg)
     // blockIdx.x % nseg = segment (probe workgroup), blockIdx.x / nseg = part
     const int seg = blockIdx.x % nseg, part = blockIdx.x / nseg, nparts = gridDim.x / nseg;
     const uint32_t n = min(B.rare_counts[seg], B.rare_seg);
-    const GbnU2 *qs = B.rareq + (size_t)seg * B.rare_seg;
+    const GbnRareItem *qs = B.rareq + (size_t)seg * B.rare_seg;
     // dense-seed shapes (lut == word: every lookup hit is a seed) stage their seeds in LDS
     constexpr uint32_t CAP = 1536;
     __shared__ GbnDevSeed s_buf[CAP];
@@ -1032,21 +1062,16 @@ probe_rare_kernel(GbnBinParams B, int nseg)
         if (staged) { __syncthreads(); if (s_n > CAP - 512u) flush(); }      // s_n is stable between the barriers
         const uint32_t i = i0 + threadIdx.x;
         if (i >= n) continue;
-        uint32_t pid = qs[i].x; const uint32_t cv = qs[i].y;
-        uint32_t cw;
+        const uint4 item = *reinterpret_cast<const uint4 *>(qs + i);
+        uint32_t pid = item.x; const uint32_t cv = item.y;
+        uint32_t idx = item.z, cw = item.w;
         {   // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
             const uint32_t bin = (cv & 0x7fffffffu) >> B.cbits;
             const uint32_t wr = pid / B.subcap, j = pid - wr * B.subcap;
             const uint32_t *__restrict__ cur = B.tcur + ((size_t)bin * B.nwriters + wr) * B.nseq;
+#if !GBN_PROBE_FETCH
             // everything that hangs on the queue item alone is asked for here, in front of the cursor search
-#if GBN_RARE_ABL & 2
-            const uint32_t idx = j & 0xffffu;                   // ablation: no index read (wrong results)
-#else
-            const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, j))];
-#endif
-#if GBN_RARE_ABL & 4
-            cw = (cv * 2654435761u) & 0x7fffffffu;              // ablation: no cell word read (wrong results)
-#else
+            idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, j))];
             cw = P.cellw[cv & 0x7fffffffu];
 #endif
             // tiles of this writer: one per full round, and one of the last, incomplete round if its rotated index falls into it
@@ -1137,7 +1162,7 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
     if (parts & 4) {
         // parts per segment (workgroups per queue segment).  Same box, C2, kernel alone / in the pipeline: 2 parts 1.95 / 2.09 ms,
         // 3: 1.60 / 1.72, 4: 1.49-1.52 / 1.61-1.69, 5: 1.47 / 1.86, 6: 1.81 / 1.91-1.93, 8 (rounds 1-4): 1.61 / 1.69-1.71,
-        // 12: 1.62 / 1.70-1.72, 24: 1.55 / 1.63 (profiles/r04k_rare_kernel.txt) -- the kernel is bound by the rate at which HBM
+        // 12: 1.62 / 1.70-1.72, 24: 1.55 / 1.63 (profiles/r04k_probe_and_rare_kernel.txt) -- the kernel is bound by the rate at which HBM
         // takes its scattered sectors, and more waves in flight do not raise it
         const int parts = (int)std::max(1ll, std::min(64ll, gbn::switch_value("GBN_RARE_PARTS", 4)));
         if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * parts), dim3(256), 0, st, b, grid2);

@@ -24,8 +24,11 @@ static inline hipError_t raise_dynamic_lds(const void *fn, size_t lds, std::atom
 #ifndef GBN_PROBE_MASKS
 #define GBN_PROBE_MASKS 1   // probe kernel: the tests of a record combined as lane masks in scalar registers (0: the round-3 select chains, A/B)
 #endif
-#ifndef GBN_RARE_ABL
-#define GBN_RARE_ABL 0      // ablations of the rare kernel (timing only, wrong results): 1 no subject read, 2 no index read, 4 no cell word read
+#ifndef GBN_PROBE_ABL
+#define GBN_PROBE_ABL 0     // ablations of the probe kernel (timing only, wrong results): 1 the streams alone (no table lookup, no test)
+#endif
+#ifndef GBN_PROBE_FETCH
+#define GBN_PROBE_FETCH 1   // 1: the probe kernel fetches a queued item's 16-bit index and cell word (0: the rare kernel does; measured the same sum)
 #endif
 #ifndef GBN_RARE_CUR4
 #define GBN_RARE_CUR4 1     // rare kernel: the run of a record from four cursors in one load (0: two cursors + binary search, A/B)
