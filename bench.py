@@ -475,8 +475,10 @@ def side_workloads(device_index):
     import subprocess
     out = {}
     for wl, steps in (("C3", "32"), ("C4", "80")):
-        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", steps, "--warmup", "2", "--no-cpu-baseline",
-               "--engine-steps", "0", "--min-seconds", "1.0", "--side"]
+        # C3 carries a CPU baseline of its own (the oracle on the same 100-query batch, ~6 s per host core); C4's preliminary
+        # search is C2's -- its baseline is the C2 line's
+        cmd = [sys.executable, os.path.abspath(__file__), "--workload", wl, "--steps", steps, "--warmup", "2",
+               "--engine-steps", "0", "--min-seconds", "1.0", "--side"] + (["--cpu-seconds", "6"] if wl == "C3" else ["--no-cpu-baseline"])
         env = dict(os.environ); env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", "")
         if not env["HIP_VISIBLE_DEVICES"]:
             del env["HIP_VISIBLE_DEVICES"]
@@ -493,6 +495,7 @@ def side_workloads(device_index):
                        "launches_per_step": (r.get("launches") or 0) / max(j["steps"], 1),
                        "scan_kernel": r.get("kernel"), "scan_kernel_hbm_frac": r.get("frac"), "valu": r.get("valu"),
                        "stage_ms_per_launch": j["config"].get("stage_ms_per_pass"),
+                       "cpu_baseline": j.get("cpu_baseline") if wl == "C3" else "the preliminary search is C2's: see this line's cpu_baseline",
                        "command": "python bench.py --workload %s --steps %s" % (wl, steps)}
         except Exception as e:      # noqa
             out[wl] = {"error": repr(e)[:300]}
@@ -606,8 +609,8 @@ def cpu_baseline(args, batch_queries, gopt, layout):
     single = max(r[0] / r[1] for r in res if r[1] > 0) / 1e9
     return {"value": done / t / 1e9 if t > 0 else 0.0, "unit": "Gbp/s", "cores": cores, "kind": "port",
             "single_core_value": single,
-            "sample": "%d subjects (%.0f Mbp) of the rank-0 shard spread over %d processes, one 5 Mb query batch, %.1f s each"
-                      % (done // layout.length, done / 1e6, cores, t)}
+            "sample": "%d subjects (%.0f Mbp) of the rank-0 shard spread over %d processes, one query batch of %.2f Mb, %.1f s each"
+                      % (done // layout.length, done / 1e6, cores, sum(len(q) for q in batch_queries) / 1e6, t)}
 
 
 if __name__ == "__main__":
