@@ -20,9 +20,21 @@ def main():
         for r in cur.execute(q):
             print("%s,%s,%d,%.6g,%.6g" % (short(r[0]), r[1], r[2], r[3], r[4]))
     else:
-        print("kernel,calls,total_us,avg_us,percent")
+        # avg_us is what rocprofv3 --stats prints (the top_kernels view); min / median / max from the dispatches themselves:
+        # the first launch of a kernel in a process (cold code, first touch of its buffers) can be several times the others
+        print("kernel,calls,total_us,avg_us,percent,min_us,median_us,max_us")
+        per = {}
+        try:
+            q = ("select S.display_name, K.end - K.start from rocpd_kernel_dispatch K "
+                 "inner join rocpd_info_kernel_symbol S on S.id = K.kernel_id and S.guid = K.guid")
+            for name, dur in con.cursor().execute(q):
+                per.setdefault(name, []).append(dur / 1000.0)
+        except sqlite3.Error:
+            per = {}
         for r in cur.execute("select name,total_calls,total_duration,average,percentage from top_kernels"):
-            print("%s,%d,%.3f,%.3f,%.2f" % (short(r[0]), r[1], r[2], r[3], r[4]))
+            d = sorted(per.get(r[0], []))
+            extra = ",%.3f,%.3f,%.3f" % (d[0], d[len(d) // 2], d[-1]) if d else ",,,"
+            print("%s,%d,%.3f,%.3f,%.2f%s" % (short(r[0]), r[1], r[2], r[3], r[4], extra))
 
 
 if __name__ == "__main__":

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-rXX}; O=$R/gpurun_out/prof_$TAG
 mkdir -p $O/kt $O/fetch $O/write
 cd $R
-timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --steps 4 --warmup 1 --no-cpu-baseline --engine-steps 0 --no-side-workloads --min-seconds 0 > $O/bench_under_rocprof.json 2> $O/kt.err
+timeout 400 rocprofv3 --kernel-trace --stats -d $O/kt -- python bench.py --steps 16 --warmup 2 --no-cpu-baseline --engine-steps 0 --no-side-workloads --min-seconds 0 > $O/bench_under_rocprof.json 2> $O/kt.err
 timeout 400 rocprofv3 --pmc FETCH_SIZE -d $O/fetch -- python bench.py --steps 2 --warmup 0 --no-cpu-baseline --engine-steps 0 --no-side-workloads --min-seconds 0 > /dev/null 2> $O/fetch.err
 timeout 400 rocprofv3 --pmc WRITE_SIZE -d $O/write -- python bench.py --steps 2 --warmup 0 --no-cpu-baseline --engine-steps 0 --no-side-workloads --min-seconds 0 > /dev/null 2> $O/write.err
 python tools/prof_summary.py $(find $O/kt -name "*.db" | head -1) > $O/kernel_stats.csv
