@@ -925,7 +925,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     if (nb > 1)
         for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) npos += (db.len[s] - b.lut.lut) / b.lut.step + 1;
     double slack = 1.25;
-    size_t rare_seg_hint = 0, slice_seg_cap = 0; int slice_blocks = 0; bool slice_ordered = false;
+    size_t rare_seg_hint = 0, rare_seg_used = 0, slice_seg_cap = 0; int slice_blocks = 0; bool slice_ordered = false;
     const bool reuse_binning = gbn::switch_value("GBN_REUSE_BINNING", 0) != 0;
     GbnBinParams last_B; std::memset(&last_B, 0, sizeof(last_B)); int last_grid2 = 0;
     if (E.seed_copy_pending) { HIPCHK(hipStreamWaitEvent(E.stream, E.ev_seed, 0)); E.seed_copy_pending = false; }
@@ -1017,6 +1017,11 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                     E.rareq_cap = want;
                 }
                 seg = E.rareq_cap / (size_t)grid2;
+                // tests: GBN_RARE_SEG=n starts with segments of n items, so that a small search overflows them and takes the
+                // way a repeat-rich range takes at full size (scan again with the room the counts ask for)
+                const long long seg_sw = gbn::switch_value("GBN_RARE_SEG", 0);
+                if (seg_sw > 0 && !rare_seg_hint) seg = std::min<size_t>(seg, (size_t)seg_sw);
+                rare_seg_used = seg;
                 if (!E.rare_counts && (rc = dev_alloc(E.rare_counts, (size_t)2048))) return rc;
                 B.rareq = E.rareq; B.rare_seg = (uint32_t)std::min<size_t>(seg, 0x7fffffff); B.rare_counts = E.rare_counts;
             }
@@ -1124,7 +1129,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                     fprintf(stderr, "[gbn dbg] scan_bin workgroup 0 (GBN_BIN_TIMING build), cycles/16 of wave %d per phase: %u %u %u %u %u %u %u %u %u\n",
                             w ? 15 : 0, ph[12 * w], ph[12 * w + 1], ph[12 * w + 2], ph[12 * w + 3], ph[12 * w + 4], ph[12 * w + 5], ph[12 * w + 6], ph[12 * w + 7], ph[12 * w + 8]);
             }
-            if ((size_t)mx > E.rareq_cap / (size_t)grid2) {    // a segment overflowed: grow and rescan this range
+            if ((size_t)mx > rare_seg_used) {                  // a segment overflowed: grow and rescan this range
                 rare_seg_hint = (size_t)mx + (mx >> 2);
                 continue;
             }

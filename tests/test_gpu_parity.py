@@ -746,3 +746,29 @@ def test_repeats_in_the_queries_give_long_cells(task, period):
     ora, s = util.oracle_run(opt, queries, subjects)
     util.compare_stages(gpu, ora)
     assert ps.diagnostics.lookup_hits == s.stats.lookup_hits and len(gpu["seeds"]) > 500
+
+
+def test_rare_queue_segments_that_overflow_are_scanned_again(monkeypatch):
+    """The probe kernel queues its survivors in a segment per workgroup, sized for random subjects; a segment that overflows
+    (repeat-rich ranges at full size) is counted past its end and the range is scanned again with the room the counts ask
+    for.  GBN_RARE_SEG=1 makes a small search take that way: same stages as the oracle's, one scan launch more per range --
+    single searches and pipelined passes (whose binning kernel may have run ahead) alike."""
+    db, queries, plants, subjects, opt = util.small_case(8, 300_000, 40, task="megablast", seed=5, planted_fraction=0.8)
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ora, s = util.oracle_run(opt, queries, subjects)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    binned = ps.info()["scan_path"] == 0 and os.environ.get("GBN_SCAN_BINS", "0") in ("", "0")
+    gpu = ps.run(keep_stages=True)
+    util.compare_stages(gpu, ora)
+    base = ps.diagnostics.scan_launches
+    want = gpu["hsps"].tobytes()
+    ps.close()
+    monkeypatch.setenv("GBN_RARE_SEG", "1")
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    gpu = ps.run(keep_stages=True)
+    util.compare_stages(gpu, ora)
+    if binned:
+        assert ps.diagnostics.scan_launches > base, (ps.diagnostics.scan_launches, base)
+    for _ in range(3):                                  # pipelined passes
+        ps.begin(); assert ps.end()["hsps"].tobytes() == want
+    ps.close(); src.close()
