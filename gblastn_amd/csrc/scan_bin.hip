@@ -872,42 +872,35 @@ probe_bin_kernel(GbnBinParams B)
         }
     };
 
+    // one piece of a writer stream per wave at a time; streams are cut into `split` pieces
+    // (multiples of 512 records) when there are fewer streams than waves working on the bin
+    constexpr uint32_t U = GBN_PROBE_U, BLK = 256u * U, NR = 4 * U;    // records per wave and per lane and round
+    const int nwaves = nw * (GBN_BIN_THREADS / 64);
+    const int split = (nwaves + B.nwriters - 1) / B.nwriters;
+    const int V = B.nwriters * split, v0 = wi + nw * wave;          // this wave's pieces of a bin: v0, v0 + nwaves, ...
+    // hi words of a piece: blocks of 64 records = 96 words; a round of BLK records starts at a block
+    // boundary (lo and BLK are multiples of 512), so a lane's words of round r sit at a fixed offset from
+    // the piece's first block + r * (BLK / 64 * 96)
+    uint32_t loff[U];
+    #pragma unroll
+    for (uint32_t u = 0; u < U; u++) { const uint32_t j = u * 256u + (uint32_t)lane * 4u; loff[u] = (j >> 6) * 96u + (j & 63u); }
     for (int b = grp % bstep; b < B.nb; b += GBN_BIN_GROUPS) {
-        __syncthreads();
-        {
-            const uint4 *src = reinterpret_cast<const uint4 *>(B.cellt + ((size_t)b << cbits));
-            uint4 *dst = reinterpret_cast<uint4 *>(s_tab + GBN_BIN_TAB0);
-            for (uint32_t i = tid; i < ncell_bin / 4; i += GBN_BIN_THREADS) dst[i] = src[i];
-            const uint32_t s0 = B.side_start[b], s1 = B.side_start[b + 1];
-            for (uint32_t i = tid; i < s1 - s0 && i < GBN_BIN_SIDE; i += GBN_BIN_THREADS) s_side[i] = B.sidet[s0 + i];
-        }
-        __syncthreads();
         const uint32_t pad = GBN_REC_PAD(cbits, b);
         const int32_t tadj = GBN_BIN_TAB0 - (int32_t)(GBN_REC_PAR(cbits, b) << 15);     // s_tab index = low 16 bits of the hi word + tadj
         const uint32_t tab_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)s_tab + (uint32_t)(tadj * 4);   // LDS byte address of index 0
-        // one piece of a writer stream per wave at a time; streams are cut into `split` pieces
-        // (multiples of 512 records) when there are fewer streams than waves working on the bin
-        const int nwaves = nw * (GBN_BIN_THREADS / 64);
-        const int split = (nwaves + B.nwriters - 1) / B.nwriters;
-        for (int v = wi + nw * wave; v < B.nwriters * split; v += nwaves) {
+        // state of the piece in work; software pipeline: the loads of the next round are in flight while this round's
+        // records are looked up
+        uint32_t n = 0, rbase = 0;
+        const uint32_t *__restrict__ pbase = B.rec;
+        uint4 cur[U], nxt[U];
+        auto start_piece = [&](int v, uint32_t ntot) {
             const int w = v / split, part = v - w * split;
-            const uint32_t ntot = B.gcount[(size_t)b * B.nwriters + w];
-            constexpr uint32_t U = GBN_PROBE_U, BLK = 256u * U, NR = 4 * U;    // records per wave and per lane and round
             const uint32_t piece = ((ntot + (uint32_t)split * BLK - 1u) / ((uint32_t)split * BLK)) * BLK;
-            const uint32_t lo = min((uint32_t)part * piece, ntot), n = min(piece, ntot - lo);
+            const uint32_t lo = min((uint32_t)part * piece, ntot);
+            n = min(piece, ntot - lo);
             // lo and every round start are multiples of 512 (one chunk per round in the chunked layout)
-            const uint32_t *__restrict__ recb = B.rec;
-            const uint32_t rbase = (uint32_t)w * B.subcap + lo;     // of this piece inside the bin's region
-            // software pipeline: the loads of the next round are in flight while this round's
-            // records are looked up
-            uint4 cur[U], nxt[U];
-            // hi words of the piece: blocks of 64 records = 96 words; a round of BLK records starts at a block
-            // boundary (lo and BLK are multiples of 512), so a lane's words of round r sit at a fixed offset from
-            // the piece's first block + r * (BLK / 64 * 96)
-            const uint32_t *__restrict__ pbase = recb + GBN_REC_HI(GBN_RECIDX(B, b, w, lo));
-            uint32_t loff[U];
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) { const uint32_t j = u * 256u + (uint32_t)lane * 4u; loff[u] = (j >> 6) * 96u + (j & 63u); }
+            rbase = (uint32_t)w * B.subcap + lo;                    // of this piece inside the bin's region
+            pbase = B.rec + GBN_REC_HI(GBN_RECIDX(B, b, w, lo));
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t j = u * 256u + (uint32_t)lane * 4u;
@@ -915,6 +908,35 @@ probe_bin_kernel(GbnBinParams B)
                 cur[u].x = (j < n) ? v.x : pad; cur[u].y = (j < n) ? v.y : pad;
                 cur[u].z = (j < n) ? v.z : pad; cur[u].w = (j < n) ? v.w : pad;
             }
+        };
+        {
+            // What a bin needs from memory before its first record is looked up -- the table slice, the side list, the
+            // size of the wave's first piece and that piece's first round -- is asked for BEFORE the barrier behind which
+            // the table of the bin before may be overwritten, every load in flight at once (written as `dst[i] = src[i]`
+            // loops, a thread's eight + four loads went out one after the other, each waited for, and the piece's count
+            // and first round behind the second barrier: some fourteen memory latencies per bin, 64 bins per workgroup,
+            // with nothing else running on the CU)
+            const uint4 *src = reinterpret_cast<const uint4 *>(B.cellt + ((size_t)b << cbits));
+            uint4 *dst = reinterpret_cast<uint4 *>(s_tab + GBN_BIN_TAB0);
+            constexpr uint32_t SL = GBN_BIN_CELLS / 4 / GBN_BIN_THREADS, SS = GBN_BIN_SIDE / GBN_BIN_THREADS;
+            const uint32_t s0 = B.side_start[b], s1 = B.side_start[b + 1];
+            const uint32_t nside = min(s1 - s0, (uint32_t)GBN_BIN_SIDE);
+            uint4 tv4[SL]; uint16_t sv[SS];
+            #pragma unroll
+            for (uint32_t k = 0; k < SL; k++) { const uint32_t i = (uint32_t)tid + k * GBN_BIN_THREADS; tv4[k] = (i < ncell_bin / 4) ? src[i] : make_uint4(0, 0, 0, 0); }
+            __builtin_amdgcn_sched_barrier(0);                      // (the count is wanted in a scalar register at once: behind the slice's loads, not in front of them)
+            const uint32_t g0 = (v0 < V) ? B.gcount[(size_t)b * B.nwriters + v0 / split] : 0u;
+            #pragma unroll
+            for (uint32_t k = 0; k < SS; k++) { const uint32_t i = (uint32_t)tid + k * GBN_BIN_THREADS; sv[k] = (i < nside) ? B.sidet[s0 + i] : (uint16_t)0; }
+            if (v0 < V) start_piece(v0, g0);
+            __syncthreads();                                        // every wave is through with the table of the bin before
+            #pragma unroll
+            for (uint32_t k = 0; k < SL; k++) { const uint32_t i = (uint32_t)tid + k * GBN_BIN_THREADS; if (i < ncell_bin / 4) dst[i] = tv4[k]; }
+            #pragma unroll
+            for (uint32_t k = 0; k < SS; k++) { const uint32_t i = (uint32_t)tid + k * GBN_BIN_THREADS; if (i < nside) s_side[i] = sv[k]; }
+        }
+        __syncthreads();
+        for (int v = v0; v < V; ) {
             for (uint32_t j0 = 0; j0 < n; j0 += BLK) {
                 const uint32_t rnext = ((j0 + BLK) >> 6) * 96u;       // word offset of the next round (a stream is far below 2^32 bytes)
                 #pragma unroll
@@ -1014,6 +1036,8 @@ probe_bin_kernel(GbnBinParams B)
                 #pragma unroll
                 for (uint32_t u = 0; u < U; u++) cur[u] = nxt[u];
             }
+            v += nwaves;
+            if (v < V) start_piece(v, B.gcount[(size_t)b * B.nwriters + v / split]);
         }
         if (qn > 0) { flush(0, qn, b); qn = 0; }                    // the side list changes with the bin
     }
