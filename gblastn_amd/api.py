@@ -88,7 +88,8 @@ EXPORTS = ["gbn_init", "gbn_release", "gbn_release_db_memory", "gbn_debug_check_
            "gbn_pipeline_diagnostics",
            "gbn_batch_scan_params", "gbn_batch_ext_params", "gbn_batch_gap_params", "gbn_batch_diag_layout",
            "gbn_prelim_search_lists", "gbn_db_cache_find", "gbn_db_cache_insert", "gbn_block_cache_find", "gbn_block_cache_insert",
-           "gbn_debug_db_bytes_uploaded", "gbn_debug_seed_order", "gbn_debug_bin_ahead_hits",
+           "gbn_debug_db_bytes_uploaded", "gbn_debug_seed_order", "gbn_debug_bin_ahead_hits", "gbn_debug_bin_ahead_misses",
+           "gbn_record_cache_set_limit", "gbn_record_cache_stats", "gbn_block_view", "gbn_results_emit_lists", "gbn_debug_counting_sink",
            "gbn_set_max_dbseq_len", "gbn_db_set_ambiguities", "gbn_traceback_merge", "gbn_shard_builder_new", "gbn_shard_builder_add", "gbn_shard_builder_finish", "gbn_shard_builder_free"]
 
 # ---- include/gblastn_amd_kernels.h: parameter blocks of the gbn_launch_* entry points (device pointers as integers)
@@ -163,6 +164,12 @@ def lib():
         L.gbn_block_cache_insert.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_void_p, C.POINTER(C.c_void_p)]
         L.gbn_debug_db_bytes_uploaded.restype = C.c_longlong; L.gbn_debug_db_bytes_uploaded.argtypes = []
         L.gbn_debug_bin_ahead_hits.restype = C.c_longlong; L.gbn_debug_bin_ahead_hits.argtypes = []
+        if hasattr(L, "gbn_record_cache_set_limit"):            # (an older build loaded through GBN_AMD_LIB for an A/B has none of these)
+            L.gbn_debug_bin_ahead_misses.restype = C.c_longlong; L.gbn_debug_bin_ahead_misses.argtypes = []
+            L.gbn_record_cache_set_limit.argtypes = [C.c_longlong]
+            L.gbn_record_cache_stats.argtypes = [C.POINTER(C.c_longlong), C.c_int]
+            L.gbn_block_view.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]
+            L.gbn_results_emit_lists.argtypes = [C.c_void_p, GbnHspListFn, C.c_void_p]
         L.gbn_debug_seed_order.restype = C.c_int
         L.gbn_debug_seed_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int32,
                                            C.c_int, C.c_void_p, C.POINTER(C.c_int64)]
@@ -261,6 +268,25 @@ def default_options(task="megablast", db_length=0, db_num_seqs=0, **kw):
     return o
 
 
+def record_cache_set_limit(nbytes=-1):
+    """Bytes of scan records the calling thread's device keeps resident ("bin once, probe many"); 0: off, < 0: default."""
+    _check(lib().gbn_record_cache_set_limit(int(nbytes)))
+
+
+def record_cache_stats():
+    v = (C.c_longlong * 8)()
+    _check(lib().gbn_record_cache_stats(v, 8))
+    return dict(zip(("limit", "bytes", "sets", "hits", "misses", "evictions", "bypassed", "ahead_hits"), [int(x) for x in v]))
+
+
+def block_view(blocks):
+    """Several resident blocks (BlastSeqSrc) searched as ONE shard; the library caches and owns the view."""
+    arr = (C.c_void_p * len(blocks))(*[b._h for b in blocks])
+    h = C.c_void_p()
+    _check(lib().gbn_block_view(arr, len(blocks), C.byref(h)))
+    return BlastSeqSrc(h, keep=list(blocks), owned=False)
+
+
 def set_max_dbseq_len(n=200000000):
     """MAX_DBSEQ_LEN for shards made from now on (longer sequences are searched in overlapping chunks)"""
     _check(lib().gbn_set_max_dbseq_len(n))
@@ -293,9 +319,10 @@ def dust_masks(queries, level=20, window=64, linker=1):
 class BlastSeqSrc:
     """One database shard resident in HBM."""
 
-    def __init__(self, handle, keep=None):
+    def __init__(self, handle, keep=None, owned=True):
         self._h = handle
         self._keep = keep
+        self._owned = owned         # False: a view or a block the library's caches own (close() only forgets the handle)
 
     @classmethod
     def from_packed(cls, subjects, first_oid=0):
@@ -333,13 +360,31 @@ class BlastSeqSrc:
 
     def close(self):
         if self._h:
-            lib().gbn_db_free(self._h); self._h = None
+            if self._owned:
+                lib().gbn_db_free(self._h)
+            self._h = None
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+    @classmethod
+    def from_oids(cls, subjects, oids):
+        """A block as the shim builds one: subjects appended one by one with their OIDs (gbn_shard_builder_*)."""
+        L = lib()
+        sb = C.c_void_p()
+        _check(L.gbn_shard_builder_new(C.byref(sb), len(subjects)))
+        try:
+            for (p, n), oid in zip(subjects, oids):
+                a = np.ascontiguousarray(p, dtype=np.uint8)
+                _check(L.gbn_shard_builder_add_oid(sb, int(oid), a.ctypes.data, int(n)))
+            h = C.c_void_p()
+            _check(L.gbn_shard_builder_finish(sb, C.byref(h)))
+        finally:
+            L.gbn_shard_builder_free(sb)
+        return cls(h)
 
 
 class QuerySet:
@@ -426,6 +471,16 @@ class BlastPrelimSearch:
         L = lib()
         _check(L.gbn_prelim_search_end(self._r))
         return dict(hsps=self._grab(L.gbn_results_num_hsps, L.gbn_results_hsps, HSP_DT))
+
+    def emit_lists(self):
+        """The finished results as the HSP stream takes them: [(oid, HSP_DT records)] ascending (gbn_results_emit_lists)."""
+        got = []
+
+        def sink(arg, oid, ptr, n):
+            got.append((int(oid), np.frombuffer(C.string_at(ptr, n * HSP_DT.itemsize), dtype=HSP_DT).copy()))
+            return 0
+        _check(lib().gbn_results_emit_lists(self._r, GbnHspListFn(sink), None))
+        return got
 
     def scan_only(self, seqsrc=None, repeats=1):
         d = GbnDiagnostics()

@@ -133,47 +133,59 @@ struct Engine {
     uint32_t *seg_counts = nullptr; unsigned long long *seg_firsts = nullptr;     // GBN_SLICE_SEGS counts / + 1 prefix sums (scratch of the consumers)
     GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
     hipEvent_t ev_seed = nullptr;
-    unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;     // records (all bins)
-    uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;             // per-run stream cursors (6-byte records)
-    GbnRareItem *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue
+    GbnRareItem *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue (the probe kernel's output: per query batch)
     // what the host reads after a scan, in ONE pinned block filled by asynchronous copies behind the kernels (round 4: the
     // counters, the overflow word and the rare-path counts came back through three blocking copies to pageable memory)
     struct ScanBack { unsigned long long cnt[2], seg_max; uint32_t overflow, pad_; uint32_t rare_counts[2048]; } *scan_back = nullptr;
-    uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;   // [nb][nwriters] + overflow flag
-    // a second set of the five buffers above: the rare kernel of pass k reads one set on stream2 while the binning
-    // and probe kernels of pass k + 1 fill the other (search_range, deferred rare path); swapped when a pass is handed over
-    struct ScanSet { unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0; uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;
-                     GbnRareItem *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr; uint32_t *bin_count = nullptr; size_t bin_count_cap = 0; } alt;
-    void swap_scan_sets() {
-        std::swap(bin_rec, alt.bin_rec); std::swap(bin_rec_cap, alt.bin_rec_cap); std::swap(bin_tcur, alt.bin_tcur); std::swap(bin_tcur_cap, alt.bin_tcur_cap);
-        std::swap(rareq, alt.rareq); std::swap(rareq_cap, alt.rareq_cap); std::swap(rare_counts, alt.rare_counts);
-        std::swap(bin_count, alt.bin_count); std::swap(bin_count_cap, alt.bin_count_cap);
-    }
-    // Binning ahead (pipelined passes over one range of one shard, GBN_BIN_AHEAD=0: off): the binning kernel reads the
+    // ---- the scan records: what the binning kernel writes.  They depend on the shard, the subject range and the SHAPE of
+    // the lookup table (lut width, stride, bins, fingerprint widths, stream geometry) -- not on the queries.  A RecordSet is
+    // the three buffers of one such key.
+    struct RecKey { const void *db = nullptr; int32_t s0 = 0, s1 = 0; int lut = 0, step = 0, nb = 0, nwriters = 0, rfl = 0, rfrbits = 0, cbits = 0;
+                    const void *tiles = nullptr; size_t subcap = 0;
+                    bool same_shape(const RecKey &o) const {      // everything but the streams' capacity
+                        return db == o.db && s0 == o.s0 && s1 == o.s1 && lut == o.lut && step == o.step && nb == o.nb && nwriters == o.nwriters &&
+                               rfl == o.rfl && rfrbits == o.rfrbits && cbits == o.cbits && tiles == o.tiles; }
+                    bool operator==(const RecKey &o) const { return same_shape(o) && subcap == o.subcap; } };
+    struct RecordSet { unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;      // records (all bins)
+                       uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;              // per-run stream cursors (6-byte records)
+                       uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;            // [nb][nwriters] + overflow flag
+                       RecKey key; bool complete = false;      // the buffers hold every record of `key` (binned, no stream overflowed)
+                       unsigned long long stamp = 0;           // last use (record cache: least recently used goes first)
+                       size_t bytes() const { return bin_rec_cap * 8 + bin_tcur_cap * 4 + bin_count_cap * 4; } };
+    // Record cache (the default): bin once, probe many.  Complete record sets stay resident, least recently
+    // used first out, up to rec_limit bytes (gbn_record_cache_set_limit / GBN_RECORD_CACHE_MB; default a quarter of the
+    // device's memory): a pass whose key is cached queues probe + rare kernel only -- every later query batch of a stream
+    // over one shard, every block view the shim searches again.  The reference keeps what ITS scan needs of the database on
+    // the device for the life of the process the same way (the per-OID subject cache, GB/gpu_blastn_MB_and_smallNa.cu:1461-1468).
+    // rec_limit == 0: off -- every pass bins for itself into `scratch` (bench.py's headline: the north_star scan).
+    std::vector<RecordSet *> rec_sets; long long rec_limit = -1; unsigned long long rec_clock = 0;
+    long long rec_hits = 0, rec_misses = 0, rec_evictions = 0, rec_bypass = 0;
+    RecordSet scratch, alt;             // cache off, or a set larger than the cache: the pass's own records; alt: binned ahead
+    void swap_scan_sets() { std::swap(scratch, alt); }
+    // Binning ahead (cache off; pipelined passes over one range of one shard, GBN_BIN_AHEAD=0: off): the binning kernel reads the
     // subjects only, so a pass queues the binning kernel of the NEXT pass -- into the other set of buffers -- behind its own
-    // kernels and in front of its host synchronisation; the next pass, if its records are to be the same (same shard, range,
-    // table shape, stream geometry), finds them there and queues probe + rare kernel only.  Every pass still bins once; what
-    // goes is the idle time of the GPU between a pass's last kernel and the next pass's first (0.5 ms of 13.5 on C2).
-    struct BinAhead { bool valid = false; const void *db = nullptr; int32_t s0 = 0, s1 = 0; int lut = 0, step = 0, nb = 0, nwriters = 0, rfl = 0, rfrbits = 0, cbits = 0;
-                      size_t subcap = 0; const void *tiles = nullptr;
+    // kernels and in front of its host synchronisation; the next pass, if its records are to be the same, finds them there and
+    // queues probe + rare kernel only.  Every pass still bins once; what goes is the idle time of the GPU between a pass's last
+    // kernel and the next pass's first (0.5 ms of 13.5 on C2).  A pass speculates only when the pass BEFORE it had the same key
+    // (a repeat has been seen: a caller that rotates shards or table shapes never pays for a binning kernel nobody uses).
+    struct BinAhead { bool valid = false; RecKey key;
                       hipEvent_t ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}; int pair = 0; } ahead;     // (two pairs of events around the kernel: a pass reads one pair while it records the other)
+    RecKey last_key; bool last_key_valid = false;      // the key of the last binned pass (cache off)
     bool want_ahead = false;            // the pass being scanned may bin ahead (set by run_search)
     bool counters_zeroed = false;       // counters[0 .. 3] are zero and nothing is queued that writes them (the pass before binned ahead)
     bool seed_copy_pending = false;     // ev_seed stands for a copy of the seeds on stream2 that the next scan must not overtake
-    long long ahead_hits = 0;
+    long long ahead_hits = 0, ahead_misses = 0;
     hipEvent_t ev_back = nullptr;       // behind the read-back copies of a scan
-    hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;       // around a deferred rare kernel (stream2)
     hipEvent_t ev0 = nullptr, ev1 = nullptr, evk[4] = {nullptr, nullptr, nullptr, nullptr};
     std::mutex mu;
-    // which scan records bin_rec holds (GBN_REUSE_BINNING)
-    struct BinKey { const void *db; int32_t s0, s1; int lut, step, nb, nwriters; size_t subcap; bool valid; } binkey = {nullptr, 0, 0, 0, 0, 0, 0, 0, false};
     // pinned host copies of a range's initial hits and gapped extensions, handed out again (hitbuf_get)
     struct HitBuf { GbnDevInitHit *hih = nullptr; GbnDevGapped *hg = nullptr; size_t cap = 0; };
     std::mutex hitbuf_mu; std::vector<HitBuf> hitbuf_idle;
     // traceback stage: stream and pinned staging buffer of gather_shard_bytes
     std::mutex gather_mu; hipStream_t gather_stream = nullptr; uint8_t *gather_stage = nullptr; size_t gather_stage_cap = 0;
 };
-typedef Engine::BinKey BinKey;
+typedef Engine::RecKey RecKey;
+typedef Engine::RecordSet RecordSet;
 typedef Engine::HitBuf HitBuf;
 
 // One engine per device, created by gbn_init / gbn_use_device (or by the first call that needs one) and alive
@@ -342,7 +354,9 @@ void pool_drain(int dev) {
 template <class T> static int dev_alloc(T *&p, size_t n) {
     p = nullptr;
     if (n == 0) n = 1;
-    HIPCHK(pool_alloc((void **)&p, n * sizeof(T)));
+    const hipError_t e = pool_alloc((void **)&p, n * sizeof(T));
+    if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); p = nullptr; set_error("out of device memory (" + std::to_string(n * sizeof(T)) + " bytes asked for)"); return GBN_ERR_NOMEM; }
+    HIPCHK(e);
     return GBN_OK;
 }
 template <class T> static int dev_upload(T *&p, const T *h, size_t n) {
@@ -875,12 +889,54 @@ static int scan_slices(const GbnBatch &b) {
     return scan_slice_count(P);
 }
 
+// ---- record cache (Engine::rec_sets) ----
+static void recset_free(RecordSet &r) {
+    dev_free(r.bin_rec); dev_free(r.bin_tcur); dev_free(r.bin_count);
+    r.bin_rec_cap = r.bin_tcur_cap = r.bin_count_cap = 0; r.complete = false;
+}
+// the buffers of `r` at least this long (freed and allocated anew when one is too short: whatever they held is gone)
+static int recset_size(RecordSet &r, size_t need_u64, size_t need_tcur, size_t need_count) {
+    int rc;
+    if (need_u64 > r.bin_rec_cap) { dev_free(r.bin_rec); r.bin_rec_cap = 0; r.complete = false; if ((rc = dev_alloc(r.bin_rec, need_u64))) return rc; r.bin_rec_cap = need_u64; }
+    if (need_tcur > r.bin_tcur_cap) { dev_free(r.bin_tcur); r.bin_tcur_cap = 0; r.complete = false; if ((rc = dev_alloc(r.bin_tcur, need_tcur))) return rc; r.bin_tcur_cap = need_tcur; }
+    if (need_count > r.bin_count_cap) { dev_free(r.bin_count); r.bin_count_cap = 0; r.complete = false; if ((rc = dev_alloc(r.bin_count, need_count))) return rc; r.bin_count_cap = need_count; }
+    return GBN_OK;
+}
+// bytes the cache may hold: gbn_record_cache_set_limit, else GBN_RECORD_CACHE_MB, else a quarter of the device's memory
+static long long rec_limit_bytes() {
+    if (E.rec_limit >= 0) return E.rec_limit;
+    if (gbn::switch_is_set("GBN_RECORD_CACHE_MB")) return std::max(0ll, gbn::switch_value("GBN_RECORD_CACHE_MB", 0)) << 20;
+    static thread_local long long dflt[kMaxDevices];        // (per device; the query costs a driver call)
+    long long &d = dflt[E.device >= 0 && E.device < kMaxDevices ? E.device : 0];
+    if (d == 0) { size_t fr = 0, tot = 0; d = hipMemGetInfo(&fr, &tot) == hipSuccess && tot ? (long long)(tot / 4) : (64ll << 30); }
+    return d;
+}
+static size_t rec_held_bytes() { size_t n = 0; for (const RecordSet *r : E.rec_sets) n += r->bytes(); return n; }
+static void rec_drop(size_t i, bool evicted) {
+    recset_free(*E.rec_sets[i]); delete E.rec_sets[i]; E.rec_sets.erase(E.rec_sets.begin() + (long)i);
+    if (evicted) E.rec_evictions++;
+}
+// the least recently used sets go until `need` more bytes fit under `limit` (keep: the set the pass is using)
+static void rec_make_room(size_t need, long long limit, const RecordSet *keep) {
+    while (!E.rec_sets.empty() && (long long)(rec_held_bytes() + need) > limit) {
+        size_t lru = E.rec_sets.size();
+        for (size_t i = 0; i < E.rec_sets.size(); i++)
+            if (E.rec_sets[i] != keep && (lru == E.rec_sets.size() || E.rec_sets[i]->stamp < E.rec_sets[lru]->stamp)) lru = i;
+        if (lru == E.rec_sets.size()) break;
+        rec_drop(lru, true);
+    }
+}
+// the shard goes (gbn_db_free), or everything (release, a limit of 0)
+static void rec_purge(const void *db) {
+    for (size_t i = E.rec_sets.size(); i-- > 0; ) if (!db || E.rec_sets[i]->key.db == db) rec_drop(i, false);
+    if (!db || E.scratch.key.db == db) E.scratch.complete = false;
+    if (!db || E.alt.key.db == db) E.alt.complete = false;
+}
+
 // one scan of the subjects [s0, s1): fills E.seeds / cnt[0] seeds, cnt[1] raw hits;
 // dispatches to the direct-probe kernel (small tables) or the partitioned pair
-// the rare kernel of a scan, left for another stream to run (search_range): its parameter block and launch shape
-struct DeferredRare { bool valid = false; GbnBinParams B; int grid2 = 0; };
 static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
-                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed, DeferredRare *defer = nullptr);
+                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed);
 
 // The partitioned scan sizes its streams for lookup words spread evenly over the bins (x1.25, x2.5).
 // Subjects dominated by one repeat (satellite arrays, poly-A) put most positions of a range into a
@@ -888,10 +944,10 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
 static const int kSkewedRange = -1000;       // internal: split this subject range and try again
 
 static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
-                    unsigned long long cnt[2], int64_t *bases_out, DeferredRare *defer = nullptr)
+                    unsigned long long cnt[2], int64_t *bases_out)
 {
     bool skewed = false;
-    int rc = run_scan_impl(b, db, s0, s1, diag, cnt, bases_out, false, &skewed, defer);
+    int rc = run_scan_impl(b, db, s0, s1, diag, cnt, bases_out, false, &skewed);
     if (rc != GBN_OK || !skewed) return rc;
     int64_t bases = 0;
     for (int32_t s = s0; s < s1; s++) bases += db.len[s];
@@ -902,15 +958,15 @@ static int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnosti
 }
 
 static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
-                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed, DeferredRare *defer)
+                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed)
 {
     // tables as wide as the word (stride 1, every lookup hit a seed): the presence bits are sliced through the LDS
     // instead of the scan positions being written out by key range (scan_slice_kernel); GBN_SCAN_SLICE=0: off
     const bool sliced = !direct && scan_slices(b) > 0;
     E.seg_valid = false;
     const int nb = (direct || sliced) ? 1 : choose_bins(b);
-    if (nb == 1) defer = nullptr;                           // the direct-probe kernel has no rare kernel
-    if (defer) defer->valid = false;
+    if (nb == 1 && E.ahead.valid) { E.ahead.valid = false; E.ahead_misses++; }       // (a scan of another kind: nobody will want the records binned ahead)
+    if (nb == 1) E.last_key_valid = false;
     const TileSet *tsp = nullptr;
     int rc = get_tiles(db, b.lut.lut, b.lut.step, nb > 1 ? GBN_BIN_TILE_POS : GBN_TILE_POS, s0, s1, &tsp);
     if (rc) return rc;
@@ -926,8 +982,12 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) npos += (db.len[s] - b.lut.lut) / b.lut.step + 1;
     double slack = 1.25;
     size_t rare_seg_hint = 0, rare_seg_used = 0, slice_seg_cap = 0; int slice_blocks = 0; bool slice_ordered = false;
-    const bool reuse_binning = gbn::switch_value("GBN_REUSE_BINNING", 0) != 0;
     GbnBinParams last_B; std::memset(&last_B, 0, sizeof(last_B)); int last_grid2 = 0;
+    const long long rec_limit = nb > 1 ? rec_limit_bytes() : 0;        // bytes the record cache may hold; 0: off
+    if (rec_limit == 0 && !E.rec_sets.empty()) rec_purge(nullptr);     // (switched off: what it held goes)
+    RecordSet *rs = nullptr;                    // the records of this pass
+    bool binned_here = false;                   // ... were written (completely) by this call
+    bool repeat_seen = false;                   // cache off: the pass before this one had the same key
     if (E.seed_copy_pending) { HIPCHK(hipStreamWaitEvent(E.stream, E.ev_seed, 0)); E.seed_copy_pending = false; }
     for (;;) {
         bool binned_ahead = false; int hit_pair = -1;
@@ -974,38 +1034,57 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             subcap = (subcap + 511) & ~(size_t)511;       // whole record blocks, whole probe pieces
             if (subcap > 0x7ffffff0u) { set_error("bin capacity overflow: split the range"); return GBN_ERR_NOMEM; }
             const int rfl_now = std::min(4, b.dev->fl), rfrbits_now = std::min(7, 2 * b.dev->fr);
-            Engine::BinAhead &AH = E.ahead;
-            const bool ahead_hit = AH.valid && !defer && AH.db == (const void *)&db && AH.s0 == s0 && AH.s1 == s1 && AH.lut == b.lut.lut && AH.step == b.lut.step &&
-                                   AH.nb == nb && AH.nwriters == nwriters && AH.subcap == subcap && AH.rfl == rfl_now && AH.rfrbits == rfrbits_now &&
-                                   AH.cbits == GBN_BIN_CBITS(b.lut.lut) && AH.tiles == (const void *)P.tiles;
-            if (AH.valid) {
-                AH.valid = false;
-                if (ahead_hit) { E.swap_scan_sets(); E.binkey.valid = false; E.ahead_hits++; hit_pair = AH.pair; }     // the records of this pass are in the other set: that one is the current set now
-            }
-            size_t need = subcap * nstream;
-            const size_t need_u64 = (GBN_REC_WORDS(need) + 1) / 2;
-            if (need_u64 > E.bin_rec_cap) {
-                dev_free(E.bin_rec); E.bin_rec_cap = 0; E.binkey.valid = false;
-                if ((rc = dev_alloc(E.bin_rec, need_u64))) return rc;
-                E.bin_rec_cap = need_u64;
-            }
+            RecKey key; key.db = (const void *)&db; key.s0 = s0; key.s1 = s1; key.lut = b.lut.lut; key.step = b.lut.step; key.nb = nb; key.nwriters = nwriters;
+            key.rfl = rfl_now; key.rfrbits = rfrbits_now; key.cbits = GBN_BIN_CBITS(b.lut.lut); key.tiles = (const void *)P.tiles; key.subcap = subcap;
             const size_t nseq = ((size_t)((ts.ntiles + nwriters - 1) / nwriters) + ((size_t)1 << GBN_TCUR_SHIFT) - 1) >> GBN_TCUR_SHIFT;    // cursor entries per stream
-            if (nstream * nseq > E.bin_tcur_cap) {
-                dev_free(E.bin_tcur); E.bin_tcur_cap = 0; E.binkey.valid = false;
-                if ((rc = dev_alloc(E.bin_tcur, nstream * nseq))) return rc;
-                E.bin_tcur_cap = nstream * nseq;
+            bool hit = false, ahead_hit = false;
+            Engine::BinAhead &AH = E.ahead;
+            if (rec_limit > 0) {
+                // ---- record cache: a complete set of this shape whose streams are at least as long as this attempt asks for
+                if (AH.valid) { AH.valid = false; E.ahead_misses++; }
+                rs = nullptr;
+                for (RecordSet *c : E.rec_sets) if (c->complete && c->key.same_shape(key) && c->key.subcap >= subcap) { rs = c; break; }
+                if (rs) { hit = true; subcap = rs->key.subcap; key.subcap = subcap; if (!binned_here) E.rec_hits++; }
+                else {
+                    E.rec_misses++;
+                    for (size_t i = E.rec_sets.size(); i-- > 0; ) if (E.rec_sets[i]->key.same_shape(key)) rec_drop(i, false);     // (incomplete, or shorter streams: replaced)
+                    const size_t need_bytes = (GBN_REC_WORDS(subcap * nstream) + 1) / 2 * 8 + nstream * nseq * 4 + (nstream + 4) * 4;
+                    if ((long long)need_bytes <= rec_limit) {
+                        rec_make_room(need_bytes, rec_limit, nullptr);
+                        rs = new RecordSet(); E.rec_sets.push_back(rs);
+                    } else { rs = &E.scratch; E.rec_bypass++; }      // larger than the whole cache: this pass's own
+                }
+            } else {
+                rs = &E.scratch;
+                ahead_hit = AH.valid && AH.key == key;
+                if (AH.valid) {
+                    AH.valid = false;
+                    if (ahead_hit) { E.swap_scan_sets(); E.ahead_hits++; hit_pair = AH.pair; }     // the records of this pass are in the other set: that one is the current set now
+                    else E.ahead_misses++;
+                }
+                // (a rare-path segment overflowed and the range is scanned again: the records this call wrote are still there)
+                hit = !ahead_hit && binned_here && rs->complete && rs->key == key;
+                repeat_seen = E.last_key_valid && E.last_key == key;
+                E.last_key = key; E.last_key_valid = true;
             }
-            if (nstream + 4 > E.bin_count_cap) {
-                dev_free(E.bin_count); E.bin_count_cap = 0;
-                if ((rc = dev_alloc(E.bin_count, nstream + 4))) return rc;
-                E.bin_count_cap = nstream + 4;
+            const size_t need = subcap * nstream;
+            const size_t need_u64 = (GBN_REC_WORDS(need) + 1) / 2;
+            if (!hit && !ahead_hit) {
+                rc = recset_size(*rs, need_u64, nstream * nseq, nstream + 4);
+                if (rc == GBN_ERR_NOMEM && rec_limit > 0 && rs != &E.scratch) {      // the device is full: everything else the cache holds goes, once
+                    rec_make_room((size_t)rec_limit, rec_limit, rs);
+                    rc = recset_size(*rs, need_u64, nstream * nseq, nstream + 4);
+                }
+                if (rc) { if (rs != &E.scratch) { for (size_t i = 0; i < E.rec_sets.size(); i++) if (E.rec_sets[i] == rs) { rec_drop(i, false); break; } } return rc; }
+                rs->key = key; rs->complete = false;
+                HIPCHK(hipMemsetAsync(rs->bin_count + nstream, 0, 16, E.stream));     // (records that exist already: the flag of THAT launch is read back below)
             }
-            if (!ahead_hit) HIPCHK(hipMemsetAsync(E.bin_count + nstream, 0, 16, E.stream));     // (binned ahead: the flag of THAT launch is read back below)
+            rs->stamp = ++E.rec_clock;
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
             B.S = P; B.nb = nb; B.cbits = GBN_BIN_CBITS(b.lut.lut); B.nwriters = nwriters; dbg_nwriters = nwriters; dbg_subcap = (uint32_t)subcap;
             B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfrbits = std::min(7, 2 * b.dev->fr);
-            B.rec = reinterpret_cast<uint32_t *>(E.bin_rec); B.tcur = E.bin_tcur; B.nseq = (uint32_t)nseq; B.gcount = E.bin_count; B.subcap = (uint32_t)subcap;
-            B.overflow = E.bin_count + nstream;
+            B.rec = reinterpret_cast<uint32_t *>(rs->bin_rec); B.tcur = rs->bin_tcur; B.nseq = (uint32_t)nseq; B.gcount = rs->bin_count; B.subcap = (uint32_t)subcap;
+            B.overflow = rs->bin_count + nstream;
             B.dbg = (int)gbn::switch_value("GBN_DBG", 0);
             int grid2 = std::max(8, E.num_cu & ~7);   // one 1024-thread workgroup per CU; group = blockIdx & 7
             {   // rare-path queue: one segment per probe workgroup (~1.2 % of scan positions in total)
@@ -1025,38 +1104,24 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 if (!E.rare_counts && (rc = dev_alloc(E.rare_counts, (size_t)2048))) return rc;
                 B.rareq = E.rareq; B.rare_seg = (uint32_t)std::min<size_t>(seg, 0x7fffffff); B.rare_counts = E.rare_counts;
             }
-            // The scan records depend on the shard and on (lut width, stride) only, not on the queries.
-            // GBN_REUSE_BINNING=1 (off by default; bench.py never sets it for the headline number) keeps
-            // them for the next query batch with the same table shape: a database-side index held in HBM.
-            BinKey &have = E.binkey;
-            const BinKey want_key = {(const void *)&db, s0, s1, b.lut.lut, b.lut.step, nb, nwriters, subcap, true};
-            const bool reuse = gbn::switch_value("GBN_REUSE_BINNING", 0) != 0;
-            const bool hit = reuse && have.valid && have.db == want_key.db && have.s0 == s0 && have.s1 == s1 && have.lut == want_key.lut &&
-                             have.step == want_key.step && have.nb == nb && have.nwriters == nwriters && have.subcap == subcap;
-            have.valid = false;
             last_B = B; last_grid2 = grid2;
-            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, ((hit || ahead_hit) ? 2 : 3) | (defer ? 0 : 4) | (ahead_hit ? 8 : 0), b.dev->ready));
-            have = want_key;                                    // invalidated below if this launch overflowed
+            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, ((hit || ahead_hit) ? 2 : 3) | 4 | (ahead_hit ? 8 : 0), b.dev->ready));
             binned = true; binned_ahead = ahead_hit;
-            if (defer) { defer->B = B; defer->grid2 = grid2; }
             HIPCHK(hipMemcpyAsync(&E.scan_back->overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
             HIPCHK(hipMemcpyAsync(E.scan_back->rare_counts, E.rare_counts, (size_t)grid2 * 4, hipMemcpyDeviceToHost, E.stream));
         }
         HIPCHK(hipMemcpyAsync(E.scan_back->cnt, E.counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, E.stream));     // seeds, raw hits, the fullest segment
         if (!E.ev_back) HIPCHK(hipEventCreate(&E.ev_back));
         HIPCHK(hipEventRecord(E.ev_back, E.stream));
-        if (binned && E.want_ahead && !defer && !reuse_binning && slack <= 1.25) {
+        if (binned && rec_limit == 0 && E.want_ahead && repeat_seen && slack <= 1.25) {
             // the next pass's binning kernel, into the other set (sized like this one)
-            Engine::ScanSet &A = E.alt;
-            const size_t nstream = (size_t)last_B.nb * (size_t)last_B.nwriters, need_u64 = E.bin_rec_cap, need_tcur = nstream * last_B.nseq;
-            int arc = GBN_OK;
-            if (A.bin_rec_cap < need_u64) { dev_free(A.bin_rec); A.bin_rec_cap = 0; if (!(arc = dev_alloc(A.bin_rec, need_u64))) A.bin_rec_cap = need_u64; }
-            if (!arc && A.bin_tcur_cap < need_tcur) { dev_free(A.bin_tcur); A.bin_tcur_cap = 0; if (!(arc = dev_alloc(A.bin_tcur, need_tcur))) A.bin_tcur_cap = need_tcur; }
-            if (!arc && A.bin_count_cap < nstream + 4) { dev_free(A.bin_count); A.bin_count_cap = 0; if (!(arc = dev_alloc(A.bin_count, nstream + 4))) A.bin_count_cap = nstream + 4; }
-            if (!arc) {                                     // (no room for a second set: no binning ahead)
+            RecordSet &A = E.alt;
+            const size_t nstream = (size_t)last_B.nb * (size_t)last_B.nwriters;
+            if (recset_size(A, rs->bin_rec_cap, nstream * last_B.nseq, nstream + 4) == GBN_OK) {        // (no room for a second set: no binning ahead)
                 GbnBinParams A2 = last_B;
                 A2.rec = reinterpret_cast<uint32_t *>(A.bin_rec); A2.tcur = A.bin_tcur; A2.gcount = A.bin_count; A2.overflow = A.bin_count + nstream;
-                A2.rareq = nullptr; A2.rare_counts = nullptr;
+                A2.rareq = nullptr;                         // (the binning kernel queues nothing; rare_counts: where a GBN_BIN_TIMING build leaves its clocks)
+                A.key = rs->key; A.complete = false;
                 Engine::BinAhead &AH = E.ahead;
                 if (!AH.ev[0][0]) for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&AH.ev[i >> 1][i & 1]));
                 AH.pair = hit_pair >= 0 ? (hit_pair ^ 1) : (AH.pair ^ 1);
@@ -1065,8 +1130,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 HIPCHK(hipEventRecord(AH.ev[AH.pair][0], E.stream));
                 HIPCHK(launch_scan_bin_parts(A2, last_grid2, E.stream, nullptr, 1, nullptr));
                 HIPCHK(hipEventRecord(AH.ev[AH.pair][1], E.stream));
-                AH.valid = true; AH.db = (const void *)&db; AH.s0 = s0; AH.s1 = s1; AH.lut = b.lut.lut; AH.step = b.lut.step; AH.nb = last_B.nb; AH.nwriters = last_B.nwriters;
-                AH.subcap = last_B.subcap; AH.rfl = last_B.rfl; AH.rfrbits = last_B.rfrbits; AH.cbits = last_B.cbits; AH.tiles = (const void *)last_B.S.tiles;
+                AH.valid = true; AH.key = rs->key;
             }
         }
         trace_mark("scan: kernels queued");
@@ -1074,7 +1138,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         trace_mark("scan: kernels done");
         cnt[0] = E.scan_back->cnt[0]; cnt[1] = E.scan_back->cnt[1];
         const unsigned long long seg_max = sliced ? E.scan_back->seg_max : 0;
-        if (binned) overflow = E.scan_back->overflow;
+        if (binned) { overflow = E.scan_back->overflow; rs->complete = overflow == 0; binned_here = rs->complete; }
         finish_build(b.dev);                                // (the scan has waited for the builder's event)
         if (diag) {
             float ms = 0, ahead_ms = 0;
@@ -1108,7 +1172,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 {   // stream fill statistics
                     const size_t ns = (size_t)nb * (size_t)dbg_nwriters;
                     std::vector<uint32_t> gc(ns);
-                    HIPCHK(hipMemcpy(gc.data(), E.bin_count, ns * 4, hipMemcpyDeviceToHost));
+                    HIPCHK(hipMemcpy(gc.data(), rs->bin_count, ns * 4, hipMemcpyDeviceToHost));
                     uint32_t mn = ~0u, mx2 = 0; unsigned long long sum = 0;
                     for (uint32_t v : gc) { mn = std::min(mn, v); mx2 = std::max(mx2, v); sum += v; }
                     fprintf(stderr, "[gbn dbg] %zu streams: records min %u max %u total %llu (capacity %u each)\n", ns, mn, mx2, sum, dbg_subcap);
@@ -1143,7 +1207,6 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             if (slack > 3.0) { *skewed = true; return GBN_OK; }
             continue;
         }
-        if (defer) { defer->valid = true; break; }          // (the seeds do not exist yet: whoever runs the rare kernel sizes their buffer)
         if (sliced) {       // the seeds sit in the workgroups' segments; E.seeds only has to be long enough for compact_seeds
             if (cnt[0] > E.seed_cap && (rc = grow_seed_buffers((size_t)cnt[0] + (cnt[0] >> 3)))) return rc;
             E.seg_valid = cnt[0] > 0; E.seg_n = slice_blocks; E.seg_len = (uint32_t)slice_seg_cap; E.seg_ordered = slice_ordered;
@@ -1330,16 +1393,7 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_stage = now();
     trace_mark("range: scan starts");
-    // Megablast shapes (lookup words shorter than the word size: a handful of seeds per million lookup hits) with the
-    // next batch already waiting: the rare kernel -- random sectors, latency bound -- is left to the asynchronous
-    // stage, where it runs on stream2 next to the HBM-bound binning kernel of the next pass.  Opt-in (GBN_DEFER_RARE=1):
-    // measured +1.2 .. 3.4 % Gbp/s on C2, while the binning kernel, sharing the chip, runs 8.0 -> 9.05 ms -- the GPU is
-    // busy either way, and the default keeps the dominant kernel's launch duration what the kernel itself takes.
-    const bool defer_on = gbn::switch_value("GBN_DEFER_RARE", 0) != 0;
-    const bool reuse_on = gbn::switch_value("GBN_REUSE_BINNING", 0) != 0;
-    DeferredRare defer;
-    const bool want_defer = defer_on && !reuse_on && overlap && !keep_stages && b.lut.lut != b.lut.word;
-    int rc = run_scan(b, db, s0, s1, diag, cnt, &bases, want_defer ? &defer : nullptr);
+    int rc = run_scan(b, db, s0, s1, diag, cnt, &bases);
     trace_mark("scan done");
     if (rc == kSkewedRange) {
         // lookup words of this range pile up in a few bins: halve it (by packed size) until the repeat-rich
@@ -1356,59 +1410,6 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
     if (rc) return rc;
     if (diag) diag->scan_stage_ms += ms_since(t_stage);
     t_stage = now();
-    if (defer.valid) {
-        if (diag) diag->subject_bases_scanned += bases;
-        if ((rc = wait_pending_gpu())) return rc;           // one asynchronous stage in flight at most; its buffer set is free again
-        if (E.seeds_async_cap < ((size_t)1 << 22)) {
-            dev_free(E.seeds_async); E.seeds_async_cap = 0;
-            if ((rc = dev_alloc(E.seeds_async, (size_t)1 << 22))) return rc;
-            E.seeds_async_cap = (size_t)1 << 22;
-        }
-        if (!E.ev_r0) { HIPCHK(hipEventCreate(&E.ev_r0)); HIPCHK(hipEventCreate(&E.ev_r1)); }
-        E.swap_scan_sets();                                 // the next scan fills the other set
-        E.slot ^= 1;
-        E.pending_err.clear();
-        const int dev = E.device, ksi = 0;                  // (no stage is in flight: either key set)
-        const unsigned long long raw_probe = cnt[1];
-        GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
-        Engine *eng = tl_eng;
-        E.pending = std::async(std::launch::async, [=]() -> int {
-            tl_eng = eng;
-            auto fail = [](int code, const char *what) { E.pending_err = what; return code; };
-            if (hipSetDevice(dev) != hipSuccess) return fail(GBN_ERR_HIP, "hipSetDevice failed in the extension thread");
-            GbnBinParams B = defer.B;
-            unsigned long long c2[2] = {0, 0};
-            for (;;) {
-                if (hipMemsetAsync(E.counters + 6, 0, 2 * sizeof(unsigned long long), E.stream2) != hipSuccess) return fail(GBN_ERR_HIP, "memset failed");
-                B.S.seeds = E.seeds_async; B.S.seed_count = E.counters + 6; B.S.seed_cap = E.seeds_async_cap; B.S.raw_hits = E.counters + 7;
-                (void)hipEventRecord(E.ev_r0, E.stream2);
-                if (launch_scan_bin_parts(B, defer.grid2, E.stream2, nullptr, 4, nullptr) != hipSuccess) return fail(GBN_ERR_HIP, "rare kernel launch failed");
-                (void)hipEventRecord(E.ev_r1, E.stream2);
-                if (hipMemcpyAsync(c2, E.counters + 6, sizeof(c2), hipMemcpyDeviceToHost, E.stream2) != hipSuccess ||
-                    hipStreamSynchronize(E.stream2) != hipSuccess) return fail(GBN_ERR_HIP, "rare kernel failed");
-                if (c2[0] <= E.seeds_async_cap) break;
-                dev_free(E.seeds_async); E.seeds_async_cap = 0;     // more seeds than room: once more with room
-                const size_t want = (size_t)c2[0] + (size_t)(c2[0] >> 3);
-                if (dev_alloc(E.seeds_async, want)) return fail(GBN_ERR_NOMEM, "out of device memory (seeds)");
-                E.seeds_async_cap = want;
-            }
-            if (diag) {
-                float ms = 0; (void)hipEventElapsedTime(&ms, E.ev_r0, E.ev_r1);
-                diag->rare_kernel_ms += ms; diag->scan_kernel_ms += ms;
-                diag->lookup_hits += (int64_t)(raw_probe + c2[1]); diag->seeds += (int64_t)c2[0];
-            }
-            const int64_t n2 = (int64_t)c2[0];
-            if (n2 == 0) return GBN_OK;
-            if (n2 > INT32_MAX) return fail(GBN_ERR_NOMEM, "too many seeds in one range");
-            unsigned long long nih2 = 0;
-            int r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n2, E.counters + 4, E.stream2, &nih2, s0, s1, ksi);
-            if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2, true);
-            if (r) E.pending_err = gbn_last_error();      // the error text is per thread
-            return r;
-        });
-        E.has_pending = true; E.pending_res = rp; E.pending_ks = ksi; E.pending_batch = bp;
-        return GBN_OK;
-    }
     if (diag) { diag->lookup_hits += (int64_t)cnt[1]; diag->seeds += (int64_t)cnt[0]; diag->subject_bases_scanned += bases; }
     const int64_t n = (int64_t)cnt[0];
     if (n == 0) return GBN_OK;
@@ -1426,10 +1427,12 @@ static int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
             if ((rc = dev_alloc(E.seeds_async, std::max<size_t>((size_t)n + (size_t)n / 4, 1 << 16)))) return rc;
             E.seeds_async_cap = std::max<size_t>((size_t)n + (size_t)n / 4, 1 << 16);
         }
-        if ((rc = compact_seeds(E.stream))) return rc;
         // (a binning kernel queued ahead sits on the engine's stream: the copy goes to the stage's own stream -- the host has
-        // seen the scan finish -- and the next scan's kernels wait for it before they write seeds again: run_scan_impl)
-        hipStream_t copy_st = E.ahead.valid ? E.stream2 : E.stream;
+        // seen the scan finish -- and the next scan's kernels wait for it before they write seeds again: run_scan_impl.  Seeds
+        // that had to be put back to back first (a slice scan's segments) are copied behind that kernel, on its stream.)
+        const bool compacting = E.seg_valid;
+        if ((rc = compact_seeds(E.stream))) return rc;
+        hipStream_t copy_st = (E.ahead.valid && !compacting) ? E.stream2 : E.stream;
         HIPCHK(hipMemcpyAsync(E.seeds_async, E.seeds, (size_t)n * sizeof(GbnDevSeed), hipMemcpyDeviceToDevice, copy_st));
         HIPCHK(hipEventRecord(E.ev_seed, copy_st));
         E.seed_copy_pending = copy_st == E.stream2;
@@ -1864,6 +1867,105 @@ int gbn_block_cache_insert(const char *db_name, const int32_t *oids, int32_t n, 
 }
 long long gbn_debug_db_bytes_uploaded(void) { return g_db_bytes_uploaded.load(); }
 long long gbn_debug_bin_ahead_hits(void) { return tl_eng ? E.ahead_hits : 0; }
+long long gbn_debug_bin_ahead_misses(void) { return tl_eng ? E.ahead_misses : 0; }
+
+// ---- the record cache of the calling thread's device (Engine::rec_sets) ----
+int gbn_record_cache_set_limit(long long bytes) {
+    return gbn::guard(__func__, [&]() -> int {
+    const int rc = enter_current();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(E.mu);
+    E.rec_limit = bytes < 0 ? -1 : bytes;
+    const long long limit = rec_limit_bytes();
+    if (limit == 0) rec_purge(nullptr);
+    else rec_make_room(0, limit, nullptr);
+    return GBN_OK;
+    });
+}
+int gbn_record_cache_stats(long long *out, int n) {
+    return gbn::guard(__func__, [&]() -> int {
+    if (!out || n < 0) return GBN_ERR_ARG;
+    const int rc = enter_current();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(E.mu);
+    const long long v[8] = {rec_limit_bytes(), (long long)rec_held_bytes(), (long long)E.rec_sets.size(), E.rec_hits, E.rec_misses, E.rec_evictions, E.rec_bypass, E.ahead_hits};
+    for (int i = 0; i < n && i < 8; i++) out[i] = v[i];
+    return GBN_OK;
+    });
+}
+
+// ---- views: several resident blocks searched as one shard ----
+static std::map<std::vector<const GbnDb *>, GbnDb *> g_view_cache;      // (under g_cache_mu) keyed by the blocks, ascending first OID
+static void free_view(GbnDb *v);
+int gbn_block_view(GbnDb *const *blocks, int32_t n, GbnDb **out) {
+    return gbn::guard(__func__, [&]() -> int {
+    if (!blocks || n <= 0 || !out) { set_error("gbn_block_view: bad argument"); return GBN_ERR_ARG; }
+    *out = nullptr;
+    std::vector<const GbnDb *> parts(blocks, blocks + n);
+    for (const GbnDb *p : parts) {
+        if (!p || !p->engine || p->engine != parts[0]->engine) { set_error("gbn_block_view: the blocks live on different devices"); return GBN_ERR_ARG; }
+        if (!p->real_of.empty() || !p->view_parts.empty()) { set_error("gbn_block_view: a block with chunked sequences, or a view"); return GBN_ERR_UNSUPPORTED; }
+    }
+    std::stable_sort(parts.begin(), parts.end(), [](const GbnDb *a, const GbnDb *b) {
+        return (a->num_seqs ? a->oid_of(0) : a->first_oid) < (b->num_seqs ? b->oid_of(0) : b->first_oid); });
+    for (size_t i = 1; i < parts.size(); i++) if (parts[i] == parts[i - 1]) { set_error("gbn_block_view: a block twice"); return GBN_ERR_ARG; }
+    if (n == 1) { *out = const_cast<GbnDb *>(parts[0]); return GBN_OK; }
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_view_cache.find(parts);
+        if (it != g_view_cache.end()) { *out = it->second; return GBN_OK; }
+    }
+    // every subject is addressed from the lowest slab: tiles carry 32-bit offsets in units of 16 bytes (GbnTile::off16)
+    const uint8_t *base = parts[0]->d_packed; const uint8_t *top = base;
+    for (const GbnDb *p : parts) { base = std::min(base, p->d_packed); top = std::max(top, p->d_packed + p->nbytes); }
+    if ((((uintptr_t)base) & 15) || (uint64_t)(top - base) >= ((uint64_t)1 << 36)) {
+        set_error("gbn_block_view: the blocks' slabs lie too far apart for one view (search them one by one)"); return GBN_ERR_UNSUPPORTED; }
+    Engine *eng = static_cast<Engine *>(parts[0]->engine);
+    enter(eng);
+    GbnDb *v = new GbnDb();
+    v->engine = eng; v->d_packed = base; v->owns = false; v->nbytes = (int64_t)(top - base); v->view_parts = parts;
+    v->chunk_len = parts[0]->chunk_len;
+    bool any_amb = false; int32_t last_oid = -1; bool ascending = true;
+    for (const GbnDb *p : parts) any_amb = any_amb || !p->amb.empty();
+    for (const GbnDb *p : parts) {
+        const int64_t delta = (int64_t)(p->d_packed - base);
+        if (delta & 15) { delete v; set_error("gbn_block_view: a slab that is not 16-byte aligned"); return GBN_ERR_ARG; }
+        for (int32_t s = 0; s < p->num_seqs; s++) {
+            v->byte_off.push_back(delta + p->byte_off[(size_t)s]); v->len.push_back(p->len[(size_t)s]);
+            const int32_t oid = p->oid_of(s);
+            ascending = ascending && oid > last_oid; last_oid = oid;
+            v->oid_map.push_back(oid);
+            if (any_amb) v->amb.push_back(p->amb.empty() ? std::vector<GbnDb::AmbRun>() : p->amb[(size_t)s]);
+        }
+        v->total_bases += p->total_bases;
+    }
+    if (!ascending) { delete v; set_error("gbn_block_view: the blocks' OIDs overlap"); return GBN_ERR_ARG; }
+    v->num_seqs = v->real_seqs = (int32_t)v->len.size(); v->first_oid = v->oid_map.empty() ? 0 : v->oid_map[0];
+    int rc;
+    if ((rc = dev_upload(v->d_byte_off, v->byte_off.data(), v->byte_off.size())) || (rc = dev_upload(v->d_len, v->len.data(), v->len.size()))) { free_view(v); return rc; }
+    GbnDb *loser = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        auto it = g_view_cache.find(parts);
+        if (it == g_view_cache.end()) { g_view_cache.emplace(parts, v); *out = v; }
+        else { *out = it->second; loser = v; }          // (two threads built it at the same time: the first stays)
+    }
+    if (loser) free_view(loser);
+    return GBN_OK;
+    });
+}
+// the views over `block` (nullptr: all of them) leave the cache and are freed; the calling thread holds no lock
+static void drop_views_of(const GbnDb *block) {
+    std::vector<GbnDb *> drop;
+    {
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto it = g_view_cache.begin(); it != g_view_cache.end(); ) {
+            const bool has = !block || std::find(it->first.begin(), it->first.end(), block) != it->first.end();
+            if (has) { drop.push_back(it->second); it = g_view_cache.erase(it); } else ++it;
+        }
+    }
+    for (GbnDb *v : drop) free_view(v);
+}
 
 // tests: seed_order.hip on segments given in host memory.  The keys of the seeds ordered by (subject, slot), scan order
 // inside, as the engine's seed stage builds them for the composite-key form (q_bits from qlen, s_bits from max_len;
@@ -1898,6 +2000,7 @@ int gbn_debug_seed_order(const GbnDevSeed *seg, const uint32_t *seg_count, int n
     });
 }
 void gbn_release_db_memory(void) {
+    drop_views_of(nullptr);
     std::map<const void *, GbnDb *> drop;
     std::map<BlockKey, GbnDb *> drop_blocks;
     { std::lock_guard<std::mutex> lk(g_cache_mu); drop.swap(g_db_cache); drop_blocks.swap(g_block_cache); }
@@ -1911,7 +2014,7 @@ static void release_engine() {              // (the calling thread has entered i
     (void)wait_pending();
     (void)hipDeviceSynchronize();                       // nothing of ours is queued or running when buffers, streams and events go
     (void)pool_check_guards();
-    E.binkey.valid = false;
+    rec_purge(nullptr); recset_free(E.scratch); recset_free(E.alt); E.last_key_valid = false;
     dev_free(E.slice_seg); E.slice_seg_cap = 0; dev_free(E.seg_counts); dev_free(E.seg_firsts);
     if (E.scan_back) { (void)hipHostFree(E.scan_back); E.scan_back = nullptr; }
     E.ahead.valid = false;
@@ -1922,11 +2025,8 @@ static void release_engine() {              // (the calling thread has entered i
     dev_free(E.seeds);
     for (auto &KS : E.ks) { dev_free(KS.key_a); dev_free(KS.key_b); dev_free(KS.idx_a); dev_free(KS.idx_b); dev_free(KS.cell_diag); dev_free(KS.cell_level); dev_free(KS.ext_rec); dev_free(KS.sort_tmp); KS.key_cap = 0; KS.sort_tmp_bytes = 0; }
     for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
-    dev_free(E.counters); dev_free(E.bin_rec); dev_free(E.bin_tcur); E.bin_tcur_cap = 0; dev_free(E.bin_count); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
-    dev_free(E.alt.bin_rec); dev_free(E.alt.bin_tcur); dev_free(E.alt.bin_count); dev_free(E.alt.rareq); dev_free(E.alt.rare_counts); E.alt = Engine::ScanSet();
-    if (E.ev_r0) { (void)hipEventDestroy(E.ev_r0); (void)hipEventDestroy(E.ev_r1); E.ev_r0 = E.ev_r1 = nullptr; }
+    dev_free(E.counters); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
     for (int i = 0; i < 2; i++) { E.ks[i].kt.destroy(); E.kt_gap[i].destroy(); }
-    E.bin_rec_cap = 0; E.bin_count_cap = 0;
     E.seed_cap = 0;
     if (E.gather_stage) (void)hipHostFree(E.gather_stage);
     E.gather_stage = nullptr; E.gather_stage_cap = 0;
@@ -2099,16 +2199,26 @@ int gbn_db_set_ambiguities(GbnDb *db, int32_t local, int32_t n, const int32_t *s
     });
 }
 
+static void free_db_now(GbnDb *db);
+static void free_view(GbnDb *v) { free_db_now(v); }
 void gbn_db_free(GbnDb *db) {
     if (!db) return;
+    if (!db->view_parts.empty()) {                      // a view: out of the view cache
+        std::lock_guard<std::mutex> lk(g_cache_mu);
+        for (auto it = g_view_cache.begin(); it != g_view_cache.end(); ) { if (it->second == db) it = g_view_cache.erase(it); else ++it; }
+    } else drop_views_of(db);                           // a block: the views that reach into it go first
+    free_db_now(db);
+}
+static void free_db_now(GbnDb *db) {
     if (!db->engine) { delete db; return; }
     enter(static_cast<Engine *>(db->engine));
     {   // a stage in flight may still read this shard
         std::lock_guard<std::mutex> lk(E.mu);
         if (E.has_pending) (void)wait_pending();
         wait_host();
-        if (E.binkey.db == (const void *)db) E.binkey.valid = false;
-        if (E.ahead.valid && E.ahead.db == (const void *)db) { (void)hipStreamSynchronize(E.stream); E.ahead.valid = false; }    // (a binning kernel queued ahead reads the shard)
+        if (E.ahead.valid && E.ahead.key.db == (const void *)db) { (void)hipStreamSynchronize(E.stream); E.ahead.valid = false; }    // (a binning kernel queued ahead reads the shard)
+        rec_purge((const void *)db);                        // the scan records of this shard go with it
+        if (E.last_key.db == (const void *)db) E.last_key_valid = false;
     }
     free_tile_cache(*db);
     if (db->owns && db->d_packed) (void)hipFree((void *)db->d_packed);
@@ -2394,18 +2504,33 @@ int gbn_prelim_search_lists(GbnBatch *batch, GbnDb *db, GbnHspListFn sink, void 
     int rc = gbn_results_new(&res);
     if (rc) return rc;
     rc = gbn_prelim_search(batch, db, res, diag, 0, interrupt, progress);
-    if (rc == GBN_OK) {
-        const GbnHSP *h = res->hsps.data();
-        const int64_t n = (int64_t)res->hsps.size();
-        for (int64_t i = 0; i < n && rc == GBN_OK; ) {
-            int64_t j = i;
-            while (j < n && h[j].oid == h[i].oid) j++;
-            if (sink(sink_arg, h[i].oid, h + i, (int32_t)(j - i))) { set_error("gbn_prelim_search_lists: the sink failed"); rc = GBN_ERR_ARG; }
-            i = j;
-        }
-    }
+    if (rc == GBN_OK) rc = gbn_results_emit_lists(res, sink, sink_arg);
     gbn_results_free(res);
     return rc;
+    });
+}
+// bench / tests: a sink that counts -- arg = long long[2]: lists, HSPs (what a caller's BlastHSPStreamWrite would be handed)
+int gbn_debug_counting_sink(void *arg, int32_t oid, const GbnHSP *hsps, int32_t n) {
+    return gbn::guard(__func__, [&]() -> int {
+    (void)oid; (void)hsps;
+    if (arg) { long long *c = static_cast<long long *>(arg); c[0] += 1; c[1] += n; }
+    return 0;
+    });
+}
+// the HSPs of finished results (gbn_prelim_search, or gbn_prelim_search_begin + _end) as one call per subject that
+// has any, ascending OID: what a pipelined caller hands to BlastHSPStreamWrite while its next search is running
+int gbn_results_emit_lists(const GbnResults *res, GbnHspListFn sink, void *sink_arg) {
+    return gbn::guard(__func__, [&]() -> int {
+    if (!res || !sink) { set_error("gbn_results_emit_lists: bad argument"); return GBN_ERR_ARG; }
+    const GbnHSP *h = res->hsps.data();
+    const int64_t n = (int64_t)res->hsps.size();
+    for (int64_t i = 0; i < n; ) {
+        int64_t j = i;
+        while (j < n && h[j].oid == h[i].oid) j++;
+        if (sink(sink_arg, h[i].oid, h + i, (int32_t)(j - i))) { set_error("gbn_results_emit_lists: the sink failed"); return GBN_ERR_ARG; }
+        i = j;
+    }
+    return GBN_OK;
     });
 }
 

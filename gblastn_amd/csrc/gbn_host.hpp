@@ -104,6 +104,10 @@ struct GbnDb {
         return lo < oid_map.size() && oid_map[lo] == oid ? (int32_t)lo : -1;
     }
     int32_t chunk_of(int32_t v) const { return real_of.empty() ? 0 : chunk_ord[(size_t)v]; }
+    // A VIEW (gbn_block_view): the subjects of several resident blocks as one shard.  It owns no subject bytes --
+    // d_packed is the lowest slab address of its blocks and byte_off reaches into every one of them -- only its own
+    // subject tables; the blocks must outlive it (freeing a block frees the views over it).  Empty: not a view.
+    std::vector<const GbnDb *> view_parts;
 };
 constexpr int32_t kDbseqChunkOverlap = 100;     // COREI/blast_hits.h:169
 

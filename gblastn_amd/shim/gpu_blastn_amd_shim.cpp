@@ -15,7 +15,8 @@
 // tests/test_boundary.py syntax-checks it against the reference's headers where /root/reference exists.
 //
 // Everything that does not need a toolkit type lives in the library and is tested there:
-//   gbn_prelim_search_lists    grouping of the HSPs into per-subject lists, ascending oid
+//   gbn_results_emit_lists     grouping of the HSPs into per-subject lists, ascending oid
+//   gbn_block_view             the resident blocks of several OID chunks searched as one shard
 //   gbn_db_cache_find/_insert  the cache of resident OID blocks that gpu_ReleaseDBMemory() empties
 //   gbn_shard_builder_*        subjects appended one by one into a 16-byte aligned slab, with their OIDs
 //   gbn_use_device             the calling thread's GPU (the lease of GB/gpu_blast_multi_gpu_utils.cpp:105-139)
@@ -34,6 +35,7 @@
 #include <algo/blast/core/blast_diagnostics.h>
 #include <algo/blast/gpu_blast/gpu_blastn_na_ungapped_v3.h>
 #include <string.h>
+#include <stdlib.h>
 #include <mutex>
 #include <vector>
 #include "gblastn_amd.h"
@@ -197,6 +199,19 @@ GbnDb* s_GetBlock(const BlastSeqSrc* seq_src, const std::vector<Int4>& oids, Int
     return kept;
 }
 
+// Chunks per group.  A group is one search: the larger, the fewer fixed costs per query batch (each search loads the
+// lookup table's slices once per bin and ends in one host synchronisation); the smaller, the finer the N threads that
+// share the source's bookmark balance at the end of the database.  Default: a quarter of the chunks one GPU gets when
+// the leased GPUs share the database evenly (1 GPU: 25 chunks = 4 searches per query batch; 8 GPUs: 3);
+// GBN_SHIM_GROUP_CHUNKS overrides (1 = the reference's chunk-by-chunk loop).
+int s_leased_at_init = 1;
+int s_GroupChunks()
+{
+    if (const char* e = getenv("GBN_SHIM_GROUP_CHUNKS")) { const int v = atoi(e); if (v >= 1) return v; }
+    const int g = 100 / (4 * (s_leased_at_init > 0 ? s_leased_at_init : 1));
+    return g < 1 ? 1 : g;
+}
+
 struct SListSink { BlastHSPStream* stream; const BlastQueryInfo* query_info; };
 
 // TInterruptFnPtr returns a Boolean (one byte), GbnInterruptFn an int: called through its own signature
@@ -279,35 +294,71 @@ Int2 Blast_gpu_RunPreliminarySearchWithInterrupt(EBlastProgramType program,
     else if (lut_word == word && !s_MasksFromTable(lookup_wrap, query_info, mq, mfrom, mto)) return -1;
     // (word > lut and no masked_locations: the table was built from the whole query, CORE/blast_nalookup.c:413-417)
 
-    // Chunks of OIDs are fetched and searched one after the other, as the reference's loop does (GB/...engine.cpp:
-    // 1243-1290): N search threads (GPU-leased or on the stock CPU path) share the source's bookmark, nobody drains it.
-    // The query batch is set up once per call; every chunk is a resident block (s_GetBlock).
+    // Chunks of OIDs are fetched from the source as the reference's loop fetches them (GB/...engine.cpp:1243-1290; chunk =
+    // a hundredth of the database, so that every chunk any thread ever gets is the same stretch of the source's bookmark
+    // and its resident block is found again): N search threads (GPU-leased or on the stock CPU path) share the bookmark,
+    // nobody drains it.  What differs is how they are SEARCHED: not one synchronous search per chunk (a hundred rounds of
+    // launches, read-backs and host synchronisations per query batch) but
+    //   * in GROUPS of up to s_GroupChunks() chunks, a group being one VIEW over its resident blocks (gbn_block_view: one
+    //     tile table, one launch per kernel, one cached record set -- no subject byte is copied), and
+    //   * PIPELINED: gbn_prelim_search_begin of group k returns when its scan is done; while its extension stages run,
+    //     this thread fetches (and, on a cold cache, uploads) the blocks of group k + 1 and writes the lists of group k - 1
+    //     to the HSP stream.
+    // The lists reach the stream in ascending OID order per group, as the reference's subject-by-subject loop writes them.
+    // The query batch is set up once per call.
     GbnBatch* batch = NULL; GbnDiagnostics d; memset(&d, 0, sizeof d);
     SListSink sink = { hsp_stream, query_info };
     SInterrupt intr = { interrupt_search, progress_info };
     int rc = GBN_OK;
     BlastSeqSrcIterator* itr = BlastSeqSrcIteratorNewEx(MAX(BlastSeqSrcGetNumSeqs(seq_src) / 100, 1));
     if (!itr) return -1;
+    GbnResults* res[2] = { NULL, NULL };
+    if (gbn_results_new(&res[0]) != GBN_OK || gbn_results_new(&res[1]) != GBN_OK) rc = GBN_ERR_NOMEM;
+    int cur = 0; bool in_flight = false;                // res[cur ^ 1] belongs to the search begun last
+    const int group_chunks = s_GroupChunks();
     std::vector<Int4> oids;
+    std::vector<GbnDb*> blocks;
     for (bool more = true; more && rc == GBN_OK; ) {
-        oids.clear();
-        for (;;) {                                      // one chunk: until the iterator has used up what the source gave it
-            const Int4 oid = BlastSeqSrcIteratorNext(seq_src, itr);
-            if (oid == BLAST_SEQSRC_EOF) { more = false; break; }
-            if (oid == BLAST_SEQSRC_ERROR) { more = false; rc = GBN_ERR_ARG; break; }
-            oids.push_back(oid);
-            if (itr->current_pos == UINT4_MAX) break;
+        blocks.clear();
+        while (more && rc == GBN_OK && (int)blocks.size() < group_chunks) {
+            oids.clear();
+            for (;;) {                                  // one chunk: until the iterator has used up what the source gave it
+                const Int4 oid = BlastSeqSrcIteratorNext(seq_src, itr);
+                if (oid == BLAST_SEQSRC_EOF) { more = false; break; }
+                if (oid == BLAST_SEQSRC_ERROR) { more = false; rc = GBN_ERR_ARG; break; }
+                oids.push_back(oid);
+                if (itr->current_pos == UINT4_MAX) break;
+            }
+            if (oids.empty() || rc != GBN_OK) break;
+            Int2 status = 0;
+            GbnDb* block = s_GetBlock(seq_src, oids, &status);
+            if (!block) { if (status) rc = GBN_ERR_HIP; continue; }     // (a chunk without a usable sequence: as the reference's loop)
+            blocks.push_back(block);
         }
-        if (oids.empty() || rc != GBN_OK) break;
-        Int2 status = 0;
-        GbnDb* block = s_GetBlock(seq_src, oids, &status);
-        if (!block) { rc = status ? GBN_ERR_HIP : GBN_OK; if (status) break; continue; }
+        if (blocks.empty() || rc != GBN_OK) break;
         if (!batch)
             rc = gbn_batch_new_masked(&batch, &o, (int32_t)seqs.size(), seqs.data(), lens.data(),
                                       (int32_t)mq.size(), mq.data(), mfrom.data(), mto.data(), 1);
-        if (rc == GBN_OK)
-            rc = gbn_prelim_search_lists(batch, block, s_WriteList, &sink, &d, interrupt_search ? s_Interrupt : NULL, &intr);
+        // the group as one shard; blocks whose slabs lie too far apart for a view are searched one by one
+        GbnDb* view = NULL;
+        const bool one = rc == GBN_OK && gbn_block_view(blocks.data(), (int32_t)blocks.size(), &view) == GBN_OK && view;
+        for (size_t k = 0; rc == GBN_OK && k < (one ? 1 : blocks.size()); ++k) {
+            gbn_results_clear(res[cur]);
+            rc = gbn_prelim_search_begin(batch, one ? view : blocks[k], res[cur], &d, interrupt_search ? s_Interrupt : NULL, &intr);
+            if (rc != GBN_OK) break;
+            if (in_flight) {                            // the search before this one: finished by now or soon, its lists go out
+                rc = gbn_prelim_search_end(res[cur ^ 1]);
+                if (rc == GBN_OK) rc = gbn_results_emit_lists(res[cur ^ 1], s_WriteList, &sink);
+            }
+            in_flight = true; cur ^= 1;
+        }
     }
+    if (in_flight) {                                    // (also after a failure: nothing may stay in flight on these results)
+        const int rc2 = gbn_prelim_search_end(res[cur ^ 1]);
+        if (rc == GBN_OK) rc = rc2;
+        if (rc == GBN_OK) rc = gbn_results_emit_lists(res[cur ^ 1], s_WriteList, &sink);
+    }
+    gbn_results_free(res[0]); gbn_results_free(res[1]);
     BlastSeqSrcIteratorFree(itr);
     if (rc == GBN_OK && diagnostics) {                  // (per-thread counters; the caller's structure may be shared: COREI/blast_diagnostics.h:118-126)
         if (diagnostics->ungapped_stat) {
@@ -341,6 +392,7 @@ int Blast_gpu_Init(bool isInit, int gpu_id)
         for (int d = n - 1; d >= 0; --d) if (gbn_init(1, d) == GBN_OK) s_free_gpus.push_back(d);
     }
     s_use_gpu = !s_free_gpus.empty();
+    s_leased_at_init = (int)s_free_gpus.size();
     return (int)s_free_gpus.size();
 }
 

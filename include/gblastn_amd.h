@@ -175,6 +175,24 @@ struct GbnDevSeed;
 int gbn_debug_seed_order(const struct GbnDevSeed *seg, const uint32_t *seg_count, int nseg, uint32_t seg_cap, int nsubj, int subj_base,
                          int container_hash, int diag_len, int32_t qlen, int32_t max_len, int q_descending, uint64_t *keys_out, int64_t *n_out);
 long long gbn_debug_bin_ahead_hits(void);       /* tests: passes of the calling thread's engine whose binning kernel had been queued by the pass before (GBN_BIN_AHEAD) */
+long long gbn_debug_bin_ahead_misses(void);     /* ... and binning kernels queued ahead that no pass used */
+/* The record cache of the calling thread's device.  The records the binning kernel writes (every scan position of a subject
+ * range filed by the key range of its lookup word) depend on the shard, the range and the SHAPE of the lookup table, not
+ * on the queries: complete sets stay resident, least recently used first out, and a pass whose set is there runs the probe
+ * kernels only ("bin once, probe many").  The reference keeps what its scan needs of the database on the device for the
+ * life of the process the same way: its per-OID subject cache, GB/gpu_blastn_MB_and_smallNa.cu:1461-1468.
+ * limit: bytes the cache may hold; 0: off (every pass bins for itself); < 0: the default -- GBN_RECORD_CACHE_MB, else a
+ * quarter of the device's memory.  stats: out[0..n) of {limit, bytes held, sets, passes served from the cache, passes
+ * that binned, sets evicted, passes whose set is larger than the whole cache, passes served by a kernel queued ahead}. */
+int  gbn_record_cache_set_limit(long long bytes);
+int  gbn_record_cache_stats(long long *out, int n);
+/* A VIEW over resident blocks: their subjects as ONE shard (one tile table, one launch per kernel, one record set), for
+ * the shim's loop over OID chunks (GB/gpu_blastn_pre_search_engine.cpp:1243-1441 searches chunk after chunk inside one
+ * call).  No subject byte is copied: the view addresses every block's slab from the lowest one.  Views are cached by their
+ * blocks (any order; they are put into ascending OID order) and freed by gbn_release_db_memory / with any of their blocks;
+ * n == 1 returns the block itself.  GBN_ERR_UNSUPPORTED: blocks with chunked sequences, or slabs more than 64 GiB apart
+ * (the caller searches them one by one). */
+int  gbn_block_view(struct GbnDb *const *blocks, int32_t n, struct GbnDb **out);
 long long gbn_debug_db_bytes_uploaded(void);    /* tests: slab bytes copied host -> device by gbn_db_new / the shard builder so far */
 
 /* ---- database shard resident in HBM ---- */
@@ -320,6 +338,10 @@ int  gbn_prelim_search_lists(GbnBatch *batch, GbnDb *db, GbnHspListFn sink, void
 int  gbn_prelim_search_begin(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
                              GbnInterruptFn interrupt, void *progress);
 int  gbn_prelim_search_end(GbnResults *results);   /* NULL: whatever is in flight */
+/* finished results as gbn_prelim_search_lists delivers them: one call of `sink` per subject that has HSPs, oids ascending
+ * (a pipelined caller writes the lists of search k to the HSP stream while search k + 1 scans) */
+int  gbn_results_emit_lists(const GbnResults *results, GbnHspListFn sink, void *sink_arg);
+int  gbn_debug_counting_sink(void *arg, int32_t oid, const GbnHSP *hsps, int32_t n);   /* bench / tests: a GbnHspListFn that counts; arg = long long[2] {lists, HSPs} */
 /* scan stage only (bench / roofline): runs the scan+seed kernel over the
  * whole shard `repeats` times and reports the HIP-event time per launch */
 int  gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag);

