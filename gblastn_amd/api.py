@@ -89,7 +89,7 @@ EXPORTS = ["gbn_init", "gbn_release", "gbn_release_db_memory", "gbn_debug_check_
            "gbn_batch_scan_params", "gbn_batch_ext_params", "gbn_batch_gap_params", "gbn_batch_diag_layout",
            "gbn_prelim_search_lists", "gbn_db_cache_find", "gbn_db_cache_insert", "gbn_block_cache_find", "gbn_block_cache_insert",
            "gbn_debug_db_bytes_uploaded", "gbn_debug_seed_order", "gbn_debug_bin_ahead_hits", "gbn_debug_bin_ahead_misses",
-           "gbn_record_cache_set_limit", "gbn_record_cache_stats", "gbn_block_view", "gbn_results_emit_lists", "gbn_debug_counting_sink",
+           "gbn_record_cache_set_limit", "gbn_record_cache_stats", "gbn_record_cache_invalidate", "gbn_block_view", "gbn_results_emit_lists", "gbn_debug_counting_sink",
            "gbn_set_max_dbseq_len", "gbn_db_set_ambiguities", "gbn_traceback_merge", "gbn_shard_builder_new", "gbn_shard_builder_add", "gbn_shard_builder_finish", "gbn_shard_builder_free"]
 
 # ---- include/gblastn_amd_kernels.h: parameter blocks of the gbn_launch_* entry points (device pointers as integers)
@@ -271,6 +271,11 @@ def default_options(task="megablast", db_length=0, db_num_seqs=0, **kw):
 def record_cache_set_limit(nbytes=-1):
     """Bytes of scan records the calling thread's device keeps resident ("bin once, probe many"); 0: off, < 0: default."""
     _check(lib().gbn_record_cache_set_limit(int(nbytes)))
+
+
+def record_cache_invalidate():
+    """Every cached record set forgets its records (the buffers stay): the next pass of each key bins again."""
+    _check(lib().gbn_record_cache_invalidate())
 
 
 def record_cache_stats():

@@ -926,8 +926,21 @@ static void rec_make_room(size_t need, long long limit, const RecordSet *keep) {
         rec_drop(lru, true);
     }
 }
-// the shard goes (gbn_db_free), or everything (release, a limit of 0)
-static void rec_purge(const void *db) {
+// buffers change hands (what `dst` had is freed); neither side holds records afterwards
+static void recset_move(RecordSet &dst, RecordSet &src) {
+    recset_free(dst);
+    dst.bin_rec = src.bin_rec; dst.bin_rec_cap = src.bin_rec_cap; dst.bin_tcur = src.bin_tcur; dst.bin_tcur_cap = src.bin_tcur_cap;
+    dst.bin_count = src.bin_count; dst.bin_count_cap = src.bin_count_cap; dst.complete = false;
+    src.bin_rec = nullptr; src.bin_tcur = nullptr; src.bin_count = nullptr; src.bin_rec_cap = src.bin_tcur_cap = src.bin_count_cap = 0; src.complete = false;
+}
+// the shard goes (gbn_db_free), or everything (release, a limit of 0; to_scratch: the cache was switched off and the largest
+// set's buffers become the passes' own -- no gigabytes freed and allocated again)
+static void rec_purge(const void *db, bool to_scratch = false) {
+    if (to_scratch && !db && !E.scratch.bin_rec && !E.rec_sets.empty()) {
+        size_t big = 0;
+        for (size_t i = 1; i < E.rec_sets.size(); i++) if (E.rec_sets[i]->bytes() > E.rec_sets[big]->bytes()) big = i;
+        recset_move(E.scratch, *E.rec_sets[big]);
+    }
     for (size_t i = E.rec_sets.size(); i-- > 0; ) if (!db || E.rec_sets[i]->key.db == db) rec_drop(i, false);
     if (!db || E.scratch.key.db == db) E.scratch.complete = false;
     if (!db || E.alt.key.db == db) E.alt.complete = false;
@@ -984,7 +997,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     size_t rare_seg_hint = 0, rare_seg_used = 0, slice_seg_cap = 0; int slice_blocks = 0; bool slice_ordered = false;
     GbnBinParams last_B; std::memset(&last_B, 0, sizeof(last_B)); int last_grid2 = 0;
     const long long rec_limit = nb > 1 ? rec_limit_bytes() : 0;        // bytes the record cache may hold; 0: off
-    if (rec_limit == 0 && !E.rec_sets.empty()) rec_purge(nullptr);     // (switched off: what it held goes)
+    if (rec_limit == 0 && nb > 1 && !E.rec_sets.empty()) rec_purge(nullptr, true);     // (switched off: what it held goes)
     RecordSet *rs = nullptr;                    // the records of this pass
     bool binned_here = false;                   // ... were written (completely) by this call
     bool repeat_seen = false;                   // cache off: the pass before this one had the same key
@@ -1041,18 +1054,29 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             Engine::BinAhead &AH = E.ahead;
             if (rec_limit > 0) {
                 // ---- record cache: a complete set of this shape whose streams are at least as long as this attempt asks for
-                if (AH.valid) { AH.valid = false; E.ahead_misses++; }
+                if (AH.valid) { AH.valid = false; E.ahead_misses++; HIPCHK(hipStreamSynchronize(E.stream)); }     // (a kernel queued ahead writes the other scratch set, which may change hands below)
                 rs = nullptr;
                 for (RecordSet *c : E.rec_sets) if (c->complete && c->key.same_shape(key) && c->key.subcap >= subcap) { rs = c; break; }
                 if (rs) { hit = true; subcap = rs->key.subcap; key.subcap = subcap; if (!binned_here) E.rec_hits++; }
                 else {
                     E.rec_misses++;
-                    for (size_t i = E.rec_sets.size(); i-- > 0; ) if (E.rec_sets[i]->key.same_shape(key)) rec_drop(i, false);     // (incomplete, or shorter streams: replaced)
+                    // a set of this shape that holds no complete records (forgotten: gbn_record_cache_invalidate; overflowed) or whose
+                    // streams are shorter: its buffers serve again
+                    RecordSet *old = nullptr;
+                    for (size_t i = E.rec_sets.size(); i-- > 0; ) if (E.rec_sets[i]->key.same_shape(key)) { if (!old) old = E.rec_sets[i]; else rec_drop(i, false); }
                     const size_t need_bytes = (GBN_REC_WORDS(subcap * nstream) + 1) / 2 * 8 + nstream * nseq * 4 + (nstream + 4) * 4;
                     if ((long long)need_bytes <= rec_limit) {
-                        rec_make_room(need_bytes, rec_limit, nullptr);
-                        rs = new RecordSet(); E.rec_sets.push_back(rs);
-                    } else { rs = &E.scratch; E.rec_bypass++; }      // larger than the whole cache: this pass's own
+                        if (old) rs = old;
+                        else {
+                            rs = new RecordSet(); E.rec_sets.push_back(rs);
+                            // (the cache was switched on after passes that binned for themselves: their buffers are the first set's)
+                            if (E.scratch.bin_rec) { recset_move(*rs, E.scratch); recset_free(E.alt); }
+                        }
+                        rec_make_room(need_bytes > rs->bytes() ? need_bytes - rs->bytes() : 0, rec_limit, rs);
+                    } else {                                         // larger than the whole cache: this pass's own
+                        if (old) for (size_t i = 0; i < E.rec_sets.size(); i++) if (E.rec_sets[i] == old) { rec_drop(i, false); break; }
+                        rs = &E.scratch; E.rec_bypass++;
+                    }
                 }
             } else {
                 rs = &E.scratch;
@@ -1876,9 +1900,25 @@ int gbn_record_cache_set_limit(long long bytes) {
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(E.mu);
     E.rec_limit = bytes < 0 ? -1 : bytes;
+    if (E.ahead.valid) { (void)hipStreamSynchronize(E.stream); E.ahead.valid = false; E.ahead_misses++; }     // (a binning kernel queued ahead: done before buffers change hands)
+    E.last_key_valid = false;
     const long long limit = rec_limit_bytes();
-    if (limit == 0) rec_purge(nullptr);
+    if (limit == 0) rec_purge(nullptr, true);
     else rec_make_room(0, limit, nullptr);
+    return GBN_OK;
+    });
+}
+// every set forgets its records and keeps its buffers: the next pass of each key bins again (bench: a cold start without
+// giving gigabytes back to the driver and asking for them again)
+int gbn_record_cache_invalidate(void) {
+    return gbn::guard(__func__, [&]() -> int {
+    const int rc = enter_current();
+    if (rc) return rc;
+    std::lock_guard<std::mutex> lk(E.mu);
+    for (RecordSet *r : E.rec_sets) r->complete = false;
+    E.scratch.complete = false;
+    if (E.ahead.valid) { (void)hipStreamSynchronize(E.stream); E.ahead.valid = false; }
+    E.last_key_valid = false;
     return GBN_OK;
     });
 }

@@ -186,6 +186,7 @@ long long gbn_debug_bin_ahead_misses(void);     /* ... and binning kernels queue
  * that binned, sets evicted, passes whose set is larger than the whole cache, passes served by a kernel queued ahead}. */
 int  gbn_record_cache_set_limit(long long bytes);
 int  gbn_record_cache_stats(long long *out, int n);
+int  gbn_record_cache_invalidate(void);     /* every cached set forgets its records (its buffers stay): the next pass of each key bins again */
 /* A VIEW over resident blocks: their subjects as ONE shard (one tile table, one launch per kernel, one record set), for
  * the shim's loop over OID chunks (GB/gpu_blastn_pre_search_engine.cpp:1243-1441 searches chunk after chunk inside one
  * call).  No subject byte is copied: the view addresses every block's slab from the lowest one.  Views are cached by their
