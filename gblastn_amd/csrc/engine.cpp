@@ -916,22 +916,40 @@ static void rec_drop(size_t i, bool evicted) {
     recset_free(*E.rec_sets[i]); delete E.rec_sets[i]; E.rec_sets.erase(E.rec_sets.begin() + (long)i);
     if (evicted) E.rec_evictions++;
 }
-// the least recently used sets go until `need` more bytes fit under `limit` (keep: the set the pass is using)
-static void rec_make_room(size_t need, long long limit, const RecordSet *keep) {
-    while (!E.rec_sets.empty() && (long long)(rec_held_bytes() + need) > limit) {
-        size_t lru = E.rec_sets.size();
-        for (size_t i = 0; i < E.rec_sets.size(); i++)
-            if (E.rec_sets[i] != keep && (lru == E.rec_sets.size() || E.rec_sets[i]->stamp < E.rec_sets[lru]->stamp)) lru = i;
-        if (lru == E.rec_sets.size()) break;
-        rec_drop(lru, true);
-    }
-}
 // buffers change hands (what `dst` had is freed); neither side holds records afterwards
 static void recset_move(RecordSet &dst, RecordSet &src) {
     recset_free(dst);
     dst.bin_rec = src.bin_rec; dst.bin_rec_cap = src.bin_rec_cap; dst.bin_tcur = src.bin_tcur; dst.bin_tcur_cap = src.bin_tcur_cap;
     dst.bin_count = src.bin_count; dst.bin_count_cap = src.bin_count_cap; dst.complete = false;
     src.bin_rec = nullptr; src.bin_tcur = nullptr; src.bin_count = nullptr; src.bin_rec_cap = src.bin_tcur_cap = src.bin_count_cap = 0; src.complete = false;
+}
+// Sets go until `need` more bytes fit under `limit` (keep: the set the pass is using).  Which: a pass over (shard, range) of
+// a table shape is one step of a SWEEP -- every query batch visits the ranges / block views of its database in the same
+// order, again and again -- and under such a cyclic pattern "least recently used first" evicts exactly the set that is needed
+// next (no hits at all once the sets of a sweep exceed the limit).  So, as buffer managers do for sequential scans: among the
+// sets of the pass's own database shape (same lut width, stride and stream geometry: its sweep) the MOST recently used one goes
+// -- the sets from the start of the sweep stay and are hit again by the next batch --; only when there is none, the least
+// recently used of the others.  If `into` is given and empty, the last victim's buffers move there instead of being freed.
+static void rec_make_room(size_t need, long long limit, const RecordSet *keep, const RecKey *sweep = nullptr, RecordSet *into = nullptr) {
+    while (!E.rec_sets.empty() && (long long)(rec_held_bytes() + need) > limit) {
+        const size_t none = E.rec_sets.size();
+        size_t mru = none, lru = none;
+        for (size_t i = 0; i < E.rec_sets.size(); i++) {
+            const RecordSet *r = E.rec_sets[i];
+            if (r == keep || r == into) continue;
+            const bool same_sweep = sweep && r->key.lut == sweep->lut && r->key.step == sweep->step && r->key.nb == sweep->nb && r->key.cbits == sweep->cbits &&
+                                    r->key.rfl == sweep->rfl && r->key.rfrbits == sweep->rfrbits;
+            if (same_sweep) { if (mru == none || r->stamp > E.rec_sets[mru]->stamp) mru = i; }
+            else if (lru == none || r->stamp < E.rec_sets[lru]->stamp) lru = i;
+        }
+        const size_t victim = lru != none ? lru : mru;      // (sets of other shapes: nobody is sweeping them now)
+        if (victim == none) break;
+        if (into && !into->bin_rec && (long long)(rec_held_bytes() - E.rec_sets[victim]->bytes() + std::max(need, E.rec_sets[victim]->bytes())) <= limit) {
+            recset_move(*into, *E.rec_sets[victim]);        // (the room it makes is the room the newcomer takes: no driver call)
+            need = need > into->bytes() ? need - into->bytes() : 0;
+        }
+        rec_drop(victim, true);
+    }
 }
 // the shard goes (gbn_db_free), or everything (release, a limit of 0; to_scratch: the cache was switched off and the largest
 // set's buffers become the passes' own -- no gigabytes freed and allocated again)
@@ -1072,7 +1090,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                             // (the cache was switched on after passes that binned for themselves: their buffers are the first set's)
                             if (E.scratch.bin_rec) { recset_move(*rs, E.scratch); recset_free(E.alt); }
                         }
-                        rec_make_room(need_bytes > rs->bytes() ? need_bytes - rs->bytes() : 0, rec_limit, rs);
+                        rec_make_room(need_bytes > rs->bytes() ? need_bytes - rs->bytes() : 0, rec_limit, rs, &key, rs);
                     } else {                                         // larger than the whole cache: this pass's own
                         if (old) for (size_t i = 0; i < E.rec_sets.size(); i++) if (E.rec_sets[i] == old) { rec_drop(i, false); break; }
                         rs = &E.scratch; E.rec_bypass++;

@@ -238,3 +238,30 @@ def test_shim_shaped_loop_equals_the_whole_shard_search(cache_default, group):
             L.gbn_results_free(r)
         a.close()
     ref.close()
+
+
+def test_sweeps_over_more_ranges_than_the_cache_holds_still_hit(cache_default):
+    """Every query batch sweeps the views of its database in the same order.  With room for two of three record sets a
+    least-recently-used cache would never hit (it evicts the set the sweep needs next); the cache evicts the MOST recently
+    used set of the sweep instead, so the sets from the start of a sweep are found again by the next one."""
+    subjects, queries, opt, blocks = _blocks_case()
+    views = [api.block_view(blocks[k:k + 2]) for k in (0, 2, 4)]
+    ps = api.BlastPrelimSearch(queries, opt)
+    api.record_cache_set_limit(0)
+    want = [ps.run(seqsrc=v)["hsps"].tobytes() for v in views]
+    assert sum(len(w) for w in want) > 0
+    api.record_cache_set_limit(-1)
+    ps.run(seqsrc=views[0])
+    one = api.record_cache_stats()["bytes"]
+    assert one > 0
+    api.record_cache_set_limit(2 * one + one // 2)
+    st0 = api.record_cache_stats()
+    for sweep in range(4):
+        for v, w in zip(views, want):
+            assert ps.run(seqsrc=v)["hsps"].tobytes() == w
+            st = api.record_cache_stats()
+            assert st["sets"] <= 2 and st["bytes"] <= 2 * one + one // 2
+    st = api.record_cache_stats()
+    assert st["hits"] - st0["hits"] >= 4, (st, st0)             # (least recently used first: 1, the very first pass)
+    assert st["evictions"] - st0["evictions"] >= 3
+    ps.close()
