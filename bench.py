@@ -319,16 +319,20 @@ def main():
         for _ in range(7):
             api.record_cache_set_limit(-1); api.record_cache_invalidate()      # every region starts without records (the buffers stay allocated)
             st0 = api.record_cache_stats()
-            _, el = timed(lambda: run_passes(npass_config, []))
+
+            def whole_config():
+                src.prepare_records(opt, qsets[0])              # the caller knows its first batch: the shard's records are binned underneath its set-up
+                return run_passes(npass_config, [])
+            _, el = timed(whole_config)
             st1 = api.record_cache_stats()
             walls.append(el * 1e3); binned_passes.append(st1["misses"] - st0["misses"])
         walls_sorted = sorted(walls)
         config_measured = {"ms": walls_sorted[(len(walls) - 1) // 2], "minmax": [walls_sorted[0], walls_sorted[-1]], "regions": len(walls),
-                           "passes": npass_config, "passes_that_binned": sorted(set(binned_passes)),
+                           "passes": npass_config, "passes_that_binned_for_themselves": sorted(set(binned_passes)), "record_sets_prepared_per_region": 1,
                            "what": "wall clock of the WHOLE config (%d query batches of %d, set up from scratch inside the region, scanned, extended, merged) as one "
-                                   "timed region in this process, library default policy: the record cache holds the shard's scan records after the first "
-                                   "batch's binning kernel, later batches run probe + rare kernel only; every region starts with an empty cache and nothing "
-                                   "set up ahead" % (npass_config, args.batch_queries)}
+                                   "timed region in this process, library default policy: gbn_db_prepare_records queues the shard's binning kernel when the region starts "
+                                   "(it runs underneath the first batch's set-up), the record cache holds the records, both batches run probe + rare kernel only; every "
+                                   "region starts with no records and nothing set up ahead" % (npass_config, args.batch_queries)}
         # later batches of a stream over the cached records (what C4 and the shim see per batch)
         keep_primed[0] = True
         run_passes(2, [])

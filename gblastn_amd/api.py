@@ -89,7 +89,7 @@ EXPORTS = ["gbn_init", "gbn_release", "gbn_release_db_memory", "gbn_debug_check_
            "gbn_batch_scan_params", "gbn_batch_ext_params", "gbn_batch_gap_params", "gbn_batch_diag_layout",
            "gbn_prelim_search_lists", "gbn_db_cache_find", "gbn_db_cache_insert", "gbn_block_cache_find", "gbn_block_cache_insert",
            "gbn_debug_db_bytes_uploaded", "gbn_debug_seed_order", "gbn_debug_bin_ahead_hits", "gbn_debug_bin_ahead_misses",
-           "gbn_record_cache_set_limit", "gbn_record_cache_stats", "gbn_record_cache_invalidate", "gbn_block_view", "gbn_results_emit_lists", "gbn_debug_counting_sink",
+           "gbn_record_cache_set_limit", "gbn_record_cache_stats", "gbn_record_cache_invalidate", "gbn_db_prepare_records", "gbn_block_view", "gbn_results_emit_lists", "gbn_debug_counting_sink",
            "gbn_set_max_dbseq_len", "gbn_db_set_ambiguities", "gbn_traceback_merge", "gbn_shard_builder_new", "gbn_shard_builder_add", "gbn_shard_builder_finish", "gbn_shard_builder_free"]
 
 # ---- include/gblastn_amd_kernels.h: parameter blocks of the gbn_launch_* entry points (device pointers as integers)
@@ -169,6 +169,7 @@ def lib():
             L.gbn_record_cache_set_limit.argtypes = [C.c_longlong]
             L.gbn_record_cache_stats.argtypes = [C.POINTER(C.c_longlong), C.c_int]
             L.gbn_block_view.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.c_void_p)]
+            L.gbn_db_prepare_records.argtypes = [C.c_void_p, C.POINTER(GbnOptions), C.c_int32, C.POINTER(C.c_int32)]
             L.gbn_results_emit_lists.argtypes = [C.c_void_p, GbnHspListFn, C.c_void_p]
         L.gbn_debug_seed_order.restype = C.c_int
         L.gbn_debug_seed_order.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int32, C.c_int32,
@@ -279,9 +280,9 @@ def record_cache_invalidate():
 
 
 def record_cache_stats():
-    v = (C.c_longlong * 8)()
-    _check(lib().gbn_record_cache_stats(v, 8))
-    return dict(zip(("limit", "bytes", "sets", "hits", "misses", "evictions", "bypassed", "ahead_hits"), [int(x) for x in v]))
+    v = (C.c_longlong * 9)()
+    _check(lib().gbn_record_cache_stats(v, 9))
+    return dict(zip(("limit", "bytes", "sets", "hits", "misses", "evictions", "bypassed", "ahead_hits", "prepared"), [int(x) for x in v]))
 
 
 def block_view(blocks):
@@ -362,6 +363,12 @@ class BlastSeqSrc:
     @property
     def num_seqs(self):
         return lib().gbn_db_num_seqs(self._h)
+
+    def prepare_records(self, options, queries):
+        """The scan records a batch of these queries (a QuerySet, or BLASTNA arrays) will want of this shard, binned now,
+        asynchronously, underneath the batch's set-up (gbn_db_prepare_records)."""
+        qs = queries if isinstance(queries, QuerySet) else QuerySet(queries)
+        _check(lib().gbn_db_prepare_records(self._h, C.byref(options), len(qs), qs.lens))
 
     def close(self):
         if self._h:

@@ -96,6 +96,20 @@ static int choose_lookup(const GbnOptions &o, int32_t entries, int32_t max_off, 
     return type;
 }
 
+// The table a batch of unmasked queries of these lengths gets (kind, lut width, stride): EstimateNumTableEntries over the
+// two strands of every query + BlastChooseNaLookupTable, as choose_table below applies them to a batch's stretches.
+void predict_table_shape(const GbnOptions &opt, int32_t nq, const int32_t *lens, int &type, int &lut, int &step) {
+    int64_t entries = 0, off = 0, max_off = 0;
+    for (int32_t i = 0; i < nq; i++)
+        for (int strand = 0; strand < 2; strand++) {
+            if (lens[i] > 0) { entries += lens[i] - 1; max_off = off + lens[i] - 1; }
+            off += lens[i] + 1;                         // (a sentinel between contexts)
+        }
+    int width = 0;
+    type = choose_lookup(opt, (int32_t)std::min<int64_t>(entries, INT32_MAX), (int32_t)std::min<int64_t>(max_off, INT32_MAX), width);
+    lut = width; step = opt.word_size - width + 1;
+}
+
 // Index every lut-word that lies inside an indexed stretch [left, right] of the concatenated query,
 // has no ambiguity code, and whose stretch can hold a full word_size word
 // (CORE/blast_lookup.c:87-137, CORE/blast_nalookup.c:873-928).

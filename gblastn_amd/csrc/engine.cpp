@@ -150,6 +150,7 @@ struct Engine {
                        uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;              // per-run stream cursors (6-byte records)
                        uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;            // [nb][nwriters] + overflow flag
                        RecKey key; bool complete = false;      // the buffers hold every record of `key` (binned, no stream overflowed)
+                       bool queued = false;                    // the binning kernel that writes them is queued on the engine's stream, its overflow flag not read yet (gbn_db_prepare_records)
                        unsigned long long stamp = 0;           // last use (record cache: least recently used goes first)
                        size_t bytes() const { return bin_rec_cap * 8 + bin_tcur_cap * 4 + bin_count_cap * 4; } };
     // Record cache (the default): bin once, probe many.  Complete record sets stay resident, least recently
@@ -159,7 +160,7 @@ struct Engine {
     // the device for the life of the process the same way (the per-OID subject cache, GB/gpu_blastn_MB_and_smallNa.cu:1461-1468).
     // rec_limit == 0: off -- every pass bins for itself into `scratch` (bench.py's headline: the north_star scan).
     std::vector<RecordSet *> rec_sets; long long rec_limit = -1; unsigned long long rec_clock = 0;
-    long long rec_hits = 0, rec_misses = 0, rec_evictions = 0, rec_bypass = 0;
+    long long rec_hits = 0, rec_misses = 0, rec_evictions = 0, rec_bypass = 0, rec_prepared = 0;
     RecordSet scratch, alt;             // cache off, or a set larger than the cache: the pass's own records; alt: binned ahead
     void swap_scan_sets() { std::swap(scratch, alt); }
     // Binning ahead (cache off; pipelined passes over one range of one shard, GBN_BIN_AHEAD=0: off): the binning kernel reads the
@@ -892,7 +893,7 @@ static int scan_slices(const GbnBatch &b) {
 // ---- record cache (Engine::rec_sets) ----
 static void recset_free(RecordSet &r) {
     dev_free(r.bin_rec); dev_free(r.bin_tcur); dev_free(r.bin_count);
-    r.bin_rec_cap = r.bin_tcur_cap = r.bin_count_cap = 0; r.complete = false;
+    r.bin_rec_cap = r.bin_tcur_cap = r.bin_count_cap = 0; r.complete = false; r.queued = false;
 }
 // the buffers of `r` at least this long (freed and allocated anew when one is too short: whatever they held is gone)
 static int recset_size(RecordSet &r, size_t need_u64, size_t need_tcur, size_t need_count) {
@@ -913,14 +914,16 @@ static long long rec_limit_bytes() {
 }
 static size_t rec_held_bytes() { size_t n = 0; for (const RecordSet *r : E.rec_sets) n += r->bytes(); return n; }
 static void rec_drop(size_t i, bool evicted) {
+    if (E.rec_sets[i]->queued) (void)hipStreamSynchronize(E.stream);       // (a binning kernel queued by gbn_db_prepare_records may still write it)
     recset_free(*E.rec_sets[i]); delete E.rec_sets[i]; E.rec_sets.erase(E.rec_sets.begin() + (long)i);
     if (evicted) E.rec_evictions++;
 }
 // buffers change hands (what `dst` had is freed); neither side holds records afterwards
 static void recset_move(RecordSet &dst, RecordSet &src) {
+    if (src.queued || dst.queued) (void)hipStreamSynchronize(E.stream);
     recset_free(dst);
     dst.bin_rec = src.bin_rec; dst.bin_rec_cap = src.bin_rec_cap; dst.bin_tcur = src.bin_tcur; dst.bin_tcur_cap = src.bin_tcur_cap;
-    dst.bin_count = src.bin_count; dst.bin_count_cap = src.bin_count_cap; dst.complete = false;
+    dst.bin_count = src.bin_count; dst.bin_count_cap = src.bin_count_cap; dst.complete = false; dst.queued = false; src.queued = false;
     src.bin_rec = nullptr; src.bin_tcur = nullptr; src.bin_count = nullptr; src.bin_rec_cap = src.bin_tcur_cap = src.bin_count_cap = 0; src.complete = false;
 }
 // Sets go until `need` more bytes fit under `limit` (keep: the set the pass is using).  Which: a pass over (shard, range) of
@@ -962,6 +965,62 @@ static void rec_purge(const void *db, bool to_scratch = false) {
     for (size_t i = E.rec_sets.size(); i-- > 0; ) if (!db || E.rec_sets[i]->key.db == db) rec_drop(i, false);
     if (!db || E.scratch.key.db == db) E.scratch.complete = false;
     if (!db || E.alt.key.db == db) E.alt.complete = false;
+}
+
+// ---- the partitioned scan's record streams: a private output stream per (bin, binning workgroup), no reservation atomics
+struct BinLayout { int nb = 0, nwriters = 0; size_t nstream = 0, subcap = 0, nseq = 0, need_u64 = 0;
+                   size_t bytes() const { return need_u64 * 8 + nstream * nseq * 4 + (nstream + 4) * 4; } };
+static int64_t bin_positions(const GbnDb &db, int32_t s0, int32_t s1, int lut, int step) {
+    int64_t npos = 0;
+    for (int32_t s = s0; s < s1; s++) if (db.len[s] >= lut) npos += (db.len[s] - lut) / step + 1;
+    return npos;
+}
+static int bin_layout(int nb, int64_t ntiles, int64_t npos, double slack, BinLayout &L) {
+    L.nb = nb;
+    L.nwriters = (int)std::max<int64_t>(8, std::min<int64_t>((int64_t)E.num_cu * GBN_BIN_WG_PER_CU, ntiles));
+    if (gbn::switch_is_set("GBN_BIN_WRITERS")) L.nwriters = std::max(8, std::min(L.nwriters, (int)gbn::switch_value("GBN_BIN_WRITERS", 0)));     // experiments
+    L.nstream = (size_t)nb * L.nwriters;
+    const double expect = (double)npos / (double)L.nstream + 2.0 * GBN_OPEN_LINE;   // + the pads of the stream's last line
+    L.subcap = (size_t)(expect * slack) + 256;
+    L.subcap = (L.subcap + 511) & ~(size_t)511;       // whole record blocks, whole probe pieces
+    if (L.subcap > 0x7ffffff0u) { set_error("bin capacity overflow: split the range"); return GBN_ERR_NOMEM; }
+    L.nseq = ((size_t)((ntiles + L.nwriters - 1) / L.nwriters) + ((size_t)1 << GBN_TCUR_SHIFT) - 1) >> GBN_TCUR_SHIFT;    // cursor entries per stream
+    L.need_u64 = (GBN_REC_WORDS(L.subcap * L.nstream) + 1) / 2;
+    return GBN_OK;
+}
+// the cached set that serves `key`: complete (or being written on the engine's stream), streams at least as long
+static RecordSet *rec_find(const RecKey &key) {
+    for (RecordSet *c : E.rec_sets) if ((c->complete || c->queued) && c->key.same_shape(key) && c->key.subcap >= key.subcap) return c;
+    return nullptr;
+}
+// a set to bin `key` into, its buffers sized: a cached one (room made for it) or -- larger than the whole cache -- the passes'
+// own scratch set
+static int rec_acquire(const RecKey &key, const BinLayout &L, long long limit, RecordSet **out) {
+    // a set of this shape that holds no complete records (forgotten: gbn_record_cache_invalidate; overflowed) or whose
+    // streams are shorter: its buffers serve again
+    RecordSet *old = nullptr, *rs = nullptr;
+    for (size_t i = E.rec_sets.size(); i-- > 0; ) if (E.rec_sets[i]->key.same_shape(key)) { if (!old) old = E.rec_sets[i]; else rec_drop(i, false); }
+    if ((long long)L.bytes() <= limit) {
+        if (old) rs = old;
+        else {
+            rs = new RecordSet(); E.rec_sets.push_back(rs);
+            // (the cache was switched on after passes that binned for themselves: their buffers are the first set's)
+            if (E.scratch.bin_rec) { recset_move(*rs, E.scratch); recset_free(E.alt); }
+        }
+        rec_make_room(L.bytes() > rs->bytes() ? L.bytes() - rs->bytes() : 0, limit, rs, &key, rs);
+    } else {                                         // larger than the whole cache: this pass's own
+        if (old) for (size_t i = 0; i < E.rec_sets.size(); i++) if (E.rec_sets[i] == old) { rec_drop(i, false); break; }
+        rs = &E.scratch; E.rec_bypass++;
+    }
+    int rc = recset_size(*rs, L.need_u64, L.nstream * L.nseq, L.nstream + 4);
+    if (rc == GBN_ERR_NOMEM && rs != &E.scratch) {      // the device is full: everything else the cache holds goes, once
+        rec_make_room((size_t)limit, limit, rs);
+        rc = recset_size(*rs, L.need_u64, L.nstream * L.nseq, L.nstream + 4);
+    }
+    if (rc) { if (rs != &E.scratch) { for (size_t i = 0; i < E.rec_sets.size(); i++) if (E.rec_sets[i] == rs) { rec_drop(i, false); break; } } return rc; }
+    rs->key = key; rs->complete = false; rs->queued = false;
+    *out = rs;
+    return GBN_OK;
 }
 
 // one scan of the subjects [s0, s1): fills E.seeds / cnt[0] seeds, cnt[1] raw hits;
@@ -1008,9 +1067,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     if (nb > 1 && ts.ntiles > (1 << 19)) { set_error("subject range too large for 32-bit position ids"); return GBN_ERR_ARG; }
     if ((rc = grow_seed_buffers(std::max<size_t>(E.seed_cap, (size_t)1 << 22)))) return rc;
     if (!E.scan_back) { HIPCHK(hipHostMalloc((void **)&E.scan_back, sizeof(*E.scan_back))); std::memset(E.scan_back, 0, sizeof(*E.scan_back)); }
-    int64_t npos = 0;
-    if (nb > 1)
-        for (int32_t s = s0; s < s1; s++) if (db.len[s] >= b.lut.lut) npos += (db.len[s] - b.lut.lut) / b.lut.step + 1;
+    const int64_t npos = nb > 1 ? bin_positions(db, s0, s1, b.lut.lut, b.lut.step) : 0;
     double slack = 1.25;
     size_t rare_seg_hint = 0, rare_seg_used = 0, slice_seg_cap = 0; int slice_blocks = 0; bool slice_ordered = false;
     GbnBinParams last_B; std::memset(&last_B, 0, sizeof(last_B)); int last_grid2 = 0;
@@ -1055,47 +1112,21 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             } else HIPCHK(launch_scan_seed(P, scan_grid(ts.ntiles), E.stream));
             HIPCHK(hipEventRecord(E.ev1, E.stream));
         } else {
-            // private output stream per (bin, binning workgroup): no reservation atomics
-            const int wg_per_cu = GBN_BIN_WG_PER_CU;
-            int nwriters = (int)std::max<int64_t>(8, std::min<int64_t>((int64_t)E.num_cu * wg_per_cu, ts.ntiles));
-            if (gbn::switch_is_set("GBN_BIN_WRITERS")) nwriters = std::max(8, std::min(nwriters, (int)gbn::switch_value("GBN_BIN_WRITERS", 0)));     // experiments
-            const size_t nstream = (size_t)nb * nwriters;
-            double expect = (double)npos / (double)nstream + 2.0 * GBN_OPEN_LINE;   // + the pads of the stream's last line
-            size_t subcap = (size_t)(expect * slack) + 256;
-            subcap = (subcap + 511) & ~(size_t)511;       // whole record blocks, whole probe pieces
-            if (subcap > 0x7ffffff0u) { set_error("bin capacity overflow: split the range"); return GBN_ERR_NOMEM; }
+            BinLayout BL;
+            if ((rc = bin_layout(nb, ts.ntiles, npos, slack, BL))) return rc;
+            const int nwriters = BL.nwriters; const size_t nstream = BL.nstream, nseq = BL.nseq;
+            size_t subcap = BL.subcap;
             const int rfl_now = std::min(4, b.dev->fl), rfrbits_now = std::min(7, 2 * b.dev->fr);
             RecKey key; key.db = (const void *)&db; key.s0 = s0; key.s1 = s1; key.lut = b.lut.lut; key.step = b.lut.step; key.nb = nb; key.nwriters = nwriters;
             key.rfl = rfl_now; key.rfrbits = rfrbits_now; key.cbits = GBN_BIN_CBITS(b.lut.lut); key.tiles = (const void *)P.tiles; key.subcap = subcap;
-            const size_t nseq = ((size_t)((ts.ntiles + nwriters - 1) / nwriters) + ((size_t)1 << GBN_TCUR_SHIFT) - 1) >> GBN_TCUR_SHIFT;    // cursor entries per stream
             bool hit = false, ahead_hit = false;
             Engine::BinAhead &AH = E.ahead;
             if (rec_limit > 0) {
                 // ---- record cache: a complete set of this shape whose streams are at least as long as this attempt asks for
                 if (AH.valid) { AH.valid = false; E.ahead_misses++; HIPCHK(hipStreamSynchronize(E.stream)); }     // (a kernel queued ahead writes the other scratch set, which may change hands below)
-                rs = nullptr;
-                for (RecordSet *c : E.rec_sets) if (c->complete && c->key.same_shape(key) && c->key.subcap >= subcap) { rs = c; break; }
+                rs = rec_find(key);
                 if (rs) { hit = true; subcap = rs->key.subcap; key.subcap = subcap; if (!binned_here) E.rec_hits++; }
-                else {
-                    E.rec_misses++;
-                    // a set of this shape that holds no complete records (forgotten: gbn_record_cache_invalidate; overflowed) or whose
-                    // streams are shorter: its buffers serve again
-                    RecordSet *old = nullptr;
-                    for (size_t i = E.rec_sets.size(); i-- > 0; ) if (E.rec_sets[i]->key.same_shape(key)) { if (!old) old = E.rec_sets[i]; else rec_drop(i, false); }
-                    const size_t need_bytes = (GBN_REC_WORDS(subcap * nstream) + 1) / 2 * 8 + nstream * nseq * 4 + (nstream + 4) * 4;
-                    if ((long long)need_bytes <= rec_limit) {
-                        if (old) rs = old;
-                        else {
-                            rs = new RecordSet(); E.rec_sets.push_back(rs);
-                            // (the cache was switched on after passes that binned for themselves: their buffers are the first set's)
-                            if (E.scratch.bin_rec) { recset_move(*rs, E.scratch); recset_free(E.alt); }
-                        }
-                        rec_make_room(need_bytes > rs->bytes() ? need_bytes - rs->bytes() : 0, rec_limit, rs, &key, rs);
-                    } else {                                         // larger than the whole cache: this pass's own
-                        if (old) for (size_t i = 0; i < E.rec_sets.size(); i++) if (E.rec_sets[i] == old) { rec_drop(i, false); break; }
-                        rs = &E.scratch; E.rec_bypass++;
-                    }
-                }
+                else { E.rec_misses++; if ((rc = rec_acquire(key, BL, rec_limit, &rs))) return rc; }
             } else {
                 rs = &E.scratch;
                 ahead_hit = AH.valid && AH.key == key;
@@ -1108,19 +1139,12 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 hit = !ahead_hit && binned_here && rs->complete && rs->key == key;
                 repeat_seen = E.last_key_valid && E.last_key == key;
                 E.last_key = key; E.last_key_valid = true;
-            }
-            const size_t need = subcap * nstream;
-            const size_t need_u64 = (GBN_REC_WORDS(need) + 1) / 2;
-            if (!hit && !ahead_hit) {
-                rc = recset_size(*rs, need_u64, nstream * nseq, nstream + 4);
-                if (rc == GBN_ERR_NOMEM && rec_limit > 0 && rs != &E.scratch) {      // the device is full: everything else the cache holds goes, once
-                    rec_make_room((size_t)rec_limit, rec_limit, rs);
-                    rc = recset_size(*rs, need_u64, nstream * nseq, nstream + 4);
+                if (!hit && !ahead_hit) {
+                    if ((rc = recset_size(*rs, BL.need_u64, nstream * nseq, nstream + 4))) return rc;
+                    rs->key = key; rs->complete = false;
                 }
-                if (rc) { if (rs != &E.scratch) { for (size_t i = 0; i < E.rec_sets.size(); i++) if (E.rec_sets[i] == rs) { rec_drop(i, false); break; } } return rc; }
-                rs->key = key; rs->complete = false;
-                HIPCHK(hipMemsetAsync(rs->bin_count + nstream, 0, 16, E.stream));     // (records that exist already: the flag of THAT launch is read back below)
             }
+            if (!hit && !ahead_hit) HIPCHK(hipMemsetAsync(rs->bin_count + nstream, 0, 16, E.stream));     // (records that exist already: the flag of THAT launch is read back below)
             rs->stamp = ++E.rec_clock;
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
             B.S = P; B.nb = nb; B.cbits = GBN_BIN_CBITS(b.lut.lut); B.nwriters = nwriters; dbg_nwriters = nwriters; dbg_subcap = (uint32_t)subcap;
@@ -1180,7 +1204,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         trace_mark("scan: kernels done");
         cnt[0] = E.scan_back->cnt[0]; cnt[1] = E.scan_back->cnt[1];
         const unsigned long long seg_max = sliced ? E.scan_back->seg_max : 0;
-        if (binned) { overflow = E.scan_back->overflow; rs->complete = overflow == 0; binned_here = rs->complete; }
+        if (binned) { overflow = E.scan_back->overflow; rs->complete = overflow == 0; rs->queued = false; binned_here = rs->complete; }
         finish_build(b.dev);                                // (the scan has waited for the builder's event)
         if (diag) {
             float ms = 0, ahead_ms = 0;
@@ -1933,7 +1957,7 @@ int gbn_record_cache_invalidate(void) {
     const int rc = enter_current();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(E.mu);
-    for (RecordSet *r : E.rec_sets) r->complete = false;
+    for (RecordSet *r : E.rec_sets) { if (r->queued) (void)hipStreamSynchronize(E.stream); r->complete = false; r->queued = false; }
     E.scratch.complete = false;
     if (E.ahead.valid) { (void)hipStreamSynchronize(E.stream); E.ahead.valid = false; }
     E.last_key_valid = false;
@@ -1946,8 +1970,8 @@ int gbn_record_cache_stats(long long *out, int n) {
     const int rc = enter_current();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(E.mu);
-    const long long v[8] = {rec_limit_bytes(), (long long)rec_held_bytes(), (long long)E.rec_sets.size(), E.rec_hits, E.rec_misses, E.rec_evictions, E.rec_bypass, E.ahead_hits};
-    for (int i = 0; i < n && i < 8; i++) out[i] = v[i];
+    const long long v[9] = {rec_limit_bytes(), (long long)rec_held_bytes(), (long long)E.rec_sets.size(), E.rec_hits, E.rec_misses, E.rec_evictions, E.rec_bypass, E.ahead_hits, E.rec_prepared};
+    for (int i = 0; i < n && i < 9; i++) out[i] = v[i];
     return GBN_OK;
     });
 }
@@ -2458,6 +2482,96 @@ const GbnSeed *gbn_results_seeds(const GbnResults *r) { return r->seeds.data(); 
 int64_t gbn_results_num_init_hits(const GbnResults *r) { return (int64_t)r->init_hits.size(); }
 const GbnInitHit *gbn_results_init_hits(const GbnResults *r) { return r->init_hits.data(); }
 
+// The subject ranges a shard is searched in: bounded by packed size so that scratch stays modest, and by the width of
+// the position ids.
+static void plan_ranges(const GbnDb &dbr, int step, std::vector<std::pair<int32_t, int32_t>> &out) {
+    const GbnDb *db = &dbr;
+    int64_t range_gib = 16;
+    if (gbn::switch_is_set("GBN_RANGE_GIB")) range_gib = (int)std::max<long long>(1, gbn::switch_value("GBN_RANGE_GIB", 0));
+    int64_t range_bytes = range_gib << 30;
+    if (gbn::switch_is_set("GBN_RANGE_MIB")) range_bytes = (int64_t)std::max<long long>(1, gbn::switch_value("GBN_RANGE_MIB", 0)) << 20;    // tests
+    // Hard limits of a range: packed bytes (scratch) and 32-bit position ids.  Seed-rich shapes (small
+    // stride) are cut into ~1 G scan positions, so that the seed / extension stages of one range run
+    // underneath the scan of the next.  Whatever number of ranges that takes, they are made equal:
+    // a big range followed by a small remainder would leave nothing to overlap with.
+    int64_t tile_limit = ((int64_t)1 << (32 - GBN_BIN_TILE_BITS)) - 1;
+    if (step <= 4) tile_limit = std::min<int64_t>(tile_limit, (int64_t)1 << 17);
+    if (gbn::switch_is_set("GBN_RANGE_TILES")) tile_limit = (int)std::max<long long>(1, gbn::switch_value("GBN_RANGE_TILES", 0));                  // tests
+    auto tiles_of = [&](int32_t s) { return (int64_t)(db->len[s] / step) / GBN_BIN_TILE_POS + 1; };
+    int64_t all_bytes = 0, all_tiles = 0;
+    for (int32_t s = 0; s < db->num_seqs; s++) { all_bytes += (db->len[s] + 3) / 4; all_tiles += tiles_of(s); }
+    const int64_t nranges = std::max<int64_t>(1, std::max((all_bytes + range_bytes - 1) / range_bytes, (all_tiles + tile_limit - 1) / tile_limit));
+    const int64_t want_bytes = (all_bytes + nranges - 1) / nranges, want_tiles = (all_tiles + nranges - 1) / nranges;
+    int32_t s0 = 0;
+    while (s0 < db->num_seqs) {
+        int32_t s1 = s0; int64_t acc = 0, tiles = 0;
+        while (s1 < db->num_seqs) {
+            const int64_t nb = (db->len[s1] + 3) / 4, nt = tiles_of(s1);
+            if (s1 > s0 && (acc + nb > range_bytes || tiles + nt > tile_limit)) break;       // hard limits
+            if (s1 > s0 && (acc >= want_bytes || tiles >= want_tiles)) break;                // equal shares
+            acc += nb; tiles += nt; s1++;
+        }
+        out.emplace_back(s0, s1);
+        s0 = s1;
+    }
+}
+// The scan records a query batch of these lengths will want of this shard, queued NOW: the binning kernel reads the
+// subjects only, so a caller that knows its next batch's size starts it before the batch is set up -- the kernel runs
+// underneath the batch's set-up (host work + table build: 5 ms for a 5 Mb batch), and the batch's pass finds the set in the
+// record cache (queued on the engine's stream, in front of its own probe kernel).  Returns at once; does nothing when the
+// record cache is off, when the predicted table is scanned without records (lut = word, tiny tables), or when the sets are
+// there already.  A batch that comes out with another shape (masked queries near a threshold of the table choice) bins for
+// itself as ever.
+int gbn_db_prepare_records(GbnDb *db, const GbnOptions *opt, int32_t nq, const int32_t *lens) {
+    return gbn::guard(__func__, [&]() -> int {
+    if (!db || !opt || nq <= 0 || !lens || !db->engine) { set_error("gbn_db_prepare_records: bad argument"); return GBN_ERR_ARG; }
+    enter(static_cast<Engine *>(db->engine));
+    if (!E.ready) { set_error("the engine was released (gbn_release) after this shard was made"); return GBN_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(E.mu);
+    int type = 0, lut = 0, step = 0;
+    gbn::predict_table_shape(*opt, nq, lens, type, lut, step);
+    const int word = opt->word_size;
+    int64_t nb = ((int64_t)1 << (2 * lut)) >> GBN_BIN_CBITS(lut);
+    if (lut == word || nb < 2 || nb > GBN_BIN_MAXNB || gbn::switch_value("GBN_SCAN_BINS", 0) == 1 || opt->db_num_seqs == 0) return GBN_OK;
+    const long long limit = rec_limit_bytes();
+    if (limit <= 0) return GBN_OK;
+    // fingerprint widths as upload_batch derives them from word - lut
+    const int e = word - lut, h = (e + 1) / 2;
+    const int fl = std::min(8, h), fr = std::min(7, e - h + 1);
+    std::vector<std::pair<int32_t, int32_t>> ranges;
+    plan_ranges(*db, step, ranges);
+    for (const auto &rg : ranges) {
+        const int32_t s0 = rg.first, s1 = rg.second;
+        const TileSet *tsp = nullptr;
+        int rc = get_tiles(*db, lut, step, GBN_BIN_TILE_POS, s0, s1, &tsp);
+        if (rc) return rc;
+        if (tsp->ntiles == 0 || tsp->ntiles > (1 << 19)) continue;
+        BinLayout BL;
+        if (bin_layout((int)nb, tsp->ntiles, bin_positions(*db, s0, s1, lut, step), 1.25, BL)) continue;
+        RecKey key; key.db = (const void *)db; key.s0 = s0; key.s1 = s1; key.lut = lut; key.step = step; key.nb = (int)nb; key.nwriters = BL.nwriters;
+        key.rfl = std::min(4, fl); key.rfrbits = std::min(7, 2 * fr); key.cbits = GBN_BIN_CBITS(lut); key.tiles = (const void *)tsp->d_tiles; key.subcap = BL.subcap;
+        if (rec_find(key)) continue;
+        if ((long long)BL.bytes() > limit) continue;        // (larger than the whole cache: the pass bins into its own scratch)
+        if (E.ahead.valid) { E.ahead.valid = false; E.ahead_misses++; HIPCHK(hipStreamSynchronize(E.stream)); }
+        RecordSet *rs = nullptr;
+        if ((rc = rec_acquire(key, BL, limit, &rs))) return rc;
+        GbnBinParams B; std::memset(&B, 0, sizeof(B));
+        B.S.db = db->d_packed; B.S.byte_off = db->d_byte_off; B.S.len = db->d_len; B.S.tiles = tsp->d_tiles; B.S.ntiles = tsp->ntiles;
+        B.S.ncells = (int64_t)1 << (2 * lut); B.S.lut = lut; B.S.word = word; B.S.step = step; B.S.fl = fl; B.S.fr = fr;
+        B.nb = (int)nb; B.cbits = GBN_BIN_CBITS(lut); B.nwriters = BL.nwriters; B.rfl = key.rfl; B.rfrbits = key.rfrbits;
+        B.rec = reinterpret_cast<uint32_t *>(rs->bin_rec); B.tcur = rs->bin_tcur; B.nseq = (uint32_t)BL.nseq; B.gcount = rs->bin_count; B.subcap = (uint32_t)BL.subcap;
+        B.overflow = rs->bin_count + BL.nstream;
+        if (!E.rare_counts && (rc = dev_alloc(E.rare_counts, (size_t)2048))) return rc;
+        B.rare_counts = E.rare_counts;                      // (where a GBN_BIN_TIMING build leaves its clocks)
+        HIPCHK(hipMemsetAsync(rs->bin_count + BL.nstream, 0, 16, E.stream));
+        HIPCHK(launch_scan_bin_parts(B, std::max(8, E.num_cu & ~7), E.stream, nullptr, 1, nullptr));
+        rs->queued = true; rs->stamp = ++E.rec_clock;
+        E.rec_prepared++;
+    }
+    return GBN_OK;
+    });
+}
+
 // argument checks of the search entry points; the calling thread enters the engine the batch and the shard live on
 static int search_enter(GbnBatch *batch, GbnDb *db, GbnResults *results) {
     if (!batch || !db || !results) { set_error("bad argument"); return GBN_ERR_ARG; }
@@ -2499,39 +2613,15 @@ static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
             if (interrupt && interrupt(progress)) { set_error("interrupted"); return GBN_ERR_INTERRUPTED; }
         }
     } else {
-        // ranges of subjects bounded by packed size so that scratch stays modest
-        int64_t range_gib = 16;
-        if (gbn::switch_is_set("GBN_RANGE_GIB")) range_gib = (int)std::max<long long>(1, gbn::switch_value("GBN_RANGE_GIB", 0));
-        int64_t range_bytes = range_gib << 30;
-        if (gbn::switch_is_set("GBN_RANGE_MIB")) range_bytes = (int64_t)std::max<long long>(1, gbn::switch_value("GBN_RANGE_MIB", 0)) << 20;    // tests
-        // Hard limits of a range: packed bytes (scratch) and 32-bit position ids.  Seed-rich shapes (small
-        // stride) are cut into ~1 G scan positions, so that the seed / extension stages of one range run
-        // underneath the scan of the next.  Whatever number of ranges that takes, they are made equal:
-        // a big range followed by a small remainder would leave nothing to overlap with.
-        const int step = batch->lut.step;
-        int64_t tile_limit = ((int64_t)1 << (32 - GBN_BIN_TILE_BITS)) - 1;
-        if (step <= 4) tile_limit = std::min<int64_t>(tile_limit, (int64_t)1 << 17);
-        if (gbn::switch_is_set("GBN_RANGE_TILES")) tile_limit = (int)std::max<long long>(1, gbn::switch_value("GBN_RANGE_TILES", 0));                  // tests
-        auto tiles_of = [&](int32_t s) { return (int64_t)(db->len[s] / step) / GBN_BIN_TILE_POS + 1; };
-        int64_t all_bytes = 0, all_tiles = 0;
-        for (int32_t s = 0; s < db->num_seqs; s++) { all_bytes += (db->len[s] + 3) / 4; all_tiles += tiles_of(s); }
-        const int64_t nranges = std::max<int64_t>(1, std::max((all_bytes + range_bytes - 1) / range_bytes, (all_tiles + tile_limit - 1) / tile_limit));
-        const int64_t want_bytes = (all_bytes + nranges - 1) / nranges, want_tiles = (all_tiles + nranges - 1) / nranges;
-        int32_t s0 = 0;
-        while (s0 < db->num_seqs) {
-            int32_t s1 = s0; int64_t acc = 0, tiles = 0;
-            while (s1 < db->num_seqs) {
-                const int64_t nb = (db->len[s1] + 3) / 4, nt = tiles_of(s1);
-                if (s1 > s0 && (acc + nb > range_bytes || tiles + nt > tile_limit)) break;       // hard limits
-                if (s1 > s0 && (acc >= want_bytes || tiles >= want_tiles)) break;                // equal shares
-                acc += nb; tiles += nt; s1++;
-            }
+        std::vector<std::pair<int32_t, int32_t>> ranges;
+        plan_ranges(*db, batch->lut.step, ranges);
+        for (const auto &rg : ranges) {
+            const int32_t s0 = rg.first, s1 = rg.second;
             E.want_ahead = overlap && !keep_stages && s0 == 0 && s1 == db->num_seqs && batch->lut.lut != batch->lut.word && gbn::switch_value("GBN_BIN_AHEAD", 1) != 0;    // the pass is ONE range (the next pass of a pipelined caller bins the same) of a megablast shape (a handful of seeds: their stages run on the second stream)
             rc = search_range(*batch, *db, s0, s1, *results, diag, keep_stages, overlap);
             E.want_ahead = false;
             if (rc) return rc;
             if (interrupt && interrupt(progress)) { set_error("interrupted"); return GBN_ERR_INTERRUPTED; }
-            s0 = s1;
         }
     }
     if (diag) diag->total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();

@@ -131,6 +131,7 @@ struct QueryMask { int32_t query, from, to; };      // soft mask, plus-strand co
 int  build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq,
                  const uint8_t *const *seqs, const int32_t *lens,
                  const std::vector<QueryMask> &masks = std::vector<QueryMask>(), bool host_tables = true);
+void predict_table_shape(const GbnOptions &opt, int32_t nq, const int32_t *lens, int &type, int &lut, int &step);   // batch.cpp
 void fill_lookup_host(GbnBatch &b);     // the host-side table builder (host-only set-up, GBN_HOST_LOOKUP=1)
 int  upload_batch(GbnBatch &b);
 void free_device_batch(DeviceBatch *d);

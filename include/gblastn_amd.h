@@ -183,10 +183,17 @@ long long gbn_debug_bin_ahead_misses(void);     /* ... and binning kernels queue
  * life of the process the same way: its per-OID subject cache, GB/gpu_blastn_MB_and_smallNa.cu:1461-1468.
  * limit: bytes the cache may hold; 0: off (every pass bins for itself); < 0: the default -- GBN_RECORD_CACHE_MB, else a
  * quarter of the device's memory.  stats: out[0..n) of {limit, bytes held, sets, passes served from the cache, passes
- * that binned, sets evicted, passes whose set is larger than the whole cache, passes served by a kernel queued ahead}. */
+ * that binned, sets evicted, passes whose set is larger than the whole cache, passes served by a kernel queued ahead,
+ * sets queued by gbn_db_prepare_records}. */
 int  gbn_record_cache_set_limit(long long bytes);
 int  gbn_record_cache_stats(long long *out, int n);
 int  gbn_record_cache_invalidate(void);     /* every cached set forgets its records (its buffers stay): the next pass of each key bins again */
+/* The scan records a batch of nq unmasked queries of these lengths will want of `db`, binned NOW, asynchronously: the binning
+ * kernel needs no lookup table, so it runs underneath the set-up of the batch (gbn_batch_new*), whose pass then finds the
+ * records in the cache.  Returns at once.  No effect when the cache is off, when such a batch is scanned without records
+ * (tables as wide as the word, tiny tables), or when the records are resident. */
+struct GbnOptions;
+int  gbn_db_prepare_records(struct GbnDb *db, const struct GbnOptions *opt, int32_t nq, const int32_t *lens);
 /* A VIEW over resident blocks: their subjects as ONE shard (one tile table, one launch per kernel, one record set), for
  * the shim's loop over OID chunks (GB/gpu_blastn_pre_search_engine.cpp:1243-1441 searches chunk after chunk inside one
  * call).  No subject byte is copied: the view addresses every block's slab from the lowest one.  Views are cached by their

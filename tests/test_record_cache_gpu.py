@@ -265,3 +265,43 @@ def test_sweeps_over_more_ranges_than_the_cache_holds_still_hit(cache_default):
     assert st["hits"] - st0["hits"] >= 4, (st, st0)             # (least recently used first: 1, the very first pass)
     assert st["evictions"] - st0["evictions"] >= 3
     ps.close()
+
+
+def test_records_prepared_ahead_of_the_batch(cache_default):
+    """gbn_db_prepare_records queues the binning kernel for the table shape a batch of these query lengths gets -- before the
+    batch exists; the batch's pass finds the set (still being written on the engine's stream) and probes it.  The predicted
+    shape is the batch's shape for megablast batches of several sizes; a blastn batch whose table is as wide as the word
+    prepares nothing; a shard freed right behind the call takes its half-written records with it."""
+    subjects, opt, qa, qb, qc = _shapes_case()
+    src = api.BlastSeqSrc.from_packed(subjects)
+    api.record_cache_set_limit(0)
+    want = {}
+    for name, q in (("a", qa), ("c", qc)):
+        ps = api.BlastPrelimSearch(q, opt, src); want[name] = ps.run()["hsps"].tobytes(); ps.close()
+    api.record_cache_set_limit(-1)
+    for name, q in (("a", qa), ("c", qc), ("a", qa)):
+        api.record_cache_invalidate()
+        st0 = api.record_cache_stats()
+        src.prepare_records(opt, q)
+        st1 = api.record_cache_stats()
+        assert st1["prepared"] - st0["prepared"] == 1
+        src.prepare_records(opt, q)                                 # queued already: nothing more
+        assert api.record_cache_stats()["prepared"] == st1["prepared"]
+        ps = api.BlastPrelimSearch(q, opt, src)
+        assert ps.run()["hsps"].tobytes() == want[name]
+        assert ps.run()["hsps"].tobytes() == want[name]
+        st2 = api.record_cache_stats()
+        assert (st2["misses"] - st0["misses"], st2["hits"] - st0["hits"]) == (0, 2), (name, st0, st2)
+        ps.close()
+    optn = api.default_options("blastn", db_length=opt.db_length, db_num_seqs=opt.db_num_seqs)
+    p0 = api.record_cache_stats()["prepared"]
+    src.prepare_records(optn, qa)                                   # lut 11 = word 11: the slice scan keeps no records
+    assert api.record_cache_stats()["prepared"] == p0
+    api.record_cache_invalidate()
+    src.prepare_records(opt, qa)
+    src.close()                                                     # the kernel may still be writing
+    assert api.record_cache_stats()["sets"] == 0
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(qa, opt, src)
+    assert ps.run()["hsps"].tobytes() == want["a"]
+    ps.close(); src.close()
