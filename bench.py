@@ -45,7 +45,8 @@ def parse():
                     help="C2 (the metric's config): megablast W=28 vs 50 Gbp; C3: blastn W=11 vs 5 Gbp, 100 kb batches; "
                          "C4: 100k queries streamed in 5 Mb batches through the host pipeline, CPU traceback overlapped with the GPU stages; "
                          "shim: the C2 shard as 100 resident blocks searched the way gblastn_amd/shim/gpu_blastn_amd_shim.cpp searches them")
-    ap.add_argument("--trace-threads", type=int, default=4, help="C4: traceback consumer threads")
+    ap.add_argument("--trace-threads", type=int, default=0, help="C4: traceback consumer threads (0: a quarter of the host cores, 4 .. 16; round 4 ran 4, "
+                                                                  "with which the traceback of a batch, not the GPU, sets the pace once the records are cached)")
     ap.add_argument("--no-traceback", action="store_true", help="C4 diagnostics: the pipeline without its traceback stage")
     ap.add_argument("--subjects", type=int, default=None, help="subjects per GPU shard")
     ap.add_argument("--subject-len", type=int, default=1_000_000)
@@ -74,6 +75,8 @@ def parse():
         a.steps = 20                                    # 100,000 queries = 20 batches of 5,000
     if a.workload == "shim" and "--steps" not in " ".join(sys.argv):
         a.steps = 10
+    if a.trace_threads <= 0:
+        a.trace_threads = max(4, min(16, (os.cpu_count() or 16) // 4))
     if a.subjects is None:
         a.subjects = 5_000 if a.workload == "C3" else 50_000
     if a.batch_queries is None:
