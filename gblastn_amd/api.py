@@ -49,7 +49,7 @@ class GbnDiagnostics(C.Structure):
                 ("seed_stage_ms", C.c_double), ("gapped_stage_ms", C.c_double),
                 ("host_stage_ms", C.c_double), ("kernel_ms", C.c_double * 8)]
     KERNEL_CLASSES = ["seed keys", "seed order (radix sort / seed_order kernels)", "seed_ext_ck_kernel + seed_exact_kernel", "diag_replay_kernel", "diag_ungapped_kernel",
-                      "dynprog_lane_kernel", "dynprog_wave_kernel", "dynprog_kernel / greedy_kernel"]
+                      "dynprog_lane_kernel", "dynprog_wave_kernel / greedy_wave_kernel", "dynprog_kernel / greedy_kernel"]
 
 
 HSP_DT = np.dtype([("oid", "<i4"), ("context", "<i4"), ("q_offset", "<i4"), ("q_end", "<i4"),

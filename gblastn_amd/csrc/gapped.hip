@@ -254,6 +254,182 @@ __device__ void greedy_hit(const GbnGapParams &P, int64_t i, int64_t slot)
 }
 }  // namespace
 
+// ---------------------------------------------------------------------------
+// greedy_wave_kernel: BLAST_GreedyAlign with the diagonals of a distance across the lanes of a wave.
+// The thread-per-hit kernel below walks ~d diagonals per distance d one after the other, each with a dependent chain of
+// scattered loads (the match run): ~2,000 round trips to memory per initial hit, 2.1 ms for the 1,900 hits of a C2 pass on 30
+// waves.  Here a workgroup of two waves takes one hit -- wave 0 its right half, wave 1 its left half -- and a lane takes one
+// diagonal: the furthest-reaching offsets of two distances live in a window of the wave's LDS, the match runs of a distance
+// are in flight together, and what the reference's loop over the diagonals decides one by one (diag_lower / diag_upper, which
+// cells are marked invalid, the furthest point, the longest run) comes out of four lane masks and two wave-wide maxima in
+// closed form.  Same reads and writes of the same cells as greedy_linear (the oracle's order), so the same scores and boxes;
+// a half that needs more distance than the window holds (GBN_GW_DMAX) is left to greedy_kernel (GBN_GAP_REDO).
+// ---------------------------------------------------------------------------
+namespace {
+#define GBN_GW_C    256         // LDS row window: diagonals -254 .. +254 around the start diagonal
+#define GBN_GW_DMAX 250
+#define GBN_GW_MS   512         // max_score window
+
+__device__ __forceinline__ int32_t wave_max_i32(int32_t v)
+{
+    #pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) v = max(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ int32_t greedy_linear_wave(const GQ &q, int32_t len1, const uint8_t *subj, int32_t s_base, int32_t len2,
+                                      bool reverse, int32_t xdrop, int32_t match_cost, int32_t mismatch_cost,
+                                      int32_t *l1, int32_t *l2, GSeed &seed, int32_t *row0, int32_t *row1,
+                                      int32_t *max_score_base, bool &redo)
+{
+    const int32_t kInvalid = -2;
+    const int lane = (int)(threadIdx.x & 63);
+    const unsigned long long lane_lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const int32_t max_dist = min(10000, len2 / 2 + 1);
+    const int32_t xdrop_offset = (xdrop + match_cost / 2) / (match_cost + mismatch_cost) + 1;
+    int32_t index = reverse ? match_run_rev(q, subj, len1, len2, 0, 0) : match_run_fwd(q, subj, len1, len2, 0, 0, s_base);
+    index = __builtin_amdgcn_readfirstlane(index);
+    *l1 = index; *l2 = index;
+    seed.start_q = 0; seed.start_s = 0; seed.match_length = index;
+    int32_t longest = index, best_dist = 0;
+    if (index == len1 || index == len2) return 0;
+    if (xdrop_offset > GBN_GW_MS - GBN_GW_DMAX - 2) { redo = true; return 0; }
+    int32_t *max_score = max_score_base + xdrop_offset;
+    for (int32_t t = lane; t < xdrop_offset; t += 64) max_score_base[t] = 0;
+    if (lane == 0) { row0[GBN_GW_C] = index; max_score[0] = index * match_cost; }
+    // diagonals relative to the start diagonal: kk = k - diag_origin, seq1_index = seq2_index + kk
+    int32_t dl = -1, du = 1;
+    bool end1 = false, end2 = false;
+    for (int32_t d = 1; d <= max_dist; d++) {
+        if (d > GBN_GW_DMAX) { redo = true; return 0; }
+        const int32_t tl = dl, tu = du;
+        int32_t *prev = ((d - 1) & 1) ? row1 : row0, *cur = (d & 1) ? row1 : row0;
+        if (lane == 0) {
+            prev[GBN_GW_C + dl - 1] = kInvalid; prev[GBN_GW_C + dl] = kInvalid;
+            prev[GBN_GW_C + du] = kInvalid; prev[GBN_GW_C + du + 1] = kInvalid;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        int32_t xs = max_score[d - xdrop_offset] + (match_cost + mismatch_cost) * d - xdrop;
+        xs = (int32_t)ceil((double)xs / (double)(match_cost / 2));
+        int32_t curr_extent = 0, curr_seq2 = 0, curr_kk = 0;
+        bool open = true, any_pass = false, last_h1 = false; int32_t last_pass_kk = 0;
+        for (int32_t base = tl; base <= tu; base += 64) {
+            const int32_t kk = base + lane;
+            const bool valid = kk <= tu;
+            int32_t s2 = kInvalid, s1 = 0, idx = 0;
+            if (valid) {
+                s2 = max(prev[GBN_GW_C + kk + 1], prev[GBN_GW_C + kk]) + 1;
+                s2 = max(s2, prev[GBN_GW_C + kk - 1]);
+                s1 = s2 + kk;
+            }
+            const bool pass = valid && !(s2 < 0 || s1 + s2 < xs);
+            if (pass) idx = reverse ? match_run_rev(q, subj, len1, len2, s1, s2) : match_run_fwd(q, subj, len1, len2, s1, s2, s_base);
+            const int32_t e1 = s1 + idx, e2 = s2 + idx;
+            const unsigned long long P = __ballot(pass), F = __ballot(valid && !pass);
+            const unsigned long long H2 = __ballot(pass && e2 == len2), H1 = __ballot(pass && e1 == len1);
+            // cells: a passing diagonal stores its offset; a failing one is marked invalid unless it sits in the run of failures
+            // that moves diag_lower up (nothing passed below it since the start of the row or since a diagonal that reached
+            // the end of the subject: there the reference leaves the cell as it is)
+            if (pass) cur[GBN_GW_C + kk] = e2;
+            else if (valid) {
+                const unsigned long long below = P & lane_lt;
+                const bool moves_lower = below ? (((H2 >> (63 - __clzll((long long)below))) & 1ull) != 0) : open;
+                if (!moves_lower) cur[GBN_GW_C + kk] = kInvalid;
+            }
+            if (H2) {
+                const int hl = 63 - __clzll((long long)H2);
+                const unsigned long long after = hl == 63 ? 0ull : (F >> (hl + 1));
+                const int run = (~after) ? (__ffsll((long long)~after) - 1) : 64;
+                dl = base + hl + 1 + run;
+            } else if (open) {
+                const int nvalid = min(64, tu - base + 1);
+                dl += P ? (__ffsll((long long)P) - 1) : nvalid;
+            }
+            if (P) {
+                const int hp = 63 - __clzll((long long)P);
+                open = ((H2 >> hp) & 1ull) != 0; any_pass = true; last_pass_kk = base + hp; last_h1 = ((H1 >> hp) & 1ull) != 0;
+            }
+            end1 = end1 || H1 != 0; end2 = end2 || H2 != 0;
+            // the furthest point of this distance (the first diagonal that reaches it) and the longest run so far
+            const int32_t ext = pass ? e1 + e2 : -1;
+            const int32_t m = wave_max_i32(ext);
+            if (m > curr_extent) {
+                const int who = __ffsll((long long)__ballot(pass && ext == m)) - 1;
+                curr_extent = m; curr_seq2 = __shfl(e2, who, 64); curr_kk = base + who;
+            }
+            const int32_t mi = wave_max_i32(pass ? idx : -1);
+            if (mi > longest) {
+                const int who = __ffsll((long long)__ballot(pass && idx == mi)) - 1;
+                longest = mi; seed.start_q = __shfl(s1, who, 64); seed.start_s = __shfl(s2, who, 64); seed.match_length = mi;
+            }
+        }
+        if (any_pass) du = last_h1 ? last_pass_kk - 1 : last_pass_kk;
+        const int32_t curr_score = curr_extent * (match_cost / 2) - d * (match_cost + mismatch_cost);
+        const int32_t before = max_score[d - 1];
+        int32_t now_best = before;
+        if (curr_score > before) { now_best = curr_score; best_dist = d; *l2 = curr_seq2; *l1 = curr_seq2 + curr_kk; }
+        if (lane == 0) max_score[d] = now_best;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        if (dl > du) break;
+        if (!end2) dl--;
+        if (!end1) du++;
+    }
+    return best_dist;
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(128) greedy_wave_kernel(GbnGapParams P)
+{
+    __shared__ int32_t rows[2][2][2 * GBN_GW_C + 8];
+    __shared__ int32_t msb[2][GBN_GW_MS + 8];
+    __shared__ int32_t half_out[2][8];        // dist, l1, l2, seed.start_q, seed.start_s, seed.match_length, redo
+    const int w = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+    for (int64_t i = blockIdx.x; i < P.n; i += gridDim.x) {
+        const GbnDevInitHit h = P.ihits[P.first + i];
+        const uint8_t *__restrict__ subj = P.db + P.byte_off[h.subj];
+        const int32_t slen = P.len[h.subj];
+        int lo = 0, hi = P.nctx;
+        while (lo < hi - 1) { int m = (lo + hi) >> 1; if (P.ctx_off[m] > h.q_off) hi = m; else lo = m; }
+        const int32_t qstart = P.ctx_off[lo], qlen = P.ctx_len[lo];
+        const GQ q = {P.q2, P.qinv, (int64_t)qstart};
+        const int32_t q_off = h.q_start - qstart + h.length / 2, s_off = h.s_start + h.length / 2;
+        const int32_t reward = P.reward, pen = -P.penalty;
+        int32_t X = P.xdrop, mc = reward, mm = pen;
+        if (mc % 2 == 1) { mc *= 2; mm *= 2; X *= 2; }
+        int32_t a1 = 0, a2 = 0; GSeed sd; bool redo = false;
+        int32_t dist;
+        if (w == 0) dist = greedy_linear_wave(q + q_off, qlen - q_off, subj, s_off, slen - s_off, false, X, mc, mm, &a1, &a2, sd, rows[0][0], rows[0][1], msb[0], redo);
+        else dist = greedy_linear_wave(q, q_off, subj, 0, s_off, true, X, mc, mm, &a1, &a2, sd, rows[1][0], rows[1][1], msb[1], redo);
+        if (lane == 0) {
+            int32_t *o = half_out[w];
+            o[0] = dist; o[1] = a1; o[2] = a2; o[3] = sd.start_q; o[4] = sd.start_s; o[5] = sd.match_length; o[6] = redo ? 1 : 0;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const int32_t *f = half_out[0], *r = half_out[1];
+            GbnDevGapped g;
+            if (f[6] || r[6]) { g.q_start = g.q_stop = g.s_start = g.s_stop = g.seed_q = g.seed_s = 0; g.context = lo; g.score = GBN_GAP_REDO; }
+            else {
+                const int32_t qr = f[1], sr = f[2], ql = r[1], sl = r[2];
+                const int32_t score = (qr + sr + ql + sl) * reward / 2 - (f[0] + r[0]) * (reward - P.penalty);
+                const int32_t q_box_l = q_off - ql, s_box_l = s_off - sl, q_box_r = q_off + qr, s_box_r = s_off + sr;
+                int32_t qsl = q_off - r[3], ssl = s_off - r[4];
+                int32_t qsr = q_off + f[3], ssr = s_off + f[4];
+                int32_t vl = 0, vr = 0;
+                if (qsr < q_box_r && ssr < s_box_r) { vr = min(min(q_box_r - qsr, s_box_r - ssr), f[5]) / 2; }
+                else { qsr = q_off; ssr = s_off; }
+                if (qsl > q_box_l && ssl > s_box_l) { vl = min(min(qsl - q_box_l, ssl - s_box_l), r[5]) / 2; }
+                else { qsl = q_off; ssl = s_off; }
+                if (vr > vl) { g.seed_q = qsr + vr; g.seed_s = ssr + vr; } else { g.seed_q = qsl - vl; g.seed_s = ssl - vl; }
+                g.q_start = q_box_l; g.s_start = s_box_l; g.q_stop = q_box_r; g.s_stop = s_box_r;
+                g.score = score; g.context = lo;
+            }
+            P.out[P.first + i] = g;
+        }
+        __syncthreads();
+    }
+}
+
 // The gapped kernels run on the second stream underneath the next range's scan, whose kernels need whole
 // CUs (one 1024-thread workgroup + most of the LDS each): a grid sized to the initial hits would fill
 // every wave slot for as long as its longest extension lasts and keep those workgroups waiting.  So the
@@ -262,7 +438,10 @@ __device__ void greedy_hit(const GbnGapParams &P, int64_t i, int64_t slot)
 extern "C" __global__ void greedy_kernel(GbnGapParams P)
 {
     const int64_t slot = (int64_t)blockIdx.x * blockDim.x + threadIdx.x, total = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = slot; i < P.n; i += total) greedy_hit(P, i, slot);
+    for (int64_t i = slot; i < P.n; i += total) {
+        if (P.redo_only && P.out[P.first + i].score != GBN_GAP_REDO) continue;     // second launch: what greedy_wave_kernel left
+        greedy_hit(P, i, slot);
+    }
 }
 
 namespace {
@@ -930,7 +1109,21 @@ hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st, Gbn
     if (p.n <= 0) return hipSuccess;
     const int64_t need = (p.n + 63) / 64;
     const unsigned blocks = (unsigned)std::max<int64_t>(1, p.max_blocks > 0 ? std::min<int64_t>(need, p.max_blocks) : need);
-    if (greedy) { mark(GBN_KT_THREAD_GAP); hipLaunchKernelGGL(greedy_kernel, dim3(blocks), dim3(64), 0, st, p); mark(-1); return hipGetLastError(); }
+    if (greedy) {
+        // linear gap costs (megablast's default 0 / 0): a workgroup of two waves per initial hit, the diagonals of a distance across
+        // the lanes (greedy_wave_kernel); what needs more distance than its LDS window holds, and affine costs: a thread per hit
+        GbnGapParams r = p;
+        const bool wave = p.gap_open == 0 && p.gap_extend == 0 && gbn::switch_value("GBN_GREEDY_WAVE", 1) != 0;
+        if (wave) {
+            const unsigned wblocks = (unsigned)std::max<int64_t>(1, std::min<int64_t>(p.n, p.max_blocks > 0 ? (int64_t)p.max_blocks * 8 : p.n));
+            mark(GBN_KT_WAVE_DP);
+            hipLaunchKernelGGL(greedy_wave_kernel, dim3(wblocks), dim3(128), 0, st, p);
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            r.redo_only = 1;
+        }
+        mark(GBN_KT_THREAD_GAP); hipLaunchKernelGGL(greedy_kernel, dim3(blocks), dim3(64), 0, st, r); mark(-1); return hipGetLastError();
+    }
     // blastn, three kernels: one extension per LANE with the band in LDS (dynprog_lane_kernel: the many short
     // extensions of chance hits); what it leaves (GBN_GAP_REDO: a window wider than its LDS slots, a long run) one
     // extension per WAVE with the band in registers; what that leaves (a band wider than a wave, gap_extend 0) the

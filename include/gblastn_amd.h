@@ -118,7 +118,7 @@ typedef struct GbnInitHit {
 #define GBN_KT_REPLAY      3   /* run_heads_kernel + diag_replay_kernel */
 #define GBN_KT_DIAG        4   /* diag_ungapped_kernel (few seeds: filter + extension in one) */
 #define GBN_KT_LANE_DP     5   /* gap_context_kernel + dynprog_lane_kernel */
-#define GBN_KT_WAVE_DP     6   /* dynprog_wave_kernel */
+#define GBN_KT_WAVE_DP     6   /* dynprog_wave_kernel (blastn) / greedy_wave_kernel (megablast) */
 #define GBN_KT_THREAD_GAP  7   /* dynprog_kernel / greedy_kernel */
 #define GBN_KT_N           8
 typedef struct GbnDiagnostics {

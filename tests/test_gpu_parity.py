@@ -817,3 +817,62 @@ def test_rare_queue_segments_that_overflow_are_scanned_again(monkeypatch):
     for _ in range(3):                                  # pipelined passes
         ps.begin(); assert ps.end()["hsps"].tobytes() == want
     ps.close(); src.close()
+
+
+@pytest.mark.parametrize("wave", ["1", "0"])
+def test_greedy_extension_a_wave_per_hit_and_its_fallback(wave, monkeypatch):
+    """megablast, gap costs 0 / 0: greedy_wave_kernel (a workgroup of two waves per initial hit, the diagonals of a distance
+    across the lanes, offsets in LDS) against the oracle -- homologs of every kind on both strands: exact, substitutions only,
+    indels, ends of the query and of the subject inside the alignment, an ambiguity code in the query, and long diverged ones
+    (12 kb at 4-6 % differences: more distance than the kernel's LDS window holds, so those halves go to the thread-per-hit
+    kernel behind the GBN_GAP_REDO mark).  GBN_GREEDY_WAVE=0: the thread-per-hit kernel alone; both equal the oracle."""
+    from oracle import orc
+    monkeypatch.setenv("GBN_GREEDY_WAVE", wave)
+    rng = np.random.default_rng(123)
+    comp = np.array([3, 2, 1, 0], dtype=np.uint8)
+
+    def mutate(x, sub, indel):
+        y = x.copy()
+        m = rng.random(len(y)) < sub
+        y[m] = (y[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
+        out, i = [], 0
+        for pos in sorted(rng.choice(len(y), indel, replace=False).tolist()) if indel else []:
+            out.append(y[i:pos]); i = pos
+            if rng.random() < 0.5:
+                out.append(rng.integers(0, 4, int(rng.integers(1, 4)), dtype=np.uint8))      # insertion
+            else:
+                i = min(len(y), pos + int(rng.integers(1, 4)))                                # deletion
+        out.append(y[i:])
+        return np.concatenate(out)
+    nsub, slen = 10, 60_000
+    subs = [rng.integers(0, 4, slen, dtype=np.uint8) for _ in range(nsub)]
+    queries = []
+    plans = [(900, 0.0, 0), (900, 0.03, 0), (900, 0.02, 3), (1500, 0.05, 6), (700, 0.0, 1), (12_000, 0.04, 10), (12_000, 0.06, 25), (3000, 0.08, 0),
+             (900, 0.01, 2), (900, 0.05, 2), (2500, 0.03, 8), (600, 0.0, 0)]
+    for k, (n, sub, indel) in enumerate(plans):
+        s = subs[k % nsub]
+        at = int(rng.integers(0, slen - n))
+        if k == 4:
+            at = 0                                                   # the subject's start inside the alignment
+        if k == 8:
+            at = slen - n                                            # ... and its end
+        piece = mutate(s[at:at + n], sub, indel)
+        if k % 2:
+            piece = comp[piece[::-1]]
+        flank = int(rng.integers(0, 300)) if k not in (0, 11) else 0  # (no flank: the query's ends inside the alignment)
+        qq = np.concatenate([rng.integers(0, 4, flank, dtype=np.uint8), piece, rng.integers(0, 4, flank, dtype=np.uint8)])
+        if k == 9:
+            qq[len(qq) // 2] = 14                                     # an ambiguity code (N) in the middle
+        queries.append(qq)
+    subjects = [(orc.pack_ncbi2na(x), len(x)) for x in subs]
+    opt = api.default_options("megablast", db_length=nsub * slen, db_num_seqs=nsub)
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    gpu = ps.run(keep_stages=True)
+    ora, s = util.oracle_run(opt, queries, subjects)
+    util.compare_stages(gpu, ora)
+    assert len(gpu["hsps"]) >= len(plans) - 1
+    assert ps.diagnostics.gapped_extensions == s.stats.gapped_extensions
+    km = dict(zip(api.GbnDiagnostics.KERNEL_CLASSES, list(ps.diagnostics.kernel_ms)))
+    assert (km["dynprog_wave_kernel / greedy_wave_kernel"] > 0) == (wave == "1")
+    ps.close(); src.close()
