@@ -266,9 +266,10 @@ __device__ void greedy_hit(const GbnGapParams &P, int64_t i, int64_t slot)
 // a half that needs more distance than the window holds (GBN_GW_DMAX) is left to greedy_kernel (GBN_GAP_REDO).
 // ---------------------------------------------------------------------------
 namespace {
-#define GBN_GW_C    256         // LDS row window: diagonals -254 .. +254 around the start diagonal
-#define GBN_GW_DMAX 250
-#define GBN_GW_MS   512         // max_score window
+// (6.4 KB of LDS per workgroup: the probe kernel of the next pass, next to which this one runs, leaves 8 KB of a CU's 160)
+#define GBN_GW_C    128         // LDS row window: diagonals -126 .. +126 around the start diagonal
+#define GBN_GW_DMAX 122
+#define GBN_GW_MS   256         // max_score window
 
 __device__ __forceinline__ int32_t wave_max_i32(int32_t v)
 {
