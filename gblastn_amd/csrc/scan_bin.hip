@@ -7,7 +7,13 @@
 #include <type_traits>
 
 #ifndef GBN_BIN_ABL
-#define GBN_BIN_ABL 0       // timing experiments only (scan_bin_kernel), bits: 2 no record stores, 4 no `hi` stores, 8 no index stores: wrong results
+#define GBN_BIN_ABL 0       // timing experiments only (scan_bin_kernel), bits: 2 no record stores, 4 no `hi` stores, 8 no index stores, 16 rank atomics without return (rank = k): wrong results
+#endif
+// In-situ marginal cost of one class of LDS operations (round 5, profiles/r05_lds_atomics.txt): the class is issued TWICE, everything
+// else -- barriers, loads, stores, the other LDS traffic -- stays as it is, and the results stay right.  Bits: 1 the rank atomics
+// (a second, shadow histogram), 2 the descriptor reads, 4 the scatter writes, 8 the store phase's LDS reads.
+#ifndef GBN_BIN_DUP
+#define GBN_BIN_DUP 0
 #endif
 
 // ===========================================================================
@@ -63,6 +69,9 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     __shared__ __attribute__((aligned(16))) uint32_t s_hi[STAGE + GBN_BIN_MAXNB * LINE];
     __shared__ __attribute__((aligned(16))) uint16_t s_ix[STAGE + GBN_BIN_MAXNB * LINE];
     __shared__ uint32_t s_hist[GBN_BIN_MAXNB];
+#if GBN_BIN_DUP & 1
+    __shared__ uint32_t s_hist2[GBN_BIN_MAXNB];
+#endif
     __shared__ uint32_t s_wtot[GBN_BIN_MAXNB / 64];
     // scatter descriptor of a bin (r = rank of a record among the tile's records of the bin):
     //   .x [15:0]  slot of r = 0 while the open line has room     [31:16] the same for the staging area (signed)
@@ -156,8 +165,16 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     // by the piece below 128 bytes (tools/write_microbench.hip: 64 + 32 byte pieces 3.5 TB/s, 128 + 64: 6+)
     uint32_t *const rec32 = B.rec; uint16_t *const rec16 = reinterpret_cast<uint16_t *>(B.rec);
     auto store_part = [&](uint32_t dl, uint32_t p, uint32_t src) {
-        const uint4 h = *reinterpret_cast<const uint4 *>(&s_hi[src]);
-        const uint2 x = *reinterpret_cast<const uint2 *>(&s_ix[src]);
+        uint4 h = *reinterpret_cast<const uint4 *>(&s_hi[src]);
+        uint2 x = *reinterpret_cast<const uint2 *>(&s_ix[src]);
+#if GBN_BIN_DUP & 8
+        {
+            // (the neighbouring quarter line: same banks pattern, an address the compiler cannot fold into the first read)
+            const uint4 h2 = *reinterpret_cast<const uint4 *>(&s_hi[src ^ 4u]);
+            const uint2 x2 = *reinterpret_cast<const uint2 *>(&s_ix[src ^ 4u]);
+            h.x |= h2.x & h.x & 0x80000000u; x.x |= x2.x & x.x & 0u;
+        }
+#endif
         // = GBN_REC_HI / GBN_REC_IDX16 of record dl * 32 + p * 4 (blocks of 64 records: 64 hi words, 64 indices)
         const size_t blk = (size_t)(dl >> 1) * 96, in = (size_t)((dl & 1u) * 32u + p * 4u);
         if (!(GBN_BIN_ABL & 4)) *reinterpret_cast<uint4 *>(rec32 + blk + in) = h;
@@ -165,6 +182,10 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     };
 
     if (tid < GBN_BIN_MAXNB) s_hist[tid] = 0;
+#if GBN_BIN_DUP & 1
+    if (tid < GBN_BIN_MAXNB) s_hist2[tid] = 0;
+    uint32_t dup_acc = 0;
+#endif
     // Tile of (writer w, round k) = k * writers + (w + k) mod writers: the rotation keeps tiles of one kind
     // (the short last tile of every subject, when the tiles per subject divide the grid) from always
     // landing on the same workgroups (GBN_TILE_OF in gbn_dev.h; the rare kernel inverts it).
@@ -219,8 +240,21 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         #pragma unroll
         for (int k = 0; k < PER; k++) {     // (positions past the end of a partial tile all carry the same key: they must not touch the histogram)
             rank[k] = 0;
+#if GBN_BIN_ABL & 16
+            if (valid[k]) { __hip_atomic_fetch_add(&s_hist[bin[k]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); rank[k] = (uint32_t)k; }
+#else
             if (valid[k]) rank[k] = atomicAdd(&s_hist[bin[k]], 1u);
+#endif
         }
+#if GBN_BIN_DUP & 1
+        {
+            uint32_t r2[PER];
+            #pragma unroll
+            for (int k = 0; k < PER; k++) { r2[k] = 0; if (valid[k]) r2[k] = atomicAdd(&s_hist2[bin[k]], 1u); }
+            #pragma unroll
+            for (int k = 0; k < PER; k++) dup_acc += r2[k];
+        }
+#endif
         Raw R;
         if constexpr (STEP > 0) fetch(T1, R);
         GbnTile T2 = P.tiles[min((int64_t)(seq + 2) * stride + (int64_t)rot_next(rot_next(rot)), last)];
@@ -260,6 +294,9 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
             if (tid == nb - 1) s_nlines = l0 + my_nl;
             wpos += my_nl * LINE; cc = my_cc;
             s_hist[tid] = 0;                                    // for the next tile: its atomics come after (C)
+#if GBN_BIN_DUP & 1
+            s_hist2[tid] = 0;
+#endif
         }
         GBN_LAP1(4);
         __syncthreads();                                        // (B) descriptors known
@@ -269,6 +306,13 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
             uint2 pk[PER];
             #pragma unroll
             for (int k = 0; k < PER; k++) pk[k] = s_pk[bin[k]];
+#if GBN_BIN_DUP & 2
+            #pragma unroll
+            for (int k = 0; k < PER; k++) {
+                const uint2 q2 = s_pk[bin[k] ^ 1u];            // (the neighbouring bin's descriptor: a second random 8-byte read)
+                pk[k].y |= q2.y & 0x80000000u & pk[k].y;
+            }
+#endif
             // the records of the previous tile that waited: their open lines were stored in that tile's [4]
             #pragma unroll
             for (int k = 0; k < PER; k++)
@@ -286,6 +330,9 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
                 keep_hi[k] = hi[k];
                 if (valid[k] && !waits) {
                     s_hi[slot] = hi[k]; s_ix[slot] = (uint16_t)(idx_of(k) | ((seq & 7u) << 13));
+#if GBN_BIN_DUP & 4
+                    *reinterpret_cast<volatile uint32_t *>(&s_hi[slot]) = hi[k]; *reinterpret_cast<volatile uint16_t *>(&s_ix[slot]) = (uint16_t)(idx_of(k) | ((seq & 7u) << 13));
+#endif
                 }
             }
         }
@@ -316,6 +363,9 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     }
 #endif
     late_stores();
+#if GBN_BIN_DUP & 1
+    if (dup_acc == 0xfffffffeu) B.gcount[0] = dup_acc;        // (keeps the shadow atomics' results alive)
+#endif
     __syncthreads();
     // the records of the last tile that waited
     #pragma unroll

@@ -68,6 +68,81 @@ __global__ void __launch_bounds__(1024) k(uint32_t *out, unsigned long long *cyc
     out[blockIdx.x * 1024 + tid] = acc + s_hist[tid] + s_rec[tid].x;
 }
 
+// ---- round 5: the LDS side of the binning kernel's tile loop, step by step (MODE bits), 8,192 records per iteration as in a tile:
+//   1  the rank atomics (returning; bit 64: without return)      2  barrier + 512 owner threads read and zero the histogram + barrier
+//   4  the descriptor read (random 8 bytes per record)           8  the two scatter writes per record (4 + 2 bytes, random slots)
+//  16  barrier + the store phase's reads (16 + 8 bytes per 4 records, sequential)
+// Time per iteration / 128 = ns per "rank atomic slot" of the kernel's account (12.6 ns in the kernel).
+template <int MODE>
+__global__ void __launch_bounds__(1024) tile_loop(uint32_t *out, int iters)
+{
+    __shared__ __attribute__((aligned(16))) uint32_t s_hi[8192 + 512 * 32];
+    __shared__ __attribute__((aligned(16))) uint16_t s_ix[8192 + 512 * 32];
+    __shared__ uint32_t s_hist[512];
+    __shared__ uint2 s_pk[512];
+    const int tid = threadIdx.x;
+    if (tid < 512) { s_hist[tid] = 0; s_pk[tid] = make_uint2(8192 + tid * 32, 0); }
+    __syncthreads();
+    uint32_t x = tid * 2654435761u + blockIdx.x * 40503u + 12345u, acc = 0;
+    for (int it = 0; it < iters; it++) {
+        uint32_t b[8], r[8];
+        #pragma unroll
+        for (int j = 0; j < 8; j++) { x = x * 1664525u + 1013904223u; b[j] = (x >> 11) & 511u; r[j] = (x >> 5) & 31u; }
+        if (MODE & 1) {
+            if (MODE & 64) {
+                #pragma unroll
+                for (int j = 0; j < 8; j++) __hip_atomic_fetch_add(&s_hist[b[j]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            } else {
+                #pragma unroll
+                for (int j = 0; j < 8; j++) r[j] = atomicAdd(&s_hist[b[j]], 1u) & 31u;
+            }
+        }
+        if (MODE & 2) {
+            __syncthreads();
+            if (tid < 512) { acc += s_hist[tid]; s_hist[tid] = 0; }
+            __syncthreads();
+        }
+        uint2 pk[8];
+        #pragma unroll
+        for (int j = 0; j < 8; j++) pk[j] = make_uint2(8192 + b[j] * 32, 0);
+        if (MODE & 4) {
+            #pragma unroll
+            for (int j = 0; j < 8; j++) pk[j] = s_pk[b[j]];
+        }
+        if (MODE & 8) {
+            #pragma unroll
+            for (int j = 0; j < 8; j++) { const uint32_t slot = pk[j].x + r[j]; s_hi[slot] = x + j; s_ix[slot] = (uint16_t)(tid * 8 + j); }
+        }
+        if (MODE & 16) {
+            __syncthreads();
+            #pragma unroll
+            for (int q = 0; q < 2; q++) {       // 2,048 quarter lines per tile
+                const uint32_t src = (uint32_t)(8192 + ((tid + q * 1024 + it * 8) & 4095) * 4);
+                const uint4 h = *reinterpret_cast<const uint4 *>(&s_hi[src]);
+                const uint2 v = *reinterpret_cast<const uint2 *>(&s_ix[src]);
+                acc += h.x ^ h.w ^ v.x;
+            }
+        }
+        #pragma unroll
+        for (int j = 0; j < 8; j++) acc += r[j] + pk[j].y;
+    }
+    out[blockIdx.x * 1024 + tid] = acc + s_hist[tid & 511];
+}
+template <int MODE> int run_tile(const char *what, uint32_t *out, int iters)
+{
+    hipLaunchKernelGGL((tile_loop<MODE>), dim3(256), dim3(1024), 0, 0, out, 16);
+    CHK(hipDeviceSynchronize());
+    hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
+    CHK(hipEventRecord(e0, 0));
+    hipLaunchKernelGGL((tile_loop<MODE>), dim3(256), dim3(1024), 0, 0, out, iters);
+    CHK(hipEventRecord(e1, 0));
+    CHK(hipDeviceSynchronize());
+    float ms = 0; CHK(hipEventElapsedTime(&ms, e0, e1));
+    printf("tile loop: %-78s %7.3f us per tile = %6.2f ns per rank-atomic slot (128 per tile); a C2 pass has 1,402 tiles per CU: %5.2f ms\n",
+           what, ms * 1e3 / iters, ms * 1e6 / ((double)iters * 128.0), ms / iters * 1402.0);
+    return 0;
+}
+
 template <int MODE, int NBINS> int run(const char *what, uint32_t *out, unsigned long long *cyc, int iters)
 {
     const int grid = 256;
@@ -105,5 +180,17 @@ int main()
     run<5, 512>("ds_write_b32 random", out, cyc, iters);
     run<3, 512>("ds_read_b32 random", out, cyc, iters);
     run<4, 512>("ds_read_b64 random", out, cyc, iters);
+    const int tiles = 4000;
+    run_tile<0>("nothing (key arithmetic of the loop)", out, tiles);
+    run_tile<1>("rank atomics", out, tiles);
+    run_tile<1 | 64>("rank atomics without return", out, tiles);
+    run_tile<1 | 2>("rank atomics | barrier, owners read + zero, barrier", out, tiles);
+    run_tile<1 | 64 | 2>("atomics without return | barrier, owners, barrier", out, tiles);
+    run_tile<1 | 2 | 4>("rank atomics | owners | descriptor reads", out, tiles);
+    run_tile<1 | 2 | 4 | 8>("rank atomics | owners | descriptor reads + scatter writes", out, tiles);
+    run_tile<1 | 2 | 4 | 8 | 16>("rank atomics | owners | descriptors + scatter | barrier, store-phase reads", out, tiles);
+    run_tile<2 | 4 | 8 | 16>("the same without the rank atomics", out, tiles);
+    run_tile<1 | 2 | 8 | 16>("the same without the descriptor reads", out, tiles);
+    run_tile<1 | 2 | 4 | 16>("the same without the scatter writes", out, tiles);
     return 0;
 }
