@@ -115,10 +115,33 @@ def main(argv=None):
         cur.append(q); acc += len(q[1])
     if cur:
         batches.append(cur)
+    # tests: GBN_TEST_FAIL="rank:batch" makes that rank's preliminary search of that batch raise -- the protocol must end on every
+    # rank with the failure reported, nobody waiting in a collective (tests/test_shard_gpu.py, eight ranks)
+    fail_rank, fail_batch = (int(x) for x in os.environ["GBN_TEST_FAIL"].split(":")) if os.environ.get("GBN_TEST_FAIL") else (-1, -1)
+    if fail_rank == rank:
+        real = S._search
+
+        def failing(queries, masks, _n=[0]):
+            _n[0] += 1
+            if _n[0] - 1 == fail_batch:
+                raise RuntimeError("injected failure of the preliminary search (GBN_TEST_FAIL)")
+            return real(queries, masks)
+        S._search = failing
     for b in batches:
         seqs = [s for _, s in b]
         S.submit(seqs, masks=api.dust_masks(seqs) if a.dust == "yes" else None)
-    res = S.results()
+    failed = None
+    try:
+        res = S.results()
+    except api.BlastError as e:
+        failed = str(e)
+    if failed is not None:
+        sys.stderr.write("blastn_sharded: rank %d: a batch failed: %s\n" % (rank, failed))
+        S.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return 3
     if rank == 0:
         out = sys.stdout if a.out == "-" else open(a.out, "w")
         n = 0

@@ -46,7 +46,12 @@ def gather_records(records, dst=0, device=None, group=None, force=False):
     `gather` sized by the largest shard and a `.item()` per rank)."""
     if not (_active(group) or (force and dist.is_initialized())):
         return records
+    # `dst` is a rank OF THE GROUP (0 .. world - 1), like every rank in this module; torch's point-to-point calls take
+    # global ranks: peer() converts (round 4 compared the group rank with `dst` and sent to the global rank `dst`: in a
+    # sub-group that does not start at global rank 0 nobody received)
     world, rank = dist.get_world_size(group), dist.get_rank(group)
+    if not 0 <= dst < world:
+        raise ValueError("gather_records: dst = %d is not a rank of this group of %d" % (dst, world))
     dev = device if device is not None else torch.device("cpu")
     raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1)
     mine = torch.tensor([raw.size], dtype=torch.int64, device=dev)
@@ -92,15 +97,16 @@ def broadcast_records(records, dtype, src=0, device=None, group=None):
     """A 1-D structured array from `src` to every rank (size first, then payload); `records` is ignored elsewhere."""
     if not _active(group):
         return records
-    rank = dist.get_rank(group)
+    rank = dist.get_rank(group)                         # `src`: a rank of the group; dist.broadcast wants the global one
+    src_global = dist.get_global_rank(group, src) if group is not None else src
     dev = device if device is not None else torch.device("cpu")
     raw = np.ascontiguousarray(records).view(np.uint8).reshape(-1) if rank == src else np.zeros(0, dtype=np.uint8)
     n = torch.tensor([raw.size], dtype=torch.int64, device=dev)
-    dist.broadcast(n, src=src, group=group)
+    dist.broadcast(n, src=src_global, group=group)
     size = int(n.item())
     buf = torch.from_numpy(raw.copy()).to(dev) if rank == src else torch.zeros(size, dtype=torch.uint8, device=dev)
     if size:
-        dist.broadcast(buf, src=src, group=group)
+        dist.broadcast(buf, src=src_global, group=group)
     return buf.cpu().numpy().view(dtype) if size else np.zeros(0, dtype=dtype)
 
 

@@ -254,3 +254,52 @@ def test_volume_shards_cover_the_database():
     three = [shard.VolumeShard(G, 3, r, load=False) for r in range(3)]
     assert [p.num_oids for p in three] == [2004, 1, 0] and three[2].src is None
     assert parts[0].owns(2003) and not parts[0].owns(2004) and parts[1].owns(2004)
+
+
+def test_sharded_search_protocol_eight_ranks_gloo():
+    run_protocol(8, 29629)          # 9 volumes over 8 ranks: 2 + 1 + 1 + 1 + 1 + 1 + 1 + 1 (the C5 width)
+    run_protocol(8, 29631, fail_stage="search")
+
+
+SUBGROUP_WORKER = r'''
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, datetime, torch.distributed as dist
+from gblastn_amd import shard, api
+dist.init_process_group("gloo", timeout=datetime.timedelta(seconds=60))
+r = dist.get_rank()
+grp = dist.new_group([1, 2])                    # a group that does not start at global rank 0
+if r in (1, 2):
+    gr = dist.get_rank(grp)
+    rec = np.zeros(5 + gr, dtype=api.HSP_DT); rec["oid"] = 100 * gr + np.arange(5 + gr); rec["score"] = 7 + gr
+    for dst in (0, 1):                           # ranks OF THE GROUP
+        got = shard.gather_records(rec, dst=dst, group=grp)
+        if gr == dst:
+            assert got is not None and len(got) == 11 and got["oid"].tolist() == list(range(5)) + [100 + i for i in range(6)], got["oid"]
+        else:
+            assert got is None
+        parts = shard.gather_parts(rec, dst=dst, group=grp)
+        assert (parts is None) == (gr != dst) and (parts is None or [len(x) for x in parts] == [5, 6])
+    for src in (0, 1):
+        out = shard.broadcast_records(rec if gr == src else None, api.HSP_DT, src=src, group=grp)
+        assert len(out) == 5 + src and int(out["score"][0]) == 7 + src
+    try:
+        shard.gather_records(rec, dst=2, group=grp); raise SystemExit("dst outside the group was accepted")
+    except ValueError:
+        pass
+    print("SUBGROUP_OK", gr)
+dist.barrier(); dist.destroy_process_group()
+'''
+
+
+def test_gather_and_broadcast_in_a_subgroup_that_does_not_start_at_rank_zero():
+    """dst / src of the exchange helpers are ranks OF THE GROUP; torch's calls take global ranks (round 4 mixed the two)."""
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with tempfile.NamedTemporaryFile("w", suffix=".py", delete=False) as f:
+        f.write(SUBGROUP_WORKER); path = f.name
+    env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"
+    p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=3", "--master-addr", "127.0.0.1",
+                        "--master-port", "29633", path, root], env=env, capture_output=True, text=True, timeout=300)
+    os.unlink(path)
+    assert p.returncode == 0 and p.stdout.count("SUBGROUP_OK") == 2, p.stdout[-2000:] + p.stderr[-3000:]

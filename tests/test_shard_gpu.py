@@ -29,10 +29,11 @@ def make_case(tmp_path):
     return str(tmp_path / "three"), str(tmp_path / "q.fa")
 
 
-def launch(nproc, db, fa, out, task, backend="nccl", port=29711, batch=None):
+def launch(nproc, db, fa, out, task, backend="nccl", port=29711, batch=None, extra_env=None, expect_rc=0):
     env = dict(os.environ); env["MASTER_ADDR"] = "127.0.0.1"; env["PYTHONPATH"] = ROOT
     if batch:
         env["BATCH_SIZE"] = str(batch)
+    env.update(extra_env or {})
     cmd = [sys.executable]
     if nproc > 1:
         cmd += ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % nproc, "--master-addr", "127.0.0.1",
@@ -40,6 +41,9 @@ def launch(nproc, db, fa, out, task, backend="nccl", port=29711, batch=None):
     cmd += ["-m", "gblastn_amd.blastn_sharded", "-db", db, "-query", fa, "-out", out, "-task", task, "-evalue", "1e-3",
             "-max_target_seqs", "5", "-backend", backend]
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    if expect_rc:
+        assert p.returncode != 0, p.stderr[-3000:]
+        return None, p.stderr
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
     return open(out).read().splitlines(), p.stderr
 
@@ -91,3 +95,32 @@ ex.close(); dist.destroy_process_group(); print("NCCL_ONE_RANK_OK")
 ''' % ROOT
     p = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
     assert p.returncode == 0 and "NCCL_ONE_RANK_OK" in p.stdout, p.stdout[-1000:] + p.stderr[-3000:]
+
+
+def test_eight_ranks_on_one_device_uneven_volumes_an_idle_rank_and_a_failing_one(tmp_path):
+    """The C5 protocol at its full width without an 8-GPU node: EIGHT ranks over RCCL on the one device of the box.
+    (a) ten volumes over eight ranks (2, 2, 1, 1, 1, 1, 1, 1): rows equal the one-rank rows, several batches in flight;
+    (b) seven volumes over eight ranks: the last rank holds nothing and still takes part in every exchange;
+    (c) rank 5's preliminary search of the second batch fails: every rank ends, with the failure reported, within the timeout
+        -- nobody waits in a gather or a broadcast for a rank that dropped out;
+    (d) the C++ command line with eight search threads sharing the device (-gpu_id -1 -num_threads 8): the same rows.
+    Not a scaling measurement (one device): bench.py --gpus 8 on a real node is the driver's."""
+    db3, fa = make_case(tmp_path)
+    vols = " ".join(["%s/seqn %s/nt.41646578" % (G, G)] * 5)
+    (tmp_path / "ten.nal").write_text("TITLE ten volumes\nDBLIST %s\n" % vols)
+    ten = str(tmp_path / "ten")
+    one, _ = launch(1, ten, fa, str(tmp_path / "one.tsv"), "megablast")
+    eight, err = launch(8, ten, fa, str(tmp_path / "eight.tsv"), "megablast", port=29721, batch=1000)
+    assert len(one) >= 16 and eight == one and "on 8 ranks (10 volumes, 0..2 here)" in err, err[-400:]
+    vols7 = " ".join(["%s/seqn %s/nt.41646578" % (G, G)] * 3) + " %s/seqn" % G
+    (tmp_path / "seven.nal").write_text("TITLE seven volumes\nDBLIST %s\n" % vols7)
+    seven = str(tmp_path / "seven")
+    a, _ = launch(1, seven, fa, str(tmp_path / "a.tsv"), "megablast")
+    b, err = launch(8, seven, fa, str(tmp_path / "b.tsv"), "megablast", port=29723, batch=3000)
+    assert a == b and len(a) > 0 and "on 8 ranks" in err
+    _, err = launch(8, ten, fa, str(tmp_path / "f.tsv"), "megablast", port=29725, batch=1000, extra_env={"GBN_TEST_FAIL": "5:1"}, expect_rc=3)
+    assert "injected failure" in err and "failed on another rank" in err, err[-1500:]
+    p = subprocess.run([CLI, "-db", ten, "-query", fa, "-task", "megablast", "-use_gpu", "true", "-gpu_id", "-1", "-num_threads", "8",
+                        "-evalue", "1e-3", "-max_target_seqs", "5", "-out", str(tmp_path / "cli8.tsv")], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert open(tmp_path / "cli8.tsv").read().splitlines() == one
