@@ -34,6 +34,8 @@ hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_seed_order(const GbnKeyParams &k, int nsubj, uint32_t *scratch, hipStream_t st);       // seed_order.hip
+bool seed_sort_small_fits(const GbnKeyParams &K, int nsubj);                                              // seed_sort.hip
+hipError_t launch_seed_sort_small(const GbnKeyParams &K, int nsubj, uint32_t *idx_out, uint32_t *scratch, uint64_t *key_group_out, hipStream_t st);
 size_t seed_order_scratch_words(int64_t n, int nsubj, int group_bits);
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st, GbnKernelTimer *kt = nullptr);
 hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st, GbnKernelTimer *kt = nullptr);
@@ -1336,7 +1338,18 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     const bool segmented = seeds == E.seeds && E.seg_valid;           // (an asynchronous stage works on a copy of its own)
     const bool from_segments = segmented && composite && !keep_stages;  // seed_ckeys_kernel reads the segments as they are
     if (phase != 2 && segmented && !from_segments && (rc = compact_seeds(st))) return rc;
-    if (phase != 2 && (!composite || keep_stages)) {
+    // Few seeds (megablast shapes: some 24 thousand per C2 pass): ONE workgroup sorts their indices by (subject, slot, scan
+    // position, query key) in ONE launch (seed_sort.hip; GBN_SMALL_SORT=0: the two library sorts of rounds 1-4, which also
+    // serve keep_stages -- it wants the scan order by itself -- and more than GBN_SMALL_SORT_MAX seeds)
+    const bool small_sort = !composite && !keep_stages && gbn::switch_value("GBN_SMALL_SORT", 1) != 0 && seed_sort_small_fits(K, s1 - s0);
+    if (phase != 2 && small_sort) {
+        if (segmented && (rc = compact_seeds(st))) return rc;
+        KS.kt.mark(GBN_KT_SORT, st);
+        HIPCHK(launch_seed_sort_small(K, s1 - s0, KS.idx_a, KS.idx_b, KS.key_b, st));
+        KS.kt.mark(-1, st);
+        // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
+    }
+    if (phase != 2 && !small_sort && (!composite || keep_stages)) {
         KS.kt.mark(GBN_KT_KEYS, st);
         HIPCHK(launch_seed_keys(K, st));
         size_t tb = KS.sort_tmp_bytes;
@@ -1392,7 +1405,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
             KS.kt.mark(-1, st);
         }
         // key_b = sorted composite keys, idx_b = ext_left of the seeds in that order (packed: both in key_b)
-    } else {
+    } else if (!small_sort) {
         K.idx = KS.idx_b; K.key_group = KS.key_a;
         if (phase != 2) {
             KS.kt.mark(GBN_KT_KEYS, st);

@@ -121,6 +121,9 @@ struct GbnOrderParams {
     uint32_t *slot_base;                // [subject][slot]
 };
 
+// seed_sort.hip: most seeds ONE workgroup puts into the diagonal filter's order (beyond: the two library sorts, as rounds 1-4)
+#define GBN_SMALL_SORT_MAX 65536
+
 // seeds per launch below which the diagonal kernel runs thread-per-seed instead of on compacted run heads
 #ifndef GBN_DIAG_COMPACT_MIN
 #define GBN_DIAG_COMPACT_MIN (1 << 20)

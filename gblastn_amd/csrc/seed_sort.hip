@@ -1,0 +1,138 @@
+// seed_sort.hip -- the FEW seeds of a megablast-shaped range (tens of thousands per 50 Gbp pass) put into the order the
+// diagonal filter replays them in: by (subject, diagonal slot), scan order (scan position, chain order) inside -- what the CPU
+// scanner gets for free (CORE/blast_nascan.c:1489-1591 walks a subject from its first base; CORE/na_ungapped.c:1025-1144
+// hands every seed to the container as it turns up).  Rounds 1-4 did this with two stable radix sorts of the library
+// (hipCUB: two key kernels + ~16 launches per range, the last library kernels on the C2 path); here ONE launch of ONE
+// workgroup sorts seed INDICES by a 64-bit key that is never stored: every pass of its stable LSD radix sort (6-bit digits)
+// reads a seed through its index (the seeds of a range fit the L2 many times over) and cuts the digit out of
+//     subject | slot | scan position | high bits of the query key
+// -- two seeds of one (subject, slot, scan position) agree in their query positions modulo the number of slots, so the query
+// key's low bits decide nothing (as in gbn_composite_key).  4 KB of LDS (a histogram per wave): the workgroup finds room on a
+// CU next to the probe kernel of the pass behind it, which leaves 8 KB.  Integer work only: no MFMA.
+#include "gbn_dev.h"
+#include <hip/hip_runtime.h>
+
+namespace {
+constexpr int SS_THREADS = 1024, SS_WAVES = SS_THREADS / 64, SS_BITS = 6, SS_DIGITS = 1 << SS_BITS;
+
+struct SeedSortParams {
+    GbnKeyParams K;                 // seeds, n, the key layout (q_bits, group_bits, s_bits, subj_base, q_descending, container)
+    int subj_bits;                  // subjects of the launch < 2^subj_bits (counted from K.subj_base)
+    int npass;                      // ceil(key bits / 6)
+    uint32_t *ping, *pong;          // n indices each; the sorted indices end up in `pong` if npass is odd, else in `ping`... see launch
+    uint64_t *key_group;            // out: (subject << group_bits | slot) of the seeds in sorted order
+};
+
+__device__ __forceinline__ uint64_t sort_key(const GbnKeyParams &K, const GbnDevSeed &sd, uint32_t qmax)
+{
+    const uint32_t qkey = K.q_descending ? (qmax - (uint32_t)sd.q_pos) : (uint32_t)sd.q_pos;
+    const uint32_t slot = K.container_hash ? ((uint32_t)(sd.s_scan - sd.q_pos) & 511u)
+                                           : ((uint32_t)(sd.s_scan + K.diag_len - sd.q_pos) & (uint32_t)(K.diag_len - 1));
+    uint64_t key = ((uint64_t)(uint32_t)(sd.subj - K.subj_base) << K.group_bits) | slot;
+    key = (key << K.s_bits) | (uint32_t)sd.s_scan;
+    return (key << K.qh_bits) | (K.qh_bits ? (qkey >> K.group_bits) : 0u);
+}
+
+// lanes of the wave whose digit equals this lane's (among the lanes of `valid`)
+__device__ __forceinline__ unsigned long long same_digit(uint32_t d, bool valid)
+{
+    unsigned long long m = __ballot(valid);
+    #pragma unroll
+    for (int b = 0; b < SS_BITS; b++) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long bal = __ballot(bit);
+        m &= bit ? bal : ~bal;
+    }
+    return m;
+}
+}  // namespace
+
+extern "C" __global__ void __launch_bounds__(SS_THREADS) seed_sort_small_kernel(SeedSortParams S)
+{
+    __shared__ uint32_t hist[SS_DIGITS][SS_WAVES];          // [digit][wave]: digit-major = the order of the prefix sum
+    __shared__ uint32_t wtot[SS_WAVES];
+    const GbnKeyParams &K = S.K;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
+    const uint32_t n = (uint32_t)K.n;
+    const uint32_t per_wave = ((n + SS_WAVES - 1) / SS_WAVES + 63u) & ~63u;
+    const uint32_t i0 = (uint32_t)w * per_wave, i1 = min(n, i0 + per_wave);
+    const uint32_t qmax = (K.q_bits >= 32) ? 0xffffffffu : ((1u << K.q_bits) - 1u);
+    for (int p = 0; p < S.npass; p++) {
+        const uint32_t *__restrict__ src = (p & 1) ? S.pong : S.ping;       // (pass 0: the identity, nothing is read)
+        uint32_t *__restrict__ dst = (p & 1) ? S.ping : S.pong;
+        const int shift = SS_BITS * p;
+        hist[tid >> 4][tid & 15] = 0;
+        __syncthreads();
+        // ---- count: the wave's stretch of the list, 64 elements at a time
+        for (uint32_t i = i0 + lane; i - lane < i1; i += 64) {
+            const bool valid = i < i1;
+            const uint32_t id = valid ? (p == 0 ? i : src[i]) : 0u;
+            const uint32_t d = valid ? (uint32_t)(sort_key(K, K.seeds[id], qmax) >> shift) & (SS_DIGITS - 1) : 0u;
+            const unsigned long long m = same_digit(d, valid);
+            if (valid && !(m & lt)) hist[d][w] += (uint32_t)__popcll(m);      // (the group's lowest lane; a wave's row is its own)
+        }
+        __syncthreads();
+        // ---- exclusive prefix sum over (digit, wave), digit-major: where every wave's elements of every digit go
+        {
+            const uint32_t v = hist[tid >> 4][tid & 15];
+            uint32_t incl = v;
+            #pragma unroll
+            for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
+            if (lane == 63) wtot[w] = incl;
+            __syncthreads();
+            uint32_t base = 0;
+            for (int k = 0; k < w; k++) base += wtot[k];
+            hist[tid >> 4][tid & 15] = base + incl - v;
+        }
+        __syncthreads();
+        // ---- scatter, in the same order (stable)
+        for (uint32_t i = i0 + lane; i - lane < i1; i += 64) {
+            const bool valid = i < i1;
+            const uint32_t id = valid ? (p == 0 ? i : src[i]) : 0u;
+            const uint32_t d = valid ? (uint32_t)(sort_key(K, K.seeds[id], qmax) >> shift) & (SS_DIGITS - 1) : 0u;
+            const unsigned long long m = same_digit(d, valid);
+            uint32_t at = 0;
+            if (valid) at = hist[d][w];
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // (every lane of a group has read the counter before its first lane moves it on)
+            if (valid) {
+                dst[at + (uint32_t)__popcll(m & lt)] = id;
+                if (!(m & lt)) hist[d][w] = at + (uint32_t)__popcll(m);
+            }
+        }
+        __syncthreads();                                                    // (workgroup scope: the indices written are read by other waves in the next pass)
+    }
+    // the sorted indices are in `pong` after an odd number of passes, in `ping` after an even one: the launcher picked the
+    // buffers so that this is the caller's output array; the run keys beside them
+    const uint32_t *__restrict__ fin = (S.npass & 1) ? S.pong : S.ping;
+    for (uint32_t i = tid; i < n; i += SS_THREADS) {
+        const GbnDevSeed sd = K.seeds[S.npass ? fin[i] : i];
+        const int32_t q = sd.q_pos - sd.ext_left, s = sd.s_scan - sd.ext_left;
+        const uint32_t grp = K.container_hash ? ((uint32_t)(s - q) & 511u) : ((uint32_t)(s + K.diag_len - q) & (uint32_t)(K.diag_len - 1));
+        S.key_group[i] = ((uint64_t)(uint32_t)sd.subj << K.group_bits) | grp;
+    }
+}
+
+namespace gbn {
+// can the small sort take this launch?  (n seeds, subjects [subj_base, subj_base + nsubj))
+bool seed_sort_small_fits(const GbnKeyParams &K, int nsubj)
+{
+    auto bits_for = [](uint64_t below) { int k = 1; while (k < 63 && ((uint64_t)1 << k) < below) k++; return k; };
+    return K.n > 0 && K.n <= GBN_SMALL_SORT_MAX && K.group_bits < 32 && K.qh_bits + K.s_bits + K.group_bits + bits_for((uint64_t)nsubj + 1) <= 64;
+}
+// idx_out[i] = index of the i-th seed in (subject, slot, scan position, query key) order, key_group_out[i] = its
+// (subject << group_bits | slot); `scratch`: n indices.  One launch.
+hipError_t launch_seed_sort_small(const GbnKeyParams &K, int nsubj, uint32_t *idx_out, uint32_t *scratch, uint64_t *key_group_out, hipStream_t st)
+{
+    auto bits_for = [](uint64_t below) { int k = 1; while (k < 63 && ((uint64_t)1 << k) < below) k++; return k; };
+    SeedSortParams S;
+    S.K = K; S.subj_bits = bits_for((uint64_t)nsubj + 1);
+    const int key_bits = K.qh_bits + K.s_bits + K.group_bits + S.subj_bits;
+    S.npass = (key_bits + SS_BITS - 1) / SS_BITS;
+    // pass p writes `pong` when p is even: after npass passes the result is in pong (npass odd) or ping (npass even)
+    if (S.npass & 1) { S.pong = idx_out; S.ping = scratch; } else { S.ping = idx_out; S.pong = scratch; }
+    S.key_group = key_group_out;
+    hipLaunchKernelGGL(seed_sort_small_kernel, dim3(1), dim3(SS_THREADS), 0, st, S);
+    return hipGetLastError();
+}
+}  // namespace gbn

@@ -876,3 +876,58 @@ def test_greedy_extension_a_wave_per_hit_and_its_fallback(wave, monkeypatch):
     km = dict(zip(api.GbnDiagnostics.KERNEL_CLASSES, list(ps.diagnostics.kernel_ms)))
     assert (km["dynprog_wave_kernel / greedy_wave_kernel"] > 0) == (wave == "1")
     ps.close(); src.close()
+
+
+@pytest.mark.parametrize("case", ["mb_hash", "smallna_array", "mb_lut11", "ragged"])
+def test_few_seeds_ordered_by_one_workgroup(case, monkeypatch):
+    """Without keep_stages the few seeds of a megablast-shaped search go to the diagonal filter through seed_sort.hip (one
+    launch of one workgroup: indices sorted by subject | slot | scan position | query key, never stored); GBN_SMALL_SORT=0 takes
+    the two library sorts of rounds 1-4.  Both give the oracle's HSPs -- hash and array container, tables whose chains come
+    out descending (megablast) and ascending (small-NA), subjects of very different lengths with repeats of the query in them
+    (many seeds of one diagonal slot, several per scan position)."""
+    from oracle import orc
+    rng = np.random.default_rng({"mb_hash": 1, "smallna_array": 2, "mb_lut11": 3, "ragged": 4}[case])
+    if case == "smallna_array":
+        nq, qlen, nsub, slen = 1, 1000, 6, 200_000          # C1's shape: small-NA table, diagonal array
+    elif case == "mb_lut11":
+        nq, qlen, nsub, slen = 20, 1000, 8, 300_000
+    elif case == "ragged":
+        nq, qlen, nsub, slen = 40, 900, 30, 0
+    else:
+        nq, qlen, nsub, slen = 400, 1000, 10, 400_000
+    queries = [rng.integers(0, 4, qlen, dtype=np.uint8) for _ in range(nq)]
+    lens = [int(x) for x in rng.integers(40, 120_000, nsub)] if case == "ragged" else [slen] * nsub
+    subs = [rng.integers(0, 4, n, dtype=np.uint8) for n in lens]
+    for k in range(min(nq, 60)):
+        s = subs[k % nsub]
+        if len(s) < 2000:
+            continue
+        q = queries[k]
+        piece = q[100:100 + 600].copy()
+        m = rng.random(len(piece)) < 0.02
+        piece[m] = (piece[m] + 1) & 3
+        for rep in range(1 + k % 3):                              # the same stretch several times: seeds of one slot at many scan positions
+            at = int(rng.integers(0, len(s) - 700))
+            s[at:at + len(piece)] = piece
+    subjects = [(orc.pack_ncbi2na(x), len(x)) for x in subs]
+    opt = api.default_options("megablast", db_length=sum(lens), db_num_seqs=nsub)
+    ora, osearch = util.oracle_run(opt, queries, subjects)
+    want = np.concatenate([o["hsps"] for o in ora]) if ora else None
+    assert sum(len(o["hsps"]) for o in ora) >= 3
+    src = api.BlastSeqSrc.from_packed(subjects)
+    seen = {}
+    for sw in ("1", "0"):
+        monkeypatch.setenv("GBN_SMALL_SORT", sw)
+        ps = api.BlastPrelimSearch(queries, opt, src)
+        if case == "smallna_array":
+            assert ps.info()["container"] == 0 and ps.info()["lut_type"] != 3
+        got = ps.run()["hsps"]
+        util.compare_stages({"hsps": got}, ora)
+        ps.begin(); got2 = ps.end()["hsps"]
+        assert got2.tobytes() == got.tobytes()
+        km = dict(zip(api.GbnDiagnostics.KERNEL_CLASSES, list(ps.diagnostics.kernel_ms)))
+        seen[sw] = (got.tobytes(), km["seed keys"])
+        ps.close()
+    assert seen["1"][0] == seen["0"][0]
+    assert seen["1"][1] == 0 and seen["0"][1] > 0                 # (the key kernels belong to the library sorts only)
+    src.close()
