@@ -35,7 +35,7 @@ hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_seed_order(const GbnKeyParams &k, int nsubj, uint32_t *scratch, hipStream_t st);       // seed_order.hip
 bool seed_sort_small_fits(const GbnKeyParams &K, int nsubj);                                              // seed_sort.hip
-hipError_t launch_seed_sort_small(const GbnKeyParams &K, int nsubj, uint32_t *idx_out, uint32_t *scratch, uint64_t *key_group_out, hipStream_t st);
+hipError_t launch_seed_sort_small(const GbnKeyParams &K, int nsubj, uint32_t *idx_out, uint32_t *idx_tmp, uint64_t *key_group_out, uint64_t *key_tmp, hipStream_t st);
 size_t seed_order_scratch_words(int64_t n, int nsubj, int group_bits);
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st, GbnKernelTimer *kt = nullptr);
 hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st, GbnKernelTimer *kt = nullptr);
@@ -1345,7 +1345,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     if (phase != 2 && small_sort) {
         if (segmented && (rc = compact_seeds(st))) return rc;
         KS.kt.mark(GBN_KT_SORT, st);
-        HIPCHK(launch_seed_sort_small(K, s1 - s0, KS.idx_a, KS.idx_b, KS.key_b, st));
+        HIPCHK(launch_seed_sort_small(K, s1 - s0, KS.idx_a, KS.idx_b, KS.key_b, KS.key_a, st));
         KS.kt.mark(-1, st);
         // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
     }

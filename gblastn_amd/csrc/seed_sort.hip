@@ -3,8 +3,8 @@
 // scanner gets for free (CORE/blast_nascan.c:1489-1591 walks a subject from its first base; CORE/na_ungapped.c:1025-1144
 // hands every seed to the container as it turns up).  Rounds 1-4 did this with two stable radix sorts of the library
 // (hipCUB: two key kernels + ~16 launches per range, the last library kernels on the C2 path); here ONE launch of ONE
-// workgroup sorts seed INDICES by a 64-bit key that is never stored: every pass of its stable LSD radix sort (6-bit digits)
-// reads a seed through its index (the seeds of a range fit the L2 many times over) and cuts the digit out of
+// workgroup sorts (key, seed index) pairs with a stable LSD radix sort of 6-bit digits -- every pass reads and writes the list
+// coalesced (it stays in the L2), the first makes the keys from the seeds --, the 64-bit key being
 //     subject | slot | scan position | high bits of the query key
 // -- two seeds of one (subject, slot, scan position) agree in their query positions modulo the number of slots, so the query
 // key's low bits decide nothing (as in gbn_composite_key).  4 KB of LDS (a histogram per wave): the workgroup finds room on a
@@ -13,14 +13,14 @@
 #include <hip/hip_runtime.h>
 
 namespace {
-constexpr int SS_THREADS = 1024, SS_WAVES = SS_THREADS / 64, SS_BITS = 6, SS_DIGITS = 1 << SS_BITS;
+constexpr int SS_THREADS = 1024, SS_WAVES = SS_THREADS / 64, SS_BITS = 6, SS_DIGITS = 1 << SS_BITS, SS_DEEP = 8;
 
 struct SeedSortParams {
-    GbnKeyParams K;                 // seeds, n, the key layout (q_bits, group_bits, s_bits, subj_base, q_descending, container)
-    int subj_bits;                  // subjects of the launch < 2^subj_bits (counted from K.subj_base)
+    GbnKeyParams K;                 // seeds, n, the key layout (q_bits, group_bits, s_bits, qh_bits, subj_base, q_descending, container)
     int npass;                      // ceil(key bits / 6)
-    uint32_t *ping, *pong;          // n indices each; the sorted indices end up in `pong` if npass is odd, else in `ping`... see launch
-    uint64_t *key_group;            // out: (subject << group_bits | slot) of the seeds in sorted order
+    uint64_t *key_ping, *key_pong;  // n keys each: the list travels as (key, index) pairs, every pass reads and writes it coalesced
+    uint32_t *idx_ping, *idx_pong;  // n indices each (the launcher picks ping / pong so that the last pass writes the caller's arrays)
+    uint64_t *key_group;            // out: (subject << group_bits | slot) of the seeds in sorted order (may be the array the last pass wrote its keys to)
 };
 
 __device__ __forceinline__ uint64_t sort_key(const GbnKeyParams &K, const GbnDevSeed &sd, uint32_t qmax)
@@ -56,21 +56,37 @@ extern "C" __global__ void __launch_bounds__(SS_THREADS) seed_sort_small_kernel(
     const unsigned long long lt = lane ? (~0ull >> (64 - lane)) : 0ull;
     const uint32_t n = (uint32_t)K.n;
     const uint32_t per_wave = ((n + SS_WAVES - 1) / SS_WAVES + 63u) & ~63u;
-    const uint32_t i0 = (uint32_t)w * per_wave, i1 = min(n, i0 + per_wave);
+    const uint32_t i0 = (uint32_t)w * per_wave, i1 = i0 < n ? min(n, i0 + per_wave) : i0;
     const uint32_t qmax = (K.q_bits >= 32) ? 0xffffffffu : ((1u << K.q_bits) - 1u);
     for (int p = 0; p < S.npass; p++) {
-        const uint32_t *__restrict__ src = (p & 1) ? S.pong : S.ping;       // (pass 0: the identity, nothing is read)
-        uint32_t *__restrict__ dst = (p & 1) ? S.ping : S.pong;
+        const uint64_t *__restrict__ ksrc = (p & 1) ? S.key_pong : S.key_ping;
+        const uint32_t *__restrict__ isrc = (p & 1) ? S.idx_pong : S.idx_ping;
+        uint64_t *__restrict__ kdst = (p & 1) ? S.key_ping : S.key_pong;
+        uint32_t *__restrict__ idst = (p & 1) ? S.idx_ping : S.idx_pong;
         const int shift = SS_BITS * p;
         hist[tid >> 4][tid & 15] = 0;
         __syncthreads();
-        // ---- count: the wave's stretch of the list, 64 elements at a time
-        for (uint32_t i = i0 + lane; i - lane < i1; i += 64) {
-            const bool valid = i < i1;
-            const uint32_t id = valid ? (p == 0 ? i : src[i]) : 0u;
-            const uint32_t d = valid ? (uint32_t)(sort_key(K, K.seeds[id], qmax) >> shift) & (SS_DIGITS - 1) : 0u;
-            const unsigned long long m = same_digit(d, valid);
-            if (valid && !(m & lt)) hist[d][w] += (uint32_t)__popcll(m);      // (the group's lowest lane; a wave's row is its own)
+        // a wave walks its stretch of the list 64 elements at a time, SS_DEEP such batches loaded together (pass 0 makes the
+        // keys from the seeds, element i = seed i)
+        auto load = [&](uint32_t i, uint64_t &key, uint32_t &id) {
+            if (i >= i1) { key = 0; id = 0; return; }
+            if (p == 0) { key = sort_key(K, K.seeds[i], qmax); id = i; }
+            else { key = ksrc[i]; id = isrc[i]; }
+        };
+        // ---- count
+        for (uint32_t b0 = i0; b0 < i1; b0 += 64 * SS_DEEP) {
+            uint64_t key[SS_DEEP]; uint32_t id[SS_DEEP];
+            #pragma unroll
+            for (int u = 0; u < SS_DEEP; u++) load(b0 + 64 * u + lane, key[u], id[u]);
+            #pragma unroll
+            for (int u = 0; u < SS_DEEP; u++) {
+                const uint32_t i = b0 + 64 * u + lane;
+                if (b0 + 64 * u >= i1) break;                                 // (uniform)
+                const bool valid = i < i1;
+                const uint32_t d = (uint32_t)(key[u] >> shift) & (SS_DIGITS - 1);
+                const unsigned long long m = same_digit(d, valid);
+                if (valid && !(m & lt)) hist[d][w] += (uint32_t)__popcll(m);  // (the group's lowest lane; a wave's row is its own)
+            }
         }
         __syncthreads();
         // ---- exclusive prefix sum over (digit, wave), digit-major: where every wave's elements of every digit go
@@ -87,29 +103,36 @@ extern "C" __global__ void __launch_bounds__(SS_THREADS) seed_sort_small_kernel(
         }
         __syncthreads();
         // ---- scatter, in the same order (stable)
-        for (uint32_t i = i0 + lane; i - lane < i1; i += 64) {
-            const bool valid = i < i1;
-            const uint32_t id = valid ? (p == 0 ? i : src[i]) : 0u;
-            const uint32_t d = valid ? (uint32_t)(sort_key(K, K.seeds[id], qmax) >> shift) & (SS_DIGITS - 1) : 0u;
-            const unsigned long long m = same_digit(d, valid);
-            uint32_t at = 0;
-            if (valid) at = hist[d][w];
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");        // (every lane of a group has read the counter before its first lane moves it on)
-            if (valid) {
-                dst[at + (uint32_t)__popcll(m & lt)] = id;
-                if (!(m & lt)) hist[d][w] = at + (uint32_t)__popcll(m);
+        for (uint32_t b0 = i0; b0 < i1; b0 += 64 * SS_DEEP) {
+            uint64_t key[SS_DEEP]; uint32_t id[SS_DEEP];
+            #pragma unroll
+            for (int u = 0; u < SS_DEEP; u++) load(b0 + 64 * u + lane, key[u], id[u]);
+            #pragma unroll
+            for (int u = 0; u < SS_DEEP; u++) {
+                const uint32_t i = b0 + 64 * u + lane;
+                if (b0 + 64 * u >= i1) break;
+                const bool valid = i < i1;
+                const uint32_t d = (uint32_t)(key[u] >> shift) & (SS_DIGITS - 1);
+                const unsigned long long m = same_digit(d, valid);
+                uint32_t at = 0;
+                if (valid) at = hist[d][w];
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");    // (every lane of a group has read the counter before its first lane moves it on)
+                if (valid) {
+                    const uint32_t o = at + (uint32_t)__popcll(m & lt);
+                    kdst[o] = key[u]; idst[o] = id[u];
+                    if (!(m & lt)) hist[d][w] = at + (uint32_t)__popcll(m);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
         }
-        __syncthreads();                                                    // (workgroup scope: the indices written are read by other waves in the next pass)
+        __syncthreads();                                                    // (workgroup scope: what was written is read by other waves in the next pass)
     }
-    // the sorted indices are in `pong` after an odd number of passes, in `ping` after an even one: the launcher picked the
-    // buffers so that this is the caller's output array; the run keys beside them
-    const uint32_t *__restrict__ fin = (S.npass & 1) ? S.pong : S.ping;
+    // the last pass wrote the caller's index array; the run keys (subject << group_bits | slot) follow from the sort keys
+    const uint64_t *kfin = (S.npass & 1) ? S.key_pong : S.key_ping;      // (may be the array the run keys go to: element by element, in place)
+    const int low = K.qh_bits + K.s_bits;
     for (uint32_t i = tid; i < n; i += SS_THREADS) {
-        const GbnDevSeed sd = K.seeds[S.npass ? fin[i] : i];
-        const int32_t q = sd.q_pos - sd.ext_left, s = sd.s_scan - sd.ext_left;
-        const uint32_t grp = K.container_hash ? ((uint32_t)(s - q) & 511u) : ((uint32_t)(s + K.diag_len - q) & (uint32_t)(K.diag_len - 1));
-        S.key_group[i] = ((uint64_t)(uint32_t)sd.subj << K.group_bits) | grp;
+        const uint64_t k = (S.npass ? kfin[i] : sort_key(K, K.seeds[i], qmax)) >> low;
+        S.key_group[i] = (((k >> K.group_bits) + (uint64_t)(uint32_t)K.subj_base) << K.group_bits) | (k & (((uint64_t)1 << K.group_bits) - 1));
     }
 }
 
@@ -121,16 +144,18 @@ bool seed_sort_small_fits(const GbnKeyParams &K, int nsubj)
     return K.n > 0 && K.n <= GBN_SMALL_SORT_MAX && K.group_bits < 32 && K.qh_bits + K.s_bits + K.group_bits + bits_for((uint64_t)nsubj + 1) <= 64;
 }
 // idx_out[i] = index of the i-th seed in (subject, slot, scan position, query key) order, key_group_out[i] = its
-// (subject << group_bits | slot); `scratch`: n indices.  One launch.
-hipError_t launch_seed_sort_small(const GbnKeyParams &K, int nsubj, uint32_t *idx_out, uint32_t *scratch, uint64_t *key_group_out, hipStream_t st)
+// (subject << group_bits | slot); scratch: key_tmp n keys, idx_tmp n indices (key_group_out doubles as the other key array).
+// One launch.
+hipError_t launch_seed_sort_small(const GbnKeyParams &K, int nsubj, uint32_t *idx_out, uint32_t *idx_tmp, uint64_t *key_group_out, uint64_t *key_tmp, hipStream_t st)
 {
     auto bits_for = [](uint64_t below) { int k = 1; while (k < 63 && ((uint64_t)1 << k) < below) k++; return k; };
     SeedSortParams S;
-    S.K = K; S.subj_bits = bits_for((uint64_t)nsubj + 1);
-    const int key_bits = K.qh_bits + K.s_bits + K.group_bits + S.subj_bits;
+    S.K = K;
+    const int key_bits = K.qh_bits + K.s_bits + K.group_bits + bits_for((uint64_t)nsubj + 1);
     S.npass = (key_bits + SS_BITS - 1) / SS_BITS;
     // pass p writes `pong` when p is even: after npass passes the result is in pong (npass odd) or ping (npass even)
-    if (S.npass & 1) { S.pong = idx_out; S.ping = scratch; } else { S.ping = idx_out; S.pong = scratch; }
+    if (S.npass & 1) { S.idx_pong = idx_out; S.idx_ping = idx_tmp; S.key_pong = key_group_out; S.key_ping = key_tmp; }
+    else { S.idx_ping = idx_out; S.idx_pong = idx_tmp; S.key_ping = key_group_out; S.key_pong = key_tmp; }
     S.key_group = key_group_out;
     hipLaunchKernelGGL(seed_sort_small_kernel, dim3(1), dim3(SS_THREADS), 0, st, S);
     return hipGetLastError();

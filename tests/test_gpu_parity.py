@@ -898,11 +898,11 @@ def test_few_seeds_ordered_by_one_workgroup(case, monkeypatch):
     queries = [rng.integers(0, 4, qlen, dtype=np.uint8) for _ in range(nq)]
     lens = [int(x) for x in rng.integers(40, 120_000, nsub)] if case == "ragged" else [slen] * nsub
     subs = [rng.integers(0, 4, n, dtype=np.uint8) for n in lens]
-    for k in range(min(nq, 60)):
+    for k in range(min(max(nq, 8), 60)):
         s = subs[k % nsub]
         if len(s) < 2000:
             continue
-        q = queries[k]
+        q = queries[k % nq]
         piece = q[100:100 + 600].copy()
         m = rng.random(len(piece)) < 0.02
         piece[m] = (piece[m] + 1) & 3
