@@ -82,10 +82,10 @@ extern "C" __global__ void __launch_bounds__(SS_THREADS) seed_sort_small_kernel(
             for (int u = 0; u < SS_DEEP; u++) {
                 const uint32_t i = b0 + 64 * u + lane;
                 if (b0 + 64 * u >= i1) break;                                 // (uniform)
-                const bool valid = i < i1;
                 const uint32_t d = (uint32_t)(key[u] >> shift) & (SS_DIGITS - 1);
-                const unsigned long long m = same_digit(d, valid);
-                if (valid && !(m & lt)) hist[d][w] += (uint32_t)__popcll(m);  // (the group's lowest lane; a wave's row is its own)
+                // (counting needs no ranks: one LDS atomic without return per element instead of the six ballots of same_digit --
+                // the kernel is bound by the instructions ONE compute unit issues)
+                if (i < i1) __hip_atomic_fetch_add(&hist[d][w], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         }
         __syncthreads();

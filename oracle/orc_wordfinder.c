@@ -384,8 +384,18 @@ void orc_word_finder(OrcSearch *S, const uint8_t *subj, int32_t slen, OrcStats *
         S->carry_started = 1;
     }
 
+    /* stride 1 (blastn with a table as wide as the word): the reference's specialised scanners do not cut every word out of
+     * the bytes anew, they roll it on by one base (CORE/blast_nascan.c:1943-2072 for lut 11, the accumulating `index` of
+     * :361-445 for lut 8); `roll` holds the lut - 1 bases in front of s_off + lut - 1 */
+    uint32_t roll = 0; const int rolling = step == 1 && last >= 0;
+    if (rolling) { int32_t k; for (k = 0; k < lut - 1; k++) roll = (roll << 2) | ((subj[k >> 2] >> (2 * (3 - (k & 3)))) & 3u); }
     for (s_off = 0; s_off <= last; s_off += step) {
         uint32_t idx; int32_t nh, j;
+        if (rolling) {
+            const int32_t k = s_off + lut - 1;
+            roll = ((roll << 2) | ((subj[k >> 2] >> (2 * (3 - (k & 3)))) & 3u)) & mask;
+            idx = roll;
+        } else
         {   /* the lookup word from the packed bytes with shifts and a mask, as the reference's scanners cut it
              * (CORE/blast_nascan.c:1489-1591; lut <= 12: at most 4 + 1 bytes; the caller pads the subject) */
             const uint8_t *sp = subj + (s_off >> 2);
