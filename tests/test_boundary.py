@@ -175,7 +175,7 @@ def test_every_status_returning_entry_point_runs_behind_the_firewall():
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     missing = []
-    for f in ("engine.cpp", "collector.cpp", "dbreader.cpp", "traceback.cpp", "pipeline.cpp", "dust.cpp"):
+    for f in ("engine_abi.cpp", "engine.cpp", "collector.cpp", "dbreader.cpp", "traceback.cpp", "pipeline.cpp", "dust.cpp"):
         lines = open(os.path.join(root, "gblastn_amd", "csrc", f)).read().split("\n")
         for i, line in enumerate(lines):
             m = re.match(r'^(?:extern "C" )?(int|int64_t|int32_t|long) (gbn_\w+)\(', line)
