@@ -929,5 +929,6 @@ def test_few_seeds_ordered_by_one_workgroup(case, monkeypatch):
         seen[sw] = (got.tobytes(), km["seed keys"])
         ps.close()
     assert seen["1"][0] == seen["0"][0]
-    assert seen["1"][1] == 0 and seen["0"][1] > 0                 # (the key kernels belong to the library sorts only)
+    if not os.environ.get("GBN_DIAG_COMPACT_MIN"):                # (a run that sends every launch through the composite-key stage sorts that way whatever this switch says)
+        assert seen["1"][1] == 0 and seen["0"][1] > 0             # (the key kernels belong to the library sorts only)
     src.close()
