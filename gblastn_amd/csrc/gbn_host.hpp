@@ -42,7 +42,7 @@ struct HostLookup {
     bool masked = false;                // the reference's lut->masked_locations != NULL: seeds are re-checked
 };
 
-struct DeviceBatch;     // device mirrors, defined in engine.cpp
+struct DeviceBatch;     // device mirrors, defined in engine.hpp
 void trace_mark(const char *what);   // GBN_TRACE=1: wall-clock marks on stderr (engine.cpp)
 }  // namespace gbn
 
@@ -80,7 +80,7 @@ struct GbnDb {
     int64_t *d_byte_off = nullptr;
     int32_t *d_len = nullptr;
     void *tile_cache = nullptr;         // engine-private (tile tables per lut/step)
-    void *engine = nullptr;             // the device context (engine.cpp: Engine) the shard is resident on
+    void *engine = nullptr;             // the device context (engine.hpp: Engine) the shard is resident on
     // Sequences longer than the engine's MAX_DBSEQ_LEN are held and searched as chunks of that length overlapping
     // by DBSEQ_CHUNK_OVERLAP (CORE/blast_engine.c:218-262, :455-540): num_seqs / byte_off / len above describe the
     // chunks -- subjects of their own to every kernel -- and these map them back.  Empty: nothing is chunked.

@@ -1,6 +1,6 @@
 // lutbuild.hip -- the lookup structures of a query batch, built on the device.
 //
-// Same tables as the host builder (batch.cpp build_lookup + the cell tables of engine.cpp), i.e. the word
+// Same tables as the host builder (batch.cpp build_lookup + the cell tables of engine.cpp: upload_host_tables), i.e. the word
 // enumeration of CORE/blast_lookup.c:87-137 / CORE/blast_nalookup.c:873-928 over the indexed stretches
 // (strands minus soft masks, only stretches of at least word_size bases, no word with an ambiguity code),
 // every cell's query offsets in the order the reference reports them (megablast chains: descending;

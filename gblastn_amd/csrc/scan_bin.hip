@@ -1197,8 +1197,8 @@ probe_rare_kernel(GbnBinParams B, int nseg)
 }
 
 namespace gbn {
-// parts: 1 = binning kernel, 2 = probe kernel, 4 = rare kernel (7 = all; the rare kernel of a pass may run on another
-// stream next to the binning kernel of the next pass: engine.cpp, deferred rare path)
+// parts: 1 = binning kernel, 2 = probe kernel, 4 = rare kernel (7 = all; 6 = a pass over records that exist: the record cache,
+// a kernel queued ahead -- engine_scan.cpp; 1 = binning alone: bin-ahead, gbn_db_prepare_records)
 hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts, hipEvent_t tables_ready)
 {
     // ev[0..3]: before bin, after bin, after probe, after rare (optional); parts: 1 binning, 2 probe, 4 rare kernel, 8 no
