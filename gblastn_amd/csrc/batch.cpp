@@ -6,6 +6,7 @@
 // sbp, lookup_wrap): CORE/blast_setup.c:502-775, CORE/blast_parameters.c:160-470,
 // :822-979, CORE/blast_nalookup.c:51-189,384-427,831-1041, CORE/blast_lookup.c:87-137.
 #include "gbn_host.hpp"
+#include <functional>
 #include <thread>
 #include <algorithm>
 #include <cmath>
@@ -206,8 +207,15 @@ void fill_lookup_host(GbnBatch &b) {
     for (int64_t i = 0; i < L.ncells; i++) if (count[i]) L.pv[i >> 5] |= 1u << (i & 31);
 }
 
+// Order (round 5): what the LOOKUP TABLE needs first -- the concatenated query, the indexed stretches, the table's kind --
+// then `tables_hook` (the caller starts the device upload of the query and the table build there: they run on the builder's
+// stream while this thread goes on), then what only the HOST needs before the search: Karlin-Altschul parameters per
+// context, cut-offs, effective lengths (2 of a 5 Mb batch's 3 ms).  A context that turns out invalid only then (no
+// Karlin-Altschul solution: a query of ambiguity codes) was counted in the stretches; the table is chosen again without it
+// and *tables_stale says so.
 int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *const *seqs, const int32_t *lens,
-                const std::vector<QueryMask> &masks, bool host_tables) {
+                const std::vector<QueryMask> &masks, bool host_tables, const std::function<int()> &tables_hook, bool *tables_stale) {
+    if (tables_stale) *tables_stale = false;
     b.opt = opt; b.nq = nq;
     trace_mark("batch: set-up starts");
     b.ctx.assign((size_t)2 * nq, GbnContext{});
@@ -222,9 +230,9 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
     for (int i = 0; i < nq; i++) {
         int32_t L = lens[i];
         GbnContext &p = b.ctx[2 * i], &m = b.ctx[2 * i + 1];
-        p.query_offset = off; p.query_length = L; p.frame = 1; p.query_index = i;
+        p.query_offset = off; p.query_length = L; p.frame = 1; p.query_index = i; p.is_valid = L > 0;
         off += L + 1;
-        m.query_offset = off; m.query_length = L; m.frame = -1; m.query_index = i;
+        m.query_offset = off; m.query_length = L; m.frame = -1; m.query_index = i; m.is_valid = L > 0;
         off += L + 1;
     }
     b.qlen = off - 1;
@@ -247,6 +255,20 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
         }
     }
     trace_mark("batch: query concatenated");
+    // masks: per query ascending, disjoint, inside the query
+    for (size_t i = 0; i < masks.size(); i++) {
+        const QueryMask &k = masks[i];
+        if (k.query < 0 || k.query >= nq || k.from < 0 || k.to < k.from || k.to >= lens[k.query] ||
+            (i > 0 && masks[i - 1].query == k.query && masks[i - 1].to >= k.from) || (i > 0 && masks[i - 1].query > k.query)) {
+            set_error("query masks must be sorted by (query, from), disjoint and inside their query"); return GBN_ERR_ARG;
+        }
+    }
+    indexed_stretches(b, masks);
+    choose_table(b);
+    b.lut.masked = b.lut.masked && b.lut.word > b.lut.lut;
+    if (host_tables) fill_lookup_host(b);
+    trace_mark(host_tables ? "batch: lookup table built" : "batch: table kind chosen (tables are built on the device)");
+    if (tables_hook) { const int hrc = tables_hook(); if (hrc) return hrc; }
     build_score_matrix(opt.reward, opt.penalty, b.matrix);
     for (int i = 0; i < 256; i++) {
         int32_t s = 0;
@@ -261,7 +283,6 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
     auto ka_range = [&](size_t c0, size_t c1) {
         for (size_t i = c0; i < c1; i++) {
             GbnContext &c = b.ctx[i];
-            c.is_valid = 1;
             if (c.query_length <= 0) { c.is_valid = 0; continue; }
             double comp[16]; strand_composition(q + c.query_offset, c.query_length, comp);
             Karlin k;
@@ -298,20 +319,18 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
     b.container = b.qlen > 8000 ? 1 : 0;
     b.diag_len = 1;
     while (b.diag_len < b.qlen) b.diag_len <<= 1;
-    // masks: per query ascending, disjoint, inside the query
-    for (size_t i = 0; i < masks.size(); i++) {
-        const QueryMask &k = masks[i];
-        if (k.query < 0 || k.query >= nq || k.from < 0 || k.to < k.from || k.to >= lens[k.query] ||
-            (i > 0 && masks[i - 1].query == k.query && masks[i - 1].to >= k.from) || (i > 0 && masks[i - 1].query > k.query)) {
-            set_error("query masks must be sorted by (query, from), disjoint and inside their query"); return GBN_ERR_ARG;
-        }
-    }
     trace_mark("batch: cut-offs done");
-    indexed_stretches(b, masks);
-    choose_table(b);
-    if (host_tables) fill_lookup_host(b);
-    trace_mark(host_tables ? "batch: lookup table built" : "batch: table kind chosen (tables are built on the device)");
-    b.lut.masked = b.lut.masked && b.lut.word > b.lut.lut;
+    // a context without a Karlin-Altschul solution is no part of the search (CORE/blast_setup.c: the context is marked invalid
+    // before the lookup table is built): the stretches above counted it -- once more without it
+    bool lost = false;
+    for (const GbnContext &c : b.ctx) if (c.query_length > 0 && !c.is_valid) lost = true;
+    if (lost) {
+        indexed_stretches(b, masks);
+        choose_table(b);
+        b.lut.masked = b.lut.masked && b.lut.word > b.lut.lut;
+        if (host_tables) fill_lookup_host(b);
+        if (tables_stale) *tables_stale = true;
+    }
     return GBN_OK;
 }
 

@@ -422,6 +422,10 @@ static int build_tables_on_device(GbnBatch &b) {
 }
 
 int upload_batch(GbnBatch &b) {
+    const int rc = upload_batch_tables(b);
+    return rc ? rc : upload_batch_contexts(b);
+}
+int upload_batch_tables(GbnBatch &b) {
     int rc = enter_current();
     if (rc) return rc;
     DeviceBatch *d = new DeviceBatch();
@@ -467,6 +471,13 @@ int upload_batch(GbnBatch &b) {
         if ((rc = build_tables_on_device(b))) return rc;
     }
     trace_mark("upload: lookup structures on the device");
+    return GBN_OK;
+}
+int upload_batch_contexts(GbnBatch &b) {
+    DeviceBatch *d = b.dev;
+    if (!d || !d->eng) { set_error("upload_batch_contexts: no device structures"); return GBN_ERR_ARG; }
+    enter(d->eng);
+    int rc;
     std::vector<int32_t> off, len;
     for (auto &c : b.ctx) { off.push_back(c.query_offset); len.push_back(c.query_length); }
     if ((rc = dev_upload(d->ctx_off, off.data(), off.size()))) return rc;

@@ -502,8 +502,17 @@ int gbn_batch_new_masked(GbnBatch **out, const GbnOptions *opt, int32_t nq, cons
     for (int32_t i = 0; i < nmask; i++) masks[(size_t)i] = QueryMask{mask_query[i], mask_from[i], mask_to[i]};
     std::unique_ptr<GbnBatch, void (*)(GbnBatch *)> b(new GbnBatch(), gbn_batch_free);      // (freed if the set-up throws)
     // with a device the lookup tables are built there (upload_batch); a host-only set-up fills them here
-    int rc = build_batch(*b, *opt, nq, seqs, lens, masks, /* host_tables = */ upload == 0);
-    if (rc == GBN_OK && upload) rc = upload_batch(*b);
+    // (the device part starts in the middle of the host part: the query goes up and the lookup structures are queued on the
+    // builder's stream as soon as the table's kind is known, while this thread computes the Karlin-Altschul parameters)
+    bool stale = false;
+    GbnBatch *bp = b.get();
+    int rc = build_batch(*b, *opt, nq, seqs, lens, masks, /* host_tables = */ upload == 0,
+                         upload ? std::function<int()>([bp]() { return upload_batch_tables(*bp); }) : std::function<int()>(), &stale);
+    if (rc == GBN_OK && upload && stale) {              // a context dropped out after the tables were queued: once more, from the final stretches
+        if (bp->dev) { finish_build(bp->dev); free_device_batch(bp->dev); bp->dev = nullptr; }
+        rc = upload_batch_tables(*bp);
+    }
+    if (rc == GBN_OK && upload) rc = upload_batch_contexts(*b);
     if (rc != GBN_OK) return rc;
     *out = b.release();
     return GBN_OK;

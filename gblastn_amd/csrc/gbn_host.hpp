@@ -3,6 +3,7 @@
 #pragma once
 #include "../../include/gblastn_amd.h"
 #include <cstdint>
+#include <functional>
 #include <future>
 #include <string>
 #include <utility>
@@ -130,10 +131,13 @@ void set_error(const std::string &msg);
 struct QueryMask { int32_t query, from, to; };      // soft mask, plus-strand coordinates, inclusive
 int  build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq,
                  const uint8_t *const *seqs, const int32_t *lens,
-                 const std::vector<QueryMask> &masks = std::vector<QueryMask>(), bool host_tables = true);
+                 const std::vector<QueryMask> &masks = std::vector<QueryMask>(), bool host_tables = true,
+                 const std::function<int()> &tables_hook = std::function<int()>(), bool *tables_stale = nullptr);
 void predict_table_shape(const GbnOptions &opt, int32_t nq, const int32_t *lens, int &type, int &lut, int &step);   // batch.cpp
 void fill_lookup_host(GbnBatch &b);     // the host-side table builder (host-only set-up, GBN_HOST_LOOKUP=1)
-int  upload_batch(GbnBatch &b);
+int  upload_batch(GbnBatch &b);             // = upload_batch_tables + upload_batch_contexts
+int  upload_batch_tables(GbnBatch &b);      // the query on the device, the lookup structures queued on the builder's stream (needs what build_batch has when it calls its hook)
+int  upload_batch_contexts(GbnBatch &b);    // contexts, cut-offs, score tables (needs the finished host set-up)
 void free_device_batch(DeviceBatch *d);
 // chunk lists of one sequence (GbnHSP::pad_ = chunk ordinal + 1) -> one list per sequence (Blast_HSPListsMerge)
 void merge_chunk_lists(std::vector<GbnHSP> &hsps, int32_t chunk_len, const GbnResults::ChunkMerge &b, GbnDiagnostics *diag);
