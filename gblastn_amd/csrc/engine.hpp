@@ -120,11 +120,6 @@ struct Engine {
     GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
     hipEvent_t ev_seed = nullptr;
     GbnRareItem *rareq = nullptr; size_t rareq_cap = 0; uint32_t *rare_counts = nullptr;   // rare-path queue (the probe kernel's output: per query batch)
-    // ... twice: the rare kernel of pass k may run on the second stream, behind the host's back, while the probe kernel of pass
-    // k + 1 fills the other set (search_range: passes over cached records)
-    GbnRareItem *rareq_alt = nullptr; size_t rareq_alt_cap = 0; uint32_t *rare_counts_alt = nullptr;
-    void swap_rare_sets() { std::swap(rareq, rareq_alt); std::swap(rareq_cap, rareq_alt_cap); std::swap(rare_counts, rare_counts_alt); }
-    hipEvent_t ev_r0 = nullptr, ev_r1 = nullptr;       // around a rare kernel on the second stream
     // what the host reads after a scan, in ONE pinned block filled by asynchronous copies behind the kernels (round 4: the
     // counters, the overflow word and the rare-path counts came back through three blocking copies to pageable memory)
     struct ScanBack { unsigned long long cnt[2], seg_max; uint32_t overflow, pad_; uint32_t rare_counts[2048]; } *scan_back = nullptr;
@@ -256,9 +251,7 @@ int bin_layout(int nb, int64_t ntiles, int64_t npos, double slack, BinLayout &L)
 RecordSet *rec_find(const RecKey &key);
 int rec_acquire(const RecKey &key, const BinLayout &L, long long limit, RecordSet **out);
 constexpr int kSkewedRange = -1000;       // internal status of run_scan: split this subject range and try again
-// the rare kernel of a scan, left for another stream to run (search_range): its parameter block and launch shape
-struct DeferredRare { bool valid = false; GbnBinParams B; int grid2 = 0; };
-int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag, unsigned long long cnt[2], int64_t *bases_out, DeferredRare *defer = nullptr);
+int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag, unsigned long long cnt[2], int64_t *bases_out);
 
 // ---- the stages behind the scan (engine_stages.cpp)
 int compact_seeds(hipStream_t st);

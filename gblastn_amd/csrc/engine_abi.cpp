@@ -278,8 +278,6 @@ static void release_engine() {              // (the calling thread has entered i
     for (auto &KS : E.ks) { dev_free(KS.key_a); dev_free(KS.key_b); dev_free(KS.idx_a); dev_free(KS.idx_b); dev_free(KS.cell_diag); dev_free(KS.cell_level); dev_free(KS.ext_rec); dev_free(KS.sort_tmp); KS.key_cap = 0; KS.sort_tmp_bytes = 0; }
     for (int i = 0; i < 2; i++) { dev_free(E.ihits_s[i]); dev_free(E.gapped_s[i]); dev_free(E.gap_scratch_s[i]); E.ihit_cap_s[i] = E.gap_scratch_ints_s[i] = 0; }
     dev_free(E.counters); dev_free(E.rareq); E.rareq_cap = 0; dev_free(E.rare_counts);
-    dev_free(E.rareq_alt); E.rareq_alt_cap = 0; dev_free(E.rare_counts_alt);
-    if (E.ev_r0) { (void)hipEventDestroy(E.ev_r0); (void)hipEventDestroy(E.ev_r1); E.ev_r0 = E.ev_r1 = nullptr; }
     for (int i = 0; i < 2; i++) { E.ks[i].kt.destroy(); E.kt_gap[i].destroy(); }
     E.seed_cap = 0;
     if (E.gather_stage) (void)hipHostFree(E.gather_stage);

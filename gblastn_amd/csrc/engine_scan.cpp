@@ -63,14 +63,12 @@ long long rec_limit_bytes() {
 }
 size_t rec_held_bytes() { size_t n = 0; for (const RecordSet *r : E.rec_sets) n += r->bytes(); return n; }
 void rec_drop(size_t i, bool evicted) {
-    if (E.has_pending) (void)wait_pending_gpu();                               // (a rare kernel left to the stage in flight may still read it)
     if (E.rec_sets[i]->queued) (void)hipStreamSynchronize(E.stream);       // (a binning kernel queued by gbn_db_prepare_records may still write it)
     recset_free(*E.rec_sets[i]); delete E.rec_sets[i]; E.rec_sets.erase(E.rec_sets.begin() + (long)i);
     if (evicted) E.rec_evictions++;
 }
 // buffers change hands (what `dst` had is freed); neither side holds records afterwards
 void recset_move(RecordSet &dst, RecordSet &src) {
-    if (E.has_pending) (void)wait_pending_gpu();
     if (src.queued || dst.queued) (void)hipStreamSynchronize(E.stream);
     recset_free(dst);
     dst.bin_rec = src.bin_rec; dst.bin_rec_cap = src.bin_rec_cap; dst.bin_tcur = src.bin_tcur; dst.bin_tcur_cap = src.bin_tcur_cap;
@@ -150,7 +148,7 @@ int rec_acquire(const RecKey &key, const BinLayout &L, long long limit, RecordSe
     RecordSet *old = nullptr, *rs = nullptr;
     for (size_t i = E.rec_sets.size(); i-- > 0; ) if (E.rec_sets[i]->key.same_shape(key)) { if (!old) old = E.rec_sets[i]; else rec_drop(i, false); }
     if ((long long)L.bytes() <= limit) {
-        if (old) { rs = old; if (E.has_pending) (void)wait_pending_gpu(); }      // (binned into again: a rare kernel left to the stage in flight may still read it)
+        if (old) rs = old;
         else {
             rs = new RecordSet(); E.rec_sets.push_back(rs);
             // (the cache was switched on after passes that binned for themselves: their buffers are the first set's)
@@ -175,18 +173,17 @@ int rec_acquire(const RecKey &key, const BinLayout &L, long long limit, RecordSe
 // one scan of the subjects [s0, s1): fills E.seeds / cnt[0] seeds, cnt[1] raw hits;
 // dispatches to the direct-probe kernel (small tables) or the partitioned pair
 static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
-                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed, DeferredRare *defer = nullptr);
+                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed);
 
 // The partitioned scan sizes its streams for lookup words spread evenly over the bins (x1.25, x2.5).
 // Subjects dominated by one repeat (satellite arrays, poly-A) put most positions of a range into a
 // few bins; such a range goes through the direct-probe kernel instead, which has no streams.
 
 int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
-                    unsigned long long cnt[2], int64_t *bases_out, DeferredRare *defer)
+                    unsigned long long cnt[2], int64_t *bases_out)
 {
     bool skewed = false;
-    if (defer) defer->valid = false;
-    int rc = run_scan_impl(b, db, s0, s1, diag, cnt, bases_out, false, &skewed, defer);
+    int rc = run_scan_impl(b, db, s0, s1, diag, cnt, bases_out, false, &skewed);
     if (rc != GBN_OK || !skewed) return rc;
     int64_t bases = 0;
     for (int32_t s = s0; s < s1; s++) bases += db.len[s];
@@ -197,7 +194,7 @@ int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *dia
 }
 
 static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *diag,
-                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed, DeferredRare *defer)
+                         unsigned long long cnt[2], int64_t *bases_out, bool direct, bool *skewed)
 {
     // tables as wide as the word (stride 1, every lookup hit a seed): the presence bits are sliced through the LDS
     // instead of the scan positions being written out by key range (scan_slice_kernel); GBN_SCAN_SLICE=0: off
@@ -232,7 +229,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         E.counters_zeroed = false;
         GbnScanParams P; fill_scan_params(P, b, db, ts);
         uint32_t overflow = 0; int dbg_nwriters = 0; uint32_t dbg_subcap = 0;
-        bool binned = false, deferred = false;
+        bool binned = false;
         if (nb == 1) {
             HIPCHK(hipEventRecord(E.ev0, E.stream));
             if (b.dev->ready) HIPCHK(hipStreamWaitEvent(E.stream, b.dev->ready, 0));
@@ -295,9 +292,6 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             }
             if (!hit && !ahead_hit) HIPCHK(hipMemsetAsync(rs->bin_count + nstream, 0, 16, E.stream));     // (records that exist already: the flag of THAT launch is read back below)
             rs->stamp = ++E.rec_clock;
-            // the rare kernel is left to the caller's asynchronous stage when the records are the cache's (they stay where they are
-            // while it runs; a pass's own scratch set is written again by the next pass)
-            deferred = defer != nullptr && rec_limit > 0 && rs != &E.scratch;
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
             B.S = P; B.nb = nb; B.cbits = GBN_BIN_CBITS(b.lut.lut); B.nwriters = nwriters; dbg_nwriters = nwriters; dbg_subcap = (uint32_t)subcap;
             B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfrbits = std::min(7, 2 * b.dev->fr);
@@ -323,7 +317,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 B.rareq = E.rareq; B.rare_seg = (uint32_t)std::min<size_t>(seg, 0x7fffffff); B.rare_counts = E.rare_counts;
             }
             last_B = B; last_grid2 = grid2;
-            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, ((hit || ahead_hit) ? 2 : 3) | (deferred ? 0 : 4) | (ahead_hit ? 8 : 0), b.dev->ready));
+            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, ((hit || ahead_hit) ? 2 : 3) | 4 | (ahead_hit ? 8 : 0), b.dev->ready));
             binned = true; binned_ahead = ahead_hit;
             HIPCHK(hipMemcpyAsync(&E.scan_back->overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
             HIPCHK(hipMemcpyAsync(E.scan_back->rare_counts, E.rare_counts, (size_t)grid2 * 4, hipMemcpyDeviceToHost, E.stream));
@@ -425,7 +419,6 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             if (slack > 3.0) { *skewed = true; return GBN_OK; }
             continue;
         }
-        if (deferred) { defer->B = last_B; defer->grid2 = last_grid2; defer->valid = true; break; }     // (the seeds do not exist yet: whoever runs the rare kernel sizes their buffer)
         if (sliced) {       // the seeds sit in the workgroups' segments; E.seeds only has to be long enough for compact_seeds
             if (cnt[0] > E.seed_cap && (rc = grow_seed_buffers((size_t)cnt[0] + (cnt[0] >> 3)))) return rc;
             E.seg_valid = cnt[0] > 0; E.seg_n = slice_blocks; E.seg_len = (uint32_t)slice_seg_cap; E.seg_ordered = slice_ordered;

@@ -190,14 +190,7 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
         return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_stage = now();
     trace_mark("range: scan starts");
-    // Megablast shapes (a handful of seeds per million lookup hits) over CACHED records, with the caller pipelining: the rare
-    // kernel -- scattered sectors, bound by the rate at which HBM takes them, not by the CUs -- is left to the asynchronous
-    // stage, where it runs on the second stream next to the probe kernel of the NEXT pass (a stream of full lines): the two want
-    // different things of the memory system.  (Round 2 tried it next to the binning kernel of a fresh pass, which owns every CU:
-    // the binning kernel paid what the rare kernel gained.)  GBN_DEFER_RARE=0: the rare kernel stays on the scan's stream.
-    DeferredRare defer;
-    const bool want_defer = overlap && !keep_stages && b.lut.lut != b.lut.word && gbn::switch_value("GBN_DEFER_RARE", 1) != 0;
-    int rc = run_scan(b, db, s0, s1, diag, cnt, &bases, want_defer ? &defer : nullptr);
+    int rc = run_scan(b, db, s0, s1, diag, cnt, &bases);
     trace_mark("scan done");
     if (rc == kSkewedRange) {
         // lookup words of this range pile up in a few bins: halve it (by packed size) until the repeat-rich
@@ -214,59 +207,6 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
     if (rc) return rc;
     if (diag) diag->scan_stage_ms += ms_since(t_stage);
     t_stage = now();
-    if (defer.valid) {
-        if (diag) diag->subject_bases_scanned += bases;
-        if ((rc = wait_pending_gpu())) return rc;           // one asynchronous stage in flight at most; its buffers are free again
-        if (E.seeds_async_cap < ((size_t)1 << 20)) {
-            dev_free(E.seeds_async); E.seeds_async_cap = 0;
-            if ((rc = dev_alloc(E.seeds_async, (size_t)1 << 20))) return rc;
-            E.seeds_async_cap = (size_t)1 << 20;
-        }
-        if (!E.ev_r0) { HIPCHK(hipEventCreate(&E.ev_r0)); HIPCHK(hipEventCreate(&E.ev_r1)); }
-        E.swap_rare_sets();                                 // the next pass's probe kernel fills the other queue
-        E.slot ^= 1;
-        E.pending_err.clear();
-        const int dev = E.device, ksi = 0;                  // (no stage is in flight: either key set)
-        const unsigned long long raw_probe = cnt[1];
-        GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
-        Engine *eng = tl_eng;
-        E.pending = std::async(std::launch::async, [=]() -> int {
-            tl_eng = eng;
-            auto fail = [](int code, const char *what) { E.pending_err = what; return code; };
-            if (hipSetDevice(dev) != hipSuccess) return fail(GBN_ERR_HIP, "hipSetDevice failed in the extension thread");
-            GbnBinParams B = defer.B;
-            unsigned long long c2[2] = {0, 0};
-            for (;;) {
-                if (hipMemsetAsync(E.counters + 6, 0, 2 * sizeof(unsigned long long), E.stream2) != hipSuccess) return fail(GBN_ERR_HIP, "memset failed");
-                B.S.seeds = E.seeds_async; B.S.seed_count = E.counters + 6; B.S.seed_cap = E.seeds_async_cap; B.S.raw_hits = E.counters + 7;
-                (void)hipEventRecord(E.ev_r0, E.stream2);
-                if (launch_scan_bin_parts(B, defer.grid2, E.stream2, nullptr, 4, nullptr) != hipSuccess) return fail(GBN_ERR_HIP, "rare kernel launch failed");
-                (void)hipEventRecord(E.ev_r1, E.stream2);
-                if (hipMemcpyAsync(c2, E.counters + 6, sizeof(c2), hipMemcpyDeviceToHost, E.stream2) != hipSuccess ||
-                    hipStreamSynchronize(E.stream2) != hipSuccess) return fail(GBN_ERR_HIP, "rare kernel failed");
-                if (c2[0] <= E.seeds_async_cap) break;
-                dev_free(E.seeds_async); E.seeds_async_cap = 0;     // more seeds than room: once more with room
-                const size_t want = (size_t)c2[0] + (size_t)(c2[0] >> 3);
-                if (dev_alloc(E.seeds_async, want)) return fail(GBN_ERR_NOMEM, "out of device memory (seeds)");
-                E.seeds_async_cap = want;
-            }
-            if (diag) {
-                float ms = 0; (void)hipEventElapsedTime(&ms, E.ev_r0, E.ev_r1);
-                GBN_DIAG_LOCKED(diag->rare_kernel_ms += ms; diag->scan_kernel_ms += ms;
-                                diag->lookup_hits += (int64_t)(raw_probe + c2[1]); diag->seeds += (int64_t)c2[0]);
-            }
-            const int64_t n2 = (int64_t)c2[0];
-            if (n2 == 0) return GBN_OK;
-            if (n2 > INT32_MAX) return fail(GBN_ERR_NOMEM, "too many seeds in one range");
-            unsigned long long nih2 = 0;
-            int r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n2, E.counters + 4, E.stream2, &nih2, s0, s1, ksi);
-            if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2, true);
-            if (r) E.pending_err = gbn_last_error();      // the error text is per thread
-            return r;
-        });
-        E.has_pending = true; E.pending_res = rp; E.pending_ks = ksi; E.pending_batch = bp;
-        return GBN_OK;
-    }
     if (diag) { diag->lookup_hits += (int64_t)cnt[1]; diag->seeds += (int64_t)cnt[0]; diag->subject_bases_scanned += bases; }
     const int64_t n = (int64_t)cnt[0];
     if (n == 0) return GBN_OK;
