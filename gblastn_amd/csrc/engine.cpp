@@ -428,6 +428,7 @@ int upload_batch(GbnBatch &b) {
 int upload_batch_tables(GbnBatch &b) {
     int rc = enter_current();
     if (rc) return rc;
+    std::lock_guard<std::mutex> build_lock(E.build_mu);
     DeviceBatch *d = new DeviceBatch();
     d->eng = tl_eng;
     b.dev = d;

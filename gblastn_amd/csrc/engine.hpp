@@ -105,6 +105,10 @@ struct Engine {
     int32_t *gap_scratch_s[2] = {nullptr, nullptr}; size_t gap_scratch_ints_s[2] = {0, 0};
     int slot = 0; hipStream_t stream2 = nullptr;
     hipStream_t stream_build = nullptr;      // lookup structures of the next query batch are built next to a running search
+    // one batch's build is queued as a whole: two set-up threads that queue theirs at the same time would interleave their
+    // kernels on the builder's stream, and the batch that is searched first would have its tables when BOTH builds are done
+    // (round 5, seen in the trace of the cold config: the first probe kernel started 1.2 ms late)
+    std::mutex build_mu;
     std::future<int> pending; bool has_pending = false; std::string pending_err; const GbnResults *pending_res = nullptr;
     // host replays of finished gapped stages, one after the other in the order they were queued (each waits for its
     // predecessor): the stage's thread hands its copies over and is free for the next range's kernels
