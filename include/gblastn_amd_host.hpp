@@ -121,7 +121,6 @@ public:
     {
         for (int i = 0; i < kSetupThreads; i++) setup_.emplace_back([this] { SetupThread(); });
         prelim_ = std::thread([this] { PrelimSearchThread(); });
-        close_ = std::thread([this] { CloseThread(); });
         // two batches in the traceback stage at a time, each on half of the traceback threads
         inner_threads_ = std::max(1, (trace_threads + 1) / 2);
         for (int i = 0; i < (trace_threads > 1 ? 2 : 1); i++) trace_.emplace_back([this] { TraceBackThread(); });
@@ -152,7 +151,6 @@ public:
         for (auto &t : setup_) if (t.joinable()) t.join();
         setup_.clear();
         if (prelim_.joinable()) prelim_.join();
-        if (close_.joinable()) close_.join();
         for (auto &t : trace_) if (t.joinable()) t.join();
         trace_.clear();
     }
@@ -161,10 +159,10 @@ private:
     std::mutex mu_; std::condition_variable cv_;
     int inner_threads_ = 1;
     static const int kSetupThreads = 2;                  // a 5 Mb batch takes longer to set up than the GPU takes to scan it
-    std::deque<TItem> query_queue_, close_queue_, trace_queue_; std::map<int64_t, TItem> prelim_queue_, done_;   // prelim_queue_: set up, by number
+    std::deque<TItem> query_queue_, trace_queue_; std::map<int64_t, TItem> prelim_queue_, done_;   // prelim_queue_: set up, by number
     int64_t submitted_ = 0, delivered_ = 0, next_search_ = 0; int in_setup_ = 0, setup_exited_ = 0;
-    bool no_more_ = false, closing_ = false, setup_done_ = false, prelim_done_ = false, close_done_ = false;
-    std::thread prelim_, close_; std::vector<std::thread> setup_, trace_;
+    bool no_more_ = false, closing_ = false, setup_done_ = false, prelim_done_ = false;
+    std::thread prelim_; std::vector<std::thread> setup_, trace_;
 
     void Deliver(TItem it) { std::unique_lock<std::mutex> lk(mu_); done_[it->id] = std::move(it); cv_.notify_all(); }
     static void Guard(SWorkItem &it, const std::function<void()> &f) {
@@ -206,7 +204,7 @@ private:
                 std::unique_lock<std::mutex> lk(mu_);
                 // nothing to scan next: the batch in flight is finished now instead of underneath a scan
                 if (!prelim_queue_.count(next_search_) && in_setup_ == 0 && query_queue_.empty() && prev && !closing_ && !setup_done_) {
-                    lk.unlock(); PushClose(std::move(prev)); lk.lock();
+                    lk.unlock(); CloseStream(*prev); PushTrace(std::move(prev)); lk.lock();
                 }
                 cv_.wait(lk, [&] { return closing_ || prelim_queue_.count(next_search_) || setup_done_; });
                 auto f = prelim_queue_.find(next_search_);
@@ -215,31 +213,12 @@ private:
             }
             if (!it) continue;
             Guard(*it, [&] { it->prelim->Begin(); });                        // the scan of this batch; the stages of `prev` finish underneath
-            // (round 5) End + the collector of the batch before are the closer thread's: this thread goes straight on to the
-            // next scan -- with the scan records cached a scan is 5 ms, and the 0.3-0.5 ms of a stream's closing between two
-            // scans were time the GPU idled
-            if (prev) PushClose(std::move(prev));
+            if (prev) { CloseStream(*prev); PushTrace(std::move(prev)); }
             if (!overlap_) { CloseStream(*it); PushTrace(std::move(it)); }
             else prev = std::move(it);
         }
-        if (prev) PushClose(std::move(prev));
+        if (prev) { CloseStream(*prev); PushTrace(std::move(prev)); }
         std::unique_lock<std::mutex> lk(mu_); prelim_done_ = true; cv_.notify_all();
-    }
-    void PushClose(TItem it) { std::unique_lock<std::mutex> lk(mu_); close_queue_.push_back(std::move(it)); cv_.notify_all(); }
-    // scans that are done, in order: wait for the batch's extension stages, write its HSP lists into its stream, hand it on
-    void CloseThread() {
-        for (;;) {
-            TItem it;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return !close_queue_.empty() || prelim_done_ || closing_; });
-                if (!close_queue_.empty()) { it = std::move(close_queue_.front()); close_queue_.pop_front(); }
-                else if (prelim_done_ || closing_) { close_done_ = true; cv_.notify_all(); return; }
-            }
-            if (!it) continue;
-            CloseStream(*it);
-            PushTrace(std::move(it));
-        }
     }
     void PushTrace(TItem it) { std::unique_lock<std::mutex> lk(mu_); trace_queue_.push_back(std::move(it)); cv_.notify_all(); }
     void TraceBackThread() {
@@ -247,9 +226,9 @@ private:
             TItem it;
             {
                 std::unique_lock<std::mutex> lk(mu_);
-                cv_.wait(lk, [&] { return !trace_queue_.empty() || close_done_ || closing_; });
+                cv_.wait(lk, [&] { return !trace_queue_.empty() || prelim_done_ || closing_; });
                 if (!trace_queue_.empty()) { it = std::move(trace_queue_.front()); trace_queue_.pop_front(); }
-                else if (close_done_ || closing_) return;
+                else if (prelim_done_ || closing_) return;
             }
             if (!it) continue;
             if (traceback_) Guard(*it, [&] { it->traceback.reset(new CBlastTracebackSearch()); it->traceback->Run(*it->prelim, src_, *it->stream, inner_threads_); });
