@@ -747,7 +747,7 @@ def bench_shim(args, api, torch, dev, slab, mine, src, qsets, nbatch, opt, nsub,
     host_slab.copy_(slab); torch.cuda.synchronize()
     hs = host_slab.numpy()
     host_of = lambda k: hs[spans[k][0]:spans[k][1]]
-    default_group = 25
+    default_group = 100          # what the shim searches at a time with ONE leased GPU: every chunk the iterator still has, as one view
     up0 = L.gbn_debug_db_bytes_uploaded()
     d = api.GbnDiagnostics(); counts[0] = counts[1] = 0
     torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -756,14 +756,14 @@ def bench_shim(args, api, torch, dev, slab, mine, src, qsets, nbatch, opt, nsub,
     cold_ms = (time.perf_counter() - t0) * 1e3
     uploaded = L.gbn_debug_db_bytes_uploaded() - up0
     cold = {"ms_first_batch": cold_ms, "uploaded_GB": uploaded / 1e9, "effective_upload_GBps": uploaded / 1e9 / (cold_ms * 1e-3),
-            "what": "first call on an empty block cache, group of %d chunks: every block uploaded from pageable host memory by a synchronous copy when the loop "
-                    "reaches it (the searches of the groups before run underneath); the records are binned on the way" % default_group}
+            "what": "first call on an empty block cache: every block uploaded from pageable host memory by a synchronous copy when the loop reaches it, "
+                    "then ONE search over the view of all %d blocks, which bins its records on the way" % default_group}
     del hs, host_slab
     warm = {}
-    for group, style, tag in ((default_group, "pipelined", "group_25_chunks (the shim's default with one GPU)"), (nchunk, "pipelined", "group_100_chunks (one view = the whole shard)"),
-                              (5, "pipelined", "group_5_chunks"), (1, "pipelined", "group_1_chunk (pipelined begin / end per chunk)"),
+    for group, style, tag in ((default_group, "pipelined", "group_100_chunks (the shim's default with one GPU: one view over all blocks)"), (25, "pipelined", "group_25_chunks (four searches per batch)"),
+                              (3, "pipelined", "group_3_chunks (the shim's default with eight GPUs sharing the database)"), (1, "pipelined", "group_1_chunk (pipelined begin / end per chunk)"),
                               (1, "lists", "round_4_loop (one synchronous gbn_prelim_search_lists per chunk)")):
-        warm[tag] = measure(group, args.steps if group > 1 else max(2, args.steps // 5), style=style)
+        warm[tag] = measure(group, args.steps if group > 3 else max(2, args.steps // 5), style=style)
     # the same batches against the whole shard made the usual way (one GbnDb over the slab), set-up included, nothing overlapped
     api.record_cache_set_limit(0); api.record_cache_set_limit(-1)
     ps = api.BlastPrelimSearch(qsets[0], opt, src); ps.run(); ps.close()
@@ -776,7 +776,7 @@ def bench_shim(args, api, torch, dev, slab, mine, src, qsets, nbatch, opt, nsub,
         out.append((time.perf_counter() - t0) / args.steps * 1e3)
     out.sort()
     api.record_cache_set_limit(-1)
-    head = warm["group_25_chunks (the shim's default with one GPU)"]
+    head = warm["group_100_chunks (the shim's default with one GPU: one view over all blocks)"]
     cache = api.record_cache_stats()
     line = {"metric": "ms per query batch through the shim-shaped loop (C2 shard as 100 resident OID-chunk blocks, megablast 5,000 x 1 kb per batch)",
             "value": head["ms_per_batch"], "unit": "ms", "higher_is_better": False, "n_gpus": 1, "steps": args.steps, "warmup": 1,

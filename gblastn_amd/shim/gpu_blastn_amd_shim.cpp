@@ -200,15 +200,17 @@ GbnDb* s_GetBlock(const BlastSeqSrc* seq_src, const std::vector<Int4>& oids, Int
 }
 
 // Chunks per group.  A group is one search: the larger, the fewer fixed costs per query batch (each search loads the
-// lookup table's slices once per bin and ends in one host synchronisation); the smaller, the finer the N threads that
-// share the source's bookmark balance at the end of the database.  Default: a quarter of the chunks one GPU gets when
-// the leased GPUs share the database evenly (1 GPU: 25 chunks = 4 searches per query batch; 8 GPUs: 3);
-// GBN_SHIM_GROUP_CHUNKS overrides (1 = the reference's chunk-by-chunk loop).
+// lookup table's slices once per bin -- 0.5 ms on the C2 shard -- and ends in one host synchronisation); the smaller, the
+// finer the GPUs that share the source's bookmark balance at the end of the database.  One leased GPU: everything the
+// iterator still has, as ONE search (threads without a GPU are on the stock CPU path, a thousand times slower per chunk:
+// whatever the GPU thread leaves them is what the call waits for).  Several leased GPUs: a quarter of one GPU's share
+// (8 GPUs: 3 chunks).  GBN_SHIM_GROUP_CHUNKS overrides (1 = the reference's chunk-by-chunk loop).
 int s_leased_at_init = 1;
 int s_GroupChunks()
 {
     if (const char* e = getenv("GBN_SHIM_GROUP_CHUNKS")) { const int v = atoi(e); if (v >= 1) return v; }
-    const int g = 100 / (4 * (s_leased_at_init > 0 ? s_leased_at_init : 1));
+    if (s_leased_at_init <= 1) return 100;
+    const int g = 100 / (4 * s_leased_at_init);
     return g < 1 ? 1 : g;
 }
 
