@@ -8,11 +8,54 @@
 #include "gbn_host.hpp"
 #include <functional>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <vector>
 #include <algorithm>
 #include <cmath>
 #include <cstring>
 
 static const double kLn2 = 0.69314718055994530941723212145818;
+
+// A few worker threads that live as long as the library, for the per-context loops of a batch's set-up (10,000 contexts in a 5 Mb
+// megablast batch: strand copies, Karlin-Altschul parameters, effective lengths, cut-offs -- every context by itself, so the
+// results do not depend on who computes which).  Rounds 1-4 started and joined a set of threads per loop: 0.3-0.5 ms each time.
+namespace {
+class SetupPool {
+    std::vector<std::thread> workers_; std::mutex mu_; std::condition_variable cv_;
+    std::deque<std::function<void()>> jobs_; bool stop_ = false;
+    void loop() {
+        for (;;) {
+            std::function<void()> job;
+            { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return stop_ || !jobs_.empty(); }); if (jobs_.empty()) return; job = std::move(jobs_.front()); jobs_.pop_front(); }
+            job();
+        }
+    }
+public:
+    explicit SetupPool(int n) { for (int i = 0; i < n; i++) workers_.emplace_back([this] { loop(); }); }
+    ~SetupPool() { { std::lock_guard<std::mutex> lk(mu_); stop_ = true; } cv_.notify_all(); for (auto &t : workers_) t.join(); }
+    int size() const { return (int)workers_.size(); }
+    // f(i0, i1) over [0, n) in pieces of at least `grain`; the caller takes a piece itself and returns when all are done
+    void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)> &f) {
+        const size_t pieces = std::max<size_t>(1, std::min<size_t>((size_t)size() + 1, n / std::max<size_t>(grain, 1)));
+        if (pieces <= 1) { f(0, n); return; }
+        std::mutex dmu; std::condition_variable dcv; size_t left = pieces - 1;
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (size_t p = 1; p < pieces; p++)
+                jobs_.emplace_back([&, p] { f(n * p / pieces, n * (p + 1) / pieces); std::lock_guard<std::mutex> dl(dmu); if (--left == 0) dcv.notify_one(); });
+        }
+        cv_.notify_all();
+        f(0, n / pieces);
+        std::unique_lock<std::mutex> dl(dmu); dcv.wait(dl, [&] { return left == 0; });
+    }
+};
+SetupPool &setup_pool() {
+    static SetupPool pool((int)std::max(2u, std::min(15u, std::max(1u, std::thread::hardware_concurrency()) / 4u)));
+    return pool;
+}
+}  // namespace
 
 void gbn_default_options(GbnOptions *o, int megablast) {
     // API/blast_nucl_options.cpp:108-234
@@ -38,7 +81,9 @@ int GbnBatch::context_of(int32_t n) const {
 
 void GbnBatch::set_effective_lengths(int64_t db_len, int32_t db_nseq) {
     if (db_len == 0) return;
-    for (auto &c : ctx) {
+    setup_pool().parallel_for(ctx.size(), 256, [&](size_t i0, size_t i1) {
+    for (size_t ci = i0; ci < i1; ci++) {
+        GbnContext &c = ctx[ci];
         int32_t adj = 0; int64_t eff = 0;
         if (c.is_valid && c.query_length > 0) {
             gbn::Karlin ku; ku.lambda = c.lambda_u; ku.K = c.K_u; ku.logK = c.logK_u; ku.H = c.H_u;
@@ -52,10 +97,13 @@ void GbnBatch::set_effective_lengths(int64_t db_len, int32_t db_nseq) {
         }
         c.eff_searchsp = eff; c.length_adjustment = adj;
     }
+    });
 }
 
 void GbnBatch::update_cutoffs() {
-    for (auto &c : ctx) {
+    setup_pool().parallel_for(ctx.size(), 512, [&](size_t i0, size_t i1) {
+    for (size_t ci = i0; ci < i1; ci++) {
+        GbnContext &c = ctx[ci];
         if (!c.is_valid) { c.gap_cutoff_score = INT32_MAX; c.cutoff_score = INT32_MAX; continue; }
         if (opt.cutoff_score > 0) c.gap_cutoff_score = c.gap_cutoff_score_max = opt.cutoff_score;
         else c.gap_cutoff_score = c.gap_cutoff_score_max =
@@ -67,6 +115,7 @@ void GbnBatch::update_cutoffs() {
         c.cutoff_score = cut;
         c.reduced_cutoff = (int32_t)(0.9 * cut);
     }
+    });
 }
 
 namespace gbn {
@@ -244,16 +293,8 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
             for (int32_t j = 0; j < L; j++) r[j] = kComplement[seqs[i][L - 1 - j] & 15];
         }
     };
-    {
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const int nthr = (total < (1 << 20) || nq < 16) ? 1 : (int)std::min<unsigned>({hw, 8u, (unsigned)nq / 8u});
-        if (nthr <= 1) fill_range(0, nq);
-        else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nthr; t++) pool.emplace_back(fill_range, (int)((int64_t)nq * t / nthr), (int)((int64_t)nq * (t + 1) / nthr));
-            for (auto &th : pool) th.join();
-        }
-    }
+    if (total < (1 << 18) || nq < 16) fill_range(0, nq);
+    else setup_pool().parallel_for((size_t)nq, 64, [&](size_t i0, size_t i1) { fill_range((int)i0, (int)i1); });
     trace_mark("batch: query concatenated");
     // masks: per query ascending, disjoint, inside the query
     for (size_t i = 0; i < masks.size(); i++) {
@@ -292,17 +333,8 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
             c.lambda_u = k.lambda; c.K_u = k.K; c.logK_u = k.logK; c.H_u = k.H;
         }
     };
-    {
-        const size_t nctx = b.ctx.size();
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-        const size_t nthr = nctx < 512 ? 1 : std::min<size_t>({(size_t)hw, (size_t)16, nctx / 128});
-        if (nthr <= 1) ka_range(0, nctx);
-        else {
-            std::vector<std::thread> pool;
-            for (size_t t = 0; t < nthr; t++) pool.emplace_back(ka_range, nctx * t / nthr, nctx * (t + 1) / nthr);
-            for (auto &th : pool) th.join();
-        }
-    }
+    if (b.ctx.size() < 512) ka_range(0, b.ctx.size());
+    else setup_pool().parallel_for(b.ctx.size(), 128, ka_range);
     bool any = false; Karlin first;
     for (auto &c : b.ctx) if (c.is_valid) { first.lambda = c.lambda_u; first.K = c.K_u; first.logK = c.logK_u; first.H = c.H_u; any = true; break; }
     trace_mark("batch: Karlin-Altschul per context done");

@@ -192,8 +192,7 @@ void free_device_batch(DeviceBatch *d) {
     if (!d) return;
     finish_build(d);
     dev_free(d->q8_base); dev_free(d->q2_base); dev_free(d->qinv_base); dev_free(d->q4_base); dev_free(d->pv); dev_free(d->cellw); dev_free(d->cellt); dev_free(d->sidet); dev_free(d->side_start); dev_free(d->cell_start); dev_free(d->ent); dev_free(d->pvx); dev_free(d->pstart);
-    dev_free(d->ctx_off); dev_free(d->ctx_len); dev_free(d->ctx_xdrop); dev_free(d->ctx_cutoff); dev_free(d->ctx_pack);
-    dev_free(d->ctx_reduced); dev_free(d->ctx_hint); dev_free(d->ctx_blk); dev_free(d->matrix); dev_free(d->score_table);
+    dev_free(d->ctx_block);                             // (ctx_off ... score_table point into it)
     delete d;
 }
 
@@ -205,17 +204,37 @@ static inline uint32_t fingerprint(const uint8_t *q, int32_t off, int lut, bool 
     return (l << 15) | (r << 1) | (force ? 1u : 0u);
 }
 
+// Everything a batch's kernels read per CONTEXT lives in one device block, filled by one copy (round 5; rounds 1-4: ten
+// allocations and ten blocking copies, 0.4 ms of a 3.6 ms set-up): offsets, lengths, the cut-offs (x_dropoff, cut-off,
+// reduced cut-off, and the three packed for one 16-byte read), the context hints per 64 query positions, matrix and score
+// table.  Segments start at multiples of four words.
+namespace {
+struct CtxLayout { size_t n, h, off, len, xdrop, cutoff, reduced, pack, hint, blk, matrix, table, total; };
+CtxLayout ctx_layout(const GbnBatch &b) {
+    CtxLayout L; auto up = [](size_t v) { return (v + 3) & ~(size_t)3; };
+    L.n = b.ctx.size(); L.h = ((size_t)b.qlen >> kCtxHintShift) + 2;
+    size_t at = 0;
+    L.off = at; at += up(L.n); L.len = at; at += up(L.n);
+    L.xdrop = at; at += up(L.n); L.cutoff = at; at += up(L.n); L.reduced = at; at += up(L.n); L.pack = at; at += up(4 * L.n);
+    L.hint = at; at += up(L.h); L.blk = at; at += up(2 * L.h); L.matrix = at; at += 256; L.table = at; at += 256;
+    L.total = at;
+    return L;
+}
+void fill_cutoffs(const GbnBatch &b, const CtxLayout &L, int32_t *w) {      // w: the block's words on the host
+    for (size_t c = 0; c < L.n; c++) {
+        const GbnContext &x = b.ctx[c];
+        w[L.xdrop + c] = x.x_dropoff; w[L.cutoff + c] = x.cutoff_score; w[L.reduced + c] = x.reduced_cutoff;
+        w[L.pack + 4 * c] = x.x_dropoff; w[L.pack + 4 * c + 1] = x.reduced_cutoff; w[L.pack + 4 * c + 2] = x.cutoff_score; w[L.pack + 4 * c + 3] = 0;
+    }
+}
+}  // namespace
+// the cut-offs of every context once more (a search without a database length recomputes them per subject)
 int upload_ctx_cutoffs(GbnBatch &b) {
     DeviceBatch *d = b.dev;
-    std::vector<int32_t> xd, cu, rd;
-    for (auto &c : b.ctx) { xd.push_back(c.x_dropoff); cu.push_back(c.cutoff_score); rd.push_back(c.reduced_cutoff); }
-    size_t n = b.ctx.size();
-    HIPCHK(hipMemcpy(d->ctx_xdrop, xd.data(), n * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d->ctx_cutoff, cu.data(), n * 4, hipMemcpyHostToDevice));
-    HIPCHK(hipMemcpy(d->ctx_reduced, rd.data(), n * 4, hipMemcpyHostToDevice));
-    std::vector<int32_t> pk(4 * n);
-    for (size_t c = 0; c < n; c++) { pk[4 * c] = xd[c]; pk[4 * c + 1] = rd[c]; pk[4 * c + 2] = cu[c]; pk[4 * c + 3] = 0; }
-    HIPCHK(hipMemcpy(d->ctx_pack, pk.data(), 4 * n * 4, hipMemcpyHostToDevice));
+    const CtxLayout L = ctx_layout(b);
+    std::vector<int32_t> w(L.hint, 0);                  // (the block's words up to the end of the cut-offs)
+    fill_cutoffs(b, L, w.data());
+    HIPCHK(hipMemcpy(d->ctx_block + L.xdrop, w.data() + L.xdrop, (L.hint - L.xdrop) * 4, hipMemcpyHostToDevice));
     return GBN_OK;
 }
 
@@ -479,37 +498,32 @@ int upload_batch_contexts(GbnBatch &b) {
     if (!d || !d->eng) { set_error("upload_batch_contexts: no device structures"); return GBN_ERR_ARG; }
     enter(d->eng);
     int rc;
-    std::vector<int32_t> off, len;
-    for (auto &c : b.ctx) { off.push_back(c.query_offset); len.push_back(c.query_length); }
-    if ((rc = dev_upload(d->ctx_off, off.data(), off.size()))) return rc;
-    if ((rc = dev_upload(d->ctx_len, len.data(), len.size()))) return rc;
-    if ((rc = dev_alloc(d->ctx_xdrop, off.size()))) return rc;
-    if ((rc = dev_alloc(d->ctx_pack, 4 * off.size()))) return rc;
-    if ((rc = dev_alloc(d->ctx_cutoff, off.size()))) return rc;
-    if ((rc = dev_alloc(d->ctx_reduced, off.size()))) return rc;
-    if ((rc = upload_ctx_cutoffs(b))) return rc;
+    const CtxLayout L = ctx_layout(b);
+    std::vector<int32_t> w(L.total, 0);
+    for (size_t c = 0; c < L.n; c++) { w[L.off + c] = b.ctx[c].query_offset; w[L.len + c] = b.ctx[c].query_length; }
+    fill_cutoffs(b, L, w.data());
     {   // context of every kCtxHintShift-aligned query position (the kernels walk on from there: contexts are rarely shorter)
-        std::vector<int32_t> hint(((size_t)b.qlen >> kCtxHintShift) + 2);
         size_t c = 0;
-        for (size_t k = 0; k < hint.size(); k++) {
+        for (size_t k = 0; k < L.h; k++) {
             const int64_t qpos = (int64_t)k << kCtxHintShift;
-            while (c + 1 < off.size() && off[c + 1] <= qpos) c++;
-            hint[k] = (int32_t)c;
+            while (c + 1 < L.n && w[L.off + c + 1] <= qpos) c++;
+            w[L.hint + k] = (int32_t)c;
         }
-        if ((rc = dev_upload(d->ctx_hint, hint.data(), hint.size()))) return rc;
         // ... and per block: that context and where the next one begins (GbnExtParams::ctx_blk)
-        std::vector<int32_t> blk(2 * hint.size());
-        for (size_t k = 0; k < hint.size(); k++) {
-            const size_t ci = (size_t)hint[k];
+        for (size_t k = 0; k < L.h; k++) {
+            const size_t ci = (size_t)w[L.hint + k];
             const int64_t last = ((int64_t)k << kCtxHintShift) + ((int64_t)1 << kCtxHintShift) - 1;
-            blk[2 * k] = hint[k];
-            blk[2 * k + 1] = ci + 1 < off.size() ? off[ci + 1] : INT32_MAX;
-            if (ci + 2 < off.size() && off[ci + 2] <= last) blk[2 * k + 1] = INT32_MIN;
+            w[L.blk + 2 * k] = w[L.hint + k];
+            w[L.blk + 2 * k + 1] = ci + 1 < L.n ? w[L.off + ci + 1] : INT32_MAX;
+            if (ci + 2 < L.n && w[L.off + ci + 2] <= last) w[L.blk + 2 * k + 1] = INT32_MIN;
         }
-        if ((rc = dev_upload(d->ctx_blk, blk.data(), blk.size()))) return rc;
     }
-    if ((rc = dev_upload(d->matrix, &b.matrix[0][0], 256))) return rc;
-    if ((rc = dev_upload(d->score_table, b.score_table, 256))) return rc;
+    std::memcpy(&w[L.matrix], &b.matrix[0][0], 256 * 4);
+    std::memcpy(&w[L.table], b.score_table, 256 * 4);
+    if ((rc = dev_upload(d->ctx_block, w.data(), w.size()))) return rc;
+    d->ctx_off = d->ctx_block + L.off; d->ctx_len = d->ctx_block + L.len; d->ctx_xdrop = d->ctx_block + L.xdrop;
+    d->ctx_cutoff = d->ctx_block + L.cutoff; d->ctx_reduced = d->ctx_block + L.reduced; d->ctx_pack = d->ctx_block + L.pack;
+    d->ctx_hint = d->ctx_block + L.hint; d->ctx_blk = d->ctx_block + L.blk; d->matrix = d->ctx_block + L.matrix; d->score_table = d->ctx_block + L.table;
     trace_mark("upload: done");
     return GBN_OK;
 }

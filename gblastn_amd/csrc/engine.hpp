@@ -75,6 +75,7 @@ struct DeviceBatch {
     int32_t *ctx_off = nullptr, *ctx_len = nullptr, *ctx_xdrop = nullptr, *ctx_cutoff = nullptr,
             *ctx_reduced = nullptr, *ctx_hint = nullptr, *ctx_blk = nullptr, *ctx_pack = nullptr;   // ctx_pack[4 c ..]: x_dropoff, reduced cut-off, cut-off of context c in one 16-byte read    // ctx_hint[q >> kCtxHintShift]: the context position (q & ~mask) lies in
     int32_t *matrix = nullptr, *score_table = nullptr;
+    int32_t *ctx_block = nullptr;       // the one allocation ctx_off ... ctx_pack, ctx_hint, ctx_blk, matrix and score_table point into
     int mode = 0, fl = 0, fr = 0;
     // lookup structures still being built on the builder's stream: the event they are complete at, and the
     // builder's scratch, which goes back to the pool once it has fired
