@@ -52,7 +52,7 @@ public:
     }
 };
 SetupPool &setup_pool() {
-    static SetupPool pool((int)std::max(2u, std::min(15u, std::max(1u, std::thread::hardware_concurrency()) / 4u)));
+    static SetupPool pool((int)std::max(2u, std::min(31u, std::max(1u, std::thread::hardware_concurrency()) / 8u)));     // (a 256-thread host: 31 workers + the caller; eight ranks of a node each have their own)
     return pool;
 }
 }  // namespace
