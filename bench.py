@@ -761,7 +761,7 @@ def bench_shim(args, api, torch, dev, slab, mine, src, qsets, nbatch, opt, nsub,
     del hs, host_slab
     warm = {}
     for group, style, tag in ((default_group, "pipelined", "group_100_chunks (the shim's default with one GPU: one view over all blocks)"), (25, "pipelined", "group_25_chunks (four searches per batch)"),
-                              (3, "pipelined", "group_3_chunks (the shim's default with eight GPUs sharing the database)"), (1, "pipelined", "group_1_chunk (pipelined begin / end per chunk)"),
+                              (3, "pipelined", "group_3_chunks (the group size with eight leased GPUs; here ONE GPU searches all 34 groups -- each of eight would search four)"), (1, "pipelined", "group_1_chunk (pipelined begin / end per chunk)"),
                               (1, "lists", "round_4_loop (one synchronous gbn_prelim_search_lists per chunk)")):
         warm[tag] = measure(group, args.steps if group > 3 else max(2, args.steps // 5), style=style)
     # the same batches against the whole shard made the usual way (one GbnDb over the slab), set-up included, nothing overlapped
