@@ -81,7 +81,7 @@ struct GbnBinParams {
     uint32_t subcap;
     uint32_t *overflow;             // set to 1 if any stream did not fit
     int rfl, rfrbits;               // reduced fingerprint: bases on the left (<= 4), BITS on the right (<= 7 = 3.5 bases)
-    int dbg;                        // host-side launch switches of tools/scan_ablate.py (1: no rare kernel, 32: timing print, 64: any-stride binning kernel); never read on the device
+    int dbg;                        // launch switches of tools/scan_ablate.py (GBN_DBG; 1: no rare kernel, 32: timing print, 64: any-stride binning kernel, 128: XCD report, 256: probe kernel without the sixteenth fingerprint bit)
     GbnRareItem *rareq; uint32_t rare_seg;    // rare-path queue: one segment of rare_seg items per probe workgroup
     uint32_t *rare_counts;              // [probe workgroups] items queued (may exceed rare_seg: overflow)
 };

@@ -136,7 +136,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
                 const uint32_t w0 = o ? __builtin_amdgcn_alignbit(x[a], x[a + 1], 32 - o) : x[a];
                 const uint32_t w1 = o2 ? __builtin_amdgcn_alignbit(x[a2], x[a2 + 1 < NDW ? a2 + 1 : NDW - 1], 32 - o2) : x[a2];
                 bin[k] = (w0 >> 15) & 0x1ffu;
-                hi[k] = __builtin_amdgcn_perm(w1, w0, 0x07030100u);
+                hi[k] = (__builtin_amdgcn_perm(w1, w0, 0x07030100u) & 0x7fffffffu) | ((w1 << 8) & 0x80000000u);     // (bit 31: the EIGHTH subject bit behind the word, w1's bit 23 -- round 5)
             } else {
                 uint64_t w;
                 if constexpr (STEP > 0) {
@@ -151,7 +151,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
                 }
                 const uint32_t c = (uint32_t)(w >> cshift) & mask;
                 bin[k] = c >> cbits;
-                hi[k] = (c & lowmask) | ((uint32_t)(w >> 56) << 16) | (((uint32_t)(w >> rshift) & 0x7fu) << 24);
+                hi[k] = (c & lowmask) | ((uint32_t)(w >> 56) << 16) | (((uint32_t)(w >> rshift) & 0x7fu) << 24) | (((uint32_t)(w >> (rshift - 1)) & 1u) << 31);
             }
         }
     };
@@ -505,7 +505,7 @@ __device__ __forceinline__ void scan_bin3_body(const GbnBinParams &B)
                 const uint32_t w0 = o ? __builtin_amdgcn_alignbit(x[a], x[a + 1], 32 - o) : x[a];
                 const uint32_t w1 = o2 ? __builtin_amdgcn_alignbit(x[a2], x[a2 + 1 < NDW ? a2 + 1 : NDW - 1], 32 - o2) : x[a2];
                 bin[k] = (w0 >> 15) & 0x1ffu;
-                hi[k] = __builtin_amdgcn_perm(w1, w0, 0x07030100u);
+                hi[k] = (__builtin_amdgcn_perm(w1, w0, 0x07030100u) & 0x7fffffffu) | ((w1 << 8) & 0x80000000u);     // (bit 31: the EIGHTH subject bit behind the word, w1's bit 23 -- round 5)
             } else {
                 uint64_t w;
                 if constexpr (STEP > 0) {
@@ -520,7 +520,7 @@ __device__ __forceinline__ void scan_bin3_body(const GbnBinParams &B)
                 }
                 const uint32_t c = (uint32_t)(w >> cshift) & mask;
                 bin[k] = c >> cbits;
-                hi[k] = (c & lowmask) | ((uint32_t)(w >> 56) << 16) | (((uint32_t)(w >> rshift) & 0x7fu) << 24);
+                hi[k] = (c & lowmask) | ((uint32_t)(w >> 56) << 16) | (((uint32_t)(w >> rshift) & 0x7fu) << 24) | (((uint32_t)(w >> (rshift - 1)) & 1u) << 31);
             }
         }
     };
@@ -860,6 +860,7 @@ probe_bin_kernel(GbnBinParams B)
     const uint32_t lmask = (B.rfl <= 0) ? 0u : ((1u << (2 * B.rfl)) - 1);                               // byte 0 of an fp15
     const uint32_t rmask = (B.rfrbits <= 0) ? 0u : (((1u << B.rfrbits) - 1) << (7 - B.rfrbits));      // byte 1
     const uint32_t m4 = (lmask | (rmask << 8)) * 0x10001u;          // both fingerprints of a cell word at once
+    const bool fp16 = B.rfl >= 4 && B.rfrbits >= 7 && P.fr >= 4 && !(B.dbg & 256);       // the sixteenth fingerprint bit (flush; GBN_DBG=256: off, A/B): full reduced widths, at least 4 bases behind the word in the full fingerprint
     uint2 *q = s_q + wave * GBN_BIN_QCAP;
     int qn = 0;                                                     // wave-uniform
     unsigned long long raw = 0;
@@ -873,14 +874,14 @@ probe_bin_kernel(GbnBinParams B)
     auto flush = [&](int first, int cnt, int bin) {
         const uint32_t *const tab = s_tab + GBN_BIN_TAB0;
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");      // queue slots written by other lanes of this wave
-        bool keep = false; uint32_t at_rec = 0, cv = 0;
+        bool keep = false; uint32_t at_rec = 0, cv = 0, hv_q = 0;
         if (lane < cnt) {
             // the queue holds the record's index inside the bin's region and its hi word (picked out of the lane's eight
             // registers by a select tree when it was queued: round 4 read the record again here, a scattered load and a wait of
             // its full latency per 64 queued records -- affordable now that the main loop's tests run on the scalar unit)
             const uint2 qe = q[first + lane];
             at_rec = qe.x;
-            const uint32_t hv = qe.y;
+            const uint32_t hv = qe.y; hv_q = hv;
             const uint32_t low = hv & 0x7fffu, sf = (hv >> 16) & 0x7fffu;
             cv = ((uint32_t)bin << cbits) | low;
             keep = true;
@@ -898,6 +899,27 @@ probe_bin_kernel(GbnBinParams B)
                 }
             }
         }
+#if GBN_PROBE_FETCH
+        // the cell's direct-probe word travels with the item (GbnRareItem): fetched here, by the few lanes that keep one,
+        // underneath the streams of the other waves.  Round 5: it also decides whether the item travels at all.  The word holds
+        // the FULL fingerprint of the cell's first entry; the record's hi word holds 16 subject bits around the lookup word -- the 4
+        // bases in front and, since round 5, EIGHT bits behind (bit 31: the binning kernel's bit that was undefined).  The table
+        // in LDS has room for 15 of them per entry, which lets 2^-8 + 2^-7 of the lookup hits through; for a cell with ONE entry
+        // (55 % of the lookup hits) the sixteenth bit is tested here: a seed needs the 8 bases in front or the 7 behind to
+        // match (fp_pass), so 4 in front or 4 behind is necessary -- a sixth fewer items for the rare kernel, each of which
+        // costs it a scattered subject sector.
+        uint32_t cw = 0;
+        if (keep) {
+            cw = P.cellw[cv & 0x7fffffffu];
+            if (fp16 && !(cv >> 31) && !(cw >> 31) && !(cw & 1u)) {          // one entry, not forced, not an always-rare cell
+                const uint32_t sl8 = (hv_q >> 16) & 0xffu, sr8 = (((hv_q >> 24) & 0x7fu) << 1) | (hv_q >> 31);
+                const uint32_t el8 = (cw >> 15) & 0xffu, er8 = (cw >> 7) & 0xffu;
+                keep = sl8 == el8 || sr8 == er8;
+            }
+        }
+#else
+        const uint32_t cw = 0;                                      // (fetched by the rare kernel)
+#endif
         const unsigned long long m = __ballot(keep);
         if (m) {
             uint32_t base = 0;
@@ -907,13 +929,11 @@ probe_bin_kernel(GbnBinParams B)
                 const uint32_t at = base + (uint32_t)__popcll(m & lt);
                 if (at < B.rare_seg) {
 #if GBN_PROBE_FETCH
-                    // the record's index and the cell's direct-probe word travel with the item (GbnRareItem): two scattered
-                    // sectors per item fetched here, by the few lanes that keep one, underneath the streams of the other waves
+                    // ... and the record's index: the second scattered sector per item
                     const uint32_t wr = at_rec / B.subcap, jr = at_rec - wr * B.subcap;
                     const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, jr))];
-                    const uint32_t cw = P.cellw[cv & 0x7fffffffu];
 #else
-                    const uint32_t idx = 0, cw = 0;                 // (fetched by the rare kernel)
+                    const uint32_t idx = 0;
 #endif
                     uint4 it; it.x = at_rec; it.y = cv; it.z = idx; it.w = cw;      // at_rec: resolved to a position id by the rare kernel
                     *reinterpret_cast<uint4 *>(myq + at) = it;
