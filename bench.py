@@ -184,8 +184,8 @@ def main():
                 b = make(k)
                 n += merge(len(b._q), b.run()); diags.append(b.diagnostics); b.close()
             return n
-        def finish(b, out):                 # worker thread: merge, then release the batch
-            got = merge(len(b._q), out)
+        def finish(b):                      # worker thread: wait for the batch's extension stages (they were queued before the
+            got = merge(len(b._q), b.end())  # next batch's begin() returned: that begin() is over), merge, release the batch
             b.close()
             return got
         prev, futs = None, []
@@ -204,9 +204,9 @@ def main():
                 ahead.append(setup_pool.submit(make, queued)); queued += 1
             b.begin()                       # waits for prev's extension stages before queueing its own
             if prev is not None:
-                futs.append(merger.submit(finish, prev, prev.end())); diags.append(prev.diagnostics)
+                futs.append(merger.submit(finish, prev)); diags.append(prev.diagnostics)     # (the main thread goes straight to the next begin())
             prev = b
-        futs.append(merger.submit(finish, prev, prev.end())); diags.append(prev.diagnostics)
+        futs.append(merger.submit(finish, prev)); diags.append(prev.diagnostics)
         got = n + sum(f.result() for f in futs)
         for f in ahead:                     # the next region's first batches: set up, lookup structures queued on the builder's stream
             f.result()

@@ -223,7 +223,7 @@ template <class T> inline void dev_free(T *&p) { if (p) pool_free((void *)p); p 
 // ---- query batches on the device, tile tables, scratch, the stage in flight (engine.cpp)
 void finish_build(DeviceBatch *d);
 int upload_ctx_cutoffs(GbnBatch &b);
-struct TileSet { GbnTile *d_tiles = nullptr; int64_t ntiles = 0; std::vector<int64_t> first_tile_of_subj; int64_t bases = 0; };
+struct TileSet { GbnTile *d_tiles = nullptr; int64_t ntiles = 0; std::vector<int64_t> first_tile_of_subj; int64_t bases = 0; mutable int64_t scan_positions = -1; };     // (scan_positions: bin_positions' memo)
 int get_tiles(GbnDb &db, int lut, int step, int tpos, int32_t s0, int32_t s1, const TileSet **out);
 void free_tile_cache(GbnDb &db);
 int grow_seed_buffers(size_t want);
@@ -251,7 +251,7 @@ void rec_make_room(size_t need, long long limit, const RecordSet *keep, const Re
 void rec_purge(const void *db, bool to_scratch = false);
 struct BinLayout { int nb = 0, nwriters = 0; size_t nstream = 0, subcap = 0, nseq = 0, need_u64 = 0;
                    size_t bytes() const { return need_u64 * 8 + nstream * nseq * 4 + (nstream + 4) * 4; } };
-int64_t bin_positions(const GbnDb &db, int32_t s0, int32_t s1, int lut, int step);
+int64_t bin_positions(const GbnDb &db, const TileSet &ts, int32_t s0, int32_t s1, int lut, int step);
 int bin_layout(int nb, int64_t ntiles, int64_t npos, double slack, BinLayout &L);
 RecordSet *rec_find(const RecKey &key);
 int rec_acquire(const RecKey &key, const BinLayout &L, long long limit, RecordSet **out);

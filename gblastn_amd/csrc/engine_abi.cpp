@@ -676,6 +676,8 @@ static void plan_ranges(const GbnDb &dbr, int step, std::vector<std::pair<int32_
     int64_t tile_limit = ((int64_t)1 << (32 - GBN_BIN_TILE_BITS)) - 1;
     if (step <= 4) tile_limit = std::min<int64_t>(tile_limit, (int64_t)1 << 17);
     if (gbn::switch_is_set("GBN_RANGE_TILES")) tile_limit = (int)std::max<long long>(1, gbn::switch_value("GBN_RANGE_TILES", 0));                  // tests
+    for (const GbnDb::RangePlan &rp : db->range_plans)
+        if (rp.step == step && rp.range_bytes == range_bytes && rp.tile_limit == tile_limit) { out = rp.ranges; return; }
     auto tiles_of = [&](int32_t s) { return (int64_t)(db->len[s] / step) / GBN_BIN_TILE_POS + 1; };
     int64_t all_bytes = 0, all_tiles = 0;
     for (int32_t s = 0; s < db->num_seqs; s++) { all_bytes += (db->len[s] + 3) / 4; all_tiles += tiles_of(s); }
@@ -693,6 +695,8 @@ static void plan_ranges(const GbnDb &dbr, int step, std::vector<std::pair<int32_
         out.emplace_back(s0, s1);
         s0 = s1;
     }
+    if (db->range_plans.size() >= 8) db->range_plans.erase(db->range_plans.begin());
+    db->range_plans.push_back(GbnDb::RangePlan{step, range_bytes, tile_limit, out});
 }
 // The scan records a query batch of these lengths will want of this shard, queued NOW: the binning kernel reads the
 // subjects only, so a caller that knows its next batch's size starts it before the batch is set up -- the kernel runs
@@ -726,7 +730,7 @@ int gbn_db_prepare_records(GbnDb *db, const GbnOptions *opt, int32_t nq, const i
         if (rc) return rc;
         if (tsp->ntiles == 0 || tsp->ntiles > (1 << 19)) continue;
         BinLayout BL;
-        if (bin_layout((int)nb, tsp->ntiles, bin_positions(*db, s0, s1, lut, step), 1.25, BL)) continue;
+        if (bin_layout((int)nb, tsp->ntiles, bin_positions(*db, *tsp, s0, s1, lut, step), 1.25, BL)) continue;
         RecKey key; key.db = (const void *)db; key.s0 = s0; key.s1 = s1; key.lut = lut; key.step = step; key.nb = (int)nb; key.nwriters = BL.nwriters;
         key.rfl = std::min(4, fl); key.rfrbits = std::min(7, 2 * fr); key.cbits = GBN_BIN_CBITS(lut); key.tiles = (const void *)tsp->d_tiles; key.subcap = BL.subcap;
         if (rec_find(key)) continue;

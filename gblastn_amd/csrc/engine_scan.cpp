@@ -117,10 +117,11 @@ void rec_purge(const void *db, bool to_scratch) {
 }
 
 // ---- the partitioned scan's record streams: a private output stream per (bin, binning workgroup), no reservation atomics
-int64_t bin_positions(const GbnDb &db, int32_t s0, int32_t s1, int lut, int step) {
+int64_t bin_positions(const GbnDb &db, const TileSet &ts, int32_t s0, int32_t s1, int lut, int step) {      // (ts: the tiles of this very range, table width and stride -- get_tiles)
+    if (ts.scan_positions >= 0) return ts.scan_positions;
     int64_t npos = 0;
     for (int32_t s = s0; s < s1; s++) if (db.len[s] >= lut) npos += (db.len[s] - lut) / step + 1;
-    return npos;
+    return ts.scan_positions = npos;
 }
 int bin_layout(int nb, int64_t ntiles, int64_t npos, double slack, BinLayout &L) {
     L.nb = nb;
@@ -213,7 +214,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     if (nb > 1 && ts.ntiles > (1 << 19)) { set_error("subject range too large for 32-bit position ids"); return GBN_ERR_ARG; }
     if ((rc = grow_seed_buffers(std::max<size_t>(E.seed_cap, (size_t)1 << 22)))) return rc;
     if (!E.scan_back) { HIPCHK(hipHostMalloc((void **)&E.scan_back, sizeof(*E.scan_back))); std::memset(E.scan_back, 0, sizeof(*E.scan_back)); }
-    const int64_t npos = nb > 1 ? bin_positions(db, s0, s1, b.lut.lut, b.lut.step) : 0;
+    const int64_t npos = nb > 1 ? bin_positions(db, ts, s0, s1, b.lut.lut, b.lut.step) : 0;
     double slack = 1.25;
     size_t rare_seg_hint = 0, rare_seg_used = 0, slice_seg_cap = 0; int slice_blocks = 0; bool slice_ordered = false;
     GbnBinParams last_B; std::memset(&last_B, 0, sizeof(last_B)); int last_grid2 = 0;

@@ -109,6 +109,10 @@ struct GbnDb {
     // d_packed is the lowest slab address of its blocks and byte_off reaches into every one of them -- only its own
     // subject tables; the blocks must outlive it (freeing a block frees the views over it).  Empty: not a view.
     std::vector<const GbnDb *> view_parts;
+    // the subject ranges the shard is searched in (engine_abi.cpp: plan_ranges), remembered per (stride, limits): two passes
+    // over every subject's length otherwise, 0.1 ms per search of a 50,000-subject shard (under the engine's lock)
+    struct RangePlan { int step; int64_t range_bytes, tile_limit; std::vector<std::pair<int32_t, int32_t>> ranges; };
+    mutable std::vector<RangePlan> range_plans;
 };
 constexpr int32_t kDbseqChunkOverlap = 100;     // COREI/blast_hits.h:169
 

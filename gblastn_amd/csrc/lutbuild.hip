@@ -41,6 +41,7 @@ __global__ void __launch_bounds__(64) lut_enumerate_kernel(gbn::LutBuild B)
     // a store instruction should write 64 consecutive ones -- stored thread by thread the list took 450 MB of partial sectors per
     // 5 Mb batch for its 80 MB (profiles/r04i_pmc.csv)
     __shared__ uint32_t s_key[NT * (PER + 1)];
+    __shared__ int32_t s_seg[NT];                   // where the 64 stretches after the block's first one begin
     const int64_t nblock = ((int64_t)B.qlen + BLOCK - 1) / BLOCK;
     const uint32_t none = 1u << (2 * B.lut), cmask = none - 1u;
     const int lut = B.lut, tid = threadIdx.x;
@@ -49,23 +50,37 @@ __global__ void __launch_bounds__(64) lut_enumerate_kernel(gbn::LutBuild B)
     for (int64_t blk = blockIdx.x; blk < nblock; blk += gridDim.x) {
         const int64_t b0 = blk * BLOCK, p0 = b0 + (int64_t)tid * PER;
         const int n = (int)max((int64_t)0, min((int64_t)PER, (int64_t)B.qlen - p0));
+        // Round 5: a thread's chain of dependent loads was 14 (its own binary search over the stretches) + 27 (the bases, byte
+        // by byte) long -- 1.5 ms per 5 Mb batch alone, 2.0 ms next to the probe kernel whose CUs it shares.  Now: ONE search
+        // per workgroup (the block's first position: the same addresses in every lane), the next 64 stretches' starts through
+        // the LDS (a 1,024-position block of 1 kb queries meets two or three), and the thread's 16 + lut - 1 bases as nine
+        // aligned dwords.
+        int lo = 0, hi = B.nseg;                        // last stretch that starts at or before b0
+        while (lo < hi) { const int m = (lo + hi) >> 1; if ((int64_t)B.seg_left[m] <= b0) lo = m + 1; else hi = m; }
+        const int si0 = lo - 1;
+        s_seg[tid] = (si0 + 1 + tid < B.nseg) ? B.seg_left[si0 + 1 + tid] : INT32_MAX;
+        __syncthreads();
         if (n > 0) {
-            int lo = 0, hi = B.nseg;                    // last stretch that starts at or before p0
-            while (lo < hi) { const int m = (lo + hi) >> 1; if (B.seg_left[m] <= p0) lo = m + 1; else hi = m; }
-            int si = lo - 1;
-            int32_t left = si >= 0 ? B.seg_left[si] : 0, right = si >= 0 ? B.seg_right[si] : -1;
-            int32_t next_left = (si + 1 < B.nseg) ? B.seg_left[si + 1] : INT32_MAX;
+            int k = 0;
+            while (k < NT && (int64_t)s_seg[k] <= p0) k++;
+            int si = si0 + k;
+            int32_t left, next_left;
+            if (k == NT) {                              // more than 64 stretches begin between b0 and p0 (stretches of a few bases): search on
+                int l2 = si0 + 1 + NT, h2 = B.nseg;
+                while (l2 < h2) { const int m = (l2 + h2) >> 1; if ((int64_t)B.seg_left[m] <= p0) l2 = m + 1; else h2 = m; }
+                si = l2 - 1;
+                left = B.seg_left[si];
+                next_left = (si + 1 < B.nseg) ? B.seg_left[si + 1] : INT32_MAX;
+            } else {
+                left = k > 0 ? s_seg[k - 1] : (si0 >= 0 ? B.seg_left[si0] : 0);
+                next_left = s_seg[k];                   // (INT32_MAX past the last stretch)
+            }
+            int32_t right = si >= 0 ? B.seg_right[si] : -1;
             // the word at p is made of the bases p .. p + lut - 1 (the query has 64 bytes of sentinels past its end); `run` =
             // bases without an ambiguity code or a sentinel that end at the newest one
             uint32_t cell = 0; int run = 0;
-            for (int k = 0; k < lut - 1; k++) {
-                const uint8_t b = B.q8[p0 + k];
-                run = (b & 0xfc) ? 0 : run + 1;
-                cell = (cell << 2) | (b & 3u);
-            }
-            for (int i = 0; i < n; i++) {
+            auto position = [&](int i, uint8_t b) {     // base p0 + i + lut - 1 has arrived: the word at p0 + i is complete
                 const int64_t p = p0 + i;
-                const uint8_t b = B.q8[p + lut - 1];
                 run = (b & 0xfc) ? 0 : run + 1;
                 cell = ((cell << 2) | (b & 3u)) & cmask;
                 while (p >= (int64_t)next_left) {
@@ -75,6 +90,30 @@ __global__ void __launch_bounds__(64) lut_enumerate_kernel(gbn::LutBuild B)
                 const bool ok = si >= 0 && right - left + 1 >= B.word && p + lut - 1 <= (int64_t)right && run >= lut;
                 if (ok && B.count) atomicAdd(&B.count[cell], 1u);       // (null: the cells' sizes follow from the sorted list, lut_cell_starts_kernel)
                 s_key[tid * (PER + 1) + i] = ok ? cell : none;
+            };
+            if (lut <= 17) {
+                const uintptr_t ad = reinterpret_cast<uintptr_t>(B.q8 + p0);
+                const uint32_t *__restrict__ w = reinterpret_cast<const uint32_t *>(ad & ~(uintptr_t)3);
+                const uint32_t sh = (uint32_t)(ad & 3u) * 8u;
+                uint32_t v[9];
+                #pragma unroll
+                for (int j = 0; j < 9; j++) v[j] = w[j];
+                #pragma unroll
+                for (int j = 0; j < 32; j++) {
+                    if (j < lut + n - 1) {              // (lut + 14 <= 31)
+                        const uint32_t d = __builtin_amdgcn_alignbit(v[j / 4 + 1], v[j / 4], sh);
+                        const uint8_t b = (uint8_t)(d >> (8 * (j & 3)));
+                        if (j < lut - 1) { run = (b & 0xfc) ? 0 : run + 1; cell = ((cell << 2) | (b & 3u)) & cmask; }
+                        else position(j - (lut - 1), b);
+                    }
+                }
+            } else {
+                for (int j = 0; j < lut - 1; j++) {
+                    const uint8_t b = B.q8[p0 + j];
+                    run = (b & 0xfc) ? 0 : run + 1;
+                    cell = (cell << 2) | (b & 3u);
+                }
+                for (int i = 0; i < n; i++) position(i, B.q8[p0 + i + lut - 1]);
             }
         }
         __syncthreads();

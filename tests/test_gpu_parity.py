@@ -397,6 +397,25 @@ def test_soft_query_masks(task, nq, kw):
     assert len(gpu["hsps"]) >= 1
 
 
+@pytest.mark.parametrize("task,period", [("blastn", 12), ("blastn", 14), ("megablast", 30)])
+def test_query_masks_every_few_bases(task, period):
+    """One masked base every `period`: 70-85 indexed stretches begin inside one 1,024-position block of the table
+    builder's enumeration kernel (more than the 64 whose starts it keeps in LDS: its search-on branch), each just
+    long enough for a word (blastn: 11 and 13 bases for word size 11; megablast: 29 for 28)."""
+    db, queries, plants, subjects, opt = util.small_case(6, 100_000, 6, task=task, planted_fraction=1.0)
+    masks = [(qi, a, a) for qi, q in enumerate(queries) for a in range(qi % period, len(q), period)]
+    src = api.BlastSeqSrc.from_packed(subjects)
+    ps = api.BlastPrelimSearch(queries, opt, src, masks=masks)
+    gpu = ps.run(keep_stages=True)
+    ora, s = util.oracle_run(opt, queries, subjects, masks=masks)
+    oi, gi = s.info(), ps.info()
+    assert (oi["lut_type"], oi["lut_width"], oi["scan_step"]) == (gi["lut_type"], gi["lut_width"], gi["scan_step"])
+    util.compare_stages(gpu, ora)
+    assert len(gpu["seeds"]) >= 1
+    d = ps.diagnostics
+    assert (d.lookup_hits, d.good_init_extends) == (s.stats.lookup_hits, s.stats.good_init_extends)
+
+
 @pytest.mark.parametrize("task", ["megablast", "blastn"])
 def test_default_dust_filtering_end_to_end(task):
     """blastn's default: DUST the queries, mask at hash.  Queries and subjects share low-complexity
