@@ -715,7 +715,7 @@ int engine_init(int dev, Engine **out) {
     HIPCHK(hipEventCreate(&N.ev0)); HIPCHK(hipEventCreate(&N.ev1));
     for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&N.evk[i]));
     HIPCHK(hipEventCreateWithFlags(&N.ev_seed, hipEventDisableTiming));
-    HIPCHK(pool_alloc((void **)&N.counters, 8 * sizeof(unsigned long long)));
+    HIPCHK(pool_alloc((void **)&N.counters, 16 * sizeof(unsigned long long)));       // [0, 1] seeds, lookup hits of a scan; [2, 3] its segments / the inline seed stage; [4 .. 7] the probe kernel's item counters; [12, 13] the asynchronous seed stage
     N.device = dev; N.ready = true;
     if (g_default_dev < 0) g_default_dev = dev;
     *out = g_eng[dev];

@@ -226,7 +226,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     if (E.seed_copy_pending) { HIPCHK(hipStreamWaitEvent(E.stream, E.ev_seed, 0)); E.seed_copy_pending = false; }
     for (;;) {
         bool binned_ahead = false; int hit_pair = -1;
-        if (!E.counters_zeroed) HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream));    // (a pass that binned ahead zeroed them behind its read-back)
+        if (!E.counters_zeroed) HIPCHK(hipMemsetAsync(E.counters, 0, 8 * sizeof(unsigned long long), E.stream));    // (a pass that binned ahead zeroed them behind its read-back)
         E.counters_zeroed = false;
         GbnScanParams P; fill_scan_params(P, b, db, ts);
         uint32_t overflow = 0; int dbg_nwriters = 0; uint32_t dbg_subcap = 0;
@@ -299,6 +299,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             B.rec = reinterpret_cast<uint32_t *>(rs->bin_rec); B.tcur = rs->bin_tcur; B.nseq = (uint32_t)nseq; B.gcount = rs->bin_count; B.subcap = (uint32_t)subcap;
             B.overflow = rs->bin_count + nstream;
             B.dbg = (int)gbn::switch_value("GBN_DBG", 0);
+            B.work = gbn::switch_value("GBN_PROBE_DYN", 1) != 0 ? reinterpret_cast<uint32_t *>(E.counters + 4) : nullptr;      // (counters [4 .. 7]: zeroed with the scan's own, above)
             int grid2 = std::max(8, E.num_cu & ~7);   // one 1024-thread workgroup per CU; group = blockIdx & 7
             {   // rare-path queue: one segment per probe workgroup (~1.2 % of scan positions in total)
                 size_t seg = std::max<size_t>(rare_seg_hint, (size_t)(npos / 40 / grid2) + 4096);
@@ -339,7 +340,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 if (!AH.ev[0][0]) for (int i = 0; i < 4; i++) HIPCHK(hipEventCreate(&AH.ev[i >> 1][i & 1]));
                 AH.pair = hit_pair >= 0 ? (hit_pair ^ 1) : (AH.pair ^ 1);
                 HIPCHK(hipMemsetAsync(A.bin_count + nstream, 0, 16, E.stream));
-                HIPCHK(hipMemsetAsync(E.counters, 0, 4 * sizeof(unsigned long long), E.stream)); E.counters_zeroed = true;      // (read back above; the next scan's)
+                HIPCHK(hipMemsetAsync(E.counters, 0, 8 * sizeof(unsigned long long), E.stream)); E.counters_zeroed = true;      // (read back above; the next scan's)
                 HIPCHK(hipEventRecord(AH.ev[AH.pair][0], E.stream));
                 HIPCHK(launch_scan_bin_parts(A2, last_grid2, E.stream, nullptr, 1, nullptr));
                 HIPCHK(hipEventRecord(AH.ev[AH.pair][1], E.stream));

@@ -244,7 +244,7 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
             unsigned long long nih2 = 0;
             if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the extension thread"; return GBN_ERR_HIP; }
             if (hipStreamWaitEvent(E.stream2, E.ev_seed, 0) != hipSuccess) { E.pending_err = "hipStreamWaitEvent failed"; return GBN_ERR_HIP; }
-            r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n, E.counters + 4, E.stream2, &nih2, s0, s1, ksi);
+            r = seed_stage(*bp, *dbp, *rp, diag, 0, slot, E.seeds_async, n, E.counters + 12, E.stream2, &nih2, s0, s1, ksi);
             if (!r && nih2) r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih2, E.stream2, true);
             if (r) E.pending_err = gbn_last_error();      // the error text is per thread
             return r;

@@ -84,6 +84,11 @@ struct GbnBinParams {
     int dbg;                        // launch switches of tools/scan_ablate.py (GBN_DBG; 1: no rare kernel, 32: timing print, 64: any-stride binning kernel, 128: XCD report, 256: probe kernel without the sixteenth fingerprint bit)
     GbnRareItem *rareq; uint32_t rare_seg;    // rare-path queue: one segment of rare_seg items per probe workgroup
     uint32_t *rare_counts;              // [probe workgroups] items queued (may exceed rare_seg: overflow)
+    // probe kernel: [GBN_BIN_GROUPS] counters, zero at the launch -- the workgroups of a group draw their (bin, share of its
+    // streams) items from the group's counter instead of owning a fixed share of every bin: a workgroup that shares its CU
+    // with the table builder's or the extension stages' waves takes fewer items and the kernel does not wait for it.
+    // Null (or fewer bins than groups): fixed shares.
+    uint32_t *work;
 };
 
 struct GbnKeyParams {

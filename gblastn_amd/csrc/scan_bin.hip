@@ -947,14 +947,31 @@ probe_bin_kernel(GbnBinParams B)
     constexpr uint32_t U = GBN_PROBE_U, BLK = 256u * U, NR = 4 * U;    // records per wave and per lane and round
     const int nwaves = nw * (GBN_BIN_THREADS / 64);
     const int split = (nwaves + B.nwriters - 1) / B.nwriters;
-    const int V = B.nwriters * split, v0 = wi + nw * wave;          // this wave's pieces of a bin: v0, v0 + nwaves, ...
+    const int V = B.nwriters * split;                               // pieces of a bin; this wave's: v0, v0 + nwaves, ... (v0 below)
     // hi words of a piece: blocks of 64 records = 96 words; a round of BLK records starts at a block
     // boundary (lo and BLK are multiples of 512), so a lane's words of round r sit at a fixed offset from
     // the piece's first block + r * (BLK / 64 * 96)
     uint32_t loff[U];
     #pragma unroll
     for (uint32_t u = 0; u < U; u++) { const uint32_t j = u * 256u + (uint32_t)lane * 4u; loff[u] = (j >> 6) * 96u + (j & 63u); }
-    for (int b = grp % bstep; b < B.nb; b += GBN_BIN_GROUPS) {
+    // Round 5: which bin, and which share of its streams, comes next is drawn from the group's counter (B.work; item t = share
+    // t mod nw of the group's (t / nw)-th bin, so the group still works its way through one bin after the other and the bin's
+    // table slice is fetched into the XCD's L2 once).  With fixed shares the kernel took as long as its slowest workgroup: 3.0 ms
+    // alone, 3.5-3.9 ms next to the table builder and the extension stages of the pass before, whose waves land on some CUs
+    // and not on others.  The next item's number is asked for when an item begins and read when it ends (two barriers later).
+    const bool dyn = B.work != nullptr && B.nb >= GBN_BIN_GROUPS;
+    volatile uint32_t *s_item = s_rcount + 1;                       // [2]
+    int item = 0;                                                   // fixed shares: the item-th bin of this workgroup
+    if (dyn) {
+        if (tid == 0) s_item[0] = atomicAdd(&B.work[grp], 1u);
+        __syncthreads();
+        item = (int)s_item[0];
+    }
+    for (int par = 0; ; par ^= 1) {
+        const int b = dyn ? grp + GBN_BIN_GROUPS * (item / nw) : grp % bstep + GBN_BIN_GROUPS * item;
+        if (b >= B.nb) break;
+        const int v0 = (dyn ? item % nw : wi) + nw * wave;
+        if (dyn && tid == 0) s_item[par ^ 1] = atomicAdd(&B.work[grp], 1u);
         const uint32_t pad = GBN_REC_PAD(cbits, b);
         const int32_t tadj = GBN_BIN_TAB0 - (int32_t)(GBN_REC_PAR(cbits, b) << 15);     // s_tab index = low 16 bits of the hi word + tadj
         const uint32_t tab_addr = (uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint32_t *)s_tab + (uint32_t)(tadj * 4);   // LDS byte address of index 0
@@ -1110,6 +1127,7 @@ probe_bin_kernel(GbnBinParams B)
             if (v < V) start_piece(v, B.gcount[(size_t)b * B.nwriters + v / split]);
         }
         if (qn > 0) { flush(0, qn, b); qn = 0; }                    // the side list changes with the bin
+        item = dyn ? (int)s_item[par ^ 1] : item + 1;
     }
     if (P.raw_hits) {
         for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
@@ -1126,10 +1144,34 @@ probe_rare_kernel(GbnBinParams B, int nseg)
 {
     const GbnScanParams &P = B.S;
     unsigned long long raw = 0;
-    // blockIdx.x % nseg = segment (probe workgroup), blockIdx.x / nseg = part
-    const int seg = blockIdx.x % nseg, part = blockIdx.x / nseg, nparts = gridDim.x / nseg;
-    const uint32_t n = min(B.rare_counts[seg], B.rare_seg);
-    const GbnRareItem *qs = B.rareq + (size_t)seg * B.rare_seg;
+    // The items of all segments (one per probe workgroup) as ONE list, an equal stretch of it per workgroup: since the probe
+    // workgroups draw their work from a counter (round 5) their segments are as uneven as the CUs were busy, and with a fixed
+    // set of workgroups per segment (rounds 1-4) this kernel took as long as the fullest one.  Where the segments begin in the
+    // list: a prefix sum over their counts in every workgroup (nseg <= 1,024 values).
+    __shared__ uint32_t s_pref[1025], s_wsum[4];
+    {
+        const int per = (nseg + 255) / 256, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+        uint32_t loc[4] = {0, 0, 0, 0}, sum = 0;
+        for (int k = 0; k < per; k++) {
+            const int idx = (int)threadIdx.x * per + k;
+            loc[k] = sum;
+            sum += idx < nseg ? min(B.rare_counts[idx], B.rare_seg) : 0u;
+        }
+        uint32_t inc = sum;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        if (lane == 63) s_wsum[wv] = inc;
+        __syncthreads();
+        uint32_t base = 0;
+        for (int w = 0; w < wv; w++) base += s_wsum[w];
+        for (int k = 0; k < per; k++) { const int idx = (int)threadIdx.x * per + k; if (idx < nseg) s_pref[idx] = base + inc - sum + loc[k]; }
+        if (threadIdx.x == 0) s_pref[nseg] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        __syncthreads();
+    }
+    const uint32_t total_items = s_pref[nseg];
+    // (rounds of 256 items dealt out in turn: the workgroups in flight work on one window of the list -- a few segments at a
+    // time, each in bin order, so the cells, entries and cursors they ask for are neighbours in the tables; with a contiguous
+    // stretch of the list per workgroup the kernel was 0.2 ms slower)
+    const unsigned long long g_end = total_items, g_stride = (unsigned long long)gridDim.x * 256u;
     // dense-seed shapes (lut == word: every lookup hit is a seed) stage their seeds in LDS
     constexpr uint32_t CAP = 1536;
     __shared__ GbnDevSeed s_buf[CAP];
@@ -1152,11 +1194,13 @@ probe_rare_kernel(GbnBinParams B, int nseg)
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
     };
-    for (uint32_t i0 = (uint32_t)part * 256u; i0 < n; i0 += (uint32_t)nparts * 256u) {     // uniform over the workgroup
+    for (unsigned long long g0 = (unsigned long long)blockIdx.x * 256u; g0 < g_end; g0 += g_stride) {      // uniform over the workgroup
         if (staged) { __syncthreads(); if (s_n > CAP - 512u) flush(); }      // s_n is stable between the barriers
-        const uint32_t i = i0 + threadIdx.x;
-        if (i >= n) continue;
-        const uint4 item = *reinterpret_cast<const uint4 *>(qs + i);
+        if (g0 + threadIdx.x >= g_end) continue;
+        const uint32_t g = (uint32_t)g0 + threadIdx.x;
+        uint32_t slo = 0, shi = (uint32_t)nseg;                     // the item's segment: the last one that begins at or before it
+        while (shi - slo > 1u) { const uint32_t mid = (slo + shi) >> 1; if (s_pref[mid] <= g) slo = mid; else shi = mid; }
+        const uint4 item = *reinterpret_cast<const uint4 *>(B.rareq + (size_t)slo * B.rare_seg + (g - s_pref[slo]));
         uint32_t pid = item.x; const uint32_t cv = item.y;
         uint32_t idx = item.z, cw = item.w;
         {   // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
@@ -1259,6 +1303,7 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
         // 12: 1.62 / 1.70-1.72, 24: 1.55 / 1.63 (profiles/r04k_probe_and_rare_kernel.txt) -- the kernel is bound by the rate at which HBM
         // takes its scattered sectors, and more waves in flight do not raise it
         const int parts = (int)std::max(1ll, std::min(64ll, gbn::switch_value("GBN_RARE_PARTS", 4)));
+        if (grid2 > 1024) return hipErrorInvalidValue;             // (the kernel's prefix sum over the segments)
         if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * parts), dim3(256), 0, st, b, grid2);
         e = hipGetLastError();
     }

@@ -134,7 +134,7 @@ def test_rare_queue_overflow_rescans_against_cached_records(cache_default, monke
     want = ps.run()["hsps"].tobytes()
     ps.close(); src.close()
     src = api.BlastSeqSrc.from_packed(subjects)
-    monkeypatch.setenv("GBN_RARE_SEG", "8")
+    monkeypatch.setenv("GBN_RARE_SEG", "1")
     ps = api.BlastPrelimSearch(qa, opt, src)
     st0 = api.record_cache_stats()
     assert ps.run()["hsps"].tobytes() == want
