@@ -1144,34 +1144,26 @@ probe_rare_kernel(GbnBinParams B, int nseg)
 {
     const GbnScanParams &P = B.S;
     unsigned long long raw = 0;
-    // The items of all segments (one per probe workgroup) as ONE list, an equal stretch of it per workgroup: since the probe
-    // workgroups draw their work from a counter (round 5) their segments are as uneven as the CUs were busy, and with a fixed
-    // set of workgroups per segment (rounds 1-4) this kernel took as long as the fullest one.  Where the segments begin in the
-    // list: a prefix sum over their counts in every workgroup (nseg <= 1,024 values).
-    __shared__ uint32_t s_pref[1025], s_wsum[4];
+    // The segments (one per probe workgroup) are as uneven as the CUs were busy while the probe workgroups drew their work from
+    // a counter (round 5); with a fixed set of workgroups per segment (rounds 1-4) this kernel would take as long as the fullest
+    // one.  Every segment is in bin order, and the tables an item asks for (cursors, cells, entries) are its bin's: the
+    // workgroups in flight should be at the same RELATIVE place of their segments.  So the rounds (256 items) are dealt out by
+    // slots: slot (tick, segment) holds the rounds [tick * n / T, (tick + 1) * n / T) of a segment of n rounds (none or one),
+    // T = the rounds of the fullest segment; workgroup w takes the slots w, w + grid, ... -- a tick after the other, and a
+    // different segment every time (the segment index is rotated by the tick).  (The segments as one list dealt out round by
+    // round balanced as well, but had the workgroups in flight in 4 segments at unrelated bins: FETCH_SIZE 3.7 instead of 2.9
+    // GB per launch, 1.41 instead of 1.19 ms.)
+    __shared__ uint32_t s_cnt[1024], s_tmax;
+    if (threadIdx.x == 0) s_tmax = 0;
+    __syncthreads();
     {
-        const int per = (nseg + 255) / 256, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-        uint32_t loc[4] = {0, 0, 0, 0}, sum = 0;
-        for (int k = 0; k < per; k++) {
-            const int idx = (int)threadIdx.x * per + k;
-            loc[k] = sum;
-            sum += idx < nseg ? min(B.rare_counts[idx], B.rare_seg) : 0u;
-        }
-        uint32_t inc = sum;
-        for (int off = 1; off < 64; off <<= 1) { const uint32_t t = __shfl_up(inc, off); if (lane >= off) inc += t; }
-        if (lane == 63) s_wsum[wv] = inc;
-        __syncthreads();
-        uint32_t base = 0;
-        for (int w = 0; w < wv; w++) base += s_wsum[w];
-        for (int k = 0; k < per; k++) { const int idx = (int)threadIdx.x * per + k; if (idx < nseg) s_pref[idx] = base + inc - sum + loc[k]; }
-        if (threadIdx.x == 0) s_pref[nseg] = s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        uint32_t mx = 0;
+        for (int i = (int)threadIdx.x; i < nseg; i += 256) { const uint32_t c = min(B.rare_counts[i], B.rare_seg); s_cnt[i] = c; mx = max(mx, (c + 255u) >> 8); }
+        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
+        if ((threadIdx.x & 63) == 0 && mx) atomicMax(&s_tmax, mx);
         __syncthreads();
     }
-    const uint32_t total_items = s_pref[nseg];
-    // (rounds of 256 items dealt out in turn: the workgroups in flight work on one window of the list -- a few segments at a
-    // time, each in bin order, so the cells, entries and cursors they ask for are neighbours in the tables; with a contiguous
-    // stretch of the list per workgroup the kernel was 0.2 ms slower)
-    const unsigned long long g_end = total_items, g_stride = (unsigned long long)gridDim.x * 256u;
+    const uint32_t tmax = s_tmax, nslots = tmax * (uint32_t)nseg;
     // dense-seed shapes (lut == word: every lookup hit is a seed) stage their seeds in LDS
     constexpr uint32_t CAP = 1536;
     __shared__ GbnDevSeed s_buf[CAP];
@@ -1194,13 +1186,15 @@ probe_rare_kernel(GbnBinParams B, int nseg)
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
     };
-    for (unsigned long long g0 = (unsigned long long)blockIdx.x * 256u; g0 < g_end; g0 += g_stride) {      // uniform over the workgroup
+    for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {       // uniform over the workgroup
+        const uint32_t tick = slot / (uint32_t)nseg, seg = (slot % (uint32_t)nseg + tick) % (uint32_t)nseg;
+        const uint32_t n = s_cnt[seg], nr = (n + 255u) >> 8;
+        const uint32_t r0 = (uint32_t)(((unsigned long long)tick * nr) / tmax), r1 = (uint32_t)(((unsigned long long)(tick + 1u) * nr) / tmax);
+        if (r0 == r1) continue;                                     // (nr <= tmax: one round at most)
         if (staged) { __syncthreads(); if (s_n > CAP - 512u) flush(); }      // s_n is stable between the barriers
-        if (g0 + threadIdx.x >= g_end) continue;
-        const uint32_t g = (uint32_t)g0 + threadIdx.x;
-        uint32_t slo = 0, shi = (uint32_t)nseg;                     // the item's segment: the last one that begins at or before it
-        while (shi - slo > 1u) { const uint32_t mid = (slo + shi) >> 1; if (s_pref[mid] <= g) slo = mid; else shi = mid; }
-        const uint4 item = *reinterpret_cast<const uint4 *>(B.rareq + (size_t)slo * B.rare_seg + (g - s_pref[slo]));
+        const uint32_t i = r0 * 256u + threadIdx.x;
+        if (i >= n) continue;
+        const uint4 item = *reinterpret_cast<const uint4 *>(B.rareq + (size_t)seg * B.rare_seg + i);
         uint32_t pid = item.x; const uint32_t cv = item.y;
         uint32_t idx = item.z, cw = item.w;
         {   // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
