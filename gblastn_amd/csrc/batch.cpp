@@ -309,8 +309,7 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
     b.lut.masked = b.lut.masked && b.lut.word > b.lut.lut;
     if (host_tables) fill_lookup_host(b);
     trace_mark(host_tables ? "batch: lookup table built" : "batch: table kind chosen (tables are built on the device)");
-    if (tables_hook) { const int hrc = tables_hook(); if (hrc) return hrc; }
-    build_score_matrix(opt.reward, opt.penalty, b.matrix);
+    build_score_matrix(opt.reward, opt.penalty, b.matrix);      // (in front of the hook: they go up with the contexts' offsets)
     for (int i = 0; i < 256; i++) {
         int32_t s = 0;
         s += (i & 3) ? opt.penalty : opt.reward;
@@ -319,6 +318,7 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
         s += (i >> 6) ? opt.penalty : opt.reward;
         b.score_table[i] = s;
     }
+    if (tables_hook) { const int hrc = tables_hook(); if (hrc) return hrc; }
     double stdc[16]; uniform_acgt(stdc);
     // ungapped Karlin-Altschul parameters per context: independent, so a large batch spreads them over a few threads
     auto ka_range = [&](size_t c0, size_t c1) {

@@ -107,6 +107,7 @@ bool guard_check(void *user, size_t bytes, const char *when) {
     return ok;
 }
 hipError_t raw_alloc(void **p, size_t bytes) {
+    if (bytes >= ((size_t)1 << 20)) trace_mark(("pool: hipMalloc of " + std::to_string(bytes >> 20) + " MiB").c_str());
     if (!pool_guard()) return hipMalloc(p, bytes);
     void *raw = nullptr;
     hipError_t e = hipMalloc(&raw, bytes + 2 * kGuard);
@@ -116,6 +117,7 @@ hipError_t raw_alloc(void **p, size_t bytes) {
     return hipSuccess;
 }
 void raw_free(void *p, size_t bytes) {
+    if (bytes >= ((size_t)1 << 20)) trace_mark(("pool: hipFree of " + std::to_string(bytes >> 20) + " MiB").c_str());
     if (!pool_guard()) { (void)hipFree(p); return; }
     guard_check(p, bytes, "free");
     (void)hipFree((char *)p - kGuard);
@@ -181,10 +183,16 @@ void pool_drain(int dev) {
 }
 // the batch's lookup structures are complete (waits for the builder if they are not): scratch back to the pool
 void finish_build(DeviceBatch *d) {
-    if (!d || !d->ready) return;
+    if (!d) return;
+    if (d->ready_ctx) { (void)hipEventSynchronize(d->ready_ctx); (void)hipEventDestroy(d->ready_ctx); d->ready_ctx = nullptr; }
+    if (!d->ready) {                                    // (no event: built on the host, or the build failed half-way -- the stream decides)
+        if (d->stage && d->eng) { (void)hipStreamSynchronize(d->eng->stream_build); stage_put(d->stage, d->stage_cap); d->stage = nullptr; }
+        return;
+    }
     (void)hipEventSynchronize(d->ready);
     for (void *p : d->build_scratch) pool_free(p);
     d->build_scratch.clear();
+    if (d->stage) { stage_put(d->stage, d->stage_cap); d->stage = nullptr; }
     (void)hipEventDestroy(d->ready); d->ready = nullptr;
 }
 
@@ -227,6 +235,28 @@ void fill_cutoffs(const GbnBatch &b, const CtxLayout &L, int32_t *w) {      // w
         w[L.pack + 4 * c] = x.x_dropoff; w[L.pack + 4 * c + 1] = x.reduced_cutoff; w[L.pack + 4 * c + 2] = x.cutoff_score; w[L.pack + 4 * c + 3] = 0;
     }
 }
+// what of the block does not wait for the Karlin-Altschul parameters: offsets, lengths, position hints, score tables
+void fill_ctx_fixed(const GbnBatch &b, const CtxLayout &L, int32_t *w) {
+    for (size_t c = 0; c < L.n; c++) { w[L.off + c] = b.ctx[c].query_offset; w[L.len + c] = b.ctx[c].query_length; }
+    {   // context of every kCtxHintShift-aligned query position (the kernels walk on from there: contexts are rarely shorter)
+        size_t c = 0;
+        for (size_t k = 0; k < L.h; k++) {
+            const int64_t qpos = (int64_t)k << kCtxHintShift;
+            while (c + 1 < L.n && w[L.off + c + 1] <= qpos) c++;
+            w[L.hint + k] = (int32_t)c;
+        }
+        // ... and per block: that context and where the next one begins (GbnExtParams::ctx_blk)
+        for (size_t k = 0; k < L.h; k++) {
+            const size_t ci = (size_t)w[L.hint + k];
+            const int64_t last = ((int64_t)k << kCtxHintShift) + ((int64_t)1 << kCtxHintShift) - 1;
+            w[L.blk + 2 * k] = w[L.hint + k];
+            w[L.blk + 2 * k + 1] = ci + 1 < L.n ? w[L.off + ci + 1] : INT32_MAX;
+            if (ci + 2 < L.n && w[L.off + ci + 2] <= last) w[L.blk + 2 * k + 1] = INT32_MIN;
+        }
+    }
+    std::memcpy(&w[L.matrix], &b.matrix[0][0], 256 * 4);
+    std::memcpy(&w[L.table], b.score_table, 256 * 4);
+}
 }  // namespace
 // the cut-offs of every context once more (a search without a database length recomputes them per subject)
 int upload_ctx_cutoffs(GbnBatch &b) {
@@ -234,6 +264,7 @@ int upload_ctx_cutoffs(GbnBatch &b) {
     const CtxLayout L = ctx_layout(b);
     std::vector<int32_t> w(L.hint, 0);                  // (the block's words up to the end of the cut-offs)
     fill_cutoffs(b, L, w.data());
+    if (d->ready_ctx) HIPCHK(hipEventSynchronize(d->ready_ctx));        // (the set-up's own copy of them is not to land on top of these)
     HIPCHK(hipMemcpy(d->ctx_block + L.xdrop, w.data() + L.xdrop, (L.hint - L.xdrop) * 4, hipMemcpyHostToDevice));
     return GBN_OK;
 }
@@ -340,7 +371,15 @@ static int build_tables_on_device(GbnBatch &b) {
 #define LUTCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); (void)hipStreamSynchronize(st); cleanup(); return GBN_ERR_HIP; } } while (0)
 #define LUTRC(x) do { if ((rc = (x))) { (void)hipStreamSynchronize(st); cleanup(); return rc; } } while (0)
     const size_t nc1 = (size_t)L.ncells + 1, qn = (size_t)std::max(b.qlen, 1);
-    LUTRC(dev_upload(d_sl, sl.data(), sl.size())); LUTRC(dev_upload(d_sr, sr.data(), sr.size()));
+    {   // the stretches: through the batch's staging buffer, on the builder's stream
+        LUTRC(dev_alloc(d_sl, sl.size())); LUTRC(dev_alloc(d_sr, sr.size()));
+        int32_t *hs = reinterpret_cast<int32_t *>(static_cast<char *>(d->stage) + d->stage_seg);
+        if (!sl.empty()) {
+            std::memcpy(hs, sl.data(), sl.size() * 4); std::memcpy(hs + sl.size(), sr.data(), sr.size() * 4);
+            LUTCHK(hipMemcpyAsync(d_sl, hs, sl.size() * 4, hipMemcpyHostToDevice, st));
+            LUTCHK(hipMemcpyAsync(d_sr, hs + sl.size(), sr.size() * 4, hipMemcpyHostToDevice, st));
+        }
+    }
     LUTRC(dev_alloc(count, nc1)); LUTRC(dev_alloc(many, nc1)); LUTRC(dev_alloc(many_prefix, nc1));
     LUTRC(dev_alloc(keys_a, qn)); LUTRC(dev_alloc(keys_b, qn)); LUTRC(dev_alloc(vals_a, qn)); LUTRC(dev_alloc(vals_b, qn));
     LUTRC(dev_alloc(ctr, 2));
@@ -465,7 +504,30 @@ int upload_batch_tables(GbnBatch &b) {
         if (e == 0) { d->fl = 0; d->fr = 0; }
     }
     const bool host_lookup = gbn::switch_value("GBN_HOST_LOOKUP", 0) != 0;
-    if ((rc = dev_upload(d->q8_base, b.qbuf.data(), b.qbuf.size()))) return rc;
+    // the query goes up through a pinned staging buffer on the builder's stream (Engine::stage_idle: why)
+    // (... and with it, behind the query: the indexed stretches and the per-context block -- every copy of a set-up is an
+    // asynchronous one on the builder's stream.  A blocking hipMemcpy works on the null stream, which shares a hardware queue
+    // with one of the engine's streams once the process has more streams than queues: the 40 KB of stretches waited 14-24 ms
+    // behind the scans queued there, every few batches, and the batch's tables with them.)
+    size_t nseg = 0;
+    for (auto &sg : L.segments) if (sg.second >= sg.first) nseg++;
+    const size_t q_bytes = (b.qbuf.size() + 63) & ~(size_t)63, seg_bytes = ((2 * nseg * 4) + 63) & ~(size_t)63, ctx_bytes = ctx_layout(b).total * 4;
+    if ((rc = dev_alloc(d->q8_base, b.qbuf.size())) || (rc = stage_get(q_bytes + seg_bytes + 2 * ctx_bytes + 64, &d->stage, &d->stage_cap))) return rc;
+    d->stage_seg = q_bytes; d->stage_ctx = q_bytes + seg_bytes; d->stage_cut = d->stage_ctx + ctx_bytes;
+    std::memcpy(d->stage, b.qbuf.data(), b.qbuf.size());
+    {   // the per-context block: offsets, lengths, the position hints, the score tables now (the scan's kernels read them: they
+        // are behind the batch's event with the tables); the cut-offs follow when they have been computed (upload_batch_contexts)
+        const CtxLayout CL = ctx_layout(b);
+        int32_t *w = reinterpret_cast<int32_t *>(static_cast<char *>(d->stage) + d->stage_ctx);
+        std::memset(w, 0, CL.total * 4);
+        fill_ctx_fixed(b, CL, w);
+        if ((rc = dev_alloc(d->ctx_block, CL.total))) return rc;
+        HIPCHK(hipMemcpyAsync(d->ctx_block, w, CL.total * 4, hipMemcpyHostToDevice, E.stream_build));
+        d->ctx_off = d->ctx_block + CL.off; d->ctx_len = d->ctx_block + CL.len; d->ctx_xdrop = d->ctx_block + CL.xdrop;
+        d->ctx_cutoff = d->ctx_block + CL.cutoff; d->ctx_reduced = d->ctx_block + CL.reduced; d->ctx_pack = d->ctx_block + CL.pack;
+        d->ctx_hint = d->ctx_block + CL.hint; d->ctx_blk = d->ctx_block + CL.blk; d->matrix = d->ctx_block + CL.matrix; d->score_table = d->ctx_block + CL.table;
+    }
+    HIPCHK(hipMemcpyAsync(d->q8_base, d->stage, b.qbuf.size(), hipMemcpyHostToDevice, E.stream_build));
     d->q8 = d->q8_base + b.qpad;
     {   // packed copy for the greedy kernel's 32-bases-per-step match runs, made on the device from q8
         const int64_t pad = 256, n = (int64_t)b.qlen + 2 * pad;
@@ -495,35 +557,18 @@ int upload_batch_tables(GbnBatch &b) {
 }
 int upload_batch_contexts(GbnBatch &b) {
     DeviceBatch *d = b.dev;
-    if (!d || !d->eng) { set_error("upload_batch_contexts: no device structures"); return GBN_ERR_ARG; }
+    if (!d || !d->eng || !d->stage || !d->ctx_block) { set_error("upload_batch_contexts: no device structures"); return GBN_ERR_ARG; }
     enter(d->eng);
-    int rc;
     const CtxLayout L = ctx_layout(b);
-    std::vector<int32_t> w(L.total, 0);
-    for (size_t c = 0; c < L.n; c++) { w[L.off + c] = b.ctx[c].query_offset; w[L.len + c] = b.ctx[c].query_length; }
-    fill_cutoffs(b, L, w.data());
-    {   // context of every kCtxHintShift-aligned query position (the kernels walk on from there: contexts are rarely shorter)
-        size_t c = 0;
-        for (size_t k = 0; k < L.h; k++) {
-            const int64_t qpos = (int64_t)k << kCtxHintShift;
-            while (c + 1 < L.n && w[L.off + c + 1] <= qpos) c++;
-            w[L.hint + k] = (int32_t)c;
-        }
-        // ... and per block: that context and where the next one begins (GbnExtParams::ctx_blk)
-        for (size_t k = 0; k < L.h; k++) {
-            const size_t ci = (size_t)w[L.hint + k];
-            const int64_t last = ((int64_t)k << kCtxHintShift) + ((int64_t)1 << kCtxHintShift) - 1;
-            w[L.blk + 2 * k] = w[L.hint + k];
-            w[L.blk + 2 * k + 1] = ci + 1 < L.n ? w[L.off + ci + 1] : INT32_MAX;
-            if (ci + 2 < L.n && w[L.off + ci + 2] <= last) w[L.blk + 2 * k + 1] = INT32_MIN;
-        }
-    }
-    std::memcpy(&w[L.matrix], &b.matrix[0][0], 256 * 4);
-    std::memcpy(&w[L.table], b.score_table, 256 * 4);
-    if ((rc = dev_upload(d->ctx_block, w.data(), w.size()))) return rc;
-    d->ctx_off = d->ctx_block + L.off; d->ctx_len = d->ctx_block + L.len; d->ctx_xdrop = d->ctx_block + L.xdrop;
-    d->ctx_cutoff = d->ctx_block + L.cutoff; d->ctx_reduced = d->ctx_block + L.reduced; d->ctx_pack = d->ctx_block + L.pack;
-    d->ctx_hint = d->ctx_block + L.hint; d->ctx_blk = d->ctx_block + L.blk; d->matrix = d->ctx_block + L.matrix; d->score_table = d->ctx_block + L.table;
+    // the cut-offs (x_dropoff, cut-off, reduced cut-off per context): from a part of the staging buffer of their own -- the block's
+    // first copy may not have been read yet -- behind whatever the builder's stream holds, with an event of their own
+    int32_t *w = reinterpret_cast<int32_t *>(static_cast<char *>(d->stage) + d->stage_cut);
+    std::memset(w + L.xdrop, 0, (L.hint - L.xdrop) * 4);
+    fill_cutoffs(b, L, w);
+    HIPCHK(hipMemcpyAsync(d->ctx_block + L.xdrop, w + L.xdrop, (L.hint - L.xdrop) * 4, hipMemcpyHostToDevice, E.stream_build));
+    HIPCHK(hipEventCreateWithFlags(&d->ready_ctx, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(d->ready_ctx, E.stream_build));
+    if (!d->ready) HIPCHK(hipEventSynchronize(d->ready_ctx));         // (a batch built synchronously, or on the host, is complete when its set-up returns)
     trace_mark("upload: done");
     return GBN_OK;
 }
@@ -628,6 +673,7 @@ int wait_pending_gpu() {
     int rc = E.pending.get();
     if (rc) record_failure(E.pending_res, rc, E.pending_err);
     E.has_pending = false; E.pending_ks = -1; E.pending_batch = nullptr;
+    E.pending_res_pub.store(nullptr, std::memory_order_release); E.pending_batch_pub.store(nullptr, std::memory_order_release);
     return GBN_OK;
 }
 void wait_host() {

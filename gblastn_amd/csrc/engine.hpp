@@ -80,6 +80,11 @@ struct DeviceBatch {
     // lookup structures still being built on the builder's stream: the event they are complete at, and the
     // builder's scratch, which goes back to the pool once it has fired
     hipEvent_t ready = nullptr; std::vector<void *> build_scratch;
+    // ... and the event behind the copy of the contexts' cut-offs, which are computed while the tables are being built and go up
+    // last (upload_batch_contexts): the extension kernels read them, the engine's stream waits for it behind a scan's kernels
+    hipEvent_t ready_ctx = nullptr;
+    size_t stage_seg = 0, stage_ctx = 0, stage_cut = 0;     // where the stretches, the per-context block and (a copy of its own) the cut-offs sit in it
+    void *stage = nullptr; size_t stage_cap = 0;    // pinned host copy of the query the upload reads (stage_get): back to the engine with the builder's scratch
     struct Engine *eng = nullptr;   // the device context the batch lives on
 };
 
@@ -111,6 +116,11 @@ struct Engine {
     // (round 5, seen in the trace of the cold config: the first probe kernel started 1.2 ms late)
     std::mutex build_mu;
     std::future<int> pending; bool has_pending = false; std::string pending_err; const GbnResults *pending_res = nullptr;
+    // what the stage in flight works on, readable WITHOUT the engine's lock: gbn_prelim_search_end / gbn_batch_free / gbn_results_free
+    // of a pass whose stage is not the one in flight (a pipelined caller: the pass after it has been begun) must not wait for the
+    // lock, which the caller's other thread holds for the length of a scan -- three such waits per pass kept a collecting thread
+    // busier than the scans it was collecting behind (tools/step_jitter.py)
+    std::atomic<const void *> pending_res_pub{nullptr}, pending_batch_pub{nullptr};
     // host replays of finished gapped stages, one after the other in the order they were queued (each waits for its
     // predecessor): the stage's thread hands its copies over and is free for the next range's kernels
     std::shared_future<void> host_tail; std::mutex host_mu, failed_mu;
@@ -173,6 +183,11 @@ struct Engine {
     // pinned host copies of a range's initial hits and gapped extensions, handed out again (hitbuf_get)
     struct HitBuf { GbnDevInitHit *hih = nullptr; GbnDevGapped *hg = nullptr; size_t cap = 0; };
     std::mutex hitbuf_mu; std::vector<HitBuf> hitbuf_idle;
+    // pinned staging buffers of the batches' query uploads, handed out again.  (A blocking hipMemcpy from the batch's own
+    // pageable vector has the runtime map those pages for the device, and the vector's free() unmaps them: either one, next to
+    // running kernels, stalls the device's queues -- scans of 20-45 ms instead of 5 every few passes of a pipelined loop,
+    // tools/step_jitter.py.)
+    std::vector<std::pair<void *, size_t>> stage_idle;
     // traceback stage: stream and pinned staging buffer of gather_shard_bytes
     std::mutex gather_mu; hipStream_t gather_stream = nullptr; uint8_t *gather_stage = nullptr; size_t gather_stage_cap = 0;
 };
@@ -262,4 +277,6 @@ int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *dia
 int compact_seeds(hipStream_t st);
 int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag, int keep_stages, int overlap = 0);
 void hitbuf_drain();
+int stage_get(size_t bytes, void **p, size_t *cap);
+void stage_put(void *p, size_t cap);
 }  // namespace gbn

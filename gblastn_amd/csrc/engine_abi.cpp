@@ -538,6 +538,7 @@ static int params_ready(const GbnBatch *b, const GbnDb *db) {
     if (b->dev->eng != db->engine) { set_error("the batch and the shard live on different devices"); return GBN_ERR_ARG; }
     enter(b->dev->eng);
     if (b->dev->ready) HIPCHK(hipEventSynchronize(b->dev->ready));     // deferred lookup build
+    if (b->dev->ready_ctx) HIPCHK(hipEventSynchronize(b->dev->ready_ctx));
     return GBN_OK;
 }
 int gbn_batch_scan_params(const GbnBatch *b, const GbnDb *db, GbnScanParams *out) {
@@ -621,7 +622,7 @@ void gbn_batch_free(GbnBatch *b) {
     if (b->dev && b->dev->eng) {
         enter(b->dev->eng);
         // an extension stage still reading this batch finishes first (its memory goes back to the pool, not to hipFree)
-        { std::lock_guard<std::mutex> lk(E.mu); if (E.has_pending && E.pending_batch == b) (void)wait_pending_gpu(); }
+        if (E.pending_batch_pub.load(std::memory_order_acquire) == b) { std::lock_guard<std::mutex> lk(E.mu); if (E.has_pending && E.pending_batch == b) (void)wait_pending_gpu(); }
         wait_tail(b->host_tail);                            // (a queued host replay reads the batch's options and contexts; the engine is not locked meanwhile)
     }
     free_device_batch(b->dev); delete b;
@@ -647,7 +648,7 @@ void gbn_results_free(GbnResults *r) {
     if (!r) return;
     if (r->engine) {                                        // a stage of the engine that filled them may still write to them
         enter(static_cast<Engine *>(r->engine));
-        { std::lock_guard<std::mutex> lk(E.mu); if (E.has_pending && E.pending_res == r) (void)wait_pending_gpu(); }
+        if (E.pending_res_pub.load(std::memory_order_acquire) == r) { std::lock_guard<std::mutex> lk(E.mu); if (E.has_pending && E.pending_res == r) (void)wait_pending_gpu(); }
         wait_tail(r->host_tail);
         { std::lock_guard<std::mutex> lk2(E.failed_mu); E.failed.erase(r); }
     }
@@ -889,7 +890,7 @@ int gbn_prelim_search_end(GbnResults *results) {
     // stage was queued (one in flight at most).  The engine is locked for the look at the stage in flight only: a caller's
     // other thread may be inside gbn_prelim_search_begin of the next pass meanwhile.
     int rc;
-    {
+    if (!results || E.pending_res_pub.load(std::memory_order_acquire) == results) {     // (a stage of other results, or none: no need for the lock -- the caller's other thread may hold it for the length of a scan)
         std::lock_guard<std::mutex> lk(E.mu);
         if (!results) { (void)wait_pending(); return GBN_OK; }
         if (E.has_pending && E.pending_res == results) (void)wait_pending_gpu();

@@ -324,6 +324,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             HIPCHK(hipMemcpyAsync(&E.scan_back->overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
             HIPCHK(hipMemcpyAsync(E.scan_back->rare_counts, E.rare_counts, (size_t)grid2 * 4, hipMemcpyDeviceToHost, E.stream));
         }
+        if (b.dev->ready_ctx) HIPCHK(hipStreamWaitEvent(E.stream, b.dev->ready_ctx, 0));       // the contexts' cut-offs went up last (upload_batch_contexts): the stages that read them are launched when the host has seen this scan end
         HIPCHK(hipMemcpyAsync(E.scan_back->cnt, E.counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, E.stream));     // seeds, raw hits, the fullest segment
         if (!E.ev_back) HIPCHK(hipEventCreate(&E.ev_back));
         HIPCHK(hipEventRecord(E.ev_back, E.stream));

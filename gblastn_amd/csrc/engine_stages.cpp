@@ -250,6 +250,7 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
             return r;
         });
         E.has_pending = true; E.pending_res = rp; E.pending_ks = ksi; E.pending_batch = bp;
+        E.pending_res_pub.store(rp, std::memory_order_release); E.pending_batch_pub.store(bp, std::memory_order_release);
         return GBN_OK;
     }
     // the key set no stage in flight is working on
@@ -280,6 +281,7 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
         return r;
     });
     E.has_pending = true; E.pending_res = rp; E.pending_batch = bp;
+    E.pending_res_pub.store(rp, std::memory_order_release); E.pending_batch_pub.store(bp, std::memory_order_release);
     return GBN_OK;
 }
 
@@ -311,7 +313,21 @@ static int hitbuf_get(size_t n, HitBuf &out) {
     return GBN_OK;
 }
 static void hitbuf_put(const HitBuf &b) { if (b.hih) { std::lock_guard<std::mutex> lk(E.hitbuf_mu); E.hitbuf_idle.push_back(b); } }
+int stage_get(size_t bytes, void **p, size_t *cap) {
+    {
+        std::lock_guard<std::mutex> lk(E.hitbuf_mu);
+        for (size_t i = 0; i < E.stage_idle.size(); i++)
+            if (E.stage_idle[i].second >= bytes) { *p = E.stage_idle[i].first; *cap = E.stage_idle[i].second; E.stage_idle.erase(E.stage_idle.begin() + (long)i); return GBN_OK; }
+        if (E.stage_idle.size() >= 4) { (void)hipHostFree(E.stage_idle.back().first); E.stage_idle.pop_back(); }     // too short, all of them: one goes
+    }
+    const size_t want = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(p, want) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; set_error("out of pinned host memory (query upload)"); return GBN_ERR_NOMEM; }
+    *cap = want;
+    return GBN_OK;
+}
+void stage_put(void *p, size_t cap) { if (p) { std::lock_guard<std::mutex> lk(E.hitbuf_mu); E.stage_idle.emplace_back(p, cap); } }
 void hitbuf_drain() {
+    { std::lock_guard<std::mutex> lk(E.hitbuf_mu); for (auto &s : E.stage_idle) (void)hipHostFree(s.first); E.stage_idle.clear(); }
     std::lock_guard<std::mutex> lk(E.hitbuf_mu);
     for (HitBuf &b : E.hitbuf_idle) { (void)hipHostFree(b.hih); (void)hipHostFree(b.hg); }
     E.hitbuf_idle.clear();
