@@ -363,9 +363,9 @@ static int build_tables_on_device(GbnBatch &b) {
     std::vector<int32_t> sl, sr;
     for (auto &sg : L.segments) if (sg.second >= sg.first) { sl.push_back(sg.first); sr.push_back(sg.second); }
     int32_t *d_sl = nullptr, *d_sr = nullptr;
-    uint32_t *count = nullptr, *many = nullptr, *many_prefix = nullptr, *vals_a = nullptr, *vals_b = nullptr;
+    uint32_t *count = nullptr, *vals_a = nullptr, *vals_b = nullptr;
     uint32_t *keys_a = nullptr, *keys_b = nullptr; unsigned long long *ctr = nullptr; void *tmp = nullptr;
-    auto cleanup = [&]() { dev_free(d_sl); dev_free(d_sr); dev_free(count); dev_free(many); dev_free(many_prefix);
+    auto cleanup = [&]() { dev_free(d_sl); dev_free(d_sr); dev_free(count);
                            dev_free(vals_a); dev_free(vals_b); dev_free(keys_a); dev_free(keys_b); dev_free(ctr); if (tmp) pool_free(tmp); tmp = nullptr; };
     // (on an error kernels may already be queued on the builder's stream: they finish before their scratch goes back to the pool)
 #define LUTCHK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { set_error(std::string(#x) + ": " + hipGetErrorString(e_)); (void)hipStreamSynchronize(st); cleanup(); return GBN_ERR_HIP; } } while (0)
@@ -380,7 +380,6 @@ static int build_tables_on_device(GbnBatch &b) {
             LUTCHK(hipMemcpyAsync(d_sr, hs + sl.size(), sr.size() * 4, hipMemcpyHostToDevice, st));
         }
     }
-    LUTRC(dev_alloc(count, nc1)); LUTRC(dev_alloc(many, nc1)); LUTRC(dev_alloc(many_prefix, nc1));
     LUTRC(dev_alloc(keys_a, qn)); LUTRC(dev_alloc(keys_b, qn)); LUTRC(dev_alloc(vals_a, qn)); LUTRC(dev_alloc(vals_b, qn));
     LUTRC(dev_alloc(ctr, 2));
     LUTRC(dev_alloc(d->cell_start, nc1)); LUTRC(dev_alloc(d->cellw, (size_t)L.ncells)); LUTRC(dev_alloc(d->cellt, (size_t)L.ncells));
@@ -390,8 +389,8 @@ static int build_tables_on_device(GbnBatch &b) {
     LutBuild B; std::memset(&B, 0, sizeof(B));
     B.q8 = d->q8; B.qlen = b.qlen; B.seg_left = d_sl; B.seg_right = d_sr; B.nseg = (int32_t)sl.size();
     B.lut = L.lut; B.word = L.word; B.q_bits = std::min(31, bits_for((uint64_t)b.qlen + 1)); B.ncells = L.ncells;
-    B.count = count; B.keys_a = keys_a; B.keys_b = keys_b; B.vals_a = vals_a; B.vals_b = vals_b;
-    B.cell_start = d->cell_start; B.cellw = d->cellw; B.cellt = d->cellt; B.pv = d->pv; B.many = many; B.many_prefix = many_prefix;
+    B.count = nullptr; B.keys_a = keys_a; B.keys_b = keys_b; B.vals_a = vals_a; B.vals_b = vals_b;
+    B.cell_start = d->cell_start; B.cellw = d->cellw; B.cellt = d->cellt; B.pv = d->pv;
     B.cbits = GBN_BIN_CBITS(L.lut);
     B.nbins = (int32_t)std::max<int64_t>(1, L.ncells >> B.cbits);
     B.descending = (L.type == GBN_LUT_MB) ? 1 : 0;     // (the fallback below never produces or removes a megablast table)
@@ -406,12 +405,12 @@ static int build_tables_on_device(GbnBatch &b) {
         LUTCHK(lut_enumerate(B, st));
         B.onebyte_mode = 0;
         LUTRC(dev_alloc(d->ent, qn + 1));
-        LUTRC(dev_alloc(d->sidet, qn + 1)); LUTRC(dev_alloc(d->side_start, (size_t)B.nbins + 1));
-        LUTCHK(hipMemsetAsync(d->sidet, 0, (qn + 1) * 2, st));
+        const size_t side_len = (B.nbins <= GBN_BIN_MAXNB ? (size_t)B.nbins * GBN_BIN_SIDE : 0) + 1;      // a bin's side list has a fixed home (lut_cells_side)
+        LUTRC(dev_alloc(d->sidet, side_len)); LUTRC(dev_alloc(d->side_start, (size_t)B.nbins + 1));
+        LUTCHK(hipMemsetAsync(d->sidet, 0, side_len * 2, st));
         size_t b1 = 0, b2 = 0;
         const int key_bits = 2 * L.lut + 1;                         // (the cell; one bit more: "no word at this position" sorts last)
         LUTCHK(lut_sort(nullptr, b1, B, (int64_t)qn, key_bits, st));
-        LUTCHK(lut_scan(nullptr, b2, many, many_prefix, (int64_t)nc1, st));
         LUTCHK(pool_alloc(&tmp, std::max(b1, b2) + 256));
         size_t tb = std::max(b1, b2) + 256;
         uint32_t *n_valid = reinterpret_cast<uint32_t *>(ctr);           // (the counters' first word: nothing else uses it in this branch)
@@ -419,18 +418,17 @@ static int build_tables_on_device(GbnBatch &b) {
         LUTCHK(lut_cell_starts(B, n_valid, st));
         B.ent = d->ent; B.sidet = d->sidet; B.side_start = d->side_start;
         LUTCHK(lut_entries(B, -1, st));
-        LUTCHK(lut_cells(B, st));
-        tb = std::max(b1, b2) + 256;
-        LUTCHK(lut_scan(tmp, tb, many, many_prefix, (int64_t)nc1, st));
-        LUTCHK(lut_side(B, st));
+        LUTCHK(lut_cells_side(B, st));
         LUTCHK(lut_pv(B, st));
         LUTRC(build_rank_table(b, st, &d->build_scratch));
         LUTCHK(hipEventCreateWithFlags(&d->ready, hipEventDisableTiming));
         LUTCHK(hipEventRecord(d->ready, st));
-        for (void *p : {(void *)d_sl, (void *)d_sr, (void *)count, (void *)many, (void *)many_prefix, (void *)vals_a, (void *)vals_b,
+        for (void *p : {(void *)d_sl, (void *)d_sr, (void *)vals_a, (void *)vals_b,
                         (void *)keys_a, (void *)keys_b, (void *)ctr, tmp}) d->build_scratch.push_back(p);
         return GBN_OK;
     }
+    LUTRC(dev_alloc(count, nc1));
+    B.count = count;
     LUTCHK(hipMemsetAsync(count, 0, nc1 * 4, st));
     LUTCHK(lut_enumerate(B, st));
     if (L.type == GBN_LUT_SMALL_NA) LUTCHK(lut_overflow_cells(B, ctr + 1, st));
@@ -460,16 +458,13 @@ static int build_tables_on_device(GbnBatch &b) {
     LUTCHK(lut_sort(tmp, tb, B, (int64_t)qn, key_bits, st));
     B.ent = d->ent;
     LUTCHK(lut_entries(B, n, st));
-    LUTCHK(lut_cells(B, st));
-    tb = std::max(b1, b2) + 256;
-    LUTCHK(lut_scan(tmp, tb, many, many_prefix, (int64_t)nc1, st));
-    uint32_t side_total = 0;
-    LUTCHK(hipMemcpyAsync(&side_total, many_prefix + L.ncells, 4, hipMemcpyDeviceToHost, st));
-    LUTCHK(hipStreamSynchronize(st));
-    LUTRC(dev_alloc(d->sidet, (size_t)side_total + 1)); LUTRC(dev_alloc(d->side_start, (size_t)B.nbins + 1));
-    LUTCHK(hipMemsetAsync(d->sidet + side_total, 0, 2, st));
+    {
+        const size_t side_len = (B.nbins <= GBN_BIN_MAXNB ? (size_t)B.nbins * GBN_BIN_SIDE : 0) + 1;
+        LUTRC(dev_alloc(d->sidet, side_len)); LUTRC(dev_alloc(d->side_start, (size_t)B.nbins + 1));
+        LUTCHK(hipMemsetAsync(d->sidet, 0, side_len * 2, st));
+    }
     B.sidet = d->sidet; B.side_start = d->side_start;
-    LUTCHK(lut_side(B, st));
+    LUTCHK(lut_cells_side(B, st));
     LUTCHK(lut_pv(B, st));
     LUTRC(build_rank_table(b, st, nullptr));
     LUTCHK(hipStreamSynchronize(st));
@@ -506,9 +501,10 @@ int upload_batch_tables(GbnBatch &b) {
     const bool host_lookup = gbn::switch_value("GBN_HOST_LOOKUP", 0) != 0;
     // the query goes up through a pinned staging buffer on the builder's stream (Engine::stage_idle: why)
     // (... and with it, behind the query: the indexed stretches and the per-context block -- every copy of a set-up is an
-    // asynchronous one on the builder's stream.  A blocking hipMemcpy works on the null stream, which shares a hardware queue
-    // with one of the engine's streams once the process has more streams than queues: the 40 KB of stretches waited 14-24 ms
-    // behind the scans queued there, every few batches, and the batch's tables with them.)
+    // asynchronous one on the builder's stream.  Measured (tools/step_jitter.py with GBN_TRACE=1): every few batches of a pipelined
+    // loop a BLOCKING hipMemcpy of a set-up -- first the 10 MB of the query, and once that was gone the 40 KB of stretches -- took
+    // 14-24 ms instead of microseconds, the device's other queues stood still meanwhile, and the scan in flight lasted 20-45 ms
+    // instead of 5: a null-stream copy from pageable memory next to running kernels.  With none left: no step above 8 ms.)
     size_t nseg = 0;
     for (auto &sg : L.segments) if (sg.second >= sg.first) nseg++;
     const size_t q_bytes = (b.qbuf.size() + 63) & ~(size_t)63, seg_bytes = ((2 * nseg * 4) + 63) & ~(size_t)63, ctx_bytes = ctx_layout(b).total * 4;

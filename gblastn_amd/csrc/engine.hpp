@@ -183,10 +183,8 @@ struct Engine {
     // pinned host copies of a range's initial hits and gapped extensions, handed out again (hitbuf_get)
     struct HitBuf { GbnDevInitHit *hih = nullptr; GbnDevGapped *hg = nullptr; size_t cap = 0; };
     std::mutex hitbuf_mu; std::vector<HitBuf> hitbuf_idle;
-    // pinned staging buffers of the batches' query uploads, handed out again.  (A blocking hipMemcpy from the batch's own
-    // pageable vector has the runtime map those pages for the device, and the vector's free() unmaps them: either one, next to
-    // running kernels, stalls the device's queues -- scans of 20-45 ms instead of 5 every few passes of a pipelined loop,
-    // tools/step_jitter.py.)
+    // pinned staging buffers of the batches' uploads (query, stretches, per-context block), handed out again: a set-up makes
+    // no blocking copy from pageable memory (engine.cpp: upload_batch_tables -- why)
     std::vector<std::pair<void *, size_t>> stage_idle;
     // traceback stage: stream and pinned staging buffer of gather_shard_bytes
     std::mutex gather_mu; hipStream_t gather_stream = nullptr; uint8_t *gather_stage = nullptr; size_t gather_stage_cap = 0;

@@ -21,7 +21,6 @@ struct LutBuild {                           // device pointers throughout
     uint32_t *keys_a, *keys_b, *vals_a, *vals_b;            // qlen entries each: {cell (1 << 2 lut: no word here), offset} by list index, sorted on the cell
     uint32_t *cell_start;                   // ncells + 1
     uint32_t *cellw, *cellt, *pv; unsigned long long *ent;
-    uint32_t *many, *many_prefix;           // ncells + 1
     uint16_t *sidet; uint32_t *side_start; int32_t nbins, cbits;     // bins of 2^cbits cells (GBN_BIN_CBITS)
 };
 
@@ -31,8 +30,7 @@ hipError_t lut_sort(void *tmp, size_t &bytes, const LutBuild &b, int64_t n, int 
 hipError_t lut_cell_starts(const LutBuild &b, const uint32_t *n_valid, hipStream_t st);       // cell_start from keys_b sorted (count == nullptr builds)
 hipError_t lut_scan(void *tmp, size_t &bytes, const uint32_t *in, uint32_t *out, int64_t n, hipStream_t st);
 hipError_t lut_entries(const LutBuild &b, int64_t n, hipStream_t st);
-hipError_t lut_cells(const LutBuild &b, hipStream_t st);
-hipError_t lut_side(const LutBuild &b, hipStream_t st);
+hipError_t lut_cells_side(const LutBuild &b, hipStream_t st);      // cellw, cellt, sidet, side_start: a workgroup per bin; side_start[bin] = bin x GBN_BIN_SIDE
 hipError_t lut_pv(const LutBuild &b, hipStream_t st);
 // rank form of the cell table (scan_fold_kernel): popc[0 .. nwords] = set bits per presence word (0 at nwords), then --
 // with prefix = their exclusive sums -- pvx[w] = {pv[w], prefix[w]} and pstart[rank of a present cell] = its cell_start

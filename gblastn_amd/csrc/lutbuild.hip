@@ -152,43 +152,57 @@ __global__ void lut_entries_kernel(gbn::LutBuild B, int64_t n)
     }
 }
 
-// per cell: direct-probe word, LDS table word for cells with one or two entries, size of its side list
-__global__ void lut_cells_kernel(gbn::LutBuild B)
+// per cell: direct-probe word, LDS table word; cells with three or more entries: their reduced fingerprints go to the bin's
+// side list while it has room.  One workgroup per bin (2^cbits cells), the place of a cell's fingerprints in the list = the
+// entries of the bin's cells of that kind in front of it (a running prefix over the workgroup's rounds): rounds 1-4 wrote a
+// 16.7 M-element array of list lengths, ran a scan over all of it and read both again in a third kernel -- a third of a
+// build's time and traffic, and the part of it that ran next to the rare kernel (the end of a build).  A bin's list has a
+// fixed home of GBN_BIN_SIDE entries in `sidet` (side_start[bin] = bin x GBN_BIN_SIDE).  Tables of more bins than the
+// partitioned scan takes (use_side = 0) get cell words only: every cell of three and more entries "always rare".
+__global__ void __launch_bounds__(1024) lut_cells_side_kernel(gbn::LutBuild B, int use_side)
 {
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c <= B.ncells; c += (int64_t)gridDim.x * blockDim.x) {
-    if (c == B.ncells) { B.many[c] = 0; continue; }
-    const uint32_t s = B.cell_start[c], e = B.cell_start[c + 1];
-    uint32_t w = 0, t = 0, many = 0;
-    if (e > s) {
-        bool forced = false;
-        if (B.onebyte_mode) for (uint32_t k = s; k < e; k++) forced = forced || ((B.ent[k] >> 32) & 1ull);
-        const uint32_t fp0 = (uint32_t)(B.ent[s] >> 32);
-        w = (fp0 & 0x7fffffffu) | ((e - s > 1) ? 0x80000000u : 0u);
-        t = 0x8000u | reduce_fp(fp0) | (reduce_fp(fp0) << 16);
-        if (e - s >= 2) t = (t & 0xffffu) | 0x80000000u | (reduce_fp((uint32_t)(B.ent[s + 1] >> 32)) << 16);
-        if (forced) t = 0x80000000u;                            // always the rare path
-        else if (e - s >= 3) { t = 0x80000000u; many = (e - s < 16384u) ? e - s : 0u; }    // decided by lut_side_kernel
+    __shared__ uint32_t s_wsum[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)blockDim.x >> 6;
+    const int64_t bin = blockIdx.x, c0 = bin << B.cbits, c1 = min(c0 + ((int64_t)1 << B.cbits), B.ncells);
+    if (tid == 0) {
+        B.side_start[bin] = use_side ? (uint32_t)bin * (uint32_t)GBN_BIN_SIDE : 0u;
+        if (bin == (int64_t)gridDim.x - 1) B.side_start[bin + 1] = use_side ? (uint32_t)(bin + 1) * (uint32_t)GBN_BIN_SIDE : 0u;
     }
-    B.cellw[c] = w; B.cellt[c] = t; B.many[c] = many;
-    }
-}
-
-// cells with three or more entries: their reduced fingerprints go to the bin's side list while it has room
-__global__ void lut_side_kernel(gbn::LutBuild B)
-{
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < B.ncells; c += (int64_t)gridDim.x * blockDim.x) {
-    if (c < (int64_t)B.nbins + 1) {
-        const int64_t first = min(c << B.cbits, B.ncells);
-        B.side_start[c] = B.many_prefix[first];
-    }
-    const uint32_t cnt = B.many[c];
-    if (!cnt) continue;
-    const int64_t bin = c >> B.cbits;
-    const uint32_t base = B.many_prefix[bin << B.cbits], off = B.many_prefix[c] - base;
-    if (off + cnt > (uint32_t)GBN_BIN_SIDE) continue;           // stays "always rare"
-    const uint32_t s = B.cell_start[c];
-    for (uint32_t k = 0; k < cnt; k++) B.sidet[base + off + k] = (uint16_t)reduce_fp((uint32_t)(B.ent[s + k] >> 32));
-    B.cellt[c] = 0x80000000u | off | (cnt << 16);
+    const uint32_t base = use_side ? (uint32_t)bin * (uint32_t)GBN_BIN_SIDE : 0u;
+    uint32_t run = 0;                                   // entries of the bin's side-list cells so far (those that did not fit included)
+    for (int64_t cb = c0; cb < c1; cb += blockDim.x) {
+        const int64_t c = cb + tid;
+        uint32_t w = 0, t = 0, many = 0, s = 0, e = 0;
+        if (c < c1) {
+            s = B.cell_start[c]; e = B.cell_start[c + 1];
+            if (e > s) {
+                bool forced = false;
+                if (B.onebyte_mode) for (uint32_t k = s; k < e; k++) forced = forced || ((B.ent[k] >> 32) & 1ull);
+                const uint32_t fp0 = (uint32_t)(B.ent[s] >> 32);
+                w = (fp0 & 0x7fffffffu) | ((e - s > 1) ? 0x80000000u : 0u);
+                t = 0x8000u | reduce_fp(fp0) | (reduce_fp(fp0) << 16);
+                if (e - s >= 2) t = (t & 0xffffu) | 0x80000000u | (reduce_fp((uint32_t)(B.ent[s + 1] >> 32)) << 16);
+                if (forced) t = 0x80000000u;                        // always the rare path
+                else if (e - s >= 3) { t = 0x80000000u; many = (use_side && e - s < 16384u) ? e - s : 0u; }
+            }
+        }
+        // exclusive prefix of `many` over the workgroup
+        uint32_t inc = many;
+        for (int off = 1; off < 64; off <<= 1) { const uint32_t v = __shfl_up(inc, off); if (lane >= off) inc += v; }
+        if (lane == 63) s_wsum[wave] = inc;
+        __syncthreads();
+        uint32_t before = 0, total = 0;
+        for (int k = 0; k < nwave; k++) { const uint32_t v = s_wsum[k]; if (k < wave) before += v; total += v; }
+        __syncthreads();
+        if (many) {
+            const uint32_t off = run + before + inc - many;
+            if (off + many <= (uint32_t)GBN_BIN_SIDE) {            // (else: stays "always rare")
+                for (uint32_t k = 0; k < many; k++) B.sidet[base + off + k] = (uint16_t)reduce_fp((uint32_t)(B.ent[s + k] >> 32));
+                t = 0x80000000u | off | (many << 16);
+            }
+        }
+        if (c < c1) { B.cellw[c] = w; B.cellt[c] = t; }
+        run += total;
     }
 }
 
@@ -532,14 +546,12 @@ hipError_t lut_entries(const LutBuild &b, int64_t n, hipStream_t st)
     hipLaunchKernelGGL(lut_entries_kernel, dim3(polite_grid(n >= 0 ? std::max<int64_t>(n, 1) : b.qlen, 256)), dim3(256), 0, st, b, n);
     return hipGetLastError();
 }
-hipError_t lut_cells(const LutBuild &b, hipStream_t st)
+hipError_t lut_cells_side(const LutBuild &b, hipStream_t st)
 {
-    hipLaunchKernelGGL(lut_cells_kernel, dim3(polite_grid(b.ncells + 1, 256)), dim3(256), 0, st, b);
-    return hipGetLastError();
-}
-hipError_t lut_side(const LutBuild &b, hipStream_t st)
-{
-    hipLaunchKernelGGL(lut_side_kernel, dim3(polite_grid(b.ncells, 256)), dim3(256), 0, st, b);
+    const int use_side = b.nbins <= GBN_BIN_MAXNB ? 1 : 0;
+    const int64_t cells_per_bin = std::min<int64_t>((int64_t)1 << b.cbits, b.ncells);
+    const int threads = (int)std::max<int64_t>(64, std::min<int64_t>(1024, (cells_per_bin + 63) / 64 * 64));
+    hipLaunchKernelGGL(lut_cells_side_kernel, dim3((unsigned)b.nbins), dim3((unsigned)threads), 0, st, b, use_side);
     return hipGetLastError();
 }
 hipError_t lut_rank_count(const uint32_t *pv, int64_t nwords, uint32_t *popc, hipStream_t st)
