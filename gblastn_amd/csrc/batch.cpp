@@ -256,6 +256,26 @@ void fill_lookup_host(GbnBatch &b) {
     for (int64_t i = 0; i < L.ncells; i++) if (count[i]) L.pv[i >> 5] |= 1u << (i & 31);
 }
 
+// query buffers of batches that are gone, kept for the next ones (qbuf_take: why)
+namespace {
+std::mutex g_qbuf_mu; std::vector<std::vector<uint8_t>> g_qbuf_idle;
+}
+std::vector<uint8_t> qbuf_take(size_t n) {
+    std::vector<uint8_t> v;
+    {
+        std::lock_guard<std::mutex> lk(g_qbuf_mu);
+        for (size_t i = 0; i < g_qbuf_idle.size(); i++)
+            if (g_qbuf_idle[i].capacity() >= n && g_qbuf_idle[i].capacity() <= n + n / 2 + 4096) { v.swap(g_qbuf_idle[i]); g_qbuf_idle.erase(g_qbuf_idle.begin() + (long)i); break; }
+    }
+    v.resize(n);            // (no reallocation when it came from the list; a fresh one is value-initialised: its pages are touched here)
+    return v;
+}
+void qbuf_give(std::vector<uint8_t> &&v) {
+    if (v.capacity() < ((size_t)1 << 20)) return;           // small ones: the allocator's business
+    std::lock_guard<std::mutex> lk(g_qbuf_mu);
+    if (g_qbuf_idle.size() < 6) g_qbuf_idle.emplace_back(std::move(v));
+}
+
 // Order (round 5): what the LOOKUP TABLE needs first -- the concatenated query, the indexed stretches, the table's kind --
 // then `tables_hook` (the caller starts the device upload of the query and the table build there: they run on the builder's
 // stream while this thread goes on), then what only the HOST needs before the search: Karlin-Altschul parameters per
@@ -272,7 +292,12 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
     int64_t total = 1;
     for (int i = 0; i < nq; i++) total += 2 * ((int64_t)lens[i] + 1);
     if (total > INT32_MAX - 4 * pad) { set_error("query batch too long"); return GBN_ERR_ARG; }
-    b.qbuf.assign((size_t)total + 2 * pad, 15);
+    // the concatenation's buffer: one a batch before this one has given back, when there is one (a fresh 10 MB vector is 2,500
+    // page faults before the first base is written -- 0.5-2 ms in front of everything else a set-up does, the device part
+    // included); everything that is not a query base -- the pads, the separators -- is written below
+    b.qbuf = qbuf_take((size_t)total + 2 * pad);
+    std::memset(b.qbuf.data(), 15, (size_t)pad + 1);
+    std::memset(b.qbuf.data() + (size_t)pad + (size_t)total, 15, (size_t)pad);      // (behind the last separator)
     b.qpad = pad + 1;
     uint8_t *q = b.qbuf.data() + b.qpad;
     int32_t off = 0;
@@ -291,6 +316,7 @@ int build_batch(GbnBatch &b, const GbnOptions &opt, int32_t nq, const uint8_t *c
             std::memcpy(q + b.ctx[2 * i].query_offset, seqs[i], (size_t)L);
             uint8_t *r = q + b.ctx[2 * i + 1].query_offset;
             for (int32_t j = 0; j < L; j++) r[j] = kComplement[seqs[i][L - 1 - j] & 15];
+            q[b.ctx[2 * i].query_offset + L] = 15; r[L] = 15;          // the separators behind both strands
         }
     };
     if (total < (1 << 18) || nq < 16) fill_range(0, nq);

@@ -625,7 +625,9 @@ void gbn_batch_free(GbnBatch *b) {
         if (E.pending_batch_pub.load(std::memory_order_acquire) == b) { std::lock_guard<std::mutex> lk(E.mu); if (E.has_pending && E.pending_batch == b) (void)wait_pending_gpu(); }
         wait_tail(b->host_tail);                            // (a queued host replay reads the batch's options and contexts; the engine is not locked meanwhile)
     }
-    free_device_batch(b->dev); delete b;
+    free_device_batch(b->dev);
+    gbn::qbuf_give(std::move(b->qbuf));
+    delete b;
 }
 int32_t gbn_batch_num_contexts(const GbnBatch *b) { return (int32_t)b->ctx.size(); }
 const GbnContext *gbn_batch_contexts(const GbnBatch *b) { return b->ctx.data(); }

@@ -44,6 +44,8 @@ struct HostLookup {
 };
 
 struct DeviceBatch;     // device mirrors, defined in engine.hpp
+std::vector<uint8_t> qbuf_take(size_t n);       // batch.cpp: a batch's concatenation buffer, recycled
+void qbuf_give(std::vector<uint8_t> &&v);
 void trace_mark(const char *what);   // GBN_TRACE=1: wall-clock marks on stderr (engine.cpp)
 }  // namespace gbn
 

@@ -9,6 +9,6 @@ python bench.py $A --steps 32 --warmup 4 > $O/bench_cached.json 2> $O/bench_cach
 python bench.py $A --steps 32 --warmup 4 > $O/bench_cached2.json 2>> $O/bench_cached.err
 GBN_TRACE=1 python bench.py $A --steps 6 --warmup 2 > /dev/null 2> $O/trace_marks.txt
 timeout 400 rocprofv3 --kernel-trace -d $O/kt -- python bench.py $A --steps 16 --warmup 2 > $O/bench_cached_rocprof.json 2> $O/kt.err
-python tools/timeline.py $(find $O/kt -name "*.db" | head -1) 120 > $O/cached_timeline.txt
+python tools/timeline.py $(find $O/kt -name "*.db" | head -1) 700 > $O/cached_timeline.txt
 rm -rf $O/kt
 for f in $O/bench_cached.json $O/bench_cached2.json; do python -c "import json,sys; j=json.loads(open('$f').read().strip().splitlines()[-1]); print(j['ms_per_step'], j['value'])"; done
