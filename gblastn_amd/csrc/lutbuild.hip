@@ -159,9 +159,9 @@ __global__ void lut_entries_kernel(gbn::LutBuild B, int64_t n)
 // build's time and traffic, and the part of it that ran next to the rare kernel (the end of a build).  A bin's list has a
 // fixed home of GBN_BIN_SIDE entries in `sidet` (side_start[bin] = bin x GBN_BIN_SIDE).  Tables of more bins than the
 // partitioned scan takes (use_side = 0) get cell words only: every cell of three and more entries "always rare".
-__global__ void __launch_bounds__(1024) lut_cells_side_kernel(gbn::LutBuild B, int use_side)
+__global__ void __launch_bounds__(256) lut_cells_side_kernel(gbn::LutBuild B, int use_side)
 {
-    __shared__ uint32_t s_wsum[16];
+    __shared__ uint32_t s_wsum[4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nwave = (int)blockDim.x >> 6;
     const int64_t bin = blockIdx.x, c0 = bin << B.cbits, c1 = min(c0 + ((int64_t)1 << B.cbits), B.ncells);
     if (tid == 0) {
@@ -550,7 +550,9 @@ hipError_t lut_cells_side(const LutBuild &b, hipStream_t st)
 {
     const int use_side = b.nbins <= GBN_BIN_MAXNB ? 1 : 0;
     const int64_t cells_per_bin = std::min<int64_t>((int64_t)1 << b.cbits, b.ncells);
-    const int threads = (int)std::max<int64_t>(64, std::min<int64_t>(1024, (cells_per_bin + 63) / 64 * 64));
+    // (256 threads: one wave per SIMD is what fits next to a probe workgroup -- 85 VGPRs x 4 waves per SIMD, 155 KB of LDS; with
+    // 1,024 threads per workgroup the kernel waited for the probe kernel to end and ran next to the rare kernel instead: 3.6 ms)
+    const int threads = (int)std::max<int64_t>(64, std::min<int64_t>(256, (cells_per_bin + 63) / 64 * 64));
     hipLaunchKernelGGL(lut_cells_side_kernel, dim3((unsigned)b.nbins), dim3((unsigned)threads), 0, st, b, use_side);
     return hipGetLastError();
 }

@@ -965,7 +965,7 @@ probe_bin_kernel(GbnBinParams B)
     if (dyn) {
         if (tid == 0) s_item[0] = atomicAdd(&B.work[grp], 1u);
         __syncthreads();
-        item = (int)s_item[0];
+        item = __builtin_amdgcn_readfirstlane((int)s_item[0]);      // (wave-uniform: the bin, its table's address, the piece bookkeeping stay in scalar registers)
     }
     for (int par = 0; ; par ^= 1) {
         const int b = dyn ? grp + GBN_BIN_GROUPS * (item / nw) : grp % bstep + GBN_BIN_GROUPS * item;
@@ -1127,7 +1127,7 @@ probe_bin_kernel(GbnBinParams B)
             if (v < V) start_piece(v, B.gcount[(size_t)b * B.nwriters + v / split]);
         }
         if (qn > 0) { flush(0, qn, b); qn = 0; }                    // the side list changes with the bin
-        item = dyn ? (int)s_item[par ^ 1] : item + 1;
+        item = dyn ? __builtin_amdgcn_readfirstlane((int)s_item[par ^ 1]) : item + 1;
     }
     if (P.raw_hits) {
         for (int off = 32; off > 0; off >>= 1) raw += __shfl_down(raw, off);
