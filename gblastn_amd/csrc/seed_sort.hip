@@ -13,7 +13,11 @@
 #include <hip/hip_runtime.h>
 
 namespace {
-constexpr int SS_THREADS = 1024, SS_WAVES = SS_THREADS / 64, SS_BITS = 6, SS_DIGITS = 1 << SS_BITS, SS_DEEP = 8;
+// (512 threads: two waves of 64 registers per SIMD fit next to a probe workgroup, which leaves 160 of a SIMD's 512 -- with 1,024
+// threads the kernel found room only when it happened to be dispatched before the probe kernel of the pass behind it, and waited
+// for that kernel's 3 ms when it was not)
+constexpr int SS_THREADS = 512, SS_WAVES = SS_THREADS / 64, SS_BITS = 6, SS_DIGITS = 1 << SS_BITS, SS_DEEP = 8;
+static_assert(SS_DIGITS * SS_WAVES == SS_THREADS, "one thread per (digit, wave) counter");
 
 struct SeedSortParams {
     GbnKeyParams K;                 // seeds, n, the key layout (q_bits, group_bits, s_bits, qh_bits, subj_base, q_descending, container)
@@ -64,7 +68,7 @@ extern "C" __global__ void __launch_bounds__(SS_THREADS) seed_sort_small_kernel(
         uint64_t *__restrict__ kdst = (p & 1) ? S.key_ping : S.key_pong;
         uint32_t *__restrict__ idst = (p & 1) ? S.idx_ping : S.idx_pong;
         const int shift = SS_BITS * p;
-        hist[tid >> 4][tid & 15] = 0;
+        hist[tid / SS_WAVES][tid % SS_WAVES] = 0;
         __syncthreads();
         // a wave walks its stretch of the list 64 elements at a time, SS_DEEP such batches loaded together (pass 0 makes the
         // keys from the seeds, element i = seed i)
@@ -91,7 +95,7 @@ extern "C" __global__ void __launch_bounds__(SS_THREADS) seed_sort_small_kernel(
         __syncthreads();
         // ---- exclusive prefix sum over (digit, wave), digit-major: where every wave's elements of every digit go
         {
-            const uint32_t v = hist[tid >> 4][tid & 15];
+            const uint32_t v = hist[tid / SS_WAVES][tid % SS_WAVES];
             uint32_t incl = v;
             #pragma unroll
             for (int o = 1; o < 64; o <<= 1) { const uint32_t t = __shfl_up(incl, o, 64); if (lane >= o) incl += t; }
@@ -99,7 +103,7 @@ extern "C" __global__ void __launch_bounds__(SS_THREADS) seed_sort_small_kernel(
             __syncthreads();
             uint32_t base = 0;
             for (int k = 0; k < w; k++) base += wtot[k];
-            hist[tid >> 4][tid & 15] = base + incl - v;
+            hist[tid / SS_WAVES][tid % SS_WAVES] = base + incl - v;
         }
         __syncthreads();
         // ---- scatter, in the same order (stable)
