@@ -713,7 +713,10 @@ int gbn_db_prepare_records(GbnDb *db, const GbnOptions *opt, int32_t nq, const i
     if (!db || !opt || nq <= 0 || !lens || !db->engine) { set_error("gbn_db_prepare_records: bad argument"); return GBN_ERR_ARG; }
     enter(static_cast<Engine *>(db->engine));
     if (!E.ready) { set_error("the engine was released (gbn_release) after this shard was made"); return GBN_ERR_ARG; }
-    std::lock_guard<std::mutex> lk(E.mu);
+    // (a search is running on this device: its pass bins, or has found the records -- a set-up thread of a pipelined caller is
+    // not to wait here for the length of a scan)
+    std::unique_lock<std::mutex> lk(E.mu, std::try_to_lock);
+    if (!lk.owns_lock()) return GBN_OK;
     int type = 0, lut = 0, step = 0;
     gbn::predict_table_shape(*opt, nq, lens, type, lut, step);
     const int word = opt->word_size;

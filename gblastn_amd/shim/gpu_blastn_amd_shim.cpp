@@ -338,12 +338,16 @@ Int2 Blast_gpu_RunPreliminarySearchWithInterrupt(EBlastProgramType program,
             blocks.push_back(block);
         }
         if (blocks.empty() || rc != GBN_OK) break;
-        if (!batch)
-            rc = gbn_batch_new_masked(&batch, &o, (int32_t)seqs.size(), seqs.data(), lens.data(),
-                                      (int32_t)mq.size(), mq.data(), mfrom.data(), mto.data(), 1);
         // the group as one shard; blocks whose slabs lie too far apart for a view are searched one by one
         GbnDb* view = NULL;
         const bool one = rc == GBN_OK && gbn_block_view(blocks.data(), (int32_t)blocks.size(), &view) == GBN_OK && view;
+        if (!batch && rc == GBN_OK) {
+            // (the first group's scan records are binned underneath the set-up of the query batch when they are not resident yet:
+            // the binning kernel needs no lookup table -- gbn_db_prepare_records returns at once, and does nothing when they are)
+            if (one) (void)gbn_db_prepare_records(view, &o, (int32_t)lens.size(), lens.data());
+            rc = gbn_batch_new_masked(&batch, &o, (int32_t)seqs.size(), seqs.data(), lens.data(),
+                                      (int32_t)mq.size(), mq.data(), mfrom.data(), mto.data(), 1);
+        }
         for (size_t k = 0; rc == GBN_OK && k < (one ? 1 : blocks.size()); ++k) {
             gbn_results_clear(res[cur]);
             rc = gbn_prelim_search_begin(batch, one ? view : blocks[k], res[cur], &d, interrupt_search ? s_Interrupt : NULL, &intr);

@@ -191,7 +191,8 @@ int  gbn_record_cache_invalidate(void);     /* every cached set forgets its reco
 /* The scan records a batch of nq unmasked queries of these lengths will want of `db`, binned NOW, asynchronously: the binning
  * kernel needs no lookup table, so it runs underneath the set-up of the batch (gbn_batch_new*), whose pass then finds the
  * records in the cache.  Returns at once.  No effect when the cache is off, when such a batch is scanned without records
- * (tables as wide as the word, tiny tables), or when the records are resident. */
+ * (tables as wide as the word, tiny tables), when the records are resident, or while a search is running on the device
+ * (that pass bins for itself: a pipelined caller's set-up thread never waits here). */
 struct GbnOptions;
 int  gbn_db_prepare_records(struct GbnDb *db, const struct GbnOptions *opt, int32_t nq, const int32_t *lens);
 /* A VIEW over resident blocks: their subjects as ONE shard (one tile table, one launch per kernel, one record set), for

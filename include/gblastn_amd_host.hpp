@@ -60,6 +60,7 @@ public:
         for (auto &s : q.seqs) { p.push_back(s.data()); len.push_back((int32_t)s.size()); }
         for (auto &m : q.masks) { mq.push_back(m.query); mf.push_back(m.from); mt.push_back(m.to); }
         Check(gbn_use_device(gbn_db_device(db_)), "gbn_use_device");        // the batch lives on the shard's GPU, whatever thread sets it up
+        (void)gbn_db_prepare_records(db_, &opt, nq_, len.data());          // a shard whose scan records are not resident yet: binned underneath this set-up (returns at once)
         Check(gbn_batch_new_masked(&b_, &opt, nq_, p.data(), len.data(), (int32_t)mq.size(), mq.data(), mf.data(), mt.data(), 1), "gbn_batch_new_masked");
         Check(gbn_results_new(&r_), "gbn_results_new");
     }
