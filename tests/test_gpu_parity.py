@@ -397,6 +397,31 @@ def test_soft_query_masks(task, nq, kw):
     assert len(gpu["hsps"]) >= 1
 
 
+def test_set_up_buffers_handed_on_from_batch_to_batch():
+    """A batch's concatenation buffer and its pinned staging buffer are kept when the batch goes and handed to the next one
+    (from 1 MB up: batch.cpp qbuf_take, Engine::stage_idle).  A batch of other queries, lengths and masks in buffers a longer
+    one has just left behind: same stages as the oracle's -- every byte that is not a query base (pads, separators) is written
+    by the set-up itself, nothing of the batch before shows through."""
+    rng = np.random.default_rng(77)
+    db, qa, _, subjects, opt = util.small_case(4, 60_000, 700, qlen=1000, seed=3, planted_fraction=0.2)
+    src = api.BlastSeqSrc.from_packed(subjects)
+    for q in qa[::7]:
+        q[rng.integers(0, len(q), 5)] = 14                          # ambiguity codes in the first batch's buffer
+    a = api.BlastPrelimSearch(qa, opt, src)
+    a.run(); a.close()
+    _, qb, _, _, _ = util.small_case(4, 60_000, 560, qlen=1100, seed=3, planted_fraction=0.5)
+    qb = [q[: int(rng.integers(800, 1100))] for q in qb]           # ragged: other offsets, a buffer three quarters as long (within the hand-on rule)
+    masks = [(i, 10, 40) for i in range(0, len(qb), 5)]
+    b = api.BlastPrelimSearch(qb, opt, src, masks=masks)
+    gpu = b.run(keep_stages=True)
+    ora, s = util.oracle_run(opt, qb, subjects, masks=masks)
+    util.compare_stages(gpu, ora)
+    assert len(gpu["hsps"]) >= 50
+    d = b.diagnostics
+    assert (d.lookup_hits, d.good_init_extends) == (s.stats.lookup_hits, s.stats.good_init_extends)
+    b.close(); src.close()
+
+
 @pytest.mark.parametrize("task,period", [("blastn", 12), ("blastn", 14), ("megablast", 30)])
 def test_query_masks_every_few_bases(task, period):
     """One masked base every `period`: 70-85 indexed stretches begin inside one 1,024-position block of the table
