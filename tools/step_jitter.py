@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where a pipelined pass loses time now and then: the C2 loop of bench.py (two set-ups in flight, begin() on the main thread, end() +
+"""Where a pipelined pass loses time now and then (and a soak test of the pipelined loop: every pass of a query set must return the same HSPs): the C2 loop of bench.py (two set-ups in flight, begin() on the main thread, end() +
 close() on a worker) with the wall clock of every step taken apart -- waiting for the batch's set-up, begin() -- and the outliers
 printed.  usage: step_jitter.py [steps] [cache: 0|1]"""
 import os, sys, time, gc
@@ -33,12 +33,12 @@ def make(k):
     return b
 
 
-def finish(b):
+def finish(b, k):
     t0 = time.perf_counter()
-    n = len(b.end()["hsps"])
+    h = b.end()["hsps"]
     t1 = time.perf_counter()
     b.close()
-    return n, (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3
+    return (k & 1, len(h), hash(h.tobytes())), (t1 - t0) * 1e3, (time.perf_counter() - t1) * 1e3
 
 
 def run(count):
@@ -54,10 +54,10 @@ def run(count):
         b.begin()
         t3 = time.perf_counter()
         if prev is not None:
-            futs.append(closer.submit(finish, prev))
+            futs.append(closer.submit(finish, prev, k - 1))
         prev = b
         rows.append((k, (t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (time.perf_counter() - t0) * 1e3, b.diagnostics.total_ms, b.diagnostics.scan_stage_ms))
-    futs.append(closer.submit(finish, prev))
+    futs.append(closer.submit(finish, prev, count - 1))
     fin = [f.result() for f in futs]
     return rows, fin
 
@@ -70,6 +70,11 @@ torch.cuda.synchronize()
 wall = (time.perf_counter() - t0) * 1e3
 tot = sorted(r[4] for r in rows)
 med = tot[len(tot) // 2]
+seen = {}
+for sig, _, _ in fin:                       # the two query sets alternate: every pass of one gives the same HSPs, byte for byte
+    seen.setdefault(sig[0], set()).add(sig[1:])
+assert all(len(v) == 1 for v in seen.values()), "HSPs of one query set differ between passes: %r" % {k: sorted(v)[:4] for k, v in seen.items()}
+print("HSPs per pass (even / odd batches): %s -- identical in every pass" % [sorted(v)[0][0] for _, v in sorted(seen.items())])
 print("cache %d: %d steps, %.2f ms per step wall, median step %.2f, p90 %.2f, max %.2f" % (cache, steps, wall / steps, med, tot[int(len(tot) * 0.9)], tot[-1]))
 print("mean: wait for set-up %.3f, submit %.3f, begin %.3f; set-up (worker) mean %.2f max %.2f; end mean %.2f max %.2f; close mean %.2f max %.2f" % (
     sum(r[1] for r in rows) / steps, sum(r[2] for r in rows) / steps, sum(r[3] for r in rows) / steps,
