@@ -359,7 +359,7 @@ def main():
                                     "achieved": 0.25 * sum(d.subject_bases_scanned for d in dgc) / max(sum(d.probe_kernel_ms for d in dgc), 1e-9) / 1e6,
                                     "frac": 0.25 * sum(d.subject_bases_scanned for d in dgc) / max(sum(d.probe_kernel_ms for d in dgc), 1e-9) / 1e6 / 8000.0,
                                     "scan_stage_frac": 0.25 * sum(d.subject_bases_scanned for d in dgc) / max(sum(d.scan_kernel_ms for d in dgc), 1e-9) / 1e6 / 8000.0,
-                                    "traffic": 13.1e9 + 3.5e9, "traffic_what": "probe 13.1 GB + rare 3.5 GB per pass (profiles/scan_traffic.json, r05e_pmc.csv): 1.33 x the algorithmic 12.5 GB, against 3.8 x for a pass that bins"},
+                                    "traffic": 13.1e9 + 2.9e9, "traffic_what": "probe 13.1 GB + rare 2.9 GB per pass (profiles/scan_traffic.json): 1.28 x the algorithmic 12.5 GB, against 3.8 x for a pass that bins"},
                        "what": "the same step as the headline (set-up from scratch, scan, extension, merge) with the record cache ON and the shard's records "
                                "resident: the binning kernel does not run -- NOT the headline metric (that one bins in every pass)"}
         api.record_cache_set_limit(0)

@@ -1139,31 +1139,22 @@ probe_bin_kernel(GbnBinParams B)
 }
 
 // rare path of the partitioned scan: one queued item per thread
+// (Round 5, with the probe workgroups drawing their work from a counter the segments are no longer equally long.  Tried against
+// this arrangement -- gridDim.x / nseg workgroups per segment, each walking its segment's rounds in steps of that number -- and
+// not kept: all segments as one list dealt out round by round (FETCH_SIZE 3.7 instead of 2.9 GB per launch, 1.41 against 1.19
+// ms in the pipeline), rounds dealt out by (tick, segment) slots of equal relative progress (3.4 GB; 1.15 against 1.09 ms),
+// workgroups per segment in proportion to its length (3.55 GB, 1.5 ms).  The workgroups of this arrangement all sit at the same
+// place of their segments, i.e. in the same few bins, whose cursors, cells and entries they share in the L2s: worth more than the
+// last workgroups of the longest segment running alone.)
 extern "C" __global__ void __launch_bounds__(256)
 probe_rare_kernel(GbnBinParams B, int nseg)
 {
     const GbnScanParams &P = B.S;
     unsigned long long raw = 0;
-    // The segments (one per probe workgroup) are as uneven as the CUs were busy while the probe workgroups drew their work from
-    // a counter (round 5); with a fixed set of workgroups per segment (rounds 1-4) this kernel would take as long as the fullest
-    // one.  Every segment is in bin order, and the tables an item asks for (cursors, cells, entries) are its bin's: the
-    // workgroups in flight should be at the same RELATIVE place of their segments.  So the rounds (256 items) are dealt out by
-    // slots: slot (tick, segment) holds the rounds [tick * n / T, (tick + 1) * n / T) of a segment of n rounds (none or one),
-    // T = the rounds of the fullest segment; workgroup w takes the slots w, w + grid, ... -- a tick after the other, and a
-    // different segment every time (the segment index is rotated by the tick).  (The segments as one list dealt out round by
-    // round balanced as well, but had the workgroups in flight in 4 segments at unrelated bins: FETCH_SIZE 3.7 instead of 2.9
-    // GB per launch, 1.41 instead of 1.19 ms.)
-    __shared__ uint32_t s_cnt[1024], s_tmax;
-    if (threadIdx.x == 0) s_tmax = 0;
-    __syncthreads();
-    {
-        uint32_t mx = 0;
-        for (int i = (int)threadIdx.x; i < nseg; i += 256) { const uint32_t c = min(B.rare_counts[i], B.rare_seg); s_cnt[i] = c; mx = max(mx, (c + 255u) >> 8); }
-        for (int off = 32; off > 0; off >>= 1) mx = max(mx, (uint32_t)__shfl_down(mx, off));
-        if ((threadIdx.x & 63) == 0 && mx) atomicMax(&s_tmax, mx);
-        __syncthreads();
-    }
-    const uint32_t tmax = s_tmax, nslots = tmax * (uint32_t)nseg;
+    // blockIdx.x % nseg = segment (probe workgroup), blockIdx.x / nseg = part
+    const int seg = blockIdx.x % nseg, part = blockIdx.x / nseg, nparts = gridDim.x / nseg;
+    const uint32_t n = min(B.rare_counts[seg], B.rare_seg);
+    const GbnRareItem *qs = B.rareq + (size_t)seg * B.rare_seg;
     // dense-seed shapes (lut == word: every lookup hit is a seed) stage their seeds in LDS
     constexpr uint32_t CAP = 1536;
     __shared__ GbnDevSeed s_buf[CAP];
@@ -1186,15 +1177,11 @@ probe_rare_kernel(GbnBinParams B, int nseg)
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
     };
-    for (uint32_t slot = blockIdx.x; slot < nslots; slot += gridDim.x) {       // uniform over the workgroup
-        const uint32_t tick = slot / (uint32_t)nseg, seg = (slot % (uint32_t)nseg + tick) % (uint32_t)nseg;
-        const uint32_t n = s_cnt[seg], nr = (n + 255u) >> 8;
-        const uint32_t r0 = (uint32_t)(((unsigned long long)tick * nr) / tmax), r1 = (uint32_t)(((unsigned long long)(tick + 1u) * nr) / tmax);
-        if (r0 == r1) continue;                                     // (nr <= tmax: one round at most)
+    for (uint32_t i0 = (uint32_t)part * 256u; i0 < n; i0 += (uint32_t)nparts * 256u) {     // uniform over the workgroup
         if (staged) { __syncthreads(); if (s_n > CAP - 512u) flush(); }      // s_n is stable between the barriers
-        const uint32_t i = r0 * 256u + threadIdx.x;
+        const uint32_t i = i0 + threadIdx.x;
         if (i >= n) continue;
-        const uint4 item = *reinterpret_cast<const uint4 *>(B.rareq + (size_t)seg * B.rare_seg + i);
+        const uint4 item = *reinterpret_cast<const uint4 *>(qs + i);
         uint32_t pid = item.x; const uint32_t cv = item.y;
         uint32_t idx = item.z, cw = item.w;
         {   // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
@@ -1297,7 +1284,6 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
         // 12: 1.62 / 1.70-1.72, 24: 1.55 / 1.63 (profiles/r04k_probe_and_rare_kernel.txt) -- the kernel is bound by the rate at which HBM
         // takes its scattered sectors, and more waves in flight do not raise it
         const int parts = (int)std::max(1ll, std::min(64ll, gbn::switch_value("GBN_RARE_PARTS", 4)));
-        if (grid2 > 1024) return hipErrorInvalidValue;             // (the kernel's prefix sum over the segments)
         if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * parts), dim3(256), 0, st, b, grid2);
         e = hipGetLastError();
     }
