@@ -529,13 +529,12 @@ int upload_batch_tables(GbnBatch &b) {
         const int64_t pad = 256, n = (int64_t)b.qlen + 2 * pad;
         const size_t q2_bytes = (size_t)(n + 3) / 4 + 16, qi_bytes = (size_t)(n + 7) / 8 + 16;
         if ((rc = dev_alloc(d->q2_base, q2_bytes)) || (rc = dev_alloc(d->qinv_base, qi_bytes))) return rc;
-        HIPCHK(hipMemsetAsync(d->q2_base, 0xff, q2_bytes, E.stream_build));        // tails: "matches nothing"
-        HIPCHK(hipMemsetAsync(d->qinv_base, 0xff, qi_bytes, E.stream_build));
+        // (the arrays' tails, "matches nothing", are written by the kernels that fill them: a fill of 14 MB in three dispatches of
+        // their own cost the builder's stream 0.3 ms next to a probe kernel, where every dispatch waits for room)
         HIPCHK(lut_pack_query(d->q8_base, (int64_t)b.qbuf.size(), (int64_t)b.qpad - pad, n, d->q2_base, d->qinv_base, E.stream_build));
         d->q2 = d->q2_base + pad / 4; d->qinv = d->qinv_base + pad / 8;
         d->q4_plane = ((int64_t)b.qbuf.size() + 3) / 4 + 64;          // (an 8- or 16-byte load may start at a plane's last byte)
         if ((rc = dev_alloc(d->q4_base, (size_t)(4 * d->q4_plane)))) return rc;
-        HIPCHK(hipMemsetAsync(d->q4_base, 0xff, (size_t)(4 * d->q4_plane), E.stream_build));
         HIPCHK(lut_pack_q4(d->q8_base, (int64_t)b.qbuf.size(), d->q4_base, d->q4_plane, E.stream_build));
     }
     if (host_lookup) {

@@ -276,6 +276,11 @@ __global__ void lut_rank_fill_kernel(const uint32_t *pv, const uint32_t *prefix,
 __global__ void lut_pack_query_kernel(const uint8_t *qbuf, int64_t qbuf_len, int64_t first, int64_t n, uint8_t *q2, uint8_t *qinv)
 {
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // one thread per 8 bases
+    if (t == 0) {           // the 16 bytes behind either array ("matches nothing": a window may start at the last byte) -- no fill of the whole arrays in front of this kernel
+        const int64_t groups = (n + 7) / 8, q2_bytes = (n + 3) / 4 + 16, qi_bytes = (n + 7) / 8 + 16;
+        for (int64_t i = groups * 2; i < q2_bytes; i++) q2[i] = 0xff;
+        for (int64_t i = groups; i < qi_bytes; i++) qinv[i] = 0xff;
+    }
     if (t * 8 >= n) return;
     uint32_t two = 0, inv = 0;
     for (int k = 0; k < 8; k++) {
@@ -298,6 +303,11 @@ __global__ void lut_pack_query_kernel(const uint8_t *qbuf, int64_t qbuf_len, int
 __global__ void lut_q4_kernel(const uint8_t *qbuf, int64_t qbuf_len, uint8_t *q4, int64_t plane)
 {
     const int64_t k = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < 4 * 128) {      // the 64 (or 65) bytes behind every plane's last byte of the query (15 beyond the buffer in all four positions: 0xff)
+        const int64_t pl = k >> 7, used = qbuf_len > pl ? (qbuf_len - pl + 3) / 4 : 0;      // bytes of plane pl that offsets < qbuf_len write
+        const int64_t at = used + (k & 127);
+        if (at < plane) q4[pl * plane + at] = 0xff;
+    }
     if (k >= qbuf_len) return;
     uint32_t v = 0;
     for (int j = 0; j < 4; j++) v |= (uint32_t)(k + j < qbuf_len ? qbuf[k + j] : 15) << (6 - 2 * j);
@@ -311,7 +321,7 @@ namespace gbn {
 hipError_t lut_pack_q4(const uint8_t *qbuf, int64_t qbuf_len, uint8_t *q4, int64_t plane, hipStream_t st)
 {
     if (qbuf_len <= 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_q4_kernel, dim3((unsigned)((qbuf_len + 255) / 256)), dim3(256), 0, st, qbuf, qbuf_len, q4, plane);
+    hipLaunchKernelGGL(lut_q4_kernel, dim3((unsigned)((std::max<int64_t>(qbuf_len, 512) + 255) / 256)), dim3(256), 0, st, qbuf, qbuf_len, q4, plane);
     return hipGetLastError();
 }
 
