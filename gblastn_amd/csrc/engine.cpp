@@ -533,7 +533,7 @@ int upload_batch_tables(GbnBatch &b) {
         // their own cost the builder's stream 0.3 ms next to a probe kernel, where every dispatch waits for room)
         HIPCHK(lut_pack_query(d->q8_base, (int64_t)b.qbuf.size(), (int64_t)b.qpad - pad, n, d->q2_base, d->qinv_base, E.stream_build));
         d->q2 = d->q2_base + pad / 4; d->qinv = d->qinv_base + pad / 8;
-        d->q4_plane = ((int64_t)b.qbuf.size() + 3) / 4 + 64;          // (an 8- or 16-byte load may start at a plane's last byte)
+        d->q4_plane = ((((int64_t)b.qbuf.size() + 3) / 4 + 64) + 3) & ~(int64_t)3;      // (an 8- or 16-byte load may start at a plane's last byte; a multiple of 4: lut_q4_kernel stores dwords)
         if ((rc = dev_alloc(d->q4_base, (size_t)(4 * d->q4_plane)))) return rc;
         HIPCHK(lut_pack_q4(d->q8_base, (int64_t)b.qbuf.size(), d->q4_base, d->q4_plane, E.stream_build));
     }
