@@ -299,6 +299,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             B.rec = reinterpret_cast<uint32_t *>(rs->bin_rec); B.tcur = rs->bin_tcur; B.nseq = (uint32_t)nseq; B.gcount = rs->bin_count; B.subcap = (uint32_t)subcap;
             B.overflow = rs->bin_count + nstream;
             B.dbg = (int)gbn::switch_value("GBN_DBG", 0);
+            B.rare_parts = (hit && !binned_here) ? 5 : 0;      // (a pass over cached records: gbn_dev.h)
             B.work = gbn::switch_value("GBN_PROBE_DYN", 1) != 0 ? reinterpret_cast<uint32_t *>(E.counters + 4) : nullptr;      // (counters [4 .. 7]: zeroed with the scan's own, above)
             int grid2 = std::max(8, E.num_cu & ~7);   // one 1024-thread workgroup per CU; group = blockIdx & 7
             {   // rare-path queue: one segment per probe workgroup (~1.2 % of scan positions in total)

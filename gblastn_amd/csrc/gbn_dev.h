@@ -89,6 +89,11 @@ struct GbnBinParams {
     // with the table builder's or the extension stages' waves takes fewer items and the kernel does not wait for it.
     // Null (or fewer bins than groups): fixed shares.
     uint32_t *work;
+    // workgroups of the rare kernel per queue segment; 0: the default (4, GBN_RARE_PARTS).  The engine asks for 5 when the pass
+    // runs over cached records: the next batch's table build is in the middle of its sort then, and five workgroups of the rare
+    // kernel per CU (143 of its 160 KB of LDS, all 1,280 resident at once) leave those kernels less room than four do -- 1.22
+    // instead of 1.47 ms, 4.59 instead of 4.82 ms per pass; alone, and behind a binning kernel, four are the faster (0.97 / 1.03).
+    int rare_parts;
 };
 
 struct GbnKeyParams {

@@ -1283,7 +1283,7 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
         // 3: 1.60 / 1.72, 4: 1.49-1.52 / 1.61-1.69, 5: 1.47 / 1.86, 6: 1.81 / 1.91-1.93, 8 (rounds 1-4): 1.61 / 1.69-1.71,
         // 12: 1.62 / 1.70-1.72, 24: 1.55 / 1.63 (profiles/r04k_probe_and_rare_kernel.txt) -- the kernel is bound by the rate at which HBM
         // takes its scattered sectors, and more waves in flight do not raise it
-        const int parts = (int)std::max(1ll, std::min(64ll, gbn::switch_value("GBN_RARE_PARTS", 4)));
+        const int parts = (int)std::max(1ll, std::min(64ll, gbn::switch_value("GBN_RARE_PARTS", b.rare_parts > 0 ? b.rare_parts : 4)));
         if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * parts), dim3(256), 0, st, b, grid2);
         e = hipGetLastError();
     }
