@@ -350,12 +350,15 @@ def main():
         del primed[:]
         cr.sort(key=lambda r: r[0])
         el, dgc = cr[1]
+        rcs = api.record_cache_stats()
         nl = max(1, sum(d.scan_launches for d in dgc))
         cached_pass = {"ms_per_step": el / args.steps * 1e3, "ms_per_step_minmax": [cr[0][0] / args.steps * 1e3, cr[-1][0] / args.steps * 1e3], "steps": args.steps, "regions": 3,
                        "value": total_bases_global * args.steps / el / 1e9, "unit": "Gbp/s",
                        "scan_kernels_ms": [sum(d.bin_kernel_ms for d in dgc) / nl, sum(d.probe_kernel_ms for d in dgc) / nl, sum(d.rare_kernel_ms for d in dgc) / nl],
                        # the same algorithmic bytes (0.25 B per subject base and pass) over the kernels a cached pass runs
-                       "roofline": {"bound": "hbm", "kernel": "probe_bin_kernel", "peak": 8000.0, "unit": "GB/s",
+                       "records": {"form": "sorted by cell (runs)" if rcs.get("sorted_sets") else "streams", "resident_bytes": rcs["bytes"], "sorted_bytes": rcs.get("sorted_bytes"),
+                                   "sort_gpu_ms": rcs.get("last_sort_us", 0) / 1e3, "sorts": rcs.get("sorts"), "passes_over_sorted_records": rcs.get("sorted_passes")},
+                       "roofline": {"bound": "hbm", "kernel": "probe_runs_kernel" if rcs.get("sorted_sets") else "probe_bin_kernel", "peak": 8000.0, "unit": "GB/s",
                                     "achieved": 0.25 * sum(d.subject_bases_scanned for d in dgc) / max(sum(d.probe_kernel_ms for d in dgc), 1e-9) / 1e6,
                                     "frac": 0.25 * sum(d.subject_bases_scanned for d in dgc) / max(sum(d.probe_kernel_ms for d in dgc), 1e-9) / 1e6 / 8000.0,
                                     "scan_stage_frac": 0.25 * sum(d.subject_bases_scanned for d in dgc) / max(sum(d.scan_kernel_ms for d in dgc), 1e-9) / 1e6 / 8000.0,

@@ -280,9 +280,10 @@ def record_cache_invalidate():
 
 
 def record_cache_stats():
-    v = (C.c_longlong * 9)()
-    _check(lib().gbn_record_cache_stats(v, 9))
-    return dict(zip(("limit", "bytes", "sets", "hits", "misses", "evictions", "bypassed", "ahead_hits", "prepared"), [int(x) for x in v]))
+    v = (C.c_longlong * 14)()
+    _check(lib().gbn_record_cache_stats(v, 14))
+    return dict(zip(("limit", "bytes", "sets", "hits", "misses", "evictions", "bypassed", "ahead_hits", "prepared",
+                     "sorted_sets", "sorted_bytes", "sorts", "sorted_passes", "last_sort_us"), [int(x) for x in v]))
 
 
 def block_view(blocks):

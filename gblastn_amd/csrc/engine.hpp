@@ -28,6 +28,11 @@ namespace gbn {
 hipError_t launch_scan_seed(const GbnScanParams &p, int grid, hipStream_t st);
 hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev);
 hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts, hipEvent_t tables_ready);
+// scan_runs.hip: the sorted form of a record set
+int runs_choose_sbits(int64_t npos, int nb, int cbits);
+int runs_choose_wgroup(int64_t npos, int nb, int nwriters);
+hipError_t launch_runs_build(const GbnRunsBuild &R, void *scan_tmp, size_t scan_tmp_bytes, hipStream_t st);
+hipError_t launch_probe_runs(const GbnBinParams &b, int grid, hipStream_t st, hipEvent_t *ev, hipEvent_t tables_ready);
 hipError_t launch_seed_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_group_keys(const GbnKeyParams &k, hipStream_t st);
 hipError_t launch_seed_ckeys(const GbnKeyParams &k, hipStream_t st);
@@ -153,7 +158,13 @@ struct Engine {
                        RecKey key; bool complete = false;      // the buffers hold every record of `key` (binned, no stream overflowed)
                        bool queued = false;                    // the binning kernel that writes them is queued on the engine's stream, its overflow flag not read yet (gbn_db_prepare_records)
                        unsigned long long stamp = 0;           // last use (record cache: least recently used goes first)
-                       size_t bytes() const { return bin_rec_cap * 8 + bin_tcur_cap * 4 + bin_count_cap * 4; } };
+                       // the sorted form (scan_runs.hip): the records of a cell consecutive, a record = 16 subject bits +
+                       // its position id.  Built from the complete streams once the set has served `runs_after` passes; the streams
+                       // (bin_rec, bin_tcur) go back to the pool then, and `complete` with them.
+                       uint16_t *run_fp = nullptr; uint32_t *run_pos = nullptr; uint32_t *run_start = nullptr; size_t run_n = 0, run_cells = 0;
+                       bool runs = false, runs_failed = false; int hits = 0;
+                       size_t run_bytes() const { return run_fp ? run_n * 6 + 16 + (run_cells + 1) * 4 : 0; }
+                       size_t bytes() const { return bin_rec_cap * 8 + bin_tcur_cap * 4 + bin_count_cap * 4 + run_bytes(); } };
     // Record cache (the default): bin once, probe many.  Complete record sets stay resident, least recently
     // used first out, up to rec_limit bytes (gbn_record_cache_set_limit / GBN_RECORD_CACHE_MB; default a quarter of the
     // device's memory): a pass whose key is cached queues probe + rare kernel only -- every later query batch of a stream
@@ -161,7 +172,8 @@ struct Engine {
     // the device for the life of the process the same way (the per-OID subject cache, GB/gpu_blastn_MB_and_smallNa.cu:1461-1468).
     // rec_limit == 0: off -- every pass bins for itself into `scratch` (bench.py's headline: the north_star scan).
     std::vector<RecordSet *> rec_sets; long long rec_limit = -1; unsigned long long rec_clock = 0;
-    long long rec_hits = 0, rec_misses = 0, rec_evictions = 0, rec_bypass = 0, rec_prepared = 0;
+    long long rec_hits = 0, rec_misses = 0, rec_evictions = 0, rec_bypass = 0, rec_prepared = 0, rec_runs_built = 0, rec_runs_passes = 0;
+    double rec_runs_build_ms = 0;       // GPU time of the last build of a sorted set
     RecordSet scratch, alt;             // cache off, or a set larger than the cache: the pass's own records; alt: binned ahead
     void swap_scan_sets() { std::swap(scratch, alt); }
     // Binning ahead (cache off; pipelined passes over one range of one shard, GBN_BIN_AHEAD=0: off): the binning kernel reads the
@@ -255,6 +267,7 @@ void fill_scan_params(GbnScanParams &P, const GbnBatch &b, const GbnDb &db, cons
 int choose_bins(const GbnBatch &b);
 int scan_slices(const GbnBatch &b);
 void recset_free(RecordSet &r);
+void recset_free_runs(RecordSet &r);
 int recset_size(RecordSet &r, size_t need_u64, size_t need_tcur, size_t need_count);
 long long rec_limit_bytes();
 size_t rec_held_bytes();

@@ -127,7 +127,7 @@ int gbn_record_cache_invalidate(void) {
     const int rc = enter_current();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(E.mu);
-    for (RecordSet *r : E.rec_sets) { if (r->queued) (void)hipStreamSynchronize(E.stream); r->complete = false; r->queued = false; }
+    for (RecordSet *r : E.rec_sets) { if (r->queued) (void)hipStreamSynchronize(E.stream); r->complete = false; r->queued = false; recset_free_runs(*r); }
     E.scratch.complete = false;
     if (E.ahead.valid) { (void)hipStreamSynchronize(E.stream); E.ahead.valid = false; }
     E.last_key_valid = false;
@@ -140,8 +140,11 @@ int gbn_record_cache_stats(long long *out, int n) {
     const int rc = enter_current();
     if (rc) return rc;
     std::lock_guard<std::mutex> lk(E.mu);
-    const long long v[9] = {rec_limit_bytes(), (long long)rec_held_bytes(), (long long)E.rec_sets.size(), E.rec_hits, E.rec_misses, E.rec_evictions, E.rec_bypass, E.ahead_hits, E.rec_prepared};
-    for (int i = 0; i < n && i < 9; i++) out[i] = v[i];
+    long long sorted = 0, sorted_bytes = 0;
+    for (const RecordSet *r : E.rec_sets) if (r->runs) { sorted++; sorted_bytes += (long long)r->run_bytes(); }
+    const long long v[14] = {rec_limit_bytes(), (long long)rec_held_bytes(), (long long)E.rec_sets.size(), E.rec_hits, E.rec_misses, E.rec_evictions, E.rec_bypass, E.ahead_hits, E.rec_prepared,
+                             sorted, sorted_bytes, E.rec_runs_built, E.rec_runs_passes, (long long)(E.rec_runs_build_ms * 1000.0)};
+    for (int i = 0; i < n && i < 14; i++) out[i] = v[i];
     return GBN_OK;
     });
 }

@@ -40,9 +40,14 @@ int scan_slices(const GbnBatch &b) {
 }
 
 // ---- record cache (Engine::rec_sets) ----
+void recset_free_runs(RecordSet &r) {
+    dev_free(r.run_fp); dev_free(r.run_pos); dev_free(r.run_start);
+    r.run_n = r.run_cells = 0; r.runs = false; r.runs_failed = false; r.hits = 0;
+}
 void recset_free(RecordSet &r) {
     dev_free(r.bin_rec); dev_free(r.bin_tcur); dev_free(r.bin_count);
     r.bin_rec_cap = r.bin_tcur_cap = r.bin_count_cap = 0; r.complete = false; r.queued = false;
+    recset_free_runs(r);
 }
 // the buffers of `r` at least this long (freed and allocated anew when one is too short: whatever they held is gone)
 int recset_size(RecordSet &r, size_t need_u64, size_t need_tcur, size_t need_count) {
@@ -74,6 +79,7 @@ void recset_move(RecordSet &dst, RecordSet &src) {
     dst.bin_rec = src.bin_rec; dst.bin_rec_cap = src.bin_rec_cap; dst.bin_tcur = src.bin_tcur; dst.bin_tcur_cap = src.bin_tcur_cap;
     dst.bin_count = src.bin_count; dst.bin_count_cap = src.bin_count_cap; dst.complete = false; dst.queued = false; src.queued = false;
     src.bin_rec = nullptr; src.bin_tcur = nullptr; src.bin_count = nullptr; src.bin_rec_cap = src.bin_tcur_cap = src.bin_count_cap = 0; src.complete = false;
+    recset_free_runs(src);                      // (a sorted set's arrays are not handed on: the newcomer's are sized by ITS records)
 }
 // Sets go until `need` more bytes fit under `limit` (keep: the set the pass is using).  Which: a pass over (shard, range) of
 // a table shape is one step of a SWEEP -- every query batch visits the ranges / block views of its database in the same
@@ -138,7 +144,7 @@ int bin_layout(int nb, int64_t ntiles, int64_t npos, double slack, BinLayout &L)
 }
 // the cached set that serves `key`: complete (or being written on the engine's stream), streams at least as long
 RecordSet *rec_find(const RecKey &key) {
-    for (RecordSet *c : E.rec_sets) if ((c->complete || c->queued) && c->key.same_shape(key) && c->key.subcap >= key.subcap) return c;
+    for (RecordSet *c : E.rec_sets) if (c->key.same_shape(key) && (c->runs || ((c->complete || c->queued) && c->key.subcap >= key.subcap))) return c;
     return nullptr;
 }
 // a set to bin `key` into, its buffers sized: a cached one (room made for it) or -- larger than the whole cache -- the passes'
@@ -166,8 +172,64 @@ int rec_acquire(const RecKey &key, const BinLayout &L, long long limit, RecordSe
         rc = recset_size(*rs, L.need_u64, L.nstream * L.nseq, L.nstream + 4);
     }
     if (rc) { if (rs != &E.scratch) { for (size_t i = 0; i < E.rec_sets.size(); i++) if (E.rec_sets[i] == rs) { rec_drop(i, false); break; } } return rc; }
+    recset_free_runs(*rs);
     rs->key = key; rs->complete = false; rs->queued = false;
     *out = rs;
+    return GBN_OK;
+}
+
+// ---- the sorted form of a cached set (scan_runs.hip) ----
+// cache hits a set serves in stream form before it is sorted (GBN_RUNS_AFTER, default 1: the second hit sorts; 0: the first).
+// The build moves ~28 bytes per record (27 ms for the C2 shard) and a pass over runs saves ~2 ms: a set that serves two batches
+// (the 10,000-query config) is not worth sorting, a stream of batches is.  GBN_REC_RUNS=0: never (the stream-form path, A/B).
+static bool runs_enabled() { return gbn::switch_value("GBN_REC_RUNS", 1) != 0; }
+static int runs_after() { return (int)std::max(0ll, gbn::switch_value("GBN_RUNS_AFTER", 1)); }
+// workgroups of probe_runs_kernel (512 threads, 12 KB of LDS, 46 registers: four per CU) = queue segments of the rare kernel
+static int runs_grid() { return (int)std::min<long long>(2048, (long long)E.num_cu * std::max(1ll, std::min(8ll, gbn::switch_value("GBN_RUNS_WGS", 4)))); }
+
+// B: the streams of the complete set `rs`, npos: its records.  On success the set is in sorted form and its streams are back
+// in the pool; a build that finds no room, or whose count does not come out, leaves the set as it is (and is not tried again).
+static int build_runs(RecordSet &rs, const GbnBinParams &B, int64_t npos)
+{
+    const int64_t ncells = B.S.ncells;
+    if (npos <= 0 || npos >= ((int64_t)1 << 32) - 64 || ncells < GBN_RUNS_ITEM_CELLS || (ncells % GBN_RUNS_ITEM_CELLS) != 0) { rs.runs_failed = true; return GBN_OK; }
+    GbnRunsBuild R; std::memset(&R, 0, sizeof(R));
+    R.B = B;
+    R.sbits = runs_choose_sbits(npos, B.nb, B.cbits);
+    R.wgroup = runs_choose_wgroup(npos, B.nb, B.nwriters);
+    if ((1 << (B.cbits - R.sbits)) > GBN_RUNS_UNIT_CELLS_MAX) { rs.runs_failed = true; return GBN_OK; }
+    uint32_t *count = nullptr, *cursor = nullptr, *mid_key = nullptr, *mid_pos = nullptr, *pos = nullptr; uint16_t *fp = nullptr; uint8_t *tmp = nullptr;
+    size_t tmp_bytes = 0;
+    (void)lut_scan(nullptr, tmp_bytes, nullptr, nullptr, ncells + 1, E.stream);
+    auto give_up = [&]() {
+        dev_free(count); dev_free(cursor); dev_free(mid_key); dev_free(mid_pos); dev_free(pos); dev_free(fp); dev_free(tmp);
+        rs.runs_failed = true;
+        return GBN_OK;
+    };
+    if (dev_alloc(count, (size_t)ncells + 1) || dev_alloc(cursor, (size_t)B.nb << R.sbits) || dev_alloc(mid_key, (size_t)npos) || dev_alloc(mid_pos, (size_t)npos) ||
+        dev_alloc(pos, (size_t)npos) || dev_alloc(fp, (size_t)npos + 8) || dev_alloc(tmp, tmp_bytes)) return give_up();
+    R.count = count; R.cursor = cursor; R.mid_key = mid_key; R.mid_pos = mid_pos; R.fp = fp; R.pos = pos;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    HIPCHK(hipEventCreate(&e0)); HIPCHK(hipEventCreate(&e1));
+    HIPCHK(hipMemsetAsync(count, 0, ((size_t)ncells + 1) * 4, E.stream));
+    HIPCHK(hipMemsetAsync(fp + (size_t)npos, 0, 16, E.stream));          // (the last 16-byte chunk of the fingerprints is read whole)
+    HIPCHK(hipEventRecord(e0, E.stream));
+    HIPCHK(launch_runs_build(R, tmp, tmp_bytes, E.stream));
+    HIPCHK(hipEventRecord(e1, E.stream));
+    uint32_t total = 0;
+    HIPCHK(hipMemcpyAsync(&total, count + ncells, 4, hipMemcpyDeviceToHost, E.stream));
+    HIPCHK(hipStreamSynchronize(E.stream));
+    float ms = 0; (void)hipEventElapsedTime(&ms, e0, e1); (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if ((int64_t)total != npos) {                               // (cannot happen with complete streams; never probe runs that are not all there)
+        fprintf(stderr, "[gbn] sorted record set: %u records counted, %lld expected -- staying with the streams\n", total, (long long)npos);
+        return give_up();
+    }
+    dev_free(cursor); dev_free(mid_key); dev_free(mid_pos); dev_free(tmp);
+    rs.run_fp = fp; rs.run_pos = pos; rs.run_start = count; rs.run_n = (size_t)npos; rs.run_cells = (size_t)ncells; rs.runs = true;
+    // the streams go back to the pool (the counts stay: the passes' overflow word lives behind them)
+    dev_free(rs.bin_rec); dev_free(rs.bin_tcur); rs.bin_rec_cap = rs.bin_tcur_cap = 0; rs.complete = false;
+    E.rec_runs_built++; E.rec_runs_build_ms = ms;
+    trace_mark("scan: record set sorted");
     return GBN_OK;
 }
 
@@ -223,6 +285,8 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     RecordSet *rs = nullptr;                    // the records of this pass
     bool binned_here = false;                   // ... were written (completely) by this call
     bool repeat_seen = false;                   // cache off: the pass before this one had the same key
+    bool counted = false;                       // the cache's hit / miss of this call is counted (a range scanned again counts once)
+    bool used_runs = false;                     // the pass went over sorted records
     if (E.seed_copy_pending) { HIPCHK(hipStreamWaitEvent(E.stream, E.ev_seed, 0)); E.seed_copy_pending = false; }
     for (;;) {
         bool binned_ahead = false; int hit_pair = -1;
@@ -272,8 +336,9 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 // ---- record cache: a complete set of this shape whose streams are at least as long as this attempt asks for
                 if (AH.valid) { AH.valid = false; E.ahead_misses++; HIPCHK(hipStreamSynchronize(E.stream)); }     // (a kernel queued ahead writes the other scratch set, which may change hands below)
                 rs = rec_find(key);
-                if (rs) { hit = true; subcap = rs->key.subcap; key.subcap = subcap; if (!binned_here) E.rec_hits++; }
-                else { E.rec_misses++; if ((rc = rec_acquire(key, BL, rec_limit, &rs))) return rc; }
+                if (rs) { hit = true; subcap = rs->key.subcap; key.subcap = subcap; if (!counted) { E.rec_hits++; if (!rs->queued) rs->hits++; } }     // (a set queued by gbn_db_prepare_records: this pass is the one that would have binned)
+                else { if (!counted) E.rec_misses++; if ((rc = rec_acquire(key, BL, rec_limit, &rs))) return rc; }
+                counted = true;
             } else {
                 rs = &E.scratch;
                 ahead_hit = AH.valid && AH.key == key;
@@ -301,7 +366,16 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             B.dbg = (int)gbn::switch_value("GBN_DBG", 0);
             B.rare_parts = (hit && !binned_here) ? 5 : 0;      // (a pass over cached records: gbn_dev.h)
             B.work = gbn::switch_value("GBN_PROBE_DYN", 1) != 0 ? reinterpret_cast<uint32_t *>(E.counters + 4) : nullptr;      // (counters [4 .. 7]: zeroed with the scan's own, above)
-            int grid2 = std::max(8, E.num_cu & ~7);   // one 1024-thread workgroup per CU; group = blockIdx & 7
+            // a cached set in stream form that has served its passes is sorted now, in front of this pass
+            if (rec_limit > 0 && hit && rs->complete && !rs->queued && !rs->runs && !rs->runs_failed && runs_enabled() && rs->hits > runs_after() &&
+                (rc = build_runs(*rs, B, npos))) return rc;
+            used_runs = rec_limit > 0 && hit && rs->runs;
+            if (used_runs) {
+                B.run_fp = rs->run_fp; B.run_pos = rs->run_pos; B.run_start = rs->run_start; B.rec = nullptr; B.tcur = nullptr;
+                B.work = reinterpret_cast<uint32_t *>(E.counters + 4); B.rare_parts = (int)std::max(1ll, gbn::switch_value("GBN_RUNS_RARE_PARTS", 1));
+                E.rec_runs_passes++;
+            }
+            int grid2 = used_runs ? runs_grid() : std::max(8, E.num_cu & ~7);   // stream form: one 1024-thread workgroup per CU; group = blockIdx & 7
             {   // rare-path queue: one segment per probe workgroup (~1.2 % of scan positions in total)
                 size_t seg = std::max<size_t>(rare_seg_hint, (size_t)(npos / 40 / grid2) + 4096);
                 size_t want = seg * (size_t)grid2;
@@ -320,7 +394,8 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 B.rareq = E.rareq; B.rare_seg = (uint32_t)std::min<size_t>(seg, 0x7fffffff); B.rare_counts = E.rare_counts;
             }
             last_B = B; last_grid2 = grid2;
-            HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, ((hit || ahead_hit) ? 2 : 3) | 4 | (ahead_hit ? 8 : 0), b.dev->ready));
+            if (used_runs) HIPCHK(launch_probe_runs(B, grid2, E.stream, E.evk, b.dev->ready));
+            else HIPCHK(launch_scan_bin_parts(B, grid2, E.stream, E.evk, ((hit || ahead_hit) ? 2 : 3) | 4 | (ahead_hit ? 8 : 0), b.dev->ready));
             binned = true; binned_ahead = ahead_hit;
             HIPCHK(hipMemcpyAsync(&E.scan_back->overflow, B.overflow, 4, hipMemcpyDeviceToHost, E.stream));
             HIPCHK(hipMemcpyAsync(E.scan_back->rare_counts, E.rare_counts, (size_t)grid2 * 4, hipMemcpyDeviceToHost, E.stream));
@@ -354,7 +429,8 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         trace_mark("scan: kernels done");
         cnt[0] = E.scan_back->cnt[0]; cnt[1] = E.scan_back->cnt[1];
         const unsigned long long seg_max = sliced ? E.scan_back->seg_max : 0;
-        if (binned) { overflow = E.scan_back->overflow; rs->complete = overflow == 0; rs->queued = false; binned_here = rs->complete; }
+        if (binned && used_runs) overflow = 0;
+        else if (binned) { overflow = E.scan_back->overflow; rs->complete = overflow == 0; rs->queued = false; binned_here = rs->complete; }
         finish_build(b.dev);                                // (the scan has waited for the builder's event)
         if (diag) {
             float ms = 0, ahead_ms = 0;
@@ -372,7 +448,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             }
         }
         if (nb > 1) {
-            const int grid2 = std::max(8, E.num_cu & ~7);
+            const int grid2 = last_grid2;
             unsigned long long sc = 0; uint32_t mx = 0;
             for (int i = 0; i < grid2; i++) { const uint32_t v = E.scan_back->rare_counts[i]; sc += v; mx = std::max(mx, v); }
             if (gbn::switch_is_set("GBN_DBG")) fprintf(stderr, "[gbn dbg] rare-path items %llu, seeds %llu, raw %llu\n", sc, cnt[0], cnt[1]);

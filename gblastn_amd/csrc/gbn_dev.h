@@ -94,6 +94,30 @@ struct GbnBinParams {
     // kernel per CU (143 of its 160 KB of LDS, all 1,280 resident at once) leave those kernels less room than four do -- 1.22
     // instead of 1.47 ms, 4.59 instead of 4.82 ms per pass; alone, and behind a binning kernel, four are the faster (0.97 / 1.03).
     int rare_parts;
+    // ---- the SORTED form of a record set ("runs", scan_runs.hip): the records of a cell are consecutive,
+    // run_start[cell] .. run_start[cell + 1], a record = its 16 subject bits around the lookup word (run_fp: [7:0] the 4 bases in
+    // front, [14:8] the 7 bits behind, [15] the eighth) and its position id (run_pos: tile << GBN_BIN_TILE_BITS | index).  The
+    // cell is the run: a pass reads the runs of the cells its batch occupies and nothing else.  Null: stream form (rec / tcur).
+    const uint16_t *run_fp; const uint32_t *run_pos; const uint32_t *run_start;
+};
+
+// ---- building the runs from the streams of a complete record set (scan_runs.hip): count per cell -> run_start (prefix sums) ->
+// split (every bin's records into 2^sbits sub-bins of consecutive cells: blocks sorted in LDS, pieces appended at the sub-bin's
+// cursor) -> place (a sub-bin at a time through LDS into its cells' runs)
+#define GBN_RUNS_SPLIT_CAP 16384        // records a split workgroup sorts per round (LDS: 8 bytes each)
+#define GBN_RUNS_PLACE_CAP 24576        // records a place workgroup stages per round (LDS: 6 bytes each)
+#define GBN_RUNS_UNIT_CELLS_MAX 2048    // most cells of a sub-bin (their cursors sit in LDS next to the staged records)
+#define GBN_RUNS_SBITS_MAX 8
+#define GBN_RUNS_CURCAP 4096            // stream cursors a split workgroup keeps in LDS (more: read from global memory)
+#define GBN_RUNS_ITEM_CELLS 256         // cells a wave of the probe kernel draws at a time
+struct GbnRunsBuild {
+    GbnBinParams B;                     // the streams (rec, tcur, gcount, subcap, nb, cbits, nwriters, nseq; S.ntiles)
+    int sbits;                          // sub-bins per bin = 2^sbits
+    int wgroup;                         // consecutive writers whose streams one split workgroup works through
+    uint32_t *count;                    // [ncells + 1]: records per cell, then (in place) run_start
+    uint32_t *cursor;                   // [nb << sbits]: next free slot of every sub-bin
+    uint32_t *mid_key, *mid_pos;        // records by sub-bin: hi word, position id
+    uint16_t *fp; uint32_t *pos;        // the runs
 };
 
 struct GbnKeyParams {

@@ -32,20 +32,6 @@
 // leave LDS, through per-workgroup queues, for phase 3 (exact verification).
 // ===========================================================================
 
-namespace {
-// inclusive prefix sum over the 64 lanes of a fully active wave: DPP row shifts and row broadcasts
-__device__ __forceinline__ uint32_t wave_scan_incl(uint32_t v)
-{
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false);     // row_shr:1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xf, 0xf, false);     // row_shr:2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xf, 0xe, false);     // row_shr:4, lanes 4.. of a row
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xf, 0xc, false);     // row_shr:8, lanes 8.. of a row
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
-    return v;
-}
-}  // namespace
-
 // The binning kernel in use: the four-barrier form of rounds 2 and 3 with the record layout and the key extraction of
 // round 4 (see scan_bin3_body below for the layout).  Round 4 wrote two other forms of it -- the steps of two tiles in
 // flight between two barriers, and scan_bin3_body (no owner threads, descriptors or staging area at all) -- and measured
@@ -1184,7 +1170,8 @@ probe_rare_kernel(GbnBinParams B, int nseg)
         const uint4 item = *reinterpret_cast<const uint4 *>(qs + i);
         uint32_t pid = item.x; const uint32_t cv = item.y;
         uint32_t idx = item.z, cw = item.w;
-        {   // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
+        if (B.run_pos == nullptr) {   // (sorted records carry their position id: scan_runs.hip)
+            // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
             const uint32_t bin = (cv & 0x7fffffffu) >> B.cbits;
             const uint32_t wr = pid / B.subcap, j = pid - wr * B.subcap;
             const uint32_t *__restrict__ cur = B.tcur + ((size_t)bin * B.nwriters + wr) * B.nseq;
@@ -1242,6 +1229,7 @@ probe_rare_kernel(GbnBinParams B, int nseg)
 }
 
 namespace gbn {
+hipError_t launch_probe_rare(const GbnBinParams &b, int nseg, hipStream_t st);
 // parts: 1 = binning kernel, 2 = probe kernel, 4 = rare kernel (7 = all; 6 = a pass over records that exist: the record cache,
 // a kernel queued ahead -- engine_scan.cpp; 1 = binning alone: bin-ahead, gbn_db_prepare_records)
 hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev, int parts, hipEvent_t tables_ready)
@@ -1278,16 +1266,23 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
         if (e != hipSuccess) return e;
     }
     if (ev) (void)hipEventRecord(ev[2], st);
-    if (parts & 4) {
+    if (parts & 4) e = launch_probe_rare(b, grid2, st);
+    if (ev) (void)hipEventRecord(ev[3], st);
+    return e;
+}
+// the rare kernel over the queue segments of `nseg` probe workgroups
+hipError_t launch_probe_rare(const GbnBinParams &b, int nseg, hipStream_t st)
+{
+    hipError_t e = hipSuccess;
+    {
         // parts per segment (workgroups per queue segment).  Same box, C2, kernel alone / in the pipeline: 2 parts 1.95 / 2.09 ms,
         // 3: 1.60 / 1.72, 4: 1.49-1.52 / 1.61-1.69, 5: 1.47 / 1.86, 6: 1.81 / 1.91-1.93, 8 (rounds 1-4): 1.61 / 1.69-1.71,
         // 12: 1.62 / 1.70-1.72, 24: 1.55 / 1.63 (profiles/r04k_probe_and_rare_kernel.txt) -- the kernel is bound by the rate at which HBM
         // takes its scattered sectors, and more waves in flight do not raise it
         const int parts = (int)std::max(1ll, std::min(64ll, gbn::switch_value("GBN_RARE_PARTS", b.rare_parts > 0 ? b.rare_parts : 4)));
-        if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(grid2 * parts), dim3(256), 0, st, b, grid2);
+        if (!(b.dbg & 1)) hipLaunchKernelGGL(probe_rare_kernel, dim3(nseg * parts), dim3(256), 0, st, b, nseg);
         e = hipGetLastError();
     }
-    if (ev) (void)hipEventRecord(ev[3], st);
     return e;
 }
 hipError_t launch_scan_bin(const GbnBinParams &b, int grid2, hipStream_t st, hipEvent_t *ev)

@@ -184,7 +184,12 @@ long long gbn_debug_bin_ahead_misses(void);     /* ... and binning kernels queue
  * limit: bytes the cache may hold; 0: off (every pass bins for itself); < 0: the default -- GBN_RECORD_CACHE_MB, else a
  * quarter of the device's memory.  stats: out[0..n) of {limit, bytes held, sets, passes served from the cache, passes
  * that binned, sets evicted, passes whose set is larger than the whole cache, passes served by a kernel queued ahead,
- * sets queued by gbn_db_prepare_records}. */
+ * sets queued by gbn_db_prepare_records, sets in sorted form, their bytes, sorts done, passes over sorted records, GPU
+ * microseconds of the last sort}.
+ * A cached set that keeps being hit is SORTED BY CELL once (csrc/scan_runs.hip): a record shrinks to 16 subject bits + its
+ * position id, the streams go back to the pool, and later passes read the runs of the cells their batch occupies and
+ * nothing else -- the presence test in front of the table access (MB_ACCESS_HITS, CORE/blast_nascan.c:1413-1461) as a
+ * decision about which bytes are fetched.  GBN_REC_RUNS=0: never; GBN_RUNS_AFTER=n: hits in stream form before the sort. */
 int  gbn_record_cache_set_limit(long long bytes);
 int  gbn_record_cache_stats(long long *out, int n);
 int  gbn_record_cache_invalidate(void);     /* every cached set forgets its records (its buffers stay): the next pass of each key bins again */
