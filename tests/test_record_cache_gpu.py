@@ -78,7 +78,9 @@ def test_default_policy_bins_once_and_probes_many(cache_default):
     assert ps.run()["hsps"].tobytes() == want["a"]
     ps.close()
     b1 = api.record_cache_stats()
-    assert (b1["misses"] - b0["misses"], b1["hits"] - b0["hits"], b1["sets"], b1["bytes"]) == (1, 1, b0["sets"], b0["bytes"])
+    # (a set that had been SORTED gave its streams back to the pool when it was: its stream buffers come out of the pool again;
+    # a set still in stream form bins into the buffers it kept)
+    assert (b1["misses"] - b0["misses"], b1["hits"] - b0["hits"], b1["sets"]) == (1, 1, b0["sets"]) and b1["bytes"] >= b0["bytes"]
     # the shard goes: its records go with it
     src.close()
     assert api.record_cache_stats()["sets"] == 0
