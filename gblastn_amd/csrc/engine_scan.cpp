@@ -184,7 +184,7 @@ int rec_acquire(const RecKey &key, const BinLayout &L, long long limit, RecordSe
 // (the 10,000-query config) is not worth sorting, a stream of batches is.  GBN_REC_RUNS=0: never (the stream-form path, A/B).
 static bool runs_enabled() { return gbn::switch_value("GBN_REC_RUNS", 1) != 0; }
 static int runs_after() { return (int)std::max(0ll, gbn::switch_value("GBN_RUNS_AFTER", 1)); }
-// workgroups of probe_runs_kernel (512 threads, 12 KB of LDS, 46 registers: four per CU) = queue segments of the rare kernel
+// workgroups of probe_runs_kernel (512 threads, 12 KB of LDS, 20 KB of LDS, 58 registers: four per CU) = queue segments of the rare kernel
 static int runs_grid() { return (int)std::min<long long>(2048, (long long)E.num_cu * std::max(1ll, std::min(8ll, gbn::switch_value("GBN_RUNS_WGS", 4)))); }
 
 // B: the streams of the complete set `rs`, npos: its records.  On success the set is in sorted form and its streams are back
@@ -193,6 +193,10 @@ static int build_runs(RecordSet &rs, const GbnBinParams &B, int64_t npos)
 {
     const int64_t ncells = B.S.ncells;
     if (npos <= 0 || npos >= ((int64_t)1 << 32) - 64 || ncells < GBN_RUNS_ITEM_CELLS || (ncells % GBN_RUNS_ITEM_CELLS) != 0) { rs.runs_failed = true; return GBN_OK; }
+    // Worth it only when the runs are long: a pass over runs reads 8 bytes of table per CELL whatever the shard holds and the
+    // sorted set carries 4 bytes per cell, so a small shard's set would grow and its passes slow down (a 20 Mb shard at lut 11:
+    // 3 MB of streams against 17 MB of run starts).  GBN_REC_RUNS=2: sort regardless (tests).
+    if (gbn::switch_value("GBN_REC_RUNS", 1) != 2 && (npos < 8 * ncells || (size_t)npos * 6 + ((size_t)ncells + 1) * 4 >= rs.bytes())) { rs.runs_failed = true; return GBN_OK; }
     GbnRunsBuild R; std::memset(&R, 0, sizeof(R));
     R.B = B;
     R.sbits = runs_choose_sbits(npos, B.nb, B.cbits);

@@ -15,6 +15,9 @@
 #ifndef GBN_BIN_DUP
 #define GBN_BIN_DUP 0
 #endif
+#ifndef GBN_BIN_PRESENCE
+#define GBN_BIN_PRESENCE 0      // experiment (round 6): 1 = presence-filtered binning, 2 = the presence lookups alone (see scan_bin_line_body)
+#endif
 
 // ===========================================================================
 // Key-range partitioned scan (lookup tables too large for L2).
@@ -191,9 +194,26 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     GbnTile T = uniform(P.tiles[tile]);
     GbnTile T1 = uniform(P.tiles[min(stride + (int64_t)rot_next(rot), last)]);
     uint32_t bin[PER], hi[PER];
+#if GBN_BIN_PRESENCE
+    // Experiment of round 6 (profiles/r06_presence_binning.txt): the batch's presence bits (one per cell, 2 MB for lut 12) are
+    // looked up for every scan position and only positions whose cell is occupied become records -- 55 % fewer records written
+    // here and read by the probe kernel for a 5 Mb batch, at the price of one scattered 4-byte load per position.  The records
+    // depend on the batch then: passes that bin for themselves only (record cache off, nothing binned ahead).
+    uint32_t pw[PER];
+    auto presence_ask = [&]() {
+        #pragma unroll
+        for (int k = 0; k < PER; k++) {
+            const uint32_t cell = (bin[k] << cbits) | (hi[k] & lowmask & 0x7fffu);
+            pw[k] = P.pv ? P.pv[cell >> 5] >> (cell & 31u) : 1u;      // (no batch yet -- gbn_db_prepare_records: every position)
+        }
+    };
+#endif
     {
         Raw r0; fetch(T, r0);
         keys_all(T, r0, bin, hi);
+#if GBN_BIN_PRESENCE
+        presence_ask();
+#endif
     }
     int32_t stay[PER];                                          // slot of a record that waits for its open line to be stored, else -1
     uint32_t keep_hi[PER];
@@ -223,6 +243,13 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         uint32_t rank[PER]; bool valid[PER];
         #pragma unroll
         for (int k = 0; k < PER; k++) valid[k] = idx_of(k) < (uint32_t)T.npos;
+#if GBN_BIN_PRESENCE == 1
+        #pragma unroll
+        for (int k = 0; k < PER; k++) valid[k] = valid[k] && (pw[k] & 1u);
+#elif GBN_BIN_PRESENCE == 2       // the lookups alone: every position still becomes a record
+        #pragma unroll
+        for (int k = 0; k < PER; k++) valid[k] = valid[k] && ((pw[k] | 1u) & 1u) && (pw[k] != 0x9e3779b9u || tid != 1023);
+#endif
         #pragma unroll
         for (int k = 0; k < PER; k++) {     // (positions past the end of a partial tile all carry the same key: they must not touch the histogram)
             rank[k] = 0;
@@ -329,6 +356,9 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
         T = T1; T1 = uniform(T2);
         if constexpr (STEP == 0) fetch(T, R);
         keys_all(T, R, bin, hi);
+#if GBN_BIN_PRESENCE
+        presence_ask();
+#endif
         // Stores of the complete lines, a quarter line per thread and step.  The first 1024 quarter lines leave
         // here; the next 1024 wait until [0] of the next tile (behind its loads, next to its atomics: spreading
         // the stores over the tile keeps the store queue from stalling every wave at once); the rare rest here.
@@ -1240,6 +1270,9 @@ hipError_t launch_scan_bin_parts(const GbnBinParams &b, int grid2, hipStream_t s
     hipError_t e = hipSuccess;
     if (ev && !(parts & 8)) (void)hipEventRecord(ev[0], st);
     if (parts & 1) {
+#if GBN_BIN_PRESENCE
+        if (tables_ready) { e = hipStreamWaitEvent(st, tables_ready, 0); if (e != hipSuccess) return e; }     // (the experiment's binning kernel reads the batch's presence bits)
+#endif
         // stride-specialised variants: megablast (word 28 with lut 12 / 11 / 8) and blastn (word 11 with lut 11 / 10 / 8)
         const bool generic = (b.dbg & 64) != 0;
         const int step = b.S.step, lut = b.S.lut;

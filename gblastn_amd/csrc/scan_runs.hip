@@ -261,12 +261,15 @@ runs_place_kernel(GbnRunsBuild R)
 // Lookup hits are run lengths x entries per cell: no record is read for them.
 #define GBN_RUNS_THREADS 512
 #define GBN_RUNS_QCAP 128
+#define GBN_RUNS_SIDE_W 256         // side-list fingerprints a wave stages per stretch of 64 cells
+#define GBN_RUNS_SIDE_MAXN 16       // ... of cells with at most this many entries
 extern "C" __global__ void __launch_bounds__(GBN_RUNS_THREADS)
 probe_runs_kernel(GbnBinParams B)
 {
     const GbnScanParams &P = B.S;
     constexpr int NW = GBN_RUNS_THREADS / 64;
     __shared__ uint32_t s_qrec[NW][GBN_RUNS_QCAP], s_qcell[NW][GBN_RUNS_QCAP], s_qfp[NW][GBN_RUNS_QCAP];
+    __shared__ uint32_t s_side[NW][GBN_RUNS_SIDE_W];               // the side lists of the stretch a wave works on
     __shared__ uint32_t s_rcount;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -283,14 +286,19 @@ probe_runs_kernel(GbnBinParams B)
     unsigned long long raw = 0;
     const unsigned long long lt = (1ull << lane) - 1;
 
+    // Queued records, 64 at a time (one per lane).  What the main loop has tested completely (cells of one and two entries, cells
+    // whose side list it had staged) only needs its position id and the cell's direct-probe word for the rare kernel; records
+    // of the other cells (three and more entries beyond the staging area, cells that are always rare) get their side list
+    // from global memory here.
     auto flush = [&](int first, int cnt) {
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        bool keep = false; uint32_t rec = 0, cv = 0, f = 0;
+        bool keep = false; uint32_t rec = 0, cv = 0;
         if (lane < cnt) {
-            rec = qrec[first + lane]; cv = qcell[first + lane]; f = qfp[first + lane];
+            rec = qrec[first + lane]; cv = qcell[first + lane];
+            const uint32_t f = qfp[first + lane];
             keep = true;
-            const uint32_t t = B.cellt[cv];
-            if ((t & 0x8000u) == 0) {                                   // three or more entries (or a cell that is always rare)
+            if ((f >> 16) == 0) {                                       // kind 0: nothing tested yet
+                const uint32_t t = B.cellt[cv];
                 const uint32_t n3 = (t >> 16) & 0x7fffu, so = t & 0x7fffu, sf = f & 0x7fffu;
                 if (n3 == 0) cv |= 0x80000000u;                         // its lookup hits are counted by the rare kernel
                 else {
@@ -303,15 +311,6 @@ probe_runs_kernel(GbnBinParams B)
                 }
             }
         }
-        uint32_t cw = 0;
-        if (keep) {
-            cw = P.cellw[cv & 0x7fffffffu];
-            if (fp16 && !(cv >> 31) && !(cw >> 31) && !(cw & 1u)) {     // one entry, not forced: the sixteenth bit (probe_bin_kernel)
-                const uint32_t sl8 = f & 0xffu, sr8 = (((f >> 8) & 0x7fu) << 1) | ((f >> 15) & 1u);
-                const uint32_t el8 = (cw >> 15) & 0xffu, er8 = (cw >> 7) & 0xffu;
-                keep = sl8 == el8 || sr8 == er8;
-            }
-        }
         const unsigned long long m = __ballot(keep);
         if (m) {
             uint32_t base = 0;
@@ -320,7 +319,7 @@ probe_runs_kernel(GbnBinParams B)
             if (keep) {
                 const uint32_t at = base + (uint32_t)__popcll(m & lt);
                 if (at < B.rare_seg) {
-                    uint4 it; it.x = B.run_pos[rec]; it.y = cv; it.z = 0; it.w = cw;
+                    uint4 it; it.x = B.run_pos[rec]; it.y = cv; it.z = 0; it.w = P.cellw[cv & 0x7fffffffu];
                     *reinterpret_cast<uint4 *>(myq + at) = it;
                 }
             }
@@ -329,71 +328,124 @@ probe_runs_kernel(GbnBinParams B)
 
     const uint32_t nitems = (uint32_t)(P.ncells / GBN_RUNS_ITEM_CELLS);
     const uint4 *fp4 = reinterpret_cast<const uint4 *>(B.run_fp);
+    const uint32_t m16 = m4 | (fp16 ? 0x80008000u : 0u);               // cells of one entry: the sixteenth bit joins the test (probe_bin_kernel tests it per queued record)
+    uint32_t *side_w = s_side[wave];
     uint32_t item;
     { uint32_t v = 0; if (lane == 0) v = atomicAdd(&B.work[0], 1u); item = (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
     while (item < nitems) {
         uint32_t nitem = 0;
         if (lane == 0) nitem = atomicAdd(&B.work[0], 1u);               // (asked for now, read when this item is done)
         const uint32_t cbase = item * (uint32_t)GBN_RUNS_ITEM_CELLS;
+        const uint16_t *side_bin = B.sidet + B.side_start[cbase >> cbits];      // (an item lies in one bin)
         // table words and run boundaries of the first stretch
         uint32_t t_n = B.cellt[cbase + lane], rs_n = B.run_start[cbase + lane], re_n = B.run_start[cbase + lane + 1];
+        uint32_t cw_n = fp16 ? P.cellw[cbase + lane] : 0u;
         for (uint32_t cs = cbase; cs < cbase + (uint32_t)GBN_RUNS_ITEM_CELLS; cs += 64) {
-            const uint32_t t = t_n, rs = rs_n, re = re_n;
+            const uint32_t t = t_n, rs = rs_n, re = re_n, cw = cw_n;
             if (cs + 64 < cbase + (uint32_t)GBN_RUNS_ITEM_CELLS) {      // the next stretch's, a stretch ahead
                 t_n = B.cellt[cs + 64 + lane]; rs_n = B.run_start[cs + 64 + lane]; re_n = B.run_start[cs + 65 + lane];
+                cw_n = fp16 ? P.cellw[cs + 64 + lane] : 0u;
             }
             const bool occ = t != 0 && re > rs;
-            // lookup hits: run length x entries of the cell
+            // What a record of the cell is tested against (fw) and how (kind): 1 = two reduced fingerprints of 15 bits, 2 = the one
+            // entry's sixteen bits (from the direct-probe word), 3 = the n3 fingerprints of a cell of three and more entries, staged
+            // in the wave's LDS below (fw = first slot | n3 << 16), 0 = not here: every record takes the queue.
+            uint32_t kind = 0, fw = 0, nstage = 0, so = 0;
             if (occ) {
                 const uint32_t len = re - rs;
-                if (t & 0x8000u) raw += (unsigned long long)len * (1u + (t >> 31));
-                else raw += (unsigned long long)len * ((t >> 16) & 0x7fffu);      // (0: an always-rare cell, counted by the rare kernel)
+                // lookup hits: run length x entries of the cell (a cell whose side list is not there -- n3 = 0 -- is counted by
+                // the rare kernel, which sees every record of it)
+                if (t & 0x8000u) {
+                    raw += (unsigned long long)len * (1u + (t >> 31));
+                    kind = 1; fw = t & 0x7fff7fffu;
+                    if (fp16 && !(t >> 31) && !(cw >> 31) && !(cw & 1u)) {
+                        const uint32_t el8 = (cw >> 15) & 0xffu, er8 = (cw >> 7) & 0xffu;
+                        kind = 2; fw = (el8 | ((er8 >> 1) << 8) | ((er8 & 1u) << 15)) * 0x10001u;
+                    }
+                } else {
+                    const uint32_t n3 = (t >> 16) & 0x7fffu;
+                    raw += (unsigned long long)len * n3;
+                    if (n3 >= 1 && n3 <= (uint32_t)GBN_RUNS_SIDE_MAXN) { nstage = n3; so = t & 0x7fffu; }
+                }
+            }
+            // the side lists of this stretch's cells into the wave's LDS (a cell of three and more entries has 3.3 on average,
+            // a stretch 1.5 such cells)
+            if (__ballot(nstage != 0)) {
+                const uint32_t sidx = wave_scan_incl(nstage) - nstage;
+                if (nstage && sidx + nstage <= (uint32_t)GBN_RUNS_SIDE_W) {
+                    kind = 3; fw = sidx | (nstage << 16);
+                    for (uint32_t e0 = 0; e0 < nstage; e0 += 4) {
+                        uint32_t v[4];
+                        #pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) v[i] = side_bin[so + min(e0 + i, nstage - 1u)];
+                        #pragma unroll
+                        for (uint32_t i = 0; i < 4; i++) if (e0 + i < nstage) side_w[sidx + e0 + i] = v[i];
+                    }
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             const uint32_t k0 = rs >> 3, nch = occ ? ((re + 7u) >> 3) - k0 : 0u;
-            const uint32_t incl = wave_scan_incl(nch), excl = incl - nch;
+            const uint32_t incl = wave_scan_incl(nch), exk = (incl - nch) | (kind << 29);      // (fewer than 2^29 chunks in all: 2^32 records)
             const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
             // round g0: lane l takes chunk g0 + l of the stretch's occupied runs
-            auto fetch = [&](uint32_t g0, uint32_t &o_t, uint32_t &o_rs, uint32_t &o_re, uint32_t &o_cell, uint32_t &o_k, uint4 &d) -> bool {
+            auto fetch = [&](uint32_t g0, uint32_t &o_fw, uint32_t &o_rs, uint32_t &o_re, uint32_t &o_cell, uint32_t &o_k, uint32_t &o_kind, uint4 &d) {
                 const uint32_t g = g0 + (uint32_t)lane;
-                const bool act = g < T;
                 // owner: the first lane i with incl[i] > g
                 uint32_t l = 0;
                 #pragma unroll
-                for (int s = 32; s > 0; s >>= 1) { const uint32_t v = (uint32_t)__shfl((int)incl, (int)(l + s - 1)); if (v <= g) l += (uint32_t)s; }
+                for (int sf = 32; sf > 0; sf >>= 1) { const uint32_t v = (uint32_t)__shfl((int)incl, (int)(l + sf - 1)); if (v <= g) l += (uint32_t)sf; }
                 l = min(l, 63u);
-                o_t = (uint32_t)__shfl((int)t, (int)l); o_rs = (uint32_t)__shfl((int)rs, (int)l); o_re = (uint32_t)__shfl((int)re, (int)l);
-                const uint32_t ex = (uint32_t)__shfl((int)excl, (int)l);
+                o_fw = (uint32_t)__shfl((int)fw, (int)l); o_rs = (uint32_t)__shfl((int)rs, (int)l); o_re = (uint32_t)__shfl((int)re, (int)l);
+                const uint32_t ex = (uint32_t)__shfl((int)exk, (int)l);
+                o_kind = g < T ? (ex >> 29) | 4u : 0u;                  // bit 2: the lane has a chunk
                 o_cell = cs + l;
-                o_k = (o_rs >> 3) + (g - ex);
+                o_k = (o_rs >> 3) + (g - (ex & 0x1fffffffu));
                 d = make_uint4(0, 0, 0, 0);
-                if (act) d = fp4[o_k];
-                return act;
+                if (g < T) d = fp4[o_k];
             };
-            uint32_t ct, crs, cre, ccell, ck; uint4 cd; bool cact = false;
-            if (T) cact = fetch(0, ct, crs, cre, ccell, ck, cd);
+            uint32_t cfw = 0, crs = 0, cre = 0, ccell = 0, ck = 0, ckind = 0; uint4 cd = make_uint4(0, 0, 0, 0);
+            if (T) fetch(0, cfw, crs, cre, ccell, ck, ckind, cd);
             for (uint32_t g0 = 0; g0 < T; g0 += 64) {
-                uint32_t nt = 0, nrs = 0, nre = 0, ncell = 0, nk = 0; uint4 nd = make_uint4(0, 0, 0, 0); bool nact = false;
-                if (g0 + 64 < T) nact = fetch(g0 + 64, nt, nrs, nre, ncell, nk, nd);      // the next round's chunks in flight
+                uint32_t nfw = 0, nrs = 0, nre = 0, ncell = 0, nk = 0, nkind = 0; uint4 nd = make_uint4(0, 0, 0, 0);
+                if (g0 + 64 < T) fetch(g0 + 64, nfw, nrs, nre, ncell, nk, nkind, nd);      // the next round's chunks in flight
                 // the lane's records 8 ck .. 8 ck + 7 that belong to the run
                 uint32_t slowm = 0;
-                if (cact) {
+                const uint32_t w[4] = {cd.x, cd.y, cd.z, cd.w};
+                uint32_t z[4] = {0, 0, 0, 0};
+                // a masked byte of (w ^ fp:fp) is zero iff that side of that record matches the fingerprint: two records per operation
+                const uint32_t k3 = ckind & 3u;
+                if (k3 == 1u || k3 == 2u) {
+                    const uint32_t mm = (k3 == 2u) ? m16 : m4;
+                    const uint32_t fa = (cfw & 0xffffu) * 0x10001u, fb = (cfw >> 16) * 0x10001u;
+                    #pragma unroll
+                    for (int j = 0; j < 4; j++) {
+                        const uint32_t xa = (w[j] ^ fa) & mm, xb = (w[j] ^ fb) & mm;
+                        z[j] = ((xa - 0x01010101u) & ~xa) | ((xb - 0x01010101u) & ~xb);
+                    }
+                }
+                {   // cells of three and more entries: their fingerprints one after the other (as many rounds as the longest list in the wave)
+                    const uint32_t n3 = (ckind == 7u) ? cfw >> 16 : 0u, sidx = cfw & 0xffffu;
+                    for (uint32_t e = 0; __ballot(e < n3); e++) {
+                        if (e < n3) {
+                            const uint32_t fa = side_w[sidx + e] * 0x10001u;
+                            #pragma unroll
+                            for (int j = 0; j < 4; j++) { const uint32_t xa = (w[j] ^ fa) & m4; z[j] |= (xa - 0x01010101u) & ~xa; }
+                        }
+                    }
+                }
+                if (ckind & 4u) {
                     const uint32_t r0 = ck << 3;
                     const uint32_t lo_i = crs > r0 ? crs - r0 : 0u, hi_i = min(cre - r0, 8u);
                     const uint32_t vm = ((1u << hi_i) - 1u) & ~((1u << lo_i) - 1u);
-                    if (ct & 0x8000u) {
-                        // both reduced fingerprints of the cell word against two records at a time: a masked byte of
-                        // (w ^ fp:fp) is zero iff that side of that record matches
-                        const uint32_t fa = (ct & 0x7fffu) * 0x10001u, fb = ((ct >> 16) & 0x7fffu) * 0x10001u;
-                        const uint32_t w[4] = {cd.x, cd.y, cd.z, cd.w};
+                    if (k3 == 0u) slowm = vm;                           // nothing tested: every record takes the queue
+                    else {
                         #pragma unroll
                         for (int j = 0; j < 4; j++) {
-                            const uint32_t xa = (w[j] ^ fa) & m4, xb = (w[j] ^ fb) & m4;
-                            const uint32_t z = (((xa - 0x01010101u) & ~xa) | ((xb - 0x01010101u) & ~xb)) & 0x80808080u;
-                            slowm |= ((z & 0x00008080u) ? 1u : 0u) << (2 * j);
-                            slowm |= ((z & 0x80800000u) ? 2u : 0u) << (2 * j);
+                            const uint32_t y = (z[j] | (z[j] >> 8)) & 0x00800080u;      // bit 7: record 2 j, bit 23: record 2 j + 1
+                            slowm |= (((y >> 7) | (y >> 22)) & 3u) << (2 * j);
                         }
                         slowm &= vm;
-                    } else slowm = vm;                                  // three and more entries: every record takes the queue
+                    }
                 }
                 while (true) {
                     const unsigned long long m = __ballot(slowm != 0);
@@ -405,12 +457,12 @@ probe_runs_kernel(GbnBinParams B)
                         const uint32_t a0 = (cd.y & m1) | (cd.x & ~m1), a1 = (cd.w & m1) | (cd.z & ~m1);
                         const uint32_t wsel = (a1 & m2) | (a0 & ~m2);
                         const int at = qn + __popcll(m & lt);
-                        qrec[at] = (ck << 3) + r; qcell[at] = ccell; qfp[at] = (r & 1u) ? (wsel >> 16) : (wsel & 0xffffu);
+                        qrec[at] = (ck << 3) + r; qcell[at] = ccell; qfp[at] = ((r & 1u) ? (wsel >> 16) : (wsel & 0xffffu)) | (k3 << 16);
                     }
                     qn += __popcll(m);
                     if (qn >= 64) { qn -= 64; flush(qn, 64); }
                 }
-                ct = nt; crs = nrs; cre = nre; ccell = ncell; ck = nk; cd = nd; cact = nact;
+                cfw = nfw; crs = nrs; cre = nre; ccell = ncell; ck = nk; ckind = nkind; cd = nd;
             }
         }
         item = (uint32_t)__builtin_amdgcn_readfirstlane((int)nitem);

@@ -21,7 +21,7 @@ pytestmark = pytest.mark.gpu
 def sorted_at_first_hit(monkeypatch):
     monkeypatch.delenv("GBN_RECORD_CACHE_MB", raising=False)
     monkeypatch.delenv("GBN_SCAN_BINS", raising=False)
-    monkeypatch.delenv("GBN_REC_RUNS", raising=False)
+    monkeypatch.setenv("GBN_REC_RUNS", "2")                 # whatever the shard's size (the engine sorts only sets whose runs are long)
     monkeypatch.setenv("GBN_RUNS_AFTER", "0")
     api.record_cache_set_limit(-1)
     yield
@@ -156,16 +156,19 @@ def test_other_batches_over_one_sorted_set_and_the_stream_form_switch(monkeypatc
     assert st["sorts"] - st0["sorts"] == 1 and st["sorted_sets"] >= 1 and st["sorted_bytes"] > 0 and st["sorted_passes"] - st0["sorted_passes"] == 3
     assert st["bytes"] < 2 * st["sorted_bytes"]                         # the streams went back to the pool
     api.record_cache_invalidate()
-    monkeypatch.setenv("GBN_REC_RUNS", "0")
-    st0 = api.record_cache_stats()
-    for name, q in (("a", qa), ("b", qb), ("a", qa)):
-        ps = api.BlastPrelimSearch(q, opt, src); assert ps.run()["hsps"].tobytes() == want[name]; ps.close()
-    st = api.record_cache_stats()
-    assert st["sorts"] == st0["sorts"] and st["sorted_sets"] == 0 and st["hits"] - st0["hits"] == 2
+    for mode in ("0", "1"):                                             # never; the default: only sets whose runs are long
+        monkeypatch.setenv("GBN_REC_RUNS", mode)
+        api.record_cache_invalidate()
+        st0 = api.record_cache_stats()
+        for name, q in (("a", qa), ("b", qb), ("a", qa)):
+            ps = api.BlastPrelimSearch(q, opt, src); assert ps.run()["hsps"].tobytes() == want[name]; ps.close()
+        st = api.record_cache_stats()
+        assert st["sorts"] == st0["sorts"] and st["sorted_sets"] == 0 and st["hits"] - st0["hits"] == 2, (mode, st0, st)
     src.close()
 
 
 def test_default_policy_sorts_at_the_second_hit(monkeypatch):
+    """(of a set whose runs are long -- the size test is switched off here; test_full_size_* run the policy as it is)"""
     monkeypatch.delenv("GBN_RUNS_AFTER", raising=False)
     db, queries, plants, subjects, opt = util.small_case(8, 300_000, 40, task="megablast", seed=13)
     src = api.BlastSeqSrc.from_packed(subjects)
