@@ -201,7 +201,10 @@ def test_full_size_c2_pass_against_the_oracle_subject_by_subject():
     sample = np.union1d(hit_oids, rng.choice(nsub, 25, replace=False))
     from oracle import orc
     s = orc.Search(util.oracle_options(opt), queries)
-    for oid in sample.tolist():
+    # the reference's container semantics: ONE diagonal container carried from subject to subject in OID order
+    # (CORE/blast_extend.c:166-190); the HIP path starts every subject fresh -- DESIGN.md "a6", tests/test_diag_carry.py
+    s.carry_diag(True)
+    for oid in sample.tolist():                         # (ascending)
         o = s.subject(db.subject_packed(oid), slen)
         g = first[first["oid"] == oid]
         assert len(g) == len(o["hsps"]), (oid, len(g), len(o["hsps"]))

@@ -63,6 +63,9 @@ def test_full_size_c3_range_with_default_thresholds_against_the_oracle(monkeypat
     assert a.tobytes() == first.tobytes() and b.tobytes() == first.tobytes()
 
     s = orc.Search(util.oracle_options(opt), queries)
+    # the reference's container semantics: ONE diagonal hash carried through the subjects in OID order (CORE/blast_extend.c:166-190,
+    # CORE/na_ungapped.c:362-451); the HIP path starts every subject with a fresh one (DESIGN.md "a6", tests/test_diag_carry.py)
+    s.carry_diag(True)
     oi = s.info()
     assert (oi["lut_type"], oi["lut_width"], oi["scan_step"], oi["container"]) == (info["lut_type"], 11, 1, 1)
     nseeds = nih = 0
