@@ -41,10 +41,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=160, help="timed passes (default: > 2 s of timed region on C2)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", choices=["C2", "C3", "C4", "shim"], default="C2",
+    ap.add_argument("--workload", choices=["C2", "C3", "C4", "shim", "cli"], default="C2",
                     help="C2 (the metric's config): megablast W=28 vs 50 Gbp; C3: blastn W=11 vs 5 Gbp, 100 kb batches; "
                          "C4: 100k queries streamed in 5 Mb batches through the host pipeline, CPU traceback overlapped with the GPU stages; "
-                         "shim: the C2 shard as 100 resident blocks searched the way gblastn_amd/shim/gpu_blastn_amd_shim.cpp searches them")
+                         "shim: the C2 shard as 100 resident blocks searched the way gblastn_amd/shim/gpu_blastn_amd_shim.cpp searches them; "
+                         "cli: the documented invocation end to end -- blastn_prelim on the C2 database written as BLAST v4 volumes on disk (bench_cli.py)")
     ap.add_argument("--trace-threads", type=int, default=0, help="C4: traceback consumer threads (0: a quarter of the host cores, 4 .. 16; round 4 ran 4, "
                                                                   "with which the traceback of a batch, not the GPU, sets the pace once the records are cached)")
     ap.add_argument("--no-traceback", action="store_true", help="C4 diagnostics: the pipeline without its traceback stage")
@@ -75,6 +76,8 @@ def parse():
         a.steps = 20                                    # 100,000 queries = 20 batches of 5,000
     if a.workload == "shim" and "--steps" not in " ".join(sys.argv):
         a.steps = 10
+    if a.workload == "cli" and "--steps" not in " ".join(sys.argv):
+        a.steps = 2
     if a.trace_threads <= 0:
         a.trace_threads = max(4, min(16, (os.cpu_count() or 16) // 4))
     if a.subjects is None:
@@ -113,6 +116,9 @@ def main():
     if rc:
         raise SystemExit("gbn_init failed: %s" % api.lib().gbn_last_error().decode())
     os.environ.pop("GBN_RECORD_CACHE_MB", None)             # (the policy of this run is set through the API below)
+    if args.workload == "cli":
+        from bench_cli import bench_cli
+        return bench_cli(args, api)
     cache_on = args.record_cache == "on" or (args.record_cache == "default" and args.workload in ("C4", "shim"))
     api.record_cache_set_limit(-1 if cache_on else 0)
     if args.strong and world > 1:

@@ -66,7 +66,7 @@ IHIT_DT = np.dtype([("oid", "<i4"), ("q_off", "<i4"), ("s_off", "<i4"), ("q_star
                     ("s_start", "<i4"), ("length", "<i4"), ("score", "<i4"), ("pad_", "<i4")])
 
 EXPORTS = ["gbn_init", "gbn_release", "gbn_release_db_memory", "gbn_debug_check_guards", "gbn_device_count", "gbn_use_device", "gbn_current_device", "gbn_db_device", "gbn_shard_builder_add_oid", "gbn_default_options",
-           "gbn_db_new", "gbn_db_free", "gbn_db_total_bases", "gbn_db_num_seqs", "gbn_synth_fill",
+           "gbn_db_new", "gbn_db_new_streamed", "gbn_db_free", "gbn_db_total_bases", "gbn_db_num_seqs", "gbn_synth_fill",
            "gbn_batch_new", "gbn_batch_new_ex", "gbn_batch_new_masked", "gbn_dust_mask", "gbn_batch_free", "gbn_batch_num_contexts", "gbn_batch_contexts",
            "gbn_batch_lut_type", "gbn_batch_lut_width", "gbn_batch_scan_step", "gbn_batch_scan_path",
            "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff", "gbn_results_new",

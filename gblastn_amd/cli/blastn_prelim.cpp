@@ -23,6 +23,7 @@
 #include <future>
 #include <iostream>
 #include <map>
+#include <thread>
 #include <sstream>
 #include <string>
 #include <vector>
@@ -110,6 +111,10 @@ std::string bits_string(double s)
 
 int main(int argc, char **argv)
 {
+    // -timing true: one JSON line on stderr with the wall clock of the invocation's phases (bench.py --workload cli)
+    const auto t_main = std::chrono::steady_clock::now();
+    auto ms_since = [](std::chrono::steady_clock::time_point t) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t).count(); };
+    double ph_args_fasta = 0, ph_init = 0, ph_db = 0, ph_dust = 0, ph_emit = 0, ph_wait = 0, ph_submit = 0;
     std::map<std::string, std::string> a;
     for (int i = 1; i < argc; i++) {
         std::string k = argv[i];
@@ -124,35 +129,30 @@ int main(int argc, char **argv)
     const std::string task = get("task", "megablast");
     if (task != "megablast" && task != "blastn") die("-task must be megablast or blastn (discontiguous megablast is not supported, as in G-BLASTN)");
 
-    // ---- queries ----
-    std::vector<std::string> files;
-    if (a.count("query")) files.push_back(a["query"]);
-    if (a.count("query_list")) {
-        std::ifstream l(a["query_list"]);
-        if (!l) die("cannot open query list " + a["query_list"]);
-        std::string p; while (std::getline(l, p)) if (!p.empty()) files.push_back(p);
-    }
-    std::vector<Query> queries; std::string err;
-    for (auto &f : files) if (!read_fasta(f, queries, err)) die(err);
-    if (queries.empty()) die("no query sequences");
-
     // ---- database: its volumes dealt to the GPUs in contiguous runs (one resident shard per search thread), global OIDs ----
     const int gpu_id = std::atoi(get("gpu_id", "-1").c_str());
     const int ndev_all = gbn_device_count();
     if (ndev_all < 1) die("no HIP device visible");
     std::vector<int> devices;
     if (gpu_id >= 0) devices.push_back(gpu_id); else for (int d = 0; d < ndev_all; d++) devices.push_back(d);
+    auto t_ph = std::chrono::steady_clock::now();
     for (int d : devices) check(gbn_init(1, d), "gbn_init");
+    ph_init = ms_since(t_ph); t_ph = std::chrono::steady_clock::now();
+    // The volumes are opened and their shards uploaded on threads of their own while this one reads the queries and runs DUST
+    // (12.5 GB of a 50 Gbp database: half a second of pinned-piece uploads, gbn_db_new_streamed, that nothing else waits for).
     GbnBlastDb *bdb = nullptr;
-    check(gbn_blastdb_open(&bdb, a["db"].c_str()), "gbn_blastdb_open");
-    const int32_t nvol = gbn_blastdb_num_volumes(bdb);
-    int nparts = a.count("num_threads") ? std::max(1, std::atoi(a["num_threads"].c_str())) : (int)devices.size();
-    nparts = std::max(1, std::min(nparts, (int)nvol));                  // (a volume is not split)
+    int32_t nvol = 0; int nparts = 1;
     // (per part, for the table -stage prelim prints at the end: bases its shard holds, what its search thread scanned, the
     // wall time of its preliminary searches added up, and the time spent waiting for its results)
     struct Part { int device; GbnDb *shard = nullptr; long long scanned = 0; double prelim_ms = 0, scan_kernel_ms = 0; long long batches = 0; };
-    std::vector<Part> parts((size_t)nparts);
-    {   // shard_bounds of gblastn_amd/shard.py: part p holds volumes [p * V / P, (p + 1) * V / P); loaded in parallel
+    std::vector<Part> parts;
+    std::future<std::string> db_ready = std::async(std::launch::async, [&]() -> std::string {
+        if (gbn_blastdb_open(&bdb, a["db"].c_str())) return std::string("gbn_blastdb_open: ") + gbn_last_error();
+        nvol = gbn_blastdb_num_volumes(bdb);
+        nparts = a.count("num_threads") ? std::max(1, std::atoi(a["num_threads"].c_str())) : (int)devices.size();
+        nparts = std::max(1, std::min(nparts, (int)nvol));              // (a volume is not split)
+        parts.resize((size_t)nparts);
+        // shard_bounds of gblastn_amd/shard.py: part p holds volumes [p * V / P, (p + 1) * V / P); loaded in parallel
         std::vector<std::future<std::string>> loads;
         for (int p = 0; p < nparts; p++) {
             parts[(size_t)p].device = devices[(size_t)p % devices.size()];
@@ -165,8 +165,80 @@ int main(int argc, char **argv)
                 return "";
             }));
         }
-        for (auto &f : loads) { const std::string e = f.get(); if (!e.empty()) die(e); }
+        std::string err;
+        for (auto &f : loads) { const std::string e = f.get(); if (!e.empty() && err.empty()) err = e; }
+        ph_db = ms_since(t_ph);
+        return err;
+    });
+
+    // ---- queries ----
+    std::vector<std::string> files;
+    if (a.count("query")) files.push_back(a["query"]);
+    if (a.count("query_list")) {
+        std::ifstream l(a["query_list"]);
+        if (!l) die("cannot open query list " + a["query_list"]);
+        std::string p; while (std::getline(l, p)) if (!p.empty()) files.push_back(p);
     }
+    std::vector<Query> queries; std::string err;
+    for (auto &f : files) if (!read_fasta(f, queries, err)) die(err);
+    if (queries.empty()) die("no query sequences");
+    ph_args_fasta = ms_since(t_ph);
+
+
+    int dust_level = 20, dust_window = 64, dust_linker = 1; bool dust = true;       // blastn's default filter
+    {
+        const std::string d = get("dust", "yes");
+        if (d == "no" || d == "false") dust = false;
+        else if (d != "yes" && d != "true") {
+            std::istringstream is(d);
+            if (!(is >> dust_level >> dust_window >> dust_linker)) die("-dust takes yes, no or 'level window linker'");
+        }
+    }
+    // ---- query batches of the reference's size ----
+    // GetQueryBatchSize (blastinput/blast_input_aux.cpp:66-124), including its BATCH_SIZE override
+    int64_t batch_bases = task == "megablast" ? 5000000 : 100000;
+    if (const char *e = std::getenv("BATCH_SIZE")) batch_bases = std::max(1, std::atoi(e));
+    struct Batch { size_t first, count; };
+    std::vector<Batch> batches;
+    for (size_t i = 0; i < queries.size();) {
+        Batch bt; bt.first = i; int64_t acc = 0;
+        while (i < queries.size() && (i == bt.first || acc + (int64_t)queries[i].seq.size() <= batch_bases)) acc += (int64_t)queries[i++].seq.size();
+        bt.count = i - bt.first;
+        batches.push_back(bt);
+    }
+    // every batch as the pipeline takes it, DUST included, prepared now -- next to the database's upload -- with the queries of a
+    // batch dealt to a few threads (symmetric DUST of 10,000 x 1 kb: 120 ms on one)
+    auto make_batch = [&](const Batch &bt) {
+        gbn::SQueryBatch q;
+        q.seqs.reserve(bt.count);
+        for (size_t k = 0; k < bt.count; k++) q.seqs.push_back(queries[bt.first + k].seq);
+        if (!dust) return q;
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)hw / 2, bt.count / 64 + 1}));
+        std::vector<std::vector<gbn::SQueryBatch::Mask>> found(nt);
+        std::vector<std::thread> ts;
+        for (size_t t = 0; t < nt; t++)
+            ts.emplace_back([&, t]() {
+                std::vector<int32_t> f, to;
+                for (size_t k = bt.count * t / nt; k < bt.count * (t + 1) / nt; k++) {
+                    const Query &qq = queries[bt.first + k];
+                    if (qq.seq.empty()) continue;
+                    f.resize(qq.seq.size() / 2 + 2); to.resize(f.size());
+                    const int32_t n = gbn_dust_mask(qq.seq.data(), (int32_t)qq.seq.size(), dust_level, dust_window, dust_linker, f.data(), to.data(), (int32_t)f.size());
+                    for (int32_t j = 0; j < n && j < (int32_t)f.size(); j++) found[t].push_back(gbn::SQueryBatch::Mask{(int32_t)k, f[(size_t)j], to[(size_t)j]});
+                }
+            });
+        for (auto &t : ts) t.join();
+        for (auto &v : found) q.masks.insert(q.masks.end(), v.begin(), v.end());      // (threads hold ascending query ranges: the list stays in query order)
+        return q;
+    };
+    std::vector<gbn::SQueryBatch> prepared;
+    {
+        const auto t_d = std::chrono::steady_clock::now();
+        for (const Batch &bt : batches) prepared.push_back(make_batch(bt));
+        ph_dust = ms_since(t_d);
+    }
+    { const std::string e = db_ready.get(); if (!e.empty()) die(e); }
 
     // ---- options (API/blast_nucl_options.cpp defaults of the task, then the flags) ----
     GbnOptions opt; gbn_default_options(&opt, task == "megablast");
@@ -185,15 +257,6 @@ int main(int argc, char **argv)
     opt.db_length = stat_len > 0 ? stat_len : gbn_blastdb_total_length(bdb);
     opt.db_num_seqs = stat_n > 0 ? stat_n : gbn_blastdb_num_seqs(bdb);
 
-    int dust_level = 20, dust_window = 64, dust_linker = 1; bool dust = true;       // blastn's default filter
-    {
-        const std::string d = get("dust", "yes");
-        if (d == "no" || d == "false") dust = false;
-        else if (d != "yes" && d != "true") {
-            std::istringstream is(d);
-            if (!(is >> dust_level >> dust_window >> dust_linker)) die("-dust takes yes, no or 'level window linker'");
-        }
-    }
     const int outfmt = std::atoi(get("outfmt", "6").c_str());
     if (outfmt != 6 && outfmt != 7) die("-outfmt 6 or 7 (tabular)");
     const bool overlapped = get("mode", "1") != "1";                 // 0 and 2: the reference's pipelined methods
@@ -204,31 +267,6 @@ int main(int argc, char **argv)
     FILE *out = stdout;
     if (a.count("out")) { out = std::fopen(a["out"].c_str(), "w"); if (!out) die("cannot write " + a["out"]); }
 
-    // ---- query batches of the reference's size ----
-    // GetQueryBatchSize (blastinput/blast_input_aux.cpp:66-124), including its BATCH_SIZE override
-    int64_t batch_bases = task == "megablast" ? 5000000 : 100000;
-    if (const char *e = std::getenv("BATCH_SIZE")) batch_bases = std::max(1, std::atoi(e));
-    struct Batch { size_t first, count; };
-    std::vector<Batch> batches;
-    for (size_t i = 0; i < queries.size();) {
-        Batch bt; bt.first = i; int64_t acc = 0;
-        while (i < queries.size() && (i == bt.first || acc + (int64_t)queries[i].seq.size() <= batch_bases)) acc += (int64_t)queries[i++].seq.size();
-        bt.count = i - bt.first;
-        batches.push_back(bt);
-    }
-    auto make_batch = [&](const Batch &bt) {
-        gbn::SQueryBatch q;
-        for (size_t k = 0; k < bt.count; k++) {
-            const Query &qq = queries[bt.first + k];
-            q.seqs.push_back(qq.seq);
-            if (dust && !qq.seq.empty()) {
-                std::vector<int32_t> f(qq.seq.size() / 2 + 2), t(f.size());
-                const int32_t n = gbn_dust_mask(qq.seq.data(), (int32_t)qq.seq.size(), dust_level, dust_window, dust_linker, f.data(), t.data(), (int32_t)f.size());
-                for (int32_t j = 0; j < n && j < (int32_t)f.size(); j++) q.masks.push_back(gbn::SQueryBatch::Mask{(int32_t)k, f[(size_t)j], t[(size_t)j]});
-            }
-        }
-        return q;
-    };
     // the twelve standard columns of a final alignment: qseqid sseqid pident length mismatch gapopen qstart qend sstart send evalue bitscore
     auto emit_final = [&](const Batch &bt, const GbnTbHSP *h, const int64_t *qs, const GbnContext *ctx) {
         for (size_t k = 0; k < bt.count; k++) {
@@ -303,14 +341,18 @@ int main(int argc, char **argv)
         const size_t ahead = overlapped ? 8 : 1;
         while (printed < batches.size()) {
             while (submitted < batches.size() && submitted < printed + ahead) {
-                for (auto &pp : pipes) pp->Submit(make_batch(batches[submitted]));
+                const auto t_s = std::chrono::steady_clock::now();
+                for (auto &pp : pipes) pp->Submit(prepared[submitted]);
+                ph_submit += ms_since(t_s);
                 submitted++;
             }
             if (submitted == batches.size()) for (auto &pp : pipes) pp->Finish();
             std::vector<gbn::CSearchPipeline::TItem> items;
             for (size_t pi = 0; pi < pipes.size(); pi++) {
                 auto &pp = pipes[pi];
+                const auto t_w = std::chrono::steady_clock::now();
                 gbn::CSearchPipeline::TItem it = pp->Next();
+                ph_wait += ms_since(t_w);
                 if (!it) die("the pipeline ended early");
                 if (it->status != GBN_OK) die(it->error);
                 const GbnDiagnostics &d = it->prelim->diagnostics;
@@ -320,6 +362,7 @@ int main(int argc, char **argv)
                 items.push_back(std::move(it));
             }
             const Batch &bt = batches[printed];
+            const auto t_e = std::chrono::steady_clock::now();
             const GbnContext *ctx = gbn_batch_contexts(items[0]->prelim->Batch());
             if (with_traceback) {
                 if (items.size() == 1) {
@@ -345,6 +388,7 @@ int main(int argc, char **argv)
                 all.Close();
                 emit_prelim(bt, all.Get(), *items[0]);
             }
+            ph_emit += ms_since(t_e);
             printed++;
         }
         for (auto &pp : pipes) pp->Close();
@@ -367,7 +411,22 @@ int main(int argc, char **argv)
                      parts.size(), devices.size(), all / 1e9, wall_ms, wall_ms > 0 ? all / 1e9 / (wall_ms * 1e-3) : 0.0);
     }
     if (out != stdout) std::fclose(out);
-    for (Part &pt : parts) gbn_db_free(pt.shard);
-    gbn_blastdb_close(bdb); gbn_release();
+    const auto t_down = std::chrono::steady_clock::now();
+    long long shard_bytes = 0;
+    for (Part &pt : parts) shard_bytes += gbn_db_total_bases(pt.shard) / 4;
+    // A one-shot program leaves the device's memory to the driver, as the reference's blastn does: freeing a 12.5 GB shard, the
+    // pools and the streams one by one took 0.23 s of a 1.2 s invocation.  GBN_CLI_TEARDOWN=1: the orderly way (leak checks).
+    const bool teardown = std::getenv("GBN_CLI_TEARDOWN") != nullptr;
+    if (teardown) { for (Part &pt : parts) gbn_db_free(pt.shard); gbn_blastdb_close(bdb); gbn_release(); }
+    if (get("timing", "false") == "true") {
+        // submit = FASTA batches -> SQueryBatch incl. DUST (dust_ms of it); wait = blocked on the pipeline for a batch's results
+        // (set-up, preliminary search and traceback of the batches in flight); emit = formatting + writing the rows
+        std::fprintf(stderr, "{\"blastn_prelim_timing\": {\"total_ms\": %.1f, \"args_fasta_ms\": %.1f, \"gbn_init_ms\": %.1f, \"db_open_upload_ms\": %.1f, "
+                             "\"shard_GB\": %.2f, \"search_wall_ms\": %.1f, \"submit_ms\": %.1f, \"dust_ms\": %.1f, \"wait_results_ms\": %.1f, \"emit_rows_ms\": %.1f, "
+                             "\"prelim_search_ms_max_batch\": %.1f, \"teardown_ms\": %.1f, \"queries\": %zu, \"batches\": %zu, \"parts\": %zu}}\n",
+                     ms_since(t_main), ph_args_fasta, ph_init, ph_db, shard_bytes / 1e9, wall_ms, ph_submit, ph_dust, ph_wait, ph_emit, diag.total_ms, ms_since(t_down),
+                     queries.size(), batches.size(), parts.size());
+    }
+    if (!teardown) { std::fflush(nullptr); std::_Exit(0); }
     return 0;
 }

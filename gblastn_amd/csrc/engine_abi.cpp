@@ -440,6 +440,95 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
     return GBN_OK;
     });
 }
+// The shard's bytes produced piece by piece by the caller's callback, through pinned staging buffers, uploads overlapping
+// the fills: what a database that comes from files wants (gbn_blastdb_load_shard) -- the one-slab form above costs a
+// zero-filled host copy of the whole shard (3 s of page faults for 12.5 GB) and one blocking copy from pageable memory.
+int gbn_db_new_streamed(GbnDb **out, int64_t nbytes, int32_t num_seqs, const int64_t *byte_off, const int32_t *len,
+                        int32_t first_oid, GbnFillFn fill, void *ctx, int threads) {
+    return gbn::guard(__func__, [&]() -> int {
+    if (!out || !fill || nbytes < 144 || num_seqs < 0 || (num_seqs > 0 && (!byte_off || !len))) { set_error("bad argument"); return GBN_ERR_ARG; }
+    int rc = enter_current();
+    if (rc) return rc;
+    constexpr int64_t kPiece = 16ll << 20;
+    int64_t total = 0;
+    for (int32_t i = 0; i < num_seqs; i++) {
+        const int64_t nb = ((int64_t)len[i] + 3) / 4;
+        if (byte_off[i] < 16 || (byte_off[i] & 15) || byte_off[i] + nb + 128 > nbytes || (i > 0 && byte_off[i] < byte_off[i - 1] + ((int64_t)len[i - 1] + 3) / 4)) {
+            set_error("subject offsets must be ascending, 16-byte aligned, >= 16, and leave 128 pad bytes"); return GBN_ERR_ARG;
+        }
+        if (len[i] > g_max_dbseq_len || nb > kPiece) { set_error("a sequence longer than MAX_DBSEQ_LEN: gbn_db_new holds it as chunk copies"); return GBN_ERR_UNSUPPORTED; }
+        total += len[i];
+    }
+    // pieces: runs of consecutive sequences whose image on the device is at most kPiece bytes
+    struct Piece { int32_t first, count; int64_t base, bytes; };
+    std::vector<Piece> pieces;
+    for (int32_t i = 0; i < num_seqs; ) {
+        Piece pc; pc.first = i; pc.base = byte_off[i];
+        int32_t j = i;
+        while (j < num_seqs && byte_off[j] + ((int64_t)len[j] + 3) / 4 - pc.base <= kPiece) j++;
+        pc.count = j - i; pc.bytes = byte_off[j - 1] + ((int64_t)len[j - 1] + 3) / 4 - pc.base;
+        pieces.push_back(pc); i = j;
+    }
+    uint8_t *p = nullptr;
+    if (hipMalloc((void **)&p, (size_t)nbytes) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
+    hipEvent_t zeroed = nullptr;
+    bool ok = hipEventCreateWithFlags(&zeroed, hipEventDisableTiming) == hipSuccess &&
+              hipMemsetAsync(p, 0, (size_t)nbytes, E.stream) == hipSuccess && hipEventRecord(zeroed, E.stream) == hipSuccess;
+    const int nthreads = (int)std::max<size_t>(1, std::min<size_t>({pieces.size(), (size_t)(threads > 0 ? threads : (int)gbn::switch_value("GBN_UPLOAD_THREADS", std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 2)))), (size_t)64}));
+    std::atomic<size_t> next{0}; std::atomic<int> status{ok ? GBN_OK : GBN_ERR_HIP};
+    Engine *eng = tl_eng;
+    uint8_t *pinned = nullptr;              // two pieces per worker, ONE allocation (pinning memory is the slow part: 32 workers' 64 allocations cost more than they gained)
+    if (ok && hipHostMalloc((void **)&pinned, (size_t)kPiece * 2 * (size_t)nthreads) != hipSuccess) { (void)hipGetLastError(); ok = false; status = GBN_ERR_NOMEM; }
+    std::atomic<int> wid{0};
+    auto worker = [&]() {
+        enter(eng);
+        const int me = wid.fetch_add(1);
+        hipStream_t st = nullptr; uint8_t *buf[2] = {pinned + (size_t)kPiece * 2 * (size_t)me, pinned + (size_t)kPiece * (2 * (size_t)me + 1)};
+        hipEvent_t done[2] = {nullptr, nullptr}; bool busy[2] = {false, false};
+        bool good = hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess && hipStreamWaitEvent(st, zeroed, 0) == hipSuccess;
+        for (int k = 0; k < 2 && good; k++) good = hipEventCreateWithFlags(&done[k], hipEventDisableTiming) == hipSuccess;
+        for (int k = 0; good && status.load() == GBN_OK; k ^= 1) {
+            const size_t i = next.fetch_add(1);
+            if (i >= pieces.size()) break;
+            const Piece &pc = pieces[i];
+            if (busy[k]) { good = hipEventSynchronize(done[k]) == hipSuccess; busy[k] = false; if (!good) break; }
+            std::memset(buf[k], 0, (size_t)pc.bytes);
+            const int frc = fill(ctx, pc.first, pc.count, buf[k], pc.base);
+            if (frc) { int want = GBN_OK; status.compare_exchange_strong(want, frc); break; }
+            good = hipMemcpyAsync(p + pc.base, buf[k], (size_t)pc.bytes, hipMemcpyHostToDevice, st) == hipSuccess && hipEventRecord(done[k], st) == hipSuccess;
+            busy[k] = good;
+        }
+        if (st) good = (hipStreamSynchronize(st) == hipSuccess) && good;
+        if (!good) { int want = GBN_OK; status.compare_exchange_strong(want, GBN_ERR_HIP); }
+        for (int k = 0; k < 2; k++) if (done[k]) (void)hipEventDestroy(done[k]);
+        if (st) (void)hipStreamDestroy(st);
+    };
+    if (ok) {
+        std::vector<std::thread> ts;
+        for (int t = 1; t < nthreads; t++) ts.emplace_back(worker);
+        worker();
+        for (auto &t : ts) t.join();
+        enter(eng);
+    }
+    if (zeroed) { (void)hipEventSynchronize(zeroed); (void)hipEventDestroy(zeroed); }
+    if (pinned) (void)hipHostFree(pinned);
+    if (status.load() != GBN_OK) {
+        (void)hipFree(p);
+        if (status.load() == GBN_ERR_HIP) set_error("uploading the shard's pieces failed");
+        return status.load();
+    }
+    g_db_bytes_uploaded += (long long)nbytes;
+    GbnDb *db = new GbnDb();
+    db->engine = tl_eng; db->first_oid = first_oid; db->real_seqs = num_seqs; db->chunk_len = g_max_dbseq_len;
+    db->num_seqs = num_seqs; db->nbytes = nbytes; db->total_bases = total;
+    db->byte_off.assign(byte_off, byte_off + num_seqs); db->len.assign(len, len + num_seqs);
+    db->d_packed = p; db->owns = true;
+    if ((rc = dev_upload(db->d_byte_off, db->byte_off.data(), db->byte_off.size())) ||
+        (rc = dev_upload(db->d_len, db->len.data(), db->len.size()))) { gbn_db_free(db); return rc; }
+    *out = db;
+    return GBN_OK;
+    });
+}
 // ambiguity runs of sequence `local` (0-based in the shard), values in NCBI4na as the database stores them
 // (gbn_blastdb_get_ambiguities); gbn_blastdb_load_shard calls this for every sequence that has runs
 int gbn_db_set_ambiguities(GbnDb *db, int32_t local, int32_t n, const int32_t *start, const int32_t *length, const uint8_t *ncbi4na) {

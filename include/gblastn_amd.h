@@ -219,6 +219,15 @@ typedef struct GbnDb GbnDb;
 int  gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_seqs,
                 const int64_t *byte_off, const int32_t *len, int32_t first_oid,
                 int is_device);
+/* The same shard, its subject bytes produced piece by piece: the library allocates the slab on the device and calls
+ * fill(ctx, first, count, dst, dst_base) from `threads` worker threads (0: a default) for runs of consecutive sequences -- the
+ * callback writes sequence i's NCBI2na bytes at dst + (byte_off[i] - dst_base), for i in [first, first + count); dst is pinned
+ * host memory, zeroed, and goes to the device asynchronously while other pieces are being filled (no 12.5 GB host copy of a
+ * 50 Gbp shard, no blocking copy from pageable memory).  gbn_blastdb_load_shard reads the volumes' mapped .nsq files this way.
+ * GBN_ERR_UNSUPPORTED: a sequence longer than MAX_DBSEQ_LEN (held as chunk copies: gbn_db_new).  fill returns 0 or a status. */
+typedef int (*GbnFillFn)(void *ctx, int32_t first, int32_t count, uint8_t *dst, int64_t dst_base);
+int  gbn_db_new_streamed(GbnDb **out, int64_t nbytes, int32_t num_seqs, const int64_t *byte_off, const int32_t *len,
+                         int32_t first_oid, GbnFillFn fill, void *ctx, int threads);
 void gbn_db_free(GbnDb *db);
 /* Ambiguity runs of sequence `local` (0-based in the shard; values in NCBI4na as gbn_blastdb_get_ambiguities gives
  * them): the slab holds 2 bits per base, the traceback stage puts these codes back before it aligns, as the

@@ -104,3 +104,21 @@ def test_search_a_database_loaded_from_files():
     ora, s = util.oracle_run(opt, queries, subjects)
     assert {5, 700, 1500, 1999} <= set(got["oid"].tolist())
     util.compare_stages(dict(hsps=got), ora)
+
+
+@pytest.mark.gpu
+def test_shard_uploaded_in_pieces_equals_the_one_slab_form(monkeypatch):
+    """gbn_blastdb_load_shard fills pinned pieces from the volumes' files (pread) on worker threads and uploads them while
+    others are being filled (gbn_db_new_streamed); GBN_LOAD_ONE_SLAB=1 is the loader of rounds 1-5 -- one host slab, one copy.
+    Same search results either way, over both volumes of the alias, ambiguity runs attached."""
+    db = api.BlastDb(os.path.join(G, "two_vols"))
+    queries = [db.blastna(i) for i in (5, 700, 1500, 1999, 2004)]
+    opt = api.default_options("megablast", db_length=db.stat_length, db_num_seqs=db.stat_num_seqs)
+    got = {}
+    for mode in ("pieces", "slab"):
+        if mode == "slab":
+            monkeypatch.setenv("GBN_LOAD_ONE_SLAB", "1")
+        src = db.load_shard()
+        got[mode] = api.BlastPrelimSearch(queries, opt, src).run()["hsps"].tobytes()
+        src.close()
+    assert got["pieces"] == got["slab"] and len(got["pieces"]) > 0
