@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <chrono>
+#include <cstdint>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -83,7 +84,8 @@ const char *kUsage =
     "       -num_threads N: search threads = database parts (default: one per GPU used); more parts than GPUs share them\n"
     "         round robin (N > 1 on one GPU exercises the same merge); host threads besides: -mode 2 set-up threads, -trace_t_num\n"
     "       (one process per GPU instead: python -m torch.distributed.run --nproc-per-node N -m gblastn_amd.blastn_sharded ...)\n"
-    "       environment BATCH_SIZE overrides the query batch size\n";
+    "       -batch_plan mixer|fixed: the reference's adaptive batch plan (a 10,000-base sample, then towards 2 M extensions per batch)\n"
+    "         or batches of GetQueryBatchSize's fixed size; environment BATCH_SIZE: that many bases per batch (fixed)\n";
 
 // e-value and bit score as the reference's formatter prints them (objtools/align_format/align_format_util.cpp:669-723)
 std::string evalue_string(double e)
@@ -106,6 +108,38 @@ std::string bits_string(double s)
     else std::snprintf(b, sizeof b, "%4.1lf", s);
     return b;
 }
+
+// The reference's adaptive batch plan (CBatchSizeMixer, APP/blast_app_util.hpp:54-73, blast_app_util.cpp:67-86; used by
+// APP/blastn_app.cpp:360-386): the first batch asks for 10,000 bases -- a sample --, every later one for as many bases as are
+// expected to give `target` ungapped extensions that passed their cut-off (CLocalBlast::GetNumExtensions = good_init_extends),
+// the hits-per-base ratio smoothed over the batches with weight 0.3 for the newest; never more than the query chunk size - 1000,
+// never fewer than 100; a batch without a hit, or a size that hits a limit, forgets the history.
+class BatchSizeMixer {
+public:
+    BatchSizeMixer(int32_t target, int32_t most) : target_(target), most_(most) {}
+    // hits of the batch that has just come back (< 0: none has), and the bases THAT batch had been asked for -- the size of the
+    // batch before, as in the reference, when batches run one at a time; with several in flight an older one's
+    int32_t Next(int64_t hits = -1, int64_t asked = 0) {
+        if (hits > 0) {
+            const double now = 1.0 * (double)hits / (double)(asked > 0 ? asked : size_);
+            ratio_ = ratio_ < 0 ? now : kMixIn * now + (1.0 - kMixIn) * ratio_;
+            // (Int4)(1.0 * k_TargetHits / m_Ratio) in the reference: with fewer than 2e6 / 2^31 hits per base -- a sample of random
+            // queries -- the quotient does not fit an Int4, and what an x86-64 build of blastn computes is the conversion's
+            // "integer indefinite", INT_MIN: the size falls to the 100-base floor, one query goes alone, and ITS ratio (or its
+            // having no hit at all) sends the plan to the cap.  Reproduced as that value, not as undefined behaviour.
+            const double want = 1.0 * target_ / ratio_;
+            size_ = (want >= 2147483648.0 || want != want) ? INT32_MIN : (int32_t)want;
+            if (size_ > most_) { size_ = most_; ratio_ = -1.0; }
+            else if (size_ < 100) { size_ = 100; ratio_ = -1.0; }
+        } else if (hits == 0) { size_ = most_; ratio_ = -1.0; }
+        return size_;
+    }
+private:
+    static constexpr double kMixIn = 0.3;
+    const int32_t target_, most_;
+    double ratio_ = -1.0;
+    int32_t size_ = 10000;
+};
 
 }  // namespace
 
@@ -194,18 +228,31 @@ int main(int argc, char **argv)
             if (!(is >> dust_level >> dust_window >> dust_linker)) die("-dust takes yes, no or 'level window linker'");
         }
     }
-    // ---- query batches of the reference's size ----
-    // GetQueryBatchSize (blastinput/blast_input_aux.cpp:66-124), including its BATCH_SIZE override
+    // ---- query batches ----
+    // BATCH_SIZE (the reference's experimentation knob, blastinput/blast_input_aux.cpp:66-124) or -batch_plan fixed: batches of a
+    // fixed size -- GetQueryBatchSize's 5 Mb for megablast, 100 kb for blastn.  Otherwise the reference's adaptive plan
+    // (BatchSizeMixer above; chunk sizes of SplitQuery_GetChunkSize, API/local_blast.cpp:61-101): a 10,000-base sample first.
+    // (Its pipelined methods never feed the mixer -- APP/blastn_app.cpp:808-811: 10,000 bases per batch throughout; here every mode
+    // does, and until the sample is back nothing else is submitted.)  A batch takes whole queries until it has the bases asked
+    // for (CBlastInput::GetNextSeqBatch, blastinput/blast_input.cpp:135-170).
+    const bool fixed_plan = std::getenv("BATCH_SIZE") != nullptr || get("batch_plan", "mixer") == "fixed";
     int64_t batch_bases = task == "megablast" ? 5000000 : 100000;
     if (const char *e = std::getenv("BATCH_SIZE")) batch_bases = std::max(1, std::atoi(e));
-    struct Batch { size_t first, count; };
+    int32_t mix_target = 2000000, mix_most = (task == "megablast" ? 5000000 : 1000000) - 1000;
+    if (const char *e = std::getenv("GBN_CLI_MIXER_TARGET")) mix_target = std::max(1, std::atoi(e));       // (tests: plans of several batches on a small input)
+    if (const char *e = std::getenv("GBN_CLI_MIXER_MOST")) mix_most = std::max(100, std::atoi(e));
+    BatchSizeMixer mixer(mix_target, mix_most);
+    std::vector<int64_t> hits_seen;
+    if (!fixed_plan) batch_bases = mixer.Next();
+    struct Batch { size_t first, count; int64_t asked; };
     std::vector<Batch> batches;
-    for (size_t i = 0; i < queries.size();) {
-        Batch bt; bt.first = i; int64_t acc = 0;
-        while (i < queries.size() && (i == bt.first || acc + (int64_t)queries[i].seq.size() <= batch_bases)) acc += (int64_t)queries[i++].seq.size();
-        bt.count = i - bt.first;
+    size_t cursor = 0;
+    auto form_batch = [&]() {                        // the next batch of the plan (cursor < queries.size())
+        Batch bt; bt.first = cursor; bt.asked = batch_bases; int64_t acc = 0;
+        while (cursor < queries.size() && acc < batch_bases) acc += (int64_t)queries[cursor++].seq.size();
+        bt.count = cursor - bt.first;
         batches.push_back(bt);
-    }
+    };
     // every batch as the pipeline takes it, DUST included, prepared now -- next to the database's upload -- with the queries of a
     // batch dealt to a few threads (symmetric DUST of 10,000 x 1 kb: 120 ms on one)
     auto make_batch = [&](const Batch &bt) {
@@ -232,12 +279,13 @@ int main(int argc, char **argv)
         for (auto &v : found) q.masks.insert(q.masks.end(), v.begin(), v.end());      // (threads hold ascending query ranges: the list stays in query order)
         return q;
     };
-    std::vector<gbn::SQueryBatch> prepared;
-    {
+    std::vector<gbn::SQueryBatch> prepared;         // batches[i] as the pipeline takes it, for the i that have been formed
+    auto prepare_more = [&](size_t upto) {          // batches formed and prepared until there are `upto` (or no query is left)
         const auto t_d = std::chrono::steady_clock::now();
-        for (const Batch &bt : batches) prepared.push_back(make_batch(bt));
-        ph_dust = ms_since(t_d);
-    }
+        while (prepared.size() < upto && cursor < queries.size()) { form_batch(); prepared.push_back(make_batch(batches.back())); }
+        ph_dust += ms_since(t_d);
+    };
+    prepare_more(fixed_plan ? (size_t)-1 : 1);      // (a fixed plan: everything now, next to the upload; the mixer's: the sample)
     { const std::string e = db_ready.get(); if (!e.empty()) die(e); }
 
     // ---- options (API/blast_nucl_options.cpp defaults of the task, then the flags) ----
@@ -336,17 +384,21 @@ int main(int argc, char **argv)
             srcs.emplace_back(new gbn::CBlastSeqSrc(pt.shard, false));
             pipes.emplace_back(new gbn::CSearchPipeline(opt, *srcs.back(), trace_threads, with_traceback, overlapped));
         }
-        // batches enter a few ahead of the results coming out (a batch holds its lookup tables in HBM until printed)
+        // batches enter a few ahead of the results coming out (a batch holds its lookup tables in HBM until printed); under the
+        // mixer's plan the sample goes alone, and a batch is formed when it is submitted, with the size the mixer asks for then
         size_t submitted = 0, printed = 0;
-        const size_t ahead = overlapped ? 8 : 1;
-        while (printed < batches.size()) {
-            while (submitted < batches.size() && submitted < printed + ahead) {
+        bool sampled = fixed_plan, finished = false;
+        while (printed < batches.size() || cursor < queries.size()) {
+            const size_t ahead = (overlapped && sampled && batch_bases >= 50000) ? 8 : 1;        // (the plan's small batches go one at a time, as in the reference's Method1)
+            while (submitted < printed + ahead && (submitted < prepared.size() || cursor < queries.size())) {
+                prepare_more(submitted + 1);
                 const auto t_s = std::chrono::steady_clock::now();
                 for (auto &pp : pipes) pp->Submit(prepared[submitted]);
+                prepared[submitted] = gbn::SQueryBatch();       // (the pipeline has its copy)
                 ph_submit += ms_since(t_s);
                 submitted++;
             }
-            if (submitted == batches.size()) for (auto &pp : pipes) pp->Finish();
+            if (!finished && cursor >= queries.size() && submitted == batches.size()) { for (auto &pp : pipes) pp->Finish(); finished = true; }
             std::vector<gbn::CSearchPipeline::TItem> items;
             for (size_t pi = 0; pi < pipes.size(); pi++) {
                 auto &pp = pipes[pi];
@@ -361,7 +413,12 @@ int main(int argc, char **argv)
                 diag.total_ms = std::max(diag.total_ms, d.total_ms);
                 items.push_back(std::move(it));
             }
-            const Batch &bt = batches[printed];
+            if (!fixed_plan) {
+                int64_t hits = 0;
+                for (auto &it : items) hits += it->prelim->diagnostics.good_init_extends;
+                batch_bases = mixer.Next(hits, batches[printed].asked); sampled = true; hits_seen.push_back(hits);
+            }
+            const Batch bt = batches[printed];
             const auto t_e = std::chrono::steady_clock::now();
             const GbnContext *ctx = gbn_batch_contexts(items[0]->prelim->Batch());
             if (with_traceback) {
@@ -397,6 +454,16 @@ int main(int argc, char **argv)
     std::fprintf(stderr, "blastn_prelim: %zu queries in %zu batches, %lld subject bases scanned, %lld seeds, %lld gapped extensions, %.1f ms in the preliminary stage\n",
                  queries.size(), batches.size(), (long long)diag.subject_bases_scanned, (long long)diag.seeds,
                  (long long)diag.gapped_extensions, diag.total_ms);
+    {
+        std::string plan;
+        for (size_t i = 0; i < batches.size() && i < 12; i++) plan += (i ? " " : "") + std::to_string(batches[i].asked) + "/" + std::to_string(batches[i].count);
+        std::fprintf(stderr, "blastn_prelim: batch plan %s (bases asked for / queries taken)%s: %s%s\n", fixed_plan ? "fixed" : "mixer",
+                     fixed_plan ? "" : " -- CBatchSizeMixer, APP/blast_app_util.cpp:67-86", plan.c_str(), batches.size() > 12 ? " ..." : "");
+    }
+    if (!fixed_plan) {
+        std::string h; for (size_t i = 0; i < hits_seen.size() && i < 12; i++) h += " " + std::to_string(hits_seen[i]);
+        std::fprintf(stderr, "blastn_prelim: hits per batch (good_init_extends, what the mixer is fed):%s\n", h.c_str());
+    } else std::fprintf(stderr, "blastn_prelim: hits per batch: \n");
     if (!with_traceback) {
         // -stage prelim: the scaling self-check.  One line per part (= search thread, on its device), then the whole run:
         // run it with -gpu_id 0 and with -gpu_id -1 on a node of N GPUs and the last lines give the 1 / N table.

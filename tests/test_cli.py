@@ -213,3 +213,68 @@ def test_cli_search_threads_over_database_parts_give_the_rows_of_one(tmp_path, t
             total = [l for l in tab if l.startswith("# total:")]
             assert len(total) == 1 and ("%d parts" % int(n)) in total[0] and "Gbp/s" in total[0]
     assert len(rows["1"]) >= 4 and rows["1"] == rows["2"]
+
+
+def _mixer_sizes(hits_per_batch, asked_first=10000, target=2000000, most=4999000):
+    """CBatchSizeMixer::GetBatchSize transcribed (APP/blast_app_util.cpp:67-86, .hpp:54-73): the sizes asked for, batch by batch,
+    given the hits (good_init_extends) every batch came back with; batches run one at a time"""
+    ratio, size, out = -1.0, asked_first, [asked_first]
+    for hits in hits_per_batch:
+        if hits > 0:
+            r = 1.0 * hits / size
+            ratio = r if ratio < 0 else 0.3 * r + 0.7 * ratio
+            want = 1.0 * target / ratio
+            size = int(want) if want < 2147483648.0 else -2147483648     # (Int4)double beyond Int4 on x86-64: INT_MIN, i.e. the 100-base floor
+            if size > most:
+                size, ratio = most, -1.0
+            elif size < 100:
+                size, ratio = 100, -1.0
+        elif hits == 0:
+            size, ratio = most, -1.0
+        out.append(size)
+    return out
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_cli_batch_plan_of_the_reference_and_unchanged_rows(tmp_path, mode):
+    """blastn starts with a 10,000-base sample and steers towards 2 M extensions per batch (CBatchSizeMixer; APP/blastn_app.cpp:360-386);
+    a batch takes whole queries until it has the bases asked for (CBlastInput::GetNextSeqBatch).  46 queries of ~1 kb against the
+    unit-test database with target / cap scaled down by the test's knobs so that three and more batches form: the sizes the program asked
+    for equal the transcription fed with the hits the program reports, and the rows equal those of one fixed batch."""
+    db = api.BlastDb(DB)
+    rng = np.random.default_rng(5)
+    qs = []
+    for k in range(46):
+        s = db.blastna(int(rng.integers(0, 2000))).copy()
+        s = s[:min(len(s), 1000)]
+        qs.append(("q%02d" % k, np.minimum(s, 3).astype(np.uint8)))
+    fa = tmp_path / "q.fa"
+    fa.write_text("".join(">%s\n%s\n" % (n, "".join(IUPAC[int(x)] for x in s)) for n, s in qs))
+    rows = {}
+    env = dict(os.environ); env.pop("BATCH_SIZE", None)
+    env["GBN_CLI_MIXER_TARGET"] = "40"; env["GBN_CLI_MIXER_MOST"] = "12000"      # (tests: the mixer's two constants)
+    for plan in ("mixer", "fixed"):
+        out = tmp_path / (plan + ".tsv")
+        p = subprocess.run([CLI, "-db", DB, "-query", str(fa), "-use_gpu", "true", "-gpu_id", "0", "-mode", mode, "-batch_plan", plan, "-evalue", "1e-3",
+                            "-max_target_seqs", "5", "-out", str(out), "-timing", "true"], capture_output=True, text=True, timeout=600, env=env)
+        assert p.returncode == 0, p.stderr[-2000:]
+        rows[plan] = out.read_text().splitlines()
+        line = [l for l in p.stderr.splitlines() if l.startswith("blastn_prelim: batch plan " + plan)]
+        assert len(line) == 1, p.stderr[-1500:]
+        plan_items = [x.split("/") for x in line[0].split(": ")[-1].split()]
+        asked = [int(x[0]) for x in plan_items]; taken = [int(x[1]) for x in plan_items]
+        hits = [int(x) for x in [l for l in p.stderr.splitlines() if l.startswith("blastn_prelim: hits per batch")][0].split(":")[-1].split()]
+        if plan == "fixed":
+            assert asked == [5000000] and taken == [46]
+        else:
+            assert len(asked) >= 3 and asked[0] == 10000 and sum(taken) == 46, (asked, taken, hits)
+            if mode == "1":     # one batch at a time: exactly the reference's sequence
+                assert asked == _mixer_sizes(hits, target=40, most=12000)[:len(asked)], (asked, hits)
+            lens = [len(s) for _, s in qs]; i = 0
+            for a_, t_ in zip(asked, taken):        # whole queries until the bases asked for are there
+                acc = n = 0
+                while i + n < len(lens) and acc < a_:
+                    acc += lens[i + n]; n += 1
+                assert n == t_; i += n
+    assert len(rows["mixer"]) >= 40 and rows["mixer"] == rows["fixed"]
