@@ -33,6 +33,7 @@ Engine *g_eng[kMaxDevices];
 std::mutex g_eng_mu;
 int g_default_dev = -1;
 thread_local Engine *tl_eng = nullptr;
+thread_local Engine *tl_mu_owner = nullptr;
 thread_local int tl_sel = -1;
 
 // the calling thread's engine for calls that create batches / shards: its chosen device, else the process default,

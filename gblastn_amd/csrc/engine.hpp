@@ -163,6 +163,7 @@ struct Engine {
                        // (bin_rec, bin_tcur) go back to the pool then, and `complete` with them.
                        uint16_t *run_fp = nullptr; uint32_t *run_pos = nullptr; uint32_t *run_start = nullptr; size_t run_n = 0, run_cells = 0;
                        bool runs = false, runs_failed = false; int hits = 0;
+                       bool in_use = false;                    // the pass that is being scanned reads (or writes) this set: not to be evicted for memory
                        size_t run_bytes() const { return run_fp ? run_n * 6 + 16 + (run_cells + 1) * 4 : 0; }
                        size_t bytes() const { return bin_rec_cap * 8 + bin_tcur_cap * 4 + bin_count_cap * 4 + run_bytes(); } };
     // Record cache (the default): bin once, probe many.  Complete record sets stay resident, least recently
@@ -218,6 +219,17 @@ extern int g_default_dev;
 extern thread_local Engine *tl_eng;         // the engine the calling thread is working with (set by enter)
 extern thread_local int tl_sel;             // gbn_use_device
 #define E (*gbn::tl_eng)
+// the engine whose lock the calling thread holds (EngLock below): what lets an allocation that fails give cached records up
+extern thread_local Engine *tl_mu_owner;
+struct EngLock {                            // std::lock_guard over Engine::mu that says so
+    Engine &e; bool held;
+    explicit EngLock(Engine &en) : e(en), held(true) { e.mu.lock(); tl_mu_owner = &e; }
+    EngLock(Engine &en, std::try_to_lock_t) : e(en), held(en.mu.try_lock()) { if (held) tl_mu_owner = &e; }
+    bool owns_lock() const { return held; }
+    ~EngLock() { if (held) { tl_mu_owner = nullptr; e.mu.unlock(); } }
+    EngLock(const EngLock &) = delete; EngLock &operator=(const EngLock &) = delete;
+};
+size_t rec_evict_for_memory();              // engine_scan.cpp: the record cache's sets that no pass is using go (bytes given up)
 int engine_init(int dev, Engine **out);
 inline void enter(Engine *e) { tl_eng = e; if (e && e->device >= 0) (void)hipSetDevice(e->device); }
 int enter_current();
@@ -232,7 +244,10 @@ int pool_poison();
 template <class T> inline int dev_alloc(T *&p, size_t n) {
     p = nullptr;
     if (n == 0) n = 1;
-    const hipError_t e = pool_alloc((void **)&p, n * sizeof(T));
+    hipError_t e = pool_alloc((void **)&p, n * sizeof(T));
+    // the device is full while gigabytes of evictable scan records are resident: they go, once -- if this thread
+    // holds the engine's lock (a search, a call of the cache's own entry points): nobody else is walking the cache then
+    if (e == hipErrorOutOfMemory && tl_eng && tl_mu_owner == tl_eng && rec_evict_for_memory() > 0) { (void)hipGetLastError(); e = pool_alloc((void **)&p, n * sizeof(T)); }
     if (e == hipErrorOutOfMemory) { (void)hipGetLastError(); p = nullptr; set_error("out of device memory (" + std::to_string(n * sizeof(T)) + " bytes asked for)"); return GBN_ERR_NOMEM; }
     HIPCHK(e);
     return GBN_OK;

@@ -110,7 +110,7 @@ int gbn_record_cache_set_limit(long long bytes) {
     return gbn::guard(__func__, [&]() -> int {
     const int rc = enter_current();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(E.mu);
+    gbn::EngLock lk(E);
     E.rec_limit = bytes < 0 ? -1 : bytes;
     if (E.ahead.valid) { (void)hipStreamSynchronize(E.stream); E.ahead.valid = false; E.ahead_misses++; }     // (a binning kernel queued ahead: done before buffers change hands)
     E.last_key_valid = false;
@@ -126,7 +126,7 @@ int gbn_record_cache_invalidate(void) {
     return gbn::guard(__func__, [&]() -> int {
     const int rc = enter_current();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(E.mu);
+    gbn::EngLock lk(E);
     for (RecordSet *r : E.rec_sets) { if (r->queued) (void)hipStreamSynchronize(E.stream); r->complete = false; r->queued = false; recset_free_runs(*r); }
     E.scratch.complete = false;
     if (E.ahead.valid) { (void)hipStreamSynchronize(E.stream); E.ahead.valid = false; }
@@ -139,7 +139,7 @@ int gbn_record_cache_stats(long long *out, int n) {
     if (!out || n < 0) return GBN_ERR_ARG;
     const int rc = enter_current();
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(E.mu);
+    gbn::EngLock lk(E);
     long long sorted = 0, sorted_bytes = 0;
     for (const RecordSet *r : E.rec_sets) if (r->runs) { sorted++; sorted_bytes += (long long)r->run_bytes(); }
     const long long v[14] = {rec_limit_bytes(), (long long)rec_held_bytes(), (long long)E.rec_sets.size(), E.rec_hits, E.rec_misses, E.rec_evictions, E.rec_bypass, E.ahead_hits, E.rec_prepared,
@@ -264,7 +264,7 @@ void gbn_release_db_memory(void) {
 }
 
 static void release_engine() {              // (the calling thread has entered it)
-    std::lock_guard<std::mutex> lk(E.mu);
+    gbn::EngLock lk(E);
     if (!E.ready) return;
     (void)wait_pending();
     (void)hipDeviceSynchronize();                       // nothing of ours is queued or running when buffers, streams and events go
@@ -367,6 +367,20 @@ int gbn_set_max_dbseq_len(int32_t n) {
     });
 }
 
+// a shard's slab: when the device is full the record cache's sets (and the pool's idle blocks) go first, once (a
+// block uploaded on a cold cache after earlier groups were searched used to fail while gigabytes of evictable records were held)
+static hipError_t db_malloc(uint8_t **p, size_t bytes) {
+    hipError_t e = hipMalloc((void **)p, bytes);
+    if (e != hipErrorOutOfMemory) return e;
+    (void)hipGetLastError();
+    size_t freed = 0;
+    { gbn::EngLock lk(E); freed = rec_evict_for_memory(); }
+    pool_drain(E.device);
+    (void)freed;
+    e = hipMalloc((void **)p, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
+}
 int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_seqs,
                const int64_t *byte_off, const int32_t *len, int32_t first_oid, int is_device) {
     return gbn::guard(__func__, [&]() -> int {
@@ -390,7 +404,7 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
         if (is_device) { db->d_packed = packed; db->owns = false; }
         else {
             uint8_t *p = nullptr;
-            if (hipMalloc((void **)&p, (size_t)nbytes) != hipSuccess) { delete db; set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
+            if (db_malloc(&p, (size_t)nbytes) != hipSuccess) { delete db; set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
             if (hipMemcpy(p, packed, (size_t)nbytes, hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(p); delete db; set_error("H2D(db) failed"); return GBN_ERR_HIP; }
             g_db_bytes_uploaded += (long long)nbytes;
             db->d_packed = p; db->owns = true;
@@ -416,7 +430,7 @@ int gbn_db_new(GbnDb **out, const uint8_t *packed, int64_t nbytes, int32_t num_s
         }
         db->num_seqs = (int32_t)db->len.size(); db->nbytes = pos + 128;
         uint8_t *p = nullptr;
-        if (hipMalloc((void **)&p, (size_t)db->nbytes) != hipSuccess) { delete db; set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
+        if (db_malloc(&p, (size_t)db->nbytes) != hipSuccess) { delete db; set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
         // (the bytes between the chunk copies: defined, like the pad bytes of a caller's slab)
         if (hipMemset(p, pool_poison() >= 0 ? pool_poison() : 0, (size_t)db->nbytes) != hipSuccess) { (void)hipFree(p); delete db; set_error("hipMemset(db) failed"); return GBN_ERR_HIP; }
         db->d_packed = p; db->owns = true;
@@ -470,7 +484,7 @@ int gbn_db_new_streamed(GbnDb **out, int64_t nbytes, int32_t num_seqs, const int
         pieces.push_back(pc); i = j;
     }
     uint8_t *p = nullptr;
-    if (hipMalloc((void **)&p, (size_t)nbytes) != hipSuccess) { (void)hipGetLastError(); set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
+    if (db_malloc(&p, (size_t)nbytes) != hipSuccess) { set_error("hipMalloc(db) failed"); return GBN_ERR_NOMEM; }
     hipEvent_t zeroed = nullptr;
     bool ok = hipEventCreateWithFlags(&zeroed, hipEventDisableTiming) == hipSuccess &&
               hipMemsetAsync(p, 0, (size_t)nbytes, E.stream) == hipSuccess && hipEventRecord(zeroed, E.stream) == hipSuccess;
@@ -557,7 +571,7 @@ static void free_db_now(GbnDb *db) {
     if (!db->engine) { delete db; return; }
     enter(static_cast<Engine *>(db->engine));
     {   // a stage in flight may still read this shard
-        std::lock_guard<std::mutex> lk(E.mu);
+        gbn::EngLock lk(E);
         if (E.has_pending) (void)wait_pending();
         wait_host();
         if (E.ahead.valid && E.ahead.key.db == (const void *)db) { (void)hipStreamSynchronize(E.stream); E.ahead.valid = false; }    // (a binning kernel queued ahead reads the shard)
@@ -714,7 +728,7 @@ void gbn_batch_free(GbnBatch *b) {
     if (b->dev && b->dev->eng) {
         enter(b->dev->eng);
         // an extension stage still reading this batch finishes first (its memory goes back to the pool, not to hipFree)
-        if (E.pending_batch_pub.load(std::memory_order_acquire) == b) { std::lock_guard<std::mutex> lk(E.mu); if (E.has_pending && E.pending_batch == b) (void)wait_pending_gpu(); }
+        if (E.pending_batch_pub.load(std::memory_order_acquire) == b) { gbn::EngLock lk(E); if (E.has_pending && E.pending_batch == b) (void)wait_pending_gpu(); }
         wait_tail(b->host_tail);                            // (a queued host replay reads the batch's options and contexts; the engine is not locked meanwhile)
     }
     free_device_batch(b->dev);
@@ -742,7 +756,7 @@ void gbn_results_free(GbnResults *r) {
     if (!r) return;
     if (r->engine) {                                        // a stage of the engine that filled them may still write to them
         enter(static_cast<Engine *>(r->engine));
-        if (E.pending_res_pub.load(std::memory_order_acquire) == r) { std::lock_guard<std::mutex> lk(E.mu); if (E.has_pending && E.pending_res == r) (void)wait_pending_gpu(); }
+        if (E.pending_res_pub.load(std::memory_order_acquire) == r) { gbn::EngLock lk(E); if (E.has_pending && E.pending_res == r) (void)wait_pending_gpu(); }
         wait_tail(r->host_tail);
         { std::lock_guard<std::mutex> lk2(E.failed_mu); E.failed.erase(r); }
     }
@@ -807,7 +821,7 @@ int gbn_db_prepare_records(GbnDb *db, const GbnOptions *opt, int32_t nq, const i
     if (!E.ready) { set_error("the engine was released (gbn_release) after this shard was made"); return GBN_ERR_ARG; }
     // (a search is running on this device: its pass bins, or has found the records -- a set-up thread of a pipelined caller is
     // not to wait here for the length of a scan)
-    std::unique_lock<std::mutex> lk(E.mu, std::try_to_lock);
+    gbn::EngLock lk(E, std::try_to_lock);
     if (!lk.owns_lock()) return GBN_OK;
     int type = 0, lut = 0, step = 0;
     gbn::predict_table_shape(*opt, nq, lens, type, lut, step);
@@ -866,7 +880,7 @@ static int search_enter(GbnBatch *batch, GbnDb *db, GbnResults *results) {
 static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
                       int keep_stages, GbnInterruptFn interrupt, void *progress, int overlap) {
     int rc = GBN_OK;
-    std::lock_guard<std::mutex> lk(E.mu);                   // (the caller has entered the engine: search_enter)
+    gbn::EngLock lk(E);                   // (the caller has entered the engine: search_enter)
     results->engine = tl_eng; results->diag = diag;
     results->merge.kbp_gap = batch->kbp_gap; results->merge.evalue = batch->opt.evalue; results->merge.eff_searchsp.clear();
     for (const GbnContext &c : batch->ctx) results->merge.eff_searchsp.push_back(c.eff_searchsp);
@@ -916,7 +930,7 @@ int gbn_prelim_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagno
     int rc = search_enter(batch, db, results);
     if (rc) return rc;
     rc = run_search(batch, db, results, diag, keep_stages, interrupt, progress, 0);
-    std::lock_guard<std::mutex> lk(E.mu);
+    gbn::EngLock lk(E);
     (void)wait_pending();                               // of an earlier gbn_prelim_search_begin (its status stays with its results)
     const int rc2 = take_failure(results);
     if (!rc && !rc2 && results->chunk_len > 0) { merge_chunk_lists(results->hsps, results->chunk_len, results->merge, results->diag); results->chunk_len = 0; }
@@ -988,7 +1002,7 @@ int gbn_prelim_search_end(GbnResults *results) {
     // other thread may be inside gbn_prelim_search_begin of the next pass meanwhile.
     int rc;
     if (!results || E.pending_res_pub.load(std::memory_order_acquire) == results) {     // (a stage of other results, or none: no need for the lock -- the caller's other thread may hold it for the length of a scan)
-        std::lock_guard<std::mutex> lk(E.mu);
+        gbn::EngLock lk(E);
         if (!results) { (void)wait_pending(); return GBN_OK; }
         if (E.has_pending && E.pending_res == results) (void)wait_pending_gpu();
     }
@@ -1004,7 +1018,7 @@ int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag)
     if (!batch || !db || repeats <= 0) { set_error("bad argument"); return GBN_ERR_ARG; }
     int rc = params_ready(batch, db);                       // (enters the engine both live on)
     if (rc) return rc;
-    std::lock_guard<std::mutex> lk(E.mu);
+    gbn::EngLock lk(E);
     auto t0 = std::chrono::steady_clock::now();
     unsigned long long cnt[2] = {0, 0};
     for (int r = 0; r < repeats; r++) {

@@ -63,8 +63,22 @@ long long rec_limit_bytes() {
     if (gbn::switch_is_set("GBN_RECORD_CACHE_MB")) return std::max(0ll, gbn::switch_value("GBN_RECORD_CACHE_MB", 0)) << 20;
     static thread_local long long dflt[kMaxDevices];        // (per device; the query costs a driver call)
     long long &d = dflt[E.device >= 0 && E.device < kMaxDevices ? E.device : 0];
-    if (d == 0) { size_t fr = 0, tot = 0; d = hipMemGetInfo(&fr, &tot) == hipSuccess && tot ? (long long)(tot / 4) : (64ll << 30); }
+    // a quarter of the device's memory, and never more than half of what is FREE when the cache is first used: resident
+    // shards count (the limit used to ignore them)
+    if (d == 0) { size_t fr = 0, tot = 0; d = hipMemGetInfo(&fr, &tot) == hipSuccess && tot ? (long long)std::min(tot / 4, std::max<size_t>(fr / 2, (size_t)1 << 30)) : (64ll << 30); }
     return d;
+}
+// an allocation failed: every set no pass is using goes back to the driver (the pool's idle blocks went before the caller's
+// second attempt: pool_alloc).  Called with the engine's lock held (dev_alloc checks).
+size_t rec_evict_for_memory() {
+    size_t freed = 0;
+    for (size_t i = E.rec_sets.size(); i-- > 0; ) {
+        if (E.rec_sets[i]->in_use) continue;
+        freed += E.rec_sets[i]->bytes();
+        rec_drop(i, true);
+    }
+    if (freed) pool_drain(E.device);
+    return freed;
 }
 size_t rec_held_bytes() { size_t n = 0; for (const RecordSet *r : E.rec_sets) n += r->bytes(); return n; }
 void rec_drop(size_t i, bool evicted) {
@@ -291,6 +305,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     bool repeat_seen = false;                   // cache off: the pass before this one had the same key
     bool counted = false;                       // the cache's hit / miss of this call is counted (a range scanned again counts once)
     bool used_runs = false;                     // the pass went over sorted records
+    struct NotInUse { ~NotInUse() { for (RecordSet *c : E.rec_sets) c->in_use = false; } } not_in_use_on_return;     // (in_use: a failing allocation may not evict the pass's own set)
     if (E.seed_copy_pending) { HIPCHK(hipStreamWaitEvent(E.stream, E.ev_seed, 0)); E.seed_copy_pending = false; }
     for (;;) {
         bool binned_ahead = false; int hit_pair = -1;
@@ -362,6 +377,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             }
             if (!hit && !ahead_hit) HIPCHK(hipMemsetAsync(rs->bin_count + nstream, 0, 16, E.stream));     // (records that exist already: the flag of THAT launch is read back below)
             rs->stamp = ++E.rec_clock;
+            for (RecordSet *c : E.rec_sets) c->in_use = (c == rs);
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
             B.S = P; B.nb = nb; B.cbits = GBN_BIN_CBITS(b.lut.lut); B.nwriters = nwriters; dbg_nwriters = nwriters; dbg_subcap = (uint32_t)subcap;
             B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfrbits = std::min(7, 2 * b.dev->fr);

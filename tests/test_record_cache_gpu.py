@@ -307,3 +307,39 @@ def test_records_prepared_ahead_of_the_batch(cache_default):
     ps = api.BlastPrelimSearch(qa, opt, src)
     assert ps.run()["hsps"].tobytes() == want["a"]
     ps.close(); src.close()
+
+
+def test_a_full_device_gives_cached_records_up(cache_default):
+    """the cache is on by default and used to hold on to its sets while the allocation of a new shard failed.  A 2 Gbp
+    shard is searched (its record set stays resident: ~1 GB), the rest of the device is taken away, and a second shard that does
+    not fit next to the records is uploaded: the set goes (an eviction), the upload succeeds, and both shards still give their
+    results (the first one bins again)."""
+    import torch
+    from gblastn_amd import synth
+    nsub, slen = 2000, 1_000_000
+    db = synth.SynthDb(nsub, slen, seed=77)
+    slab = torch.empty(db.nbytes, dtype=torch.uint8, device="cuda")
+    api._check(api.lib().gbn_synth_fill(slab.data_ptr(), db.nbytes, db.seed, None))
+    src = api.BlastSeqSrc.from_slab((slab.data_ptr(), db.nbytes), db.byte_off, db.lens, is_device=True, keep=slab)
+    queries, plants = synth.make_queries(400, db)
+    opt = api.default_options("megablast", db_length=nsub * slen, db_num_seqs=nsub)
+    ps = api.BlastPrelimSearch(queries, opt, src)
+    want = ps.run()["hsps"].tobytes()
+    st0 = api.record_cache_stats()
+    assert st0["sets"] >= 1 and st0["bytes"] > 500_000_000
+    # a second shard, on the host for now
+    small = util.small_case(40, 10_000_000, 4, task="megablast", seed=3)
+    subjects2 = small[3]
+    need = sum(len(p) for p, n in subjects2)                         # ~100 MB
+    torch.cuda.synchronize()
+    free, total = torch.cuda.mem_get_info()
+    hog = torch.empty(free - need // 2, dtype=torch.uint8, device="cuda")      # less than the second shard needs is left
+    src2 = api.BlastSeqSrc.from_packed(subjects2)                   # hipMalloc fails, the cached set goes, the second attempt succeeds
+    st1 = api.record_cache_stats()
+    assert st1["evictions"] > st0["evictions"] and st1["bytes"] < st0["bytes"]
+    del hog
+    torch.cuda.empty_cache()
+    assert ps.run()["hsps"].tobytes() == want                       # (bins again)
+    ps2 = api.BlastPrelimSearch(small[1], small[4], src2)
+    assert len(ps2.run()["hsps"]) >= 1
+    ps.close(); ps2.close(); src.close(); src2.close()
