@@ -5,6 +5,7 @@
 // Mirrors what the reference hands INTO its GPU boundary (query, query_info,
 // sbp, lookup_wrap): CORE/blast_setup.c:502-775, CORE/blast_parameters.c:160-470,
 // :822-979, CORE/blast_nalookup.c:51-189,384-427,831-1041, CORE/blast_lookup.c:87-137.
+#include <unistd.h>
 #include "gbn_host.hpp"
 #include <functional>
 #include <thread>
@@ -41,19 +42,37 @@ public:
         const size_t pieces = std::max<size_t>(1, std::min<size_t>((size_t)size() + 1, n / std::max<size_t>(grain, 1)));
         if (pieces <= 1) { f(0, n); return; }
         std::mutex dmu; std::condition_variable dcv; size_t left = pieces - 1;
+        std::exception_ptr failed;                      // what a piece threw (a worker must not take the process down: ADVICE r05): rethrown on the caller
         {
             std::lock_guard<std::mutex> lk(mu_);
             for (size_t p = 1; p < pieces; p++)
-                jobs_.emplace_back([&, p] { f(n * p / pieces, n * (p + 1) / pieces); std::lock_guard<std::mutex> dl(dmu); if (--left == 0) dcv.notify_one(); });
+                jobs_.emplace_back([&, p] {
+                    std::exception_ptr ex;
+                    try { f(n * p / pieces, n * (p + 1) / pieces); } catch (...) { ex = std::current_exception(); }
+                    std::lock_guard<std::mutex> dl(dmu);
+                    if (ex && !failed) failed = ex;
+                    if (--left == 0) dcv.notify_one();
+                });
         }
         cv_.notify_all();
-        f(0, n / pieces);
-        std::unique_lock<std::mutex> dl(dmu); dcv.wait(dl, [&] { return left == 0; });
+        std::exception_ptr mine;
+        try { f(0, n / pieces); } catch (...) { mine = std::current_exception(); }
+        { std::unique_lock<std::mutex> dl(dmu); dcv.wait(dl, [&] { return left == 0; }); }     // (the pieces refer to this frame: waited for whatever happened)
+        if (mine) std::rethrow_exception(mine);
+        if (failed) std::rethrow_exception(failed);
     }
 };
+// One pool per PROCESS: after fork() (Python's multiprocessing, default start method) the child has the parent's pool object
+// and none of its threads -- jobs would wait for ever.  The child makes its own; the parent's object is left alone there (its
+// thread handles belong to threads that do not exist in this process: neither joined nor destroyed).
 SetupPool &setup_pool() {
-    static SetupPool pool((int)std::max(2u, std::min(31u, std::max(1u, std::thread::hardware_concurrency()) / 8u)));     // (a 256-thread host: 31 workers + the caller; eight ranks of a node each have their own)
-    return pool;
+    static std::mutex mu; static SetupPool *pool = nullptr; static pid_t owner = 0;
+    std::lock_guard<std::mutex> lk(mu);
+    if (!pool || owner != getpid()) {
+        pool = new SetupPool((int)std::max(2u, std::min(31u, std::max(1u, std::thread::hardware_concurrency()) / 8u)));     // (a 256-thread host: 31 workers + the caller; eight ranks of a node each have their own)
+        owner = getpid();
+    }
+    return *pool;
 }
 }  // namespace
 

@@ -354,9 +354,27 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             if (rec_limit > 0) {
                 // ---- record cache: a complete set of this shape whose streams are at least as long as this attempt asks for
                 if (AH.valid) { AH.valid = false; E.ahead_misses++; HIPCHK(hipStreamSynchronize(E.stream)); }     // (a kernel queued ahead writes the other scratch set, which may change hands below)
-                rs = rec_find(key);
-                if (rs) { hit = true; subcap = rs->key.subcap; key.subcap = subcap; if (!counted) { E.rec_hits++; if (!rs->queued) rs->hits++; } }     // (a set queued by gbn_db_prepare_records: this pass is the one that would have binned)
-                else { if (!counted) E.rec_misses++; if ((rc = rec_acquire(key, BL, rec_limit, &rs))) return rc; }
+                // (a rare-path segment overflowed and the range is scanned again with a set larger than the cache: the records this call
+                // binned into the passes' own scratch set are still there -- ADVICE r05: rec_find does not look at scratch)
+                const bool scratch_again = binned_here && rs == &E.scratch && rs->complete && rs->key.same_shape(key);
+                if (!scratch_again) rs = rec_find(key);
+                if (scratch_again) { hit = true; subcap = rs->key.subcap; key.subcap = subcap; }
+                else if (rs) { hit = true; subcap = rs->key.subcap; key.subcap = subcap; if (!counted) { E.rec_hits++; if (!rs->queued) rs->hits++; } }     // (a set queued by gbn_db_prepare_records: this pass is the one that would have binned)
+                else {
+                    if (!counted) E.rec_misses++;
+                    // a set gbn_db_prepare_records queued for this shard that no pass has taken (the batch came out with another table
+                    // shape than its unmasked lengths predicted -- ADVICE r05): its kernel is done by now or soon; its overflow word
+                    // decides whether it is a complete set of ITS shape, and it stops being "queued"
+                    for (RecordSet *c : E.rec_sets)
+                        if (c->queued && c->key.db == key.db) {
+                            uint32_t ov = 1;
+                            const size_t ns = (size_t)c->key.nb * (size_t)c->key.nwriters;
+                            HIPCHK(hipStreamSynchronize(E.stream));
+                            if (c->bin_count && hipMemcpy(&ov, c->bin_count + ns, 4, hipMemcpyDeviceToHost) != hipSuccess) ov = 1;
+                            c->queued = false; c->complete = ov == 0;
+                        }
+                    if ((rc = rec_acquire(key, BL, rec_limit, &rs))) return rc;
+                }
                 counted = true;
             } else {
                 rs = &E.scratch;

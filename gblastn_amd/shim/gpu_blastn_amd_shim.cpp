@@ -339,8 +339,11 @@ Int2 Blast_gpu_RunPreliminarySearchWithInterrupt(EBlastProgramType program,
         }
         if (blocks.empty() || rc != GBN_OK) break;
         // the group as one shard; blocks whose slabs lie too far apart for a view are searched one by one
+        // (GBN_ERR_UNSUPPORTED: no view over these blocks -- one by one; anything else, out of memory included, is the call's failure)
         GbnDb* view = NULL;
-        const bool one = rc == GBN_OK && gbn_block_view(blocks.data(), (int32_t)blocks.size(), &view) == GBN_OK && view;
+        const int vrc = rc == GBN_OK ? gbn_block_view(blocks.data(), (int32_t)blocks.size(), &view) : rc;
+        const bool one = vrc == GBN_OK && view;
+        if (rc == GBN_OK && vrc != GBN_OK && vrc != GBN_ERR_UNSUPPORTED) { rc = vrc; break; }
         if (!batch && rc == GBN_OK) {
             // (the first group's scan records are binned underneath the set-up of the query batch when they are not resident yet:
             // the binning kernel needs no lookup table -- gbn_db_prepare_records returns at once, and does nothing when they are)

@@ -113,3 +113,30 @@ def test_masked_setup_matches_oracle_and_rejects_bad_masks():
     for bad in ([(0, 10, 5)], [(0, 10, 2000)], [(12, 1, 2)], [(0, 10, 50), (0, 40, 60)], [(-1, 0, 1)]):
         with pytest.raises(api.BlastError):
             api.BlastPrelimSearch(qs, gopt, upload=False, masks=bad)
+
+
+def test_batch_setup_in_a_forked_child():
+    """the set-up's worker pool lives with the library; a child made by fork() (multiprocessing's default start method)
+    has the parent's pool object and none of its threads.  The parent sets a batch up (the pool exists), forks, and the child sets
+    one up by itself -- the per-context loops of 800 contexts are spread over workers -- and reports the same cut-offs."""
+    import os
+    rng = np.random.default_rng(3)
+    qs = [rng.integers(0, 4, 1000, dtype=np.uint8) for _ in range(400)]
+    gopt = api.default_options("megablast", db_length=50_000_000_000, db_num_seqs=50_000)
+    want = [c.cutoff_score for c in api.BlastPrelimSearch(qs, gopt, upload=False).contexts]
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        try:
+            got = [c.cutoff_score for c in api.BlastPrelimSearch(qs, gopt, upload=False).contexts]
+            os.write(w, b"ok" if got == want else b"differs")
+        finally:
+            os._exit(0)
+    os.close(w)
+    import select
+    ready, _, _ = select.select([r], [], [], 60)
+    out = os.read(r, 16) if ready else b"timeout"
+    if not ready:
+        os.kill(pid, 9)
+    os.waitpid(pid, 0)
+    assert out == b"ok", out
