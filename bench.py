@@ -67,6 +67,10 @@ def parse():
     ap.add_argument("--record-cache", choices=["default", "on", "off"], default="default",
                     help="the library's record cache (bin once, probe many).  default: OFF for the C2 / C3 headline (every pass bins: "
                          "the north_star scan), ON -- the library's own default -- for C4 and the shim workload")
+    ap.add_argument("--skew", action="store_true",
+                    help="repeats over the synthetic database (gbn_synth_skew: 8 %% of every subject as homopolymer runs / tandem repeats, a 1,200-base family "
+                         "element in one subject of fifty) and 2 %% of the queries carrying a piece of the family element; reports rescans, direct-kernel "
+                         "ranges and library sorts beside the step")
     ap.add_argument("--strong", action="store_true",
                     help="N > 1: strong scaling -- the --subjects of ONE shard are divided among the ranks (fixed total work) instead of every rank holding --subjects (weak, the default)")
     a = ap.parse_args()
@@ -126,11 +130,13 @@ def main():
 
     # ---- database shard of this rank, generated in HBM ----
     nsub, slen = args.subjects, args.subject_len
-    layouts = [synth.SynthDb(nsub, slen, seed=0x9E3779B97F4A7C15 ^ (r + 1), first_oid=r * nsub)
+    layouts = [synth.SynthDb(nsub, slen, seed=0x9E3779B97F4A7C15 ^ (r + 1), first_oid=r * nsub, skew=args.skew)
                for r in range(world)]
     mine = layouts[rank]
     slab = torch.empty(mine.nbytes, dtype=torch.uint8, device=dev)
     api._check(api.lib().gbn_synth_fill(slab.data_ptr(), mine.nbytes, mine.seed, None))
+    if args.skew:
+        mine.skew_on_device(api, slab.data_ptr())
     src = api.BlastSeqSrc.from_slab((slab.data_ptr(), mine.nbytes), mine.byte_off, mine.lens,
                                     first_oid=mine.first_oid, is_device=True, keep=slab)
     total_bases_global = world * nsub * slen
@@ -146,7 +152,8 @@ def main():
                     self._cache.clear()
                 self._cache[g] = layouts[g // nsub].subject_bases(g % nsub)
             return self._cache[g]
-    queries, plants = synth.make_queries(args.queries, AnyShard())
+    AnyShard.seed = layouts[0].seed
+    queries, plants = synth.make_queries(args.queries, AnyShard(), family_fraction=0.02 if args.skew else 0.0)
     task = "blastn" if args.workload == "C3" else "megablast"
     opt = api.default_options(task, db_length=total_bases_global, db_num_seqs=world * nsub)
     nbatch = (len(queries) + args.batch_queries - 1) // args.batch_queries
@@ -160,10 +167,14 @@ def main():
     if args.workload == "C4":
         return bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, total_bases_global, nsub, slen, queries)
 
+    # --skew: the queries are DUST-filtered as blastn filters them by default (a planted slice of a poly-A stretch would otherwise seed at
+    # every scan position of every poly-A stretch of the database: 5e10 seeds); the masks are the caller's input, made once
+    qmasks = [api.dust_masks(queries[i * args.batch_queries:(i + 1) * args.batch_queries]) if args.skew else None for i in range(nbatch)]
+
     def make(k):
         """set-up of the query batch of pass k from scratch: concatenation, Karlin-Altschul parameters,
         cut-offs on the host; lookup structures built on the device"""
-        return api.BlastPrelimSearch(qsets[k % nbatch], opt, src)
+        return api.BlastPrelimSearch(qsets[k % nbatch], opt, src, masks=qmasks[k % nbatch])
 
     def merge(nq, out):
         # exchange + merge step: gather to rank 0, replay through the per-query top-N collector
@@ -469,6 +480,15 @@ def main():
                 "seeds_per_pass": seeds / max(launches, 1),
                 "lookup_hits_per_pass": lookup_hits / max(launches, 1),
                 "other_workloads": others,
+                "skew": None if not args.skew else {
+                    "what": "gbn_synth_skew over the shard (8 % of every subject homopolymer runs / tandem repeats, a 1,200-base family element in one subject "
+                            "of fifty), 2 % of the queries carry a piece of the element; parity of this shape against the oracle: "
+                            "tests/test_workload_size_gpu.py::test_skewed_shard_against_the_oracle",
+                    "ranges_per_pass": sum(d.ranges for d in diags) / max(args.steps, 1), "scan_launches_per_pass": launches / max(args.steps, 1),
+                    "rescans_per_pass": sum(d.scan_rescans for d in diags) / max(args.steps, 1),
+                    "direct_kernel_ranges_per_pass": sum(d.direct_ranges for d in diags) / max(args.steps, 1),
+                    "library_sort_launches_per_pass": sum(d.library_sorts for d in diags) / max(args.steps, 1),
+                    "seeds_per_pass": seeds / max(args.steps, 1), "init_hits_per_pass": sum(d.good_init_extends for d in diags) / max(args.steps, 1)},
             },
             "roofline": {"bound": "hbm", "kernel": dom_label,
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

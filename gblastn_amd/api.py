@@ -47,7 +47,8 @@ class GbnDiagnostics(C.Structure):
                 ("bin_kernel_ms", C.c_double), ("probe_kernel_ms", C.c_double),
                 ("rare_kernel_ms", C.c_double), ("scan_stage_ms", C.c_double),
                 ("seed_stage_ms", C.c_double), ("gapped_stage_ms", C.c_double),
-                ("host_stage_ms", C.c_double), ("kernel_ms", C.c_double * 8)]
+                ("host_stage_ms", C.c_double), ("kernel_ms", C.c_double * 8),
+                ("ranges", C.c_int64), ("scan_rescans", C.c_int64), ("direct_ranges", C.c_int64), ("library_sorts", C.c_int64)]
     KERNEL_CLASSES = ["seed keys", "seed order (radix sort / seed_order kernels)", "seed_ext_ck_kernel + seed_exact_kernel", "diag_replay_kernel", "diag_ungapped_kernel",
                       "dynprog_lane_kernel", "dynprog_wave_kernel / greedy_wave_kernel", "dynprog_kernel / greedy_kernel"]
 
@@ -66,7 +67,7 @@ IHIT_DT = np.dtype([("oid", "<i4"), ("q_off", "<i4"), ("s_off", "<i4"), ("q_star
                     ("s_start", "<i4"), ("length", "<i4"), ("score", "<i4"), ("pad_", "<i4")])
 
 EXPORTS = ["gbn_init", "gbn_release", "gbn_release_db_memory", "gbn_debug_check_guards", "gbn_device_count", "gbn_use_device", "gbn_current_device", "gbn_db_device", "gbn_shard_builder_add_oid", "gbn_default_options",
-           "gbn_db_new", "gbn_db_new_streamed", "gbn_db_free", "gbn_db_total_bases", "gbn_db_num_seqs", "gbn_synth_fill",
+           "gbn_db_new", "gbn_db_new_streamed", "gbn_db_free", "gbn_db_total_bases", "gbn_db_num_seqs", "gbn_synth_fill", "gbn_synth_skew",
            "gbn_batch_new", "gbn_batch_new_ex", "gbn_batch_new_masked", "gbn_dust_mask", "gbn_batch_free", "gbn_batch_num_contexts", "gbn_batch_contexts",
            "gbn_batch_lut_type", "gbn_batch_lut_width", "gbn_batch_scan_step", "gbn_batch_scan_path",
            "gbn_batch_diag_container", "gbn_batch_gap_x_dropoff", "gbn_results_new",
@@ -181,6 +182,7 @@ def lib():
         L.gbn_db_total_bases.restype = C.c_int64; L.gbn_db_total_bases.argtypes = [C.c_void_p]
         L.gbn_db_num_seqs.restype = C.c_int32; L.gbn_db_num_seqs.argtypes = [C.c_void_p]
         L.gbn_synth_fill.argtypes = [C.c_void_p, C.c_int64, C.c_uint64, C.c_void_p]
+        L.gbn_synth_skew.argtypes = [C.c_void_p, C.c_int64, C.c_int64, C.c_int64, C.c_int32, C.c_int64, C.c_uint64, C.c_void_p]
         L.gbn_batch_new.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GbnOptions), C.c_int32,
                                     C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
         L.gbn_batch_new_ex.argtypes = [C.POINTER(C.c_void_p), C.POINTER(GbnOptions), C.c_int32,

@@ -43,6 +43,7 @@ size_t seed_order_scratch_words(int64_t n, int nsubj, int group_bits);
 hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st, GbnKernelTimer *kt = nullptr);
 hipError_t launch_gapped(const GbnGapParams &p, bool greedy, hipStream_t st, GbnKernelTimer *kt = nullptr);
 hipError_t launch_synth_fill(void *dev, int64_t nbytes, uint64_t seed, hipStream_t st);
+hipError_t launch_synth_skew(void *dev, int64_t first_off, int64_t stride, int64_t nb, int32_t num, int64_t first_oid, uint64_t seed, hipStream_t st);
 hipError_t launch_gather_bytes(const uint8_t *src, const int64_t *src_off, const int64_t *dst_off, const int32_t *nbytes,
                                int32_t n, uint8_t *dst, hipStream_t st);
 hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
@@ -154,7 +155,11 @@ struct Engine {
                     bool operator==(const RecKey &o) const { return same_shape(o) && subcap == o.subcap; } };
     struct RecordSet { unsigned long long *bin_rec = nullptr; size_t bin_rec_cap = 0;      // records (all bins)
                        uint32_t *bin_tcur = nullptr; size_t bin_tcur_cap = 0;              // per-run stream cursors (6-byte records)
-                       uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;            // [nb][nwriters] + overflow flag
+                       uint32_t *bin_count = nullptr; size_t bin_count_cap = 0;            // [nb][nwriters] + overflow flag (4 words) + [nb][nwriters] uncapped totals
+                       // streams of bins that differ in size (repeat-rich subjects): {capacity, offset in a writer's row} per bin on the
+                       // device, records per row; null: uniform streams of key.subcap records.  Made from the totals of an attempt that
+                       // overflowed (run_scan_impl) and kept with the set: the next binning of this key starts with them.
+                       uint32_t *bin_caps = nullptr; size_t row_records = 0; int bin_caps_nb = 0;
                        RecKey key; bool complete = false;      // the buffers hold every record of `key` (binned, no stream overflowed)
                        bool queued = false;                    // the binning kernel that writes them is queued on the engine's stream, its overflow flag not read yet (gbn_db_prepare_records)
                        unsigned long long stamp = 0;           // last use (record cache: least recently used goes first)
@@ -291,7 +296,8 @@ void recset_move(RecordSet &dst, RecordSet &src);
 void rec_make_room(size_t need, long long limit, const RecordSet *keep, const RecKey *sweep = nullptr, RecordSet *into = nullptr);
 void rec_purge(const void *db, bool to_scratch = false);
 struct BinLayout { int nb = 0, nwriters = 0; size_t nstream = 0, subcap = 0, nseq = 0, need_u64 = 0;
-                   size_t bytes() const { return need_u64 * 8 + nstream * nseq * 4 + (nstream + 4) * 4; } };
+                   size_t count_words() const { return 2 * nstream + 4; }      // counts, overflow word + spare, uncapped totals
+                   size_t bytes() const { return need_u64 * 8 + nstream * nseq * 4 + count_words() * 4; } };
 int64_t bin_positions(const GbnDb &db, const TileSet &ts, int32_t s0, int32_t s1, int lut, int step);
 int bin_layout(int nb, int64_t ntiles, int64_t npos, double slack, BinLayout &L);
 RecordSet *rec_find(const RecKey &key);

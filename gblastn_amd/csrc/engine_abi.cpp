@@ -597,6 +597,17 @@ int gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream) {
     });
 }
 
+int gbn_synth_skew(void *dev_ptr, int64_t first_off, int64_t stride, int64_t nb, int32_t num, int64_t first_oid, uint64_t seed, void *stream) {
+    return gbn::guard(__func__, [&]() -> int {
+    int rc = enter_current();
+    if (rc) return rc;
+    hipStream_t st = stream ? (hipStream_t)stream : E.stream;
+    HIPCHK(launch_synth_skew(dev_ptr, first_off, stride, nb, num, first_oid, seed, st));
+    HIPCHK(hipStreamSynchronize(st));
+    return GBN_OK;
+    });
+}
+
 int gbn_batch_new_masked(GbnBatch **out, const GbnOptions *opt, int32_t nq, const uint8_t *const *seqs,
                          const int32_t *lens, int32_t nmask, const int32_t *mask_query, const int32_t *mask_from,
                          const int32_t *mask_to, int upload) {
@@ -855,7 +866,8 @@ int gbn_db_prepare_records(GbnDb *db, const GbnOptions *opt, int32_t nq, const i
         B.S.ncells = (int64_t)1 << (2 * lut); B.S.lut = lut; B.S.word = word; B.S.step = step; B.S.fl = fl; B.S.fr = fr;
         B.nb = (int)nb; B.cbits = GBN_BIN_CBITS(lut); B.nwriters = BL.nwriters; B.rfl = key.rfl; B.rfrbits = key.rfrbits;
         B.rec = reinterpret_cast<uint32_t *>(rs->bin_rec); B.tcur = rs->bin_tcur; B.nseq = (uint32_t)BL.nseq; B.gcount = rs->bin_count; B.subcap = (uint32_t)BL.subcap;
-        B.overflow = rs->bin_count + BL.nstream;
+        B.overflow = rs->bin_count + BL.nstream; B.gtotal = rs->bin_count + BL.nstream + 4;
+        dev_free(rs->bin_caps); rs->bin_caps_nb = 0; rs->row_records = 0;      // (uniform streams; a pass that finds them too short bins again with per-bin capacities)
         if (!E.rare_counts && (rc = dev_alloc(E.rare_counts, (size_t)2048))) return rc;
         B.rare_counts = E.rare_counts;                      // (where a GBN_BIN_TIMING build leaves its clocks)
         HIPCHK(hipMemsetAsync(rs->bin_count + BL.nstream, 0, 16, E.stream));

@@ -45,7 +45,7 @@ void recset_free_runs(RecordSet &r) {
     r.run_n = r.run_cells = 0; r.runs = false; r.runs_failed = false; r.hits = 0;
 }
 void recset_free(RecordSet &r) {
-    dev_free(r.bin_rec); dev_free(r.bin_tcur); dev_free(r.bin_count);
+    dev_free(r.bin_rec); dev_free(r.bin_tcur); dev_free(r.bin_count); dev_free(r.bin_caps); r.row_records = 0; r.bin_caps_nb = 0;
     r.bin_rec_cap = r.bin_tcur_cap = r.bin_count_cap = 0; r.complete = false; r.queued = false;
     recset_free_runs(r);
 }
@@ -94,6 +94,7 @@ void recset_move(RecordSet &dst, RecordSet &src) {
     dst.bin_count = src.bin_count; dst.bin_count_cap = src.bin_count_cap; dst.complete = false; dst.queued = false; src.queued = false;
     src.bin_rec = nullptr; src.bin_tcur = nullptr; src.bin_count = nullptr; src.bin_rec_cap = src.bin_tcur_cap = src.bin_count_cap = 0; src.complete = false;
     recset_free_runs(src);                      // (a sorted set's arrays are not handed on: the newcomer's are sized by ITS records)
+    dev_free(src.bin_caps); src.row_records = 0; src.bin_caps_nb = 0;
 }
 // Sets go until `need` more bytes fit under `limit` (keep: the set the pass is using).  Which: a pass over (shard, range) of
 // a table shape is one step of a SWEEP -- every query batch visits the ranges / block views of its database in the same
@@ -158,7 +159,7 @@ int bin_layout(int nb, int64_t ntiles, int64_t npos, double slack, BinLayout &L)
 }
 // the cached set that serves `key`: complete (or being written on the engine's stream), streams at least as long
 RecordSet *rec_find(const RecKey &key) {
-    for (RecordSet *c : E.rec_sets) if (c->key.same_shape(key) && (c->runs || ((c->complete || c->queued) && c->key.subcap >= key.subcap))) return c;
+    for (RecordSet *c : E.rec_sets) if (c->key.same_shape(key) && (c->runs || ((c->complete || c->queued) && (c->bin_caps || c->key.subcap >= key.subcap)))) return c;
     return nullptr;
 }
 // a set to bin `key` into, its buffers sized: a cached one (room made for it) or -- larger than the whole cache -- the passes'
@@ -180,10 +181,10 @@ int rec_acquire(const RecKey &key, const BinLayout &L, long long limit, RecordSe
         if (old) for (size_t i = 0; i < E.rec_sets.size(); i++) if (E.rec_sets[i] == old) { rec_drop(i, false); break; }
         rs = &E.scratch; E.rec_bypass++;
     }
-    int rc = recset_size(*rs, L.need_u64, L.nstream * L.nseq, L.nstream + 4);
+    int rc = recset_size(*rs, L.need_u64, L.nstream * L.nseq, L.count_words());
     if (rc == GBN_ERR_NOMEM && rs != &E.scratch) {      // the device is full: everything else the cache holds goes, once
         rec_make_room((size_t)limit, limit, rs);
-        rc = recset_size(*rs, L.need_u64, L.nstream * L.nseq, L.nstream + 4);
+        rc = recset_size(*rs, L.need_u64, L.nstream * L.nseq, L.count_words());
     }
     if (rc) { if (rs != &E.scratch) { for (size_t i = 0; i < E.rec_sets.size(); i++) if (E.rec_sets[i] == rs) { rec_drop(i, false); break; } } return rc; }
     recset_free_runs(*rs);
@@ -271,6 +272,7 @@ int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *dia
     int64_t split_mb = 256;
     if (gbn::switch_is_set("GBN_SKEW_SPLIT_MB")) split_mb = (int)std::max<long long>(1, gbn::switch_value("GBN_SKEW_SPLIT_MB", 0));       // tests
     if (s1 - s0 > 1 && bases > (split_mb << 20)) return kSkewedRange;         // the caller halves the range
+    if (diag) diag->direct_ranges++;
     return run_scan_impl(b, db, s0, s1, diag, cnt, bases_out, true, &skewed);
 }
 
@@ -303,6 +305,10 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     RecordSet *rs = nullptr;                    // the records of this pass
     bool binned_here = false;                   // ... were written (completely) by this call
     bool repeat_seen = false;                   // cache off: the pass before this one had the same key
+    int attempt = 0;                            // scans of this call so far (the second and later ones are rescans)
+    // streams of bins that differ in size: {capacity, offset in a writer's row} per bin, made from the uncapped totals of an attempt that
+    // overflowed (repeat-rich subjects: a few bins take most of the scan positions); exact_row: records per row
+    std::vector<uint32_t> exact; size_t exact_row = 0; size_t last_nstream = 0;
     bool counted = false;                       // the cache's hit / miss of this call is counted (a range scanned again counts once)
     bool used_runs = false;                     // the pass went over sorted records
     struct NotInUse { ~NotInUse() { for (RecordSet *c : E.rec_sets) c->in_use = false; } } not_in_use_on_return;     // (in_use: a failing allocation may not evict the pass's own set)
@@ -349,6 +355,15 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             const int rfl_now = std::min(4, b.dev->fl), rfrbits_now = std::min(7, 2 * b.dev->fr);
             RecKey key; key.db = (const void *)&db; key.s0 = s0; key.s1 = s1; key.lut = b.lut.lut; key.step = b.lut.step; key.nb = nb; key.nwriters = nwriters;
             key.rfl = rfl_now; key.rfrbits = rfrbits_now; key.cbits = GBN_BIN_CBITS(b.lut.lut); key.tiles = (const void *)P.tiles; key.subcap = subcap;
+            last_nstream = nstream;
+            // cache off: the passes' own set remembers the capacities an earlier pass over this key found (the counts are a function of
+            // the shard, the range and the table's shape: no attempt is wasted again)
+            const bool reuse_caps = exact.empty() && rec_limit == 0 && !(E.ahead.valid && E.ahead.key.same_shape(key)) && E.scratch.bin_caps && E.scratch.bin_caps_nb == nb && E.scratch.row_records && E.scratch.key.same_shape(key);
+            if (!exact.empty() || reuse_caps) {
+                const size_t row = reuse_caps ? E.scratch.row_records : exact_row;
+                BL.subcap = 0; BL.need_u64 = (GBN_REC_WORDS(row * (size_t)nwriters) + 1) / 2;
+                subcap = 0; key.subcap = 0;
+            }
             bool hit = false, ahead_hit = false;
             Engine::BinAhead &AH = E.ahead;
             if (rec_limit > 0) {
@@ -389,18 +404,28 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                 repeat_seen = E.last_key_valid && E.last_key == key;
                 E.last_key = key; E.last_key_valid = true;
                 if (!hit && !ahead_hit) {
-                    if ((rc = recset_size(*rs, BL.need_u64, nstream * nseq, nstream + 4))) return rc;
+                    if ((rc = recset_size(*rs, BL.need_u64, nstream * nseq, BL.count_words()))) return rc;
                     rs->key = key; rs->complete = false;
                 }
             }
-            if (!hit && !ahead_hit) HIPCHK(hipMemsetAsync(rs->bin_count + nstream, 0, 16, E.stream));     // (records that exist already: the flag of THAT launch is read back below)
+            if (!hit && !ahead_hit) {
+                // the layout this attempt bins into: capacities just computed, the set's own (cache off, same key), or uniform streams
+                if (!exact.empty()) {
+                    if (rs->bin_caps_nb != nb) { dev_free(rs->bin_caps); rs->bin_caps_nb = 0; if ((rc = dev_alloc(rs->bin_caps, (size_t)2 * nb))) return rc; rs->bin_caps_nb = nb; }
+                    HIPCHK(hipMemcpyAsync(rs->bin_caps, exact.data(), (size_t)2 * nb * 4, hipMemcpyHostToDevice, E.stream));
+                    HIPCHK(hipStreamSynchronize(E.stream));                 // (`exact` is pageable; 4 KB, once per skewed set)
+                    rs->row_records = exact_row;
+                } else if (!(reuse_caps && rs == &E.scratch)) { dev_free(rs->bin_caps); rs->bin_caps_nb = 0; rs->row_records = 0; }
+                HIPCHK(hipMemsetAsync(rs->bin_count + nstream, 0, 16, E.stream));     // (records that exist already: the flag of THAT launch is read back below)
+            }
             rs->stamp = ++E.rec_clock;
             for (RecordSet *c : E.rec_sets) c->in_use = (c == rs);
             GbnBinParams B; std::memset(&B, 0, sizeof(B));
             B.S = P; B.nb = nb; B.cbits = GBN_BIN_CBITS(b.lut.lut); B.nwriters = nwriters; dbg_nwriters = nwriters; dbg_subcap = (uint32_t)subcap;
             B.cellt = b.dev->cellt; B.sidet = b.dev->sidet; B.side_start = b.dev->side_start; B.rfl = std::min(4, b.dev->fl); B.rfrbits = std::min(7, 2 * b.dev->fr);
             B.rec = reinterpret_cast<uint32_t *>(rs->bin_rec); B.tcur = rs->bin_tcur; B.nseq = (uint32_t)nseq; B.gcount = rs->bin_count; B.subcap = (uint32_t)subcap;
-            B.overflow = rs->bin_count + nstream;
+            B.overflow = rs->bin_count + nstream; B.gtotal = rs->bin_count + nstream + 4;
+            B.bincap = rs->bin_caps; B.rowsize = rs->row_records;
             B.dbg = (int)gbn::switch_value("GBN_DBG", 0);
             B.rare_parts = (hit && !binned_here) ? 5 : 0;      // (a pass over cached records: gbn_dev.h)
             B.work = gbn::switch_value("GBN_PROBE_DYN", 1) != 0 ? reinterpret_cast<uint32_t *>(E.counters + 4) : nullptr;      // (counters [4 .. 7]: zeroed with the scan's own, above)
@@ -442,13 +467,13 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         HIPCHK(hipMemcpyAsync(E.scan_back->cnt, E.counters, 3 * sizeof(unsigned long long), hipMemcpyDeviceToHost, E.stream));     // seeds, raw hits, the fullest segment
         if (!E.ev_back) HIPCHK(hipEventCreate(&E.ev_back));
         HIPCHK(hipEventRecord(E.ev_back, E.stream));
-        if (binned && rec_limit == 0 && E.want_ahead && repeat_seen && slack <= 1.25) {
+        if (binned && rec_limit == 0 && E.want_ahead && repeat_seen && slack <= 1.25 && !rs->bin_caps) {     // (a skewed range's capacities stay with ONE set)
             // the next pass's binning kernel, into the other set (sized like this one)
             RecordSet &A = E.alt;
             const size_t nstream = (size_t)last_B.nb * (size_t)last_B.nwriters;
-            if (recset_size(A, rs->bin_rec_cap, nstream * last_B.nseq, nstream + 4) == GBN_OK) {        // (no room for a second set: no binning ahead)
+            if (recset_size(A, rs->bin_rec_cap, nstream * last_B.nseq, 2 * nstream + 4) == GBN_OK) {        // (no room for a second set: no binning ahead)
                 GbnBinParams A2 = last_B;
-                A2.rec = reinterpret_cast<uint32_t *>(A.bin_rec); A2.tcur = A.bin_tcur; A2.gcount = A.bin_count; A2.overflow = A.bin_count + nstream;
+                A2.rec = reinterpret_cast<uint32_t *>(A.bin_rec); A2.tcur = A.bin_tcur; A2.gcount = A.bin_count; A2.overflow = A.bin_count + nstream; A2.gtotal = A.bin_count + nstream + 4;
                 A2.rareq = nullptr;                         // (the binning kernel queues nothing; rare_counts: where a GBN_BIN_TIMING build leaves its clocks)
                 A.key = rs->key; A.complete = false;
                 Engine::BinAhead &AH = E.ahead;
@@ -475,7 +500,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             if (binned) (void)hipEventElapsedTime(&ms, E.evk[binned_ahead ? 1 : 0], E.evk[3]);     // (the launcher's own events bracket the stage)
             else (void)hipEventElapsedTime(&ms, E.ev0, E.ev1);
             if (binned_ahead && hit_pair >= 0) (void)hipEventElapsedTime(&ahead_ms, E.ahead.ev[hit_pair][0], E.ahead.ev[hit_pair][1]);    // this pass's binning kernel ran ahead
-            diag->scan_kernel_ms += ms + ahead_ms; diag->scan_launches++;
+            diag->scan_kernel_ms += ms + ahead_ms; diag->scan_launches++; if (attempt++) diag->scan_rescans++;
             if (binned) {
                 float a = 0, c = 0, r = 0;
                 if (!binned_ahead) (void)hipEventElapsedTime(&a, E.evk[0], E.evk[1]);
@@ -532,7 +557,29 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             slice_seg_cap = std::max<size_t>(2 * slice_seg_cap, (size_t)seg_max + (size_t)(seg_max >> 2));
             continue;
         }
-        if (overflow) {     // the records are incomplete: once more with twice the room, then give the range to the direct kernel
+        if (overflow) {
+            // The records are incomplete: some stream was too short.  The binning kernel counted on past the streams' ends, so the
+            // attempt says exactly how much room every stream needs (GbnBinParams::gtotal): the range is binned once more with streams
+            // of per-bin capacities -- the most any writer has of that bin -- and fits.  (Rounds 1-5: twice the room, then the range
+            // halved until the repeat-rich subjects sat in ranges for the direct-probe kernel: 256 ranges, 1,278 scan launches and
+            // 1.4 s for a C2 step over a shard with 8 % low-complexity sequence, profiles/r06_skew.txt.)  GBN_EXACT_FIT=0: that.
+            if (exact.empty() && rs && last_nstream && gbn::switch_value("GBN_EXACT_FIT", 1) != 0) {
+                const int nwr = last_B.nwriters;
+                std::vector<uint32_t> tot(last_nstream);
+                HIPCHK(hipMemcpy(tot.data(), rs->bin_count + last_nstream + 4, last_nstream * 4, hipMemcpyDeviceToHost));
+                exact.assign((size_t)2 * nb, 0u); size_t row = 0;
+                for (int bb = 0; bb < nb; bb++) {
+                    uint32_t mx = 0;
+                    for (int w = 0; w < nwr; w++) mx = std::max(mx, tot[(size_t)bb * nwr + w]);
+                    const size_t cap = ((size_t)mx + 511) & ~(size_t)511;
+                    exact[(size_t)2 * bb] = (uint32_t)std::max<size_t>(cap, 512); exact[(size_t)2 * bb + 1] = (uint32_t)row;
+                    row += exact[(size_t)2 * bb];
+                    if (row > 0x7ffffff0u) { exact.clear(); break; }
+                }
+                exact_row = row;
+                if (!exact.empty()) continue;
+            }
+            if (!exact.empty() || gbn::switch_value("GBN_EXACT_FIT", 1) != 0) { *skewed = true; return GBN_OK; }     // (cannot fit: the direct kernel)
             slack *= 2;
             if (slack > 3.0) { *skewed = true; return GBN_OK; }
             continue;

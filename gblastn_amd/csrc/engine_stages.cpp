@@ -72,7 +72,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         HIPCHK(launch_seed_keys(K, st));
         size_t tb = KS.sort_tmp_bytes;
         KS.kt.mark(GBN_KT_SORT, st);
-        HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, n, scan_bits, st));
+        HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, n, scan_bits, st)); if (diag) GBN_DIAG_LOCKED(diag->library_sorts++);
         KS.kt.mark(-1, st);
         // idx_b = seed indices in scan order (s_scan, chain order), subjects interleaved
     }
@@ -118,7 +118,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
             // (seeds that come in scan order are in the order of the key's scan-position bits already: the stable sort has
             // subject | slot left to do)
             const int s_done = (from_segments && E.seg_ordered) ? K.s_bits : 0;
-            if (packed) HIPCHK(sort_keys_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, n, v_bits + s_done, v_bits + ck_bits, st));
+            if (packed) HIPCHK(sort_keys_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, n, v_bits + s_done, v_bits + ck_bits, st)); if (diag) GBN_DIAG_LOCKED(diag->library_sorts++);
             else HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, n, ck_bits, st));
             KS.kt.mark(-1, st);
         }
@@ -130,7 +130,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
             HIPCHK(launch_group_keys(K, st));
             size_t tb = KS.sort_tmp_bytes;
             KS.kt.mark(GBN_KT_SORT, st);
-            HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_b, KS.idx_a, n, group_key_bits, st));
+            HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_b, KS.idx_a, n, group_key_bits, st)); if (diag) GBN_DIAG_LOCKED(diag->library_sorts++);
             KS.kt.mark(-1, st);
         }
         // key_b = sorted (subject, slot) keys, idx_a = seed indices grouped by run, scan order inside
@@ -205,7 +205,7 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
         return search_range(b, db, mid, s1, res, diag, keep_stages, overlap);
     }
     if (rc) return rc;
-    if (diag) diag->scan_stage_ms += ms_since(t_stage);
+    if (diag) { diag->scan_stage_ms += ms_since(t_stage); diag->ranges++; }
     t_stage = now();
     if (diag) { diag->lookup_hits += (int64_t)cnt[1]; diag->seeds += (int64_t)cnt[0]; diag->subject_bases_scanned += bases; }
     const int64_t n = (int64_t)cnt[0];

@@ -79,6 +79,12 @@ struct GbnBinParams {
     uint32_t *tcur; uint32_t nseq;
     uint32_t *gcount;               // [nb][nwriters] records written (multiple of 4, pads included)
     uint32_t subcap;
+    // Streams of bins that differ in size (round 6; repeat-rich subjects put most of their scan positions into a few bins): bincap[2 b] =
+    // records a stream of bin b has room for (a multiple of 512), bincap[2 b + 1] = where bin b's stream begins inside a writer's row,
+    // rowsize = records per row.  Null: every stream has room for `subcap` records (GBN_BINCAP / GBN_RECIDX, scan_dev.hpp).  gtotal
+    // [nb][nwriters]: what every stream WOULD hold -- the binning kernel counts on past a stream's end, so an attempt that overflows
+    // tells the engine exactly how much room the next one needs.
+    const uint32_t *bincap; size_t rowsize; uint32_t *gtotal;
     uint32_t *overflow;             // set to 1 if any stream did not fit
     int rfl, rfrbits;               // reduced fingerprint: bases on the left (<= 4), BITS on the right (<= 7 = 3.5 bases)
     int dbg;                        // launch switches of tools/scan_ablate.py (GBN_DBG; 1: no rare kernel, 32: timing print, 64: any-stride binning kernel, 128: XCD report, 256: probe kernel without the sixteenth fingerprint bit)

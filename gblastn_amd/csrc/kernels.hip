@@ -624,6 +624,50 @@ extern "C" __global__ void synth_fill_kernel(uint64_t *out, int64_t nwords, uint
     }
 }
 
+// ---------------------------------------------------------------------------
+// Repeats written over a synthetic shard (bench.py --skew; gblastn_amd/synth.py: skew_subject is the numpy form, bit for bit).
+// Real nucleotide databases are repeat- and low-complexity-rich; i.i.d. uniform bases exercise none of what that does to a scan
+// (lookup words piling up in a few cells and bins, seed floods).  Per subject of nb packed bytes, from splitmix64 hashes of
+// (seed, global oid): FOUR stretches of nb / 50 bytes each (8 % of the subject) -- homopolymer runs (one of AAAA, CCCC, GGGG, TTTT)
+// or tandem repeats of a 4 .. 24-base unit --, and in one subject of fifty ONE copy of a family element of 1,200 bases (the
+// same 300 bytes for the whole database, a base changed in ~1.2 % of the positions per copy).
+// ---------------------------------------------------------------------------
+__host__ __device__ inline uint64_t gbn_splitmix64(uint64_t x)
+{
+    x += 0x9E3779B97F4A7C15ull; x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull; x = (x ^ (x >> 27)) * 0x94D049BB133111EBull; return x ^ (x >> 31);
+}
+extern "C" __global__ void synth_skew_kernel(uint8_t *slab, int64_t first_off, int64_t stride, int64_t nb, int32_t num, int64_t first_oid, uint64_t seed)
+{
+    const int32_t s = (int32_t)blockIdx.x;
+    if (s >= num || nb < 2000) return;
+    uint8_t *p = slab + first_off + (int64_t)s * stride;
+    const uint64_t oid = (uint64_t)(first_oid + s);
+    const int64_t rl = nb / 50;
+    for (int r = 0; r < 4; r++) {
+        const uint64_t h = gbn_splitmix64(seed ^ gbn_splitmix64(oid * 4 + (uint64_t)r));
+        const int64_t start = (int64_t)(h % (uint64_t)(nb - rl));
+        const uint64_t h2 = gbn_splitmix64(h);
+        if (((h >> 40) & 1) == 0) {
+            const uint8_t b = (uint8_t)(0x55u * ((h >> 42) & 3));
+            for (int64_t j = threadIdx.x; j < rl; j += blockDim.x) p[start + j] = b;
+        } else {
+            const int64_t period = 1 + (int64_t)((h >> 44) % 6);
+            for (int64_t j = threadIdx.x; j < rl; j += blockDim.x) p[start + j] = (uint8_t)(h2 >> (8 * (j % period)));
+        }
+        __syncthreads();                    // (stretches may overlap: the later one wins, as in the numpy form)
+    }
+    const uint64_t he = gbn_splitmix64(seed ^ gbn_splitmix64(oid ^ 0xE1E1E1E1ull));
+    if (he % 50 == 0) {
+        const int64_t at = (int64_t)(gbn_splitmix64(he) % (uint64_t)(nb - 300));
+        for (int64_t k = threadIdx.x; k < 300; k += blockDim.x) {
+            uint8_t e = (uint8_t)(gbn_splitmix64(seed ^ (0xFA111ull + (uint64_t)(k >> 3))) >> (8 * (k & 7)));
+            const uint64_t hm = gbn_splitmix64(he ^ (uint64_t)(k + 1));
+            if ((hm & 15) == 0) e ^= (uint8_t)(((hm >> 4) & 3) << (2 * ((hm >> 6) & 3)));
+            p[at + k] = e;
+        }
+    }
+}
+
 // stretches of the shard packed back to back (the traceback stage reads back what its extensions can reach:
 // one kernel and one copy per query batch instead of a copy per subject)
 extern "C" __global__ void gather_bytes_kernel(const uint8_t *src, const int64_t *src_off, const int64_t *dst_off, const int32_t *nbytes, uint8_t *dst)
@@ -738,6 +782,12 @@ hipError_t launch_gather_bytes(const uint8_t *src, const int64_t *src_off, const
     return hipGetLastError();
 }
 
+hipError_t launch_synth_skew(void *dev, int64_t first_off, int64_t stride, int64_t nb, int32_t num, int64_t first_oid, uint64_t seed, hipStream_t st)
+{
+    if (num <= 0) return hipSuccess;
+    hipLaunchKernelGGL(synth_skew_kernel, dim3((unsigned)num), dim3(256), 0, st, (uint8_t *)dev, first_off, stride, nb, num, first_oid, seed);
+    return hipGetLastError();
+}
 hipError_t launch_synth_fill(void *dev, int64_t nbytes, uint64_t seed, hipStream_t st)
 {
     int64_t nwords = nbytes / 8;

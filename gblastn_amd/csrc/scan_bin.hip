@@ -182,12 +182,13 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     auto rot_next = [&](uint32_t r) -> uint32_t { return r + 1u == (uint32_t)stride ? 0u : r + 1u; };
     int64_t tile = blockIdx.x;
     if (tile > last) {
-        for (int b = tid; b < nb; b += GBN_SORT_THREADS) B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0;
+        for (int b = tid; b < nb; b += GBN_SORT_THREADS) { B.gcount[(size_t)b * B.nwriters + blockIdx.x] = 0; if (B.gtotal) B.gtotal[(size_t)b * B.nwriters + blockIdx.x] = 0; }
         return;
     }
     // owner thread of bin `tid`: its stream's state lives in registers
     uint32_t wpos = 0, cc = 0;                                  // records stored so far (multiple of LINE), records in the open line (< LINE)
-    const uint32_t sline0 = (uint32_t)((GBN_STREAM(B, (tid < nb ? tid : 0), wid) * (size_t)B.subcap) >> 5);    // first line of the stream (subcap is a multiple of 512)
+    const uint32_t sline0 = (uint32_t)(GBN_RECIDX(B, (tid < nb ? tid : 0), wid, 0) >> 5);    // first line of the stream (capacities are multiples of 512)
+    const uint32_t mycap = GBN_BINCAP(B, (tid < nb ? tid : 0));  // room in this owner's stream
     const uint32_t open0 = (uint32_t)(STAGE + tid * LINE);      // the bin's open line
     uint32_t *const tcur = B.tcur + ((size_t)(tid < nb ? tid : 0) * B.nwriters + wid) * B.nseq;
 
@@ -299,9 +300,9 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
             const uint32_t first_past = my_nl ? my_nl * LINE - cc : 0xffffu;
             s_pk[tid] = make_uint2((open0 + cc) | ((off + cc - LINE) << 16), first_past | ((LINE - cc) << 16));
             if ((seq & 7u) == 0) tcur[seq >> 3] = wpos + cc;    // stream index of this tile's first record
-            if (wpos + my_nl * LINE > B.subcap) atomicOr(B.overflow, 1u);
+            if (wpos + my_nl * LINE > mycap) atomicOr(B.overflow, 1u);
             for (uint32_t l = 0; l < my_nl; l++) {
-                const bool fits = wpos + (l + 1) * LINE <= B.subcap;
+                const bool fits = wpos + (l + 1) * LINE <= mycap;
                 s_line[l0 + l] = make_uint2(sline0 + (wpos >> 5) + l, fits ? (l == 0 ? open0 : off + (l - 1) * LINE) : 0xffffffffu);
             }
             if (tid == nb - 1) s_nlines = l0 + my_nl;
@@ -399,14 +400,15 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
     for (uint32_t i = tid; i < (uint32_t)nb * LP; i += GBN_SORT_THREADS) {
         const uint32_t b = i / LP, p = i % LP;
         const uint2 f = s_fin[b];
-        if (f.y && f.x + LINE <= B.subcap && !(GBN_BIN_ABL & 2))
-            store_part((uint32_t)((GBN_STREAM(B, b, wid) * (size_t)B.subcap + f.x) >> 5), p, STAGE + b * LINE + p * 4);
+        if (f.y && f.x + LINE <= GBN_BINCAP(B, b) && !(GBN_BIN_ABL & 2))
+            store_part((uint32_t)((GBN_RECIDX(B, b, wid, 0) + f.x) >> 5), p, STAGE + b * LINE + p * 4);
     }
     for (int b = tid; b < nb; b += GBN_SORT_THREADS) {
         const uint2 f = s_fin[b];
-        const uint32_t total = f.x + (f.y ? LINE : 0u);
-        if (total > B.subcap) atomicOr(B.overflow, 1u);
-        B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(total, B.subcap);
+        const uint32_t total = f.x + (f.y ? LINE : 0u), capb = GBN_BINCAP(B, b);
+        if (total > capb) atomicOr(B.overflow, 1u);
+        B.gcount[(size_t)b * B.nwriters + blockIdx.x] = min(total, capb);
+        if (B.gtotal) B.gtotal[(size_t)b * B.nwriters + blockIdx.x] = total;      // (counted on past the stream's end)
     }
 }
 
@@ -446,6 +448,7 @@ __device__ __forceinline__ void scan_bin_line_body(const GbnBinParams &B)
 // its bin: GBN_REC_PAR), otherwise 0; bit 31 is not defined.  For lut 12 the word, the four bases in front and the seven
 // bits behind are bytes 0-2 of one 32-bit window and the top byte of another: two funnel shifts, one bit-field extract
 // (the bin) and one byte permute per scan position.
+// (Streams of one capacity only: the per-bin capacities of round 6 -- GbnBinParams::bincap -- are the four-barrier form's.)
 template <int STEP, int LUT>
 __device__ __forceinline__ void scan_bin3_body(const GbnBinParams &B)
 {
@@ -946,7 +949,7 @@ probe_bin_kernel(GbnBinParams B)
                 if (at < B.rare_seg) {
 #if GBN_PROBE_FETCH
                     // ... and the record's index: the second scattered sector per item
-                    const uint32_t wr = at_rec / B.subcap, jr = at_rec - wr * B.subcap;
+                    const uint32_t capb = GBN_BINCAP(B, bin), wr = at_rec / capb, jr = at_rec - wr * capb;
                     const uint32_t idx = reinterpret_cast<const uint16_t *>(B.rec)[GBN_REC_IDX16(GBN_RECIDX(B, bin, wr, jr))];
 #else
                     const uint32_t idx = 0;
@@ -1002,7 +1005,7 @@ probe_bin_kernel(GbnBinParams B)
             const uint32_t lo = min((uint32_t)part * piece, ntot);
             n = min(piece, ntot - lo);
             // lo and every round start are multiples of 512 (one chunk per round in the chunked layout)
-            rbase = (uint32_t)w * B.subcap + lo;                    // of this piece inside the bin's region
+            rbase = (uint32_t)w * GBN_BINCAP(B, b) + lo;            // of this piece inside the bin's region (writer x the bin's stream capacity + index)
             pbase = B.rec + GBN_REC_HI(GBN_RECIDX(B, b, w, lo));
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
@@ -1203,7 +1206,7 @@ probe_rare_kernel(GbnBinParams B, int nseg)
         if (B.run_pos == nullptr) {   // (sorted records carry their position id: scan_runs.hip)
             // record index inside the bin's region -> (writer, index) -> tile via the cursor table -> position id
             const uint32_t bin = (cv & 0x7fffffffu) >> B.cbits;
-            const uint32_t wr = pid / B.subcap, j = pid - wr * B.subcap;
+            const uint32_t capb = GBN_BINCAP(B, bin), wr = pid / capb, j = pid - wr * capb;
             const uint32_t *__restrict__ cur = B.tcur + ((size_t)bin * B.nwriters + wr) * B.nseq;
 #if !GBN_PROBE_FETCH
             // everything that hangs on the queue item alone is asked for here, in front of the cursor search

@@ -38,9 +38,12 @@ static inline hipError_t raise_dynamic_lds(const void *fn, size_t lds, std::atom
 #endif
 // stream of (bin, writer): writer-major keeps the 512 streams a binning workgroup appends to
 // inside one ~100 MB stretch instead of spreading them over the whole buffer
-#define GBN_STREAM(B, bin, writer) ((size_t)(writer) * (B).nb + (bin))
+// (a writer's row = its nb streams one after the other; uniform streams of subcap records, or per-bin capacities: GbnBinParams::bincap)
+#define GBN_BINCAP(B, bin) ((B).bincap ? (B).bincap[2 * (size_t)(bin)] : (B).subcap)
+#define GBN_BINOFF(B, bin) ((B).bincap ? (size_t)(B).bincap[2 * (size_t)(bin) + 1] : (size_t)(bin) * (B).subcap)
+#define GBN_ROW(B) ((B).bincap ? (B).rowsize : (size_t)(B).nb * (B).subcap)
 // linear index of record j of stream (bin, writer)
-#define GBN_RECIDX(B, bin, writer, j) (GBN_STREAM(B, bin, writer) * (B).subcap + (size_t)(j))
+#define GBN_RECIDX(B, bin, writer, j) ((size_t)(writer) * GBN_ROW(B) + GBN_BINOFF(B, bin) + (size_t)(j))
 #ifndef GBN_BIN_OCC
 #define GBN_BIN_OCC 4       // waves per SIMD the binning kernel is compiled for
 #endif

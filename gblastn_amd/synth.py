@@ -51,10 +51,57 @@ def pack_bases(bases, pad=16):
     return np.concatenate([out.astype(np.uint8), np.zeros(pad, dtype=np.uint8)])
 
 
-class SynthDb:
-    """Layout of a synthetic shard: `num` subjects of `length` bases, 16-byte aligned."""
+def _splitmix64(x):
+    with np.errstate(over="ignore"):
+        x = np.uint64(x) + GOLDEN
+        x = (x ^ (x >> np.uint64(30))) * _M1
+        x = (x ^ (x >> np.uint64(27))) * _M2
+        return x ^ (x >> np.uint64(31))
 
-    def __init__(self, num, length, seed=0, first_oid=0):
+
+def family_element(seed):
+    """the 300 packed bytes (1,200 bases) of the database's interspersed repeat family (synth_skew_kernel)"""
+    out = np.empty(300, dtype=np.uint8)
+    for k in range(300):
+        out[k] = (int(_splitmix64(np.uint64(seed) ^ np.uint64(0xFA111 + (k >> 3)))) >> (8 * (k & 7))) & 0xff
+    return out
+
+
+def skew_subject(raw, nb, oid, seed):
+    """synth_skew_kernel on one subject's packed bytes (raw[:nb], modified in place): four stretches of nb // 50 bytes as homopolymer
+    runs or tandem repeats, and in one subject of fifty a slightly changed copy of the family element"""
+    if nb < 2000:
+        return raw
+    rl = nb // 50
+    with np.errstate(over="ignore"):
+        for r in range(4):
+            h = int(_splitmix64(np.uint64(seed) ^ _splitmix64(np.uint64(oid * 4 + r))))
+            start = h % (nb - rl)
+            h2 = int(_splitmix64(np.uint64(h)))
+            if ((h >> 40) & 1) == 0:
+                raw[start:start + rl] = (0x55 * ((h >> 42) & 3)) & 0xff
+            else:
+                period = 1 + ((h >> 44) % 6)
+                unit = np.array([(h2 >> (8 * j)) & 0xff for j in range(period)], dtype=np.uint8)
+                raw[start:start + rl] = np.tile(unit, rl // period + 1)[:rl]
+        he = int(_splitmix64(np.uint64(seed) ^ _splitmix64(np.uint64(oid) ^ np.uint64(0xE1E1E1E1))))
+        if he % 50 == 0:
+            at = int(_splitmix64(np.uint64(he))) % (nb - 300)
+            e = family_element(seed).copy()
+            for k in range(300):
+                hm = int(_splitmix64(np.uint64(he) ^ np.uint64(k + 1)))
+                if (hm & 15) == 0:
+                    e[k] ^= (((hm >> 4) & 3) << (2 * ((hm >> 6) & 3))) & 0xff
+            raw[at:at + 300] = e
+    return raw
+
+
+class SynthDb:
+    """Layout of a synthetic shard: `num` subjects of `length` bases, 16-byte aligned.  skew: repeats written over the uniform
+    bases (gbn_synth_skew / skew_subject)."""
+
+    def __init__(self, num, length, seed=0, first_oid=0, skew=False):
+        self.skew = skew
         self.num, self.length, self.seed, self.first_oid = num, length, seed, first_oid
         self.stride = (((length + 3) // 4) + 15) // 16 * 16
         self.front = 16
@@ -67,7 +114,13 @@ class SynthDb:
         """Packed bytes of subject i (local index) exactly as the device slab holds them."""
         nb = (self.length + 3) // 4
         raw = synth_bytes_numpy(int(self.byte_off[i]), nb + pad, self.seed)
+        if self.skew:
+            skew_subject(raw, nb, self.first_oid + i, self.seed)
         return raw
+
+    def skew_on_device(self, api, slab_ptr):
+        """the same repeats over the slab gbn_synth_fill wrote"""
+        api._check(api.lib().gbn_synth_skew(slab_ptr, int(self.byte_off[0]), int(self.stride), (self.length + 3) // 4, self.num, self.first_oid, self.seed, None))
 
     def subject_bases(self, i):
         return unpack_bases(self.subject_packed(i, pad=0), self.length)
@@ -79,7 +132,7 @@ class SynthDb:
 _COMP = np.array([3, 2, 1, 0], dtype=np.uint8)
 
 
-def make_queries(nq, db, qlen=1000, first_query_id=0, planted_fraction=0.2):
+def make_queries(nq, db, qlen=1000, first_query_id=0, planted_fraction=0.2, family_fraction=0.0):
     """Queries per BASELINE.md: seed 42 + query_id; planted ones copy a 300-900 base
     slice of a chosen subject with 0-5 % substitutions and 0-2 single-base indels,
     random strand.  Returns (list of uint8 BLASTNA arrays, list of plant records)."""
@@ -109,5 +162,14 @@ def make_queries(nq, db, qlen=1000, first_query_id=0, planted_fraction=0.2):
             q0 = int(rng.integers(0, qlen - len(piece) + 1))
             q[q0:q0 + len(piece)] = piece
             plants.append(dict(query=qid, subject=db.first_oid + subj, s0=s0, length=ln, q0=q0))
+        elif family_fraction > 0 and rng.random() < family_fraction:
+            # a 600-base piece of the database's repeat family, 2 % substitutions: hits every copy (one subject in fifty)
+            fam = unpack_bases(family_element(db.seed), 1200)
+            a = int(rng.integers(0, 600))
+            piece = fam[a:a + 600].copy()
+            mut = rng.random(600) < 0.02
+            piece[mut] = (piece[mut] + rng.integers(1, 4, size=int(mut.sum()), dtype=np.uint8)) & 3
+            q0 = int(rng.integers(0, qlen - 600 + 1))
+            q[q0:q0 + 600] = piece
         queries.append(q)
     return queries, plants

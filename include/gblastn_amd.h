@@ -139,6 +139,10 @@ typedef struct GbnDiagnostics {
     double  host_stage_ms;          /* replay of the acceptance rules, HSP list rules */
     /* GPU time (HIP events on the stage's stream) per kernel class of the stages behind the scan, GBN_KT_* */
     double  kernel_ms[GBN_KT_N];
+    /* what repeat-rich subjects cost (round 6): subject ranges searched (a range whose lookup words pile up in a few bins is halved:
+     * more ranges), scans that had to be repeated (a stream or queue segment overflowed), ranges scanned by the direct-probe kernel,
+     * launches of the library's radix sort (seed counts beyond what the engine's own sort kernels take) */
+    int64_t ranges, scan_rescans, direct_ranges, library_sorts;
 } GbnDiagnostics;
 
 typedef int (*GbnInterruptFn)(void *progress);   /* TInterruptFnPtr analogue */
@@ -256,6 +260,10 @@ int  gbn_db_device(const GbnDb *db);       /* the GPU the shard is resident on *
 int32_t gbn_db_num_seqs(const GbnDb *db);
 /* deterministic synthetic DB bytes generated on the device (bench/tests) */
 int  gbn_synth_fill(void *dev_ptr, int64_t nbytes, uint64_t seed, void *stream);
+/* Repeats over a synthetic shard of `num` subjects of nb packed bytes each, `stride` bytes apart from first_off (bench.py --skew):
+ * per subject four stretches of nb / 50 bytes -- homopolymer runs or tandem repeats of a short unit -- and in one subject of fifty
+ * a copy of one family element of 1,200 bases; gblastn_amd/synth.py: skew_subject is its numpy form. */
+int  gbn_synth_skew(void *dev_ptr, int64_t first_off, int64_t stride, int64_t nb, int32_t num, int64_t first_oid, uint64_t seed, void *stream);
 
 /* ---- BLAST database files (format version 4, nucleotide): alias (.nal), index (.nin), sequence
  * (.nsq) incl. ambiguity runs.  Replaces what the reference reaches through its SeqDB BlastSeqSrc

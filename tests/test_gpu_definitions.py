@@ -656,3 +656,23 @@ def test_seed_order_kernels_equal_a_stable_sort(nsubj, nseg, mean, container_has
     key = ((((group << s_bits) | s_scan) << v_bits) | val).astype(np.uint64)
     expect = key[np.argsort(group, kind="stable")]
     assert np.array_equal(out[:n], expect)
+
+
+def test_skewed_synthetic_database_equals_its_numpy_form():
+    """bench.py --skew: gbn_synth_skew over a gbn_synth_fill slab = synth.SynthDb(skew=True).subject_packed, subject by subject (the
+    oracle's input for the parity sample of the skewed workload)"""
+    import torch
+    from gblastn_amd import synth
+    db = synth.SynthDb(120, 400_000, seed=0x1234567, first_oid=1000, skew=True)
+    slab = torch.empty(db.nbytes, dtype=torch.uint8, device="cuda")
+    api._check(api.lib().gbn_synth_fill(slab.data_ptr(), db.nbytes, db.seed, None))
+    db.skew_on_device(api, slab.data_ptr())
+    host = slab.cpu().numpy()
+    fam = 0
+    for i in range(db.num):
+        want = db.subject_packed(i, pad=0)
+        got = host[db.byte_off[i]: db.byte_off[i] + len(want)]
+        assert np.array_equal(got, want), i
+    plain = synth.SynthDb(120, 400_000, seed=0x1234567, first_oid=1000)
+    changed = sum(int((plain.subject_packed(i, pad=0) != db.subject_packed(i, pad=0)).sum()) for i in range(10))
+    assert changed > 10 * 100_000 * 0.05            # ~8 % of the bytes of every subject

@@ -184,3 +184,43 @@ print(json.dumps(out))
     assert res["0"][0][1] > 100 and res["0"][1][1] > 100           # both batches find their planted homologs
     assert res["1"][0][2] > 1.0 and res["1"][1][2] < 0.5           # shared: the second batch ran no binning kernel (an empty event interval)
     assert res["0"][1][2] > 1.0                                    # two full passes: it did
+
+
+def test_skewed_shard_against_the_oracle(monkeypatch):
+    """bench.py --skew at a size the oracle finishes: 1,500 x 1 Mb subjects with repeats written over them (gbn_synth_skew: 8 % of every
+    subject homopolymer runs / tandem repeats -- lookup words pile up in a few bins, the range is halved and the repeat-rich parts go to the
+    direct-probe kernel --, a family element in one subject of fifty), 600 queries of which 2 % carry a piece of the element (they hit every
+    copy).  HSPs of every subject that has one, of every carrier of the element and of a sample of the others equal the oracle's, in
+    stream form and over cached records."""
+    for k in ("GBN_RANGE_MIB", "GBN_RANGE_TILES", "GBN_RANGE_GIB", "GBN_SCAN_BINS", "GBN_RECORD_CACHE_MB", "GBN_SKEW_SPLIT_MB"):
+        monkeypatch.delenv(k, raising=False)
+    import torch
+    nsub, slen, nq = 1500, 1_000_000, 600
+    db = synth.SynthDb(nsub, slen, seed=0x9E3779B97F4A7C15 ^ 5, skew=True)
+    slab = torch.empty(db.nbytes, dtype=torch.uint8, device="cuda")
+    api._check(api.lib().gbn_synth_fill(slab.data_ptr(), db.nbytes, db.seed, None))
+    db.skew_on_device(api, slab.data_ptr())
+    src = api.BlastSeqSrc.from_slab((slab.data_ptr(), db.nbytes), db.byte_off, db.lens, is_device=True, keep=slab)
+    queries, plants = synth.make_queries(nq, db, family_fraction=0.02)
+    opt = api.default_options("megablast", db_length=nsub * slen, db_num_seqs=nsub)
+    # DUST as blastn applies it by default: a planted slice of a poly-A stretch would seed at every scan position of every poly-A stretch
+    masks = api.dust_masks(queries)
+    ps = api.BlastPrelimSearch(queries, opt, src, masks=masks)
+    first = ps.run()["hsps"]
+    d = ps.diagnostics
+    again = ps.run()["hsps"]                                    # (over cached records where the ranges were cached)
+    assert first.tobytes() == again.tobytes()
+    hit = set(first["oid"].tolist())
+    rng = np.random.default_rng(1)
+    sample = sorted(hit | set(rng.choice(nsub, 20, replace=False).tolist()))
+    assert len(hit) >= 30                                       # the element's carriers (one subject in fifty) are among them
+    s = orc.Search(util.oracle_options(opt), queries, masks=masks)
+    for oid in sample:
+        o = s.subject(db.subject_packed(oid), slen)
+        g = first[first["oid"] == oid]
+        assert len(g) == len(o["hsps"]), (oid, len(g), len(o["hsps"]))
+        for f in HSP_FIELDS[1:]:
+            assert np.array_equal(g[f], o["hsps"][f]), (oid, f)
+        assert np.array_equal(g["evalue"].view(np.uint64), o["hsps"]["evalue"].view(np.uint64)), oid
+    print("skewed shard: %d ranges, %d rescans, %d direct-kernel ranges, %d library sorts, %d seeds, %d HSPs on %d subjects"
+          % (d.ranges, d.scan_rescans, d.direct_ranges, d.library_sorts, d.seeds, len(first), len(hit)))
