@@ -118,8 +118,9 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
             // (seeds that come in scan order are in the order of the key's scan-position bits already: the stable sort has
             // subject | slot left to do)
             const int s_done = (from_segments && E.seg_ordered) ? K.s_bits : 0;
-            if (packed) HIPCHK(sort_keys_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, n, v_bits + s_done, v_bits + ck_bits, st)); if (diag) GBN_DIAG_LOCKED(diag->library_sorts++);
+            if (packed) HIPCHK(sort_keys_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, n, v_bits + s_done, v_bits + ck_bits, st));
             else HIPCHK(sort_pairs_u64(KS.sort_tmp, tb, KS.key_a, KS.key_b, KS.idx_a, KS.idx_b, n, ck_bits, st));
+            if (diag) GBN_DIAG_LOCKED(diag->library_sorts++);
             KS.kt.mark(-1, st);
         }
         // key_b = sorted composite keys, idx_b = ext_left of the seeds in that order (packed: both in key_b)

@@ -8,7 +8,6 @@
 //                        every seed extended by a thread of its own, the runs replayed afterwards
 // Integer work only: no MFMA.
 #include "scan_dev.hpp"
-#include <hipcub/hipcub.hpp>
 #include <cstring>
 #include <algorithm>
 
@@ -1107,17 +1106,6 @@ hipError_t launch_diag_ungapped(const GbnExtParams &p, hipStream_t st, GbnKernel
 }
 
 
-// stable LSD radix sort of u64 keys on bits [begin_bit, end_bit)
-hipError_t sort_keys_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, int64_t n, int begin_bit, int end_bit, hipStream_t st)
-{
-    return hipcub::DeviceRadixSort::SortKeys(tmp, tmp_bytes, kin, kout, (int)n, begin_bit, end_bit, st);
-}
-
-// stable LSD radix sort of (u64 key, u32 value) pairs
-hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout,
-                          const uint32_t *vin, uint32_t *vout, int64_t n, int end_bit, hipStream_t st)
-{
-    return hipcub::DeviceRadixSort::SortPairs(tmp, tmp_bytes, kin, kout, vin, vout, (int)n, 0, end_bit, st);
-}
+// (sort_keys_u64 / sort_pairs_u64: radix64.hip)
 
 }  // namespace gbn

@@ -6,7 +6,7 @@ set -e
 cd "$(dirname "$0")/../gblastn_amd/csrc"
 NAME=$1; FLAGS=$2
 OUT=../../variants; mkdir -p $OUT /tmp/var_$NAME
-for f in kernels.hip seed_stage.hip scan_bin.hip scan_runs.hip seed_order.hip seed_sort.hip gapped.hip lutbuild.hip engine.cpp engine_scan.cpp engine_stages.cpp engine_abi.cpp batch.cpp stat.cpp hsp_host.cpp collector.cpp dbreader.cpp dust.cpp traceback.cpp pipeline.cpp; do
+for f in kernels.hip seed_stage.hip scan_bin.hip scan_runs.hip seed_order.hip seed_sort.hip radix64.hip gapped.hip lutbuild.hip engine.cpp engine_scan.cpp engine_stages.cpp engine_abi.cpp batch.cpp stat.cpp hsp_host.cpp collector.cpp dbreader.cpp dust.cpp traceback.cpp pipeline.cpp; do
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -ffp-contract=off $FLAGS -c $f -o /tmp/var_$NAME/${f%.*}.o &
 done
 wait
