@@ -435,6 +435,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             used_runs = rec_limit > 0 && hit && rs->runs;
             if (used_runs) {
                 B.run_fp = rs->run_fp; B.run_pos = rs->run_pos; B.run_start = rs->run_start; B.rec = nullptr; B.tcur = nullptr;
+                B.run_item_cells = B.S.ncells <= ((int64_t)1 << 20) ? 64 : GBN_RUNS_ITEM_CELLS;
                 B.work = reinterpret_cast<uint32_t *>(E.counters + 4); B.rare_parts = (int)std::max(1ll, gbn::switch_value("GBN_RUNS_RARE_PARTS", 1));
                 E.rec_runs_passes++;
             }

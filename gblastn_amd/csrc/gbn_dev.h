@@ -105,6 +105,7 @@ struct GbnBinParams {
     // front, [14:8] the 7 bits behind, [15] the eighth) and its position id (run_pos: tile << GBN_BIN_TILE_BITS | index).  The
     // cell is the run: a pass reads the runs of the cells its batch occupies and nothing else.  Null: stream form (rec / tcur).
     const uint16_t *run_fp; const uint32_t *run_pos; const uint32_t *run_start;
+    int run_item_cells;             // cells a wave of probe_runs_kernel draws at a time (a multiple of 64 that divides the table; 0: GBN_RUNS_ITEM_CELLS)
 };
 
 // ---- building the runs from the streams of a complete record set (scan_runs.hip): count per cell -> run_start (prefix sums) ->

@@ -326,7 +326,10 @@ probe_runs_kernel(GbnBinParams B)
         }
     };
 
-    const uint32_t nitems = (uint32_t)(P.ncells / GBN_RUNS_ITEM_CELLS);
+    // (small tables -- 4^8 cells, runs of tens of thousands of records -- are dealt out in stretches of 64 cells: with 256 a one-query
+    // batch kept 256 of the 6,144 waves busy)
+    const uint32_t item_cells = B.run_item_cells > 0 ? (uint32_t)B.run_item_cells : (uint32_t)GBN_RUNS_ITEM_CELLS;
+    const uint32_t nitems = (uint32_t)(P.ncells / item_cells);
     const uint4 *fp4 = reinterpret_cast<const uint4 *>(B.run_fp);
     const uint32_t m16 = m4 | (fp16 ? 0x80008000u : 0u);               // cells of one entry: the sixteenth bit joins the test (probe_bin_kernel tests it per queued record)
     uint32_t *side_w = s_side[wave];
@@ -335,14 +338,14 @@ probe_runs_kernel(GbnBinParams B)
     while (item < nitems) {
         uint32_t nitem = 0;
         if (lane == 0) nitem = atomicAdd(&B.work[0], 1u);               // (asked for now, read when this item is done)
-        const uint32_t cbase = item * (uint32_t)GBN_RUNS_ITEM_CELLS;
+        const uint32_t cbase = item * item_cells;
         const uint16_t *side_bin = B.sidet + B.side_start[cbase >> cbits];      // (an item lies in one bin)
         // table words and run boundaries of the first stretch
         uint32_t t_n = B.cellt[cbase + lane], rs_n = B.run_start[cbase + lane], re_n = B.run_start[cbase + lane + 1];
         uint32_t cw_n = fp16 ? P.cellw[cbase + lane] : 0u;
-        for (uint32_t cs = cbase; cs < cbase + (uint32_t)GBN_RUNS_ITEM_CELLS; cs += 64) {
+        for (uint32_t cs = cbase; cs < cbase + item_cells; cs += 64) {
             const uint32_t t = t_n, rs = rs_n, re = re_n, cw = cw_n;
-            if (cs + 64 < cbase + (uint32_t)GBN_RUNS_ITEM_CELLS) {      // the next stretch's, a stretch ahead
+            if (cs + 64 < cbase + item_cells) {      // the next stretch's, a stretch ahead
                 t_n = B.cellt[cs + 64 + lane]; rs_n = B.run_start[cs + 64 + lane]; re_n = B.run_start[cs + 65 + lane];
                 cw_n = fp16 ? P.cellw[cs + 64 + lane] : 0u;
             }
