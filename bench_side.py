@@ -14,10 +14,12 @@ BENCH = os.path.join(ROOT, "bench.py")
 
 def valu_roofline(workload, ms_per_step, launches_per_step):
     """VALU issue roofline of a whole step: wave-instructions per step (SQ_INSTS_VALU summed over the kernels of the committed
-    rocprofv3 --pmc pass named in profiles/valu_counts.json -- a constant of that profile, not a counter of this run) against
-    what 1,024 SIMDs issue in ms_per_step.  tools/valu_microbench.hip (profiles/r04_valu_microbench.txt): a wave64 add / sub /
-    and / or / xor / mov / lshr issues every 2.4 cycles, everything else integer (shifts left, bfe, alignbit, perm, cmp, min /
-    max, cndmask, three-operand forms, DPP) every 4.4; the fraction is given for both."""
+    rocprofv3 --pmc pass named in profiles/valu_counts.json -- a constant of that profile, refreshed every round, not a counter of
+    this run) against ONE peak: 1,024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: a wave64 VALU op
+    issues over two cycles) = 1.2288e12 wave-instructions per second.  Beside the fraction, as explanation and not as other
+    denominators: what tools/valu_microbench.hip measures per instruction class on this part (profiles/r04_valu_microbench.txt: add /
+    sub / and / or / xor / mov / lshr every 2.4 cycles, everything else integer -- shifts left, bfe, alignbit, perm, cmp, min / max,
+    cndmask, three-operand forms, DPP -- every 4.4)."""
     tf = os.path.join(ROOT, "profiles", "valu_counts.json")
     if not os.path.exists(tf):
         return None
@@ -26,11 +28,13 @@ def valu_roofline(workload, ms_per_step, launches_per_step):
         if not e:
             return None
         n = float(e["valu_wave_instructions_per_launch"]) * launches_per_step
-        clock = 2.4e9
-        per_ms = lambda cyc: 1024 * clock / cyc * 1e-3
+        peak = 1024 * 2.4e9 / 2.0
         return {"bound": "valu issue", "wave_instructions_per_step": n, "source": e.get("source"),
-                "frac_at_4.4_cycles": n / (per_ms(4.4) * ms_per_step), "frac_at_2.4_cycles": n / (per_ms(2.4) * ms_per_step),
-                "peak_wave_instructions_per_ms": [per_ms(4.4), per_ms(2.4)], "by_kernel_per_launch": e.get("by_kernel")}
+                "peak_wave_instructions_per_s": peak, "peak_what": "1,024 SIMDs x 2.4 GHz / 2 cycles per wave64 VALU instruction (MI355X_MICROARCH.md)",
+                "frac": n / (peak * ms_per_step * 1e-3),
+                "measured_issue_cycles_by_class": {"add/sub/and/or/xor/mov/lshr": 2.4, "other integer (shl, bfe, alignbit, perm, cmp, min/max, cndmask, 3-operand, DPP)": 4.4,
+                                                   "source": "tools/valu_microbench.hip, profiles/r04_valu_microbench.txt -- why the step cannot reach frac 1: its instruction mix issues at 4.0 cycles on average"},
+                "by_kernel_per_launch": e.get("by_kernel")}
     except Exception:
         return None
 
