@@ -5,6 +5,7 @@ database -- the twelve standard tabular columns of the final alignments equal th
 exactly the rows the library calls give (a consistency property, not oracle parity)."""
 import os
 import subprocess
+import sys
 import numpy as np
 import pytest
 from gblastn_amd import api
@@ -278,3 +279,27 @@ def test_cli_batch_plan_of_the_reference_and_unchanged_rows(tmp_path, mode):
                     acc += lens[i + n]; n += 1
                 assert n == t_; i += n
     assert len(rows["mixer"]) >= 40 and rows["mixer"] == rows["fixed"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("stage", ["traceback", "prelim"])
+def test_cli_eight_search_threads_on_one_device_give_the_rows_of_one(tmp_path, stage):
+    """The C5 width inside one process: -gpu_id -1 -num_threads 8 deals the database's volumes (ten here, written by
+    tools/make_synth_blastdb.py) to EIGHT search threads -- a pipeline and a resident shard each, all on the one device of this box, as
+    eight GPUs of a node would each hold theirs (GB/gpu_blast_multi_gpu_utils.cpp:105-139) -- and merges their results per query:
+    the rows of one thread over the whole database, the batch plan included (the parts' hits are summed for the mixer)."""
+    d = tmp_path / "db"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "make_synth_blastdb.py"), str(d), "--subjects", "100", "--subject-len", "200000",
+                        "--volumes", "10", "--queries", "60", "--planted-fraction", "0.7"], capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-1000:]
+    rows = {}
+    for n in ("1", "8"):
+        out = tmp_path / ("out%s.tsv" % n)
+        p = subprocess.run([CLI, "-db", str(d / "c2db"), "-query", str(d / "queries.fa"), "-use_gpu", "true", "-gpu_id", "-1", "-num_threads", n,
+                            "-mode", "2", "-stage", stage, "-out", str(out)], capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        rows[n] = out.read_text().splitlines()
+        if stage == "prelim":
+            parts = [l.split() for l in p.stderr.splitlines() if l.startswith("# ") and l[2].isdigit()]
+            assert len(parts) == int(n), p.stderr[-1500:]
+    assert len(rows["1"]) >= 30 and rows["1"] == rows["8"]
