@@ -684,7 +684,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
     trace_mark("traceback: starts");
     // subjects that have lists, each fetched once -- of a long subject only the stretch the extensions can reach
     // (AdjustSubjectRange: query length + 3000 either side of an HSP) is read back and unpacked
-    struct Work { int32_t local; int64_t first_list, end_list; int32_t lo; std::vector<uint8_t> bases; };
+    struct Work { int32_t local; int64_t first_list, end_list; int32_t lo; std::vector<uint8_t> bases; int32_t hi = 0; size_t packed_at = 0; };
     std::vector<Work> work;
     for (int64_t l = 0; l < nlists;) {
         const int32_t oid = hsps[list_start[l]].oid;
@@ -695,6 +695,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
         work.push_back(Work{local, l, e, 0, {}});
         l = e;
     }
+    std::vector<uint8_t> packed;
     {
         std::vector<int64_t> src_off; std::vector<int32_t> nbytes; std::vector<int32_t> his, wbytes;
         const bool chunked = !db->real_of.empty();
@@ -732,32 +733,34 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
                 wbytes.push_back(total);
             }
         }
-        std::vector<uint8_t> packed;
         const int rc = gather_shard_bytes(*db, src_off, nbytes, packed);
         if (rc != GBN_OK) return rc;
         trace_mark("traceback: subject stretches read back");
         size_t at = 0;
-        for (size_t k = 0; k < work.size(); k++) {
-            Work &w = work[k];
-            const int32_t n = his[k] - w.lo; const uint8_t *p = packed.data() + at;
-            w.bases.resize(((size_t)n + 3) / 4 * 4 + 4);
-            uint8_t *o = w.bases.data();
-            for (int32_t i = 0; i < (n + 3) / 4; i++, o += 4) { const uint8_t c = p[i]; o[0] = c >> 6; o[1] = (c >> 4) & 3; o[2] = (c >> 2) & 3; o[3] = c & 3; }
-            at += (size_t)wbytes[k];
-            if (!db->amb.empty())               // the codes the 2-bit data cannot hold
-                for (const GbnDb::AmbRun &r : db->amb[(size_t)w.local]) {
-                    const int32_t a = std::max(r.start, w.lo), e = std::min(r.start + r.length, his[k]);
-                    for (int32_t x = a; x < e; x++) w.bases[(size_t)(x - w.lo)] = r.code;
-                }
-        }
+        for (size_t k = 0; k < work.size(); k++) { work[k].hi = his[k]; work[k].packed_at = at; at += (size_t)wbytes[k]; }
     }
+    // a subject's stretch one base per byte, with the codes the 2-bit data cannot hold: made by the thread that aligns the subject's
+    // lists (round 6; one thread used to unpack all stretches of a batch -- 20 MB for 2,500 subjects -- in front of the parallel part:
+    // the serial third of a batch's traceback at sixteen threads)
+    auto unpack = [&](Work &w) {
+        const int32_t n = w.hi - w.lo; const uint8_t *p = packed.data() + w.packed_at;
+        w.bases.resize(((size_t)n + 3) / 4 * 4 + 4);
+        uint8_t *o = w.bases.data();
+        for (int32_t i = 0; i < (n + 3) / 4; i++, o += 4) { const uint8_t c = p[i]; o[0] = c >> 6; o[1] = (c >> 4) & 3; o[2] = (c >> 2) & 3; o[3] = c & 3; }
+        if (!db->amb.empty())
+            for (const GbnDb::AmbRun &r : db->amb[(size_t)w.local]) {
+                const int32_t a = std::max(r.start, w.lo), e = std::min(r.start + r.length, w.hi);
+                for (int32_t x = a; x < e; x++) w.bases[(size_t)(x - w.lo)] = r.code;
+            }
+    };
     struct Done { int32_t oid, query; std::vector<Item> items; };
     std::vector<std::vector<Done>> per_work(work.size());
     std::atomic<size_t> next{0}; std::atomic<int> failed{GBN_OK}; std::string err;
     std::mutex err_mu;
     auto body = [&]() {
         for (size_t k; (k = next.fetch_add(1)) < work.size();) {
-            const Work &w = work[k];
+            Work &w = work[k];
+            unpack(w);
             for (int64_t l = w.first_list; l < w.end_list; l++) {
                 const GbnHSP *first = hsps + list_start[l]; const size_t n = (size_t)(list_start[l + 1] - list_start[l]);
                 Done d; d.oid = first->oid; d.query = first->context / 2;

@@ -114,6 +114,7 @@ public:
         int64_t id = 0; SQueryBatch queries;
         std::unique_ptr<CBlastPrelimSearch> prelim; std::unique_ptr<CBlastHSPStream> stream; std::unique_ptr<CBlastTracebackSearch> traceback;
         std::string error; int status = GBN_OK;
+        bool closed = false;                            // gbn_prelim_search_end called, the lists through the collector
     };
     typedef std::unique_ptr<SWorkItem> TItem;
 
@@ -205,7 +206,7 @@ private:
                 std::unique_lock<std::mutex> lk(mu_);
                 // nothing to scan next: the batch in flight is finished now instead of underneath a scan
                 if (!prelim_queue_.count(next_search_) && in_setup_ == 0 && query_queue_.empty() && prev && !closing_ && !setup_done_) {
-                    lk.unlock(); CloseStream(*prev); PushTrace(std::move(prev)); lk.lock();
+                    lk.unlock(); PushTrace(std::move(prev)); lk.lock();
                 }
                 cv_.wait(lk, [&] { return closing_ || prelim_queue_.count(next_search_) || setup_done_; });
                 auto f = prelim_queue_.find(next_search_);
@@ -214,11 +215,14 @@ private:
             }
             if (!it) continue;
             Guard(*it, [&] { it->prelim->Begin(); });                        // the scan of this batch; the stages of `prev` finish underneath
-            if (prev) { CloseStream(*prev); PushTrace(std::move(prev)); }
-            if (!overlap_) { CloseStream(*it); PushTrace(std::move(it)); }
+            // (round 6: `prev` is finished -- gbn_prelim_search_end + its lists through the collector -- by the traceback thread that takes
+            // it, not here: this thread goes straight to the next batch's scan, as bench.py's loop hands its passes to a merger thread;
+            // 0.4 ms per 5 Mb batch that the GPU used to idle)
+            if (prev) PushTrace(std::move(prev));
+            if (!overlap_) { CloseStream(*it); it->closed = true; PushTrace(std::move(it)); }
             else prev = std::move(it);
         }
-        if (prev) { CloseStream(*prev); PushTrace(std::move(prev)); }
+        if (prev) PushTrace(std::move(prev));
         std::unique_lock<std::mutex> lk(mu_); prelim_done_ = true; cv_.notify_all();
     }
     void PushTrace(TItem it) { std::unique_lock<std::mutex> lk(mu_); trace_queue_.push_back(std::move(it)); cv_.notify_all(); }
@@ -232,6 +236,7 @@ private:
                 else if (prelim_done_ || closing_) return;
             }
             if (!it) continue;
+            if (!it->closed) { CloseStream(*it); it->closed = true; }
             if (traceback_) Guard(*it, [&] { it->traceback.reset(new CBlastTracebackSearch()); it->traceback->Run(*it->prelim, src_, *it->stream, inner_threads_); });
             Deliver(std::move(it));
         }
