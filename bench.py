@@ -546,7 +546,7 @@ def report(R, regions, elapsed, nhsp, diags, region_ms, engine_only, config_meas
             },
             "roofline": {"bound": "hbm", "kernel": dom_label,
                          "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "box_copy_GBps": box_copy,
+                         "box_copy_GBps": box_copy, "box": box_facts(dev),
                          "frac": achieved / 8000.0, "traffic": traffic,
                          "traffic_source": ("profiles/scan_traffic.json (%s): rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this workload, "
                                             "corrected as MI355X_MICROARCH.md prescribes; a constant of that profile, not a counter of this run"
@@ -569,6 +569,29 @@ def report(R, regions, elapsed, nhsp, diags, region_ms, engine_only, config_meas
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def box_facts(dev):
+    """what may tell one box from another (the binning kernel's time differs 7.0-7.7 ms between boxes): the device's clocks as the runtime
+    reports them and, when rocm-smi answers, the power cap and the current clocks -- best effort, never fails the line"""
+    out = {}
+    try:
+        import torch
+        p = torch.cuda.get_device_properties(dev)
+        for k in ("name", "gcnArchName", "multi_processor_count", "clock_rate", "memory_clock_rate", "memory_bus_width", "total_memory", "L2_cache_size"):
+            if hasattr(p, k):
+                out[k] = getattr(p, k)
+    except Exception as e:      # noqa
+        out["props_error"] = repr(e)[:100]
+    try:
+        import subprocess
+        r = subprocess.run(["rocm-smi", "--showpower", "--showmaxpower", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
+        j = json.loads(r.stdout)
+        card = j.get("card%d" % (dev.index or 0)) or next(iter(j.values()))
+        out["rocm_smi"] = {k: v for k, v in card.items() if any(t in k.lower() for t in ("power", "sclk", "mclk", "fclk"))}
+    except Exception as e:      # noqa
+        out["rocm_smi_error"] = repr(e)[:100]
+    return out
 
 
 def main():

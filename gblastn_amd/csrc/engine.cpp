@@ -625,7 +625,13 @@ int grow_seed_buffers(size_t want) {
     return GBN_OK;
 }
 int grow_key_buffers(Engine::KeySet &KS, size_t n) {
-    if (n <= KS.key_cap) return GBN_OK;
+    if (n <= KS.key_cap) {
+        // (buffers made while the run-head threshold was above their size have no extension records; a range that is over the
+        // threshold as it stands now -- GBN_DIAG_COMPACT_MIN changed in between -- gets them here, not the other path)
+        if (!KS.ext_rec && n >= (size_t)gbn::switch_value("GBN_DIAG_COMPACT_MIN", (long long)GBN_DIAG_COMPACT_MIN))
+            return dev_alloc(KS.ext_rec, KS.key_cap * 8);
+        return GBN_OK;
+    }
     dev_free(KS.key_a); dev_free(KS.key_b); dev_free(KS.idx_a); dev_free(KS.idx_b);
     dev_free(KS.cell_diag); dev_free(KS.cell_level); dev_free(KS.ext_rec); dev_free(KS.sort_tmp);
     size_t cap = std::max<size_t>(n + n / 8, 1 << 16);      // (room to spare: seed counts of consecutive ranges differ by a fraction of a percent, and a regrow frees and allocates gigabytes)

@@ -51,10 +51,10 @@ hipError_t sort_pairs_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uin
 int scan_slice_count(const GbnScanParams &p);
 int scan_slice_blocks(const GbnScanParams &p, int num_cu);
 hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
-                             unsigned long long *seg_max, hipStream_t st);
+                             unsigned long long *seg_max, hipStream_t st, const GbnKeyParams *keys = nullptr);
 int scan_slice_segments(const GbnScanParams &p, int num_cu, int *ordered);
 hipError_t launch_seed_compact(const GbnDevSeed *seg, const uint32_t *seg_count, unsigned long long *seg_first, int nseg, uint32_t seg_cap,
-                               GbnDevSeed *out, unsigned long long out_cap, hipStream_t st);
+                               GbnDevSeed *out, unsigned long long out_cap, hipStream_t st, const GbnKeyParams *keys = nullptr);
 hipError_t sort_keys_u64(void *tmp, size_t &tmp_bytes, const uint64_t *kin, uint64_t *kout, int64_t n, int begin_bit, int end_bit, hipStream_t st);
 
 
@@ -137,6 +137,8 @@ struct Engine {
     GbnDevSeed *slice_seg = nullptr; size_t slice_seg_cap = 0;        // scan_slice_kernel: the workgroups' seed segments
     bool seg_valid = false; int seg_n = 0; uint32_t seg_len = 0;       // the last scan left its seeds there (seg_n segments of seg_len slots, counts in seg_counts), not in `seeds`
     bool seg_ordered = false;       // ... and the segments read one after the other are in scan order (subject, position, entry)
+    bool seg_keys = false; GbnKeyParams seg_key_params;     // ... and they hold 8-byte composite keys made with these parameters, not seeds (round 6)
+    bool want_key_seeds = false;    // the range being scanned may leave its seeds as keys (set by search_range: not with keep_stages)
     uint32_t *seg_counts = nullptr; unsigned long long *seg_firsts = nullptr;     // GBN_SLICE_SEGS counts / + 1 prefix sums (scratch of the consumers)
     GbnDevSeed *seeds_async = nullptr; size_t seeds_async_cap = 0;     // the seeds an asynchronous seed stage works on
     hipEvent_t ev_seed = nullptr;
@@ -307,6 +309,8 @@ int run_scan(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiagnostics *dia
 
 // ---- the stages behind the scan (engine_stages.cpp)
 int compact_seeds(hipStream_t st);
+void seed_key_layout(const GbnBatch &b, const GbnDb &db, int32_t s0, int32_t s1, GbnKeyParams &K, int *ck_bits, int *scan_bits = nullptr, int *group_key_bits = nullptr);
+bool seed_key_layout_fits(const GbnBatch &b, const GbnKeyParams &K, int ck_bits);
 int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res, GbnDiagnostics *diag, int keep_stages, int overlap = 0);
 void hitbuf_drain();
 int stage_get(size_t bytes, void **p, size_t *cap);

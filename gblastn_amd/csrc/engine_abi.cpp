@@ -1035,6 +1035,7 @@ int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag)
     unsigned long long cnt[2] = {0, 0};
     for (int r = 0; r < repeats; r++) {
         int64_t bases = 0;
+        E.want_key_seeds = false;                           // (a scan alone: its seeds stay seeds)
         rc = run_scan(*batch, *db, 0, db->num_seqs, diag, cnt, &bases);
         if (rc == kSkewedRange) { set_error("gbn_scan_only: lookup words pile up in a few bins of this shard (use gbn_prelim_search, which splits the range)"); return GBN_ERR_UNSUPPORTED; }
         if (rc) return rc;

@@ -282,7 +282,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     // tables as wide as the word (stride 1, every lookup hit a seed): the presence bits are sliced through the LDS
     // instead of the scan positions being written out by key range (scan_slice_kernel); GBN_SCAN_SLICE=0: off
     const bool sliced = !direct && scan_slices(b) > 0;
-    E.seg_valid = false;
+    E.seg_valid = false; E.seg_keys = false;
     const int nb = (direct || sliced) ? 1 : choose_bins(b);
     if (nb == 1 && E.ahead.valid) { E.ahead.valid = false; E.ahead_misses++; }       // (a scan of another kind: nobody will want the records binned ahead)
     if (nb == 1) E.last_key_valid = false;
@@ -309,6 +309,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
     // streams of bins that differ in size: {capacity, offset in a writer's row} per bin, made from the uncapped totals of an attempt that
     // overflowed (repeat-rich subjects: a few bins take most of the scan positions); exact_row: records per row
     std::vector<uint32_t> exact; size_t exact_row = 0; size_t last_nstream = 0;
+    bool keys_written = false;                  // the slice scan wrote composite keys, not seeds (round 6)
     bool counted = false;                       // the cache's hit / miss of this call is counted (a range scanned again counts once)
     bool used_runs = false;                     // the pass went over sorted records
     struct NotInUse { ~NotInUse() { for (RecordSet *c : E.rec_sets) c->in_use = false; } } not_in_use_on_return;     // (in_use: a failing allocation may not evict the pass's own set)
@@ -344,7 +345,20 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
                     E.slice_seg_cap = need + need / 8;
                 }
                 if (!E.seg_counts && ((rc = dev_alloc(E.seg_counts, (size_t)GBN_SLICE_SEGS)) || (rc = dev_alloc(E.seg_firsts, (size_t)GBN_SLICE_SEGS + 1)))) return rc;
-                HIPCHK(launch_scan_slice(P, E.num_cu, E.slice_seg, (uint32_t)slice_seg_cap, E.seg_counts, E.counters + 2, E.stream));
+                // Round 6: when the range's seeds will go through the seed-order kernels -- an ordered scan, the composite key and its value
+                // fit 64 bits, few enough subjects and slots, no seed list asked for -- the scan writes the 8-byte key instead of the 16-byte
+                // seed (what is only known afterwards -- enough seeds? -- decides in seed_stage; keys are decoded again if not).
+                // GBN_SEED_KEYS=0: seeds as before (A/B).
+                GbnKeyParams CK; int ck_bits = 0; keys_written = false;
+                if (ordered && E.want_key_seeds && gbn::switch_value("GBN_SEED_KEYS", 1) != 0 && gbn::switch_value("GBN_SEED_CKEYS", 1) == 1 &&
+                    gbn::switch_value("GBN_SEED_ORDER", 1) != 0) {
+                    seed_key_layout(b, db, s0, s1, CK, &ck_bits);
+                    CK.v_bits = 8 + CK.qh_bits;
+                    if (seed_key_layout_fits(b, CK, ck_bits) && ck_bits + CK.v_bits <= 64 && s1 - s0 <= GBN_ORDER_MAX_SUBJ && (1 << CK.group_bits) <= GBN_ORDER_MAX_SLOTS) {
+                        CK.seg_keys = 1; keys_written = true; E.seg_key_params = CK;
+                    }
+                }
+                HIPCHK(launch_scan_slice(P, E.num_cu, E.slice_seg, (uint32_t)slice_seg_cap, E.seg_counts, E.counters + 2, E.stream, keys_written ? &CK : nullptr));
             } else HIPCHK(launch_scan_seed(P, scan_grid(ts.ntiles), E.stream));
             HIPCHK(hipEventRecord(E.ev1, E.stream));
         } else {
@@ -587,7 +601,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
         }
         if (sliced) {       // the seeds sit in the workgroups' segments; E.seeds only has to be long enough for compact_seeds
             if (cnt[0] > E.seed_cap && (rc = grow_seed_buffers((size_t)cnt[0] + (cnt[0] >> 3)))) return rc;
-            E.seg_valid = cnt[0] > 0; E.seg_n = slice_blocks; E.seg_len = (uint32_t)slice_seg_cap; E.seg_ordered = slice_ordered;
+            E.seg_valid = cnt[0] > 0; E.seg_n = slice_blocks; E.seg_len = (uint32_t)slice_seg_cap; E.seg_ordered = slice_ordered; E.seg_keys = keys_written && E.seg_valid;
             break;
         }
         if (cnt[0] <= E.seed_cap) break;

@@ -11,9 +11,32 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
 // the seeds of the last scan in one array (E.seeds), for the consumers that do not read scan_slice_kernel's segments
 int compact_seeds(hipStream_t st) {
     if (!E.seg_valid) return GBN_OK;
-    HIPCHK(launch_seed_compact(E.slice_seg, E.seg_counts, E.seg_firsts, E.seg_n, E.seg_len, E.seeds, E.seed_cap, st));
-    E.seg_valid = false;
+    HIPCHK(launch_seed_compact(E.slice_seg, E.seg_counts, E.seg_firsts, E.seg_n, E.seg_len, E.seeds, E.seed_cap, st, E.seg_keys ? &E.seg_key_params : nullptr));
+    E.seg_valid = false; E.seg_keys = false;
     return GBN_OK;
+}
+
+// The layout of a seed's composite key for the range [s0, s1) of this shard and this batch (gbn_composite_key): what seed_stage
+// sorts by, and -- since round 6 -- what the ordered slice scan writes instead of seeds when it may (run_scan_impl).
+void seed_key_layout(const GbnBatch &b, const GbnDb &db, int32_t s0, int32_t s1, GbnKeyParams &K, int *ck_bits, int *scan_bits, int *group_key_bits)
+{
+    std::memset(&K, 0, sizeof(K));
+    K.q_descending = (b.lut.type == GBN_LUT_MB); K.container_hash = b.container; K.diag_len = b.diag_len;
+    // key widths: the radix sorts stop at the top bit a key can have
+    auto bits_for = [](uint64_t below) { int k = 1; while (k < 63 && ((uint64_t)1 << k) < below) k++; return k; };
+    int32_t max_len = 1;
+    for (int32_t s = 0; s < db.num_seqs; s++) max_len = std::max(max_len, db.len[s]);
+    K.q_bits = std::min(32, bits_for((uint64_t)b.qlen + 1));
+    K.group_bits = b.container ? 9 : bits_for((uint64_t)std::max(b.diag_len, 2));
+    if (scan_bits) *scan_bits = std::min(64, K.q_bits + bits_for((uint64_t)max_len + 1));
+    if (group_key_bits) *group_key_bits = std::min(64, K.group_bits + bits_for((uint64_t)db.num_seqs + 1));
+    K.s_bits = bits_for((uint64_t)max_len + 1); K.qh_bits = std::max(0, K.q_bits - K.group_bits);
+    K.subj_base = s0;
+    if (ck_bits) *ck_bits = K.group_bits + bits_for((uint64_t)(s1 - s0) + 1) + K.s_bits;        // (the query key's high bits travel in the value)
+}
+bool seed_key_layout_fits(const GbnBatch &b, const GbnKeyParams &K, int ck_bits)
+{
+    return ck_bits <= 64 && K.group_bits < 32 && K.qh_bits <= 24 && b.lut.word - b.lut.lut < 256;
 }
 
 // seeds of a range -> scan order (two stable sorts) -> diagonal filter + ungapped extension on stream `st`;
@@ -33,28 +56,32 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_stage = now();
     if (phase != 2 && (rc = grow_key_buffers(KS, (size_t)n))) return rc;
-    GbnKeyParams K; std::memset(&K, 0, sizeof(K));
+    GbnKeyParams K; int ck_bits = 0, scan_bits = 0, group_key_bits = 0;
+    seed_key_layout(b, db, s0, s1, K, &ck_bits, &scan_bits, &group_key_bits);
     K.seeds = seeds; K.n = n; K.key_scan = KS.key_a; K.idx = KS.idx_a;
-    K.q_descending = (b.lut.type == GBN_LUT_MB); K.container_hash = b.container; K.diag_len = b.diag_len;
-    // key widths: the radix sorts stop at the top bit a key can have
-    auto bits_for = [](uint64_t below) { int k = 1; while (k < 63 && ((uint64_t)1 << k) < below) k++; return k; };
-    int32_t max_len = 1;
-    for (int32_t s = 0; s < db.num_seqs; s++) max_len = std::max(max_len, db.len[s]);
-    K.q_bits = std::min(32, bits_for((uint64_t)b.qlen + 1));
-    K.group_bits = b.container ? 9 : bits_for((uint64_t)std::max(b.diag_len, 2));
-    const int scan_bits = std::min(64, K.q_bits + bits_for((uint64_t)max_len + 1));
-    const int group_key_bits = std::min(64, K.group_bits + bits_for((uint64_t)db.num_seqs + 1));
     // Many seeds (blastn shapes): ONE sort of a composite key, the seed itself travels in the key (seed_ckeys_kernel) --
     // when subject | slot | s_scan | query key fit 64 bits; else, and for the few seeds of megablast shapes, two
     // stable sorts of (rank, index) pairs
     const int64_t compact_min = (int64_t)gbn::switch_value("GBN_DIAG_COMPACT_MIN", (long long)GBN_DIAG_COMPACT_MIN);
     const bool ck_on = gbn::switch_value("GBN_SEED_CKEYS", 1) != 0;
-    K.s_bits = bits_for((uint64_t)max_len + 1); K.qh_bits = std::max(0, K.q_bits - K.group_bits);
-    K.subj_base = s0;
-    const int ck_bits = K.group_bits + bits_for((uint64_t)(s1 - s0) + 1) + K.s_bits;        // (the query key's high bits travel in the value)
-    const bool composite = ck_on && KS.ext_rec && n >= compact_min && ck_bits <= 64 && K.group_bits < 32 && K.qh_bits <= 24 && b.lut.word - b.lut.lut < 256;
-    const bool segmented = seeds == E.seeds && E.seg_valid;           // (an asynchronous stage works on a copy of its own)
-    const bool from_segments = segmented && composite && !keep_stages;  // seed_ckeys_kernel reads the segments as they are
+    const bool composite = ck_on && KS.ext_rec && n >= compact_min && seed_key_layout_fits(b, K, ck_bits);
+    bool segmented = seeds == E.seeds && E.seg_valid;                 // (an asynchronous stage works on a copy of its own)
+    bool from_segments = segmented && composite && !keep_stages;      // seed_ckeys_kernel reads the segments as they are
+    // ... and when the value (ext_left and the query key's high bits) fits underneath the key too, it travels in the
+    // key's low bits: a sort of keys only, on the bits above the value (GBN_SEED_CKEYS=2: always pairs)
+    const bool ck_pack = gbn::switch_value("GBN_SEED_CKEYS", 1) != 2;
+    const int v_bits = 8 + K.qh_bits;
+    const bool packed = composite && ck_pack && ck_bits + v_bits <= 64;
+    // Seeds that come in scan order, subject by subject (scan_fold_ordered_kernel's segments): a stable partition of every
+    // subject's seeds by slot is all that is left, and seed_order.hip does it as a counting sort that builds the keys
+    // on its way -- no key kernel, no radix passes (GBN_SEED_ORDER=0: keys + the library sort, as rounds 2-3)
+    const int nsubj = s1 - s0;
+    const bool order = from_segments && E.seg_ordered && packed && nsubj <= GBN_ORDER_MAX_SUBJ && (1 << K.group_bits) <= GBN_ORDER_MAX_SLOTS &&
+                       n >= (int64_t)nsubj * 64 && n < ((int64_t)1 << 31) && gbn::switch_value("GBN_SEED_ORDER", 1) != 0 &&
+                       seed_order_scratch_words(n, nsubj, K.group_bits) * sizeof(uint32_t) <= KS.sort_tmp_bytes;
+    // (round 6: a scan that wrote its seeds as composite keys for the seed-order kernels, and a range that does not go through them after
+    // all -- too few seeds, a switch --: the keys are decoded into E.seeds and the range goes on as if the scan had left seeds)
+    if (phase != 2 && segmented && E.seg_keys && !order) { if ((rc = compact_seeds(st))) return rc; segmented = false; from_segments = false; }
     if (phase != 2 && segmented && !from_segments && (rc = compact_seeds(st))) return rc;
     // Few seeds (megablast shapes: some 24 thousand per C2 pass): ONE workgroup sorts their indices by (subject, slot, scan
     // position, query key) in ONE launch (seed_sort.hip; GBN_SMALL_SORT=0: the two library sorts of rounds 1-4, which also
@@ -90,23 +117,11 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         std::stable_sort(tmp.begin(), tmp.end(), [](const GbnSeed &a, const GbnSeed &c) { return a.oid < c.oid; });
         res.seeds.insert(res.seeds.end(), tmp.begin(), tmp.end());
     }
-    // ... and when the value (ext_left and the query key's high bits) fits underneath the key too, it travels in the
-    // key's low bits: a sort of keys only, on the bits above the value (GBN_SEED_CKEYS=2: always pairs)
-    const bool ck_pack = gbn::switch_value("GBN_SEED_CKEYS", 1) != 2;
-    const int v_bits = 8 + K.qh_bits;
-    const bool packed = composite && ck_pack && ck_bits + v_bits <= 64;
     if (composite) {
         K.key_scan = KS.key_a; K.idx = KS.idx_a; K.v_bits = packed ? v_bits : 0;
         if (from_segments) { K.seg = E.slice_seg; K.seg_count = E.seg_counts; K.nseg = E.seg_n; K.seg_cap = E.seg_len; K.seg_first = E.seg_firsts; }
-        // Seeds that come in scan order, subject by subject (scan_fold_ordered_kernel's segments): a stable partition of every
-        // subject's seeds by slot is all that is left, and seed_order.hip does it as a counting sort that builds the keys
-        // on its way -- no key kernel, no radix passes (GBN_SEED_ORDER=0: keys + the library sort, as rounds 2-3)
-        const int nsubj = s1 - s0;
-        const bool order = from_segments && E.seg_ordered && packed && nsubj <= GBN_ORDER_MAX_SUBJ && (1 << K.group_bits) <= GBN_ORDER_MAX_SLOTS &&
-                           n >= (int64_t)nsubj * 64 && n < ((int64_t)1 << 31) && gbn::switch_value("GBN_SEED_ORDER", 1) != 0 &&
-                           seed_order_scratch_words(n, nsubj, K.group_bits) * sizeof(uint32_t) <= KS.sort_tmp_bytes;
         if (phase != 2 && order) {
-            K.key_scan = KS.key_b;
+            K.key_scan = KS.key_b; K.seg_keys = (segmented && E.seg_keys) ? 1 : 0;
             KS.kt.mark(GBN_KT_SORT, st);
             HIPCHK(launch_seed_order(K, nsubj, static_cast<uint32_t *>(KS.sort_tmp), st));
             KS.kt.mark(-1, st);
@@ -191,6 +206,7 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
         return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_stage = now();
     trace_mark("range: scan starts");
+    E.want_key_seeds = !keep_stages;                        // (the seed list of keep_stages wants seeds)
     int rc = run_scan(b, db, s0, s1, diag, cnt, &bases);
     trace_mark("scan done");
     if (rc == kSkewedRange) {

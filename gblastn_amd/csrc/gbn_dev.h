@@ -139,6 +139,10 @@ struct GbnKeyParams {
     // them in segment s (scan_slice_kernel's output as it is); seed i = the i-th of the segments read one after the other
     const GbnDevSeed *seg; const uint32_t *seg_count; int nseg; uint32_t seg_cap;
     unsigned long long *seg_first;      // nseg + 1 entries of scratch (launch_seed_ckeys fills them: index of a segment's first seed)
+    // round 6: the segments hold 8-byte composite keys (key << v_bits | value, what gbn_composite_key makes of a seed) instead of
+    // 16-byte seeds -- scan_fold_ordered_kernel writes them when the engine knows at scan time that the range's seeds go through the
+    // seed-order kernels (seg_cap counts elements either way; a key segment uses half of its bytes)
+    int seg_keys;
 };
 
 // scan_slice_kernel: a slice of the presence bits per workgroup
@@ -210,6 +214,29 @@ __device__ __forceinline__ uint64_t gbn_composite_key(const GbnKeyParams &K, con
     // the value, and seed_ext_kernel puts such a group into their order -- nine bits less to sort
     val = (uint32_t)sd.ext_left | ((K.qh_bits ? (qkey >> K.group_bits) : 0u) << 8);
     return key;
+}
+// ... and back: the seed a packed key (key << v_bits | value) stands for.  The query offset's low bits are not in the key; the slot
+// gives them (slot = (s_scan [+ diag_len] - q_pos) mod slots), its high bits travel in the value.
+__device__ __forceinline__ GbnDevSeed gbn_seed_of_key(const GbnKeyParams &K, uint64_t packed, uint32_t qmax)
+{
+    const uint32_t val = (uint32_t)(packed & ((1ull << K.v_bits) - 1ull));
+    const uint64_t key = packed >> K.v_bits;
+    GbnDevSeed sd;
+    sd.s_scan = (int32_t)(uint32_t)(key & ((1ull << K.s_bits) - 1ull));
+    const uint32_t nslots = K.container_hash ? 512u : (uint32_t)K.diag_len;
+    const uint32_t slot = (uint32_t)(key >> K.s_bits) & (nslots - 1u);
+    sd.subj = (int32_t)(uint32_t)(key >> (K.s_bits + K.group_bits)) + K.subj_base;
+    sd.ext_left = (int32_t)(val & 0xffu);
+    const uint32_t qh = val >> 8;
+    const uint32_t qlow = ((uint32_t)sd.s_scan - slot) & (nslots - 1u);            // q_pos mod slots (diag_len is a multiple of the slots: it drops out)
+    uint32_t q;
+    if (K.q_descending) {
+        // qkey = qmax - q_pos, qkey >> group_bits = qh: q_pos lies in (qmax - (qh << g) - slots, qmax - (qh << g)], one value of which has the low bits
+        const uint32_t top = qmax - (K.qh_bits ? (qh << K.group_bits) : 0u);
+        q = top - ((top - qlow) & (nslots - 1u));
+    } else q = (K.qh_bits ? (qh << K.group_bits) : 0u) | qlow;
+    sd.q_pos = (int32_t)q;
+    return sd;
 }
 #endif
 

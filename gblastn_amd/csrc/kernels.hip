@@ -344,7 +344,7 @@ __device__ __forceinline__ void scan_slice_body(const GbnScanParams &P, int nsli
 #define GBN_SLICE_OQ 192            // ring of (position, rank) pairs per wave: 64 left over + 128 of a tile's hits at a time
 extern "C" __global__ void __launch_bounds__(GBN_SLICE_THREADS)
 scan_fold_ordered_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
-                         unsigned long long *seg_max)
+                         unsigned long long *seg_max, GbnKeyParams CK)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t s_slice[];
     uint32_t *s_pv = s_slice;
@@ -376,6 +376,7 @@ scan_fold_ordered_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnD
     const int top = 64 - 2 * P.lut, top32 = 32 - 2 * P.lut;
     const int wd_shift = top32 + 5, wd_bits = slice_cell_bits - 5;
     const uint2 *__restrict__ pvx = reinterpret_cast<const uint2 *>(P.pvx);
+    const uint32_t ck_qmax = (CK.q_bits >= 32) ? 0xffffffffu : ((1u << CK.q_bits) - 1u);
 
     // the `cnt` oldest queued hits, a lane each: their cells' entries become seeds at the end of the wave's segment
     auto flush = [&](int cnt) {
@@ -393,6 +394,19 @@ scan_fold_ordered_kernel(GbnScanParams P, int nslices, int slice_cell_bits, GbnD
         for (int d = 1; d < 64; d <<= 1) { const uint32_t v = __shfl_up(incl, d); incl += (lane >= d) ? v : 0u; }
         const uint32_t total = __shfl(incl, 63);
         const uint32_t base = used + (incl - n);
+        if (CK.seg_keys) {
+            // round 6: the seed leaves as the 8-byte composite key the seed-order kernels would make of it (subject | slot | scan position
+            // | value): 8 bytes written here, 8 read by the count and 8 by the scatter kernel, instead of 16 each
+            uint64_t *__restrict__ mykeys = reinterpret_cast<uint64_t *>(myseg);
+            for (uint32_t e = 0; e < n; e++) {
+                if (base + e < seg_cap) {
+                    GbnDevSeed sd; sd.subj = cur_subj; sd.s_scan = sp; sd.q_pos = (int32_t)(uint32_t)(P.ent[start + e] & 0xffffffffull); sd.ext_left = 0;
+                    uint32_t slot, val;
+                    const uint64_t key = gbn_composite_key(CK, sd, ck_qmax, slot, val);
+                    mykeys[base + e] = (key << CK.v_bits) | val;
+                }
+            }
+        } else
         for (uint32_t e = 0; e < n; e++) {
             if (base + e < seg_cap) {
                 GbnDevSeed sd; sd.subj = cur_subj; sd.s_scan = sp; sd.q_pos = (int32_t)(uint32_t)(P.ent[start + e] & 0xffffffffull); sd.ext_left = 0;
@@ -605,6 +619,21 @@ seed_compact_kernel(const GbnDevSeed *__restrict__ seg, const uint32_t *__restri
         if (at + i < out_cap) dst[at + i] = src[i];
 }
 
+// ... the same for segments of composite keys (round 6): every key decoded to the seed it stands for -- the way out for a range whose
+// seeds turn out not to go through the seed-order kernels after all (too few of them, a switch)
+extern "C" __global__ void __launch_bounds__(256)
+seed_compact_keys_kernel(const uint64_t *__restrict__ seg, const uint32_t *__restrict__ seg_count, const unsigned long long *__restrict__ seg_first,
+                         int nseg, uint32_t seg_cap, GbnDevSeed *__restrict__ out, unsigned long long out_cap, GbnKeyParams CK)
+{
+    const int sg = blockIdx.x % nseg, part = blockIdx.x / nseg, nparts = gridDim.x / nseg;
+    const uint64_t *__restrict__ src = seg + (size_t)sg * seg_cap * 2;          // (a segment is seg_cap 16-byte elements long whatever it holds)
+    const unsigned long long at = seg_first[sg];
+    const uint32_t have = min(seg_count[sg], seg_cap);
+    const uint32_t qmax = (CK.q_bits >= 32) ? 0xffffffffu : ((1u << CK.q_bits) - 1u);
+    for (uint32_t i = (uint32_t)part * 256u + threadIdx.x; i < have; i += (uint32_t)nparts * 256u)
+        if (at + i < out_cap) out[at + i] = gbn_seed_of_key(CK, src[i], qmax);
+}
+
 // ---------------------------------------------------------------------------
 // deterministic synthetic database bytes: xorshift64* streams, one per 4 KiB
 // ---------------------------------------------------------------------------
@@ -718,12 +747,16 @@ int scan_slice_blocks(const GbnScanParams &p, int num_cu)
 // of seeds, *seg_max the fullest segment's count (above seg_cap: seeds were dropped, scan again with longer segments).
 // p.seeds is not written: launch_seed_compact puts the segments back to back for whoever wants them in one array
 hipError_t launch_seed_compact(const GbnDevSeed *seg, const uint32_t *seg_count, unsigned long long *seg_first, int nseg, uint32_t seg_cap,
-                               GbnDevSeed *out, unsigned long long out_cap, hipStream_t st)
+                               GbnDevSeed *out, unsigned long long out_cap, hipStream_t st, const GbnKeyParams *keys)
 {
     if (nseg <= 0) return hipSuccess;
     if (!seg_first || nseg > GBN_SLICE_SEGS) return hipErrorInvalidValue;
     GbnKeyParams k; std::memset(&k, 0, sizeof(k)); k.seg_count = seg_count; k.nseg = nseg; k.seg_cap = seg_cap; k.seg_first = seg_first;
     if (hipError_t e = launch_seg_first(k, st)) return e;
+    if (keys && keys->seg_keys) {           // segments of composite keys: decoded on the way
+        hipLaunchKernelGGL(seed_compact_keys_kernel, dim3((unsigned)(nseg * (nseg > 1024 ? 1 : 8))), dim3(256), 0, st, reinterpret_cast<const uint64_t *>(seg), seg_count, seg_first, nseg, seg_cap, out, out_cap, *keys);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(seed_compact_kernel, dim3((unsigned)(nseg * (nseg > 1024 ? 1 : 8))), dim3(256), 0, st, seg, seg_count, seg_first, nseg, seg_cap, out, out_cap);
     return hipGetLastError();
 }
@@ -750,7 +783,7 @@ int scan_slice_segments(const GbnScanParams &p, int num_cu, int *ordered)
 }
 
 hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg, uint32_t seg_cap, uint32_t *seg_count,
-                             unsigned long long *seg_max, hipStream_t st)
+                             unsigned long long *seg_max, hipStream_t st, const GbnKeyParams *keys)
 {
     if (p.ntiles <= 0) return hipSuccess;
     const int nslices = scan_slice_count(p), blocks = scan_slice_blocks(p, num_cu);
@@ -761,7 +794,9 @@ hipError_t launch_scan_slice(const GbnScanParams &p, int num_cu, GbnDevSeed *seg
     const int form = scan_slice_form(p, nslices);
     if (form == 2) {
         if (hipError_t e = raise_dynamic_lds((const void *)scan_fold_ordered_kernel, lds, attr_set_ord)) return e;
-        hipLaunchKernelGGL(scan_fold_ordered_kernel, dim3((unsigned)blocks), dim3(GBN_SLICE_THREADS), lds, st, p, nslices, cell_bits, seg, seg_cap, seg_count, seg_max);
+        GbnKeyParams ck; std::memset(&ck, 0, sizeof(ck));
+        if (keys && keys->seg_keys) ck = *keys;             // (only this form can write keys: its seeds come subject by subject)
+        hipLaunchKernelGGL(scan_fold_ordered_kernel, dim3((unsigned)blocks), dim3(GBN_SLICE_THREADS), lds, st, p, nslices, cell_bits, seg, seg_cap, seg_count, seg_max, ck);
         return hipGetLastError();
     }
     if (form == 1) {

@@ -37,6 +37,13 @@ __device__ __forceinline__ uint32_t slot_of(const GbnKeyParams &K, const GbnDevS
                             : ((uint32_t)(sd.s_scan + K.diag_len - sd.q_pos) & (uint32_t)(K.diag_len - 1));
 }
 
+// segments of 8-byte composite keys (K.seg_keys, round 6): element idx of the segment array, its subject (relative) and slot
+// (a segment is seg_cap 16-byte elements long whatever it holds: key `off` of segment `sg` sits at 2 sg seg_cap + off)
+__device__ __forceinline__ uint64_t seg_key(const GbnKeyParams &K, int sg, size_t off) { return reinterpret_cast<const uint64_t *>(K.seg)[(size_t)sg * K.seg_cap * 2 + off]; }
+__device__ __forceinline__ int32_t key_subj_rel(const GbnKeyParams &K, uint64_t packed) { return (int32_t)(uint32_t)(packed >> (K.v_bits + K.s_bits + K.group_bits)); }
+__device__ __forceinline__ uint32_t key_slot(const GbnKeyParams &K, uint64_t packed) { return (uint32_t)(packed >> (K.v_bits + K.s_bits)) & ((1u << K.group_bits) - 1u); }
+__device__ __forceinline__ int32_t seg_subj_rel(const GbnKeyParams &K, int sg, size_t off) { return K.seg_keys ? key_subj_rel(K, seg_key(K, sg, off)) : K.seg[(size_t)sg * K.seg_cap + off].subj - K.subj_base; }
+
 // a chunk's subject and its stretch [i0, i1) of the seeds (uniform over the workgroup: scalar loads)
 __device__ __forceinline__ bool chunk_of(const GbnOrderParams &O, uint32_t c, int &s, uint32_t &i0, uint32_t &i1)
 {
@@ -94,7 +101,7 @@ extern "C" __global__ void __launch_bounds__(256) seed_order_plan_kernel(GbnOrde
     #pragma unroll
     for (int k = 0; k < GP; k++) {
         const int g = tid * GP + k;
-        v[k] = (g < K.nseg && first[g + 1] > first[g]) ? K.seg[(size_t)g * K.seg_cap].subj - K.subj_base : INT32_MAX;
+        v[k] = (g < K.nseg && first[g + 1] > first[g]) ? seg_subj_rel(K, g, 0) : INT32_MAX;
     }
     #pragma unroll
     for (int k = GP - 2; k >= 0; k--) v[k] = min(v[k], v[k + 1]);
@@ -119,9 +126,8 @@ extern "C" __global__ void __launch_bounds__(256) seed_order_plan_kernel(GbnOrde
             if (lo == 0) at = 0;
             else {
                 const int g = lo - 1;                   // its seeds begin inside segment g (or right behind it)
-                const GbnDevSeed *__restrict__ sg = K.seg + (size_t)g * K.seg_cap;
                 uint32_t a = 1, b = (uint32_t)(first[g + 1] - first[g]);
-                while (a < b) { const uint32_t mid = (a + b) >> 1; if (sg[mid].subj - K.subj_base < s) a = mid + 1; else b = mid; }
+                while (a < b) { const uint32_t mid = (a + b) >> 1; if (seg_subj_rel(K, g, mid) < s) a = mid + 1; else b = mid; }
                 at = (uint32_t)first[g] + a;
             }
         }
@@ -159,17 +165,18 @@ extern "C" __global__ void __launch_bounds__(ORD_THREADS) seed_order_count_kerne
     __syncthreads();
     int sgi = seg_locate(first, K.nseg, i0);
     unsigned long long lo = first[sgi], hi = first[sgi + 1];
-    GbnDevSeed sd[ORD_ROUNDS];
+    uint32_t slot[ORD_ROUNDS];
     #pragma unroll
     for (int r = 0; r < ORD_ROUNDS; r++) {
         const uint32_t i = i0 + (uint32_t)(r * ORD_THREADS + tid);
-        if (i >= i1) { sd[r] = GbnDevSeed{0, 0, 0, 0}; continue; }
+        slot[r] = 0;
+        if (i >= i1) continue;
         while ((unsigned long long)i >= hi) { sgi++; lo = hi; hi = first[sgi + 1]; }
-        sd[r] = K.seg[(size_t)sgi * K.seg_cap + (size_t)(i - lo)];
+        slot[r] = K.seg_keys ? key_slot(K, seg_key(K, sgi, (size_t)(i - lo))) : slot_of(K, K.seg[(size_t)sgi * K.seg_cap + (size_t)(i - lo)]);      // (8 bytes per seed instead of 16)
     }
     #pragma unroll
     for (int r = 0; r < ORD_ROUNDS; r++)
-        if (i0 + (uint32_t)(r * ORD_THREADS + tid) < i1) atomicAdd(&s_hist[slot_of(K, sd[r])], 1u);
+        if (i0 + (uint32_t)(r * ORD_THREADS + tid) < i1) atomicAdd(&s_hist[slot[r]], 1u);
     __syncthreads();
     uint32_t *__restrict__ row = O.counts + (size_t)blockIdx.x * nslots;
     for (int t = tid; t < nslots; t += ORD_THREADS) row[t] = s_hist[t];
@@ -177,14 +184,16 @@ extern "C" __global__ void __launch_bounds__(ORD_THREADS) seed_order_count_kerne
 
 // One workgroup per subject: counts[c][t] becomes the number of the subject's seeds of slot t in the chunks before c,
 // slot_base[s][t] = where the subject's seeds of slot t begin in the output.
-extern "C" __global__ void __launch_bounds__(1024) seed_order_scan_kernel(GbnOrderParams O)
+// (round 6: 256 threads a workgroup instead of 1,024, so that one fits beside whatever else a CU holds; no measurable change at C3,
+// 26.8 ms either way -- the kernel's 0.4-0.6 ms per range are its chunk-serial walk over `counts`, not its dispatch)
+extern "C" __global__ void __launch_bounds__(256) seed_order_scan_kernel(GbnOrderParams O)
 {
     __shared__ uint32_t s_tot[GBN_ORDER_MAX_SLOTS];
-    __shared__ uint32_t s_wave[16];
+    __shared__ uint32_t s_wave[4];
     const int s = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int nslots = 1 << O.K.group_bits;
     const uint32_t c0 = O.chunk_first[s], c1 = O.chunk_first[s + 1];
-    for (int t = tid; t < nslots; t += 1024) {
+    for (int t = tid; t < nslots; t += 256) {
         uint32_t run = 0;
         uint32_t c = c0;
         for (; c + 8 <= c1; c += 8) {
@@ -198,7 +207,7 @@ extern "C" __global__ void __launch_bounds__(1024) seed_order_scan_kernel(GbnOrd
         s_tot[t] = run;
     }
     __syncthreads();
-    constexpr int TP = GBN_ORDER_MAX_SLOTS / 1024;
+    constexpr int TP = GBN_ORDER_MAX_SLOTS / 256;
     uint32_t v[TP], sum = 0;
     #pragma unroll
     for (int k = 0; k < TP; k++) { const int t = tid * TP + k; v[k] = t < nslots ? s_tot[t] : 0u; sum += v[k]; }
@@ -209,7 +218,7 @@ extern "C" __global__ void __launch_bounds__(1024) seed_order_scan_kernel(GbnOrd
     __syncthreads();
     uint32_t at = O.subj_first[s] + incl - sum;
     #pragma unroll
-    for (int w = 0; w < 16; w++) at += (w < wave) ? s_wave[w] : 0u;
+    for (int w = 0; w < 4; w++) at += (w < wave) ? s_wave[w] : 0u;
     #pragma unroll
     for (int k = 0; k < TP; k++) { const int t = tid * TP + k; if (t < nslots) O.slot_base[(size_t)s * nslots + t] = at; at += v[k]; }
 }
@@ -229,22 +238,23 @@ extern "C" __global__ void __launch_bounds__(ORD_THREADS) seed_order_scatter_ker
     const uint32_t w0 = wbase + (uint32_t)lane;
     int sgi = seg_locate(first, K.nseg, min(wbase, i1 - 1));           // (uniform over the wave: scalar loads; the lanes step forward from there)
     unsigned long long lo = first[sgi], hi = first[sgi + 1];
-    GbnDevSeed sd[ORD_ROUNDS];
+    const uint32_t qmax = (K.q_bits >= 32) ? 0xffffffffu : ((1u << K.q_bits) - 1u);
+    uint64_t key[ORD_ROUNDS]; uint32_t slots[ORD_ROUNDS];
     #pragma unroll
     for (int r = 0; r < ORD_ROUNDS; r++) {
         const uint32_t i = w0 + (uint32_t)(r * 64);
-        if (i >= i1) { sd[r] = GbnDevSeed{0, 0, 0, 0}; continue; }
+        key[r] = 0; slots[r] = 0;
+        if (i >= i1) continue;
         while ((unsigned long long)i >= hi) { sgi++; lo = hi; hi = first[sgi + 1]; }
-        sd[r] = K.seg[(size_t)sgi * K.seg_cap + (size_t)(i - lo)];
+        if (K.seg_keys) { key[r] = seg_key(K, sgi, (size_t)(i - lo)); slots[r] = key_slot(K, key[r]); }        // (the scan wrote the key: 8 bytes read, 8 written)
+        else { uint32_t val; key[r] = (gbn_composite_key(K, K.seg[(size_t)sgi * K.seg_cap + (size_t)(i - lo)], qmax, slots[r], val) << K.v_bits) | val; }
     }
     uint32_t *__restrict__ mine = s_cnt + wave * nslots;
-    const uint32_t qmax = (K.q_bits >= 32) ? 0xffffffffu : ((1u << K.q_bits) - 1u);
-    uint64_t key[ORD_ROUNDS]; uint32_t sr[ORD_ROUNDS];         // slot << 16 | rank among the wave's seeds of the slot
+    uint32_t sr[ORD_ROUNDS];                                    // slot << 16 | rank among the wave's seeds of the slot
     #pragma unroll
     for (int r = 0; r < ORD_ROUNDS; r++) {
         const bool valid = w0 + (uint32_t)(r * 64) < i1;
-        uint32_t slot, val;
-        key[r] = (gbn_composite_key(K, sd[r], qmax, slot, val) << K.v_bits) | val;
+        const uint32_t slot = slots[r];
         // the lanes of this round with the same slot (a ballot per slot bit), in lane order = scan order
         unsigned long long peers = __ballot(valid);
         for (int b = 0; b < K.group_bits; b++) {
@@ -301,7 +311,7 @@ hipError_t launch_seed_order(const GbnKeyParams &K, int nsubj, uint32_t *scratch
     if (hipError_t e = launch_seg_first(K, st)) return e;
     hipLaunchKernelGGL(seed_order_plan_kernel, dim3(1), dim3(256), 0, st, O);
     hipLaunchKernelGGL(seed_order_count_kernel, dim3((unsigned)chunks), dim3(ORD_THREADS), nslots * sizeof(uint32_t), st, O);
-    hipLaunchKernelGGL(seed_order_scan_kernel, dim3((unsigned)nsubj), dim3(1024), 0, st, O);
+    hipLaunchKernelGGL(seed_order_scan_kernel, dim3((unsigned)nsubj), dim3(256), 0, st, O);
     hipLaunchKernelGGL(seed_order_scatter_kernel, dim3((unsigned)chunks), dim3(ORD_THREADS), ORD_WAVES * nslots * sizeof(uint32_t), st, O);
     return hipGetLastError();
 }
