@@ -99,7 +99,15 @@ def drop_page_cache():
         return False
 
 
+# Between two runs the bench waits: a process that starts within a second of one that has just dropped 35 GB of device memory
+# finds its 21.5 GB hipMalloc (the record streams) waiting 2-3.5 s for the driver to hand the dropped memory out again -- every
+# other back-to-back run, none of twelve runs started 2 s after the one before (profiles/r06_cli_stall.txt).  One invocation is
+# what is measured here, not a loop of them.
+PAUSE_S = float(os.environ.get("GBN_CLI_BENCH_PAUSE", "2.5"))
+
+
 def run_cli(dbname, fasta, out, extra=(), env=None):
+    time.sleep(PAUSE_S)
     cmd = [CLI, "-db", dbname, "-query", fasta, "-outfmt", "6", "-use_gpu", "true", "-gpu_id", "0", "-mode", "2", "-out", out, "-timing", "true"] + list(extra)
     t0 = time.perf_counter()
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=1800, env=env)
@@ -151,11 +159,13 @@ def bench_cli(args, api):
                    "warm_trace_t_num_8": {"wall_ms": min(x[0] for x in t8), "phases": min(t8, key=lambda x: x[0])[1], "rows_equal": rows_t8 == rows_cli},
                    "one_slab_loader_of_rounds_1_to_5": {"wall_ms": old[0], "phases": old[1]},
                    "rows": len(rows_cli), "rows_equal_library_calls": same, "library_load_shard_s": load_s,
-                   "database_written_s": made_s,
+                   "database_written_s": made_s, "pause_before_each_run_s": PAUSE_S,
                    "what": "phases are the program's own clocks (-timing true): args_fasta = argument + FASTA parse, gbn_init = HIP runtime + engine, db_open_upload = "
                            "mmap of the volumes + upload of the shard (gbn_db_new_streamed: pinned pieces, fills and uploads overlapped), search_wall = first batch "
                            "submitted to last batch printed (submit incl. DUST, waiting for results = set-up + preliminary search + traceback of the batches in "
-                           "flight, emit = formatting), teardown = freeing the shard and the engine; wall_ms is the parent's clock around the child process"},
+                           "flight, emit = formatting), teardown = freeing the shard and the engine; wall_ms is the parent's clock around the child process.  "
+                           "The bench waits pause_before_each_run_s between two child processes: started back to back, every other one waits 2-3.5 s in its "
+                           "hipMalloc of the record streams for memory the process before has just dropped (profiles/r06_cli_stall.txt)"},
     }
     if not same:
         line["config"]["row_diff_sample"] = [r for r in rows_cli if r not in set(rows_lib)][:3] + ["--"] + [r for r in rows_lib if r not in set(rows_cli)][:3]
