@@ -47,7 +47,7 @@ def parse():
                          "C4: 100k queries streamed in 5 Mb batches through the host pipeline, CPU traceback overlapped with the GPU stages; "
                          "shim: the C2 shard as 100 resident blocks searched the way gblastn_amd/shim/gpu_blastn_amd_shim.cpp searches them; "
                          "cli: the documented invocation end to end -- blastn_prelim on the C2 database written as BLAST v4 volumes on disk (bench_cli.py)")
-    ap.add_argument("--trace-threads", type=int, default=0, help="C4: traceback consumer threads (0: a quarter of the host cores, 4 .. 16; round 4 ran 4, "
+    ap.add_argument("--trace-threads", type=int, default=0, help="C4: traceback consumer threads (0: the CPUs granted to this process -- gbn_host_cpus --, 4 .. 16; round 4 ran 4, "
                                                                   "with which the traceback of a batch, not the GPU, sets the pace once the records are cached)")
     ap.add_argument("--no-traceback", action="store_true", help="C4 diagnostics: the pipeline without its traceback stage")
     ap.add_argument("--subjects", type=int, default=None, help="subjects per GPU shard")
@@ -83,8 +83,6 @@ def parse():
         a.steps = 10
     if a.workload == "cli" and "--steps" not in " ".join(sys.argv):
         a.steps = 2
-    if a.trace_threads <= 0:
-        a.trace_threads = max(4, min(16, (os.cpu_count() or 16) // 4))
     if a.subjects is None:
         a.subjects = 5_000 if a.workload == "C3" else 50_000
     if a.batch_queries is None:

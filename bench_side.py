@@ -100,11 +100,17 @@ def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, 
     """C4: query batches streamed through the C++ host pipeline (gblastn_amd_host.hpp CSearchPipeline behind its C
     ABI): set-up thread, preliminary search on the GPU, `--trace-threads` traceback consumers -- a step is one
     5 Mb batch from the caller's arrays to its final alignments (edit scripts, identities, e-values)."""
+    if args.trace_threads <= 0:
+        # (the CPUs this process is granted, not the hardware threads it sees: 16 of 256 on the GPU boxes.  Measured there: 8 threads
+        # 5.6 ms per batch, 16 threads 4.0 -- a 5,000-query batch's 2,469 alignments are some 50 ms of CPU)
+        args.trace_threads = max(4, min(16, api.host_cpus()))
+    window = int(os.environ.get("GBN_C4_WINDOW", "8"))          # batches the caller keeps in the pipeline
+
     def run(count):
         pipe = api.SearchPipeline(opt, src, trace_threads=args.trace_threads, traceback=not args.no_traceback, overlap=not args.no_overlap)
         sub = got = 0; nfinal = 0; diags = []
         while got < count:
-            while sub < count and sub < got + 8:
+            while sub < count and sub < got + window:
                 pipe.submit(qsets[sub % nbatch]); sub += 1
             if sub == count:
                 pipe.finish()
@@ -139,12 +145,14 @@ def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, 
     bin_ms = sum(d.bin_kernel_ms for d in diags); probe_ms = sum(d.probe_kernel_ms for d in diags); rare_ms = sum(d.rare_kernel_ms for d in diags)
     scanned = sum(d.subject_bases_scanned for d in diags)
     algo = 0.25 * scanned
-    by_kernel = {"scan_bin_kernel_s17": bin_ms / max(launches, 1), "probe_bin_kernel": probe_ms / max(launches, 1), "probe_rare_kernel": rare_ms / max(launches, 1)}
+    cache = api.record_cache_stats()
+    # (the kernel that went over the cached records: probe_runs_kernel once the set is sorted by cell -- from its second hit on)
+    probe_name = "probe_runs_kernel" if cache.get("sorted_passes", 0) > 0 else "probe_bin_kernel"
+    by_kernel = {"scan_bin_kernel_s17": bin_ms / max(launches, 1), probe_name: probe_ms / max(launches, 1), "probe_rare_kernel": rare_ms / max(launches, 1)}
     for i, name in enumerate(api.GbnDiagnostics.KERNEL_CLASSES):
         t = sum(d.kernel_ms[i] for d in diags) / max(launches, 1)
         if t > 0:
             by_kernel[name] = t
-    cache = api.record_cache_stats()
     if rank == 0:
         line = {
             "metric": "subject Gbp scanned/sec (megablast, query batches streamed through preliminary search + overlapped CPU traceback)",
@@ -156,13 +164,13 @@ def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, 
                                    % (args.steps * args.batch_queries, args.steps, args.batch_queries, len(queries), nsub * slen / 1e9, opt.word_size, args.trace_threads),
                        "pipeline": "set-up thread -> preliminary search (GPU) -> traceback threads; overlapped" if not args.no_overlap else "one batch at a time",
                        "record_cache": ("on (the library's default: the shard's scan records are binned by the first batch and stay resident; later batches run "
-                                        "probe + rare kernel only) -- %d passes served from the cache, %d binned, %.1f GB of records resident"
-                                        % (cache["hits"], cache["misses"], cache["bytes"] / 1e9)) if cache["limit"] > 0 else "off (--record-cache off): every batch bins",
+                                        "probe + rare kernel only) -- %d passes served from the cache (%d of them over records sorted by cell), %d binned, %.1f GB of records resident"
+                                        % (cache["hits"], cache.get("sorted_passes", 0), cache["misses"], cache["bytes"] / 1e9)) if cache["limit"] > 0 else "off (--record-cache off): every batch bins",
                        "stage_ms_per_pass": {k: sum(getattr(d, k) for d in diags) / max(launches, 1)
                                              for k in ["scan_stage_ms", "seed_stage_ms", "gapped_stage_ms", "host_stage_ms"]},
                        "final_hsps_per_batch": int(len(rec)), "final_identity_mean": float((rec["num_ident"] / np.maximum(rec["align_length"], 1)).mean()) if len(rec) else None,
                        "gapped_alignments_per_batch": int((rec["gaps"] > 0).sum()) if len(rec) else 0},
-            "roofline": {"bound": "hbm", "kernel": "probe_bin_kernel" if cache["limit"] > 0 else "scan_bin_kernel_s17",
+            "roofline": {"bound": "hbm", "kernel": probe_name if cache["limit"] > 0 else "scan_bin_kernel_s17",
                          "achieved": algo / ((probe_ms if cache["limit"] > 0 else bin_ms) * 1e-3) / 1e9 if bin_ms + probe_ms else 0.0, "peak": 8000.0, "unit": "GB/s",
                          "frac": (algo / ((probe_ms if cache["limit"] > 0 else bin_ms) * 1e-3) / 1e9 / 8000.0) if bin_ms + probe_ms else 0.0, "traffic": None,
                          "avg_launch_ms": (probe_ms if cache["limit"] > 0 else bin_ms) / max(launches, 1), "launches": launches,
@@ -360,7 +368,9 @@ def cpu_baseline(args, batch_queries, gopt, layout):
     reference shares OID chunks among threads the same way, x_LaunchMultiThreadedSearch)."""
     import multiprocessing as mp
     from gblastn_amd import api
-    cores = args.cpu_cores if args.cpu_cores > 0 else max(1, min(64, (os.cpu_count() or 1) // 2))
+    # one process per CPU this job is granted (gbn_host_cpus: hardware threads cut down to affinity and cgroup quota -- the GPU boxes
+    # show 256 hardware threads and grant 16 CPUs; rounds 1-5 started 64 processes there, which the quota ran as sixteen)
+    cores = args.cpu_cores if args.cpu_cores > 0 else max(1, min(64, api.host_cpus()))
     optd = {f: getattr(gopt, f) for f, _ in api.GbnOptions._fields_}
     jobs = [(w, cores, args.cpu_seconds, batch_queries, optd, layout.num, layout.length, layout.seed, layout.first_oid)
             for w in range(cores)]

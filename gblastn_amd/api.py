@@ -281,6 +281,14 @@ def record_cache_invalidate():
     _check(lib().gbn_record_cache_invalidate())
 
 
+def host_cpus():
+    """CPUs this process may use at a time (hardware threads cut down to the affinity mask and the cgroup's CPU quota):
+    gbn_host_cpus; what thread pools on the host are sized from."""
+    L = lib()
+    L.gbn_host_cpus.restype = C.c_int32; L.gbn_host_cpus.argtypes = []
+    return int(L.gbn_host_cpus())
+
+
 def record_cache_stats():
     v = (C.c_longlong * 14)()
     _check(lib().gbn_record_cache_stats(v, 14))

@@ -260,7 +260,7 @@ int main(int argc, char **argv)
         q.seqs.reserve(bt.count);
         for (size_t k = 0; k < bt.count; k++) q.seqs.push_back(queries[bt.first + k].seq);
         if (!dust) return q;
-        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const unsigned hw = (unsigned)std::max(1, (int)gbn_host_cpus());
         const size_t nt = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)hw / 2, bt.count / 64 + 1}));
         std::vector<std::vector<gbn::SQueryBatch::Mask>> found(nt);
         std::vector<std::thread> ts;

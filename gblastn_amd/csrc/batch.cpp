@@ -65,11 +65,45 @@ public:
 // One pool per PROCESS: after fork() (Python's multiprocessing, default start method) the child has the parent's pool object
 // and none of its threads -- jobs would wait for ever.  The child makes its own; the parent's object is left alone there (its
 // thread handles belong to threads that do not exist in this process: neither joined nor destroyed).
+}  // namespace
+
+namespace gbn {
+unsigned host_cpus() {
+    static const unsigned n = [] {
+        unsigned v = std::max(1u, std::thread::hardware_concurrency());
+        if (const char *e = getenv("GBN_HOST_CPUS")) { const int k = atoi(e); if (k > 0) return (unsigned)k; }
+        cpu_set_t set; CPU_ZERO(&set);
+        if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int k = CPU_COUNT(&set); if (k > 0) v = std::min(v, (unsigned)k); }
+        auto read_line = [](const char *path, char *buf, size_t cap) {
+            FILE *f = fopen(path, "r"); if (!f) return false;
+            const bool ok = fgets(buf, (int)cap, f) != nullptr; fclose(f); return ok; };
+        char buf[128];
+        // cgroup v2: "max 100000" or "<quota> <period>"; v1: two files, quota -1 = none
+        if (read_line("/sys/fs/cgroup/cpu.max", buf, sizeof(buf))) {
+            long long q = 0, per = 0;
+            if (sscanf(buf, "%lld %lld", &q, &per) == 2 && q > 0 && per > 0) v = std::min<unsigned>(v, (unsigned)std::max<long long>(1, (q + per - 1) / per));
+        } else if (read_line("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", buf, sizeof(buf))) {
+            const long long q = atoll(buf);
+            if (q > 0 && read_line("/sys/fs/cgroup/cpu/cpu.cfs_period_us", buf, sizeof(buf))) {
+                const long long per = atoll(buf);
+                if (per > 0) v = std::min<unsigned>(v, (unsigned)std::max<long long>(1, (q + per - 1) / per));
+            }
+        }
+        return v;
+    }();
+    return n;
+}
+}  // namespace gbn
+
+namespace {
 SetupPool &setup_pool() {
     static std::mutex mu; static SetupPool *pool = nullptr; static pid_t owner = 0;
     std::lock_guard<std::mutex> lk(mu);
     if (!pool || owner != getpid()) {
-        pool = new SetupPool((int)std::max(2u, std::min(31u, std::max(1u, std::thread::hardware_concurrency()) / 8u)));     // (a 256-thread host: 31 workers + the caller; eight ranks of a node each have their own)
+        // (a 256-thread host without a quota: 31 workers + the caller, eight ranks of a node each have their own; under a quota half of
+        // the CPUs granted: two batches are set up at a time, and the search, extension and traceback threads want the rest)
+        const unsigned cpus = gbn::host_cpus(), hw = std::max(1u, std::thread::hardware_concurrency());
+        pool = new SetupPool((int)std::max(2u, std::min(31u, cpus < hw ? cpus / 2u : hw / 8u)));
         owner = getpid();
     }
     return *pool;

@@ -23,8 +23,10 @@ void trace_mark(const char *what) {
     static const bool on = getenv("GBN_TRACE") && atoi(getenv("GBN_TRACE")) != 0;
     if (!on) return;
     static const auto t0 = std::chrono::steady_clock::now();
-    fprintf(stderr, "[gbn trace] %9.3f ms  %s\n",
-            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+    static const bool with_thread = atoi(getenv("GBN_TRACE")) > 1;       // GBN_TRACE=2: the calling thread behind the mark
+    const double ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    if (with_thread) fprintf(stderr, "[gbn trace] %9.3f ms  %s  [thread %03u]\n", ms, what, (unsigned)(std::hash<std::thread::id>()(std::this_thread::get_id()) % 1000u));
+    else fprintf(stderr, "[gbn trace] %9.3f ms  %s\n", ms, what);
 }
 
 // One engine per device, created by gbn_init / gbn_use_device (or by the first call that needs one) and alive
@@ -158,16 +160,27 @@ hipError_t pool_alloc(void **p, size_t bytes) {
 void pool_free(void *p) {
     if (!p) return;
     size_t bytes = 0; int dev = cur_dev();
+    bool known = false;
+    std::vector<std::pair<void *, size_t>> drop;
     {
         std::lock_guard<std::mutex> lk(g_pool.mu);
         auto it = g_pool.size_of.find(p);
         if (it != g_pool.size_of.end()) {
             bytes = it->second.first; dev = it->second.second; g_pool.size_of.erase(it);
             if (pool_guard()) guard_check(p, bytes, "release");
-            if (g_pool.held[dev] + bytes <= pool_cap()) { g_pool.idle[dev].emplace(bytes, p); g_pool.held[dev] += bytes; return; }
+            // the block stays; when that takes the idle blocks over the cap, the LARGEST ones go (round 6: the record streams of a set that
+            // has been sorted by cell come back as one 21 GB block, which then sat at the cap while every batch's few hundred MB of tables,
+            // a dozen blocks, were handed to hipFree -- which waits for the device -- batch after batch: 3 ms of a C4 step)
+            g_pool.idle[dev].emplace(bytes, p); g_pool.held[dev] += bytes;
+            while (g_pool.held[dev] > pool_cap() && !g_pool.idle[dev].empty()) {
+                auto big = std::prev(g_pool.idle[dev].end());
+                drop.emplace_back(big->second, big->first); g_pool.held[dev] -= big->first; g_pool.idle[dev].erase(big);
+            }
+            known = true;
         }
     }
-    raw_free_on(p, bytes, dev);
+    if (!known) { raw_free_on(p, bytes, dev); return; }
+    for (auto &q : drop) raw_free_on(q.first, q.second, dev);
 }
 // every block the pool knows (handed out or idle): guards intact?  Returns the violations seen so far.
 long pool_check_guards() {

@@ -488,7 +488,7 @@ int gbn_db_new_streamed(GbnDb **out, int64_t nbytes, int32_t num_seqs, const int
     hipEvent_t zeroed = nullptr;
     bool ok = hipEventCreateWithFlags(&zeroed, hipEventDisableTiming) == hipSuccess &&
               hipMemsetAsync(p, 0, (size_t)nbytes, E.stream) == hipSuccess && hipEventRecord(zeroed, E.stream) == hipSuccess;
-    const int nthreads = (int)std::max<size_t>(1, std::min<size_t>({pieces.size(), (size_t)(threads > 0 ? threads : (int)gbn::switch_value("GBN_UPLOAD_THREADS", std::max(2u, std::min(8u, std::thread::hardware_concurrency() / 2)))), (size_t)64}));
+    const int nthreads = (int)std::max<size_t>(1, std::min<size_t>({pieces.size(), (size_t)(threads > 0 ? threads : (int)gbn::switch_value("GBN_UPLOAD_THREADS", std::max(2u, std::min(8u, gbn::host_cpus() / 2)))), (size_t)64}));
     std::atomic<size_t> next{0}; std::atomic<int> status{ok ? GBN_OK : GBN_ERR_HIP};
     Engine *eng = tl_eng;
     uint8_t *pinned = nullptr;              // two pieces per worker, ONE allocation (pinning memory is the slow part: 32 workers' 64 allocations cost more than they gained)
@@ -1053,3 +1053,5 @@ int gbn_scan_only(GbnBatch *batch, GbnDb *db, int repeats, GbnDiagnostics *diag)
 long gbn_debug_check_guards(void) { return pool_check_guards(); }
 
 }  // extern "C"
+
+extern "C" int32_t gbn_host_cpus(void) { return (int32_t)gbn::host_cpus(); }

@@ -55,6 +55,7 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
     auto ms_since = [&](std::chrono::steady_clock::time_point t) {
         return std::chrono::duration<double, std::milli>(now() - t).count(); };
     auto t_stage = now();
+    trace_mark("seed stage: starts");
     if (phase != 2 && (rc = grow_key_buffers(KS, (size_t)n))) return rc;
     GbnKeyParams K; int ck_bits = 0, scan_bits = 0, group_key_bits = 0;
     seed_key_layout(b, db, s0, s1, K, &ck_bits, &scan_bits, &group_key_bits);
@@ -181,7 +182,9 @@ static int seed_stage(GbnBatch &b, GbnDb &db, GbnResults &res, GbnDiagnostics *d
         X.ihits = E.ihits_s[slot]; X.ihit_count = ctr; X.ihit_cap = E.ihit_cap_s[slot];
         HIPCHK(launch_diag_ungapped(X, st, &KS.kt));
         HIPCHK(hipMemcpyAsync(&nih, ctr, sizeof(nih), hipMemcpyDeviceToHost, st));
+        trace_mark("seed stage: kernels queued");
         HIPCHK(hipStreamSynchronize(st));
+        trace_mark("seed stage: kernels done");
         { double km[GBN_KT_N] = {0}; KS.kt.collect(km); if (diag) GBN_DIAG_LOCKED(for (int i = 0; i < GBN_KT_N; i++) diag->kernel_ms[i] += km[i]); }
         if (nih <= E.ihit_cap_s[slot]) break;
         if ((rc = grow_ihit_buffers(slot, (size_t)nih + (nih >> 3)))) return rc;
@@ -236,6 +239,7 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
     const bool async_seed = overlap && !keep_stages && n < ((int64_t)1 << 20);
     if (async_seed) {
         if ((rc = wait_pending_gpu())) return rc;           // one asynchronous stage in flight at most
+        trace_mark("previous asynchronous stage finished");
         if ((size_t)n > E.seeds_async_cap) {
             dev_free(E.seeds_async); E.seeds_async_cap = 0;
             if ((rc = dev_alloc(E.seeds_async, std::max<size_t>((size_t)n + (size_t)n / 4, 1 << 16)))) return rc;
@@ -317,10 +321,12 @@ static int hitbuf_get(size_t n, HitBuf &out) {
             if (E.hitbuf_idle[i].cap >= n) { out = E.hitbuf_idle[i]; E.hitbuf_idle.erase(E.hitbuf_idle.begin() + (long)i); return GBN_OK; }
         if (!E.hitbuf_idle.empty()) {           // too short: let one go, its successor is longer
             HitBuf old = E.hitbuf_idle.back(); E.hitbuf_idle.pop_back();
+            trace_mark("hitbuf: pinned pair freed (too short)");
             (void)hipHostFree(old.hih); (void)hipHostFree(old.hg);
         }
     }
     HitBuf b; b.cap = std::max<size_t>(n + n / 4, 1 << 16);
+    trace_mark("hitbuf: pinned pair allocated");
     if (hipHostMalloc((void **)&b.hih, b.cap * sizeof(GbnDevInitHit)) != hipSuccess ||
         hipHostMalloc((void **)&b.hg, b.cap * sizeof(GbnDevGapped)) != hipSuccess) {
         if (b.hih) (void)hipHostFree(b.hih);
@@ -335,9 +341,10 @@ int stage_get(size_t bytes, void **p, size_t *cap) {
         std::lock_guard<std::mutex> lk(E.hitbuf_mu);
         for (size_t i = 0; i < E.stage_idle.size(); i++)
             if (E.stage_idle[i].second >= bytes) { *p = E.stage_idle[i].first; *cap = E.stage_idle[i].second; E.stage_idle.erase(E.stage_idle.begin() + (long)i); return GBN_OK; }
-        if (E.stage_idle.size() >= 4) { (void)hipHostFree(E.stage_idle.back().first); E.stage_idle.pop_back(); }     // too short, all of them: one goes
+        if (E.stage_idle.size() >= 4) { trace_mark("stage: pinned upload buffer freed"); (void)hipHostFree(E.stage_idle.back().first); E.stage_idle.pop_back(); }     // too short, all of them: one goes
     }
     const size_t want = bytes + bytes / 4 + 4096;
+    trace_mark("stage: pinned upload buffer allocated");
     if (hipHostMalloc(p, want) != hipSuccess) { (void)hipGetLastError(); *p = nullptr; set_error("out of pinned host memory (query upload)"); return GBN_ERR_NOMEM; }
     *cap = want;
     return GBN_OK;
@@ -496,7 +503,7 @@ static int gapped_host(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResult
             for (GbnHSP &h : outs[k]) { h.s_offset += off; h.s_end += off; h.s_gapped_start += off; h.pad_ = ord + 1; }
         }
     };
-    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned hw = gbn::host_cpus();
     const unsigned nthreads = (nih < 20000 || spans.size() < 2) ? 1u : std::min({hw, 16u, (unsigned)spans.size()});
     std::vector<GbnDiagnostics> dloc(nthreads);
     for (auto &dl : dloc) std::memset(&dl, 0, sizeof(dl));
@@ -547,6 +554,7 @@ int gather_shard_bytes(const GbnDb &db, const std::vector<int64_t> &src_off, con
     // pages, and their release next to running kernels stalls the device's queues -- see HitBuf)
     uint8_t *&stage = E.gather_stage; size_t &stage_cap = E.gather_stage_cap;
     if (e == hipSuccess && (size_t)total > stage_cap) {
+        trace_mark("gather: pinned stage grows");
         if (stage) (void)hipHostFree(stage);
         stage = nullptr; stage_cap = 0;
         const size_t want = (size_t)total + (size_t)total / 4 + (1 << 20);

@@ -47,6 +47,11 @@ struct DeviceBatch;     // device mirrors, defined in engine.hpp
 std::vector<uint8_t> qbuf_take(size_t n);       // batch.cpp: a batch's concatenation buffer, recycled
 void qbuf_give(std::vector<uint8_t> &&v);
 void trace_mark(const char *what);   // GBN_TRACE=1: wall-clock marks on stderr (engine.cpp)
+// The processors this PROCESS may use at a time (batch.cpp): the hardware threads, cut down to the scheduler affinity mask and to the
+// cgroup's CPU quota (cpu.max / cpu.cfs_quota_us).  Every pool of host threads is sized from this, not from
+// std::thread::hardware_concurrency(): a container that shows 256 hardware threads and grants 16 CPUs of quota stops ALL threads of
+// a process for the rest of a 100 ms period once they have used 1.6 CPU-seconds of it (round 6: C4 lost a quarter of its time so).
+unsigned host_cpus();
 }  // namespace gbn
 
 struct GbnBatch {

@@ -1,6 +1,8 @@
 // pipeline.cpp -- C ABI of the host pipeline (include/gblastn_amd_host.hpp: set-up -> preliminary search ->
 // traceback on their own threads), for callers that cannot include the C++ header (the ctypes test binding,
 // bench.py --workload C4).  GB/work_thread.cpp:60-156 / APP/blastn_app.cpp:725-989 are the reference's shape.
+namespace gbn { void trace_mark(const char *what); }
+#define GBN_HOST_TRACE(what) gbn::trace_mark(what)      // the pipeline's hand-overs among the library's host marks (GBN_TRACE=1)
 #include "../../include/gblastn_amd_host.hpp"
 #include "gbn_guard.hpp"
 #include "gbn_host.hpp"

@@ -673,7 +673,7 @@ const int64_t *gbn_traceback_query_starts(const GbnTraceback *t) { return t->que
 
 // lists: the collector's output -- HSPs of one (subject, query) pair contiguous, sorted by score, pairs in ascending
 // (oid, query) order (list_start[nlists + 1]).  Subjects are read back from the shard in HBM, unpacked and traced
-// on `threads` host threads (0: one per four hardware threads, at most 16).
+// on `threads` host threads (0: one per four CPUs this process may use -- gbn_host_cpus --, at most 16).
 int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int64_t *list_start, int64_t nlists,
                       int32_t threads, GbnTraceback *out)
 {
@@ -772,7 +772,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
             }
         }
     };
-    unsigned nthreads = threads > 0 ? (unsigned)threads : std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));
+    unsigned nthreads = threads > 0 ? (unsigned)threads : std::min(16u, std::max(1u, gbn::host_cpus() / 4));
     nthreads = (unsigned)std::min<size_t>(nthreads, work.size());
     if (nthreads <= 1) body();
     else { std::vector<std::thread> pool; for (unsigned t = 0; t < nthreads; t++) pool.emplace_back(body); for (auto &th : pool) th.join(); }

@@ -458,6 +458,13 @@ int  gbn_launch_gapped(const struct GbnGapParams *p, int greedy, void *stream);
 
 const char *gbn_last_error(void);
 
+/* The processors this process may use at a time: hardware threads, cut down to the affinity mask and to the cgroup's CPU quota
+ * (a container that shows 256 hardware threads may grant 16 CPUs; a process that runs more busy threads than that is stopped by the
+ * scheduler for the rest of every 100 ms period).  The library sizes its own host pools from this; callers that make threads of
+ * their own (traceback consumers, DUST) should too.  GBN_HOST_CPUS=n overrides.  No reference counterpart (blastn's -num_threads
+ * is the caller's number). */
+int32_t gbn_host_cpus(void);
+
 #ifdef __cplusplus
 }
 #endif

@@ -108,6 +108,9 @@ public:
 // (the reference's query_queue -> prelim_queue -> result_queue with PrelimSearchThread / TraceBackThread).
 // Results come out in submission order.
 // ---------------------------------------------------------------------------------------------------
+#ifndef GBN_HOST_TRACE
+#define GBN_HOST_TRACE(what) ((void)0)          // (csrc/pipeline.cpp: the library's host marks, GBN_TRACE=1)
+#endif
 class CSearchPipeline {
 public:
     struct SWorkItem {                                  // GBI/thread_work_queue.hpp work_item
@@ -133,6 +136,7 @@ public:
         TItem it(new SWorkItem()); it->queries = std::move(q);
         std::unique_lock<std::mutex> lk(mu_);
         it->id = submitted_++;
+        GBN_HOST_TRACE("pipeline: batch submitted");
         query_queue_.push_back(std::move(it));
         cv_.notify_all();
         return submitted_ - 1;
@@ -166,7 +170,7 @@ private:
     bool no_more_ = false, closing_ = false, setup_done_ = false, prelim_done_ = false;
     std::thread prelim_; std::vector<std::thread> setup_, trace_;
 
-    void Deliver(TItem it) { std::unique_lock<std::mutex> lk(mu_); done_[it->id] = std::move(it); cv_.notify_all(); }
+    void Deliver(TItem it) { GBN_HOST_TRACE("pipeline: batch delivered"); std::unique_lock<std::mutex> lk(mu_); done_[it->id] = std::move(it); cv_.notify_all(); }
     static void Guard(SWorkItem &it, const std::function<void()> &f) {
         if (it.status != GBN_OK) return;
         try { f(); }
@@ -183,6 +187,7 @@ private:
                 if (closing_ || query_queue_.empty()) { if (++setup_exited_ == kSetupThreads) setup_done_ = true; cv_.notify_all(); return; }
                 it = std::move(query_queue_.front()); query_queue_.pop_front(); in_setup_++;
             }
+            GBN_HOST_TRACE("pipeline: set-up thread takes a batch");
             Guard(*it, [&] { it->prelim.reset(new CBlastPrelimSearch(it->queries, opt_, src_)); });
             std::unique_lock<std::mutex> lk(mu_);
             in_setup_--;
@@ -236,7 +241,9 @@ private:
                 else if (prelim_done_ || closing_) return;
             }
             if (!it) continue;
+            GBN_HOST_TRACE("pipeline: traceback thread takes a batch");
             if (!it->closed) { CloseStream(*it); it->closed = true; }
+            GBN_HOST_TRACE("pipeline: batch closed (end + collector)");
             if (traceback_) Guard(*it, [&] { it->traceback.reset(new CBlastTracebackSearch()); it->traceback->Run(*it->prelim, src_, *it->stream, inner_threads_); });
             Deliver(std::move(it));
         }

@@ -140,3 +140,27 @@ def test_batch_setup_in_a_forked_child():
         os.kill(pid, 9)
     os.waitpid(pid, 0)
     assert out == b"ok", out
+
+
+def test_host_cpus_follow_the_affinity_mask_and_the_cgroup_quota():
+    """gbn_host_cpus: what the library sizes its host pools from.  Never more than the hardware threads or the affinity mask, the
+    cgroup's quota when there is one (the GPU boxes: 16 CPUs of quota on 256 hardware threads -- pools sized from the hardware
+    threads had the scheduler stop the whole process for the rest of a period), GBN_HOST_CPUS overrides."""
+    import math, subprocess, sys
+    n = api.host_cpus()
+    want = min(os.cpu_count() or 1, len(os.sched_getaffinity(0)))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            want = min(want, max(1, math.ceil(int(q) / int(per))))
+    except OSError:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                want = min(want, max(1, math.ceil(q / per)))
+        except OSError:
+            pass
+    assert n == want and n >= 1
+    out = subprocess.run([sys.executable, "-c", "from gblastn_amd import api; print(api.host_cpus())"], env=dict(os.environ, GBN_HOST_CPUS="3"),
+                         capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert out.stdout.strip() == "3", out.stderr[-500:]
