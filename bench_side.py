@@ -137,6 +137,18 @@ def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, 
     order = sorted(range(len(regions)), key=lambda i: regions[i][0])
     elapsed, diags = regions[order[(len(order) - 1) // 2]]
     region_ms = [r[0] / args.steps * 1e3 for r in regions]
+    if os.environ.get("GBN_CPU_ACCOUNT") and rank == 0:
+        # CPU time of the library's host threads by what they did (csrc/gbn_host.hpp GBN_CPU_*), per batch, next to the process's total
+        import ctypes as C
+        L = api.lib(); ms = (C.c_double * 16)(); L.gbn_debug_cpu_account.argtypes = [C.POINTER(C.c_double), C.c_int]
+        n = L.gbn_debug_cpu_account(ms, 16)
+        names = ["set-up (calling thread)", "set-up (pool workers)", "search thread (begin: scan stage)", "extension stage thread", "host replay",
+                 "end + collector", "traceback (calling thread)", "traceback (workers)", "submit (copy of the queries)"]
+        batches = max(args.warmup, 2) + args.steps * len(regions)
+        tot = time.process_time() * 1e3
+        print("[cpu account] %d batches; process CPU %.0f ms in all (incl. start-up)" % (batches, tot), file=sys.stderr)
+        for i in range(n):
+            print("[cpu account]   %-36s %8.2f ms per batch" % (names[i], ms[i] / batches), file=sys.stderr)
     # final alignments of one batch, counted once outside the timed region
     pipe = api.SearchPipeline(opt, src, trace_threads=args.trace_threads, traceback=True, overlap=False)
     pipe.submit(qsets[0]); pipe.finish(); _, res, _ = pipe.next(); pipe.close()

@@ -9,6 +9,8 @@
 #include "gbn_host.hpp"
 #include <functional>
 #include <thread>
+#include <atomic>
+#include <time.h>
 #include <mutex>
 #include <condition_variable>
 #include <deque>
@@ -23,6 +25,7 @@ static const double kLn2 = 0.69314718055994530941723212145818;
 // megablast batch: strand copies, Karlin-Altschul parameters, effective lengths, cut-offs -- every context by itself, so the
 // results do not depend on who computes which).  Rounds 1-4 started and joined a set of threads per loop: 0.3-0.5 ms each time.
 namespace {
+thread_local int tl_setup_pieces = 0;       // gbn_set_setup_threads
 class SetupPool {
     std::vector<std::thread> workers_; std::mutex mu_; std::condition_variable cv_;
     std::deque<std::function<void()>> jobs_; bool stop_ = false;
@@ -30,7 +33,7 @@ class SetupPool {
         for (;;) {
             std::function<void()> job;
             { std::unique_lock<std::mutex> lk(mu_); cv_.wait(lk, [&] { return stop_ || !jobs_.empty(); }); if (jobs_.empty()) return; job = std::move(jobs_.front()); jobs_.pop_front(); }
-            job();
+            { gbn::CpuScope cpu(gbn::GBN_CPU_SETUP_POOL); job(); }
         }
     }
 public:
@@ -39,7 +42,8 @@ public:
     int size() const { return (int)workers_.size(); }
     // f(i0, i1) over [0, n) in pieces of at least `grain`; the caller takes a piece itself and returns when all are done
     void parallel_for(size_t n, size_t grain, const std::function<void(size_t, size_t)> &f) {
-        const size_t pieces = std::max<size_t>(1, std::min<size_t>((size_t)size() + 1, n / std::max<size_t>(grain, 1)));
+        const size_t most = tl_setup_pieces > 0 ? (size_t)tl_setup_pieces : (size_t)size() + 1;        // (gbn_set_setup_threads: the calling thread's share)
+        const size_t pieces = std::max<size_t>(1, std::min<size_t>({(size_t)size() + 1, most, n / std::max<size_t>(grain, 1)}));
         if (pieces <= 1) { f(0, n); return; }
         std::mutex dmu; std::condition_variable dcv; size_t left = pieces - 1;
         std::exception_ptr failed;                      // what a piece threw (a worker must not take the process down: ADVICE r05): rethrown on the caller
@@ -54,7 +58,8 @@ public:
                     if (--left == 0) dcv.notify_one();
                 });
         }
-        cv_.notify_all();
+        if (pieces - 1 >= (size_t)size()) cv_.notify_all();          // (one system call for all of them)
+        else for (size_t p = 1; p < pieces; p++) cv_.notify_one();   // (a share of the pool: as many workers as there are pieces for them)
         std::exception_ptr mine;
         try { f(0, n / pieces); } catch (...) { mine = std::current_exception(); }
         { std::unique_lock<std::mutex> dl(dmu); dcv.wait(dl, [&] { return left == 0; }); }     // (the pieces refer to this frame: waited for whatever happened)
@@ -66,6 +71,19 @@ public:
 // and none of its threads -- jobs would wait for ever.  The child makes its own; the parent's object is left alone there (its
 // thread handles belong to threads that do not exist in this process: neither joined nor destroyed).
 }  // namespace
+
+namespace gbn {
+static std::atomic<long long> g_cpu_ns[GBN_CPU_N];
+static bool cpu_account_on() { static const bool v = getenv("GBN_CPU_ACCOUNT") && atoi(getenv("GBN_CPU_ACCOUNT")) != 0; return v; }
+static long long thread_cpu_ns() { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return (long long)ts.tv_sec * 1000000000ll + ts.tv_nsec; }
+CpuScope::CpuScope(int c) : cat(c), t0(cpu_account_on() ? thread_cpu_ns() : -1) {}
+CpuScope::~CpuScope() { if (t0 >= 0) g_cpu_ns[cat] += thread_cpu_ns() - t0; }
+}  // namespace gbn
+extern "C" void gbn_set_setup_threads(int32_t n) { tl_setup_pieces = n > 0 ? n : 0; }
+extern "C" int gbn_debug_cpu_account(double *ms, int n) {
+    for (int i = 0; i < n && i < gbn::GBN_CPU_N; i++) ms[i] = (double)gbn::g_cpu_ns[i].load() / 1e6;
+    return gbn::GBN_CPU_N;
+}
 
 namespace gbn {
 unsigned host_cpus() {
@@ -100,10 +118,11 @@ SetupPool &setup_pool() {
     static std::mutex mu; static SetupPool *pool = nullptr; static pid_t owner = 0;
     std::lock_guard<std::mutex> lk(mu);
     if (!pool || owner != getpid()) {
-        // (a 256-thread host without a quota: 31 workers + the caller, eight ranks of a node each have their own; under a quota half of
-        // the CPUs granted: two batches are set up at a time, and the search, extension and traceback threads want the rest)
+        // (a 256-thread host without a quota: 31 workers + the caller, eight ranks of a node each have their own; under a quota the CPUs
+        // granted: a set-up nothing else runs beside -- the shim's, 16 pieces 6.3 ms per batch, 8 pieces 7.2 -- uses them all; a
+        // pipeline's set-up threads ask for half (gbn_set_setup_threads), the traceback threads want the rest: C4 4.1 against 4.2-4.4)
         const unsigned cpus = gbn::host_cpus(), hw = std::max(1u, std::thread::hardware_concurrency());
-        pool = new SetupPool((int)std::max(2u, std::min(31u, cpus < hw ? cpus / 2u : hw / 8u)));
+        pool = new SetupPool((int)std::max(2u, std::min(31u, cpus < hw ? cpus - 1u : hw / 8u)));
         owner = getpid();
     }
     return *pool;

@@ -615,6 +615,7 @@ int gbn_batch_new_masked(GbnBatch **out, const GbnOptions *opt, int32_t nq, cons
     if (!out || !opt || nq <= 0 || !seqs || !lens || nmask < 0 || (nmask > 0 && (!mask_query || !mask_from || !mask_to))) {
         set_error("bad argument"); return GBN_ERR_ARG;
     }
+    gbn::CpuScope cpu(gbn::GBN_CPU_SETUP);
     std::vector<QueryMask> masks((size_t)nmask);
     for (int32_t i = 0; i < nmask; i++) masks[(size_t)i] = QueryMask{mask_query[i], mask_from[i], mask_to[i]};
     std::unique_ptr<GbnBatch, void (*)(GbnBatch *)> b(new GbnBatch(), gbn_batch_free);      // (freed if the set-up throws)
@@ -892,6 +893,7 @@ static int search_enter(GbnBatch *batch, GbnDb *db, GbnResults *results) {
 static int run_search(GbnBatch *batch, GbnDb *db, GbnResults *results, GbnDiagnostics *diag,
                       int keep_stages, GbnInterruptFn interrupt, void *progress, int overlap) {
     int rc = GBN_OK;
+    gbn::CpuScope cpu(gbn::GBN_CPU_SEARCH);
     gbn::EngLock lk(E);                   // (the caller has entered the engine: search_enter)
     results->engine = tl_eng; results->diag = diag;
     results->merge.kbp_gap = batch->kbp_gap; results->merge.evalue = batch->opt.evalue; results->merge.eff_searchsp.clear();
@@ -999,6 +1001,7 @@ int gbn_prelim_search_begin(GbnBatch *batch, GbnDb *db, GbnResults *results, Gbn
 
 int gbn_prelim_search_end(GbnResults *results) {
     return gbn::guard(__func__, [&]() -> int {
+    gbn::CpuScope cpu(gbn::GBN_CPU_END_COLLECT);
     // the engine that is filling these results; without results: whatever the calling thread's engine has in flight
     if (results && results->engine) enter(static_cast<Engine *>(results->engine));
     else if (results) return GBN_OK;                        // never searched: nothing in flight for them

@@ -503,6 +503,10 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             }
         }
         trace_mark("scan: kernels queued");
+        // (tried in round 6 and not kept: sleeping through 60 % of what the last wait of this kind took instead of spinning in the runtime for
+        // all of it -- the search thread's CPU 2.8 -> 1.3 ms per C4 batch and C4 4.08 -> 4.01 ms under the box's CPU quota, but the cached
+        // C2 pass 3.08 -> 3.11-3.25 and C3 26.7 -> 27.0: the wake-up costs the GPU-bound passes more than the CPU-bound one gains;
+        // profiles/r06_wait_ab.txt)
         HIPCHK(hipEventSynchronize(E.ev_back));
         trace_mark("scan: kernels done");
         cnt[0] = E.scan_back->cnt[0]; cnt[1] = E.scan_back->cnt[1];

@@ -261,6 +261,7 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
         Engine *eng = tl_eng;
         E.pending = std::async(std::launch::async, [=]() -> int {
             tl_eng = eng;
+            gbn::CpuScope cpu(gbn::GBN_CPU_STAGE);
             int r = GBN_OK;
             unsigned long long nih2 = 0;
             if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the extension thread"; return GBN_ERR_HIP; }
@@ -296,6 +297,7 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
     Engine *eng = tl_eng;
     E.pending = std::async(std::launch::async, [=]() -> int {
         tl_eng = eng;
+        gbn::CpuScope cpu(gbn::GBN_CPU_STAGE);
         if (hipSetDevice(dev) != hipSuccess) { E.pending_err = "hipSetDevice failed in the gapped-stage thread"; return GBN_ERR_HIP; }
         const int r = gapped_stage(*bp, *dbp, s0, s1, *rp, diag, 0, slot, nih, E.stream2, true);
         if (r) E.pending_err = gbn_last_error();      // the error text is per thread
@@ -426,6 +428,7 @@ static int gapped_stage(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResul
         std::shared_future<void> prev = E.host_tail;
         E.host_tail = std::async(std::launch::async, [=]() mutable {
             enter(eng);
+            gbn::CpuScope cpu(gbn::GBN_CPU_REPLAY);
             if (prev.valid()) prev.wait();
             try {
                 const int r = gapped_host(*bp, *dbp, s0, s1, *rp, diag, 0, hb.hih, hb.hg, n_hits);

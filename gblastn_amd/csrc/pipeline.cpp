@@ -33,6 +33,7 @@ int64_t gbn_pipeline_submit(GbnPipeline *p, int32_t nq, const uint8_t *const *se
 {
     return gbn::guard_as<int64_t>(__func__, (int64_t)-1, (int64_t)-1, [&]() -> int64_t {
     if (!p || nq <= 0 || !seqs || !lens) { gbn::set_error("gbn_pipeline_submit: bad argument"); return -1; }
+    gbn::CpuScope cpu(gbn::GBN_CPU_SUBMIT);
     gbn::SQueryBatch q;
     for (int32_t i = 0; i < nq; i++) q.seqs.emplace_back(seqs[i], seqs[i] + lens[i]);
     for (int32_t i = 0; i < nmask; i++) q.masks.push_back(gbn::SQueryBatch::Mask{mask_query[i], mask_from[i], mask_to[i]});

@@ -681,6 +681,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
     if (!batch || !db || !out || nlists < 0 || (nlists > 0 && (!hsps || !list_start))) { set_error("gbn_traceback_run: bad argument"); return GBN_ERR_ARG; }
     out->hsps.clear(); out->op.clear(); out->op_len.clear(); out->query_start.assign((size_t)batch->nq + 1, 0);
     if (nlists == 0) return GBN_OK;
+    gbn::CpuScope cpu(gbn::GBN_CPU_TRACEBACK);
     trace_mark("traceback: starts");
     // subjects that have lists, each fetched once -- of a long subject only the stretch the extensions can reach
     // (AdjustSubjectRange: query length + 3000 either side of an HSP) is read back and unpacked
@@ -758,6 +759,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
     std::atomic<size_t> next{0}; std::atomic<int> failed{GBN_OK}; std::string err;
     std::mutex err_mu;
     auto body = [&]() {
+        gbn::CpuScope cpu_w(gbn::GBN_CPU_TRACEBACK_WORKERS);
         for (size_t k; (k = next.fetch_add(1)) < work.size();) {
             Work &w = work[k];
             unpack(w);

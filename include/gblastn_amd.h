@@ -161,6 +161,7 @@ int  gbn_use_device(int gpu_id);
 int  gbn_current_device(void);              /* of the calling thread; -1: none armed yet */
 void gbn_release(void);                     /* every engine: stages finished, device idle, buffers / streams / events freed */
 void gbn_release_db_memory(void);   /* frees every shard held by the cache below (GB/gpu_blastn_na_ungapped_v3.h:21) */
+int gbn_debug_cpu_account(double *ms, int n);     /* bench, GBN_CPU_ACCOUNT=1: CPU ms of the host threads by class (csrc/gbn_host.hpp GBN_CPU_*); returns the number of classes */
 long gbn_debug_check_guards(void);  /* tests, GBN_GUARD=1: guard zones around every device block of the pool intact? */
 /* shards kept per caller handle (the shim keys them by BlastSeqSrc*): the cache owns what is inserted */
 struct GbnDb;
@@ -464,6 +465,10 @@ const char *gbn_last_error(void);
  * their own (traceback consumers, DUST) should too.  GBN_HOST_CPUS=n overrides.  No reference counterpart (blastn's -num_threads
  * is the caller's number). */
 int32_t gbn_host_cpus(void);
+/* Threads the per-context loops of the batches THE CALLING THREAD sets up from now on are spread over (Karlin-Altschul parameters,
+ * effective lengths, cut-offs of 10,000 contexts: 14 ms of CPU per 5 Mb batch); 0 = the library's pool in full (the default: the CPUs
+ * granted).  For callers that set batches up in the background of other CPU work: CSearchPipeline's set-up threads ask for half. */
+void gbn_set_setup_threads(int32_t n);
 
 #ifdef __cplusplus
 }

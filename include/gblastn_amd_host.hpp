@@ -179,6 +179,7 @@ private:
     }
     // set-up of a batch (host part + lookup structures on the device) on two threads, at most three batches ahead of the search
     void SetupThread() {
+        gbn_set_setup_threads(std::max(2, (int)gbn_host_cpus() / 2));      // (the traceback threads want the other half of the CPUs granted)
         for (;;) {
             TItem it;
             {
