@@ -143,7 +143,7 @@ def bench_c4(args, api, torch, dist, world, rank, dev, src, qsets, nbatch, opt, 
         L = api.lib(); ms = (C.c_double * 16)(); L.gbn_debug_cpu_account.argtypes = [C.POINTER(C.c_double), C.c_int]
         n = L.gbn_debug_cpu_account(ms, 16)
         names = ["set-up (calling thread)", "set-up (pool workers)", "search thread (begin: scan stage)", "extension stage thread", "host replay",
-                 "end + collector", "traceback (calling thread)", "traceback (workers)", "submit (copy of the queries)"]
+                 "end + collector", "traceback (calling thread)", "traceback (workers)", "submit (copy of the queries)", "  of the workers: unpacking the subject stretches", "  of the workers: start points", "  of the workers: alignment (incl. what follows in the loop)", "  of the workers: rescoring, identities, containment (to the end of the list)", "  of the calling thread: per-query order and output"]
         batches = max(args.warmup, 2) + args.steps * len(regions)
         tot = time.process_time() * 1e3
         print("[cpu account] %d batches; process CPU %.0f ms in all (incl. start-up)" % (batches, tot), file=sys.stderr)

@@ -134,8 +134,8 @@ void gbn_collector_free(GbnCollector *c) { delete c; }
 // records grouped by oid (as gbn_results_hsps yields them); every oid group is one
 // BlastHSPStreamWrite.  Writing after close is an error (CORE/blast_hspstream.c:332-335).
 int gbn_collector_write(GbnCollector *c, const GbnHSP *h, int64_t n) {
-    gbn::CpuScope cpu(gbn::GBN_CPU_END_COLLECT);
     return gbn::guard(__func__, [&]() -> int {
+    gbn::CpuScope cpu(gbn::GBN_CPU_END_COLLECT);
     if (!c || (n > 0 && !h)) { gbn::set_error("gbn_collector_write: bad argument"); return GBN_ERR_ARG; }
     if (c->closed) { gbn::set_error("gbn_collector_write: collector already closed"); return GBN_ERR_ARG; }
     std::vector<std::unique_ptr<SubjectHits>> split((size_t)c->nq);
@@ -160,8 +160,8 @@ int gbn_collector_write(GbnCollector *c, const GbnHSP *h, int64_t n) {
 // surviving lists in (oid, query) ascending order -- the order BlastHSPStreamRead hands
 // them to the traceback stage (ascending oid)
 int gbn_collector_close(GbnCollector *c) {
-    gbn::CpuScope cpu(gbn::GBN_CPU_END_COLLECT);
     return gbn::guard(__func__, [&]() -> int {
+    gbn::CpuScope cpu(gbn::GBN_CPU_END_COLLECT);
     if (!c) return GBN_ERR_ARG;
     if (c->closed) return GBN_OK;
     std::vector<const SubjectHits *> all;

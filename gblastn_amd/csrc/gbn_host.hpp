@@ -54,7 +54,7 @@ void trace_mark(const char *what);   // GBN_TRACE=1: wall-clock marks on stderr 
 unsigned host_cpus();
 // GBN_CPU_ACCOUNT=1: CPU time (CLOCK_THREAD_CPUTIME_ID) of the host threads by what they were doing, summed over the process; read with
 // gbn_debug_cpu_account.  A scope adds the calling thread's CPU time between its construction and its end to one class.
-enum { GBN_CPU_SETUP = 0, GBN_CPU_SETUP_POOL, GBN_CPU_SEARCH, GBN_CPU_STAGE, GBN_CPU_REPLAY, GBN_CPU_END_COLLECT, GBN_CPU_TRACEBACK, GBN_CPU_TRACEBACK_WORKERS, GBN_CPU_SUBMIT, GBN_CPU_N };
+enum { GBN_CPU_SETUP = 0, GBN_CPU_SETUP_POOL, GBN_CPU_SEARCH, GBN_CPU_STAGE, GBN_CPU_REPLAY, GBN_CPU_END_COLLECT, GBN_CPU_TRACEBACK, GBN_CPU_TRACEBACK_WORKERS, GBN_CPU_SUBMIT, GBN_CPU_TB_UNPACK, GBN_CPU_TB_START, GBN_CPU_TB_ALIGN, GBN_CPU_TB_RESCORE, GBN_CPU_TB_SORT_OUT, GBN_CPU_N };
 struct CpuScope { int cat; long long t0; explicit CpuScope(int c); ~CpuScope(); };
 }  // namespace gbn
 

@@ -17,6 +17,7 @@
 #include "gbn_guard.hpp"
 #include "envelope_index.hpp"
 #include <algorithm>
+#include <array>
 #include <atomic>
 #include <cmath>
 #include <cstring>
@@ -176,12 +177,17 @@ int32_t greedy_half(const uint8_t *a, int32_t la, const uint8_t *b, int32_t lb, 
     if (run == la || run == lb) { append_op(path, kSub, run); return 0; }
     // furthest subject offset per (distance, diagonal); a row spans the diagonals its distance can reach plus two
     // either side (the reference's allocation for the rows it adds, :677-683; its first two rows span everything)
-    std::vector<int32_t> store; struct RowRef { size_t at; int32_t lo; };
-    std::vector<RowRef> rows;
+    // (the buffers stay with the thread: `top` is 10,000 entries for a subject of 20 kb and more -- 40 KB allocated and cleared per half
+    // and alignment, a quarter of a traceback worker's time at 2,469 alignments per batch -- and only its first `lookback` entries are
+    // read before they are written)
+    struct RowRef { size_t at; int32_t lo; };
+    thread_local std::vector<int32_t> store; thread_local std::vector<RowRef> rows; thread_local std::vector<int32_t> top;
+    store.clear(); rows.clear();
     auto new_row = [&](int32_t lo, int32_t n) { rows.push_back(RowRef{store.size(), lo}); store.resize(store.size() + (size_t)n, 0); };
     auto at = [&](int32_t d, int32_t k) -> int32_t & { return store[rows[(size_t)d].at + (size_t)(k - rows[(size_t)d].lo)]; };
     new_row(origin - 2, 7); new_row(origin - 3, 9);
-    std::vector<int32_t> top((size_t)(dmax + 2 + lookback), 0);     // best score per distance, `lookback` zeros in front
+    if (top.size() < (size_t)(dmax + 2 + lookback)) top.resize((size_t)(dmax + 2 + lookback));
+    std::fill(top.begin(), top.begin() + lookback + 1, 0);          // best score per distance, `lookback` zeros in front
     auto best_at = [&](int32_t d) -> int32_t & { return top[(size_t)(d + lookback)]; };
     at(0, origin) = run;
     best_at(0) = run * match2;
@@ -593,12 +599,14 @@ int traceback_list(const GbnBatch &b, const uint8_t *subject, int32_t slen, cons
             const uint8_t *q = b.query() + cx.query_offset;
             if (index.enveloped(h, o.min_diag_separation)) { it.live = false; continue; }
             int32_t q0, s0;
+            { gbn::CpuScope c1(gbn::GBN_CPU_TB_START);
             if ((h.q_gapped_start == 0 && h.s_gapped_start == 0) || !start_scores_positive(b.matrix, h, q, subject)) {
                 if (!best_window_start(b.matrix, q, subject, h, q0, s0)) { it.live = false; continue; }
                 h.q_gapped_start = q0; h.s_gapped_start = s0;
             } else {
                 longest_identity_run_start(q, subject, h);
                 q0 = h.q_gapped_start; s0 = h.s_gapped_start;
+            }
             }
             // long subjects: only the stretch an extension can reach (AdjustSubjectRange)
             int32_t shift = 0, sub_len = slen;
@@ -609,6 +617,7 @@ int traceback_list(const GbnBatch &b, const uint8_t *subject, int32_t slen, cons
             }
             const uint8_t *sub = subject + shift;
             h.s_gapped_start = s0;
+            gbn::CpuScope c2(gbn::GBN_CPU_TB_ALIGN);
             Extent e = greedy ? greedy_traceback(q, sub, cx.query_length, sub_len, q0, s0, X, o.reward, o.penalty, o.gap_open, o.gap_extend, it.sc)
                               : gapped_traceback(b.matrix, q, sub, cx.query_length, sub_len, q0, s0, X, o.gap_open, o.gap_extend, it.sc);
             h.score = e.score; h.q_offset = e.q_start; h.q_end = e.q_stop; h.s_offset = e.s_start; h.s_end = e.s_stop;
@@ -619,6 +628,7 @@ int traceback_list(const GbnBatch &b, const uint8_t *subject, int32_t slen, cons
         }
     }
     items.erase(std::remove_if(items.begin(), items.end(), [](const Item &t) { return !t.live; }), items.end());
+    gbn::CpuScope c3(gbn::GBN_CPU_TB_RESCORE);
     size_t first_to_rescore = trim_shared_ends(items);
     if (greedy) first_to_rescore = 0;           // the greedy aligner ignored ambiguities: every HSP is re-scored
     for (size_t i = first_to_rescore; i < items.size(); i++) {
@@ -747,7 +757,12 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
         const int32_t n = w.hi - w.lo; const uint8_t *p = packed.data() + w.packed_at;
         w.bases.resize(((size_t)n + 3) / 4 * 4 + 4);
         uint8_t *o = w.bases.data();
-        for (int32_t i = 0; i < (n + 3) / 4; i++, o += 4) { const uint8_t c = p[i]; o[0] = c >> 6; o[1] = (c >> 4) & 3; o[2] = (c >> 2) & 3; o[3] = c & 3; }
+        // (a packed byte's four bases as one 32-bit store out of a 1 KB table: the byte-wise loop was a fifth of a worker's time)
+        static const std::array<uint32_t, 256> four = [] {
+            std::array<uint32_t, 256> t{};
+            for (int c = 0; c < 256; c++) { const uint8_t b[4] = {(uint8_t)(c >> 6), (uint8_t)((c >> 4) & 3), (uint8_t)((c >> 2) & 3), (uint8_t)(c & 3)}; std::memcpy(&t[(size_t)c], b, 4); }
+            return t; }();
+        for (int32_t i = 0; i < (n + 3) / 4; i++, o += 4) std::memcpy(o, &four[p[i]], 4);
         if (!db->amb.empty())
             for (const GbnDb::AmbRun &r : db->amb[(size_t)w.local]) {
                 const int32_t a = std::max(r.start, w.lo), e = std::min(r.start + r.length, w.hi);
@@ -762,7 +777,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
         gbn::CpuScope cpu_w(gbn::GBN_CPU_TRACEBACK_WORKERS);
         for (size_t k; (k = next.fetch_add(1)) < work.size();) {
             Work &w = work[k];
-            unpack(w);
+            { gbn::CpuScope cpu_u(gbn::GBN_CPU_TB_UNPACK); unpack(w); }
             for (int64_t l = w.first_list; l < w.end_list; l++) {
                 const GbnHSP *first = hsps + list_start[l]; const size_t n = (size_t)(list_start[l + 1] - list_start[l]);
                 Done d; d.oid = first->oid; d.query = first->context / 2;
@@ -780,6 +795,7 @@ int gbn_traceback_run(GbnBatch *batch, GbnDb *db, const GbnHSP *hsps, const int6
     else { std::vector<std::thread> pool; for (unsigned t = 0; t < nthreads; t++) pool.emplace_back(body); for (auto &th : pool) th.join(); }
     if (failed != GBN_OK) { set_error(err); return failed; }
     trace_mark("traceback: lists aligned");
+    gbn::CpuScope c4(gbn::GBN_CPU_TB_SORT_OUT);
     // per query: subjects by (best e-value, best score, oid descending), at most hitlist_size of them
     std::vector<std::vector<Done *>> by_query((size_t)batch->nq);
     for (auto &v : per_work) for (Done &d : v) by_query[(size_t)d.query].push_back(&d);
