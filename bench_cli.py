@@ -156,6 +156,7 @@ def bench_cli(args, api):
         "config": {"workload": "cli: %d x 1 kb queries (FASTA) vs %.1f Gbp in 13 BLAST v4 volumes on disk (%.1f GB), megablast, default DUST, traceback, 12-column rows"
                                % (len(seqs), args.subjects * args.subject_len / 1e9, disk / 1e9),
                    "first_run": runs[0], "warm_runs_ms": [r["wall_ms"] for r in runs[1:]], "warm_phases": best["phases"],
+                   "warm_runs_upload_and_wait_ms": [[(r["phases"] or {}).get("db_open_upload_ms"), (r["phases"] or {}).get("wait_results_ms")] for r in runs[1:]],
                    "warm_trace_t_num_8": {"wall_ms": min(x[0] for x in t8), "phases": min(t8, key=lambda x: x[0])[1], "rows_equal": rows_t8 == rows_cli},
                    "one_slab_loader_of_rounds_1_to_5": {"wall_ms": old[0], "phases": old[1]},
                    "rows": len(rows_cli), "rows_equal_library_calls": same, "library_load_shard_s": load_s,
