@@ -10,6 +10,7 @@
 #include "gbn_host.hpp"
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <cstdlib>
 
 namespace gbn {
@@ -236,8 +237,14 @@ void uniform_acgt(double comp[16]) {
 }
 
 void strand_composition(const uint8_t *seq, int32_t len, double comp[16]) {
-    int32_t cnt[16] = {0};
-    for (int32_t i = 0; i < len; i++) ++cnt[seq[i] & 0x0f];
+    // (four histograms: one counter array makes every increment wait for the store of the one before when letters repeat -- the loop was
+    // 12 of the 14 ms of CPU a 5 Mb batch's per-context set-up took)
+    int32_t c4[4][16] = {{0}};
+    int32_t i = 0;
+    for (; i + 4 <= len; i += 4) { ++c4[0][seq[i] & 0x0f]; ++c4[1][seq[i + 1] & 0x0f]; ++c4[2][seq[i + 2] & 0x0f]; ++c4[3][seq[i + 3] & 0x0f]; }
+    for (; i < len; i++) ++c4[0][seq[i] & 0x0f];
+    int32_t cnt[16];
+    for (int k = 0; k < 16; k++) cnt[k] = c4[0][k] + c4[1][k] + c4[2][k] + c4[3][k];
     cnt[14] = 0; cnt[15] = 0;       // 'N' and '-' are not counted
     double sum = 0.;
     for (int i = 0; i < 16; i++) sum += cnt[i];
@@ -245,20 +252,32 @@ void strand_composition(const uint8_t *seq, int32_t len, double comp[16]) {
 }
 
 bool ungapped_karlin(int reward, int penalty, const double c1[16], const double c2[16], Karlin &out) {
-    int32_t m[16][16];
-    build_score_matrix(reward, penalty, m);
-    int lo = kScoreMax, hi = kScoreMin;
-    for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {
-        int s = m[i][j];
-        if (s <= kScoreMin || s >= kScoreMax) continue;
-        lo = std::min(lo, s); hi = std::max(hi, s);
+    // (the matrix and its score range are the same for every context of a batch: kept with the thread)
+    struct Mat { int reward = 0, penalty = 0, lo = 0, hi = 0; bool made = false; int32_t m[16][16]; };
+    thread_local Mat M;
+    if (!M.made || M.reward != reward || M.penalty != penalty) {
+        build_score_matrix(reward, penalty, M.m);
+        int lo0 = kScoreMax, hi0 = kScoreMin;
+        for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {
+            int s = M.m[i][j];
+            if (s <= kScoreMin || s >= kScoreMax) continue;
+            lo0 = std::min(lo0, s); hi0 = std::max(hi0, s);
+        }
+        M.reward = reward; M.penalty = penalty; M.lo = lo0; M.hi = hi0; M.made = true;
     }
+    const int32_t (*m)[16] = M.m;
+    const int lo = M.lo, hi = M.hi;
     out = Karlin(); out.logK = HUGE_VAL;
     if (!range_ok(lo, hi)) return false;
     ScoreDist d; d.lo = lo; d.hi = hi; d.mass.assign((size_t)(hi - lo + 1), 0.0);
-    for (int i = 0; i < 16; i++) for (int j = 0; j < 16; j++) {
-        int s = m[i][j];
-        if (s >= lo) d.at(s) += c1[i] * c2[j];
+    // (letters that do not occur add 0.0 to a sum: left out, the sums are the same doubles)
+    for (int i = 0; i < 16; i++) {
+        if (c1[i] == 0.0) continue;
+        for (int j = 0; j < 16; j++) {
+            if (c2[j] == 0.0) continue;
+            int s = m[i][j];
+            if (s >= lo) d.at(s) += c1[i] * c2[j];
+        }
     }
     double total = 0.; int omin = kScoreMin, omax = kScoreMin;
     for (int s = lo; s <= hi; s++) if (d.at(s) > 0.) { total += d.at(s); omax = s; if (omin == kScoreMin) omin = s; }
@@ -267,14 +286,27 @@ bool ungapped_karlin(int reward, int penalty, const double c1[16], const double 
     if (total > 0.0001 || total < -0.0001)
         for (int s = omin; s <= omax; s++) { d.at(s) /= total; avg += s * d.at(s); }
     d.mean = avg;
+    // lambda, H and K are a function of the score distribution alone, and the 10,000 contexts of a nucleotide batch share a handful of
+    // them (match / mismatch against uniform background frequencies: 1/4 and 3/4 whatever the query's composition, up to the last bit of
+    // the sums): the solutions of the distributions this thread has seen are kept and found again by their exact bits -- the same
+    // doubles as solving again, a tenth of the time (round 6: the set-up's per-context loop was 14 ms of CPU per 5 Mb batch)
+    struct Solved { int lo, hi, obs_lo, obs_hi; double mean; std::vector<double> mass; bool ok; Karlin k; };
+    thread_local std::vector<Solved> memo;
+    for (const Solved &m0 : memo)
+        if (m0.lo == d.lo && m0.hi == d.hi && m0.obs_lo == d.obs_lo && m0.obs_hi == d.obs_hi && std::memcmp(&m0.mean, &d.mean, sizeof(double)) == 0 &&
+            m0.mass.size() == d.mass.size() && std::memcmp(m0.mass.data(), d.mass.data(), d.mass.size() * sizeof(double)) == 0) {
+            if (m0.ok) out = m0.k;
+            return m0.ok;
+        }
+    auto remember = [&](bool ok) { if (memo.size() >= 64) memo.erase(memo.begin()); memo.push_back(Solved{d.lo, d.hi, d.obs_lo, d.obs_hi, d.mean, d.mass, ok, out}); return ok; };
     double lam;
-    if (!solve_lambda(d, lam) || lam < 0.) return false;
+    if (!solve_lambda(d, lam) || lam < 0.) return remember(false);
     double H = entropy_H(d, lam);
-    if (H < 0.) return false;
+    if (H < 0.) return remember(false);
     double K = solve_K(d, lam, H);
-    if (K < 0.) return false;
+    if (K < 0.) return remember(false);
     out.lambda = lam; out.H = H; out.K = K; out.logK = std::log(K);
-    return true;
+    return remember(true);
 }
 
 int gapped_karlin(int gap_open, int gap_extend, int reward, int penalty, const Karlin &ungapped,

@@ -166,6 +166,24 @@ inline int32_t run_of_matches(const uint8_t *a, const uint8_t *b, int32_t la, in
     else while (i < la && j < lb && a[i] < 4 && a[i] == b[j]) { i++; j++; }
     return i - i0;
 }
+// ... with the direction known at compile time, eight bases per step where both sequences have them (forwards: the first byte that
+// differs or is no base, from the low end of the words; backwards: from the high end of the words that END at the positions)
+template <bool kBackwards>
+inline int32_t run_of_matches_dir(const uint8_t *a, const uint8_t *b, int32_t la, int32_t lb, int32_t i, int32_t j) {
+    const int32_t i0 = i;
+    while (i + 8 <= la && j + 8 <= lb) {
+        uint64_t x, y;
+        if (kBackwards) { std::memcpy(&x, a + la - 8 - i, 8); std::memcpy(&y, b + lb - 8 - j, 8); }
+        else { std::memcpy(&x, a + i, 8); std::memcpy(&y, b + j, 8); }
+        const uint64_t bad = (x ^ y) | (x & 0xFCFCFCFCFCFCFCFCull);     // a byte is non-zero where the letters differ or a's is no base
+        if (bad == 0) { i += 8; j += 8; continue; }
+        const int32_t n = kBackwards ? (__builtin_clzll(bad) >> 3) : (__builtin_ctzll(bad) >> 3);
+        return i + n - i0;
+    }
+    if (kBackwards) while (i < la && j < lb && a[la - 1 - i] < 4 && a[la - 1 - i] == b[lb - 1 - j]) { i++; j++; }
+    else while (i < la && j < lb && a[i] < 4 && a[i] == b[j]) { i++; j++; }
+    return i - i0;
+}
 int32_t greedy_half(const uint8_t *a, int32_t la, const uint8_t *b, int32_t lb, bool backwards, int32_t xdrop,
                     int32_t match2, int32_t mismatch2, int32_t &used_a, int32_t &used_b, Script &path)
 {
@@ -181,7 +199,8 @@ int32_t greedy_half(const uint8_t *a, int32_t la, const uint8_t *b, int32_t lb, 
     // and alignment, a quarter of a traceback worker's time at 2,469 alignments per batch -- and only its first `lookback` entries are
     // read before they are written)
     struct RowRef { size_t at; int32_t lo; };
-    thread_local std::vector<int32_t> store; thread_local std::vector<RowRef> rows; thread_local std::vector<int32_t> top;
+    thread_local std::vector<int32_t> tl_store, tl_top; thread_local std::vector<RowRef> tl_rows;
+    std::vector<int32_t> &store = tl_store, &top = tl_top; std::vector<RowRef> &rows = tl_rows;    // (one look-up of the thread's copies, not one per use)
     store.clear(); rows.clear();
     auto new_row = [&](int32_t lo, int32_t n) { rows.push_back(RowRef{store.size(), lo}); store.resize(store.size() + (size_t)n, 0); };
     auto at = [&](int32_t d, int32_t k) -> int32_t & { return store[rows[(size_t)d].at + (size_t)(k - rows[(size_t)d].lo)]; };
@@ -195,19 +214,23 @@ int32_t greedy_half(const uint8_t *a, int32_t la, const uint8_t *b, int32_t lb, 
     bool hit_end_a = false, hit_end_b = false;
     for (int32_t d = 1; d <= dmax; d++) {
         const int32_t from = lower, to = upper;
-        at(d - 1, lower - 1) = kNone; at(d - 1, lower) = kNone; at(d - 1, upper) = kNone; at(d - 1, upper + 1) = kNone;
+        // (rows d - 1 and d through pointers of their own: both exist, and nothing is appended to `store` inside the loop over the
+        // diagonals; round 6)
+        int32_t *const prev = store.data() + rows[(size_t)d - 1].at - rows[(size_t)d - 1].lo;
+        int32_t *const cur = store.data() + rows[(size_t)d].at - rows[(size_t)d].lo;
+        prev[lower - 1] = kNone; prev[lower] = kNone; prev[upper] = kNone; prev[upper + 1] = kNone;
         int32_t floor_sum = best_at(d - lookback) + (match2 + mismatch2) * d - xdrop;
         floor_sum = (int32_t)std::ceil((double)floor_sum / (match2 / 2));
         int32_t far = 0, far_j = 0, far_k = 0;
         for (int32_t k = from; k <= to; k++) {
-            int32_t j = std::max(at(d - 1, k + 1), at(d - 1, k)) + 1;
-            j = std::max(j, at(d - 1, k - 1));
+            int32_t j = std::max(prev[k + 1], prev[k]) + 1;
+            j = std::max(j, prev[k - 1]);
             int32_t i = j + k - origin;
-            if (j < 0 || i + j < floor_sum) { if (k == lower) lower++; else at(d, k) = kNone; continue; }
+            if (j < 0 || i + j < floor_sum) { if (k == lower) lower++; else cur[k] = kNone; continue; }
             upper = k;
-            const int32_t more = run_of_matches(a, b, la, lb, i, j, backwards);
+            const int32_t more = backwards ? run_of_matches_dir<true>(a, b, la, lb, i, j) : run_of_matches_dir<false>(a, b, la, lb, i, j);
             i += more; j += more;
-            at(d, k) = j;
+            cur[k] = j;
             if (i + j > far) { far = i + j; far_j = j; far_k = k; }
             if (j == lb) { lower = k + 1; hit_end_b = true; }
             if (i == la) { upper = k - 1; hit_end_a = true; }
