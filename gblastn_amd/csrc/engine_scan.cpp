@@ -199,8 +199,13 @@ int rec_acquire(const RecKey &key, const BinLayout &L, long long limit, RecordSe
 // (the 10,000-query config) is not worth sorting, a stream of batches is.  GBN_REC_RUNS=0: never (the stream-form path, A/B).
 static bool runs_enabled() { return gbn::switch_value("GBN_REC_RUNS", 1) != 0; }
 static int runs_after() { return (int)std::max(0ll, gbn::switch_value("GBN_RUNS_AFTER", 1)); }
-// workgroups of probe_runs_kernel (512 threads, 12 KB of LDS, 20 KB of LDS, 58 registers: four per CU) = queue segments of the rare kernel
-static int runs_grid() { return (int)std::min<long long>(2048, (long long)E.num_cu * std::max(1ll, std::min(8ll, gbn::switch_value("GBN_RUNS_WGS", 4)))); }
+// workgroups of probe_runs_kernel (512 threads, 20 KB of LDS, 58 registers: four fit a CU) = queue segments of the rare kernel.  THREE per
+// CU: four take all 32 wave slots of a CU, and the extension stage of the batch before -- seed sort, diagonal kernel, greedy kernel, on
+// the second stream -- then runs only once the probe kernel has ended, next to the rare kernel, and overruns into the next pass (the
+// search thread waited 0.9 ms per C4 batch for it).  Same box, two runs each: cached C2 step 3.18 / 3.02 ms with four, 2.97 / 2.98 with
+// three, 3.20 / 3.19 with two (the kernel itself 1.43 -> 1.44 -> 1.55 ms); C4 3.40 / 3.33, 3.29 / 3.35, 3.18 / 3.17
+// (profiles/r06_runs_wgs_ab.txt)
+static int runs_grid() { return (int)std::min<long long>(2048, (long long)E.num_cu * std::max(1ll, std::min(8ll, gbn::switch_value("GBN_RUNS_WGS", 3)))); }
 
 // B: the streams of the complete set `rs`, npos: its records.  On success the set is in sorted form and its streams are back
 // in the pool; a build that finds no room, or whose count does not come out, leaves the set as it is (and is not tried again).
