@@ -61,7 +61,7 @@ def side_workloads(device_index):
         cmd = [sys.executable, BENCH, "--workload", wl, "--steps", steps, "--warmup", "2",
                "--engine-steps", "0", "--min-seconds", "1.0", "--side"] + (["--cpu-seconds", "6"] if wl == "C3" else ["--no-cpu-baseline"])
         if wl == "skew":        # the C2 step over a repeat-rich shard (profiles/r06_skew.txt), the library's default policy
-            cmd = [sys.executable, BENCH, "--skew", "--record-cache", "on", "--steps", steps, "--warmup", "2", "--engine-steps", "0", "--min-seconds", "0.5",
+            cmd = [sys.executable, BENCH, "--skew", "--record-cache", "on", "--steps", steps, "--warmup", "6", "--engine-steps", "0", "--min-seconds", "0.5",
                    "--side", "--no-cpu-baseline", "--no-side-workloads"]
         env = dict(os.environ); env["HIP_VISIBLE_DEVICES"] = env.get("HIP_VISIBLE_DEVICES", "")
         if not env["HIP_VISIBLE_DEVICES"]:
@@ -76,7 +76,10 @@ def side_workloads(device_index):
                 out[wl] = {"workload": j["config"]["workload"] + " with gbn_synth_skew over it", "ms_per_step": j["ms_per_step"], "steps": j["steps"],
                            "uniform_step_is": "this line's cached_pass (record cache on)", "skew": j["config"].get("skew"),
                            "hsps_per_pass": j["config"].get("hsps_per_pass"), "gpu_ms_per_launch_by_kernel": j["roofline"].get("gpu_ms_per_launch_by_kernel"),
-                           "scan_kernels_ms": j["roofline"]["scan_stage"]["avg_ms_by_kernel"], "command": "python bench.py --skew --record-cache on --steps %s" % steps}
+                           "scan_kernels_ms": j["roofline"]["scan_stage"]["avg_ms_by_kernel"], "command": "python bench.py --skew --record-cache on --steps %s --warmup 6" % steps,
+                           "warmup_what": "six passes: the set's one-time work -- binned again with per-bin stream capacities when the first pass's streams overflow (a new 25 GB "
+                                          "buffer: up to 2 s when the driver has to hand out memory just freed), sorted by cell at its second hit -- is over before the timed "
+                                          "regions; with two, one run in three had it inside (17.9 / 24.6 / 112 ms per step)"}
                 continue
             r = j["roofline"]
             out[wl] = {"workload": j["config"]["workload"], "ms_per_step": j["ms_per_step"], "ms_per_step_minmax": j.get("ms_per_step_minmax"),
