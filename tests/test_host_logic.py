@@ -164,3 +164,40 @@ def test_host_cpus_follow_the_affinity_mask_and_the_cgroup_quota():
     out = subprocess.run([sys.executable, "-c", "from gblastn_amd import api; print(api.host_cpus())"], env=dict(os.environ, GBN_HOST_CPUS="3"),
                          capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.stdout.strip() == "3", out.stderr[-500:]
+
+
+def test_setup_of_many_compositions_matches_oracle_whatever_the_thread_share():
+    """The per-context Karlin-Altschul parameters are solved once per score distribution a thread has seen and found again by the
+    distribution's exact bits (csrc/stat.cpp, round 6): a batch of very different compositions -- uniform, AT-rich, one letter only,
+    half ambiguity codes, a query of Ns alone -- against the oracle, bit for bit, set up on the whole pool and on one thread
+    (gbn_set_setup_threads)."""
+    rng = np.random.default_rng(99)
+    qs = []
+    for i in range(300):
+        kind = i % 6
+        if kind == 0: q = rng.integers(0, 4, 600 + i, dtype=np.uint8)
+        elif kind == 1: q = rng.choice(np.array([0, 3, 0, 3, 1, 2], dtype=np.uint8), 500 + i)
+        elif kind == 2: q = np.full(400 + i, i % 4, dtype=np.uint8)
+        elif kind == 3: q = rng.integers(0, 4, 700, dtype=np.uint8); q[rng.random(700) < 0.5] = 14
+        elif kind == 4: q = rng.choice(np.array([0, 0, 0, 1, 2, 3], dtype=np.uint8), 900)
+        else: q = rng.integers(0, 4, 300 + 3 * i, dtype=np.uint8); q[::7] = np.uint8(4 + i % 10)
+        qs.append(q)
+    qs[17] = np.full(200, 14, dtype=np.uint8)           # no valid context
+    gopt = api.default_options("blastn", db_length=5_000_000_000, db_num_seqs=5_000)
+    s = orc.Search(util.oracle_options(gopt), qs)
+    L = api.lib()
+    L.gbn_set_setup_threads.argtypes = [C.c_int32]; L.gbn_set_setup_threads.restype = None
+    try:
+        for share in (0, 1, 3):
+            L.gbn_set_setup_threads(share)
+            b = api.BlastPrelimSearch(qs, gopt, upload=False)
+            gc, oc = b.contexts, s.contexts
+            assert len(gc) == len(oc) == 2 * len(qs)
+            for g, o in zip(gc, oc):
+                for f in CTX_INT:
+                    assert getattr(g, f) == getattr(o, f), (share, f)
+                for f in CTX_F64:
+                    assert bits(getattr(g, f)) == bits(getattr(o, f)), (share, f)
+            b.close()
+    finally:
+        L.gbn_set_setup_threads(0)
