@@ -124,3 +124,31 @@ def test_pipeline_streams_batches_with_traceback_overlapped():
             prod.setdefault((int(r["context"]) // 2, int(r["oid"])), []).append((r, o))
         total += compare(prod, ora)
     assert total >= nbatch * per // 3
+
+
+def test_greedy_traceback_with_ambiguity_codes_and_long_exact_runs():
+    """Round 6: the greedy half compares match runs eight bases at a time (a byte is a mismatch where the letters differ or the
+    query's is no base) and walks its rows through pointers.  Queries with ambiguity codes inside and at the ends of their homologies,
+    homologies that are exact for hundreds of bases (runs that cross many 8-byte words from every alignment of the two sequences),
+    short queries (runs that end within the last 8 bases of a sequence) -- rows and edit scripts against the oracle's."""
+    db, queries, plants, subjects, opt = util.small_case(5, 130_000, 30, planted_fraction=1.0)
+    rng = np.random.default_rng(5)
+    queries = [np.array(q, dtype=np.uint8) for q in queries]
+    bases = [orc.unpack_ncbi2na(s[0], s[1]) for s in subjects]
+    for i, q in enumerate(queries):
+        kind = i % 5
+        if kind == 0:                                   # ambiguity codes sprinkled over the query
+            q[rng.integers(0, len(q), 6)] = 14
+        elif kind == 1:                                 # an exact copy of a subject stretch, offset by every residue mod 8
+            s = bases[i % len(bases)]; at = 1000 + 37 * i + (i // 5)
+            q[:] = s[at:at + len(q)]
+        elif kind == 2:                                 # exact copy, reverse strand, with one N in the middle and one at the very end
+            s = bases[i % len(bases)]; at = 5000 + 11 * i
+            q[:] = (3 - s[at:at + len(q)])[::-1]
+            q[len(q) // 2] = 14; q[-1] = 14
+        elif kind == 3:                                 # a short query: its runs end inside the last word
+            queries[i] = q[:61 + i].copy()
+        # kind 4: as planted
+    ora, _ = oracle_final(opt, queries, subjects)
+    prod, *_ = product_final(opt, queries, subjects, threads=2)
+    assert compare(prod, ora) >= 20
