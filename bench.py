@@ -108,6 +108,9 @@ def open_run(args):
     torch.cuda.set_device(dev)
     shared_device = world > ndev
     if world > 1:
+        # the ranks of one node share what the node (or its container) grants: every rank sizes its host pools from ITS share of the CPUs,
+        # not from all of them (gbn_host_cpus reads GBN_HOST_CPUS at its first use, which is below)
+        api.share_cpus_among_local_ranks()
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if shared_device:
             # more ranks than devices (the builder's one-GPU box): NOT a scaling measurement, only a way to run the

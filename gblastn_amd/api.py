@@ -281,6 +281,37 @@ def record_cache_invalidate():
     _check(lib().gbn_record_cache_invalidate())
 
 
+def granted_cpus():
+    """What gbn_host_cpus computes, without the library: hardware threads cut down to the affinity mask and the cgroup's CPU quota.
+    For launchers that hand every rank of a node its share (GBN_HOST_CPUS) before the library sizes its pools."""
+    import math
+    n = os.cpu_count() or 1
+    try:
+        n = min(n, len(os.sched_getaffinity(0)))
+    except Exception:
+        pass
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, math.ceil(int(q) / int(per))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and per > 0:
+                n = min(n, max(1, math.ceil(q / per)))
+        except Exception:
+            pass
+    return n
+
+
+def share_cpus_among_local_ranks():
+    """One process per GPU on a node: every rank sizes its host pools from its share of the CPUs the node (or its container) grants, not
+    from all of them.  Call before the first library call of the process (gbn_host_cpus reads GBN_HOST_CPUS once)."""
+    lw = int(os.environ.get("LOCAL_WORLD_SIZE", os.environ.get("WORLD_SIZE", "1")))
+    if lw > 1:
+        os.environ.setdefault("GBN_HOST_CPUS", str(max(2, granted_cpus() // lw)))
+
+
 def host_cpus():
     """CPUs this process may use at a time (hardware threads cut down to the affinity mask and the cgroup's CPU quota):
     gbn_host_cpus; what thread pools on the host are sized from."""

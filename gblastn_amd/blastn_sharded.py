@@ -91,6 +91,7 @@ def main(argv=None):
     dev = torch.device("cuda", local_rank % ndev)       # more ranks than devices: they share (tests on one GPU)
     torch.cuda.set_device(dev)
     if world > 1:
+        api.share_cpus_among_local_ranks()              # (every rank its share of the CPUs the node grants: csrc gbn_host_cpus)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if world > ndev and a.backend == "nccl":
             # ranks that share a device (tests on a one-GPU box): RCCL refuses two ranks of one host on one device

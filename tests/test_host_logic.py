@@ -161,6 +161,7 @@ def test_host_cpus_follow_the_affinity_mask_and_the_cgroup_quota():
         except OSError:
             pass
     assert n == want and n >= 1
+    assert api.granted_cpus() == n                      # (the launchers' copy of the rule, without the library)
     out = subprocess.run([sys.executable, "-c", "from gblastn_amd import api; print(api.host_cpus())"], env=dict(os.environ, GBN_HOST_CPUS="3"),
                          capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     assert out.stdout.strip() == "3", out.stderr[-500:]
