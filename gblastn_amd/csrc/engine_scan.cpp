@@ -455,7 +455,7 @@ static int run_scan_impl(GbnBatch &b, GbnDb &db, int32_t s0, int32_t s1, GbnDiag
             if (used_runs) {
                 B.run_fp = rs->run_fp; B.run_pos = rs->run_pos; B.run_start = rs->run_start; B.rec = nullptr; B.tcur = nullptr;
                 B.run_item_cells = B.S.ncells <= ((int64_t)1 << 20) ? 64 : GBN_RUNS_ITEM_CELLS;
-                B.work = reinterpret_cast<uint32_t *>(E.counters + 4); B.rare_parts = (int)std::max(1ll, gbn::switch_value("GBN_RUNS_RARE_PARTS", 1));
+                B.work = reinterpret_cast<uint32_t *>(E.counters + 4); B.rare_parts = (int)std::max(1ll, gbn::switch_value("GBN_RUNS_RARE_PARTS", 6));      // (rare workgroups per queue segment over sorted records: with 768 segments -- three probe workgroups per CU -- one each took 1.3-1.4 ms, four to six 0.95-1.05; step 3.05-3.21 -> 2.98-3.06, one-query pass 0.77 -> 0.68: profiles/r06_runs_wgs_ab.txt)
                 E.rec_runs_passes++;
             }
             int grid2 = used_runs ? runs_grid() : std::max(8, E.num_cu & ~7);   // stream form: one 1024-thread workgroup per CU; group = blockIdx & 7
