@@ -16,11 +16,17 @@ namespace {
 
 __device__ __forceinline__ uint32_t fingerprint_dev(const uint8_t *__restrict__ q, int32_t off, int lut, bool force)
 {
-    uint32_t l = 0, r = 0;
-    #pragma unroll
-    for (int k = 1; k <= 8; k++) l |= (uint32_t)(q[off - k] & 3) << (2 * (k - 1));
-    #pragma unroll
-    for (int j = 0; j < 7; j++) r |= (uint32_t)(q[off + lut + j] & 3) << (2 * (6 - j));
+    // (round 6: the eight bases to the left and the seven to the right as two 8-byte loads -- the buffer has 64 bytes of padding either
+    // side -- instead of fifteen byte loads; the low two bits of every byte, the byte nearest the word in the lowest bits)
+    typedef uint64_t u64u __attribute__((aligned(1)));
+    auto pack8 = [](uint64_t x) -> uint32_t {           // bytes 7 .. 0 of x -> bits 1:0 .. 15:14
+        uint64_t y = __builtin_bswap64(x) & 0x0303030303030303ull;
+        y = (y | (y >> 6)) & 0x000F000F000F000Full;
+        y = (y | (y >> 12)) & 0x000000FF000000FFull;
+        return (uint32_t)((y | (y >> 24)) & 0xFFFFull);
+    };
+    const uint32_t l = pack8(*reinterpret_cast<const u64u *>(q + off - 8));
+    const uint32_t r = pack8(*reinterpret_cast<const u64u *>(q + off + lut) << 8) & 0x3FFFu;      // (the eighth byte is not part of it)
     return (l << 15) | (r << 1) | (force ? 1u : 0u);
 }
 // 15-bit reduced fingerprint: 3.5 bases to the right (7 bits, high) and 4 bases to the left (8 bits, low)
