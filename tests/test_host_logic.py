@@ -202,3 +202,18 @@ def test_setup_of_many_compositions_matches_oracle_whatever_the_thread_share():
             b.close()
     finally:
         L.gbn_set_setup_threads(0)
+
+
+def test_local_ranks_share_the_granted_cpus():
+    """One process per GPU: a launcher hands every rank of a node its share of the CPUs the node grants (api.share_cpus_among_local_ranks
+    sets GBN_HOST_CPUS before the library sizes its pools); an explicit GBN_HOST_CPUS stays."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "from gblastn_amd import api; api.share_cpus_among_local_ranks(); print(api.host_cpus(), api.granted_cpus())"
+    env = {k: v for k, v in os.environ.items() if k not in ("GBN_HOST_CPUS", "LOCAL_WORLD_SIZE", "WORLD_SIZE")}
+    one = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, cwd=root).stdout.split()
+    assert one[0] == one[1]                                             # a single process: everything it is granted
+    four = subprocess.run([sys.executable, "-c", code], env=dict(env, LOCAL_WORLD_SIZE="4"), capture_output=True, text=True, cwd=root).stdout.split()
+    assert int(four[0]) == max(2, int(four[1]) // 4)
+    kept = subprocess.run([sys.executable, "-c", code], env=dict(env, LOCAL_WORLD_SIZE="4", GBN_HOST_CPUS="5"), capture_output=True, text=True, cwd=root).stdout.split()
+    assert kept[0] == "5"
